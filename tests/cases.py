@@ -1,0 +1,270 @@
+"""
+Neutral descriptions of the parity cases.
+
+The same description builds a study with the *reference* package (only inside
+``tests/golden/gen_golden.py``, in the build container) and with ``bayesloop_amd`` (in the tests),
+because both expose the same ``bl.Study / bl.HyperStudy / bl.ChangepointStudy / bl.om / bl.tm`` surface.
+:func:`oracle_call` turns a description into a call of the CPU oracle.
+
+Case ids starting with ``kat_`` are the reference's own known-answer tests for the path
+(tests/test_transitionmodels.py, tests/test_observationmodels.py, tests/test_study.py,
+tests/test_hyperstudy.py in the reference); ``c1..c5`` are the BASELINE.json configs at fixture size.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------------------
+# named priors (callables cannot be stored in fixtures; both sides look them up here)
+# ----------------------------------------------------------------------------------------------------------
+PRIORS = {
+    'inv_s3': lambda m, s: 1 / s ** 3,
+    'inv_x': lambda x: 1. / x,
+    'inv_s': lambda s: 1. / s,
+}
+
+COAL = np.array([5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4,
+                 4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2, 1, 3, 2, 2, 1, 1, 1, 1, 3, 0,
+                 0, 1, 0, 1, 1, 0, 0, 3, 1, 0, 3, 2, 2, 0, 1, 1, 1, 0, 1, 0, 1, 0, 0,
+                 0, 2, 1, 0, 0, 0, 1, 1, 0, 2, 3, 3, 1, 1, 2, 1, 1, 1, 1, 2, 3, 3, 0,
+                 0, 0, 1, 4, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0])
+COAL_T = np.arange(1852, 1962)
+
+
+def series(seed, T, jump_at=None, jump=0.0):
+    """Synthetic mean-tracking series of SURVEY.md section 8(d)."""
+    rng = np.random.default_rng(seed)
+    mu = np.cumsum(rng.normal(0, 0.02, T))
+    if jump_at is not None:
+        mu[jump_at:] += jump
+    return mu + rng.normal(0, 1.0, T)
+
+
+def gm_data(seed, T):
+    """GaussianMean data (value, std) of config C2."""
+    x = series(seed, T)
+    return np.stack([x, np.ones(T)], 1)
+
+
+def _g(kind, a, b, n):
+    return (kind, a, b, n)
+
+
+D15 = np.array([1, 2, 3, 4, 5])
+D10100 = np.array([1, 0, 1, 0, 0])
+GM5 = np.array([[1, 0.5], [0, 0.4], [1, 0.3], [0, 0.2], [0, 0.1]])
+
+G2020 = ('Gaussian', [('mean', _g('cint', 0, 6, 20)), ('sigma', _g('oint', 0, 2, 20))], 'inv_s3')
+
+
+def gauss2d(n, lo=-8, hi=8, smax=4):
+    return ('Gaussian', [('mean', _g('cint', lo, hi, n)), ('std', _g('oint', 0, smax, n))], 'default')
+
+
+CASES = {
+    # --- reference tests/test_transitionmodels.py:9-21, 40-52, 82-94
+    'kat_static': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                       tm=('Static',), kat=-10.372209708143769),
+    'kat_grw': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                    tm=('GRW', 'sigma', 0.2, 'rate', None), kat=-10.323144246611964),
+    'kat_changepoint': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                            tm=('ChangePoint', 't_change', 2, None), kat=-12.894336092378385),
+    # --- reference tests/test_observationmodels.py:138-148, 150-160, 174-184
+    'kat_poisson': dict(study='Study', data=D10100, om=('Poisson', [('rate', _g('oint', 0, 1, 100))], 'default'),
+                        tm=('Static',), kat=-4.433708287229158),
+    'kat_gaussian': dict(study='Study', data=D10100,
+                         om=('Gaussian', [('mu', _g('oint', 0, 1, 100)), ('std', _g('oint', 0, 1, 100))], 'inv_s3'),
+                         tm=('Static',), kat=-12.430583625665736),
+    'kat_gaussianmean': dict(study='Study', data=GM5, om=('GaussianMean', [('mu', _g('oint', 0, 1, 100))], 'default'),
+                             tm=('Static',), kat=-6.3333705075036226),
+    # --- reference tests/test_study.py:32-52 (default 1000-pt estimated grid), :80-100 (array prior), :102-...
+    'kat_study_1hp': dict(study='Study', data=D15, om=('Poisson', [('rate', None)], 'default'),
+                          tm=('GRW', 'sigma', 0.1, 'rate', None), kat=-10.4337420351, kat_decimal=2),
+    'kat_study_prior_array': dict(study='Study', data=D15,
+                                  om=('Poisson', [('rate', _g('oint', 0, 6, 1000))], ('ones', 1000)),
+                                  tm=('GRW', 'sigma', 0.1, 'rate', None), kat=-10.0866227472, kat_decimal=2),
+    'kat_study_prior_function': dict(study='Study', data=D15,
+                                     om=('Poisson', [('rate', _g('oint', 0, 6, 1000))], 'inv_x'),
+                                     tm=('GRW', 'sigma', 0.1, 'rate', None)),
+    # --- reference tests/test_hyperstudy.py:10-30, 32-59, 104-187
+    'kat_hyper_0hp': dict(study='HyperStudy', data=D15, om=G2020, tm=('Static',), kat=-16.1946904707),
+    'kat_hyper_1hp': dict(study='HyperStudy', data=D15, om=G2020,
+                          tm=('GRW', 'sigma', _g('cint', 0, 0.2, 2), 'mean', None), kat=-16.0629517262,
+                          kat_hpd=[0.43828499, 0.56171501]),
+    'kat_hyper_prior_array': dict(study='HyperStudy', data=D15, om=G2020,
+                                  tm=('GRW', 'sigma', _g('cint', 0, 0.2, 2), 'mean', ('array', [0.2, 0.8])),
+                                  kat=-15.9915077133, kat_hpd=[0.16322581, 0.83677419]),
+    'kat_hyper_prior_function': dict(study='HyperStudy', data=D15, om=G2020,
+                                     tm=('GRW', 'sigma', _g('cint', 0.1, 0.3, 2), 'mean', 'inv_s'),
+                                     kat=-15.9898700147, kat_hpd=[0.61609973, 0.38390027]),
+    # --- BASELINE.json configs
+    'c1_coal': dict(study='Study', data=COAL, timestamps=COAL_T,
+                    om=('Poisson', [('rate', _g('oint', 0, 6, 200))], 'default'),
+                    tm=('GRW', 'sigma', 0.2, 'rate', None), kat=-171.68672187433867, kat_decimal=9),
+    'c1_coal_hyper': dict(study='HyperStudy', data=COAL, timestamps=COAL_T,
+                          om=('Poisson', [('rate', _g('oint', 0, 6, 200))], 'default'),
+                          tm=('GRW', 'sigma', _g('cint', 0, 1, 20), 'rate', None), kat=-172.6703099789132,
+                          kat_decimal=9),
+    'c1_coal_changepoint': dict(study='ChangepointStudy', data=COAL, timestamps=COAL_T,
+                                om=('Poisson', [('rate', _g('oint', 0, 6, 200))], 'default'),
+                                tm=('ChangePoint', 'tChange', 'all', None)),
+    'c2_small': dict(study='Study', data=('gm', 20260927, 300),
+                     om=('GaussianMean', [('mean', _g('cint', -8, 8, 4096))], 'default'),
+                     tm=('GRW', 'sigma', 0.02, 'mean', None)),
+    'c2_full': dict(study='Study', data=('gm', 20260927, 10000),
+                    om=('GaussianMean', [('mean', _g('cint', -8, 8, 4096))], 'default'),
+                    tm=('GRW', 'sigma', 0.02, 'mean', None), kat=-14319.827959661387, kat_decimal=7,
+                    store='sparse', slow=True),
+    'c3_small': dict(study='Study', data=('series', 3, 10), om=gauss2d(128),
+                     tm=('Combined', [('GRW', 's1', 0.24, 'mean', None), ('GRW', 's2', 0.064, 'std', None)])),
+    'c3_t10': dict(study='Study', data=('series', 3, 10), om=gauss2d(1024),
+                   tm=('Combined', [('GRW', 's1', 0.03, 'mean', None), ('GRW', 's2', 0.008, 'std', None)]),
+                   kat=-17.470610045317024, kat_decimal=9, store='sparse', slow=True),
+    'c3_missing': dict(study='Study', data=('series_nan', 3, 12, [4, 7]), om=gauss2d(64),
+                       tm=('Combined', [('GRW', 's1', 0.4, 'mean', None), ('GRW', 's2', 0.1, 'std', None)])),
+    'c3_forward_only': dict(study='Study', data=('series', 3, 10), om=gauss2d(96),
+                            tm=('Combined', [('GRW', 's1', 0.3, 'mean', None), ('GRW', 's2', 0.09, 'std', None)]),
+                            fit=dict(forwardOnly=True)),
+    'c3_evidence_only': dict(study='Study', data=('series', 3, 10), om=gauss2d(96),
+                             tm=('Combined', [('GRW', 's1', 0.3, 'mean', None), ('GRW', 's2', 0.09, 'std', None)]),
+                             fit=dict(evidenceOnly=True)),
+    'c3_std_first': dict(study='Study', data=('series', 3, 8), om=gauss2d(80),
+                         tm=('Combined', [('GRW', 's2', 0.09, 'std', None), ('GRW', 's1', 0.3, 'mean', None)])),
+    'c3_one_axis': dict(study='Study', data=('series', 3, 8), om=gauss2d(80),
+                        tm=('GRW', 's2', 0.11, 'std', None)),
+    'wide_filter': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 40))], 'default'),
+                        tm=('GRW', 'sigma', 3.5, 'rate', None)),          # lw = 97 > n = 40: multi-period reflect
+    'wide_filter_2d': dict(study='Study', data=('series', 7, 6), om=gauss2d(24, -3, 3, 2),
+                           tm=('Combined', [('GRW', 's1', 2.0, 'mean', None), ('GRW', 's2', 1.1, 'std', None)])),
+    'tiny_sigma': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                       tm=('GRW', 'sigma', 0.005, 'rate', None)),         # sigma/delta < 0.125 -> lw = 0 (identity)
+    'zero_sigma': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                       tm=('GRW', 'sigma', 0.0, 'rate', None)),
+    'multidim_data': dict(study='Study', data=('series2d', 11, 9), om=gauss2d(48, -4, 4, 3),
+                          tm=('GRW', 's1', 0.2, 'mean', None)),
+    'abort_forward': dict(study='Study', data=np.array([0.2, 0.1, 500.0, 0.3]), om=gauss2d(32, -2, 2, 0.5),
+                          tm=('Static',)),                                # zero normaliser at step 2 -> logE = -inf
+    'c4_small': dict(study='HyperStudy', data=('series', 4, 32), om=gauss2d(128),
+                     tm=('GRW', 'sigma', _g('cint', 0, 0.3, 16), 'mean', None), kat=-48.69144546025129,
+                     kat_decimal=9, store='sparse'),
+    'c4_small_evidence': dict(study='HyperStudy', data=('series', 4, 32), om=gauss2d(128),
+                              tm=('GRW', 'sigma', _g('cint', 0, 0.3, 16), 'mean', None), fit=dict(evidenceOnly=True)),
+    'c4_2hp': dict(study='HyperStudy', data=('series', 4, 12), om=gauss2d(48, -4, 4, 3),
+                   tm=('Combined', [('GRW', 's1', _g('cint', 0, 0.4, 4), 'mean', None),
+                                    ('GRW', 's2', _g('cint', 0.02, 0.2, 3), 'std', 'inv_s')])),
+    'c4_njobs3': dict(study='HyperStudy', data=('series', 4, 12), om=gauss2d(48, -4, 4, 3),
+                      tm=('GRW', 'sigma', _g('cint', 0, 0.3, 7), 'mean', None), fit=dict(nJobs=3)),
+    'c5_small': dict(study='ChangepointStudy', data=('series_jump', 5, 64, 32, 2.0), om=gauss2d(128),
+                     tm=('ChangePoint', 'tChange', ('arange', 3, 63, 4), None), kat=-105.38594028835217,
+                     kat_decimal=9, store='sparse'),
+    'c5_cp_grw': dict(study='ChangepointStudy', data=('series_jump', 5, 24, 12, 2.0), om=gauss2d(40, -4, 6, 3),
+                      tm=('Combined', [('ChangePoint', 'tChange', ('arange', 2, 22, 3), None),
+                                       ('GRW', 'sigma', _g('cint', 0.05, 0.25, 3), 'mean', None)])),
+    'c5_grw_cp': dict(study='ChangepointStudy', data=('series_jump', 5, 24, 12, 2.0), om=gauss2d(40, -4, 6, 3),
+                      tm=('Combined', [('GRW', 'sigma', 0.2, 'mean', None),
+                                       ('ChangePoint', 'tChange', ('arange', 2, 22, 3), None)])),
+    'c5_two_cp': dict(study='ChangepointStudy', data=('series_jump', 5, 14, 7, 2.0), om=gauss2d(24, -4, 6, 3),
+                      tm=('Combined', [('ChangePoint', 't1', ('arange', 1, 12, 2), None),
+                                       ('ChangePoint', 't2', ('arange', 1, 12, 2), None)])),
+    'cp_nonunit_time': dict(study='Study', data=D15, timestamps=np.array([0., 2., 4., 6., 8.]),
+                            om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                            tm=('ChangePoint', 't_change', 4., None)),   # forward fires at t=4, backward at t-1: never
+}
+
+
+def make_data(spec):
+    if isinstance(spec, np.ndarray):
+        return spec
+    kind = spec[0]
+    if kind == 'gm':
+        return gm_data(spec[1], spec[2])
+    if kind == 'series':
+        return series(spec[1], spec[2])
+    if kind == 'series_nan':
+        x = series(spec[1], spec[2])
+        x[list(spec[3])] = np.nan
+        return x
+    if kind == 'series_jump':
+        return series(spec[1], spec[2], jump_at=spec[3], jump=spec[4])
+    if kind == 'series2d':
+        a = series(spec[1], spec[2])
+        b = series(spec[1] + 1, spec[2])
+        b[3] = np.nan
+        return np.stack([a, b], 1)
+    raise ValueError(spec)
+
+
+def make_values(bl, v):
+    if v is None or isinstance(v, (int, float, str)):
+        return v
+    if isinstance(v, tuple) and v[0] in ('cint', 'oint'):
+        return getattr(bl, v[0])(v[1], v[2], v[3])
+    if isinstance(v, tuple) and v[0] == 'arange':
+        return np.arange(v[1], v[2], v[3])
+    return np.asarray(v)
+
+
+def make_prior(p):
+    if p is None or p == 'default':
+        return p
+    if isinstance(p, str):
+        return PRIORS[p]
+    if p[0] == 'ones':
+        return np.ones(p[1])
+    if p[0] == 'array':
+        return np.array(p[1], dtype=float)
+    raise ValueError(p)
+
+
+def make_tm(bl, spec):
+    kind = spec[0]
+    if kind == 'Static':
+        return bl.tm.Static()
+    if kind == 'GRW':
+        return bl.tm.GaussianRandomWalk(spec[1], make_values(bl, spec[2]), target=spec[3], prior=make_prior(spec[4]))
+    if kind == 'ChangePoint':
+        return bl.tm.ChangePoint(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
+    if kind == 'Combined':
+        return bl.tm.CombinedTransitionModel(*[make_tm(bl, s) for s in spec[1]])
+    raise ValueError(spec)
+
+
+def make_om(bl, spec):
+    name, params, prior = spec
+    args = []
+    for pname, values in params:
+        args += [pname, make_values(bl, values)]
+    cls = getattr(bl.om, name)
+    if prior == 'default':
+        return cls(*args)
+    return cls(*args, prior=make_prior(prior))
+
+
+def build(bl, case):
+    """Un-fitted study of the given package for a case description."""
+    c = CASES[case] if isinstance(case, str) else case
+    S = getattr(bl, c['study'])(silent=True)
+    S.loadData(make_data(c['data']), timestamps=c.get('timestamps'), silent=True)
+    S.set(make_om(bl, c['om']), make_tm(bl, c['tm']), silent=True)
+    return S
+
+
+def fit_kwargs(case):
+    c = CASES[case] if isinstance(case, str) else case
+    kw = dict(c.get('fit', {}))
+    if c['study'] != 'ChangepointStudy' or True:
+        kw['silent'] = True
+    return kw
+
+
+# rows of the posterior sequence kept for 'sparse' fixtures
+def sparse_rows(T):
+    return sorted(set([0, 1, T // 3, T // 2, T - 2, T - 1]) & set(range(T)))
+
+
+def sparse_stride(grid_shape, limit=70_000):
+    """Per-axis subsampling stride of the stored posterior rows for large grids."""
+    stride = [1] * len(grid_shape)
+    while np.prod([-(-n // s) for n, s in zip(grid_shape, stride)]) > limit:
+        stride = [s * 2 for s in stride]
+    return stride

@@ -1,0 +1,68 @@
+"""Shared result comparison: a result dict (oracle or product) against a golden fixture."""
+from __future__ import annotations
+
+import numpy as np
+
+import cases
+
+# The parity bar of BASELINE.json / SURVEY.md section 8(d), float64:
+#   log-evidence: 1e-9 relative;  posteriors: |dp| <= 1e-12 + 1e-9 * p
+GPU_TOL = dict(logE_rtol=1e-9, post_rtol=1e-9, post_atol=1e-12, small_rtol=1e-9, small_atol=1e-12)
+# the oracle restates the reference operation by operation -> rounding-level agreement
+ORACLE_TOL = dict(logE_rtol=1e-13, post_rtol=1e-11, post_atol=1e-300, small_rtol=1e-11, small_atol=1e-300)
+
+
+def _close(a, b, rtol, atol, what):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), '%s: NaN pattern differs (%d vs %d NaNs)' % (what, nan_a.sum(), nan_b.sum())
+    inf_a, inf_b = np.isinf(a), np.isinf(b)
+    assert np.array_equal(inf_a, inf_b) and np.array_equal(a[inf_a], b[inf_b]), '%s: inf pattern differs' % what
+    ok = ~(nan_a | inf_a)
+    err = np.abs(a[ok] - b[ok]) - (atol + rtol * np.abs(b[ok]))
+    if err.size and err.max() > 0:
+        k = np.argmax(err)
+        raise AssertionError('%s: max excess %.3e (got %r, want %r)' % (what, err.max(), a[ok][k], b[ok][k]))
+
+
+def check(res, gold, tol, aborted_ok=True):
+    """res: dict with the attribute names of the reference's study objects."""
+    gl = float(gold['logEvidence'])
+    rl = float(res['logEvidence'])
+    if not np.isfinite(gl):
+        assert rl == gl, 'logEvidence %r vs %r' % (rl, gl)
+        if 'logEvidenceList' not in gold:
+            return                       # aborted Study.fit: remaining attributes are uninitialised in the reference
+    else:
+        assert abs(rl - gl) <= tol['logE_rtol'] * abs(gl), 'logEvidence %r vs %r (rel %.2e)' % (
+            rl, gl, abs(rl - gl) / abs(gl))
+    _close(res['localEvidence'], gold['localEvidence'], tol['small_rtol'], tol['small_atol'], 'localEvidence')
+    if 'posteriorMeanValues' in gold:
+        _close(res['posteriorMeanValues'], gold['posteriorMeanValues'], tol['small_rtol'], 1e-11, 'posteriorMeanValues')
+    if 'posteriorSequence' in gold:
+        _close(res['posteriorSequence'], gold['posteriorSequence'], tol['post_rtol'], tol['post_atol'],
+               'posteriorSequence')
+    if 'posteriorRows' in gold:
+        post = np.asarray(res['posteriorSequence'])
+        rows = gold['posteriorRowsIndex']
+        stride = gold['posteriorRowsStride'] if 'posteriorRowsStride' in gold else [1] * (post.ndim - 1)
+        sub = post[rows][(slice(None),) + tuple(slice(None, None, int(s)) for s in stride)]
+        _close(sub, gold['posteriorRows'], tol['post_rtol'], tol['post_atol'], 'posteriorRows')
+        if 'marginalSequence0' in gold:
+            _close(post.sum(axis=2), gold['marginalSequence0'], tol['post_rtol'], tol['post_atol'], 'marginal0')
+            _close(post.sum(axis=1), gold['marginalSequence1'], tol['post_rtol'], tol['post_atol'], 'marginal1')
+    for key in ('logEvidenceList',):
+        if key in gold:
+            g = gold[key]
+            r = np.asarray(res[key], dtype=float)
+            fin = np.isfinite(g)
+            assert np.array_equal(fin, np.isfinite(r)), key + ': finiteness differs'
+            assert np.all(np.abs(r[fin] - g[fin]) <= tol['logE_rtol'] * np.abs(g[fin])), key
+    for key in ('hyperParameterDistribution', 'flatHyperPriorValues', 'hyperGridValues', 'hyperGridConstant'):
+        if key in gold and key in res:
+            _close(res[key], gold[key], max(tol['small_rtol'], 1e-9 if key == 'hyperParameterDistribution' else 0),
+                   1e-15, key)
+    if 'mask' in gold and 'mask' in res:
+        assert np.array_equal(res['mask'], gold['mask'])

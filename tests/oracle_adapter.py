@@ -1,0 +1,127 @@
+"""Turns a case description (tests/cases.py) into calls of the CPU oracle (oracle/bl_oracle.py)."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import bl_oracle as orc   # noqa: E402
+import cases                           # noqa: E402
+
+OM_NAME = {'Poisson': 'poisson', 'Gaussian': 'gaussian', 'GaussianMean': 'gaussian_mean', 'Bernoulli': 'bernoulli',
+           'Laplace': 'laplace', 'WhiteNoise': 'white_noise', 'AR1': 'ar1', 'ScaledAR1': 'scaled_ar1'}
+
+
+class _Orc:
+    """namespace so that cases.make_values can resolve cint/oint against the oracle's helpers"""
+    cint = staticmethod(orc.cint)
+    oint = staticmethod(orc.oint)
+
+
+def estimate_values(om, pname_index, raw):
+    """Default grids (observationModels.py:516-518 Poisson; :581-587 Gaussian; :720-726 GaussianMean)."""
+    if om == 'poisson':
+        return orc.oint(0, 1.25 * np.nanmax(np.ravel(raw)), 1000)
+    if om == 'gaussian':
+        mean, std = np.nanmean(np.ravel(raw)), np.nanstd(np.ravel(raw))
+        return orc.cint(mean - 2 * std, mean + 2 * std, 200) if pname_index == 0 else orc.oint(0, 2 * std, 200)
+    if om == 'gaussian_mean':
+        obs = np.array([d[0] for d in raw])
+        lo, hi = np.nanmin(obs), np.nanmax(obs)
+        return orc.oint(lo - (hi - lo), hi + (hi - lo), 1000)
+    raise ValueError(om)
+
+
+def flatten_tm(spec, param_names):
+    """-> ops, hyper values (scalar/array/'all'), hyper priors; in the order of the reference's flattened
+    hyper-parameter list (core.py:623-656)."""
+    kind = spec[0]
+    if kind == 'Static':
+        return [('static',)], [], []
+    if kind == 'GRW':
+        return [('grw', param_names.index(spec[3]))], [cases.make_values(_Orc, spec[2])], [cases.make_prior(spec[4])]
+    if kind == 'ChangePoint':
+        return [('changepoint',)], [cases.make_values(_Orc, spec[2])], [cases.make_prior(spec[3])]
+    if kind == 'Combined':
+        ops, vals, pri = [], [], []
+        for s in spec[1]:
+            o, v, p = flatten_tm(s, param_names)
+            ops += o
+            vals += v
+            pri += p
+        return ops, vals, pri
+    raise ValueError(spec)
+
+
+def run(case):
+    c = cases.CASES[case] if isinstance(case, str) else case
+    raw = cases.make_data(c['data'])
+    om_cls, params, prior_spec = c['om']
+    om = OM_NAME[om_cls]
+    marginals = []
+    for k, (pname, values) in enumerate(params):
+        v = cases.make_values(_Orc, values)
+        marginals.append(estimate_values(om, k, raw) if v is None else v)
+    g = orc.Grid(marginals)
+    pnames = [p[0] for p in params]
+
+    seg = orc.OM_INFO[om][0]
+    data = orc.moving_window(raw, seg)
+    ts = c.get('timestamps')
+    ts = np.arange(len(raw)) if ts is None else np.asarray(ts)
+    ts = ts[seg - 1:]
+
+    prior_obj = orc.jeffreys(om) if prior_spec == 'default' else cases.make_prior(prior_spec)
+    prior = orc.compute_prior(g, prior_obj)
+    reset = orc.changepoint_prior(g, prior_obj)
+
+    ops, vals, hpriors = flatten_tm(c['tm'], pnames)
+    kw = dict(c.get('fit', {}))
+    fo, eo = kw.get('forwardOnly', False), kw.get('evidenceOnly', False)
+
+    if c['study'] == 'Study':
+        r = orc.fit(g, om, data, ts, prior, ops, orc.align_values(ops, vals), forward_only=fo, evidence_only=eo,
+                    reset=reset)
+        r['prior'] = prior
+        r['grid'] = g
+        return r
+
+    vals = [ts[:-1] if (isinstance(v, str) and v == 'all') else v for v in vals]
+    if len(vals) == 0 or all(np.ndim(v) == 0 for v in vals) and np.prod([np.size(v) for v in vals]) <= 1:
+        # <= 1 hyper-grid point: falls back to Study.fit (core.py:1434-1441)
+        r = orc.fit(g, om, data, ts, prior, ops, orc.align_values(ops, [np.ravel(v)[0] for v in vals]),
+                    forward_only=fo, evidence_only=eo, reset=reset)
+        r['prior'] = prior
+        r['grid'] = g
+        return r
+    hv, pv, const = orc.hyper_grid(vals, hpriors)
+    extra = {}
+    if c['study'] == 'ChangepointStudy':
+        cols = [k for k, op in enumerate([o for o in ops if o[0] != 'static']) if op[0] == 'changepoint']
+        mask, hv_m, pv_m = orc.changepoint_mask(hv, pv, cols)
+        extra = dict(allHyperGridValues=hv, mask=mask)
+        hv, pv = hv_m, pv_m
+    r = orc.hyper_fit(g, om, data, ts, prior, ops, hv, pv, const, forward_only=fo, evidence_only=eo, reset=reset,
+                      n_jobs=kw.get('nJobs', 1))
+    if c['study'] == 'ChangepointStudy':                       # core.py:1846-1852
+        temp = np.zeros(len(extra['mask']))
+        temp[extra['mask']] = r['hyperParameterDistribution']
+        r['hyperParameterDistribution'] = temp
+        temp = np.zeros(len(extra['mask']))
+        temp[extra['mask']] = pv
+        pv_out = temp
+    else:
+        pv_out = pv
+    r.update(extra)
+    r.update(prior=prior, grid=g, hyperGridValues=hv, flatHyperPriorValues=pv_out, hyperGridConstant=const)
+    return r
+
+
+def load_golden(case):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', case + '.npz')
+    return dict(np.load(path))
