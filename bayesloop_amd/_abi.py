@@ -1,0 +1,126 @@
+"""
+ctypes binding of libblhip.so (include/blhip.h).  Thin by design: structures, prototypes, error mapping.
+
+There is no CPU fallback: if the shared library is missing, cannot be loaded, or no HIP device is visible,
+:func:`load` / :class:`Context` raise :class:`~bayesloop_amd.exceptions.BackendError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .exceptions import BackendError
+
+LIB_NAME = 'libblhip.so'
+ABI_VERSION = 1
+
+OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
+OP_STATIC, OP_GRW, OP_CHANGEPOINT = 0, 1, 2
+FORWARD_ONLY, EVIDENCE_ONLY, KEEP_POSTERIOR, ACCUMULATE = 1, 2, 4, 8
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('axis', C.c_int32)]
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ('ndim', C.c_int32), ('obs_model', C.c_int32),
+        ('n', C.c_int64 * 2),
+        ('marginal', c_double_p * 2),
+        ('lattice', C.c_double * 2),
+        ('T', C.c_int64),
+        ('seg_len', C.c_int32), ('data_dim', C.c_int32),
+        ('data', c_double_p), ('timestamps', c_double_p), ('prior', c_double_p), ('reset_prior', c_double_p),
+        ('lik', c_double_p),
+        ('n_ops', C.c_int32),
+        ('ops', C.POINTER(Op)),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ('log_evidence', c_double_p), ('local_evidence', c_double_p), ('posterior_mean', c_double_p),
+        ('abort_step', C.POINTER(C.c_int64)), ('abort_phase', C.POINTER(C.c_int32)),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ('forward_ms', C.c_double), ('backward_ms', C.c_double), ('accumulate_ms', C.c_double), ('total_ms', C.c_double),
+        ('forward_launches', C.c_int64), ('backward_launches', C.c_int64), ('accumulate_launches', C.c_int64),
+        ('cells_per_launch', C.c_int64), ('batches', C.c_int64),
+        ('fwd_kernel_variant', C.c_int32), ('bwd_kernel_variant', C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# name -> (restype, argtypes); the single source of truth checked against include/blhip.h by tests/test_abi.py
+PROTOTYPES = {
+    'blhip_abi_version': (C.c_int, []),
+    'blhip_device_count': (C.c_int, []),
+    'blhip_create': (C.c_void_p, [C.c_int]),
+    'blhip_destroy': (None, [C.c_void_p]),
+    'blhip_last_error': (C.c_char_p, [C.c_void_p]),
+    'blhip_device_name': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    'blhip_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    'blhip_synchronize': (C.c_int, [C.c_void_p]),
+    'blhip_fit': (C.c_int, [C.c_void_p, C.POINTER(Problem), C.c_int64, c_double_p, c_double_p, C.c_uint32,
+                            C.POINTER(Result)]),
+    'blhip_last_timing': (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    'blhip_posterior_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_double_p]),
+    'blhip_posterior_devptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'blhip_posterior_release': (C.c_int, [C.c_void_p]),
+    'blhip_accum_begin': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    'blhip_accum_state': (C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'blhip_accum_rescale': (C.c_int, [C.c_void_p, C.c_double]),
+    'blhip_accum_finalize': (C.c_int, [C.c_void_p, C.POINTER(Problem), c_double_p]),
+    'blhip_accum_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
+    'blhip_accum_end': (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def library_path():
+    env = os.environ.get('BLHIP_LIBRARY')
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+def load():
+    """Loads libblhip.so (built in-tree by ``__graft_entry__.build()`` / ``bayesloop_amd/csrc/build.py``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise BackendError('%s not found: build it with `python -m bayesloop_amd.csrc.build` '
+                           '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise BackendError('cannot load %s: %s' % (path, e)) from e
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BackendError('%s does not export %s' % (path, name)) from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.blhip_abi_version() != ABI_VERSION:
+        raise BackendError('%s has ABI version %d, expected %d' % (path, lib.blhip_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    """float64 C-contiguous numpy array -> double* (None -> NULL)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(c_double_p)

@@ -1,0 +1,815 @@
+"""
+Study classes -- ``bl.Study``, ``bl.HyperStudy``, ``bl.ChangepointStudy`` -- with the reference's public surface
+(bayesloop/core.py:39-486, 1118-1495, 1743-1852) and a ``fit()`` that runs on an MI355X.
+
+What stays on the host (cheap, data-independent of the grid size): building the parameter grid and the prior, formatting
+the data, compiling the transition model into a flat program, creating the hyper-parameter grid and hyper-priors, and
+the final evidence algebra over the handful of per-chain scalars.  Everything that touches a grid-sized array -- the
+likelihood, the alpha/beta recursion, the normalisers, the posterior means and the evidence-weighted average over
+hyper-parameter values -- runs in the HIP kernels behind :mod:`bayesloop_amd.engine`.
+"""
+from __future__ import annotations
+
+from collections.abc import Iterable
+
+import numpy as np
+
+from . import _abi
+from . import engine as _engine_mod
+from .engine import FitProblem
+from .exceptions import ConfigurationError, PostProcessingError
+from .helper import flatten
+from .observationModels import ObservationModel
+from .preprocessing import movingWindow
+from .transitionModels import TransitionModel, ChangePoint, CombinedTransitionModel
+
+COAL_MINING = (5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4, 4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2,
+               1, 3, 2, 2, 1, 1, 1, 1, 3, 0, 0, 1, 0, 1, 1, 0, 0, 3, 1, 0, 3, 2, 2, 0, 1, 1, 1, 0, 1, 0, 1, 0, 0, 0, 2, 1,
+               0, 0, 0, 1, 1, 0, 2, 3, 3, 1, 1, 2, 1, 1, 1, 1, 2, 3, 3, 0, 0, 0, 1, 4, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0,
+               1, 0)   # UK coal mining disasters per year, 1852-1961 (the reference's example data, core.py:82-88)
+
+
+def _leaf_models(model):
+    """Depth-first list of the leaf transition models of a (nested) model."""
+    if hasattr(model, 'models'):
+        out = []
+        for m in model.models:
+            out += _leaf_models(m)
+        return out
+    return [model]
+
+
+class Study(object):
+    """Fit with fixed hyper-parameter values (reference core.py:39-486)."""
+
+    def __init__(self, silent=False):
+        self.observationModel = None
+        self.transitionModel = None
+        self.gridSize = []
+        self.boundaries = []
+        self.marginalGrid = []
+        self.grid = []
+        self.latticeConstant = []
+        self.rawData = np.array([])
+        self.formattedData = np.array([])
+        self.rawTimestamps = None
+        self.formattedTimestamps = None
+        self._posteriorSequence = []
+        self._posterior_pending = None
+        self.posteriorMeanValues = []
+        self.logEvidence = 0
+        self.localEvidence = []
+        self.selectedHyperParameters = []
+        self.fitWarningCounter = 0
+        self.lastTiming = {}
+        if not silent:
+            print('+ Created new study.')
+
+    # ---- results that may still live on the GPU ------------------------------------------------------------------
+    @property
+    def posteriorSequence(self):
+        self._materialize_posterior()
+        return self._posteriorSequence
+
+    @posteriorSequence.setter
+    def posteriorSequence(self, value):
+        self._posterior_pending = None
+        self._posteriorSequence = value
+
+    def _materialize_posterior(self):
+        pending = self._posterior_pending
+        if pending is not None:
+            self._posterior_pending = None
+            self._posteriorSequence = pending()
+
+    def __getstate__(self):
+        self._materialize_posterior()     # keep study objects picklable (reference fileIO.py:10-37)
+        state = dict(self.__dict__)
+        state['_posterior_pending'] = None
+        return state
+
+    @property
+    def log10Evidence(self):
+        return self.logEvidence / np.log(10)
+
+    # ---- data ----------------------------------------------------------------------------------------------------
+    def loadExampleData(self, silent=False):
+        self.rawData = np.array(COAL_MINING)
+        self.rawTimestamps = np.arange(1852, 1962)
+        if not silent:
+            print('+ Successfully imported example data.')
+
+    def loadData(self, array, timestamps=None, silent=False):
+        if isinstance(array, np.ndarray):
+            self.rawData = array
+        elif isinstance(array, list):
+            if not silent:
+                print('! WARNING: Data supplied as list, not as Numpy array. Converting list to Numpy array '
+                      '(dtype=float).')
+            self.rawData = np.array(array, dtype=float)
+        else:
+            raise ConfigurationError('Data type not supported. Please provide data as Numpy array.')
+        self.rawTimestamps = np.arange(len(self.rawData))
+        if timestamps is not None:
+            if len(timestamps) == len(array):
+                self.rawTimestamps = np.array(timestamps)
+            elif not silent:
+                print('! WARNING: Number of timestamps does not match number of data points. Omitting timestamps.')
+        if not silent:
+            print('+ Successfully imported array.')
+
+    def load(self, array, timestamps=None, silent=False):
+        self.loadData(array, timestamps=timestamps, silent=silent)
+
+    # ---- models --------------------------------------------------------------------------------------------------
+    def setObservationModel(self, L, silent=False):
+        """Sets the likelihood and builds the regular parameter grid (reference core.py:130-176)."""
+        self.observationModel = L
+        self.marginalGrid, self.gridSize, self.boundaries, self.latticeConstant = [], [], [], []
+        for values, name in zip(L.parameterValues, L.parameterNames):
+            if values is None:
+                try:
+                    values = L.estimateParameterValues(name, self.rawData)
+                except Exception:
+                    raise ConfigurationError('Could not estimate parameter values for "{}".'.format(name))
+                print('+ Estimated parameter interval for "{}": [{}, {}] ({} values).'
+                      .format(name, values[0], values[-1], len(values)))
+            values = np.array(values, dtype=float)
+            if values.ndim != 1 or len(values) < 2:
+                raise ConfigurationError('Parameter "{}" needs at least two grid values.'.format(name))
+            self.marginalGrid.append(values)
+            self.gridSize.append(len(values))
+            self.boundaries.append([values[0], values[-1]])
+            if np.any(np.abs(np.diff(np.diff(values))) > 10 ** -10):
+                print('! WARNING: Supplied parameter values for "{}" are not equally spaced. Assuming categorical '
+                      'parameter.'.format(name))
+                self.latticeConstant.append(1.)
+            else:
+                self.latticeConstant.append(np.abs(values[0] - values[1]))
+        self.grid = [m for m in np.meshgrid(*self.marginalGrid, indexing='ij')]
+        if self.transitionModel is not None:
+            self.transitionModel.latticeConstant = self.latticeConstant
+        if not silent:
+            print('+ Observation model: {}. Parameter(s): {}'.format(L, L.parameterNames))
+
+    def setOM(self, L, silent=False):
+        self.setObservationModel(L, silent=silent)
+
+    def setTransitionModel(self, T, silent=False):
+        if str(T) == 'Break-point':
+            raise ConfigurationError('The "BreakPoint" transition model can only be used with the '
+                                     '"SerialTransitionModel" class.')
+        self.transitionModel = T
+        T.study = self
+        T.latticeConstant = self.latticeConstant
+        if not silent:
+            print('+ Transition model: {}. Hyper-Parameter(s): {}'.format(T, self._unpackAllHyperParameters(values=False)))
+
+    def setTM(self, T, silent=False):
+        self.setTransitionModel(T, silent=silent)
+
+    def set(self, *args, **kwargs):
+        for key in kwargs:
+            if key not in ['silent']:
+                raise TypeError("set() got an unexpected keyword argument '{}'".format(key))
+        silent = kwargs.pop('silent', False)
+        om = tm = False
+        for model in args:
+            if isinstance(model, ObservationModel):
+                if om:
+                    raise ConfigurationError('More than one observation model supplied.')
+                om = True
+                self.setObservationModel(model, silent=silent)
+            elif isinstance(model, TransitionModel):
+                if tm:
+                    raise ConfigurationError('More than one transition model supplied.')
+                tm = True
+                self.setTransitionModel(model, silent=silent)
+            else:
+                raise ConfigurationError('Expected observation model or transition model instance as first argument.')
+
+    # ---- prior ---------------------------------------------------------------------------------------------------
+    def _computePrior(self, silent=False):
+        """Prior on the grid for None / ndarray / callable priors (reference core.py:184-235).  Unlike the reference
+        an ndarray prior is copied, never normalised in place."""
+        prior = self.observationModel.prior
+        cell = np.prod(self.latticeConstant)
+        if prior is None:
+            if not silent:
+                print('    + Set uniform prior with parameter boundaries.')
+            p = np.ones(self.gridSize)
+            p /= np.sum(p)
+            p /= cell
+            return p
+        if isinstance(prior, np.ndarray):
+            if tuple(prior.shape) != tuple(self.gridSize):
+                raise ConfigurationError('Prior array does not match parameter grid size.')
+            p = np.array(prior, dtype=float)
+            norm = np.sum(p)
+            if norm != 1.:
+                p /= norm
+                p /= cell
+            if not silent:
+                print('    + Set prior (numpy array).')
+            return p
+        if hasattr(prior, '__call__'):
+            p = prior(*self.grid) * np.ones(self.gridSize)
+            norm = np.sum(p)
+            if norm != 1.:
+                p /= norm
+                p /= cell
+            if not silent:
+                print('    + Set prior (function): {}'.format(getattr(prior, '__name__', 'callable')))
+            return p
+        return self._sympy_prior(prior, silent)
+
+    def _sympy_prior(self, prior, silent):
+        """SymPy random variable(s) as prior: product density evaluated on the grid, not re-normalised
+        (reference core.py:238-265)."""
+        try:
+            import sympy
+            from sympy import lambdify, symbols, abc
+            from sympy.stats import density
+        except ImportError:
+            raise ConfigurationError('Only None, arrays, functions or SymPy random variables can be used as a prior.')
+        if type(prior) is sympy.stats.rv.RandomSymbol:
+            prior = [prior]
+        if not isinstance(prior, (list, tuple)):
+            raise ConfigurationError('Only None, arrays, functions or SymPy random variables can be used as a prior.')
+        if len(prior) != len(self.observationModel.parameterNames):
+            raise ConfigurationError('Observation model contains {} parameters, but {} priors were provided.'
+                                     .format(len(self.observationModel.parameterNames), len(prior)))
+        import string
+        x = symbols(' '.join(list(string.ascii_lowercase)[:len(prior)])) if len(prior) > 1 else [abc.x]
+        pdf = 1
+        for k, rv in enumerate(prior):
+            if type(rv) is not sympy.stats.rv.RandomSymbol:
+                raise ConfigurationError('Only lambda functions or SymPy random variables can be used as a prior.')
+            pdf = pdf * density(rv)(x[k])
+        if not silent:
+            print('    + Set prior (sympy): {}'.format(pdf))
+        return np.asarray(lambdify(x, pdf, modules=['numpy'])(*self.grid), dtype=float) * np.ones(self.gridSize)
+
+    def _changepointPrior(self):
+        """The distribution a change-point restarts from (reference transitionModels.py:300-312)."""
+        prior = self.observationModel.prior
+        if hasattr(prior, '__call__'):
+            p = prior(*self.grid) * np.ones(self.gridSize)
+        elif isinstance(prior, np.ndarray):
+            p = np.array(prior, dtype=float)
+        else:
+            p = np.ones(self.gridSize)
+        p = p / np.sum(p)
+        return p * np.prod(self.latticeConstant)
+
+    # ---- hyper-parameter plumbing (reference core.py:623-824) -------------------------------------------------------
+    def _hyperSlots(self):
+        """[(model, index into model.hyperParameterValues, name)] in the reference's flattened order."""
+        slots = []
+        if self.transitionModel is None:
+            return slots
+        for m in _leaf_models(self.transitionModel):
+            for k, name in enumerate(getattr(m, 'hyperParameterNames', [])):
+                slots.append((m, k, name))
+        return slots
+
+    def _unpackAllHyperParameters(self, values=True):
+        return [m.hyperParameterValues[k] if values else name for m, k, name in self._hyperSlots()]
+
+    def _selectedSlots(self):
+        slots = self._hyperSlots()
+        if not self.selectedHyperParameters:
+            return slots
+        out, used = [], set()
+        for name in self.selectedHyperParameters:
+            hit = [i for i, s in enumerate(slots) if s[2] == name and i not in used]
+            if not hit:
+                raise ConfigurationError('Could not find any hyper-parameter named {}.'.format(name))
+            used.add(hit[0])
+            out.append(slots[hit[0]])
+        return out
+
+    def _unpackSelectedHyperParameters(self):
+        return [m.hyperParameterValues[k] for m, k, _ in self._selectedSlots()]
+
+    def _setAllHyperParameters(self, x):
+        for (m, k, _), v in zip(self._hyperSlots(), list(x)):
+            m.hyperParameterValues[k] = v
+
+    def _setSelectedHyperParameters(self, x):
+        for (m, k, _), v in zip(self._selectedSlots(), list(x)):
+            m.hyperParameterValues[k] = v
+        return 1
+
+    def _unpackChangepointNames(self, transitionModel=None):
+        return [name for m, k, name in self._hyperSlots() if isinstance(m, ChangePoint)]
+
+    def _getHyperParameterIndex(self, transitionModel, name):
+        names = self._unpackAllHyperParameters(values=False)
+        if name not in names:
+            raise PostProcessingError('Could not find any hyper-parameter with name: {}.'.format(name))
+        return names.index(name)
+
+    def getHyperParameterValue(self, name):
+        return self._unpackAllHyperParameters(values=True)[self._getHyperParameterIndex(self.transitionModel, name)]
+
+    def _checkConsistency(self):
+        """Raised before any device work starts (reference core.py:1098-1115)."""
+        if len(self.rawData) == 0:
+            raise ConfigurationError('No data loaded.')
+        if not self.observationModel:
+            raise ConfigurationError('No observation model chosen.')
+        if not self.transitionModel:
+            raise ConfigurationError('No transition model chosen.')
+        names = self._unpackAllHyperParameters(values=False)
+        u, i = np.unique(names, return_inverse=True)
+        duplicates = u[np.bincount(i) > 1] if len(names) else []
+        if len(duplicates) > 0:
+            raise ConfigurationError('Detected duplicate hyper-parameter names: {}.'.format(duplicates))
+
+    # ---- compiling the study into a device problem ---------------------------------------------------------------
+    def _formatData(self):
+        seg = self.observationModel.segmentLength
+        self.formattedData = movingWindow(self.rawData, seg)
+        self.formattedTimestamps = self.rawTimestamps[seg - 1:]
+
+    def _compile(self, silent=True):
+        """-> (FitProblem, program) ; program = [(kind, axis, model, hyper index)] in list order."""
+        om = self.observationModel
+        program = self.transitionModel._program(om.parameterNames)
+        if len(self.gridSize) not in (1, 2):
+            raise ConfigurationError('The MI355X engine supports observation models with 1 or 2 parameters '
+                                     '(got {}).'.format(len(self.gridSize)))
+        prior = self._computePrior(silent=silent)
+        reset = self._changepointPrior() if any(op[0] == _abi.OP_CHANGEPOINT for op in program) else None
+        data = np.asarray(self.formattedData, dtype=float)
+        lik = None
+        code = getattr(om, 'device_model', _abi.OM_TABLE)
+        if code == _abi.OM_TABLE or om.segmentLength != 1:
+            # the model's own pdf, evaluated once per time step on the host (plug-in interface of the reference)
+            code = _abi.OM_TABLE
+            lik = np.array([np.asarray(om.processedPdf(self.grid, seg), dtype=float) * np.ones(self.gridSize)
+                            for seg in self.formattedData])
+        problem = FitProblem(obs_model=code, marginal=self.marginalGrid, lattice=self.latticeConstant, data=data,
+                             timestamps=np.asarray(self.formattedTimestamps, dtype=float), prior=prior,
+                             ops=[(op[0], op[1]) for op in program], reset_prior=reset, lik=lik,
+                             seg_len=om.segmentLength)
+        return problem, program
+
+    def _opValues(self, program, flat_values=None):
+        """One row of op values: the current hyper-parameter value of every op (NaN for Static)."""
+        slots = self._hyperSlots()
+        row = []
+        for kind, axis, model, k in program:
+            if k is None:
+                row.append(np.nan)
+                continue
+            if flat_values is None:
+                v = model.hyperParameterValues[k]
+            else:
+                idx = [i for i, s in enumerate(slots) if s[0] is model and s[1] == k][0]
+                v = flat_values[idx]
+            if isinstance(v, str) or np.ndim(v) != 0:
+                raise ConfigurationError('Hyper-parameter "{}" holds several values; use a HyperStudy to fit a range of '
+                                         'hyper-parameter values.'.format(model.hyperParameterNames[k]))
+            row.append(float(v))
+        return row
+
+    def _warnZero(self, phase):
+        which = 'Forward pass distribution' if phase == 0 else 'Posterior distribution'
+        if self.fitWarningCounter < 5:
+            print('    ! WARNING: {} contains only zeros, check parameter boundaries!'.format(which))
+            print('      Stopping inference process. Setting model evidence to zero.')
+        elif self.fitWarningCounter == 5:
+            print('    ! WARNING: Will omit further warnings about parameter boundaries.')
+        self.fitWarningCounter += 1
+
+    # ---- fit -----------------------------------------------------------------------------------------------------
+    def fit(self, forwardOnly=False, evidenceOnly=False, silent=False):
+        """
+        Posterior sequence, posterior means, local evidence and log-evidence for the current hyper-parameter values
+        (reference core.py:330-486), computed on the GPU.  ``posteriorSequence`` stays on the device until first read.
+        """
+        self._checkConsistency()
+        if not silent:
+            print('+ Started new fit:')
+        self._formatData()
+        if not silent:
+            print('    + Formatted data.')
+        problem, program = self._compile(silent=silent)
+        eng = _engine_mod.get_engine()
+        T = len(self.formattedData)
+        keep = not evidenceOnly
+        res = eng.fit(problem, [self._opValues(program)], forward_only=forwardOnly, evidence_only=evidenceOnly,
+                      keep_posterior=keep, owner=self)
+        self.lastTiming = res.timing
+        self.logEvidence = float(res.log_evidence[0])
+        self.localEvidence = res.local_evidence[0].copy()
+        if res.abort_step[0] >= 0:
+            # zero normaliser: the reference warns, sets logEvidence = -inf and returns early (core.py:390-400, 442-452)
+            self._warnZero(int(res.abort_phase[0]))
+            self.logEvidence = -np.inf
+            if keep:
+                eng.release_posterior(self)
+            return
+        if not silent:
+            print('    + Finished forward pass.')
+            print('    + Log10-evidence: {:.5f}'.format(self.logEvidence / np.log(10)))
+        if evidenceOnly:
+            self.posteriorMeanValues = []
+            return
+        grid_size = list(self.gridSize)
+        self._posteriorSequence = None
+        self._posterior_pending = lambda: eng.posterior(0, T, grid_size)
+        self.posteriorMeanValues = res.posterior_mean[0].copy()
+        if not silent:
+            if not forwardOnly:
+                print('    + Finished backward pass.')
+            print('    + Computed mean parameter values.')
+
+    def optimize(self, parameterList=[], forwardOnly=False, **kwargs):
+        """COBYLA maximisation of the log-evidence over hyper-parameters (reference core.py:488-565); every
+        objective evaluation is an evidence-only fit on the GPU."""
+        from scipy.optimize import minimize
+        self.selectedHyperParameters = [parameterList] if isinstance(parameterList, str) else list(parameterList)
+        print('+ Starting optimization...')
+        self._checkConsistency()
+        if not self.selectedHyperParameters:
+            points = self._unpackChangepointNames()
+            self.selectedHyperParameters = [n for n in self._unpackAllHyperParameters(values=False) if n not in points]
+        x0 = self._unpackSelectedHyperParameters()
+        if len(x0) == 0:
+            self.selectedHyperParameters = []
+            raise ConfigurationError('No parameters to optimize. Check parameter names.')
+
+        def objective(x):
+            self._setSelectedHyperParameters(x)
+            self.fit(evidenceOnly=True, silent=True)
+            print('    + Log10-evidence: {:.5f}'.format(self.logEvidence / np.log(10)), '- Parameter values:', x)
+            return -self.logEvidence
+
+        result = minimize(objective, x0, method='COBYLA', **kwargs)
+        print('+ Finished optimization.')
+        self._setSelectedHyperParameters(result.x)
+        self.fit(forwardOnly=forwardOnly)
+        self.selectedHyperParameters = []
+
+    # ---- accessors (host-side consumers of the fit results) -------------------------------------------------------
+    def _parameterIndex(self, name):
+        names = list(self.observationModel.parameterNames)
+        if name not in names:
+            raise PostProcessingError('Wrong parameter name. Available options: {0}'.format(names))
+        return names.index(name)
+
+    def _requirePosterior(self):
+        post = self.posteriorSequence
+        if post is None or len(post) == 0:
+            raise PostProcessingError('Cannot plot posterior sequence as it has not yet been computed. Run complete fit.')
+        return post
+
+    def getParameterMeanValues(self, name):
+        return self.posteriorMeanValues[self._parameterIndex(name)]
+
+    def getParameterDistribution(self, t, name, plot=False, density=True, **kwargs):
+        """Marginal distribution of one parameter at time stamp ``t`` or time-averaged (``t='avg'``)."""
+        post = self._requirePosterior()
+        if isinstance(t, str) and t == 'avg':
+            dist = np.sum(post, axis=0) / len(post)
+        else:
+            if t not in self.formattedTimestamps:
+                raise PostProcessingError('Supplied time ({}) does not exist in data or is out of range.'.format(t))
+            dist = post[list(self.formattedTimestamps).index(t)]
+        k = self._parameterIndex(name)
+        axes = tuple(a for a in range(len(self.gridSize)) if a != k)
+        marginal = np.sum(dist, axis=axes) if axes else np.array(dist)
+        if density:
+            marginal = marginal / self.latticeConstant[k]
+        return self.marginalGrid[k], marginal
+
+    def getPD(self, t, name, plot=False, density=True, **kwargs):
+        return self.getParameterDistribution(t, name, plot=plot, density=density, **kwargs)
+
+    def getParameterDistributions(self, name, plot=False, density=True, **kwargs):
+        """Time series of marginal posterior distributions of one parameter: (values, (T, n) array)."""
+        post = self._requirePosterior()
+        k = self._parameterIndex(name)
+        axes = tuple(a + 1 for a in range(len(self.gridSize)) if a != k)
+        marginal = np.sum(post, axis=axes) if axes else np.array(post)
+        if density:
+            marginal = marginal / self.latticeConstant[k]
+        return self.marginalGrid[k], marginal
+
+    def getPDs(self, name, plot=False, density=True, **kwargs):
+        return self.getParameterDistributions(name, plot=plot, density=density, **kwargs)
+
+
+class HyperStudy(Study):
+    """Hyper-parameter inference over a grid of hyper-parameter values (reference core.py:1118-1495).
+
+    All hyper-grid points are independent forward-backward chains; they run batched on the GPU (one kernel launch per
+    time step for the whole batch) and, when a communicator is attached (:mod:`bayesloop_amd.dist`), sharded over the
+    GPUs of a node in the contiguous chunks of ``np.array_split`` that the reference's ``_parallelFit`` uses.
+    """
+
+    def __init__(self, silent=False):
+        super(HyperStudy, self).__init__(silent=silent)
+        self.hyperGrid = []
+        self.hyperGridValues = []
+        self.hyperGridConstant = []
+        self.flatHyperParameters = []
+        self.flatHyperParameterNames = []
+        self.flatHyperPriors = []
+        self.flatHyperPriorValues = []
+        self.hyperParameterDistribution = None
+        self.averagePosteriorSequence = None
+        self.logEvidenceList = []
+        self.localEvidenceList = []
+        self.communicator = None        # bayesloop_amd.dist communicator; None = single GPU
+        if not silent:
+            print('  --> Hyper-study')
+
+    def _unpackAllHyperPriors(self):
+        priors = []
+        for m in _leaf_models(self.transitionModel):
+            if len(getattr(m, 'hyperParameterNames', [])) > 0:
+                priors.append(getattr(m, 'prior', None))
+        return priors
+
+    def _createHyperGrid(self, silent=False):
+        """Hyper-grid, its lattice constants and the joint hyper-prior (reference core.py:1142-1245)."""
+        self.flatHyperParameters = self._unpackAllHyperParameters()
+        self.flatHyperParameterNames = self._unpackAllHyperParameters(values=False)
+        self.flatHyperPriors = self._unpackAllHyperPriors()
+        for k, v in enumerate(self.flatHyperParameters):
+            if isinstance(v, str) and v == 'all':
+                self.flatHyperParameters[k] = self.formattedTimestamps[:-1]
+
+        if len(self.flatHyperParameterNames) > 0:
+            mesh = np.meshgrid(*self.flatHyperParameters, indexing='ij')
+            self.hyperGridValues = np.array([m.ravel() for m in mesh]).T
+        else:
+            self.hyperGridValues = np.array([])
+
+        constants = []
+        for values in self.flatHyperParameters:
+            c = 1
+            if isinstance(values, Iterable) and len(values) > 1:
+                a = np.array(values)
+                d = a[1:] - a[:-1]
+                if np.all(np.abs(d[1:] - d[:-1]) < 10 ** -10):
+                    c = np.abs(d[0])
+            constants.append(c)
+        self.hyperGridConstant = np.array(constants)
+
+        priorValuesList, priorNames = [], []
+        for prior, values, c, name in zip(self.flatHyperPriors, self.flatHyperParameters, self.hyperGridConstant,
+                                          self.flatHyperParameterNames):
+            if prior is None:
+                pv = np.ones_like(values, dtype=float)
+                pv /= np.sum(pv)
+                pv /= c
+                priorNames.append('uniform')
+            elif hasattr(prior, '__call__'):
+                try:
+                    pv = np.array([prior(v) for v in np.atleast_1d(values)], dtype=float)
+                    pv = pv / np.sum(pv) / c
+                except Exception:
+                    raise ConfigurationError('Failed to set hyper-prior for "{}" from function "{}".'
+                                             .format(name, getattr(prior, '__name__', 'callable')))
+                priorNames.append(getattr(prior, '__name__', 'callable'))
+            elif isinstance(prior, Iterable):
+                if len(prior) != len(values):
+                    raise ConfigurationError('Failed to set hyper-prior for "{}" from list/array.'.format(name))
+                pv = np.array(prior, dtype=float)
+                pv = pv / np.sum(pv) / c
+                priorNames.append('list/array')
+            else:
+                pv = self._sympyHyperPrior(prior, values, name)
+                priorNames.append('sympy')
+            priorValuesList.append(pv)
+
+        if len(self.flatHyperParameterNames) > 0:
+            mesh = np.meshgrid(*priorValuesList, indexing='ij')
+            self.flatHyperPriorValues = np.prod(np.array([m.ravel() for m in mesh]).T, axis=1)
+            if not silent and len(self.hyperGridValues) > 1:
+                print('+ Set hyper-prior(s): {}'.format(priorNames))
+        else:
+            self.flatHyperPriorValues = np.array([1])
+
+    @staticmethod
+    def _sympyHyperPrior(prior, values, name):
+        try:
+            from sympy import lambdify, abc
+            from sympy.stats import density
+            pdf = lambdify([abc.x], density(prior)(abc.x), modules=['numpy'])
+            return np.asarray(pdf(np.asarray(values, dtype=float)), dtype=float)
+        except Exception:
+            raise ConfigurationError('Failed to set hyper-prior for "{}".'.format(name))
+
+    def fit(self, forwardOnly=False, evidenceOnly=False, silent=False, nJobs=1, customHyperGrid=False):
+        """
+        Fits every hyper-grid point and averages the models with their evidence (reference core.py:1247-1441).
+        ``nJobs`` is accepted for compatibility; parallelism comes from batching on the GPU and, across GPUs, from
+        ``self.communicator``.
+        """
+        self.fitWarningCounter = 0
+        self._formatData()
+        if not customHyperGrid:
+            self._createHyperGrid(silent=silent)
+            names = self._unpackChangepointNames()
+            if len(names) > 1:
+                cols = [self.flatHyperParameterNames.index(n) for n in names]
+                for v in self.hyperGridValues[:, cols]:
+                    if np.unique(v).size < v.size:
+                        raise ConfigurationError('Detected multiple change-/break-points with identical values and/or '
+                                                 'overlapping value intervals. Use "ChangepointStudy" instead of '
+                                                 '"HyperStudy" for such cases.')
+        self._checkConsistency()
+        self.logEvidenceList, self.localEvidenceList = [], []
+        if len(self.hyperGridValues) <= 1:
+            if not silent:
+                print('+ At most one combination of hyper-parameter values, switching to standard fit method.')
+            if len(self.hyperGridValues) == 1:
+                self._setAllHyperParameters(self.hyperGridValues[0])
+            Study.fit(self, forwardOnly=forwardOnly, evidenceOnly=evidenceOnly, silent=silent)
+            if len(self.hyperGridValues) == 1:
+                self._setAllHyperParameters(self.flatHyperParameters)
+            return
+
+        if not silent:
+            print('+ Started new fit.')
+            print('    + {} analyses to run.'.format(len(self.hyperGridValues)))
+        # one representative value per hyper-parameter while compiling (values come from the hyper-grid rows)
+        self._setAllHyperParameters(self.hyperGridValues[0])
+        try:
+            problem, program = self._compile(silent=True)
+        finally:
+            self._setAllHyperParameters(self.flatHyperParameters)
+        slots = self._hyperSlots()
+        col = []
+        for kind, axis, model, k in program:
+            col.append(None if k is None else [i for i, s in enumerate(slots) if s[0] is model and s[1] == k][0])
+        hv = np.asarray(self.hyperGridValues, dtype=float)
+        op_values = np.full((len(hv), max(1, len(program))), np.nan)
+        for j, c in enumerate(col):
+            if c is not None:
+                op_values[:, j] = hv[:, c]
+        prior_values = np.asarray(self.flatHyperPriorValues, dtype=float)
+
+        from . import dist as _dist
+        out = _dist.sharded_hyper_fit(_engine_mod.get_engine(), problem, op_values, prior_values, self.communicator,
+                                      forward_only=forwardOnly, evidence_only=evidenceOnly, owner=self)
+        self.lastTiming = out['timing']
+        self.logEvidenceList = list(out['log_evidence'])
+        localList = out['local_evidence']
+        n_abort = int(np.sum(out['abort_step'] >= 0))
+        for _ in range(min(n_abort, 6)):
+            self._warnZero(0)
+        self.fitWarningCounter += max(0, n_abort - 6)
+
+        if not evidenceOnly:
+            self.averagePosteriorSequence = None
+            self._posteriorSequence = None
+            self._posterior_pending = out['posterior']          # callable or None (non-root ranks)
+            if not silent:
+                print('    + Computed average posterior sequence')
+
+        # hyper-parameter distribution and evidence of the average model (reference core.py:1391-1410)
+        with np.errstate(divide='ignore'):
+            logHPD = np.array(self.logEvidenceList) + np.log(prior_values) + np.sum(np.log(self.hyperGridConstant))
+        scaled = logHPD - np.amax(logHPD)
+        self.hyperParameterDistribution = np.exp(scaled)
+        self.hyperParameterDistribution /= np.sum(self.hyperParameterDistribution)
+        self.hyperParameterDistribution /= np.prod(self.hyperGridConstant)
+        m = np.amax(logHPD)
+        self.logEvidence = float(m + np.log(np.sum(np.exp(logHPD - m))))     # logsumexp
+        if not silent:
+            print('    + Computed hyper-parameter distribution')
+            print('    + Log10-evidence of average model: {:.5f}'.format(self.logEvidence / np.log(10)))
+        self.localEvidence = np.sum((np.array(localList).T * prior_values).T, axis=0)
+        if not evidenceOnly:
+            self.posteriorMeanValues = out['posterior_mean']
+        self.localEvidenceList = []
+        self._setAllHyperParameters(self.flatHyperParameters)
+        if not silent:
+            print('+ Finished fit.')
+
+    @property
+    def averagePosteriorSequence(self):
+        return self.posteriorSequence if self._avg_is_posterior else self._averagePosteriorSequence
+
+    @averagePosteriorSequence.setter
+    def averagePosteriorSequence(self, value):
+        self._avg_is_posterior = value is None
+        self._averagePosteriorSequence = value
+
+    def optimize(self, *args, **kwargs):
+        raise NotImplementedError('HyperStudy object has no optimizing method.')
+
+    # ---- accessors -------------------------------------------------------------------------------------------------
+    def _hyperGridSteps(self):
+        return [len(x) if isinstance(x, Iterable) and not isinstance(x, str) else 1 for x in self.flatHyperParameters]
+
+    def getHyperParameterDistribution(self, name, plot=False, **kwargs):
+        """Marginal distribution of one hyper-parameter: (values, probabilities) (reference core.py:1535-1585)."""
+        if len(self.hyperGridValues) < 2:
+            raise PostProcessingError('At least two combinations of hyper-parameter values need to be fitted to '
+                                      'evaluate a hyper-parameter distribution. Check transition model.')
+        k = self._getHyperParameterIndex(self.transitionModel, name)
+        dist = np.asarray(self.hyperParameterDistribution).reshape(self._hyperGridSteps(), order='C')
+        axes = tuple(a for a in range(dist.ndim) if a != k)
+        marginal = np.sum(dist, axis=axes) if axes else np.array(dist)
+        marginal = marginal * np.prod(self.hyperGridConstant)
+        return self.flatHyperParameters[k], marginal
+
+    def getHPD(self, name, plot=False, **kwargs):
+        return self.getHyperParameterDistribution(name, plot=plot, **kwargs)
+
+    def getJointHyperParameterDistribution(self, names, plot=False, figure=None, subplot=111, **kwargs):
+        """Joint distribution of two hyper-parameters: (x, y, probabilities) (reference core.py:1593-1694)."""
+        if len(self.hyperGridValues) < 2:
+            raise PostProcessingError('At least two combinations of hyper-parameter values need to be fitted to '
+                                      'evaluate a hyper-parameter distribution. Check transition model.')
+        if not isinstance(names, Iterable) or isinstance(names, str) or len(names) != 2:
+            raise PostProcessingError('A list of exactly two hyper-parameters has to be provided.')
+        idx = [self._getHyperParameterIndex(self.transitionModel, n) for n in names]
+        switch = idx[0] > idx[1]
+        lo, hi = sorted(idx)
+        dist = np.asarray(self.hyperParameterDistribution).reshape(self._hyperGridSteps(), order='C')
+        axes = tuple(a for a in range(dist.ndim) if a not in (lo, hi))
+        marginal = np.sum(dist, axis=axes) if axes else np.array(dist)
+        marginal = marginal * np.prod(self.hyperGridConstant)
+        x, y = self.flatHyperParameters[lo], self.flatHyperParameters[hi]
+        if switch:
+            x, y, marginal = y, x, marginal.T
+        return x, y, marginal
+
+    def getJHPD(self, names, plot=False, figure=None, subplot=111, **kwargs):
+        return self.getJointHyperParameterDistribution(names, plot=plot, figure=figure, subplot=subplot, **kwargs)
+
+
+class ChangepointStudy(HyperStudy):
+    """Change-point inference: a HyperStudy over ordered combinations of change-point times
+    (reference core.py:1743-1852)."""
+
+    def __init__(self, silent=False):
+        super(ChangepointStudy, self).__init__(silent=silent)
+        self.allHyperGridValues = []
+        self.allHyperPriorValues = []
+        self.mask = []
+        if not silent:
+            print('  --> Change-point analysis')
+
+    def fit(self, forwardOnly=False, evidenceOnly=False, silent=False, nJobs=1):
+        self._formatData()
+        changepoints = self._unpackChangepointNames()
+        if len(changepoints) == 0:
+            raise ConfigurationError('No change-points or break-points detected in transition model. Check transition '
+                                     'model.')
+        self.flatHyperParameters = self._unpackAllHyperParameters()
+        self.flatHyperParameterNames = self._unpackAllHyperParameters(values=False)
+        if not silent:
+            print('+ Detected {} change-point(s) in transition model: {}'.format(len(changepoints), changepoints))
+
+        self._createHyperGrid(silent=silent)
+        self.allHyperGridValues = self.hyperGridValues[:]
+        self.allHyperPriorValues = self.flatHyperPriorValues[:]
+
+        # keep ordered combinations of change-point times only and re-weight the prior (reference core.py:1823-1834)
+        cols = [self.flatHyperParameterNames.index(n) for n in changepoints]
+        points = self.allHyperGridValues[:, cols]
+        self.mask = np.ones(len(points), dtype=bool)
+        for a in range(points.shape[1] - 1):
+            self.mask &= points[:, a] < points[:, a + 1]
+        self.hyperGridValues = self.allHyperGridValues[self.mask]
+        self.flatHyperPriorValues = self.allHyperPriorValues[self.mask] * \
+            (np.sum(self.allHyperPriorValues) / np.sum(self.allHyperPriorValues[self.mask]))
+
+        HyperStudy.fit(self, forwardOnly=forwardOnly, evidenceOnly=evidenceOnly, silent=silent, nJobs=nJobs,
+                       customHyperGrid=True)
+
+        # scatter back to the full grid, invalid combinations get probability zero (reference core.py:1846-1852)
+        if self.hyperParameterDistribution is not None and len(self.hyperGridValues) > 1:
+            full = np.zeros(len(self.allHyperGridValues))
+            full[self.mask] = self.hyperParameterDistribution
+            self.hyperParameterDistribution = full
+        full = np.zeros(len(self.allHyperPriorValues))
+        full[self.mask] = self.flatHyperPriorValues
+        self.flatHyperPriorValues = full
+
+    def getDurationDistribution(self, names, plot=False, **kwargs):
+        """Distribution of the number of time steps between two change-points (reference core.py:1875-1924)."""
+        if not isinstance(names, Iterable) or isinstance(names, str) or len(names) != 2:
+            raise PostProcessingError('A list of exactly two hyper-parameters has to be provided.')
+        idx = sorted(self._getHyperParameterIndex(self.transitionModel, n) for n in names)
+        values = self.hyperGridValues[:, idx].T
+        duration = np.unique(values[1] - values[0])
+        dist = np.zeros(len(duration))
+        for k, v in enumerate(self.allHyperGridValues[:, idx]):
+            if v[1] > v[0]:
+                j = np.where(duration.round(10) == (v[1] - v[0]).round(10))[0][0]
+                dist[j] += self.hyperParameterDistribution[k]
+        return duration, dist / np.sum(dist)
+
+    def getDD(self, names, plot=False, **kwargs):
+        return self.getDurationDistribution(names, plot=plot, **kwargs)

@@ -1,0 +1,910 @@
+// libblhip: C-ABI (include/blhip.h) + host orchestration of the forward-backward recursion on one MI355X.
+//
+// The host side owns what the reference's Study.fit loop owns (bayesloop/core.py:330-486): the order of steps, the
+// evidence bookkeeping and the per-step transition program; the arithmetic on the grid runs in the HIP kernels of
+// blhip_kernels.hpp / blhip_fast.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/blhip.h"
+#include "blhip_kernels.hpp"
+
+using namespace blk;
+
+namespace {
+
+struct Fail {
+    std::string msg;
+};
+
+[[noreturn]] void fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Fail{buf};
+}
+
+#define HIPCHECK(expr)                                                                                        \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        release();
+        HIPCHECK(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct blhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::string err;
+    std::string name;
+    std::map<std::string, double> opt;
+    // reusable device buffers
+    DevBuf state, post, psumF, psumB, redF, redB, meta, tables, likbuf, small, accum_own, stats;
+    // kept posterior of the last fit
+    bool post_valid = false;
+    int64_t post_chains = 0, post_T = 0, post_G = 0;
+    // accumulator
+    bool acc_active = false, acc_final = false, acc_first = true;
+    double *acc = nullptr;
+    int64_t acc_T = 0, acc_G = 0, acc_folded = 0;
+    double acc_logref = -std::numeric_limits<double>::infinity();
+    blhip_timing timing = {};
+
+    double option(const char *k, double dflt) const {
+        auto it = opt.find(k);
+        return it == opt.end() ? dflt : it->second;
+    }
+};
+
+namespace {
+
+struct TapTable {
+    std::vector<double> w;       // concatenated half kernels: w[off + k], k = 0..lw
+    std::vector<int> off, lw;
+    std::map<std::pair<int, double>, int> index;   // (internal axis, normed sigma) -> id
+
+    // SciPy's kernel: lw = int(4 sd + 0.5); phi = exp(-0.5/sd^2 x^2); phi / sum(phi)   (_filters.py, gaussian_filter1d)
+    int get(int axis, double ns) {
+        auto key = std::make_pair(axis, ns);
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        const int r = (int)(4.0 * ns + 0.5);
+        int id = -1;
+        if (r > 0) {
+            std::vector<double> phi(2 * r + 1);
+            const double s2 = ns * ns;
+            double sum = 0.0;
+            for (int k = -r; k <= r; ++k) {
+                phi[k + r] = std::exp(-0.5 / s2 * (double)(k * k));
+                sum += phi[k + r];
+            }
+            id = (int)off.size();
+            off.push_back((int)w.size());
+            lw.push_back(r);
+            for (int k = 0; k <= r; ++k) w.push_back(phi[r + k] / sum);
+        }
+        index[key] = id;
+        return id;
+    }
+};
+
+struct Geometry {
+    int n0, n1;          // internal rows / cols
+    int axis_map[2];     // ABI parameter index -> internal axis
+    long long G;
+};
+
+struct Tile {
+    int TI, TJ, LW0, LW1, tiles_i, tiles_j, nblk;
+    size_t lds_bytes;
+};
+
+size_t lds_need(int TI, int TJ, int LW0, int LW1) {
+    const size_t pitch = (size_t)TJ + 2 * LW1;
+    return ((size_t)(TI + 2 * LW0) * pitch + (size_t)TI * pitch + 16) * sizeof(double);
+}
+
+Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1) {
+    Tile t{};
+    const size_t cap = (size_t)ctx->option("lds_cap_bytes", 64 * 1024);
+    int TI, TJ;
+    if (g.n0 == 1) {
+        TI = 1;
+        TJ = (int)ctx->option("tile_1d", g.n1 <= 65536 ? 256 : 1024);
+    } else {
+        TI = (int)ctx->option("tile_i", 16);
+        TJ = (int)ctx->option("tile_j", 128);
+    }
+    TI = std::max(1, std::min(TI, g.n0));
+    TJ = std::max(1, std::min(TJ, g.n1));
+    while (lds_need(TI, TJ, LW0, LW1) > cap) {
+        if (TI > 4 && (TI >= TJ / 4 || TJ <= 32)) TI = (TI + 1) / 2;
+        else if (TJ > 16) TJ = (TJ + 1) / 2;
+        else if (TI > 1) TI = (TI + 1) / 2;
+        else break;
+    }
+    if (lds_need(TI, TJ, LW0, LW1) > 160 * 1024 - 512)
+        fail("filter radius (%d, %d) too large for the fused step kernel (needs %zu B of LDS)", LW0, LW1,
+             lds_need(TI, TJ, LW0, LW1));
+    t.TI = TI; t.TJ = TJ; t.LW0 = LW0; t.LW1 = LW1;
+    t.tiles_i = (g.n0 + TI - 1) / TI;
+    t.tiles_j = (g.n1 + TJ - 1) / TJ;
+    t.nblk = t.tiles_i * t.tiles_j;
+    t.lds_bytes = lds_need(TI, TJ, LW0, LW1);
+    return t;
+}
+
+template <int OM, int MODE, bool MEANS>
+void launch_step_t(hipStream_t s, const StepParams &P, const Tile &t, int B) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<OM, MODE, MEANS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((step_kernel<OM, MODE, MEANS>), dim3(t.nblk, B), dim3(NTHREADS), t.lds_bytes, s, P);
+}
+
+template <int OM>
+void launch_step_om(hipStream_t s, const StepParams &P, const Tile &t, int B, int mode, bool means) {
+    if (mode == MODE_FWD) {
+        if (means) launch_step_t<OM, MODE_FWD, true>(s, P, t, B);
+        else launch_step_t<OM, MODE_FWD, false>(s, P, t, B);
+    } else if (mode == MODE_BWD) {
+        launch_step_t<OM, MODE_BWD, true>(s, P, t, B);
+    } else {
+        launch_step_t<OM, MODE_FILTER, false>(s, P, t, B);
+    }
+}
+
+void launch_step(hipStream_t s, int om, const StepParams &P, const Tile &t, int B, int mode, bool means) {
+    switch (om) {
+        case BLHIP_OM_POISSON: launch_step_om<OM_POISSON>(s, P, t, B, mode, means); break;
+        case BLHIP_OM_GAUSSIAN: launch_step_om<OM_GAUSSIAN>(s, P, t, B, mode, means); break;
+        case BLHIP_OM_GAUSSIAN_MEAN: launch_step_om<OM_GAUSSIAN_MEAN>(s, P, t, B, mode, means); break;
+        case BLHIP_OM_TABLE: launch_step_om<OM_TABLE>(s, P, t, B, mode, means); break;
+        default: fail("unknown observation model %d", om);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+void validate(const blhip_problem *p, int64_t n_chains, const double *op_values) {
+    if (!p) fail("problem is NULL");
+    if (p->ndim != 1 && p->ndim != 2) fail("ndim must be 1 or 2 (got %d)", p->ndim);
+    for (int k = 0; k < p->ndim; ++k) {
+        if (p->n[k] < 1) fail("grid size n[%d] = %lld", k, (long long)p->n[k]);
+        if (!p->marginal[k]) fail("marginal[%d] is NULL", k);
+        if (p->n[k] > (1ll << 30)) fail("grid axis too long");
+    }
+    if (p->T < 1) fail("T must be >= 1");
+    if (!p->data || !p->timestamps || !p->prior) fail("data / timestamps / prior must not be NULL");
+    if (n_chains < 1) fail("n_chains must be >= 1");
+    if (p->n_ops < 0 || (p->n_ops > 0 && !p->ops)) fail("bad transition program");
+    if (p->n_ops > 0 && !op_values) fail("op_values is NULL");
+    bool has_cp = false;
+    for (int k = 0; k < p->n_ops; ++k) {
+        const blhip_op &op = p->ops[k];
+        if (op.kind == BLHIP_OP_GRW) {
+            if (op.axis < 0 || op.axis >= p->ndim) fail("GRW op %d: axis %d out of range", k, op.axis);
+        } else if (op.kind == BLHIP_OP_CHANGEPOINT) {
+            has_cp = true;
+        } else if (op.kind != BLHIP_OP_STATIC) {
+            fail("op %d: unknown kind %d", k, op.kind);
+        }
+    }
+    if (has_cp && !p->reset_prior) fail("CHANGEPOINT op needs reset_prior");
+    switch (p->obs_model) {
+        case BLHIP_OM_POISSON:
+            if (p->ndim != 1) fail("Poisson model has 1 parameter");
+            if (p->seg_len != 1) fail("Poisson model has segment length 1");
+            break;
+        case BLHIP_OM_GAUSSIAN:
+            if (p->ndim != 2) fail("Gaussian model has 2 parameters");
+            if (p->seg_len != 1) fail("Gaussian model has segment length 1");
+            break;
+        case BLHIP_OM_GAUSSIAN_MEAN:
+            if (p->ndim != 1) fail("GaussianMean model has 1 parameter");
+            if (p->seg_len != 1 || p->data_dim != 2) fail("GaussianMean data must be (T, 1, 2)");
+            break;
+        case BLHIP_OM_TABLE:
+            if (!p->lik) fail("BLHIP_OM_TABLE needs lik");
+            break;
+        default: fail("unknown observation model %d", p->obs_model);
+    }
+    if (p->data_dim < 1) fail("data_dim must be >= 1");
+}
+
+// per-step records consumed by blk::likelihood<>
+void build_records(const blhip_problem *p, std::vector<double> &rec, int &rec_len, int &d) {
+    const int64_t T = p->T;
+    const int dd = p->data_dim;
+    if (p->obs_model == BLHIP_OM_GAUSSIAN) {
+        d = dd; rec_len = dd;
+        rec.assign(p->data, p->data + T * dd);
+    } else if (p->obs_model == BLHIP_OM_GAUSSIAN_MEAN) {
+        d = 1; rec_len = 3;
+        rec.resize(T * 3);
+        for (int64_t t = 0; t < T; ++t) {
+            const double x = p->data[t * 2], s = p->data[t * 2 + 1];
+            const bool miss = std::isnan(x) || std::isnan(s);
+            rec[t * 3 + 0] = miss ? std::numeric_limits<double>::quiet_NaN() : x;
+            rec[t * 3 + 1] = 1.0 / (2.0 * s * s);
+            rec[t * 3 + 2] = 0.5 * std::log(2.0 * M_PI * s * s);
+        }
+    } else if (p->obs_model == BLHIP_OM_POISSON) {
+        d = dd; rec_len = 2 * dd;
+        rec.resize(T * 2 * dd);
+        for (int64_t t = 0; t < T; ++t)
+            for (int k = 0; k < dd; ++k) {
+                const double c = p->data[t * dd + k];
+                double f = 1.0;
+                if (!std::isnan(c)) {
+                    if (c < 0 || c != std::floor(c)) fail("Poisson data must be non-negative integers (step %lld)", (long long)t);
+                    for (double q = 2.0; q <= c; q += 1.0) f *= q;
+                }
+                rec[(t * dd + k) * 2] = c;
+                rec[(t * dd + k) * 2 + 1] = f;
+            }
+    } else {
+        d = 1; rec_len = 1;
+        rec.assign(T, 0.0);
+    }
+}
+
+struct ChainProgram {
+    // per (step, chain): source kind and tap ids per internal axis, forward and backward
+    std::vector<unsigned char> kindF, kindB;
+    std::vector<int> tapF0, tapF1, tapB0, tapB1;
+    int LW0 = 0, LW1 = 0;
+};
+
+void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_t B, const double *op_values,
+                   TapTable &taps, ChainProgram &prog) {
+    const int64_t T = p->T;
+    const int nops = p->n_ops;
+    prog.kindF.assign(T * B, SRC_PREV); prog.kindB.assign(T * B, SRC_PREV);
+    prog.tapF0.assign(T * B, -1); prog.tapF1.assign(T * B, -1);
+    prog.tapB0.assign(T * B, -1); prog.tapB1.assign(T * B, -1);
+    prog.LW0 = prog.LW1 = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const double *val = op_values ? op_values + (c0 + b) * nops : nullptr;
+        // tap ids of this chain's GRW ops
+        std::vector<int> op_tap(nops, -1), op_axis(nops, -1);
+        bool any_cp = false;
+        for (int k = 0; k < nops; ++k) {
+            if (p->ops[k].kind == BLHIP_OP_GRW) {
+                const int ax = g.axis_map[p->ops[k].axis];
+                const double ns = val[k] / p->lattice[p->ops[k].axis];     // transitionModels.py:108
+                op_axis[k] = ax;
+                op_tap[k] = (ns > 0.0) ? taps.get(ax, ns) : -1;            // :110-113 (sigma <= 0: copy)
+                if (std::isnan(ns)) fail("chain %lld: GRW sigma is NaN", (long long)(c0 + b));
+            } else if (p->ops[k].kind == BLHIP_OP_CHANGEPOINT) {
+                any_cp = true;
+            }
+        }
+        auto run = [&](double tstamp, unsigned char &kind, int &t0, int &t1) {
+            kind = SRC_PREV; t0 = -1; t1 = -1;
+            for (int k = 0; k < nops; ++k) {
+                if (p->ops[k].kind == BLHIP_OP_GRW) {
+                    if (op_tap[k] < 0) continue;
+                    int &slot = op_axis[k] == 0 ? t0 : t1;
+                    if (slot >= 0)
+                        fail("two GaussianRandomWalk ops on the same parameter in one combined model are not supported");
+                    slot = op_tap[k];
+                } else if (p->ops[k].kind == BLHIP_OP_CHANGEPOINT) {
+                    if (tstamp == val[k]) { kind = SRC_RESET; t0 = -1; t1 = -1; }   // transitionModels.py:300-312
+                }
+            }
+        };
+        unsigned char kstat; int s0, s1;
+        run(std::numeric_limits<double>::quiet_NaN(), kstat, s0, s1);   // the program away from change-points
+        for (int64_t t = 0; t < T; ++t) {
+            // forward step t consumes T_fwd(post_{t-1}, ts[t-1])   core.py:411
+            unsigned char kf = SRC_PRIOR; int f0 = -1, f1 = -1;
+            if (t > 0) {
+                if (any_cp) run(p->timestamps[t - 1], kf, f0, f1); else { kf = kstat; f0 = s0; f1 = s1; }
+            }
+            // backward step t consumes T_bwd(beta_{t+1} L_{t+1}, ts[t+1]) = T_fwd(., ts[t+1] - 1)   core.py:467, transitionModels.py:316-317
+            unsigned char kb = SRC_UNIFORM; int b0 = -1, b1 = -1;
+            if (t < T - 1) {
+                if (any_cp) run(p->timestamps[t + 1] - 1.0, kb, b0, b1); else { kb = kstat; b0 = s0; b1 = s1; }
+            }
+            prog.kindF[t * B + b] = kf; prog.tapF0[t * B + b] = f0; prog.tapF1[t * B + b] = f1;
+            prog.kindB[t * B + b] = kb; prog.tapB0[t * B + b] = b0; prog.tapB1[t * B + b] = b1;
+        }
+        if (s0 >= 0) prog.LW0 = std::max(prog.LW0, taps.lw[s0]);
+        if (s1 >= 0) prog.LW1 = std::max(prog.LW1, taps.lw[s1]);
+    }
+}
+
+template <class T> T *carve(char *&cur, size_t count) {
+    T *p = reinterpret_cast<T *>(cur);
+    cur += ((count * sizeof(T) + 255) / 256) * 256;
+    return p;
+}
+size_t carve_size(size_t bytes) { return ((bytes + 255) / 256) * 256; }
+
+void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const double *op_values,
+            const double *log_w, uint32_t flags, blhip_result *res) {
+    validate(p, n_chains, op_values);
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool evidence_only = flags & BLHIP_EVIDENCE_ONLY;
+    const bool forward_only = (flags & BLHIP_FORWARD_ONLY) && !evidence_only;
+    const bool full = !evidence_only && !forward_only;
+    const bool keep = (flags & BLHIP_KEEP_POSTERIOR) && !evidence_only;
+    const bool accumulate = (flags & BLHIP_ACCUMULATE) && !evidence_only;
+    if (accumulate && !ctx->acc_active) fail("BLHIP_ACCUMULATE without blhip_accum_begin");
+    if (accumulate && !log_w) fail("BLHIP_ACCUMULATE needs log_chain_weight");
+    const int64_t T = p->T;
+
+    Geometry g{};
+    if (p->ndim == 1) { g.n0 = 1; g.n1 = (int)p->n[0]; g.axis_map[0] = 1; g.axis_map[1] = 1; }
+    else { g.n0 = (int)p->n[0]; g.n1 = (int)p->n[1]; g.axis_map[0] = 0; g.axis_map[1] = 1; }
+    g.G = (long long)g.n0 * g.n1;
+    const long long G = g.G;
+    if (accumulate && (ctx->acc_T != T || ctx->acc_G != G)) fail("accumulator shape mismatch");
+    double dV = 1.0;
+    for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
+
+    ctx->post_valid = false;
+    ctx->timing = blhip_timing{};
+
+    // ---- shared tables -------------------------------------------------------------------------------------------
+    std::vector<double> rec; int rec_len = 0, d = 1;
+    build_records(p, rec, rec_len, d);
+    std::vector<double> colA(g.n1, 0.0), colB(g.n1, 0.0);
+    const double *mcol = p->ndim == 1 ? p->marginal[0] : p->marginal[1];
+    if (p->obs_model == BLHIP_OM_GAUSSIAN)
+        for (int j = 0; j < g.n1; ++j) {
+            const double s = mcol[j];
+            colA[j] = 1.0 / (2.0 * s * s);
+            colB[j] = 0.5 * std::log(2.0 * M_PI * s * s);
+        }
+    if (p->obs_model == BLHIP_OM_POISSON)
+        for (int j = 0; j < g.n1; ++j) colA[j] = std::exp(-mcol[j]);
+
+    const bool has_reset = p->reset_prior != nullptr;
+    size_t tb = 0;
+    tb += carve_size(sizeof(double) * std::max(1, g.n0)) + 3 * carve_size(sizeof(double) * g.n1);
+    tb += carve_size(sizeof(double) * rec.size()) + 3 * carve_size(sizeof(double) * G);
+    ctx->tables.ensure(tb);
+    char *cur = ctx->tables.as<char>();
+    double *d_m0 = carve<double>(cur, std::max(1, g.n0));
+    double *d_m1 = carve<double>(cur, g.n1);
+    double *d_colA = carve<double>(cur, g.n1);
+    double *d_colB = carve<double>(cur, g.n1);
+    double *d_rec = carve<double>(cur, rec.size());
+    double *d_prior = carve<double>(cur, G);
+    double *d_reset = carve<double>(cur, G);
+    double *d_uniform = carve<double>(cur, G);
+    if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(d_m0, p->marginal[0], sizeof(double) * g.n0, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_m1, mcol, sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_colA, colA.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_colB, colB.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_prior, p->prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    if (has_reset) HIPCHECK(hipMemcpyAsync(d_reset, p->reset_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    if (full) {
+        // beta_T = 1/G   core.py:424-425
+        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);
+    }
+    double *d_lik = nullptr;
+    if (p->obs_model == BLHIP_OM_TABLE) {
+        ctx->likbuf.ensure(sizeof(double) * T * G);
+        d_lik = ctx->likbuf.as<double>();
+        HIPCHECK(hipMemcpyAsync(d_lik, p->lik, sizeof(double) * T * G, hipMemcpyHostToDevice, st));
+    }
+    HIPCHECK(hipStreamSynchronize(st));   // host vectors above go out of use
+
+    // ---- batching ------------------------------------------------------------------------------------------------
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+    const double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap,
+                                   ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
+    const double per_chain = (evidence_only ? 2.0 : (double)T + 2.0) * (double)G * 8.0 +
+                             (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
+    int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
+    Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024));
+    Bmax = std::min<int64_t>(Bmax, 65535);
+    if (keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
+    const int64_t nbatch = (n_chains + Bmax - 1) / Bmax;
+    const int64_t Bcap = (n_chains + nbatch - 1) / nbatch;
+    ctx->timing.batches = nbatch;
+
+    hipEvent_t *ev = ctx->ev;
+    HIPCHECK(hipEventRecord(ev[6], st));
+
+    std::vector<double> redF, redB;
+    for (int64_t c0 = 0; c0 < n_chains; c0 += Bcap) {
+        const int64_t B = std::min(Bcap, n_chains - c0);
+        TapTable taps;
+        ChainProgram prog;
+        build_program(p, g, c0, B, op_values, taps, prog);
+        const Tile tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
+        ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
+
+        // --- device metadata ---
+        const size_t nT = (size_t)T * B;
+        size_t mb = 2 * carve_size(nT) + 4 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
+                    2 * carve_size(taps.off.size() * 4 + 4) + 2 * carve_size(sizeof(double) * nT) + carve_size(8 * B);
+        ctx->meta.ensure(mb);
+        cur = ctx->meta.as<char>();
+        unsigned char *d_kindF = carve<unsigned char>(cur, nT), *d_kindB = carve<unsigned char>(cur, nT);
+        int *d_tapF0 = carve<int>(cur, nT), *d_tapF1 = carve<int>(cur, nT);
+        int *d_tapB0 = carve<int>(cur, nT), *d_tapB1 = carve<int>(cur, nT);
+        double *d_taps = carve<double>(cur, taps.w.size() + 1);
+        int *d_off = carve<int>(cur, taps.off.size() + 1), *d_lw = carve<int>(cur, taps.off.size() + 1);
+        double *d_invN = carve<double>(cur, nT);
+        double *d_inv_tmp = carve<double>(cur, nT);
+        double *d_w = carve<double>(cur, B);
+        (void)d_inv_tmp;
+        HIPCHECK(hipMemcpyAsync(d_kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(d_tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(d_tapF1, prog.tapF1.data(), nT * 4, hipMemcpyHostToDevice, st));
+        if (full) {
+            HIPCHECK(hipMemcpyAsync(d_kindB, prog.kindB.data(), nT, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_tapB1, prog.tapB1.data(), nT * 4, hipMemcpyHostToDevice, st));
+        }
+        if (!taps.w.empty()) {
+            HIPCHECK(hipMemcpyAsync(d_taps, taps.w.data(), taps.w.size() * 8, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_off, taps.off.data(), taps.off.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_lw, taps.lw.data(), taps.lw.size() * 4, hipMemcpyHostToDevice, st));
+        }
+
+        // --- state ---
+        const size_t psz = (size_t)T * B * NRED * tile.nblk;
+        ctx->psumF.ensure(psz * 8);
+        ctx->redF.ensure((size_t)T * B * NRED * 8);
+        double *d_psF = ctx->psumF.as<double>();
+        double *d_post = nullptr, *d_pp[2] = {nullptr, nullptr};
+        ctx->state.ensure((size_t)2 * B * G * 8);
+        d_pp[0] = ctx->state.as<double>();
+        d_pp[1] = d_pp[0] + (size_t)B * G;
+        if (!evidence_only) {
+            ctx->post.ensure((size_t)B * T * G * 8);
+            d_post = ctx->post.as<double>();
+        }
+
+        StepParams P{};
+        P.n0 = g.n0; P.n1 = g.n1; P.TI = tile.TI; P.TJ = tile.TJ; P.LW0 = tile.LW0; P.LW1 = tile.LW1;
+        P.tiles_i = tile.tiles_i; P.tiles_j = tile.tiles_j; P.nblk = tile.nblk; P.ndim = p->ndim; P.d = d;
+        P.rec_len = rec_len; P.shared[SRC_PREV] = nullptr; P.shared[SRC_PRIOR] = d_prior; P.shared[SRC_RESET] = d_reset;
+        P.shared[SRC_UNIFORM] = d_uniform; P.taps = d_taps; P.tap_off = d_off; P.tap_lw = d_lw;
+        P.m0 = d_m0; P.m1 = d_m1; P.colA = d_colA; P.colB = d_colB; P.chains = (int)B;
+        P.prev_nblk = tile.nblk;
+
+        // --- forward pass (core.py:372-411) ---
+        HIPCHECK(hipEventRecord(ev[0], st));
+        for (int64_t t = 0; t < T; ++t) {
+            StepParams Q = P;
+            if (evidence_only) {
+                Q.src = d_pp[(t + 1) & 1]; Q.src_stride = G;
+                Q.dst = d_pp[t & 1]; Q.dst_stride = G;
+            } else {
+                Q.src = d_post + (t > 0 ? (size_t)(t - 1) * G : 0); Q.src_stride = (long long)T * G;
+                Q.dst = d_post + (size_t)t * G; Q.dst_stride = (long long)T * G;
+            }
+            Q.srckind = d_kindF + t * B; Q.tap0 = d_tapF0 + t * B; Q.tap1 = d_tapF1 + t * B;
+            Q.psum_prev = t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : d_psF; Q.prev_slot = 0;
+            Q.psum_out = d_psF + (size_t)t * B * NRED * tile.nblk;
+            Q.rec = d_rec + t * rec_len;
+            Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
+            launch_step(st, p->obs_model, Q, tile, (int)B, MODE_FWD, forward_only);
+        }
+        HIPCHECK(hipEventRecord(ev[1], st));
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
+                           ctx->redF.as<double>(), tile.nblk);
+        redF.resize((size_t)T * B * NRED);
+        HIPCHECK(hipMemcpyAsync(redF.data(), ctx->redF.p, redF.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        ctx->timing.forward_ms += ms;
+        ctx->timing.forward_launches += T;
+
+        // --- evidence bookkeeping on the host, in the reference's order (core.py:385-404, 417) ---
+        std::vector<double> logE(B, 0.0);
+        std::vector<int64_t> abort_step(B, -1);
+        std::vector<int32_t> abort_phase(B, 0);
+        std::vector<double> local((size_t)B * T, 0.0);
+        for (int64_t b = 0; b < B; ++b) {
+            double le = 0.0;
+            for (int64_t t = 0; t < T; ++t) {
+                const double norm = redF[((size_t)t * B + b) * NRED + 0];
+                if (!(norm > 0.0)) { abort_step[b] = t; abort_phase[b] = 0; le = -INFINITY; break; }
+                le += std::log(norm);
+                local[(size_t)b * T + t] = norm * dV;
+            }
+            if (abort_step[b] < 0) le += std::log(dV);
+            logE[b] = le;
+        }
+
+        std::vector<double> means;
+        if (!evidence_only) means.assign((size_t)B * p->ndim * T, 0.0);
+        if (forward_only) {
+            for (int64_t b = 0; b < B; ++b)
+                for (int64_t t = 0; t < T; ++t) {
+                    const double *r = &redF[((size_t)t * B + b) * NRED];
+                    for (int k = 0; k < p->ndim; ++k) means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
+                }
+        }
+
+        // --- backward pass (core.py:424-470) ---
+        std::vector<double> invN((size_t)B * T, 0.0);
+        if (full) {
+            ctx->psumB.ensure(psz * 8);
+            ctx->redB.ensure((size_t)T * B * NRED * 8);
+            double *d_psB = ctx->psumB.as<double>();
+            HIPCHECK(hipEventRecord(ev[2], st));
+            for (int64_t t = T - 1; t >= 0; --t) {
+                StepParams Q = P;
+                Q.src = d_pp[(t + 1) & 1]; Q.src_stride = G;          // c_{t+1}
+                Q.dst = d_pp[t & 1]; Q.dst_stride = G;                // c_t
+                Q.post = d_post + (size_t)t * G; Q.post_stride = (long long)T * G;
+                Q.srckind = d_kindB + t * B; Q.tap0 = d_tapB0 + t * B; Q.tap1 = d_tapB1 + t * B;
+                Q.psum_prev = t < T - 1 ? d_psB + (size_t)(t + 1) * B * NRED * tile.nblk : d_psB; Q.prev_slot = 2;
+                Q.psum_out = d_psB + (size_t)t * B * NRED * tile.nblk;
+                Q.rec = d_rec + t * rec_len;
+                Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
+                launch_step(st, p->obs_model, Q, tile, (int)B, MODE_BWD, true);
+            }
+            HIPCHECK(hipEventRecord(ev[3], st));
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
+                               ctx->redB.as<double>(), tile.nblk);
+            redB.resize((size_t)T * B * NRED);
+            HIPCHECK(hipMemcpyAsync(redB.data(), ctx->redB.p, redB.size() * 8, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            HIPCHECK(hipEventElapsedTime(&ms, ev[2], ev[3]));
+            ctx->timing.backward_ms += ms;
+            ctx->timing.backward_launches += T;
+            for (int64_t b = 0; b < B; ++b) {
+                if (abort_step[b] >= 0) continue;
+                for (int64_t t = T - 1; t >= 0; --t) {
+                    const double *r = &redB[((size_t)t * B + b) * NRED];
+                    if (!(r[0] > 0.0)) { abort_step[b] = t; abort_phase[b] = 1; logE[b] = -INFINITY; break; }
+                    local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
+                    invN[(size_t)b * T + t] = 1.0 / r[0];
+                    for (int k = 0; k < p->ndim; ++k) means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
+                }
+            }
+        } else if (forward_only) {
+            for (int64_t b = 0; b < B; ++b)
+                for (int64_t t = 0; t < T; ++t) {
+                    const double n0 = redF[((size_t)t * B + b) * NRED];
+                    invN[(size_t)b * T + t] = n0 > 0.0 ? 1.0 / n0 : 0.0;
+                }
+        }
+
+        // --- fold into the average posterior (core.py:1358-1366) ---
+        if (accumulate) {
+            double newref = ctx->acc_logref;
+            std::vector<double> lw(B, -INFINITY);
+            std::vector<char> valid(B, 0);
+            for (int64_t b = 0; b < B; ++b) {
+                // np.isfinite(logEvidence) guard (core.py:1358); a zero hyper-prior contributes log(0) = -inf, i.e. nothing
+                valid[b] = abort_step[b] < 0 && std::isfinite(logE[b]) && std::isfinite(log_w[c0 + b]);
+                if (!valid[b]) continue;
+                lw[b] = logE[b] + log_w[c0 + b];
+                if (lw[b] > newref) newref = lw[b];
+            }
+            if (std::isfinite(newref)) {
+                std::vector<double> w(B, 0.0);
+                int nfold = 0;
+                for (int64_t b = 0; b < B; ++b)
+                    if (valid[b]) { w[b] = std::exp(lw[b] - newref); nfold++; }
+                const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref);
+                HIPCHECK(hipMemcpyAsync(d_w, w.data(), B * 8, hipMemcpyHostToDevice, st));
+                HIPCHECK(hipMemcpyAsync(d_invN, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
+                HIPCHECK(hipEventRecord(ev[4], st));
+                const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+                hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
+                                   (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
+                HIPCHECK(hipEventRecord(ev[5], st));
+                HIPCHECK(hipStreamSynchronize(st));
+                HIPCHECK(hipEventElapsedTime(&ms, ev[4], ev[5]));
+                ctx->timing.accumulate_ms += ms;
+                ctx->timing.accumulate_launches += 1;
+                ctx->acc_logref = newref;
+                ctx->acc_first = false;
+                ctx->acc_folded += nfold;
+            }
+        }
+
+        // --- normalise the kept posterior (core.py:389 / :441, applied lazily) ---
+        if (keep) {
+            HIPCHECK(hipMemcpyAsync(d_invN, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
+            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+            for (int64_t b = 0; b < B; ++b)
+                hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st,
+                                   d_post + (size_t)b * T * G, G, d_invN + b * T);
+            HIPCHECK(hipStreamSynchronize(st));
+            ctx->post_valid = true; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = G;
+        }
+
+        // --- results ---
+        if (res) {
+            for (int64_t b = 0; b < B; ++b) {
+                if (res->log_evidence) res->log_evidence[c0 + b] = logE[b];
+                if (res->abort_step) res->abort_step[c0 + b] = abort_step[b];
+                if (res->abort_phase) res->abort_phase[c0 + b] = abort_phase[b];
+                if (res->local_evidence)
+                    std::memcpy(res->local_evidence + (size_t)(c0 + b) * T, &local[(size_t)b * T], T * 8);
+                if (res->posterior_mean && !evidence_only)
+                    std::memcpy(res->posterior_mean + (size_t)(c0 + b) * p->ndim * T,
+                                &means[(size_t)b * p->ndim * T], (size_t)p->ndim * T * 8);
+            }
+        }
+    }
+    HIPCHECK(hipEventRecord(ev[7], st));
+    HIPCHECK(hipEventSynchronize(ev[7]));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, ev[6], ev[7]));
+    ctx->timing.total_ms = ms;
+    ctx->timing.fwd_kernel_variant = 0;
+    ctx->timing.bwd_kernel_variant = 0;
+}
+
+template <class F> int guarded(blhip_ctx *ctx, F &&f) {
+    if (!ctx) return -1;
+    try {
+        f();
+        return 0;
+    } catch (const Fail &e) {
+        ctx->err = e.msg;
+    } catch (const std::exception &e) {
+        ctx->err = e.what();
+    } catch (...) {
+        ctx->err = "unknown error";
+    }
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blhip_abi_version(void) { return BLHIP_ABI_VERSION; }
+
+int blhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+blhip_ctx *blhip_create(int device) {
+    blhip_ctx *ctx = nullptr;
+    try {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) fail("no HIP device visible");
+        if (device < 0 || device >= n) fail("device %d out of range (%d visible)", device, n);
+        HIPCHECK(hipSetDevice(device));
+        ctx = new blhip_ctx();
+        ctx->device = device;
+        HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        for (auto &e : ctx->ev) HIPCHECK(hipEventCreate(&e));
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, device));
+        ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        return ctx;
+    } catch (const Fail &e) {
+        g_create_error = e.msg;
+    } catch (...) {
+        g_create_error = "unknown error in blhip_create";
+    }
+    delete ctx;
+    return nullptr;
+}
+
+void blhip_destroy(blhip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
+                      &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats})
+        b->release();
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *blhip_last_error(blhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int blhip_device_name(blhip_ctx *ctx, char *buf, int buflen) {
+    if (!ctx || !buf || buflen <= 0) return -1;
+    std::snprintf(buf, (size_t)buflen, "%s", ctx->name.c_str());
+    return 0;
+}
+
+int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
+    if (!ctx || !key) return -1;
+    ctx->opt[key] = value;
+    return 0;
+}
+
+int blhip_synchronize(blhip_ctx *ctx) {
+    return guarded(ctx, [&] {
+        HIPCHECK(hipSetDevice(ctx->device));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int blhip_fit(blhip_ctx *ctx, const blhip_problem *problem, int64_t n_chains, const double *op_values,
+              const double *log_chain_weight, uint32_t flags, blhip_result *result) {
+    return guarded(ctx, [&] { do_fit(ctx, problem, n_chains, op_values, log_chain_weight, flags, result); });
+}
+
+int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out) {
+    if (!ctx || !out) return -1;
+    *out = ctx->timing;
+    return 0;
+}
+
+int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, double *host_out) {
+    return guarded(ctx, [&] {
+        if (!ctx->post_valid) fail("no posterior kept (run blhip_fit with BLHIP_KEEP_POSTERIOR)");
+        if (chain < 0 || chain >= ctx->post_chains || t0 < 0 || t1 > ctx->post_T || t0 > t1 || !host_out)
+            fail("blhip_posterior_read: bad range");
+        HIPCHECK(hipSetDevice(ctx->device));
+        const double *src = ctx->post.as<double>() + ((size_t)chain * ctx->post_T + t0) * ctx->post_G;
+        HIPCHECK(hipMemcpyAsync(host_out, src, (size_t)(t1 - t0) * ctx->post_G * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int blhip_posterior_devptr(blhip_ctx *ctx, void **devptr, int64_t *chain_stride, int64_t *step_stride) {
+    return guarded(ctx, [&] {
+        if (!ctx->post_valid) fail("no posterior kept");
+        if (devptr) *devptr = ctx->post.p;
+        if (chain_stride) *chain_stride = ctx->post_T * ctx->post_G;
+        if (step_stride) *step_stride = ctx->post_G;
+    });
+}
+
+int blhip_posterior_release(blhip_ctx *ctx) {
+    return guarded(ctx, [&] {
+        HIPCHECK(hipSetDevice(ctx->device));
+        ctx->post_valid = false;
+        ctx->post.release();
+    });
+}
+
+int blhip_accum_begin(blhip_ctx *ctx, int64_t T, int64_t G, void *external_devptr) {
+    return guarded(ctx, [&] {
+        if (T < 1 || G < 1) fail("blhip_accum_begin: bad shape");
+        HIPCHECK(hipSetDevice(ctx->device));
+        if (external_devptr) {
+            ctx->acc = reinterpret_cast<double *>(external_devptr);
+        } else {
+            ctx->accum_own.ensure((size_t)T * G * 8);
+            ctx->acc = ctx->accum_own.as<double>();
+        }
+        ctx->acc_T = T; ctx->acc_G = G; ctx->acc_folded = 0;
+        ctx->acc_logref = -std::numeric_limits<double>::infinity();
+        ctx->acc_active = true; ctx->acc_final = false; ctx->acc_first = true;
+    });
+}
+
+int blhip_accum_state(blhip_ctx *ctx, double *log_ref, void **devptr, int64_t *n_folded) {
+    return guarded(ctx, [&] {
+        if (!ctx->acc_active) fail("no active accumulator");
+        if (log_ref) *log_ref = ctx->acc_logref;
+        if (devptr) *devptr = ctx->acc;
+        if (n_folded) *n_folded = ctx->acc_folded;
+    });
+}
+
+int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref) {
+    return guarded(ctx, [&] {
+        if (!ctx->acc_active) fail("no active accumulator");
+        HIPCHECK(hipSetDevice(ctx->device));
+        const long long n = (long long)ctx->acc_T * ctx->acc_G;
+        if (ctx->acc_first) {
+            // nothing folded on this rank: contributes zeros
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, ctx->stream, ctx->acc, n, 0.0);
+            ctx->acc_first = false;
+        } else {
+            if (new_log_ref < ctx->acc_logref) fail("blhip_accum_rescale: new reference below the current one");
+            const double r = std::exp(ctx->acc_logref - new_log_ref);
+            if (r != 1.0)
+                hipLaunchKernelGGL(scale_all_kernel, dim3(2048), dim3(NTHREADS), 0, ctx->stream, ctx->acc, n, r);
+        }
+        ctx->acc_logref = new_log_ref;
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *p, double *posterior_mean) {
+    return guarded(ctx, [&] {
+        if (!ctx->acc_active) fail("no active accumulator");
+        if (!p) fail("problem is NULL");
+        HIPCHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const int64_t T = ctx->acc_T, G = ctx->acc_G;
+        const int n1 = p->ndim == 1 ? (int)p->n[0] : (int)p->n[1];
+        const int n0 = p->ndim == 1 ? 1 : (int)p->n[0];
+        if ((int64_t)n0 * n1 != G) fail("blhip_accum_finalize: grid mismatch");
+        if (ctx->acc_first) fail("blhip_accum_finalize: nothing was accumulated");
+        const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 256);
+        size_t bytes = carve_size((size_t)T * 3 * gx * 8) + carve_size((size_t)T * 3 * 8) + carve_size((size_t)T * 8) +
+                       carve_size(8 * (size_t)std::max(1, n0)) + carve_size(8 * (size_t)n1);
+        ctx->stats.ensure(bytes);
+        char *cur = ctx->stats.as<char>();
+        double *d_part = carve<double>(cur, (size_t)T * 3 * gx);
+        double *d_red = carve<double>(cur, (size_t)T * 3);
+        double *d_inv = carve<double>(cur, (size_t)T);
+        double *d_m0 = carve<double>(cur, std::max(1, n0));
+        double *d_m1 = carve<double>(cur, n1);
+        if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(d_m0, p->marginal[0], 8 * (size_t)n0, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(d_m1, p->ndim == 1 ? p->marginal[0] : p->marginal[1], 8 * (size_t)n1, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(row_stats_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, n1,
+                           p->ndim, d_m0, d_m1, d_part);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * 3)), dim3(NTHREADS), 0, st, d_part, d_red, (int)gx);
+        std::vector<double> red((size_t)T * 3), inv(T);
+        HIPCHECK(hipMemcpyAsync(red.data(), d_red, red.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        for (int64_t t = 0; t < T; ++t) {
+            inv[t] = 1.0 / red[t * 3];                                           // core.py:1379-1382
+            if (posterior_mean)
+                for (int k = 0; k < p->ndim; ++k) posterior_mean[k * T + t] = red[t * 3 + 1 + k] / red[t * 3];   // :1416-1419
+        }
+        HIPCHECK(hipMemcpyAsync(d_inv, inv.data(), T * 8, hipMemcpyHostToDevice, st));
+        const unsigned gs = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(gs, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, d_inv);
+        HIPCHECK(hipStreamSynchronize(st));
+        ctx->acc_final = true;
+    });
+}
+
+int blhip_accum_read(blhip_ctx *ctx, int64_t t0, int64_t t1, double *host_out) {
+    return guarded(ctx, [&] {
+        if (!ctx->acc_active) fail("no active accumulator");
+        if (t0 < 0 || t1 > ctx->acc_T || t0 > t1 || !host_out) fail("blhip_accum_read: bad range");
+        HIPCHECK(hipSetDevice(ctx->device));
+        HIPCHECK(hipMemcpyAsync(host_out, ctx->acc + (size_t)t0 * ctx->acc_G, (size_t)(t1 - t0) * ctx->acc_G * 8,
+                                hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int blhip_accum_end(blhip_ctx *ctx) {
+    return guarded(ctx, [&] {
+        ctx->acc_active = false;
+        ctx->acc = nullptr;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+// Device code of libblhip: fused forward / backward step kernels of the grid-based forward-backward recursion
+// (reference: bayesloop/core.py:372-411 forward, :434-470 backward) for gfx950 / MI355X.  fp64 throughout.
+//
+// Data layout in HBM: every distribution is a dense C-order array (n0, n1) of doubles, n1 (the LAST observation-model
+// parameter) fastest; 1-D grids are (1, n).  A batch of chains is an outer dimension with an explicit stride.
+//
+// Formulation (see DESIGN.md "lazy normalisation"): the state written by step t is the UNNORMALISED product
+//     a_t = T(a_{t-1}) * (1 / sum a_{t-1}) * L_t
+// so one step reads the previous state once (plus stencil halo, served by L2) and writes the new state once
+// (16 B / cell); the normaliser of step t is produced by step t as per-block partial sums and consumed lazily by
+// step t+1.  The transition is linear, so filtering before normalising equals the reference's order to rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blk {
+
+constexpr int NTHREADS = 256;
+constexpr int NRED = 5;          // partial-sum slots per (step, chain): 0 N  1 S(p/L)  2 C  3 M0  4 M1
+
+enum Mode { MODE_FWD = 0, MODE_BWD = 1, MODE_FILTER = 2 };
+enum SrcKind { SRC_PREV = 0, SRC_PRIOR = 1, SRC_RESET = 2, SRC_UNIFORM = 3 };
+
+struct StepParams {
+    // geometry (internal axes: 0 = rows (slow), 1 = cols (fast))
+    int n0, n1;
+    int TI, TJ;                  // output tile
+    int LW0, LW1;                // launch-wide maximal filter radii (LDS geometry)
+    int tiles_i, tiles_j, nblk;
+    int ndim;                    // 1 or 2 observation-model parameters
+    int d;                       // data dimensions per step
+    int rec_len;                 // doubles per step record
+    // state
+    const double *src;  long long src_stride;     // SRC_PREV source, per-chain stride (doubles)
+    double       *dst;  long long dst_stride;     // new state (FWD: a_t ; BWD: c_i ; FILTER: filtered)
+    double       *post; long long post_stride;    // BWD: stored alpha_i (in) -> posterior_i (out), per-chain stride
+    const double *shared[4];                      // [SRC_PRIOR], [SRC_RESET], [SRC_UNIFORM] shared sources (G)
+    // per-chain metadata of this step (pre-offset to the step)
+    const unsigned char *srckind;                 // [B]
+    const int *tap0, *tap1;                       // [B] tap-set ids per internal axis, -1 = identity
+    // tap table
+    const double *taps; const int *tap_off; const int *tap_lw;
+    // lazy normalisation
+    const double *psum_prev; int prev_slot; int prev_nblk;   // partials of the producing step [B][NRED][prev_nblk]
+    double *psum_out;                                         // [B][NRED][nblk]
+    // likelihood
+    const double *m0, *m1;       // marginal grids along internal axes (m0 unused for 1-D)
+    const double *colA, *colB;   // per-column tables (model specific)
+    const double *rec;           // step record (rec_len doubles)
+    const double *lik;           // OM_TABLE: likelihood of this step (G)
+    int chains;                  // B
+};
+
+__device__ __forceinline__ int reflect(int i, int n) {
+    // half-sample symmetric extension with period 2n (SciPy NI_EXTEND_REFLECT), any offset
+    if ((unsigned)i < (unsigned)n) return i;
+    const int p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - 1 - i : i;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Sum over the block; result valid in every thread.  `red` = NTHREADS/64 doubles of LDS scratch (+1).
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < NTHREADS / 64; ++k) s += red[k];
+    return s;
+}
+
+// Deterministic sum of n partials (fixed order for a fixed block size).
+__device__ __forceinline__ double sum_partials(const double *p, int n, double *red) {
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += NTHREADS) v += p[k];
+    return block_sum(v, red);
+}
+
+enum { OM_POISSON = 1, OM_GAUSSIAN = 2, OM_GAUSSIAN_MEAN = 3, OM_TABLE = 100 };
+
+// Likelihood of the step's data segment at grid cell (i, j).  NaN data => factor 1 (observationModels.py:53-54).
+template <int OM>
+__device__ __forceinline__ double likelihood(const StepParams &P, int i, int j, double cA, double cB, double g1) {
+    if constexpr (OM == OM_GAUSSIAN) {
+        // exp(-(x-mu)^2 / (2 s^2) - 0.5 log(2 pi s^2))  observationModels.py:566-567; cA = 1/(2 s^2), cB = 0.5 log(2 pi s^2)
+        const double mu = P.m0[i];
+        double L = 1.0;
+        for (int k = 0; k < P.d; ++k) {
+            const double x = P.rec[k];
+            if (x == x) {
+                const double q = x - mu;
+                L *= exp(-(q * q) * cA - cB);
+            }
+        }
+        return L;
+    } else if constexpr (OM == OM_GAUSSIAN_MEAN) {
+        // observationModels.py:705-706; rec = [x, 1/(2 s^2), 0.5 log(2 pi s^2)]
+        const double x = P.rec[0];
+        if (x != x) return 1.0;
+        const double q = x - g1;
+        return exp(-(q * q) * P.rec[1] - P.rec[2]);
+    } else if constexpr (OM == OM_POISSON) {
+        // lambda^k exp(-lambda) / k!   observationModels.py:502; cA = exp(-lambda); rec = [k, k!] per dimension
+        double L = 1.0;
+        for (int k = 0; k < P.d; ++k) {
+            const double cnt = P.rec[2 * k];
+            if (cnt == cnt) L *= pow(g1, cnt) * cA / P.rec[2 * k + 1];
+        }
+        return L;
+    } else {
+        return P.lik[(long long)i * P.n1 + j];
+    }
+}
+
+// One fused step for a batch of chains.  grid = (nblk, B), block = 256, dynamic LDS:
+//   in_tile [(TI + 2 LW0)][pitch]  +  v_tile [TI][pitch]  + scratch,  pitch = TJ + 2 LW1
+template <int OM, int MODE, bool MEANS>
+__global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.y;
+    const int blk = blockIdx.x;
+    const int ti = blk / P.tiles_j, tj = blk - ti * P.tiles_j;
+    const int i0 = ti * P.TI, j0 = tj * P.TJ;
+    const int th = min(P.TI, P.n0 - i0), tw = min(P.TJ, P.n1 - j0);
+    const int pitch = P.TJ + 2 * P.LW1;
+    double *in_tile = lds;
+    double *v_tile = lds + (size_t)(P.TI + 2 * P.LW0) * pitch;
+    double *red = v_tile + (size_t)P.TI * pitch;
+
+    const int kind = P.srckind[b];
+    const int t0 = P.tap0[b], t1 = P.tap1[b];
+    const int lw0 = t0 >= 0 ? P.tap_lw[t0] : 0;
+    const int lw1 = t1 >= 0 ? P.tap_lw[t1] : 0;
+    const double *w0 = t0 >= 0 ? P.taps + P.tap_off[t0] : nullptr;   // w[0] = centre, w[k] = offset +-k
+    const double *w1 = t1 >= 0 ? P.taps + P.tap_off[t1] : nullptr;
+    const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
+
+    // thread mapping: XW columns x YN row groups (a single-row tile, i.e. a 1-D grid, uses all 256 threads on columns)
+    const int XW = P.TI == 1 ? NTHREADS : 64, YN = NTHREADS / XW;
+    const int x = threadIdx.x & (XW - 1), y = threadIdx.x / XW;
+
+    // ---- phase 1: source tile + halo -> LDS (reflect boundary resolved here) -----------------------------------
+    for (int r = P.LW0 - lw0 + y; r < P.LW0 + th + lw0; r += YN) {
+        const int gi = reflect(i0 - P.LW0 + r, P.n0);
+        const double *row = src + (long long)gi * P.n1;
+        double *dstrow = in_tile + (size_t)r * pitch;
+        for (int c = P.LW1 - lw1 + x; c < P.LW1 + tw + lw1; c += XW) {
+            const int gj = reflect(j0 - P.LW1 + c, P.n1);
+            dstrow[c] = row[gj];
+        }
+    }
+
+    // lazy normaliser of the producing step (every block sums the same partials in the same order)
+    double scale = 1.0;
+    if (MODE != MODE_FILTER && kind == SRC_PREV) {
+        const double s = sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
+        scale = 1.0 / s;
+    }
+    __syncthreads();
+
+    // ---- phase 2: filter along axis 0 (rows), SciPy's symmetric correlate1d order -------------------------------
+    const double *hsrc = in_tile + (size_t)P.LW0 * pitch;      // rows [0, th) of the un-filtered tile
+    if (lw0 > 0) {
+        for (int r = y; r < th; r += YN) {
+            const double *cen = in_tile + (size_t)(r + P.LW0) * pitch;
+            for (int c = P.LW1 - lw1 + x; c < P.LW1 + tw + lw1; c += XW) {
+                double acc = cen[c] * w0[0];
+                for (int k = lw0; k >= 1; --k)
+                    acc += (cen[c - (long long)k * pitch] + cen[c + (long long)k * pitch]) * w0[k];
+                v_tile[(size_t)r * pitch + c] = acc;
+            }
+        }
+        hsrc = v_tile;
+        __syncthreads();
+    }
+
+    // ---- phase 3: filter along axis 1 (cols) + epilogue ---------------------------------------------------------
+    double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
+    for (int c = x; c < tw; c += XW) {
+        const int gj = j0 + c;
+        double cA = 0.0, cB = 0.0, g1 = 0.0;
+        if (MODE != MODE_FILTER) {
+            if (OM == OM_GAUSSIAN) { cA = P.colA[gj]; cB = P.colB[gj]; }
+            if (OM == OM_POISSON) cA = P.colA[gj];
+            g1 = P.m1[gj];
+        }
+        for (int r = y; r < th; r += YN) {
+            const double *cen = hsrc + (size_t)r * pitch + P.LW1 + c;
+            double o;
+            if (lw1 > 0) {
+                o = cen[0] * w1[0];
+                for (int k = lw1; k >= 1; --k) o += (cen[-k] + cen[k]) * w1[k];
+            } else {
+                o = cen[0];
+            }
+            const int gi = i0 + r;
+            const long long cell = (long long)gi * P.n1 + gj;
+            if (MODE == MODE_FILTER) {
+                P.dst[(long long)b * P.dst_stride + cell] = o;
+            } else {
+                const double L = likelihood<OM>(P, gi, gj, cA, cB, g1);
+                if (MODE == MODE_FWD) {
+                    const double a = o * scale * L;
+                    P.dst[(long long)b * P.dst_stride + cell] = a;
+                    sN += a;
+                    if (MEANS) {
+                        if (P.ndim == 2) { sM0 += a * P.m0[gi]; sM1 += a * g1; } else { sM0 += a * g1; }
+                    }
+                } else {
+                    const double beta = o * scale;
+                    double *pp = P.post + (long long)b * P.post_stride + cell;
+                    const double p = (*pp) * beta;
+                    *pp = p;
+                    const double cn = beta * L;
+                    P.dst[(long long)b * P.dst_stride + cell] = cn;
+                    sN += p;
+                    sS += p / L;               // 0/0 -> NaN exactly as numpy does (core.py:463)
+                    sC += cn;
+                    if (P.ndim == 2) { sM0 += p * P.m0[gi]; sM1 += p * g1; } else { sM0 += p * g1; }
+                }
+            }
+        }
+    }
+    if (MODE == MODE_FILTER) return;
+
+    double *out = P.psum_out + (long long)b * NRED * P.nblk + blk;
+    double r0 = block_sum(sN, red);
+    if (threadIdx.x == 0) out[0] = r0;
+    if (MODE == MODE_BWD) {
+        double r1 = block_sum(sS, red);
+        double r2 = block_sum(sC, red);
+        if (threadIdx.x == 0) { out[1 * P.nblk] = r1; out[2 * P.nblk] = r2; }
+    }
+    if (MODE == MODE_BWD || MEANS) {
+        double r3 = block_sum(sM0, red);
+        double r4 = block_sum(sM1, red);
+        if (threadIdx.x == 0) { out[3 * P.nblk] = r3; out[4 * P.nblk] = r4; }
+    }
+}
+
+// out[k] = sum of nblk partials, k over (step, chain, slot); same summation order as sum_partials in the step kernel.
+__global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double *psum, double *out, int nblk) {
+    __shared__ double red[NTHREADS / 64 + 1];
+    const long long k = blockIdx.x;
+    const double s = sum_partials(psum + k * nblk, nblk, red);
+    if (threadIdx.x == 0) out[k] = s;
+}
+
+// rows[t][cell] *= inv[t]   (normalisation of stored posteriors, core.py:389 / :441 applied lazily)
+__global__ __launch_bounds__(NTHREADS) void scale_rows_kernel(double *rows, long long G, const double *inv) {
+    const long long t = blockIdx.y;
+    const double s = inv[t];
+    double *row = rows + t * G;
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS)
+        row[c] *= s;
+}
+
+// A[t][cell] = A[t][cell] * r + sum_b w[b] * max(post[b][t][cell] * invN[b][t], 1e-300)   (core.py:1362-1366, linear space)
+__global__ __launch_bounds__(NTHREADS) void accumulate_kernel(double *A, const double *post, long long chain_stride,
+                                                              int B, long long G, int T, const double *w,
+                                                              const double *invN, double r, int first) {
+    const long long t = blockIdx.y;
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
+        double acc = first ? 0.0 : A[t * G + c] * r;
+        for (int b = 0; b < B; ++b) {
+            const double wb = w[b];
+            if (wb > 0.0) {
+                double p = post[(long long)b * chain_stride + t * G + c] * invN[(long long)b * T + t];
+                p = p < 1e-300 ? 1e-300 : p;
+                acc += wb * p;
+            }
+        }
+        A[t * G + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void scale_all_kernel(double *A, long long n, double r) {
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < n; c += (long long)gridDim.x * NTHREADS)
+        A[c] *= r;
+}
+
+// per-step statistics of the accumulator: out[t][0..2] = sum A, sum A*g0, sum A*g1 (partials per block -> second pass)
+__global__ __launch_bounds__(NTHREADS) void row_stats_kernel(const double *A, long long G, int n1, int ndim,
+                                                             const double *m0, const double *m1, double *partial) {
+    __shared__ double red[NTHREADS / 64 + 1];
+    const long long t = blockIdx.y;
+    double s = 0.0, a0 = 0.0, a1 = 0.0;
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
+        const double v = A[t * G + c];
+        s += v;
+        if (ndim == 2) { a0 += v * m0[c / n1]; a1 += v * m1[c % n1]; } else { a0 += v * m1[c]; }
+    }
+    s = block_sum(s, red); a0 = block_sum(a0, red); a1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        double *o = partial + (t * 3) * gridDim.x + blockIdx.x;
+        o[0] = s; o[gridDim.x] = a0; o[2 * gridDim.x] = a1;
+    }
+}
+
+__global__ void fill_kernel(double *p, long long n, double v) {
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (long long)gridDim.x * blockDim.x)
+        p[c] = v;
+}
+
+}  // namespace blk

@@ -1,0 +1,250 @@
+"""
+The compute engine behind ``Study.fit`` / ``HyperStudy.fit``: a problem description in plain arrays and the
+MI355X engine that runs it through the C-ABI of libblhip.so.
+
+``FitProblem`` is the drop-in boundary seen from Python: everything ``Study.fit`` (reference bayesloop/core.py:330-486)
+reads from the study object, flattened into arrays.  ``HipEngine`` is the only engine the product ships; it raises
+:class:`BackendError` when the HIP library or the GPU is missing (no CPU fallback).  Tests may install another object
+with the same methods through :func:`set_engine` to exercise the host-side logic on a machine without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _abi
+from .exceptions import BackendError
+
+
+@dataclass
+class FitProblem:
+    obs_model: int                      # _abi.OM_*
+    marginal: List[np.ndarray]          # marginal grid per parameter (core.py:156)
+    lattice: List[float]                # lattice constants (core.py:161-166)
+    data: np.ndarray                    # formatted data (T, seg[, d]) (core.py:349)
+    timestamps: np.ndarray              # formatted timestamps (T,) (core.py:350)
+    prior: np.ndarray                   # alpha_0 on the grid (core.py:363)
+    ops: List[Tuple[int, int]]          # transition program [(kind, axis)], list order
+    reset_prior: Optional[np.ndarray] = None    # what a ChangePoint resets to (transitionModels.py:300-312)
+    lik: Optional[np.ndarray] = None    # (T, G) host-evaluated likelihood for OM_TABLE
+    seg_len: int = 1
+
+    @property
+    def grid_size(self):
+        return [len(m) for m in self.marginal]
+
+    @property
+    def T(self):
+        return len(self.data)
+
+    @property
+    def G(self):
+        return int(np.prod(self.grid_size))
+
+
+@dataclass
+class FitResult:
+    log_evidence: np.ndarray            # (n_chains,)
+    local_evidence: np.ndarray          # (n_chains, T)
+    posterior_mean: Optional[np.ndarray]    # (n_chains, ndim, T) or None (evidenceOnly)
+    abort_step: np.ndarray              # (n_chains,) -1 or step index
+    abort_phase: np.ndarray             # (n_chains,) 0 forward / 1 backward
+    timing: dict = field(default_factory=dict)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class HipEngine:
+    """One libblhip context on one GPU."""
+
+    name = 'hip'
+
+    def __init__(self, device: int = 0):
+        self.lib = _abi.load()
+        if self.lib.blhip_device_count() <= 0:
+            raise BackendError('no HIP device visible: bayesloop_amd needs an AMD MI355X (gfx950); there is no CPU fallback')
+        self.device = device
+        self.ctx = self.lib.blhip_create(device)
+        if not self.ctx:
+            raise BackendError('blhip_create(%d) failed: %s' % (device, self.lib.blhip_last_error(None).decode()))
+        self._posterior_owner = None
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if getattr(self, 'ctx', None):
+                self.lib.blhip_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise BackendError(self.lib.blhip_last_error(self.ctx).decode())
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.blhip_device_name(self.ctx, buf, 256))
+        return buf.value.decode()
+
+    def set_option(self, key, value):
+        self._check(self.lib.blhip_set_option(self.ctx, key.encode(), float(value)))
+
+    def _problem(self, p: FitProblem):
+        """-> (ctypes Problem, list of arrays that must stay alive)"""
+        ndim = len(p.marginal)
+        if ndim not in (1, 2):
+            raise BackendError('the MI355X engine supports 1 or 2 observation-model parameters (got %d)' % ndim)
+        keep = []
+        cp = _abi.Problem()
+        cp.ndim = ndim
+        cp.obs_model = p.obs_model
+        for k in range(ndim):
+            m = _f64(p.marginal[k])
+            keep.append(m)
+            cp.n[k] = len(m)
+            cp.marginal[k] = _abi.dptr(m)
+            cp.lattice[k] = float(p.lattice[k])
+        data = _f64(p.data)
+        T = data.shape[0]
+        if data.ndim == 1:
+            data = data.reshape(T, 1, 1)
+        elif data.ndim == 2:
+            data = data.reshape(T, data.shape[1], 1)
+        elif data.ndim != 3:
+            raise BackendError('formatted data must have 1 to 3 dimensions')
+        data = np.ascontiguousarray(data)
+        ts = _f64(p.timestamps)
+        prior = _f64(p.prior).ravel()
+        G = int(np.prod([len(m) for m in p.marginal]))
+        if prior.size != G or ts.size != T:
+            raise BackendError('prior / timestamps do not match grid / data')
+        keep += [data, ts, prior]
+        cp.T = T
+        cp.seg_len = data.shape[1]
+        cp.data_dim = data.shape[2]
+        cp.data = _abi.dptr(data)
+        cp.timestamps = _abi.dptr(ts)
+        cp.prior = _abi.dptr(prior)
+        if p.reset_prior is not None:
+            rp = _f64(p.reset_prior).ravel()
+            keep.append(rp)
+            cp.reset_prior = _abi.dptr(rp)
+        if p.lik is not None:
+            lik = _f64(p.lik).reshape(T, G)
+            keep.append(lik)
+            cp.lik = _abi.dptr(lik)
+        ops = (_abi.Op * max(1, len(p.ops)))()
+        for k, (kind, axis) in enumerate(p.ops):
+            ops[k].kind = kind
+            ops[k].axis = axis
+        keep.append(ops)
+        cp.n_ops = len(p.ops)
+        cp.ops = ops
+        return cp, keep
+
+    def fit(self, problem: FitProblem, op_values, forward_only=False, evidence_only=False, keep_posterior=False,
+            accumulate=False, log_chain_weight=None, owner=None) -> FitResult:
+        """n_chains = len(op_values) independent passes (Study.fit per hyper-grid point)."""
+        if self._posterior_owner is not None and self._posterior_owner is not owner:
+            prev, self._posterior_owner = self._posterior_owner, None
+            prev._materialize_posterior()
+        cp, keep = self._problem(problem)
+        ov = _f64(op_values).reshape(-1, max(1, len(problem.ops))) if len(problem.ops) else np.zeros((len(op_values), 1))
+        n = ov.shape[0] if len(problem.ops) else len(op_values)
+        T, ndim = problem.T, len(problem.marginal)
+        logE = np.zeros(n)
+        local = np.zeros((n, T))
+        means = None if evidence_only else np.zeros((n, ndim, T))
+        astep = np.full(n, -1, dtype=np.int64)
+        aphase = np.zeros(n, dtype=np.int32)
+        res = _abi.Result()
+        res.log_evidence = _abi.dptr(logE)
+        res.local_evidence = _abi.dptr(local)
+        res.posterior_mean = _abi.dptr(means)
+        res.abort_step = astep.ctypes.data_as(C.POINTER(C.c_int64))
+        res.abort_phase = aphase.ctypes.data_as(C.POINTER(C.c_int32))
+        flags = (_abi.FORWARD_ONLY if forward_only else 0) | (_abi.EVIDENCE_ONLY if evidence_only else 0) | \
+                (_abi.KEEP_POSTERIOR if keep_posterior else 0) | (_abi.ACCUMULATE if accumulate else 0)
+        lw = None if log_chain_weight is None else _f64(log_chain_weight)
+        self._check(self.lib.blhip_fit(self.ctx, C.byref(cp), n, _abi.dptr(ov), _abi.dptr(lw), flags, C.byref(res)))
+        del keep
+        if keep_posterior and not evidence_only:
+            self._posterior_owner = owner
+        return FitResult(logE, local, means, astep, aphase, self.last_timing())
+
+    def last_timing(self):
+        t = _abi.Timing()
+        self._check(self.lib.blhip_last_timing(self.ctx, C.byref(t)))
+        return t.as_dict()
+
+    def posterior(self, chain, T, grid_size):
+        """Normalised posterior sequence of one chain of the last fit(keep_posterior=True) as (T, *grid_size)."""
+        out = np.empty([T] + list(grid_size))
+        self._check(self.lib.blhip_posterior_read(self.ctx, chain, 0, T, _abi.dptr(out)))
+        return out
+
+    def release_posterior(self, owner=None):
+        if owner is None or self._posterior_owner is owner:
+            self._posterior_owner = None
+
+    # ---- average posterior of a hyper-study ----------------------------------------------------------------------
+    def accum_begin(self, T, G, external=None):
+        """external: optional torch CUDA tensor of T*G float64 that backs the accumulator (for RCCL)."""
+        self._accum_external = external
+        ptr = None if external is None else C.c_void_p(external.data_ptr())
+        self._check(self.lib.blhip_accum_begin(self.ctx, T, G, ptr))
+
+    def accum_log_ref(self):
+        ref = C.c_double()
+        n = C.c_int64()
+        self._check(self.lib.blhip_accum_state(self.ctx, C.byref(ref), None, C.byref(n)))
+        return ref.value, n.value
+
+    def accum_rescale(self, new_log_ref):
+        self._check(self.lib.blhip_accum_rescale(self.ctx, float(new_log_ref)))
+
+    def accum_finalize(self, problem: FitProblem):
+        cp, keep = self._problem(problem)
+        ndim = len(problem.marginal)
+        means = np.zeros((ndim, problem.T))
+        self._check(self.lib.blhip_accum_finalize(self.ctx, C.byref(cp), _abi.dptr(means)))
+        return means
+
+    def accum_read(self, T, grid_size):
+        out = np.empty([T] + list(grid_size))
+        self._check(self.lib.blhip_accum_read(self.ctx, 0, T, _abi.dptr(out)))
+        return out
+
+    def accum_end(self):
+        self._check(self.lib.blhip_accum_end(self.ctx))
+        self._accum_external = None
+
+    def synchronize(self):
+        self._check(self.lib.blhip_synchronize(self.ctx))
+
+
+_engine = None
+
+
+def get_engine():
+    """The process-wide engine (created on first use on the device chosen by ``BLHIP_DEVICE`` / ``LOCAL_RANK``)."""
+    global _engine
+    if _engine is None:
+        import os
+        dev = int(os.environ.get('BLHIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        _engine = HipEngine(dev)
+    return _engine
+
+
+def set_engine(engine):
+    """Install an engine object (tests use this to run host-side logic without a GPU).  Returns the previous one."""
+    global _engine
+    prev, _engine = _engine, engine
+    return prev

@@ -1,0 +1,272 @@
+"""
+Observation models (likelihood functions) -- the ``bl.om`` namespace.
+
+Same constructor arguments and attributes as the reference (bayesloop/observationModels.py), so user code reads the
+same.  What differs is who evaluates the likelihood on the grid during ``fit()``:
+
+* ``Poisson``, ``Gaussian``, ``GaussianMean`` are evaluated INSIDE the fused HIP step kernels from the data point and
+  per-axis tables (``device_model`` is their C-ABI code; reference pdfs at observationModels.py:502, 566-567, 705-706).
+* every other model -- the remaining closed-form ones below and any user subclass with a ``pdf(grid, dataSegment)``
+  method (the reference's duck-typed plug-in interface, observationModels.py:35-56) -- is evaluated once on the host
+  with the model's own ``pdf`` and uploaded as a (T, G) likelihood table; the recursion itself still runs on the GPU.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _abi
+from .exceptions import ConfigurationError
+from .helper import cint, oint
+
+try:
+    from inspect import getfullargspec as _argspec
+except ImportError:  # pragma: no cover
+    from inspect import getargspec as _argspec
+
+
+class ObservationModel:
+    """Base class: missing data and multi-dimensional data handling (reference observationModels.py:35-56)."""
+
+    device_model = _abi.OM_TABLE     # subclasses evaluated in-kernel override this
+    segmentLength = 1
+    multiplyLikelihoods = True
+    name = 'observation model'
+
+    def __str__(self):
+        return self.name
+
+    def processedPdf(self, grid, dataSegment):
+        dataSegment = np.asarray(dataSegment)
+        if dataSegment.ndim == 2 and self.multiplyLikelihoods:
+            # one likelihood per data dimension, multiplied
+            factors = [self.processedPdf(grid, column) for column in dataSegment.T]
+            return np.prod(np.array(factors), axis=0)
+        if np.isnan(dataSegment).any():
+            return np.ones_like(grid[0])       # a missing observation leaves the distribution untouched
+        return self.pdf(grid, dataSegment)
+
+    def _init_params(self, names, values, prior, jeffreys=None):
+        self.parameterNames = list(names)
+        self.parameterValues = list(values)
+        if isinstance(prior, str) and prior == 'Jeffreys':
+            self.prior = jeffreys
+        else:
+            self.prior = prior
+
+
+class Poisson(ObservationModel):
+    """Poisson counts with rate ``name`` (reference observationModels.py:467-526)."""
+    device_model = _abi.OM_POISSON
+
+    def __init__(self, name='lambda', value=None, prior='Jeffreys'):
+        self.name = 'Poisson'
+        self.segmentLength = 1
+        self.multiplyLikelihoods = True
+        self._init_params([name], [value], prior, self.jeffreys)
+
+    def pdf(self, grid, dataSegment):
+        k = dataSegment[0]
+        return (grid[0] ** k) * np.exp(-grid[0]) / math.factorial(int(k))
+
+    def estimateParameterValues(self, name, rawData):
+        if name != self.parameterNames[0]:
+            raise ConfigurationError('Poisson model does not contain a parameter "{}".'.format(name))
+        return oint(0, 1.25 * np.nanmax(np.ravel(rawData)), 1000)
+
+    def jeffreys(self, x):
+        return np.sqrt(1. / x)
+
+
+class Gaussian(ObservationModel):
+    """Independent Gaussian observations with parameters mean, std (reference observationModels.py:529-595)."""
+    device_model = _abi.OM_GAUSSIAN
+
+    def __init__(self, name1='mean', value1=None, name2='std', value2=None, prior='Jeffreys'):
+        self.name = 'Gaussian observations'
+        self.segmentLength = 1
+        self.multiplyLikelihoods = True
+        self._init_params([name1, name2], [value1, value2], prior, self.jeffreys)
+
+    def pdf(self, grid, dataSegment):
+        x = dataSegment[0]
+        return np.exp(-((x - grid[0]) ** 2.) / (2. * grid[1] ** 2.) - .5 * np.log(2. * np.pi * grid[1] ** 2.))
+
+    def estimateParameterValues(self, name, rawData):
+        mean = np.nanmean(np.ravel(rawData))
+        std = np.nanstd(np.ravel(rawData))
+        if name == self.parameterNames[0]:
+            return cint(mean - 2 * std, mean + 2 * std, 200)
+        if name == self.parameterNames[1]:
+            return oint(0, 2 * std, 200)
+        raise ConfigurationError('Gaussian model does not contain a parameter "{}".'.format(name))
+
+    def jeffreys(self, mu, sigma):
+        return 1. / sigma ** 2.
+
+
+class GaussianMean(ObservationModel):
+    """Observed mean values with given error: data rows are (value, std) (reference observationModels.py:666-728)."""
+    device_model = _abi.OM_GAUSSIAN_MEAN
+
+    def __init__(self, name='mean', value=None, prior=None):
+        self.name = 'Gaussian mean model'
+        self.segmentLength = 1
+        self.multiplyLikelihoods = False
+        self._init_params([name], [value], prior)
+
+    def pdf(self, grid, dataSegment):
+        x, s = dataSegment[0, 0], dataSegment[0, 1]
+        return np.exp(-((x - grid[0]) ** 2.) / (2. * s ** 2.) - .5 * np.log(2. * np.pi * s ** 2.))
+
+    def estimateParameterValues(self, name, rawData):
+        if name != self.parameterNames[0]:
+            raise ConfigurationError('Gaussian mean model does not contain a parameter "{}".'.format(name))
+        obs = np.array([d[0] for d in rawData])
+        lo, hi = np.nanmin(obs), np.nanmax(obs)
+        return oint(lo - (hi - lo), hi + (hi - lo), 1000)
+
+
+# ---- closed-form models evaluated through the likelihood-table path ----------------------------------------------
+
+
+class Bernoulli(ObservationModel):
+    """Bernoulli trials with success probability p (reference observationModels.py:394-464)."""
+
+    def __init__(self, name='p', value=None, prior='Jeffreys'):
+        self.name = 'Bernoulli'
+        self.segmentLength = 1
+        self.multiplyLikelihoods = True
+        self._init_params([name], [value], prior, self.jeffreys)
+
+    def pdf(self, grid, dataSegment):
+        p = np.array(grid[0], dtype=float)
+        p[(p > 1.) | (p < 0.)] = 0.
+        return p if dataSegment[0] else 1. - p
+
+    def estimateParameterValues(self, name, rawData):
+        if name != self.parameterNames[0]:
+            raise ConfigurationError('Bernoulli model does not contain a parameter "{}".'.format(name))
+        return cint(0, 1, 1000)
+
+    def jeffreys(self, x):
+        return 1. / np.sqrt(x * (1. - x))
+
+
+class Laplace(ObservationModel):
+    """Laplace observations with mean and scale (reference observationModels.py:598-663)."""
+
+    def __init__(self, name1='mean', value1=None, name2='scale', value2=None, prior='Jeffreys'):
+        self.name = 'Laplace observations'
+        self.segmentLength = 1
+        self.multiplyLikelihoods = True
+        self._init_params([name1, name2], [value1, value2], prior, self.jeffreys)
+
+    def pdf(self, grid, dataSegment):
+        return np.exp(-np.abs(dataSegment[0] - grid[0]) / grid[1]) / (2. * grid[1])
+
+    def estimateParameterValues(self, name, rawData):
+        mean = np.nanmean(np.ravel(rawData))
+        std = np.nanstd(np.ravel(rawData))
+        if name == self.parameterNames[0]:
+            return cint(mean - 2 * std, mean + 2 * std, 200)
+        if name == self.parameterNames[1]:
+            return oint(0, np.sqrt(2) * std, 200)
+        raise ConfigurationError('Laplace model does not contain a parameter "{}".'.format(name))
+
+    def jeffreys(self, mu, scale):
+        return 1. / scale ** 2.
+
+
+class WhiteNoise(ObservationModel):
+    """Zero-mean Gaussian noise with amplitude std (reference observationModels.py:731-792)."""
+
+    def __init__(self, name='std', value=None, prior='Jeffreys'):
+        self.name = 'White noise process (Zero-mean Gaussian)'
+        self.segmentLength = 1
+        self.multiplyLikelihoods = True
+        self._init_params([name], [value], prior, self.jeffreys)
+
+    def pdf(self, grid, dataSegment):
+        return np.exp(-(dataSegment[0] ** 2.) / (2. * grid[0] ** 2.) - .5 * np.log(2. * np.pi * grid[0] ** 2.))
+
+    def estimateParameterValues(self, name, rawData):
+        if name != self.parameterNames[0]:
+            raise ConfigurationError('White noise model does not contain a parameter "{}".'.format(name))
+        return oint(0, 2 * np.nanstd(np.ravel(rawData)), 1000)
+
+    def jeffreys(self, sigma):
+        return 1. / sigma
+
+
+class AR1(ObservationModel):
+    """Auto-regressive process of first order, segment length 2 (reference observationModels.py:795-852)."""
+
+    def __init__(self, name1='correlation coefficient', value1=None, name2='noise amplitude', value2=None, prior=None):
+        self.name = 'Autoregressive process of first order (AR1)'
+        self.segmentLength = 2
+        self.multiplyLikelihoods = True
+        self._init_params([name1, name2], [value1, value2], prior)
+
+    def pdf(self, grid, dataSegment):
+        resid = dataSegment[1] - grid[0] * dataSegment[0]
+        return np.exp(-(resid ** 2.) / (2. * grid[1] ** 2.) - .5 * np.log(2. * np.pi * grid[1] ** 2.))
+
+    def estimateParameterValues(self, name, rawData):
+        if name == self.parameterNames[0]:
+            return oint(-1, 1, 200)
+        if name == self.parameterNames[1]:
+            return oint(0, 2 * np.nanstd(np.ravel(rawData)), 200)
+        raise ConfigurationError('AR1 model does not contain a parameter "{}".'.format(name))
+
+
+class ScaledAR1(ObservationModel):
+    """AR1 parametrised by the standard deviation of the observations (reference observationModels.py:855-917)."""
+
+    def __init__(self, name1='correlation coefficient', value1=None, name2='standard deviation', value2=None,
+                 prior=None):
+        self.name = 'Scaled autoregressive process of first order (AR1)'
+        self.segmentLength = 2
+        self.multiplyLikelihoods = True
+        self._init_params([name1, name2], [value1, value2], prior)
+
+    def pdf(self, grid, dataSegment):
+        r, s = grid[0], grid[1]
+        scaled = s * np.sqrt(1 - r ** 2.)
+        resid = dataSegment[1] - r * dataSegment[0]
+        return np.exp(-(resid ** 2.) / (2. * scaled ** 2.) - .5 * np.log(2. * np.pi * scaled ** 2.))
+
+    def estimateParameterValues(self, name, rawData):
+        if name == self.parameterNames[0]:
+            return oint(-1, 1, 200)
+        if name == self.parameterNames[1]:
+            return oint(0, 2 * np.nanstd(np.ravel(rawData)), 200)
+        raise ConfigurationError('AR1 model does not contain a parameter "{}".'.format(name))
+
+
+class NumPy(ObservationModel):
+    """User-defined likelihood ``function(data, *parameter_arrays)`` (reference observationModels.py:59-143)."""
+
+    def __init__(self, function, *args, **kwargs):
+        if not hasattr(function, '__call__'):
+            raise ConfigurationError('Expected a function as the first argument of NumPy observation model')
+        for key in kwargs:
+            if key not in ['prior']:
+                raise TypeError("__init__() got an unexpected keyword argument '{}'".format(key))
+        self.function = function
+        self.name = function.__name__
+        self.segmentLength = 1
+        self.multiplyLikelihoods = False
+        self.parameterNames = list(args[::2])
+        self.parameterValues = list(args[1::2])
+        spec = _argspec(function).args
+        if len(self.parameterNames) != len(spec) - 1:
+            raise ConfigurationError('Supplied function has {} parameters, observation model has {}'
+                                     .format(len(spec) - 1, len(self.parameterNames)))
+        if spec[0] != 'data':
+            raise ConfigurationError('First argument of supplied function must be called "data"')
+        self.prior = kwargs.get('prior', None)
+
+    def pdf(self, grid, dataSegment):
+        return self.function(dataSegment[0], *grid)

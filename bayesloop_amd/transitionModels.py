@@ -1,0 +1,149 @@
+"""
+Transition models -- the ``bl.tm`` namespace.
+
+A transition model maps the posterior of one time step to the prior of the next (and the mirrored map backwards).
+In the reference each model does this itself in numpy/SciPy (``computeForwardPrior`` / ``computeBackwardPrior``,
+bayesloop/transitionModels.py:49-63, 96-118, 289-317, 632-662).  Here a model only DESCRIBES the map: ``fit()``
+compiles the (possibly nested) model into a flat *transition program* -- a list of ops executed, in list order and in
+both directions, inside the fused HIP step kernels:
+
+    Static                  -> nothing                                   (identity)
+    GaussianRandomWalk      -> GRW(axis, sigma): reflect-boundary Gaussian stencil along one grid axis
+    ChangePoint             -> CHANGEPOINT(tChange): restart from the (re-normalised) prior at one time stamp
+    CombinedTransitionModel -> concatenation of the sub-models' programs
+
+Constructor arguments and the attributes the study classes rely on (``hyperParameterNames``, ``hyperParameterValues``,
+``prior``, ``models``) are those of the reference, so the hyper-parameter plumbing of HyperStudy / ChangepointStudy
+works unchanged.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+from .exceptions import ConfigurationError
+
+
+class TransitionModel:
+    """Base class of all transition models."""
+
+    hyperParameterNames = ()
+    hyperParameterValues = ()
+
+    def _program(self, parameterNames):
+        """-> list of (op kind, axis, owner model, hyper-parameter index or None)"""
+        raise ConfigurationError('Transition model "{}" cannot be compiled for the MI355X engine.'.format(self))
+
+    def computeForwardPrior(self, posterior, t):
+        raise NotImplementedError('bayesloop_amd executes transition models inside the HIP step kernels; '
+                                  'host-side computeForwardPrior is not part of this build.')
+
+    def computeBackwardPrior(self, posterior, t):
+        return self.computeForwardPrior(posterior, t - 1)
+
+
+def _as_values(value):
+    return np.array(value) if isinstance(value, (list, tuple)) else value
+
+
+class Static(TransitionModel):
+    """Constant parameters (reference transitionModels.py:34-63)."""
+
+    def __init__(self):
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = []
+        self.hyperParameterValues = []
+        self.prior = None
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Static/constant parameter values'
+
+    def _program(self, parameterNames):
+        return [(_abi.OP_STATIC, 0, self, None)]
+
+
+class GaussianRandomWalk(TransitionModel):
+    """Gaussian fluctuations of one parameter with standard deviation sigma (reference transitionModels.py:66-118)."""
+
+    def __init__(self, name='sigma', value=None, target=None, prior=None):
+        if target is None:
+            raise ConfigurationError('No parameter set for transition model "GaussianRandomWalk"')
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = [name]
+        self.hyperParameterValues = [_as_values(value)]
+        self.prior = prior
+        self.selectedParameter = target
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Gaussian random walk'
+
+    def _program(self, parameterNames):
+        if self.selectedParameter not in parameterNames:
+            raise ConfigurationError('GaussianRandomWalk: observation model has no parameter "{}".'
+                                     .format(self.selectedParameter))
+        return [(_abi.OP_GRW, list(parameterNames).index(self.selectedParameter), self, 0)]
+
+
+class ChangePoint(TransitionModel):
+    """Abrupt change right after time stamp tChange (reference transitionModels.py:263-317)."""
+
+    def __init__(self, name='tChange', value=None, prior=None):
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = [name]
+        self.hyperParameterValues = [_as_values(value)]
+        self.prior = prior
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Change-point'
+
+    def _program(self, parameterNames):
+        return [(_abi.OP_CHANGEPOINT, 0, self, 0)]
+
+
+class CombinedTransitionModel(TransitionModel):
+    """Several models acting at the same time, applied in the given order (reference transitionModels.py:609-662)."""
+
+    def __init__(self, *args):
+        if any(str(arg) == 'Break-point' for arg in args):
+            raise ConfigurationError('The "BreakPoint" transition model can only be used with the '
+                                     '"SerialTransitionModel" class.')
+        self.study = None
+        self.latticeConstant = None
+        self.models = args
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Combined transition model'
+
+    def _program(self, parameterNames):
+        program = []
+        for m in self.models:
+            program += m._program(parameterNames)
+        return program
+
+
+def _not_yet(name, where):
+    class _Unavailable(TransitionModel):
+        def __init__(self, *args, **kwargs):
+            raise NotImplementedError('bl.tm.{} (reference {}) is not available on the MI355X engine yet; this build '
+                                      'covers Static, GaussianRandomWalk, ChangePoint and CombinedTransitionModel.'
+                                      .format(name, where))
+    _Unavailable.__name__ = name
+    return _Unavailable
+
+
+# rows of SURVEY.md section 8(f): not on the hot path named by BASELINE.json
+AlphaStableRandomWalk = _not_yet('AlphaStableRandomWalk', 'transitionModels.py:121-260')
+Independent = _not_yet('Independent', 'transitionModels.py:320-363')
+RegimeSwitch = _not_yet('RegimeSwitch', 'transitionModels.py:366-415')
+NotEqual = _not_yet('NotEqual', 'transitionModels.py:418-474')
+Deterministic = _not_yet('Deterministic', 'transitionModels.py:477-606')
+SerialTransitionModel = _not_yet('SerialTransitionModel', 'transitionModels.py:665-818')
+BreakPoint = _not_yet('BreakPoint', 'transitionModels.py:821-840')
+BivariateRandomWalk = _not_yet('BivariateRandomWalk', 'transitionModels.py:843-911')

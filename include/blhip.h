@@ -1,0 +1,156 @@
+/*
+ * blhip.h -- C-ABI of libblhip.so: the MI355X (gfx950) implementation of bayesloop's grid-based
+ * forward-backward inference loop.
+ *
+ * The reference (christophmark/bayesloop v1.5.7) is pure Python and has NO FFI for this path; its boundary is the
+ * duck-typed method level.  Each entry point below names the reference interface it stands in for
+ * (file:line relative to the reference checkout):
+ *
+ *   blhip_fit            Study.fit                        bayesloop/core.py:330-486
+ *                        (+ the per-hyper-point loop of   bayesloop/core.py:1349-1366 / 1473-1489 when n_chains > 1)
+ *   blhip_accum_*        the evidence-weighted average    bayesloop/core.py:1295, 1362-1366, 1339, 1375-1382, 1416-1419
+ *   blhip_posterior_*    the posteriorSequence attribute  bayesloop/core.py:356, 408, 436-441
+ *
+ * inside which the library evaluates
+ *   ObservationModel.processedPdf + Poisson/Gaussian/GaussianMean.pdf   observationModels.py:35-56, 502, 566-567, 705-706
+ *   GaussianRandomWalk / CombinedTransitionModel / ChangePoint / Static  transitionModels.py:49-63, 96-118, 289-317, 632-662
+ *   (scipy.ndimage.gaussian_filter1d, mode='reflect', truncate=4.0, called at transitionModels.py:111).
+ *
+ * Conventions
+ *   - plain C, no C++ / torch types; every array is float64 (double) or the integer type shown, C-contiguous.
+ *   - the caller owns every host buffer and keeps it alive for the duration of the call; the library owns all
+ *     device memory inside the opaque context.  No callbacks.  Nothing throws across the ABI.
+ *   - return value: 0 = ok, < 0 = hard error (message via blhip_last_error).  Numerical failure of a chain (a zero
+ *     normaliser, core.py:390-400 / 442-452) is NOT an error: it is reported per chain in abort_step/abort_phase and
+ *     the caller mirrors the reference (logEvidence = -inf, early return).
+ *   - one context per device; calls on one context must be serialised by the caller.
+ */
+#ifndef BLHIP_H
+#define BLHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLHIP_ABI_VERSION 1
+
+typedef struct blhip_ctx blhip_ctx;
+
+/* observation models (likelihood evaluated on the device from the data point and the grid) */
+enum {
+    BLHIP_OM_POISSON       = 1,   /* observationModels.py:502      1 parameter  (rate)            */
+    BLHIP_OM_GAUSSIAN      = 2,   /* observationModels.py:566-567  2 parameters (mean, std)       */
+    BLHIP_OM_GAUSSIAN_MEAN = 3,   /* observationModels.py:705-706  1 parameter  (mean); data (T,1,2) = (value, std) */
+    BLHIP_OM_TABLE         = 100  /* likelihood evaluated by the caller (any ObservationModel.pdf): lik (T,G) */
+};
+
+/* transition-model ops, applied in list order in both directions (transitionModels.py:645-649, 656-660) */
+enum {
+    BLHIP_OP_STATIC      = 0,     /* transitionModels.py:49-63    no hyper-parameter                          */
+    BLHIP_OP_GRW         = 1,     /* transitionModels.py:96-118   value = sigma, axis = target parameter index */
+    BLHIP_OP_CHANGEPOINT = 2      /* transitionModels.py:289-317  value = tChange                              */
+};
+
+typedef struct {
+    int32_t kind;                 /* BLHIP_OP_* */
+    int32_t axis;                 /* GRW: index of the target parameter (0 .. ndim-1) */
+} blhip_op;
+
+/* The fit problem: grid, data, prior, transition program (shared by all chains of a call). */
+typedef struct {
+    int32_t        ndim;          /* number of observation-model parameters = grid dimensions: 1 or 2           */
+    int32_t        obs_model;     /* BLHIP_OM_*                                                                  */
+    int64_t        n[2];          /* grid size per parameter (core.py:157)                                       */
+    const double  *marginal[2];   /* marginal grid values per parameter, n[k] doubles (core.py:156)              */
+    double         lattice[2];    /* lattice constants (core.py:161-166)                                         */
+    int64_t        T;             /* number of formatted time steps                                              */
+    int32_t        seg_len;       /* segment length of the observation model (1 for the device-side models)      */
+    int32_t        data_dim;      /* trailing data dimension d (1 for scalar series); GAUSSIAN_MEAN: 2           */
+    const double  *data;          /* formatted data (T, seg_len, data_dim), NaN = missing (observationModels.py:53) */
+    const double  *timestamps;    /* formatted timestamps (T,) (core.py:350)                                     */
+    const double  *prior;         /* alpha_0: Study._computePrior() on the grid, (G,) (core.py:363)              */
+    const double  *reset_prior;   /* what a change-point resets to, (G,) (transitionModels.py:300-312); NULL if no CHANGEPOINT op */
+    const double  *lik;           /* BLHIP_OM_TABLE only: likelihood (T, G) evaluated by the caller; else NULL   */
+    int32_t        n_ops;         /* length of the transition program                                            */
+    const blhip_op *ops;
+} blhip_problem;
+
+/* Flags of blhip_fit */
+#define BLHIP_FORWARD_ONLY   1u   /* Study.fit(forwardOnly=True)   core.py:422                                   */
+#define BLHIP_EVIDENCE_ONLY  2u   /* Study.fit(evidenceOnly=True)  core.py:355, 407, 422, 477                    */
+#define BLHIP_KEEP_POSTERIOR 4u   /* keep each chain's normalised posterior sequence on the device (blhip_posterior_read) */
+#define BLHIP_ACCUMULATE     8u   /* fold each finite chain into the context's average-posterior accumulator (blhip_accum_*) */
+
+/* Per-chain results; every pointer may be NULL. */
+typedef struct {
+    double  *log_evidence;        /* (n_chains,)          Study.logEvidence (core.py:403, 417); -inf on abort    */
+    double  *local_evidence;      /* (n_chains, T)        Study.localEvidence (core.py:404, 463-464)             */
+    double  *posterior_mean;      /* (n_chains, ndim, T)  Study.posteriorMeanValues (core.py:480-483)            */
+    int64_t *abort_step;          /* (n_chains,)          -1, or the step i at which the normaliser was zero     */
+    int32_t *abort_phase;         /* (n_chains,)          0 = forward (core.py:390-400), 1 = backward (442-452)  */
+} blhip_result;
+
+/* Timing of the last blhip_fit, measured with HIP events on the library's stream. */
+typedef struct {
+    double  forward_ms;           /* all forward-step launches                                                   */
+    double  backward_ms;          /* all backward-step launches                                                  */
+    double  accumulate_ms;        /* hyper-average accumulation launches                                         */
+    double  total_ms;             /* whole call on the device timeline                                           */
+    int64_t forward_launches;
+    int64_t backward_launches;
+    int64_t accumulate_launches;
+    int64_t cells_per_launch;     /* grid cells x chains processed by one step launch (largest batch)            */
+    int64_t batches;              /* number of chain batches the call was split into                             */
+    int32_t fwd_kernel_variant;   /* which step kernel ran (library-internal id)                   */
+    int32_t bwd_kernel_variant;
+} blhip_timing;
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+int         blhip_abi_version(void);
+int         blhip_device_count(void);
+blhip_ctx  *blhip_create(int device);
+void        blhip_destroy(blhip_ctx *ctx);
+const char *blhip_last_error(blhip_ctx *ctx);        /* ctx may be NULL for errors of blhip_create              */
+int         blhip_device_name(blhip_ctx *ctx, char *buf, int buflen);
+int         blhip_set_option(blhip_ctx *ctx, const char *key, double value);   /* tuning knobs, see DESIGN.md    */
+int         blhip_synchronize(blhip_ctx *ctx);
+
+/* ---- the hot path --------------------------------------------------------------------------------------------- */
+/* Runs n_chains independent forward(-backward) passes that share `problem` and differ in the hyper-parameter value
+ * of each op: op_values is (n_chains, n_ops), row-major; entries of STATIC ops are ignored.
+ * log_chain_weight (n_chains,) is only read with BLHIP_ACCUMULATE: log of the hyper-prior value of each chain
+ * (core.py:1366); the library adds the chain's log-evidence itself. */
+int blhip_fit(blhip_ctx *ctx, const blhip_problem *problem, int64_t n_chains, const double *op_values,
+              const double *log_chain_weight, uint32_t flags, blhip_result *result);
+
+int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out);
+
+/* ---- posterior sequence of the last blhip_fit(..., BLHIP_KEEP_POSTERIOR) ---------------------------------------- */
+/* Copies the normalised posteriors of steps [t0, t1) of one chain to host memory ((t1-t0) * G doubles). */
+int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, double *host_out);
+/* Device address of chain 0 / step 0 and the strides in doubles (device-side consumers, e.g. RCCL). */
+int blhip_posterior_devptr(blhip_ctx *ctx, void **devptr, int64_t *chain_stride, int64_t *step_stride);
+int blhip_posterior_release(blhip_ctx *ctx);
+
+/* ---- evidence-weighted average posterior (HyperStudy) ----------------------------------------------------------- */
+/* The accumulator holds  A[t, cell] = sum_h exp(logE_h + log prior_h - log_ref) * max(post_h[t, cell], 1e-300)
+ * in linear space with a running reference exponent `log_ref` (equal to the reference's log-space logaddexp
+ * accumulation, core.py:1362-1366, up to rounding).  external_devptr, if not NULL, is caller-owned device memory of
+ * T*G doubles (e.g. a torch tensor handed to RCCL); otherwise the library allocates it. */
+int blhip_accum_begin(blhip_ctx *ctx, int64_t T, int64_t G, void *external_devptr);
+int blhip_accum_state(blhip_ctx *ctx, double *log_ref, void **devptr, int64_t *n_folded);
+/* Re-express the accumulator against a new reference exponent (>= current), e.g. the maximum over ranks, so that
+ * accumulators of several GPUs can be summed (core.py:1339). */
+int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref);
+/* Per-step normalisation (core.py:1379-1382) and posterior means (core.py:1416-1419); the normalised average stays
+ * on the device and is read with blhip_accum_read.  posterior_mean: (ndim, T) or NULL. */
+int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *problem, double *posterior_mean);
+int blhip_accum_read(blhip_ctx *ctx, int64_t t0, int64_t t1, double *host_out);
+int blhip_accum_end(blhip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLHIP_H */

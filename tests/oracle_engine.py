@@ -1,0 +1,131 @@
+"""
+TEST DOUBLE: an object with the interface of bayesloop_amd.engine.HipEngine whose arithmetic is the CPU oracle.
+
+It exists so that the host-side logic of the product (grid / prior construction, transition-program compilation,
+hyper-grid plumbing, sharding and the merge of bayesloop_amd.dist) can be tested on a machine without a GPU
+(``-m "not gpu"``).  It is installed with ``bayesloop_amd.set_engine`` by tests only; the product never imports it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import bl_oracle as orc
+from bayesloop_amd import _abi
+from bayesloop_amd.engine import FitResult
+
+OM = {_abi.OM_POISSON: 'poisson', _abi.OM_GAUSSIAN: 'gaussian', _abi.OM_GAUSSIAN_MEAN: 'gaussian_mean',
+      _abi.OM_TABLE: 'table'}
+OPS = {_abi.OP_STATIC: 'static', _abi.OP_GRW: 'grw', _abi.OP_CHANGEPOINT: 'changepoint'}
+
+
+class OracleEngine:
+    name = 'oracle-test-double'
+
+    def __init__(self):
+        self._post = None
+        self._posterior_owner = None
+        self.acc_log = None
+        self.acc_ext = None
+        self.acc_lin = None
+        self.fits = 0
+
+    def _unpack(self, p):
+        g = orc.Grid(p.marginal)
+        ops = [(OPS[k],) if k != _abi.OP_GRW else ('grw', a) for k, a in p.ops]
+        data = np.asarray(p.data, dtype=float)
+        lik = None if p.lik is None else np.asarray(p.lik, dtype=float).reshape([p.T] + g.size)
+        reset = None if p.reset_prior is None else np.asarray(p.reset_prior, dtype=float).reshape(g.size)
+        return g, OM[p.obs_model], ops, data, lik, reset
+
+    def fit(self, problem, op_values, forward_only=False, evidence_only=False, keep_posterior=False,
+            accumulate=False, log_chain_weight=None, owner=None):
+        if self._posterior_owner is not None and self._posterior_owner is not owner:
+            prev, self._posterior_owner = self._posterior_owner, None
+            prev._materialize_posterior()
+        g, om, ops, data, lik, reset = self._unpack(problem)
+        n, T, ndim = len(op_values), problem.T, len(g.size)
+        logE = np.zeros(n)
+        local = np.zeros((n, T))
+        means = None if evidence_only else np.zeros((n, ndim, T))
+        astep = np.full(n, -1, dtype=np.int64)
+        aphase = np.zeros(n, dtype=np.int32)
+        self._post = None
+        for c in range(n):
+            vals = [None if op[0] == 'static' else op_values[c][k] for k, op in enumerate(ops)]
+            with np.errstate(all='ignore'):
+                r = orc.fit(g, om, data, problem.timestamps, np.asarray(problem.prior).reshape(g.size), ops, vals,
+                            forward_only=forward_only, evidence_only=evidence_only, reset=reset, lik_table=lik)
+            self.fits += 1
+            logE[c] = r['logEvidence']
+            local[c] = r['localEvidence']
+            if r['abort'] is not None:
+                astep[c] = r['abort'][1]
+                aphase[c] = 0 if r['abort'][0] == 'forward' else 1
+                continue
+            if not evidence_only:
+                means[c] = r['posteriorMeanValues']
+                if keep_posterior:
+                    self._post = r['posteriorSequence'].copy()
+                if accumulate and np.isfinite(r['logEvidence']):
+                    with np.errstate(divide='ignore'):
+                        flat = dict(r, posteriorSequence=r['posteriorSequence'].reshape(T, -1))
+                        self.acc_log = orc.hyper_accumulate(self.acc_log, flat, log_chain_weight[c])
+        if keep_posterior and not evidence_only:
+            self._posterior_owner = owner
+        return FitResult(logE, local, means, astep, aphase, {})
+
+    def posterior(self, chain, T, grid_size):
+        return self._post.reshape([T] + list(grid_size))
+
+    def release_posterior(self, owner=None):
+        self._posterior_owner = None
+
+    def last_timing(self):
+        return {}
+
+    # ---- accumulator (log space inside, linear space for the cross-rank merge) -----------------------------------
+    def accum_begin(self, T, G, external=None):
+        self.acc_shape = (T, G)
+        self.acc_log = np.zeros((T, G)) - np.inf
+        self.acc_ext = external
+        self.acc_lin = None
+
+    def _acc3(self, problem):
+        return [problem.T] + list(problem.grid_size)
+
+    def fit_shape(self, a, shape):
+        return a.reshape(shape)
+
+    def accum_log_ref(self):
+        return float(np.amax(self.acc_log)), 0
+
+    def accum_rescale(self, new_log_ref):
+        lin = np.exp(self.acc_log - new_log_ref)
+        if self.acc_ext is not None:
+            self.acc_ext.numpy()[:] = lin.ravel()
+            self.acc_lin = self.acc_ext.numpy()
+        else:
+            self.acc_lin = lin.ravel()
+
+    def accum_finalize(self, problem):
+        T, G = self.acc_shape
+        if self.acc_lin is not None:
+            avg = np.array(self.acc_lin, dtype=float).reshape(T, G)
+        else:
+            avg = np.exp(self.acc_log - np.amax(self.acc_log))
+        avg /= avg.sum(axis=1)[:, None]
+        self.acc_final = avg
+        g = orc.Grid(problem.marginal)
+        means = np.empty((len(g.size), T))
+        for k in range(len(g.size)):
+            means[k] = np.array([np.sum(p.reshape(g.size) * g.grid[k]) for p in avg])
+        return means
+
+    def accum_read(self, T, grid_size):
+        return self.acc_final.reshape([T] + list(grid_size)).copy()
+
+    def accum_end(self):
+        pass
+
+    def synchronize(self):
+        pass

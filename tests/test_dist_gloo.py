@@ -1,0 +1,78 @@
+"""The multi-rank HyperStudy path (bayesloop_amd.dist) with world_size 2 over gloo on CPU: sharded chunks, the single
+gather and the accumulator merge must reproduce the unsharded golden result."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(%(root)r, 'tests')); sys.path.insert(0, %(root)r)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=%(world)d)
+    import bayesloop_amd as bl
+    import cases, compare, oracle_adapter as oa
+    from oracle_engine import OracleEngine
+    bl.set_engine(OracleEngine())
+    for case in %(cases)r:
+        S = cases.build(bl, case)
+        S.communicator = bl.dist.TorchCommunicator()
+        with np.errstate(all='ignore'):
+            S.fit(**cases.fit_kwargs(case))
+        gold = oa.load_golden(case)
+        res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence, logEvidenceList=np.array(S.logEvidenceList),
+                   hyperParameterDistribution=S.hyperParameterDistribution)
+        if not cases.CASES[case].get('fit', {}).get('evidenceOnly'):
+            res['posteriorMeanValues'] = S.posteriorMeanValues
+            if dist.get_rank() == 0:
+                res['posteriorSequence'] = S.posteriorSequence
+            else:
+                assert S.posteriorSequence is None
+                gold = {k: v for k, v in gold.items() if not k.startswith('posteriorS') and not k.startswith('posteriorR')
+                        and not k.startswith('marginalS')}
+        compare.check(res, gold, dict(compare.ORACLE_TOL, post_rtol=1e-10, small_rtol=1e-10))
+        n = bl.get_engine().fits
+        print('rank', dist.get_rank(), case, 'ok; chains fitted on this rank so far:', n)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_hyperstudy_matches_unsharded(tmp_path, world):
+    pytest.importorskip('torch')
+    script = tmp_path / 'worker.py'
+    names = ['kat_hyper_1hp', 'c4_2hp', 'c4_small_evidence', 'c5_cp_grw', 'c1_coal_hyper']
+    script.write_text(WORKER % dict(root=ROOT, port=free_port(), world=world, cases=names))
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank %d failed:\\n%s' % (r, out)
+        assert out.count(' ok;') == len(names), out
+
+
+def test_chunks_equal_array_split():
+    from bayesloop_amd.dist import chunk_bounds
+    for n in (1, 2, 7, 16, 512, 513):
+        for size in (1, 2, 3, 4, 8):
+            parts = np.array_split(np.arange(n), size)
+            got = chunk_bounds(n, size)
+            for p, (a, b) in zip(parts, got):
+                assert list(p) == list(range(a, b))

@@ -1,0 +1,121 @@
+"""Host-side logic of bayesloop_amd (grid/prior construction, transition-program compilation, hyper-grid plumbing,
+ChangepointStudy masking, evidence algebra) on CPU: the product's study classes run with the oracle-backed TEST DOUBLE
+engine (tests/oracle_engine.py) and must reproduce the reference's golden vectors."""
+import numpy as np
+import pytest
+
+import bayesloop_amd as bl
+import cases
+import compare
+import oracle_adapter as oa
+from oracle_engine import OracleEngine
+
+
+@pytest.fixture(autouse=True)
+def oracle_engine():
+    prev = bl.set_engine(OracleEngine())
+    yield
+    bl.set_engine(prev)
+
+
+def result_of(S, case):
+    c = cases.CASES[case]
+    res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence)
+    kw = c.get('fit', {})
+    if not kw.get('evidenceOnly', False) and np.isfinite(S.logEvidence):
+        res['posteriorSequence'] = S.posteriorSequence
+        res['posteriorMeanValues'] = S.posteriorMeanValues
+    for key in ('logEvidenceList', 'hyperParameterDistribution', 'hyperGridValues', 'flatHyperPriorValues',
+                'hyperGridConstant', 'mask'):
+        if hasattr(S, key) and getattr(S, key) is not None and len(np.atleast_1d(getattr(S, key))) > 0:
+            res[key] = np.asarray(getattr(S, key))
+    return res
+
+
+FAST = [k for k, c in cases.CASES.items() if not c.get('slow')]
+
+
+@pytest.mark.parametrize('case', FAST)
+def test_study_classes_reproduce_reference(case, capsys):
+    S = cases.build(bl, case)
+    with np.errstate(all='ignore'):
+        S.fit(**{k: v for k, v in cases.fit_kwargs(case).items()})
+    gold = oa.load_golden(case)
+    np.testing.assert_array_equal(S.marginalGrid[0], gold['marginal0'])
+    np.testing.assert_allclose(S.latticeConstant, gold['latticeConstant'], rtol=0, atol=0)
+    compare.check(result_of(S, case), gold, compare.ORACLE_TOL)
+
+
+def test_reference_test_expectations_through_accessors():
+    """tests/test_hyperstudy.py:32-59 of the reference, verbatim expectations, via the accessor methods."""
+    S = cases.build(bl, 'kat_hyper_1hp')
+    S.fit(silent=True)
+    np.testing.assert_allclose(S.getParameterDistributions('mean', density=False)[1][:, 5],
+                               [0.017242, 0.014581, 0.012691, 0.011705, 0.011586], rtol=1e-04)
+    np.testing.assert_allclose(S.getParameterMeanValues('mean'), [2.92089, 2.952597, 3., 3.047403, 3.07911], rtol=1e-05)
+    np.testing.assert_almost_equal(S.logEvidence, -16.0629517262, decimal=5)
+    x, p = S.getHyperParameterDistribution('sigma')
+    np.testing.assert_allclose(np.array([x, p]), [[0., 0.2], [0.43828499, 0.56171501]], rtol=1e-05)
+
+
+def test_study_accessors_reference_test_study():
+    """tests/test_study.py:32-52 of the reference (default estimated 1000-point grid)."""
+    S = cases.build(bl, 'kat_study_1hp')
+    S.fit(silent=True)
+    np.testing.assert_allclose(S.getParameterDistributions('rate', density=False)[1][:, 250],
+                               [0.000417, 0.000386, 0.000356, 0.000336, 0.000332], rtol=1e-02)
+    np.testing.assert_allclose(S.getParameterMeanValues('rate'),
+                               [3.073534, 3.08179, 3.093091, 3.104016, 3.111173], rtol=1e-02)
+
+
+def test_configuration_errors():
+    S = bl.Study(silent=True)
+    with pytest.raises(bl.ConfigurationError):
+        S.fit()
+    S.loadData(np.array([1, 2, 3]), silent=True)
+    with pytest.raises(bl.ConfigurationError):
+        S.fit()
+    S.setOM(bl.om.Poisson('rate', bl.oint(0, 6, 50)), silent=True)
+    with pytest.raises(bl.ConfigurationError):
+        S.fit()
+    with pytest.raises(bl.ConfigurationError):
+        S.set(bl.om.Poisson('a', bl.oint(0, 1, 5)), bl.om.Poisson('b', bl.oint(0, 1, 5)), silent=True)
+    with pytest.raises(bl.ConfigurationError):
+        bl.tm.GaussianRandomWalk('sigma', 0.1)          # no target
+    with pytest.raises(NotImplementedError):
+        bl.tm.RegimeSwitch('p', -3)
+    S.setTM(bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s', 0.1, target='rate'),
+                                          bl.tm.GaussianRandomWalk('s', 0.2, target='rate')), silent=True)
+    with pytest.raises(bl.ConfigurationError):
+        S.fit(silent=True)                               # duplicate hyper-parameter names
+
+
+def test_table_likelihood_path_matches_native_models():
+    """A user-defined observation model (plug-in pdf) goes through the likelihood-table path."""
+    class MyPoisson(bl.om.ObservationModel):
+        def __init__(self, name, value):
+            self.name = 'my poisson'
+            self.segmentLength = 1
+            self.multiplyLikelihoods = True
+            self.parameterNames = [name]
+            self.parameterValues = [value]
+            self.prior = lambda x: np.sqrt(1. / x)
+
+        def pdf(self, grid, dataSegment):
+            import math
+            return (grid[0] ** dataSegment[0]) * np.exp(-grid[0]) / math.factorial(int(dataSegment[0]))
+
+    S = bl.Study(silent=True)
+    S.loadData(cases.D15, silent=True)
+    S.set(MyPoisson('rate', bl.oint(0, 6, 100)), bl.tm.GaussianRandomWalk('sigma', 0.2, target='rate'), silent=True)
+    S.fit(silent=True)
+    np.testing.assert_allclose(S.logEvidence, -10.323144246611964, rtol=1e-13)
+
+
+def test_pickle_roundtrip_materialises_posterior():
+    import pickle
+    S = cases.build(bl, 'kat_grw')
+    S.fit(silent=True)
+    S2 = pickle.loads(pickle.dumps(S))
+    np.testing.assert_array_equal(S2.posteriorSequence, S.posteriorSequence)
+    assert S2.logEvidence == S.logEvidence
