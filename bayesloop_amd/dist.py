@@ -106,7 +106,7 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
     buf = None
     if want_post:
         buf = comm.new_buffer(T * G) if comm is not None else None
-        engine.accum_begin(T, G, external=buf)
+        engine.accum_begin(T, G, external=buf, owner=owner)
 
     n_mine = hi - lo
     logE = np.zeros(n_mine)

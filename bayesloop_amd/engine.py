@@ -10,6 +10,7 @@ with the same methods through :func:`set_engine` to exercise the host-side logic
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
@@ -152,9 +153,10 @@ class HipEngine:
     def fit(self, problem: FitProblem, op_values, forward_only=False, evidence_only=False, keep_posterior=False,
             accumulate=False, log_chain_weight=None, owner=None) -> FitResult:
         """n_chains = len(op_values) independent passes (Study.fit per hyper-grid point)."""
-        if self._posterior_owner is not None and self._posterior_owner is not owner:
-            prev, self._posterior_owner = self._posterior_owner, None
-            prev._materialize_posterior()
+        prev = self._posterior_owner() if self._posterior_owner is not None else None
+        if prev is not None and prev is not owner:
+            self._posterior_owner = None
+            prev._materialize_posterior()      # the previous study's posterior still lives in this context
         cp, keep = self._problem(problem)
         ov = _f64(op_values).reshape(-1, max(1, len(problem.ops))) if len(problem.ops) else np.zeros((len(op_values), 1))
         n = ov.shape[0] if len(problem.ops) else len(op_values)
@@ -176,7 +178,7 @@ class HipEngine:
         self._check(self.lib.blhip_fit(self.ctx, C.byref(cp), n, _abi.dptr(ov), _abi.dptr(lw), flags, C.byref(res)))
         del keep
         if keep_posterior and not evidence_only:
-            self._posterior_owner = owner
+            self._posterior_owner = None if owner is None else weakref.ref(owner)
         return FitResult(logE, local, means, astep, aphase, self.last_timing())
 
     def last_timing(self):
@@ -191,12 +193,23 @@ class HipEngine:
         return out
 
     def release_posterior(self, owner=None):
-        if owner is None or self._posterior_owner is owner:
+        """Forget who owns the device-resident results (they will not be copied to the host when overwritten)."""
+        cur = self._posterior_owner() if self._posterior_owner is not None else None
+        if owner is None or cur is owner:
             self._posterior_owner = None
+        cur = self._accum_owner() if getattr(self, '_accum_owner', None) is not None else None
+        if owner is None or cur is owner:
+            self._accum_owner = None
 
     # ---- average posterior of a hyper-study ----------------------------------------------------------------------
-    def accum_begin(self, T, G, external=None):
+    def accum_begin(self, T, G, external=None, owner=None):
         """external: optional torch CUDA tensor of T*G float64 that backs the accumulator (for RCCL)."""
+        ref = getattr(self, '_accum_owner', None)
+        prev = ref() if ref is not None else None
+        if prev is not None and prev is not owner:
+            self._accum_owner = None
+            prev._materialize_posterior()       # the previous study's average posterior still lives in the accumulator
+        self._accum_owner = None if owner is None else weakref.ref(owner)
         self._accum_external = external
         ptr = None if external is None else C.c_void_p(external.data_ptr())
         self._check(self.lib.blhip_accum_begin(self.ctx, T, G, ptr))

@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""
+bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|fwd2048] [--no-extra] [--no-cpu]
+
+A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
+
+Workloads (synthetic data, seeds fixed):
+  c4       HyperStudy, 512 x 512 Gaussian (mean, std) grid, GaussianRandomWalk on 'mean' with 512 sigma values
+           cint(0, 0.3, 512), T = 256, FULL fit (forward + backward + evidence-weighted average posterior).
+           The headline at every N: the 512 hyper-grid points are sharded over the N ranks in np.array_split chunks
+           (strong scaling: total work fixed), one gather + one reduce over RCCL at the end.
+  c3       Study, 1024 x 1024 grid, T = 2000, GRW x GRW separable stencil, full fit             (N = 1)
+  c2       Study, 4096-point 1-D GaussianMean grid, T = 10 000, full fit (latency-bound)       (N = 1)
+  fwd2048  Study, 2048 x 2048 grid, T = 200, evidenceOnly: the fused-forward-step roofline point (N = 1)
+
+Inputs are KBs (the series, the marginal grids) and are uploaded inside fit(); all grid-sized state is created and
+stays in HBM.  The posterior sequence is left on the device (lazy D2H on first access, not part of the timed region).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+# algorithmic bytes per grid-cell x timestep of THIS build's kernels (DESIGN.md "bytes"):
+BYTES_FWD = 16.0           # fused forward step: read state 8 + write state 8 (the state write IS the stored posterior)
+BYTES_BWD = 32.0           # fused backward step: read alpha 8, read c 8, write posterior 8, write c 8
+
+
+def series(seed, T):
+    rng = np.random.default_rng(seed)
+    mu = np.cumsum(rng.normal(0, 0.02, T))
+    return mu + rng.normal(0, 1.0, T)
+
+
+def make_study(bl, name, comm=None, scale=1.0):
+    """-> (study, fit kwargs, cells x steps x chains of one fit, description dict)"""
+    if name == 'c4':
+        n, T, nh = 512, 256, 512
+        S = bl.HyperStudy(silent=True)
+        S.loadData(series(4, T), silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
+              bl.tm.GaussianRandomWalk('sigma', bl.cint(0, 0.3, nh), target='mean'), silent=True)
+        S.communicator = comm
+        return S, dict(silent=True), n * n * T * nh, dict(workload='C4 HyperStudy 512x512 grid x 512 sigma values, T=256, '
+                                                           'full fit (forward+backward+average posterior)',
+                                                           grid=[n, n], T=T, n_hyper=nh, mode='full')
+    if name == 'c3':
+        n, T = 1024, 2000
+        S = bl.Study(silent=True)
+        S.loadData(series(3, T), silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
+              bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s1', 0.03, target='mean'),
+                                            bl.tm.GaussianRandomWalk('s2', 0.008, target='std')), silent=True)
+        return S, dict(silent=True), n * n * T, dict(workload='C3 Study 1024x1024 grid, T=2000, GRWxGRW, full fit',
+                                                      grid=[n, n], T=T, n_hyper=1, mode='full')
+    if name == 'c2':
+        n, T = 4096, 10000
+        S = bl.Study(silent=True)
+        x = series(20260927, T)
+        S.loadData(np.stack([x, np.ones(T)], 1), silent=True)
+        S.set(bl.om.GaussianMean('mean', bl.cint(-8, 8, n)), bl.tm.GaussianRandomWalk('sigma', 0.02, target='mean'),
+              silent=True)
+        return S, dict(silent=True), n * T, dict(workload='C2 Study 4096-pt 1-D GaussianMean grid, T=10000, full fit',
+                                                  grid=[n], T=T, n_hyper=1, mode='full')
+    if name == 'fwd2048':
+        n, T = 2048, 200
+        S = bl.Study(silent=True)
+        S.loadData(series(3, T), silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
+              bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s1', 0.015, target='mean'),
+                                            bl.tm.GaussianRandomWalk('s2', 0.004, target='std')), silent=True)
+        return S, dict(silent=True, evidenceOnly=True), n * n * T, dict(
+            workload='fused forward step, 2048x2048 grid, T=200, evidenceOnly', grid=[n, n], T=T, n_hyper=1,
+            mode='evidenceOnly')
+    raise ValueError(name)
+
+
+def roofline_of(timing, cells_per_launch):
+    """achieved GB/s of the dominant step kernel from the library's HIP-event timing of its own stream."""
+    out = {}
+    for key, bytes_per in (('forward', BYTES_FWD), ('backward', BYTES_BWD)):
+        n = timing.get(key + '_launches', 0)
+        ms = timing.get(key + '_ms', 0.0)
+        if n and ms > 0:
+            per_launch_s = ms * 1e-3 / n
+            out[key] = dict(kernel='step_kernel<%s>' % key, launches=int(n), avg_launch_us=per_launch_s * 1e6,
+                            achieved=bytes_per * cells_per_launch / per_launch_s / 1e9, bytes_per_cell_step=bytes_per)
+    return out
+
+
+def run_workload(bl, name, steps, warmup, comm, barrier):
+    S, kw, units, desc = make_study(bl, name, comm)
+    for _ in range(warmup):
+        S.fit(**kw)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        S.fit(**kw)
+    bl.get_engine().synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    return S, units, desc, dt
+
+
+def cpu_baseline(nh=4, T=32, n=512):
+    """The CPU oracle (numpy restatement of the reference path) on a bounded sample of the C4 workload, 1 core."""
+    from oracle import bl_oracle as orc
+    g = orc.Grid([orc.cint(-8, 8, n), orc.oint(0, 4, n)])
+    data = orc.moving_window(series(4, T), 1)
+    ts = np.arange(T)
+    prior = orc.compute_prior(g, orc.jeffreys('gaussian'))
+    hv, pv, const = orc.hyper_grid([orc.cint(0, 0.3, 512)[::512 // nh][:nh]], [None])
+    t0 = time.perf_counter()
+    with np.errstate(all='ignore'):
+        orc.hyper_fit(g, 'gaussian', data, ts, prior, [('grw', 0)], hv, pv, const)
+    dt = time.perf_counter() - t0
+    return dict(value=n * n * T * nh / dt, unit='grid-cells*timesteps/s', cores=1, kind='port',
+                sample='oracle/bl_oracle.py hyper_fit: %dx%d grid, %d sigma values, T=%d, full fit, %.1f s' % (n, n, nh, T, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c4')
+    ap.add_argument('--no-extra', action='store_true')
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('BLHIP_DEVICE', str(local_rank))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+    comm = None
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    import bayesloop_amd as bl
+    if world > 1:
+        comm = bl.dist.TorchCommunicator()
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng = bl.get_engine()
+    S, units, desc, dt = run_workload(bl, args.workload, args.steps, args.warmup, comm, barrier)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    timing = dict(S.lastTiming)
+    S._posterior_pending = None      # results stay on the device; nothing is copied back
+    eng.release_posterior()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = units * args.steps / dt
+        rf = roofline_of(timing, timing.get('cells_per_launch', 0))
+        dom = max(rf.values(), key=lambda r: r['avg_launch_us'] * r['launches']) if rf else None
+        roof = None
+        if dom:
+            roof = dict(bound='hbm', achieved=dom['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=dom['achieved'] / HBM_PEAK_GBS, traffic=None, kernel=dom['kernel'],
+                        avg_launch_us=dom['avg_launch_us'], bytes_per_cell_step=dom['bytes_per_cell_step'],
+                        cells_per_launch=int(timing.get('cells_per_launch', 0)))
+        out = dict(metric='grid-cells*timesteps/sec (fit())', value=value, unit='grid-cells*timesteps/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
+                   scaling='strong', vs_baseline=None, dtype='f64', data='synthetic',
+                   config=dict(desc, parallelism='hyper-grid points sharded over %d GPU(s)' % world),
+                   log_evidence=float(S.logEvidence), roofline=roof, kernels=rf, device=eng.device_name())
+        if not args.no_extra and world == 1:
+            extra = {}
+            for name in ('fwd2048', 'c3', 'c2'):
+                if name == args.workload:
+                    continue
+                try:
+                    S2, u2, d2, dt2 = run_workload(bl, name, 1, 1 if name != 'c3' else 0, None, lambda: None)
+                    tm = dict(S2.lastTiming)
+                    extra[name] = dict(value=u2 / dt2, ms_per_step=dt2 * 1e3, log_evidence=float(S2.logEvidence),
+                                       config=d2, kernels=roofline_of(tm, tm.get('cells_per_launch', 0)))
+                    S2._posterior_pending = None
+                    eng.release_posterior()
+                    del S2
+                except Exception as e:     # a failed side workload must not lose the headline line
+                    extra[name] = dict(error=repr(e))
+            out['extra'] = extra
+        if not args.no_cpu and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

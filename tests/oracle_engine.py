@@ -84,7 +84,7 @@ class OracleEngine:
         return {}
 
     # ---- accumulator (log space inside, linear space for the cross-rank merge) -----------------------------------
-    def accum_begin(self, T, G, external=None):
+    def accum_begin(self, T, G, external=None, owner=None):
         self.acc_shape = (T, G)
         self.acc_log = np.zeros((T, G)) - np.inf
         self.acc_ext = external

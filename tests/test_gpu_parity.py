@@ -1,0 +1,194 @@
+"""
+Parity of the HIP path (through the C-ABI of libblhip.so) on a real MI355X against
+  (a) the golden vectors generated from the reference (tests/golden), and
+  (b) the CPU oracle on seeded inputs the fixtures do not cover.
+Bar (BASELINE.json / SURVEY.md 8d, float64): log-evidence 1e-9 relative; posteriors |dp| <= 1e-12 + 1e-9 p.
+"""
+import numpy as np
+import pytest
+
+import bayesloop_amd as bl
+import cases
+import compare
+import oracle_adapter as oa
+from bayesloop_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def hip_engine():
+    prev = bl.set_engine(None)
+    eng = bl.get_engine()                    # raises BackendError if libblhip.so or the GPU is missing
+    assert type(eng).__name__ == 'HipEngine'
+    yield eng
+    bl.set_engine(prev)
+
+
+def result_of(S, case):
+    c = cases.CASES[case] if isinstance(case, str) else case
+    res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence)
+    if not c.get('fit', {}).get('evidenceOnly', False) and np.isfinite(S.logEvidence):
+        res['posteriorSequence'] = S.posteriorSequence
+        res['posteriorMeanValues'] = S.posteriorMeanValues
+    for key in ('logEvidenceList', 'hyperParameterDistribution', 'hyperGridValues', 'flatHyperPriorValues',
+                'hyperGridConstant', 'mask'):
+        if hasattr(S, key) and getattr(S, key) is not None and len(np.atleast_1d(getattr(S, key))) > 0:
+            res[key] = np.asarray(getattr(S, key))
+    return res
+
+
+@pytest.mark.parametrize('case', list(cases.CASES))
+def test_hip_matches_reference_golden(case):
+    S = cases.build(bl, case)
+    S.fit(**cases.fit_kwargs(case))
+    compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL)
+
+
+EXTRA = {
+    # seeded inputs beyond the fixtures: ragged grid sizes (tile remainders), wide/narrow filters, 1-D and 2-D
+    'x_ragged_2d': dict(study='Study', data=('series', 21, 14), om=cases.gauss2d(131, -5, 5, 3),
+                        tm=('Combined', [('GRW', 's1', 0.21, 'mean', None), ('GRW', 's2', 0.05, 'std', None)])),
+    'x_ragged_2d_b': dict(study='Study', data=('series', 22, 9),
+                          om=('Gaussian', [('mean', ('cint', -4, 4, 67)), ('std', ('oint', 0, 3, 301))], 'default'),
+                          tm=('Combined', [('GRW', 's1', 0.5, 'mean', None), ('GRW', 's2', 0.03, 'std', None)])),
+    'x_tall_2d': dict(study='Study', data=('series', 23, 9),
+                      om=('Gaussian', [('mean', ('cint', -4, 4, 515)), ('std', ('oint', 0, 3, 33))], 'default'),
+                      tm=('Combined', [('GRW', 's1', 0.05, 'mean', None), ('GRW', 's2', 0.3, 'std', None)])),
+    'x_1d_long': dict(study='Study', data=('gm', 5, 64), om=('GaussianMean', [('mean', ('cint', -6, 6, 70001))], 'default'),
+                      tm=('GRW', 'sigma', 0.002, 'mean', None)),
+    'x_1d_static_forward': dict(study='Study', data=cases.COAL, timestamps=cases.COAL_T,
+                                om=('Poisson', [('rate', ('oint', 0, 6, 777))], 'default'), tm=('Static',),
+                                fit=dict(forwardOnly=True)),
+    'x_hyper_many': dict(study='HyperStudy', data=('series', 24, 20), om=cases.gauss2d(72, -5, 5, 3),
+                         tm=('Combined', [('GRW', 's1', ('cint', 0, 0.6, 9), 'mean', None),
+                                          ('GRW', 's2', ('cint', 0, 0.12, 5), 'std', None)])),
+    'x_hyper_forward': dict(study='HyperStudy', data=('series', 25, 16), om=cases.gauss2d(40, -5, 5, 3),
+                            tm=('GRW', 'sigma', ('cint', 0.05, 0.5, 6), 'mean', None), fit=dict(forwardOnly=True)),
+    'x_cp_all': dict(study='ChangepointStudy', data=('series_jump', 26, 30, 17, 2.5), om=cases.gauss2d(50, -5, 7, 3),
+                     tm=('ChangePoint', 'tc', 'all', None)),
+}
+
+
+@pytest.mark.parametrize('case', list(EXTRA))
+def test_hip_matches_oracle(case):
+    c = EXTRA[case]
+    S = cases.build(bl, c)
+    S.fit(**cases.fit_kwargs(c))
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL)
+
+
+def test_table_likelihood_path_on_device():
+    """An observation model the kernels do not know (plug-in pdf) -> likelihood table path; equals the native model."""
+    import math
+
+    class MyGaussian(bl.om.ObservationModel):
+        def __init__(self):
+            self.name = 'plug-in gaussian'
+            self.segmentLength = 1
+            self.multiplyLikelihoods = True
+            self.parameterNames = ['mean', 'std']
+            self.parameterValues = [bl.cint(-5, 5, 60), bl.oint(0, 3, 44)]
+            self.prior = lambda m, s: 1. / s ** 2.
+
+        def pdf(self, grid, seg):
+            return np.exp(-((seg[0] - grid[0]) ** 2.) / (2. * grid[1] ** 2.) - .5 * np.log(2. * np.pi * grid[1] ** 2.))
+
+    x = cases.series(31, 12)
+    T = bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s1', 0.3, target='mean'),
+                                      bl.tm.GaussianRandomWalk('s2', 0.1, target='std'))
+    A = bl.Study(silent=True); A.loadData(x, silent=True); A.set(MyGaussian(), T, silent=True); A.fit(silent=True)
+    B = bl.Study(silent=True); B.loadData(x, silent=True)
+    B.set(bl.om.Gaussian('mean', bl.cint(-5, 5, 60), 'std', bl.oint(0, 3, 44)), T, silent=True); B.fit(silent=True)
+    assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
+    np.testing.assert_allclose(A.posteriorSequence, B.posteriorSequence, rtol=1e-9, atol=1e-13)
+    L = bl.om.AR1('rho', bl.oint(-1, 1, 100), 'sigma', bl.oint(0, 1, 100))        # reference tests/test_observationmodels.py:198-208
+    C = bl.Study(silent=True); C.loadData(np.array([1, 0, 1, 0, 0]), silent=True); C.set(L, bl.tm.Static(), silent=True)
+    C.fit(silent=True)
+    np.testing.assert_almost_equal(C.logEvidence, -4.3291291450463421, decimal=5)
+
+
+# ---- size-independent properties at BASELINE.json sizes ----------------------------------------------------------
+
+def _c3(n, T, seed=3, s1=None, s2=None, **fit):
+    S = bl.Study(silent=True)
+    S.loadData(cases.series(seed, T), silent=True)
+    s1 = 0.03 * 1024 / n if s1 is None else s1
+    s2 = 0.008 * 1024 / n if s2 is None else s2
+    S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
+          bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s1', s1, target='mean'),
+                                        bl.tm.GaussianRandomWalk('s2', s2, target='std')), silent=True)
+    S.fit(silent=True, **fit)
+    return S
+
+
+def test_full_size_c3_properties():
+    """1024 x 1024 grid (config C3, shortened series): the identities the recursion must satisfy at any size."""
+    T = 24
+    S = _c3(1024, T)
+    E = _c3(1024, T, evidenceOnly=True)
+    F = _c3(1024, T, forwardOnly=True)
+    # evidence does not depend on the mode
+    assert S.logEvidence == E.logEvidence == F.logEvidence
+    # logE = sum log(localEvidence_forward) - (T-1) log dV   
+    dV = np.prod(S.latticeConstant)
+    assert abs(np.sum(np.log(E.localEvidence)) - (T - 1) * np.log(dV) - E.logEvidence) < 1e-9 * abs(E.logEvidence)
+    post = S.posteriorSequence
+    assert post.shape == (T, 1024, 1024)
+    np.testing.assert_allclose(post.reshape(T, -1).sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    assert np.all(post >= 0)
+    # means are the first moments of the stored posteriors
+    np.testing.assert_allclose(S.posteriorMeanValues[0], (post.sum(axis=2) * S.marginalGrid[0]).sum(axis=1), rtol=1e-10)
+    np.testing.assert_allclose(S.posteriorMeanValues[1], (post.sum(axis=1) * S.marginalGrid[1]).sum(axis=1), rtol=1e-10)
+    # last smoothed posterior == last filtered posterior (beta_T is uniform)
+    np.testing.assert_allclose(post[-1], F.posteriorSequence[-1], rtol=1e-9, atol=1e-14)
+    # the first 10 steps of the series are the golden anchor c3_t10: forward local evidence must agree
+    gold = oa.load_golden('c3_t10')
+    S10 = _c3(1024, 10, evidenceOnly=True)
+    assert abs(S10.logEvidence - float(gold['logEvidence'])) <= 1e-9 * abs(float(gold['logEvidence']))
+
+
+def test_full_size_c2_evidence():
+    """Config C2 at full size (4096-point grid, 10 000 steps): log-evidence against the golden value."""
+    S = cases.build(bl, 'c2_full')
+    S.fit(evidenceOnly=True, silent=True)
+    gold = float(oa.load_golden('c2_full')['logEvidence'])
+    assert abs(S.logEvidence - gold) <= 1e-9 * abs(gold)
+
+
+def test_hyperstudy_sharding_invariance_on_device():
+    """Splitting the hyper-grid into batches (what multi-GPU sharding does per rank) must not change the results."""
+    eng = bl.get_engine()
+    c = 'c4_small'
+    S1 = cases.build(bl, c); S1.fit(silent=True)
+    eng.set_option('max_batch', 3)
+    try:
+        S2 = cases.build(bl, c); S2.fit(silent=True)
+    finally:
+        eng.set_option('max_batch', 1024)
+    assert np.array_equal(S1.logEvidenceList, S2.logEvidenceList)
+    np.testing.assert_allclose(S1.posteriorSequence, S2.posteriorSequence, rtol=1e-10, atol=1e-15)
+    assert abs(S1.logEvidence - S2.logEvidence) < 1e-12 * abs(S1.logEvidence)
+
+
+def test_linearity_of_transition_filter_only():
+    """The stencil alone: filtering a one-hot distribution reproduces SciPy's reflect-boundary kernel row."""
+    from oracle import bl_oracle as orc
+    n = 97
+    x = np.zeros((1, n)); x[0, 3] = 1.0
+    want = orc.gaussian_filter1d(x, 2.3, 1)
+    # drive one forward step with a flat likelihood (all data missing) so that alpha_1 = filter(alpha_0)
+    S = bl.Study(silent=True)
+    S.loadData(np.array([[np.nan, 1.0], [np.nan, 1.0]]), silent=True)
+    grid = bl.cint(0, 96, n)
+    prior = np.zeros(n); prior[3] = 1.0
+    S.set(bl.om.GaussianMean('mean', grid, prior=prior), bl.tm.GaussianRandomWalk('sigma', 2.3, target='mean'), silent=True)
+    S.fit(forwardOnly=True, silent=True)
+    np.testing.assert_allclose(S.posteriorSequence[1], want[0], rtol=1e-13, atol=1e-300)
