@@ -135,7 +135,12 @@ CASES = {
     'wide_filter': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 40))], 'default'),
                         tm=('GRW', 'sigma', 3.5, 'rate', None)),          # lw = 97 > n = 40: multi-period reflect
     'wide_filter_2d': dict(study='Study', data=('series', 7, 6), om=gauss2d(24, -3, 3, 2),
-                           tm=('Combined', [('GRW', 's1', 2.0, 'mean', None), ('GRW', 's2', 1.1, 'std', None)])),
+                           tm=('Combined', [('GRW', 's1', 2.0, 'mean', None), ('GRW', 's2', 1.1, 'std', None)]),
+                           # std values down to 0.08 put DENORMAL likelihood values (not yet zero) on the grid at step 0;
+                           # the reference's backward localEvidence = 1/sum(post/L) is then dominated by cells whose
+                           # alpha*L product keeps only a few significant bits, i.e. the golden value itself is only
+                           # defined to ~1e-4 (any change of operation order moves it) -> looser bar for that one number
+                           tol=dict(local_rtol=1e-3)),
     'tiny_sigma': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                        tm=('GRW', 'sigma', 0.005, 'rate', None)),         # sigma/delta < 0.125 -> lw = 0 (identity)
     'zero_sigma': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),

@@ -42,7 +42,7 @@ def result_of(S, case):
 def test_hip_matches_reference_golden(case):
     S = cases.build(bl, case)
     S.fit(**cases.fit_kwargs(case))
-    compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL)
+    compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL, case_tol=cases.CASES[case].get('tol'))
 
 
 EXTRA = {
