@@ -17,6 +17,7 @@
 
 #include "../../include/blhip.h"
 #include "blhip_kernels.hpp"
+#include "blhip_fast.hpp"
 
 using namespace blk;
 
@@ -197,6 +198,61 @@ void launch_step(hipStream_t s, int om, const StepParams &P, const Tile &t, int 
         default: fail("unknown observation model %d", om);
     }
     HIPCHECK(hipGetLastError());
+}
+
+
+// ---- fast path (blhip_fast.hpp): 2-D grids, axis-0 radius <= 40, axis-1 radius <= 8 -------------------------------
+constexpr int FAST_R0_MAX = 40;
+
+template <int OM, int MODE, int R0>
+void launch_fast_r(hipStream_t s, const blf::FastParams &P, bool H, int nchains) {
+    if (H) hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, true>), dim3(P.nblk, nchains), dim3(NTHREADS), 0, s, P);
+    else hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, false>), dim3(P.nblk, nchains), dim3(NTHREADS), 0, s, P);
+}
+
+template <int OM, int MODE>
+void launch_fast_om(hipStream_t s, const blf::FastParams &P, int R0, bool H, int nchains) {
+    switch (R0) {
+        case 0: launch_fast_r<OM, MODE, 0>(s, P, H, nchains); break;
+        case 8: launch_fast_r<OM, MODE, 8>(s, P, H, nchains); break;
+        case 16: launch_fast_r<OM, MODE, 16>(s, P, H, nchains); break;
+        case 24: launch_fast_r<OM, MODE, 24>(s, P, H, nchains); break;
+        case 32: launch_fast_r<OM, MODE, 32>(s, P, H, nchains); break;
+        case 40: launch_fast_r<OM, MODE, 40>(s, P, H, nchains); break;
+        default: fail("fast path: bad radius bucket %d", R0);
+    }
+}
+
+void launch_fast(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, bool H, int nchains) {
+    if (om == BLHIP_OM_GAUSSIAN) {
+        if (mode == MODE_FWD) launch_fast_om<OM_GAUSSIAN, MODE_FWD>(s, P, R0, H, nchains);
+        else launch_fast_om<OM_GAUSSIAN, MODE_BWD>(s, P, R0, H, nchains);
+    } else {
+        if (mode == MODE_FWD) launch_fast_om<OM_TABLE, MODE_FWD>(s, P, R0, H, nchains);
+        else launch_fast_om<OM_TABLE, MODE_BWD>(s, P, R0, H, nchains);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+struct FastRange { int start, count, R0; bool H; };
+
+// chains of one step ordered by (axis-0 radius bucket, axis-1 filter present); one launch per non-empty group
+void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, int B, int *order, std::vector<FastRange> &ranges) {
+    int cnt[12] = {0};
+    auto key = [&](int b) {
+        const int l0 = tap0[b] >= 0 ? lw[tap0[b]] : 0;
+        const int bucket = l0 == 0 ? 0 : (l0 + 7) / 8;      // 0..5
+        return bucket * 2 + (tap1[b] >= 0 ? 1 : 0);
+    };
+    for (int b = 0; b < B; ++b) cnt[key(b)]++;
+    int start[12], acc = 0;
+    ranges.clear();
+    for (int k = 0; k < 12; ++k) {
+        start[k] = acc;
+        if (cnt[k]) ranges.push_back(FastRange{acc, cnt[k], (k / 2) * 8, (k & 1) != 0});
+        acc += cnt[k];
+    }
+    for (int b = 0; b < B; ++b) order[start[key(b)]++] = b;
 }
 
 void validate(const blhip_problem *p, int64_t n_chains, const double *op_values) {
@@ -452,18 +508,34 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         TapTable taps;
         ChainProgram prog;
         build_program(p, g, c0, B, op_values, taps, prog);
-        const Tile tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
+        // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
+        const bool fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
+                          ctx->option("fast", 1.0) != 0.0 && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX;
+        Tile tile{};
+        if (fast) {
+            tile.TI = blf::TI; tile.LW0 = prog.LW0; tile.LW1 = prog.LW1 > 0 ? blf::R1MAX : 0;
+            tile.TJ = blf::BW - 2 * tile.LW1;
+            tile.tiles_i = (g.n0 + tile.TI - 1) / tile.TI;
+            tile.tiles_j = (g.n1 + tile.TJ - 1) / tile.TJ;
+            tile.nblk = tile.tiles_i * tile.tiles_j;
+            tile.lds_bytes = 0;
+        } else {
+            tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
+        }
+        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : 0;
         ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
 
         // --- device metadata ---
         const size_t nT = (size_t)T * B;
-        size_t mb = 2 * carve_size(nT) + 4 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
+        taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
+        size_t mb = 2 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
                     2 * carve_size(taps.off.size() * 4 + 4) + 2 * carve_size(sizeof(double) * nT) + carve_size(8 * B);
         ctx->meta.ensure(mb);
         cur = ctx->meta.as<char>();
         unsigned char *d_kindF = carve<unsigned char>(cur, nT), *d_kindB = carve<unsigned char>(cur, nT);
         int *d_tapF0 = carve<int>(cur, nT), *d_tapF1 = carve<int>(cur, nT);
         int *d_tapB0 = carve<int>(cur, nT), *d_tapB1 = carve<int>(cur, nT);
+        int *d_orderF = carve<int>(cur, nT), *d_orderB = carve<int>(cur, nT);
         double *d_taps = carve<double>(cur, taps.w.size() + 1);
         int *d_off = carve<int>(cur, taps.off.size() + 1), *d_lw = carve<int>(cur, taps.off.size() + 1);
         double *d_invN = carve<double>(cur, nT);
@@ -477,6 +549,20 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             HIPCHECK(hipMemcpyAsync(d_kindB, prog.kindB.data(), nT, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_tapB1, prog.tapB1.data(), nT * 4, hipMemcpyHostToDevice, st));
+        }
+        std::vector<int> orderF, orderB;
+        std::vector<std::vector<FastRange>> rangesF, rangesB;
+        if (fast) {
+            orderF.resize(nT); rangesF.resize(T);
+            for (int64_t t = 0; t < T; ++t)
+                bucket_step(&prog.tapF0[t * B], &prog.tapF1[t * B], taps.lw, (int)B, &orderF[t * B], rangesF[t]);
+            HIPCHECK(hipMemcpyAsync(d_orderF, orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
+            if (full) {
+                orderB.resize(nT); rangesB.resize(T);
+                for (int64_t t = 0; t < T; ++t)
+                    bucket_step(&prog.tapB0[t * B], &prog.tapB1[t * B], taps.lw, (int)B, &orderB[t * B], rangesB[t]);
+                HIPCHECK(hipMemcpyAsync(d_orderB, orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
+            }
         }
         if (!taps.w.empty()) {
             HIPCHECK(hipMemcpyAsync(d_taps, taps.w.data(), taps.w.size() * 8, hipMemcpyHostToDevice, st));
@@ -506,23 +592,68 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         P.m0 = d_m0; P.m1 = d_m1; P.colA = d_colA; P.colB = d_colB; P.chains = (int)B;
         P.prev_nblk = tile.nblk;
 
+        blf::FastParams FP{};
+        if (fast) {
+            FP.n0 = g.n0; FP.n1 = g.n1; FP.TJ = tile.TJ; FP.LW1 = tile.LW1; FP.tiles_i = tile.tiles_i;
+            FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk; FP.swizzle = (tile.nblk % 8 == 0) ? 1 : 0;
+            FP.ndim = p->ndim; FP.d = d; FP.means = forward_only ? 1 : 0;
+            FP.shared[SRC_PREV] = nullptr; FP.shared[SRC_PRIOR] = d_prior; FP.shared[SRC_RESET] = d_reset;
+            FP.shared[SRC_UNIFORM] = d_uniform; FP.taps = d_taps; FP.tap_off = d_off; FP.tap_lw = d_lw;
+            FP.m0 = d_m0; FP.m1 = d_m1; FP.colA = d_colA; FP.colB = d_colB; FP.prev_nblk = tile.nblk;
+            // likelihood recurrence along rows needs an equally spaced row axis (to rounding)
+            const double *m0h = p->marginal[0];
+            const double step = (m0h[g.n0 - 1] - m0h[0]) / (double)(g.n0 - 1);
+            double dev = 0.0, mx = 0.0;
+            for (int i = 0; i < g.n0; ++i) {
+                dev = std::max(dev, std::fabs(m0h[i] - (m0h[0] + i * step)));
+                mx = std::max(mx, std::fabs(m0h[i]));
+            }
+            FP.step0 = step;
+            FP.use_rec = (p->obs_model == BLHIP_OM_GAUSSIAN && dev <= 8.0 * 2.3e-16 * mx && ctx->option("recurrence", 1.0) != 0.0) ? 1 : 0;
+        }
+        auto run_step = [&](int mode, int64_t t, const double *srcp, long long src_stride, double *dstp, long long dst_stride,
+                            double *postp, long long post_stride, const double *ps_prev, int prev_slot, double *ps_out,
+                            bool means) {
+            if (fast) {
+                blf::FastParams Q = FP;
+                Q.src = srcp; Q.src_stride = src_stride; Q.dst = dstp; Q.dst_stride = dst_stride;
+                Q.post = postp; Q.post_stride = post_stride;
+                Q.srckind = (mode == MODE_FWD ? d_kindF : d_kindB) + t * B;
+                Q.tap0 = (mode == MODE_FWD ? d_tapF0 : d_tapB0) + t * B;
+                Q.tap1 = (mode == MODE_FWD ? d_tapF1 : d_tapB1) + t * B;
+                Q.psum_prev = ps_prev; Q.prev_slot = prev_slot; Q.psum_out = ps_out;
+                Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
+                const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
+                for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
+                    Q.chain_ids = ord + r.start;
+                    launch_fast(st, p->obs_model, mode, Q, r.R0, r.H, r.count);
+                }
+            } else {
+                StepParams Q = P;
+                Q.src = srcp; Q.src_stride = src_stride; Q.dst = dstp; Q.dst_stride = dst_stride;
+                Q.post = postp; Q.post_stride = post_stride;
+                Q.srckind = (mode == MODE_FWD ? d_kindF : d_kindB) + t * B;
+                Q.tap0 = (mode == MODE_FWD ? d_tapF0 : d_tapB0) + t * B;
+                Q.tap1 = (mode == MODE_FWD ? d_tapF1 : d_tapB1) + t * B;
+                Q.psum_prev = ps_prev; Q.prev_slot = prev_slot; Q.psum_out = ps_out;
+                Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
+                launch_step(st, p->obs_model, Q, tile, (int)B, mode, means);
+            }
+        };
+
         // --- forward pass (core.py:372-411) ---
         HIPCHECK(hipEventRecord(ev[0], st));
         for (int64_t t = 0; t < T; ++t) {
-            StepParams Q = P;
+            const double *srcp; double *dstp; long long sstr, dstr;
             if (evidence_only) {
-                Q.src = d_pp[(t + 1) & 1]; Q.src_stride = G;
-                Q.dst = d_pp[t & 1]; Q.dst_stride = G;
+                srcp = d_pp[(t + 1) & 1]; sstr = G; dstp = d_pp[t & 1]; dstr = G;
             } else {
-                Q.src = d_post + (t > 0 ? (size_t)(t - 1) * G : 0); Q.src_stride = (long long)T * G;
-                Q.dst = d_post + (size_t)t * G; Q.dst_stride = (long long)T * G;
+                srcp = d_post + (t > 0 ? (size_t)(t - 1) * G : 0); sstr = (long long)T * G;
+                dstp = d_post + (size_t)t * G; dstr = (long long)T * G;
             }
-            Q.srckind = d_kindF + t * B; Q.tap0 = d_tapF0 + t * B; Q.tap1 = d_tapF1 + t * B;
-            Q.psum_prev = t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : d_psF; Q.prev_slot = 0;
-            Q.psum_out = d_psF + (size_t)t * B * NRED * tile.nblk;
-            Q.rec = d_rec + t * rec_len;
-            Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
-            launch_step(st, p->obs_model, Q, tile, (int)B, MODE_FWD, forward_only);
+            run_step(MODE_FWD, t, srcp, sstr, dstp, dstr, nullptr, 0,
+                     t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : d_psF, 0,
+                     d_psF + (size_t)t * B * NRED * tile.nblk, forward_only);
         }
         HIPCHECK(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
@@ -570,16 +701,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             double *d_psB = ctx->psumB.as<double>();
             HIPCHECK(hipEventRecord(ev[2], st));
             for (int64_t t = T - 1; t >= 0; --t) {
-                StepParams Q = P;
-                Q.src = d_pp[(t + 1) & 1]; Q.src_stride = G;          // c_{t+1}
-                Q.dst = d_pp[t & 1]; Q.dst_stride = G;                // c_t
-                Q.post = d_post + (size_t)t * G; Q.post_stride = (long long)T * G;
-                Q.srckind = d_kindB + t * B; Q.tap0 = d_tapB0 + t * B; Q.tap1 = d_tapB1 + t * B;
-                Q.psum_prev = t < T - 1 ? d_psB + (size_t)(t + 1) * B * NRED * tile.nblk : d_psB; Q.prev_slot = 2;
-                Q.psum_out = d_psB + (size_t)t * B * NRED * tile.nblk;
-                Q.rec = d_rec + t * rec_len;
-                Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
-                launch_step(st, p->obs_model, Q, tile, (int)B, MODE_BWD, true);
+                // reads c_{t+1} and the stored alpha_t, writes c_t and posterior_t
+                run_step(MODE_BWD, t, d_pp[(t + 1) & 1], G, d_pp[t & 1], G, d_post + (size_t)t * G, (long long)T * G,
+                         t < T - 1 ? d_psB + (size_t)(t + 1) * B * NRED * tile.nblk : d_psB, 2,
+                         d_psB + (size_t)t * B * NRED * tile.nblk, true);
             }
             HIPCHECK(hipEventRecord(ev[3], st));
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
@@ -673,8 +798,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
     float ms = 0;
     HIPCHECK(hipEventElapsedTime(&ms, ev[6], ev[7]));
     ctx->timing.total_ms = ms;
-    ctx->timing.fwd_kernel_variant = 0;
-    ctx->timing.bwd_kernel_variant = 0;
 }
 
 template <class F> int guarded(blhip_ctx *ctx, F &&f) {

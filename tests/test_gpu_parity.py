@@ -45,6 +45,22 @@ def test_hip_matches_reference_golden(case):
     compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL, case_tol=cases.CASES[case].get('tol'))
 
 
+@pytest.mark.parametrize('option', ['fast', 'recurrence'])
+@pytest.mark.parametrize('case', ['c3_small', 'c3_missing', 'multidim_data', 'c4_small', 'c5_cp_grw', 'c3_forward_only'])
+def test_alternative_kernel_paths_match_golden(case, option):
+    """The generic LDS-tile kernel (fast=0) and the exact-exp likelihood (recurrence=0) on the 2-D cases."""
+    eng = bl.get_engine()
+    eng.set_option(option, 0)
+    try:
+        S = cases.build(bl, case)
+        S.fit(**cases.fit_kwargs(case))
+        if option == 'fast':
+            assert S.lastTiming['fwd_kernel_variant'] == 0
+        compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL, case_tol=cases.CASES[case].get('tol'))
+    finally:
+        eng.set_option(option, 1)
+
+
 EXTRA = {
     # seeded inputs beyond the fixtures: ragged grid sizes (tile remainders), wide/narrow filters, 1-D and 2-D
     'x_ragged_2d': dict(study='Study', data=('series', 21, 14), om=cases.gauss2d(131, -5, 5, 3),
