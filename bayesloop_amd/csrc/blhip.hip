@@ -206,8 +206,15 @@ constexpr int FAST_R0_MAX = 40;
 
 template <int OM, int MODE, int R0>
 void launch_fast_r(hipStream_t s, const blf::FastParams &P, bool H, int nchains) {
-    if (H) hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, true>), dim3(P.nblk, nchains), dim3(NTHREADS), 0, s, P);
-    else hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, false>), dim3(P.nblk, nchains), dim3(NTHREADS), 0, s, P);
+    constexpr bool G = OM == OM_GAUSSIAN;
+    const dim3 grid(P.nblk, nchains), block(NTHREADS);
+    if (G && P.use_rec) {
+        if (H) hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, true, G>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, false, G>), grid, block, 0, s, P);
+    } else {
+        if (H) hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, true, false>), grid, block, 0, s, P);
+        else hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, false, false>), grid, block, 0, s, P);
+    }
 }
 
 template <int OM, int MODE>
@@ -510,14 +517,34 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         build_program(p, g, c0, B, op_values, taps, prog);
         // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
         const bool fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
-                          ctx->option("fast", 1.0) != 0.0 && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX;
+                          ctx->option("fast", 1.0) != 0.0 && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
+                          g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
         Tile tile{};
+        int fastS = 0, fast_nseg = 1;
         if (fast) {
-            tile.TI = blf::TI; tile.LW0 = prog.LW0; tile.LW1 = prog.LW1 > 0 ? blf::R1MAX : 0;
+            tile.TI = blf::CH; tile.LW0 = prog.LW0; tile.LW1 = prog.LW1 > 0 ? blf::R1MAX : 0;
             tile.TJ = blf::BW - 2 * tile.LW1;
-            tile.tiles_i = (g.n0 + tile.TI - 1) / tile.TI;
             tile.tiles_j = (g.n1 + tile.TJ - 1) / tile.TJ;
-            tile.nblk = tile.tiles_i * tile.tiles_j;
+            // rows per block segment: long segments read every element once (+ 2*R0 halo rows per segment), short ones
+            // give enough blocks to fill 256 CUs when there are few chains.  Model: cost = waves * blocks_per_CU * rows.
+            const long long colblocks = (long long)tile.tiles_j * B;
+            const int R0 = prog.LW0 == 0 ? 0 : ((prog.LW0 + 7) / 8) * 8;
+            double best = 1e300;
+            const int forceS = (int)ctx->option("fast_S", 0);
+            for (int k = 1; k <= 4; k *= 2) {
+                const double pen = k == 1 ? 1.6 : (k == 2 ? 1.15 : 1.0);
+                for (int ns = 1; ns <= std::max(1, g.n0 / 16); ++ns) {
+                    int S = ((g.n0 + ns - 1) / ns + blf::CH - 1) / blf::CH * blf::CH;
+                    const int real = (g.n0 + S - 1) / S;
+                    const long long blocks = colblocks * real;
+                    const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
+                    const double cost = pen * (double)waves * k * (S + 2.0 * R0 + 4.0);
+                    if (cost < best - 1e-9) { best = cost; fastS = S; fast_nseg = real; }
+                }
+            }
+            if (forceS > 0) { fastS = (forceS + blf::CH - 1) / blf::CH * blf::CH; fast_nseg = (g.n0 + fastS - 1) / fastS; }
+            tile.tiles_i = fast_nseg;
+            tile.nblk = tile.tiles_j * fast_nseg;
             tile.lds_bytes = 0;
         } else {
             tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
@@ -594,8 +621,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
 
         blf::FastParams FP{};
         if (fast) {
-            FP.n0 = g.n0; FP.n1 = g.n1; FP.TJ = tile.TJ; FP.LW1 = tile.LW1; FP.tiles_i = tile.tiles_i;
-            FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk; FP.swizzle = (tile.nblk % 8 == 0) ? 1 : 0;
+            FP.n0 = g.n0; FP.n1 = g.n1; FP.TJ = tile.TJ; FP.S = fastS; FP.nseg = fast_nseg;
+            FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk;
             FP.ndim = p->ndim; FP.d = d; FP.means = forward_only ? 1 : 0;
             FP.shared[SRC_PREV] = nullptr; FP.shared[SRC_PRIOR] = d_prior; FP.shared[SRC_RESET] = d_reset;
             FP.shared[SRC_UNIFORM] = d_uniform; FP.taps = d_taps; FP.tap_off = d_off; FP.tap_lw = d_lw;

@@ -1,17 +1,21 @@
-// Fast fused step kernels for 2-D grids (gfx950).  Same math as blk::step_kernel (blhip_kernels.hpp), organised for
-// the MI355X memory system and its fp64 VALU budget:
+// Fast fused step kernels for 2-D grids (gfx950): the STREAMING COLUMN kernel.
+// Same math as blk::step_kernel (blhip_kernels.hpp), organised for the MI355X memory system and fp64 VALU budget:
 //
-//  * a thread OWNS ONE GRID COLUMN of a (TI x 256) tile.  It loads its column strip (TI + 2*R0 rows) straight from
-//    HBM/L2 into registers -- consecutive lanes read consecutive doubles, so every load instruction is one fully
-//    coalesced 512-B wave access and all TI + 2*R0 loads of a thread are in flight together -- and runs the axis-0
-//    (row) stencil out of registers with a compile-time radius bucket R0 (weights in SGPRs).
-//  * the axis-1 (column) stencil needs neighbouring columns: the row-filtered values go through one LDS tile
-//    (TI x 256 doubles = 32 KiB, conflict-free ds_read_b64), halo columns are owned by halo threads of the same block.
-//  * the Gaussian likelihood is NOT evaluated with one exp per cell: along a column the exponent is a quadratic in the
-//    row index, so L(row) follows a second-order multiplicative recurrence.  It is carried as mantissa * 2^exponent
-//    (three fp64 multiplies + one v_ldexp per cell), which can neither overflow nor lose a value to underflow on the
-//    way towards the likelihood peak; three exps per column per tile re-anchor it (error << 1e-12 relative).
-//  * lazy normalisation, per-block partial sums and the XCD-aware tile order are as in DESIGN.md.
+//  * a block owns a strip of 256 grid columns (240 useful + 2 x 8 halo lanes when the launch has an axis-1 filter) and
+//    a SEGMENT of S rows; a thread owns ONE COLUMN and walks down the segment in chunks of CH = 8 rows.
+//  * every load is one fully coalesced 512-B wave access (consecutive lanes = consecutive doubles of a grid row).
+//    The thread keeps a sliding window of 2*R0 + CH rows of its column in registers (R0 = compile-time radius bucket of
+//    the axis-0 stencil), so each state element is read ONCE per step (plus 2*R0 rows per segment), and the loads of
+//    chunk k+1 are issued before the arithmetic of chunk k starts: HBM latency hides under the fp64 work of the same
+//    wave instead of relying on other waves that would be in the same phase anyway.
+//  * axis-0 (row) stencil: out of the register window, weights in SGPRs, SciPy's symmetric correlate1d order.
+//  * axis-1 (column) stencil: the row-filtered chunk goes through one LDS tile (CH x 257 doubles, conflict-free
+//    ds_read_b64); halo columns are owned by the halo lanes of the same block (reflect boundary via the column index).
+//  * Gaussian likelihood WITHOUT an exp per cell: along a column the exponent is a quadratic in the row index, so
+//    L(row) follows a second-order multiplicative recurrence, carried as mantissa * 2^exponent (cannot overflow, and
+//    cannot lose a value to underflow on the way towards the likelihood peak); re-anchored every 16 rows with exact
+//    exponentials (error << 1e-12 relative).  p / L of the backward pass uses the reciprocal recurrence: no division.
+//  * lazy normalisation and deterministic per-block partial sums as in blk::step_kernel.
 //
 // Algorithmic HBM traffic per cell and step: forward 16 B (read state, write state), backward 32 B.
 #pragma once
@@ -23,16 +27,16 @@ using blk::NRED;
 using blk::NTHREADS;
 using blk::SRC_PREV;
 
-constexpr int TI = 16;          // rows per tile
-constexpr int BW = NTHREADS;    // columns per tile including the axis-1 halo
+constexpr int CH = 8;           // rows per chunk
+constexpr int BW = NTHREADS;    // columns per block including the axis-1 halo lanes
 constexpr int R1MAX = 8;        // largest axis-1 radius of the fast path
+constexpr int ANCHOR = 16;      // rows between exact re-anchorings of the likelihood recurrence
 
 struct FastParams {
     int n0, n1;
-    int TJ;                      // useful columns per tile = BW - 2*LW1 (same for every launch of a batch)
-    int LW1;                     // axis-1 halo lanes on each side of a tile: R1MAX if the batch has an axis-1 filter, else 0
-    int tiles_i, tiles_j, nblk;
-    int swizzle;                 // 1: XCD-aware tile order (nblk % 8 == 0)
+    int TJ;                      // useful columns per block: BW - 2*R1MAX if the batch has an axis-1 filter, else BW
+    int S;                       // rows per segment (multiple of CH)
+    int nseg, tiles_j, nblk;     // nblk = nseg * tiles_j blocks per chain
     int ndim, d, means, use_rec;
     double step0;                // lattice step of the row axis (likelihood recurrence)
     const double *src;  long long src_stride;
@@ -47,6 +51,14 @@ struct FastParams {
     double *psum_out;
     const double *m0, *m1, *colA, *colB, *rec, *lik;
 };
+
+// Pin a wave-uniform double into SGPRs (the compiler cannot prove that the tap table is not aliased by the stores,
+// so without this the stencil weights occupy 2 VGPRs each).
+__device__ __forceinline__ double uniform(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
 
 // exp(a) = m * 2^n with m in [0.70, 1.42]; never overflows / underflows.  |error| < 2e-16 relative.
 __device__ __forceinline__ void exp_mn(double a, double &m, int &n) {
@@ -72,190 +84,267 @@ __device__ __forceinline__ void exp_mn(double a, double &m, int &n) {
     n = (int)kn;
 }
 
-// Likelihood along one column as a recurrence over rows: L(i0 + r) = mE * 2^nE, advanced by step().
-struct GaussRec {
-    double mE, mR, mq;       // value, ratio to the next row, ratio of ratios (mantissas)
-    int nE, nR, nq;          // their binary exponents
-    double iE, iR, iq;       // mantissas of the reciprocals (backward pass: p / L without a division)
+// wave-uniform read-only tables go through the scalar cache (s_load): no VGPRs, no vmcnt traffic
+typedef const double __attribute__((address_space(4))) *cdptr;
+typedef const int __attribute__((address_space(4))) *ciptr;
+__device__ __forceinline__ double sld(const double *p, long long i) { return ((cdptr)(unsigned long long)p)[i]; }
+__device__ __forceinline__ int sldi(const int *p, long long i) { return ((ciptr)(unsigned long long)p)[i]; }
 
-    template <bool INV>
-    __device__ __forceinline__ void init(const FastParams &P, int i0, double cA, double cB) {
-        // arg(r) = sum_k [ -(x_k - mu_r)^2 cA - cB ]   (observationModels.py:566-567, product over data dimensions :49-50)
-        // first difference  arg(1)-arg(0) = cA (mu_1 - mu_0) sum_k (2 x_k - mu_0 - mu_1)
-        // second difference                = -2 cA dn step^2      (regular grid)
-        const int i1 = min(i0 + 1, P.n0 - 1);
-        const double mu0 = P.m0[i0], mu1 = P.m0[i1];
-        double a0 = 0.0, s1 = 0.0, dn = 0.0;
-        for (int k = 0; k < P.d; ++k) {
-            const double x = P.rec[k];
-            if (x == x) {
-                const double q = x - mu0;
-                a0 = fma(-(q * q), cA, a0) - cB;
-                s1 += (x - mu0) + (x - mu1);
-                dn += 1.0;
-            }
-        }
-        const double d1 = cA * (mu1 - mu0) * s1;
-        const double d2 = -2.0 * cA * dn * P.step0 * P.step0;
-        exp_mn(a0, mE, nE);
-        exp_mn(d1, mR, nR);                        // ratio L(1)/L(0)
-        exp_mn(d2, mq, nq);
-        if (INV) {
-            int t;
-            exp_mn(-a0, iE, t);
-            exp_mn(-d1, iR, t);
-            exp_mn(-d2, iq, t);
-        }
-    }
-    __device__ __forceinline__ double value() const { return ldexp(mE, nE); }
-    // p / L with L = mE 2^nE, without forming 1/L (which may overflow while p/L does not)
-    __device__ __forceinline__ double divide(double p, double L) const {
-        return L == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
-    }
-    template <bool INV>
-    __device__ __forceinline__ void step() {
-        mE *= mR; nE += nR;
-        mR *= mq; nR += nq;
-        if (INV) { iE *= iR; iR *= iq; }
-    }
-};
+// single-period half-sample reflection, branch-free (the host guarantees |offset| < n for every use in the fast path)
+__device__ __forceinline__ int reflect1(int i, int n) {
+    i = i < 0 ? -1 - i : i;
+    i = i >= n ? 2 * n - 1 - i : i;
+    return min(max(i, 0), n - 1);
+}
 
-template <int OM, int MODE, int R0, bool H>
-__global__ __launch_bounds__(NTHREADS) void fast_step_kernel(const FastParams P) {
+constexpr int DMAX = 4;         // data dimensions kept in registers
+
+#ifndef BL_MINW
+#define BL_MINW 1
+#endif
+
+template <int OM, int MODE, int R0, bool H, bool REC>
+__global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_kernel(const FastParams P) {
     constexpr bool BWD = MODE == blk::MODE_BWD;
-    constexpr int NROW = TI + 2 * R0;
-    __shared__ __attribute__((aligned(16))) double vt[H ? TI * (BW + 1) : 1];
+    constexpr bool GAUSS = OM == blk::OM_GAUSSIAN;
+    constexpr int WIN = 2 * R0 + CH;
+    __shared__ __attribute__((aligned(16))) double vt[H ? CH * (BW + 1) : 1];
     __shared__ double red[NTHREADS / 64 + 1];
 
-    const int b = P.chain_ids[blockIdx.y];
-    int tile = blockIdx.x;
-    if (P.swizzle) {                              // XCD-aware order: block x runs on XCD x % 8; give each XCD a
-        const int per = P.nblk >> 3;              // contiguous range of tiles so that row-halo re-reads hit its L2
-        tile = (tile & 7) * per + (tile >> 3);
-    }
-    const int tj = tile / P.tiles_i, ti = tile - tj * P.tiles_i;     // consecutive tiles are vertical neighbours
-    const int i0 = ti * TI, j0 = tj * P.TJ;
+    const int b = sldi(P.chain_ids, blockIdx.y);
+    const int blkid = blockIdx.x;
+    const int tj = blkid / P.nseg, seg = blkid - tj * P.nseg;
+    const int i_lo = seg * P.S, i_hi = min(P.n0, i_lo + P.S);
+    const int j0 = tj * P.TJ;
     const int tid = threadIdx.x;
 
-    const int kind = P.srckind[b];
-    const int t0 = P.tap0[b];
-    const int lw0 = (R0 > 0 && t0 >= 0) ? P.tap_lw[t0] : 0;
+    const int kind = ((const unsigned char __attribute__((address_space(4))) *)(unsigned long long)P.srckind)[b];
+    const int t0 = sldi(P.tap0, b);
+    const int lw0 = (R0 > 0 && t0 >= 0) ? sldi(P.tap_lw, t0) : 0;
     const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
 
     // ---- this thread's column ------------------------------------------------------------------------------------
     const int jc = j0 - (H ? R1MAX : 0) + tid;                 // grid column (may lie in the halo / outside)
-    const int gj = blk::reflect(jc, P.n1);
+    const int gj = reflect1(jc, P.n1);
     const bool owner = H ? (tid >= R1MAX && tid < R1MAX + P.TJ && jc < P.n1) : (tid < P.TJ && jc < P.n1);
+    const double *col = src + gj;
 
-    // ---- column strip -> registers (coalesced: lanes = consecutive columns) -----------------------------------------
-    double x[NROW];
+    // ---- prologue: first window of the column, then the lazy normaliser while those loads are in flight -----------
+    double w[WIN];
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) {
-        const int gi = blk::reflect(i0 - R0 + k, P.n0);
-        x[k] = src[(long long)gi * P.n1 + gj];
-    }
+    for (int k = 0; k < WIN; ++k) w[k] = col[(long long)reflect1(i_lo - R0 + k, P.n0) * P.n1];
 
-    // ---- lazy normaliser of the producing step ------------------------------------------------------------------------
     double scale = 1.0;
     if (kind == SRC_PREV) {
         const double s = blk::sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
         scale = 1.0 / s;
     }
 
-    // ---- axis-0 stencil out of registers (SciPy's symmetric correlate1d order, zero weights beyond lw0) ------------
-    double v[TI];
-    if (R0 > 0 && lw0 > 0) {
-        const double *w = P.taps + P.tap_off[t0];
-        double wk[R0 + 1];
+    // stencil weights (SGPRs), zero beyond this chain's radius
+    double wk[R0 + 1];
+    if (R0 > 0) {
+        const long long o0 = t0 >= 0 ? sldi(P.tap_off, t0) : 0;
 #pragma unroll
-        for (int k = 0; k <= R0; ++k) wk[k] = k <= lw0 ? w[k] : 0.0;
-#pragma unroll
-        for (int r = 0; r < TI; ++r) {
-            double acc = x[r + R0] * wk[0];
-#pragma unroll
-            for (int k = R0; k >= 1; --k) acc = fma(x[r + R0 - k] + x[r + R0 + k], wk[k], acc);
-            v[r] = acc;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < TI; ++r) v[r] = x[r + R0];
+        for (int k = 0; k <= R0; ++k) wk[k] = (lw0 > 0 && k <= lw0) ? sld(P.taps, o0 + k) : (k == 0 ? 1.0 : 0.0);
     }
-
-    // ---- axis-1 stencil through LDS -------------------------------------------------------------------------------------
     double w1[R1MAX + 1];
-    int lw1 = 0;
     if (H) {
-        const int t1 = P.tap1[b];
-        lw1 = t1 >= 0 ? P.tap_lw[t1] : 0;
-        const double *w = P.taps + (t1 >= 0 ? P.tap_off[t1] : 0);
+        const int t1 = sldi(P.tap1, b);
+        const int lw1 = t1 >= 0 ? sldi(P.tap_lw, t1) : 0;
+        const long long o1 = t1 >= 0 ? sldi(P.tap_off, t1) : 0;
 #pragma unroll
-        for (int k = 0; k <= R1MAX; ++k) w1[k] = (t1 >= 0 && k <= lw1) ? w[k] : (k == 0 ? 1.0 : 0.0);
-#pragma unroll
-        for (int r = 0; r < TI; ++r) vt[r * (BW + 1) + tid] = v[r];
-        __syncthreads();
+        for (int k = 0; k <= R1MAX; ++k) w1[k] = (t1 >= 0 && k <= lw1) ? sld(P.taps, o1 + k) : (k == 0 ? 1.0 : 0.0);
     }
+    // data of this step (NaN = missing, observationModels.py:53-54)
+    double xd[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) xd[k] = (GAUSS && k < P.d) ? sld(P.rec, k) : __builtin_nan("");
 
-    // ---- epilogue: likelihood, products, partial sums -----------------------------------------------------------------
+    const double g1 = P.m1[gj];
+    double cA = 0.0, cB = 0.0;
+    if (GAUSS) { cA = P.colA[gj]; cB = P.colB[gj]; }
+    // land the per-column table values (and the window) BEFORE the loop: a first use inside the loop would make the
+    // compiler wait with vmcnt(0) there, i.e. drain the prefetch of the next chunk every iteration
+    asm volatile("" : "+v"(cA), "+v"(cB) : "v"(g1), "v"(scale), "v"(w[WIN - 1]));
+
+    // likelihood recurrence state (REC): L = mE 2^nE, ratio mR 2^nR, curvature mq 2^nq; reciprocals for the backward pass
+    double mE = 1.0, mR = 1.0, mq = 1.0, iE = 1.0, iR = 1.0, iq = 1.0;
+    int nE = 0, nR = 0, nq = 0;
     double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
-    if (owner) {
-        const double g1 = P.m1[gj];
-        double cA = 0.0, cB = 0.0;
-        GaussRec L;
-        if (OM == blk::OM_GAUSSIAN) {
-            cA = P.colA[gj]; cB = P.colB[gj];
-            if (P.use_rec) L.template init<BWD>(P, i0, cA, cB);
+    double *dcol = P.dst + (long long)b * P.dst_stride + gj;
+    double *pcol = BWD ? P.post + (long long)b * P.post_stride + gj : nullptr;
+    const double *lcol = (!GAUSS) ? P.lik + gj : nullptr;
+
+    // ---- software pipeline: while chunk c is computed, the CH rows that enter the window for chunk c+1 are in flight ----
+    for (int i = i_lo; i < i_hi; i += CH) {
+        // loads in consumption order: this chunk's stored alpha / tabulated likelihood first, then the prefetch, so that
+        // waiting for the former (vmcnt is in-order) leaves the prefetch in flight during the arithmetic
+        double al[CH], lk[CH];
+        if (BWD) {
+#pragma unroll
+            for (int r = 0; r < CH; ++r) al[r] = pcol[(long long)min(i + r, P.n0 - 1) * P.n1];
         }
+        if (!GAUSS) {
 #pragma unroll
-        for (int r = 0; r < TI; ++r) {
-            const int gi = i0 + r;
-            double o;
+            for (int r = 0; r < CH; ++r) lk[r] = lcol[(long long)min(i + r, P.n0 - 1) * P.n1];
+        }
+        double nx[CH];
+        const bool more = i + CH < i_hi;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) nx[k] = col[(long long)reflect1(i + CH + R0 + k, P.n0) * P.n1];
+        }
+
+        // ---- axis-0 stencil out of the register window: the CH rows are independent accumulator chains, interleaved
+        //      tap by tap so that consecutive fp64 instructions never depend on each other (per-row order = SciPy's) ------
+        double v[CH];
+#ifdef BL_ABL_NOVERT
+        if (false) {
+#else
+        if (R0 > 0) {
+#endif
+#pragma unroll
+            for (int r = 0; r < CH; ++r) v[r] = w[r + R0] * wk[0];
+#pragma unroll
+            for (int k = R0; k >= 1; --k) {
+                double t[CH];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) t[r] = w[r + R0 - k] + w[r + R0 + k];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) v[r] = fma(t[r], wk[k], v[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < CH; ++r) v[r] = w[r + R0];
+        }
+
+        // ---- axis-1 stencil through LDS ---------------------------------------------------------------------------------
+        if (H) {
+#pragma unroll
+            for (int r = 0; r < CH; ++r) vt[r * (BW + 1) + tid] = v[r];
+            __syncthreads();
+        }
+
+        // ---- re-anchor the likelihood recurrence with exact exponentials every ANCHOR rows ------------------------------
+        if (GAUSS && REC && ((i - i_lo) % ANCHOR) == 0) {
+            // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
+            // arg(1) - arg(0) = cA (mu_1 - mu_0) sum_k (2 x_k - mu_0 - mu_1);  second difference = -2 cA dn step^2
+            const double mu0 = sld(P.m0, min(i, P.n0 - 1)), mu1 = sld(P.m0, min(i + 1, P.n0 - 1));
+            double a0 = 0.0, s1 = 0.0, dn = 0.0;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                const double x = xd[k];
+                if (x == x) {
+                    const double q = x - mu0;
+                    a0 = fma(-(q * q), cA, a0) - cB;
+                    s1 += (x - mu0) + (x - mu1);
+                    dn += 1.0;
+                }
+            }
+            const double d1 = cA * (mu1 - mu0) * s1;
+            const double d2 = -2.0 * cA * dn * P.step0 * P.step0;
+            exp_mn(a0, mE, nE);
+            exp_mn(d1, mR, nR);
+            exp_mn(d2, mq, nq);
+            if (BWD) {
+                int t;
+                exp_mn(-a0, iE, t);
+                exp_mn(-d1, iR, t);
+                exp_mn(-d2, iq, t);
+            }
+        }
+
+        // ---- epilogue (straight-line: no loads besides LDS); rows in pairs so that two independent chains interleave ----
+#pragma unroll
+        for (int r2 = 0; r2 < CH; r2 += 2) {
+            double o[2];
             if (H) {
-                const double *cen = vt + r * (BW + 1) + tid;
-                o = cen[0] * w1[0];
+                const double *cen = vt + r2 * (BW + 1) + min(max(tid, R1MAX), BW - 1 - R1MAX) - R1MAX;
+                double c0[2 * R1MAX + 1], c1[2 * R1MAX + 1];
 #pragma unroll
-                for (int k = R1MAX; k >= 1; --k) o = fma(cen[-k] + cen[k], w1[k], o);   // halo lanes exist: tid in [R1MAX, R1MAX+TJ)
-            } else {
-                o = v[r];
-            }
-            double Lv;
-            if (OM == blk::OM_GAUSSIAN && P.use_rec) {
-                Lv = L.value();
-            } else if (OM == blk::OM_GAUSSIAN) {
-                Lv = 1.0;
-                const double mu = P.m0[min(gi, P.n0 - 1)];
-                for (int k = 0; k < P.d; ++k) {
-                    const double xx = P.rec[k];
-                    if (xx == xx) { const double q = xx - mu; Lv *= exp(-(q * q) * cA - cB); }
+#ifdef BL_ABL_NOLDSREAD
+                for (int k = 0; k <= 2 * R1MAX; ++k) { c0[k] = cen[R1MAX] + k; c1[k] = cen[(BW + 1) + R1MAX] - k; }
+#else
+                for (int k = 0; k <= 2 * R1MAX; ++k) { c0[k] = cen[k]; c1[k] = cen[(BW + 1) + k]; }   // all LDS reads in flight
+#endif
+                o[0] = c0[R1MAX] * w1[0];
+                o[1] = c1[R1MAX] * w1[0];
+#pragma unroll
+                for (int k = R1MAX; k >= 1; --k) {
+                    const double t0 = c0[R1MAX - k] + c0[R1MAX + k];
+                    const double t1 = c1[R1MAX - k] + c1[R1MAX + k];
+                    o[0] = fma(t0, w1[k], o[0]);
+                    o[1] = fma(t1, w1[k], o[1]);
                 }
             } else {
-                Lv = gi < P.n0 ? P.lik[(long long)gi * P.n1 + gj] : 1.0;
+                o[0] = v[r2]; o[1] = v[r2 + 1];
             }
-            if (gi < P.n0) {
-                const long long cell = (long long)gi * P.n1 + gj;
-                if (!BWD) {
-                    const double a = o * scale * Lv;
-                    P.dst[(long long)b * P.dst_stride + cell] = a;
-                    sN += a;
-                    if (P.means) { sM0 = fma(a, P.m0[gi], sM0); sM1 = fma(a, g1, sM1); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = r2 + q;
+                const int gi = i + r;
+                double Lv;
+                if (GAUSS && REC) {
+                    Lv = ldexp(mE, nE);
+                } else if (GAUSS) {
+                    Lv = 1.0;
+                    const double mu = sld(P.m0, min(gi, P.n0 - 1));
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) {
+                        const double xx = xd[k];
+                        if (xx == xx) { const double dq = xx - mu; Lv *= exp(-(dq * dq) * cA - cB); }
+                    }
                 } else {
-                    const double beta = o * scale;
-                    double *pp = P.post + (long long)b * P.post_stride + cell;
-                    const double p = (*pp) * beta;
-                    *pp = p;
+                    Lv = lk[r];
+                }
+                const bool live = owner && gi < i_hi;
+                const long long off = (long long)gi * P.n1;
+                if (!BWD) {
+                    const double a = o[q] * scale * Lv;
+                    if (live) {
+#ifndef BL_ABL_NOSTORE
+                        dcol[off] = a;
+#else
+                        if (a == 1.2345e300) dcol[off] = a;
+#endif
+                        sN += a;
+                        if (P.means) { sM0 = fma(a, sld(P.m0, min(gi, P.n0 - 1)), sM0); sM1 = fma(a, g1, sM1); }
+                    }
+                } else {
+                    const double beta = o[q] * scale;
+                    const double p = al[r] * beta;
                     const double cn = beta * Lv;
-                    P.dst[(long long)b * P.dst_stride + cell] = cn;
-                    sN += p;
-                    sS += (OM == blk::OM_GAUSSIAN && P.use_rec) ? L.divide(p, Lv) : p / Lv;     // 0/0 -> NaN (core.py:463)
-                    sC += cn;
-                    sM0 = fma(p, P.m0[gi], sM0);
-                    sM1 = fma(p, g1, sM1);
+                    // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
+                    const double pl = (GAUSS && REC) ? (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)) : p / Lv;
+                    if (live) {
+                        pcol[off] = p;
+                        dcol[off] = cn;
+                        sN += p;
+                        sS += pl;
+                        sC += cn;
+                        sM0 = fma(p, sld(P.m0, min(gi, P.n0 - 1)), sM0);
+                        sM1 = fma(p, g1, sM1);
+                    }
+                }
+                if (GAUSS && REC) {
+                    mE *= mR; nE += nR;
+                    mR *= mq; nR += nq;
+                    if (BWD) { iE *= iR; iR *= iq; }
                 }
             }
-            if (OM == blk::OM_GAUSSIAN && P.use_rec) L.template step<BWD>();
+        }
+
+        // ---- slide the window ---------------------------------------------------------------------------------------------
+        if (more) {
+            if (H) __syncthreads();          // everyone is done reading vt before the next chunk overwrites it
+#pragma unroll
+            for (int k = 0; k < 2 * R0; ++k) w[k] = w[k + CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) w[2 * R0 + k] = nx[k];
         }
     }
 
-    double *out = P.psum_out + (long long)b * NRED * P.nblk + tile;
+    double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
     const double r0 = blk::block_sum(sN, red);
     if (tid == 0) out[0] = r0;
     if (BWD) {
