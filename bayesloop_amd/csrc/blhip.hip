@@ -244,14 +244,29 @@ void launch_fast(hipStream_t s, int om, int mode, const blf::FastParams &P, int 
 struct FastRange { int start, count, R0; bool H; };
 
 // chains of one step ordered by (axis-0 radius bucket, axis-1 filter present); one launch per non-empty group
-void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, int B, int *order, std::vector<FastRange> &ranges) {
+void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, int B, int *order, std::vector<FastRange> &ranges,
+                 int min_chains) {
     int cnt[12] = {0};
-    auto key = [&](int b) {
+    int promote[12];
+    for (int k = 0; k < 12; ++k) promote[k] = k;
+    auto key0 = [&](int b) {
         const int l0 = tap0[b] >= 0 ? lw[tap0[b]] : 0;
         const int bucket = l0 == 0 ? 0 : (l0 + 7) / 8;      // 0..5
         return bucket * 2 + (tap1[b] >= 0 ? 1 : 0);
     };
-    for (int b = 0; b < B; ++b) cnt[key(b)]++;
+    auto key = [&](int b) { int k = key0(b); while (promote[k] != k) k = promote[k]; return k; };
+    for (int b = 0; b < B; ++b) cnt[key0(b)]++;
+    // a bucket with only a few chains cannot fill the chip: promote its chains to the next larger radius bucket
+    // (zero-padded weights make that exact); keys are bucket*2 + H
+    for (int h = 0; h < 2; ++h)
+        for (int bk = 0; bk < 5; ++bk) {
+            const int k = bk * 2 + h;
+            if (cnt[k] > 0 && cnt[k] < min_chains) {
+                int up = -1;
+                for (int b2 = bk + 1; b2 < 6; ++b2) if (cnt[b2 * 2 + h] > 0) { up = b2 * 2 + h; break; }
+                if (up >= 0) { promote[k] = up; cnt[up] += cnt[k]; cnt[k] = 0; }
+            }
+        }
     int start[12], acc = 0;
     ranges.clear();
     for (int k = 0; k < 12; ++k) {
@@ -580,14 +595,16 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         std::vector<int> orderF, orderB;
         std::vector<std::vector<FastRange>> rangesF, rangesB;
         if (fast) {
+            // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle
+            const int min_chains = (int)std::min<long long>(B, (128 + (long long)tile.nblk - 1) / tile.nblk);
             orderF.resize(nT); rangesF.resize(T);
             for (int64_t t = 0; t < T; ++t)
-                bucket_step(&prog.tapF0[t * B], &prog.tapF1[t * B], taps.lw, (int)B, &orderF[t * B], rangesF[t]);
+                bucket_step(&prog.tapF0[t * B], &prog.tapF1[t * B], taps.lw, (int)B, &orderF[t * B], rangesF[t], min_chains);
             HIPCHECK(hipMemcpyAsync(d_orderF, orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
             if (full) {
                 orderB.resize(nT); rangesB.resize(T);
                 for (int64_t t = 0; t < T; ++t)
-                    bucket_step(&prog.tapB0[t * B], &prog.tapB1[t * B], taps.lw, (int)B, &orderB[t * B], rangesB[t]);
+                    bucket_step(&prog.tapB0[t * B], &prog.tapB1[t * B], taps.lw, (int)B, &orderB[t * B], rangesB[t], min_chains);
                 HIPCHECK(hipMemcpyAsync(d_orderB, orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
             }
         }
