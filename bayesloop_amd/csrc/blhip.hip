@@ -798,9 +798,15 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 HIPCHECK(hipMemcpyAsync(d_w, w.data(), B * 8, hipMemcpyHostToDevice, st));
                 HIPCHECK(hipMemcpyAsync(d_invN, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
                 HIPCHECK(hipEventRecord(ev[4], st));
-                const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-                hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
-                                   (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
+                if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
+                    const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
+                    hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
+                                       (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
+                } else {
+                    const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+                    hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
+                                       (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
+                }
                 HIPCHECK(hipEventRecord(ev[5], st));
                 HIPCHECK(hipStreamSynchronize(st));
                 HIPCHECK(hipEventElapsedTime(&ms, ev[4], ev[5]));

@@ -146,13 +146,19 @@ def main():
 
     comm = None
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('BLHIP_FORCE_DIST') == '1'      # exercise the RCCL path with a single rank (tests)
+    if force_dist and world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     import bayesloop_amd as bl
-    if world > 1:
+    if world > 1 or force_dist:
         comm = bl.dist.TorchCommunicator()
 
     def barrier():
@@ -173,6 +179,7 @@ def main():
     S._posterior_pending = None      # results stay on the device; nothing is copied back
     eng.release_posterior()
 
+    out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = units * args.steps / dt
@@ -207,10 +214,12 @@ def main():
             out['extra'] = extra
         if not args.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)       # the ONE JSON line, last on stdout
 
 
 if __name__ == '__main__':

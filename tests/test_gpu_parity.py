@@ -208,3 +208,37 @@ def test_linearity_of_transition_filter_only():
     S.set(bl.om.GaussianMean('mean', grid, prior=prior), bl.tm.GaussianRandomWalk('sigma', 2.3, target='mean'), silent=True)
     S.fit(forwardOnly=True, silent=True)
     np.testing.assert_allclose(S.posteriorSequence[1], want[0], rtol=1e-13, atol=1e-300)
+
+
+def test_rccl_path_single_rank():
+    """The multi-GPU code path (torch.distributed 'nccl' = RCCL, accumulator in a torch CUDA tensor handed to libblhip,
+    gather + reduce) with one rank must reproduce the plain single-GPU result."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import os, sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+        import torch, torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1,
+                                device_id=torch.device('cuda', 0))
+        import bayesloop_amd as bl, cases, compare, oracle_adapter as oa
+        for case in ('c4_small', 'c5_cp_grw', 'c4_small_evidence'):
+            S = cases.build(bl, case)
+            S.communicator = bl.dist.TorchCommunicator()
+            S.fit(**cases.fit_kwargs(case))
+            res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence, logEvidenceList=np.array(S.logEvidenceList),
+                       hyperParameterDistribution=S.hyperParameterDistribution)
+            if 'evidence' not in case:
+                res.update(posteriorSequence=S.posteriorSequence, posteriorMeanValues=S.posteriorMeanValues)
+            compare.check(res, oa.load_golden(case), compare.GPU_TOL)
+            print('ok', case)
+        dist.destroy_process_group()
+    ''') % (root, root)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('ok ') == 3, out.stdout + out.stderr
