@@ -18,6 +18,7 @@
 #include "../../include/blhip.h"
 #include "blhip_kernels.hpp"
 #include "blhip_fast.hpp"
+#include "blhip_persist1d.hpp"
 
 using namespace blk;
 
@@ -277,6 +278,30 @@ void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, i
     for (int b = 0; b < B; ++b) order[start[key(b)]++] = b;
 }
 
+// ---- persistent 1-D path (blhip_persist1d.hpp): one workgroup per chain for the whole time loop ------------------------
+template <int OM>
+void launch_persist_om(hipStream_t s, const bl1::P1Params &P, bool bwd, size_t lds) {
+    if (bwd) {
+        static bool a = false;
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((bl1::persist1d_kernel<OM, true>), dim3(P.B), dim3(bl1::NT), lds, s, P);
+    } else {
+        static bool a = false;
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((bl1::persist1d_kernel<OM, false>), dim3(P.B), dim3(bl1::NT), lds, s, P);
+    }
+}
+
+void launch_persist(hipStream_t s, int om, const bl1::P1Params &P, bool bwd, size_t lds) {
+    switch (om) {
+        case BLHIP_OM_POISSON: launch_persist_om<OM_POISSON>(s, P, bwd, lds); break;
+        case BLHIP_OM_GAUSSIAN_MEAN: launch_persist_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
+        case BLHIP_OM_TABLE: launch_persist_om<OM_TABLE>(s, P, bwd, lds); break;
+        default: fail("persistent 1-D path: observation model %d", om);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
 void validate(const blhip_problem *p, int64_t n_chains, const double *op_values) {
     if (!p) fail("problem is NULL");
     if (p->ndim != 1 && p->ndim != 2) fail("ndim must be 1 or 2 (got %d)", p->ndim);
@@ -534,6 +559,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         const bool fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
                           ctx->option("fast", 1.0) != 0.0 && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
                           g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
+        const size_t p1_lds = ((size_t)2 * (g.n1 + 2 * prog.LW1) + 64 + prog.LW1 + 2) * sizeof(double);
+        const bool persist = p->ndim == 1 && !fast && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
+                             prog.LW1 <= g.n1 && p1_lds <= 150 * 1024 &&
+                             (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
+                              p->obs_model == BLHIP_OM_TABLE);
         Tile tile{};
         int fastS = 0, fast_nseg = 1;
         if (fast) {
@@ -564,7 +594,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         } else {
             tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
         }
-        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : 0;
+        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : (persist ? 2 : 0);
         ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
 
         // --- device metadata ---
@@ -685,9 +715,23 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             }
         };
 
+        bl1::P1Params PP{};
+        if (persist) {
+            PP.n = g.n1; PP.T = (int)T; PP.B = (int)B; PP.LW = prog.LW1; PP.d = d; PP.rec_len = rec_len;
+            PP.shared[SRC_PREV] = nullptr; PP.shared[SRC_PRIOR] = d_prior; PP.shared[SRC_RESET] = d_reset;
+            PP.shared[SRC_UNIFORM] = d_uniform; PP.post = d_post; PP.post_stride = (long long)T * G;
+            PP.taps = d_taps; PP.tap_off = d_off; PP.tap_lw = d_lw; PP.m1 = d_m1; PP.colA = d_colA; PP.rec = d_rec;
+            PP.lik = d_lik;
+        }
         // --- forward pass (core.py:372-411) ---
         HIPCHECK(hipEventRecord(ev[0], st));
-        for (int64_t t = 0; t < T; ++t) {
+        if (persist) {
+            bl1::P1Params Q = PP;
+            Q.srckind = d_kindF; Q.tap = d_tapF1; Q.red_out = ctx->redF.as<double>();
+            Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0;
+            launch_persist(st, p->obs_model, Q, false, p1_lds);
+        }
+        for (int64_t t = 0; t < T && !persist; ++t) {
             const double *srcp; double *dstp; long long sstr, dstr;
             if (evidence_only) {
                 srcp = d_pp[(t + 1) & 1]; sstr = G; dstp = d_pp[t & 1]; dstr = G;
@@ -700,8 +744,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                      d_psF + (size_t)t * B * NRED * tile.nblk, forward_only);
         }
         HIPCHECK(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
-                           ctx->redF.as<double>(), tile.nblk);
+        if (!persist)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
+                               ctx->redF.as<double>(), tile.nblk);
         redF.resize((size_t)T * B * NRED);
         HIPCHECK(hipMemcpyAsync(redF.data(), ctx->redF.p, redF.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
@@ -744,15 +789,21 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             ctx->redB.ensure((size_t)T * B * NRED * 8);
             double *d_psB = ctx->psumB.as<double>();
             HIPCHECK(hipEventRecord(ev[2], st));
-            for (int64_t t = T - 1; t >= 0; --t) {
+            if (persist) {
+                bl1::P1Params Q = PP;
+                Q.srckind = d_kindB; Q.tap = d_tapB1; Q.red_out = ctx->redB.as<double>(); Q.store = 1; Q.means = 1;
+                launch_persist(st, p->obs_model, Q, true, p1_lds);
+            }
+            for (int64_t t = T - 1; t >= 0 && !persist; --t) {
                 // reads c_{t+1} and the stored alpha_t, writes c_t and posterior_t
                 run_step(MODE_BWD, t, d_pp[(t + 1) & 1], G, d_pp[t & 1], G, d_post + (size_t)t * G, (long long)T * G,
                          t < T - 1 ? d_psB + (size_t)(t + 1) * B * NRED * tile.nblk : d_psB, 2,
                          d_psB + (size_t)t * B * NRED * tile.nblk, true);
             }
             HIPCHECK(hipEventRecord(ev[3], st));
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
-                               ctx->redB.as<double>(), tile.nblk);
+            if (!persist)
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
+                                   ctx->redB.as<double>(), tile.nblk);
             redB.resize((size_t)T * B * NRED);
             HIPCHECK(hipMemcpyAsync(redB.data(), ctx->redB.p, redB.size() * 8, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'libblhip.so')
 SOURCES = ['blhip.hip']
-DEPS = ['blhip.hip', 'blhip_kernels.hpp', os.path.join('..', '..', 'include', 'blhip.h')]
+DEPS = ['blhip.hip', 'blhip_kernels.hpp', 'blhip_fast.hpp', 'blhip_persist1d.hpp', os.path.join('..', '..', 'include', 'blhip.h')]
 
 
 def hipcc():
