@@ -85,6 +85,15 @@ def make_study(bl, name, comm=None, scale=1.0):
     raise ValueError(name)
 
 
+def measured_traffic(key):
+    """HBM bytes per step launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+        return d[key].get('hbm_bytes_per_step_launch', d[key].get('hbm_bytes_per_launch'))
+    except Exception:
+        return None
+
+
 def roofline_of(timing, cells_per_launch):
     """achieved GB/s of the dominant step kernel from the library's HIP-event timing of its own stream."""
     out = {}
@@ -187,8 +196,13 @@ def main():
         dom = max(rf.values(), key=lambda r: r['avg_launch_us'] * r['launches']) if rf else None
         roof = None
         if dom:
+            traffic = None
+            if args.workload == 'c4' and world == 1:
+                traffic = measured_traffic('bwd' if 'backward' in dom['kernel'] else 'fwd')
+            elif args.workload == 'fwd2048':
+                traffic = measured_traffic('fwd2048')
             roof = dict(bound='hbm', achieved=dom['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=dom['achieved'] / HBM_PEAK_GBS, traffic=None, kernel=dom['kernel'],
+                        frac=dom['achieved'] / HBM_PEAK_GBS, traffic=traffic, kernel=dom['kernel'],
                         avg_launch_us=dom['avg_launch_us'], bytes_per_cell_step=dom['bytes_per_cell_step'],
                         cells_per_launch=int(timing.get('cells_per_launch', 0)))
         out = dict(metric='grid-cells*timesteps/sec (fit())', value=value, unit='grid-cells*timesteps/s',
