@@ -68,6 +68,11 @@ struct blhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
+    // radius buckets of a batch are independent pipelines: one stream per bucket key, joined with events
+    static constexpr int NBS = 12;
+    hipStream_t bstream[NBS] = {};
+    hipEvent_t bev[NBS] = {};
+    hipEvent_t fork_ev = nullptr;
     std::string err;
     std::string name;
     std::map<std::string, double> opt;
@@ -242,7 +247,7 @@ void launch_fast(hipStream_t s, int om, int mode, const blf::FastParams &P, int 
     HIPCHECK(hipGetLastError());
 }
 
-struct FastRange { int start, count, R0; bool H; };
+struct FastRange { int start, count, R0; bool H; int key; };
 
 // chains of one step ordered by (axis-0 radius bucket, axis-1 filter present); one launch per non-empty group
 void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, int B, int *order, std::vector<FastRange> &ranges,
@@ -272,7 +277,7 @@ void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, i
     ranges.clear();
     for (int k = 0; k < 12; ++k) {
         start[k] = acc;
-        if (cnt[k]) ranges.push_back(FastRange{acc, cnt[k], (k / 2) * 8, (k & 1) != 0});
+        if (cnt[k]) ranges.push_back(FastRange{acc, cnt[k], (k / 2) * 8, (k & 1) != 0, k});
         acc += cnt[k];
     }
     for (int b = 0; b < B; ++b) order[start[key(b)]++] = b;
@@ -685,6 +690,28 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             FP.step0 = step;
             FP.use_rec = (p->obs_model == BLHIP_OM_GAUSSIAN && dev <= 8.0 * 2.3e-16 * mx && ctx->option("recurrence", 1.0) != 0.0) ? 1 : 0;
         }
+        // bucket streams: fork = every bucket stream waits for the main stream; join = the main stream waits for all of them
+        const bool multistream = fast && ctx->option("multistream", 1.0) != 0.0;
+        auto fork_streams = [&]() {
+            if (!multistream) return;
+            HIPCHECK(hipEventRecord(ctx->fork_ev, st));
+            for (auto &bs : ctx->bstream) HIPCHECK(hipStreamWaitEvent(bs, ctx->fork_ev, 0));
+        };
+        auto join_streams = [&]() {
+            if (!multistream) return;
+            for (int k = 0; k < blhip_ctx::NBS; ++k) {
+                HIPCHECK(hipEventRecord(ctx->bev[k], ctx->bstream[k]));
+                HIPCHECK(hipStreamWaitEvent(st, ctx->bev[k], 0));
+            }
+        };
+        // a chain only depends on its own previous step: streams need a barrier only where bucket membership changes
+        auto same_membership = [&](const std::vector<int> &order, const std::vector<std::vector<FastRange>> &ranges,
+                                   int64_t ta, int64_t tb) {
+            if (ranges[ta].size() != ranges[tb].size()) return false;
+            for (size_t k = 0; k < ranges[ta].size(); ++k)
+                if (ranges[ta][k].key != ranges[tb][k].key || ranges[ta][k].count != ranges[tb][k].count) return false;
+            return std::equal(order.begin() + ta * B, order.begin() + (ta + 1) * B, order.begin() + tb * B);
+        };
         auto run_step = [&](int mode, int64_t t, const double *srcp, long long src_stride, double *dstp, long long dst_stride,
                             double *postp, long long post_stride, const double *ps_prev, int prev_slot, double *ps_out,
                             bool means) {
@@ -700,7 +727,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
-                    launch_fast(st, p->obs_model, mode, Q, r.R0, r.H, r.count);
+                    launch_fast(multistream ? ctx->bstream[r.key] : st, p->obs_model, mode, Q, r.R0, r.H, r.count);
                 }
             } else {
                 StepParams Q = P;
@@ -731,7 +758,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0;
             launch_persist(st, p->obs_model, Q, false, p1_lds);
         }
+        fork_streams();
         for (int64_t t = 0; t < T && !persist; ++t) {
+            if (multistream && t > 0 && !same_membership(orderF, rangesF, t - 1, t)) { join_streams(); fork_streams(); }
             const double *srcp; double *dstp; long long sstr, dstr;
             if (evidence_only) {
                 srcp = d_pp[(t + 1) & 1]; sstr = G; dstp = d_pp[t & 1]; dstr = G;
@@ -743,6 +772,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                      t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : d_psF, 0,
                      d_psF + (size_t)t * B * NRED * tile.nblk, forward_only);
         }
+        join_streams();
         HIPCHECK(hipEventRecord(ev[1], st));
         if (!persist)
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
@@ -794,12 +824,15 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 Q.srckind = d_kindB; Q.tap = d_tapB1; Q.red_out = ctx->redB.as<double>(); Q.store = 1; Q.means = 1;
                 launch_persist(st, p->obs_model, Q, true, p1_lds);
             }
+            fork_streams();
             for (int64_t t = T - 1; t >= 0 && !persist; --t) {
+                if (multistream && t < T - 1 && !same_membership(orderB, rangesB, t + 1, t)) { join_streams(); fork_streams(); }
                 // reads c_{t+1} and the stored alpha_t, writes c_t and posterior_t
                 run_step(MODE_BWD, t, d_pp[(t + 1) & 1], G, d_pp[t & 1], G, d_post + (size_t)t * G, (long long)T * G,
                          t < T - 1 ? d_psB + (size_t)(t + 1) * B * NRED * tile.nblk : d_psB, 2,
                          d_psB + (size_t)t * B * NRED * tile.nblk, true);
             }
+            join_streams();
             HIPCHECK(hipEventRecord(ev[3], st));
             if (!persist)
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
@@ -939,6 +972,9 @@ blhip_ctx *blhip_create(int device) {
         ctx->device = device;
         HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         for (auto &e : ctx->ev) HIPCHECK(hipEventCreate(&e));
+        for (auto &bs : ctx->bstream) HIPCHECK(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
+        for (auto &e : ctx->bev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, device));
         ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
@@ -961,6 +997,11 @@ void blhip_destroy(blhip_ctx *ctx) {
         b->release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &bs : ctx->bstream)
+        if (bs) { (void)hipStreamSynchronize(bs); (void)hipStreamDestroy(bs); }
+    for (auto &e : ctx->bev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
