@@ -691,7 +691,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             FP.use_rec = (p->obs_model == BLHIP_OM_GAUSSIAN && dev <= 8.0 * 2.3e-16 * mx && ctx->option("recurrence", 1.0) != 0.0) ? 1 : 0;
         }
         // bucket streams: fork = every bucket stream waits for the main stream; join = the main stream waits for all of them
-        const bool multistream = fast && ctx->option("multistream", 1.0) != 0.0;
+        // (only worth it when a step really has several launches: a launch on a secondary stream costs ~9 us more
+        //  than a back-to-back launch on the main stream -- measured on single-chain fits)
+        size_t max_ranges = 0;
+        for (const auto &r : rangesF) max_ranges = std::max(max_ranges, r.size());
+        for (const auto &r : rangesB) max_ranges = std::max(max_ranges, r.size());
+        const bool multistream = fast && max_ranges >= 2 && ctx->option("multistream", 1.0) != 0.0;
         auto fork_streams = [&]() {
             if (!multistream) return;
             HIPCHECK(hipEventRecord(ctx->fork_ev, st));

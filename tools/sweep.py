@@ -62,3 +62,14 @@ if which == 'bucket':
             lw, t['forward_ms'] * 1e3 / t['forward_launches'], 16.0 * cells / (t['forward_ms'] * 1e-3 / t['forward_launches']) / 1e9,
             t['backward_ms'] * 1e3 / t['backward_launches'], 32.0 * cells / (t['backward_ms'] * 1e-3 / t['backward_launches']) / 1e9,
             t['accumulate_ms'], t['total_ms']), flush=True)
+if which == 'S':
+    n = int(sys.argv[2])
+    for S_ in [int(x) for x in sys.argv[3].split(',')]:
+        run(n, 24, {'fast_S': S_}, 'full')
+    run(n, 24, {}, 'full')
+if which == 'ms':
+    for n in (1024, 2048):
+        run(n, 24, {'multistream': 0}, 'full')
+        run(n, 24, {}, 'full')
+        run(n, 24, {'multistream': 0}, 'full')
+        run(n, 24, {}, 'full')
