@@ -257,3 +257,34 @@ def test_rccl_path_single_rank():
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('ok ') == 3, out.stdout + out.stderr
+
+
+# ---- BASELINE.json grid sizes, short series: direct comparison with the oracle ---------------------------------------
+
+FULL_SIZE = {
+    'full_c4_512': dict(study='HyperStudy', data=('series', 4, 12), om=cases.gauss2d(512),
+                        tm=('GRW', 'sigma', ('cint', 0, 0.3, 7), 'mean', None)),          # radii 0 .. 38: every bucket
+    'full_c5_512': dict(study='ChangepointStudy', data=('series_jump', 5, 20, 10, 2.0), om=cases.gauss2d(512),
+                        tm=('ChangePoint', 'tChange', ('arange', 3, 19, 4), None)),
+    'full_fwd2048': dict(study='Study', data=('series', 3, 5), om=cases.gauss2d(2048),
+                         tm=('Combined', [('GRW', 's1', 0.015, 'mean', None), ('GRW', 's2', 0.004, 'std', None)]),
+                         fit=dict(evidenceOnly=True)),
+    'full_c3_1024_fwd': dict(study='Study', data=('series', 9, 6), om=cases.gauss2d(1024),
+                             tm=('Combined', [('GRW', 's1', 0.03, 'mean', None), ('GRW', 's2', 0.008, 'std', None)]),
+                             fit=dict(forwardOnly=True)),
+}
+
+
+@pytest.mark.parametrize('case', list(FULL_SIZE))
+def test_baseline_grid_sizes_match_oracle(case):
+    c = FULL_SIZE[case]
+    S = cases.build(bl, c)
+    S.fit(**cases.fit_kwargs(c))
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL)
