@@ -75,6 +75,8 @@ PROTOTYPES = {
     'blhip_posterior_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_double_p]),
     'blhip_posterior_devptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'blhip_posterior_release': (C.c_int, [C.c_void_p]),
+    'blhip_posterior_marginal': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, c_double_p]),
+    'blhip_posterior_time_average': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p]),
     'blhip_accum_begin': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'blhip_accum_state': (C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     'blhip_accum_rescale': (C.c_int, [C.c_void_p, C.c_double]),

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _abi
 from . import engine as _engine_mod
-from .engine import FitProblem
+from .engine import FitProblem, DevicePosterior
 from .exceptions import ConfigurationError, PostProcessingError
 from .helper import flatten
 from .observationModels import ObservationModel
@@ -420,7 +420,7 @@ class Study(object):
             return
         grid_size = list(self.gridSize)
         self._posteriorSequence = None
-        self._posterior_pending = lambda: eng.posterior(0, T, grid_size)
+        self._posterior_pending = DevicePosterior(eng, 0, T, grid_size)
         self.posteriorMeanValues = res.posterior_mean[0].copy()
         if not silent:
             if not forwardOnly:
@@ -471,15 +471,26 @@ class Study(object):
         return self.posteriorMeanValues[self._parameterIndex(name)]
 
     def getParameterDistribution(self, t, name, plot=False, density=True, **kwargs):
-        """Marginal distribution of one parameter at time stamp ``t`` or time-averaged (``t='avg'``)."""
-        post = self._requirePosterior()
+        """Marginal distribution of one parameter at time stamp ``t`` or time-averaged (``t='avg'``).  While the
+        posterior sequence is still on the GPU the reduction happens there (no (T, G) copy)."""
+        k = self._parameterIndex(name)
+        pending = self._posterior_pending
         if isinstance(t, str) and t == 'avg':
-            dist = np.sum(post, axis=0) / len(post)
+            if pending is not None and hasattr(pending, 'time_average'):
+                dist = pending.time_average()
+            else:
+                post = self._requirePosterior()
+                dist = np.sum(post, axis=0) / len(post)
         else:
             if t not in self.formattedTimestamps:
                 raise PostProcessingError('Supplied time ({}) does not exist in data or is out of range.'.format(t))
-            dist = post[list(self.formattedTimestamps).index(t)]
-        k = self._parameterIndex(name)
+            index = list(self.formattedTimestamps).index(t)
+            if pending is not None and hasattr(pending, 'marginal'):
+                marginal = pending.marginal(k)[index]
+                if density:
+                    marginal = marginal / self.latticeConstant[k]
+                return self.marginalGrid[k], marginal
+            dist = self._requirePosterior()[index]
         axes = tuple(a for a in range(len(self.gridSize)) if a != k)
         marginal = np.sum(dist, axis=axes) if axes else np.array(dist)
         if density:
@@ -490,11 +501,16 @@ class Study(object):
         return self.getParameterDistribution(t, name, plot=plot, density=density, **kwargs)
 
     def getParameterDistributions(self, name, plot=False, density=True, **kwargs):
-        """Time series of marginal posterior distributions of one parameter: (values, (T, n) array)."""
-        post = self._requirePosterior()
+        """Time series of marginal posterior distributions of one parameter: (values, (T, n) array); reduced on the GPU
+        while the posterior sequence is still there."""
         k = self._parameterIndex(name)
-        axes = tuple(a + 1 for a in range(len(self.gridSize)) if a != k)
-        marginal = np.sum(post, axis=axes) if axes else np.array(post)
+        pending = self._posterior_pending
+        if pending is not None and hasattr(pending, 'marginal'):
+            marginal = pending.marginal(k)
+        else:
+            post = self._requirePosterior()
+            axes = tuple(a + 1 for a in range(len(self.gridSize)) if a != k)
+            marginal = np.sum(post, axis=axes) if axes else np.array(post)
         if density:
             marginal = marginal / self.latticeConstant[k]
         return self.marginalGrid[k], marginal

@@ -81,6 +81,7 @@ struct blhip_ctx {
     // kept posterior of the last fit
     bool post_valid = false;
     int64_t post_chains = 0, post_T = 0, post_G = 0;
+    int post_n0 = 1, post_n1 = 1, acc_n0 = 1, acc_n1 = 1;
     // accumulator
     bool acc_active = false, acc_final = false, acc_first = true;
     double *acc = nullptr;
@@ -916,6 +917,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                                    d_post + (size_t)b * T * G, G, d_invN + b * T);
             HIPCHECK(hipStreamSynchronize(st));
             ctx->post_valid = true; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = G;
+            ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
         }
 
         // --- results ---
@@ -1072,6 +1074,62 @@ int blhip_posterior_release(blhip_ctx *ctx) {
     });
 }
 
+namespace {
+struct SeqView { const double *p; int64_t T; int n0, n1; };
+SeqView sequence_view(blhip_ctx *ctx, int source, int64_t chain) {
+    if (source == 0) {
+        if (!ctx->post_valid) fail("no posterior kept (run blhip_fit with BLHIP_KEEP_POSTERIOR)");
+        if (chain < 0 || chain >= ctx->post_chains) fail("chain out of range");
+        return SeqView{ctx->post.as<double>() + (size_t)chain * ctx->post_T * ctx->post_G, ctx->post_T, ctx->post_n0, ctx->post_n1};
+    }
+    if (source == 1) {
+        if (!ctx->acc_active || !ctx->acc_final) fail("accumulator not finalised");
+        return SeqView{ctx->acc, ctx->acc_T, ctx->acc_n0, ctx->acc_n1};
+    }
+    fail("bad source %d", source);
+}
+}  // namespace
+
+int blhip_posterior_marginal(blhip_ctx *ctx, int source, int64_t chain, int keep_axis, double *host_out) {
+    return guarded(ctx, [&] {
+        if (!host_out) fail("host_out is NULL");
+        HIPCHECK(hipSetDevice(ctx->device));
+        const SeqView v = sequence_view(ctx, source, chain);
+        const bool one_d = v.n0 == 1;
+        if (keep_axis < 0 || keep_axis > (one_d ? 0 : 1)) fail("keep_axis out of range");
+        const int nk = one_d ? v.n1 : (keep_axis == 0 ? v.n0 : v.n1);
+        ctx->stats.ensure((size_t)v.T * nk * 8);
+        double *d_out = ctx->stats.as<double>();
+        hipStream_t st = ctx->stream;
+        if (one_d) {
+            HIPCHECK(hipMemcpyAsync(d_out, v.p, (size_t)v.T * nk * 8, hipMemcpyDeviceToDevice, st));
+        } else if (keep_axis == 0) {
+            hipLaunchKernelGGL(marginal_rows_kernel, dim3(v.n0, (unsigned)v.T), dim3(NTHREADS), 0, st, v.p, d_out, v.n0, v.n1);
+        } else {
+            hipLaunchKernelGGL(marginal_cols_kernel, dim3((v.n1 + NTHREADS - 1) / NTHREADS, (unsigned)v.T), dim3(NTHREADS), 0, st,
+                               v.p, d_out, v.n0, v.n1);
+        }
+        HIPCHECK(hipMemcpyAsync(host_out, d_out, (size_t)v.T * nk * 8, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+    });
+}
+
+int blhip_posterior_time_average(blhip_ctx *ctx, int source, int64_t chain, double *host_out) {
+    return guarded(ctx, [&] {
+        if (!host_out) fail("host_out is NULL");
+        HIPCHECK(hipSetDevice(ctx->device));
+        const SeqView v = sequence_view(ctx, source, chain);
+        const long long G = (long long)v.n0 * v.n1;
+        ctx->stats.ensure((size_t)G * 8);
+        double *d_out = ctx->stats.as<double>();
+        hipStream_t st = ctx->stream;
+        hipLaunchKernelGGL(time_average_kernel, dim3((unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096)),
+                           dim3(NTHREADS), 0, st, v.p, d_out, G, (int)v.T);
+        HIPCHECK(hipMemcpyAsync(host_out, d_out, (size_t)G * 8, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+    });
+}
+
 int blhip_accum_begin(blhip_ctx *ctx, int64_t T, int64_t G, void *external_devptr) {
     return guarded(ctx, [&] {
         if (T < 1 || G < 1) fail("blhip_accum_begin: bad shape");
@@ -1156,6 +1214,7 @@ int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *p, double *posteri
         hipLaunchKernelGGL(scale_rows_kernel, dim3(gs, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, d_inv);
         HIPCHECK(hipStreamSynchronize(st));
         ctx->acc_final = true;
+        ctx->acc_n0 = n0; ctx->acc_n1 = n1;
     });
 }
 

@@ -354,6 +354,37 @@ __global__ __launch_bounds__(NTHREADS) void row_stats_kernel(const double *A, lo
     }
 }
 
+// out[t][i] = sum_j p[t][i][j]   (one block per (row i, t); coalesced along j)
+__global__ __launch_bounds__(NTHREADS) void marginal_rows_kernel(const double *p, double *out, int n0, int n1) {
+    __shared__ double red[NTHREADS / 64 + 1];
+    const long long t = blockIdx.y, i = blockIdx.x;
+    const double *row = p + (t * n0 + i) * n1;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n1; j += NTHREADS) s += row[j];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[t * n0 + i] = s;
+}
+
+// out[t][j] = sum_i p[t][i][j]   (a thread owns a column; coalesced along j)
+__global__ __launch_bounds__(NTHREADS) void marginal_cols_kernel(const double *p, double *out, int n0, int n1) {
+    const long long t = blockIdx.y;
+    const int j = blockIdx.x * NTHREADS + threadIdx.x;
+    if (j >= n1) return;
+    const double *col = p + t * (long long)n0 * n1 + j;
+    double s = 0.0;
+    for (int i = 0; i < n0; ++i) s += col[(long long)i * n1];
+    out[t * n1 + j] = s;
+}
+
+// out[c] = (1/T) sum_t p[t][c]
+__global__ __launch_bounds__(NTHREADS) void time_average_kernel(const double *p, double *out, long long G, int T) {
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
+        double s = 0.0;
+        for (int t = 0; t < T; ++t) s += p[(long long)t * G + c];
+        out[c] = s / (double)T;
+    }
+}
+
 __global__ void fill_kernel(double *p, long long n, double v) {
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (long long)gridDim.x * blockDim.x)
         p[c] = v;

@@ -144,7 +144,8 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
             ok = np.isfinite(ref)
         if ok and rank == 0:
             means = engine.accum_finalize(problem)
-            posterior = lambda: engine.accum_read(T, grid_size)      # noqa: E731  (lazy D2H of the (T, G) average)
+            from .engine import DevicePosterior
+            posterior = DevicePosterior(engine, 1, T, grid_size)     # lazy D2H / device-side reductions of the average
         if comm is not None:
             m = comm.broadcast(means if means is not None else np.full((ndim, T), np.nan), src=0)
             means = m if ok else None

@@ -60,6 +60,27 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+class DevicePosterior:
+    """Handle of a posterior sequence that still lives in HBM (source 0: kept posterior of a fit, 1: finalised average
+    posterior).  Calling it copies the (T, *gridSize) array to the host; ``marginal`` / ``time_average`` reduce on the
+    device and copy only the result (the consumers of posteriorSequence in the reference reduce it immediately:
+    bayesloop/core.py:886, 915, 979-980)."""
+
+    def __init__(self, engine, source, T, grid_size, chain=0):
+        self.engine, self.source, self.T, self.grid_size, self.chain = engine, source, T, list(grid_size), chain
+
+    def __call__(self):
+        if self.source == 0:
+            return self.engine.posterior(self.chain, self.T, self.grid_size)
+        return self.engine.accum_read(self.T, self.grid_size)
+
+    def marginal(self, k):
+        return self.engine.marginal(self.source, self.chain, k, self.T, self.grid_size[k])
+
+    def time_average(self):
+        return self.engine.time_average(self.source, self.chain, self.grid_size)
+
+
 class HipEngine:
     """One libblhip context on one GPU."""
 
@@ -190,6 +211,18 @@ class HipEngine:
         """Normalised posterior sequence of one chain of the last fit(keep_posterior=True) as (T, *grid_size)."""
         out = np.empty([T] + list(grid_size))
         self._check(self.lib.blhip_posterior_read(self.ctx, chain, 0, T, _abi.dptr(out)))
+        return out
+
+    def marginal(self, source, chain, keep_axis, T, n_keep):
+        """(T, n_keep) marginal probabilities of one parameter, reduced on the device (source 0: kept posterior of
+        `chain`, 1: finalised average posterior)."""
+        out = np.empty((T, n_keep))
+        self._check(self.lib.blhip_posterior_marginal(self.ctx, source, chain, keep_axis, _abi.dptr(out)))
+        return out
+
+    def time_average(self, source, chain, grid_size):
+        out = np.empty(list(grid_size))
+        self._check(self.lib.blhip_posterior_time_average(self.ctx, source, chain, _abi.dptr(out)))
         return out
 
     def release_posterior(self, owner=None):

@@ -134,6 +134,14 @@ int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, 
 int blhip_posterior_devptr(blhip_ctx *ctx, void **devptr, int64_t *chain_stride, int64_t *step_stride);
 int blhip_posterior_release(blhip_ctx *ctx);
 
+/* ---- reductions of a device-resident posterior sequence (consumers of posteriorSequence: marginal parameter
+ *      distributions, bayesloop/core.py:915, 979-980; time average, core.py:588, 886) -------------------------------
+ * source: 0 = posterior of `chain` kept by the last blhip_fit(BLHIP_KEEP_POSTERIOR), 1 = the finalised accumulator.
+ * keep_axis: the parameter whose marginal is wanted; host_out is (T, n[keep_axis]) probabilities (sums, no density). */
+int blhip_posterior_marginal(blhip_ctx *ctx, int source, int64_t chain, int keep_axis, double *host_out);
+/* host_out is (G,): mean over time steps of the posterior. */
+int blhip_posterior_time_average(blhip_ctx *ctx, int source, int64_t chain, double *host_out);
+
 /* ---- evidence-weighted average posterior (HyperStudy) ----------------------------------------------------------- */
 /* The accumulator holds  A[t, cell] = sum_h exp(logE_h + log prior_h - log_ref) * max(post_h[t, cell], 1e-300)
  * in linear space with a running reference exponent `log_ref` (equal to the reference's log-space logaddexp

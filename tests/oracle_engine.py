@@ -43,6 +43,7 @@ class OracleEngine:
             prev, self._posterior_owner = self._posterior_owner, None
             prev._materialize_posterior()
         g, om, ops, data, lik, reset = self._unpack(problem)
+        self._gs = list(g.size)
         n, T, ndim = len(op_values), problem.T, len(g.size)
         logE = np.zeros(n)
         local = np.zeros((n, T))
@@ -77,6 +78,15 @@ class OracleEngine:
     def posterior(self, chain, T, grid_size):
         return self._post.reshape([T] + list(grid_size))
 
+    def marginal(self, source, chain, keep_axis, T, n_keep):
+        post = self._post.reshape([T] + self._gs) if source == 0 else self.acc_final.reshape([T] + self._gs)
+        axes = tuple(a + 1 for a in range(len(self._gs)) if a != keep_axis)
+        return post.sum(axis=axes) if axes else post.copy()
+
+    def time_average(self, source, chain, grid_size):
+        post = self._post if source == 0 else self.acc_final
+        return post.reshape([-1] + list(grid_size)).mean(axis=0)
+
     def release_posterior(self, owner=None):
         self._posterior_owner = None
 
@@ -109,6 +119,7 @@ class OracleEngine:
 
     def accum_finalize(self, problem):
         T, G = self.acc_shape
+        self._gs = list(problem.grid_size)
         if self.acc_lin is not None:
             avg = np.array(self.acc_lin, dtype=float).reshape(T, G)
         else:

@@ -288,3 +288,22 @@ def test_baseline_grid_sizes_match_oracle(case):
         if k in want and want[k] is not None and len(np.atleast_1d(want[k])):
             gold[k] = np.asarray(want[k])
     compare.check(got, gold, compare.GPU_TOL)
+
+
+def test_device_side_marginals():
+    """blhip_posterior_marginal / _time_average against host reductions of the copied posterior (2-D and 1-D)."""
+    for case in ('c3_small', 'c4_2hp', 'c1_coal'):
+        S = cases.build(bl, case)
+        S.fit(silent=True)
+        names = S.observationModel.parameterNames
+        got = [S.getParameterDistributions(n, density=False)[1] for n in names]
+        avg = S.getParameterDistribution('avg', names[0], density=False)[1]
+        assert S._posterior_pending is not None
+        post = S.posteriorSequence
+        for k in range(len(names)):
+            axes = tuple(a + 1 for a in range(len(names)) if a != k)
+            want = post.sum(axis=axes) if axes else post
+            np.testing.assert_allclose(got[k], want, rtol=1e-12, atol=1e-300)
+        axes = tuple(a for a in range(len(names)) if a != 0)
+        want = post.mean(axis=0)
+        np.testing.assert_allclose(avg, want.sum(axis=axes) if axes else want, rtol=1e-12, atol=1e-300)

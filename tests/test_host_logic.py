@@ -119,3 +119,22 @@ def test_pickle_roundtrip_materialises_posterior():
     S2 = pickle.loads(pickle.dumps(S))
     np.testing.assert_array_equal(S2.posteriorSequence, S.posteriorSequence)
     assert S2.logEvidence == S.logEvidence
+
+
+def test_device_side_reductions_equal_host_reductions():
+    """getParameterDistributions / getParameterDistribution use the engine's reductions while the posterior is still on
+    the device; they must equal reductions of the materialised array."""
+    for case in ('c3_small', 'c4_2hp'):
+        S = cases.build(bl, case)
+        S.fit(silent=True)
+        assert S._posterior_pending is not None
+        x, m0 = S.getParameterDistributions('mean', density=False)
+        x1, m1 = S.getParameterDistributions('std')
+        xa, avg = S.getParameterDistribution('avg', 'mean')
+        xt, pt = S.getParameterDistribution(S.formattedTimestamps[3], 'std', density=False)
+        assert S._posterior_pending is not None           # nothing was materialised
+        post = S.posteriorSequence
+        np.testing.assert_allclose(m0, post.sum(axis=2), rtol=1e-13)
+        np.testing.assert_allclose(m1, post.sum(axis=1) / S.latticeConstant[1], rtol=1e-13)
+        np.testing.assert_allclose(avg, post.mean(axis=0).sum(axis=1) / S.latticeConstant[0], rtol=1e-13)
+        np.testing.assert_allclose(pt, post[3].sum(axis=0), rtol=1e-13)
