@@ -12,17 +12,17 @@ import os
 from .exceptions import BackendError
 
 LIB_NAME = 'libblhip.so'
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
-OP_STATIC, OP_GRW, OP_CHANGEPOINT = 0, 1, 2
+OP_STATIC, OP_GRW, OP_CHANGEPOINT, OP_REGIMESWITCH, OP_INDEPENDENT, OP_BREAKPOINT = 0, 1, 2, 3, 4, 5
 FORWARD_ONLY, EVIDENCE_ONLY, KEEP_POSTERIOR, ACCUMULATE = 1, 2, 4, 8
 
 c_double_p = C.POINTER(C.c_double)
 
 
 class Op(C.Structure):
-    _fields_ = [('kind', C.c_int32), ('axis', C.c_int32)]
+    _fields_ = [('kind', C.c_int32), ('axis', C.c_int32), ('segment', C.c_int32), ('flags', C.c_int32)]
 
 
 class Problem(C.Structure):
@@ -34,7 +34,7 @@ class Problem(C.Structure):
         ('T', C.c_int64),
         ('seg_len', C.c_int32), ('data_dim', C.c_int32),
         ('data', c_double_p), ('timestamps', c_double_p), ('prior', c_double_p), ('reset_prior', c_double_p),
-        ('lik', c_double_p),
+        ('indep_prior', c_double_p), ('lik', c_double_p),
         ('n_ops', C.c_int32),
         ('ops', C.POINTER(Op)),
     ]

@@ -21,7 +21,7 @@ from .exceptions import ConfigurationError, PostProcessingError
 from .helper import flatten
 from .observationModels import ObservationModel
 from .preprocessing import movingWindow
-from .transitionModels import TransitionModel, ChangePoint, CombinedTransitionModel
+from .transitionModels import TransitionModel, ChangePoint, CombinedTransitionModel, SerialTransitionModel
 
 COAL_MINING = (5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4, 4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2,
                1, 3, 2, 2, 1, 1, 1, 1, 3, 0, 0, 1, 0, 1, 1, 0, 0, 3, 1, 0, 3, 2, 2, 0, 1, 1, 1, 0, 1, 0, 1, 0, 0, 0, 2, 1,
@@ -29,14 +29,15 @@ COAL_MINING = (5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1,
                1, 0)   # UK coal mining disasters per year, 1852-1961 (the reference's example data, core.py:82-88)
 
 
-def _leaf_models(model):
-    """Depth-first list of the leaf transition models of a (nested) model."""
-    if hasattr(model, 'models'):
-        out = []
-        for m in model.models:
-            out += _leaf_models(m)
-        return out
-    return [model]
+def _hyper_slots(model):
+    """[(model, index, name)] of all hyper-parameters of a (nested) transition model in the reference's flattened order:
+    sub-models first (depth first), then the model's own hyper-parameters (reference core.py:623-647)."""
+    out = []
+    for m in getattr(model, 'models', []):
+        out += _hyper_slots(m)
+    for k, name in enumerate(getattr(model, 'hyperParameterNames', [])):
+        out.append((model, k, name))
+    return out
 
 
 class Study(object):
@@ -265,13 +266,9 @@ class Study(object):
     # ---- hyper-parameter plumbing (reference core.py:623-824) -------------------------------------------------------
     def _hyperSlots(self):
         """[(model, index into model.hyperParameterValues, name)] in the reference's flattened order."""
-        slots = []
         if self.transitionModel is None:
-            return slots
-        for m in _leaf_models(self.transitionModel):
-            for k, name in enumerate(getattr(m, 'hyperParameterNames', [])):
-                slots.append((m, k, name))
-        return slots
+            return []
+        return _hyper_slots(self.transitionModel)
 
     def _unpackAllHyperParameters(self, values=True):
         return [m.hyperParameterValues[k] if values else name for m, k, name in self._hyperSlots()]
@@ -302,7 +299,12 @@ class Study(object):
         return 1
 
     def _unpackChangepointNames(self, transitionModel=None):
+        """Names of stand-alone change-points (reference core.py:761-780)."""
         return [name for m, k, name in self._hyperSlots() if isinstance(m, ChangePoint)]
+
+    def _unpackBreakpointNames(self, transitionModel=None):
+        """Names of the break-/change-points of serial transition models (reference core.py:782-801)."""
+        return [name for m, k, name in self._hyperSlots() if isinstance(m, SerialTransitionModel)]
 
     def _getHyperParameterIndex(self, transitionModel, name):
         names = self._unpackAllHyperParameters(values=False)
@@ -342,6 +344,9 @@ class Study(object):
                                      '(got {}).'.format(len(self.gridSize)))
         prior = self._computePrior(silent=silent)
         reset = self._changepointPrior() if any(op[0] == _abi.OP_CHANGEPOINT for op in program) else None
+        indep = None
+        if any(op[0] == _abi.OP_INDEPENDENT for op in program):
+            indep = self._changepointPrior() / np.prod(self.latticeConstant)      # sum 1 (reference transitionModels.py:351-360)
         data = np.asarray(self.formattedData, dtype=float)
         lik = None
         code = getattr(om, 'device_model', _abi.OM_TABLE)
@@ -352,7 +357,8 @@ class Study(object):
                             for seg in self.formattedData])
         problem = FitProblem(obs_model=code, marginal=self.marginalGrid, lattice=self.latticeConstant, data=data,
                              timestamps=np.asarray(self.formattedTimestamps, dtype=float), prior=prior,
-                             ops=[(op[0], op[1]) for op in program], reset_prior=reset, lik=lik,
+                             ops=[(op[0], op[1], op[4], op[5]) for op in program], reset_prior=reset, indep_prior=indep,
+                             lik=lik,
                              seg_len=om.segmentLength)
         return problem, program
 
@@ -360,7 +366,7 @@ class Study(object):
         """One row of op values: the current hyper-parameter value of every op (NaN for Static)."""
         slots = self._hyperSlots()
         row = []
-        for kind, axis, model, k in program:
+        for kind, axis, model, k, seg, flg in program:
             if k is None:
                 row.append(np.nan)
                 continue
@@ -435,7 +441,7 @@ class Study(object):
         print('+ Starting optimization...')
         self._checkConsistency()
         if not self.selectedHyperParameters:
-            points = self._unpackChangepointNames()
+            points = self._unpackChangepointNames() + self._unpackBreakpointNames()
             self.selectedHyperParameters = [n for n in self._unpackAllHyperParameters(values=False) if n not in points]
         x0 = self._unpackSelectedHyperParameters()
         if len(x0) == 0:
@@ -546,9 +552,9 @@ class HyperStudy(Study):
 
     def _unpackAllHyperPriors(self):
         priors = []
-        for m in _leaf_models(self.transitionModel):
-            if len(getattr(m, 'hyperParameterNames', [])) > 0:
-                priors.append(getattr(m, 'prior', None))
+        for m, k, name in self._hyperSlots():
+            prior = getattr(m, 'prior', None)
+            priors.append(prior[k] if isinstance(m, SerialTransitionModel) else prior)
         return priors
 
     def _createHyperGrid(self, silent=False):
@@ -632,7 +638,7 @@ class HyperStudy(Study):
         self._formatData()
         if not customHyperGrid:
             self._createHyperGrid(silent=silent)
-            names = self._unpackChangepointNames()
+            names = self._unpackChangepointNames() + self._unpackBreakpointNames()
             if len(names) > 1:
                 cols = [self.flatHyperParameterNames.index(n) for n in names]
                 for v in self.hyperGridValues[:, cols]:
@@ -663,7 +669,7 @@ class HyperStudy(Study):
             self._setAllHyperParameters(self.flatHyperParameters)
         slots = self._hyperSlots()
         col = []
-        for kind, axis, model, k in program:
+        for kind, axis, model, k, seg, flg in program:
             col.append(None if k is None else [i for i, s in enumerate(slots) if s[0] is model and s[1] == k][0])
         hv = np.asarray(self.hyperGridValues, dtype=float)
         op_values = np.full((len(hv), max(1, len(program))), np.nan)
@@ -778,10 +784,21 @@ class ChangepointStudy(HyperStudy):
 
     def fit(self, forwardOnly=False, evidenceOnly=False, silent=False, nJobs=1):
         self._formatData()
+        serials = [m for m, k, name in self._hyperSlots() if isinstance(m, SerialTransitionModel)]
+        if len(set(id(m) for m in serials)) > 1:
+            raise NotImplementedError('Multiple instances of SerialTransition models are currently not supported by '
+                                      'ChangepointStudy.')
         changepoints = self._unpackChangepointNames()
-        if len(changepoints) == 0:
+        breakpoints = self._unpackBreakpointNames()
+        if len(changepoints) > 0 and len(breakpoints) > 0:
+            raise NotImplementedError('Detected both change-points (Changepoint transition model) and break-points '
+                                      '(SerialTransitionModel). Currently, only one type is supported in a single '
+                                      'transition model.')
+        if len(changepoints) == 0 and len(breakpoints) == 0:
             raise ConfigurationError('No change-points or break-points detected in transition model. Check transition '
                                      'model.')
+        if len(changepoints) == 0:
+            changepoints = breakpoints
         self.flatHyperParameters = self._unpackAllHyperParameters()
         self.flatHyperParameterNames = self._unpackAllHyperParameters(values=False)
         if not silent:

@@ -328,7 +328,9 @@ void validate(const blhip_problem *p, int64_t n_chains, const double *op_values)
             if (op.axis < 0 || op.axis >= p->ndim) fail("GRW op %d: axis %d out of range", k, op.axis);
         } else if (op.kind == BLHIP_OP_CHANGEPOINT) {
             has_cp = true;
-        } else if (op.kind != BLHIP_OP_STATIC) {
+        } else if (op.kind == BLHIP_OP_INDEPENDENT) {
+            if (!p->indep_prior) fail("INDEPENDENT op needs indep_prior");
+        } else if (op.kind != BLHIP_OP_STATIC && op.kind != BLHIP_OP_REGIMESWITCH && op.kind != BLHIP_OP_BREAKPOINT) {
             fail("op %d: unknown kind %d", k, op.kind);
         }
     }
@@ -392,68 +394,114 @@ void build_records(const blhip_problem *p, std::vector<double> &rec, int &rec_le
 }
 
 struct ChainProgram {
-    // per (step, chain): source kind and tap ids per internal axis, forward and backward
-    std::vector<unsigned char> kindF, kindB;
+    // per (step, chain): source kind, tap ids per internal axis, clamp mode/limit (RegimeSwitch); forward and backward
+    std::vector<unsigned char> kindF, kindB, cmodeF, cmodeB;
     std::vector<int> tapF0, tapF1, tapB0, tapB1;
+    std::vector<double> limitF, limitB;
     int LW0 = 0, LW1 = 0;
+    bool has_clamp = false;
+};
+
+struct StepProg {
+    unsigned char kind = SRC_PREV, cmode = 0;   // cmode: 0 none, 1 clamp the source (before the stencil), 2 clamp after it
+    int t0 = -1, t1 = -1;
+    double limit = 0.0;
 };
 
 void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_t B, const double *op_values,
                    TapTable &taps, ChainProgram &prog) {
     const int64_t T = p->T;
     const int nops = p->n_ops;
-    prog.kindF.assign(T * B, SRC_PREV); prog.kindB.assign(T * B, SRC_PREV);
-    prog.tapF0.assign(T * B, -1); prog.tapF1.assign(T * B, -1);
-    prog.tapB0.assign(T * B, -1); prog.tapB1.assign(T * B, -1);
+    const size_t nT = (size_t)T * B;
+    prog.kindF.assign(nT, SRC_PREV); prog.kindB.assign(nT, SRC_PREV);
+    prog.cmodeF.assign(nT, 0); prog.cmodeB.assign(nT, 0);
+    prog.limitF.assign(nT, 0.0); prog.limitB.assign(nT, 0.0);
+    prog.tapF0.assign(nT, -1); prog.tapF1.assign(nT, -1);
+    prog.tapB0.assign(nT, -1); prog.tapB1.assign(nT, -1);
     prog.LW0 = prog.LW1 = 0;
+    prog.has_clamp = false;
+    double dV = 1.0;
+    for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
     for (int64_t b = 0; b < B; ++b) {
         const double *val = op_values ? op_values + (c0 + b) * nops : nullptr;
         // tap ids of this chain's GRW ops
         std::vector<int> op_tap(nops, -1), op_axis(nops, -1);
-        bool any_cp = false;
+        bool time_dependent = false;
         for (int k = 0; k < nops; ++k) {
-            if (p->ops[k].kind == BLHIP_OP_GRW) {
-                const int ax = g.axis_map[p->ops[k].axis];
-                const double ns = val[k] / p->lattice[p->ops[k].axis];     // transitionModels.py:108
+            const blhip_op &op = p->ops[k];
+            if (op.kind == BLHIP_OP_GRW) {
+                const int ax = g.axis_map[op.axis];
+                const double ns = val[k] / p->lattice[op.axis];            // transitionModels.py:108
                 op_axis[k] = ax;
                 op_tap[k] = (ns > 0.0) ? taps.get(ax, ns) : -1;            // :110-113 (sigma <= 0: copy)
                 if (std::isnan(ns)) fail("chain %lld: GRW sigma is NaN", (long long)(c0 + b));
-            } else if (p->ops[k].kind == BLHIP_OP_CHANGEPOINT) {
-                any_cp = true;
+            } else if (op.kind == BLHIP_OP_CHANGEPOINT || op.kind == BLHIP_OP_BREAKPOINT) {
+                time_dependent = true;
+            } else if (op.kind == BLHIP_OP_REGIMESWITCH) {
+                prog.has_clamp = true;
             }
         }
-        auto run = [&](double tstamp, unsigned char &kind, int &t0, int &t1) {
-            kind = SRC_PREV; t0 = -1; t1 = -1;
+        // the transition from one step to the next, evaluated at time stamp tau (list order, transitionModels.py:645-649)
+        auto run = [&](double tau, bool have_tau) {
+            StepProg sp;
+            int seg = 0;                                                   // active sub-model of a serial model (:768)
+            if (have_tau)
+                for (int k = 0; k < nops; ++k) {
+                    const blhip_op &op = p->ops[k];
+                    if ((op.kind == BLHIP_OP_BREAKPOINT || (op.kind == BLHIP_OP_CHANGEPOINT && (op.flags & 1))) && val[k] <= tau) seg++;
+                }
+            bool filtered = false;
             for (int k = 0; k < nops; ++k) {
-                if (p->ops[k].kind == BLHIP_OP_GRW) {
-                    if (op_tap[k] < 0) continue;
-                    int &slot = op_axis[k] == 0 ? t0 : t1;
-                    if (slot >= 0)
-                        fail("two GaussianRandomWalk ops on the same parameter in one combined model are not supported");
-                    slot = op_tap[k];
-                } else if (p->ops[k].kind == BLHIP_OP_CHANGEPOINT) {
-                    if (tstamp == val[k]) { kind = SRC_RESET; t0 = -1; t1 = -1; }   // transitionModels.py:300-312
+                const blhip_op &op = p->ops[k];
+                if (op.segment >= 0 && op.segment != seg) continue;
+                switch (op.kind) {
+                    case BLHIP_OP_GRW: {
+                        if (op_tap[k] < 0) break;
+                        if (sp.cmode == 2) fail("a GaussianRandomWalk after a RegimeSwitch in one combined model is not supported");
+                        int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
+                        if (slot >= 0)
+                            fail("two GaussianRandomWalk ops on the same parameter in one combined model are not supported");
+                        slot = op_tap[k];
+                        filtered = true;
+                        break;
+                    }
+                    case BLHIP_OP_CHANGEPOINT:
+                        if (!(op.flags & 1) && have_tau && tau == val[k]) {      // transitionModels.py:300-312
+                            sp = StepProg(); sp.kind = SRC_RESET; filtered = false;
+                        }
+                        break;
+                    case BLHIP_OP_INDEPENDENT:                                    // transitionModels.py:351-360
+                        sp = StepProg(); sp.kind = SRC_INDEP; filtered = false;
+                        break;
+                    case BLHIP_OP_REGIMESWITCH:                                   // transitionModels.py:405-410
+                        if (sp.cmode != 0) fail("two RegimeSwitch models acting at the same time are not supported");
+                        sp.cmode = filtered ? 2 : 1;
+                        sp.limit = std::pow(10.0, val[k]) * dV;
+                        break;
+                    default: break;
                 }
             }
+            if (have_tau)
+                for (int k = 0; k < nops; ++k) {                                  // serial change-points, :801-813
+                    const blhip_op &op = p->ops[k];
+                    if (op.kind == BLHIP_OP_CHANGEPOINT && (op.flags & 1) && tau == val[k]) { sp = StepProg(); sp.kind = SRC_RESET; }
+                }
+            if (sp.t0 >= 0) prog.LW0 = std::max(prog.LW0, taps.lw[sp.t0]);
+            if (sp.t1 >= 0) prog.LW1 = std::max(prog.LW1, taps.lw[sp.t1]);
+            return sp;
         };
-        unsigned char kstat; int s0, s1;
-        run(std::numeric_limits<double>::quiet_NaN(), kstat, s0, s1);   // the program away from change-points
+        const StepProg stat = run(0.0, false);       // the program when nothing depends on the time stamp
         for (int64_t t = 0; t < T; ++t) {
             // forward step t consumes T_fwd(post_{t-1}, ts[t-1])   core.py:411
-            unsigned char kf = SRC_PRIOR; int f0 = -1, f1 = -1;
-            if (t > 0) {
-                if (any_cp) run(p->timestamps[t - 1], kf, f0, f1); else { kf = kstat; f0 = s0; f1 = s1; }
-            }
+            StepProg f; f.kind = SRC_PRIOR;
+            if (t > 0) f = time_dependent ? run(p->timestamps[t - 1], true) : stat;
             // backward step t consumes T_bwd(beta_{t+1} L_{t+1}, ts[t+1]) = T_fwd(., ts[t+1] - 1)   core.py:467, transitionModels.py:316-317
-            unsigned char kb = SRC_UNIFORM; int b0 = -1, b1 = -1;
-            if (t < T - 1) {
-                if (any_cp) run(p->timestamps[t + 1] - 1.0, kb, b0, b1); else { kb = kstat; b0 = s0; b1 = s1; }
-            }
-            prog.kindF[t * B + b] = kf; prog.tapF0[t * B + b] = f0; prog.tapF1[t * B + b] = f1;
-            prog.kindB[t * B + b] = kb; prog.tapB0[t * B + b] = b0; prog.tapB1[t * B + b] = b1;
+            StepProg r; r.kind = SRC_UNIFORM;
+            if (t < T - 1) r = time_dependent ? run(p->timestamps[t + 1] - 1.0, true) : stat;
+            const size_t k = (size_t)t * B + b;
+            prog.kindF[k] = f.kind; prog.tapF0[k] = f.t0; prog.tapF1[k] = f.t1; prog.cmodeF[k] = f.cmode; prog.limitF[k] = f.limit;
+            prog.kindB[k] = r.kind; prog.tapB0[k] = r.t0; prog.tapB1[k] = r.t1; prog.cmodeB[k] = r.cmode; prog.limitB[k] = r.limit;
         }
-        if (s0 >= 0) prog.LW0 = std::max(prog.LW0, taps.lw[s0]);
-        if (s1 >= 0) prog.LW1 = std::max(prog.LW1, taps.lw[s1]);
     }
 }
 
@@ -507,7 +555,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
     const bool has_reset = p->reset_prior != nullptr;
     size_t tb = 0;
     tb += carve_size(sizeof(double) * std::max(1, g.n0)) + 3 * carve_size(sizeof(double) * g.n1);
-    tb += carve_size(sizeof(double) * rec.size()) + 3 * carve_size(sizeof(double) * G);
+    tb += carve_size(sizeof(double) * rec.size()) + 4 * carve_size(sizeof(double) * G);
     ctx->tables.ensure(tb);
     char *cur = ctx->tables.as<char>();
     double *d_m0 = carve<double>(cur, std::max(1, g.n0));
@@ -518,6 +566,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
     double *d_prior = carve<double>(cur, G);
     double *d_reset = carve<double>(cur, G);
     double *d_uniform = carve<double>(cur, G);
+    double *d_indep = carve<double>(cur, G);
     if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(d_m0, p->marginal[0], sizeof(double) * g.n0, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(d_m1, mcol, sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(d_colA, colA.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
@@ -525,6 +574,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
     HIPCHECK(hipMemcpyAsync(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(d_prior, p->prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
     if (has_reset) HIPCHECK(hipMemcpyAsync(d_reset, p->reset_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    if (p->indep_prior) HIPCHECK(hipMemcpyAsync(d_indep, p->indep_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
     if (full) {
         // beta_T = 1/G   core.py:424-425
         hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);
@@ -563,10 +613,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         build_program(p, g, c0, B, op_values, taps, prog);
         // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
         const bool fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
-                          ctx->option("fast", 1.0) != 0.0 && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
+                          ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
                           g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
         const size_t p1_lds = ((size_t)2 * (g.n1 + 2 * prog.LW1) + 64 + prog.LW1 + 2) * sizeof(double);
-        const bool persist = p->ndim == 1 && !fast && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
+        const bool persist = p->ndim == 1 && !fast && !prog.has_clamp && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
                              prog.LW1 <= g.n1 && p1_lds <= 150 * 1024 &&
                              (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
                               p->obs_model == BLHIP_OM_TABLE);
@@ -606,11 +656,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         // --- device metadata ---
         const size_t nT = (size_t)T * B;
         taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
-        size_t mb = 2 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
-                    2 * carve_size(taps.off.size() * 4 + 4) + 2 * carve_size(sizeof(double) * nT) + carve_size(8 * B);
+        size_t mb = 4 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
+                    2 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B);
         ctx->meta.ensure(mb);
         cur = ctx->meta.as<char>();
         unsigned char *d_kindF = carve<unsigned char>(cur, nT), *d_kindB = carve<unsigned char>(cur, nT);
+        unsigned char *d_cmodeF = carve<unsigned char>(cur, nT), *d_cmodeB = carve<unsigned char>(cur, nT);
+        double *d_limitF = carve<double>(cur, nT), *d_limitB = carve<double>(cur, nT);
         int *d_tapF0 = carve<int>(cur, nT), *d_tapF1 = carve<int>(cur, nT);
         int *d_tapB0 = carve<int>(cur, nT), *d_tapB1 = carve<int>(cur, nT);
         int *d_orderF = carve<int>(cur, nT), *d_orderB = carve<int>(cur, nT);
@@ -623,6 +675,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         HIPCHECK(hipMemcpyAsync(d_kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(d_tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(d_tapF1, prog.tapF1.data(), nT * 4, hipMemcpyHostToDevice, st));
+        if (prog.has_clamp) {
+            HIPCHECK(hipMemcpyAsync(d_cmodeF, prog.cmodeF.data(), nT, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_limitF, prog.limitF.data(), nT * 8, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_cmodeB, prog.cmodeB.data(), nT, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_limitB, prog.limitB.data(), nT * 8, hipMemcpyHostToDevice, st));
+        }
         if (full) {
             HIPCHECK(hipMemcpyAsync(d_kindB, prog.kindB.data(), nT, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
@@ -668,7 +726,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         P.n0 = g.n0; P.n1 = g.n1; P.TI = tile.TI; P.TJ = tile.TJ; P.LW0 = tile.LW0; P.LW1 = tile.LW1;
         P.tiles_i = tile.tiles_i; P.tiles_j = tile.tiles_j; P.nblk = tile.nblk; P.ndim = p->ndim; P.d = d;
         P.rec_len = rec_len; P.shared[SRC_PREV] = nullptr; P.shared[SRC_PRIOR] = d_prior; P.shared[SRC_RESET] = d_reset;
-        P.shared[SRC_UNIFORM] = d_uniform; P.taps = d_taps; P.tap_off = d_off; P.tap_lw = d_lw;
+        P.shared[SRC_UNIFORM] = d_uniform; P.shared[SRC_INDEP] = d_indep; P.taps = d_taps; P.tap_off = d_off; P.tap_lw = d_lw;
         P.m0 = d_m0; P.m1 = d_m1; P.colA = d_colA; P.colB = d_colB; P.chains = (int)B;
         P.prev_nblk = tile.nblk;
 
@@ -678,7 +736,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk;
             FP.ndim = p->ndim; FP.d = d; FP.means = forward_only ? 1 : 0;
             FP.shared[SRC_PREV] = nullptr; FP.shared[SRC_PRIOR] = d_prior; FP.shared[SRC_RESET] = d_reset;
-            FP.shared[SRC_UNIFORM] = d_uniform; FP.taps = d_taps; FP.tap_off = d_off; FP.tap_lw = d_lw;
+            FP.shared[SRC_UNIFORM] = d_uniform; FP.shared[SRC_INDEP] = d_indep; P.shared[SRC_INDEP] = d_indep; FP.taps = d_taps; FP.tap_off = d_off; FP.tap_lw = d_lw;
             FP.m0 = d_m0; FP.m1 = d_m1; FP.colA = d_colA; FP.colB = d_colB; FP.prev_nblk = tile.nblk;
             // likelihood recurrence along rows needs an equally spaced row axis (to rounding)
             const double *m0h = p->marginal[0];
@@ -742,6 +800,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 Q.srckind = (mode == MODE_FWD ? d_kindF : d_kindB) + t * B;
                 Q.tap0 = (mode == MODE_FWD ? d_tapF0 : d_tapB0) + t * B;
                 Q.tap1 = (mode == MODE_FWD ? d_tapF1 : d_tapB1) + t * B;
+                Q.cmode = prog.has_clamp ? (mode == MODE_FWD ? d_cmodeF : d_cmodeB) + t * B : nullptr;
+                Q.limit = prog.has_clamp ? (mode == MODE_FWD ? d_limitF : d_limitB) + t * B : nullptr;
                 Q.psum_prev = ps_prev; Q.prev_slot = prev_slot; Q.psum_out = ps_out;
                 Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
                 launch_step(st, p->obs_model, Q, tile, (int)B, mode, means);
@@ -752,7 +812,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         if (persist) {
             PP.n = g.n1; PP.T = (int)T; PP.B = (int)B; PP.LW = prog.LW1; PP.d = d; PP.rec_len = rec_len;
             PP.shared[SRC_PREV] = nullptr; PP.shared[SRC_PRIOR] = d_prior; PP.shared[SRC_RESET] = d_reset;
-            PP.shared[SRC_UNIFORM] = d_uniform; PP.post = d_post; PP.post_stride = (long long)T * G;
+            PP.shared[SRC_UNIFORM] = d_uniform; PP.shared[SRC_INDEP] = d_indep; P.shared[SRC_INDEP] = d_indep; PP.post = d_post; PP.post_stride = (long long)T * G;
             PP.taps = d_taps; PP.tap_off = d_off; PP.tap_lw = d_lw; PP.m1 = d_m1; PP.colA = d_colA; PP.rec = d_rec;
             PP.lik = d_lik;
         }
@@ -799,7 +859,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         for (int64_t b = 0; b < B; ++b) {
             double le = 0.0;
             for (int64_t t = 0; t < T; ++t) {
-                const double norm = redF[((size_t)t * B + b) * NRED + 0];
+                double norm = redF[((size_t)t * B + b) * NRED + 0];
+                // RegimeSwitch renormalises the clamped prior (transitionModels.py:410): alpha = (u / sum u) L
+                if (prog.has_clamp && prog.cmodeF[(size_t)t * B + b]) norm /= redF[((size_t)t * B + b) * NRED + 1];
                 if (!(norm > 0.0)) { abort_step[b] = t; abort_phase[b] = 0; le = -INFINITY; break; }
                 le += std::log(norm);
                 local[(size_t)b * T + t] = norm * dV;

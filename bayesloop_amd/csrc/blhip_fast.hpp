@@ -42,7 +42,7 @@ struct FastParams {
     const double *src;  long long src_stride;
     double       *dst;  long long dst_stride;
     double       *post; long long post_stride;
-    const double *shared[4];
+    const double *shared[5];
     const int *chain_ids;        // [gridDim.y] -> chain index in the batch
     const unsigned char *srckind;
     const int *tap0, *tap1;

@@ -16,10 +16,10 @@
 namespace blk {
 
 constexpr int NTHREADS = 256;
-constexpr int NRED = 5;          // partial-sum slots per (step, chain): 0 N  1 S(p/L)  2 C  3 M0  4 M1
+constexpr int NRED = 6;          // partial-sum slots per (step, chain): 0 N  1 S(p/L) [fwd: U]  2 C  3 M0  4 M1  5 B (clamp only)
 
 enum Mode { MODE_FWD = 0, MODE_BWD = 1, MODE_FILTER = 2 };
-enum SrcKind { SRC_PREV = 0, SRC_PRIOR = 1, SRC_RESET = 2, SRC_UNIFORM = 3 };
+enum SrcKind { SRC_PREV = 0, SRC_PRIOR = 1, SRC_RESET = 2, SRC_UNIFORM = 3, SRC_INDEP = 4 };
 
 struct StepParams {
     // geometry (internal axes: 0 = rows (slow), 1 = cols (fast))
@@ -34,10 +34,11 @@ struct StepParams {
     const double *src;  long long src_stride;     // SRC_PREV source, per-chain stride (doubles)
     double       *dst;  long long dst_stride;     // new state (FWD: a_t ; BWD: c_i ; FILTER: filtered)
     double       *post; long long post_stride;    // BWD: stored alpha_i (in) -> posterior_i (out), per-chain stride
-    const double *shared[4];                      // [SRC_PRIOR], [SRC_RESET], [SRC_UNIFORM] shared sources (G)
+    const double *shared[5];                      // [SRC_PRIOR], [SRC_RESET], [SRC_UNIFORM], [SRC_INDEP] shared sources (G)
     // per-chain metadata of this step (pre-offset to the step)
     const unsigned char *srckind;                 // [B]
     const int *tap0, *tap1;                       // [B] tap-set ids per internal axis, -1 = identity
+    const unsigned char *cmode; const double *limit;   // [B] RegimeSwitch clamp (0 none, 1 source, 2 after stencil); nullptr if unused
     // tap table
     const double *taps; const int *tap_off; const int *tap_lw;
     // lazy normalisation
@@ -149,23 +150,35 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     const int XW = P.TI == 1 ? NTHREADS : 64, YN = NTHREADS / XW;
     const int x = threadIdx.x & (XW - 1), y = threadIdx.x / XW;
 
-    // ---- phase 1: source tile + halo -> LDS (reflect boundary resolved here) -----------------------------------
+    // lazy normaliser of the producing step (every block sums the same partials in the same order)
+    double scale = 1.0, kappa = 1.0;
+    const int cm = P.cmode ? P.cmode[b] : 0;
+    const double lim = P.cmode ? P.limit[b] : 0.0;
+    if (MODE != MODE_FILTER && kind == SRC_PREV) {
+        const double s = sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
+        scale = 1.0 / s;
+        if (MODE == MODE_BWD && P.cmode) {
+            // RegimeSwitch clamps F(beta_norm * L) (transitionModels.py:405-407): that needs 1 / sum(beta) of the producing
+            // step (slot 5); products keep the well-scaled normaliser 1 / sum(c) (slot 2):  beta_used = u * kappa
+            const double sb = sum_partials(P.psum_prev + ((long long)b * NRED + 5) * P.prev_nblk, P.prev_nblk, red);
+            kappa = sb * scale;
+            scale = 1.0 / sb;
+        }
+    }
+
+    // ---- phase 1: source tile + halo -> LDS (reflect boundary resolved here; a source clamp is applied here too) ------
     for (int r = P.LW0 - lw0 + y; r < P.LW0 + th + lw0; r += YN) {
         const int gi = reflect(i0 - P.LW0 + r, P.n0);
         const double *row = src + (long long)gi * P.n1;
         double *dstrow = in_tile + (size_t)r * pitch;
         for (int c = P.LW1 - lw1 + x; c < P.LW1 + tw + lw1; c += XW) {
             const int gj = reflect(j0 - P.LW1 + c, P.n1);
-            dstrow[c] = row[gj];
+            double v = row[gj];
+            if (cm == 1) { v *= scale; v = v < lim ? lim : v; }
+            dstrow[c] = v;
         }
     }
-
-    // lazy normaliser of the producing step (every block sums the same partials in the same order)
-    double scale = 1.0;
-    if (MODE != MODE_FILTER && kind == SRC_PREV) {
-        const double s = sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
-        scale = 1.0 / s;
-    }
+    if (cm == 1) scale = 1.0;
     __syncthreads();
 
     // ---- phase 2: filter along axis 0 (rows), SciPy's symmetric correlate1d order -------------------------------
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     }
 
     // ---- phase 3: filter along axis 1 (cols) + epilogue ---------------------------------------------------------
-    double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
+    double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0, sU = 0.0;
     for (int c = x; c < tw; c += XW) {
         const int gj = j0 + c;
         double cA = 0.0, cB = 0.0, g1 = 0.0;
@@ -209,15 +222,19 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
                 P.dst[(long long)b * P.dst_stride + cell] = o;
             } else {
                 const double L = likelihood<OM>(P, gi, gj, cA, cB, g1);
+                double u = o * scale;                                    // the (normalised) prior of this step
+                if (cm == 2) u = u < lim ? lim : u;                      // RegimeSwitch after the stencil
+                // mass of the clamped distribution (the reference renormalises by it, transitionModels.py:410)
+                sU += cm == 1 ? in_tile[(size_t)(r + P.LW0) * pitch + P.LW1 + c] : u;
                 if (MODE == MODE_FWD) {
-                    const double a = o * scale * L;
+                    const double a = u * L;
                     P.dst[(long long)b * P.dst_stride + cell] = a;
                     sN += a;
                     if (MEANS) {
                         if (P.ndim == 2) { sM0 += a * P.m0[gi]; sM1 += a * g1; } else { sM0 += a * g1; }
                     }
                 } else {
-                    const double beta = o * scale;
+                    const double beta = u * kappa;
                     double *pp = P.post + (long long)b * P.post_stride + cell;
                     const double p = (*pp) * beta;
                     *pp = p;
@@ -245,6 +262,10 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
         double r3 = block_sum(sM0, red);
         double r4 = block_sum(sM1, red);
         if (threadIdx.x == 0) { out[3 * P.nblk] = r3; out[4 * P.nblk] = r4; }
+    }
+    if (P.cmode) {                                 // clamp bookkeeping: fwd U = sum u (slot 1), bwd B = sum beta_used (slot 5)
+        double r5 = block_sum(MODE == MODE_BWD ? sU * kappa : sU, red);
+        if (threadIdx.x == 0) out[(MODE == MODE_BWD ? 5 : 1) * P.nblk] = r5;
     }
 }
 

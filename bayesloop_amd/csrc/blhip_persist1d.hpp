@@ -22,7 +22,7 @@ constexpr int MAXC = 8;           // cells per thread (grids up to 8192 cells)
 
 struct P1Params {
     int n, T, B, LW, d, rec_len, store, means;
-    const double *shared[4];      // [SRC_PRIOR], [SRC_RESET], [SRC_UNIFORM]
+    const double *shared[5];      // [SRC_PRIOR], [SRC_RESET], [SRC_UNIFORM]
     double *post; long long post_stride;            // (B, T, n) or nullptr (evidence only)
     const unsigned char *srckind;                   // [T][B]
     const int *tap;                                 // [T][B] tap-set id of the (single) axis, -1 = identity

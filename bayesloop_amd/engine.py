@@ -28,8 +28,9 @@ class FitProblem:
     data: np.ndarray                    # formatted data (T, seg[, d]) (core.py:349)
     timestamps: np.ndarray              # formatted timestamps (T,) (core.py:350)
     prior: np.ndarray                   # alpha_0 on the grid (core.py:363)
-    ops: List[Tuple[int, int]]          # transition program [(kind, axis)], list order
+    ops: List[Tuple]                    # transition program [(kind, axis[, segment, flags])], list order
     reset_prior: Optional[np.ndarray] = None    # what a ChangePoint resets to (transitionModels.py:300-312)
+    indep_prior: Optional[np.ndarray] = None    # what Independent restarts from (transitionModels.py:351-360)
     lik: Optional[np.ndarray] = None    # (T, G) host-evaluated likelihood for OM_TABLE
     seg_len: int = 1
 
@@ -158,14 +159,20 @@ class HipEngine:
             rp = _f64(p.reset_prior).ravel()
             keep.append(rp)
             cp.reset_prior = _abi.dptr(rp)
+        if p.indep_prior is not None:
+            ip = _f64(p.indep_prior).ravel()
+            keep.append(ip)
+            cp.indep_prior = _abi.dptr(ip)
         if p.lik is not None:
             lik = _f64(p.lik).reshape(T, G)
             keep.append(lik)
             cp.lik = _abi.dptr(lik)
         ops = (_abi.Op * max(1, len(p.ops)))()
-        for k, (kind, axis) in enumerate(p.ops):
-            ops[k].kind = kind
-            ops[k].axis = axis
+        for k, op in enumerate(p.ops):
+            ops[k].kind = op[0]
+            ops[k].axis = op[1]
+            ops[k].segment = op[2] if len(op) > 2 else -1
+            ops[k].flags = op[3] if len(op) > 3 else 0
         keep.append(ops)
         cp.n_ops = len(p.ops)
         cp.ops = ops

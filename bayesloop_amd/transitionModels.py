@@ -10,7 +10,10 @@ both directions, inside the fused HIP step kernels:
     Static                  -> nothing                                   (identity)
     GaussianRandomWalk      -> GRW(axis, sigma): reflect-boundary Gaussian stencil along one grid axis
     ChangePoint             -> CHANGEPOINT(tChange): restart from the (re-normalised) prior at one time stamp
+    RegimeSwitch            -> REGIMESWITCH(log10pMin): clamp from below and renormalise
+    Independent             -> INDEPENDENT: restart from the normalised prior at every step
     CombinedTransitionModel -> concatenation of the sub-models' programs
+    SerialTransitionModel   -> the sub-models' programs tagged with their segment + BREAKPOINT / boundary CHANGEPOINT ops
 
 Constructor arguments and the attributes the study classes rely on (``hyperParameterNames``, ``hyperParameterValues``,
 ``prior``, ``models``) are those of the reference, so the hyper-parameter plumbing of HyperStudy / ChangepointStudy
@@ -31,7 +34,7 @@ class TransitionModel:
     hyperParameterValues = ()
 
     def _program(self, parameterNames):
-        """-> list of (op kind, axis, owner model, hyper-parameter index or None)"""
+        """-> list of (op kind, axis, owner model, hyper-parameter index or None, serial segment or -1, flags)"""
         raise ConfigurationError('Transition model "{}" cannot be compiled for the MI355X engine.'.format(self))
 
     def computeForwardPrior(self, posterior, t):
@@ -61,7 +64,7 @@ class Static(TransitionModel):
         return 'Static/constant parameter values'
 
     def _program(self, parameterNames):
-        return [(_abi.OP_STATIC, 0, self, None)]
+        return [(_abi.OP_STATIC, 0, self, None, -1, 0)]
 
 
 class GaussianRandomWalk(TransitionModel):
@@ -85,7 +88,7 @@ class GaussianRandomWalk(TransitionModel):
         if self.selectedParameter not in parameterNames:
             raise ConfigurationError('GaussianRandomWalk: observation model has no parameter "{}".'
                                      .format(self.selectedParameter))
-        return [(_abi.OP_GRW, list(parameterNames).index(self.selectedParameter), self, 0)]
+        return [(_abi.OP_GRW, list(parameterNames).index(self.selectedParameter), self, 0, -1, 0)]
 
 
 class ChangePoint(TransitionModel):
@@ -103,7 +106,7 @@ class ChangePoint(TransitionModel):
         return 'Change-point'
 
     def _program(self, parameterNames):
-        return [(_abi.OP_CHANGEPOINT, 0, self, 0)]
+        return [(_abi.OP_CHANGEPOINT, 0, self, 0, -1, 0)]
 
 
 class CombinedTransitionModel(TransitionModel):
@@ -128,11 +131,115 @@ class CombinedTransitionModel(TransitionModel):
         return program
 
 
+class RegimeSwitch(TransitionModel):
+    """Minimal probability density 10**log10pMin for every parameter value at each step (clamp from below, then
+    renormalise; reference transitionModels.py:366-415)."""
+
+    def __init__(self, name='log10pMin', value=None, prior=None):
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = [name]
+        self.hyperParameterValues = [_as_values(value)]
+        self.prior = prior
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Regime-switching model'
+
+    def _program(self, parameterNames):
+        return [(_abi.OP_REGIMESWITCH, 0, self, 0, -1, 0)]
+
+
+class Independent(TransitionModel):
+    """Independent observations: the (normalised) prior is restored at every step (reference transitionModels.py:320-363)."""
+
+    def __init__(self):
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = []
+        self.hyperParameterValues = []
+        self.prior = None
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Independent observations model'
+
+    def _program(self, parameterNames):
+        return [(_abi.OP_INDEPENDENT, 0, self, None, -1, 0)]
+
+
+class BreakPoint(TransitionModel):
+    """Break-point between two sub-models of a SerialTransitionModel (reference transitionModels.py:821-840)."""
+
+    def __init__(self, name='tBreak', value=None, prior=None):
+        self.name = name
+        self.value = _as_values(value)
+        self.prior = prior
+
+    def __str__(self):
+        return 'Break-point'
+
+
+class SerialTransitionModel(TransitionModel):
+    """Different models act at different times: n sub-models separated by n-1 break-points / change-points given in
+    increasing order (reference transitionModels.py:665-818).  At time stamp t the sub-model with index
+    ``#(boundaries <= t)`` acts; a change-point additionally restarts the parameters from the prior."""
+
+    def __init__(self, *args):
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames, self.hyperParameterValues, self.prior = [], [], []
+        self.models, mask = [], []
+        for arg in args:
+            if str(arg) == 'Break-point':
+                self.hyperParameterNames.append(arg.name)
+                self.hyperParameterValues.append(arg.value)
+                self.prior.append(arg.prior)
+                mask.append(0)
+            elif str(arg) == 'Change-point':
+                self.hyperParameterNames.append(arg.hyperParameterNames[0])
+                self.hyperParameterValues.append(arg.hyperParameterValues[0])
+                self.prior.append(arg.prior)
+                mask.append(1)
+            else:
+                self.models.append(arg)
+        self.changePointMask = np.array(mask).astype(bool)
+
+        first = []
+        for v in self.hyperParameterValues:
+            first.append(v if (isinstance(v, str) or np.ndim(v) == 0) else v[0])
+        for x, y in zip(first, first[1:]):
+            if not (isinstance(x, str) or isinstance(y, str)) and not x < y:
+                raise ConfigurationError('Time steps for structural breaks and/or change-points have to be passed in '
+                                         'monotonically increasing order.')
+        if len(self.models) - 1 != len(self.hyperParameterValues):
+            raise ConfigurationError('Wrong number of structural breaks/change-points and models. For n models, n-1 '
+                                     'structural breaks/change-points are required.')
+
+    def __str__(self):
+        return 'Serial transition model'
+
+    def _program(self, parameterNames):
+        program = []
+        for seg, m in enumerate(self.models):
+            for op in m._program(parameterNames):
+                if op[4] != -1 or op[0] == _abi.OP_BREAKPOINT or (op[0] == _abi.OP_CHANGEPOINT and op[5] & 1):
+                    raise ConfigurationError('Nested SerialTransitionModel instances are not supported.')
+                program.append((op[0], op[1], op[2], op[3], seg, op[5]))
+        for k in range(len(self.hyperParameterNames)):
+            if self.changePointMask[k]:
+                program.append((_abi.OP_CHANGEPOINT, 0, self, k, -1, 1))
+            else:
+                program.append((_abi.OP_BREAKPOINT, 0, self, k, -1, 0))
+        return program
+
+
 def _not_yet(name, where):
     class _Unavailable(TransitionModel):
         def __init__(self, *args, **kwargs):
             raise NotImplementedError('bl.tm.{} (reference {}) is not available on the MI355X engine yet; this build '
-                                      'covers Static, GaussianRandomWalk, ChangePoint and CombinedTransitionModel.'
+                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, Independent, Combined- and '
+                                      'SerialTransitionModel (with BreakPoint).'
                                       .format(name, where))
     _Unavailable.__name__ = name
     return _Unavailable
@@ -140,10 +247,6 @@ def _not_yet(name, where):
 
 # rows of SURVEY.md section 8(f): not on the hot path named by BASELINE.json
 AlphaStableRandomWalk = _not_yet('AlphaStableRandomWalk', 'transitionModels.py:121-260')
-Independent = _not_yet('Independent', 'transitionModels.py:320-363')
-RegimeSwitch = _not_yet('RegimeSwitch', 'transitionModels.py:366-415')
 NotEqual = _not_yet('NotEqual', 'transitionModels.py:418-474')
 Deterministic = _not_yet('Deterministic', 'transitionModels.py:477-606')
-SerialTransitionModel = _not_yet('SerialTransitionModel', 'transitionModels.py:665-818')
-BreakPoint = _not_yet('BreakPoint', 'transitionModels.py:821-840')
 BivariateRandomWalk = _not_yet('BivariateRandomWalk', 'transitionModels.py:843-911')

@@ -14,6 +14,7 @@
  * inside which the library evaluates
  *   ObservationModel.processedPdf + Poisson/Gaussian/GaussianMean.pdf   observationModels.py:35-56, 502, 566-567, 705-706
  *   GaussianRandomWalk / CombinedTransitionModel / ChangePoint / Static  transitionModels.py:49-63, 96-118, 289-317, 632-662
+ *   RegimeSwitch / Independent / SerialTransitionModel + BreakPoint      transitionModels.py:339-363, 394-415, 756-818
  *   (scipy.ndimage.gaussian_filter1d, mode='reflect', truncate=4.0, called at transitionModels.py:111).
  *
  * Conventions
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BLHIP_ABI_VERSION 1
+#define BLHIP_ABI_VERSION 2
 
 typedef struct blhip_ctx blhip_ctx;
 
@@ -48,14 +49,24 @@ enum {
 
 /* transition-model ops, applied in list order in both directions (transitionModels.py:645-649, 656-660) */
 enum {
-    BLHIP_OP_STATIC      = 0,     /* transitionModels.py:49-63    no hyper-parameter                          */
-    BLHIP_OP_GRW         = 1,     /* transitionModels.py:96-118   value = sigma, axis = target parameter index */
-    BLHIP_OP_CHANGEPOINT = 2      /* transitionModels.py:289-317  value = tChange                              */
+    BLHIP_OP_STATIC       = 0,    /* transitionModels.py:49-63    no hyper-parameter                           */
+    BLHIP_OP_GRW          = 1,    /* transitionModels.py:96-118   value = sigma, axis = target parameter index  */
+    BLHIP_OP_CHANGEPOINT  = 2,    /* transitionModels.py:289-317  value = tChange (flags bit 0: see below)      */
+    BLHIP_OP_REGIMESWITCH = 3,    /* transitionModels.py:394-415  value = log10 pMin: clamp from below, renormalise */
+    BLHIP_OP_INDEPENDENT  = 4,    /* transitionModels.py:339-363  restart from the normalised prior at every step */
+    BLHIP_OP_BREAKPOINT   = 5     /* transitionModels.py:821-840  value = tBreak: boundary between two sub-models of a
+                                     SerialTransitionModel (transitionModels.py:756-786) */
 };
 
+/* A SerialTransitionModel (transitionModels.py:665-818) is flattened into the same program: the ops of its n sub-models
+ * carry segment = 0..n-1, its n-1 boundaries are BREAKPOINT ops or CHANGEPOINT ops with flags bit 0 set (in list order).
+ * At time stamp t the active segment is the number of boundary values <= t (:768); ops with segment >= 0 act only
+ * while their segment is active; a boundary change-point additionally restarts from the prior at t == value (:801-813). */
 typedef struct {
     int32_t kind;                 /* BLHIP_OP_* */
     int32_t axis;                 /* GRW: index of the target parameter (0 .. ndim-1) */
+    int32_t segment;              /* -1: always active; >= 0: sub-model index of the serial model */
+    int32_t flags;                /* CHANGEPOINT: bit 0 = boundary of the serial model */
 } blhip_op;
 
 /* The fit problem: grid, data, prior, transition program (shared by all chains of a call). */
@@ -72,6 +83,7 @@ typedef struct {
     const double  *timestamps;    /* formatted timestamps (T,) (core.py:350)                                     */
     const double  *prior;         /* alpha_0: Study._computePrior() on the grid, (G,) (core.py:363)              */
     const double  *reset_prior;   /* what a change-point resets to, (G,) (transitionModels.py:300-312); NULL if no CHANGEPOINT op */
+    const double  *indep_prior;   /* what INDEPENDENT restarts from, (G,) (transitionModels.py:351-360); NULL if no such op */
     const double  *lik;           /* BLHIP_OM_TABLE only: likelihood (T, G) evaluated by the caller; else NULL   */
     int32_t        n_ops;         /* length of the transition program                                            */
     const blhip_op *ops;

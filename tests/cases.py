@@ -171,6 +171,40 @@ CASES = {
     'c5_two_cp': dict(study='ChangepointStudy', data=('series_jump', 5, 14, 7, 2.0), om=gauss2d(24, -4, 6, 3),
                       tm=('Combined', [('ChangePoint', 't1', ('arange', 1, 12, 2), None),
                                        ('ChangePoint', 't2', ('arange', 1, 12, 2), None)])),
+    # --- rows of SURVEY.md 8(f): RegimeSwitch, Independent, SerialTransitionModel + BreakPoint
+    # reference tests/test_transitionmodels.py:96-108, :110-122, :139-161
+    'kat_regimeswitch': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                             tm=('RS', 'p_min', -3, None), kat=-10.372866559561402),
+    'kat_independent': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                            tm=('Independent',), kat=-11.087360077190617),
+    'kat_nested': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                       tm=('Serial', [('Static',), ('ChangePoint', 't_change', 1, None),
+                                      ('Combined', [('GRW', 'sigma', 0.2, 'rate', None), ('RS', 'p_min', -3, None)]),
+                                      ('BreakPoint', 't_break', 3, None), ('Independent',)]), kat=-13.269918024215237),
+    # reference tests/test_study.py:54-78 and tests/test_hyperstudy.py:61-103
+    'kat_study_2hp': dict(study='Study', data=D15, om=('Poisson', [('rate', None)], 'default'),
+                          tm=('Combined', [('GRW', 'sigma', 0.1, 'rate', None), ('RS', 'log10pMin', -3, None)]),
+                          kat=-10.4342948181, kat_decimal=2),
+    'kat_hyper_2hp': dict(study='HyperStudy', data=D15, om=G2020,
+                          tm=('Combined', [('GRW', 'sigma', _g('cint', 0, 0.2, 2), 'mean', None),
+                                           ('RS', 'log10pMin', [-3, -1], None)]), kat=-10.7601875492),
+    # reference tests/test_changepointstudy.py:10-52
+    'kat_changepointstudy': dict(study='ChangepointStudy', data=D15, om=G2020,
+                                 tm=('Serial', [('Static',), ('ChangePoint', 'ChangePoint', [0, 1], None),
+                                                ('Combined', [('GRW', 'sigma', _g('cint', 0, 0.2, 2), 'mean', None),
+                                                              ('RS', 'log10pMin', [-3, -1], None)]),
+                                                ('BreakPoint', 'BreakPoint', 'all', None), ('Static',)]),
+                                 kat=-15.072007461556161),
+    'rs_before_grw_2d': dict(study='Study', data=('series', 12, 9), om=gauss2d(40, -4, 4, 3),
+                             tm=('Combined', [('RS', 'p', -4.5, None), ('GRW', 's1', 0.3, 'mean', None),
+                                              ('GRW', 's2', 0.1, 'std', None)])),
+    'rs_after_grw_2d': dict(study='HyperStudy', data=('series', 12, 9), om=gauss2d(40, -4, 4, 3),
+                            tm=('Combined', [('GRW', 's1', _g('cint', 0.1, 0.5, 3), 'mean', None),
+                                             ('RS', 'p', [-6, -3], None)])),
+    'serial_breakpoints_2d': dict(study='ChangepointStudy', data=('series_jump', 5, 16, 8, 2.0), om=gauss2d(32, -4, 6, 3),
+                                  tm=('Serial', [('GRW', 'sa', 0.1, 'mean', None), ('BreakPoint', 'b1', ('arange', 2, 14, 3), None),
+                                                 ('Static',), ('BreakPoint', 'b2', ('arange', 3, 15, 3), None),
+                                                 ('Combined', [('GRW', 'sb', 0.4, 'mean', None), ('GRW', 'sc', 0.1, 'std', None)])])),
     'cp_nonunit_time': dict(study='Study', data=D15, timestamps=np.array([0., 2., 4., 6., 8.]),
                             om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                             tm=('ChangePoint', 't_change', 4., None)),   # forward fires at t=4, backward at t-1: never
@@ -231,6 +265,14 @@ def make_tm(bl, spec):
         return bl.tm.ChangePoint(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'Combined':
         return bl.tm.CombinedTransitionModel(*[make_tm(bl, s) for s in spec[1]])
+    if kind == 'RS':
+        return bl.tm.RegimeSwitch(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
+    if kind == 'Independent':
+        return bl.tm.Independent()
+    if kind == 'BreakPoint':
+        return bl.tm.BreakPoint(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
+    if kind == 'Serial':
+        return bl.tm.SerialTransitionModel(*[make_tm(bl, s) for s in spec[1]])
     raise ValueError(spec)
 
 

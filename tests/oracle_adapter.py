@@ -55,6 +55,26 @@ def flatten_tm(spec, param_names):
             vals += v
             pri += p
         return ops, vals, pri
+    if kind == 'RS':
+        return [('regimeswitch',)], [cases.make_values(_Orc, spec[2])], [cases.make_prior(spec[3])]
+    if kind == 'Independent':
+        return [('independent',)], [], []
+    if kind == 'Serial':
+        # sub-models first (tagged with their segment), then the serial model's own break-/change-points
+        ops, vals, pri, seg = [], [], [], 0
+        bops, bvals, bpri = [], [], []
+        for s in spec[1]:
+            if s[0] == 'BreakPoint':
+                bops.append(('breakpoint', None, -1, 0)); bvals.append(cases.make_values(_Orc, s[2])); bpri.append(cases.make_prior(s[3]))
+            elif s[0] == 'ChangePoint':
+                bops.append(('changepoint', None, -1, 1)); bvals.append(cases.make_values(_Orc, s[2])); bpri.append(cases.make_prior(s[3]))
+            else:
+                o, v, p = flatten_tm(s, param_names)
+                ops += [(x[0], x[1] if len(x) > 1 else None, seg, 0) for x in o]
+                vals += v
+                pri += p
+                seg += 1
+        return ops + bops, vals + bvals, pri + bpri
     raise ValueError(spec)
 
 
@@ -79,6 +99,7 @@ def run(case):
     prior_obj = orc.jeffreys(om) if prior_spec == 'default' else cases.make_prior(prior_spec)
     prior = orc.compute_prior(g, prior_obj)
     reset = orc.changepoint_prior(g, prior_obj)
+    indep = reset / np.prod(g.lattice)
 
     ops, vals, hpriors = flatten_tm(c['tm'], pnames)
     kw = dict(c.get('fit', {}))
@@ -86,7 +107,7 @@ def run(case):
 
     if c['study'] == 'Study':
         r = orc.fit(g, om, data, ts, prior, ops, orc.align_values(ops, vals), forward_only=fo, evidence_only=eo,
-                    reset=reset)
+                    reset=reset, indep=indep)
         r['prior'] = prior
         r['grid'] = g
         return r
@@ -95,19 +116,22 @@ def run(case):
     if len(vals) == 0 or all(np.ndim(v) == 0 for v in vals) and np.prod([np.size(v) for v in vals]) <= 1:
         # <= 1 hyper-grid point: falls back to Study.fit (core.py:1434-1441)
         r = orc.fit(g, om, data, ts, prior, ops, orc.align_values(ops, [np.ravel(v)[0] for v in vals]),
-                    forward_only=fo, evidence_only=eo, reset=reset)
+                    forward_only=fo, evidence_only=eo, reset=reset, indep=indep)
         r['prior'] = prior
         r['grid'] = g
         return r
     hv, pv, const = orc.hyper_grid(vals, hpriors)
     extra = {}
     if c['study'] == 'ChangepointStudy':
-        cols = [k for k, op in enumerate([o for o in ops if o[0] != 'static']) if op[0] == 'changepoint']
+        hops = [o for o in ops if o[0] not in ('static', 'independent')]
+        cols = [k for k, op in enumerate(hops) if op[0] == 'changepoint' and not orc._is_boundary(op)]
+        if not cols:        # break-/change-points of a serial model (reference core.py:1793-1815)
+            cols = [k for k, op in enumerate(hops) if orc._is_boundary(op)]
         mask, hv_m, pv_m = orc.changepoint_mask(hv, pv, cols)
         extra = dict(allHyperGridValues=hv, mask=mask)
         hv, pv = hv_m, pv_m
     r = orc.hyper_fit(g, om, data, ts, prior, ops, hv, pv, const, forward_only=fo, evidence_only=eo, reset=reset,
-                      n_jobs=kw.get('nJobs', 1))
+                      n_jobs=kw.get('nJobs', 1), indep=indep)
     if c['study'] == 'ChangepointStudy':                       # core.py:1846-1852
         temp = np.zeros(len(extra['mask']))
         temp[extra['mask']] = r['hyperParameterDistribution']

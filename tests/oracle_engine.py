@@ -15,7 +15,8 @@ from bayesloop_amd.engine import FitResult
 
 OM = {_abi.OM_POISSON: 'poisson', _abi.OM_GAUSSIAN: 'gaussian', _abi.OM_GAUSSIAN_MEAN: 'gaussian_mean',
       _abi.OM_TABLE: 'table'}
-OPS = {_abi.OP_STATIC: 'static', _abi.OP_GRW: 'grw', _abi.OP_CHANGEPOINT: 'changepoint'}
+OPS = {_abi.OP_STATIC: 'static', _abi.OP_GRW: 'grw', _abi.OP_CHANGEPOINT: 'changepoint', _abi.OP_REGIMESWITCH: 'regimeswitch',
+       _abi.OP_INDEPENDENT: 'independent', _abi.OP_BREAKPOINT: 'breakpoint'}
 
 
 class OracleEngine:
@@ -31,10 +32,11 @@ class OracleEngine:
 
     def _unpack(self, p):
         g = orc.Grid(p.marginal)
-        ops = [(OPS[k],) if k != _abi.OP_GRW else ('grw', a) for k, a in p.ops]
+        ops = [(OPS[op[0]], op[1], op[2] if len(op) > 2 else -1, op[3] if len(op) > 3 else 0) for op in p.ops]
         data = np.asarray(p.data, dtype=float)
         lik = None if p.lik is None else np.asarray(p.lik, dtype=float).reshape([p.T] + g.size)
         reset = None if p.reset_prior is None else np.asarray(p.reset_prior, dtype=float).reshape(g.size)
+        self._indep = None if p.indep_prior is None else np.asarray(p.indep_prior, dtype=float).reshape(g.size)
         return g, OM[p.obs_model], ops, data, lik, reset
 
     def fit(self, problem, op_values, forward_only=False, evidence_only=False, keep_posterior=False,
@@ -52,10 +54,11 @@ class OracleEngine:
         aphase = np.zeros(n, dtype=np.int32)
         self._post = None
         for c in range(n):
-            vals = [None if op[0] == 'static' else op_values[c][k] for k, op in enumerate(ops)]
+            vals = [None if op[0] in ('static', 'independent') else op_values[c][k] for k, op in enumerate(ops)]
             with np.errstate(all='ignore'):
                 r = orc.fit(g, om, data, problem.timestamps, np.asarray(problem.prior).reshape(g.size), ops, vals,
-                            forward_only=forward_only, evidence_only=evidence_only, reset=reset, lik_table=lik)
+                            forward_only=forward_only, evidence_only=evidence_only, reset=reset, lik_table=lik,
+                            indep=self._indep)
             self.fits += 1
             logE[c] = r['logEvidence']
             local[c] = r['localEvidence']

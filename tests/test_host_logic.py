@@ -83,7 +83,7 @@ def test_configuration_errors():
     with pytest.raises(bl.ConfigurationError):
         bl.tm.GaussianRandomWalk('sigma', 0.1)          # no target
     with pytest.raises(NotImplementedError):
-        bl.tm.RegimeSwitch('p', -3)
+        bl.tm.NotEqual('p', -3)
     S.setTM(bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s', 0.1, target='rate'),
                                           bl.tm.GaussianRandomWalk('s', 0.2, target='rate')), silent=True)
     with pytest.raises(bl.ConfigurationError):
