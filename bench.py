@@ -102,7 +102,10 @@ def roofline_of(timing, cells_per_launch):
         ms = timing.get(key + '_ms', 0.0)
         if n and ms > 0:
             per_launch_s = ms * 1e-3 / n
-            out[key] = dict(kernel='step_kernel<%s>' % key, launches=int(n), avg_launch_us=per_launch_s * 1e6,
+            variant = timing.get('fwd_kernel_variant' if key == 'forward' else 'bwd_kernel_variant', 0)
+            kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel'}.get(variant, 'step_kernel')
+            out[key] = dict(kernel='%s<%s> (one logical step launch = all radius-bucket launches of the batch)' % (kname, key),
+                            launches=int(n), avg_launch_us=per_launch_s * 1e6,
                             achieved=bytes_per * cells_per_launch / per_launch_s / 1e9, bytes_per_cell_step=bytes_per)
     return out
 
@@ -121,7 +124,7 @@ def run_workload(bl, name, steps, warmup, comm, barrier):
     return S, units, desc, dt
 
 
-def cpu_baseline(nh=4, T=32, n=512):
+def cpu_baseline(nh=6, T=64, n=512):
     """The CPU oracle (numpy restatement of the reference path) on a bounded sample of the C4 workload, 1 core."""
     from oracle import bl_oracle as orc
     g = orc.Grid([orc.cint(-8, 8, n), orc.oint(0, 4, n)])
