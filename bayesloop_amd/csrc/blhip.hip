@@ -18,6 +18,7 @@
 #include "../../include/blhip.h"
 #include "blhip_kernels.hpp"
 #include "blhip_fast.hpp"
+#include "blhip_mfma.hpp"
 #include "blhip_persist1d.hpp"
 
 using namespace blk;
@@ -214,7 +215,7 @@ constexpr int FAST_R0_MAX = 40;
 template <int OM, int MODE, int R0>
 void launch_fast_r(hipStream_t s, const blf::FastParams &P, bool H, int nchains) {
     constexpr bool G = OM == OM_GAUSSIAN;
-    const dim3 grid(P.nblk, nchains), block(NTHREADS);
+    const dim3 grid(P.fnblk, nchains), block(NTHREADS);
     if (G && P.use_rec) {
         if (H) hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, true, G>), grid, block, 0, s, P);
         else hipLaunchKernelGGL((blf::fast_step_kernel<OM, MODE, R0, false, G>), grid, block, 0, s, P);
@@ -235,6 +236,37 @@ void launch_fast_om(hipStream_t s, const blf::FastParams &P, int R0, bool H, int
         case 40: launch_fast_r<OM, MODE, 40>(s, P, H, nchains); break;
         default: fail("fast path: bad radius bucket %d", R0);
     }
+}
+
+// ---- wide-radius path (blhip_mfma.hpp): axis-0 stencil on the fp64 matrix pipe, K = 16 + 2*R0 = 4*NK -----------------
+template <int OM, int MODE, int NK>
+void launch_mfma_k(hipStream_t s, const blf::FastParams &P, int nchains) {
+    const dim3 grid(P.mnblk, nchains), block(NTHREADS);
+    if (OM == OM_GAUSSIAN && P.use_rec) hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, OM == OM_GAUSSIAN>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, false>), grid, block, 0, s, P);
+}
+
+template <int OM, int MODE>
+void launch_mfma_om(hipStream_t s, const blf::FastParams &P, int R0, int nchains) {
+    switch (R0) {
+        case 8: launch_mfma_k<OM, MODE, 8>(s, P, nchains); break;
+        case 16: launch_mfma_k<OM, MODE, 12>(s, P, nchains); break;
+        case 24: launch_mfma_k<OM, MODE, 16>(s, P, nchains); break;
+        case 32: launch_mfma_k<OM, MODE, 20>(s, P, nchains); break;
+        case 40: launch_mfma_k<OM, MODE, 24>(s, P, nchains); break;
+        default: fail("mfma path: bad radius bucket %d", R0);
+    }
+}
+
+void launch_mfma(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, int nchains) {
+    if (om == BLHIP_OM_GAUSSIAN) {
+        if (mode == MODE_FWD) launch_mfma_om<OM_GAUSSIAN, MODE_FWD>(s, P, R0, nchains);
+        else launch_mfma_om<OM_GAUSSIAN, MODE_BWD>(s, P, R0, nchains);
+    } else {
+        if (mode == MODE_FWD) launch_mfma_om<OM_TABLE, MODE_FWD>(s, P, R0, nchains);
+        else launch_mfma_om<OM_TABLE, MODE_BWD>(s, P, R0, nchains);
+    }
+    HIPCHECK(hipGetLastError());
 }
 
 void launch_fast(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, bool H, int nchains) {
@@ -621,7 +653,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                              (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
                               p->obs_model == BLHIP_OM_TABLE);
         Tile tile{};
-        int fastS = 0, fast_nseg = 1;
+        int fastS = 0, fast_nseg = 1, fast_fnblk = 1, mS = 0, m_nseg = 1, m_tiles_j = 1, m_nblk = 1;
+        bool use_mfma = false;
         if (fast) {
             tile.TI = blf::CH; tile.LW0 = prog.LW0; tile.LW1 = prog.LW1 > 0 ? blf::R1MAX : 0;
             tile.TJ = blf::BW - 2 * tile.LW1;
@@ -645,7 +678,31 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             }
             if (forceS > 0) { fastS = (forceS + blf::CH - 1) / blf::CH * blf::CH; fast_nseg = (g.n0 + fastS - 1) / fastS; }
             tile.tiles_i = fast_nseg;
-            tile.nblk = tile.tiles_j * fast_nseg;
+            fast_fnblk = tile.tiles_j * fast_nseg;
+            // geometry of the matrix-pipe kernel (64-column strips, segments of mS rows, mS a multiple of 16)
+            {
+                m_tiles_j = (g.n1 + blm::BCOL - 1) / blm::BCOL;
+                const long long mcol = (long long)m_tiles_j * B;
+                double mbest = 1e300;
+                for (int k = 1; k <= 4; ++k) {                     // resident blocks per CU
+                    const double pen = k == 1 ? 1.5 : (k == 2 ? 1.15 : 1.0);
+                    for (int ns = 1; ns <= std::max(1, g.n0 / 32); ++ns) {
+                        int S = ((g.n0 + ns - 1) / ns + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q;
+                        if (S > blm::MS_MAX) continue;
+                        const int real = (g.n0 + S - 1) / S;
+                        const long long blocks = mcol * real;
+                        const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
+                        const double cost = pen * (double)waves * k * (S + 1.0 * R0 + 24.0);
+                        if (cost < mbest - 1e-9) { mbest = cost; mS = S; m_nseg = real; }
+                    }
+                }
+                const int forceM = (int)ctx->option("mfma_S", 0);
+                if (forceM > 0) { mS = std::min(blm::MS_MAX, (forceM + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q); m_nseg = (g.n0 + mS - 1) / mS; }
+                if (mS == 0) { mS = blm::MS_MAX; m_nseg = (g.n0 + mS - 1) / mS; }
+                m_nblk = m_tiles_j * m_nseg;
+            }
+            use_mfma = ctx->option("mfma", 1.0) != 0.0;
+            tile.nblk = use_mfma ? std::max(fast_fnblk, m_nblk) : fast_fnblk;
             tile.lds_bytes = 0;
         } else {
             tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
@@ -657,7 +714,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         const size_t nT = (size_t)T * B;
         taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
         size_t mb = 4 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
-                    2 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B);
+                    2 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * NTHREADS);
         ctx->meta.ensure(mb);
         cur = ctx->meta.as<char>();
         unsigned char *d_kindF = carve<unsigned char>(cur, nT), *d_kindB = carve<unsigned char>(cur, nT);
@@ -671,6 +728,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         double *d_invN = carve<double>(cur, nT);
         double *d_inv_tmp = carve<double>(cur, nT);
         double *d_w = carve<double>(cur, B);
+        double *d_dump = carve<double>(cur, NTHREADS);
         (void)d_inv_tmp;
         HIPCHECK(hipMemcpyAsync(d_kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(d_tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
@@ -733,7 +791,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         blf::FastParams FP{};
         if (fast) {
             FP.n0 = g.n0; FP.n1 = g.n1; FP.TJ = tile.TJ; FP.S = fastS; FP.nseg = fast_nseg;
-            FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk;
+            FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk; FP.fnblk = fast_fnblk;
+            FP.dump = d_dump;
+            FP.mS = mS; FP.mnseg = m_nseg; FP.mtiles_j = m_tiles_j; FP.mnblk = m_nblk;
             FP.ndim = p->ndim; FP.d = d; FP.means = forward_only ? 1 : 0;
             FP.shared[SRC_PREV] = nullptr; FP.shared[SRC_PRIOR] = d_prior; FP.shared[SRC_RESET] = d_reset;
             FP.shared[SRC_UNIFORM] = d_uniform; FP.shared[SRC_INDEP] = d_indep; P.shared[SRC_INDEP] = d_indep; FP.taps = d_taps; FP.tap_off = d_off; FP.tap_lw = d_lw;
@@ -776,6 +836,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 if (ranges[ta][k].key != ranges[tb][k].key || ranges[ta][k].count != ranges[tb][k].count) return false;
             return std::equal(order.begin() + ta * B, order.begin() + (ta + 1) * B, order.begin() + tb * B);
         };
+        const int mfma_min_r0 = (int)ctx->option("mfma_min_r0", 8);
         auto run_step = [&](int mode, int64_t t, const double *srcp, long long src_stride, double *dstp, long long dst_stride,
                             double *postp, long long post_stride, const double *ps_prev, int prev_slot, double *ps_out,
                             bool means) {
@@ -791,7 +852,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
-                    launch_fast(multistream ? ctx->bstream[r.key] : st, p->obs_model, mode, Q, r.R0, r.H, r.count);
+                    hipStream_t ls = multistream ? ctx->bstream[r.key] : st;
+                    if (use_mfma && !r.H && r.R0 >= mfma_min_r0) launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.count);
+                    else launch_fast(ls, p->obs_model, mode, Q, r.R0, r.H, r.count);
                 }
             } else {
                 StepParams Q = P;

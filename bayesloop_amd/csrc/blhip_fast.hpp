@@ -36,7 +36,10 @@ struct FastParams {
     int n0, n1;
     int TJ;                      // useful columns per block: BW - 2*R1MAX if the batch has an axis-1 filter, else BW
     int S;                       // rows per segment (multiple of CH)
-    int nseg, tiles_j, nblk;     // nblk = nseg * tiles_j blocks per chain
+    int nseg, tiles_j, fnblk;    // fnblk = nseg * tiles_j blocks per chain
+    int nblk;                    // partial-sum slots per chain and reduction = max(fnblk, mnblk): both kernel families of a
+                                 // batch write the same slot layout (blocks zero the slots their family does not use)
+    int mS, mnseg, mtiles_j, mnblk;   // geometry of blm::mfma_step_kernel (blhip_mfma.hpp): 64-column strips, mS rows
     int ndim, d, means, use_rec;
     double step0;                // lattice step of the row axis (likelihood recurrence)
     const double *src;  long long src_stride;
@@ -50,7 +53,15 @@ struct FastParams {
     const double *psum_prev; int prev_slot; int prev_nblk;
     double *psum_out;
     const double *m0, *m1, *colA, *colB, *rec, *lik;
+    double *dump;                // NTHREADS doubles nobody reads: where dead lanes store (keeps the stores branch-free)
 };
+
+// block `blkid` of a kernel family with my_nblk blocks per chain publishes its partial sum in slot blkid and zeroes the
+// slots blkid + k * my_nblk the family does not own (left = slots from blkid to the end)
+__device__ __forceinline__ void put_partial(double *out, double v, int my_nblk, int left) {
+    out[0] = v;
+    for (int j = my_nblk; j < left; j += my_nblk) out[j] = 0.0;
+}
 
 // Pin a wave-uniform double into SGPRs (the compiler cannot prove that the tap table is not aliased by the stores,
 // so without this the stencil weights occupy 2 VGPRs each).
@@ -352,17 +363,18 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
     }
 
     double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
+    const int left = P.nblk - blkid;
     const double r0 = blk::block_sum(sN, red);
-    if (tid == 0) out[0] = r0;
+    if (tid == 0) put_partial(out, r0, P.fnblk, left);
     if (BWD) {
         const double r1 = blk::block_sum(sS, red);
         const double r2 = blk::block_sum(sC, red);
-        if (tid == 0) { out[1 * P.nblk] = r1; out[2 * P.nblk] = r2; }
+        if (tid == 0) { put_partial(out + 1 * P.nblk, r1, P.fnblk, left); put_partial(out + 2 * P.nblk, r2, P.fnblk, left); }
     }
     if (BWD || P.means) {
         const double r3 = blk::block_sum(sM0, red);
         const double r4 = blk::block_sum(sM1, red);
-        if (tid == 0) { out[3 * P.nblk] = r3; out[4 * P.nblk] = r4; }
+        if (tid == 0) { put_partial(out + 3 * P.nblk, r3, P.fnblk, left); put_partial(out + 4 * P.nblk, r4, P.fnblk, left); }
     }
 }
 

@@ -1,0 +1,262 @@
+// Wide-radius step kernels for 2-D grids (gfx950): the axis-0 Gaussian-random-walk stencil on the fp64 MATRIX pipe.
+//
+// Why: with a stencil radius of 8..40 rows a cell costs 17..81 fp64 FMAs.  On the vector ALU one wave issues a dependent-
+// free fp64 instruction every ~9 cycles and the 2*R0+8-row register window of blf::fast_step_kernel leaves 1-2 waves per
+// SIMD, so those buckets run at ~30 % of the fp64 peak and far below the HBM roof (profiles/r01_notes.md).  The same
+// stencil is a banded Toeplitz product  OUT(16 x 16) = W(16 x K) * X(K x 16),  K = 16 + 2*R0, and
+// v_mfma_f64_16x16x4_f64 sustains ~75 TFLOP/s = the whole fp64 pipe from ONE wave per SIMD with a single dependent
+// accumulator chain (tools/ubench/mfma_f64_rate.hip).  The band wastes 16 of the K products per output, the issue
+// efficiency more than pays for it.  (This is fp64 compute-bound work; nothing is "reshaped into a GEMM" to dodge HBM.)
+//
+// Structure (one wave = one 16-column strip, streaming down a segment of rows in tiles of 16):
+//  * B operand = the state itself: lane (g = lane>>4, c = lane&15) holds X[row0 + 4*kb + g][col c] for the NK = K/4
+//    k-blocks of the current window: a register ring that advances by 4 k-blocks (16 rows) per tile; the 4 new values
+//    per lane are loaded one tile ahead (a load instruction = 4 rows x 128 contiguous bytes).
+//  * A operand = the band of the weight matrix: W[m][k] = w(|k - R0 - m|), identical for every tile, wave and block of a
+//    chain: built once per block in LDS (NK x 64 doubles) and read with one conflict-free ds_read_b64 per MFMA.
+//  * D (lane holds rows g, g+4, g+8, g+12 of column c) feeds the same fused epilogue as blf::fast_step_kernel: lazy
+//    normaliser, likelihood, posterior / next state stores, deterministic per-block partial sums.  The Gaussian
+//    likelihood recurrence runs along the lane's own rows, i.e. with stride 4.
+//
+// Algorithmic HBM traffic per cell and step: forward 16 B, backward 32 B (as the other kernels).
+#pragma once
+#include "blhip_fast.hpp"
+
+namespace blm {
+
+using blf::FastParams;
+using blf::exp_mn;
+using blf::reflect1;
+using blf::sld;
+using blf::sldi;
+using blf::DMAX;
+using blk::NRED;
+using blk::NTHREADS;
+using blk::SRC_PREV;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#ifndef BLM_PF
+#define BLM_PF 2             // tiles between the load of a row block and its use
+#endif
+constexpr int TM = 16;            // rows per tile (MFMA M)
+constexpr int WCOL = 16;          // columns per wave (MFMA N)
+constexpr int BCOL = WCOL * (NTHREADS / 64);   // columns per block
+constexpr int RSTEPS = 16;        // recurrence steps (of 4 rows) between exact re-anchorings
+constexpr int SEG_Q = BLM_PF * TM; // segment lengths are multiples of this (the tile loop is unrolled BLM_PF times)
+constexpr int MS_MAX = 2048;      // longest row segment of a block (the row coordinates are staged in LDS)
+
+template <int OM, int MODE, int NK, bool REC>
+__global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P) {
+    constexpr bool BWD = MODE == blk::MODE_BWD;
+    constexpr bool GAUSS = OM == blk::OM_GAUSSIAN;
+    constexpr int R0 = (4 * NK - TM) / 2;
+    __shared__ double As[NK * 64];
+    __shared__ double m0s[MS_MAX + 2 * TM];
+    __shared__ double red[NTHREADS / 64 + 1];
+
+    const int b = sldi(P.chain_ids, blockIdx.y);
+    const int blkid = blockIdx.x;
+    const int tj = blkid / P.mnseg, seg = blkid - tj * P.mnseg;
+    const int i_lo = seg * P.mS, i_hi = min(P.n0, i_lo + P.mS);
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+
+    const int kind = ((const unsigned char __attribute__((address_space(4))) *)(unsigned long long)P.srckind)[b];
+    const int t0 = sldi(P.tap0, b);
+    const int lw0 = t0 >= 0 ? sldi(P.tap_lw, t0) : 0;
+    const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
+
+    const int jc = tj * BCOL + (tid >> 6) * WCOL + c;
+    const int gj = min(jc, P.n1 - 1);
+    const bool owner = jc < P.n1;
+    const double *col = src + gj;
+
+    // ---- prologue: first window of the strip (B ring), while those loads fly: A band + row coordinates -> LDS, normaliser
+    double Bv[NK];
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) Bv[kb] = col[(long long)reflect1(i_lo - R0 + 4 * kb + g, P.n0) * P.n1];
+
+    {
+        const long long o0 = t0 >= 0 ? sldi(P.tap_off, t0) : 0;
+        for (int e = tid; e < NK * 64; e += NTHREADS) {
+            const int kb = e >> 6, l = e & 63;
+            const int a = abs(4 * kb + (l >> 4) - R0 - (l & 15));
+            As[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);
+        }
+        for (int e = tid; e < P.mS + 2 * TM; e += NTHREADS) m0s[e] = P.m0[min(i_lo + e, P.n0 - 1)];
+    }
+    double scale = 1.0;
+    if (kind == SRC_PREV) {
+        const double s = blk::sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
+        scale = 1.0 / s;
+    }
+    __syncthreads();
+
+    double xd[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) xd[k] = (GAUSS && k < P.d) ? sld(P.rec, k) : __builtin_nan("");
+    const double g1 = P.m1[gj];
+    double cA = 0.0, cB = 0.0;
+    if (GAUSS) { cA = P.colA[gj]; cB = P.colB[gj]; }
+    asm volatile("" : "+v"(cA), "+v"(cB) : "v"(g1), "v"(scale), "v"(Bv[NK - 1]));
+
+    double mE = 1.0, mR = 1.0, mq = 1.0, iE = 1.0, iR = 1.0, iq = 1.0;
+    int nE = 0, nR = 0, nq = 0;
+    double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
+    double *dcol = P.dst + (long long)b * P.dst_stride + gj;
+    double *pcol = BWD ? P.post + (long long)b * P.post_stride + gj : nullptr;
+    const double *lcol = (!GAUSS) ? P.lik + gj : nullptr;
+    typedef const double __attribute__((address_space(3))) *lds_cp;
+    lds_cp Al = (lds_cp)As + lane;
+
+    static_assert(BLM_PF % 2 == 0, "prefetch depth must be even (two alpha / likelihood slots)");
+    // Memory pipeline.  Everything inside the tile loop is straight-line and UNCONDITIONAL (clamped / reflected addresses
+    // for the loads, a dump slot for the stores of dead lanes): with control flow around a memory instruction the compiler
+    // cannot count what is outstanding and falls back to s_waitcnt vmcnt(0), i.e. drains the stores of the tile and the
+    // prefetch before every ring advance.  Register slots are static (the loop is unrolled BLM_PF times): a rotating
+    // copy would read -- i.e. wait for -- registers whose loads are still in flight.
+    //   nxt[u] : the 4 k-blocks (16 rows) that enter the window when the ring advances from tile u to tile u+1 (mod BLM_PF),
+    //            re-filled right after they are consumed, i.e. BLM_PF tiles before their next use
+    //   al/lk  : stored forward posterior / tabulated likelihood of a tile, loaded one tile ahead
+    double nxt[BLM_PF][4];
+#pragma unroll
+    for (int u = 0; u < BLM_PF; ++u) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt[u][q] = col[(long long)reflect1(i_lo + (u + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
+    }
+    double al[2][4], lk[2][4];
+    if (BWD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) al[0][r] = pcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * P.n1];
+    }
+    if (!GAUSS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lk[0][r] = lcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * P.n1];
+    }
+    double *const dump = P.dump + tid;
+
+    for (int i0 = i_lo; i0 < i_hi; i0 += BLM_PF * TM) {
+#pragma unroll
+        for (int u = 0; u < BLM_PF; ++u) {
+            const int i = i0 + u * TM;             // (a tile past the end of the segment is all dead lanes: mS % (BLM_PF * TM) == 0
+                                                   //  keeps that to the ragged end of the grid)
+            const int li = i - i_lo + g;               // this lane's first row of the tile, relative to the segment
+            if (BWD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) al[(u + 1) & 1][r] = pcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * P.n1];
+            }
+            if (!GAUSS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lk[(u + 1) & 1][r] = lcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * P.n1];
+            }
+
+            // ---- axis-0 stencil: NK chained MFMAs (k ascending) ---------------------------------------------------------
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+
+            // ---- re-anchor the stride-4 likelihood recurrence of this lane's rows ----------------------------------------
+            if (GAUSS && REC && ((i - i_lo) % (4 * RSTEPS)) == 0) {
+                // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
+                // arg(r+4) - arg(r) = cA (mu_{r+4} - mu_r) sum_k (2 x_k - mu_r - mu_{r+4});  2nd difference = -2 cA dn (4 step)^2
+                const double mu0 = m0s[li], mu4 = m0s[li + 4];
+                double a0 = 0.0, s1 = 0.0, dn = 0.0;
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) {
+                    const double x = xd[k];
+                    if (x == x) {
+                        const double q = x - mu0;
+                        a0 = fma(-(q * q), cA, a0) - cB;
+                        s1 += (x - mu0) + (x - mu4);
+                        dn += 1.0;
+                    }
+                }
+                const double d1 = cA * (mu4 - mu0) * s1;
+                const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                exp_mn(a0, mE, nE);
+                exp_mn(d1, mR, nR);
+                exp_mn(d2, mq, nq);
+                if (BWD) {
+                    int t;
+                    exp_mn(-a0, iE, t);
+                    exp_mn(-d1, iR, t);
+                    exp_mn(-d2, iq, t);
+                }
+            }
+
+            // ---- epilogue: the lane's 4 cells (rows i + g + 4 r) -------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i + g + 4 * r;
+                const double mu = m0s[li + 4 * r];
+                double Lv;
+                if (GAUSS && REC) {
+                    Lv = ldexp(mE, nE);
+                } else if (GAUSS) {
+                    Lv = 1.0;
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) {
+                        const double xx = xd[k];
+                        if (xx == xx) { const double dq = xx - mu; Lv *= exp(-(dq * dq) * cA - cB); }
+                    }
+                } else {
+                    Lv = lk[u & 1][r];
+                }
+                const bool live = owner && gi < i_hi;
+                const long long off = (long long)gi * P.n1;
+                if (!BWD) {
+                    const double a = acc[r] * scale * Lv;
+                    *(live ? dcol + off : dump) = a;
+                    const double am = live ? a : 0.0;
+                    sN += am;
+                    if (P.means) { sM0 = fma(am, mu, sM0); sM1 = fma(am, g1, sM1); }
+                } else {
+                    const double beta = acc[r] * scale;
+                    const double p = al[u & 1][r] * beta;
+                    const double cn = beta * Lv;
+                    // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
+                    const double pl = (GAUSS && REC) ? (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)) : p / Lv;
+                    *(live ? pcol + off : dump) = p;
+                    *(live ? dcol + off : dump) = cn;
+                    const double pm = live ? p : 0.0;
+                    sN += pm;
+                    sS += live ? pl : 0.0;
+                    sC += live ? cn : 0.0;
+                    sM0 = fma(pm, mu, sM0);
+                    sM1 = fma(pm, g1, sM1);
+                }
+                if (GAUSS && REC) {
+                    mE *= mR; nE += nR;
+                    mR *= mq; nR += nq;
+                    if (BWD) { iE *= iR; iR *= iq; }
+                }
+            }
+
+            // ---- advance the ring by one tile, re-fill the slot ------------------------------------------------------------
+#pragma unroll
+            for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = nxt[u][q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                nxt[u][q] = col[(long long)reflect1(i + (BLM_PF + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
+        }
+    }
+
+    double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
+    const bool z = tid == 0;
+    const double r0 = blk::block_sum(sN, red);
+    if (z) blf::put_partial(out, r0, P.mnblk, P.nblk - blkid);
+    if (BWD) {
+        const double r1 = blk::block_sum(sS, red);
+        const double r2 = blk::block_sum(sC, red);
+        if (z) { blf::put_partial(out + 1 * P.nblk, r1, P.mnblk, P.nblk - blkid); blf::put_partial(out + 2 * P.nblk, r2, P.mnblk, P.nblk - blkid); }
+    }
+    if (BWD || P.means) {
+        const double r3 = blk::block_sum(sM0, red);
+        const double r4 = blk::block_sum(sM1, red);
+        if (z) { blf::put_partial(out + 3 * P.nblk, r3, P.mnblk, P.nblk - blkid); blf::put_partial(out + 4 * P.nblk, r4, P.mnblk, P.nblk - blkid); }
+    }
+}
+
+}  // namespace blm

@@ -15,6 +15,8 @@ def study(n, T, s1f=1.0, s2f=1.0, two=True):
     return S
 
 eng = bl.get_engine()
+for kv in os.environ.get('BLHIP_OPTS', '').split(','):
+    if '=' in kv: eng.set_option(kv.split('=')[0], float(kv.split('=')[1]))
 def run(n, T, opts, mode, **kw):
     for k, v in opts.items(): eng.set_option(k, v)
     S = study(n, T, **kw)
@@ -49,7 +51,7 @@ if which == 'one':
 if which == 'bucket':
     # C4-like: 512x512 grid, 64 chains, GRW on 'mean' only, all chains in one radius bucket
     n, T, nh = 512, 32, 64
-    for lw in (0, 4, 8, 12, 16, 24, 32, 38):
+    for lw in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 4, 8, 12, 16, 24, 32, 38)):
         sig = (lw / 4.0) * (16.0 / (n - 1)) if lw else 0.0
         S = bl.HyperStudy(silent=True); S.loadData(series(4, T), silent=True)
         vals = bl.cint(sig * 0.97 + 1e-9, sig + 1e-9, nh) if lw else bl.cint(1e-6, 2e-6, nh)
