@@ -837,6 +837,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             return std::equal(order.begin() + ta * B, order.begin() + (ta + 1) * B, order.begin() + tb * B);
         };
         const int mfma_min_r0 = (int)ctx->option("mfma_min_r0", 8);
+        long long n_mfma[2] = {0, 0}, n_fast[2] = {0, 0};
         auto run_step = [&](int mode, int64_t t, const double *srcp, long long src_stride, double *dstp, long long dst_stride,
                             double *postp, long long post_stride, const double *ps_prev, int prev_slot, double *ps_out,
                             bool means) {
@@ -853,8 +854,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
                     hipStream_t ls = multistream ? ctx->bstream[r.key] : st;
-                    if (use_mfma && !r.H && r.R0 >= mfma_min_r0) launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.count);
-                    else launch_fast(ls, p->obs_model, mode, Q, r.R0, r.H, r.count);
+                    if (use_mfma && !r.H && r.R0 >= mfma_min_r0) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }
+                    else { launch_fast(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_fast[mode == MODE_FWD ? 0 : 1]; }
                 }
             } else {
                 StepParams Q = P;
@@ -913,6 +914,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
         ctx->timing.forward_ms += ms;
         ctx->timing.forward_launches += T;
+        if (n_mfma[0] > 0 && n_mfma[0] >= n_fast[0]) ctx->timing.fwd_kernel_variant = 3;
 
         // --- evidence bookkeeping on the host, in the reference's order (core.py:385-404, 417) ---
         std::vector<double> logE(B, 0.0);
@@ -973,6 +975,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             HIPCHECK(hipStreamSynchronize(st));
             HIPCHECK(hipEventElapsedTime(&ms, ev[2], ev[3]));
             ctx->timing.backward_ms += ms;
+            if (n_mfma[1] > 0 && n_mfma[1] >= n_fast[1]) ctx->timing.bwd_kernel_variant = 3;
             ctx->timing.backward_launches += T;
             for (int64_t b = 0; b < B; ++b) {
                 if (abort_step[b] >= 0) continue;

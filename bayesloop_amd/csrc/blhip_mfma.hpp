@@ -153,7 +153,11 @@ __global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P)
             // ---- axis-0 stencil: NK chained MFMAs (k ascending) ---------------------------------------------------------
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
+#ifdef BLM_ABL_NOMFMA
+            for (int kb = 0; kb < 4; ++kb) acc[kb] = Bv[NK / 2 - 2 + kb] * Al[kb * 64];
+#else
             for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+#endif
 
             // ---- re-anchor the stride-4 likelihood recurrence of this lane's rows ----------------------------------------
             if (GAUSS && REC && ((i - i_lo) % (4 * RSTEPS)) == 0) {
@@ -202,7 +206,11 @@ __global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P)
                 } else {
                     Lv = lk[u & 1][r];
                 }
+#ifdef BLM_ABL_NOSTORE
+                const bool live0 = owner && gi < i_hi; const bool live = live0 && acc[r] == 1.2345e300;
+#else
                 const bool live = owner && gi < i_hi;
+#endif
                 const long long off = (long long)gi * P.n1;
                 if (!BWD) {
                     const double a = acc[r] * scale * Lv;
@@ -239,7 +247,11 @@ __global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P)
             for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = nxt[u][q];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
+#ifdef BLM_ABL_NOLOAD
+                nxt[u][q] = nxt[u][q] * 1.0000001;
+#else
                 nxt[u][q] = col[(long long)reflect1(i + (BLM_PF + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
+#endif
         }
     }
 

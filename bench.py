@@ -103,7 +103,8 @@ def roofline_of(timing, cells_per_launch):
         if n and ms > 0:
             per_launch_s = ms * 1e-3 / n
             variant = timing.get('fwd_kernel_variant' if key == 'forward' else 'bwd_kernel_variant', 0)
-            kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel'}.get(variant, 'step_kernel')
+            kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel',
+                     3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)'}.get(variant, 'step_kernel')
             out[key] = dict(kernel='%s<%s> (one logical step launch = all radius-bucket launches of the batch)' % (kname, key),
                             launches=int(n), avg_launch_us=per_launch_s * 1e6,
                             achieved=bytes_per * cells_per_launch / per_launch_s / 1e9, bytes_per_cell_step=bytes_per)

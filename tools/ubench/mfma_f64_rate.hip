@@ -30,6 +30,40 @@ __global__ void layout_kernel(const double *A, const double *B, double *D) {   /
     for (int r = 0; r < 4; ++r) D[(g + 4 * r) * 16 + c] = acc[r];
 }
 
+// MFMA f64 next to 32-bit integer VALU work (does the f64 matrix op leave issue slots to the integer ALU?)
+template <int NACC, int NINT>
+__global__ void mfma_int_kernel(double *out, int iters) {
+    d4 acc[NACC > 0 ? NACC : 1];
+    for (int k = 0; k < NACC; ++k) acc[k] = d4{0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
+    unsigned v[NINT > 0 ? NINT : 1];
+    for (int k = 0; k < NINT; ++k) v[k] = threadIdx.x + k;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NINT; ++k) v[k] = (v[k] ^ (unsigned)i) + 0x9e3779b9u;
+    }
+    double s = 0;
+    for (int k = 0; k < NACC; ++k) s += acc[k].x + acc[k].y + acc[k].z + acc[k].w;
+    unsigned t = 0;
+    for (int k = 0; k < NINT; ++k) t += v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + t;
+}
+
+template <int NACC, int NINT>
+static void run_int(double *out, int waves, int iters) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int threads = 256 * waves;
+    hipLaunchKernelGGL((mfma_int_kernel<NACC, NINT>), dim3(256), dim3(threads), 0, 0, out, iters); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((mfma_int_kernel<NACC, NINT>), dim3(256), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("waves/SIMD %d  MFMA %d + 2x%d int VALU ops per iter: %.1f ns per iteration per wave-slot (MFMA alone would be %.1f ns at 77 TFLOP/s)\n",
+           waves, NACC, NINT, ms * 1e6 / iters / waves, NACC * 2048.0 * 256 * 4 / 77e12 * 1e9);
+}
+
 template <int NACC, int NVALU>
 static void run(double *out, int waves, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -59,5 +93,6 @@ int main() {
     for (int w : {1, 2, 4}) { run<1, 0>(out, w, it); run<2, 0>(out, w, it); run<4, 0>(out, w, it); }
     for (int w : {1, 2, 4}) { run<0, 8>(out, w, it); run<0, 16>(out, w, it); }
     for (int w : {1, 2, 4}) { run<2, 8>(out, w, it); run<2, 16>(out, w, it); run<2, 32>(out, w, it); run<4, 16>(out, w, it); }
+    for (int w : {1, 2}) { run_int<0, 32>(out, w, it); run_int<2, 0>(out, w, it); run_int<2, 16>(out, w, it); run_int<2, 32>(out, w, it); run_int<2, 64>(out, w, it); }
     return 0;
 }
