@@ -238,33 +238,45 @@ void launch_fast_om(hipStream_t s, const blf::FastParams &P, int R0, bool H, int
     }
 }
 
-// ---- wide-radius path (blhip_mfma.hpp): axis-0 stencil on the fp64 matrix pipe, K = 16 + 2*R0 = 4*NK -----------------
-template <int OM, int MODE, int NK>
+// ---- matrix-pipe path (blhip_mfma.hpp): stencils as banded products on v_mfma_f64_16x16x4, K = 16 + 2*R0 = 4*NK ----------
+template <int OM, int MODE, int NK, bool H>
 void launch_mfma_k(hipStream_t s, const blf::FastParams &P, int nchains) {
-    const dim3 grid(P.mnblk, nchains), block(NTHREADS);
-    if (OM == OM_GAUSSIAN && P.use_rec) hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, OM == OM_GAUSSIAN>), grid, block, 0, s, P);
-    else hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, false>), grid, block, 0, s, P);
+    const dim3 grid(P.mnblk, nchains), block(H ? blm::NT_H : blm::NT_V);
+    if (OM == OM_GAUSSIAN && P.use_rec) hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, OM == OM_GAUSSIAN, H>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, false, H>), grid, block, 0, s, P);
 }
 
 template <int OM, int MODE>
-void launch_mfma_om(hipStream_t s, const blf::FastParams &P, int R0, int nchains) {
-    switch (R0) {
-        case 8: launch_mfma_k<OM, MODE, 8>(s, P, nchains); break;
-        case 16: launch_mfma_k<OM, MODE, 12>(s, P, nchains); break;
-        case 24: launch_mfma_k<OM, MODE, 16>(s, P, nchains); break;
-        case 32: launch_mfma_k<OM, MODE, 20>(s, P, nchains); break;
-        case 40: launch_mfma_k<OM, MODE, 24>(s, P, nchains); break;
-        default: fail("mfma path: bad radius bucket %d", R0);
+void launch_mfma_om(hipStream_t s, const blf::FastParams &P, int R0, bool H, int nchains) {
+    if (H) {
+        switch (R0) {
+            case 0: launch_mfma_k<OM, MODE, 4, true>(s, P, nchains); break;
+            case 8: launch_mfma_k<OM, MODE, 8, true>(s, P, nchains); break;
+            case 16: launch_mfma_k<OM, MODE, 12, true>(s, P, nchains); break;
+            case 24: launch_mfma_k<OM, MODE, 16, true>(s, P, nchains); break;
+            case 32: launch_mfma_k<OM, MODE, 20, true>(s, P, nchains); break;
+            case 40: launch_mfma_k<OM, MODE, 24, true>(s, P, nchains); break;
+            default: fail("mfma path: bad radius bucket %d", R0);
+        }
+    } else {
+        switch (R0) {
+            case 8: launch_mfma_k<OM, MODE, 8, false>(s, P, nchains); break;
+            case 16: launch_mfma_k<OM, MODE, 12, false>(s, P, nchains); break;
+            case 24: launch_mfma_k<OM, MODE, 16, false>(s, P, nchains); break;
+            case 32: launch_mfma_k<OM, MODE, 20, false>(s, P, nchains); break;
+            case 40: launch_mfma_k<OM, MODE, 24, false>(s, P, nchains); break;
+            default: fail("mfma path: bad radius bucket %d", R0);
+        }
     }
 }
 
-void launch_mfma(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, int nchains) {
+void launch_mfma(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, bool H, int nchains) {
     if (om == BLHIP_OM_GAUSSIAN) {
-        if (mode == MODE_FWD) launch_mfma_om<OM_GAUSSIAN, MODE_FWD>(s, P, R0, nchains);
-        else launch_mfma_om<OM_GAUSSIAN, MODE_BWD>(s, P, R0, nchains);
+        if (mode == MODE_FWD) launch_mfma_om<OM_GAUSSIAN, MODE_FWD>(s, P, R0, H, nchains);
+        else launch_mfma_om<OM_GAUSSIAN, MODE_BWD>(s, P, R0, H, nchains);
     } else {
-        if (mode == MODE_FWD) launch_mfma_om<OM_TABLE, MODE_FWD>(s, P, R0, nchains);
-        else launch_mfma_om<OM_TABLE, MODE_BWD>(s, P, R0, nchains);
+        if (mode == MODE_FWD) launch_mfma_om<OM_TABLE, MODE_FWD>(s, P, R0, H, nchains);
+        else launch_mfma_om<OM_TABLE, MODE_BWD>(s, P, R0, H, nchains);
     }
     HIPCHECK(hipGetLastError());
 }
@@ -837,6 +849,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             return std::equal(order.begin() + ta * B, order.begin() + (ta + 1) * B, order.begin() + tb * B);
         };
         const int mfma_min_r0 = (int)ctx->option("mfma_min_r0", 8);
+        // both-axes launches: the matrix-pipe kernel wins while the launch is latency-bound (few cells per CU); with the chip
+        // full the vector kernel's 2 x 17 FMAs per cell beat 2 x 32 band products (measured: 1024^2 12.7 vs 14.9 us,
+        // 2048^2 30.0 vs 27.7 us, 4096^2 97 vs 77 us per forward step)
+        const bool mfma_h = ctx->option("mfma_h", 1.0) != 0.0;
+        const double mfma_h_max_cells = ctx->option("mfma_h_max_cells", 2.5e6);
         long long n_mfma[2] = {0, 0}, n_fast[2] = {0, 0};
         auto run_step = [&](int mode, int64_t t, const double *srcp, long long src_stride, double *dstp, long long dst_stride,
                             double *postp, long long post_stride, const double *ps_prev, int prev_slot, double *ps_out,
@@ -854,7 +871,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
                     hipStream_t ls = multistream ? ctx->bstream[r.key] : st;
-                    if (use_mfma && !r.H && r.R0 >= mfma_min_r0) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }
+                    if (use_mfma && (r.H ? (mfma_h && (double)r.count * g.n0 * g.n1 <= mfma_h_max_cells) : r.R0 >= mfma_min_r0)) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }
                     else { launch_fast(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_fast[mode == MODE_FWD ? 0 : 1]; }
                 }
             } else {

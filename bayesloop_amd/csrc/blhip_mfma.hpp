@@ -1,19 +1,28 @@
-// Wide-radius step kernels for 2-D grids (gfx950): the axis-0 Gaussian-random-walk stencil on the fp64 MATRIX pipe.
+// Step kernels for 2-D grids on the fp64 MATRIX pipe (gfx950): the Gaussian-random-walk stencils as banded Toeplitz
+// products with v_mfma_f64_16x16x4_f64.
 //
 // Why: with a stencil radius of 8..40 rows a cell costs 17..81 fp64 FMAs.  On the vector ALU one wave issues a dependent-
 // free fp64 instruction every ~9 cycles and the 2*R0+8-row register window of blf::fast_step_kernel leaves 1-2 waves per
-// SIMD, so those buckets run at ~30 % of the fp64 peak and far below the HBM roof (profiles/r01_notes.md).  The same
+// SIMD, so those launches run at ~30 % of the fp64 peak and far below the HBM roof (profiles/r01_notes.md).  The same
 // stencil is a banded Toeplitz product  OUT(16 x 16) = W(16 x K) * X(K x 16),  K = 16 + 2*R0, and
 // v_mfma_f64_16x16x4_f64 sustains ~75 TFLOP/s = the whole fp64 pipe from ONE wave per SIMD with a single dependent
-// accumulator chain (tools/ubench/mfma_f64_rate.hip).  The band wastes 16 of the K products per output, the issue
-// efficiency more than pays for it.  (This is fp64 compute-bound work; nothing is "reshaped into a GEMM" to dodge HBM.)
+// accumulator chain (tools/ubench/mfma_f64_rate.hip).  The band wastes 16 of the K products per output; the issue
+// efficiency more than pays for it.  On gfx950 the f64 matrix op runs on the same fp64 lanes as the vector ALU and blocks
+// ALL other VALU issue of its SIMD while it executes (same microbenchmark): kernel time ~ MFMA cycles + every other VALU
+// instruction, so the loop body is kept lean.  (This is fp64 compute-bound work; nothing is "reshaped into a GEMM" to
+// dodge HBM: a launch still reads and writes every state element once.)
 //
 // Structure (one wave = one 16-column strip, streaming down a segment of rows in tiles of 16):
-//  * B operand = the state itself: lane (g = lane>>4, c = lane&15) holds X[row0 + 4*kb + g][col c] for the NK = K/4
-//    k-blocks of the current window: a register ring that advances by 4 k-blocks (16 rows) per tile; the 4 new values
-//    per lane are loaded one tile ahead (a load instruction = 4 rows x 128 contiguous bytes).
-//  * A operand = the band of the weight matrix: W[m][k] = w(|k - R0 - m|), identical for every tile, wave and block of a
-//    chain: built once per block in LDS (NK x 64 doubles) and read with one conflict-free ds_read_b64 per MFMA.
+//  * axis 0.  B operand = the state itself: lane (g = lane>>4, c = lane&15) holds X[row0 + 4*kb + g][col c] for the
+//    NK = K/4 k-blocks of the current window: a register ring that advances by 4 k-blocks (16 rows) per tile; the 4 new
+//    values per lane are loaded BLM_PF tiles ahead (a load instruction = 4 rows x 128 contiguous bytes).
+//    A operand = the band of the weight matrix: W[m][k] = w(|k - R0 - m|), identical for every tile, wave and block of a
+//    chain: built once per block in LDS (NK x 64 doubles), conflict-free ds_read_b64.
+//  * axis 1 (H kernels: blocks of 5 waves).  Waves 0-3 own 16 columns each, wave 4 the 8 + 8 halo columns left and right
+//    of the block (reflected at the grid edge through the column index).  Every wave runs the axis-0 product for its
+//    columns and writes the 16 x 16 result to an LDS tile (16 x 80, double-buffered, one barrier per tile); waves 0-3
+//    then compute  OUT(16 x 16) = V(16 x 32) * W1(32 x 16)  with V read from LDS as the A operand (row stride 82
+//    doubles: conflict-free) and the axis-1 band as a per-lane constant B operand (8 registers).
 //  * D (lane holds rows g, g+4, g+8, g+12 of column c) feeds the same fused epilogue as blf::fast_step_kernel: lazy
 //    normaliser, likelihood, posterior / next state stores, deterministic per-block partial sums.  The Gaussian
 //    likelihood recurrence runs along the lane's own rows, i.e. with stride 4.
@@ -31,7 +40,6 @@ using blf::sld;
 using blf::sldi;
 using blf::DMAX;
 using blk::NRED;
-using blk::NTHREADS;
 using blk::SRC_PREV;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -41,54 +49,90 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int TM = 16;            // rows per tile (MFMA M)
 constexpr int WCOL = 16;          // columns per wave (MFMA N)
-constexpr int BCOL = WCOL * (NTHREADS / 64);   // columns per block
+constexpr int BCOL = 4 * WCOL;    // output columns per block
 constexpr int RSTEPS = 16;        // recurrence steps (of 4 rows) between exact re-anchorings
 constexpr int SEG_Q = BLM_PF * TM; // segment lengths are multiples of this (the tile loop is unrolled BLM_PF times)
 constexpr int MS_MAX = 2048;      // longest row segment of a block (the row coordinates are staged in LDS)
+constexpr int R1 = 8;             // axis-1 radius bucket of the H kernels (= blf::R1MAX)
+constexpr int NK1 = (TM + 2 * R1) / 4;   // k-blocks of the axis-1 product
+constexpr int RS = BCOL + 2 * R1 + 2;    // LDS row stride of the row-filtered tile (82 doubles)
+constexpr int NT_V = 256, NT_H = 320;    // threads per block without / with the axis-1 pass
 
-template <int OM, int MODE, int NK, bool REC>
-__global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P) {
+template <int NW>
+__device__ __forceinline__ double block_sum_w(double v, double *red) {
+    v = blk::wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) s += red[k];
+    return s;
+}
+
+template <int OM, int MODE, int NK, bool REC, bool H>
+__global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastParams P) {
     constexpr bool BWD = MODE == blk::MODE_BWD;
     constexpr bool GAUSS = OM == blk::OM_GAUSSIAN;
     constexpr int R0 = (4 * NK - TM) / 2;
+    constexpr int NT = H ? NT_H : NT_V, NW = NT / 64;
+    static_assert(NK >= 4 && (NK > 4 || H), "NK = 4 (no axis-0 filter) only makes sense with the axis-1 pass");
     __shared__ double As[NK * 64];
     __shared__ double m0s[MS_MAX + 2 * TM];
-    __shared__ double red[NTHREADS / 64 + 1];
+    __shared__ double red[NW + 1];
+    __shared__ double Vt[H ? 2 * TM * RS : 1];
 
     const int b = sldi(P.chain_ids, blockIdx.y);
     const int blkid = blockIdx.x;
     const int tj = blkid / P.mnseg, seg = blkid - tj * P.mnseg;
     const int i_lo = seg * P.mS, i_hi = min(P.n0, i_lo + P.mS);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mainw = !H || wv < 4;                              // wave-uniform: wave 4 of an H block = halo columns
 
     const int kind = ((const unsigned char __attribute__((address_space(4))) *)(unsigned long long)P.srckind)[b];
     const int t0 = sldi(P.tap0, b);
-    const int lw0 = t0 >= 0 ? sldi(P.tap_lw, t0) : 0;
+    const int lw0 = (NK > 4 && t0 >= 0) ? sldi(P.tap_lw, t0) : 0;
     const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
 
-    const int jc = tj * BCOL + (tid >> 6) * WCOL + c;
-    const int gj = min(jc, P.n1 - 1);
-    const bool owner = jc < P.n1;
+    // ---- this lane's column ---------------------------------------------------------------------------------------------
+    const int jc = mainw ? tj * BCOL + wv * WCOL + c : (c < R1 ? tj * BCOL - R1 + c : tj * BCOL + BCOL + (c - R1));
+    const int gj = H ? reflect1(jc, P.n1) : min(jc, P.n1 - 1);
+    const bool owner = mainw && jc < P.n1;
     const double *col = src + gj;
 
-    // ---- prologue: first window of the strip (B ring), while those loads fly: A band + row coordinates -> LDS, normaliser
+    // ---- prologue: first window of the strip (B ring), while those loads fly: bands + row coordinates -> LDS, normaliser
     double Bv[NK];
 #pragma unroll
     for (int kb = 0; kb < NK; ++kb) Bv[kb] = col[(long long)reflect1(i_lo - R0 + 4 * kb + g, P.n0) * P.n1];
 
-    {
+    if (NK > 4) {
         const long long o0 = t0 >= 0 ? sldi(P.tap_off, t0) : 0;
-        for (int e = tid; e < NK * 64; e += NTHREADS) {
+        for (int e = tid; e < NK * 64; e += NT) {
             const int kb = e >> 6, l = e & 63;
             const int a = abs(4 * kb + (l >> 4) - R0 - (l & 15));
             As[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);
         }
-        for (int e = tid; e < P.mS + 2 * TM; e += NTHREADS) m0s[e] = P.m0[min(i_lo + e, P.n0 - 1)];
+    }
+    for (int e = tid; e < P.mS + 2 * TM; e += NT) m0s[e] = P.m0[min(i_lo + e, P.n0 - 1)];
+    double w1b[H ? NK1 : 1];                                      // axis-1 band, B operand: W1[k = 4 kb + g][n = c]
+    if (H) {
+        const int t1 = sldi(P.tap1, b);
+        const int lw1 = t1 >= 0 ? sldi(P.tap_lw, t1) : 0;
+        const long long o1 = t1 >= 0 ? sldi(P.tap_off, t1) : 0;
+#pragma unroll
+        for (int kb = 0; kb < NK1; ++kb) {
+            const int a = abs(4 * kb + g - R1 - c);
+            w1b[kb] = a == 0 ? (lw1 > 0 ? P.taps[o1] : 1.0) : (a <= lw1 ? P.taps[o1 + a] : 0.0);
+        }
     }
     double scale = 1.0;
     if (kind == SRC_PREV) {
-        const double s = blk::sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
-        scale = 1.0 / s;
+        const double *pp = P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk;
+        double v = 0.0;
+        for (int k = tid; k < P.prev_nblk; k += NT) v += pp[k];
+        scale = 1.0 / block_sum_w<NW>(v, red);
     }
     __syncthreads();
 
@@ -103,13 +147,17 @@ __global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P)
     double mE = 1.0, mR = 1.0, mq = 1.0, iE = 1.0, iR = 1.0, iq = 1.0;
     int nE = 0, nR = 0, nq = 0;
     double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
-    double *dcol = P.dst + (long long)b * P.dst_stride + gj;
-    double *pcol = BWD ? P.post + (long long)b * P.post_stride + gj : nullptr;
-    const double *lcol = (!GAUSS) ? P.lik + gj : nullptr;
+    // Lanes that own no output column (columns past the grid edge, the halo wave) address a dump slot with row stride 0:
+    // their loads and stores need no mask inside the loop, their sums are discarded at the end.
+    double *const dump = P.dump + (tid & 255);
+    const long long rs = owner ? P.n1 : 0;
+    double *const dcol = owner ? P.dst + (long long)b * P.dst_stride + gj : dump;
+    double *const pcol = (BWD && owner) ? P.post + (long long)b * P.post_stride + gj : dump;
+    const double *const lcol = (!GAUSS && owner) ? P.lik + gj : dump;
     typedef const double __attribute__((address_space(3))) *lds_cp;
     lds_cp Al = (lds_cp)As + lane;
 
-    static_assert(BLM_PF % 2 == 0, "prefetch depth must be even (two alpha / likelihood slots)");
+    static_assert(BLM_PF % 2 == 0, "prefetch depth must be even (two alpha / likelihood slots, two LDS tiles)");
     // Memory pipeline.  Everything inside the tile loop is straight-line and UNCONDITIONAL (clamped / reflected addresses
     // for the loads, a dump slot for the stores of dead lanes): with control flow around a memory instruction the compiler
     // cannot count what is outstanding and falls back to s_waitcnt vmcnt(0), i.e. drains the stores of the tile and the
@@ -127,116 +175,146 @@ __global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P)
     double al[2][4], lk[2][4];
     if (BWD) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) al[0][r] = pcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * P.n1];
+        for (int r = 0; r < 4; ++r) al[0][r] = pcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * rs];
     }
     if (!GAUSS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lk[0][r] = lcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * P.n1];
+        for (int r = 0; r < 4; ++r) lk[0][r] = lcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * rs];
     }
-    double *const dump = P.dump + tid;
 
     for (int i0 = i_lo; i0 < i_hi; i0 += BLM_PF * TM) {
 #pragma unroll
         for (int u = 0; u < BLM_PF; ++u) {
-            const int i = i0 + u * TM;             // (a tile past the end of the segment is all dead lanes: mS % (BLM_PF * TM) == 0
+            const int i = i0 + u * TM;             // (a tile past the end of the segment is all dead rows: mS % (BLM_PF * TM) == 0
                                                    //  keeps that to the ragged end of the grid)
-            const int li = i - i_lo + g;               // this lane's first row of the tile, relative to the segment
+            const int li = i - i_lo + g;           // this lane's first row of the tile, relative to the segment
             if (BWD) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) al[(u + 1) & 1][r] = pcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * P.n1];
+                for (int r = 0; r < 4; ++r) al[(u + 1) & 1][r] = pcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * rs];
             }
             if (!GAUSS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lk[(u + 1) & 1][r] = lcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * P.n1];
+                for (int r = 0; r < 4; ++r) lk[(u + 1) & 1][r] = lcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * rs];
             }
 
-            // ---- axis-0 stencil: NK chained MFMAs (k ascending) ---------------------------------------------------------
+            // ---- axis-0 stencil: NK chained MFMAs (k ascending); NK == 4: no filter, the ring IS the D layout -------------
             d4 acc = {0.0, 0.0, 0.0, 0.0};
+            if (NK > 4) {
 #pragma unroll
-#ifdef BLM_ABL_NOMFMA
-            for (int kb = 0; kb < 4; ++kb) acc[kb] = Bv[NK / 2 - 2 + kb] * Al[kb * 64];
-#else
-            for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
-#endif
+                for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = Bv[r];
+            }
 
-            // ---- re-anchor the stride-4 likelihood recurrence of this lane's rows ----------------------------------------
-            if (GAUSS && REC && ((i - i_lo) % (4 * RSTEPS)) == 0) {
-                // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
-                // arg(r+4) - arg(r) = cA (mu_{r+4} - mu_r) sum_k (2 x_k - mu_r - mu_{r+4});  2nd difference = -2 cA dn (4 step)^2
-                const double mu0 = m0s[li], mu4 = m0s[li + 4];
-                double a0 = 0.0, s1 = 0.0, dn = 0.0;
+            // ---- axis-1 stencil: row-filtered tile -> LDS -> second banded product (waves 0-3) ----------------------------
+            if (H) {
+                double *vt = Vt + (u & 1) * (TM * RS);
+                const int lc = mainw ? R1 + wv * WCOL + c : (c < R1 ? c : BCOL + c);
 #pragma unroll
-                for (int k = 0; k < DMAX; ++k) {
-                    const double x = xd[k];
-                    if (x == x) {
-                        const double q = x - mu0;
-                        a0 = fma(-(q * q), cA, a0) - cB;
-                        s1 += (x - mu0) + (x - mu4);
-                        dn += 1.0;
+                for (int r = 0; r < 4; ++r) vt[(g + 4 * r) * RS + lc] = acc[r];
+                __syncthreads();
+                if (mainw) {
+                    lds_cp va = (lds_cp)vt + c * RS + wv * WCOL + g;
+                    d4 acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kb = 0; kb < NK1; ++kb) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[4 * kb], w1b[kb], acc2, 0, 0, 0);
+                    acc = acc2;
+                }
+            }
+
+            double st1[4], st2[4];                 // what the 4 cells store: forward a | backward posterior, next state
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st1[r] = acc[r]; st2[r] = acc[r]; }   // (halo wave: anything, goes to the dump slot)
+            if (mainw) {
+                // ---- re-anchor the stride-4 likelihood recurrence of this lane's rows ------------------------------------
+                if (GAUSS && REC && ((i - i_lo) % (4 * RSTEPS)) == 0) {
+                    // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
+                    // arg(r+4) - arg(r) = cA (mu_{r+4} - mu_r) sum_k (2 x_k - mu_r - mu_{r+4});  2nd difference = -2 cA dn (4 step)^2
+                    const double mu0 = m0s[li], mu4 = m0s[li + 4];
+                    double a0 = 0.0, s1 = 0.0, dn = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) {
+                        const double x = xd[k];
+                        if (x == x) {
+                            const double q = x - mu0;
+                            a0 = fma(-(q * q), cA, a0) - cB;
+                            s1 += (x - mu0) + (x - mu4);
+                            dn += 1.0;
+                        }
+                    }
+                    const double d1 = cA * (mu4 - mu0) * s1;
+                    const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                    exp_mn(a0, mE, nE);
+                    exp_mn(d1, mR, nR);
+                    exp_mn(d2, mq, nq);
+                    if (BWD) {
+                        int t;
+                        exp_mn(-a0, iE, t);
+                        exp_mn(-d1, iR, t);
+                        exp_mn(-d2, iq, t);
                     }
                 }
-                const double d1 = cA * (mu4 - mu0) * s1;
-                const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
-                exp_mn(a0, mE, nE);
-                exp_mn(d1, mR, nR);
-                exp_mn(d2, mq, nq);
-                if (BWD) {
-                    int t;
-                    exp_mn(-a0, iE, t);
-                    exp_mn(-d1, iR, t);
-                    exp_mn(-d2, iq, t);
+
+                // ---- epilogue arithmetic: the lane's 4 cells (rows i + g + 4 r) ------------------------------------------
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = i + g + 4 * r;
+                    const double mu = m0s[li + 4 * r];
+                    double Lv;
+                    if (GAUSS && REC) {
+                        Lv = ldexp(mE, nE);
+                    } else if (GAUSS) {
+                        Lv = 1.0;
+#pragma unroll
+                        for (int k = 0; k < DMAX; ++k) {
+                            const double xx = xd[k];
+                            if (xx == xx) { const double dq = xx - mu; Lv *= exp(-(dq * dq) * cA - cB); }
+                        }
+                    } else {
+                        Lv = lk[u & 1][r];
+                    }
+                    const bool live = gi < i_hi;
+                    if (!BWD) {
+                        const double a = acc[r] * scale * Lv;
+                        st1[r] = a;
+                        const double am = live ? a : 0.0;
+                        sN += am;
+                        if (P.means) { sM0 = fma(am, mu, sM0); sM1 = fma(am, g1, sM1); }
+                    } else {
+                        const double beta = acc[r] * scale;
+                        const double p = al[u & 1][r] * beta;
+                        const double cn = beta * Lv;
+                        // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
+                        const double pl = (GAUSS && REC) ? (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)) : p / Lv;
+                        st1[r] = p;
+                        st2[r] = cn;
+                        const double pm = live ? p : 0.0;
+                        sN += pm;
+                        sS += live ? pl : 0.0;
+                        sC += live ? cn : 0.0;
+                        sM0 = fma(pm, mu, sM0);
+                        sM1 = fma(pm, g1, sM1);
+                    }
+                    if (GAUSS && REC) {
+                        mE *= mR; nE += nR;
+                        mR *= mq; nR += nq;
+                        if (BWD) { iE *= iR; iR *= iq; }
+                    }
                 }
             }
 
-            // ---- epilogue: the lane's 4 cells (rows i + g + 4 r) -------------------------------------------------------------
+            // ---- stores (every wave, every lane: dead rows / lanes hit the dump slot) ---------------------------------------
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = i + g + 4 * r;
-                const double mu = m0s[li + 4 * r];
-                double Lv;
-                if (GAUSS && REC) {
-                    Lv = ldexp(mE, nE);
-                } else if (GAUSS) {
-                    Lv = 1.0;
-#pragma unroll
-                    for (int k = 0; k < DMAX; ++k) {
-                        const double xx = xd[k];
-                        if (xx == xx) { const double dq = xx - mu; Lv *= exp(-(dq * dq) * cA - cB); }
-                    }
-                } else {
-                    Lv = lk[u & 1][r];
-                }
-#ifdef BLM_ABL_NOSTORE
-                const bool live0 = owner && gi < i_hi; const bool live = live0 && acc[r] == 1.2345e300;
-#else
-                const bool live = owner && gi < i_hi;
-#endif
-                const long long off = (long long)gi * P.n1;
+                const bool live = gi < i_hi;
+                const long long off = (long long)gi * rs;
                 if (!BWD) {
-                    const double a = acc[r] * scale * Lv;
-                    *(live ? dcol + off : dump) = a;
-                    const double am = live ? a : 0.0;
-                    sN += am;
-                    if (P.means) { sM0 = fma(am, mu, sM0); sM1 = fma(am, g1, sM1); }
+                    *(live ? dcol + off : dump) = st1[r];
                 } else {
-                    const double beta = acc[r] * scale;
-                    const double p = al[u & 1][r] * beta;
-                    const double cn = beta * Lv;
-                    // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
-                    const double pl = (GAUSS && REC) ? (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)) : p / Lv;
-                    *(live ? pcol + off : dump) = p;
-                    *(live ? dcol + off : dump) = cn;
-                    const double pm = live ? p : 0.0;
-                    sN += pm;
-                    sS += live ? pl : 0.0;
-                    sC += live ? cn : 0.0;
-                    sM0 = fma(pm, mu, sM0);
-                    sM1 = fma(pm, g1, sM1);
-                }
-                if (GAUSS && REC) {
-                    mE *= mR; nE += nR;
-                    mR *= mq; nR += nq;
-                    if (BWD) { iE *= iR; iR *= iq; }
+                    *(live ? pcol + off : dump) = st1[r];
+                    *(live ? dcol + off : dump) = st2[r];
                 }
             }
 
@@ -247,27 +325,25 @@ __global__ __launch_bounds__(NTHREADS) void mfma_step_kernel(const FastParams P)
             for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = nxt[u][q];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-#ifdef BLM_ABL_NOLOAD
-                nxt[u][q] = nxt[u][q] * 1.0000001;
-#else
                 nxt[u][q] = col[(long long)reflect1(i + (BLM_PF + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
-#endif
         }
     }
 
+    if (!owner) { sN = 0.0; sS = 0.0; sC = 0.0; sM0 = 0.0; sM1 = 0.0; }
     double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
+    const int left = P.nblk - blkid;
     const bool z = tid == 0;
-    const double r0 = blk::block_sum(sN, red);
-    if (z) blf::put_partial(out, r0, P.mnblk, P.nblk - blkid);
+    const double r0 = block_sum_w<NW>(sN, red);
+    if (z) blf::put_partial(out, r0, P.mnblk, left);
     if (BWD) {
-        const double r1 = blk::block_sum(sS, red);
-        const double r2 = blk::block_sum(sC, red);
-        if (z) { blf::put_partial(out + 1 * P.nblk, r1, P.mnblk, P.nblk - blkid); blf::put_partial(out + 2 * P.nblk, r2, P.mnblk, P.nblk - blkid); }
+        const double r1 = block_sum_w<NW>(sS, red);
+        const double r2 = block_sum_w<NW>(sC, red);
+        if (z) { blf::put_partial(out + 1 * P.nblk, r1, P.mnblk, left); blf::put_partial(out + 2 * P.nblk, r2, P.mnblk, left); }
     }
     if (BWD || P.means) {
-        const double r3 = blk::block_sum(sM0, red);
-        const double r4 = blk::block_sum(sM1, red);
-        if (z) { blf::put_partial(out + 3 * P.nblk, r3, P.mnblk, P.nblk - blkid); blf::put_partial(out + 4 * P.nblk, r4, P.mnblk, P.nblk - blkid); }
+        const double r3 = block_sum_w<NW>(sM0, red);
+        const double r4 = block_sum_w<NW>(sM1, red);
+        if (z) { blf::put_partial(out + 3 * P.nblk, r3, P.mnblk, left); blf::put_partial(out + 4 * P.nblk, r4, P.mnblk, left); }
     }
 }
 

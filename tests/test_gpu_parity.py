@@ -45,10 +45,11 @@ def test_hip_matches_reference_golden(case):
     compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL, case_tol=cases.CASES[case].get('tol'))
 
 
-@pytest.mark.parametrize('option', ['fast', 'recurrence'])
+@pytest.mark.parametrize('option', ['fast', 'recurrence', 'mfma', 'mfma_h'])
 @pytest.mark.parametrize('case', ['c3_small', 'c3_missing', 'multidim_data', 'c4_small', 'c5_cp_grw', 'c3_forward_only'])
 def test_alternative_kernel_paths_match_golden(case, option):
-    """The generic LDS-tile kernel (fast=0) and the exact-exp likelihood (recurrence=0) on the 2-D cases."""
+    """The generic LDS-tile kernel (fast=0), the exact-exp likelihood (recurrence=0) and the vector-ALU streaming kernels
+    (mfma=0: all launches, mfma_h=0: the both-axes launches) on the 2-D cases."""
     eng = bl.get_engine()
     eng.set_option(option, 0)
     try:
@@ -56,6 +57,8 @@ def test_alternative_kernel_paths_match_golden(case, option):
         S.fit(**cases.fit_kwargs(case))
         if option == 'fast':
             assert S.lastTiming['fwd_kernel_variant'] == 0
+        if option == 'mfma':
+            assert S.lastTiming['fwd_kernel_variant'] in (0, 1)        # (0: the case is too small for the streaming kernels)
         compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL, case_tol=cases.CASES[case].get('tol'))
     finally:
         eng.set_option(option, 1)
@@ -96,6 +99,24 @@ EXTRA = {
                                           ('GRW', 's2', ('cint', 0, 0.12, 5), 'std', None)])),
     'x_hyper_forward': dict(study='HyperStudy', data=('series', 25, 16), om=cases.gauss2d(40, -5, 5, 3),
                             tm=('GRW', 'sigma', ('cint', 0.05, 0.5, 6), 'mean', None), fit=dict(forwardOnly=True)),
+    # matrix-pipe kernels (blhip_mfma.hpp): wide axis-0 radius, ragged rows / columns, all radius buckets in one batch
+    'x_mfma_wide': dict(study='Study', data=('series', 27, 12),
+                        om=('Gaussian', [('mean', ('cint', -5, 5, 150)), ('std', ('oint', 0, 3, 70))], 'default'),
+                        tm=('GRW', 's1', 0.537, 'mean', None)),
+    'x_mfma_ragged': dict(study='Study', data=('series', 28, 10),
+                          om=('Gaussian', [('mean', ('cint', -5, 5, 83)), ('std', ('oint', 0, 3, 129))], 'default'),
+                          tm=('GRW', 's1', 0.9, 'mean', None)),
+    'x_mfma_buckets': dict(study='HyperStudy', data=('series', 29, 14), om=cases.gauss2d(96, -5, 5, 3),
+                           tm=('GRW', 'sigma', ('cint', 0, 1.0, 11), 'mean', None)),
+    'x_mfma_cp': dict(study='HyperStudy', data=('series_jump', 30, 24, 11, 2.0), om=cases.gauss2d(80, -5, 7, 3),
+                      tm=('Combined', [('GRW', 'sigma', ('cint', 0.1, 0.9, 4), 'mean', None),
+                                       ('ChangePoint', 'tc', ('arange', 4, 20, 5), None)])),
+    'x_mfma_both_ragged': dict(study='Study', data=('series', 32, 9),
+                               om=('Gaussian', [('mean', ('cint', -4, 4, 203)), ('std', ('oint', 0, 3, 77))], 'default'),
+                               tm=('Combined', [('GRW', 's1', 0.31, 'mean', None), ('GRW', 's2', 0.06, 'std', None)])),
+    'x_mfma_axis1_only': dict(study='Study', data=('series', 33, 9),
+                              om=('Gaussian', [('mean', ('cint', -4, 4, 97)), ('std', ('oint', 0, 3, 111))], 'default'),
+                              tm=('GRW', 's2', 0.05, 'std', None)),
     'x_cp_all': dict(study='ChangepointStudy', data=('series_jump', 26, 30, 17, 2.5), om=cases.gauss2d(50, -5, 7, 3),
                      tm=('ChangePoint', 'tc', 'all', None)),
 }
@@ -114,6 +135,46 @@ def test_hip_matches_oracle(case):
         if k in want and want[k] is not None and (k != 'posteriorMeanValues' or len(want[k])):
             gold[k] = np.asarray(want[k])
     compare.check(got, gold, compare.GPU_TOL)
+
+
+def test_matrix_pipe_kernels_ran():
+    """The cases above really go through blm::mfma_step_kernel (timing variant 3), in both directions."""
+    for name in ('x_mfma_wide', 'x_mfma_both_ragged'):
+        S = cases.build(bl, EXTRA[name])
+        S.fit(silent=True)
+        assert S.lastTiming['fwd_kernel_variant'] == 3 and S.lastTiming['bwd_kernel_variant'] == 3, S.lastTiming
+
+
+def test_matrix_pipe_table_likelihood_and_forced_both_axes():
+    """Tabulated likelihood through the matrix-pipe kernels, and the both-axes variant forced on a launch larger than its
+    default size limit: both equal the vector-ALU kernels (mfma=0) to rounding."""
+    eng = bl.get_engine()
+
+    def fit(n0, n1, s1, s2, **opts):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        try:
+            S = bl.Study(silent=True)
+            S.loadData(cases.series(34, 8), silent=True)
+            tms = [bl.tm.GaussianRandomWalk('s1', s1, target='location')]
+            if s2:
+                tms.append(bl.tm.GaussianRandomWalk('s2', s2, target='scale'))
+            S.set(bl.om.Laplace('location', bl.cint(-5, 5, n0), 'scale', bl.oint(0, 3, n1)),
+                  bl.tm.CombinedTransitionModel(*tms), silent=True)
+            S.fit(silent=True)
+            return S
+        finally:
+            for k in opts:
+                eng.set_option(k, 1 if k != 'mfma_h_max_cells' else 2.5e6)
+
+    for (n0, n1, s1, s2) in ((140, 90, 0.6, 0.0), (140, 90, 0.3, 0.05)):
+        A = fit(n0, n1, s1, s2, mfma_h_max_cells=1e15)
+        assert A.lastTiming['fwd_kernel_variant'] == 3
+        B = fit(n0, n1, s1, s2, mfma=0)
+        assert B.lastTiming['fwd_kernel_variant'] == 1
+        assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
+        np.testing.assert_allclose(A.posteriorSequence, B.posteriorSequence, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(A.posteriorMeanValues, B.posteriorMeanValues, rtol=1e-10)
 
 
 def test_table_likelihood_path_on_device():
