@@ -141,7 +141,7 @@ struct Tile {
 
 size_t lds_need(int TI, int TJ, int LW0, int LW1) {
     const size_t pitch = (size_t)TJ + 2 * LW1;
-    return ((size_t)(TI + 2 * LW0) * pitch + (size_t)TI * pitch + 16) * sizeof(double);
+    return ((size_t)(TI + 2 * LW0) * pitch + (size_t)TI * pitch + 32) * sizeof(double);
 }
 
 Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1) {

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
     // the barrier of the chunk in between, i.e. after every lane has finished reading that tile)
     constexpr int VTSZ = CH * (BW + 1);
     __shared__ __attribute__((aligned(16))) double vtbuf[H ? 2 * VTSZ : 1];
-    __shared__ double red[NTHREADS / 64 + 1];
+    __shared__ double red[5 * (NTHREADS / 64) + 1];
 
     const int b = sldi(P.chain_ids, blockIdx.y);
     const int blkid = blockIdx.x;
@@ -364,17 +364,21 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
 
     double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
     const int left = P.nblk - blkid;
-    const double r0 = blk::block_sum(sN, red);
-    if (tid == 0) put_partial(out, r0, P.fnblk, left);
     if (BWD) {
-        const double r1 = blk::block_sum(sS, red);
-        const double r2 = blk::block_sum(sC, red);
-        if (tid == 0) { put_partial(out + 1 * P.nblk, r1, P.fnblk, left); put_partial(out + 2 * P.nblk, r2, P.fnblk, left); }
-    }
-    if (BWD || P.means) {
-        const double r3 = blk::block_sum(sM0, red);
-        const double r4 = blk::block_sum(sM1, red);
-        if (tid == 0) { put_partial(out + 3 * P.nblk, r3, P.fnblk, left); put_partial(out + 4 * P.nblk, r4, P.fnblk, left); }
+        double v[5] = {sN, sS, sC, sM0, sM1};
+        blk::block_sums<5, NTHREADS / 64>(v, red);
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) put_partial(out + k * P.nblk, v[k], P.fnblk, left);
+        }
+    } else if (P.means) {
+        double v[3] = {sN, sM0, sM1};
+        blk::block_sums<3, NTHREADS / 64>(v, red);
+        if (tid == 0) { put_partial(out, v[0], P.fnblk, left); put_partial(out + 3 * P.nblk, v[1], P.fnblk, left); put_partial(out + 4 * P.nblk, v[2], P.fnblk, left); }
+    } else {
+        double v[1] = {sN};
+        blk::block_sums<1, NTHREADS / 64>(v, red);
+        if (tid == 0) put_partial(out, v[0], P.fnblk, left);
     }
 }
 

@@ -61,10 +61,27 @@ __device__ __forceinline__ int reflect(int i, int n) {
     return i >= n ? p - 1 - i : i;
 }
 
+// Wave-wide sum on the DPP cross-lane path (no LDS round trips): 4 row_shr steps inside each row of 16 lanes, then
+// row_bcast:15 / row_bcast:31 fold the four rows; the total lands in lane 63 and is broadcast through an SGPR.
+// (__shfl_down on a double is 2 ds_bpermute_b32 per step: ~1200 cycles per sum vs ~100 here -- per block that was 1-2 us
+// of serial tail for the 5 sums of a step kernel.)  Fixed summation tree => deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);             // lanes without a source (or outside ROW_MASK) add 0.0
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v = dpp_add<0x111, 0xf>(v);                      // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);                      // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);                      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);                      // row_shr:8   -> lane 15 of every row = row total
+    v = dpp_add<0x142, 0xa>(v);                      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);                      // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // Sum over the block; result valid in every thread.  `red` = NTHREADS/64 doubles of LDS scratch (+1).
@@ -78,6 +95,27 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
 #pragma unroll
     for (int k = 1; k < NTHREADS / 64; ++k) s += red[k];
     return s;
+}
+
+// NV sums over a block of NW waves with two barriers in total; results valid in every thread; red = NV * NW doubles.
+template <int NV, int NW>
+__device__ __forceinline__ void block_sums(double (&v)[NV], double *red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[w * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = red[k];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) s += red[q * NV + k];
+        v[k] = s;
+    }
 }
 
 // Deterministic sum of n partials (fixed order for a fixed block size).
@@ -251,21 +289,14 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     if (MODE == MODE_FILTER) return;
 
     double *out = P.psum_out + (long long)b * NRED * P.nblk + blk;
-    double r0 = block_sum(sN, red);
-    if (threadIdx.x == 0) out[0] = r0;
-    if (MODE == MODE_BWD) {
-        double r1 = block_sum(sS, red);
-        double r2 = block_sum(sC, red);
-        if (threadIdx.x == 0) { out[1 * P.nblk] = r1; out[2 * P.nblk] = r2; }
-    }
-    if (MODE == MODE_BWD || MEANS) {
-        double r3 = block_sum(sM0, red);
-        double r4 = block_sum(sM1, red);
-        if (threadIdx.x == 0) { out[3 * P.nblk] = r3; out[4 * P.nblk] = r4; }
-    }
-    if (P.cmode) {                                 // clamp bookkeeping: fwd U = sum u (slot 1), bwd B = sum beta_used (slot 5)
-        double r5 = block_sum(MODE == MODE_BWD ? sU * kappa : sU, red);
-        if (threadIdx.x == 0) out[(MODE == MODE_BWD ? 5 : 1) * P.nblk] = r5;
+    // all sums of the block with two barriers (red holds 6 * NTHREADS/64 doubles)
+    double v[6] = {sN, sS, sC, sM0, sM1, MODE == MODE_BWD ? sU * kappa : sU};
+    block_sums<6, NTHREADS / 64>(v, red);
+    if (threadIdx.x == 0) {
+        out[0] = v[0];
+        if (MODE == MODE_BWD) { out[1 * P.nblk] = v[1]; out[2 * P.nblk] = v[2]; }
+        if (MODE == MODE_BWD || MEANS) { out[3 * P.nblk] = v[3]; out[4 * P.nblk] = v[4]; }
+        if (P.cmode) out[(MODE == MODE_BWD ? 5 : 1) * P.nblk] = v[5];   // clamp bookkeeping: fwd U = sum u, bwd B = sum beta_used
     }
 }
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     static_assert(NK >= 4 && (NK > 4 || H), "NK = 4 (no axis-0 filter) only makes sense with the axis-1 pass");
     __shared__ double As[NK * 64];
     __shared__ double m0s[MS_MAX + 2 * TM];
-    __shared__ double red[NW + 1];
+    __shared__ double red[5 * NW + 1];
     __shared__ double Vt[H ? 2 * TM * RS : 1];
 
     const int b = sldi(P.chain_ids, blockIdx.y);
@@ -333,17 +333,21 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
     const int left = P.nblk - blkid;
     const bool z = tid == 0;
-    const double r0 = block_sum_w<NW>(sN, red);
-    if (z) blf::put_partial(out, r0, P.mnblk, left);
     if (BWD) {
-        const double r1 = block_sum_w<NW>(sS, red);
-        const double r2 = block_sum_w<NW>(sC, red);
-        if (z) { blf::put_partial(out + 1 * P.nblk, r1, P.mnblk, left); blf::put_partial(out + 2 * P.nblk, r2, P.mnblk, left); }
-    }
-    if (BWD || P.means) {
-        const double r3 = block_sum_w<NW>(sM0, red);
-        const double r4 = block_sum_w<NW>(sM1, red);
-        if (z) { blf::put_partial(out + 3 * P.nblk, r3, P.mnblk, left); blf::put_partial(out + 4 * P.nblk, r4, P.mnblk, left); }
+        double v[5] = {sN, sS, sC, sM0, sM1};
+        blk::block_sums<5, NW>(v, red);
+        if (z) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) blf::put_partial(out + k * P.nblk, v[k], P.mnblk, left);
+        }
+    } else if (P.means) {
+        double v[3] = {sN, sM0, sM1};
+        blk::block_sums<3, NW>(v, red);
+        if (z) { blf::put_partial(out, v[0], P.mnblk, left); blf::put_partial(out + 3 * P.nblk, v[1], P.mnblk, left); blf::put_partial(out + 4 * P.nblk, v[2], P.mnblk, left); }
+    } else {
+        double v[1] = {sN};
+        blk::block_sums<1, NW>(v, red);
+        if (z) blf::put_partial(out, v[0], P.mnblk, left);
     }
 }
 

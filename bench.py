@@ -220,7 +220,7 @@ def main():
                 if name == args.workload:
                     continue
                 try:
-                    S2, u2, d2, dt2 = run_workload(bl, name, 1, 1 if name != 'c3' else 0, None, lambda: None)
+                    S2, u2, d2, dt2 = run_workload(bl, name, 1, 1, None, lambda: None)
                     tm = dict(S2.lastTiming)
                     extra[name] = dict(value=u2 / dt2, ms_per_step=dt2 * 1e3, log_evidence=float(S2.logEvidence),
                                        config=d2, kernels=roofline_of(tm, tm.get('cells_per_launch', 0)))
