@@ -19,6 +19,7 @@
 #include "blhip_kernels.hpp"
 #include "blhip_fast.hpp"
 #include "blhip_mfma.hpp"
+#include "blhip_fused1d.hpp"
 #include "blhip_persist1d.hpp"
 
 using namespace blk;
@@ -352,6 +353,31 @@ void launch_persist(hipStream_t s, int om, const bl1::P1Params &P, bool bwd, siz
     HIPCHECK(hipGetLastError());
 }
 
+// ---- 1-D path, K time steps per launch (blhip_fused1d.hpp) ---------------------------------------------------------------
+template <int OM>
+void launch_fused1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
+    const dim3 grid(P.nblk, P.B), block(bl1f::NT);
+    if (bwd) {
+        static bool a = false;
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((bl1f::fused1d_kernel<OM, true>), grid, block, lds, s, P);
+    } else {
+        static bool a = false;
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((bl1f::fused1d_kernel<OM, false>), grid, block, lds, s, P);
+    }
+}
+
+void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, size_t lds) {
+    switch (om) {
+        case BLHIP_OM_POISSON: launch_fused1d_om<OM_POISSON>(s, P, bwd, lds); break;
+        case BLHIP_OM_GAUSSIAN_MEAN: launch_fused1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
+        case BLHIP_OM_TABLE: launch_fused1d_om<OM_TABLE>(s, P, bwd, lds); break;
+        default: fail("fused 1-D path: observation model %d", om);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
 void validate(const blhip_problem *p, int64_t n_chains, const double *op_values) {
     if (!p) fail("problem is NULL");
     if (p->ndim != 1 && p->ndim != 2) fail("ndim must be 1 or 2 (got %d)", p->ndim);
@@ -664,6 +690,19 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                              prog.LW1 <= g.n1 && p1_lds <= 150 * 1024 &&
                              (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
                               p->obs_model == BLHIP_OM_TABLE);
+        // 1-D grids: K time steps per launch (blhip_fused1d.hpp); K = 1 is the same kernel with a launch per step
+        int64_t fusedK = 1;
+        int f1_TJ = 128;
+        bool fused1d = false;
+        if (p->ndim == 1 && !fast && !persist && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
+            (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
+            f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
+            fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
+            // keep the redundantly recomputed halo (K * LW cells per side) within ~4x the owned cells and the window in LDS
+            while (fusedK > 1 && (fusedK * prog.LW1 > 2 * f1_TJ || (size_t)(f1_TJ + 2 * fusedK * prog.LW1) * 32 > 96 * 1024)) --fusedK;
+            fused1d = (size_t)(f1_TJ + 2 * fusedK * prog.LW1) * 32 + (size_t)fusedK * f1_TJ * 8 + 4096 <= 150 * 1024;
+        }
+        auto f1_lds = [&](int64_t K) { return (size_t)(4 * (f1_TJ + 2 * K * prog.LW1) + K * f1_TJ + K * (prog.LW1 + 1) + K * rec_len + 4 * 8 + 2 + K + 8) * sizeof(double); };
         Tile tile{};
         int fastS = 0, fast_nseg = 1, fast_fnblk = 1, mS = 0, m_nseg = 1, m_tiles_j = 1, m_nblk = 1;
         bool use_mfma = false;
@@ -716,10 +755,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             use_mfma = ctx->option("mfma", 1.0) != 0.0;
             tile.nblk = use_mfma ? std::max(fast_fnblk, m_nblk) : fast_fnblk;
             tile.lds_bytes = 0;
+        } else if (fused1d) {
+            tile.TI = 1; tile.TJ = f1_TJ; tile.LW0 = 0; tile.LW1 = prog.LW1; tile.tiles_i = 1;
+            tile.tiles_j = (g.n1 + f1_TJ - 1) / f1_TJ; tile.nblk = tile.tiles_j; tile.lds_bytes = 0;
         } else {
             tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
         }
-        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : (persist ? 2 : 0);
+        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : (persist ? 2 : (fused1d ? 4 : 0));
         ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
 
         // --- device metadata ---
@@ -897,6 +939,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             PP.taps = d_taps; PP.tap_off = d_off; PP.tap_lw = d_lw; PP.m1 = d_m1; PP.colA = d_colA; PP.rec = d_rec;
             PP.lik = d_lik;
         }
+        float ms = 0;
+        std::vector<double> logE, local, means, invN;
+        std::vector<int64_t> abort_step;
+        std::vector<int32_t> abort_phase;
+        auto passes = [&](const int64_t K) -> bool {
+        bl1f::F1Params F1{};
+        if (fused1d) {
+            F1.n = g.n1; F1.TJ = f1_TJ; F1.nblk = tile.nblk; F1.LW = prog.LW1; F1.T = (int)T; F1.B = (int)B; F1.d = d; F1.rec_len = rec_len;
+            F1.shared[SRC_PREV] = nullptr; F1.shared[SRC_PRIOR] = d_prior; F1.shared[SRC_RESET] = d_reset;
+            F1.shared[SRC_UNIFORM] = d_uniform; F1.shared[SRC_INDEP] = d_indep;
+            F1.taps = d_taps; F1.tap_off = d_off; F1.tap_lw = d_lw; F1.m1 = d_m1; F1.colA = d_colA; F1.rec = d_rec; F1.lik = d_lik;
+        }
         // --- forward pass (core.py:372-411) ---
         HIPCHECK(hipEventRecord(ev[0], st));
         if (persist) {
@@ -905,8 +959,26 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0;
             launch_persist(st, p->obs_model, Q, false, p1_lds);
         }
+        if (fused1d) {
+            for (int64_t t = 0; t < T; t += K) {
+                bl1f::F1Params Q = F1;
+                Q.K = (int)std::min<int64_t>(K, T - t); Q.dir = 1; Q.t_first = (int)t;
+                Q.srckind = d_kindF; Q.tap = d_tapF1; Q.psum = d_psF; Q.prev_slot = 0;
+                Q.psum_prev = t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : nullptr;
+                Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0;
+                const int64_t tl = t + Q.K - 1;              // last step of this launch
+                if (evidence_only) {
+                    Q.post = nullptr; Q.src = d_pp[(t / K + 1) & 1]; Q.src_stride = G; Q.dst = d_pp[(t / K) & 1]; Q.dst_stride = G;
+                } else {
+                    Q.post = d_post; Q.post_stride = (long long)T * G; Q.dst = nullptr; Q.dst_stride = 0;
+                    Q.src = d_post + (t > 0 ? (size_t)(t - 1) * G : 0); Q.src_stride = (long long)T * G;
+                }
+                (void)tl;
+                launch_fused1d(st, p->obs_model, Q, false, f1_lds(Q.K));
+            }
+        }
         fork_streams();
-        for (int64_t t = 0; t < T && !persist; ++t) {
+        for (int64_t t = 0; t < T && !persist && !fused1d; ++t) {
             if (multistream && t > 0 && !same_membership(orderF, rangesF, t - 1, t)) { join_streams(); fork_streams(); }
             const double *srcp; double *dstp; long long sstr, dstr;
             if (evidence_only) {
@@ -927,21 +999,27 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         redF.resize((size_t)T * B * NRED);
         HIPCHECK(hipMemcpyAsync(redF.data(), ctx->redF.p, redF.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
-        float ms = 0;
+        ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
         ctx->timing.forward_ms += ms;
         ctx->timing.forward_launches += T;
         if (n_mfma[0] > 0 && n_mfma[0] >= n_fast[0]) ctx->timing.fwd_kernel_variant = 3;
 
         // --- evidence bookkeeping on the host, in the reference's order (core.py:385-404, 417) ---
-        std::vector<double> logE(B, 0.0);
-        std::vector<int64_t> abort_step(B, -1);
-        std::vector<int32_t> abort_phase(B, 0);
-        std::vector<double> local((size_t)B * T, 0.0);
+        logE.assign(B, 0.0);
+        abort_step.assign(B, -1);
+        abort_phase.assign(B, 0);
+        local.assign((size_t)B * T, 0.0);
+        bool raw_ok = true;                         // fused 1-D passes: no raw sum near the bottom of the fp64 range
         for (int64_t b = 0; b < B; ++b) {
             double le = 0.0;
             for (int64_t t = 0; t < T; ++t) {
                 double norm = redF[((size_t)t * B + b) * NRED + 0];
+                if (fused1d) {
+                    // raw sums of the K-step launches (blhip_fused1d.hpp): inner steps carry the scale of their predecessor
+                    if (!(norm > 1e-200)) raw_ok = false;
+                    if (t % K != 0 && prog.kindF[(size_t)t * B + b] == SRC_PREV) norm /= redF[((size_t)(t - 1) * B + b) * NRED];
+                }
                 // RegimeSwitch renormalises the clamped prior (transitionModels.py:410): alpha = (u / sum u) L
                 if (prog.has_clamp && prog.cmodeF[(size_t)t * B + b]) norm /= redF[((size_t)t * B + b) * NRED + 1];
                 if (!(norm > 0.0)) { abort_step[b] = t; abort_phase[b] = 0; le = -INFINITY; break; }
@@ -952,7 +1030,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             logE[b] = le;
         }
 
-        std::vector<double> means;
+        means.clear();
         if (!evidence_only) means.assign((size_t)B * p->ndim * T, 0.0);
         if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
@@ -963,19 +1041,32 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         }
 
         // --- backward pass (core.py:424-470) ---
-        std::vector<double> invN((size_t)B * T, 0.0);
+        invN.assign((size_t)B * T, 0.0);
         if (full) {
             ctx->psumB.ensure(psz * 8);
             ctx->redB.ensure((size_t)T * B * NRED * 8);
             double *d_psB = ctx->psumB.as<double>();
+            if (fused1d && !raw_ok && K > 1) return false;
             HIPCHECK(hipEventRecord(ev[2], st));
             if (persist) {
                 bl1::P1Params Q = PP;
                 Q.srckind = d_kindB; Q.tap = d_tapB1; Q.red_out = ctx->redB.as<double>(); Q.store = 1; Q.means = 1;
                 launch_persist(st, p->obs_model, Q, true, p1_lds);
             }
+            if (fused1d) {
+                for (int64_t t = T - 1; t >= 0; t -= K) {
+                    bl1f::F1Params Q = F1;
+                    Q.K = (int)std::min<int64_t>(K, t + 1); Q.dir = -1; Q.t_first = (int)t;
+                    Q.srckind = d_kindB; Q.tap = d_tapB1; Q.psum = d_psB; Q.prev_slot = 2;
+                    Q.psum_prev = t < T - 1 ? d_psB + (size_t)(t + 1) * B * NRED * tile.nblk : nullptr;
+                    Q.store = 1; Q.means = 1; Q.post = d_post; Q.post_stride = (long long)T * G;
+                    const int64_t li = (T - 1 - t) / K;
+                    Q.src = d_pp[(li + 1) & 1]; Q.src_stride = G; Q.dst = d_pp[li & 1]; Q.dst_stride = G;
+                    launch_fused1d(st, p->obs_model, Q, true, f1_lds(Q.K));
+                }
+            }
             fork_streams();
-            for (int64_t t = T - 1; t >= 0 && !persist; --t) {
+            for (int64_t t = T - 1; t >= 0 && !persist && !fused1d; --t) {
                 if (multistream && t < T - 1 && !same_membership(orderB, rangesB, t + 1, t)) { join_streams(); fork_streams(); }
                 // reads c_{t+1} and the stored alpha_t, writes c_t and posterior_t
                 run_step(MODE_BWD, t, d_pp[(t + 1) & 1], G, d_pp[t & 1], G, d_post + (size_t)t * G, (long long)T * G,
@@ -998,6 +1089,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 if (abort_step[b] >= 0) continue;
                 for (int64_t t = T - 1; t >= 0; --t) {
                     const double *r = &redB[((size_t)t * B + b) * NRED];
+                    if (fused1d && !(r[0] > 1e-200)) raw_ok = false;
                     if (!(r[0] > 0.0)) { abort_step[b] = t; abort_phase[b] = 1; logE[b] = -INFINITY; break; }
                     local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
                     invN[(size_t)b * T + t] = 1.0 / r[0];
@@ -1011,6 +1103,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                     invN[(size_t)b * T + t] = n0 > 0.0 ? 1.0 / n0 : 0.0;
                 }
         }
+
+        return raw_ok || K == 1;
+        };
+        if (!passes(fusedK)) passes(1);
 
         // --- fold into the average posterior (core.py:1358-1366) ---
         if (accumulate) {

@@ -103,7 +103,7 @@ def roofline_of(timing, cells_per_launch):
         if n and ms > 0:
             per_launch_s = ms * 1e-3 / n
             variant = timing.get('fwd_kernel_variant' if key == 'forward' else 'bwd_kernel_variant', 0)
-            kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel',
+            kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel', 4: 'bl1f::fused1d_kernel (8 time steps per launch)',
                      3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)'}.get(variant, 'step_kernel')
             out[key] = dict(kernel='%s<%s> (one logical step launch = all radius-bucket launches of the batch)' % (kname, key),
                             launches=int(n), avg_launch_us=per_launch_s * 1e6,
@@ -182,6 +182,9 @@ def main():
             torch.cuda.synchronize()
 
     eng = bl.get_engine()
+    for kv in os.environ.get('BLHIP_OPTS', '').split(','):      # tuning experiments: BLHIP_OPTS=key=value,key=value
+        if '=' in kv:
+            eng.set_option(kv.split('=')[0], float(kv.split('=')[1]))
     S, units, desc, dt = run_workload(bl, args.workload, args.steps, args.warmup, comm, barrier)
     if dist is not None:
         import torch

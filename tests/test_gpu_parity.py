@@ -66,6 +66,22 @@ def test_alternative_kernel_paths_match_golden(case, option):
 
 @pytest.mark.parametrize('case', ['c1_coal', 'c2_small', 'kat_changepoint', 'c1_coal_changepoint', 'kat_gaussianmean',
                                   'c1_coal_hyper', 'kat_study_prior_array', 'cp_nonunit_time'])
+def test_one_launch_per_step_1d_kernels_match_golden(case):
+    """1-D cases with the K-steps-per-launch kernel switched off (fuse1d=0: generic kernel) and with K = 1 / K = 3."""
+    eng = bl.get_engine()
+    for k, variant in ((0, 0), (1, 4), (3, 4)):
+        eng.set_option('fuse1d', k)
+        try:
+            S = cases.build(bl, case)
+            S.fit(**cases.fit_kwargs(case))
+            assert S.lastTiming['fwd_kernel_variant'] == variant
+            compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL)
+        finally:
+            eng.set_option('fuse1d', 8)
+
+
+@pytest.mark.parametrize('case', ['c1_coal', 'c2_small', 'kat_changepoint', 'c1_coal_changepoint', 'kat_gaussianmean',
+                                  'c1_coal_hyper', 'kat_study_prior_array', 'cp_nonunit_time'])
 def test_persistent_1d_kernel_matches_golden(case):
     """The experimental one-workgroup-per-chain kernels for 1-D grids (off by default) against the goldens."""
     eng = bl.get_engine()
