@@ -125,7 +125,7 @@ def run_workload(bl, name, steps, warmup, comm, barrier):
     return S, units, desc, dt
 
 
-def cpu_baseline(nh=6, T=64, n=512):
+def cpu_baseline(nh=8, T=160, n=512):
     """The CPU oracle (numpy restatement of the reference path) on a bounded sample of the C4 workload, 1 core."""
     from oracle import bl_oracle as orc
     g = orc.Grid([orc.cint(-8, 8, n), orc.oint(0, 4, n)])
