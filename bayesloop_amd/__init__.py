@@ -8,7 +8,7 @@ the C-ABI of ``libblhip.so`` (``include/blhip.h``).  Same public surface as the 
     S.set(bl.om.Poisson('rate', bl.oint(0, 6, 1000)), bl.tm.GaussianRandomWalk('sigma', 0.2, target='rate'))
     S.fit()
 """
-from .core import Study, HyperStudy, ChangepointStudy
+from .core import Study, HyperStudy, ChangepointStudy, OnlineStudy
 from . import observationModels
 from . import observationModels as om
 from . import transitionModels

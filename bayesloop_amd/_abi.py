@@ -12,11 +12,11 @@ import os
 from .exceptions import BackendError
 
 LIB_NAME = 'libblhip.so'
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
 OP_STATIC, OP_GRW, OP_CHANGEPOINT, OP_REGIMESWITCH, OP_INDEPENDENT, OP_BREAKPOINT = 0, 1, 2, 3, 4, 5
-FORWARD_ONLY, EVIDENCE_ONLY, KEEP_POSTERIOR, ACCUMULATE = 1, 2, 4, 8
+FORWARD_ONLY, EVIDENCE_ONLY, KEEP_POSTERIOR, ACCUMULATE, RESUME, CARRY = 1, 2, 4, 8, 16, 32
 
 c_double_p = C.POINTER(C.c_double)
 
@@ -37,6 +37,7 @@ class Problem(C.Structure):
         ('indep_prior', c_double_p), ('lik', c_double_p),
         ('n_ops', C.c_int32),
         ('ops', C.POINTER(Op)),
+        ('resume_time', C.c_double), ('carry_slot', C.c_int32), ('reserved0', C.c_int32),
     ]
 
 
@@ -83,6 +84,9 @@ PROTOTYPES = {
     'blhip_accum_finalize': (C.c_int, [C.c_void_p, C.POINTER(Problem), c_double_p]),
     'blhip_accum_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
     'blhip_accum_end': (C.c_int, [C.c_void_p]),
+    'blhip_carry_mix': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, C.c_int]),
+    'blhip_carry_read': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p]),
+    'blhip_carry_release': (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

@@ -846,3 +846,389 @@ class ChangepointStudy(HyperStudy):
 
     def getDD(self, names, plot=False, **kwargs):
         return self.getDurationDistribution(names, plot=plot, **kwargs)
+
+
+class OnlineStudy(HyperStudy):
+    """Model selection on a data stream (reference core.py:1963-2226): ``step(dataPoint)`` advances the forward filter of
+    EVERY (transition model, hyper-parameter value) pair by one data point and re-weights them with their evidence.
+
+    On the GPU each pair is a chain whose filtered distribution stays on the device between calls ("carried state",
+    include/blhip.h BLHIP_CARRY / BLHIP_RESUME): a step is one fused forward-step launch per transition model over all of
+    its hyper-parameter values, and the evidence-weighted mixtures the study exposes (``marginalizedPosterior``,
+    ``transitionModelPosterior``) are reduced on the device.  The host keeps the reference's evidence bookkeeping
+    (core.py:2169-2214) on the handful of per-chain scalars.
+    """
+    _slot_counter = [0]
+
+    def __init__(self, storeHistory=False, silent=False):
+        super(OnlineStudy, self).__init__(silent=silent)
+        self.firstStep = True
+        self.transitionModels = []
+        self.transitionModelNames = []
+        self.tmCount = None
+        self.tmCounts = []
+        self.hyperParameterValues = []
+        self.allFlatHyperParameterValues = []
+        self.hyperParameterNames = []
+        self.hyperGridConstants = []
+        self.logEvidenceList = None
+        self.hyperLogEvidenceList = None
+        self.hyperPrior = []
+        self.hyperPriorValues = []
+        self.transitionModelPrior = None
+        self.marginalizedPosterior = None
+        self.hyperParameterDistribution = None
+        self.transitionModelDistribution = None
+        self.localTransitionModelDistribution = None
+        self.storeHistory = storeHistory
+        self.posteriorMeanValues = []
+        self._posteriorSequence = []
+        self.hyperParameterSequence = []
+        self.transitionModelSequence = []
+        self.localTransitionModelSequence = []
+        self._slots = []            # carry slot of every transition model in the engine's context
+        self._device = []           # per transition model: (ops, op_values, reset prior, indep prior)
+        if not silent:
+            print('  --> Online study')
+
+    # the history is a plain list of host arrays (the reference appends a copy per step, core.py:2219)
+    @property
+    def posteriorSequence(self):
+        return self._posteriorSequence
+
+    @posteriorSequence.setter
+    def posteriorSequence(self, value):
+        self._posteriorSequence = value
+
+    def __del__(self):
+        try:
+            eng = _engine_mod.get_engine()
+            for s in self._slots:
+                eng.carry_release(s)
+        except Exception:
+            pass
+
+    # ---- configuration (reference core.py:2007-2060) -------------------------------------------------------------------
+    def addTransitionModel(self, name, transitionModel):
+        self.setTransitionModel(transitionModel, silent=True)
+        self._createHyperGrid(silent=True)
+        self.transitionModels.append(transitionModel)
+        self.transitionModelNames.append(name)
+        self.hyperParameterValues.append(self.hyperGridValues[:])
+        self.allFlatHyperParameterValues.append(self.flatHyperParameters)
+        self.hyperParameterNames.append(self.flatHyperParameterNames[:])
+        self.hyperGridConstants.append(self.hyperGridConstant[:])
+        self.hyperPrior.append(self.flatHyperPriors[:])
+        self.hyperPriorValues.append(self.flatHyperPriorValues[:])
+        self.tmCounts = [len(hpv) if len(hpv) > 0 else 1 for hpv in self.hyperParameterValues]
+        self.tmCount = int(np.sum(self.tmCounts))
+        if len(self.hyperGridValues) > 0:
+            print('+ Added transition model: {} ({} combination(s) of the following hyper-parameters: {})'
+                  .format(name, len(self.hyperGridValues), self.hyperParameterNames[-1]))
+        else:
+            print('+ Added transition model: {} (no hyper-parameters)'.format(name))
+
+    def addTM(self, name, transitionModel):
+        self.addTransitionModel(name, transitionModel)
+
+    def add(self, name, transitionModel):
+        self.addTransitionModel(name, transitionModel)
+
+    def setTransitionModelPrior(self, transitionModelPrior, silent=False):
+        if not (isinstance(transitionModelPrior, Iterable) and len(transitionModelPrior) == len(self.transitionModels)):
+            raise ConfigurationError('Length of transition model prior ({}) does not fit number of transition models '
+                                     '({})'.format(len(transitionModelPrior), len(self.transitionModels)))
+        self.transitionModelPrior = np.array(transitionModelPrior, dtype=float)
+        if not np.sum(transitionModelPrior) == 1.:
+            print('+ WARNING: Transition model prior does not sum up to one. Will re-normalize.')
+            self.transitionModelPrior /= np.sum(self.transitionModelPrior)
+        if not silent:
+            print('+ Set custom transition model prior.')
+
+    def fit(self, *args, **kwargs):
+        raise NotImplementedError('OnlineStudy object has no "fit" method. Use "step" instead.')
+
+    # ---- one data point (reference core.py:2062-2226) -------------------------------------------------------------------
+    def _compileModels(self):
+        """Per transition model: its flat program and the op-aligned hyper-parameter values of all of its chains."""
+        om = self.observationModel
+        self._device = []
+        for tm, hpv in zip(self.transitionModels, self.hyperParameterValues):
+            self.setTransitionModel(tm, silent=True)
+            program = tm._program(om.parameterNames)
+            slots = self._hyperSlots()
+            n = max(1, len(hpv))
+            op_values = np.full((n, max(1, len(program))), np.nan)
+            if len(hpv) > 0:
+                hv = np.asarray(hpv, dtype=float)
+                for j, (kind, axis, model, k, seg, flg) in enumerate(program):
+                    if k is not None:
+                        c = [i for i, s in enumerate(slots) if s[0] is model and s[1] == k][0]
+                        op_values[:, j] = hv[:, c]
+            reset = self._changepointPrior() if any(op[0] == _abi.OP_CHANGEPOINT for op in program) else None
+            indep = None
+            if any(op[0] == _abi.OP_INDEPENDENT for op in program):
+                indep = self._changepointPrior() / np.prod(self.latticeConstant)
+            self._device.append(([(op[0], op[1], op[4], op[5]) for op in program], op_values, reset, indep))
+            OnlineStudy._slot_counter[0] += 1
+            self._slots.append(OnlineStudy._slot_counter[0])
+
+    def step(self, dataPoint):
+        """Update every chain with a new data point (float, int, or 1-D array for multi-dimensional data)."""
+        if (self.tmCount is None) and (self.transitionModel is None):
+            raise ConfigurationError('No transition model set or added.')
+        if (self.tmCount is None) and (self.transitionModel is not None):
+            self.addTransitionModel('transition model', self.transitionModel)
+        if not isinstance(dataPoint, list):
+            dataPoint = [dataPoint]
+
+        if len(self.rawData) == 0:
+            print('+ Start model fit')
+            allNames = list(flatten(self.hyperParameterNames))
+            if len(allNames) != len(np.unique(allNames)):
+                raise ConfigurationError('Detected duplicate hyper-parameter names. Choose unique identifiers.')
+            self.rawData = np.array(dataPoint)
+            Study._checkConsistency(self)
+            self.rawTimestamps = np.array([0])
+            self.formattedTimestamps = []
+        else:
+            self.rawData = np.append(self.rawData, np.array(dataPoint), axis=0)
+            self.rawTimestamps = np.append(self.rawTimestamps, self.rawTimestamps[-1] + 1)
+
+        om = self.observationModel
+        if len(self.rawData) < om.segmentLength:
+            print('+ Not enough data points to start analysis. Will wait for more data.')
+            return
+        self.formattedTimestamps.append(self.rawTimestamps[-1])
+        eng = _engine_mod.get_engine()
+        nTM = len(self.transitionModels)
+
+        if self.firstStep:
+            if len(self.gridSize) not in (1, 2):
+                raise ConfigurationError('The MI355X engine supports observation models with 1 or 2 parameters '
+                                         '(got {}).'.format(len(self.gridSize)))
+            self._prior = self._computePrior(silent=False)
+            if self.transitionModelPrior is None:
+                self.transitionModelPrior = np.ones(nTM) / nTM
+                if nTM > 1:
+                    print('    + Set flat transition model prior.')
+            dV = np.prod(self.latticeConstant)
+            self.logEvidenceList = [np.zeros(tmc) + np.log(dV) for tmc in self.tmCounts]
+            self.hyperLogEvidenceList = np.array([0. for tmc in self.tmCounts])
+            self.hyperParameterDistribution = [np.zeros(tmc) for tmc in self.tmCounts]
+            self.transitionModelDistribution = np.zeros(nTM)
+            self.localTransitionModelDistribution = np.zeros(nTM)
+            self._compileModels()
+
+        # the current data segment as a one-step problem; the likelihood is evaluated ONCE for all chains (core.py:2146):
+        # in-kernel for the closed-form device models, on the host through the model's own pdf otherwise
+        segment = self.rawData[-om.segmentLength:]
+        data = np.asarray([segment], dtype=float)
+        code = getattr(om, 'device_model', _abi.OM_TABLE)
+        lik = None
+        if code == _abi.OM_TABLE or om.segmentLength != 1:
+            code = _abi.OM_TABLE
+            lik = np.array([np.asarray(om.processedPdf(self.grid, segment), dtype=float) * np.ones(self.gridSize)])
+        dV = np.prod(self.latticeConstant)
+
+        for i, (ops, op_values, reset, indep) in enumerate(self._device):
+            problem = FitProblem(obs_model=code, marginal=self.marginalGrid, lattice=self.latticeConstant, data=data,
+                                 timestamps=np.asarray([self.rawTimestamps[-1]], dtype=float), prior=self._prior, ops=ops,
+                                 reset_prior=reset, indep_prior=indep, lik=lik, seg_len=om.segmentLength,
+                                 resume_time=-1.0,      # the reference evaluates transitions at len(formattedData) - 1 = -1
+                                 carry_slot=self._slots[i])
+            res = eng.fit(problem, op_values, evidence_only=True, resume=not self.firstStep, carry=True)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                ni = res.local_evidence[:, 0] / dV                                               # core.py:2167
+                self.logEvidenceList[i] = self.logEvidenceList[i] + np.log(ni)                   # :2170
+                hpd = self.logEvidenceList[i] + np.log(self.hyperPriorValues[i])                 # :2171
+                old = self.hyperLogEvidenceList[i]
+                x = self.logEvidenceList[i] + np.log(self.hyperPriorValues[i])
+                m = np.amax(x)
+                self.hyperLogEvidenceList[i] = m + np.log(np.sum(np.exp(x - m)))                 # :2178 logsumexp
+                self.transitionModelDistribution[i] = self.hyperLogEvidenceList[i]               # :2179
+                self.localTransitionModelDistribution[i] = self.hyperLogEvidenceList[i] - old + \
+                    np.log(self.transitionModelPrior[i])                                         # :2180-2181
+                hpd = np.exp(hpd - np.amax(hpd))                                                 # :2184-2186
+                hpd /= np.sum(hpd)
+                if len(self.hyperGridConstants[i]) > 0:
+                    hpd /= np.prod(self.hyperGridConstants[i])                                   # :2187-2188
+            self.hyperParameterDistribution[i] = hpd
+
+        with np.errstate(divide='ignore', invalid='ignore'):
+            tmd = self.transitionModelDistribution
+            tmd = np.exp(tmd - np.amax(tmd)); tmd /= np.sum(tmd)                                 # :2199-2201
+            self.transitionModelDistribution = tmd
+            ltd = self.localTransitionModelDistribution
+            ltd = np.exp(ltd - np.amax(ltd)); ltd /= np.sum(ltd)                                 # :2203-2205
+            self.localTransitionModelDistribution = ltd
+            x = self.hyperLogEvidenceList + np.log(self.transitionModelPrior)
+            m = np.amax(x)
+            self.logEvidence = float(m + np.log(np.sum(np.exp(x - m))))                          # :2214
+
+        # marginalised posterior = sum_i tmd_i sum_j hpd_ij prod(dh_i) posterior_ij, reduced on the device (:2194-2211)
+        for i in range(nTM):
+            w = self.hyperParameterDistribution[i] * np.prod(self.hyperGridConstants[i]) * self.transitionModelDistribution[i]
+            eng.carry_mix(self._slots[i], w, accumulate=i > 0)
+        self.marginalizedPosterior = eng.carry_read(0, -1, self.gridSize)
+
+        if self.storeHistory:
+            self.posteriorMeanValues.append(np.array([np.sum(self.marginalizedPosterior * g) for g in self.grid]))
+            self.posteriorSequence.append(self.marginalizedPosterior.copy())
+            self.hyperParameterSequence.append([h.copy() for h in self.hyperParameterDistribution])
+            self.transitionModelSequence.append(self.transitionModelDistribution.copy())
+            self.localTransitionModelSequence.append(self.localTransitionModelDistribution.copy())
+        if self.firstStep:
+            self.firstStep = False
+
+    # ---- device-resident per-chain results, fetched on demand -----------------------------------------------------------
+    @property
+    def parameterPosterior(self):
+        """[transition model][hyper-parameter value] filtered distributions (core.py:2173), copied from the device."""
+        if self.firstStep:
+            return None
+        eng = _engine_mod.get_engine()
+        return [np.array([eng.carry_read(s, j, self.gridSize) for j in range(c)]) for s, c in zip(self._slots, self.tmCounts)]
+
+    @property
+    def transitionModelPosterior(self):
+        """Per transition model: posterior marginalised over its hyper-parameters (core.py:2190-2196)."""
+        if self.firstStep:
+            return None
+        eng = _engine_mod.get_engine()
+        out = []
+        for i, s in enumerate(self._slots):
+            eng.carry_mix(s, self.hyperParameterDistribution[i] * np.prod(self.hyperGridConstants[i]), accumulate=False)
+            out.append(eng.carry_read(0, -1, self.gridSize))
+        return np.array(out)
+
+    # ---- accessors (reference core.py:2231-2835; plotting is not part of this build) ------------------------------------
+    def _needHistory(self, what, alt):
+        if not self.storeHistory:
+            raise PostProcessingError('To get past {}, Online Study must be called with flag "storeHistory=True". '
+                                      'Use "{}" instead.'.format(what, alt))
+
+    def getParameterDistribution(self, t, name, plot=False, density=True, **kwargs):
+        self._needHistory('parameter distributions', 'getCurrentParameterDistribution')
+        k = self._parameterIndex(name)
+        if t not in self.formattedTimestamps:
+            raise PostProcessingError('Supplied time ({}) does not exist in data or is out of range.'.format(t))
+        dist = self.posteriorSequence[list(self.formattedTimestamps).index(t)]
+        axes = tuple(a for a in range(len(self.gridSize)) if a != k)
+        marginal = np.sum(dist, axis=axes) if axes else np.array(dist)
+        return self.marginalGrid[k], marginal / self.latticeConstant[k] if density else marginal
+
+    def getCurrentParameterDistribution(self, name, plot=False, density=True, **kwargs):
+        k = self._parameterIndex(name)
+        axes = tuple(a for a in range(len(self.gridSize)) if a != k)
+        marginal = np.sum(self.marginalizedPosterior, axis=axes) if axes else np.array(self.marginalizedPosterior)
+        return self.marginalGrid[k], marginal / self.latticeConstant[k] if density else marginal
+
+    def getCPD(self, name, plot=False, density=True, **kwargs):
+        return self.getCurrentParameterDistribution(name, plot=plot, density=density, **kwargs)
+
+    def getParameterDistributions(self, name, plot=False, density=True, **kwargs):
+        self._needHistory('parameter distributions', 'getCurrentParameterDistribution')
+        k = self._parameterIndex(name)
+        post = np.array(self.posteriorSequence)
+        axes = tuple(a + 1 for a in range(len(self.gridSize)) if a != k)
+        marginal = np.sum(post, axis=axes) if axes else post
+        return self.marginalGrid[k], marginal / self.latticeConstant[k] if density else marginal
+
+    def getCurrentTransitionModelDistribution(self, local=False):
+        d = self.localTransitionModelDistribution if local else self.transitionModelDistribution
+        return np.array(self.transitionModelNames), d
+
+    def getCTMD(self, local=False):
+        return self.getCurrentTransitionModelDistribution(local=local)
+
+    def getCurrentTransitionModelProbability(self, transitionModel, local=False):
+        return self.getCurrentTransitionModelDistribution(local=local)[1][self.transitionModelNames.index(transitionModel)]
+
+    def getCTMP(self, transitionModel, local=False):
+        return self.getCurrentTransitionModelProbability(transitionModel, local=local)
+
+    def getTransitionModelDistributions(self, local=False):
+        self._needHistory('transition model distributions', 'getCurrentTransitionModelDistribution')
+        seq = self.localTransitionModelSequence if local else self.transitionModelSequence
+        return np.array(self.transitionModelNames), np.array(seq)
+
+    def getTransitionModelProbabilities(self, transitionModel, local=False):
+        return self.getTransitionModelDistributions(local=local)[1][:, self.transitionModelNames.index(transitionModel)]
+
+    def getTMPs(self, transitionModel, local=False):
+        return self.getTransitionModelProbabilities(transitionModel, local=local)
+
+    def getCurrentParameterMeanValue(self, name):
+        return np.sum(self.marginalizedPosterior * self.grid[self._parameterIndex(name)])
+
+    def getParameterMeanValue(self, t, name):
+        self._needHistory('parameter mean values', 'getCurrentParameterMeanValue')
+        k = self._parameterIndex(name)
+        if t not in self.formattedTimestamps:
+            raise PostProcessingError('Supplied time ({}) does not exist in data or is out of range.'.format(t))
+        return self.posteriorMeanValues[list(self.formattedTimestamps).index(t)][k]
+
+    def getParameterMeanValues(self, name):
+        self._needHistory('parameter mean values', 'getCurrentParameterMeanValue')
+        return np.array(self.posteriorMeanValues).T[self._parameterIndex(name)]
+
+    def _findHyperParameter(self, name):
+        for i, tm in enumerate(self.transitionModels):
+            if name in self.hyperParameterNames[i]:
+                return i, list(self.hyperParameterNames[i]).index(name)
+        raise PostProcessingError('No hyper-parameter "{}" found. Check hyper-parameter names.'.format(name))
+
+    def getHyperParameterMeanValue(self, t, name):
+        self._needHistory('hyper-parameter mean values', 'getCurrentHyperParameterMeanValue')
+        i, k = self._findHyperParameter(name)
+        if t not in self.formattedTimestamps:
+            raise PostProcessingError('Supplied time ({}) does not exist in data or is out of range.'.format(t))
+        h = self.hyperParameterSequence[list(self.formattedTimestamps).index(t)][i][:, None]
+        return np.sum(self.hyperParameterValues[i] * h * np.prod(self.hyperGridConstants[i]), axis=0)[k]
+
+    def getHyperParameterMeanValues(self, name):
+        self._needHistory('hyper-parameter mean values', 'getCurrentHyperParameterMeanValue')
+        i, k = self._findHyperParameter(name)
+        seq = np.array([hp[i].tolist() for hp in self.hyperParameterSequence])[:, :, None]
+        return np.sum(seq * self.hyperParameterValues[i] * np.prod(self.hyperGridConstants[i]), axis=1).T[k]
+
+    def _marginalHyper(self, i, k, distribution):
+        steps = [len(x) for x in self.allFlatHyperParameterValues[i]]
+        d = np.asarray(distribution).reshape(steps, order='C')
+        axes = tuple(a for a in range(len(steps)) if a != k)
+        return np.sum(d, axis=axes) if axes else d
+
+    def getHyperParameterDistribution(self, t, name, plot=False, **kwargs):
+        self._needHistory('hyper-parameter distributions', 'getCurrentHyperParameterDistribution')
+        i, k = self._findHyperParameter(name)
+        if isinstance(t, str) and t == 'avg':
+            h = np.sum([hp[i] for hp in self.hyperParameterSequence], axis=0) / len(self.hyperParameterSequence)
+        else:
+            if t not in self.formattedTimestamps:
+                raise PostProcessingError('Supplied time ({}) does not exist in data or is out of range.'.format(t))
+            h = self.hyperParameterSequence[list(self.formattedTimestamps).index(t)][i]
+        return self.allFlatHyperParameterValues[i][k], self._marginalHyper(i, k, h)
+
+    def getHPD(self, t, name, plot=False, **kwargs):
+        return self.getHyperParameterDistribution(t, name, plot=plot, **kwargs)
+
+    def getCurrentHyperParameterDistribution(self, name, plot=False, **kwargs):
+        i, k = self._findHyperParameter(name)
+        m = self._marginalHyper(i, k, self.hyperParameterDistribution[i]) * np.prod(self.hyperGridConstants[i])
+        return self.allFlatHyperParameterValues[i][k], m
+
+    def getCHPD(self, name, plot=False, **kwargs):
+        return self.getCurrentHyperParameterDistribution(name, plot=plot, **kwargs)
+
+    def getHyperParameterDistributions(self, name):
+        self._needHistory('hyper-parameter distributions', 'getCurrentHyperParameterDistributions')
+        i, k = self._findHyperParameter(name)
+        seq = np.array([x[i] for x in self.hyperParameterSequence])
+        values = np.array(self.hyperParameterValues[i])[:, k]
+        unique = np.sort(np.unique(values))
+        m = np.array([[np.sum(hp[values == v]) for hp in seq] for v in unique]).T
+        return unique, m / np.sum(m, axis=1)[:, None]
+
+    def getHPDs(self, name):
+        return self.getHyperParameterDistributions(name)

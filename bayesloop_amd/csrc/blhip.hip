@@ -90,6 +90,11 @@ struct blhip_ctx {
     int64_t acc_T = 0, acc_G = 0, acc_folded = 0;
     double acc_logref = -std::numeric_limits<double>::infinity();
     blhip_timing timing = {};
+    // carried states of streaming fits (BLHIP_CARRY / BLHIP_RESUME): slot -> (chains, G) normalised distributions
+    struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; };
+    std::map<int, Carry> carry;
+    DevBuf mix, unit;
+    int64_t mix_G = 0;
 
     double option(const char *k, double dflt) const {
         auto it = opt.find(k);
@@ -479,7 +484,7 @@ struct StepProg {
 };
 
 void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_t B, const double *op_values,
-                   TapTable &taps, ChainProgram &prog) {
+                   TapTable &taps, ChainProgram &prog, bool resume) {
     const int64_t T = p->T;
     const int nops = p->n_ops;
     const size_t nT = (size_t)T * B;
@@ -565,6 +570,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
             // forward step t consumes T_fwd(post_{t-1}, ts[t-1])   core.py:411
             StepProg f; f.kind = SRC_PRIOR;
             if (t > 0) f = time_dependent ? run(p->timestamps[t - 1], true) : stat;
+            else if (resume) f = run(p->resume_time, true);   // continues a carried state (OnlineStudy.step, core.py:2164-2165)
             // backward step t consumes T_bwd(beta_{t+1} L_{t+1}, ts[t+1]) = T_fwd(., ts[t+1] - 1)   core.py:467, transitionModels.py:316-317
             StepProg r; r.kind = SRC_UNIFORM;
             if (t < T - 1) r = time_dependent ? run(p->timestamps[t + 1] - 1.0, true) : stat;
@@ -592,6 +598,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
     const bool full = !evidence_only && !forward_only;
     const bool keep = (flags & BLHIP_KEEP_POSTERIOR) && !evidence_only;
     const bool accumulate = (flags & BLHIP_ACCUMULATE) && !evidence_only;
+    const bool resume = flags & BLHIP_RESUME, carry = flags & BLHIP_CARRY;
+    if (resume || carry) {
+        if (full) fail("BLHIP_RESUME / BLHIP_CARRY need a forward-only or evidence-only fit");
+        if (p->carry_slot < 0) fail("carry_slot must be >= 0");
+    }
     if (accumulate && !ctx->acc_active) fail("BLHIP_ACCUMULATE without blhip_accum_begin");
     if (accumulate && !log_w) fail("BLHIP_ACCUMULATE needs log_chain_weight");
     const int64_t T = p->T;
@@ -668,6 +679,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
     Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024));
     Bmax = std::min<int64_t>(Bmax, 65535);
     if (keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
+    if ((resume || carry) && n_chains > Bmax) fail("carried states: %lld chains do not fit in one batch", (long long)n_chains);
+    if (resume) {
+        auto it = ctx->carry.find(p->carry_slot);
+        if (it == ctx->carry.end() || !it->second.valid) fail("BLHIP_RESUME: carry slot %d holds no state", p->carry_slot);
+        if (it->second.chains != n_chains || it->second.G != G)
+            fail("BLHIP_RESUME: carry slot %d holds %lld chains x %lld cells, the call has %lld x %lld", p->carry_slot,
+                 (long long)it->second.chains, (long long)it->second.G, (long long)n_chains, (long long)G);
+    }
     const int64_t nbatch = (n_chains + Bmax - 1) / Bmax;
     const int64_t Bcap = (n_chains + nbatch - 1) / nbatch;
     ctx->timing.batches = nbatch;
@@ -680,13 +699,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         const int64_t B = std::min(Bcap, n_chains - c0);
         TapTable taps;
         ChainProgram prog;
-        build_program(p, g, c0, B, op_values, taps, prog);
+        build_program(p, g, c0, B, op_values, taps, prog, resume);
         // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
         const bool fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
                           ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
                           g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
         const size_t p1_lds = ((size_t)2 * (g.n1 + 2 * prog.LW1) + 64 + prog.LW1 + 2) * sizeof(double);
-        const bool persist = p->ndim == 1 && !fast && !prog.has_clamp && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
+        const bool persist = p->ndim == 1 && !fast && !prog.has_clamp && !resume && !carry && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
                              prog.LW1 <= g.n1 && p1_lds <= 150 * 1024 &&
                              (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
                               p->obs_model == BLHIP_OM_TABLE);
@@ -834,6 +853,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             d_post = ctx->post.as<double>();
         }
 
+        // BLHIP_RESUME: step 0 reads each chain's carried (normalised) state; its "previous partial sums" add up to 1
+        const double *d_carry_src = nullptr, *d_unit = nullptr;
+        if (resume) {
+            d_carry_src = ctx->carry[p->carry_slot].buf.as<double>();
+            std::vector<double> unit((size_t)B * NRED * tile.nblk, 0.0);
+            for (int64_t b = 0; b < B; ++b)
+                for (int k = 0; k < NRED; ++k) unit[((size_t)b * NRED + k) * tile.nblk] = 1.0;
+            ctx->unit.ensure(unit.size() * 8);
+            HIPCHECK(hipMemcpyAsync(ctx->unit.p, unit.data(), unit.size() * 8, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            d_unit = ctx->unit.as<double>();
+        }
         StepParams P{};
         P.n0 = g.n0; P.n1 = g.n1; P.TI = tile.TI; P.TJ = tile.TJ; P.LW0 = tile.LW0; P.LW1 = tile.LW1;
         P.tiles_i = tile.tiles_i; P.tiles_j = tile.tiles_j; P.nblk = tile.nblk; P.ndim = p->ndim; P.d = d;
@@ -964,7 +995,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 bl1f::F1Params Q = F1;
                 Q.K = (int)std::min<int64_t>(K, T - t); Q.dir = 1; Q.t_first = (int)t;
                 Q.srckind = d_kindF; Q.tap = d_tapF1; Q.psum = d_psF; Q.prev_slot = 0;
-                Q.psum_prev = t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : nullptr;
+                Q.psum_prev = t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : d_unit;
                 Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0;
                 const int64_t tl = t + Q.K - 1;              // last step of this launch
                 if (evidence_only) {
@@ -974,6 +1005,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                     Q.src = d_post + (t > 0 ? (size_t)(t - 1) * G : 0); Q.src_stride = (long long)T * G;
                 }
                 (void)tl;
+                if (t == 0 && resume) { Q.src = d_carry_src; Q.src_stride = G; }
                 launch_fused1d(st, p->obs_model, Q, false, f1_lds(Q.K));
             }
         }
@@ -987,8 +1019,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
                 srcp = d_post + (t > 0 ? (size_t)(t - 1) * G : 0); sstr = (long long)T * G;
                 dstp = d_post + (size_t)t * G; dstr = (long long)T * G;
             }
+            if (t == 0 && resume) { srcp = d_carry_src; sstr = G; }
             run_step(MODE_FWD, t, srcp, sstr, dstp, dstr, nullptr, 0,
-                     t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : d_psF, 0,
+                     t > 0 ? d_psF + (size_t)(t - 1) * B * NRED * tile.nblk : (resume ? d_unit : d_psF), 0,
                      d_psF + (size_t)t * B * NRED * tile.nblk, forward_only);
         }
         join_streams();
@@ -1106,7 +1139,24 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
 
         return raw_ok || K == 1;
         };
-        if (!passes(fusedK)) passes(1);
+        int64_t usedK = fusedK;
+        if (!passes(fusedK)) { usedK = 1; passes(1); }
+
+        // --- BLHIP_CARRY: keep every chain's filtered distribution of the last step, normalised (core.py:2173) ---
+        if (carry) {
+            blhip_ctx::Carry &cs = ctx->carry[p->carry_slot];
+            cs.buf.ensure((size_t)B * G * 8);
+            std::vector<double> inv(B);
+            for (int64_t b = 0; b < B; ++b) inv[b] = 1.0 / redF[((size_t)(T - 1) * B + b) * NRED];
+            HIPCHECK(hipMemcpyAsync(d_w, inv.data(), B * 8, hipMemcpyHostToDevice, st));
+            const double *fin; long long fstr;
+            if (!evidence_only) { fin = d_post + (size_t)(T - 1) * G; fstr = (long long)T * G; }
+            else { fin = fused1d ? d_pp[((T - 1) / usedK) & 1] : d_pp[(T - 1) & 1]; fstr = G; }
+            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+            hipLaunchKernelGGL(carry_store_kernel, dim3(gx, (unsigned)B), dim3(NTHREADS), 0, st, cs.buf.as<double>(), fin, fstr, G, d_w);
+            HIPCHECK(hipStreamSynchronize(st));
+            cs.chains = B; cs.G = G; cs.valid = true;
+        }
 
         // --- fold into the average posterior (core.py:1358-1366) ---
         if (accumulate) {
@@ -1241,8 +1291,9 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
-                      &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats})
+                      &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit})
         b->release();
+    for (auto &kv : ctx->carry) kv.second.buf.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &bs : ctx->bstream)
@@ -1368,6 +1419,60 @@ int blhip_posterior_time_average(blhip_ctx *ctx, int source, int64_t chain, doub
                            dim3(NTHREADS), 0, st, v.p, d_out, G, (int)v.T);
         HIPCHECK(hipMemcpyAsync(host_out, d_out, (size_t)G * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
+    });
+}
+
+int blhip_carry_mix(blhip_ctx *ctx, int slot, int64_t n_chains, const double *weights, int accumulate) {
+    return guarded(ctx, [&] {
+        if (!weights) fail("weights is NULL");
+        HIPCHECK(hipSetDevice(ctx->device));
+        auto it = ctx->carry.find(slot);
+        if (it == ctx->carry.end() || !it->second.valid) fail("blhip_carry_mix: carry slot %d holds no state", slot);
+        blhip_ctx::Carry &cs = it->second;
+        if (cs.chains != n_chains) fail("blhip_carry_mix: slot %d holds %lld chains, got %lld weights", slot, (long long)cs.chains, (long long)n_chains);
+        if (accumulate && ctx->mix_G != cs.G) fail("blhip_carry_mix: accumulating %lld cells into a mix of %lld", (long long)cs.G, (long long)ctx->mix_G);
+        hipStream_t st = ctx->stream;
+        ctx->mix.ensure((size_t)cs.G * 8);
+        ctx->mix_G = cs.G;
+        ctx->small.ensure((size_t)n_chains * 8);
+        HIPCHECK(hipMemcpyAsync(ctx->small.p, weights, (size_t)n_chains * 8, hipMemcpyHostToDevice, st));
+        const unsigned gx = (unsigned)std::min<long long>((cs.G + NTHREADS - 1) / NTHREADS, 8192);
+        hipLaunchKernelGGL(carry_mix_kernel, dim3(gx), dim3(NTHREADS), 0, st, ctx->mix.as<double>(), cs.buf.as<double>(),
+                           (long long)cs.G, (int)n_chains, ctx->small.as<double>(), accumulate ? 1 : 0);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(st));
+    });
+}
+
+int blhip_carry_read(blhip_ctx *ctx, int slot, int64_t chain, double *host_out) {
+    return guarded(ctx, [&] {
+        if (!host_out) fail("host_out is NULL");
+        HIPCHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        if (chain < 0) {
+            if (ctx->mix_G <= 0) fail("blhip_carry_read: no mix computed");
+            HIPCHECK(hipMemcpyAsync(host_out, ctx->mix.p, (size_t)ctx->mix_G * 8, hipMemcpyDeviceToHost, st));
+        } else {
+            auto it = ctx->carry.find(slot);
+            if (it == ctx->carry.end() || !it->second.valid) fail("blhip_carry_read: carry slot %d holds no state", slot);
+            if (chain >= it->second.chains) fail("blhip_carry_read: chain %lld of %lld", (long long)chain, (long long)it->second.chains);
+            HIPCHECK(hipMemcpyAsync(host_out, it->second.buf.as<double>() + (size_t)chain * it->second.G, (size_t)it->second.G * 8,
+                                    hipMemcpyDeviceToHost, st));
+        }
+        HIPCHECK(hipStreamSynchronize(st));
+    });
+}
+
+int blhip_carry_release(blhip_ctx *ctx, int slot) {
+    return guarded(ctx, [&] {
+        HIPCHECK(hipSetDevice(ctx->device));
+        if (slot < 0) {
+            for (auto &kv : ctx->carry) kv.second.buf.release();
+            ctx->carry.clear(); ctx->mix.release(); ctx->mix_G = 0;
+        } else {
+            auto it = ctx->carry.find(slot);
+            if (it != ctx->carry.end()) { it->second.buf.release(); ctx->carry.erase(it); }
+        }
     });
 }
 

@@ -308,6 +308,25 @@ __global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double 
     if (threadIdx.x == 0) out[k] = s;
 }
 
+// dst[b][c] = src[b * stride + c] * inv[b]   (BLHIP_CARRY: the filtered distribution of the last step, normalised)
+__global__ __launch_bounds__(NTHREADS) void carry_store_kernel(double *dst, const double *src, long long stride, long long G,
+                                                               const double *inv) {
+    const long long b = blockIdx.y;
+    const double s = inv[b];
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS)
+        dst[b * G + c] = src[b * stride + c] * s;
+}
+
+// mix[c] = (accumulate ? mix[c] : 0) + sum_b w[b] * states[b][c]   (OnlineStudy: core.py:2196-2212)
+__global__ __launch_bounds__(NTHREADS) void carry_mix_kernel(double *mix, const double *states, long long G, int B, const double *w,
+                                                             int accumulate) {
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
+        double s = accumulate ? mix[c] : 0.0;
+        for (int b = 0; b < B; ++b) s = fma(w[b], states[(long long)b * G + c], s);
+        mix[c] = s;
+    }
+}
+
 // rows[t][cell] *= inv[t]   (normalisation of stored posteriors, core.py:389 / :441 applied lazily)
 __global__ __launch_bounds__(NTHREADS) void scale_rows_kernel(double *rows, long long G, const double *inv) {
     const long long t = blockIdx.y;

@@ -33,6 +33,8 @@ class FitProblem:
     indep_prior: Optional[np.ndarray] = None    # what Independent restarts from (transitionModels.py:351-360)
     lik: Optional[np.ndarray] = None    # (T, G) host-evaluated likelihood for OM_TABLE
     seg_len: int = 1
+    resume_time: float = -1.0           # BLHIP_RESUME: time stamp the transition into step 0 is evaluated at
+    carry_slot: int = 0                 # which carried state of the context (OnlineStudy: one per transition model)
 
     @property
     def grid_size(self):
@@ -176,10 +178,12 @@ class HipEngine:
         keep.append(ops)
         cp.n_ops = len(p.ops)
         cp.ops = ops
+        cp.resume_time = float(p.resume_time)
+        cp.carry_slot = int(p.carry_slot)
         return cp, keep
 
     def fit(self, problem: FitProblem, op_values, forward_only=False, evidence_only=False, keep_posterior=False,
-            accumulate=False, log_chain_weight=None, owner=None) -> FitResult:
+            accumulate=False, log_chain_weight=None, owner=None, resume=False, carry=False) -> FitResult:
         """n_chains = len(op_values) independent passes (Study.fit per hyper-grid point)."""
         prev = self._posterior_owner() if self._posterior_owner is not None else None
         if prev is not None and prev is not owner:
@@ -201,13 +205,29 @@ class HipEngine:
         res.abort_step = astep.ctypes.data_as(C.POINTER(C.c_int64))
         res.abort_phase = aphase.ctypes.data_as(C.POINTER(C.c_int32))
         flags = (_abi.FORWARD_ONLY if forward_only else 0) | (_abi.EVIDENCE_ONLY if evidence_only else 0) | \
-                (_abi.KEEP_POSTERIOR if keep_posterior else 0) | (_abi.ACCUMULATE if accumulate else 0)
+                (_abi.KEEP_POSTERIOR if keep_posterior else 0) | (_abi.ACCUMULATE if accumulate else 0) | \
+                (_abi.RESUME if resume else 0) | (_abi.CARRY if carry else 0)
         lw = None if log_chain_weight is None else _f64(log_chain_weight)
         self._check(self.lib.blhip_fit(self.ctx, C.byref(cp), n, _abi.dptr(ov), _abi.dptr(lw), flags, C.byref(res)))
         del keep
         if keep_posterior and not evidence_only:
             self._posterior_owner = None if owner is None else weakref.ref(owner)
         return FitResult(logE, local, means, astep, aphase, self.last_timing())
+
+    # ---- carried states of streaming fits (OnlineStudy.step) -------------------------------------------------------
+    def carry_mix(self, slot, weights, accumulate=False):
+        """mix = (accumulate ? mix : 0) + sum_j weights[j] * carried state j of `slot` (stays on the device)."""
+        w = _f64(weights)
+        self._check(self.lib.blhip_carry_mix(self.ctx, int(slot), len(w), _abi.dptr(w), 1 if accumulate else 0))
+
+    def carry_read(self, slot, chain, grid_size):
+        """One chain's carried distribution (chain >= 0) or the mix buffer (chain = -1) as an array of `grid_size`."""
+        out = np.empty(list(grid_size))
+        self._check(self.lib.blhip_carry_read(self.ctx, int(slot), int(chain), _abi.dptr(out)))
+        return out
+
+    def carry_release(self, slot=-1):
+        self._check(self.lib.blhip_carry_release(self.ctx, int(slot)))
 
     def last_timing(self):
         t = _abi.Timing()

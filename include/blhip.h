@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BLHIP_ABI_VERSION 2
+#define BLHIP_ABI_VERSION 3
 
 typedef struct blhip_ctx blhip_ctx;
 
@@ -87,6 +87,11 @@ typedef struct {
     const double  *lik;           /* BLHIP_OM_TABLE only: likelihood (T, G) evaluated by the caller; else NULL   */
     int32_t        n_ops;         /* length of the transition program                                            */
     const blhip_op *ops;
+    /* streaming use (OnlineStudy.step, core.py:2062-2226): see BLHIP_RESUME / BLHIP_CARRY */
+    double         resume_time;   /* BLHIP_RESUME: the time stamp the transition into step 0 is evaluated at
+                                     (OnlineStudy passes len(formattedData) - 1 = -1, core.py:2164-2165)         */
+    int32_t        carry_slot;    /* which carried state (one per transition model of an OnlineStudy), >= 0      */
+    int32_t        reserved0;
 } blhip_problem;
 
 /* Flags of blhip_fit */
@@ -94,6 +99,10 @@ typedef struct {
 #define BLHIP_EVIDENCE_ONLY  2u   /* Study.fit(evidenceOnly=True)  core.py:355, 407, 422, 477                    */
 #define BLHIP_KEEP_POSTERIOR 4u   /* keep each chain's normalised posterior sequence on the device (blhip_posterior_read) */
 #define BLHIP_ACCUMULATE     8u   /* fold each finite chain into the context's average-posterior accumulator (blhip_accum_*) */
+#define BLHIP_RESUME         16u  /* step 0 consumes T_fwd(carried state of carry_slot, resume_time) of every chain instead of
+                                     the prior (core.py:2164-2165); the slot must hold n_chains states of this grid  */
+#define BLHIP_CARRY          32u  /* keep every chain's filtered, normalised distribution of the LAST step in carry_slot
+                                     (core.py:2173 parameterPosterior[i][j]); forward-only / evidence-only fits      */
 
 /* Per-chain results; every pointer may be NULL. */
 typedef struct {
@@ -169,6 +178,16 @@ int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref);
 int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *problem, double *posterior_mean);
 int blhip_accum_read(blhip_ctx *ctx, int64_t t0, int64_t t1, double *host_out);
 int blhip_accum_end(blhip_ctx *ctx);
+
+/* ---- carried states (OnlineStudy.step, core.py:2062-2226) ------------------------------------------------------------
+ * A blhip_fit with BLHIP_CARRY leaves every chain's normalised filtered distribution of its last step in slot
+ * `carry_slot` of the context; the next call with BLHIP_RESUME continues from it.  What the online study does with these
+ * states after each step (core.py:2196-2212) are evidence-weighted sums over chains:
+ *   mix = (accumulate ? mix : 0) + sum_j weights[j] * state_j      (transitionModelPosterior / marginalizedPosterior)
+ * blhip_carry_read copies one chain's state (chain >= 0) or the mix buffer (chain = -1, slot ignored) to the host, (G,). */
+int blhip_carry_mix(blhip_ctx *ctx, int slot, int64_t n_chains, const double *weights, int accumulate);
+int blhip_carry_read(blhip_ctx *ctx, int slot, int64_t chain, double *host_out);
+int blhip_carry_release(blhip_ctx *ctx, int slot);   /* slot < 0: all slots and the mix buffer */
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,7 @@ PRIORS = {
     'inv_s3': lambda m, s: 1 / s ** 3,
     'inv_x': lambda x: 1. / x,
     'inv_s': lambda s: 1. / s,
+    'inv_s_2d': lambda m, s: 1. / s,
 }
 
 COAL = np.array([5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4,
@@ -211,6 +212,55 @@ CASES = {
 }
 
 
+# ---- OnlineStudy (reference core.py:1963-2226, tests/test_onlinestudy.py) ----------------------
+G20 = ('Gaussian', [('mean', _g('cint', 0, 6, 20)), ('sigma', _g('oint', 0, 2, 20))])
+ONLINE_CASES = {
+    # reference tests/test_onlinestudy.py:10-32 (setTM only: the model is added on the first step)
+    'online_kat_static': dict(om=G20 + ('inv_s3',), set_tm=('Static',), data=[1, 2, 3, 4, 5], kat=-16.1946904707),
+    # reference tests/test_onlinestudy.py:34-84
+    'online_kat_2tm': dict(om=G20 + ('inv_s_2d',),
+                           models=[('T1', ('Combined', [('GRW', 's1', [0.25, 0.5], 'mean', ('sympy_exp', 0.5)),
+                                                        ('GRW', 's2', _g('cint', 0, 0.2, 2), 'sigma', ('array', [0.2, 0.8]))])),
+                                   ('T2', ('Independent',))],
+                           tm_prior=[0.9, 0.1], data=[1, 2, 3, 4, 5], kat=-9.46900822686),
+    'online_poisson_3tm': dict(om=('Poisson', [('rate', _g('oint', 0, 6, 150))], 'default'),
+                               models=[('static', ('Static',)),
+                                       ('walk', ('GRW', 'sigma', _g('cint', 0.05, 0.4, 6), 'rate', None)),
+                                       ('switch', ('RS', 'log10pMin', [-5, -3], None))],
+                               data=COAL[:30].tolist()),
+    'online_gauss2d': dict(om=('Gaussian', [('mean', _g('cint', -5, 5, 48)), ('std', _g('oint', 0, 3, 40))], 'default'),
+                           models=[('walk', ('GRW', 'sm', [0.0, 0.1, 0.3], 'mean', None)),
+                                   ('both', ('Combined', [('GRW', 'a', 0.2, 'mean', None),
+                                                          ('GRW', 'b', _g('cint', 0.02, 0.1, 3), 'std', None)])),
+                                   ('cp', ('ChangePoint', 'tc', [-1, 3], None))],
+                           tm_prior=[0.5, 0.3, 0.2], data=('series', 41, 12)),
+    'online_ar1_wait': dict(om=('AR1', [('rho', _g('oint', -1, 1, 30)), ('sigma', _g('oint', 0, 1, 25))], 'default'),
+                            models=[('static', ('Static',)), ('walk', ('GRW', 's', [0.05, 0.1], 'rho', None))],
+                            data=[1, 0, 1, 0, 0, 1]),
+}
+
+
+def online_data(c):
+    d = c['data']
+    return list(make_data(d)) if isinstance(d, tuple) else list(d)
+
+
+def build_online(bl, case, storeHistory=True):
+    """OnlineStudy of the given package, models added, no data yet."""
+    import contextlib, io
+    c = ONLINE_CASES[case] if isinstance(case, str) else case
+    with contextlib.redirect_stdout(io.StringIO()):
+        S = bl.OnlineStudy(storeHistory=storeHistory, silent=True)
+        S.setOM(make_om(bl, c['om']), silent=True)
+        if 'set_tm' in c:
+            S.setTM(make_tm(bl, c['set_tm']), silent=True)
+        for name, spec in c.get('models', []):
+            S.addTransitionModel(name, make_tm(bl, spec))
+        if c.get('tm_prior') is not None:
+            S.setTransitionModelPrior(c['tm_prior'], silent=True)
+    return S
+
+
 def make_data(spec):
     if isinstance(spec, np.ndarray):
         return spec
@@ -252,6 +302,9 @@ def make_prior(p):
         return np.ones(p[1])
     if p[0] == 'array':
         return np.array(p[1], dtype=float)
+    if p[0] == 'sympy_exp':                      # reference tests/test_onlinestudy.py:41
+        import sympy.stats as stats
+        return stats.Exponential('e', p[1])
     raise ValueError(p)
 
 

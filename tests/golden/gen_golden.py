@@ -111,9 +111,42 @@ def run(case):
     return out
 
 
+def run_online(case):
+    """OnlineStudy.step over the case's data: everything the study exposes after every step (storeHistory=True)."""
+    c = cases.ONLINE_CASES[case]
+    S = cases.build_online(bl, case)
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        with np.errstate(all='ignore'):
+            for d in cases.online_data(c):
+                S.step(d)
+    for k, m in enumerate(S.marginalGrid):
+        out['marginal%d' % k] = np.asarray(m)
+    out['rawData'] = np.asarray(S.rawData, dtype=float)
+    out['logEvidence'] = np.float64(S.logEvidence)
+    out['posteriorSequence'] = np.asarray(S.posteriorSequence, dtype=float)
+    out['posteriorMeanValues'] = np.asarray(S.posteriorMeanValues, dtype=float)
+    out['transitionModelSequence'] = np.asarray(S.transitionModelSequence, dtype=float)
+    out['localTransitionModelSequence'] = np.asarray(S.localTransitionModelSequence, dtype=float)
+    out['n_models'] = len(S.transitionModels)
+    for i in range(len(S.transitionModels)):
+        out['hyperParameterSequence%d' % i] = np.asarray([h[i] for h in S.hyperParameterSequence], dtype=float)
+        out['logEvidenceList%d' % i] = np.asarray(S.logEvidenceList[i], dtype=float)
+        out['parameterPosterior%d' % i] = np.asarray(S.parameterPosterior[i], dtype=float)
+    out['hyperLogEvidenceList'] = np.asarray(S.hyperLogEvidenceList, dtype=float)
+    return out
+
+
 def main():
-    names = sys.argv[1:] or list(cases.CASES)
-    for name in names:
+    names = sys.argv[1:] or (list(cases.CASES) + list(cases.ONLINE_CASES))
+    for name in [n for n in names if n in cases.ONLINE_CASES]:
+        out = run_online(name)
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **out)
+        kat = cases.ONLINE_CASES[name].get('kat')
+        msg = '' if kat is None else '  (reference test value %r, diff %.2e)' % (kat, abs(out['logEvidence'] - kat))
+        print('%-26s logE=%r  %6.1f kB%s' % (name, float(out['logEvidence']), os.path.getsize(path) / 1e3, msg))
+    for name in [n for n in names if n in cases.CASES]:
         out = run(name)
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **out)

@@ -149,3 +149,52 @@ def run(case):
 def load_golden(case):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', case + '.npz')
     return dict(np.load(path))
+
+
+def run_online(case):
+    """The oracle's restatement of OnlineStudy.step over an ONLINE_CASES entry -> per-step results like the golden file."""
+    c = cases.ONLINE_CASES[case] if isinstance(case, str) else case
+    om_cls, params, prior_spec = c['om']
+    om = OM_NAME[om_cls]
+    g = orc.Grid([cases.make_values(_Orc, v) for _, v in params])
+    pnames = [p[0] for p in params]
+    prior_obj = orc.jeffreys(om) if prior_spec == 'default' else cases.make_prior(prior_spec)
+    prior = orc.compute_prior(g, prior_obj)
+    reset = orc.changepoint_prior(g, prior_obj)
+    specs = c.get('models') or [('transition model', c['set_tm'])]
+    models = []
+    for name, spec in specs:
+        ops, vals, pri = flatten_tm(spec, pnames)
+        if len(vals) == 0:
+            models.append(dict(ops=ops, values=[orc.align_values(ops, [])], prior_values=np.array([1.]), grid_constants=[],
+                               reset=reset, indep=reset / np.prod(g.lattice)))
+            continue
+        pri2 = []
+        for p, v in zip(pri, vals):
+            if p is not None and not hasattr(p, '__call__') and not isinstance(p, (list, tuple, np.ndarray)):
+                from sympy import lambdify, abc                       # SymPy random variable (test_onlinestudy.py:41)
+                from sympy.stats import density
+                p = ('density', lambdify([abc.x], density(p)(abc.x), modules=['numpy'])(np.asarray(v, dtype=float)))
+            pri2.append(p)
+        hv, pv, const = orc.hyper_grid(vals, pri2)
+        models.append(dict(ops=ops, values=[orc.align_values(ops, row) for row in hv], prior_values=pv, grid_constants=const,
+                           reset=reset, indep=reset / np.prod(g.lattice)))
+    state = orc.OnlineState(g, prior, models, c.get('tm_prior'))
+    seg = orc.OM_INFO[om][0]
+    raw = np.asarray(cases.online_data(c), dtype=float)
+    out = dict(posteriorSequence=[], posteriorMeanValues=[], transitionModelSequence=[], localTransitionModelSequence=[],
+               hyperParameterSequence=[])
+    for k in range(len(raw)):
+        if k + 1 < seg:
+            continue
+        with np.errstate(all='ignore'):
+            r = orc.online_step(state, om, raw[k + 1 - seg:k + 1])
+        out['posteriorSequence'].append(r['marginalizedPosterior'])
+        out['posteriorMeanValues'].append(r['posteriorMeanValues'])
+        out['transitionModelSequence'].append(r['transitionModelDistribution'])
+        out['localTransitionModelSequence'].append(r['localTransitionModelDistribution'])
+        out['hyperParameterSequence'].append(r['hyperParameterDistribution'])
+    out['logEvidence'] = state.log_evidence
+    out['parameterPosterior'] = state.parameter_posterior
+    out['logEvidenceList'] = state.log_evidence_list
+    return out

@@ -29,6 +29,8 @@ class OracleEngine:
         self.acc_ext = None
         self.acc_lin = None
         self.fits = 0
+        self._carry = {}
+        self._mix = None
 
     def _unpack(self, p):
         g = orc.Grid(p.marginal)
@@ -39,8 +41,48 @@ class OracleEngine:
         self._indep = None if p.indep_prior is None else np.asarray(p.indep_prior, dtype=float).reshape(g.size)
         return g, OM[p.obs_model], ops, data, lik, reset
 
+    def _online(self, problem, op_values, resume, carry):
+        """One forward step from the prior or from the carried states (OnlineStudy.step, core.py:2157-2174)."""
+        g, om, ops, data, lik, reset = self._unpack(problem)
+        assert problem.T == 1
+        n = len(op_values)
+        L = orc.processed_pdf(om, g.grid, data[0]) if lik is None else lik[0]
+        logE, local = np.zeros(n), np.zeros((n, 1))
+        states = np.zeros([n] + g.size)
+        for c in range(n):
+            vals = [None if op[0] in ('static', 'independent') else op_values[c][k] for k, op in enumerate(ops)]
+            with np.errstate(all='ignore'):
+                if resume:
+                    alpha = orc.transition_forward(ops, vals, self._carry[problem.carry_slot][c], problem.resume_time, g, reset,
+                                                   self._indep) * L
+                else:
+                    alpha = np.asarray(problem.prior, dtype=float).reshape(g.size) * L
+                ni = np.sum(alpha)
+                local[c, 0] = ni * g.dV
+                logE[c] = np.log(ni) + np.log(g.dV)
+                states[c] = alpha / ni
+        if carry:
+            self._carry[problem.carry_slot] = states
+        return FitResult(logE, local, None, np.full(n, -1, dtype=np.int64), np.zeros(n, dtype=np.int32), {})
+
+    def carry_mix(self, slot, weights, accumulate=False):
+        st = self._carry[slot]
+        m = np.tensordot(np.asarray(weights, dtype=float), st, axes=(0, 0))
+        self._mix = m if not accumulate else self._mix + m
+
+    def carry_read(self, slot, chain, grid_size):
+        return (self._mix if chain < 0 else self._carry[slot][chain]).copy().reshape(grid_size)
+
+    def carry_release(self, slot=-1):
+        if slot < 0:
+            self._carry.clear()
+        else:
+            self._carry.pop(slot, None)
+
     def fit(self, problem, op_values, forward_only=False, evidence_only=False, keep_posterior=False,
-            accumulate=False, log_chain_weight=None, owner=None):
+            accumulate=False, log_chain_weight=None, owner=None, resume=False, carry=False):
+        if resume or carry:
+            return self._online(problem, op_values, resume, carry)
         if self._posterior_owner is not None and self._posterior_owner is not owner:
             prev, self._posterior_owner = self._posterior_owner, None
             prev._materialize_posterior()
