@@ -506,6 +506,30 @@ class Study(object):
     def getPD(self, t, name, plot=False, density=True, **kwargs):
         return self.getParameterDistribution(t, name, plot=plot, density=density, **kwargs)
 
+    def simulate(self, x, t=None, density=False):
+        """Probability (density) of the observation values ``x`` under the inferred parameter distribution of time stamp
+        ``t`` (or its time average), reference core.py:566-597.  Only the (time-averaged) distribution of one step leaves
+        the GPU: G doubles, not the (T, G) sequence."""
+        om = self.observationModel
+        if om.segmentLength > 1:
+            raise NotImplementedError('Method "simulate" is only available for observation models with segment length 1.')
+        pending = self._posterior_pending
+        if t is None:
+            if pending is not None and hasattr(pending, 'time_average'):
+                post = pending.time_average()
+            else:
+                seq = self._requirePosterior()
+                post = np.sum(seq, axis=0) / len(seq)
+        else:
+            if t not in self.formattedTimestamps:
+                raise PostProcessingError('Supplied time ({}) does not exist in data or is out of range.'.format(t))
+            index = list(self.formattedTimestamps).index(t)
+            post = pending.row(index) if pending is not None and hasattr(pending, 'row') else self._requirePosterior()[index]
+        prob = np.array([np.sum(om.pdf(self.grid, [xi]) * post) for xi in x])
+        if not density:
+            prob /= np.sum(prob)
+        return prob
+
     def getParameterDistributions(self, name, plot=False, density=True, **kwargs):
         """Time series of marginal posterior distributions of one parameter: (values, (T, n) array); reduced on the GPU
         while the posterior sequence is still there."""

@@ -91,7 +91,7 @@ struct blhip_ctx {
     double acc_logref = -std::numeric_limits<double>::infinity();
     blhip_timing timing = {};
     // carried states of streaming fits (BLHIP_CARRY / BLHIP_RESUME): slot -> (chains, G) normalised distributions
-    struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; };
+    struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; std::vector<double> maxv; };
     std::map<int, Carry> carry;
     DevBuf mix, unit;
     int64_t mix_G = 0;
@@ -405,7 +405,8 @@ void validate(const blhip_problem *p, int64_t n_chains, const double *op_values)
             has_cp = true;
         } else if (op.kind == BLHIP_OP_INDEPENDENT) {
             if (!p->indep_prior) fail("INDEPENDENT op needs indep_prior");
-        } else if (op.kind != BLHIP_OP_STATIC && op.kind != BLHIP_OP_REGIMESWITCH && op.kind != BLHIP_OP_BREAKPOINT) {
+        } else if (op.kind != BLHIP_OP_STATIC && op.kind != BLHIP_OP_REGIMESWITCH && op.kind != BLHIP_OP_BREAKPOINT &&
+                   op.kind != BLHIP_OP_NOTEQUAL) {
             fail("op %d: unknown kind %d", k, op.kind);
         }
     }
@@ -512,7 +513,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                 if (std::isnan(ns)) fail("chain %lld: GRW sigma is NaN", (long long)(c0 + b));
             } else if (op.kind == BLHIP_OP_CHANGEPOINT || op.kind == BLHIP_OP_BREAKPOINT) {
                 time_dependent = true;
-            } else if (op.kind == BLHIP_OP_REGIMESWITCH) {
+            } else if (op.kind == BLHIP_OP_REGIMESWITCH || op.kind == BLHIP_OP_NOTEQUAL) {
                 prog.has_clamp = true;
             }
         }
@@ -547,6 +548,13 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                         break;
                     case BLHIP_OP_INDEPENDENT:                                    // transitionModels.py:351-360
                         sp = StepProg(); sp.kind = SRC_INDEP; filtered = false;
+                        break;
+                    case BLHIP_OP_NOTEQUAL:                                       // transitionModels.py:462-471
+                        if (sp.cmode != 0 || filtered)
+                            fail("a NotEqual model after another model acting on the same step is not supported");
+                        if (sp.kind != SRC_PREV) fail("a NotEqual model right after a change-point / independent restart is not supported");
+                        sp.cmode = 3;
+                        sp.limit = std::pow(10.0, val[k]) * dV;
                         break;
                     case BLHIP_OP_REGIMESWITCH:                                   // transitionModels.py:405-410
                         if (sp.cmode != 0) fail("two RegimeSwitch models acting at the same time are not supported");
@@ -858,8 +866,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         if (resume) {
             d_carry_src = ctx->carry[p->carry_slot].buf.as<double>();
             std::vector<double> unit((size_t)B * NRED * tile.nblk, 0.0);
+            const std::vector<double> &mv = ctx->carry[p->carry_slot].maxv;
             for (int64_t b = 0; b < B; ++b)
-                for (int k = 0; k < NRED; ++k) unit[((size_t)b * NRED + k) * tile.nblk] = 1.0;
+                for (int k = 0; k < NRED; ++k)       // slot 6 = maximum of the carried state (NotEqual inverts around it)
+                    unit[((size_t)b * NRED + k) * tile.nblk] = (k == 6 && (int64_t)mv.size() == B) ? mv[b] : 1.0;
             ctx->unit.ensure(unit.size() * 8);
             HIPCHECK(hipMemcpyAsync(ctx->unit.p, unit.data(), unit.size() * 8, hipMemcpyHostToDevice, st));
             HIPCHECK(hipStreamSynchronize(st));
@@ -1028,7 +1038,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
         HIPCHECK(hipEventRecord(ev[1], st));
         if (!persist)
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
-                               ctx->redF.as<double>(), tile.nblk);
+                               ctx->redF.as<double>(), tile.nblk, NRED);
         redF.resize((size_t)T * B * NRED);
         HIPCHECK(hipMemcpyAsync(redF.data(), ctx->redF.p, redF.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
@@ -1110,7 +1120,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             HIPCHECK(hipEventRecord(ev[3], st));
             if (!persist)
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
-                                   ctx->redB.as<double>(), tile.nblk);
+                                   ctx->redB.as<double>(), tile.nblk, NRED);
             redB.resize((size_t)T * B * NRED);
             HIPCHECK(hipMemcpyAsync(redB.data(), ctx->redB.p, redB.size() * 8, hipMemcpyDeviceToHost, st));
             HIPCHECK(hipStreamSynchronize(st));
@@ -1156,6 +1166,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
             hipLaunchKernelGGL(carry_store_kernel, dim3(gx, (unsigned)B), dim3(NTHREADS), 0, st, cs.buf.as<double>(), fin, fstr, G, d_w);
             HIPCHECK(hipStreamSynchronize(st));
             cs.chains = B; cs.G = G; cs.valid = true;
+            cs.maxv.clear();
+            if (prog.has_clamp)                      // clamp batches run the generic kernel, which reports the state maximum
+                for (int64_t b = 0; b < B; ++b) cs.maxv.push_back(redF[((size_t)(T - 1) * B + b) * NRED + 6] * inv[b]);
         }
 
         // --- fold into the average posterior (core.py:1358-1366) ---
@@ -1546,7 +1559,7 @@ int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *p, double *posteri
         HIPCHECK(hipMemcpyAsync(d_m1, p->ndim == 1 ? p->marginal[0] : p->marginal[1], 8 * (size_t)n1, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(row_stats_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, n1,
                            p->ndim, d_m0, d_m1, d_part);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * 3)), dim3(NTHREADS), 0, st, d_part, d_red, (int)gx);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * 3)), dim3(NTHREADS), 0, st, d_part, d_red, (int)gx, 0);
         std::vector<double> red((size_t)T * 3), inv(T);
         HIPCHECK(hipMemcpyAsync(red.data(), d_red, red.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));

@@ -16,7 +16,8 @@
 namespace blk {
 
 constexpr int NTHREADS = 256;
-constexpr int NRED = 6;          // partial-sum slots per (step, chain): 0 N  1 S(p/L) [fwd: U]  2 C  3 M0  4 M1  5 B (clamp only)
+constexpr int NRED = 7;          // partial slots per (step, chain): 0 N  1 S(p/L) [fwd: U]  2 C  3 M0  4 M1  5 B (clamp only)
+                                 //                                  6 MAX of the new state (clamp batches only: NotEqual)
 
 enum Mode { MODE_FWD = 0, MODE_BWD = 1, MODE_FILTER = 2 };
 enum SrcKind { SRC_PREV = 0, SRC_PRIOR = 1, SRC_RESET = 2, SRC_UNIFORM = 3, SRC_INDEP = 4 };
@@ -38,7 +39,8 @@ struct StepParams {
     // per-chain metadata of this step (pre-offset to the step)
     const unsigned char *srckind;                 // [B]
     const int *tap0, *tap1;                       // [B] tap-set ids per internal axis, -1 = identity
-    const unsigned char *cmode; const double *limit;   // [B] RegimeSwitch clamp (0 none, 1 source, 2 after stencil); nullptr if unused
+    const unsigned char *cmode; const double *limit;   // [B] clamp mode: 0 none, 1 RegimeSwitch on the source, 2 RegimeSwitch after the stencil,
+                                                       //     3 NotEqual (invert + clamp the source); nullptr if the batch has none
     // tap table
     const double *taps; const int *tap_off; const int *tap_lw;
     // lazy normalisation
@@ -118,6 +120,20 @@ __device__ __forceinline__ void block_sums(double (&v)[NV], double *red) {
     }
 }
 
+// Block-wide maximum (clamp batches only, not on the hot path); result valid in every thread.
+__device__ __forceinline__ double block_max(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < NTHREADS / 64; ++k) s = fmax(s, red[k]);
+    return s;
+}
+
 // Deterministic sum of n partials (fixed order for a fixed block size).
 __device__ __forceinline__ double sum_partials(const double *p, int n, double *red) {
     double v = 0.0;
@@ -192,9 +208,17 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     double scale = 1.0, kappa = 1.0;
     const int cm = P.cmode ? P.cmode[b] : 0;
     const double lim = P.cmode ? P.limit[b] : 0.0;
+    double ne_max = 0.0, ne_inv = 0.0;             // NotEqual: (max - x) / (G max - sum x) of the producing step's state
     if (MODE != MODE_FILTER && kind == SRC_PREV) {
         const double s = sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
         scale = 1.0 / s;
+        if (cm == 3) {
+            const double *pm = P.psum_prev + ((long long)b * NRED + 6) * P.prev_nblk;
+            double m = -1.0;
+            for (int k = threadIdx.x; k < P.prev_nblk; k += NTHREADS) m = fmax(m, pm[k]);
+            ne_max = block_max(m, red);
+            ne_inv = 1.0 / ((double)P.n0 * (double)P.n1 * ne_max - s);     // transitionModels.py:465-466 (0/0 -> NaN as numpy)
+        }
         if (MODE == MODE_BWD && P.cmode) {
             // RegimeSwitch clamps F(beta_norm * L) (transitionModels.py:405-407): that needs 1 / sum(beta) of the producing
             // step (slot 5); products keep the well-scaled normaliser 1 / sum(c) (slot 2):  beta_used = u * kappa
@@ -213,10 +237,12 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
             const int gj = reflect(j0 - P.LW1 + c, P.n1);
             double v = row[gj];
             if (cm == 1) { v *= scale; v = v < lim ? lim : v; }
+            if (cm == 3) { v = (ne_max - v) * ne_inv; v = v < lim ? lim : v; }                 // transitionModels.py:465-467
             dstrow[c] = v;
         }
     }
-    if (cm == 1) scale = 1.0;
+    if (cm == 1 || cm == 3) scale = 1.0;
+    if (cm == 3) kappa = 1.0;                      // NotEqual is scale-invariant in its input: beta_used = u
     __syncthreads();
 
     // ---- phase 2: filter along axis 0 (rows), SciPy's symmetric correlate1d order -------------------------------
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     }
 
     // ---- phase 3: filter along axis 1 (cols) + epilogue ---------------------------------------------------------
-    double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0, sU = 0.0;
+    double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0, sU = 0.0, sMax = 0.0;
     for (int c = x; c < tw; c += XW) {
         const int gj = j0 + c;
         double cA = 0.0, cB = 0.0, g1 = 0.0;
@@ -263,11 +289,12 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
                 double u = o * scale;                                    // the (normalised) prior of this step
                 if (cm == 2) u = u < lim ? lim : u;                      // RegimeSwitch after the stencil
                 // mass of the clamped distribution (the reference renormalises by it, transitionModels.py:410)
-                sU += cm == 1 ? in_tile[(size_t)(r + P.LW0) * pitch + P.LW1 + c] : u;
+                sU += (cm == 1 || cm == 3) ? in_tile[(size_t)(r + P.LW0) * pitch + P.LW1 + c] : u;
                 if (MODE == MODE_FWD) {
                     const double a = u * L;
                     P.dst[(long long)b * P.dst_stride + cell] = a;
                     sN += a;
+                    sMax = fmax(sMax, a);
                     if (MEANS) {
                         if (P.ndim == 2) { sM0 += a * P.m0[gi]; sM1 += a * g1; } else { sM0 += a * g1; }
                     }
@@ -278,6 +305,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
                     *pp = p;
                     const double cn = beta * L;
                     P.dst[(long long)b * P.dst_stride + cell] = cn;
+                    sMax = fmax(sMax, cn);
                     sN += p;
                     sS += p / L;               // 0/0 -> NaN exactly as numpy does (core.py:463)
                     sC += cn;
@@ -298,12 +326,23 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
         if (MODE == MODE_BWD || MEANS) { out[3 * P.nblk] = v[3]; out[4 * P.nblk] = v[4]; }
         if (P.cmode) out[(MODE == MODE_BWD ? 5 : 1) * P.nblk] = v[5];   // clamp bookkeeping: fwd U = sum u, bwd B = sum beta_used
     }
+    if (P.cmode) {                                 // NotEqual needs the maximum of the state it inverts
+        const double mx = block_max(sMax, red);
+        if (threadIdx.x == 0) out[6 * P.nblk] = mx;
+    }
 }
 
 // out[k] = sum of nblk partials, k over (step, chain, slot); same summation order as sum_partials in the step kernel.
-__global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double *psum, double *out, int nblk) {
+__global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double *psum, double *out, int nblk, int period) {
     __shared__ double red[NTHREADS / 64 + 1];
     const long long k = blockIdx.x;
+    if (period > 0 && k % period == 6) {           // step-kernel partials (period = NRED): slot 6 holds block MAXIMA
+        double m = -1.0;
+        for (int q = threadIdx.x; q < nblk; q += NTHREADS) m = fmax(m, psum[k * nblk + q]);
+        m = block_max(m, red);
+        if (threadIdx.x == 0) out[k] = m;
+        return;
+    }
     const double s = sum_partials(psum + k * nblk, nblk, red);
     if (threadIdx.x == 0) out[k] = s;
 }

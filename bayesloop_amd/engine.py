@@ -77,6 +77,12 @@ class DevicePosterior:
             return self.engine.posterior(self.chain, self.T, self.grid_size)
         return self.engine.accum_read(self.T, self.grid_size)
 
+    def row(self, index):
+        """One time step of the sequence as an array of gridSize (copies G doubles, not T * G)."""
+        if self.source == 0:
+            return self.engine.posterior(self.chain, self.T, self.grid_size, t0=index, t1=index + 1)[0]
+        return self.engine.accum_read(self.T, self.grid_size, t0=index, t1=index + 1)[0]
+
     def marginal(self, k):
         return self.engine.marginal(self.source, self.chain, k, self.T, self.grid_size[k])
 
@@ -234,10 +240,12 @@ class HipEngine:
         self._check(self.lib.blhip_last_timing(self.ctx, C.byref(t)))
         return t.as_dict()
 
-    def posterior(self, chain, T, grid_size):
-        """Normalised posterior sequence of one chain of the last fit(keep_posterior=True) as (T, *grid_size)."""
-        out = np.empty([T] + list(grid_size))
-        self._check(self.lib.blhip_posterior_read(self.ctx, chain, 0, T, _abi.dptr(out)))
+    def posterior(self, chain, T, grid_size, t0=0, t1=None):
+        """Normalised posterior sequence of one chain of the last fit(keep_posterior=True) as (T, *grid_size)
+        (or the rows t0 .. t1-1 of it)."""
+        t1 = T if t1 is None else t1
+        out = np.empty([t1 - t0] + list(grid_size))
+        self._check(self.lib.blhip_posterior_read(self.ctx, chain, t0, t1, _abi.dptr(out)))
         return out
 
     def marginal(self, source, chain, keep_axis, T, n_keep):
@@ -290,9 +298,10 @@ class HipEngine:
         self._check(self.lib.blhip_accum_finalize(self.ctx, C.byref(cp), _abi.dptr(means)))
         return means
 
-    def accum_read(self, T, grid_size):
-        out = np.empty([T] + list(grid_size))
-        self._check(self.lib.blhip_accum_read(self.ctx, 0, T, _abi.dptr(out)))
+    def accum_read(self, T, grid_size, t0=0, t1=None):
+        t1 = T if t1 is None else t1
+        out = np.empty([t1 - t0] + list(grid_size))
+        self._check(self.lib.blhip_accum_read(self.ctx, t0, t1, _abi.dptr(out)))
         return out
 
     def accum_end(self):

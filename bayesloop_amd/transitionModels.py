@@ -11,6 +11,7 @@ both directions, inside the fused HIP step kernels:
     GaussianRandomWalk      -> GRW(axis, sigma): reflect-boundary Gaussian stencil along one grid axis
     ChangePoint             -> CHANGEPOINT(tChange): restart from the (re-normalised) prior at one time stamp
     RegimeSwitch            -> REGIMESWITCH(log10pMin): clamp from below and renormalise
+    NotEqual                -> NOTEQUAL(log10pMin): max(p) - p, renormalise, clamp from below, renormalise
     Independent             -> INDEPENDENT: restart from the normalised prior at every step
     CombinedTransitionModel -> concatenation of the sub-models' programs
     SerialTransitionModel   -> the sub-models' programs tagged with their segment + BREAKPOINT / boundary CHANGEPOINT ops
@@ -150,6 +151,25 @@ class RegimeSwitch(TransitionModel):
         return [(_abi.OP_REGIMESWITCH, 0, self, 0, -1, 0)]
 
 
+class NotEqual(TransitionModel):
+    """Unlikely parameter values are preferred in the next step: max(p) - p, renormalised, clamped from below at
+    10**log10pMin and renormalised again (reference transitionModels.py:418-474; mostly used with OnlineStudy)."""
+
+    def __init__(self, name='log10pMin', value=None, prior=None):
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = [name]
+        self.hyperParameterValues = [_as_values(value)]
+        self.prior = prior
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Not-Equal model'
+
+    def _program(self, parameterNames):
+        return [(_abi.OP_NOTEQUAL, 0, self, 0, -1, 0)]
+
+
 class Independent(TransitionModel):
     """Independent observations: the (normalised) prior is restored at every step (reference transitionModels.py:320-363)."""
 
@@ -238,7 +258,7 @@ def _not_yet(name, where):
     class _Unavailable(TransitionModel):
         def __init__(self, *args, **kwargs):
             raise NotImplementedError('bl.tm.{} (reference {}) is not available on the MI355X engine yet; this build '
-                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, Independent, Combined- and '
+                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, NotEqual, Independent, Combined- and '
                                       'SerialTransitionModel (with BreakPoint).'
                                       .format(name, where))
     _Unavailable.__name__ = name
@@ -247,6 +267,5 @@ def _not_yet(name, where):
 
 # rows of SURVEY.md section 8(f): not on the hot path named by BASELINE.json
 AlphaStableRandomWalk = _not_yet('AlphaStableRandomWalk', 'transitionModels.py:121-260')
-NotEqual = _not_yet('NotEqual', 'transitionModels.py:418-474')
 Deterministic = _not_yet('Deterministic', 'transitionModels.py:477-606')
 BivariateRandomWalk = _not_yet('BivariateRandomWalk', 'transitionModels.py:843-911')

@@ -54,8 +54,10 @@ enum {
     BLHIP_OP_CHANGEPOINT  = 2,    /* transitionModels.py:289-317  value = tChange (flags bit 0: see below)      */
     BLHIP_OP_REGIMESWITCH = 3,    /* transitionModels.py:394-415  value = log10 pMin: clamp from below, renormalise */
     BLHIP_OP_INDEPENDENT  = 4,    /* transitionModels.py:339-363  restart from the normalised prior at every step */
-    BLHIP_OP_BREAKPOINT   = 5     /* transitionModels.py:821-840  value = tBreak: boundary between two sub-models of a
+    BLHIP_OP_BREAKPOINT   = 5,    /* transitionModels.py:821-840  value = tBreak: boundary between two sub-models of a
                                      SerialTransitionModel (transitionModels.py:756-786) */
+    BLHIP_OP_NOTEQUAL     = 6     /* transitionModels.py:450-474  value = log10 pMin: max(p) - p, renormalise, clamp from
+                                     below, renormalise */
 };
 
 /* A SerialTransitionModel (transitionModels.py:665-818) is flattened into the same program: the ops of its n sub-models

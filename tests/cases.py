@@ -176,6 +176,13 @@ CASES = {
     # reference tests/test_transitionmodels.py:96-108, :110-122, :139-161
     'kat_regimeswitch': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                              tm=('RS', 'p_min', -3, None), kat=-10.372866559561402),
+    # reference tests/test_transitionmodels.py:124-136
+    'kat_notequal': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                         tm=('NE', 'p_min', -3, None), kat=-10.569099863134156),
+    'notequal_2d_hyper': dict(study='HyperStudy', data=('series', 61, 9), om=gauss2d(36, -5, 5, 3),
+                              tm=('NE', 'p_min', [-6., -4., -2.], None)),
+    'notequal_before_grw_2d': dict(study='Study', data=('series', 62, 8), om=gauss2d(30, -5, 5, 3),
+                                   tm=('Combined', [('NE', 'p_min', -4, None), ('GRW', 's', 0.4, 'mean', None)])),
     'kat_independent': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                             tm=('Independent',), kat=-11.087360077190617),
     'kat_nested': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
@@ -234,6 +241,10 @@ ONLINE_CASES = {
                                                           ('GRW', 'b', _g('cint', 0.02, 0.1, 3), 'std', None)])),
                                    ('cp', ('ChangePoint', 'tc', [-1, 3], None))],
                            tm_prior=[0.5, 0.3, 0.2], data=('series', 41, 12)),
+    'online_notequal': dict(om=('Poisson', [('rate', _g('oint', 0, 6, 120))], 'default'),
+                            models=[('static', ('Static',)), ('different', ('NE', 'log10pMin', [-7., -3.], None)),
+                                    ('walk+different', ('Combined', [('NE', 'q', -5., None), ('GRW', 'sg', 0.2, 'rate', None)]))],
+                            data=COAL[30:52].tolist()),
     'online_ar1_wait': dict(om=('AR1', [('rho', _g('oint', -1, 1, 30)), ('sigma', _g('oint', 0, 1, 25))], 'default'),
                             models=[('static', ('Static',)), ('walk', ('GRW', 's', [0.05, 0.1], 'rho', None))],
                             data=[1, 0, 1, 0, 0, 1]),
@@ -322,6 +333,8 @@ def make_tm(bl, spec):
         return bl.tm.RegimeSwitch(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'Independent':
         return bl.tm.Independent()
+    if kind == 'NE':
+        return bl.tm.NotEqual(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'BreakPoint':
         return bl.tm.BreakPoint(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'Serial':

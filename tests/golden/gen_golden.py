@@ -137,7 +137,31 @@ def run_online(case):
     return out
 
 
+SIMULATE = {'c1_coal': np.arange(0, 9), 'kat_gaussian': np.linspace(-2, 8, 11), 'c4_small': np.linspace(-3, 3, 7)}
+
+
+def run_simulate():
+    """Study.simulate (core.py:566-597) on three fitted cases: time-averaged and at one time stamp, probability and density."""
+    out = {}
+    for case, x in SIMULATE.items():
+        S = cases.build(bl, case)
+        with contextlib.redirect_stdout(io.StringIO()):
+            with np.errstate(all='ignore'):
+                S.fit(**cases.fit_kwargs(case))
+        t = S.formattedTimestamps[len(S.formattedTimestamps) // 2]
+        out[case + '_x'] = np.asarray(x, dtype=float)
+        out[case + '_t'] = np.float64(t)
+        out[case + '_avg'] = np.asarray(S.simulate(x), dtype=float)
+        out[case + '_at'] = np.asarray(S.simulate(x, t=t), dtype=float)
+        out[case + '_avg_density'] = np.asarray(S.simulate(x, density=True), dtype=float)
+    return out
+
+
 def main():
+    if sys.argv[1:] == ['simulate']:
+        np.savez_compressed(os.path.join(HERE, 'simulate.npz'), **run_simulate())
+        print('simulate.npz written')
+        return
     names = sys.argv[1:] or (list(cases.CASES) + list(cases.ONLINE_CASES))
     for name in [n for n in names if n in cases.ONLINE_CASES]:
         out = run_online(name)

@@ -59,6 +59,8 @@ def flatten_tm(spec, param_names):
         return [('regimeswitch',)], [cases.make_values(_Orc, spec[2])], [cases.make_prior(spec[3])]
     if kind == 'Independent':
         return [('independent',)], [], []
+    if kind == 'NE':
+        return [('notequal',)], [cases.make_values(_Orc, spec[2])], [cases.make_prior(spec[3])]
     if kind == 'Serial':
         # sub-models first (tagged with their segment), then the serial model's own break-/change-points
         ops, vals, pri, seg = [], [], [], 0

@@ -384,3 +384,16 @@ def test_device_side_marginals():
         axes = tuple(a for a in range(len(names)) if a != 0)
         want = post.mean(axis=0)
         np.testing.assert_allclose(avg, want.sum(axis=axes) if axes else want, rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.gpu
+def test_simulate_matches_reference_golden():
+    """Study.simulate (core.py:566-597) on device-resident posteriors (time average / single row reads) vs the reference."""
+    gold = oa.load_golden('simulate')
+    for case in ('c1_coal', 'kat_gaussian', 'c4_small'):
+        S = cases.build(bl, case)
+        S.fit(**cases.fit_kwargs(case))
+        x = gold[case + '_x']
+        np.testing.assert_allclose(S.simulate(x), gold[case + '_avg'], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(S.simulate(x, t=float(gold[case + '_t'])), gold[case + '_at'], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(S.simulate(x, density=True), gold[case + '_avg_density'], rtol=1e-9, atol=1e-300)

@@ -83,7 +83,7 @@ def test_configuration_errors():
     with pytest.raises(bl.ConfigurationError):
         bl.tm.GaussianRandomWalk('sigma', 0.1)          # no target
     with pytest.raises(NotImplementedError):
-        bl.tm.NotEqual('p', -3)
+        bl.tm.BivariateRandomWalk('s1', 0.1, 's2', 0.1, 'rho', 0.)
     S.setTM(bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s', 0.1, target='rate'),
                                           bl.tm.GaussianRandomWalk('s', 0.2, target='rate')), silent=True)
     with pytest.raises(bl.ConfigurationError):
@@ -138,3 +138,21 @@ def test_device_side_reductions_equal_host_reductions():
         np.testing.assert_allclose(m1, post.sum(axis=1) / S.latticeConstant[1], rtol=1e-13)
         np.testing.assert_allclose(avg, post.mean(axis=0).sum(axis=1) / S.latticeConstant[0], rtol=1e-13)
         np.testing.assert_allclose(pt, post[3].sum(axis=0), rtol=1e-13)
+
+
+def test_simulate_matches_reference_golden_host_side():
+    """Study.simulate (core.py:566-597) over the test double (row / time-average reads of the posterior handle)."""
+    gold = oa.load_golden('simulate')
+    for case in ('c1_coal', 'kat_gaussian'):
+        S = cases.build(bl, case)
+        with np.errstate(all='ignore'):
+            S.fit(**cases.fit_kwargs(case))
+        x = gold[case + '_x']
+        np.testing.assert_allclose(S.simulate(x), gold[case + '_avg'], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(S.simulate(x, t=float(gold[case + '_t'])), gold[case + '_at'], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(S.simulate(x, density=True), gold[case + '_avg_density'], rtol=1e-9, atol=1e-300)
+    S = bl.Study(silent=True)
+    S.loadData(np.array([1, 0, 1, 0, 0]), silent=True)
+    S.set(bl.om.AR1('rho', bl.oint(-1, 1, 20), 'sigma', bl.oint(0, 1, 20)), bl.tm.Static(), silent=True)
+    with pytest.raises(NotImplementedError):
+        S.simulate([0.])
