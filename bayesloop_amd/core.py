@@ -19,7 +19,7 @@ from . import engine as _engine_mod
 from .engine import FitProblem, DevicePosterior
 from .exceptions import ConfigurationError, PostProcessingError
 from .helper import flatten
-from .observationModels import ObservationModel
+from .observationModels import ObservationModel, device_code
 from .preprocessing import movingWindow
 from .transitionModels import TransitionModel, ChangePoint, CombinedTransitionModel, SerialTransitionModel
 
@@ -349,10 +349,9 @@ class Study(object):
             indep = self._changepointPrior() / np.prod(self.latticeConstant)      # sum 1 (reference transitionModels.py:351-360)
         data = np.asarray(self.formattedData, dtype=float)
         lik = None
-        code = getattr(om, 'device_model', _abi.OM_TABLE)
-        if code == _abi.OM_TABLE or om.segmentLength != 1:
+        code = device_code(om)
+        if code == _abi.OM_TABLE:
             # the model's own pdf, evaluated once per time step on the host (plug-in interface of the reference)
-            code = _abi.OM_TABLE
             lik = np.array([np.asarray(om.processedPdf(self.grid, seg), dtype=float) * np.ones(self.gridSize)
                             for seg in self.formattedData])
         problem = FitProblem(obs_model=code, marginal=self.marginalGrid, lattice=self.latticeConstant, data=data,
@@ -1048,10 +1047,9 @@ class OnlineStudy(HyperStudy):
         # in-kernel for the closed-form device models, on the host through the model's own pdf otherwise
         segment = self.rawData[-om.segmentLength:]
         data = np.asarray([segment], dtype=float)
-        code = getattr(om, 'device_model', _abi.OM_TABLE)
+        code = device_code(om)
         lik = None
-        if code == _abi.OM_TABLE or om.segmentLength != 1:
-            code = _abi.OM_TABLE
+        if code == _abi.OM_TABLE:
             lik = np.array([np.asarray(om.processedPdf(self.grid, segment), dtype=float) * np.ones(self.gridSize)])
         dV = np.prod(self.latticeConstant)
 

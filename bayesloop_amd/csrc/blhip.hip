@@ -93,7 +93,7 @@ struct blhip_ctx {
     // carried states of streaming fits (BLHIP_CARRY / BLHIP_RESUME): slot -> (chains, G) normalised distributions
     struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; std::vector<double> maxv; };
     std::map<int, Carry> carry;
-    DevBuf mix, unit;
+    DevBuf mix, unit, databuf;
     int64_t mix_G = 0;
 
     double option(const char *k, double dflt) const {
@@ -427,6 +427,15 @@ void validate(const blhip_problem *p, int64_t n_chains, const double *op_values)
         case BLHIP_OM_TABLE:
             if (!p->lik) fail("BLHIP_OM_TABLE needs lik");
             break;
+        case BLHIP_OM_BERNOULLI: case BLHIP_OM_WHITE_NOISE:
+            if (p->ndim != 1 || p->seg_len != 1) fail("Bernoulli / white-noise models have 1 parameter and segment length 1");
+            break;
+        case BLHIP_OM_LAPLACE:
+            if (p->ndim != 2 || p->seg_len != 1) fail("Laplace model has 2 parameters and segment length 1");
+            break;
+        case BLHIP_OM_AR1: case BLHIP_OM_SCALED_AR1:
+            if (p->ndim != 2 || p->seg_len != 2) fail("AR1 models have 2 parameters and segment length 2");
+            break;
         default: fail("unknown observation model %d", p->obs_model);
     }
     if (p->data_dim < 1) fail("data_dim must be >= 1");
@@ -596,9 +605,15 @@ template <class T> T *carve(char *&cur, size_t count) {
 }
 size_t carve_size(size_t bytes) { return ((bytes + 255) / 256) * 256; }
 
-void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const double *op_values,
+void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const double *op_values,
             const double *log_w, uint32_t flags, blhip_result *res) {
-    validate(p, n_chains, op_values);
+    validate(p_in, n_chains, op_values);
+    // closed-form models without an in-kernel likelihood: their (T, G) table is built on the device, the step kernels
+    // then see a tabulated likelihood
+    blhip_problem p_local = *p_in;
+    const int table_model = (p_in->obs_model >= BLHIP_OM_BERNOULLI && p_in->obs_model <= BLHIP_OM_SCALED_AR1) ? p_in->obs_model : 0;
+    if (table_model) p_local.obs_model = BLHIP_OM_TABLE;
+    const blhip_problem *p = &p_local;
     HIPCHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool evidence_only = flags & BLHIP_EVIDENCE_ONLY;
@@ -672,7 +687,17 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const doub
     if (p->obs_model == BLHIP_OM_TABLE) {
         ctx->likbuf.ensure(sizeof(double) * T * G);
         d_lik = ctx->likbuf.as<double>();
-        HIPCHECK(hipMemcpyAsync(d_lik, p->lik, sizeof(double) * T * G, hipMemcpyHostToDevice, st));
+        if (table_model) {
+            const size_t nd = (size_t)T * p->seg_len * p->data_dim;
+            ctx->databuf.ensure(nd * 8);
+            HIPCHECK(hipMemcpyAsync(ctx->databuf.p, p->data, nd * 8, hipMemcpyHostToDevice, st));
+            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 2048);
+            hipLaunchKernelGGL(lik_table_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, table_model, d_lik, (long long)G, g.n1,
+                               p->ndim, d_m0, d_m1, ctx->databuf.as<double>(), p->seg_len, p->data_dim);
+            HIPCHECK(hipGetLastError());
+        } else {
+            HIPCHECK(hipMemcpyAsync(d_lik, p->lik, sizeof(double) * T * G, hipMemcpyHostToDevice, st));
+        }
     }
     HIPCHECK(hipStreamSynchronize(st));   // host vectors above go out of use
 
@@ -1304,7 +1329,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
-                      &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit})
+                      &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit, &ctx->databuf})
         b->release();
     for (auto &kv : ctx->carry) kv.second.buf.release();
     for (auto &e : ctx->ev)

@@ -141,7 +141,8 @@ __device__ __forceinline__ double sum_partials(const double *p, int n, double *r
     return block_sum(v, red);
 }
 
-enum { OM_POISSON = 1, OM_GAUSSIAN = 2, OM_GAUSSIAN_MEAN = 3, OM_TABLE = 100 };
+enum { OM_POISSON = 1, OM_GAUSSIAN = 2, OM_GAUSSIAN_MEAN = 3, OM_BERNOULLI = 4, OM_LAPLACE = 5, OM_WHITE_NOISE = 6, OM_AR1 = 7,
+       OM_SCALED_AR1 = 8, OM_TABLE = 100 };
 
 // Likelihood of the step's data segment at grid cell (i, j).  NaN data => factor 1 (observationModels.py:53-54).
 template <int OM>
@@ -345,6 +346,41 @@ __global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double 
     }
     const double s = sum_partials(psum + k * nblk, nblk, red);
     if (threadIdx.x == 0) out[k] = s;
+}
+
+// Likelihood table of the closed-form models without an in-kernel path: lik[t][cell] = processedPdf(grid, segment_t)
+// (observationModels.py:35-56: product over the data dimensions; a dimension whose segment holds a NaN counts as 1).  grid = (blockIdx.x chunks, T).
+__global__ __launch_bounds__(NTHREADS) void lik_table_kernel(int om, double *lik, long long G, int n1, int ndim, const double *m0,
+                                                             const double *m1, const double *data, int seg, int d) {
+    const long long t = blockIdx.y;
+    const double *x = data + t * seg * d;              // (seg, d); a NaN makes its data DIMENSION a factor of 1 (:49-54)
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
+        const double g0 = ndim == 2 ? m0[c / n1] : m1[c];
+        const double g1 = ndim == 2 ? m1[c % n1] : 0.0;
+        double L = 1.0;
+        for (int k = 0; k < d; ++k) {
+            const double x0 = x[k], x1 = seg > 1 ? x[d + k] : 0.0;
+            if (x0 != x0 || x1 != x1) continue;
+            double f;
+            if (om == OM_BERNOULLI) {                     // observationModels.py:428-430 (values outside [0, 1] -> 0)
+                const double p = (g0 > 1.0 || g0 < 0.0) ? 0.0 : g0;
+                f = x0 != 0.0 ? p : 1.0 - p;
+            } else if (om == OM_LAPLACE) {                // :635
+                f = exp(-fabs(x0 - g0) / g1) / (2.0 * g1);
+            } else if (om == OM_WHITE_NOISE) {            // :767
+                f = exp(-(x0 * x0) / (2.0 * g0 * g0) - 0.5 * log(2.0 * M_PI * g0 * g0));
+            } else if (om == OM_AR1) {                    // :830-831
+                const double r = x1 - g0 * x0;
+                f = exp(-(r * r) / (2.0 * g1 * g1) - 0.5 * log(2.0 * M_PI * g1 * g1));
+            } else {                                      // OM_SCALED_AR1 :893-896
+                const double sc = g1 * sqrt(1.0 - g0 * g0);
+                const double r = x1 - g0 * x0;
+                f = exp(-(r * r) / (2.0 * sc * sc) - 0.5 * log(2.0 * M_PI * sc * sc));
+            }
+            L *= f;
+        }
+        lik[t * G + c] = L;
+    }
 }
 
 // dst[b][c] = src[b * stride + c] * inv[b]   (BLHIP_CARRY: the filtered distribution of the last step, normalised)

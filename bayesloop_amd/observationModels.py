@@ -6,9 +6,13 @@ same.  What differs is who evaluates the likelihood on the grid during ``fit()``
 
 * ``Poisson``, ``Gaussian``, ``GaussianMean`` are evaluated INSIDE the fused HIP step kernels from the data point and
   per-axis tables (``device_model`` is their C-ABI code; reference pdfs at observationModels.py:502, 566-567, 705-706).
-* every other model -- the remaining closed-form ones below and any user subclass with a ``pdf(grid, dataSegment)``
-  method (the reference's duck-typed plug-in interface, observationModels.py:35-56) -- is evaluated once on the host
-  with the model's own ``pdf`` and uploaded as a (T, G) likelihood table; the recursion itself still runs on the GPU.
+* ``Bernoulli``, ``Laplace``, ``WhiteNoise``, ``AR1``, ``ScaledAR1``: their (T, G) likelihood table is built ON THE DEVICE
+  from the data (``blk::lik_table_kernel``; reference pdfs at observationModels.py:428-430, 635, 767, 830-831, 893-896):
+  no host evaluation, no upload.
+* any other model -- user subclasses with a ``pdf(grid, dataSegment)`` method (the reference's duck-typed plug-in
+  interface, observationModels.py:35-56), including subclasses that override the ``pdf`` of a model above -- is
+  evaluated once on the host with the model's own ``pdf`` and uploaded as a (T, G) likelihood table; the recursion
+  itself still runs on the GPU.
 """
 from __future__ import annotations
 
@@ -134,6 +138,8 @@ class GaussianMean(ObservationModel):
 class Bernoulli(ObservationModel):
     """Bernoulli trials with success probability p (reference observationModels.py:394-464)."""
 
+    device_model = _abi.OM_BERNOULLI    # likelihood table built on the device (include/blhip.h)
+
     def __init__(self, name='p', value=None, prior='Jeffreys'):
         self.name = 'Bernoulli'
         self.segmentLength = 1
@@ -156,6 +162,8 @@ class Bernoulli(ObservationModel):
 
 class Laplace(ObservationModel):
     """Laplace observations with mean and scale (reference observationModels.py:598-663)."""
+
+    device_model = _abi.OM_LAPLACE    # likelihood table built on the device (include/blhip.h)
 
     def __init__(self, name1='mean', value1=None, name2='scale', value2=None, prior='Jeffreys'):
         self.name = 'Laplace observations'
@@ -182,6 +190,8 @@ class Laplace(ObservationModel):
 class WhiteNoise(ObservationModel):
     """Zero-mean Gaussian noise with amplitude std (reference observationModels.py:731-792)."""
 
+    device_model = _abi.OM_WHITE_NOISE    # likelihood table built on the device (include/blhip.h)
+
     def __init__(self, name='std', value=None, prior='Jeffreys'):
         self.name = 'White noise process (Zero-mean Gaussian)'
         self.segmentLength = 1
@@ -203,6 +213,8 @@ class WhiteNoise(ObservationModel):
 class AR1(ObservationModel):
     """Auto-regressive process of first order, segment length 2 (reference observationModels.py:795-852)."""
 
+    device_model = _abi.OM_AR1    # likelihood table built on the device (include/blhip.h)
+
     def __init__(self, name1='correlation coefficient', value1=None, name2='noise amplitude', value2=None, prior=None):
         self.name = 'Autoregressive process of first order (AR1)'
         self.segmentLength = 2
@@ -223,6 +235,8 @@ class AR1(ObservationModel):
 
 class ScaledAR1(ObservationModel):
     """AR1 parametrised by the standard deviation of the observations (reference observationModels.py:855-917)."""
+
+    device_model = _abi.OM_SCALED_AR1    # likelihood table built on the device (include/blhip.h)
 
     def __init__(self, name1='correlation coefficient', value1=None, name2='standard deviation', value2=None,
                  prior=None):
@@ -270,3 +284,12 @@ class NumPy(ObservationModel):
 
     def pdf(self, grid, dataSegment):
         return self.function(dataSegment[0], *grid)
+
+
+def device_code(om):
+    """C-ABI code of the observation model, or OM_TABLE when its ``pdf`` is not the built-in one (user subclass)."""
+    for cls in type(om).__mro__:
+        code = cls.__dict__.get('device_model')
+        if code is not None:
+            return code if getattr(type(om), 'pdf', None) is cls.__dict__.get('pdf', None) and code != _abi.OM_TABLE else _abi.OM_TABLE
+    return _abi.OM_TABLE

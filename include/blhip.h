@@ -44,6 +44,12 @@ enum {
     BLHIP_OM_POISSON       = 1,   /* observationModels.py:502      1 parameter  (rate)            */
     BLHIP_OM_GAUSSIAN      = 2,   /* observationModels.py:566-567  2 parameters (mean, std)       */
     BLHIP_OM_GAUSSIAN_MEAN = 3,   /* observationModels.py:705-706  1 parameter  (mean); data (T,1,2) = (value, std) */
+    /* closed-form models whose likelihood table (T,G) is built ON THE DEVICE from the data (no host pdf, no upload): */
+    BLHIP_OM_BERNOULLI     = 4,   /* observationModels.py:419-439  1 parameter  (p)                               */
+    BLHIP_OM_LAPLACE       = 5,   /* observationModels.py:624-635  2 parameters (mean, scale)                     */
+    BLHIP_OM_WHITE_NOISE   = 6,   /* observationModels.py:756-767  1 parameter  (sigma)                           */
+    BLHIP_OM_AR1           = 7,   /* observationModels.py:819-831  2 parameters (rho, sigma); seg_len 2           */
+    BLHIP_OM_SCALED_AR1    = 8,   /* observationModels.py:881-896  2 parameters (rho, sigma); seg_len 2           */
     BLHIP_OM_TABLE         = 100  /* likelihood evaluated by the caller (any ObservationModel.pdf): lik (T,G) */
 };
 

@@ -78,6 +78,28 @@ CASES = {
                          tm=('Static',), kat=-12.430583625665736),
     'kat_gaussianmean': dict(study='Study', data=GM5, om=('GaussianMean', [('mu', _g('oint', 0, 1, 100))], 'default'),
                              tm=('Static',), kat=-6.3333705075036226),
+    # --- reference tests/test_observationmodels.py:126-220: the closed-form models whose likelihood table is built on the device
+    'kat_bernoulli': dict(study='Study', data=D10100, om=('Bernoulli', [('p', _g('oint', 0, 1, 100))], 'default'),
+                          tm=('Static',), kat=-4.3494298741972859),
+    'kat_laplace': dict(study='Study', data=D10100, om=('Laplace', [('mu', None), ('b', None)], 'default'),
+                        tm=('Static',), kat=-10.658573159),
+    'kat_whitenoise': dict(study='Study', data=D10100, om=('WhiteNoise', [('std', _g('oint', 0, 1, 100))], 'default'),
+                           tm=('Static',), kat=-6.8161638661444073),
+    'kat_ar1': dict(study='Study', data=D10100, om=('AR1', [('rho', _g('oint', -1, 1, 100)), ('sigma', _g('oint', 0, 1, 100))], 'default'),
+                    tm=('Static',), kat=-4.3291291450463421),
+    'kat_scaledar1': dict(study='Study', data=D10100,
+                          om=('ScaledAR1', [('rho', _g('oint', -1, 1, 100)), ('sigma', _g('oint', 0, 1, 100))], 'default'),
+                          tm=('Static',), kat=-4.4178639067800738),
+    'laplace_grw_2d': dict(study='Study', data=('series', 71, 12),
+                           om=('Laplace', [('mu', _g('cint', -4, 4, 60)), ('b', _g('oint', 0, 3, 44))], 'default'),
+                           tm=('Combined', [('GRW', 's1', 0.3, 'mu', None), ('GRW', 's2', 0.1, 'b', None)])),
+    'whitenoise_multidim_nan': dict(study='Study', data=('series2d', 72, 10), om=('WhiteNoise', [('std', _g('oint', 0, 3, 300))], 'default'),
+                                    tm=('GRW', 's', 0.05, 'std', None)),
+    'scaledar1_hyper': dict(study='HyperStudy', data=('series', 73, 14),
+                            om=('ScaledAR1', [('rho', _g('oint', -1, 1, 40)), ('sigma', _g('oint', 0, 3, 36))], 'default'),
+                            tm=('GRW', 's', _g('cint', 0.02, 0.2, 4), 'rho', None)),
+    'bernoulli_changepoint': dict(study='Study', data=np.array([1, 1, 0, 1, 1, 0, 0, 0, 1, 0, 0, 0]),
+                                  om=('Bernoulli', [('p', _g('oint', 0, 1, 200))], 'default'), tm=('ChangePoint', 'tc', 5, None)),
     # --- reference tests/test_study.py:32-52 (default 1000-pt estimated grid), :80-100 (array prior), :102-...
     'kat_study_1hp': dict(study='Study', data=D15, om=('Poisson', [('rate', None)], 'default'),
                           tm=('GRW', 'sigma', 0.1, 'rate', None), kat=-10.4337420351, kat_decimal=2),

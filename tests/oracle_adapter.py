@@ -34,6 +34,9 @@ def estimate_values(om, pname_index, raw):
         obs = np.array([d[0] for d in raw])
         lo, hi = np.nanmin(obs), np.nanmax(obs)
         return orc.oint(lo - (hi - lo), hi + (hi - lo), 1000)
+    if om == 'laplace':                                  # observationModels.py:637-652
+        mean, std = np.nanmean(np.ravel(raw)), np.nanstd(np.ravel(raw))
+        return orc.cint(mean - 2 * std, mean + 2 * std, 200) if pname_index == 0 else orc.oint(0, np.sqrt(2) * std, 200)
     raise ValueError(om)
 
 
