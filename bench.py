@@ -2,7 +2,7 @@
 """
 bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|fwd2048] [--no-extra] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|c5|fwd2048] [--no-extra] [--no-cpu]
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
@@ -11,6 +11,7 @@ Workloads (synthetic data, seeds fixed):
            cint(0, 0.3, 512), T = 256, FULL fit (forward + backward + evidence-weighted average posterior).
            The headline at every N: the 512 hyper-grid points are sharded over the N ranks in np.array_split chunks
            (strong scaling: total work fixed), one gather + one reduce over RCCL at the end.
+  c5       ChangepointStudy, 512 x 512 grid, T = 1000, 256 candidate change-points, full fit     (sharded like c4)
   c3       Study, 1024 x 1024 grid, T = 2000, GRW x GRW separable stencil, full fit             (N = 1)
   c2       Study, 4096-point 1-D GaussianMean grid, T = 10 000, full fit (latency-bound)       (N = 1)
   fwd2048  Study, 2048 x 2048 grid, T = 200, evidenceOnly: the fused-forward-step roofline point (N = 1)
@@ -72,6 +73,17 @@ def make_study(bl, name, comm=None, scale=1.0):
               silent=True)
         return S, dict(silent=True), n * T, dict(workload='C2 Study 4096-pt 1-D GaussianMean grid, T=10000, full fit',
                                                   grid=[n], T=T, n_hyper=1, mode='full')
+    if name == 'c5':
+        n, T, nh = 512, 1000, 256
+        x = series(5, T)
+        x[500:] += 2.0
+        S = bl.ChangepointStudy(silent=True)
+        S.loadData(x, silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
+              bl.tm.ChangePoint('tChange', np.arange(3, 1000, 4)[:nh]), silent=True)
+        S.communicator = comm
+        return S, dict(silent=True), n * n * T * nh, dict(workload='C5 ChangepointStudy 512x512 grid, T=1000, 256 candidate '
+                                                           'change-points, full fit', grid=[n, n], T=T, n_hyper=nh, mode='full')
     if name == 'fwd2048':
         n, T = 2048, 200
         S = bl.Study(silent=True)
@@ -219,7 +231,7 @@ def main():
                    log_evidence=float(S.logEvidence), roofline=roof, kernels=rf, device=eng.device_name())
         if not args.no_extra and world == 1:
             extra = {}
-            for name in ('fwd2048', 'c3', 'c2'):
+            for name in ('fwd2048', 'c3', 'c2', 'c5'):
                 if name == args.workload:
                     continue
                 try:
