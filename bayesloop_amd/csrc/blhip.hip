@@ -106,8 +106,35 @@ namespace {
 
 struct TapTable {
     std::vector<double> w;       // concatenated half kernels: w[off + k], k = 0..lw
-    std::vector<int> off, lw;
+    std::vector<int> off, lw, lw2;   // lw2: axis-1 radius of a dense 2-D kernel (0 for 1-D tap sets)
     std::map<std::pair<int, double>, int> index;   // (internal axis, normed sigma) -> id
+    std::map<std::tuple<double, double, double>, int> index2;   // dense kernels: (ns1, ns2, rho) -> id
+
+    // BivariateRandomWalk.createKernel (transitionModels.py:898-911): bivariate normal density on the integer lattice
+    // |x| <= 3 ceil(ns1), |y| <= 3 ceil(ns2), normalised to sum 1 (the density's own constant cancels); row-major
+    int get2d(double ns1, double ns2, double rho) {
+        auto key = std::make_tuple(ns1, ns2, rho);
+        auto it = index2.find(key);
+        if (it != index2.end()) return it->second;
+        const int r0 = 3 * (int)std::ceil(ns1), r1 = 3 * (int)std::ceil(ns2);
+        std::vector<double> k((size_t)(2 * r0 + 1) * (2 * r1 + 1));
+        double sum = 0.0;
+        for (int a = -r0; a <= r0; ++a)
+            for (int b = -r1; b <= r1; ++b) {
+                const double x = a, y = b;
+                const double q = (x * x / (ns1 * ns1) - 2.0 * rho * x * y / (ns1 * ns2) + y * y / (ns2 * ns2)) / (2.0 * (1.0 - rho * rho));
+                const double v = std::exp(-q);
+                k[(size_t)(a + r0) * (2 * r1 + 1) + (b + r1)] = v;
+                sum += v;
+            }
+        const int id = (int)off.size();
+        off.push_back((int)w.size());
+        lw.push_back(r0);
+        lw2.push_back(r1);
+        for (double v : k) w.push_back(v / sum);
+        index2[key] = id;
+        return id;
+    }
 
     // SciPy's kernel: lw = int(4 sd + 0.5); phi = exp(-0.5/sd^2 x^2); phi / sum(phi)   (_filters.py, gaussian_filter1d)
     int get(int axis, double ns) {
@@ -127,6 +154,7 @@ struct TapTable {
             id = (int)off.size();
             off.push_back((int)w.size());
             lw.push_back(r);
+            lw2.push_back(0);
             for (int k = 0; k <= r; ++k) w.push_back(phi[r + k] / sum);
         }
         index[key] = id;
@@ -405,8 +433,12 @@ void validate(const blhip_problem *p, int64_t n_chains, const double *op_values)
             has_cp = true;
         } else if (op.kind == BLHIP_OP_INDEPENDENT) {
             if (!p->indep_prior) fail("INDEPENDENT op needs indep_prior");
+        } else if (op.kind == BLHIP_OP_BIVARIATE) {
+            if (p->ndim != 2) fail("BIVARIATE op %d needs a 2-parameter grid", k);
+            if (k + 2 >= p->n_ops || p->ops[k + 1].kind != BLHIP_OP_BIVARIATE_ARG || p->ops[k + 2].kind != BLHIP_OP_BIVARIATE_ARG)
+                fail("BIVARIATE op %d must be followed by two BIVARIATE_ARG ops (sigma2, rho)", k);
         } else if (op.kind != BLHIP_OP_STATIC && op.kind != BLHIP_OP_REGIMESWITCH && op.kind != BLHIP_OP_BREAKPOINT &&
-                   op.kind != BLHIP_OP_NOTEQUAL) {
+                   op.kind != BLHIP_OP_NOTEQUAL && op.kind != BLHIP_OP_BIVARIATE_ARG) {
             fail("op %d: unknown kind %d", k, op.kind);
         }
     }
@@ -524,6 +556,13 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                 time_dependent = true;
             } else if (op.kind == BLHIP_OP_REGIMESWITCH || op.kind == BLHIP_OP_NOTEQUAL) {
                 prog.has_clamp = true;
+            } else if (op.kind == BLHIP_OP_BIVARIATE) {
+                // transitionModels.py:881-885; a singular covariance makes scipy.stats.multivariate_normal raise in the reference
+                const double n1 = val[k] / p->lattice[0], n2 = val[k + 1] / p->lattice[1], rho = val[k + 2];
+                if (!(n1 > 0.0) || !(n2 > 0.0) || !(std::fabs(rho) < 1.0))
+                    fail("chain %lld: BivariateRandomWalk needs sigma1, sigma2 > 0 and |rho| < 1", (long long)(c0 + b));
+                op_tap[k] = taps.get2d(n1, n2, rho);
+                prog.has_clamp = true;                       // (mode 4 of the generic kernel: dense kernel + renormalisation)
             }
         }
         // the transition from one step to the next, evaluated at time stamp tau (list order, transitionModels.py:645-649)
@@ -543,6 +582,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                     case BLHIP_OP_GRW: {
                         if (op_tap[k] < 0) break;
                         if (sp.cmode == 2) fail("a GaussianRandomWalk after a RegimeSwitch in one combined model is not supported");
+                        if (sp.cmode == 4) fail("a GaussianRandomWalk combined with a BivariateRandomWalk is not supported");
                         int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
                         if (slot >= 0)
                             fail("two GaussianRandomWalk ops on the same parameter in one combined model are not supported");
@@ -557,6 +597,13 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                         break;
                     case BLHIP_OP_INDEPENDENT:                                    // transitionModels.py:351-360
                         sp = StepProg(); sp.kind = SRC_INDEP; filtered = false;
+                        break;
+                    case BLHIP_OP_BIVARIATE:                                      // transitionModels.py:880-891
+                        if (sp.cmode != 0 || filtered)
+                            fail("a BivariateRandomWalk combined with another model acting on the same step is not supported");
+                        sp.cmode = 4;
+                        sp.t0 = op_tap[k];
+                        filtered = true;
                         break;
                     case BLHIP_OP_NOTEQUAL:                                       // transitionModels.py:462-471
                         if (sp.cmode != 0 || filtered)
@@ -579,6 +626,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                     if (op.kind == BLHIP_OP_CHANGEPOINT && (op.flags & 1) && tau == val[k]) { sp = StepProg(); sp.kind = SRC_RESET; }
                 }
             if (sp.t0 >= 0) prog.LW0 = std::max(prog.LW0, taps.lw[sp.t0]);
+            if (sp.cmode == 4) prog.LW1 = std::max(prog.LW1, taps.lw2[sp.t0]);
             if (sp.t1 >= 0) prog.LW1 = std::max(prog.LW1, taps.lw[sp.t1]);
             return sp;
         };
@@ -820,7 +868,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         const size_t nT = (size_t)T * B;
         taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
         size_t mb = 4 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
-                    2 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * NTHREADS);
+                    3 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * NTHREADS);
         ctx->meta.ensure(mb);
         cur = ctx->meta.as<char>();
         unsigned char *d_kindF = carve<unsigned char>(cur, nT), *d_kindB = carve<unsigned char>(cur, nT);
@@ -831,6 +879,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         int *d_orderF = carve<int>(cur, nT), *d_orderB = carve<int>(cur, nT);
         double *d_taps = carve<double>(cur, taps.w.size() + 1);
         int *d_off = carve<int>(cur, taps.off.size() + 1), *d_lw = carve<int>(cur, taps.off.size() + 1);
+        int *d_lw2 = carve<int>(cur, taps.off.size() + 1);
         double *d_invN = carve<double>(cur, nT);
         double *d_inv_tmp = carve<double>(cur, nT);
         double *d_w = carve<double>(cur, B);
@@ -870,6 +919,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             HIPCHECK(hipMemcpyAsync(d_taps, taps.w.data(), taps.w.size() * 8, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_off, taps.off.data(), taps.off.size() * 4, hipMemcpyHostToDevice, st));
             HIPCHECK(hipMemcpyAsync(d_lw, taps.lw.data(), taps.lw.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_lw2, taps.lw2.data(), taps.lw2.size() * 4, hipMemcpyHostToDevice, st));
         }
 
         // --- state ---
@@ -904,7 +954,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         P.n0 = g.n0; P.n1 = g.n1; P.TI = tile.TI; P.TJ = tile.TJ; P.LW0 = tile.LW0; P.LW1 = tile.LW1;
         P.tiles_i = tile.tiles_i; P.tiles_j = tile.tiles_j; P.nblk = tile.nblk; P.ndim = p->ndim; P.d = d;
         P.rec_len = rec_len; P.shared[SRC_PREV] = nullptr; P.shared[SRC_PRIOR] = d_prior; P.shared[SRC_RESET] = d_reset;
-        P.shared[SRC_UNIFORM] = d_uniform; P.shared[SRC_INDEP] = d_indep; P.taps = d_taps; P.tap_off = d_off; P.tap_lw = d_lw;
+        P.shared[SRC_UNIFORM] = d_uniform; P.shared[SRC_INDEP] = d_indep; P.taps = d_taps; P.tap_off = d_off; P.tap_lw = d_lw; P.tap_lw2 = d_lw2;
         P.m0 = d_m0; P.m1 = d_m1; P.colA = d_colA; P.colB = d_colB; P.chains = (int)B;
         P.prev_nblk = tile.nblk;
 

@@ -40,9 +40,11 @@ struct StepParams {
     const unsigned char *srckind;                 // [B]
     const int *tap0, *tap1;                       // [B] tap-set ids per internal axis, -1 = identity
     const unsigned char *cmode; const double *limit;   // [B] clamp mode: 0 none, 1 RegimeSwitch on the source, 2 RegimeSwitch after the stencil,
-                                                       //     3 NotEqual (invert + clamp the source); nullptr if the batch has none
+                                                       //     3 NotEqual (invert + clamp the source), 4 dense 2-D kernel tap0 with zero boundary, renormalised
+                                                       //     (BivariateRandomWalk); nullptr if the batch has none
     // tap table
     const double *taps; const int *tap_off; const int *tap_lw;
+    const int *tap_lw2;          // dense 2-D kernels (clamp mode 4): axis-1 radius; weights at taps[off + a * (2 lw2 + 1) + b]
     // lazy normalisation
     const double *psum_prev; int prev_slot; int prev_nblk;   // partials of the producing step [B][NRED][prev_nblk]
     double *psum_out;                                         // [B][NRED][nblk]
@@ -194,10 +196,13 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     double *red = v_tile + (size_t)P.TI * pitch;
 
     const int kind = P.srckind[b];
-    const int t0 = P.tap0[b], t1 = P.tap1[b];
+    const int cm = P.cmode ? P.cmode[b] : 0;
+    const double lim = P.cmode ? P.limit[b] : 0.0;
+    const bool dense = cm == 4;                    // BivariateRandomWalk: tap0 is a dense (2 lw0 + 1) x (2 lw1 + 1) kernel
+    const int t0 = P.tap0[b], t1 = dense ? -1 : P.tap1[b];
     const int lw0 = t0 >= 0 ? P.tap_lw[t0] : 0;
-    const int lw1 = t1 >= 0 ? P.tap_lw[t1] : 0;
-    const double *w0 = t0 >= 0 ? P.taps + P.tap_off[t0] : nullptr;   // w[0] = centre, w[k] = offset +-k
+    const int lw1 = dense ? P.tap_lw2[t0] : (t1 >= 0 ? P.tap_lw[t1] : 0);
+    const double *w0 = t0 >= 0 ? P.taps + P.tap_off[t0] : nullptr;   // w[0] = centre, w[k] = offset +-k (dense: row-major kernel)
     const double *w1 = t1 >= 0 ? P.taps + P.tap_off[t1] : nullptr;
     const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
 
@@ -207,8 +212,6 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
 
     // lazy normaliser of the producing step (every block sums the same partials in the same order)
     double scale = 1.0, kappa = 1.0;
-    const int cm = P.cmode ? P.cmode[b] : 0;
-    const double lim = P.cmode ? P.limit[b] : 0.0;
     double ne_max = 0.0, ne_inv = 0.0;             // NotEqual: (max - x) / (G max - sum x) of the producing step's state
     if (MODE != MODE_FILTER && kind == SRC_PREV) {
         const double s = sum_partials(P.psum_prev + ((long long)b * NRED + P.prev_slot) * P.prev_nblk, P.prev_nblk, red);
@@ -231,12 +234,15 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
 
     // ---- phase 1: source tile + halo -> LDS (reflect boundary resolved here; a source clamp is applied here too) ------
     for (int r = P.LW0 - lw0 + y; r < P.LW0 + th + lw0; r += YN) {
-        const int gi = reflect(i0 - P.LW0 + r, P.n0);
+        const int ri = i0 - P.LW0 + r;
+        const int gi = reflect(ri, P.n0);
         const double *row = src + (long long)gi * P.n1;
         double *dstrow = in_tile + (size_t)r * pitch;
         for (int c = P.LW1 - lw1 + x; c < P.LW1 + tw + lw1; c += XW) {
-            const int gj = reflect(j0 - P.LW1 + c, P.n1);
+            const int cj = j0 - P.LW1 + c;
+            const int gj = reflect(cj, P.n1);
             double v = row[gj];
+            if (dense && ((unsigned)ri >= (unsigned)P.n0 || (unsigned)cj >= (unsigned)P.n1)) v = 0.0;   // convolve2d zero fill
             if (cm == 1) { v *= scale; v = v < lim ? lim : v; }
             if (cm == 3) { v = (ne_max - v) * ne_inv; v = v < lim ? lim : v; }                 // transitionModels.py:465-467
             dstrow[c] = v;
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
 
     // ---- phase 2: filter along axis 0 (rows), SciPy's symmetric correlate1d order -------------------------------
     const double *hsrc = in_tile + (size_t)P.LW0 * pitch;      // rows [0, th) of the un-filtered tile
-    if (lw0 > 0) {
+    if (lw0 > 0 && !dense) {
         for (int r = y; r < th; r += YN) {
             const double *cen = in_tile + (size_t)(r + P.LW0) * pitch;
             for (int c = P.LW1 - lw1 + x; c < P.LW1 + tw + lw1; c += XW) {
@@ -275,7 +281,15 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
         for (int r = y; r < th; r += YN) {
             const double *cen = hsrc + (size_t)r * pitch + P.LW1 + c;
             double o;
-            if (lw1 > 0) {
+            if (dense) {                                   // transitionModels.py:889: convolve2d(posterior, kernel, 'same')
+                o = 0.0;                                   // (the kernel is point-symmetric: convolution = correlation)
+                const int kw = 2 * lw1 + 1;
+                for (int a = -lw0; a <= lw0; ++a) {
+                    const double *line = cen + (long long)a * pitch;
+                    const double *wl = w0 + (a + lw0) * kw + lw1;
+                    for (int q = -lw1; q <= lw1; ++q) o = fma(wl[q], line[q], o);
+                }
+            } else if (lw1 > 0) {
                 o = cen[0] * w1[0];
                 for (int k = lw1; k >= 1; --k) o += (cen[-k] + cen[k]) * w1[k];
             } else {

@@ -12,6 +12,7 @@ both directions, inside the fused HIP step kernels:
     ChangePoint             -> CHANGEPOINT(tChange): restart from the (re-normalised) prior at one time stamp
     RegimeSwitch            -> REGIMESWITCH(log10pMin): clamp from below and renormalise
     NotEqual                -> NOTEQUAL(log10pMin): max(p) - p, renormalise, clamp from below, renormalise
+    BivariateRandomWalk     -> BIVARIATE(sigma1) + 2 x BIVARIATE_ARG(sigma2, rho): dense 2-D convolution, zero boundary, renormalised
     Independent             -> INDEPENDENT: restart from the normalised prior at every step
     CombinedTransitionModel -> concatenation of the sub-models' programs
     SerialTransitionModel   -> the sub-models' programs tagged with their segment + BREAKPOINT / boundary CHANGEPOINT ops
@@ -170,6 +171,29 @@ class NotEqual(TransitionModel):
         return [(_abi.OP_NOTEQUAL, 0, self, 0, -1, 0)]
 
 
+class BivariateRandomWalk(TransitionModel):
+    """Correlated Gaussian fluctuations of both parameters of a two-parameter observation model: dense 2-D convolution
+    with a bivariate normal kernel, zero boundary, renormalised (reference transitionModels.py:843-911)."""
+
+    def __init__(self, name1='sigma1', value1=None, name2='sigma2', value2=None, name3='rho', value3=None,
+                 prior=(None, None, None)):
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = [name1, name2, name3]
+        self.hyperParameterValues = [_as_values(value1), _as_values(value2), _as_values(value3)]
+        self.prior = prior
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Bivariate random walk'
+
+    def _program(self, parameterNames):
+        if len(parameterNames) != 2:
+            raise ConfigurationError('BivariateRandomWalk needs an observation model with exactly two parameters.')
+        return [(_abi.OP_BIVARIATE, 0, self, 0, -1, 0), (_abi.OP_BIVARIATE_ARG, 0, self, 1, -1, 0),
+                (_abi.OP_BIVARIATE_ARG, 0, self, 2, -1, 0)]
+
+
 class Independent(TransitionModel):
     """Independent observations: the (normalised) prior is restored at every step (reference transitionModels.py:320-363)."""
 
@@ -258,7 +282,7 @@ def _not_yet(name, where):
     class _Unavailable(TransitionModel):
         def __init__(self, *args, **kwargs):
             raise NotImplementedError('bl.tm.{} (reference {}) is not available on the MI355X engine yet; this build '
-                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, NotEqual, Independent, Combined- and '
+                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, NotEqual, BivariateRandomWalk, Independent, Combined- and '
                                       'SerialTransitionModel (with BreakPoint).'
                                       .format(name, where))
     _Unavailable.__name__ = name
@@ -268,4 +292,3 @@ def _not_yet(name, where):
 # rows of SURVEY.md section 8(f): not on the hot path named by BASELINE.json
 AlphaStableRandomWalk = _not_yet('AlphaStableRandomWalk', 'transitionModels.py:121-260')
 Deterministic = _not_yet('Deterministic', 'transitionModels.py:477-606')
-BivariateRandomWalk = _not_yet('BivariateRandomWalk', 'transitionModels.py:843-911')

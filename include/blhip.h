@@ -62,8 +62,12 @@ enum {
     BLHIP_OP_INDEPENDENT  = 4,    /* transitionModels.py:339-363  restart from the normalised prior at every step */
     BLHIP_OP_BREAKPOINT   = 5,    /* transitionModels.py:821-840  value = tBreak: boundary between two sub-models of a
                                      SerialTransitionModel (transitionModels.py:756-786) */
-    BLHIP_OP_NOTEQUAL     = 6     /* transitionModels.py:450-474  value = log10 pMin: max(p) - p, renormalise, clamp from
+    BLHIP_OP_NOTEQUAL     = 6,    /* transitionModels.py:450-474  value = log10 pMin: max(p) - p, renormalise, clamp from
                                      below, renormalise */
+    BLHIP_OP_BIVARIATE    = 7,    /* transitionModels.py:872-911  value = sigma1; MUST be followed by two BIVARIATE_ARG ops
+                                     carrying sigma2 and rho: dense 2-D convolution with the bivariate normal kernel on
+                                     |x| <= 3 ceil(sigma / lattice), zero boundary, renormalised (2-D grids only) */
+    BLHIP_OP_BIVARIATE_ARG = 8    /* value = sigma2 (first) / rho (second) of the BIVARIATE op before it */
 };
 
 /* A SerialTransitionModel (transitionModels.py:665-818) is flattened into the same program: the ops of its n sub-models

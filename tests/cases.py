@@ -198,6 +198,11 @@ CASES = {
     # reference tests/test_transitionmodels.py:96-108, :110-122, :139-161
     'kat_regimeswitch': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                              tm=('RS', 'p_min', -3, None), kat=-10.372866559561402),
+    # reference tests/test_transitionmodels.py:53-66
+    'kat_bivariate': dict(study='Study', data=D15, om=('Gaussian', [('mu', _g('oint', 0, 6, 20)), ('sigma', _g('oint', 0, 2, 20))], 'default'),
+                          tm=('Bivariate', 'sigma1', 1., 'sigma2', 0.1, 'rho', 0.5), kat=-7.330706514472251),
+    'bivariate_hyper': dict(study='HyperStudy', data=('series', 81, 8), om=gauss2d(40, -5, 5, 3),
+                            tm=('Bivariate', 's1', [0.3, 0.6], 's2', 0.15, 'rho', [-0.4, 0.0, 0.7])),
     # reference tests/test_transitionmodels.py:124-136
     'kat_notequal': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                          tm=('NE', 'p_min', -3, None), kat=-10.569099863134156),
@@ -355,6 +360,9 @@ def make_tm(bl, spec):
         return bl.tm.RegimeSwitch(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'Independent':
         return bl.tm.Independent()
+    if kind == 'Bivariate':
+        return bl.tm.BivariateRandomWalk(spec[1], make_values(bl, spec[2]), spec[3], make_values(bl, spec[4]),
+                                         spec[5], make_values(bl, spec[6]))
     if kind == 'NE':
         return bl.tm.NotEqual(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'BreakPoint':

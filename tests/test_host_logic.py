@@ -83,7 +83,7 @@ def test_configuration_errors():
     with pytest.raises(bl.ConfigurationError):
         bl.tm.GaussianRandomWalk('sigma', 0.1)          # no target
     with pytest.raises(NotImplementedError):
-        bl.tm.BivariateRandomWalk('s1', 0.1, 's2', 0.1, 'rho', 0.)
+        bl.tm.AlphaStableRandomWalk('c', 0.2, 'alpha', 1.5, target='rate')
     S.setTM(bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s', 0.1, target='rate'),
                                           bl.tm.GaussianRandomWalk('s', 0.2, target='rate')), silent=True)
     with pytest.raises(bl.ConfigurationError):
