@@ -22,7 +22,7 @@ from .helper import flatten
 from .observationModels import ObservationModel, device_code
 from .preprocessing import movingWindow
 from .transitionModels import (TransitionModel, ChangePoint, CombinedTransitionModel, SerialTransitionModel,
-                               BivariateRandomWalk)
+                               BivariateRandomWalk, AlphaStableRandomWalk)
 
 COAL_MINING = (5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4, 4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2,
                1, 3, 2, 2, 1, 1, 1, 1, 3, 0, 0, 1, 0, 1, 1, 0, 0, 3, 1, 0, 3, 2, 2, 0, 1, 1, 1, 0, 1, 0, 1, 0, 0, 0, 2, 1,
@@ -578,7 +578,7 @@ class HyperStudy(Study):
         priors = []
         for m, k, name in self._hyperSlots():
             prior = getattr(m, 'prior', None)
-            priors.append(prior[k] if isinstance(m, (SerialTransitionModel, BivariateRandomWalk)) else prior)
+            priors.append(prior[k] if isinstance(m, (SerialTransitionModel, BivariateRandomWalk, AlphaStableRandomWalk)) else prior)
         return priors
 
     def _createHyperGrid(self, silent=False):

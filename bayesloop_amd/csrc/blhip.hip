@@ -110,6 +110,31 @@ struct TapTable {
     std::map<std::pair<int, double>, int> index;   // (internal axis, normed sigma) -> id
     std::map<std::tuple<double, double, double>, int> index2;   // dense kernels: (ns1, ns2, rho) -> id
 
+    // AlphaStableRandomWalk.createKernel (transitionModels.py:196-240) for an axis of n points: k[d], d = 0 .. n-1, of the
+    // inverse real DFT (numpy.fft.irfft) of exp(-|c w|^alpha) sampled at m = int(3n/2 + 1) points of [0, pi]; the reference's
+    // roll + 3x zero padding + fftconvolve(mode='same') (:233-260) is out[i] = sum_j in[j] k[|i - j|] inside the grid
+    std::map<std::tuple<int, double, double, int>, int> index_as;
+    int get_alphastable(int axis, double c, double alpha, int n) {
+        auto key = std::make_tuple(axis, c, alpha, n);
+        auto it = index_as.find(key);
+        if (it != index_as.end()) return it->second;
+        const int m = (int)(3.0 * n / 2.0 + 1.0), K = 2 * (m - 1);
+        std::vector<double> X(m);
+        for (int q = 0; q < m; ++q) X[q] = std::exp(-std::pow(std::fabs(c * (M_PI * q / (m - 1))), alpha));
+        const int id = (int)off.size();
+        off.push_back((int)w.size());
+        lw.push_back(n - 1);
+        lw2.push_back(0);
+        for (int j = 0; j < n; ++j) {
+            long double acc = X[0] + ((j & 1) ? -X[m - 1] : X[m - 1]);
+            for (int q = 1; q < m - 1; ++q)
+                acc += 2.0L * X[q] * std::cos(2.0L * (long double)M_PIl * (long double)(((long long)j * q) % K) / (long double)K);
+            w.push_back((double)(acc / K));
+        }
+        index_as[key] = id;
+        return id;
+    }
+
     // BivariateRandomWalk.createKernel (transitionModels.py:898-911): bivariate normal density on the integer lattice
     // |x| <= 3 ceil(ns1), |y| <= 3 ceil(ns2), normalised to sum 1 (the density's own constant cancels); row-major
     int get2d(double ns1, double ns2, double rho) {
@@ -433,12 +458,16 @@ void validate(const blhip_problem *p, int64_t n_chains, const double *op_values)
             has_cp = true;
         } else if (op.kind == BLHIP_OP_INDEPENDENT) {
             if (!p->indep_prior) fail("INDEPENDENT op needs indep_prior");
+        } else if (op.kind == BLHIP_OP_ALPHASTABLE) {
+            if (op.axis < 0 || op.axis >= p->ndim) fail("ALPHASTABLE op %d: axis %d out of range", k, op.axis);
+            if (k + 1 >= p->n_ops || p->ops[k + 1].kind != BLHIP_OP_ALPHASTABLE_ARG)
+                fail("ALPHASTABLE op %d must be followed by an ALPHASTABLE_ARG op (alpha)", k);
         } else if (op.kind == BLHIP_OP_BIVARIATE) {
             if (p->ndim != 2) fail("BIVARIATE op %d needs a 2-parameter grid", k);
             if (k + 2 >= p->n_ops || p->ops[k + 1].kind != BLHIP_OP_BIVARIATE_ARG || p->ops[k + 2].kind != BLHIP_OP_BIVARIATE_ARG)
                 fail("BIVARIATE op %d must be followed by two BIVARIATE_ARG ops (sigma2, rho)", k);
         } else if (op.kind != BLHIP_OP_STATIC && op.kind != BLHIP_OP_REGIMESWITCH && op.kind != BLHIP_OP_BREAKPOINT &&
-                   op.kind != BLHIP_OP_NOTEQUAL && op.kind != BLHIP_OP_BIVARIATE_ARG) {
+                   op.kind != BLHIP_OP_NOTEQUAL && op.kind != BLHIP_OP_BIVARIATE_ARG && op.kind != BLHIP_OP_ALPHASTABLE_ARG) {
             fail("op %d: unknown kind %d", k, op.kind);
         }
     }
@@ -556,6 +585,12 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                 time_dependent = true;
             } else if (op.kind == BLHIP_OP_REGIMESWITCH || op.kind == BLHIP_OP_NOTEQUAL) {
                 prog.has_clamp = true;
+            } else if (op.kind == BLHIP_OP_ALPHASTABLE) {
+                const double c = val[k] / p->lattice[op.axis], alpha = val[k + 1];          // transitionModels.py:170-176
+                if (std::isnan(c) || std::isnan(alpha)) fail("chain %lld: AlphaStableRandomWalk parameters are NaN", (long long)(c0 + b));
+                op_axis[k] = g.axis_map[op.axis];
+                op_tap[k] = taps.get_alphastable(op_axis[k], c, alpha, (int)p->n[op.axis]);
+                prog.has_clamp = true;                       // (mode 5 of the generic kernel: zero boundary + renormalisation)
             } else if (op.kind == BLHIP_OP_BIVARIATE) {
                 // transitionModels.py:881-885; a singular covariance makes scipy.stats.multivariate_normal raise in the reference
                 const double n1 = val[k] / p->lattice[0], n2 = val[k + 1] / p->lattice[1], rho = val[k + 2];
@@ -582,7 +617,8 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                     case BLHIP_OP_GRW: {
                         if (op_tap[k] < 0) break;
                         if (sp.cmode == 2) fail("a GaussianRandomWalk after a RegimeSwitch in one combined model is not supported");
-                        if (sp.cmode == 4) fail("a GaussianRandomWalk combined with a BivariateRandomWalk is not supported");
+                        if (sp.cmode == 4 || sp.cmode == 5)
+                            fail("a GaussianRandomWalk combined with a Bivariate- / AlphaStableRandomWalk is not supported");
                         int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
                         if (slot >= 0)
                             fail("two GaussianRandomWalk ops on the same parameter in one combined model are not supported");
@@ -598,6 +634,14 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                     case BLHIP_OP_INDEPENDENT:                                    // transitionModels.py:351-360
                         sp = StepProg(); sp.kind = SRC_INDEP; filtered = false;
                         break;
+                    case BLHIP_OP_ALPHASTABLE: {                                  // transitionModels.py:167-187
+                        if (sp.cmode != 0 || filtered)
+                            fail("an AlphaStableRandomWalk combined with another model acting on the same step is not supported");
+                        sp.cmode = 5;
+                        (op_axis[k] == 0 ? sp.t0 : sp.t1) = op_tap[k];
+                        filtered = true;
+                        break;
+                    }
                     case BLHIP_OP_BIVARIATE:                                      // transitionModels.py:880-891
                         if (sp.cmode != 0 || filtered)
                             fail("a BivariateRandomWalk combined with another model acting on the same step is not supported");

@@ -41,7 +41,8 @@ struct StepParams {
     const int *tap0, *tap1;                       // [B] tap-set ids per internal axis, -1 = identity
     const unsigned char *cmode; const double *limit;   // [B] clamp mode: 0 none, 1 RegimeSwitch on the source, 2 RegimeSwitch after the stencil,
                                                        //     3 NotEqual (invert + clamp the source), 4 dense 2-D kernel tap0 with zero boundary, renormalised
-                                                       //     (BivariateRandomWalk); nullptr if the batch has none
+                                                       //     (BivariateRandomWalk), 5 separable taps with zero boundary, renormalised (AlphaStableRandomWalk);
+                                                       //     nullptr if the batch has none
     // tap table
     const double *taps; const int *tap_off; const int *tap_lw;
     const int *tap_lw2;          // dense 2-D kernels (clamp mode 4): axis-1 radius; weights at taps[off + a * (2 lw2 + 1) + b]
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
             const int cj = j0 - P.LW1 + c;
             const int gj = reflect(cj, P.n1);
             double v = row[gj];
-            if (dense && ((unsigned)ri >= (unsigned)P.n0 || (unsigned)cj >= (unsigned)P.n1)) v = 0.0;   // convolve2d zero fill
+            if ((dense || cm == 5) && ((unsigned)ri >= (unsigned)P.n0 || (unsigned)cj >= (unsigned)P.n1)) v = 0.0;   // zero fill
             if (cm == 1) { v *= scale; v = v < lim ? lim : v; }
             if (cm == 3) { v = (ne_max - v) * ne_inv; v = v < lim ? lim : v; }                 // transitionModels.py:465-467
             dstrow[c] = v;

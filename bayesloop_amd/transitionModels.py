@@ -12,6 +12,7 @@ both directions, inside the fused HIP step kernels:
     ChangePoint             -> CHANGEPOINT(tChange): restart from the (re-normalised) prior at one time stamp
     RegimeSwitch            -> REGIMESWITCH(log10pMin): clamp from below and renormalise
     NotEqual                -> NOTEQUAL(log10pMin): max(p) - p, renormalise, clamp from below, renormalise
+    AlphaStableRandomWalk   -> ALPHASTABLE(axis, c) + ALPHASTABLE_ARG(alpha): zero-boundary stencil with the stable density, renormalised
     BivariateRandomWalk     -> BIVARIATE(sigma1) + 2 x BIVARIATE_ARG(sigma2, rho): dense 2-D convolution, zero boundary, renormalised
     Independent             -> INDEPENDENT: restart from the normalised prior at every step
     CombinedTransitionModel -> concatenation of the sub-models' programs
@@ -171,6 +172,32 @@ class NotEqual(TransitionModel):
         return [(_abi.OP_NOTEQUAL, 0, self, 0, -1, 0)]
 
 
+class AlphaStableRandomWalk(TransitionModel):
+    """Heavy-tailed fluctuations of one parameter: convolution with a symmetric alpha-stable density of scale c and tail
+    index alpha (alpha = 1: Cauchy, 2: Gauss), zero boundary, renormalised (reference transitionModels.py:121-260)."""
+
+    def __init__(self, name1='c', value1=None, name2='alpha', value2=None, target=None, prior=(None, None)):
+        if target is None:
+            raise ConfigurationError('No parameter set for transition model "AlphaStableRandomWalk"')
+        self.study = None
+        self.latticeConstant = None
+        self.hyperParameterNames = [name1, name2]
+        self.hyperParameterValues = [_as_values(value1), _as_values(value2)]
+        self.prior = prior
+        self.selectedParameter = target
+        self.tOffset = 0
+
+    def __str__(self):
+        return 'Alpha-stable random walk'
+
+    def _program(self, parameterNames):
+        if self.selectedParameter not in parameterNames:
+            raise ConfigurationError('AlphaStableRandomWalk: observation model has no parameter "{}".'
+                                     .format(self.selectedParameter))
+        axis = list(parameterNames).index(self.selectedParameter)
+        return [(_abi.OP_ALPHASTABLE, axis, self, 0, -1, 0), (_abi.OP_ALPHASTABLE_ARG, 0, self, 1, -1, 0)]
+
+
 class BivariateRandomWalk(TransitionModel):
     """Correlated Gaussian fluctuations of both parameters of a two-parameter observation model: dense 2-D convolution
     with a bivariate normal kernel, zero boundary, renormalised (reference transitionModels.py:843-911)."""
@@ -282,7 +309,7 @@ def _not_yet(name, where):
     class _Unavailable(TransitionModel):
         def __init__(self, *args, **kwargs):
             raise NotImplementedError('bl.tm.{} (reference {}) is not available on the MI355X engine yet; this build '
-                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, NotEqual, BivariateRandomWalk, Independent, Combined- and '
+                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, NotEqual, AlphaStable- and BivariateRandomWalk, Independent, Combined- and '
                                       'SerialTransitionModel (with BreakPoint).'
                                       .format(name, where))
     _Unavailable.__name__ = name
@@ -290,5 +317,4 @@ def _not_yet(name, where):
 
 
 # rows of SURVEY.md section 8(f): not on the hot path named by BASELINE.json
-AlphaStableRandomWalk = _not_yet('AlphaStableRandomWalk', 'transitionModels.py:121-260')
 Deterministic = _not_yet('Deterministic', 'transitionModels.py:477-606')

@@ -67,7 +67,11 @@ enum {
     BLHIP_OP_BIVARIATE    = 7,    /* transitionModels.py:872-911  value = sigma1; MUST be followed by two BIVARIATE_ARG ops
                                      carrying sigma2 and rho: dense 2-D convolution with the bivariate normal kernel on
                                      |x| <= 3 ceil(sigma / lattice), zero boundary, renormalised (2-D grids only) */
-    BLHIP_OP_BIVARIATE_ARG = 8    /* value = sigma2 (first) / rho (second) of the BIVARIATE op before it */
+    BLHIP_OP_BIVARIATE_ARG = 8,   /* value = sigma2 (first) / rho (second) of the BIVARIATE op before it */
+    BLHIP_OP_ALPHASTABLE  = 9,    /* transitionModels.py:158-260  value = scale c, axis = target parameter; MUST be followed
+                                     by one ALPHASTABLE_ARG op carrying alpha: convolution along the axis with the symmetric
+                                     alpha-stable density (inverse FFT of exp(-|c w|^alpha)), zero boundary, renormalised */
+    BLHIP_OP_ALPHASTABLE_ARG = 10 /* value = alpha of the ALPHASTABLE op before it */
 };
 
 /* A SerialTransitionModel (transitionModels.py:665-818) is flattened into the same program: the ops of its n sub-models

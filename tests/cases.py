@@ -24,6 +24,9 @@ PRIORS = {
     'inv_s_2d': lambda m, s: 1. / s,
 }
 
+# the reference convolves with scipy.signal.fftconvolve (AlphaStableRandomWalk): its own round-off is ~1e-17 ABSOLUTE
+FFT_TOL = dict(post_atol=1e-15, post_rtol=1e-9, logE_rtol=1e-12)
+
 COAL = np.array([5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4,
                  4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2, 1, 3, 2, 2, 1, 1, 1, 1, 3, 0,
                  0, 1, 0, 1, 1, 0, 0, 3, 1, 0, 3, 2, 2, 0, 1, 1, 1, 0, 1, 0, 1, 0, 0,
@@ -198,6 +201,13 @@ CASES = {
     # reference tests/test_transitionmodels.py:96-108, :110-122, :139-161
     'kat_regimeswitch': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                              tm=('RS', 'p_min', -3, None), kat=-10.372866559561402),
+    # reference tests/test_transitionmodels.py:68-80
+    'kat_alphastable': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                            tm=('AlphaStable', 'c', 0.2, 'alpha', 1.5, 'rate'), kat=-10.122384638661309, tol=FFT_TOL),
+    'alphastable_2d_hyper': dict(study='HyperStudy', data=('series', 91, 8), om=gauss2d(36, -5, 5, 3),
+                                 tm=('AlphaStable', 'c', [0.1, 0.3], 'alpha', [1.0, 1.7, 2.0], 'mean'), tol=FFT_TOL),
+    'alphastable_axis1_2d': dict(study='Study', data=('series', 92, 7), om=gauss2d(30, -5, 5, 3),
+                                 tm=('AlphaStable', 'c', 0.08, 'alpha', 1.3, 'std'), tol=FFT_TOL),
     # reference tests/test_transitionmodels.py:53-66
     'kat_bivariate': dict(study='Study', data=D15, om=('Gaussian', [('mu', _g('oint', 0, 6, 20)), ('sigma', _g('oint', 0, 2, 20))], 'default'),
                           tm=('Bivariate', 'sigma1', 1., 'sigma2', 0.1, 'rho', 0.5), kat=-7.330706514472251),
@@ -360,6 +370,8 @@ def make_tm(bl, spec):
         return bl.tm.RegimeSwitch(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'Independent':
         return bl.tm.Independent()
+    if kind == 'AlphaStable':
+        return bl.tm.AlphaStableRandomWalk(spec[1], make_values(bl, spec[2]), spec[3], make_values(bl, spec[4]), target=spec[5])
     if kind == 'Bivariate':
         return bl.tm.BivariateRandomWalk(spec[1], make_values(bl, spec[2]), spec[3], make_values(bl, spec[4]),
                                          spec[5], make_values(bl, spec[6]))

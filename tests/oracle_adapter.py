@@ -62,6 +62,9 @@ def flatten_tm(spec, param_names):
         return [('regimeswitch',)], [cases.make_values(_Orc, spec[2])], [cases.make_prior(spec[3])]
     if kind == 'Independent':
         return [('independent',)], [], []
+    if kind == 'AlphaStable':
+        return ([('alphastable', param_names.index(spec[5])), ('alphastable_arg',)],
+                [cases.make_values(_Orc, spec[2]), cases.make_values(_Orc, spec[4])], [None, None])
     if kind == 'Bivariate':
         return ([('bivariate',), ('bivariate_arg',), ('bivariate_arg',)],
                 [cases.make_values(_Orc, spec[2]), cases.make_values(_Orc, spec[4]), cases.make_values(_Orc, spec[6])], [None, None, None])

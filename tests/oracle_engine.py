@@ -18,7 +18,8 @@ OM = {_abi.OM_POISSON: 'poisson', _abi.OM_GAUSSIAN: 'gaussian', _abi.OM_GAUSSIAN
       _abi.OM_AR1: 'ar1', _abi.OM_SCALED_AR1: 'scaled_ar1'}
 OPS = {_abi.OP_STATIC: 'static', _abi.OP_GRW: 'grw', _abi.OP_CHANGEPOINT: 'changepoint', _abi.OP_REGIMESWITCH: 'regimeswitch',
        _abi.OP_INDEPENDENT: 'independent', _abi.OP_BREAKPOINT: 'breakpoint', _abi.OP_NOTEQUAL: 'notequal',
-       _abi.OP_BIVARIATE: 'bivariate', _abi.OP_BIVARIATE_ARG: 'bivariate_arg'}
+       _abi.OP_BIVARIATE: 'bivariate', _abi.OP_BIVARIATE_ARG: 'bivariate_arg',
+       _abi.OP_ALPHASTABLE: 'alphastable', _abi.OP_ALPHASTABLE_ARG: 'alphastable_arg'}
 
 
 class OracleEngine:

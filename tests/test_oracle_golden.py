@@ -15,7 +15,7 @@ SLOW = [k for k, c in cases.CASES.items() if c.get('slow')]
 def test_oracle_matches_reference_golden(case):
     with np.errstate(all='ignore'):
         res = oa.run(case)
-    compare.check(res, oa.load_golden(case), compare.ORACLE_TOL)
+    compare.check(res, oa.load_golden(case), compare.ORACLE_TOL, case_tol=cases.CASES[case].get('tol'))
 
 
 @pytest.mark.slow
@@ -23,7 +23,7 @@ def test_oracle_matches_reference_golden(case):
 def test_oracle_matches_reference_golden_slow(case):
     with np.errstate(all='ignore'):
         res = oa.run(case)
-    compare.check(res, oa.load_golden(case), compare.ORACLE_TOL)
+    compare.check(res, oa.load_golden(case), compare.ORACLE_TOL, case_tol=cases.CASES[case].get('tol'))
 
 
 @pytest.mark.parametrize('case', [k for k in FAST if 'kat' in cases.CASES[k]])
