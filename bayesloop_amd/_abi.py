@@ -18,6 +18,7 @@ OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
 OM_BERNOULLI, OM_LAPLACE, OM_WHITE_NOISE, OM_AR1, OM_SCALED_AR1 = 4, 5, 6, 7, 8
 OP_STATIC, OP_GRW, OP_CHANGEPOINT, OP_REGIMESWITCH, OP_INDEPENDENT, OP_BREAKPOINT, OP_NOTEQUAL = 0, 1, 2, 3, 4, 5, 6
 OP_BIVARIATE, OP_BIVARIATE_ARG, OP_ALPHASTABLE, OP_ALPHASTABLE_ARG = 7, 8, 9, 10
+OP_DETERMINISTIC, OP_DETERMINISTIC_ARG = 11, 12
 FORWARD_ONLY, EVIDENCE_ONLY, KEEP_POSTERIOR, ACCUMULATE, RESUME, CARRY = 1, 2, 4, 8, 16, 32
 
 c_double_p = C.POINTER(C.c_double)

@@ -22,7 +22,7 @@ from .helper import flatten
 from .observationModels import ObservationModel, device_code
 from .preprocessing import movingWindow
 from .transitionModels import (TransitionModel, ChangePoint, CombinedTransitionModel, SerialTransitionModel,
-                               BivariateRandomWalk, AlphaStableRandomWalk)
+                               BivariateRandomWalk, AlphaStableRandomWalk, Deterministic)
 
 COAL_MINING = (5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4, 4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2,
                1, 3, 2, 2, 1, 1, 1, 1, 3, 0, 0, 1, 0, 1, 1, 0, 0, 3, 1, 0, 3, 2, 2, 0, 1, 1, 1, 0, 1, 0, 1, 0, 0, 0, 2, 1,
@@ -355,6 +355,7 @@ class Study(object):
             # the model's own pdf, evaluated once per time step on the host (plug-in interface of the reference)
             lik = np.array([np.asarray(om.processedPdf(self.grid, seg), dtype=float) * np.ones(self.gridSize)
                             for seg in self.formattedData])
+        program = self._expandProgram(program, len(data))
         problem = FitProblem(obs_model=code, marginal=self.marginalGrid, lattice=self.latticeConstant, data=data,
                              timestamps=np.asarray(self.formattedTimestamps, dtype=float), prior=prior,
                              ops=[(op[0], op[1], op[4], op[5]) for op in program], reset_prior=reset, indep_prior=indep,
@@ -362,24 +363,50 @@ class Study(object):
                              seg_len=om.segmentLength)
         return problem, program
 
-    def _opValues(self, program, flat_values=None):
-        """One row of op values: the current hyper-parameter value of every op (NaN for Static)."""
+    @staticmethod
+    def _expandProgram(program, T):
+        """A Deterministic op is followed by 2 T DETERMINISTIC_ARG ops carrying its per-step shifts (include/blhip.h); their
+        hyper index is the pair ('shift', position) resolved by :meth:`_opValueMatrix`."""
+        out = []
+        for op in program:
+            out.append(op)
+            if op[0] == _abi.OP_DETERMINISTIC:
+                out += [(_abi.OP_DETERMINISTIC_ARG, 0, op[2], ('shift', q), -1, 0) for q in range(2 * T)]
+        return out
+
+    def _opValueMatrix(self, program, hyper_rows=None, timestamps=None, resume_time=-1.0):
+        """(n_chains, n_ops) op values.  ``hyper_rows``: (n_chains, n_hyper) values in the order of the flattened
+        hyper-parameter list (None: one chain with the models' current values).  Ops without a value get NaN; the
+        DETERMINISTIC_ARG ops get the shifts the Deterministic model's function gives for the chain's hyper-parameters."""
         slots = self._hyperSlots()
-        row = []
-        for kind, axis, model, k, seg, flg in program:
+        if hyper_rows is None:
+            row = []
+            for m, k, name in slots:
+                v = m.hyperParameterValues[k]
+                if isinstance(v, str) or np.ndim(v) != 0:
+                    raise ConfigurationError('Hyper-parameter "{}" holds several values; use a HyperStudy to fit a range of '
+                                             'hyper-parameter values.'.format(name))
+                row.append(float(v))
+            hyper_rows = np.array([row], dtype=float).reshape(1, len(slots))
+        hyper_rows = np.asarray(hyper_rows, dtype=float).reshape(-1, len(slots)) if len(slots) else np.zeros((max(1, len(hyper_rows)), 0))
+        n = hyper_rows.shape[0]
+        out = np.full((n, max(1, len(program))), np.nan)
+        ts = self.formattedTimestamps if timestamps is None else timestamps
+        shift_cache = {}
+        for j, (kind, axis, model, k, seg, flg) in enumerate(program):
             if k is None:
-                row.append(np.nan)
                 continue
-            if flat_values is None:
-                v = model.hyperParameterValues[k]
-            else:
-                idx = [i for i, s in enumerate(slots) if s[0] is model and s[1] == k][0]
-                v = flat_values[idx]
-            if isinstance(v, str) or np.ndim(v) != 0:
-                raise ConfigurationError('Hyper-parameter "{}" holds several values; use a HyperStudy to fit a range of '
-                                         'hyper-parameter values.'.format(model.hyperParameterNames[k]))
-            row.append(float(v))
-        return row
+            if isinstance(k, tuple):                       # ('shift', q) of a Deterministic model
+                if id(model) not in shift_cache:
+                    cols = [i for i, sl in enumerate(slots) if sl[0] is model]
+                    shift_cache[id(model)] = np.array([
+                        model.shifts({model.hyperParameterNames[sl_k]: hyper_rows[c, i] for i, sl_k in
+                                      zip(cols, [slots[i][1] for i in cols])}, ts, resume_time) for c in range(n)])
+                out[:, j] = shift_cache[id(model)][:, k[1]]
+                continue
+            col = [i for i, sl in enumerate(slots) if sl[0] is model and sl[1] == k][0]
+            out[:, j] = hyper_rows[:, col]
+        return out
 
     def _warnZero(self, phase):
         which = 'Forward pass distribution' if phase == 0 else 'Posterior distribution'
@@ -406,7 +433,7 @@ class Study(object):
         eng = _engine_mod.get_engine()
         T = len(self.formattedData)
         keep = not evidenceOnly
-        res = eng.fit(problem, [self._opValues(program)], forward_only=forwardOnly, evidence_only=evidenceOnly,
+        res = eng.fit(problem, self._opValueMatrix(program), forward_only=forwardOnly, evidence_only=evidenceOnly,
                       keep_posterior=keep, owner=self)
         self.lastTiming = res.timing
         self.logEvidence = float(res.log_evidence[0])
@@ -578,7 +605,7 @@ class HyperStudy(Study):
         priors = []
         for m, k, name in self._hyperSlots():
             prior = getattr(m, 'prior', None)
-            priors.append(prior[k] if isinstance(m, (SerialTransitionModel, BivariateRandomWalk, AlphaStableRandomWalk)) else prior)
+            priors.append(prior[k] if isinstance(m, (SerialTransitionModel, BivariateRandomWalk, AlphaStableRandomWalk, Deterministic)) else prior)
         return priors
 
     def _createHyperGrid(self, silent=False):
@@ -691,15 +718,7 @@ class HyperStudy(Study):
             problem, program = self._compile(silent=True)
         finally:
             self._setAllHyperParameters(self.flatHyperParameters)
-        slots = self._hyperSlots()
-        col = []
-        for kind, axis, model, k, seg, flg in program:
-            col.append(None if k is None else [i for i, s in enumerate(slots) if s[0] is model and s[1] == k][0])
-        hv = np.asarray(self.hyperGridValues, dtype=float)
-        op_values = np.full((len(hv), max(1, len(program))), np.nan)
-        for j, c in enumerate(col):
-            if c is not None:
-                op_values[:, j] = hv[:, c]
+        op_values = self._opValueMatrix(program, np.asarray(self.hyperGridValues, dtype=float))
         prior_values = np.asarray(self.flatHyperPriorValues, dtype=float)
 
         from . import dist as _dist
@@ -979,16 +998,10 @@ class OnlineStudy(HyperStudy):
         self._device = []
         for tm, hpv in zip(self.transitionModels, self.hyperParameterValues):
             self.setTransitionModel(tm, silent=True)
-            program = tm._program(om.parameterNames)
-            slots = self._hyperSlots()
-            n = max(1, len(hpv))
-            op_values = np.full((n, max(1, len(program))), np.nan)
-            if len(hpv) > 0:
-                hv = np.asarray(hpv, dtype=float)
-                for j, (kind, axis, model, k, seg, flg) in enumerate(program):
-                    if k is not None:
-                        c = [i for i, s in enumerate(slots) if s[0] is model and s[1] == k][0]
-                        op_values[:, j] = hv[:, c]
+            program = self._expandProgram(tm._program(om.parameterNames), 1)
+            # every step is a one-step problem resumed at t = -1 (core.py:2164-2165): the op values never change
+            op_values = self._opValueMatrix(program, np.asarray(hpv, dtype=float) if len(hpv) > 0 else np.zeros((1, 0)),
+                                            timestamps=[0.0], resume_time=-1.0)
             reset = self._changepointPrior() if any(op[0] == _abi.OP_CHANGEPOINT for op in program) else None
             indep = None
             if any(op[0] == _abi.OP_INDEPENDENT for op in program):

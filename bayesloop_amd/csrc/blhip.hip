@@ -110,6 +110,36 @@ struct TapTable {
     std::map<std::pair<int, double>, int> index;   // (internal axis, normed sigma) -> id
     std::map<std::tuple<double, double, double>, int> index2;   // dense kernels: (ns1, ns2, rho) -> id
 
+    // Deterministic (transitionModels.py:581, :600): scipy.ndimage.shift(order=3, mode='nearest') by d grid cells = stencil
+    // out[i] = sum_m K[m] ext[i + m], K[m] = eta(-d - m) with the cardinal cubic spline eta(u) = sum_n sqrt(3) pole^|n| beta3(u - n)
+    // (prefilter impulse response x B-spline), |m| <= ceil|d| + 34, over the extension blk::extend_index(rule 2) builds.
+    // Exact for |d| <= 12 (beyond, SciPy extends the COEFFICIENTS by their edge values: oracle/bl_oracle.py).  Stored with all
+    // 2 lw + 1 weights; lw2 = -1 marks the asymmetric layout.
+    std::map<std::pair<int, double>, int> index_shift;
+    int get_shift(int axis, double d) {
+        auto key = std::make_pair(axis, d);
+        auto it = index_shift.find(key);
+        if (it != index_shift.end()) return it->second;
+        const double pole = std::sqrt(3.0) - 2.0, gain = -6.0 * pole / (1.0 - pole * pole);
+        const int r = (int)std::ceil(std::fabs(d)) + 34;
+        const int id = (int)off.size();
+        off.push_back((int)w.size());
+        lw.push_back(r);
+        lw2.push_back(-1);
+        for (int m = -r; m <= r; ++m) {
+            const double u = -d - (double)m, n0 = std::floor(u);
+            double eta = 0.0;
+            for (int k = -1; k <= 2; ++k) {
+                const double n = n0 + k, a = std::fabs(u - n);
+                const double b3 = a < 1.0 ? 2.0 / 3.0 - a * a + a * a * a / 2.0 : (a < 2.0 ? (2.0 - a) * (2.0 - a) * (2.0 - a) / 6.0 : 0.0);
+                eta += gain * std::pow(pole, std::fabs(n)) * b3;
+            }
+            w.push_back(eta);
+        }
+        index_shift[key] = id;
+        return id;
+    }
+
     // AlphaStableRandomWalk.createKernel (transitionModels.py:196-240) for an axis of n points: k[d], d = 0 .. n-1, of the
     // inverse real DFT (numpy.fft.irfft) of exp(-|c w|^alpha) sampled at m = int(3n/2 + 1) points of [0, pi]; the reference's
     // roll + 3x zero padding + fftconvolve(mode='same') (:233-260) is out[i] = sum_j in[j] k[|i - j|] inside the grid
@@ -458,6 +488,11 @@ void validate(const blhip_problem *p, int64_t n_chains, const double *op_values)
             has_cp = true;
         } else if (op.kind == BLHIP_OP_INDEPENDENT) {
             if (!p->indep_prior) fail("INDEPENDENT op needs indep_prior");
+        } else if (op.kind == BLHIP_OP_DETERMINISTIC) {
+            if (op.axis < 0 || op.axis >= p->ndim) fail("DETERMINISTIC op %d: axis %d out of range", k, op.axis);
+            for (int64_t q = 1; q <= 2 * p->T; ++q)
+                if (k + q >= p->n_ops || p->ops[k + q].kind != BLHIP_OP_DETERMINISTIC_ARG)
+                    fail("DETERMINISTIC op %d must be followed by 2 T = %lld DETERMINISTIC_ARG ops (the shifts per step)", k, (long long)(2 * p->T));
         } else if (op.kind == BLHIP_OP_ALPHASTABLE) {
             if (op.axis < 0 || op.axis >= p->ndim) fail("ALPHASTABLE op %d: axis %d out of range", k, op.axis);
             if (k + 1 >= p->n_ops || p->ops[k + 1].kind != BLHIP_OP_ALPHASTABLE_ARG)
@@ -467,7 +502,8 @@ void validate(const blhip_problem *p, int64_t n_chains, const double *op_values)
             if (k + 2 >= p->n_ops || p->ops[k + 1].kind != BLHIP_OP_BIVARIATE_ARG || p->ops[k + 2].kind != BLHIP_OP_BIVARIATE_ARG)
                 fail("BIVARIATE op %d must be followed by two BIVARIATE_ARG ops (sigma2, rho)", k);
         } else if (op.kind != BLHIP_OP_STATIC && op.kind != BLHIP_OP_REGIMESWITCH && op.kind != BLHIP_OP_BREAKPOINT &&
-                   op.kind != BLHIP_OP_NOTEQUAL && op.kind != BLHIP_OP_BIVARIATE_ARG && op.kind != BLHIP_OP_ALPHASTABLE_ARG) {
+                   op.kind != BLHIP_OP_NOTEQUAL && op.kind != BLHIP_OP_BIVARIATE_ARG && op.kind != BLHIP_OP_ALPHASTABLE_ARG &&
+                   op.kind != BLHIP_OP_DETERMINISTIC_ARG) {
             fail("op %d: unknown kind %d", k, op.kind);
         }
     }
@@ -585,6 +621,10 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                 time_dependent = true;
             } else if (op.kind == BLHIP_OP_REGIMESWITCH || op.kind == BLHIP_OP_NOTEQUAL) {
                 prog.has_clamp = true;
+            } else if (op.kind == BLHIP_OP_DETERMINISTIC) {
+                time_dependent = true;                       // a different shift at every step
+                op_axis[k] = g.axis_map[op.axis];
+                prog.has_clamp = true;                       // (mode 6 of the generic kernel)
             } else if (op.kind == BLHIP_OP_ALPHASTABLE) {
                 const double c = val[k] / p->lattice[op.axis], alpha = val[k + 1];          // transitionModels.py:170-176
                 if (std::isnan(c) || std::isnan(alpha)) fail("chain %lld: AlphaStableRandomWalk parameters are NaN", (long long)(c0 + b));
@@ -601,7 +641,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
             }
         }
         // the transition from one step to the next, evaluated at time stamp tau (list order, transitionModels.py:645-649)
-        auto run = [&](double tau, bool have_tau) {
+        auto run = [&](double tau, bool have_tau, int64_t step = -1, bool fwd = true) {
             StepProg sp;
             int seg = 0;                                                   // active sub-model of a serial model (:768)
             if (have_tau)
@@ -619,6 +659,8 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                         if (sp.cmode == 2) fail("a GaussianRandomWalk after a RegimeSwitch in one combined model is not supported");
                         if (sp.cmode == 4 || sp.cmode == 5)
                             fail("a GaussianRandomWalk combined with a Bivariate- / AlphaStableRandomWalk is not supported");
+                        if (sp.cmode == 6 && (op_axis[k] == 0 ? sp.t0 : sp.t1) >= 0)
+                            fail("a GaussianRandomWalk and a Deterministic model on the same parameter are not supported");
                         int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
                         if (slot >= 0)
                             fail("two GaussianRandomWalk ops on the same parameter in one combined model are not supported");
@@ -634,6 +676,23 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                     case BLHIP_OP_INDEPENDENT:                                    // transitionModels.py:351-360
                         sp = StepProg(); sp.kind = SRC_INDEP; filtered = false;
                         break;
+                    case BLHIP_OP_DETERMINISTIC: {                                // transitionModels.py:571-583, :585-602
+                        if (step < 0) break;                                      // (the time-independent template program)
+                        const double dd = val[k + 1 + (fwd ? step : T + step)] / p->lattice[op.axis];
+                        if (std::isnan(dd)) fail("chain %lld: Deterministic shift of step %lld is NaN", (long long)(c0 + b), (long long)step);
+                        if (std::fabs(dd) > 12.0)
+                            fail("chain %lld, step %lld: Deterministic model shifts by %.3g grid cells in one time step; the fused "
+                                 "kernel supports up to 12 (SciPy's pre-padding)", (long long)(c0 + b), (long long)step, dd);
+                        int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
+                        if (slot >= 0 || (sp.cmode != 0 && sp.cmode != 6))
+                            fail("a Deterministic model combined with another model acting on the same parameter / a clamp is not supported");
+                        if (dd != 0.0) {                                          // zero shift: identity (its renormalisation is a no-op)
+                            slot = taps.get_shift(op_axis[k], dd);
+                            sp.cmode = 6;
+                        }
+                        filtered = true;
+                        break;
+                    }
                     case BLHIP_OP_ALPHASTABLE: {                                  // transitionModels.py:167-187
                         if (sp.cmode != 0 || filtered)
                             fail("an AlphaStableRandomWalk combined with another model acting on the same step is not supported");
@@ -678,11 +737,11 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
         for (int64_t t = 0; t < T; ++t) {
             // forward step t consumes T_fwd(post_{t-1}, ts[t-1])   core.py:411
             StepProg f; f.kind = SRC_PRIOR;
-            if (t > 0) f = time_dependent ? run(p->timestamps[t - 1], true) : stat;
-            else if (resume) f = run(p->resume_time, true);   // continues a carried state (OnlineStudy.step, core.py:2164-2165)
+            if (t > 0) f = time_dependent ? run(p->timestamps[t - 1], true, t, true) : stat;
+            else if (resume) f = run(p->resume_time, true, 0, true);   // continues a carried state (OnlineStudy.step, core.py:2164-2165)
             // backward step t consumes T_bwd(beta_{t+1} L_{t+1}, ts[t+1]) = T_fwd(., ts[t+1] - 1)   core.py:467, transitionModels.py:316-317
             StepProg r; r.kind = SRC_UNIFORM;
-            if (t < T - 1) r = time_dependent ? run(p->timestamps[t + 1] - 1.0, true) : stat;
+            if (t < T - 1) r = time_dependent ? run(p->timestamps[t + 1] - 1.0, true, t, false) : stat;
             const size_t k = (size_t)t * B + b;
             prog.kindF[k] = f.kind; prog.tapF0[k] = f.t0; prog.tapF1[k] = f.t1; prog.cmodeF[k] = f.cmode; prog.limitF[k] = f.limit;
             prog.kindB[k] = r.kind; prog.tapB0[k] = r.t0; prog.tapB1[k] = r.t1; prog.cmodeB[k] = r.cmode; prog.limitB[k] = r.limit;

@@ -42,6 +42,7 @@ struct StepParams {
     const unsigned char *cmode; const double *limit;   // [B] clamp mode: 0 none, 1 RegimeSwitch on the source, 2 RegimeSwitch after the stencil,
                                                        //     3 NotEqual (invert + clamp the source), 4 dense 2-D kernel tap0 with zero boundary, renormalised
                                                        //     (BivariateRandomWalk), 5 separable taps with zero boundary, renormalised (AlphaStableRandomWalk);
+                                                       //     6 cubic-spline shift of one axis (asymmetric taps, spline boundary rule), renormalised (Deterministic);
                                                        //     nullptr if the batch has none
     // tap table
     const double *taps; const int *tap_off; const int *tap_lw;
@@ -64,6 +65,16 @@ __device__ __forceinline__ int reflect(int i, int n) {
     i %= p;
     if (i < 0) i += p;
     return i >= n ? p - 1 - i : i;
+}
+
+// Boundary rules of the tile loader per axis: 0 reflect (GaussianRandomWalk), 1 zero (Bivariate / AlphaStable), 2 the
+// extension scipy.ndimage.shift(order=3, mode='nearest') works on: 12 edge samples, then half-sample reflection of that
+// padded array (Deterministic; oracle/bl_oracle.py: spline_shift_nearest).  -1 = outside with zero fill.
+__device__ __forceinline__ int extend_index(int i, int n, int rule) {
+    if ((unsigned)i < (unsigned)n) return i;
+    if (rule == 1) return -1;
+    if (rule == 2) return min(max(reflect(i + 12, n + 24) - 12, 0), n - 1);
+    return reflect(i, n);
 }
 
 // Wave-wide sum on the DPP cross-lane path (no LDS round trips): 4 row_shr steps inside each row of 16 lanes, then
@@ -200,6 +211,10 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     const int cm = P.cmode ? P.cmode[b] : 0;
     const double lim = P.cmode ? P.limit[b] : 0.0;
     const bool dense = cm == 4;                    // BivariateRandomWalk: tap0 is a dense (2 lw0 + 1) x (2 lw1 + 1) kernel
+    // asymmetric tap sets (tap_lw2 == -1: full 2 lw + 1 weights, Deterministic spline shift) and the boundary rule per axis
+    const bool asym0 = cm == 6 && P.tap0[b] >= 0 && P.tap_lw2[P.tap0[b]] < 0;
+    const bool asym1 = cm == 6 && P.tap1[b] >= 0 && P.tap_lw2[P.tap1[b]] < 0;
+    const int rule0 = (cm == 4 || cm == 5) ? 1 : (asym0 ? 2 : 0), rule1 = (cm == 4 || cm == 5) ? 1 : (asym1 ? 2 : 0);
     const int t0 = P.tap0[b], t1 = dense ? -1 : P.tap1[b];
     const int lw0 = t0 >= 0 ? P.tap_lw[t0] : 0;
     const int lw1 = dense ? P.tap_lw2[t0] : (t1 >= 0 ? P.tap_lw[t1] : 0);
@@ -235,15 +250,12 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
 
     // ---- phase 1: source tile + halo -> LDS (reflect boundary resolved here; a source clamp is applied here too) ------
     for (int r = P.LW0 - lw0 + y; r < P.LW0 + th + lw0; r += YN) {
-        const int ri = i0 - P.LW0 + r;
-        const int gi = reflect(ri, P.n0);
-        const double *row = src + (long long)gi * P.n1;
+        const int gi = extend_index(i0 - P.LW0 + r, P.n0, rule0);
+        const double *row = src + (long long)max(gi, 0) * P.n1;
         double *dstrow = in_tile + (size_t)r * pitch;
         for (int c = P.LW1 - lw1 + x; c < P.LW1 + tw + lw1; c += XW) {
-            const int cj = j0 - P.LW1 + c;
-            const int gj = reflect(cj, P.n1);
-            double v = row[gj];
-            if ((dense || cm == 5) && ((unsigned)ri >= (unsigned)P.n0 || (unsigned)cj >= (unsigned)P.n1)) v = 0.0;   // zero fill
+            const int gj = extend_index(j0 - P.LW1 + c, P.n1, rule1);
+            double v = (gi < 0 || gj < 0) ? 0.0 : row[gj];             // (zero fill: convolve2d / fftconvolve padding)
             if (cm == 1) { v *= scale; v = v < lim ? lim : v; }
             if (cm == 3) { v = (ne_max - v) * ne_inv; v = v < lim ? lim : v; }                 // transitionModels.py:465-467
             dstrow[c] = v;
@@ -259,9 +271,15 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
         for (int r = y; r < th; r += YN) {
             const double *cen = in_tile + (size_t)(r + P.LW0) * pitch;
             for (int c = P.LW1 - lw1 + x; c < P.LW1 + tw + lw1; c += XW) {
-                double acc = cen[c] * w0[0];
-                for (int k = lw0; k >= 1; --k)
-                    acc += (cen[c - (long long)k * pitch] + cen[c + (long long)k * pitch]) * w0[k];
+                double acc;
+                if (asym0) {                                                           // out[i] = sum_m w[m + lw] in[i + m]
+                    acc = 0.0;
+                    for (int k = -lw0; k <= lw0; ++k) acc = fma(w0[k + lw0], cen[c + (long long)k * pitch], acc);
+                } else {
+                    acc = cen[c] * w0[0];
+                    for (int k = lw0; k >= 1; --k)
+                        acc += (cen[c - (long long)k * pitch] + cen[c + (long long)k * pitch]) * w0[k];
+                }
                 v_tile[(size_t)r * pitch + c] = acc;
             }
         }
@@ -290,6 +308,9 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
                     const double *wl = w0 + (a + lw0) * kw + lw1;
                     for (int q = -lw1; q <= lw1; ++q) o = fma(wl[q], line[q], o);
                 }
+            } else if (asym1) {
+                o = 0.0;
+                for (int k = -lw1; k <= lw1; ++k) o = fma(w1[k + lw1], cen[k], o);
             } else if (lw1 > 0) {
                 o = cen[0] * w1[0];
                 for (int k = lw1; k >= 1; --k) o += (cen[-k] + cen[k]) * w1[k];

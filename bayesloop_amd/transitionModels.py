@@ -12,6 +12,7 @@ both directions, inside the fused HIP step kernels:
     ChangePoint             -> CHANGEPOINT(tChange): restart from the (re-normalised) prior at one time stamp
     RegimeSwitch            -> REGIMESWITCH(log10pMin): clamp from below and renormalise
     NotEqual                -> NOTEQUAL(log10pMin): max(p) - p, renormalise, clamp from below, renormalise
+    Deterministic           -> DETERMINISTIC(axis) + 2 T DETERMINISTIC_ARG(shift per step, evaluated from the model's function)
     AlphaStableRandomWalk   -> ALPHASTABLE(axis, c) + ALPHASTABLE_ARG(alpha): zero-boundary stencil with the stable density, renormalised
     BivariateRandomWalk     -> BIVARIATE(sigma1) + 2 x BIVARIATE_ARG(sigma2, rho): dense 2-D convolution, zero boundary, renormalised
     Independent             -> INDEPENDENT: restart from the normalised prior at every step
@@ -172,6 +173,60 @@ class NotEqual(TransitionModel):
         return [(_abi.OP_NOTEQUAL, 0, self, 0, -1, 0)]
 
 
+class Deterministic(TransitionModel):
+    """Deterministic parameter variation: the distribution of ``target`` is shifted from step to step by the increments
+    of ``function(t, **hyperParameters)`` (cubic-spline shift, edge-extended, renormalised; reference
+    transitionModels.py:477-606).  The keyword arguments of ``function`` are the hyper-parameters, their defaults the
+    hyper-parameter values."""
+
+    def __init__(self, function=None, target=None, prior=None):
+        import inspect
+        self.study = None
+        self.latticeConstant = None
+        self.function = function
+        self.selectedParameter = target
+        self.tOffset = 0
+        if target is None:
+            raise ConfigurationError('No parameter set for transition model "Deterministic"')
+        spec = inspect.getfullargspec(self.function)
+        defaults = spec.defaults or ()
+        if not len(spec.args) == len(defaults) + 1:
+            raise ConfigurationError('Function to define deterministic transition model can only contain one '
+                                     'non-keyword argument (time; first argument) and keyword-arguments '
+                                     '(hyper-parameters) with default values.')
+        self.hyperParameterNames = list(spec.args[1:])
+        self.hyperParameterValues = [_as_values(d) for d in defaults]
+        if prior is None:
+            self.prior = [None] * len(defaults)
+        elif isinstance(prior, (list, tuple)):
+            if len(prior) != len(defaults):
+                raise ConfigurationError('{} priors are defined for transition model "{}", but model contains {} '
+                                         'hyper-parameters.'.format(len(prior), self.function.__name__, len(defaults)))
+            self.prior = list(prior)
+        else:
+            self.prior = [prior]
+
+    def __str__(self):
+        return 'Deterministic model ({})'.format(self.function.__name__)
+
+    def _program(self, parameterNames):
+        if self.selectedParameter not in parameterNames:
+            raise ConfigurationError('Deterministic: observation model has no parameter "{}".'.format(self.selectedParameter))
+        # the 2 T per-step shifts follow this op as DETERMINISTIC_ARG ops (added when the study is compiled, core.py)
+        return [(_abi.OP_DETERMINISTIC, list(parameterNames).index(self.selectedParameter), self, None, -1, 0)]
+
+    def shifts(self, params, timestamps, resume_time=-1.0):
+        """The 2 T values behind the DETERMINISTIC op (include/blhip.h): forward shift INTO step i, f(t'+1) - f(t') at the
+        time stamp t' of step i-1 (entry 0: at ``resume_time``, used by OnlineStudy), then backward shift into step i,
+        f(t'-1) - f(t') at the time stamp t' of step i+1 (reference transitionModels.py:573-577, :592-596)."""
+        ts = np.asarray(timestamps, dtype=float)
+        T = len(ts)
+        f = lambda t: float(self.function(t - self.tOffset, **params))
+        fwd = [f(resume_time + 1) - f(resume_time)] + [f(ts[i - 1] + 1) - f(ts[i - 1]) for i in range(1, T)]
+        bwd = [f(ts[i + 1] - 1) - f(ts[i + 1]) for i in range(T - 1)] + [0.0]
+        return np.array(fwd + bwd, dtype=float)
+
+
 class AlphaStableRandomWalk(TransitionModel):
     """Heavy-tailed fluctuations of one parameter: convolution with a symmetric alpha-stable density of scale c and tail
     index alpha (alpha = 1: Cauchy, 2: Gauss), zero boundary, renormalised (reference transitionModels.py:121-260)."""
@@ -296,6 +351,9 @@ class SerialTransitionModel(TransitionModel):
             for op in m._program(parameterNames):
                 if op[4] != -1 or op[0] == _abi.OP_BREAKPOINT or (op[0] == _abi.OP_CHANGEPOINT and op[5] & 1):
                     raise ConfigurationError('Nested SerialTransitionModel instances are not supported.')
+                if op[0] == _abi.OP_DETERMINISTIC:
+                    raise ConfigurationError('A Deterministic model inside a SerialTransitionModel (time offset at the '
+                                             'break-points, reference transitionModels.py:770-776) is not supported.')
                 program.append((op[0], op[1], op[2], op[3], seg, op[5]))
         for k in range(len(self.hyperParameterNames)):
             if self.changePointMask[k]:
@@ -303,18 +361,3 @@ class SerialTransitionModel(TransitionModel):
             else:
                 program.append((_abi.OP_BREAKPOINT, 0, self, k, -1, 0))
         return program
-
-
-def _not_yet(name, where):
-    class _Unavailable(TransitionModel):
-        def __init__(self, *args, **kwargs):
-            raise NotImplementedError('bl.tm.{} (reference {}) is not available on the MI355X engine yet; this build '
-                                      'covers Static, GaussianRandomWalk, ChangePoint, RegimeSwitch, NotEqual, AlphaStable- and BivariateRandomWalk, Independent, Combined- and '
-                                      'SerialTransitionModel (with BreakPoint).'
-                                      .format(name, where))
-    _Unavailable.__name__ = name
-    return _Unavailable
-
-
-# rows of SURVEY.md section 8(f): not on the hot path named by BASELINE.json
-Deterministic = _not_yet('Deterministic', 'transitionModels.py:477-606')

@@ -71,7 +71,15 @@ enum {
     BLHIP_OP_ALPHASTABLE  = 9,    /* transitionModels.py:158-260  value = scale c, axis = target parameter; MUST be followed
                                      by one ALPHASTABLE_ARG op carrying alpha: convolution along the axis with the symmetric
                                      alpha-stable density (inverse FFT of exp(-|c w|^alpha)), zero boundary, renormalised */
-    BLHIP_OP_ALPHASTABLE_ARG = 10 /* value = alpha of the ALPHASTABLE op before it */
+    BLHIP_OP_ALPHASTABLE_ARG = 10,/* value = alpha of the ALPHASTABLE op before it */
+    BLHIP_OP_DETERMINISTIC = 11,  /* transitionModels.py:548-606  axis = target parameter; no value of its own; MUST be
+                                     followed by 2 T DETERMINISTIC_ARG ops whose values are the shifts (in parameter units)
+                                     the caller evaluated from the model's function: first T: f(t'+1) - f(t') of the
+                                     transition INTO forward step i (t' = time stamp of step i-1; entry 0 is used with
+                                     BLHIP_RESUME only), next T: f(t'-1) - f(t') of the backward transition into step i
+                                     (t' = time stamp of step i+1; entry T-1 unused).  Cubic-spline shift as
+                                     scipy.ndimage.shift(order=3, mode='nearest'), renormalised; |shift| <= 12 grid cells */
+    BLHIP_OP_DETERMINISTIC_ARG = 12
 };
 
 /* A SerialTransitionModel (transitionModels.py:665-818) is flattened into the same program: the ops of its n sub-models

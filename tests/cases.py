@@ -24,7 +24,8 @@ PRIORS = {
     'inv_s_2d': lambda m, s: 1. / s,
 }
 
-# the reference convolves with scipy.signal.fftconvolve (AlphaStableRandomWalk): its own round-off is ~1e-17 ABSOLUTE
+# the reference convolves with scipy.signal.fftconvolve (AlphaStableRandomWalk) / shifts with a recursive spline prefilter
+# (Deterministic): its own round-off is ~1e-17 ABSOLUTE, not relative to the (possibly tiny) posterior value
 FFT_TOL = dict(post_atol=1e-15, post_rtol=1e-9, logE_rtol=1e-12)
 
 COAL = np.array([5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4,
@@ -201,6 +202,13 @@ CASES = {
     # reference tests/test_transitionmodels.py:96-108, :110-122, :139-161
     'kat_regimeswitch': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                              tm=('RS', 'p_min', -3, None), kat=-10.372866559561402),
+    # reference tests/test_transitionmodels.py:22-37 (decimal=3 there: SciPy's spline boundary handling changed over time)
+    'kat_deterministic': dict(study='HyperStudy', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
+                              tm=('Deterministic', 'linear_kat', 'rate'), kat=-9.4050089375418136, kat_decimal=3, tol=FFT_TOL),
+    'deterministic_2d_hyper': dict(study='HyperStudy', data=('series', 95, 9), om=gauss2d(40, -5, 5, 3),
+                                   tm=('Deterministic', 'quadratic', 'mean'), tol=FFT_TOL),
+    'deterministic_grw_2d': dict(study='Study', data=('series', 96, 8), om=gauss2d(36, -5, 5, 3),
+                                 tm=('Combined', [('Deterministic', 'drift', 'std'), ('GRW', 's', 0.3, 'mean', None)]), tol=FFT_TOL),
     # reference tests/test_transitionmodels.py:68-80
     'kat_alphastable': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                             tm=('AlphaStable', 'c', 0.2, 'alpha', 1.5, 'rate'), kat=-10.122384638661309, tol=FFT_TOL),
@@ -256,6 +264,21 @@ CASES = {
 }
 
 
+def _linear_kat(t, a=[1, 2]):                 # reference tests/test_transitionmodels.py:26-27
+    return 0.5 + 0.2 * a * t
+
+
+def _quadratic(t, a=0.01, b=np.array([-0.1, 0.05, 0.2])):
+    return a * (t ** 2) + b * t
+
+
+def _drift(t, slope=0.15):
+    return slope * t
+
+
+FUNCS = {'linear_kat': _linear_kat, 'quadratic': _quadratic, 'drift': _drift}
+
+
 # ---- OnlineStudy (reference core.py:1963-2226, tests/test_onlinestudy.py) ----------------------
 G20 = ('Gaussian', [('mean', _g('cint', 0, 6, 20)), ('sigma', _g('oint', 0, 2, 20))])
 ONLINE_CASES = {
@@ -282,6 +305,9 @@ ONLINE_CASES = {
                             models=[('static', ('Static',)), ('different', ('NE', 'log10pMin', [-7., -3.], None)),
                                     ('walk+different', ('Combined', [('NE', 'q', -5., None), ('GRW', 'sg', 0.2, 'rate', None)]))],
                             data=COAL[30:52].tolist()),
+    'online_deterministic': dict(om=('Poisson', [('rate', _g('oint', 0, 6, 120))], 'default'),
+                                 models=[('static', ('Static',)), ('drift', ('Deterministic', 'quadratic', 'rate'))],
+                                 data=COAL[60:75].tolist()),
     'online_ar1_wait': dict(om=('AR1', [('rho', _g('oint', -1, 1, 30)), ('sigma', _g('oint', 0, 1, 25))], 'default'),
                             models=[('static', ('Static',)), ('walk', ('GRW', 's', [0.05, 0.1], 'rho', None))],
                             data=[1, 0, 1, 0, 0, 1]),
@@ -370,6 +396,8 @@ def make_tm(bl, spec):
         return bl.tm.RegimeSwitch(spec[1], make_values(bl, spec[2]), prior=make_prior(spec[3]))
     if kind == 'Independent':
         return bl.tm.Independent()
+    if kind == 'Deterministic':
+        return bl.tm.Deterministic(FUNCS[spec[1]], target=spec[2])
     if kind == 'AlphaStable':
         return bl.tm.AlphaStableRandomWalk(spec[1], make_values(bl, spec[2]), spec[3], make_values(bl, spec[4]), target=spec[5])
     if kind == 'Bivariate':

@@ -62,6 +62,14 @@ def flatten_tm(spec, param_names):
         return [('regimeswitch',)], [cases.make_values(_Orc, spec[2])], [cases.make_prior(spec[3])]
     if kind == 'Independent':
         return [('independent',)], [], []
+    if kind == 'Deterministic':
+        import inspect
+        fn = cases.FUNCS[spec[1]]
+        sp = inspect.getfullargspec(fn)
+        names = list(sp.args[1:])
+        vals = [np.array(dflt) if isinstance(dflt, (list, tuple)) else dflt for dflt in sp.defaults]
+        ops = [('deterministic', param_names.index(spec[2]), -1, 0, fn, names)] + [('deterministic_arg',)] * (len(names) - 1)
+        return ops, vals, [None] * len(names)
     if kind == 'AlphaStable':
         return ([('alphastable', param_names.index(spec[5])), ('alphastable_arg',)],
                 [cases.make_values(_Orc, spec[2]), cases.make_values(_Orc, spec[4])], [None, None])

@@ -19,7 +19,7 @@ OM = {_abi.OM_POISSON: 'poisson', _abi.OM_GAUSSIAN: 'gaussian', _abi.OM_GAUSSIAN
 OPS = {_abi.OP_STATIC: 'static', _abi.OP_GRW: 'grw', _abi.OP_CHANGEPOINT: 'changepoint', _abi.OP_REGIMESWITCH: 'regimeswitch',
        _abi.OP_INDEPENDENT: 'independent', _abi.OP_BREAKPOINT: 'breakpoint', _abi.OP_NOTEQUAL: 'notequal',
        _abi.OP_BIVARIATE: 'bivariate', _abi.OP_BIVARIATE_ARG: 'bivariate_arg',
-       _abi.OP_ALPHASTABLE: 'alphastable', _abi.OP_ALPHASTABLE_ARG: 'alphastable_arg'}
+       _abi.OP_ALPHASTABLE: 'alphastable', _abi.OP_ALPHASTABLE_ARG: 'alphastable_arg', _abi.OP_DETERMINISTIC: 'shift_table'}
 
 
 class OracleEngine:
@@ -37,12 +37,31 @@ class OracleEngine:
 
     def _unpack(self, p):
         g = orc.Grid(p.marginal)
-        ops = [(OPS[op[0]], op[1], op[2] if len(op) > 2 else -1, op[3] if len(op) > 3 else 0) for op in p.ops]
+        ops = [(OPS[op[0]], op[1], op[2] if len(op) > 2 else -1, op[3] if len(op) > 3 else 0) for op in p.ops
+               if op[0] != _abi.OP_DETERMINISTIC_ARG]
+        # (a DETERMINISTIC op is followed by 2 T ARG ops = its table of shifts: folded into one oracle op, see _values)
+        self._abi_ops = list(p.ops)
+        self._ts = np.asarray(p.timestamps, dtype=float)
         data = np.asarray(p.data, dtype=float)
         lik = None if p.lik is None else np.asarray(p.lik, dtype=float).reshape([p.T] + g.size)
         reset = None if p.reset_prior is None else np.asarray(p.reset_prior, dtype=float).reshape(g.size)
         self._indep = None if p.indep_prior is None else np.asarray(p.indep_prior, dtype=float).reshape(g.size)
         return g, OM[p.obs_model], ops, data, lik, reset
+
+    def _values(self, row):
+        """one chain's ABI op values -> the oracle's value list (None for ops without a value; a DETERMINISTIC op takes the
+        2 T values of the ARG ops behind it as its shift table)"""
+        vals, T = [], len(self._ts)
+        for k, op in enumerate(self._abi_ops):
+            if op[0] == _abi.OP_DETERMINISTIC_ARG:
+                continue
+            if op[0] == _abi.OP_DETERMINISTIC:
+                vals.append((self._ts, np.asarray(row[k + 1:k + 1 + 2 * T], dtype=float)))
+            elif op[0] in (_abi.OP_STATIC, _abi.OP_INDEPENDENT):
+                vals.append(None)
+            else:
+                vals.append(row[k])
+        return vals
 
     def _online(self, problem, op_values, resume, carry):
         """One forward step from the prior or from the carried states (OnlineStudy.step, core.py:2157-2174)."""
@@ -53,7 +72,7 @@ class OracleEngine:
         logE, local = np.zeros(n), np.zeros((n, 1))
         states = np.zeros([n] + g.size)
         for c in range(n):
-            vals = [None if op[0] in ('static', 'independent') else op_values[c][k] for k, op in enumerate(ops)]
+            vals = self._values(op_values[c])
             with np.errstate(all='ignore'):
                 if resume:
                     alpha = orc.transition_forward(ops, vals, self._carry[problem.carry_slot][c], problem.resume_time, g, reset,
@@ -99,7 +118,7 @@ class OracleEngine:
         aphase = np.zeros(n, dtype=np.int32)
         self._post = None
         for c in range(n):
-            vals = [None if op[0] in ('static', 'independent') else op_values[c][k] for k, op in enumerate(ops)]
+            vals = self._values(op_values[c])
             with np.errstate(all='ignore'):
                 r = orc.fit(g, om, data, problem.timestamps, np.asarray(problem.prior).reshape(g.size), ops, vals,
                             forward_only=forward_only, evidence_only=evidence_only, reset=reset, lik_table=lik,

@@ -82,8 +82,10 @@ def test_configuration_errors():
         S.set(bl.om.Poisson('a', bl.oint(0, 1, 5)), bl.om.Poisson('b', bl.oint(0, 1, 5)), silent=True)
     with pytest.raises(bl.ConfigurationError):
         bl.tm.GaussianRandomWalk('sigma', 0.1)          # no target
-    with pytest.raises(NotImplementedError):
-        bl.tm.Deterministic(lambda t, slope=1: slope * t, target='rate')
+    with pytest.raises(bl.ConfigurationError):
+        bl.tm.Deterministic(lambda t, slope: slope * t, target='rate')      # hyper-parameters need default values
+    with pytest.raises(bl.ConfigurationError):
+        bl.tm.Deterministic(lambda t, slope=1: slope * t)                   # no target
     S.setTM(bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s', 0.1, target='rate'),
                                           bl.tm.GaussianRandomWalk('s', 0.2, target='rate')), silent=True)
     with pytest.raises(bl.ConfigurationError):
