@@ -10,12 +10,16 @@
  *                        (+ the per-hyper-point loop of   bayesloop/core.py:1349-1366 / 1473-1489 when n_chains > 1)
  *   blhip_accum_*        the evidence-weighted average    bayesloop/core.py:1295, 1362-1366, 1339, 1375-1382, 1416-1419
  *   blhip_posterior_*    the posteriorSequence attribute  bayesloop/core.py:356, 408, 436-441
+ *   blhip_carry_*        OnlineStudy.step                 bayesloop/core.py:2062-2226 (with BLHIP_RESUME / BLHIP_CARRY fits)
  *
  * inside which the library evaluates
  *   ObservationModel.processedPdf + Poisson/Gaussian/GaussianMean.pdf   observationModels.py:35-56, 502, 566-567, 705-706
+ *   Bernoulli / Laplace / WhiteNoise / AR1 / ScaledAR1.pdf               observationModels.py:428-430, 635, 767, 830-831, 893-896
  *   GaussianRandomWalk / CombinedTransitionModel / ChangePoint / Static  transitionModels.py:49-63, 96-118, 289-317, 632-662
  *   RegimeSwitch / Independent / SerialTransitionModel + BreakPoint      transitionModels.py:339-363, 394-415, 756-818
- *   (scipy.ndimage.gaussian_filter1d, mode='reflect', truncate=4.0, called at transitionModels.py:111).
+ *   NotEqual / AlphaStable- / BivariateRandomWalk / Deterministic        transitionModels.py:450-474, 158-260, 872-911, 548-606
+ *   (scipy.ndimage.gaussian_filter1d, mode='reflect', truncate=4.0, called at transitionModels.py:111;
+ *    scipy.signal.fftconvolve / convolve2d at :258, :889; scipy.ndimage.shift(order=3, mode='nearest') at :581, :600).
  *
  * Conventions
  *   - plain C, no C++ / torch types; every array is float64 (double) or the integer type shown, C-contiguous.
