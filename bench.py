@@ -2,7 +2,7 @@
 """
 bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|c5|fwd2048] [--no-extra] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c3|c2|c5|fwd2048] [--no-extra] [--no-cpu]
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
@@ -45,13 +45,17 @@ def series(seed, T):
 
 def make_study(bl, name, comm=None, scale=1.0):
     """-> (study, fit kwargs, cells x steps x chains of one fit, description dict)"""
-    if name == 'c4':
+    if name in ('c4', 'c4_evidence'):
         n, T, nh = 512, 256, 512
         S = bl.HyperStudy(silent=True)
         S.loadData(series(4, T), silent=True)
         S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
               bl.tm.GaussianRandomWalk('sigma', bl.cint(0, 0.3, nh), target='mean'), silent=True)
         S.communicator = comm
+        if name == 'c4_evidence':      # SURVEY.md 8(d): HyperStudy.fit(evidenceOnly=True) -- forward passes only
+            return S, dict(silent=True, evidenceOnly=True), n * n * T * nh, dict(
+                workload='C4 HyperStudy 512x512 grid x 512 sigma values, T=256, evidenceOnly (forward passes only)',
+                grid=[n, n], T=T, n_hyper=nh, mode='evidenceOnly')
         return S, dict(silent=True), n * n * T * nh, dict(workload='C4 HyperStudy 512x512 grid x 512 sigma values, T=256, '
                                                            'full fit (forward+backward+average posterior)',
                                                            grid=[n, n], T=T, n_hyper=nh, mode='full')
@@ -231,7 +235,7 @@ def main():
                    log_evidence=float(S.logEvidence), roofline=roof, kernels=rf, device=eng.device_name())
         if not args.no_extra and world == 1:
             extra = {}
-            for name in ('fwd2048', 'c3', 'c2', 'c5'):
+            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5'):
                 if name == args.workload:
                     continue
                 try:
