@@ -132,7 +132,7 @@ def run(case):
         return r
 
     vals = [ts[:-1] if (isinstance(v, str) and v == 'all') else v for v in vals]
-    if len(vals) == 0 or all(np.ndim(v) == 0 for v in vals) and np.prod([np.size(v) for v in vals]) <= 1:
+    if len(vals) == 0 or np.prod([np.size(v) for v in vals]) <= 1:
         # <= 1 hyper-grid point: falls back to Study.fit (core.py:1434-1441)
         r = orc.fit(g, om, data, ts, prior, ops, orc.align_values(ops, [np.ravel(v)[0] for v in vals]),
                     forward_only=fo, evidence_only=eo, reset=reset, indep=indep)

@@ -133,6 +133,20 @@ EXTRA = {
     'x_mfma_axis1_only': dict(study='Study', data=('series', 33, 9),
                               om=('Gaussian', [('mean', ('cint', -4, 4, 97)), ('std', ('oint', 0, 3, 111))], 'default'),
                               tm=('GRW', 's2', 0.05, 'std', None)),
+    # edge shapes: a single time step, minimal grids, a first step without data, one hyper-grid point
+    'x_single_step': dict(study='Study', data=np.array([2.5]), om=cases.gauss2d(64, -5, 5, 3),
+                          tm=('Combined', [('GRW', 's1', 0.3, 'mean', None), ('GRW', 's2', 0.1, 'std', None)])),
+    'x_single_step_1d': dict(study='Study', data=np.array([3]), om=('Poisson', [('rate', ('oint', 0, 6, 33))], 'default'),
+                             tm=('GRW', 'sigma', 0.4, 'rate', None)),
+    'x_two_cells_1d': dict(study='Study', data=cases.D15, om=('Poisson', [('rate', ('cint', 1, 3, 2))], 'default'),
+                           tm=('GRW', 'sigma', 0.7, 'rate', None)),
+    'x_tiny_2d': dict(study='Study', data=('series', 35, 6),
+                      om=('Gaussian', [('mean', ('cint', -2, 2, 3)), ('std', ('oint', 0, 3, 5))], 'default'),
+                      tm=('Combined', [('GRW', 's1', 1.5, 'mean', None), ('GRW', 's2', 0.9, 'std', None)])),
+    'x_first_step_missing': dict(study='Study', data=('series_nan', 36, 9, [0, 1, 8]), om=cases.gauss2d(40, -5, 5, 3),
+                                 tm=('GRW', 's1', 0.3, 'mean', None)),
+    'x_one_hyper_point': dict(study='HyperStudy', data=('series', 37, 7), om=cases.gauss2d(32, -5, 5, 3),
+                              tm=('GRW', 'sigma', [0.25], 'mean', None)),
     'x_cp_all': dict(study='ChangepointStudy', data=('series_jump', 26, 30, 17, 2.5), om=cases.gauss2d(50, -5, 7, 3),
                      tm=('ChangePoint', 'tc', 'all', None)),
 }
