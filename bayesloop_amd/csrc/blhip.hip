@@ -13,6 +13,8 @@
 #include <limits>
 #include <map>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/blhip.h"
@@ -62,6 +64,25 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// page-locked host staging: a hipMemcpyAsync to / from pageable memory is staged by the runtime behind blocking waits whose
+// wake-up is quantised (10-ms steps seen on a 6 KB read-back: 20-27 ms per call instead of 0.5 ms)
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        release();
+        HIPCHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -74,7 +95,7 @@ struct blhip_ctx {
     static constexpr int NBS = 12;
     hipStream_t bstream[NBS] = {};
     hipEvent_t bev[NBS] = {};
-    hipEvent_t fork_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, sync_ev = nullptr;
     std::string err;
     std::string name;
     std::map<std::string, double> opt;
@@ -94,6 +115,7 @@ struct blhip_ctx {
     struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; std::vector<double> maxv; };
     std::map<int, Carry> carry;
     DevBuf mix, unit, databuf;
+    PinBuf pinF, pinB, pinS;     // host staging of the reduced sums (forward, backward) and of small read-backs
     int64_t mix_G = 0;
 
     double option(const char *k, double dflt) const {
@@ -103,6 +125,30 @@ struct blhip_ctx {
 };
 
 namespace {
+
+// Wait for a stream by polling an event: hipStreamSynchronize blocks on an interrupt whose wake-up is quantised (~10 ms
+// steps measured on long waits: 15-25 ms of wall time per fit on top of a 365 ms device timeline).
+struct Trace {
+    bool on; std::chrono::steady_clock::time_point t0;
+    explicit Trace(bool o) : on(o), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[blhip trace] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+void sync_stream(blhip_ctx *ctx, hipStream_t st) {
+    if (ctx->option("spin_sync", 1.0) == 0.0) { HIPCHECK(hipStreamSynchronize(st)); return; }
+    HIPCHECK(hipEventRecord(ctx->sync_ev, st));
+    for (;;) {
+        const hipError_t e = hipEventQuery(ctx->sync_ev);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIPCHECK(e);
+        std::this_thread::yield();
+    }
+}
 
 struct TapTable {
     std::vector<double> w;       // concatenated half kernels: w[off + k], k = 0..lw
@@ -331,8 +377,16 @@ void launch_fast_om(hipStream_t s, const blf::FastParams &P, int R0, bool H, int
 template <int OM, int MODE, int NK, bool H>
 void launch_mfma_k(hipStream_t s, const blf::FastParams &P, int nchains) {
     const dim3 grid(P.mnblk, nchains), block(H ? blm::NT_H : blm::NT_V);
-    if (OM == OM_GAUSSIAN && P.use_rec) hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, OM == OM_GAUSSIAN, H>), grid, block, 0, s, P);
-    else hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, false, H>), grid, block, 0, s, P);
+    constexpr bool G = OM == OM_GAUSSIAN;
+    if constexpr (!H) {
+        if (P.mlean) {     // whole tile groups inside the grid, 32-bit offsets (blhip_mfma.hpp: LEAN)
+            if (G && P.use_rec) hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, G, false, true>), grid, block, 0, s, P);
+            else hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, false, false, true>), grid, block, 0, s, P);
+            return;
+        }
+    }
+    if (G && P.use_rec) hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, G, H, false>), grid, block, 0, s, P);
+    else hipLaunchKernelGGL((blm::mfma_step_kernel<OM, MODE, NK, false, H, false>), grid, block, 0, s, P);
 }
 
 template <int OM, int MODE>
@@ -758,6 +812,7 @@ size_t carve_size(size_t bytes) { return ((bytes + 255) / 256) * 256; }
 
 void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const double *op_values,
             const double *log_w, uint32_t flags, blhip_result *res) {
+    Trace tr(ctx->option("trace", 0.0) != 0.0);
     validate(p_in, n_chains, op_values);
     // closed-form models without an in-kernel likelihood: their (T, G) table is built on the device, the step kernels
     // then see a tabulated likelihood
@@ -850,7 +905,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             HIPCHECK(hipMemcpyAsync(d_lik, p->lik, sizeof(double) * T * G, hipMemcpyHostToDevice, st));
         }
     }
-    HIPCHECK(hipStreamSynchronize(st));   // host vectors above go out of use
+    sync_stream(ctx, st);   // host vectors above go out of use
+    tr.mark("tables + H2D");
 
     // ---- batching ------------------------------------------------------------------------------------------------
     size_t free_b = 0, total_b = 0;
@@ -875,15 +931,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     const int64_t Bcap = (n_chains + nbatch - 1) / nbatch;
     ctx->timing.batches = nbatch;
 
+    tr.mark("memory budget");
     hipEvent_t *ev = ctx->ev;
     HIPCHECK(hipEventRecord(ev[6], st));
 
-    std::vector<double> redF, redB;
+    double *redF = nullptr, *redB = nullptr;   // reduced sums on the host (page-locked staging of the context)
     for (int64_t c0 = 0; c0 < n_chains; c0 += Bcap) {
         const int64_t B = std::min(Bcap, n_chains - c0);
         TapTable taps;
         ChainProgram prog;
+        tr.mark("batch setup");
         build_program(p, g, c0, B, op_values, taps, prog, resume);
+        tr.mark("build_program");
         // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
         const bool fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
                           ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
@@ -1025,6 +1084,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             HIPCHECK(hipMemcpyAsync(d_lw2, taps.lw2.data(), taps.lw2.size() * 4, hipMemcpyHostToDevice, st));
         }
 
+        tr.mark("buckets + metadata H2D");
         // --- state ---
         const size_t psz = (size_t)T * B * NRED * tile.nblk;
         ctx->psumF.ensure(psz * 8);
@@ -1050,7 +1110,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     unit[((size_t)b * NRED + k) * tile.nblk] = (k == 6 && (int64_t)mv.size() == B) ? mv[b] : 1.0;
             ctx->unit.ensure(unit.size() * 8);
             HIPCHECK(hipMemcpyAsync(ctx->unit.p, unit.data(), unit.size() * 8, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipStreamSynchronize(st));
+            sync_stream(ctx, st);
             d_unit = ctx->unit.as<double>();
         }
         StepParams P{};
@@ -1066,6 +1126,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             FP.n0 = g.n0; FP.n1 = g.n1; FP.TJ = tile.TJ; FP.S = fastS; FP.nseg = fast_nseg;
             FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk; FP.fnblk = fast_fnblk;
             FP.dump = d_dump;
+            FP.mlean = (g.n0 % mS == 0 && (double)G * 8.0 < 4.0e9 && g.n1 < (1 << 20) && g.n0 < (1 << 24) &&
+                        ctx->option("mfma_lean", 1.0) != 0.0) ? 1 : 0;
             FP.mS = mS; FP.mnseg = m_nseg; FP.mtiles_j = m_tiles_j; FP.mnblk = m_nblk;
             FP.ndim = p->ndim; FP.d = d; FP.means = forward_only ? 1 : 0;
             FP.shared[SRC_PREV] = nullptr; FP.shared[SRC_PRIOR] = d_prior; FP.shared[SRC_RESET] = d_reset;
@@ -1170,6 +1232,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             F1.shared[SRC_UNIFORM] = d_uniform; F1.shared[SRC_INDEP] = d_indep;
             F1.taps = d_taps; F1.tap_off = d_off; F1.tap_lw = d_lw; F1.m1 = d_m1; F1.colA = d_colA; F1.rec = d_rec; F1.lik = d_lik;
         }
+        tr.mark("state alloc");
         // --- forward pass (core.py:372-411) ---
         HIPCHECK(hipEventRecord(ev[0], st));
         if (persist) {
@@ -1217,9 +1280,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (!persist)
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
                                ctx->redF.as<double>(), tile.nblk, NRED);
-        redF.resize((size_t)T * B * NRED);
-        HIPCHECK(hipMemcpyAsync(redF.data(), ctx->redF.p, redF.size() * 8, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+        ctx->pinF.ensure((size_t)T * B * NRED * 8);
+        redF = ctx->pinF.as<double>();
+        HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
+        sync_stream(ctx, st);
         ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
         ctx->timing.forward_ms += ms;
@@ -1299,9 +1363,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (!persist)
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
                                    ctx->redB.as<double>(), tile.nblk, NRED);
-            redB.resize((size_t)T * B * NRED);
-            HIPCHECK(hipMemcpyAsync(redB.data(), ctx->redB.p, redB.size() * 8, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
+            ctx->pinB.ensure((size_t)T * B * NRED * 8);
+            redB = ctx->pinB.as<double>();
+            HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
+            sync_stream(ctx, st);
             HIPCHECK(hipEventElapsedTime(&ms, ev[2], ev[3]));
             ctx->timing.backward_ms += ms;
             if (n_mfma[1] > 0 && n_mfma[1] >= n_fast[1]) ctx->timing.bwd_kernel_variant = 3;
@@ -1327,6 +1392,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         return raw_ok || K == 1;
         };
+        tr.mark("passes");
         int64_t usedK = fusedK;
         if (!passes(fusedK)) { usedK = 1; passes(1); }
 
@@ -1342,7 +1408,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             else { fin = fused1d ? d_pp[((T - 1) / usedK) & 1] : d_pp[(T - 1) & 1]; fstr = G; }
             const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
             hipLaunchKernelGGL(carry_store_kernel, dim3(gx, (unsigned)B), dim3(NTHREADS), 0, st, cs.buf.as<double>(), fin, fstr, G, d_w);
-            HIPCHECK(hipStreamSynchronize(st));
+            sync_stream(ctx, st);
             cs.chains = B; cs.G = G; cs.valid = true;
             cs.maxv.clear();
             if (prog.has_clamp)                      // clamp batches run the generic kernel, which reports the state maximum
@@ -1380,7 +1446,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                                        (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
                 }
                 HIPCHECK(hipEventRecord(ev[5], st));
-                HIPCHECK(hipStreamSynchronize(st));
+                sync_stream(ctx, st);
                 HIPCHECK(hipEventElapsedTime(&ms, ev[4], ev[5]));
                 ctx->timing.accumulate_ms += ms;
                 ctx->timing.accumulate_launches += 1;
@@ -1397,11 +1463,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             for (int64_t b = 0; b < B; ++b)
                 hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st,
                                    d_post + (size_t)b * T * G, G, d_invN + b * T);
-            HIPCHECK(hipStreamSynchronize(st));
+            sync_stream(ctx, st);
             ctx->post_valid = true; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = G;
             ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
         }
 
+        tr.mark("accumulate / keep");
         // --- results ---
         if (res) {
             for (int64_t b = 0; b < B; ++b) {
@@ -1416,10 +1483,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
         }
     }
+    tr.mark("batches done");
     HIPCHECK(hipEventRecord(ev[7], st));
     HIPCHECK(hipEventSynchronize(ev[7]));
     float ms = 0;
     HIPCHECK(hipEventElapsedTime(&ms, ev[6], ev[7]));
+    tr.mark("final sync");
     ctx->timing.total_ms = ms;
 }
 
@@ -1464,6 +1533,7 @@ blhip_ctx *blhip_create(int device) {
         for (auto &bs : ctx->bstream) HIPCHECK(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
         for (auto &e : ctx->bev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming));
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, device));
         ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
@@ -1485,6 +1555,7 @@ void blhip_destroy(blhip_ctx *ctx) {
                       &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit, &ctx->databuf})
         b->release();
     for (auto &kv : ctx->carry) kv.second.buf.release();
+    ctx->pinF.release(); ctx->pinB.release(); ctx->pinS.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &bs : ctx->bstream)
@@ -1492,6 +1563,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     for (auto &e : ctx->bev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1513,7 +1585,7 @@ int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
 int blhip_synchronize(blhip_ctx *ctx) {
     return guarded(ctx, [&] {
         HIPCHECK(hipSetDevice(ctx->device));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        sync_stream(ctx, ctx->stream);
     });
 }
 
@@ -1536,7 +1608,7 @@ int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, 
         HIPCHECK(hipSetDevice(ctx->device));
         const double *src = ctx->post.as<double>() + ((size_t)chain * ctx->post_T + t0) * ctx->post_G;
         HIPCHECK(hipMemcpyAsync(host_out, src, (size_t)(t1 - t0) * ctx->post_G * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        sync_stream(ctx, ctx->stream);
     });
 }
 
@@ -1593,7 +1665,7 @@ int blhip_posterior_marginal(blhip_ctx *ctx, int source, int64_t chain, int keep
                                v.p, d_out, v.n0, v.n1);
         }
         HIPCHECK(hipMemcpyAsync(host_out, d_out, (size_t)v.T * nk * 8, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+        sync_stream(ctx, st);
     });
 }
 
@@ -1609,7 +1681,7 @@ int blhip_posterior_time_average(blhip_ctx *ctx, int source, int64_t chain, doub
         hipLaunchKernelGGL(time_average_kernel, dim3((unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096)),
                            dim3(NTHREADS), 0, st, v.p, d_out, G, (int)v.T);
         HIPCHECK(hipMemcpyAsync(host_out, d_out, (size_t)G * 8, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+        sync_stream(ctx, st);
     });
 }
 
@@ -1631,7 +1703,7 @@ int blhip_carry_mix(blhip_ctx *ctx, int slot, int64_t n_chains, const double *we
         hipLaunchKernelGGL(carry_mix_kernel, dim3(gx), dim3(NTHREADS), 0, st, ctx->mix.as<double>(), cs.buf.as<double>(),
                            (long long)cs.G, (int)n_chains, ctx->small.as<double>(), accumulate ? 1 : 0);
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipStreamSynchronize(st));
+        sync_stream(ctx, st);
     });
 }
 
@@ -1650,7 +1722,7 @@ int blhip_carry_read(blhip_ctx *ctx, int slot, int64_t chain, double *host_out) 
             HIPCHECK(hipMemcpyAsync(host_out, it->second.buf.as<double>() + (size_t)chain * it->second.G, (size_t)it->second.G * 8,
                                     hipMemcpyDeviceToHost, st));
         }
-        HIPCHECK(hipStreamSynchronize(st));
+        sync_stream(ctx, st);
     });
 }
 
@@ -1708,7 +1780,7 @@ int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref) {
                 hipLaunchKernelGGL(scale_all_kernel, dim3(2048), dim3(NTHREADS), 0, ctx->stream, ctx->acc, n, r);
         }
         ctx->acc_logref = new_log_ref;
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        sync_stream(ctx, ctx->stream);
     });
 }
 
@@ -1738,18 +1810,19 @@ int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *p, double *posteri
         hipLaunchKernelGGL(row_stats_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, n1,
                            p->ndim, d_m0, d_m1, d_part);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * 3)), dim3(NTHREADS), 0, st, d_part, d_red, (int)gx, 0);
-        std::vector<double> red((size_t)T * 3), inv(T);
-        HIPCHECK(hipMemcpyAsync(red.data(), d_red, red.size() * 8, hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+        ctx->pinS.ensure((size_t)T * 4 * 8);
+        double *red = ctx->pinS.as<double>(), *inv = red + (size_t)T * 3;
+        HIPCHECK(hipMemcpyAsync(red, d_red, (size_t)T * 3 * 8, hipMemcpyDeviceToHost, st));
+        sync_stream(ctx, st);
         for (int64_t t = 0; t < T; ++t) {
             inv[t] = 1.0 / red[t * 3];                                           // core.py:1379-1382
             if (posterior_mean)
                 for (int k = 0; k < p->ndim; ++k) posterior_mean[k * T + t] = red[t * 3 + 1 + k] / red[t * 3];   // :1416-1419
         }
-        HIPCHECK(hipMemcpyAsync(d_inv, inv.data(), T * 8, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(d_inv, inv, T * 8, hipMemcpyHostToDevice, st));
         const unsigned gs = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
         hipLaunchKernelGGL(scale_rows_kernel, dim3(gs, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, d_inv);
-        HIPCHECK(hipStreamSynchronize(st));
+        sync_stream(ctx, st);
         ctx->acc_final = true;
         ctx->acc_n0 = n0; ctx->acc_n1 = n1;
     });
@@ -1762,7 +1835,7 @@ int blhip_accum_read(blhip_ctx *ctx, int64_t t0, int64_t t1, double *host_out) {
         HIPCHECK(hipSetDevice(ctx->device));
         HIPCHECK(hipMemcpyAsync(host_out, ctx->acc + (size_t)t0 * ctx->acc_G, (size_t)(t1 - t0) * ctx->acc_G * 8,
                                 hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        sync_stream(ctx, ctx->stream);
     });
 }
 

@@ -40,6 +40,7 @@ struct FastParams {
     int nblk;                    // partial-sum slots per chain and reduction = max(fnblk, mnblk): both kernel families of a
                                  // batch write the same slot layout (blocks zero the slots their family does not use)
     int mS, mnseg, mtiles_j, mnblk;   // geometry of blm::mfma_step_kernel (blhip_mfma.hpp): 64-column strips, mS rows
+    int mlean;                        // every segment is mS full rows (mS % 32 == 0) and offsets fit 32 bits: LEAN kernels
     int ndim, d, means, use_rec;
     double step0;                // lattice step of the row axis (likelihood recurrence)
     const double *src;  long long src_stride;

@@ -71,8 +71,16 @@ __device__ __forceinline__ double block_sum_w(double v, double *red) {
     return s;
 }
 
-template <int OM, int MODE, int NK, bool REC, bool H>
+// LEAN (axis-0-only launches whose segments are whole groups of BLM_PF tiles inside the grid, state < 4 GB per chain): no
+// row masks, no dump slots (a lane past the last column recomputes and re-stores column n1 - 1 bit for bit), 32-bit byte
+// offsets from wave-uniform base pointers.  On gfx950 every VALU instruction adds to the f64 MFMA time (see above), and the
+// generic addressing / masking was ~30 % of the non-MFMA instructions of a tile.
+__device__ __forceinline__ double ld32(const double *base, unsigned byteoff) { return *(const double *)((const char *)base + byteoff); }
+__device__ __forceinline__ void st32(double *base, unsigned byteoff, double v) { *(double *)((char *)base + byteoff) = v; }
+
+template <int OM, int MODE, int NK, bool REC, bool H, bool LEAN>
 __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastParams P) {
+    static_assert(!(H && LEAN), "the lean addressing is for the axis-0-only kernels");
     constexpr bool BWD = MODE == blk::MODE_BWD;
     constexpr bool GAUSS = OM == blk::OM_GAUSSIAN;
     constexpr int R0 = (4 * NK - TM) / 2;
@@ -150,12 +158,25 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     // Lanes that own no output column (columns past the grid edge, the halo wave) address a dump slot with row stride 0:
     // their loads and stores need no mask inside the loop, their sums are discarded at the end.
     double *const dump = P.dump + (tid & 255);
-    const long long rs = owner ? P.n1 : 0;
-    double *const dcol = owner ? P.dst + (long long)b * P.dst_stride + gj : dump;
-    double *const pcol = (BWD && owner) ? P.post + (long long)b * P.post_stride + gj : dump;
-    const double *const lcol = (!GAUSS && owner) ? P.lik + gj : dump;
+    const bool addressed = owner || LEAN;          // LEAN: dead column lanes duplicate column n1 - 1 (identical values)
+    const long long rs = addressed ? P.n1 : 0;
+    double *const dcol = addressed ? P.dst + (long long)b * P.dst_stride + gj : dump;
+    double *const pcol = (BWD && addressed) ? P.post + (long long)b * P.post_stride + gj : dump;
+    const double *const lcol = (!GAUSS && addressed) ? P.lik + gj : dump;
+    // LEAN: wave-uniform bases + 32-bit byte offsets (row * n1 * 8 + column * 8 via a 24-bit multiply-add)
+    double *const dbase = P.dst + (long long)b * P.dst_stride;
+    double *const pbase = BWD ? P.post + (long long)b * P.post_stride : nullptr;
+    const unsigned n1x8 = (unsigned)P.n1 * 8u, gj8 = (unsigned)gj * 8u;
+    // rows entering the window in the steady state are >= 0: only the upper mirror and the clamp of the tail remain
+    auto refl_hi = [&](int r) { return max(min(r, 2 * P.n0 - 1 - r), 0); };
     typedef const double __attribute__((address_space(3))) *lds_cp;
+#ifdef BLM_A_FROM_LDS
+    // keep the band in LDS (re-read per tile) instead of letting the compiler hoist NK doubles into registers
+    typedef const volatile double __attribute__((address_space(3))) *lds_cvp;
+    lds_cvp Al = (lds_cvp)(lds_cp)As + lane;
+#else
     lds_cp Al = (lds_cp)As + lane;
+#endif
 
     static_assert(BLM_PF % 2 == 0, "prefetch depth must be even (two alpha / likelihood slots, two LDS tiles)");
     // Memory pipeline.  Everything inside the tile loop is straight-line and UNCONDITIONAL (clamped / reflected addresses
@@ -190,11 +211,15 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
             const int li = i - i_lo + g;           // this lane's first row of the tile, relative to the segment
             if (BWD) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) al[(u + 1) & 1][r] = pcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * rs];
+                for (int r = 0; r < 4; ++r)
+                    al[(u + 1) & 1][r] = LEAN ? ld32(pbase, __umul24(min(i + TM + g + 4 * r, P.n0 - 1), n1x8) + gj8)
+                                              : pcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * rs];
             }
             if (!GAUSS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lk[(u + 1) & 1][r] = lcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * rs];
+                for (int r = 0; r < 4; ++r)
+                    lk[(u + 1) & 1][r] = LEAN ? ld32(P.lik, __umul24(min(i + TM + g + 4 * r, P.n0 - 1), n1x8) + gj8)
+                                              : lcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * rs];
             }
 
             // ---- axis-0 stencil: NK chained MFMAs (k ascending); NK == 4: no filter, the ring IS the D layout -------------
@@ -274,7 +299,7 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                     } else {
                         Lv = lk[u & 1][r];
                     }
-                    const bool live = gi < i_hi;
+                    const bool live = LEAN || gi < i_hi;
                     if (!BWD) {
                         const double a = acc[r] * scale * Lv;
                         st1[r] = a;
@@ -308,13 +333,23 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = i + g + 4 * r;
-                const bool live = gi < i_hi;
-                const long long off = (long long)gi * rs;
-                if (!BWD) {
-                    *(live ? dcol + off : dump) = st1[r];
+                if (LEAN) {
+                    const unsigned off = __umul24(gi, n1x8) + gj8;
+                    if (!BWD) {
+                        st32(dbase, off, st1[r]);
+                    } else {
+                        st32(pbase, off, st1[r]);
+                        st32(dbase, off, st2[r]);
+                    }
                 } else {
-                    *(live ? pcol + off : dump) = st1[r];
-                    *(live ? dcol + off : dump) = st2[r];
+                    const bool live = gi < i_hi;
+                    const long long off = (long long)gi * rs;
+                    if (!BWD) {
+                        *(live ? dcol + off : dump) = st1[r];
+                    } else {
+                        *(live ? pcol + off : dump) = st1[r];
+                        *(live ? dcol + off : dump) = st2[r];
+                    }
                 }
             }
 
@@ -325,7 +360,8 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
             for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = nxt[u][q];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                nxt[u][q] = col[(long long)reflect1(i + (BLM_PF + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
+                nxt[u][q] = LEAN ? ld32(src, __umul24(refl_hi(i + (BLM_PF + 1) * TM + R0 + 4 * q + g), n1x8) + gj8)
+                                 : col[(long long)reflect1(i + (BLM_PF + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
         }
     }
 
