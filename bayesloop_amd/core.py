@@ -192,6 +192,24 @@ class Study(object):
 
     # ---- prior ---------------------------------------------------------------------------------------------------
     def _computePrior(self, silent=False):
+        """Prior on the grid (see :meth:`_evaluatePrior`).  The array of a callable / SymPy / uniform prior is kept for as
+        long as the same prior object is evaluated on the same grid: on a 2048 x 2048 grid evaluating the default Jeffreys
+        prior in numpy takes longer (13 ms) than the 200 forward steps of the fit on the GPU (5.5 ms).  An ndarray prior is
+        always re-read (it may have been modified in place).  ``self.cachePrior = False`` switches the cache off."""
+        prior = self.observationModel.prior
+        if isinstance(prior, np.ndarray) or not getattr(self, 'cachePrior', True):
+            return self._evaluatePrior(silent)
+        key = (id(self.observationModel), tuple((len(m), float(m[0]), float(m[-1])) for m in self.marginalGrid),
+               tuple(float(c) for c in self.latticeConstant))
+        cached = getattr(self, '_prior_cache', None)
+        if cached is not None and cached[0] == key and cached[1] is prior and cached[2] is self.observationModel:
+            return cached[3]                       # (read-only array)
+        p = self._evaluatePrior(silent)
+        p.setflags(write=False)
+        self._prior_cache = (key, prior, self.observationModel, p)
+        return p
+
+    def _evaluatePrior(self, silent=False):
         """Prior on the grid for None / ndarray / callable priors (reference core.py:184-235).  Unlike the reference
         an ndarray prior is copied, never normalised in place."""
         prior = self.observationModel.prior
