@@ -103,6 +103,8 @@ struct blhip_ctx {
     DevBuf state, post, psumF, psumB, redF, redB, meta, tables, likbuf, small, accum_own, stats;
     // kept posterior of the last fit
     bool post_valid = false;
+    bool post_scaled = true;     // false: the kept rows still carry their raw sums; postinv holds 1 / sum per (chain, step)
+    DevBuf postinv;
     int64_t post_chains = 0, post_T = 0, post_G = 0;
     int post_n0 = 1, post_n1 = 1, acc_n0 = 1, acc_n1 = 1;
     // accumulator
@@ -810,6 +812,19 @@ template <class T> T *carve(char *&cur, size_t count) {
 }
 size_t carve_size(size_t bytes) { return ((bytes + 255) / 256) * 256; }
 
+// normalise the kept posterior rows (core.py:389 / :441) (eagerly at the end of the fit, or on first access with option lazy_normalise)
+void ensure_post_scaled(blhip_ctx *ctx) {
+    if (!ctx->post_valid || ctx->post_scaled) return;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const long long G = ctx->post_G;
+    const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+    for (int64_t b = 0; b < ctx->post_chains; ++b)
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)ctx->post_T), dim3(NTHREADS), 0, ctx->stream,
+                           ctx->post.as<double>() + (size_t)b * ctx->post_T * G, G, ctx->postinv.as<double>() + b * ctx->post_T);
+    HIPCHECK(hipGetLastError());
+    ctx->post_scaled = true;
+}
+
 void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const double *op_values,
             const double *log_w, uint32_t flags, blhip_result *res) {
     Trace tr(ctx->option("trace", 0.0) != 0.0);
@@ -1458,14 +1473,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         // --- normalise the kept posterior (core.py:389 / :441, applied lazily) ---
         if (keep) {
-            HIPCHECK(hipMemcpyAsync(d_invN, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
-            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-            for (int64_t b = 0; b < B; ++b)
-                hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st,
-                                   d_post + (size_t)b * T * G, G, d_invN + b * T);
+            ctx->postinv.ensure(nT * 8);
+            HIPCHECK(hipMemcpyAsync(ctx->postinv.p, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
             sync_stream(ctx, st);
-            ctx->post_valid = true; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = G;
+            ctx->post_valid = true; ctx->post_scaled = false; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = G;
             ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
+            // default: normalise now, as part of the fit (core.py:441 is inside Study.fit); option lazy_normalise = 1 defers
+            // the pass to the first access of the sequence
+            if (ctx->option("lazy_normalise", 0.0) == 0.0) { ensure_post_scaled(ctx); sync_stream(ctx, st); }
         }
 
         tr.mark("accumulate / keep");
@@ -1552,7 +1567,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
-                      &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit, &ctx->databuf})
+                      &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit, &ctx->databuf, &ctx->postinv})
         b->release();
     for (auto &kv : ctx->carry) kv.second.buf.release();
     ctx->pinF.release(); ctx->pinB.release(); ctx->pinS.release();
@@ -1603,6 +1618,7 @@ int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out) {
 int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, double *host_out) {
     return guarded(ctx, [&] {
         if (!ctx->post_valid) fail("no posterior kept (run blhip_fit with BLHIP_KEEP_POSTERIOR)");
+        ensure_post_scaled(ctx);
         if (chain < 0 || chain >= ctx->post_chains || t0 < 0 || t1 > ctx->post_T || t0 > t1 || !host_out)
             fail("blhip_posterior_read: bad range");
         HIPCHECK(hipSetDevice(ctx->device));
@@ -1615,6 +1631,8 @@ int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, 
 int blhip_posterior_devptr(blhip_ctx *ctx, void **devptr, int64_t *chain_stride, int64_t *step_stride) {
     return guarded(ctx, [&] {
         if (!ctx->post_valid) fail("no posterior kept");
+        ensure_post_scaled(ctx);
+        sync_stream(ctx, ctx->stream);
         if (devptr) *devptr = ctx->post.p;
         if (chain_stride) *chain_stride = ctx->post_T * ctx->post_G;
         if (step_stride) *step_stride = ctx->post_G;
@@ -1635,6 +1653,7 @@ SeqView sequence_view(blhip_ctx *ctx, int source, int64_t chain) {
     if (source == 0) {
         if (!ctx->post_valid) fail("no posterior kept (run blhip_fit with BLHIP_KEEP_POSTERIOR)");
         if (chain < 0 || chain >= ctx->post_chains) fail("chain out of range");
+        ensure_post_scaled(ctx);
         return SeqView{ctx->post.as<double>() + (size_t)chain * ctx->post_T * ctx->post_G, ctx->post_T, ctx->post_n0, ctx->post_n1};
     }
     if (source == 1) {
