@@ -286,6 +286,140 @@ class NumPy(ObservationModel):
         return self.function(dataSegment[0], *grid)
 
 
+def _free_symbols(rv):
+    """Free parameters of a SymPy random variable, in SymPy's own order (reference helper.py:122-145)."""
+    try:
+        symbols = rv._sorted_args[0].distribution.free_symbols          # SymPy <= 1.0
+    except AttributeError:
+        symbols = rv._sorted_args[1].distribution.free_symbols          # SymPy >= 1.1
+    return list(symbols)
+
+
+def jeffreys_prior_of(rv):
+    """Jeffreys prior sqrt(det Fisher information) of a SymPy random variable, symbolically (reference jeffreys.py:18-60):
+    returns (symbolic expression, numpy lambda of the free parameters)."""
+    import sympy
+    import sympy.abc as abc
+    from sympy.stats import density
+    try:
+        support = rv._sorted_args[0].distribution.set
+    except AttributeError:
+        support = rv._sorted_args[1].distribution.set
+    params = _free_symbols(rv)
+    x = abc.x
+    pdf = density(rv)(x)
+    accumulate = sympy.summation if support.is_iterable else sympy.integrate
+    fisher = sympy.Matrix.zeros(len(params), len(params))
+    for i, pi in enumerate(params):
+        for j, pj in enumerate(params):
+            fisher[i, j] = accumulate(sympy.simplify(pdf * sympy.diff(sympy.ln(pdf), pi) * sympy.diff(sympy.ln(pdf), pj)),
+                                      (x, support.inf, support.sup))
+    expr = sympy.simplify(sympy.sqrt(fisher.det()))
+    if expr == 0:
+        raise ValueError('Jeffreys prior could not be computed.')
+    return expr, sympy.lambdify(params, expr, 'numpy')
+
+
+class SciPy(ObservationModel):
+    """Observation model from a ``scipy.stats`` distribution (reference observationModels.py:146-269):
+    ``bl.om.SciPy(scipy.stats.poisson, 'mu', bl.oint(0, 6, 1000), fixedParameters={'loc': 0})``.  Flat prior by default.
+    The likelihood is the distribution's own pdf / pmf, evaluated on the host once per time step (table path)."""
+
+    def __init__(self, rv, *args, **kwargs):
+        module = getattr(rv, '__module__', '').split('.')
+        if module[:2] != ['scipy', 'stats']:
+            raise ConfigurationError('SciPy observation model must contain SciPy probability distribution')
+        for key in kwargs:
+            if key not in ['prior', 'fixedParameters']:
+                raise TypeError("__init__() got an unexpected keyword argument '{}'".format(key))
+        self.rv = rv
+        self.name = rv.name
+        if len(args) == 1 and isinstance(args[0], dict):
+            self.parameterNames, self.parameterValues = list(args[0].keys()), list(args[0].values())
+        else:
+            self.parameterNames, self.parameterValues = list(args[::2]), list(args[1::2])
+        self.prior = kwargs.get('prior', None)
+        self.fixedParameterDict = kwargs.get('fixedParameters', {})
+        self.segmentLength = 1
+        self.multiplyLikelihoods = True
+        self.isContinuous = hasattr(rv, 'pdf')
+        shapes = [] if rv.shapes is None else rv.shapes.split(', ')
+        shapes.append('loc')
+        if self.isContinuous:
+            shapes.append('scale')
+        free = [name for name in shapes if name not in self.fixedParameterDict]
+        if len(self.parameterNames) == 0:
+            self.parameterNames, self.parameterValues = free, [None] * len(free)
+        unknown = set(self.parameterNames).difference(free)
+        if unknown:
+            raise ConfigurationError('The following parameter names from the observation model do not match the parameter '
+                                     'names of the SciPy distribution: {} (options: {})'.format(list(unknown), free))
+
+    def pdf(self, grid, dataSegment):
+        params = dict(zip(self.parameterNames, grid))
+        params.update(self.fixedParameterDict)
+        f = self.rv.pdf if self.isContinuous else self.rv.pmf
+        return f(dataSegment[0], **params)
+
+
+class SymPy(ObservationModel):
+    """Observation model from a ``sympy.stats`` random variable (reference observationModels.py:272-391):
+    ``bl.om.SymPy(sympy.stats.Normal('norm', mu, std), 'mu', bl.cint(0, 7, 200), 'std', bl.oint(0, 1, 200))``.
+    The lambdified density is evaluated on the host once per time step (table path).
+
+    Prior: the reference means to derive the Jeffreys prior symbolically when no prior is given, but reads ``self.rv``
+    before assigning it (observationModels.py:351), so the attempt always fails and the prior is FLAT -- its published
+    results (tests/test_observationmodels.py:11-27) are flat-prior results.  ``determineJeffreysPrior=True`` (default)
+    therefore gives the flat prior here too, with the reference's warning; ``determineJeffreysPrior='symbolic'`` really
+    derives sqrt(det Fisher information) with SymPy (:func:`jeffreys_prior_of`)."""
+
+    def __init__(self, rv, *args, **kwargs):
+        module = getattr(rv, '__module__', '').split('.')
+        if module[:2] != ['sympy', 'stats']:
+            raise ConfigurationError('SymPy observation model must contain SymPy random variable.')
+        for key in kwargs:
+            if key not in ['prior', 'determineJeffreysPrior']:
+                raise TypeError("__init__() got an unexpected keyword argument '{}'".format(key))
+        import sympy
+        import sympy.abc as abc
+        from sympy.stats import density
+        from scipy.special import factorial, iv
+        self.rv = rv
+        self.name = str(rv)
+        if len(args) == 1 and isinstance(args[0], dict):
+            self.parameterNames, self.parameterValues = list(args[0].keys()), list(args[0].values())
+        else:
+            self.parameterNames, self.parameterValues = list(args[::2]), list(args[1::2])
+        symbols = _free_symbols(rv)
+        names = [str(p) for p in symbols]
+        if len(self.parameterNames) == 0:
+            self.parameterNames, self.parameterValues = names, [None] * len(names)
+        unknown = set(self.parameterNames).difference(names)
+        if unknown:
+            raise ConfigurationError('The following parameter names from the observation model do not match the names '
+                                     'of SymPy random variables: {}'.format(list(unknown)))
+        ordered = [symbols[names.index(name)] for name in self.parameterNames]
+        self.prior = kwargs.get('prior', None)
+        self.segmentLength = 1
+        self.multiplyLikelihoods = True
+        mode = kwargs.get('determineJeffreysPrior', True)
+        if self.prior is None and mode:
+            print('    + Trying to determine Jeffreys prior. This might take a moment...')
+            try:
+                if mode != 'symbolic':
+                    raise AttributeError("'SymPy' object has no attribute 'rv'")     # what happens in the reference
+                expr, self.prior = jeffreys_prior_of(rv)
+                print('    + Successfully determined Jeffreys prior: {}. Will use corresponding lambda function.'.format(expr))
+            except Exception:
+                print('    ! WARNING: Failed to determine Jeffreys prior. Will use flat prior instead.')
+                self.prior = None
+        x = abc.x
+        self.density = sympy.lambdify([x] + ordered, density(rv)(x), modules=['numpy', {'factorial': factorial, 'besseli': iv}])
+
+    def pdf(self, grid, dataSegment):
+        return self.density(dataSegment[0], *grid)
+
+
 def device_code(om):
     """C-ABI code of the observation model, or OM_TABLE when its ``pdf`` is not the built-in one (user subclass)."""
     for cls in type(om).__mro__:

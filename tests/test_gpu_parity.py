@@ -411,3 +411,32 @@ def test_simulate_matches_reference_golden():
         np.testing.assert_allclose(S.simulate(x), gold[case + '_avg'], rtol=1e-9, atol=1e-300)
         np.testing.assert_allclose(S.simulate(x, t=float(gold[case + '_t'])), gold[case + '_at'], rtol=1e-9, atol=1e-300)
         np.testing.assert_allclose(S.simulate(x, density=True), gold[case + '_avg_density'], rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.gpu
+def test_plugin_observation_models_on_device():
+    """bl.om.SymPy / SciPy / NumPy (reference tests/test_observationmodels.py:11-120): host-evaluated likelihood tables,
+    recursion on the GPU; the reference's log-evidence values (decimal=5 there)."""
+    scipy_stats = pytest.importorskip('scipy.stats')
+    sympy_stats = pytest.importorskip('sympy.stats')
+    from sympy import Symbol
+
+    def logE(L, data=np.array([1, 2, 3, 4, 5])):
+        S = bl.Study(silent=True)
+        S.loadData(data, silent=True)
+        S.setOM(L, silent=True)
+        S.setTM(bl.tm.Static(), silent=True)
+        S.fit(silent=True)
+        assert S.lastTiming['forward_launches'] > 0
+        return S.logEvidence
+
+    rate = Symbol('rate', positive=True)
+    np.testing.assert_almost_equal(logE(bl.om.SymPy(sympy_stats.Poisson('poisson', rate), 'rate', bl.oint(0, 7, 100))),
+                                   -10.238278174965238, decimal=9)
+    mu, std = Symbol('mu'), Symbol('std', positive=True)
+    np.testing.assert_almost_equal(logE(bl.om.SymPy(sympy_stats.Normal('norm', mu, std), 'mu', bl.cint(0, 7, 200), 'std',
+                                                    bl.oint(0, 1, 200), prior=lambda x, y: 1.)), -13.663836264357226, decimal=9)
+    np.testing.assert_almost_equal(logE(bl.om.SciPy(scipy_stats.poisson, 'mu', bl.oint(0, 7, 100), fixedParameters={'loc': 0})),
+                                   -10.238278174965238, decimal=9)
+    np.testing.assert_almost_equal(logE(bl.om.SciPy(scipy_stats.norm, 'loc', bl.cint(0, 7, 200), 'scale', bl.oint(0, 1, 200))),
+                                   -13.663836264357225, decimal=9)

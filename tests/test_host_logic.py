@@ -158,3 +158,44 @@ def test_simulate_matches_reference_golden_host_side():
     S.set(bl.om.AR1('rho', bl.oint(-1, 1, 20), 'sigma', bl.oint(0, 1, 20)), bl.tm.Static(), silent=True)
     with pytest.raises(NotImplementedError):
         S.simulate([0.])
+
+
+def test_scipy_sympy_numpy_observation_models_reference_kats():
+    """bl.om.SymPy / SciPy / NumPy (reference tests/test_observationmodels.py:11-120): plug-in likelihoods through the
+    table path; the reference's own log-evidence values, same tolerance (decimal=5)."""
+    scipy_stats = pytest.importorskip('scipy.stats')
+    sympy_stats = pytest.importorskip('sympy.stats')
+    from sympy import Symbol
+
+    def logE(L, data=np.array([1, 2, 3, 4, 5])):
+        S = bl.Study(silent=True)
+        S.loadData(data, silent=True)
+        S.setOM(L, silent=True)
+        S.setTM(bl.tm.Static(), silent=True)
+        S.fit(silent=True)
+        return S.logEvidence
+
+    rate = Symbol('rate', positive=True)
+    np.testing.assert_almost_equal(logE(bl.om.SymPy(sympy_stats.Poisson('poisson', rate), 'rate', bl.oint(0, 7, 100))),
+                                   -10.238278174965238, decimal=5)
+    mu, std = Symbol('mu'), Symbol('std', positive=True)
+    np.testing.assert_almost_equal(logE(bl.om.SymPy(sympy_stats.Normal('norm', mu, std), 'mu', bl.cint(0, 7, 200), 'std',
+                                                    bl.oint(0, 1, 200), prior=lambda x, y: 1.)), -13.663836264357226, decimal=5)
+    np.testing.assert_almost_equal(logE(bl.om.SciPy(scipy_stats.poisson, 'mu', bl.oint(0, 7, 100), fixedParameters={'loc': 0})),
+                                   -10.238278174965238, decimal=5)
+    np.testing.assert_almost_equal(logE(bl.om.SciPy(scipy_stats.norm, 'loc', bl.cint(0, 7, 200), 'scale', bl.oint(0, 1, 200))),
+                                   -13.663836264357225, decimal=5)
+
+    def likelihood(data, mu):
+        x, s = data
+        return np.exp((x - mu) ** 2. / (2 * s ** 2.)) / np.sqrt(2 * np.pi * s ** 2.)
+    np.testing.assert_almost_equal(logE(bl.om.NumPy(likelihood, 'mu', bl.oint(0, 7, 100)),
+                                        np.array([[1, 0.5], [2, 0.5], [3, 0.5], [4, 1.], [5, 1.]])), 148.92056578058387, decimal=5)
+    # the symbolic Jeffreys prior the reference intends (1/sqrt(rate) for a Poisson rate)
+    from bayesloop_amd.observationModels import jeffreys_prior_of
+    expr, f = jeffreys_prior_of(sympy_stats.Poisson('poisson', rate))
+    assert str(expr) == '1/sqrt(rate)' and abs(f(4.0) - 0.5) < 1e-15
+    with pytest.raises(bl.ConfigurationError):
+        bl.om.SciPy(np.random, 'mu', bl.oint(0, 7, 100))
+    with pytest.raises(bl.ConfigurationError):
+        bl.om.SciPy(scipy_stats.norm, 'wrong', bl.oint(0, 7, 100))
