@@ -199,3 +199,21 @@ def test_scipy_sympy_numpy_observation_models_reference_kats():
         bl.om.SciPy(np.random, 'mu', bl.oint(0, 7, 100))
     with pytest.raises(bl.ConfigurationError):
         bl.om.SciPy(scipy_stats.norm, 'wrong', bl.oint(0, 7, 100))
+
+
+def test_save_load_roundtrip(tmp_path):
+    """bl.save / bl.load (reference fileIO.py:10-37, tests/test_fileio.py): a fitted study with a lambda prior survives."""
+    S = bl.HyperStudy(silent=True)
+    S.loadData(np.array([1, 2, 3, 4, 5]), silent=True)
+    S.setOM(bl.om.Gaussian('mean', bl.cint(0, 6, 20), 'sigma', bl.oint(0, 2, 20), prior=lambda m, s: 1 / s ** 3), silent=True)
+    S.setTM(bl.tm.GaussianRandomWalk('s', [0.1, 0.3], target='mean'), silent=True)
+    S.fit(silent=True)
+    path = str(tmp_path / 'study.bl')
+    bl.save(path, S)
+    R = bl.load(path)
+    assert R.logEvidence == S.logEvidence
+    np.testing.assert_array_equal(R.posteriorSequence, S.posteriorSequence)
+    np.testing.assert_array_equal(R.hyperParameterDistribution, S.hyperParameterDistribution)
+    assert R.observationModel.prior(1.0, 2.0) == 1 / 8.
+    R.fit(silent=True)                     # the loaded study can be fitted again
+    assert abs(R.logEvidence - S.logEvidence) < 1e-12
