@@ -72,7 +72,8 @@ __device__ __forceinline__ double block_sum_w(double v, double *red) {
 }
 
 // LEAN (axis-0-only launches whose segments are whole groups of BLM_PF tiles inside the grid, state < 4 GB per chain): no
-// row masks, no dump slots (a lane past the last column recomputes and re-stores column n1 - 1 bit for bit), 32-bit byte
+// row masks, a lane past the last column recomputes and re-stores column n1 - 1 bit for bit (except the in-place posterior
+// of the backward step, which it sends to a dump slot), 32-bit byte
 // offsets from wave-uniform base pointers.  On gfx950 every VALU instruction adds to the f64 MFMA time (see above), and the
 // generic addressing / masking was ~30 % of the non-MFMA instructions of a tile.
 __device__ __forceinline__ double ld32(const double *base, unsigned byteoff) { return *(const double *)((const char *)base + byteoff); }
@@ -338,7 +339,9 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                     if (!BWD) {
                         st32(dbase, off, st1[r]);
                     } else {
-                        st32(pbase, off, st1[r]);
+                        // the posterior overwrites the stored alpha IN PLACE: a lane past the last column must not touch
+                        // column n1 - 1 (another wave may own it and be at a different tile); the state store is idempotent
+                        *(owner ? (double *)((char *)pbase + off) : dump) = st1[r];
                         st32(dbase, off, st2[r]);
                     }
                 } else {

@@ -440,3 +440,35 @@ def test_plugin_observation_models_on_device():
                                    -10.238278174965238, decimal=9)
     np.testing.assert_almost_equal(logE(bl.om.SciPy(scipy_stats.norm, 'loc', bl.cint(0, 7, 200), 'scale', bl.oint(0, 1, 200))),
                                    -13.663836264357225, decimal=9)
+
+
+@pytest.mark.gpu
+def test_matrix_pipe_lean_kernels_partial_column_blocks():
+    """LEAN matrix-pipe kernels on a grid whose last 64-column block is mostly empty (450 columns: three of its four waves
+    own no column) -- the in-place posterior of the backward step must only be touched by the owning lanes.  Compared with
+    the vector-ALU kernels (mfma=0), several times (a race would not show every time)."""
+    eng = bl.get_engine()
+
+    def fit(**opts):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        try:
+            S = bl.HyperStudy(silent=True)
+            S.loadData(cases.series(77, 10), silent=True)
+            S.set(bl.om.Gaussian('mean', bl.cint(-6, 6, 256), 'std', bl.oint(0, 3, 450)),
+                  bl.tm.GaussianRandomWalk('sigma', bl.cint(0.1, 0.45, 6), target='mean'), silent=True)
+            S.fit(silent=True)
+            return S
+        finally:
+            for k in opts:
+                eng.set_option(k, 1)
+
+    B = fit(mfma=0)
+    assert B.lastTiming['bwd_kernel_variant'] == 1
+    want = np.array(B.posteriorSequence)
+    for _ in range(4):
+        A = fit()
+        assert A.lastTiming['bwd_kernel_variant'] == 3
+        assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
+        np.testing.assert_allclose(A.posteriorSequence, want, rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(A.posteriorMeanValues, B.posteriorMeanValues, rtol=1e-10)
