@@ -41,3 +41,22 @@ def test_no_gpu_fails_loudly():
         pytest.skip('a GPU is visible')
     with pytest.raises(BackendError):
         HipEngine(0)
+
+
+def test_header_is_plain_c_and_the_c_demo_links(tmp_path):
+    """include/blhip.h compiles as C99 (no C++ / torch types) and examples/c_abi_demo.c links against libblhip.so; without
+    a GPU the demo prints the ABI version and exits with 0 (its compute part is exercised by the -m gpu test)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        import pytest
+        pytest.skip('gcc not available')
+    exe = str(tmp_path / 'c_abi_demo')
+    libdir = os.path.dirname(_abi.library_path())
+    cmd = ['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-O2', '-I' + os.path.join(ROOT, 'include'),
+           os.path.join(ROOT, 'examples', 'c_abi_demo.c'), '-o', exe, '-L' + libdir, '-lblhip', '-Wl,-rpath,' + libdir, '-lm']
+    subprocess.run(cmd, check=True, capture_output=True)
+    if _abi.load().blhip_device_count() > 0:
+        return
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and 'ABI version %d' % _abi.ABI_VERSION in out.stdout

@@ -4,6 +4,8 @@ Parity of the HIP path (through the C-ABI of libblhip.so) on a real MI355X again
   (b) the CPU oracle on seeded inputs the fixtures do not cover.
 Bar (BASELINE.json / SURVEY.md 8d, float64): log-evidence 1e-9 relative; posteriors |dp| <= 1e-12 + 1e-9 p.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -472,3 +474,21 @@ def test_matrix_pipe_lean_kernels_partial_column_blocks():
         assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
         np.testing.assert_allclose(A.posteriorSequence, want, rtol=1e-9, atol=1e-14)
         np.testing.assert_allclose(A.posteriorMeanValues, B.posteriorMeanValues, rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_plain_c_program_through_the_abi(tmp_path):
+    """examples/c_abi_demo.c: the coal-mining fit driven from C, no Python in the call path."""
+    import shutil
+    import subprocess
+    from bayesloop_amd import _abi
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'c_abi_demo')
+    libdir = os.path.dirname(_abi.library_path())
+    subprocess.run(['gcc', '-std=c99', '-O2', '-I' + os.path.join(root, 'include'), os.path.join(root, 'examples', 'c_abi_demo.c'),
+                    '-o', exe, '-L' + libdir, '-lblhip', '-Wl,-rpath,' + libdir, '-lm'], check=True, capture_output=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'log-evidence -171.6867218' in out.stdout
