@@ -1471,6 +1471,24 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
         }
 
+#ifdef BLM_TLOG
+        if (use_mfma) {   // diagnostic build: when did the blocks of the last matrix-pipe launches start and end?
+            static unsigned long long h[2][3 * 4096];
+            HIPCHECK(hipDeviceSynchronize());
+            HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(blm::tlog), sizeof(h)));
+            for (int m = 0; m < 2; ++m) {
+                const int nb = (int)std::min<long long>(4096, (long long)FP.mnblk * B);
+                unsigned long long t0 = ~0ull, t1 = 0; double ds = 0, dl = 0, smax = 0, emin = 1e30;
+                for (int i = 0; i < nb; ++i) { t0 = std::min(t0, h[m][3 * i]); t1 = std::max(t1, h[m][3 * i + 2]); }
+                for (int i = 0; i < nb; ++i) {
+                    ds += (double)(h[m][3 * i + 2] - h[m][3 * i]); dl += (double)(h[m][3 * i + 2] - h[m][3 * i + 1]);
+                    smax = std::max(smax, (double)(h[m][3 * i] - t0)); emin = std::min(emin, (double)(h[m][3 * i + 2] - t0));
+                }
+                fprintf(stderr, "[tlog %s] blocks %d span %.2f us  mean block life %.2f us  mean loop %.2f us  last start +%.2f us  first end +%.2f us\n",
+                        m ? "bwd" : "fwd", nb, (t1 - t0) * 0.01, ds / nb * 0.01, dl / nb * 0.01, smax * 0.01, emin * 0.01);
+            }
+        }
+#endif
         // --- normalise the kept posterior (core.py:389 / :441, applied lazily) ---
         if (keep) {
             ctx->postinv.ensure(nT * 8);

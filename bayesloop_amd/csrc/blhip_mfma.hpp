@@ -32,6 +32,10 @@
 #include "blhip_fast.hpp"
 
 namespace blm {
+#ifdef BLM_TLOG
+// diagnostic build (-DBLM_TLOG): wall-clock (100 MHz) start / tile-loop start / end of every block of the last launch
+__device__ unsigned long long tlog[2][3 * 4096];
+#endif
 
 using blf::FastParams;
 using blf::exp_mn;
@@ -92,6 +96,9 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     __shared__ double red[5 * NW + 1];
     __shared__ double Vt[H ? 2 * TM * RS : 1];
 
+#ifdef BLM_TLOG
+    const unsigned long long t_start = wall_clock64();
+#endif
     const int b = sldi(P.chain_ids, blockIdx.y);
     const int blkid = blockIdx.x;
     const int tj = blkid / P.mnseg, seg = blkid - tj * P.mnseg;
@@ -204,6 +211,9 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
         for (int r = 0; r < 4; ++r) lk[0][r] = lcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * rs];
     }
 
+#ifdef BLM_TLOG
+    const unsigned long long t_loop = wall_clock64();
+#endif
     for (int i0 = i_lo; i0 < i_hi; i0 += BLM_PF * TM) {
 #pragma unroll
         for (int u = 0; u < BLM_PF; ++u) {
@@ -368,6 +378,9 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
         }
     }
 
+#ifdef BLM_TLOG
+    if (threadIdx.x == 0) { const int id = blockIdx.y * gridDim.x + blockIdx.x; if (id < 4096) { tlog[BWD][3 * id] = t_start; tlog[BWD][3 * id + 1] = t_loop; tlog[BWD][3 * id + 2] = wall_clock64(); } }
+#endif
     if (!owner) { sN = 0.0; sS = 0.0; sC = 0.0; sM0 = 0.0; sM1 = 0.0; }
     double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
     const int left = P.nblk - blkid;

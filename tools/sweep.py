@@ -50,7 +50,7 @@ if which == 'one':
     run(n, 16, {}, 'full', two=two)
 if which == 'bucket':
     # C4-like: 512x512 grid, 64 chains, GRW on 'mean' only, all chains in one radius bucket
-    n, T, nh = 512, 32, 64
+    n, T, nh = 512, int(os.environ.get('SWEEP_T', 32)), 64
     for lw in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 4, 8, 12, 16, 24, 32, 38)):
         sig = (lw / 4.0) * (16.0 / (n - 1)) if lw else 0.0
         S = bl.HyperStudy(silent=True); S.loadData(series(4, T), silent=True)
@@ -75,3 +75,18 @@ if which == 'ms':
         run(n, 24, {}, 'full')
         run(n, 24, {'multistream': 0}, 'full')
         run(n, 24, {}, 'full')
+if which == 'shape':
+    # same cell count per chain (2^18), different row lengths: does the 512-byte column strip of a block cost DRAM efficiency?
+    T, nh = 32, 64
+    lw = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    for n0, n1 in ((4096, 64), (2048, 128), (1024, 256), (512, 512), (256, 1024), (128, 2048)):
+        sig = (lw / 4.0) * (16.0 / (n0 - 1))
+        S = bl.HyperStudy(silent=True); S.loadData(series(4, T), silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n0), 'std', bl.oint(0, 4, n1)),
+              bl.tm.GaussianRandomWalk('sigma', bl.cint(sig * 0.97 + 1e-9, sig + 1e-9, nh), target='mean'), silent=True)
+        S.fit(silent=True); S.fit(silent=True)
+        t = S.lastTiming; cells = n0 * n1 * nh
+        S._posterior_pending = None; eng.release_posterior()
+        print('%4d x %4d lw0~%2d  fwd %8.1f us %5.0f GB/s   bwd %8.1f us %5.0f GB/s' % (
+            n0, n1, lw, t['forward_ms'] * 1e3 / t['forward_launches'], 16.0 * cells / (t['forward_ms'] * 1e-3 / t['forward_launches']) / 1e9,
+            t['backward_ms'] * 1e3 / t['backward_launches'], 32.0 * cells / (t['backward_ms'] * 1e-3 / t['backward_launches']) / 1e9), flush=True)
