@@ -599,7 +599,7 @@ class HyperStudy(Study):
 
     All hyper-grid points are independent forward-backward chains; they run batched on the GPU (one kernel launch per
     time step for the whole batch) and, when a communicator is attached (:mod:`bayesloop_amd.dist`), sharded over the
-    GPUs of a node in the contiguous chunks of ``np.array_split`` that the reference's ``_parallelFit`` uses.
+    GPUs of a node round-robin (the reference's ``_parallelFit`` hands out ``np.array_split`` chunks; same results).
     """
 
     def __init__(self, silent=False):

@@ -1,7 +1,11 @@
 """
-Multi-GPU HyperStudy: one process per GPU, hyper-grid points sharded in the contiguous chunks of ``np.array_split``
-(the partition the reference's ``HyperStudy._parallelFit`` uses, bayesloop/core.py:1464-1465), no communication while
-the chains run, and ONE exchange at the end over RCCL / xGMI (``torch.distributed`` backend "nccl" is RCCL on ROCm):
+Multi-GPU HyperStudy: one process per GPU, hyper-grid points dealt out round-robin (rank r runs points r, r + R, ...),
+no communication while the chains run, and ONE exchange at the end over RCCL / xGMI (``torch.distributed`` backend
+"nccl" is RCCL on ROCm).  The reference's ``HyperStudy._parallelFit`` hands out the contiguous chunks of
+``np.array_split`` (bayesloop/core.py:1464-1465); the results do not depend on which worker runs which point, but the
+cost of a chain does depend on its hyper-parameter value (a wider random walk is a wider stencil): on the C4 workload the
+last contiguous chunk takes 16 % longer than the first one, the strided shares are within 0.5 % of each other
+(tools/shard_balance.py).
 
   1. all-gather of the packed per-chain scalars  [logEvidence | localEvidence (T) | abort step]      (KBs)
   2. only when posteriors were requested: all-reduce(MAX) of one scalar (the accumulators' reference exponents),
@@ -78,6 +82,11 @@ def default_communicator():
     return None
 
 
+def shard_indices(n, size, rank):
+    """Hyper-grid points of one rank: rank, rank + size, ... (balances any smooth cost trend over the hyper-grid)."""
+    return np.arange(rank, n, size)
+
+
 def chunk_bounds(n, size):
     """Contiguous near-equal chunks, identical to np.array_split(range(n), size)."""
     parts = np.array_split(np.arange(n), size)
@@ -98,7 +107,7 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
     ndim = len(grid_size)
     size = 1 if comm is None else comm.size
     rank = 0 if comm is None else comm.rank
-    lo, hi = chunk_bounds(n_h, size)[rank]
+    mine = shard_indices(n_h, size, rank)
     with np.errstate(divide='ignore'):
         log_w = np.log(np.asarray(prior_values, dtype=float))
     want_post = not evidence_only
@@ -108,28 +117,29 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
         buf = comm.new_buffer(T * G) if comm is not None else None
         engine.accum_begin(T, G, external=buf, owner=owner)
 
-    n_mine = hi - lo
+    n_mine = len(mine)
     logE = np.zeros(n_mine)
     local = np.zeros((n_mine, T))
     astep = np.full(n_mine, -1.0)
     timing = {}
     if n_mine > 0:
-        res = engine.fit(problem, op_values[lo:hi], forward_only=forward_only, evidence_only=evidence_only,
-                         keep_posterior=False, accumulate=want_post, log_chain_weight=log_w[lo:hi], owner=owner)
+        res = engine.fit(problem, np.asarray(op_values)[mine], forward_only=forward_only, evidence_only=evidence_only,
+                         keep_posterior=False, accumulate=want_post, log_chain_weight=log_w[mine], owner=owner)
         logE, local, astep, timing = res.log_evidence, res.local_evidence, res.abort_step.astype(float), res.timing
 
     if comm is not None:
-        # ---- the single gather: [logE | local (T) | abort] per chain, padded to the largest chunk ----------------
-        bounds = chunk_bounds(n_h, size)
-        width = max(b - a for a, b in bounds)
+        # ---- the single gather: [logE | local (T) | abort] per chain, padded to the largest share ----------------
+        width = (n_h + size - 1) // size
         packed = np.zeros((width, T + 2))
         packed[:n_mine, 0] = logE
         packed[:n_mine, 1:T + 1] = local
         packed[:n_mine, T + 1] = astep
         parts = comm.all_gather(packed)
-        logE = np.concatenate([parts[r][:b - a, 0] for r, (a, b) in enumerate(bounds)])
-        local = np.concatenate([parts[r][:b - a, 1:T + 1] for r, (a, b) in enumerate(bounds)])
-        astep = np.concatenate([parts[r][:b - a, T + 1] for r, (a, b) in enumerate(bounds)])
+        full = np.zeros((n_h, T + 2))
+        for r in range(size):
+            idx = shard_indices(n_h, size, r)
+            full[idx] = parts[r][:len(idx)]
+        logE, local, astep = full[:, 0], full[:, 1:T + 1], full[:, T + 1]
 
     means, posterior = None, None
     if want_post:

@@ -9,7 +9,7 @@ A "step" is one complete pass of the hot path over one batch of synthetic input:
 Workloads (synthetic data, seeds fixed):
   c4       HyperStudy, 512 x 512 Gaussian (mean, std) grid, GaussianRandomWalk on 'mean' with 512 sigma values
            cint(0, 0.3, 512), T = 256, FULL fit (forward + backward + evidence-weighted average posterior).
-           The headline at every N: the 512 hyper-grid points are sharded over the N ranks in np.array_split chunks
+           The headline at every N: the 512 hyper-grid points are dealt out round-robin to the N ranks
            (strong scaling: total work fixed), one gather + one reduce over RCCL at the end.
   c5       ChangepointStudy, 512 x 512 grid, T = 1000, 256 candidate change-points, full fit     (sharded like c4)
   c3       Study, 1024 x 1024 grid, T = 2000, GRW x GRW separable stencil, full fit             (N = 1)

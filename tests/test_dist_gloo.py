@@ -76,3 +76,13 @@ def test_chunks_equal_array_split():
             got = chunk_bounds(n, size)
             for p, (a, b) in zip(parts, got):
                 assert list(p) == list(range(a, b))
+
+
+def test_round_robin_shares_partition_the_hyper_grid():
+    from bayesloop_amd.dist import shard_indices
+    for n in (1, 2, 7, 16, 512, 513):
+        for size in (1, 2, 3, 4, 8):
+            shares = [shard_indices(n, size, r) for r in range(size)]
+            assert sorted(np.concatenate(shares).tolist()) == list(range(n))
+            assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+            assert max(len(s) for s in shares) == (n + size - 1) // size
