@@ -251,9 +251,20 @@ def main():
             out['extra'] = extra
         if not args.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline()
+    def drain_c_stdio():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     if dist is not None:
+        drain_c_stdio()                          # every rank, before the barrier: nothing of theirs can follow rank 0's line
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio; on a pipe it sits in libc's buffer until exit, i.e. AFTER anything
+    # Python printed.  Drain it first so that the JSON line really is the last line on stdout.
+    drain_c_stdio()
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(out), flush=True)       # the ONE JSON line, last on stdout
