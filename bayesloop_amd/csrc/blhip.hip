@@ -977,9 +977,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
             // keep the redundantly recomputed halo (K * LW cells per side) within ~4x the owned cells and the window in LDS
             while (fusedK > 1 && (fusedK * prog.LW1 > 2 * f1_TJ || (size_t)(f1_TJ + 2 * fusedK * prog.LW1) * 32 > 96 * 1024)) --fusedK;
-            fused1d = (size_t)(f1_TJ + 2 * fusedK * prog.LW1) * 32 + (size_t)fusedK * f1_TJ * 8 + 4096 <= 150 * 1024;
+            fused1d = (size_t)(f1_TJ + 2 * fusedK * prog.LW1) * 32 + (size_t)fusedK * f1_TJ * 32 + 4096 <= 150 * 1024;
         }
-        auto f1_lds = [&](int64_t K) { return (size_t)(4 * (f1_TJ + 2 * K * prog.LW1) + K * f1_TJ + K * (prog.LW1 + 1) + K * rec_len + 4 * 8 + 2 + K + 8) * sizeof(double); };
+        auto f1_lds = [&](int64_t K) { return (size_t)(4 * (f1_TJ + 2 * K * prog.LW1) + K * f1_TJ + K * (prog.LW1 + 1) + K * rec_len + 4 * 8 + 2 + K + 8 + K * 3 * f1_TJ) * sizeof(double); };
         Tile tile{};
         int fastS = 0, fast_nseg = 1, fast_fnblk = 1, mS = 0, m_nseg = 1, m_tiles_j = 1, m_nblk = 1;
         bool use_mfma = false;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(NT) void fused1d_kernel(const F1Params P) {
     double *recs = wls + P.K * (P.LW + 1);                        // [K][rec_len] data records of the K steps
     double *red = recs + P.K * P.rec_len;
     int *meta = (int *)(red + 4 * (NT / 64) + 2);                 // [K] source kind, [K] radius
+    double *part = red + 4 * (NT / 64) + 2 + P.K;                 // [K][3][TJ] per-cell terms of the K steps' sums
     const int b = blockIdx.y, blkid = blockIdx.x, tid = threadIdx.x;
     const int j0 = blkid * P.TJ, tw = min(P.TJ, n - j0);
     double *post = P.post ? P.post + (long long)b * P.post_stride : nullptr;
@@ -99,8 +100,7 @@ __global__ __launch_bounds__(NT) void fused1d_kernel(const F1Params P) {
 
     for (int s = 0; s < P.K; ++s) {
         const int t = P.t_first + P.dir * s;
-        const long long tb = (long long)t * P.B + b;
-        __syncthreads();                                           // previous step's reads of cur are done (s = 0: prologue)
+        __syncthreads();                                           // previous step's writes of nxt / reads of cur are done
         const int kind = meta[s], lw = meta[P.K + s];
         const double *wl = wls + s * (P.LW + 1);
         if (s > 0 && kind != SRC_PREV) {                           // restart from a shared distribution
@@ -112,7 +112,9 @@ __global__ __launch_bounds__(NT) void fused1d_kernel(const F1Params P) {
         Q.lik = P.lik ? P.lik + (long long)t * n : nullptr;
         double *row = post ? post + (long long)t * n : nullptr;
 
-        double sN = 0.0, sS = 0.0, sC = 0.0, sM = 0.0;
+        // The step's sums (normaliser, p / L, next state, mean) are not on the critical path of the recursion: the owned
+        // cells park their terms in LDS and all K steps are reduced after the loop.  ONE barrier per step (top of the loop).
+        double *pt = part + (size_t)s * 3 * P.TJ;
         const int lo = (s + 1) * P.LW, hi = W - (s + 1) * P.LW;    // cells that are still exact after this step
         for (int e = lo + tid; e < hi; e += NT) {
             // four interleaved accumulators: a single fp64 FMA chain of 2 lw + 1 links costs ~32 cycles per link
@@ -137,8 +139,7 @@ __global__ __launch_bounds__(NT) void fused1d_kernel(const F1Params P) {
                 nxt[e] = a;
                 if (owned) {
                     if (P.store) row[j0 + oc] = a;
-                    sN += a;
-                    if (P.means) sM = fma(a, g1, sM);
+                    pt[oc] = a;
                 }
             } else {
                 const double cn = o * L;
@@ -146,24 +147,29 @@ __global__ __launch_bounds__(NT) void fused1d_kernel(const F1Params P) {
                 if (owned) {
                     const double p = als[s * P.TJ + oc] * o;
                     row[j0 + oc] = p;
-                    sN += p;
-                    sS += p / L;                                   // 0/0 -> NaN as numpy (core.py:463)
-                    sC += cn;
-                    sM = fma(p, g1, sM);
+                    pt[oc] = p;
+                    pt[P.TJ + oc] = p / L;                         // 0/0 -> NaN as numpy (core.py:463)
+                    pt[2 * P.TJ + oc] = cn;
                 }
             }
-        }
-        double v[4] = {sN, sS, sC, sM};
-        blk::block_sums<4, NT / 64>(v, red);                       // its barriers also order nxt before the next step's reads
-        if (tid == 0) {
-            double *out = P.psum + (tb * NRED) * P.nblk + blkid;
-            out[0] = v[0];
-            if (BWD) { out[1 * P.nblk] = v[1]; out[2 * P.nblk] = v[2]; }
-            if (BWD || P.means) out[3 * P.nblk] = v[3];
         }
         double *tmp = cur; cur = nxt; nxt = tmp;
     }
     __syncthreads();
+    // ---- the sums of the K steps: wave w takes the (step, slot) pairs w, w + 8, ...; fixed order -> deterministic ----------
+    for (int pr = tid >> 6; pr < 4 * P.K; pr += NT / 64) {
+        const int s = pr >> 2, k = pr & 3, lane = tid & 63;
+        if (!(k == 0 || BWD || (k == 3 && P.means))) continue;
+        const double *pt = part + (size_t)s * 3 * P.TJ + (k == 3 ? 0 : k) * P.TJ;
+        double acc = 0.0;
+        if (k == 3) { for (int c = lane; c < tw; c += 64) acc = fma(pt[c], g1s[halo + c], acc); }
+        else { for (int c = lane; c < tw; c += 64) acc += pt[c]; }
+        acc = blk::wave_sum(acc);
+        if (lane == 0) {
+            const long long tb = (long long)(P.t_first + P.dir * s) * P.B + b;
+            P.psum[(tb * NRED + k) * P.nblk + blkid] = acc;
+        }
+    }
     if (P.dst) {
         double *d = P.dst + (long long)b * P.dst_stride + j0;
         for (int c = tid; c < tw; c += NT) d[c] = cur[halo + c];
