@@ -1193,6 +1193,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         const bool mfma_h = ctx->option("mfma_h", 1.0) != 0.0;
         const double mfma_h_max_cells = ctx->option("mfma_h_max_cells", 2.5e6);
         long long n_mfma[2] = {0, 0}, n_fast[2] = {0, 0};
+        const bool uniform_launch = ctx->option("uniform_launch", 1.0) != 0.0;
         auto run_step = [&](int mode, int64_t t, const double *srcp, long long src_stride, double *dstp, long long dst_stride,
                             double *postp, long long post_stride, const double *ps_prev, int prev_slot, double *ps_out,
                             bool means) {
@@ -1208,6 +1209,16 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
+                    Q.u_valid = 0;
+                    if (r.count == 1 && uniform_launch) {      // single-chain launch: hand the chain's metadata over by value
+                        const int64_t tb = t * B;
+                        const int cb = (mode == MODE_FWD ? orderF : orderB)[tb + r.start];
+                        const int k0 = (mode == MODE_FWD ? prog.tapF0 : prog.tapB0)[tb + cb];
+                        const int k1 = (mode == MODE_FWD ? prog.tapF1 : prog.tapB1)[tb + cb];
+                        Q.u_valid = 1; Q.u_chain = cb; Q.u_kind = (mode == MODE_FWD ? prog.kindF : prog.kindB)[tb + cb];
+                        Q.u_t0 = k0; Q.u_lw0 = k0 >= 0 ? taps.lw[k0] : 0; Q.u_off0 = k0 >= 0 ? taps.off[k0] : 0;
+                        Q.u_t1 = k1; Q.u_lw1 = k1 >= 0 ? taps.lw[k1] : 0; Q.u_off1 = k1 >= 0 ? taps.off[k1] : 0;
+                    }
                     hipStream_t ls = multistream ? ctx->bstream[r.key] : st;
                     if (use_mfma && (r.H ? (mfma_h && (double)r.count * g.n0 * g.n1 <= mfma_h_max_cells) : r.R0 >= mfma_min_r0)) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }
                     else { launch_fast(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_fast[mode == MODE_FWD ? 0 : 1]; }

@@ -55,7 +55,32 @@ struct FastParams {
     double *psum_out;
     const double *m0, *m1, *colA, *colB, *rec, *lik;
     double *dump;                // NTHREADS doubles nobody reads: where dead lanes store (keeps the stores branch-free)
+    // single-chain launches (every plain Study.fit): the host already knows what the block would fetch through a chain of
+    // dependent scalar loads (chain id -> source kind / tap ids -> radius / offset, ~1 us per block): u_valid = 1
+    int u_valid, u_chain, u_kind, u_t0, u_t1, u_lw0, u_lw1;
+    long long u_off0, u_off1;
 };
+
+// per-chain launch metadata: from the kernel arguments (single-chain launch) or from the device tables
+struct ChainMeta { int b, kind, t0, lw0, t1, lw1; long long o0, o1; };
+__device__ __forceinline__ int sldi_(const int *p, long long i) { return ((const int __attribute__((address_space(4))) *)(unsigned long long)p)[i]; }
+__device__ __forceinline__ ChainMeta chain_meta(const FastParams &P, bool want0, bool want1) {
+    ChainMeta m;
+    if (P.u_valid) {
+        m.b = P.u_chain; m.kind = P.u_kind; m.t0 = P.u_t0; m.lw0 = want0 ? P.u_lw0 : 0; m.o0 = P.u_off0;
+        m.t1 = P.u_t1; m.lw1 = want1 ? P.u_lw1 : 0; m.o1 = P.u_off1;
+    } else {
+        m.b = sldi_(P.chain_ids, blockIdx.y);
+        m.kind = ((const unsigned char __attribute__((address_space(4))) *)(unsigned long long)P.srckind)[m.b];
+        m.t0 = sldi_(P.tap0, m.b);
+        m.lw0 = (want0 && m.t0 >= 0) ? sldi_(P.tap_lw, m.t0) : 0;
+        m.o0 = (want0 && m.t0 >= 0) ? sldi_(P.tap_off, m.t0) : 0;
+        m.t1 = want1 ? sldi_(P.tap1, m.b) : -1;
+        m.lw1 = (want1 && m.t1 >= 0) ? sldi_(P.tap_lw, m.t1) : 0;
+        m.o1 = (want1 && m.t1 >= 0) ? sldi_(P.tap_off, m.t1) : 0;
+    }
+    return m;
+}
 
 // block `blkid` of a kernel family with my_nblk blocks per chain publishes its partial sum in slot blkid and zeroes the
 // slots blkid + k * my_nblk the family does not own (left = slots from blkid to the end)
@@ -126,16 +151,15 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
     __shared__ __attribute__((aligned(16))) double vtbuf[H ? 2 * VTSZ : 1];
     __shared__ double red[5 * (NTHREADS / 64) + 1];
 
-    const int b = sldi(P.chain_ids, blockIdx.y);
+    const ChainMeta cmeta = chain_meta(P, R0 > 0, H);
+    const int b = cmeta.b;
     const int blkid = blockIdx.x;
     const int tj = blkid / P.nseg, seg = blkid - tj * P.nseg;
     const int i_lo = seg * P.S, i_hi = min(P.n0, i_lo + P.S);
     const int j0 = tj * P.TJ;
     const int tid = threadIdx.x;
 
-    const int kind = ((const unsigned char __attribute__((address_space(4))) *)(unsigned long long)P.srckind)[b];
-    const int t0 = sldi(P.tap0, b);
-    const int lw0 = (R0 > 0 && t0 >= 0) ? sldi(P.tap_lw, t0) : 0;
+    const int kind = cmeta.kind, lw0 = cmeta.lw0;
     const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
 
     // ---- this thread's column ------------------------------------------------------------------------------------
@@ -158,15 +182,14 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
     // stencil weights (SGPRs), zero beyond this chain's radius
     double wk[R0 + 1];
     if (R0 > 0) {
-        const long long o0 = t0 >= 0 ? sldi(P.tap_off, t0) : 0;
+        const long long o0 = cmeta.o0;
 #pragma unroll
         for (int k = 0; k <= R0; ++k) wk[k] = (lw0 > 0 && k <= lw0) ? sld(P.taps, o0 + k) : (k == 0 ? 1.0 : 0.0);
     }
     double w1[R1MAX + 1];
     if (H) {
-        const int t1 = sldi(P.tap1, b);
-        const int lw1 = t1 >= 0 ? sldi(P.tap_lw, t1) : 0;
-        const long long o1 = t1 >= 0 ? sldi(P.tap_off, t1) : 0;
+        const int t1 = cmeta.t1, lw1 = cmeta.lw1;
+        const long long o1 = cmeta.o1;
 #pragma unroll
         for (int k = 0; k <= R1MAX; ++k) w1[k] = (t1 >= 0 && k <= lw1) ? sld(P.taps, o1 + k) : (k == 0 ? 1.0 : 0.0);
     }

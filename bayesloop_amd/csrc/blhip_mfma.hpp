@@ -99,7 +99,8 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
 #ifdef BLM_TLOG
     const unsigned long long t_start = wall_clock64();
 #endif
-    const int b = sldi(P.chain_ids, blockIdx.y);
+    const blf::ChainMeta cmeta = blf::chain_meta(P, NK > 4, H);
+    const int b = cmeta.b;
     const int blkid = blockIdx.x;
     const int tj = blkid / P.mnseg, seg = blkid - tj * P.mnseg;
     const int i_lo = seg * P.mS, i_hi = min(P.n0, i_lo + P.mS);
@@ -107,9 +108,7 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool mainw = !H || wv < 4;                              // wave-uniform: wave 4 of an H block = halo columns
 
-    const int kind = ((const unsigned char __attribute__((address_space(4))) *)(unsigned long long)P.srckind)[b];
-    const int t0 = sldi(P.tap0, b);
-    const int lw0 = (NK > 4 && t0 >= 0) ? sldi(P.tap_lw, t0) : 0;
+    const int kind = cmeta.kind, lw0 = cmeta.lw0;
     const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
 
     // ---- this lane's column ---------------------------------------------------------------------------------------------
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     for (int kb = 0; kb < NK; ++kb) Bv[kb] = col[(long long)reflect1(i_lo - R0 + 4 * kb + g, P.n0) * P.n1];
 
     if (NK > 4) {
-        const long long o0 = t0 >= 0 ? sldi(P.tap_off, t0) : 0;
+        const long long o0 = cmeta.o0;
         for (int e = tid; e < NK * 64; e += NT) {
             const int kb = e >> 6, l = e & 63;
             const int a = abs(4 * kb + (l >> 4) - R0 - (l & 15));
@@ -134,9 +133,8 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     for (int e = tid; e < P.mS + 2 * TM; e += NT) m0s[e] = P.m0[min(i_lo + e, P.n0 - 1)];
     double w1b[H ? NK1 : 1];                                      // axis-1 band, B operand: W1[k = 4 kb + g][n = c]
     if (H) {
-        const int t1 = sldi(P.tap1, b);
-        const int lw1 = t1 >= 0 ? sldi(P.tap_lw, t1) : 0;
-        const long long o1 = t1 >= 0 ? sldi(P.tap_off, t1) : 0;
+        const int lw1 = cmeta.lw1;
+        const long long o1 = cmeta.o1;
 #pragma unroll
         for (int kb = 0; kb < NK1; ++kb) {
             const int a = abs(4 * kb + g - R1 - c);
