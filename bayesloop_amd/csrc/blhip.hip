@@ -1045,7 +1045,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         const size_t nT = (size_t)T * B;
         taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
         size_t mb = 4 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
-                    3 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * NTHREADS);
+                    3 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * 4 * NTHREADS);
         ctx->meta.ensure(mb);
         cur = ctx->meta.as<char>();
         unsigned char *d_kindF = carve<unsigned char>(cur, nT), *d_kindB = carve<unsigned char>(cur, nT);
@@ -1060,7 +1060,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         double *d_invN = carve<double>(cur, nT);
         double *d_inv_tmp = carve<double>(cur, nT);
         double *d_w = carve<double>(cur, B);
-        double *d_dump = carve<double>(cur, NTHREADS);
+        double *d_dump = carve<double>(cur, 4 * NTHREADS);      // (the halo wave of an H block spreads its dummy stores over 8 x 64 slots)
         (void)d_inv_tmp;
         HIPCHECK(hipMemcpyAsync(d_kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(d_tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
@@ -1487,6 +1487,19 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             static unsigned long long h[2][3 * 4096];
             HIPCHECK(hipDeviceSynchronize());
             HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(blm::tlog), sizeof(h)));
+            static unsigned long long pl[2][5][16][5];
+            HIPCHECK(hipMemcpyFromSymbol(pl, HIP_SYMBOL(blm::plog), sizeof(pl)));
+            for (int m = 0; m < 2; ++m)
+                for (int w = 0; w < 5; ++w) {
+                    if (!pl[m][w][0][0]) continue;
+                    fprintf(stderr, "[plog %s wave %d]", m ? "bwd" : "fwd", w);
+                    for (int ti = 0; ti < 16 && pl[m][w][ti][0]; ++ti)
+                        fprintf(stderr, "  t%d: +%lld | a0+w %lld | bar %lld | a1+epi %lld | ring %lld", ti, (long long)(pl[m][w][ti][0] - pl[m][0][0][0]),
+                                (long long)(pl[m][w][ti][1] - pl[m][w][ti][0]), (long long)(pl[m][w][ti][2] - pl[m][w][ti][1]),
+                                (long long)(pl[m][w][ti][3] - pl[m][w][ti][2]), (long long)(pl[m][w][ti][4] - pl[m][w][ti][3]));
+                    fprintf(stderr, "\n");
+                }
+            hipMemset(nullptr, 0, 0);
             for (int m = 0; m < 2; ++m) {
                 const int nb = (int)std::min<long long>(4096, (long long)FP.mnblk * B);
                 unsigned long long t0 = ~0ull, t1 = 0; double ds = 0, dl = 0, smax = 0, emin = 1e30;

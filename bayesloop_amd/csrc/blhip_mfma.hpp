@@ -35,6 +35,7 @@ namespace blm {
 #ifdef BLM_TLOG
 // diagnostic build (-DBLM_TLOG): wall-clock (100 MHz) start / tile-loop start / end of every block of the last launch
 __device__ unsigned long long tlog[2][3 * 4096];
+__device__ unsigned long long plog[2][5][16][5];     // [dir][wave][tile][phase] cycle counter of one block
 #endif
 
 using blf::FastParams;
@@ -218,6 +219,11 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
             const int i = i0 + u * TM;             // (a tile past the end of the segment is all dead rows: mS % (BLM_PF * TM) == 0
                                                    //  keeps that to the ragged end of the grid)
             const int li = i - i_lo + g;           // this lane's first row of the tile, relative to the segment
+#ifdef BLM_TLOG
+            const bool plg = H && blockIdx.x == gridDim.x / 2 + 1 && blockIdx.y == 0 && lane == 0 && (i - i_lo) / TM < 16;
+            const int pti = (i - i_lo) / TM;
+            if (plg) plog[BWD][wv][pti][0] = __builtin_readcyclecounter();
+#endif
             if (BWD) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -247,7 +253,13 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                 const int lc = mainw ? R1 + wv * WCOL + c : (c < R1 ? c : BCOL + c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vt[(g + 4 * r) * RS + lc] = acc[r];
+#ifdef BLM_TLOG
+                if (plg) plog[BWD][wv][pti][1] = __builtin_readcyclecounter();
+#endif
                 __syncthreads();
+#ifdef BLM_TLOG
+                if (plg) plog[BWD][wv][pti][2] = __builtin_readcyclecounter();
+#endif
                 if (mainw) {
                     lds_cp va = (lds_cp)vt + c * RS + wv * WCOL + g;
                     d4 acc2 = {0.0, 0.0, 0.0, 0.0};
@@ -338,7 +350,15 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                 }
             }
 
-            // ---- stores (every wave, every lane: dead rows / lanes hit the dump slot) ---------------------------------------
+            // ---- stores (every lane: dead rows / lanes hit the dump slot) ---------------------------------------------------
+            // The halo wave of an H block shares its SIMD with wave 0, whose f64 MFMAs block every other VALU issue there: each
+            // VALU instruction the halo wave does not need shortens the wait of the four main waves at the next barrier.  It
+            // issues the same NUMBER of stores as a main wave (the compiler's vmcnt bookkeeping stays exact where the paths
+            // join), to fixed dump addresses (the dump area holds 4 x NTHREADS doubles), with no address arithmetic.
+            if (H && !mainw) {
+#pragma unroll
+                for (int r = 0; r < (BWD ? 8 : 4); ++r) dump[64 * r] = acc[r & 3];      // (distinct addresses: nothing to eliminate)
+            } else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = i + g + 4 * r;
@@ -364,6 +384,9 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                 }
             }
 
+#ifdef BLM_TLOG
+            if (plg) plog[BWD][wv][pti][3] = __builtin_readcyclecounter();
+#endif
             // ---- advance the ring by one tile, re-fill the slot ------------------------------------------------------------
 #pragma unroll
             for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
@@ -373,6 +396,9 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
             for (int q = 0; q < 4; ++q)
                 nxt[u][q] = LEAN ? ld32(src, __umul24(refl_hi(i + (BLM_PF + 1) * TM + R0 + 4 * q + g), n1x8) + gj8)
                                  : col[(long long)reflect1(i + (BLM_PF + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
+#ifdef BLM_TLOG
+            if (plg) plog[BWD][wv][pti][4] = __builtin_readcyclecounter();
+#endif
         }
     }
 
