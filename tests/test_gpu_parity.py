@@ -492,3 +492,63 @@ def test_plain_c_program_through_the_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'log-evidence -171.6867218' in out.stdout
+
+
+def _random_case(seed):
+    """A seeded random configuration (study kind, ragged grid sizes, stencil radii from 0 to ~45 cells, missing data,
+    fit flags) small enough for the oracle to finish in about a second."""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ['1d_poisson', '1d_gm', '2d_axis0', '2d_both', '2d_axis1', 'hyper_axis0', 'hyper_both', 'cp'][seed % 8]
+    T = int(rng.integers(1, 21))
+    flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
+    nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 2 else []
+    data = ('series_nan', 500 + seed, T, nan_at) if nan_at else ('series', 500 + seed, T)
+
+    def sigma(span, n, radius):              # random-walk width whose stencil radius is about `radius` cells
+        return max(radius, 0.3) / 4.0 * span / max(n - 1, 1)
+
+    if kind == '1d_poisson':
+        n = int(rng.integers(2, 12000))
+        counts = rng.poisson(3.0, T).astype(float)
+        return dict(study='Study', data=counts, om=('Poisson', [('rate', ('oint', 0, 8, n))], 'default'),
+                    tm=('GRW', 'sigma', sigma(8, n, rng.integers(0, 46)), 'rate', None), fit=flags)
+    if kind == '1d_gm':
+        n = int(rng.integers(2, 12000))
+        return dict(study='Study', data=('gm', 600 + seed, T), om=('GaussianMean', [('mean', ('cint', -6, 6, n))], 'default'),
+                    tm=('GRW', 'sigma', sigma(12, n, rng.integers(0, 46)), 'mean', None), fit=flags)
+    big = kind in ('2d_axis0', '2d_both', '2d_axis1')
+    n0, n1 = int(rng.integers(3, 421 if big else 201)), int(rng.integers(3, 421 if big else 201))
+    om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
+    r0, r1 = int(rng.integers(0, 46)), int(rng.integers(0, 9))
+    if kind == '2d_axis0':
+        return dict(study='Study', data=data, om=om, tm=('GRW', 's1', sigma(10, n0, r0), 'mean', None), fit=flags)
+    if kind == '2d_axis1':
+        return dict(study='Study', data=data, om=om, tm=('GRW', 's2', sigma(3, n1 + 2, r1), 'std', None), fit=flags)
+    if kind == '2d_both':
+        return dict(study='Study', data=data, om=om, fit=flags,
+                    tm=('Combined', [('GRW', 's1', sigma(10, n0, r0), 'mean', None), ('GRW', 's2', sigma(3, n1 + 2, r1), 'std', None)]))
+    nh = int(rng.integers(2, 7))
+    if kind == 'hyper_axis0':
+        return dict(study='HyperStudy', data=data, om=om, fit=flags,
+                    tm=('GRW', 'sigma', ('cint', 0, sigma(10, n0, 45), nh), 'mean', None))
+    if kind == 'hyper_both':
+        return dict(study='HyperStudy', data=data, om=om, fit=flags,
+                    tm=('Combined', [('GRW', 's1', ('cint', 0, sigma(10, n0, r0 + 1), nh), 'mean', None),
+                                     ('GRW', 's2', sigma(3, n1 + 2, r1), 'std', None)]))
+    T = max(T, 6)
+    return dict(study='ChangepointStudy', data=('series_jump', 700 + seed, T, T // 2, 2.0), om=om, tm=('ChangePoint', 'tc', 'all', None))
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 48))))     # more seeds: BLHIP_FUZZ_SEEDS=400
+def test_seeded_random_configurations_match_oracle(seed):
+    c = _random_case(seed)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL)
