@@ -41,6 +41,16 @@ def _hyper_slots(model):
     return out
 
 
+def _logsumexp(a):
+    """scipy.special.logsumexp of a 1-D array, including its convention for a non-finite maximum (all -inf -> -inf)."""
+    a = np.asarray(a, dtype=float)
+    m = np.amax(a)
+    if not np.isfinite(m):
+        m = 0.0
+    with np.errstate(divide='ignore', over='ignore', invalid='ignore'):
+        return m + np.log(np.sum(np.exp(a - m)))
+
+
 class Study(object):
     """Fit with fixed hyper-parameter values (reference core.py:39-486)."""
 
@@ -764,8 +774,7 @@ class HyperStudy(Study):
         self.hyperParameterDistribution = np.exp(scaled)
         self.hyperParameterDistribution /= np.sum(self.hyperParameterDistribution)
         self.hyperParameterDistribution /= np.prod(self.hyperGridConstant)
-        m = np.amax(logHPD)
-        self.logEvidence = float(m + np.log(np.sum(np.exp(logHPD - m))))     # logsumexp
+        self.logEvidence = float(_logsumexp(logHPD))                            # :1405 scipy.special.logsumexp
         if not silent:
             print('    + Computed hyper-parameter distribution')
             print('    + Log10-evidence of average model: {:.5f}'.format(self.logEvidence / np.log(10)))
@@ -1098,8 +1107,7 @@ class OnlineStudy(HyperStudy):
                 hpd = self.logEvidenceList[i] + np.log(self.hyperPriorValues[i])                 # :2171
                 old = self.hyperLogEvidenceList[i]
                 x = self.logEvidenceList[i] + np.log(self.hyperPriorValues[i])
-                m = np.amax(x)
-                self.hyperLogEvidenceList[i] = m + np.log(np.sum(np.exp(x - m)))                 # :2178 logsumexp
+                self.hyperLogEvidenceList[i] = _logsumexp(x)                                     # :2178 logsumexp
                 self.transitionModelDistribution[i] = self.hyperLogEvidenceList[i]               # :2179
                 self.localTransitionModelDistribution[i] = self.hyperLogEvidenceList[i] - old + \
                     np.log(self.transitionModelPrior[i])                                         # :2180-2181

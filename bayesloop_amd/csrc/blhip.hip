@@ -1402,7 +1402,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 for (int64_t t = T - 1; t >= 0; --t) {
                     const double *r = &redB[((size_t)t * B + b) * NRED];
                     if (fused1d && !(r[0] > 1e-200)) raw_ok = false;
-                    if (!(r[0] > 0.0)) { abort_step[b] = t; abort_phase[b] = 1; logE[b] = -INFINITY; break; }
+                    // The reference tests sum(alpha_norm * beta_norm) > 0 (core.py:441).  r[0] is the same sum up to the lazily
+                    // dropped normalisers, which are positive -- except with signed kernels (Deterministic's cubic-spline
+                    // shift, AlphaStable's FFT kernel): there sum(alpha) = redF[t][0] and sum(beta) = r[5] may be negative and
+                    // the reference divides by them, so the sign test has to include them.
+                    double refnorm = r[0];
+                    if (prog.has_clamp) refnorm = r[0] / (redF[((size_t)t * B + b) * NRED] * (prog.cmodeB[(size_t)t * B + b] ? r[5] : 1.0));
+                    if (!(refnorm > 0.0)) { abort_step[b] = t; abort_phase[b] = 1; logE[b] = -INFINITY; break; }
                     local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
                     invN[(size_t)b * T + t] = 1.0 / r[0];
                     for (int k = 0; k < p->ndim; ++k) means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
@@ -1412,7 +1418,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             for (int64_t b = 0; b < B; ++b)
                 for (int64_t t = 0; t < T; ++t) {
                     const double n0 = redF[((size_t)t * B + b) * NRED];
-                    invN[(size_t)b * T + t] = n0 > 0.0 ? 1.0 / n0 : 0.0;
+                    invN[(size_t)b * T + t] = (n0 != 0.0 && std::isfinite(n0)) ? 1.0 / n0 : 0.0;     // (a signed kernel can leave a negative raw sum)
                 }
         }
 
