@@ -494,11 +494,26 @@ def test_plain_c_program_through_the_abi(tmp_path):
     assert 'log-evidence -171.6867218' in out.stdout
 
 
+# A denormal likelihood value carries 1..52 significant bits; post / L at such a cell can dominate sum(post / L).  Seen in 3
+# of 6000 random configurations: 1.6e-3 relative difference in ONE backward local-evidence entry, everything else < 1e-9.
+ILL_LOCAL_RTOL = 2e-2
+
+
+def _ill_conditioned_local_evidence(S, want):
+    """True if a step has cells with a DENORMAL likelihood (or exactly 0, i.e. 0/0 in the reference's backward local evidence,
+    core.py:463, with denormals next to it): 1 / sum(post / L) is then only defined to a few digits in the reference itself
+    (see cases.py: wide_filter_2d).  Everything else keeps the 1e-9 bar."""
+    with np.errstate(all='ignore'):
+        liks = [np.asarray(S.observationModel.processedPdf(S.grid, seg), dtype=float) for seg in S.formattedData]
+    return any(((L > 0) & (L < 2.3e-308)).any() for L in liks) or bool(np.isnan(np.asarray(want['localEvidence'], dtype=float)).any())
+
+
+
 def _random_case(seed):
     """A seeded random configuration (study kind, ragged grid sizes, stencil radii from 0 to ~45 cells, missing data,
     fit flags) small enough for the oracle to finish in about a second."""
     rng = np.random.default_rng(1000 + seed)
-    kind = ['1d_poisson', '1d_gm', '2d_axis0', '2d_both', '2d_axis1', 'hyper_axis0', 'hyper_both', 'cp'][seed % 8]
+    kind = ['1d_poisson', '1d_gm', '2d_axis0', '2d_both', '2d_axis1', 'hyper_axis0', 'hyper_both', 'cp', 'aligned_axis0', 'aligned_hyper'][seed % 10]
     T = int(rng.integers(1, 21))
     flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
     nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 2 else []
@@ -516,6 +531,13 @@ def _random_case(seed):
         n = int(rng.integers(2, 12000))
         return dict(study='Study', data=('gm', 600 + seed, T), om=('GaussianMean', [('mean', ('cint', -6, 6, n))], 'default'),
                     tm=('GRW', 'sigma', sigma(12, n, rng.integers(0, 46)), 'mean', None), fit=flags)
+    if kind.startswith('aligned'):           # whole tiles: the 32-bit-offset (LEAN) matrix-pipe kernels, several column blocks
+        n0, n1 = 32 * int(rng.integers(1, 9)), 16 * int(rng.integers(1, 17))
+        om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
+        if kind == 'aligned_axis0':
+            return dict(study='Study', data=data, om=om, tm=('GRW', 's1', sigma(10, n0, rng.integers(8, 46)), 'mean', None), fit=flags)
+        return dict(study='HyperStudy', data=data, om=om, fit=flags,
+                    tm=('GRW', 'sigma', ('cint', sigma(10, n0, 6), sigma(10, n0, 45), int(rng.integers(2, 6))), 'mean', None))
     big = kind in ('2d_axis0', '2d_both', '2d_axis1')
     n0, n1 = int(rng.integers(3, 421 if big else 201)), int(rng.integers(3, 421 if big else 201))
     om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
@@ -539,7 +561,7 @@ def _random_case(seed):
     return dict(study='ChangepointStudy', data=('series_jump', 700 + seed, T, T // 2, 2.0), om=om, tm=('ChangePoint', 'tc', 'all', None))
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 48))))     # more seeds: BLHIP_FUZZ_SEEDS=400
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 50))))     # more seeds: BLHIP_FUZZ_SEEDS=400
 def test_seeded_random_configurations_match_oracle(seed):
     c = _random_case(seed)
     S = cases.build(bl, c)
@@ -551,7 +573,7 @@ def test_seeded_random_configurations_match_oracle(seed):
     for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
         if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
             gold[k] = np.asarray(want[k])
-    compare.check(got, gold, compare.GPU_TOL)
+    compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
 
 
 def _random_model_case(seed):
@@ -631,11 +653,71 @@ def test_seeded_random_model_zoo_matches_oracle(seed):
         # a chain that stops with a zero normaliser leaves the rest of its localEvidence array as np.empty() left it in the
         # reference (core.py:360, :399): the hyper-study's sum over chains (core.py:1410) is then not defined
         got['localEvidence'] = gold['localEvidence']
-    with np.errstate(all='ignore'):
-        liks = [np.asarray(S.observationModel.processedPdf(S.grid, seg), dtype=float) for seg in S.formattedData]
-    if any(((L > 0) & (L < 2.3e-308)).any() for L in liks) or np.isnan(np.asarray(want['localEvidence'], dtype=float)).any():
-        # some step has cells with a DENORMAL likelihood (or exactly 0: 0/0 in the reference's backward local evidence,
-        # core.py:463, with denormals next to it): 1 / sum(post / L) is then only defined to a few digits in the reference
-        # itself (see cases.py: wide_filter_2d).  Everything else keeps the 1e-9 bar.
-        tol = dict(tol or {}, local_rtol=1e-3)
+    if _ill_conditioned_local_evidence(S, want):
+        tol = dict(tol or {}, local_rtol=ILL_LOCAL_RTOL)
     compare.check(got, gold, compare.GPU_TOL, case_tol=tol)
+
+
+def _random_hyper_case(seed):
+    """Seeded random hyper-studies: two hyper-parameters, hyper-priors (array / function), observation-model priors,
+    multi-dimensional data, serial models with break- and change-points, RegimeSwitch inside a ChangepointStudy."""
+    rng = np.random.default_rng(9000 + seed)
+    kind = ['two_hp', 'hyper_prior_array', 'hyper_prior_function', 'om_prior', 'multidim', 'serial_cps', 'cp_grw_rs', 'two_cp'][seed % 8]
+    T = int(rng.integers(4, 15))
+    n0, n1 = int(rng.integers(4, 90)), int(rng.integers(4, 90))
+    g2 = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0.2, 3, n1))], ['default', 'inv_s3', 'inv_s_2d'][int(rng.integers(0, 3))])
+    ser = ('series', 1300 + seed, T)
+    flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
+    sg = lambda k: ('cint', float(rng.uniform(0.0, 0.1)), float(rng.uniform(0.2, 0.9)), k)
+    if kind == 'two_hp':
+        return dict(study='HyperStudy', data=ser, om=g2, fit=flags,
+                    tm=('Combined', [('GRW', 's1', sg(int(rng.integers(2, 5))), 'mean', None),
+                                     ('GRW', 's2', ('cint', 0.01, float(rng.uniform(0.05, 0.3)), int(rng.integers(2, 4))), 'std', None)]))
+    if kind == 'hyper_prior_array':
+        k = int(rng.integers(2, 6))
+        return dict(study='HyperStudy', data=ser, om=g2, fit=flags,
+                    tm=('GRW', 's1', sg(k), 'mean', ('array', [float(x) for x in rng.uniform(0.1, 1.0, k)])))
+    if kind == 'hyper_prior_function':
+        return dict(study='HyperStudy', data=ser, om=g2, fit=flags,
+                    tm=('GRW', 's1', ('cint', 0.05, float(rng.uniform(0.2, 0.9)), int(rng.integers(2, 6))), 'mean', 'inv_s'))
+    if kind == 'om_prior':
+        n = int(rng.integers(3, 500))
+        if (seed // 8) % 2:      # array prior: a single fit (the reference normalises and then MUTATES the user's array in place,
+            #                      core.py:208-221 / :382, so its hyper-studies depend on the chain order; not replicated, DESIGN.md)
+            return dict(study='Study', data=rng.poisson(3.0, T), fit=flags, om=('Poisson', [('rate', ('oint', 0, 8, n))], ('ones', n)),
+                        tm=('GRW', 's', float(rng.uniform(0.1, 1.0)), 'rate', None))
+        return dict(study='HyperStudy', data=rng.poisson(3.0, T), fit=flags, om=('Poisson', [('rate', ('oint', 0, 8, n))], 'inv_x'),
+                    tm=('GRW', 's', ('cint', 0.0, float(rng.uniform(0.1, 1.0)), int(rng.integers(2, 7))), 'rate', None))
+    if kind == 'multidim':
+        return dict(study='HyperStudy', data=('series2d', 1400 + seed, max(T, 5)), om=g2, fit=flags,
+                    tm=('GRW', 's1', sg(int(rng.integers(2, 5))), 'mean', None))
+    if kind == 'serial_cps':
+        T = max(T, 8)
+        return dict(study='ChangepointStudy', data=('series_jump', 1500 + seed, T, T // 2, 1.5), om=g2,
+                    tm=('Serial', [('GRW', 'sa', float(rng.uniform(0.05, 0.4)), 'mean', None),
+                                   ('BreakPoint', 'b1', ('arange', 1, T - 2, int(rng.integers(1, 3))), None), ('Static',)]))
+    if kind == 'cp_grw_rs':
+        T = max(T, 6)
+        return dict(study='ChangepointStudy', data=('series_jump', 1600 + seed, T, T // 3, 2.0), om=g2,
+                    tm=('Combined', [('GRW', 's1', float(rng.uniform(0.05, 0.4)), 'mean', None),
+                                     ('RS', 'p', float(rng.uniform(-7, -2)), None), ('ChangePoint', 'tc', 'all', None)]))
+    T = max(T, 9)
+    return dict(study='ChangepointStudy', data=('series_jump', 1700 + seed, T, T // 2, 2.0), om=g2,
+                tm=('Combined', [('ChangePoint', 't1', ('arange', 1, T - 1, 3), None), ('ChangePoint', 't2', ('arange', 2, T - 1, 3), None)]))
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 32))))
+def test_seeded_random_hyper_studies_match_oracle(seed):
+    c = _random_hyper_case(seed)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    if 'logEvidenceList' in want and not np.all(np.isfinite(np.asarray(want['logEvidenceList'], dtype=float))):
+        got['localEvidence'] = gold['localEvidence']         # (np.empty left-overs of stopped chains, see the model-zoo test)
+    compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
