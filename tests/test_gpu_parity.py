@@ -12,6 +12,7 @@ import pytest
 import bayesloop_amd as bl
 import cases
 import compare
+import random_cases
 import oracle_adapter as oa
 from bayesloop_amd import _abi
 
@@ -509,61 +510,9 @@ def _ill_conditioned_local_evidence(S, want):
 
 
 
-def _random_case(seed):
-    """A seeded random configuration (study kind, ragged grid sizes, stencil radii from 0 to ~45 cells, missing data,
-    fit flags) small enough for the oracle to finish in about a second."""
-    rng = np.random.default_rng(1000 + seed)
-    kind = ['1d_poisson', '1d_gm', '2d_axis0', '2d_both', '2d_axis1', 'hyper_axis0', 'hyper_both', 'cp', 'aligned_axis0', 'aligned_hyper'][seed % 10]
-    T = int(rng.integers(1, 21))
-    flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
-    nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 2 else []
-    data = ('series_nan', 500 + seed, T, nan_at) if nan_at else ('series', 500 + seed, T)
-
-    def sigma(span, n, radius):              # random-walk width whose stencil radius is about `radius` cells
-        return max(radius, 0.3) / 4.0 * span / max(n - 1, 1)
-
-    if kind == '1d_poisson':
-        n = int(rng.integers(2, 12000))
-        counts = rng.poisson(3.0, T).astype(float)
-        return dict(study='Study', data=counts, om=('Poisson', [('rate', ('oint', 0, 8, n))], 'default'),
-                    tm=('GRW', 'sigma', sigma(8, n, rng.integers(0, 46)), 'rate', None), fit=flags)
-    if kind == '1d_gm':
-        n = int(rng.integers(2, 12000))
-        return dict(study='Study', data=('gm', 600 + seed, T), om=('GaussianMean', [('mean', ('cint', -6, 6, n))], 'default'),
-                    tm=('GRW', 'sigma', sigma(12, n, rng.integers(0, 46)), 'mean', None), fit=flags)
-    if kind.startswith('aligned'):           # whole tiles: the 32-bit-offset (LEAN) matrix-pipe kernels, several column blocks
-        n0, n1 = 32 * int(rng.integers(1, 9)), 16 * int(rng.integers(1, 17))
-        om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
-        if kind == 'aligned_axis0':
-            return dict(study='Study', data=data, om=om, tm=('GRW', 's1', sigma(10, n0, rng.integers(8, 46)), 'mean', None), fit=flags)
-        return dict(study='HyperStudy', data=data, om=om, fit=flags,
-                    tm=('GRW', 'sigma', ('cint', sigma(10, n0, 6), sigma(10, n0, 45), int(rng.integers(2, 6))), 'mean', None))
-    big = kind in ('2d_axis0', '2d_both', '2d_axis1')
-    n0, n1 = int(rng.integers(3, 421 if big else 201)), int(rng.integers(3, 421 if big else 201))
-    om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
-    r0, r1 = int(rng.integers(0, 46)), int(rng.integers(0, 9))
-    if kind == '2d_axis0':
-        return dict(study='Study', data=data, om=om, tm=('GRW', 's1', sigma(10, n0, r0), 'mean', None), fit=flags)
-    if kind == '2d_axis1':
-        return dict(study='Study', data=data, om=om, tm=('GRW', 's2', sigma(3, n1 + 2, r1), 'std', None), fit=flags)
-    if kind == '2d_both':
-        return dict(study='Study', data=data, om=om, fit=flags,
-                    tm=('Combined', [('GRW', 's1', sigma(10, n0, r0), 'mean', None), ('GRW', 's2', sigma(3, n1 + 2, r1), 'std', None)]))
-    nh = int(rng.integers(2, 7))
-    if kind == 'hyper_axis0':
-        return dict(study='HyperStudy', data=data, om=om, fit=flags,
-                    tm=('GRW', 'sigma', ('cint', 0, sigma(10, n0, 45), nh), 'mean', None))
-    if kind == 'hyper_both':
-        return dict(study='HyperStudy', data=data, om=om, fit=flags,
-                    tm=('Combined', [('GRW', 's1', ('cint', 0, sigma(10, n0, r0 + 1), nh), 'mean', None),
-                                     ('GRW', 's2', sigma(3, n1 + 2, r1), 'std', None)]))
-    T = max(T, 6)
-    return dict(study='ChangepointStudy', data=('series_jump', 700 + seed, T, T // 2, 2.0), om=om, tm=('ChangePoint', 'tc', 'all', None))
-
-
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 50))))     # more seeds: BLHIP_FUZZ_SEEDS=400
 def test_seeded_random_configurations_match_oracle(seed):
-    c = _random_case(seed)
+    c = random_cases.random_case(seed)
     S = cases.build(bl, c)
     with np.errstate(all='ignore'):
         S.fit(**cases.fit_kwargs(c))
@@ -576,61 +525,6 @@ def test_seeded_random_configurations_match_oracle(seed):
     compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
 
 
-def _random_model_case(seed):
-    """Seeded random configurations of the transition / observation models beyond GRW + Gaussian/Poisson (generic kernel,
-    device-built likelihood tables): ragged small grids, random hyper-parameter values."""
-    rng = np.random.default_rng(5000 + seed)
-    kind = ['rs_1d', 'rs_2d', 'ne_1d', 'bivariate', 'alphastable', 'deterministic', 'serial', 'independent',
-            'bernoulli', 'laplace', 'whitenoise', 'ar1', 'scaledar1'][seed % 13]
-    T = int(rng.integers(2, 13))
-    n = int(rng.integers(5, 400))
-    n0, n1 = int(rng.integers(4, 70)), int(rng.integers(4, 70))
-    pois = ('Poisson', [('rate', ('oint', 0, 8, n))], 'default')
-    g2 = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
-    counts = rng.poisson(3.0, T).astype(float)
-    ser = ('series', 900 + seed, T)
-    s1d = float(rng.uniform(0.02, 0.6))
-    tol = None
-    if kind == 'rs_1d':
-        c = dict(study='Study', data=counts, om=pois, tm=('Combined', [('GRW', 's', s1d, 'rate', None), ('RS', 'p', float(rng.uniform(-7, -1)), None)]))
-    elif kind == 'rs_2d':
-        order = [('RS', 'p', float(rng.uniform(-7, -2)), None), ('GRW', 's1', float(rng.uniform(0.1, 0.8)), 'mean', None)]
-        c = dict(study='Study', data=ser, om=g2, tm=('Combined', order if seed % 2 else order[::-1]))
-    elif kind == 'ne_1d':
-        c = dict(study='HyperStudy', data=counts, om=pois, tm=('NE', 'p', [float(x) for x in sorted(rng.uniform(-7, -1, 3))], None))
-    elif kind == 'bivariate':
-        c = dict(study='Study', data=ser, om=g2, tm=('Bivariate', 's1', float(rng.uniform(0.2, 0.9)), 's2', float(rng.uniform(0.05, 0.3)),
-                                                       'rho', float(rng.uniform(-0.8, 0.8))))
-    elif kind == 'alphastable':
-        c = dict(study='Study', data=counts, om=pois, tm=('AlphaStable', 'c', float(rng.uniform(0.05, 0.4)), 'alpha', float(rng.uniform(0.8, 2.0)), 'rate'))
-        tol = cases.FFT_TOL
-    elif kind == 'deterministic':
-        c = dict(study='HyperStudy', data=ser, om=g2, tm=('Deterministic', ['quadratic', 'drift'][seed % 2], ['mean', 'std'][(seed // 2) % 2]))
-        tol = cases.FFT_TOL
-    elif kind == 'serial':
-        tb = int(rng.integers(1, T - 1)) if T > 2 else 0
-        c = dict(study='Study', data=counts, om=pois,
-                 tm=('Serial', [('GRW', 'sa', s1d, 'rate', None), ('BreakPoint', 'tb', tb, None), ('Static',)]))
-    elif kind == 'independent':
-        c = dict(study='Study', data=counts, om=pois, tm=('Independent',))
-    elif kind == 'bernoulli':
-        c = dict(study='Study', data=rng.integers(0, 2, T).astype(float), om=('Bernoulli', [('p', ('oint', 0, 1, n))], 'default'),
-                 tm=('GRW', 's', float(rng.uniform(0.01, 0.2)), 'p', None))
-    elif kind == 'laplace':
-        c = dict(study='Study', data=ser, om=('Laplace', [('mu', ('cint', -4, 4, n0)), ('b', ('oint', 0, 3, n1))], 'default'),
-                 tm=('GRW', 's', float(rng.uniform(0.1, 0.6)), 'mu', None))
-    elif kind == 'whitenoise':
-        c = dict(study='Study', data=ser, om=('WhiteNoise', [('std', ('oint', 0, 3, n))], 'default'),
-                 tm=('GRW', 's', float(rng.uniform(0.02, 0.3)), 'std', None))
-    elif kind == 'ar1':
-        c = dict(study='Study', data=ser, om=('AR1', [('rho', ('oint', -1, 1, n0)), ('sigma', ('oint', 0, 3, n1))], 'default'),
-                 tm=('GRW', 's', float(rng.uniform(0.02, 0.3)), 'rho', None))
-    else:
-        c = dict(study='Study', data=ser, om=('ScaledAR1', [('rho', ('oint', -1, 1, n0)), ('sigma', ('oint', 0, 3, n1))], 'default'),
-                 tm=('GRW', 's', float(rng.uniform(0.05, 0.4)), 'sigma', None))
-    return c, tol
-
-
 # seeds that once failed: 434 / 1006 / 1110 = Deterministic shifts whose cubic-spline ringing makes a lazily dropped normaliser
 # NEGATIVE (the zero-normaliser test must follow the reference's sign), 1258 = denormal likelihood without an exact zero,
 # 1032 / 2228 = every / one chain of a hyper-study stops with a zero normaliser (logsumexp of all -inf, left-over local evidence)
@@ -639,7 +533,7 @@ ZOO_REGRESSION_SEEDS = [434, 1006, 1032, 1110, 1258, 2228]
 
 @pytest.mark.parametrize('seed', list(range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 39)))) + ZOO_REGRESSION_SEEDS)
 def test_seeded_random_model_zoo_matches_oracle(seed):
-    c, tol = _random_model_case(seed)
+    c, tol = random_cases.random_model_case(seed)
     S = cases.build(bl, c)
     with np.errstate(all='ignore'):
         S.fit(**cases.fit_kwargs(c))
@@ -658,57 +552,9 @@ def test_seeded_random_model_zoo_matches_oracle(seed):
     compare.check(got, gold, compare.GPU_TOL, case_tol=tol)
 
 
-def _random_hyper_case(seed):
-    """Seeded random hyper-studies: two hyper-parameters, hyper-priors (array / function), observation-model priors,
-    multi-dimensional data, serial models with break- and change-points, RegimeSwitch inside a ChangepointStudy."""
-    rng = np.random.default_rng(9000 + seed)
-    kind = ['two_hp', 'hyper_prior_array', 'hyper_prior_function', 'om_prior', 'multidim', 'serial_cps', 'cp_grw_rs', 'two_cp'][seed % 8]
-    T = int(rng.integers(4, 15))
-    n0, n1 = int(rng.integers(4, 90)), int(rng.integers(4, 90))
-    g2 = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0.2, 3, n1))], ['default', 'inv_s3', 'inv_s_2d'][int(rng.integers(0, 3))])
-    ser = ('series', 1300 + seed, T)
-    flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
-    sg = lambda k: ('cint', float(rng.uniform(0.0, 0.1)), float(rng.uniform(0.2, 0.9)), k)
-    if kind == 'two_hp':
-        return dict(study='HyperStudy', data=ser, om=g2, fit=flags,
-                    tm=('Combined', [('GRW', 's1', sg(int(rng.integers(2, 5))), 'mean', None),
-                                     ('GRW', 's2', ('cint', 0.01, float(rng.uniform(0.05, 0.3)), int(rng.integers(2, 4))), 'std', None)]))
-    if kind == 'hyper_prior_array':
-        k = int(rng.integers(2, 6))
-        return dict(study='HyperStudy', data=ser, om=g2, fit=flags,
-                    tm=('GRW', 's1', sg(k), 'mean', ('array', [float(x) for x in rng.uniform(0.1, 1.0, k)])))
-    if kind == 'hyper_prior_function':
-        return dict(study='HyperStudy', data=ser, om=g2, fit=flags,
-                    tm=('GRW', 's1', ('cint', 0.05, float(rng.uniform(0.2, 0.9)), int(rng.integers(2, 6))), 'mean', 'inv_s'))
-    if kind == 'om_prior':
-        n = int(rng.integers(3, 500))
-        if (seed // 8) % 2:      # array prior: a single fit (the reference normalises and then MUTATES the user's array in place,
-            #                      core.py:208-221 / :382, so its hyper-studies depend on the chain order; not replicated, DESIGN.md)
-            return dict(study='Study', data=rng.poisson(3.0, T), fit=flags, om=('Poisson', [('rate', ('oint', 0, 8, n))], ('ones', n)),
-                        tm=('GRW', 's', float(rng.uniform(0.1, 1.0)), 'rate', None))
-        return dict(study='HyperStudy', data=rng.poisson(3.0, T), fit=flags, om=('Poisson', [('rate', ('oint', 0, 8, n))], 'inv_x'),
-                    tm=('GRW', 's', ('cint', 0.0, float(rng.uniform(0.1, 1.0)), int(rng.integers(2, 7))), 'rate', None))
-    if kind == 'multidim':
-        return dict(study='HyperStudy', data=('series2d', 1400 + seed, max(T, 5)), om=g2, fit=flags,
-                    tm=('GRW', 's1', sg(int(rng.integers(2, 5))), 'mean', None))
-    if kind == 'serial_cps':
-        T = max(T, 8)
-        return dict(study='ChangepointStudy', data=('series_jump', 1500 + seed, T, T // 2, 1.5), om=g2,
-                    tm=('Serial', [('GRW', 'sa', float(rng.uniform(0.05, 0.4)), 'mean', None),
-                                   ('BreakPoint', 'b1', ('arange', 1, T - 2, int(rng.integers(1, 3))), None), ('Static',)]))
-    if kind == 'cp_grw_rs':
-        T = max(T, 6)
-        return dict(study='ChangepointStudy', data=('series_jump', 1600 + seed, T, T // 3, 2.0), om=g2,
-                    tm=('Combined', [('GRW', 's1', float(rng.uniform(0.05, 0.4)), 'mean', None),
-                                     ('RS', 'p', float(rng.uniform(-7, -2)), None), ('ChangePoint', 'tc', 'all', None)]))
-    T = max(T, 9)
-    return dict(study='ChangepointStudy', data=('series_jump', 1700 + seed, T, T // 2, 2.0), om=g2,
-                tm=('Combined', [('ChangePoint', 't1', ('arange', 1, T - 1, 3), None), ('ChangePoint', 't2', ('arange', 2, T - 1, 3), None)]))
-
-
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 32))))
 def test_seeded_random_hyper_studies_match_oracle(seed):
-    c = _random_hyper_case(seed)
+    c = random_cases.random_hyper_case(seed)
     S = cases.build(bl, c)
     with np.errstate(all='ignore'):
         S.fit(**cases.fit_kwargs(c))
