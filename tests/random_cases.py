@@ -158,3 +158,37 @@ def random_hyper_case(seed):
     T = max(T, 9)
     return dict(study='ChangepointStudy', data=('series_jump', 1700 + seed, T, T // 2, 2.0), om=g2,
                 tm=('Combined', [('ChangePoint', 't1', ('arange', 1, T - 1, 3), None), ('ChangePoint', 't2', ('arange', 2, T - 1, 3), None)]))
+
+
+def random_online_case(seed):
+    """Seeded random OnlineStudy: 1-3 competing transition models with random hyper-grids (and a random model prior), stepped
+    over a short series (reference core.py:2062-2226)."""
+    rng = np.random.default_rng(13000 + seed)
+    two_d = seed % 2 == 1
+    T = int(rng.integers(3, 11))
+    if two_d:
+        n0, n1 = int(rng.integers(4, 60)), int(rng.integers(4, 60))
+        om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0.2, 3, n1))], 'default')
+        target, data = 'mean', ('series', 1900 + seed, T)
+    else:
+        n = int(rng.integers(4, 600))
+        om = ('Poisson', [('rate', ('oint', 0, 8, n))], 'default')
+        target, data = 'rate', [int(x) for x in rng.poisson(3.0, T)]
+    pool = [
+        lambda k: ('Static',),
+        lambda k: ('GRW', 's%d' % k, [float(x) for x in sorted(rng.uniform(0.02, 0.8, int(rng.integers(1, 5))))], target, None),
+        lambda k: ('RS', 'p%d' % k, [float(x) for x in sorted(rng.uniform(-7, -1, int(rng.integers(1, 4))))], None),
+        lambda k: ('Independent',),
+        lambda k: ('ChangePoint', 'tc%d' % k, [int(x) for x in sorted(set(rng.integers(0, T, 2)))], None),
+        lambda k: ('Combined', [('GRW', 'sa%d' % k, float(rng.uniform(0.05, 0.5)), target, None),
+                                ('RS', 'q%d' % k, [float(x) for x in sorted(rng.uniform(-6, -2, 2))], None)]),
+        lambda k: ('NE', 'ne%d' % k, [float(x) for x in sorted(rng.uniform(-7, -2, 2))], None),
+    ]
+    nm = int(rng.integers(1, 4))
+    picks = rng.choice(len(pool), size=nm, replace=False)
+    models = [('M%d' % k, pool[int(p)](k)) for k, p in enumerate(picks)]
+    c = dict(om=om, models=models, data=data)
+    if nm > 1 and seed % 3 == 0:
+        w = rng.uniform(0.1, 1.0, nm)
+        c['tm_prior'] = [float(x) for x in w / w.sum()]
+    return c

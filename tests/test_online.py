@@ -5,6 +5,7 @@ logic (model compilation, evidence bookkeeping, accessors) over the oracle test 
 through the HIP kernels with device-resident carried states."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
@@ -151,3 +152,29 @@ def test_online_study_large_grid_matches_oracle_and_offline_fit():
         F.fit(forwardOnly=True, silent=True)
         assert abs(S.logEvidenceList[0][j] - F.logEvidence) <= 1e-10 * abs(F.logEvidence)
         np.testing.assert_allclose(S.parameterPosterior[0][j], F.posteriorSequence[-1], rtol=1e-9, atol=1e-14)
+
+
+def run_product_case(c):
+    S = cases.build_online(bl, c)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for d in cases.online_data(c):
+            S.step(d)
+    return S
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 40))))
+def test_online_study_seeded_random_models_match_oracle(seed):
+    """Random sets of competing transition models with random hyper-grids (tests/random_cases.py) on the device vs the oracle's
+    restatement of OnlineStudy.step (itself checked against the reference on the same seeds, test_oracle_vs_reference_random.py)."""
+    import random_cases
+    c = random_cases.random_online_case(seed)
+    S = run_product_case(c)
+    with np.errstate(all='ignore'):
+        w = oa.run_online(c)
+    assert abs(S.logEvidence - w['logEvidence']) <= RTOL * abs(w['logEvidence'])
+    for key in ('posteriorSequence', 'posteriorMeanValues', 'transitionModelSequence', 'localTransitionModelSequence'):
+        np.testing.assert_allclose(np.asarray(getattr(S, key), dtype=float), np.asarray(w[key], dtype=float), rtol=RTOL, atol=ATOL, err_msg=key)
+    for i in range(len(S.transitionModels)):
+        np.testing.assert_allclose(np.asarray([h[i] for h in S.hyperParameterSequence], dtype=float),
+                                   np.asarray([h[i] for h in w['hyperParameterSequence']], dtype=float), rtol=RTOL, atol=ATOL)

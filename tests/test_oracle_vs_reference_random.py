@@ -81,3 +81,21 @@ def test_oracle_equals_reference_on_random_model_zoo(ref, seed):
 @pytest.mark.parametrize('seed', range(40))
 def test_oracle_equals_reference_on_random_hyper_studies(ref, seed):
     _check(ref, random_cases.random_hyper_case(seed))
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_oracle_equals_reference_on_random_online_studies(ref, seed):
+    c = random_cases.random_online_case(seed)
+    S = cases.build_online(ref, c)
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(all='ignore'), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for d in cases.online_data(c):
+            S.step(d)
+        w = oa.run_online(c)
+    a, b = float(S.logEvidence), float(w['logEvidence'])
+    assert a == b or abs(a - b) <= 1e-9 * abs(a), 'logEvidence %r (reference) vs %r (oracle)' % (a, b)
+    for key in ('posteriorSequence', 'posteriorMeanValues', 'transitionModelSequence', 'localTransitionModelSequence'):
+        _close(np.asarray(getattr(S, key), dtype=float), np.asarray(w[key], dtype=float), 1e-9, 1e-13, key)
+    for i in range(len(S.transitionModels)):
+        _close(np.asarray([h[i] for h in S.hyperParameterSequence], dtype=float),
+               np.asarray([h[i] for h in w['hyperParameterSequence']], dtype=float), 1e-9, 1e-13, 'hyperParameterSequence')
