@@ -177,13 +177,8 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     // rows entering the window in the steady state are >= 0: only the upper mirror and the clamp of the tail remain
     auto refl_hi = [&](int r) { return max(min(r, 2 * P.n0 - 1 - r), 0); };
     typedef const double __attribute__((address_space(3))) *lds_cp;
-#ifdef BLM_A_FROM_LDS
-    // keep the band in LDS (re-read per tile) instead of letting the compiler hoist NK doubles into registers
-    typedef const volatile double __attribute__((address_space(3))) *lds_cvp;
-    lds_cvp Al = (lds_cvp)(lds_cp)As + lane;
-#else
-    lds_cp Al = (lds_cp)As + lane;
-#endif
+    lds_cp Al = (lds_cp)As + lane;                 // (the compiler hoists the NK band values of a lane into registers; re-reading
+                                                   //  them from LDS per tile was measured and was not faster)
 
     static_assert(BLM_PF % 2 == 0, "prefetch depth must be even (two alpha / likelihood slots, two LDS tiles)");
     // Memory pipeline.  Everything inside the tile loop is straight-line and UNCONDITIONAL (clamped / reflected addresses
