@@ -1080,7 +1080,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         std::vector<std::vector<FastRange>> rangesF, rangesB;
         if (fast) {
             // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle
-            const int min_chains = (int)std::min<long long>(B, (128 + (long long)tile.nblk - 1) / tile.nblk);
+            const long long min_blocks = (long long)ctx->option("min_bucket_blocks", 128.0);     // a radius bucket with fewer blocks per launch joins the next one
+            const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)tile.nblk - 1) / tile.nblk);
             orderF.resize(nT); rangesF.resize(T);
             for (int64_t t = 0; t < T; ++t)
                 bucket_step(&prog.tapF0[t * B], &prog.tapF1[t * B], taps.lw, (int)B, &orderF[t * B], rangesF[t], min_chains);
