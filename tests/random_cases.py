@@ -116,13 +116,21 @@ def random_hyper_case(seed):
     """Seeded random hyper-studies: two hyper-parameters, hyper-priors (array / function), observation-model priors,
     multi-dimensional data, serial models with break- and change-points, RegimeSwitch inside a ChangepointStudy."""
     rng = np.random.default_rng(9000 + seed)
-    kind = ['two_hp', 'hyper_prior_array', 'hyper_prior_function', 'om_prior', 'multidim', 'serial_cps', 'cp_grw_rs', 'two_cp'][seed % 8]
+    kind = ['two_hp', 'hyper_prior_array', 'hyper_prior_function', 'om_prior', 'multidim', 'serial_cps', 'cp_grw_rs', 'two_cp', 'cps_1d'][seed % 9]
     T = int(rng.integers(4, 15))
     n0, n1 = int(rng.integers(4, 90)), int(rng.integers(4, 90))
     g2 = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0.2, 3, n1))], ['default', 'inv_s3', 'inv_s_2d'][int(rng.integers(0, 3))])
     ser = ('series', 1300 + seed, T)
     flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
     sg = lambda k: ('cint', float(rng.uniform(0.0, 0.1)), float(rng.uniform(0.2, 0.9)), k)
+    if kind == 'cps_1d':        # 1-D grid: the K-steps-per-launch kernels with restarts at every offset inside a launch
+        T1 = int(rng.integers(6, 41))
+        n = int(rng.integers(3, 2500))
+        jump = int(rng.integers(2, T1 - 2))
+        counts = np.concatenate([rng.poisson(2.0, jump), rng.poisson(5.0, T1 - jump)])
+        tm = ('ChangePoint', 'tc', 'all', None) if seed % 2 else ('Combined', [('GRW', 's', float(rng.uniform(0.02, 0.5)), 'rate', None),
+                                                                              ('ChangePoint', 'tc', ('arange', 1, T1 - 1, int(rng.integers(1, 4))), None)])
+        return dict(study='ChangepointStudy', data=counts, om=('Poisson', [('rate', ('oint', 0, 9, n))], 'default'), tm=tm)
     if kind == 'two_hp':
         return dict(study='HyperStudy', data=ser, om=g2, fit=flags,
                     tm=('Combined', [('GRW', 's1', sg(int(rng.integers(2, 5))), 'mean', None),
@@ -136,7 +144,7 @@ def random_hyper_case(seed):
                     tm=('GRW', 's1', ('cint', 0.05, float(rng.uniform(0.2, 0.9)), int(rng.integers(2, 6))), 'mean', 'inv_s'))
     if kind == 'om_prior':
         n = int(rng.integers(3, 500))
-        if (seed // 8) % 2:      # array prior: a single fit (the reference normalises and then MUTATES the user's array in place,
+        if (seed // 9) % 2:      # array prior: a single fit (the reference normalises and then MUTATES the user's array in place,
             #                      core.py:208-221 / :382, so its hyper-studies depend on the chain order; not replicated)
             return dict(study='Study', data=rng.poisson(3.0, T), fit=flags, om=('Poisson', [('rate', ('oint', 0, 8, n))], ('ones', n)),
                         tm=('GRW', 's', float(rng.uniform(0.1, 1.0)), 'rate', None))
