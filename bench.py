@@ -141,20 +141,57 @@ def run_workload(bl, name, steps, warmup, comm, barrier):
     return S, units, desc, dt
 
 
-def cpu_baseline(nh=8, T=160, n=512):
-    """The CPU oracle (numpy restatement of the reference path) on a bounded sample of the C4 workload, 1 core."""
+def _cpu_share(args):
+    """One worker of the CPU baseline: the oracle's hyper_fit over its share of the sigma values -> seconds of compute."""
+    n, T, sigmas = args
+    os.environ.setdefault('OMP_NUM_THREADS', '1')
     from oracle import bl_oracle as orc
     g = orc.Grid([orc.cint(-8, 8, n), orc.oint(0, 4, n)])
     data = orc.moving_window(series(4, T), 1)
-    ts = np.arange(T)
     prior = orc.compute_prior(g, orc.jeffreys('gaussian'))
-    hv, pv, const = orc.hyper_grid([orc.cint(0, 0.3, 512)[::512 // nh][:nh]], [None])
+    hv, pv, const = orc.hyper_grid([np.asarray(sigmas)], [None])
     t0 = time.perf_counter()
     with np.errstate(all='ignore'):
-        orc.hyper_fit(g, 'gaussian', data, ts, prior, [('grw', 0)], hv, pv, const)
-    dt = time.perf_counter() - t0
-    return dict(value=n * n * T * nh / dt, unit='grid-cells*timesteps/s', cores=1, kind='port',
-                sample='oracle/bl_oracle.py hyper_fit: %dx%d grid, %d sigma values, T=%d, full fit, %.1f s' % (n, n, nh, T, dt))
+        orc.hyper_fit(g, 'gaussian', data, np.arange(T), prior, [('grw', 0)], hv, pv, const)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(nh=8, T=160, n=512, max_procs=16):
+    """The CPU oracle (numpy restatement of the reference path) on a bounded sample of the C4 workload.
+
+    The reference's fit() is single-threaded; its HyperStudy can spread hyper-grid points over processes (nJobs, core.py:
+    1317-1326).  Both are timed: one core on `nh` sigma values, then min(host cores, max_procs, free GB) processes with two sigma
+    values each (a shorter series keeps a worker under ~0.5 GB; on the 256-core GPU host 16 processes reach 2.4e8, 64
+    processes only 1.1e8: memory-bound numpy).  `value` is the better of the two."""
+    all_sig = np.linspace(0.0, 0.3, 512)
+    dt1 = _cpu_share((n, T, all_sig[::512 // nh][:nh]))
+    one = dict(value=n * n * T * nh / dt1, cores=1,
+               sample='oracle/bl_oracle.py hyper_fit: %dx%d grid, %d sigma values, T=%d, full fit, %.1f s' % (n, n, nh, T, dt1))
+    out = dict(value=one['value'], unit='grid-cells*timesteps/s', cores=1, kind='port', sample=one['sample'], one_core=one)
+    procs = min(os.cpu_count() or 1, max_procs)
+    try:                                  # ~0.5 GB per worker (T = 96 posteriors of a 512 x 512 grid + accumulators)
+        import psutil
+        procs = max(1, min(procs, int(psutil.virtual_memory().available / 2 ** 30)))
+    except Exception:
+        procs = min(procs, 16)
+    if procs > 1:
+        try:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            Tm, per = 96, 2
+            pick = np.linspace(0, 511, per * procs).astype(int)            # sigma values spread over the whole hyper-grid
+            shares = [(n, Tm, all_sig[pick[w::procs]].tolist()) for w in range(procs)]
+            with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context('spawn')) as pool:
+                times = list(pool.map(_cpu_share, shares, timeout=600))
+            val = n * n * Tm * per * procs / max(times)
+            multi = dict(value=val, cores=procs,
+                         sample='%d processes x %d sigma values, %dx%d grid, T=%d, full fit, slowest worker %.1f s' % (procs, per, n, n, Tm, max(times)))
+            out['all_cores'] = multi
+            if val > out['value']:
+                out.update(value=val, cores=procs, sample=multi['sample'])
+        except Exception as e:          # the one-core figure stands
+            out['all_cores'] = dict(error=repr(e))
+    return out
 
 
 def main():
