@@ -15,6 +15,7 @@ from . import transitionModels
 from . import transitionModels as tm
 from .helper import cint, oint
 from .fileIO import save, load
+from .parser import Parser
 from .exceptions import ConfigurationError, PostProcessingError, BackendError
 from . import dist
 from .engine import get_engine, set_engine

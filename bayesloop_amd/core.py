@@ -341,6 +341,12 @@ class Study(object):
             raise PostProcessingError('Could not find any hyper-parameter with name: {}.'.format(name))
         return names.index(name)
 
+    def eval(self, query, t=None, silent=False):
+        """Probability of an (in-)equality of (hyper-)parameters, or the distribution of an arithmetic combination of them
+        (reference core.py:604-621; see :class:`bayesloop_amd.parser.Parser`)."""
+        from .parser import Parser
+        return Parser(self)(query, t=t, silent=silent)
+
     def getHyperParameterValue(self, name):
         return self._unpackAllHyperParameters(values=True)[self._getHyperParameterIndex(self.transitionModel, name)]
 

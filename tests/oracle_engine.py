@@ -162,6 +162,11 @@ class OracleEngine:
 
     # ---- accumulator (log space inside, linear space for the cross-rank merge) -----------------------------------
     def accum_begin(self, T, G, external=None, owner=None):
+        prev = getattr(self, '_accum_owner', None)          # as HipEngine.accum_begin: the previous study's average posterior
+        if prev is not None and prev is not owner:          # still lives in the accumulator that is about to be reused
+            self._accum_owner = None
+            prev._materialize_posterior()
+        self._accum_owner = owner
         self.acc_shape = (T, G)
         self.acc_log = np.zeros((T, G)) - np.inf
         self.acc_ext = external
