@@ -51,6 +51,41 @@ def _logsumexp(a):
         return m + np.log(np.sum(np.exp(a - m)))
 
 
+def _plots(kind):
+    """Adds the reference's ``plot=True`` behaviour to an accessor: the numbers come from the undecorated method, the figure
+    from :mod:`bayesloop_amd.plotting` (matplotlib is only imported when something is plotted)."""
+    def wrap(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def accessor(self, *args, **kwargs):
+            plot = kwargs.pop('plot', False)
+            figure, subplot = kwargs.pop('figure', None), kwargs.pop('subplot', 111)
+            density = kwargs.get('density', True)
+            style = {k: kwargs.pop(k) for k in list(kwargs) if k not in ('density', 'local')}
+            out = fn(self, *args, **kwargs)
+            if not plot:
+                return out
+            from . import plotting
+            name = kwargs.get('name', kwargs.get('names', args[-1] if args else None))
+            if kind == 'param_dist':
+                plotting.distribution(out[0], out[1], name, density=density, **style)
+            elif kind == 'param_dists':
+                plotting.marginal_image(self.formattedTimestamps, self.boundaries[self._parameterIndex(name)], out[1],
+                                        color=style.get('c', style.get('color', 'b')))
+            elif kind == 'hyper_dist':
+                plotting.bars(out[0], out[1], name, **style)
+            elif kind == 'joint':
+                k = [self._getHyperParameterIndex(self.transitionModel, n) for n in name]
+                plotting.joint_bars(out[0], out[1], out[2], list(name), [self.hyperGridConstant[k[0]], self.hyperGridConstant[k[1]]],
+                                    figure=figure, subplot=subplot, **style)
+            elif kind == 'duration':
+                plotting.bars(out[0], out[1], 'duration between {} and {} (in time steps)'.format(*name), width=out[0][0], **style)
+            return out
+        return accessor
+    return wrap
+
+
 class Study(object):
     """Fit with fixed hyper-parameter values (reference core.py:39-486)."""
 
@@ -537,6 +572,7 @@ class Study(object):
     def getParameterMeanValues(self, name):
         return self.posteriorMeanValues[self._parameterIndex(name)]
 
+    @_plots('param_dist')
     def getParameterDistribution(self, t, name, plot=False, density=True, **kwargs):
         """Marginal distribution of one parameter at time stamp ``t`` or time-averaged (``t='avg'``).  While the
         posterior sequence is still on the GPU the reduction happens there (no (T, G) copy)."""
@@ -591,6 +627,7 @@ class Study(object):
             prob /= np.sum(prob)
         return prob
 
+    @_plots('param_dists')
     def getParameterDistributions(self, name, plot=False, density=True, **kwargs):
         """Time series of marginal posterior distributions of one parameter: (values, (T, n) array); reduced on the GPU
         while the posterior sequence is still there."""
@@ -608,6 +645,23 @@ class Study(object):
 
     def getPDs(self, name, plot=False, density=True, **kwargs):
         return self.getParameterDistributions(name, plot=plot, density=density, **kwargs)
+
+    def plotParameterEvolution(self, name, color='b', gamma=0.5, **kwargs):
+        """Image of the marginal posterior of one parameter over time (gamma-corrected) with the posterior means on top
+        (reference core.py:1007-1069)."""
+        from . import plotting
+        k = self._parameterIndex(name)
+        x, p = self.getParameterDistributions(name, density=False)
+        plotting.evolution(self.formattedTimestamps, self.boundaries[k], p, self.getParameterMeanValues(name), name,
+                           color=color, gamma=gamma, **kwargs)
+
+    def plot(self, name, **kwargs):
+        """Evolution of a parameter, or its distribution at time stamp ``t=...`` (reference core.py:1071-1096)."""
+        density = kwargs.pop('density', True)
+        if 't' in kwargs:
+            self.getParameterDistribution(kwargs.pop('t'), name, plot=True, density=density, **kwargs)
+        else:
+            self.plotParameterEvolution(name, color=kwargs.pop('color', 'b'), gamma=kwargs.pop('gamma', 0.5), **kwargs)
 
 
 class HyperStudy(Study):
@@ -808,6 +862,7 @@ class HyperStudy(Study):
     def _hyperGridSteps(self):
         return [len(x) if isinstance(x, Iterable) and not isinstance(x, str) else 1 for x in self.flatHyperParameters]
 
+    @_plots('hyper_dist')
     def getHyperParameterDistribution(self, name, plot=False, **kwargs):
         """Marginal distribution of one hyper-parameter: (values, probabilities) (reference core.py:1535-1585)."""
         if len(self.hyperGridValues) < 2:
@@ -823,6 +878,7 @@ class HyperStudy(Study):
     def getHPD(self, name, plot=False, **kwargs):
         return self.getHyperParameterDistribution(name, plot=plot, **kwargs)
 
+    @_plots('joint')
     def getJointHyperParameterDistribution(self, names, plot=False, figure=None, subplot=111, **kwargs):
         """Joint distribution of two hyper-parameters: (x, y, probabilities) (reference core.py:1593-1694)."""
         if len(self.hyperGridValues) < 2:
@@ -844,6 +900,17 @@ class HyperStudy(Study):
 
     def getJHPD(self, names, plot=False, figure=None, subplot=111, **kwargs):
         return self.getJointHyperParameterDistribution(names, plot=plot, figure=figure, subplot=subplot, **kwargs)
+
+    def plot(self, name, **kwargs):
+        """Evolution of a parameter, its distribution at ``t=...``, or the distribution of a hyper-parameter
+        (reference core.py:1702-1741)."""
+        density = kwargs.pop('density', True)
+        if 't' in kwargs:
+            self.getParameterDistribution(kwargs.pop('t'), name, plot=True, density=density, **kwargs)
+        elif name in self._unpackAllHyperParameters(values=False):
+            self.getHyperParameterDistribution(name, plot=True, **kwargs)
+        else:
+            self.plotParameterEvolution(name, color=kwargs.pop('color', 'b'), gamma=kwargs.pop('gamma', 0.5), **kwargs)
 
 
 class ChangepointStudy(HyperStudy):
@@ -906,6 +973,7 @@ class ChangepointStudy(HyperStudy):
         full[self.mask] = self.flatHyperPriorValues
         self.flatHyperPriorValues = full
 
+    @_plots('duration')
     def getDurationDistribution(self, names, plot=False, **kwargs):
         """Distribution of the number of time steps between two change-points (reference core.py:1875-1924)."""
         if not isinstance(names, Iterable) or isinstance(names, str) or len(names) != 2:
@@ -1176,6 +1244,7 @@ class OnlineStudy(HyperStudy):
             raise PostProcessingError('To get past {}, Online Study must be called with flag "storeHistory=True". '
                                       'Use "{}" instead.'.format(what, alt))
 
+    @_plots('param_dist')
     def getParameterDistribution(self, t, name, plot=False, density=True, **kwargs):
         self._needHistory('parameter distributions', 'getCurrentParameterDistribution')
         k = self._parameterIndex(name)
@@ -1186,6 +1255,7 @@ class OnlineStudy(HyperStudy):
         marginal = np.sum(dist, axis=axes) if axes else np.array(dist)
         return self.marginalGrid[k], marginal / self.latticeConstant[k] if density else marginal
 
+    @_plots('param_dist')
     def getCurrentParameterDistribution(self, name, plot=False, density=True, **kwargs):
         k = self._parameterIndex(name)
         axes = tuple(a for a in range(len(self.gridSize)) if a != k)
@@ -1195,6 +1265,7 @@ class OnlineStudy(HyperStudy):
     def getCPD(self, name, plot=False, density=True, **kwargs):
         return self.getCurrentParameterDistribution(name, plot=plot, density=density, **kwargs)
 
+    @_plots('param_dists')
     def getParameterDistributions(self, name, plot=False, density=True, **kwargs):
         self._needHistory('parameter distributions', 'getCurrentParameterDistribution')
         k = self._parameterIndex(name)
@@ -1267,6 +1338,7 @@ class OnlineStudy(HyperStudy):
         axes = tuple(a for a in range(len(steps)) if a != k)
         return np.sum(d, axis=axes) if axes else d
 
+    @_plots('hyper_dist')
     def getHyperParameterDistribution(self, t, name, plot=False, **kwargs):
         self._needHistory('hyper-parameter distributions', 'getCurrentHyperParameterDistribution')
         i, k = self._findHyperParameter(name)
@@ -1281,6 +1353,7 @@ class OnlineStudy(HyperStudy):
     def getHPD(self, t, name, plot=False, **kwargs):
         return self.getHyperParameterDistribution(t, name, plot=plot, **kwargs)
 
+    @_plots('hyper_dist')
     def getCurrentHyperParameterDistribution(self, name, plot=False, **kwargs):
         i, k = self._findHyperParameter(name)
         m = self._marginalHyper(i, k, self.hyperParameterDistribution[i]) * np.prod(self.hyperGridConstants[i])
@@ -1300,3 +1373,53 @@ class OnlineStudy(HyperStudy):
 
     def getHPDs(self, name):
         return self.getHyperParameterDistributions(name)
+
+    def plotParameterEvolution(self, name, color='b', gamma=0.5, **kwargs):
+        """As :meth:`Study.plotParameterEvolution`, from the stored history (reference core.py:2359-2413)."""
+        self._needHistory('parameter distributions', 'getCurrentParameterDistribution')
+        return Study.plotParameterEvolution(self, name, color=color, gamma=gamma, **kwargs)
+
+    def plotHyperParameterEvolution(self, name, color='b', gamma=0.5, **kwargs):
+        """Image of a hyper-parameter's distribution over time with its mean values on top (reference core.py:2839-2898)."""
+        from . import plotting
+        values, dist = self.getHyperParameterDistributions(name)
+        if len(values) > 1:
+            step = values[1] - values[0]
+            bounds = [values[0] - step / 2.0, values[-1] + step / 2.0]
+        else:
+            bounds = [values[0] - 0.5, values[0] + 0.5]
+        plotting.evolution(self.formattedTimestamps, bounds, dist, self.getHyperParameterMeanValues(name), name,
+                           color=color, gamma=gamma, **kwargs)
+        plotting._plt().ylim(values[0], values[-1])
+
+    def plot(self, name, **kwargs):
+        """Evolution or distribution of a (hyper-)parameter, or the probability of a transition model over time
+        (reference core.py:2900-2985)."""
+        from . import plotting
+        density = kwargs.pop('density', True)
+        t = kwargs.pop('t', None)
+        if t is not None and not self.storeHistory:
+            raise PostProcessingError('Online study has only stored current parameter data ("storeHistory=False"), '
+                                      'no time step can be specified, only current (hyper-)parameter distributions will'
+                                      'be plotted.')
+        hyper = any(name in names for names in self.hyperParameterNames)
+        model = name in self.transitionModelNames
+        if hyper and model:
+            raise PostProcessingError('Duplicate names of hyper-/parameters/transition models, cannot use "plot" method.')
+        if model:
+            seq = self.localTransitionModelSequence if kwargs.pop('local', False) else self.transitionModelSequence
+            plotting.line(self.formattedTimestamps, np.array(seq)[:, self.transitionModelNames.index(name)], **kwargs)
+        elif hyper:
+            if t is None and self.storeHistory:
+                self.plotHyperParameterEvolution(name, color=kwargs.pop('color', 'b'), gamma=kwargs.pop('gamma', 0.5), **kwargs)
+            elif t is not None:
+                self.getHyperParameterDistribution(t, name, plot=True, **kwargs)
+            else:
+                self.getCurrentHyperParameterDistribution(name, plot=True, **kwargs)
+        else:
+            if t is None and self.storeHistory:
+                self.plotParameterEvolution(name, color=kwargs.pop('color', 'b'), gamma=kwargs.pop('gamma', 0.5), **kwargs)
+            elif t is not None:
+                self.getParameterDistribution(t, name, plot=True, density=density, **kwargs)
+            else:
+                self.getCurrentParameterDistribution(name, plot=True, density=density, **kwargs)
