@@ -16,6 +16,8 @@ from . import transitionModels as tm
 from .helper import cint, oint
 from .fileIO import save, load
 from .parser import Parser
+from . import jeffreys
+from .jeffreys import getJeffreysPrior, computeJeffreysPriorAR1
 from .exceptions import ConfigurationError, PostProcessingError, BackendError
 from . import dist
 from .engine import get_engine, set_engine

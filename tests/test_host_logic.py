@@ -217,3 +217,28 @@ def test_save_load_roundtrip(tmp_path):
     assert R.observationModel.prior(1.0, 2.0) == 1 / 8.
     R.fit(silent=True)                     # the loaded study can be fitted again
     assert abs(R.logEvidence - S.logEvidence) < 1e-12
+
+
+def test_jeffreys_helpers():
+    """bl.getJeffreysPrior / bl.computeJeffreysPriorAR1 (reference bayesloop/jeffreys.py): the closed form of Uhlig's prior."""
+    sympy_stats = pytest.importorskip('sympy.stats')
+    from sympy import Symbol
+    expr, f = bl.getJeffreysPrior(sympy_stats.Poisson('p', Symbol('rate', positive=True)))
+    assert str(expr) == '1/sqrt(rate)' and abs(f(4.0) - 0.5) < 1e-15
+    data = np.array([0.3, -0.2, 0.5, 0.1, -0.4])
+    for om, scaled in ((bl.om.AR1, False), (bl.om.ScaledAR1, True)):
+        S = bl.Study(silent=True)
+        S.loadData(data, silent=True)
+        S.setOM(om('rho', bl.oint(-1, 1, 30), 'sigma', bl.oint(0, 2, 25)), silent=True)
+        p = bl.computeJeffreysPriorAR1(S, t=2)
+        r, s = S.grid
+        if scaled:
+            s = s * np.sqrt(1 - r ** 2)
+        want = np.exp(-data[1] ** 2 * (1 - r ** 2) / (2 * s ** 2)) / s ** 2 * np.sqrt(4 * r ** 2 / (1 - r ** 2) + 2 * (len(data) + 1))
+        np.testing.assert_allclose(p, want / want.sum(), rtol=1e-13)
+        assert abs(p.sum() - 1) < 1e-12
+    S = bl.Study(silent=True)
+    S.loadData(data, silent=True)
+    S.setOM(bl.om.Poisson('rate', bl.oint(0, 6, 20)), silent=True)
+    with pytest.raises(bl.ConfigurationError):
+        bl.computeJeffreysPriorAR1(S)
