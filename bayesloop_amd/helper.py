@@ -39,3 +39,9 @@ def assignNestedItem(lst, index, value):
     for k in index[:-1]:
         target = target[k]
     target[index[-1]] = value
+
+
+def createColormap(color, min_factor=1.0, max_factor=0.95):
+    """Colormap from white (gray level ``min_factor``) to ``max_factor`` x ``color`` (reference helper.py:65-87)."""
+    from .plotting import light_colormap
+    return light_colormap(color, min_factor=min_factor, max_factor=max_factor)

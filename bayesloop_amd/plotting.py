@@ -13,10 +13,12 @@ def _plt():
     return plt
 
 
-def light_colormap(color):
-    """White -> ``color`` (the reference's helper.createColormap)."""
+def light_colormap(color, min_factor=1.0, max_factor=0.95):
+    """Gray level ``min_factor`` (white by default) -> ``max_factor`` x ``color`` (the reference's helper.createColormap,
+    helper.py:65-87)."""
     from matplotlib.colors import LinearSegmentedColormap, to_rgb
-    return LinearSegmentedColormap.from_list('bl_' + str(color), [(1.0, 1.0, 1.0), to_rgb(color)])
+    top = tuple(max_factor * c for c in to_rgb(color))
+    return LinearSegmentedColormap.from_list('bl_' + str(color), [(min_factor,) * 3, top])
 
 
 def _is_regular(x):
