@@ -86,3 +86,64 @@ def test_round_robin_shares_partition_the_hyper_grid():
             assert sorted(np.concatenate(shares).tolist()) == list(range(n))
             assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
             assert max(len(s) for s in shares) == (n + size - 1) // size
+
+
+RANDOM_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(%(root)r, 'tests')); sys.path.insert(0, %(root)r)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=int(sys.argv[1]), world_size=%(world)d)
+    import bayesloop_amd as bl
+    import cases, compare, oracle_adapter as oa, random_cases
+    from oracle_engine import OracleEngine
+    bl.set_engine(OracleEngine())
+    done = 0
+    for seed in range(%(seeds)d):
+        for gen in (random_cases.random_hyper_case, random_cases.random_case):
+            c = gen(seed)
+            if c['study'] == 'Study':
+                continue
+            S = cases.build(bl, c)
+            S.communicator = bl.dist.TorchCommunicator()
+            with np.errstate(all='ignore'):
+                S.fit(**cases.fit_kwargs(c))
+                want = oa.run(c)
+            res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence)
+            gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+            if len(np.atleast_1d(S.logEvidenceList)) > 1:
+                res.update(logEvidenceList=np.array(S.logEvidenceList), hyperParameterDistribution=S.hyperParameterDistribution)
+                gold.update(logEvidenceList=np.asarray(want['logEvidenceList']), hyperParameterDistribution=np.asarray(want['hyperParameterDistribution']))
+                if not np.all(np.isfinite(gold['logEvidenceList'])):
+                    res['localEvidence'] = gold['localEvidence']      # np.empty left-overs of stopped chains in the reference
+            flags = cases.fit_kwargs(c)
+            if not flags.get('evidenceOnly') and np.isfinite(want['logEvidence']) and want.get('posteriorSequence') is not None:
+                res['posteriorMeanValues'] = S.posteriorMeanValues
+                gold['posteriorMeanValues'] = np.asarray(want['posteriorMeanValues'])
+                if dist.get_rank() == 0:
+                    res['posteriorSequence'] = S.posteriorSequence
+                    gold['posteriorSequence'] = np.asarray(want['posteriorSequence'])
+                else:
+                    assert S.posteriorSequence is None
+            compare.check(res, gold, dict(compare.ORACLE_TOL, post_rtol=1e-10, small_rtol=1e-10))
+            done += 1
+    print('rank', dist.get_rank(), 'random hyper-studies ok:', done)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_random_hyperstudies_match_oracle(tmp_path, world):
+    """Seeded random hyper- and change-point studies (tests/random_cases.py: hyper-priors, two hyper-parameters, serial models,
+    stopped chains, evidenceOnly / forwardOnly) dealt out to 2 and 3 ranks: gather + accumulator merge = the unsharded oracle."""
+    pytest.importorskip('torch')
+    script = tmp_path / 'worker.py'
+    script.write_text(RANDOM_WORKER % dict(root=ROOT, port=free_port(), world=world, seeds=27))
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out[-3000:])
+        assert 'random hyper-studies ok:' in out, out[-2000:]
