@@ -42,7 +42,8 @@ def check(res, gold, tol, aborted_ok=True, case_tol=None):
     # a case may state the absolute round-off floor of the REFERENCE itself (e.g. its FFT convolution) for posteriors
     tol = dict(tol, post_atol=max(tol['post_atol'], (case_tol or {}).get('post_atol', 0.0)),
                logE_rtol=max(tol['logE_rtol'], (case_tol or {}).get('logE_rtol', 0.0)),
-               post_rtol=max(tol['post_rtol'], (case_tol or {}).get('post_rtol', 0.0)))
+               post_rtol=max(tol['post_rtol'], (case_tol or {}).get('post_rtol', 0.0)),
+               small_rtol=max(tol['small_rtol'], (case_tol or {}).get('small_rtol', 0.0)))
     _close(res['localEvidence'], gold['localEvidence'], local_rtol, tol['small_atol'], 'localEvidence')
     if 'posteriorMeanValues' in gold:
         _close(res['posteriorMeanValues'], gold['posteriorMeanValues'], tol['small_rtol'], 1e-11, 'posteriorMeanValues')
