@@ -12,7 +12,7 @@ import os
 from .exceptions import BackendError
 
 LIB_NAME = 'libblhip.so'
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
 OM_BERNOULLI, OM_LAPLACE, OM_WHITE_NOISE, OM_AR1, OM_SCALED_AR1 = 4, 5, 6, 7, 8
@@ -76,6 +76,7 @@ PROTOTYPES = {
     'blhip_fit': (C.c_int, [C.c_void_p, C.POINTER(Problem), C.c_int64, c_double_p, c_double_p, C.c_uint32,
                             C.POINTER(Result)]),
     'blhip_last_timing': (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    'blhip_bandwidth_probe': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_double_p]),
     'blhip_posterior_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_double_p]),
     'blhip_posterior_devptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'blhip_posterior_release': (C.c_int, [C.c_void_p]),
@@ -87,6 +88,14 @@ PROTOTYPES = {
     'blhip_accum_finalize': (C.c_int, [C.c_void_p, C.POINTER(Problem), c_double_p]),
     'blhip_accum_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
     'blhip_accum_end': (C.c_int, [C.c_void_p]),
+    'blhip_accum_row_stats': (C.c_int, [C.c_void_p, C.POINTER(Problem), c_double_p]),
+    'blhip_comm_unique_id': (C.c_int, [C.c_char_p]),
+    'blhip_comm_init': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    'blhip_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'blhip_comm_allgather': (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    'blhip_comm_allreduce': (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int]),
+    'blhip_comm_reduce_accum': (C.c_int, [C.c_void_p, C.c_int]),
+    'blhip_comm_destroy': (C.c_int, [C.c_void_p]),
     'blhip_carry_mix': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, C.c_int]),
     'blhip_carry_read': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p]),
     'blhip_carry_release': (C.c_int, [C.c_void_p, C.c_int]),

@@ -26,131 +26,10 @@
 
 using namespace blk;
 
-namespace {
-
-struct Fail {
-    std::string msg;
-};
-
-[[noreturn]] void fail(const char *fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    throw Fail{buf};
-}
-
-#define HIPCHECK(expr)                                                                                        \
-    do {                                                                                                      \
-        hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess) fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    void ensure(size_t bytes) {
-        if (bytes <= cap) return;
-        release();
-        HIPCHECK(hipMalloc(&p, bytes));
-        cap = bytes;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-// page-locked host staging: a hipMemcpyAsync to / from pageable memory is staged by the runtime behind blocking waits whose
-// wake-up is quantised (10-ms steps seen on a 6 KB read-back: 20-27 ms per call instead of 0.5 ms)
-struct PinBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    void ensure(size_t bytes) {
-        if (bytes <= cap) return;
-        release();
-        HIPCHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
-        cap = bytes;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-thread_local std::string g_create_error;
-
-}  // namespace
-
-struct blhip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
-    // radius buckets of a batch are independent pipelines: one stream per bucket key, joined with events
-    static constexpr int NBS = 12;
-    hipStream_t bstream[NBS] = {};
-    hipEvent_t bev[NBS] = {};
-    hipEvent_t fork_ev = nullptr, sync_ev = nullptr;
-    std::string err;
-    std::string name;
-    std::map<std::string, double> opt;
-    // reusable device buffers
-    DevBuf state, post, psumF, psumB, redF, redB, meta, tables, likbuf, small, accum_own, stats;
-    // kept posterior of the last fit
-    bool post_valid = false;
-    bool post_scaled = true;     // false: the kept rows still carry their raw sums; postinv holds 1 / sum per (chain, step)
-    DevBuf postinv;
-    int64_t post_chains = 0, post_T = 0, post_G = 0;
-    int post_n0 = 1, post_n1 = 1, acc_n0 = 1, acc_n1 = 1;
-    // accumulator
-    bool acc_active = false, acc_final = false, acc_first = true;
-    double *acc = nullptr;
-    int64_t acc_T = 0, acc_G = 0, acc_folded = 0;
-    double acc_logref = -std::numeric_limits<double>::infinity();
-    blhip_timing timing = {};
-    // carried states of streaming fits (BLHIP_CARRY / BLHIP_RESUME): slot -> (chains, G) normalised distributions
-    struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; std::vector<double> maxv; };
-    std::map<int, Carry> carry;
-    DevBuf mix, unit, databuf;
-    PinBuf pinF, pinB, pinS;     // host staging of the reduced sums (forward, backward) and of small read-backs
-    int64_t mix_G = 0;
-
-    double option(const char *k, double dflt) const {
-        auto it = opt.find(k);
-        return it == opt.end() ? dflt : it->second;
-    }
-};
+#include "blhip_host.hpp"
+#include "blhip_comm.hpp"
 
 namespace {
-
-// Wait for a stream by polling an event: hipStreamSynchronize blocks on an interrupt whose wake-up is quantised (~10 ms
-// steps measured on long waits: 15-25 ms of wall time per fit on top of a 365 ms device timeline).
-struct Trace {
-    bool on; std::chrono::steady_clock::time_point t0;
-    explicit Trace(bool o) : on(o), t0(std::chrono::steady_clock::now()) {}
-    void mark(const char *what) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[blhip trace] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-
-void sync_stream(blhip_ctx *ctx, hipStream_t st) {
-    if (ctx->option("spin_sync", 1.0) == 0.0) { HIPCHECK(hipStreamSynchronize(st)); return; }
-    HIPCHECK(hipEventRecord(ctx->sync_ev, st));
-    for (;;) {
-        const hipError_t e = hipEventQuery(ctx->sync_ev);
-        if (e == hipSuccess) return;
-        if (e != hipErrorNotReady) HIPCHECK(e);
-        std::this_thread::yield();
-    }
-}
 
 struct TapTable {
     std::vector<double> w;       // concatenated half kernels: w[off + k], k = 0..lw
@@ -804,13 +683,6 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
         }
     }
 }
-
-template <class T> T *carve(char *&cur, size_t count) {
-    T *p = reinterpret_cast<T *>(cur);
-    cur += ((count * sizeof(T) + 255) / 256) * 256;
-    return p;
-}
-size_t carve_size(size_t bytes) { return ((bytes + 255) / 256) * 256; }
 
 // normalise the kept posterior rows (core.py:389 / :441) (eagerly at the end of the fit, or on first access with option lazy_normalise)
 void ensure_post_scaled(blhip_ctx *ctx) {
@@ -1489,37 +1361,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
         }
 
-#ifdef BLM_TLOG
-        if (use_mfma) {   // diagnostic build: when did the blocks of the last matrix-pipe launches start and end?
-            static unsigned long long h[2][3 * 4096];
-            HIPCHECK(hipDeviceSynchronize());
-            HIPCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(blm::tlog), sizeof(h)));
-            static unsigned long long pl[2][5][16][5];
-            HIPCHECK(hipMemcpyFromSymbol(pl, HIP_SYMBOL(blm::plog), sizeof(pl)));
-            for (int m = 0; m < 2; ++m)
-                for (int w = 0; w < 5; ++w) {
-                    if (!pl[m][w][0][0]) continue;
-                    fprintf(stderr, "[plog %s wave %d]", m ? "bwd" : "fwd", w);
-                    for (int ti = 0; ti < 16 && pl[m][w][ti][0]; ++ti)
-                        fprintf(stderr, "  t%d: +%lld | a0+w %lld | bar %lld | a1+epi %lld | ring %lld", ti, (long long)(pl[m][w][ti][0] - pl[m][0][0][0]),
-                                (long long)(pl[m][w][ti][1] - pl[m][w][ti][0]), (long long)(pl[m][w][ti][2] - pl[m][w][ti][1]),
-                                (long long)(pl[m][w][ti][3] - pl[m][w][ti][2]), (long long)(pl[m][w][ti][4] - pl[m][w][ti][3]));
-                    fprintf(stderr, "\n");
-                }
-            hipMemset(nullptr, 0, 0);
-            for (int m = 0; m < 2; ++m) {
-                const int nb = (int)std::min<long long>(4096, (long long)FP.mnblk * B);
-                unsigned long long t0 = ~0ull, t1 = 0; double ds = 0, dl = 0, smax = 0, emin = 1e30;
-                for (int i = 0; i < nb; ++i) { t0 = std::min(t0, h[m][3 * i]); t1 = std::max(t1, h[m][3 * i + 2]); }
-                for (int i = 0; i < nb; ++i) {
-                    ds += (double)(h[m][3 * i + 2] - h[m][3 * i]); dl += (double)(h[m][3 * i + 2] - h[m][3 * i + 1]);
-                    smax = std::max(smax, (double)(h[m][3 * i] - t0)); emin = std::min(emin, (double)(h[m][3 * i + 2] - t0));
-                }
-                fprintf(stderr, "[tlog %s] blocks %d span %.2f us  mean block life %.2f us  mean loop %.2f us  last start +%.2f us  first end +%.2f us\n",
-                        m ? "bwd" : "fwd", nb, (t1 - t0) * 0.01, ds / nb * 0.01, dl / nb * 0.01, smax * 0.01, emin * 0.01);
-            }
-        }
-#endif
         // --- normalise the kept posterior (core.py:389 / :441, applied lazily) ---
         if (keep) {
             ctx->postinv.ensure(nT * 8);
@@ -1556,21 +1397,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     ctx->timing.total_ms = ms;
 }
 
-template <class F> int guarded(blhip_ctx *ctx, F &&f) {
-    if (!ctx) return -1;
-    try {
-        f();
-        return 0;
-    } catch (const Fail &e) {
-        ctx->err = e.msg;
-    } catch (const std::exception &e) {
-        ctx->err = e.what();
-    } catch (...) {
-        ctx->err = "unknown error";
-    }
-    return -1;
-}
-
 }  // namespace
 
 extern "C" {
@@ -1600,7 +1426,9 @@ blhip_ctx *blhip_create(int device) {
         HIPCHECK(hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming));
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, device));
-        ctx->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        std::string marketing = prop.name;
+        if (marketing.find_first_not_of(' ') == std::string::npos) marketing = "AMD Instinct (name not reported by the driver)";
+        ctx->name = marketing + " (" + prop.gcnArchName + ")";
         return ctx;
     } catch (const Fail &e) {
         g_create_error = e.msg;
@@ -1615,6 +1443,8 @@ void blhip_destroy(blhip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)blhip_comm_destroy(ctx);
+    ctx->commbuf.release(); ctx->pinC.release();
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
                       &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit, &ctx->databuf, &ctx->postinv})
         b->release();
@@ -1656,6 +1486,31 @@ int blhip_synchronize(blhip_ctx *ctx) {
 int blhip_fit(blhip_ctx *ctx, const blhip_problem *problem, int64_t n_chains, const double *op_values,
               const double *log_chain_weight, uint32_t flags, blhip_result *result) {
     return guarded(ctx, [&] { do_fit(ctx, problem, n_chains, op_values, log_chain_weight, flags, result); });
+}
+
+int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double *gb_per_s) {
+    return guarded(ctx, [&] {
+        if (!gb_per_s || bytes < (1 << 20) || iterations < 1) fail("blhip_bandwidth_probe: bad arguments");
+        HIPCHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const long long n2 = bytes / 16;
+        DevBuf a, b;
+        a.ensure((size_t)n2 * 16); b.ensure((size_t)n2 * 16);
+        hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, a.as<double>(), n2 * 2, 1.0);
+        const unsigned gx = (unsigned)std::min<long long>((n2 + NTHREADS - 1) / NTHREADS, 256LL * 32);
+        hipLaunchKernelGGL(copy16_kernel, dim3(gx), dim3(NTHREADS), 0, st, a.as<double2>(), b.as<double2>(), n2);   // warm-up
+        HIPCHECK(hipEventRecord(ctx->ev[4], st));
+        for (int k = 0; k < iterations; ++k)
+            hipLaunchKernelGGL(copy16_kernel, dim3(gx), dim3(NTHREADS), 0, st, (k & 1) ? b.as<double2>() : a.as<double2>(),
+                               (k & 1) ? a.as<double2>() : b.as<double2>(), n2);
+        HIPCHECK(hipEventRecord(ctx->ev[5], st));
+        HIPCHECK(hipGetLastError());
+        sync_stream(ctx, st);
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+        *gb_per_s = 2.0 * (double)n2 * 16.0 * iterations / ((double)ms * 1e-3) / 1e9;
+        a.release(); b.release();
+    });
 }
 
 int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out) {
@@ -1852,36 +1707,66 @@ int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref) {
     });
 }
 
+namespace {
+// per-step sums [sum A, sum A grid_0, sum A grid_1] of the accumulator -> page-locked host memory (T, 3) (+ T spare doubles
+// behind them); d_inv: T doubles of device scratch
+struct RowStats { double *red, *d_inv; };
+RowStats accum_row_stats(blhip_ctx *ctx, const blhip_problem *p) {
+    if (!ctx->acc_active) fail("no active accumulator");
+    if (!p) fail("problem is NULL");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t T = ctx->acc_T, G = ctx->acc_G;
+    const int n1 = p->ndim == 1 ? (int)p->n[0] : (int)p->n[1];
+    const int n0 = p->ndim == 1 ? 1 : (int)p->n[0];
+    if ((int64_t)n0 * n1 != G) fail("accumulator / grid mismatch");
+    const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 256);
+    size_t bytes = carve_size((size_t)T * 3 * gx * 8) + carve_size((size_t)T * 3 * 8) + carve_size((size_t)T * 8) +
+                   carve_size(8 * (size_t)std::max(1, n0)) + carve_size(8 * (size_t)n1);
+    ctx->stats.ensure(bytes);
+    char *cur = ctx->stats.as<char>();
+    double *d_part = carve<double>(cur, (size_t)T * 3 * gx);
+    double *d_red = carve<double>(cur, (size_t)T * 3);
+    double *d_inv = carve<double>(cur, (size_t)T);
+    double *d_m0 = carve<double>(cur, std::max(1, n0));
+    double *d_m1 = carve<double>(cur, n1);
+    if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(d_m0, p->marginal[0], 8 * (size_t)n0, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_m1, p->ndim == 1 ? p->marginal[0] : p->marginal[1], 8 * (size_t)n1, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(row_stats_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, n1,
+                       p->ndim, d_m0, d_m1, d_part);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * 3)), dim3(NTHREADS), 0, st, d_part, d_red, (int)gx, 0);
+    ctx->pinS.ensure((size_t)T * 4 * 8);
+    double *red = ctx->pinS.as<double>();
+    HIPCHECK(hipMemcpyAsync(red, d_red, (size_t)T * 3 * 8, hipMemcpyDeviceToHost, st));
+    sync_stream(ctx, st);
+    ctx->acc_n0 = n0; ctx->acc_n1 = n1;
+    return RowStats{red, d_inv};
+}
+}  // namespace
+
+int blhip_accum_row_stats(blhip_ctx *ctx, const blhip_problem *p, double *host_out) {
+    return guarded(ctx, [&] {
+        if (!host_out) fail("host_out is NULL");
+        if (!ctx->acc_active) fail("no active accumulator");
+        if (!p) fail("problem is NULL");
+        const int64_t T = ctx->acc_T;
+        const int w = 1 + p->ndim;
+        if (ctx->acc_first) { std::fill(host_out, host_out + T * w, 0.0); return; }
+        const double *red = accum_row_stats(ctx, p).red;
+        for (int64_t t = 0; t < T; ++t)
+            for (int k = 0; k < w; ++k) host_out[t * w + k] = red[t * 3 + k];
+    });
+}
+
 int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *p, double *posterior_mean) {
     return guarded(ctx, [&] {
         if (!ctx->acc_active) fail("no active accumulator");
-        if (!p) fail("problem is NULL");
-        HIPCHECK(hipSetDevice(ctx->device));
+        if (ctx->acc_first) fail("blhip_accum_finalize: nothing was accumulated");
+        const RowStats rs = accum_row_stats(ctx, p);
+        double *red = rs.red, *d_inv = rs.d_inv;
         hipStream_t st = ctx->stream;
         const int64_t T = ctx->acc_T, G = ctx->acc_G;
-        const int n1 = p->ndim == 1 ? (int)p->n[0] : (int)p->n[1];
-        const int n0 = p->ndim == 1 ? 1 : (int)p->n[0];
-        if ((int64_t)n0 * n1 != G) fail("blhip_accum_finalize: grid mismatch");
-        if (ctx->acc_first) fail("blhip_accum_finalize: nothing was accumulated");
-        const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 256);
-        size_t bytes = carve_size((size_t)T * 3 * gx * 8) + carve_size((size_t)T * 3 * 8) + carve_size((size_t)T * 8) +
-                       carve_size(8 * (size_t)std::max(1, n0)) + carve_size(8 * (size_t)n1);
-        ctx->stats.ensure(bytes);
-        char *cur = ctx->stats.as<char>();
-        double *d_part = carve<double>(cur, (size_t)T * 3 * gx);
-        double *d_red = carve<double>(cur, (size_t)T * 3);
-        double *d_inv = carve<double>(cur, (size_t)T);
-        double *d_m0 = carve<double>(cur, std::max(1, n0));
-        double *d_m1 = carve<double>(cur, n1);
-        if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(d_m0, p->marginal[0], 8 * (size_t)n0, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_m1, p->ndim == 1 ? p->marginal[0] : p->marginal[1], 8 * (size_t)n1, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(row_stats_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, n1,
-                           p->ndim, d_m0, d_m1, d_part);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * 3)), dim3(NTHREADS), 0, st, d_part, d_red, (int)gx, 0);
-        ctx->pinS.ensure((size_t)T * 4 * 8);
-        double *red = ctx->pinS.as<double>(), *inv = red + (size_t)T * 3;
-        HIPCHECK(hipMemcpyAsync(red, d_red, (size_t)T * 3 * 8, hipMemcpyDeviceToHost, st));
-        sync_stream(ctx, st);
+        double *inv = red + (size_t)T * 3;
         for (int64_t t = 0; t < T; ++t) {
             inv[t] = 1.0 / red[t * 3];                                           // core.py:1379-1382
             if (posterior_mean)
@@ -1892,7 +1777,6 @@ int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *p, double *posteri
         hipLaunchKernelGGL(scale_rows_kernel, dim3(gs, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, (long long)G, d_inv);
         sync_stream(ctx, st);
         ctx->acc_final = true;
-        ctx->acc_n0 = n0; ctx->acc_n1 = n1;
     });
 }
 

@@ -1,0 +1,200 @@
+// Multi-GPU exchange of a sharded hyper-study: RCCL over xGMI, bound DIRECTLY (no PyTorch, no MPI).
+//
+// What it replaces in the reference: HyperStudy.fit(nJobs > 1) fans the hyper-grid out with pool.map(self._parallelFit, ...)
+// (bayesloop/core.py:1317-1326) and merges the sub-studies on the host: list concatenation of the per-point evidences and
+// np.logaddexp of the average posteriors (core.py:1335-1340).  Here every GPU of the node runs its share of the chains without
+// any communication; afterwards
+//   * ONE ncclAllGather of the packed per-chain rows [logEvidence | localEvidence (T) | abort step] plus one trailer row per
+//     rank (reference exponent and per-step sums of its accumulator), staged by the caller as plain doubles      -> blhip_comm_allgather
+//   * only when posteriors were requested: a local rescale to the common reference exponent (its maximum is in the
+//     gathered trailers, so no second collective is needed) and ONE ncclReduce(sum) of the (T, G) accumulator to the
+//     root, in place in HBM                                                                                   -> blhip_comm_reduce_accum
+// librccl.so is dlopen'ed on first use: single-GPU users never load it, and the library does not link against it.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "blhip_host.hpp"
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    std::string path;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+
+    template <class F> void sym(F &f, const char *name) {
+        f = reinterpret_cast<F>(dlsym(handle, name));
+        if (!f) fail("%s does not export %s", path.c_str(), name);
+    }
+
+    void load() {
+        if (handle) return;
+        std::vector<std::string> cands;
+        if (const char *e = std::getenv("BLHIP_RCCL_LIBRARY")) cands.push_back(e);
+        cands.push_back("librccl.so.1");
+        if (const char *r = std::getenv("ROCM_PATH")) cands.push_back(std::string(r) + "/lib/librccl.so.1");
+        cands.push_back("/opt/rocm/lib/librccl.so.1");
+        cands.push_back("librccl.so");
+        std::string errs;
+        for (const auto &c : cands) {
+            handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (handle) { path = c; break; }
+            const char *e = dlerror();
+            errs += "\n  " + c + ": " + (e ? e : "?");
+        }
+        if (!handle) fail("cannot load RCCL (needed for multi-GPU hyper-studies):%s", errs.c_str());
+        sym(GetUniqueId, "ncclGetUniqueId");
+        sym(CommInitRank, "ncclCommInitRank");
+        sym(CommDestroy, "ncclCommDestroy");
+        sym(AllGather, "ncclAllGather");
+        sym(AllReduce, "ncclAllReduce");
+        sym(Reduce, "ncclReduce");
+        sym(GetErrorString, "ncclGetErrorString");
+        sym(GetVersion, "ncclGetVersion");
+    }
+};
+
+RcclApi &rccl() {
+    static RcclApi api;
+    api.load();
+    return api;
+}
+
+#define RCCLCHECK(expr)                                                                                          \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess) fail("%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+ncclComm_t comm_of(blhip_ctx *ctx) {
+    if (!ctx->comm) fail("no communicator on this context (blhip_comm_init)");
+    return reinterpret_cast<ncclComm_t>(ctx->comm);
+}
+
+}  // namespace
+
+extern "C" {
+
+int blhip_comm_unique_id(void *id_out) {
+    try {
+        if (!id_out) fail("id_out is NULL");
+        static_assert(sizeof(ncclUniqueId) == BLHIP_UNIQUE_ID_BYTES, "unique id size");
+        ncclUniqueId id;
+        RCCLCHECK(rccl().GetUniqueId(&id));
+        std::memcpy(id_out, &id, sizeof id);
+        return 0;
+    } catch (const Fail &e) {
+        g_create_error = e.msg;
+    } catch (...) {
+        g_create_error = "unknown error in blhip_comm_unique_id";
+    }
+    return -1;
+}
+
+int blhip_comm_init(blhip_ctx *ctx, const void *unique_id, int world, int rank) {
+    return guarded(ctx, [&] {
+        if (!unique_id) fail("unique_id is NULL");
+        if (world < 1 || rank < 0 || rank >= world) fail("blhip_comm_init: rank %d of %d", rank, world);
+        if (ctx->comm) fail("this context already has a communicator (blhip_comm_destroy first)");
+        HIPCHECK(hipSetDevice(ctx->device));
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof id);
+        ncclComm_t c = nullptr;
+        RCCLCHECK(rccl().CommInitRank(&c, world, id, rank));
+        ctx->comm = c;
+        ctx->comm_world = world;
+        ctx->comm_rank = rank;
+    });
+}
+
+int blhip_comm_info(blhip_ctx *ctx, int *world, int *rank, int *rccl_version) {
+    return guarded(ctx, [&] {
+        if (world) *world = ctx->comm ? ctx->comm_world : 1;
+        if (rank) *rank = ctx->comm ? ctx->comm_rank : 0;
+        if (rccl_version) {
+            *rccl_version = 0;
+            if (ctx->comm) RCCLCHECK(rccl().GetVersion(rccl_version));
+        }
+    });
+}
+
+int blhip_comm_allgather(blhip_ctx *ctx, const double *host_in, int64_t count, double *host_out) {
+    return guarded(ctx, [&] {
+        if (!host_in || !host_out || count < 1) fail("blhip_comm_allgather: bad arguments");
+        ncclComm_t c = comm_of(ctx);
+        HIPCHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const size_t W = (size_t)ctx->comm_world, nb = (size_t)count * 8;
+        ctx->commbuf.ensure((W + 1) * nb);
+        ctx->pinC.ensure((W + 1) * nb);
+        double *d_send = ctx->commbuf.as<double>(), *d_recv = d_send + count;
+        double *h_send = ctx->pinC.as<double>(), *h_recv = h_send + count;
+        std::memcpy(h_send, host_in, nb);
+        HIPCHECK(hipMemcpyAsync(d_send, h_send, nb, hipMemcpyHostToDevice, st));
+        RCCLCHECK(rccl().AllGather(d_send, d_recv, (size_t)count, ncclDouble, c, st));
+        HIPCHECK(hipMemcpyAsync(h_recv, d_recv, W * nb, hipMemcpyDeviceToHost, st));
+        sync_stream(ctx, st);
+        std::memcpy(host_out, h_recv, W * nb);
+    });
+}
+
+int blhip_comm_allreduce(blhip_ctx *ctx, double *host_inout, int64_t count, int op) {
+    return guarded(ctx, [&] {
+        if (!host_inout || count < 1) fail("blhip_comm_allreduce: bad arguments");
+        if (op < 0 || op > 2) fail("blhip_comm_allreduce: op must be BLHIP_SUM, BLHIP_MAX or BLHIP_MIN");
+        ncclComm_t c = comm_of(ctx);
+        HIPCHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const size_t nb = (size_t)count * 8;
+        ctx->commbuf.ensure(nb);
+        ctx->pinC.ensure(nb);
+        double *d = ctx->commbuf.as<double>(), *h = ctx->pinC.as<double>();
+        std::memcpy(h, host_inout, nb);
+        HIPCHECK(hipMemcpyAsync(d, h, nb, hipMemcpyHostToDevice, st));
+        const ncclRedOp_t rop = op == BLHIP_SUM ? ncclSum : (op == BLHIP_MAX ? ncclMax : ncclMin);
+        RCCLCHECK(rccl().AllReduce(d, d, (size_t)count, ncclDouble, rop, c, st));
+        HIPCHECK(hipMemcpyAsync(h, d, nb, hipMemcpyDeviceToHost, st));
+        sync_stream(ctx, st);
+        std::memcpy(host_inout, h, nb);
+    });
+}
+
+int blhip_comm_reduce_accum(blhip_ctx *ctx, int root) {
+    return guarded(ctx, [&] {
+        ncclComm_t c = comm_of(ctx);
+        if (!ctx->acc_active) fail("no active accumulator");
+        if (ctx->acc_final) fail("blhip_comm_reduce_accum: the accumulator is already finalised");
+        if (root < 0 || root >= ctx->comm_world) fail("blhip_comm_reduce_accum: root %d of %d ranks", root, ctx->comm_world);
+        HIPCHECK(hipSetDevice(ctx->device));
+        const size_t n = (size_t)ctx->acc_T * (size_t)ctx->acc_G;
+        // in place: on the root the sum replaces its own share; the other ranks' buffers keep their (spent) shares
+        RCCLCHECK(rccl().Reduce(ctx->acc, ctx->acc, n, ncclDouble, ncclSum, root, c, ctx->stream));
+        sync_stream(ctx, ctx->stream);
+    });
+}
+
+int blhip_comm_destroy(blhip_ctx *ctx) {
+    return guarded(ctx, [&] {
+        if (!ctx->comm) return;
+        HIPCHECK(hipSetDevice(ctx->device));
+        sync_stream(ctx, ctx->stream);
+        ncclComm_t c = reinterpret_cast<ncclComm_t>(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_world = 1;
+        ctx->comm_rank = 0;
+        RCCLCHECK(rccl().CommDestroy(c));
+    });
+}
+
+}  // extern "C"

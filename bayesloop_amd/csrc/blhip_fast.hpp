@@ -136,12 +136,8 @@ __device__ __forceinline__ int reflect1(int i, int n) {
 
 constexpr int DMAX = 4;         // data dimensions kept in registers
 
-#ifndef BL_MINW
-#define BL_MINW 1
-#endif
-
 template <int OM, int MODE, int R0, bool H, bool REC>
-__global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_kernel(const FastParams P) {
+__global__ __launch_bounds__(NTHREADS, 1) void fast_step_kernel(const FastParams P) {
     constexpr bool BWD = MODE == blk::MODE_BWD;
     constexpr bool GAUSS = OM == blk::OM_GAUSSIAN;
     constexpr int WIN = 2 * R0 + CH;
@@ -236,11 +232,7 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
         // ---- axis-0 stencil out of the register window: the CH rows are independent accumulator chains, interleaved
         //      tap by tap so that consecutive fp64 instructions never depend on each other (per-row order = SciPy's) ------
         double v[CH];
-#ifdef BL_ABL_NOVERT
-        if (false) {
-#else
         if (R0 > 0) {
-#endif
 #pragma unroll
             for (int r = 0; r < CH; ++r) v[r] = w[r + R0] * wk[0];
 #pragma unroll
@@ -305,11 +297,7 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
                               min(max(tid, R1MAX), BW - 1 - R1MAX) - R1MAX;
                 double c0[2 * R1MAX + 1], c1[2 * R1MAX + 1];
 #pragma unroll
-#ifdef BL_ABL_NOLDSREAD
-                for (int k = 0; k <= 2 * R1MAX; ++k) { c0[k] = cen[R1MAX] + k; c1[k] = cen[(BW + 1) + R1MAX] - k; }
-#else
                 for (int k = 0; k <= 2 * R1MAX; ++k) { c0[k] = cen[k]; c1[k] = cen[(BW + 1) + k]; }   // all LDS reads in flight
-#endif
                 o[0] = c0[R1MAX] * w1[0];
                 o[1] = c1[R1MAX] * w1[0];
 #pragma unroll
@@ -345,11 +333,7 @@ __global__ __launch_bounds__(NTHREADS, (R0 <= 8 ? BL_MINW : 1)) void fast_step_k
                 if (!BWD) {
                     const double a = o[q] * scale * Lv;
                     if (live) {
-#ifndef BL_ABL_NOSTORE
                         dcol[off] = a;
-#else
-                        if (a == 1.2345e300) dcol[off] = a;
-#endif
                         sN += a;
                         if (P.means) { sM0 = fma(a, sld(P.m0, min(gi, P.n0 - 1)), sM0); sM1 = fma(a, g1, sM1); }
                     }

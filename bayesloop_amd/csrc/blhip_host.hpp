@@ -1,0 +1,169 @@
+// Host-side infrastructure of libblhip: error handling, device / page-locked buffers, the context object.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <limits>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/blhip.h"
+
+namespace {
+
+struct Fail {
+    std::string msg;
+};
+
+[[noreturn]] void fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Fail{buf};
+}
+
+#define HIPCHECK(expr)                                                                                        \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        release();
+        HIPCHECK(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// page-locked host staging: a hipMemcpyAsync to / from pageable memory is staged by the runtime behind blocking waits whose
+// wake-up is quantised (10-ms steps seen on a 6 KB read-back: 20-27 ms per call instead of 0.5 ms)
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        release();
+        HIPCHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct blhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    // radius buckets of a batch are independent pipelines: one stream per bucket key, joined with events
+    static constexpr int NBS = 12;
+    hipStream_t bstream[NBS] = {};
+    hipEvent_t bev[NBS] = {};
+    hipEvent_t fork_ev = nullptr, sync_ev = nullptr;
+    std::string err;
+    std::string name;
+    std::map<std::string, double> opt;
+    // reusable device buffers
+    DevBuf state, post, psumF, psumB, redF, redB, meta, tables, likbuf, small, accum_own, stats;
+    // kept posterior of the last fit
+    bool post_valid = false;
+    bool post_scaled = true;     // false: the kept rows still carry their raw sums; postinv holds 1 / sum per (chain, step)
+    DevBuf postinv;
+    int64_t post_chains = 0, post_T = 0, post_G = 0;
+    int post_n0 = 1, post_n1 = 1, acc_n0 = 1, acc_n1 = 1;
+    // accumulator
+    bool acc_active = false, acc_final = false, acc_first = true;
+    double *acc = nullptr;
+    int64_t acc_T = 0, acc_G = 0, acc_folded = 0;
+    double acc_logref = -std::numeric_limits<double>::infinity();
+    blhip_timing timing = {};
+    // carried states of streaming fits (BLHIP_CARRY / BLHIP_RESUME): slot -> (chains, G) normalised distributions
+    struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; std::vector<double> maxv; };
+    std::map<int, Carry> carry;
+    DevBuf mix, unit, databuf;
+    PinBuf pinF, pinB, pinS;     // host staging of the reduced sums (forward, backward) and of small read-backs
+    int64_t mix_G = 0;
+    // multi-GPU exchange (blhip_comm.hpp): RCCL communicator of this context's device, staging buffers
+    void *comm = nullptr;        // ncclComm_t
+    int comm_world = 1, comm_rank = 0;
+    DevBuf commbuf;
+    PinBuf pinC;
+
+    double option(const char *k, double dflt) const {
+        auto it = opt.find(k);
+        return it == opt.end() ? dflt : it->second;
+    }
+};
+
+namespace {
+
+// Wait for a stream by polling an event: hipStreamSynchronize blocks on an interrupt whose wake-up is quantised (~10 ms
+// steps measured on long waits: 15-25 ms of wall time per fit on top of a 365 ms device timeline).
+struct Trace {
+    bool on; std::chrono::steady_clock::time_point t0;
+    explicit Trace(bool o) : on(o), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[blhip trace] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+void sync_stream(blhip_ctx *ctx, hipStream_t st) {
+    if (ctx->option("spin_sync", 1.0) == 0.0) { HIPCHECK(hipStreamSynchronize(st)); return; }
+    HIPCHECK(hipEventRecord(ctx->sync_ev, st));
+    for (;;) {
+        const hipError_t e = hipEventQuery(ctx->sync_ev);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIPCHECK(e);
+        std::this_thread::yield();
+    }
+}
+
+template <class T> T *carve(char *&cur, size_t count) {
+    T *p = reinterpret_cast<T *>(cur);
+    cur += ((count * sizeof(T) + 255) / 256) * 256;
+    return p;
+}
+size_t carve_size(size_t bytes) { return ((bytes + 255) / 256) * 256; }
+
+template <class F> int guarded(blhip_ctx *ctx, F &&f) {
+    if (!ctx) return -1;
+    try {
+        f();
+        return 0;
+    } catch (const Fail &e) {
+        ctx->err = e.msg;
+    } catch (const std::exception &e) {
+        ctx->err = e.what();
+    } catch (...) {
+        ctx->err = "unknown error";
+    }
+    return -1;
+}
+
+}  // namespace

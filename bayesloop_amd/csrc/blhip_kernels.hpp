@@ -567,6 +567,11 @@ __global__ __launch_bounds__(NTHREADS) void time_average_kernel(const double *p,
     }
 }
 
+// streaming copy, 16 B per lane and access (the calibration of what this part reaches on a pure read + write stream)
+__global__ __launch_bounds__(NTHREADS) void copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, long long n2) {
+    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < n2; c += (long long)gridDim.x * NTHREADS) dst[c] = src[c];
+}
+
 __global__ void fill_kernel(double *p, long long n, double v) {
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (long long)gridDim.x * blockDim.x)
         p[c] = v;

@@ -32,11 +32,6 @@
 #include "blhip_fast.hpp"
 
 namespace blm {
-#ifdef BLM_TLOG
-// diagnostic build (-DBLM_TLOG): wall-clock (100 MHz) start / tile-loop start / end of every block of the last launch
-__device__ unsigned long long tlog[2][3 * 4096];
-__device__ unsigned long long plog[2][5][16][5];     // [dir][wave][tile][phase] cycle counter of one block
-#endif
 
 using blf::FastParams;
 using blf::exp_mn;
@@ -97,9 +92,6 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     __shared__ double red[5 * NW + 1];
     __shared__ double Vt[H ? 2 * TM * RS : 1];
 
-#ifdef BLM_TLOG
-    const unsigned long long t_start = wall_clock64();
-#endif
     const blf::ChainMeta cmeta = blf::chain_meta(P, NK > 4, H);
     const int b = cmeta.b;
     const int blkid = blockIdx.x;
@@ -205,20 +197,12 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
         for (int r = 0; r < 4; ++r) lk[0][r] = lcol[(long long)min(i_lo + g + 4 * r, P.n0 - 1) * rs];
     }
 
-#ifdef BLM_TLOG
-    const unsigned long long t_loop = wall_clock64();
-#endif
     for (int i0 = i_lo; i0 < i_hi; i0 += BLM_PF * TM) {
 #pragma unroll
         for (int u = 0; u < BLM_PF; ++u) {
             const int i = i0 + u * TM;             // (a tile past the end of the segment is all dead rows: mS % (BLM_PF * TM) == 0
                                                    //  keeps that to the ragged end of the grid)
             const int li = i - i_lo + g;           // this lane's first row of the tile, relative to the segment
-#ifdef BLM_TLOG
-            const bool plg = H && blockIdx.x == gridDim.x / 2 + 1 && blockIdx.y == 0 && lane == 0 && (i - i_lo) / TM < 16;
-            const int pti = (i - i_lo) / TM;
-            if (plg) plog[BWD][wv][pti][0] = __builtin_readcyclecounter();
-#endif
             if (BWD) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -248,13 +232,7 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                 const int lc = mainw ? R1 + wv * WCOL + c : (c < R1 ? c : BCOL + c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vt[(g + 4 * r) * RS + lc] = acc[r];
-#ifdef BLM_TLOG
-                if (plg) plog[BWD][wv][pti][1] = __builtin_readcyclecounter();
-#endif
                 __syncthreads();
-#ifdef BLM_TLOG
-                if (plg) plog[BWD][wv][pti][2] = __builtin_readcyclecounter();
-#endif
                 if (mainw) {
                     lds_cp va = (lds_cp)vt + c * RS + wv * WCOL + g;
                     d4 acc2 = {0.0, 0.0, 0.0, 0.0};
@@ -379,9 +357,6 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                 }
             }
 
-#ifdef BLM_TLOG
-            if (plg) plog[BWD][wv][pti][3] = __builtin_readcyclecounter();
-#endif
             // ---- advance the ring by one tile, re-fill the slot ------------------------------------------------------------
 #pragma unroll
             for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
@@ -391,15 +366,9 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
             for (int q = 0; q < 4; ++q)
                 nxt[u][q] = LEAN ? ld32(src, __umul24(refl_hi(i + (BLM_PF + 1) * TM + R0 + 4 * q + g), n1x8) + gj8)
                                  : col[(long long)reflect1(i + (BLM_PF + 1) * TM + R0 + 4 * q + g, P.n0) * P.n1];
-#ifdef BLM_TLOG
-            if (plg) plog[BWD][wv][pti][4] = __builtin_readcyclecounter();
-#endif
         }
     }
 
-#ifdef BLM_TLOG
-    if (threadIdx.x == 0) { const int id = blockIdx.y * gridDim.x + blockIdx.x; if (id < 4096) { tlog[BWD][3 * id] = t_start; tlog[BWD][3 * id + 1] = t_loop; tlog[BWD][3 * id + 2] = wall_clock64(); } }
-#endif
     if (!owner) { sN = 0.0; sS = 0.0; sC = 0.0; sM0 = 0.0; sM1 = 0.0; }
     double *out = P.psum_out + (long long)b * NRED * P.nblk + blkid;
     const int left = P.nblk - blkid;

@@ -1,4 +1,5 @@
 """Builds libblhip.so in-tree for gfx950:  python -m bayesloop_amd.csrc.build [--force]"""
+import glob
 import os
 import subprocess
 import sys
@@ -6,7 +7,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'libblhip.so')
 SOURCES = ['blhip.hip']
-DEPS = ['blhip.hip', 'blhip_kernels.hpp', 'blhip_fast.hpp', 'blhip_persist1d.hpp', os.path.join('..', '..', 'include', 'blhip.h')]
+
+
+def deps():
+    """Everything the library is compiled from: every source / header next to this file plus the public C header."""
+    d = sorted(glob.glob(os.path.join(HERE, '*.hip')) + glob.glob(os.path.join(HERE, '*.hpp')) + glob.glob(os.path.join(HERE, '*.h')))
+    d.append(os.path.join(HERE, '..', '..', 'include', 'blhip.h'))
+    return d
 
 
 def hipcc():
@@ -20,16 +27,22 @@ def stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in DEPS if os.path.exists(os.path.join(HERE, d)))
+    return any(os.path.getmtime(d) > t for d in deps() if os.path.exists(d))
 
 
 def build(force=False, verbose=True):
     if not force and not stale():
         return OUT
-    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', OUT] + SOURCES
+    # librccl is NOT linked: the communicator entry points (blhip_comm_*) dlopen it on first use
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', OUT] + SOURCES + ['-ldl']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=HERE)
+    for junk in glob.glob(OUT + '.*'):      # offload-bundle side files some hipcc versions leave behind
+        try:
+            os.remove(junk)
+        except OSError:
+            pass
     return OUT
 
 

@@ -235,6 +235,12 @@ class HipEngine:
     def carry_release(self, slot=-1):
         self._check(self.lib.blhip_carry_release(self.ctx, int(slot)))
 
+    def bandwidth_probe(self, nbytes=1 << 30, iterations=20):
+        """GB/s (read + write) of a streaming copy on this GPU: the calibrated roofline beside the 8 TB/s spec peak."""
+        out = C.c_double()
+        self._check(self.lib.blhip_bandwidth_probe(self.ctx, int(nbytes), int(iterations), C.byref(out)))
+        return out.value
+
     def last_timing(self):
         t = _abi.Timing()
         self._check(self.lib.blhip_last_timing(self.ctx, C.byref(t)))
@@ -270,17 +276,23 @@ class HipEngine:
             self._accum_owner = None
 
     # ---- average posterior of a hyper-study ----------------------------------------------------------------------
-    def accum_begin(self, T, G, external=None, owner=None):
-        """external: optional torch CUDA tensor of T*G float64 that backs the accumulator (for RCCL)."""
+    def accum_begin(self, T, G, owner=None):
+        """Starts the evidence-weighted average of a hyper-study in a library-owned (T, G) float64 buffer in HBM."""
         ref = getattr(self, '_accum_owner', None)
         prev = ref() if ref is not None else None
         if prev is not None and prev is not owner:
             self._accum_owner = None
             prev._materialize_posterior()       # the previous study's average posterior still lives in the accumulator
         self._accum_owner = None if owner is None else weakref.ref(owner)
-        self._accum_external = external
-        ptr = None if external is None else C.c_void_p(external.data_ptr())
-        self._check(self.lib.blhip_accum_begin(self.ctx, T, G, ptr))
+        self._check(self.lib.blhip_accum_begin(self.ctx, T, G, None))
+
+    def accum_row_stats(self, problem: FitProblem):
+        """(T, 1 + ndim) per-step sums [sum A, sum A grid_k] of the not yet finalised accumulator (relative to its
+        reference exponent): what a rank contributes to the merged normalisers / posterior means."""
+        cp, keep = self._problem(problem)
+        out = np.zeros((problem.T, 1 + len(problem.marginal)))
+        self._check(self.lib.blhip_accum_row_stats(self.ctx, C.byref(cp), _abi.dptr(out)))
+        return out
 
     def accum_log_ref(self):
         ref = C.c_double()
@@ -306,7 +318,6 @@ class HipEngine:
 
     def accum_end(self):
         self._check(self.lib.blhip_accum_end(self.ctx))
-        self._accum_external = None
 
     def synchronize(self):
         self._check(self.lib.blhip_synchronize(self.ctx))

@@ -6,6 +6,12 @@ bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json me
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
+Multi-GPU (one process per GPU, RCCL over xGMI through libblhip.so's blhip_comm_* entry points, no PyTorch in the process):
+  * under a launcher that exports RANK / LOCAL_RANK / WORLD_SIZE (the driver's ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py --gpus N``) every rank runs this file; WORLD_SIZE must equal --gpus;
+  * ``python bench.py --gpus N`` on its own starts the N ranks itself (one child process per GPU ordinal 0..N-1).
+Rank 0 prints the ONE JSON line; timing = barrier + device synchronise on both sides of the K timed steps, MAX over ranks.
+
 Workloads (synthetic data, seeds fixed):
   c4       HyperStudy, 512 x 512 Gaussian (mean, std) grid, GaussianRandomWalk on 'mean' with 512 sigma values
            cint(0, 0.3, 512), T = 256, FULL fit (forward + backward + evidence-weighted average posterior).
@@ -101,13 +107,36 @@ def make_study(bl, name, comm=None, scale=1.0):
     raise ValueError(name)
 
 
+
 def measured_traffic(key):
-    """HBM bytes per step launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), or None."""
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
-        return d[key].get('hbm_bytes_per_step_launch', d[key].get('hbm_bytes_per_launch'))
-    except Exception:
+    """HBM bytes per logical step launch from the committed rocprofv3 PMC passes (separate --pmc runs, tools/prof.sh), newest
+    round first; -> (bytes or None, source file or None).  bench.py does not run the profiler itself."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+            v = d[key].get('hbm_bytes_per_step_launch', d[key].get('hbm_bytes_per_launch'))
+            if v is not None:
+                return v, os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def golden_log_evidence(name):
+    """logEvidence of the REFERENCE for this exact workload (tests/golden/bench_<name>.npz, generated by importing the reference in
+    the build container: tests/golden/gen_bench_golden.py), or None."""
+    for cand in ('bench_' + name, 'bench_' + name.replace('_evidence', ''), name + '_full'):
+        f = os.path.join(ROOT, 'tests', 'golden', cand + '.npz')
+        if os.path.exists(f):
+            return float(np.load(f)['logEvidence'])
+    return None
+
+
+def rel_err(got, want):
+    if want is None:
         return None
+    return abs(got - want) / abs(want)
 
 
 def roofline_of(timing, cells_per_launch):
@@ -127,6 +156,7 @@ def roofline_of(timing, cells_per_launch):
     return out
 
 
+
 def run_workload(bl, name, steps, warmup, comm, barrier):
     S, kw, units, desc = make_study(bl, name, comm)
     for _ in range(warmup):
@@ -139,6 +169,21 @@ def run_workload(bl, name, steps, warmup, comm, barrier):
     barrier()
     dt = time.perf_counter() - t0
     return S, units, desc, dt
+
+
+def end_to_end(bl, S, kw, units):
+    """One more fit with everything the reference hands back materialised on the HOST (core.py:356, 408: posteriorSequence is a
+    host array there): fit + D2H of the (T, *gridSize) posterior sequence over PCIe.  Not part of `value`."""
+    eng = bl.get_engine()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    S.fit(**kw)
+    post = None if kw.get('evidenceOnly') else S.posteriorSequence
+    dt = time.perf_counter() - t0
+    nbytes = 0 if post is None else int(post.nbytes)
+    del post
+    return dict(ms=dt * 1e3, value=units / dt, unit='grid-cells*timesteps/s', d2h_bytes=nbytes,
+                includes='fit() + posteriorSequence copied to a pageable numpy array (PCIe)')
 
 
 def _cpu_share(args):
@@ -194,6 +239,24 @@ def cpu_baseline(nh=8, T=160, n=512, max_procs=16):
     return out
 
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU ordinal), pass rank 0's stdout through."""
+    import subprocess
+    import uuid
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), BLHIP_RDZV_KEY='bench_' + uuid.uuid4().hex, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -204,49 +267,35 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     os.environ.setdefault('BLHIP_DEVICE', str(local_rank))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
-    comm = None
-    dist = None
-    force_dist = os.environ.get('BLHIP_FORCE_DIST') == '1'      # exercise the RCCL path with a single rank (tests)
-    if force_dist and world == 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     import bayesloop_amd as bl
-    if world > 1 or force_dist:
-        comm = bl.dist.TorchCommunicator()
+    eng = bl.get_engine()
+    comm = None
+    if world > 1 or os.environ.get('BLHIP_FORCE_DIST') == '1':      # (the latter: the RCCL path with a single rank, tests)
+        comm = bl.dist.RcclCommunicator(eng, rank=rank, world=world)
 
     def barrier():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        eng.synchronize()
+        if comm is not None:
+            comm.barrier()
 
-    eng = bl.get_engine()
     for kv in os.environ.get('BLHIP_OPTS', '').split(','):      # tuning experiments: BLHIP_OPTS=key=value,key=value
         if '=' in kv:
             eng.set_option(kv.split('=')[0], float(kv.split('=')[1]))
+    peak_cal = eng.bandwidth_probe() if rank == 0 else None
     S, units, desc, dt = run_workload(bl, args.workload, args.steps, args.warmup, comm, barrier)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if comm is not None:
+        dt = comm.allreduce_max(dt)
     timing = dict(S.lastTiming)
-    S._posterior_pending = None      # results stay on the device; nothing is copied back
-    eng.release_posterior()
 
     out = None
     if rank == 0:
@@ -256,20 +305,33 @@ def main():
         dom = max(rf.values(), key=lambda r: r['avg_launch_us'] * r['launches']) if rf else None
         roof = None
         if dom:
-            traffic = None
+            traffic, src = None, None
             if args.workload == 'c4' and world == 1:
-                traffic = measured_traffic('bwd' if 'backward' in dom['kernel'] else 'fwd')
+                traffic, src = measured_traffic('bwd' if 'backward' in dom['kernel'] else 'fwd')
             elif args.workload == 'fwd2048':
-                traffic = measured_traffic('fwd2048')
+                traffic, src = measured_traffic('fwd2048')
             roof = dict(bound='hbm', achieved=dom['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=dom['achieved'] / HBM_PEAK_GBS, traffic=traffic, kernel=dom['kernel'],
+                        frac=dom['achieved'] / HBM_PEAK_GBS, traffic=traffic, traffic_from=src, kernel=dom['kernel'],
                         avg_launch_us=dom['avg_launch_us'], bytes_per_cell_step=dom['bytes_per_cell_step'],
-                        cells_per_launch=int(timing.get('cells_per_launch', 0)))
+                        cells_per_launch=int(timing.get('cells_per_launch', 0)),
+                        peak_calibrated=peak_cal, frac_calibrated=dom['achieved'] / peak_cal if peak_cal else None,
+                        peak_calibrated_from='blhip_bandwidth_probe: 16-B-per-lane streaming copy of 1 GiB, read + write')
+        gold = golden_log_evidence(args.workload)
         out = dict(metric='grid-cells*timesteps/sec (fit())', value=value, unit='grid-cells*timesteps/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling='strong', vs_baseline=None, dtype='f64', data='synthetic',
-                   config=dict(desc, parallelism='hyper-grid points sharded over %d GPU(s)' % world),
-                   log_evidence=float(S.logEvidence), roofline=roof, kernels=rf, device=eng.device_name())
+                   config=dict(desc, parallelism='hyper-grid points dealt round-robin to %d GPU(s), one RCCL gather + one reduce' % world),
+                   log_evidence=float(S.logEvidence), log_evidence_reference=gold,
+                   log_evidence_rel_err=rel_err(float(S.logEvidence), gold), roofline=roof, kernels=rf, device=eng.device_name())
+    if rank == 0 and world == 1:
+        kw = dict(silent=True, evidenceOnly=True) if args.workload in ('c4_evidence', 'fwd2048') else dict(silent=True)
+        try:
+            out['end_to_end'] = end_to_end(bl, S, kw, units)
+        except Exception as e:
+            out['end_to_end'] = dict(error=repr(e))
+    S._posterior_pending = None      # results stay on the device; nothing more is copied back
+    eng.release_posterior()
+    if rank == 0:
         if not args.no_extra and world == 1:
             extra = {}
             for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5'):
@@ -278,8 +340,12 @@ def main():
                 try:
                     S2, u2, d2, dt2 = run_workload(bl, name, 1, 1, None, lambda: None)
                     tm = dict(S2.lastTiming)
+                    g2 = golden_log_evidence(name)
                     extra[name] = dict(value=u2 / dt2, ms_per_step=dt2 * 1e3, log_evidence=float(S2.logEvidence),
+                                       log_evidence_reference=g2, log_evidence_rel_err=rel_err(float(S2.logEvidence), g2),
                                        config=d2, kernels=roofline_of(tm, tm.get('cells_per_launch', 0)))
+                    if name == 'c3':
+                        extra[name]['end_to_end'] = end_to_end(bl, S2, dict(silent=True), u2)
                     S2._posterior_pending = None
                     eng.release_posterior()
                     del S2
@@ -288,6 +354,7 @@ def main():
             out['extra'] = extra
         if not args.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline()
+
     def drain_c_stdio():
         try:
             import ctypes
@@ -295,16 +362,20 @@ def main():
         except Exception:
             pass
 
-    if dist is not None:
+    if comm is not None:
         drain_c_stdio()                          # every rank, before the barrier: nothing of theirs can follow rank 0's line
-        dist.barrier()
-        dist.destroy_process_group()
+        comm.barrier()
+        comm.close()
     # RCCL prints a version banner through C stdio; on a pipe it sits in libc's buffer until exit, i.e. AFTER anything
     # Python printed.  Drain it first so that the JSON line really is the last line on stdout.
     drain_c_stdio()
     if rank == 0:
+        bad = [k for k, v in [(args.workload, out)] + list(out.get('extra', {}).items())
+               if isinstance(v, dict) and v.get('log_evidence_rel_err') is not None and v['log_evidence_rel_err'] > 1e-9]
         sys.stdout.flush()
         print(json.dumps(out), flush=True)       # the ONE JSON line, last on stdout
+        if bad:
+            sys.exit('bench.py: log-evidence differs from the reference by more than 1e-9 relative: %s' % bad)
 
 
 if __name__ == '__main__':

@@ -11,6 +11,8 @@
  *   blhip_accum_*        the evidence-weighted average    bayesloop/core.py:1295, 1362-1366, 1339, 1375-1382, 1416-1419
  *   blhip_posterior_*    the posteriorSequence attribute  bayesloop/core.py:356, 408, 436-441
  *   blhip_carry_*        OnlineStudy.step                 bayesloop/core.py:2062-2226 (with BLHIP_RESUME / BLHIP_CARRY fits)
+ *   blhip_comm_*         HyperStudy.fit(nJobs > 1):       bayesloop/core.py:1307-1340 (pool.map fan-out and the merge of the
+ *                        sub-studies), _parallelFit       bayesloop/core.py:1443-1495 -- one process per GPU, RCCL over xGMI
  *
  * inside which the library evaluates
  *   ObservationModel.processedPdf + Poisson/Gaussian/GaussianMean.pdf   observationModels.py:35-56, 502, 566-567, 705-706
@@ -39,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BLHIP_ABI_VERSION 3
+#define BLHIP_ABI_VERSION 4
 
 typedef struct blhip_ctx blhip_ctx;
 
@@ -176,6 +178,10 @@ int blhip_fit(blhip_ctx *ctx, const blhip_problem *problem, int64_t n_chains, co
 
 int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out);
 
+/* Calibration of the attainable HBM rate on THIS device ("calibrate the attainable peak on the box"): a 16-B-per-
+ * lane streaming copy of `bytes` (read + write counted), `iterations` launches timed with HIP events -> GB/s. */
+int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double *gb_per_s);
+
 /* ---- posterior sequence of the last blhip_fit(..., BLHIP_KEEP_POSTERIOR) ---------------------------------------- */
 /* Copies the normalised posteriors of steps [t0, t1) of one chain to host memory ((t1-t0) * G doubles). */
 int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, double *host_out);
@@ -206,6 +212,34 @@ int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref);
 int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *problem, double *posterior_mean);
 int blhip_accum_read(blhip_ctx *ctx, int64_t t0, int64_t t1, double *host_out);
 int blhip_accum_end(blhip_ctx *ctx);
+/* Per-step sums of the (not yet finalised) accumulator, relative to its current reference exponent:
+ * host_out (T, 1 + ndim) = [sum A, sum A grid_0, (sum A grid_1)] per step.  Sums of several ranks, each scaled by
+ * exp(log_ref_rank - max log_ref), add up to the normalisers / posterior means of the merged average (core.py:1379-1382,
+ * 1416-1419), so every rank can form them from ONE gather.  All zeros if nothing was folded. */
+int blhip_accum_row_stats(blhip_ctx *ctx, const blhip_problem *problem, double *host_out);
+
+/* ---- multi-GPU exchange of a sharded hyper-study (HyperStudy.fit(nJobs > 1), core.py:1307-1340, 1443-1495) -------------
+ * One process per GPU, one context per process; each rank fits its share of the hyper-grid points with blhip_fit and
+ * no communication, then the ranks exchange results through RCCL (xGMI inside a node), which this library binds
+ * directly: librccl.so.1 is dlopen'ed by the first blhip_comm_* call (override the path with BLHIP_RCCL_LIBRARY).
+ *   rank 0:      blhip_comm_unique_id(id)  ->  the caller hands the 128 bytes to the other ranks (file, socket, ...)
+ *   every rank:  blhip_comm_init(ctx, id, world, rank)                      (collective; ncclCommInitRank on ctx's device)
+ *   after the fits, the ONE exchange:
+ *                blhip_comm_allgather   packed rows [logEvidence | localEvidence (T) | abort step] per chain + a trailer
+ *                                       [accumulator log_ref | row stats], `count` doubles per rank, host in / host out
+ *                                       (staged through HBM; host_out is (world, count) in rank order)     core.py:1335-1337
+ *                blhip_comm_reduce_accum  only when posteriors are wanted, after blhip_accum_rescale(max log_ref):
+ *                                       ncclReduce(sum) of the (T, G) accumulators to `root`, in place       core.py:1338-1340
+ *   blhip_comm_allreduce: small host vectors (barriers, max-over-ranks timing of bench.py). */
+#define BLHIP_UNIQUE_ID_BYTES 128
+enum { BLHIP_SUM = 0, BLHIP_MAX = 1, BLHIP_MIN = 2 };
+int blhip_comm_unique_id(void *id_out /* BLHIP_UNIQUE_ID_BYTES */);      /* errors: blhip_last_error(NULL) */
+int blhip_comm_init(blhip_ctx *ctx, const void *unique_id, int world, int rank);
+int blhip_comm_info(blhip_ctx *ctx, int *world, int *rank, int *rccl_version);   /* world = 1 without a communicator */
+int blhip_comm_allgather(blhip_ctx *ctx, const double *host_in, int64_t count, double *host_out);
+int blhip_comm_allreduce(blhip_ctx *ctx, double *host_inout, int64_t count, int op);
+int blhip_comm_reduce_accum(blhip_ctx *ctx, int root);
+int blhip_comm_destroy(blhip_ctx *ctx);
 
 /* ---- carried states (OnlineStudy.step, core.py:2062-2226) ------------------------------------------------------------
  * A blhip_fit with BLHIP_CARRY leaves every chain's normalised filtered distribution of its last step in slot

@@ -29,7 +29,6 @@ class OracleEngine:
         self._post = None
         self._posterior_owner = None
         self.acc_log = None
-        self.acc_ext = None
         self.acc_lin = None
         self.fits = 0
         self._carry = {}
@@ -161,7 +160,7 @@ class OracleEngine:
         return {}
 
     # ---- accumulator (log space inside, linear space for the cross-rank merge) -----------------------------------
-    def accum_begin(self, T, G, external=None, owner=None):
+    def accum_begin(self, T, G, owner=None):
         prev = getattr(self, '_accum_owner', None)          # as HipEngine.accum_begin: the previous study's average posterior
         if prev is not None and prev is not owner:          # still lives in the accumulator that is about to be reused
             self._accum_owner = None
@@ -169,8 +168,20 @@ class OracleEngine:
         self._accum_owner = owner
         self.acc_shape = (T, G)
         self.acc_log = np.zeros((T, G)) - np.inf
-        self.acc_ext = external
         self.acc_lin = None
+
+    def accum_row_stats(self, problem):
+        """as HipEngine.accum_row_stats: per-step sums of exp(acc_log - own reference exponent)"""
+        T, G = self.acc_shape
+        g = orc.Grid(problem.marginal)
+        out = np.zeros((T, 1 + len(g.size)))
+        ref = np.amax(self.acc_log)
+        if np.isfinite(ref):
+            lin = np.exp(self.acc_log - ref)
+            out[:, 0] = lin.sum(axis=1)
+            for k in range(len(g.size)):
+                out[:, 1 + k] = lin @ g.grid[k].ravel()
+        return out
 
     def _acc3(self, problem):
         return [problem.T] + list(problem.grid_size)
@@ -182,12 +193,7 @@ class OracleEngine:
         return float(np.amax(self.acc_log)), 0
 
     def accum_rescale(self, new_log_ref):
-        lin = np.exp(self.acc_log - new_log_ref)
-        if self.acc_ext is not None:
-            self.acc_ext.numpy()[:] = lin.ravel()
-            self.acc_lin = self.acc_ext.numpy()
-        else:
-            self.acc_lin = lin.ravel()
+        self.acc_lin = np.ascontiguousarray(np.exp(self.acc_log - new_log_ref).ravel())
 
     def accum_finalize(self, problem):
         T, G = self.acc_shape

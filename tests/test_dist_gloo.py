@@ -1,5 +1,6 @@
-"""The multi-rank HyperStudy path (bayesloop_amd.dist) with world_size 2 over gloo on CPU: sharded chunks, the single
-gather and the accumulator merge must reproduce the unsharded golden result."""
+"""The multi-rank HyperStudy path (bayesloop_amd.dist.sharded_hyper_fit) with world_size 2 and 3 on CPU: round-robin shares, the
+single gather (rows + accumulator trailer) and the accumulator merge must reproduce the unsharded golden result.  Transport:
+tests/gloo_comm.py (gloo, host arrays) + the oracle engine; the product transport (RCCL through the C-ABI) runs in the -m gpu tests."""
 import os
 import socket
 import subprocess
@@ -20,10 +21,11 @@ WORKER = textwrap.dedent('''
     import bayesloop_amd as bl
     import cases, compare, oracle_adapter as oa
     from oracle_engine import OracleEngine
+    from gloo_comm import GlooCommunicator
     bl.set_engine(OracleEngine())
     for case in %(cases)r:
         S = cases.build(bl, case)
-        S.communicator = bl.dist.TorchCommunicator()
+        S.communicator = GlooCommunicator()
         with np.errstate(all='ignore'):
             S.fit(**cases.fit_kwargs(case))
         gold = oa.load_golden(case)
@@ -38,6 +40,9 @@ WORKER = textwrap.dedent('''
                 gold = {k: v for k, v in gold.items() if not k.startswith('posteriorS') and not k.startswith('posteriorR')
                         and not k.startswith('marginalS')}
         compare.check(res, gold, dict(compare.ORACLE_TOL, post_rtol=1e-10, small_rtol=1e-10))
+        kinds = [k for k, _ in S.communicator.collectives]
+        evid = bool(cases.CASES[case].get('fit', {}).get('evidenceOnly'))
+        assert kinds == (['all_gather'] if evid else ['all_gather', 'reduce']), kinds      # ONE gather (+ ONE reduce)
         n = bl.get_engine().fits
         print('rank', dist.get_rank(), case, 'ok; chains fitted on this rank so far:', n)
     dist.barrier()
@@ -97,6 +102,7 @@ RANDOM_WORKER = textwrap.dedent('''
     import bayesloop_amd as bl
     import cases, compare, oracle_adapter as oa, random_cases
     from oracle_engine import OracleEngine
+    from gloo_comm import GlooCommunicator
     bl.set_engine(OracleEngine())
     done = 0
     for seed in range(%(seeds)d):
@@ -105,7 +111,7 @@ RANDOM_WORKER = textwrap.dedent('''
             if c['study'] == 'Study':
                 continue
             S = cases.build(bl, c)
-            S.communicator = bl.dist.TorchCommunicator()
+            S.communicator = GlooCommunicator()
             with np.errstate(all='ignore'):
                 S.fit(**cases.fit_kwargs(c))
                 want = oa.run(c)

@@ -320,8 +320,9 @@ def test_linearity_of_transition_filter_only():
 
 
 def test_rccl_path_single_rank():
-    """The multi-GPU code path (torch.distributed 'nccl' = RCCL, accumulator in a torch CUDA tensor handed to libblhip,
-    gather + reduce) with one rank must reproduce the plain single-GPU result."""
+    """The multi-GPU code path -- RCCL bound directly through the C-ABI (blhip_comm_*: unique id, ncclCommInitRank, ONE
+    ncclAllGather of rows + trailer, ncclReduce of the accumulator in HBM), no PyTorch in the process -- with one rank must
+    reproduce the plain single-GPU result; the small collectives bench.py times with are exercised too."""
     import os
     import subprocess
     import sys
@@ -330,14 +331,16 @@ def test_rccl_path_single_rank():
     code = textwrap.dedent('''
         import os, sys, numpy as np
         sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
-        import torch, torch.distributed as dist
-        torch.cuda.set_device(0)
-        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1,
-                                device_id=torch.device('cuda', 0))
         import bayesloop_amd as bl, cases, compare, oracle_adapter as oa
+        comm = bl.dist.RcclCommunicator(rank=0, world=1)
+        info = comm.info()
+        assert info['world'] == 1 and info['rank'] == 0 and info['rccl_version'] > 0, info
+        assert comm.allreduce_max(3.5) == 3.5 and list(comm.allreduce([1.0, 2.0])) == [1.0, 2.0]
+        g = comm.all_gather(np.arange(7.0))
+        assert len(g) == 1 and np.array_equal(g[0], np.arange(7.0))
         for case in ('c4_small', 'c5_cp_grw', 'c4_small_evidence'):
             S = cases.build(bl, case)
-            S.communicator = bl.dist.TorchCommunicator()
+            S.communicator = comm
             S.fit(**cases.fit_kwargs(case))
             res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence, logEvidenceList=np.array(S.logEvidenceList),
                        hyperParameterDistribution=S.hyperParameterDistribution)
@@ -345,12 +348,53 @@ def test_rccl_path_single_rank():
                 res.update(posteriorSequence=S.posteriorSequence, posteriorMeanValues=S.posteriorMeanValues)
             compare.check(res, oa.load_golden(case), compare.GPU_TOL)
             print('ok', case)
-        dist.destroy_process_group()
+        comm.barrier()
+        comm.close()
+        assert 'torch' not in sys.modules
+        print('rccl', info['rccl_version'])
     ''') % (root, root)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('ok ') == 3, out.stdout + out.stderr
+
+
+def test_accumulator_row_stats_give_the_merged_means():
+    """blhip_accum_row_stats (what a rank contributes to the ONE gather): per-step sums of the un-finalised accumulator reproduce
+    the posterior means blhip_accum_finalize computes from the same accumulator."""
+    from bayesloop_amd import dist as bdist
+    eng = bl.get_engine()
+    S = cases.build(bl, 'c4_small')
+    S._formatData(); S._createHyperGrid(silent=True); S._checkConsistency()
+    S._setAllHyperParameters(S.hyperGridValues[0])
+    problem, program = S._compile(silent=True)
+    S._setAllHyperParameters(S.flatHyperParameters)
+    ov = S._opValueMatrix(program, np.asarray(S.hyperGridValues, dtype=float))
+    eng.accum_begin(problem.T, problem.G)
+    eng.fit(problem, ov, accumulate=True, log_chain_weight=np.log(np.asarray(S.flatHyperPriorValues, dtype=float)))
+    st = eng.accum_row_stats(problem)
+    means = eng.accum_finalize(problem)
+    np.testing.assert_allclose((st[:, 1:] / st[:, :1]).T, means, rtol=1e-12)
+    eng.accum_end()
+
+
+@pytest.mark.parametrize('name', ['fwd2048', 'c3', 'c4', 'c5'])
+def test_bench_workloads_against_full_size_reference(name):
+    """The workloads bench.py times, at FULL size, evidence-only, against the reference run at the same size
+    (tests/golden/bench_*.npz from tests/golden/gen_bench_golden.py): logEvidence, forward localEvidence, per-point
+    logEvidenceList and the hyper-parameter distribution at 1e-9."""
+    import bench
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_%s.npz' % name))
+    S, kw, units, desc = bench.make_study(bl, name)
+    S.fit(silent=True, evidenceOnly=True)
+    assert np.array_equal(np.asarray(S.rawData, dtype=float), gold['rawData'])
+    assert abs(S.logEvidence - float(gold['logEvidence'])) <= 1e-9 * abs(float(gold['logEvidence']))
+    np.testing.assert_allclose(S.localEvidence, gold['localEvidence'], rtol=1e-9, atol=0)
+    if 'logEvidenceList' in gold.files:
+        np.testing.assert_allclose(np.asarray(S.logEvidenceList), gold['logEvidenceList'], rtol=1e-9, atol=0)
+        np.testing.assert_allclose(S.hyperParameterDistribution, gold['hyperParameterDistribution'], rtol=1e-6, atol=1e-300)
+    S._posterior_pending = None
+    bl.get_engine().release_posterior()
 
 
 # ---- BASELINE.json grid sizes, short series: direct comparison with the oracle ---------------------------------------
