@@ -98,6 +98,7 @@ PROTOTYPES = {
     'blhip_comm_destroy': (C.c_int, [C.c_void_p]),
     'blhip_carry_mix': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, C.c_int]),
     'blhip_carry_read': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p]),
+    'blhip_carry_write': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]),
     'blhip_carry_release': (C.c_int, [C.c_void_p, C.c_int]),
 }
 

@@ -57,17 +57,28 @@ def _plots(kind):
     def wrap(fn):
         import functools
 
+        import inspect
+        sig = inspect.signature(fn)
+        own = [n for n, q in sig.parameters.items() if q.kind in (q.POSITIONAL_OR_KEYWORD, q.KEYWORD_ONLY)]
+
         @functools.wraps(fn)
         def accessor(self, *args, **kwargs):
-            plot = kwargs.pop('plot', False)
-            figure, subplot = kwargs.pop('figure', None), kwargs.pop('subplot', 111)
-            density = kwargs.get('density', True)
-            style = {k: kwargs.pop(k) for k in list(kwargs) if k not in ('density', 'local')}
-            out = fn(self, *args, **kwargs)
+            # the accessor's own parameters (t, name, names, density, ...) may arrive by keyword, as in the reference; only
+            # what is left over is matplotlib styling
+            style = {k: kwargs.pop(k) for k in list(kwargs) if k not in own}
+            bound = sig.bind(self, *args, **kwargs)
+            bound.apply_defaults()
+            a = bound.arguments
+            plot = a.get('plot', False)
+            figure, subplot = a.get('figure', None), a.get('subplot', 111)
+            density = a.get('density', True)
+            call = {k: v for k, v in a.items() if k not in ('self', 'kwargs')}
+            call['plot'] = False
+            out = fn(self, **call)
             if not plot:
                 return out
             from . import plotting
-            name = kwargs.get('name', kwargs.get('names', args[-1] if args else None))
+            name = a.get('name', a.get('names'))
             if kind == 'param_dist':
                 plotting.distribution(out[0], out[1], name, density=density, **style)
             elif kind == 'param_dists':
@@ -502,6 +513,14 @@ class Study(object):
         eng = _engine_mod.get_engine()
         T = len(self.formattedData)
         keep = not evidenceOnly
+        if self._posterior_pending is not None:
+            # the device buffer behind the previous fit's posterior is about to be reused.  A fit that stores a new sequence
+            # replaces it anyway; an evidence-only fit leaves the previous posteriorSequence in place in the reference
+            # (core.py:355-356 allocates only `if not evidenceOnly`), so it is brought to the host first.
+            if keep:
+                self._posterior_pending = None
+            else:
+                self._materialize_posterior()
         res = eng.fit(problem, self._opValueMatrix(program), forward_only=forwardOnly, evidence_only=evidenceOnly,
                       keep_posterior=keep, owner=self)
         self.lastTiming = res.timing
@@ -513,6 +532,8 @@ class Study(object):
             self.logEvidence = -np.inf
             if keep:
                 eng.release_posterior(self)
+                self._posterior_pending = None       # (the reference leaves np.empty garbage here; nothing is exposed)
+                self._posteriorSequence = None
             return
         if not silent:
             print('    + Finished forward pass.')
@@ -1047,10 +1068,35 @@ class OnlineStudy(HyperStudy):
     def __del__(self):
         try:
             eng = _engine_mod.get_engine()
-            for s in self._slots:
+            for s in self._slots:          # (every instance allocates its own slots: a copy never shares them)
                 eng.carry_release(s)
         except Exception:
             pass
+
+    # The carried per-chain filter states live in the engine's context, not in the object: a pickled copy takes them along
+    # as host arrays and re-creates them in slots of its own, so that `bl.save` / `bl.load` / `copy.deepcopy` of an
+    # OnlineStudy can go on stepping (reference fileIO.py:10-37 pickles the whole study, parameterPosterior included).
+    def __getstate__(self):
+        state = Study.__getstate__(self)
+        carried = None
+        if not self.firstStep and self._slots:
+            eng = _engine_mod.get_engine()
+            carried = [np.array([eng.carry_read(s, j, self.gridSize) for j in range(c)])
+                       for s, c in zip(self._slots, self.tmCounts)]
+        state['_carried'] = carried
+        state['_slots'] = []
+        return state
+
+    def __setstate__(self, state):
+        carried = state.pop('_carried', None)
+        self.__dict__.update(state)
+        self._slots = []
+        if carried is not None:
+            eng = _engine_mod.get_engine()
+            for st in carried:
+                OnlineStudy._slot_counter[0] += 1
+                self._slots.append(OnlineStudy._slot_counter[0])
+                eng.carry_write(self._slots[-1], st)
 
     # ---- configuration (reference core.py:2007-2060) -------------------------------------------------------------------
     def addTransitionModel(self, name, transitionModel):

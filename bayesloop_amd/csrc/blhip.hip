@@ -23,6 +23,7 @@
 #include "blhip_mfma.hpp"
 #include "blhip_fused1d.hpp"
 #include "blhip_persist1d.hpp"
+#include "blhip_resident.hpp"
 
 using namespace blk;
 
@@ -399,6 +400,47 @@ void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, si
         default: fail("fused 1-D path: observation model %d", om);
     }
     HIPCHECK(hipGetLastError());
+}
+
+// ---- time-resident path (blhip_resident.hpp): one launch for all time steps of a single-chain 2-D fit ----------------------------
+struct ResidentPlan {
+    int TR = 0, TC = 0, SEG = 0, tr = 0, tc = 0, ntiles = 0, NT = 0;
+    size_t lds_bytes = 0;
+};
+
+template <int TR, int TC, int SEG>
+void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, size_t lds) {
+    if (bwd) {
+        static bool a = false;
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, true>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+    } else {
+        static bool a = false;
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, false>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+    }
+}
+
+void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
+    if (rp.TR == 128) launch_resident_t<128, 128, 32>(s, Q, bwd, rp.lds_bytes);
+    else if (rp.TR == 64) launch_resident_t<64, 64, 8>(s, Q, bwd, rp.lds_bytes);
+    else launch_resident_t<32, 32, 8>(s, Q, bwd, rp.lds_bytes);
+    HIPCHECK(hipGetLastError());
+}
+
+// the smallest supported tile whose tile grid fits the chip (every tile = one co-resident block)
+bool plan_resident(int n0, int n1, int max_tiles, ResidentPlan &rp) {
+    const int shapes[3][3] = {{32, 32, 8}, {64, 64, 8}, {128, 128, 32}};
+    for (const auto &sh : shapes) {
+        if (n0 % sh[0] || n1 % sh[1]) continue;
+        const long long nt = (long long)(n0 / sh[0]) * (n1 / sh[1]);
+        if (nt > max_tiles) continue;
+        rp.TR = sh[0]; rp.TC = sh[1]; rp.SEG = sh[2]; rp.tr = n0 / sh[0]; rp.tc = n1 / sh[1]; rp.ntiles = (int)nt;
+        rp.NT = sh[0] * sh[1] / sh[2];
+        rp.lds_bytes = (size_t)((size_t)sh[0] * (sh[1] + 1) + sh[0] + 8 + 5 * (rp.NT / 64 + 1) + 8) * sizeof(double);
+        return true;
+    }
+    return false;
 }
 
 void validate(const blhip_problem *p, int64_t n_chains, const double *op_values) {
@@ -974,7 +1016,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         tr.mark("buckets + metadata H2D");
         // --- state ---
-        const size_t psz = (size_t)T * B * NRED * tile.nblk;
+        size_t psz = (size_t)T * B * NRED * tile.nblk;
         ctx->psumF.ensure(psz * 8);
         ctx->redF.ensure((size_t)T * B * NRED * 8);
         double *d_psF = ctx->psumF.as<double>();
@@ -1032,6 +1074,62 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             FP.step0 = step;
             FP.use_rec = (p->obs_model == BLHIP_OM_GAUSSIAN && dev <= 8.0 * 2.3e-16 * mx && ctx->option("recurrence", 1.0) != 0.0) ? 1 : 0;
         }
+        // ---- time-resident path: one launch per pass instead of one per step (blhip_resident.hpp) ------------------------------------
+        ResidentPlan rp;
+        bool resident = false;
+        double res_w0[blr::R + 1] = {1.0}, res_w1[blr::R + 1] = {1.0};
+        if (fast && n_chains == 1 && p->obs_model == BLHIP_OM_GAUSSIAN && FP.use_rec && !resume && !carry && d <= blr::DMAX &&
+            prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
+            plan_resident(g.n0, g.n1, std::min(ctx->num_cus, 256), rp)) {
+            resident = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
+            const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
+            for (int64_t t = 1; t < T && resident; ++t)
+                resident = prog.kindF[t] == SRC_PREV && prog.tapF0[t] == k0 && prog.tapF1[t] == k1;
+            for (int64_t t = 0; t < T - 1 && resident && full; ++t)
+                resident = prog.kindB[t] == SRC_PREV && prog.tapB0[t] == k0 && prog.tapB1[t] == k1;
+            if (resident) {
+                for (int k = 1; k <= blr::R; ++k) res_w0[k] = res_w1[k] = 0.0;
+                if (k0 >= 0) for (int k = 0; k <= taps.lw[k0]; ++k) res_w0[k] = taps.w[taps.off[k0] + k];
+                if (k1 >= 0) for (int k = 0; k <= taps.lw[k1]; ++k) res_w1[k] = taps.w[taps.off[k1] + k];
+            }
+        }
+        blr::ResParams RQ{};
+        int res_nblk = 0;
+        unsigned *d_res_abort = nullptr;
+        size_t res_flag_bytes = 0;
+        if (resident) {
+            const size_t nt = (size_t)rp.ntiles;
+            const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
+            const size_t b_w = carve_size(2 * (blr::R + 1) * 8);
+            res_flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 2 * 8) + carve_size(64);
+            ctx->resx.ensure(b_cols + b_rows + b_w + res_flag_bytes);
+            char *rc = ctx->resx.as<char>();
+            RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
+            RQ.rows = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TC);
+            double *d_w = carve<double>(rc, 2 * (blr::R + 1));
+            RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
+            RQ.flagR = carve<unsigned>(rc, nt);
+            RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 2);
+            d_res_abort = carve<unsigned>(rc, 16);
+            RQ.abort_word = d_res_abort;
+            double hw[2 * (blr::R + 1)];
+            for (int k = 0; k <= blr::R; ++k) { hw[k] = res_w0[k]; hw[blr::R + 1 + k] = res_w1[k]; }
+            HIPCHECK(hipMemcpyAsync(d_w, hw, sizeof hw, hipMemcpyHostToDevice, st));
+            sync_stream(ctx, st);
+            RQ.w0 = d_w; RQ.w1 = d_w + blr::R + 1;
+            RQ.n0 = g.n0; RQ.n1 = g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = d; RQ.rec_len = rec_len;
+            RQ.lag = std::max(1, std::min(blr::MAXLAG, (int)ctx->option("resident_lag", 2.0)));
+            RQ.m0 = d_m0; RQ.m1 = d_m1; RQ.colA = d_colA; RQ.colB = d_colB; RQ.rec = d_rec; RQ.step0 = FP.step0;
+            RQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
+            // partial-sum slots per step: one per tile (the launch-per-step kernels are the fall-back and keep theirs)
+            res_nblk = rp.ntiles;
+            psz = std::max(psz, (size_t)T * NRED * res_nblk);
+            ctx->psumF.ensure(psz * 8);
+            d_psF = ctx->psumF.as<double>();
+        }
+        std::vector<double> rowsumF;                          // resident forward pass: the actual sums of the stored rows
+        bool resident_failed = false;
+
         // bucket streams: fork = every bucket stream waits for the main stream; join = the main stream waits for all of them
         // (only worth it when a step really has several launches: a launch on a secondary stream costs ~9 us more
         //  than a back-to-back launch on the main stream -- measured on single-chain fits)
@@ -1159,8 +1257,28 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 launch_fused1d(st, p->obs_model, Q, false, f1_lds(Q.K));
             }
         }
+        const bool res_now = resident && !resident_failed;
+        const int nblk_now = res_now ? res_nblk : tile.nblk;      // partial-sum slots per (step, sum) of this pass
+        auto resident_launch = [&](bool bwd, double *psum) {
+            blr::ResParams Q = RQ;
+            HIPCHECK(hipMemsetAsync(RQ.flagC, 0, res_flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
+            HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * NRED * res_nblk * 8, st));
+            Q.psum = psum;
+            if (bwd) { Q.src0 = d_uniform; Q.post = d_post; Q.store = 1; Q.means = 1; }
+            else { Q.src0 = d_prior; Q.post = evidence_only ? nullptr : d_post; Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0; }
+            launch_resident(st, rp, Q, bwd);
+        };
+        // did a tile time out waiting for a neighbour (not every block co-resident)?  -> this context stops using the path
+        auto resident_gave_up = [&]() {
+            unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
+            HIPCHECK(hipMemcpyAsync(h, d_res_abort, 4, hipMemcpyDeviceToHost, st));
+            sync_stream(ctx, st);
+            if (*h != 0u) { ctx->resident_ok = false; return true; }
+            return false;
+        };
+        if (res_now) { ctx->pinS.ensure(64); resident_launch(false, d_psF); }
         fork_streams();
-        for (int64_t t = 0; t < T && !persist && !fused1d; ++t) {
+        for (int64_t t = 0; t < T && !persist && !fused1d && !res_now; ++t) {
             if (multistream && t > 0 && !same_membership(orderF, rangesF, t - 1, t)) { join_streams(); fork_streams(); }
             const double *srcp; double *dstp; long long sstr, dstr;
             if (evidence_only) {
@@ -1178,7 +1296,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         HIPCHECK(hipEventRecord(ev[1], st));
         if (!persist)
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
-                               ctx->redF.as<double>(), tile.nblk, NRED);
+                               ctx->redF.as<double>(), nblk_now, NRED);
         ctx->pinF.ensure((size_t)T * B * NRED * 8);
         redF = ctx->pinF.as<double>();
         HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
@@ -1188,6 +1306,25 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         ctx->timing.forward_ms += ms;
         ctx->timing.forward_launches += T;
         if (n_mfma[0] > 0 && n_mfma[0] >= n_fast[0]) ctx->timing.fwd_kernel_variant = 3;
+        if (res_now) {
+            ctx->timing.fwd_kernel_variant = 5;
+            if (resident_gave_up()) { resident_failed = true; return false; }
+            // Undo the lagged scale (blhip_resident.hpp): the kernel's step k divided by the sum of step k - lag, so its row sums
+            // are S_k; the reference's normaliser is norm_k = S_k / (S_{k-1} s_k), s_k = k >= lag ? 1 / S_{k-lag} : 1.  The
+            // sums of the step are rewritten to what the launch-per-step kernels (lag 1) would have reported; S_k stays the
+            // normaliser of the stored row.  A sum near the bottom of the fp64 range (a run of extreme outliers times the lag)
+            // falls back to the launch-per-step kernels, whose magnitudes are the reference's.
+            rowsumF.assign(T, 0.0);
+            for (int64_t t = 0; t < T; ++t) rowsumF[t] = redF[(size_t)t * NRED];
+            for (int64_t t = 0; t < T; ++t) {
+                const double St = rowsumF[t];
+                if (!(St > 1e-150 && St < 1e150)) { resident_failed = true; return false; }
+                const double sk = t >= RQ.lag ? 1.0 / rowsumF[t - RQ.lag] : 1.0;
+                const double norm = t == 0 ? St : St / (rowsumF[t - 1] * sk);
+                double *r = &redF[(size_t)t * NRED];
+                r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
+            }
+        }
 
         // --- evidence bookkeeping on the host, in the reference's order (core.py:385-404, 417) ---
         logE.assign(B, 0.0);
@@ -1249,8 +1386,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     launch_fused1d(st, p->obs_model, Q, true, f1_lds(Q.K));
                 }
             }
+            if (res_now) resident_launch(true, d_psB);
             fork_streams();
-            for (int64_t t = T - 1; t >= 0 && !persist && !fused1d; --t) {
+            for (int64_t t = T - 1; t >= 0 && !persist && !fused1d && !res_now; --t) {
                 if (multistream && t < T - 1 && !same_membership(orderB, rangesB, t + 1, t)) { join_streams(); fork_streams(); }
                 // reads c_{t+1} and the stored alpha_t, writes c_t and posterior_t
                 run_step(MODE_BWD, t, d_pp[(t + 1) & 1], G, d_pp[t & 1], G, d_post + (size_t)t * G, (long long)T * G,
@@ -1261,7 +1399,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             HIPCHECK(hipEventRecord(ev[3], st));
             if (!persist)
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
-                                   ctx->redB.as<double>(), tile.nblk, NRED);
+                                   ctx->redB.as<double>(), nblk_now, NRED);
             ctx->pinB.ensure((size_t)T * B * NRED * 8);
             redB = ctx->pinB.as<double>();
             HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
@@ -1270,6 +1408,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->timing.backward_ms += ms;
             if (n_mfma[1] > 0 && n_mfma[1] >= n_fast[1]) ctx->timing.bwd_kernel_variant = 3;
             ctx->timing.backward_launches += T;
+            if (res_now) {
+                ctx->timing.bwd_kernel_variant = 5;
+                if (resident_gave_up()) { resident_failed = true; return false; }
+                for (int64_t t = 0; t < T; ++t) {             // (the lagged scale of the backward state: same range guard)
+                    const double Ct = redB[(size_t)t * NRED + 2], Nt = redB[(size_t)t * NRED];
+                    if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) { resident_failed = true; return false; }
+                }
+            }
             for (int64_t b = 0; b < B; ++b) {
                 if (abort_step[b] >= 0) continue;
                 for (int64_t t = T - 1; t >= 0; --t) {
@@ -1290,7 +1436,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
                 for (int64_t t = 0; t < T; ++t) {
-                    const double n0 = redF[((size_t)t * B + b) * NRED];
+                    const double n0 = res_now ? rowsumF[t] : redF[((size_t)t * B + b) * NRED];
                     invN[(size_t)b * T + t] = (n0 != 0.0 && std::isfinite(n0)) ? 1.0 / n0 : 0.0;     // (a signed kernel can leave a negative raw sum)
                 }
         }
@@ -1299,7 +1445,15 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         };
         tr.mark("passes");
         int64_t usedK = fusedK;
-        if (!passes(fusedK)) { usedK = 1; passes(1); }
+        if (!passes(fusedK)) {
+            if (resident_failed) {                   // the launch-per-step kernels take over (timing of the failed attempt is dropped)
+                ctx->timing.forward_ms = ctx->timing.backward_ms = 0.0;
+                ctx->timing.forward_launches = ctx->timing.backward_launches = 0;
+                ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = 1;
+                n_mfma[0] = n_mfma[1] = n_fast[0] = n_fast[1] = 0;
+                if (!passes(fusedK)) fail("internal: the launch-per-step pass failed after the resident pass gave up");
+            } else { usedK = 1; passes(1); }
+        }
 
         // --- BLHIP_CARRY: keep every chain's filtered distribution of the last step, normalised (core.py:2173) ---
         if (carry) {
@@ -1426,6 +1580,7 @@ blhip_ctx *blhip_create(int device) {
         HIPCHECK(hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming));
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, device));
+        ctx->num_cus = prop.multiProcessorCount;
         std::string marketing = prop.name;
         if (marketing.find_first_not_of(' ') == std::string::npos) marketing = "AMD Instinct (name not reported by the driver)";
         ctx->name = marketing + " (" + prop.gcnArchName + ")";
@@ -1444,7 +1599,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release();
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
                       &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit, &ctx->databuf, &ctx->postinv})
         b->release();
@@ -1497,18 +1652,24 @@ int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double 
         DevBuf a, b;
         a.ensure((size_t)n2 * 16); b.ensure((size_t)n2 * 16);
         hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, a.as<double>(), n2 * 2, 1.0);
-        const unsigned gx = (unsigned)std::min<long long>((n2 + NTHREADS - 1) / NTHREADS, 256LL * 32);
-        hipLaunchKernelGGL(copy16_kernel, dim3(gx), dim3(NTHREADS), 0, st, a.as<double2>(), b.as<double2>(), n2);   // warm-up
-        HIPCHECK(hipEventRecord(ctx->ev[4], st));
-        for (int k = 0; k < iterations; ++k)
-            hipLaunchKernelGGL(copy16_kernel, dim3(gx), dim3(NTHREADS), 0, st, (k & 1) ? b.as<double2>() : a.as<double2>(),
-                               (k & 1) ? a.as<double2>() : b.as<double2>(), n2);
-        HIPCHECK(hipEventRecord(ctx->ev[5], st));
-        HIPCHECK(hipGetLastError());
-        sync_stream(ctx, st);
-        float ms = 0;
-        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
-        *gb_per_s = 2.0 * (double)n2 * 16.0 * iterations / ((double)ms * 1e-3) / 1e9;
+        const unsigned gx = (unsigned)((n2 + 4 * NTHREADS - 1) / (4 * NTHREADS));
+        double best = 0.0;
+        for (int variant = 0; variant < 2; ++variant) {
+            auto go = [&](const double2 *src, double2 *dst) {
+                if (variant) hipLaunchKernelGGL(copy16_kernel<true>, dim3(gx), dim3(NTHREADS), 0, st, src, dst, n2);
+                else hipLaunchKernelGGL(copy16_kernel<false>, dim3(gx), dim3(NTHREADS), 0, st, src, dst, n2);
+            };
+            go(a.as<double2>(), b.as<double2>());                                                   // warm-up
+            HIPCHECK(hipEventRecord(ctx->ev[4], st));
+            for (int k = 0; k < iterations; ++k) go((k & 1) ? b.as<double2>() : a.as<double2>(), (k & 1) ? a.as<double2>() : b.as<double2>());
+            HIPCHECK(hipEventRecord(ctx->ev[5], st));
+            HIPCHECK(hipGetLastError());
+            sync_stream(ctx, st);
+            float ms = 0;
+            HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+            best = std::max(best, 2.0 * (double)n2 * 16.0 * iterations / ((double)ms * 1e-3) / 1e9);
+        }
+        *gb_per_s = best;
         a.release(); b.release();
     });
 }
@@ -1646,6 +1807,24 @@ int blhip_carry_read(blhip_ctx *ctx, int slot, int64_t chain, double *host_out) 
                                     hipMemcpyDeviceToHost, st));
         }
         sync_stream(ctx, st);
+    });
+}
+
+int blhip_carry_write(blhip_ctx *ctx, int slot, int64_t n_chains, int64_t G, const double *host_in) {
+    return guarded(ctx, [&] {
+        if (!host_in || n_chains < 1 || G < 1 || slot < 0) fail("blhip_carry_write: bad arguments");
+        HIPCHECK(hipSetDevice(ctx->device));
+        blhip_ctx::Carry &cs = ctx->carry[slot];
+        cs.buf.ensure((size_t)n_chains * G * 8);
+        HIPCHECK(hipMemcpyAsync(cs.buf.p, host_in, (size_t)n_chains * G * 8, hipMemcpyHostToDevice, ctx->stream));
+        sync_stream(ctx, ctx->stream);
+        cs.chains = n_chains; cs.G = G; cs.valid = true;
+        cs.maxv.assign(n_chains, 0.0);           // (NotEqual inverts around the maximum of the carried state)
+        for (int64_t b = 0; b < n_chains; ++b) {
+            double m = -INFINITY;
+            for (int64_t c = 0; c < G; ++c) m = std::max(m, host_in[b * G + c]);
+            cs.maxv[b] = m;
+        }
     });
 }
 

@@ -20,6 +20,7 @@
 // Algorithmic HBM traffic per cell and step: forward 16 B (read state, write state), backward 32 B.
 #pragma once
 #include "blhip_kernels.hpp"
+#include "blhip_expmn.hpp"
 
 namespace blf {
 
@@ -97,29 +98,7 @@ __device__ __forceinline__ double uniform(double x) {
     return __hiloint2double(hi, lo);
 }
 
-// exp(a) = m * 2^n with m in [0.70, 1.42]; never overflows / underflows.  |error| < 2e-16 relative.
-__device__ __forceinline__ void exp_mn(double a, double &m, int &n) {
-    a = fmin(fmax(a, -1.4e9), 1.4e9);
-    const double kn = rint(a * 1.44269504088896340736);
-    double r = fma(-kn, 6.93147180369123816490e-01, a);
-    r = fma(-kn, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;            // 1/13!
-    p = fma(p, r, 2.0876756987868100e-09);        // 1/12!
-    p = fma(p, r, 2.5052108385441720e-08);        // 1/11!
-    p = fma(p, r, 2.7557319223985893e-07);        // 1/10!
-    p = fma(p, r, 2.7557319223985888e-06);        // 1/9!
-    p = fma(p, r, 2.4801587301587302e-05);        // 1/8!
-    p = fma(p, r, 1.9841269841269841e-04);        // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);        // 1/6!
-    p = fma(p, r, 8.3333333333333332e-03);        // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);        // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);        // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    m = p;
-    n = (int)kn;
-}
+using blmath::exp_mn;
 
 // wave-uniform read-only tables go through the scalar cache (s_load): no VGPRs, no vmcnt traffic
 typedef const double __attribute__((address_space(4))) *cdptr;

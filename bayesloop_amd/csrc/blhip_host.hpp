@@ -111,6 +111,10 @@ struct blhip_ctx {
     int comm_world = 1, comm_rank = 0;
     DevBuf commbuf;
     PinBuf pinC;
+    // time-resident path (blhip_resident.hpp): halo strips / flags, and whether every tile was co-resident so far
+    DevBuf resx;
+    bool resident_ok = true;
+    int num_cus = 0;
 
     double option(const char *k, double dflt) const {
         auto it = opt.find(k);

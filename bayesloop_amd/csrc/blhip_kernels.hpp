@@ -567,9 +567,28 @@ __global__ __launch_bounds__(NTHREADS) void time_average_kernel(const double *p,
     }
 }
 
-// streaming copy, 16 B per lane and access (the calibration of what this part reaches on a pure read + write stream)
+// streaming copy, 16 B per lane and access, 4 independent accesses per thread in flight (the calibration of what this part
+// reaches on a pure read + write stream); NT: non-temporal loads / stores
+template <bool NT>
 __global__ __launch_bounds__(NTHREADS) void copy16_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, long long n2) {
-    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < n2; c += (long long)gridDim.x * NTHREADS) dst[c] = src[c];
+    const long long base = (long long)blockIdx.x * (4 * NTHREADS) + threadIdx.x;
+    double2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long c = base + k * NTHREADS;
+        if (c < n2) {
+            if (NT) { v[k].x = __builtin_nontemporal_load(&src[c].x); v[k].y = __builtin_nontemporal_load(&src[c].y); }
+            else v[k] = src[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long c = base + k * NTHREADS;
+        if (c < n2) {
+            if (NT) { __builtin_nontemporal_store(v[k].x, &dst[c].x); __builtin_nontemporal_store(v[k].y, &dst[c].y); }
+            else dst[c] = v[k];
+        }
+    }
 }
 
 __global__ void fill_kernel(double *p, long long n, double v) {

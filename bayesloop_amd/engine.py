@@ -232,6 +232,13 @@ class HipEngine:
         self._check(self.lib.blhip_carry_read(self.ctx, int(slot), int(chain), _abi.dptr(out)))
         return out
 
+    def carry_write(self, slot, states):
+        """Restore the carried distributions of `slot`: states is (n_chains, *grid_size), rows normalised."""
+        st = _f64(states)
+        n = st.shape[0]
+        st = st.reshape(n, -1)
+        self._check(self.lib.blhip_carry_write(self.ctx, int(slot), n, st.shape[1], _abi.dptr(st)))
+
     def carry_release(self, slot=-1):
         self._check(self.lib.blhip_carry_release(self.ctx, int(slot)))
 

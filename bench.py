@@ -241,9 +241,14 @@ def cpu_baseline(nh=8, T=160, n=512, max_procs=16):
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU ordinal), pass rank 0's stdout through."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU ordinal), pass rank 0's stdout through.
+    A rank that dies takes the others down with it (a survivor would wait in the RCCL bootstrap for ever)."""
     import subprocess
     import uuid
+    from bayesloop_amd import _abi
+    have = _abi.load().blhip_device_count()
+    if have < args.gpus:
+        sys.exit('bench.py: --gpus %d but only %d HIP device(s) are visible' % (args.gpus, have))
     env = dict(os.environ, WORLD_SIZE=str(args.gpus), BLHIP_RDZV_KEY='bench_' + uuid.uuid4().hex, HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.setdefault('MASTER_ADDR', '127.0.0.1')
     procs = []
@@ -252,8 +257,20 @@ def self_launch(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                rc = rc or p.returncode
+    for p in live:                       # only reached with a failed rank: stop the rest
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     sys.exit(rc)
 
 

@@ -249,6 +249,9 @@ int blhip_comm_destroy(blhip_ctx *ctx);
  * blhip_carry_read copies one chain's state (chain >= 0) or the mix buffer (chain = -1, slot ignored) to the host, (G,). */
 int blhip_carry_mix(blhip_ctx *ctx, int slot, int64_t n_chains, const double *weights, int accumulate);
 int blhip_carry_read(blhip_ctx *ctx, int slot, int64_t chain, double *host_out);
+/* Restores carried states saved with blhip_carry_read (a pickled OnlineStudy that continues in another process / context,
+ * reference fileIO.py:10-37): host_in is (n_chains, G), every row a normalised distribution. */
+int blhip_carry_write(blhip_ctx *ctx, int slot, int64_t n_chains, int64_t G, const double *host_in);
 int blhip_carry_release(blhip_ctx *ctx, int slot);   /* slot < 0: all slots and the mix buffer */
 
 #ifdef __cplusplus

@@ -94,6 +94,9 @@ class OracleEngine:
     def carry_read(self, slot, chain, grid_size):
         return (self._mix if chain < 0 else self._carry[slot][chain]).copy().reshape(grid_size)
 
+    def carry_write(self, slot, states):
+        self._carry[slot] = np.array(states, dtype=float)
+
     def carry_release(self, slot=-1):
         if slot < 0:
             self._carry.clear()

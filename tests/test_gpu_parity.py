@@ -611,3 +611,150 @@ def test_seeded_random_hyper_studies_match_oracle(seed):
     if 'logEvidenceList' in want and not np.all(np.isfinite(np.asarray(want['logEvidenceList'], dtype=float))):
         got['localEvidence'] = gold['localEvidence']         # (np.empty left-overs of stopped chains, see the model-zoo test)
     compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
+
+
+def test_online_study_survives_pickling_on_device():
+    """blhip_carry_read / blhip_carry_write: a pickled OnlineStudy re-creates its carried filter states in slots of its own and
+    continues independently of the original (reference fileIO.py:10-37)."""
+    import contextlib
+    import io
+    import pickle
+    data = np.array([1.0, 2.0, 3.0, 2.0, 4.0, 3.0])
+
+    def make():
+        O = bl.OnlineStudy(storeHistory=True, silent=True)
+        O.set(bl.om.Poisson('rate', bl.oint(0, 6, 50)), silent=True)
+        O.add('static', bl.tm.Static())
+        O.add('grw', bl.tm.GaussianRandomWalk('sigma', [0.1, 0.3], target='rate'))
+        O.add('ne', bl.tm.NotEqual('pmin', -3))
+        return O
+    with contextlib.redirect_stdout(io.StringIO()):
+        A = make()
+        for x in data[:3]:
+            A.step(x)
+        B = pickle.loads(pickle.dumps(A))
+        for x in data[3:]:
+            B.step(x)
+        for x in data[3:]:
+            A.step(x)
+        R = make()
+        for x in data:
+            R.step(x)
+    for O in (A, B):
+        np.testing.assert_allclose(O.logEvidence, R.logEvidence, rtol=1e-12)
+        np.testing.assert_allclose(O.marginalizedPosterior, R.marginalizedPosterior, rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(O.transitionModelDistribution, R.transitionModelDistribution, rtol=1e-11)
+    del B
+    with contextlib.redirect_stdout(io.StringIO()):
+        A.step(2.0)
+    assert np.isfinite(A.logEvidence)
+
+
+# ---- the time-resident kernel (blhip_resident.hpp): one launch per pass, tiles in LDS, halo strips between tiles ------------------
+
+def _g2(n0, n1, lo=-8, hi=8, smax=4):
+    return ('Gaussian', [('mean', cases._g('cint', lo, hi, n0)), ('std', cases._g('oint', 0, smax, n1))], 'default')
+
+
+def _grw2(s1, s2):
+    return ('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)])
+
+
+RESIDENT = {
+    # tiles 32 x 32: 6 tiles, every kind of tile edge (grid edge / neighbour) on both axes; full fit
+    'res_64x96_full': dict(study='Study', data=('series', 21, 9), om=_g2(64, 96), tm=_grw2(0.45, 0.09)),
+    # missing data points, lag reaching over them
+    'res_96x64_nan': dict(study='Study', data=('series_nan', 22, 11, [0, 4, 5]), om=_g2(96, 64), tm=_grw2(0.3, 0.12)),
+    # forward-only: filtered posteriors + means
+    'res_128_fwdonly': dict(study='Study', data=('series', 23, 8), om=_g2(128, 128), tm=_grw2(0.25, 0.06),
+                            fit=dict(forwardOnly=True)),
+    'res_256x128_evid': dict(study='Study', data=('series', 24, 12), om=_g2(256, 128), tm=_grw2(0.12, 0.07),
+                             fit=dict(evidenceOnly=True)),
+    # one filtered axis only / no filter at all on the other (identity pass)
+    'res_128_axis0': dict(study='Study', data=('series', 25, 7), om=_g2(128, 64), tm=('GRW', 's1', 0.3, 'mean', None)),
+    'res_128_axis1': dict(study='Study', data=('series', 26, 7), om=_g2(64, 128), tm=('GRW', 's2', 0.08, 'std', None)),
+    'res_64_static': dict(study='Study', data=('series', 27, 6), om=_g2(64, 64), tm=('Static',)),
+    # two data dimensions per step (product of likelihoods, one of them missing at one step)
+    'res_96_multidim': dict(study='Study', data=('series2d', 28, 9), om=_g2(96, 96, -4, 4, 3), tm=_grw2(0.2, 0.07)),
+    # T = 1 and T = 2 (shorter than the lag)
+    'res_T1': dict(study='Study', data=('series', 29, 1), om=_g2(64, 64), tm=_grw2(0.3, 0.1)),
+    'res_T2': dict(study='Study', data=('series', 30, 2), om=_g2(64, 64), tm=_grw2(0.3, 0.1)),
+    # tiles 64 x 64 (128 tiles) and 128 x 128 (32 tiles)
+    'res_1024x512_full': dict(study='Study', data=('series', 31, 5), om=_g2(1024, 512), tm=_grw2(0.03, 0.016)),
+    'res_2048x256_full': dict(study='Study', data=('series', 32, 4), om=_g2(2048, 256), tm=_grw2(0.015, 0.03)),
+}
+
+
+@pytest.mark.parametrize('case', list(RESIDENT))
+def test_resident_kernel_matches_oracle(case):
+    c = RESIDENT[case]
+    S = cases.build(bl, c)
+    S.fit(**cases.fit_kwargs(c))
+    assert S.lastTiming['fwd_kernel_variant'] == 5, S.lastTiming          # the resident path really ran
+    if not cases.fit_kwargs(c).get('evidenceOnly') and not cases.fit_kwargs(c).get('forwardOnly'):
+        assert S.lastTiming['bwd_kernel_variant'] == 5, S.lastTiming
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues'):
+        if k in want and want[k] is not None and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
+
+
+@pytest.mark.parametrize('lag', [1, 2, 3, 4])
+def test_resident_kernel_lag_and_determinism(lag):
+    """The lagged normaliser (resident_lag = 1 .. 4) only changes intermediate magnitudes; repeated runs are bit-identical
+    (every sum has a fixed order: a hand-off race would show as a difference between runs)."""
+    eng = bl.get_engine()
+    c = dict(study='Study', data=('series', 41, 14), om=_g2(256, 256), tm=_grw2(0.12, 0.03))
+    eng.set_option('resident', 0)
+    try:
+        B = cases.build(bl, c); B.fit(silent=True)
+        assert B.lastTiming['fwd_kernel_variant'] != 5
+        base = np.array(B.posteriorSequence)
+    finally:
+        eng.set_option('resident', 1)
+    eng.set_option('resident_lag', lag)
+    try:
+        runs = []
+        for _ in range(3):
+            A = cases.build(bl, c); A.fit(silent=True)
+            assert A.lastTiming['fwd_kernel_variant'] == 5 and A.lastTiming['bwd_kernel_variant'] == 5
+            runs.append((A.logEvidence, np.array(A.posteriorSequence), np.array(A.localEvidence)))
+    finally:
+        eng.set_option('resident_lag', 2)
+    for logE, post, loc in runs:
+        assert abs(logE - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
+        np.testing.assert_allclose(post, base, rtol=1e-9, atol=1e-14)
+        assert logE == runs[0][0] and np.array_equal(post, runs[0][1]) and np.array_equal(loc, runs[0][2], equal_nan=True)
+
+
+def test_resident_kernel_full_chip():
+    """256 tiles (one per CU): 2048 x 2048 forward (tiles 128 x 128) and 1024 x 1024 full fit (tiles 64 x 64) against the
+    launch-per-step kernels, which the tests above and the goldens pin to the oracle / the reference."""
+    eng = bl.get_engine()
+    for c, T in ((dict(study='Study', data=('series', 3, 24), om=cases.gauss2d(2048), tm=_grw2(0.015, 0.004), fit=dict(evidenceOnly=True)), 24),
+                 (dict(study='Study', data=('series', 3, 16), om=cases.gauss2d(1024), tm=_grw2(0.03, 0.008)), 16)):
+        A = cases.build(bl, c); A.fit(**cases.fit_kwargs(c))
+        assert A.lastTiming['fwd_kernel_variant'] == 5, A.lastTiming
+        eng.set_option('resident', 0)
+        try:
+            B = cases.build(bl, c); B.fit(**cases.fit_kwargs(c))
+            assert B.lastTiming['fwd_kernel_variant'] != 5
+        finally:
+            eng.set_option('resident', 1)
+        assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
+        np.testing.assert_allclose(A.localEvidence, B.localEvidence, rtol=1e-9, atol=0, equal_nan=True)
+        if not cases.fit_kwargs(c).get('evidenceOnly'):
+            np.testing.assert_allclose(A.posteriorMeanValues, B.posteriorMeanValues, rtol=1e-10)
+            for k in (0, 1):
+                np.testing.assert_allclose(A.getParameterDistributions(A.observationModel.parameterNames[k], density=False)[1],
+                                           B.getParameterDistributions(B.observationModel.parameterNames[k], density=False)[1],
+                                           rtol=1e-9, atol=1e-14)
+            a, b = A._posterior_pending.row(T // 2), B._posterior_pending.row(T // 2)
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-14)
+        for S_ in (A, B):
+            S_._posterior_pending = None
+        eng.release_posterior()

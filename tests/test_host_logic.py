@@ -242,3 +242,79 @@ def test_jeffreys_helpers():
     S.setOM(bl.om.Poisson('rate', bl.oint(0, 6, 20)), silent=True)
     with pytest.raises(bl.ConfigurationError):
         bl.computeJeffreysPriorAR1(S)
+
+
+def test_accessors_accept_keyword_arguments():
+    """The reference's accessors take their arguments by keyword as well (core.py:864-1002, 1535-1694); the plot decorator must
+    not swallow them (every call below used to raise TypeError: missing positional argument)."""
+    S = cases.build(bl, 'kat_hyper_1hp')
+    S.fit(silent=True)
+    x0, p0 = S.getParameterDistribution(S.formattedTimestamps[2], 'mean')
+    x1, p1 = S.getParameterDistribution(t=S.formattedTimestamps[2], name='mean')
+    x2, p2 = S.getParameterDistribution(S.formattedTimestamps[2], name='mean', density=False)
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_allclose(p2, p0 * S.latticeConstant[0], rtol=1e-13)
+    np.testing.assert_array_equal(S.getParameterDistributions(name='mean')[1], S.getParameterDistributions('mean')[1])
+    np.testing.assert_array_equal(S.getPDs(name='mean', density=False)[1], S.getParameterDistributions('mean', density=False)[1])
+    np.testing.assert_array_equal(S.getHyperParameterDistribution(name='sigma')[1], S.getHyperParameterDistribution('sigma')[1])
+    np.testing.assert_array_equal(S.getHPD(name='sigma')[1], S.getHPD('sigma')[1])
+    S2 = cases.build(bl, 'c4_2hp')
+    S2.fit(silent=True)
+    names = list(S2.flatHyperParameterNames[:2])
+    a = S2.getJointHyperParameterDistribution(names)
+    b = S2.getJointHyperParameterDistribution(names=names)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    C = cases.build(bl, 'kat_changepointstudy')
+    C.fit(silent=True)
+    cp = [n for n in C.flatHyperParameterNames]
+    if len(cp) >= 2:
+        np.testing.assert_array_equal(C.getDurationDistribution(names=cp[:2])[1], C.getDurationDistribution(cp[:2])[1])
+
+
+def test_evidence_only_refit_keeps_the_previous_posterior():
+    """Study.fit(evidenceOnly=True) after a full fit: the reference keeps the previous posteriorSequence (core.py:355-356)."""
+    S = cases.build(bl, 'c1_coal')
+    S.fit(silent=True)
+    logE = S.logEvidence
+    S.fit(evidenceOnly=True, silent=True)
+    assert S.logEvidence == logE
+    gold = oa.load_golden('c1_coal')
+    np.testing.assert_allclose(S.posteriorSequence, gold['posteriorSequence'], rtol=1e-9, atol=1e-15)
+    x, p = S.getParameterDistribution(1900, 'rate')
+    assert np.isfinite(p).all()
+
+
+def test_online_study_survives_pickling():
+    """A pickled / copied OnlineStudy carries its per-chain filter states along and continues stepping independently of the
+    original (reference fileIO.py:10-37)."""
+    import pickle
+    data = np.array([1.0, 2.0, 3.0, 2.0, 4.0, 3.0])
+
+    def make():
+        O = bl.OnlineStudy(storeHistory=True, silent=True)
+        O.set(bl.om.Poisson('rate', bl.oint(0, 6, 50)), silent=True)
+        O.add('static', bl.tm.Static())
+        O.add('grw', bl.tm.GaussianRandomWalk('sigma', [0.1, 0.3], target='rate'))
+        return O
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        A = make()
+        for x in data[:3]:
+            A.step(x)
+        B = pickle.loads(pickle.dumps(A))
+        for x in data[3:]:
+            B.step(x)             # the copy goes on ...
+        for x in data[3:]:
+            A.step(x)             # ... and so does the original, from its own state
+        R = make()
+        for x in data:
+            R.step(x)
+    for O in (A, B):
+        np.testing.assert_allclose(O.logEvidence, R.logEvidence, rtol=1e-12)
+        np.testing.assert_allclose(O.marginalizedPosterior, R.marginalizedPosterior, rtol=1e-12)
+        np.testing.assert_allclose(O.transitionModelDistribution, R.transitionModelDistribution, rtol=1e-12)
+    del B
+    with contextlib.redirect_stdout(io.StringIO()):
+        A.step(2.0)               # releasing the copy's slots must not touch the original's
+    assert np.isfinite(A.logEvidence)
