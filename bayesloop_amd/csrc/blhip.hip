@@ -403,41 +403,49 @@ void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, si
 }
 
 // ---- time-resident path (blhip_resident.hpp): one launch for all time steps of a single-chain 2-D fit ----------------------------
+#ifndef RES_SEG128
+#define RES_SEG128 32
+#define RES_CHK128 8
+#endif
 struct ResidentPlan {
     int TR = 0, TC = 0, SEG = 0, tr = 0, tc = 0, ntiles = 0, NT = 0;
     size_t lds_bytes = 0;
 };
 
-template <int TR, int TC, int SEG>
-void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, size_t lds) {
+template <int TR, int TC, int SEG, int CHK>
+void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd) {
+    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, false>::LDS_DOUBLES * sizeof(double);
     if (bwd) {
         static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
-        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, true>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, true>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
     } else {
         static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
-        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, false>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, false>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
     }
 }
 
+// tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
+// (tools/ubench/fp64_banks.hip), so more waves per SIMD would help -- but the 1024-thread shape of the 128 x 128 tile (segments
+// of 16, chunks of 4: -DRES_SEG128=16 -DRES_CHK128=4) has to live in 128 VGPRs, spills, and measured 18.7 us per 2048^2 step
+// against 13.2 us for 512 threads with 200 VGPRs
 void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
-    if (rp.TR == 128) launch_resident_t<128, 128, 32>(s, Q, bwd, rp.lds_bytes);
-    else if (rp.TR == 64) launch_resident_t<64, 64, 8>(s, Q, bwd, rp.lds_bytes);
-    else launch_resident_t<32, 32, 8>(s, Q, bwd, rp.lds_bytes);
+    if (rp.TR == 128) launch_resident_t<128, 128, RES_SEG128, RES_CHK128>(s, Q, bwd);
+    else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd);
+    else launch_resident_t<32, 32, 8, 8>(s, Q, bwd);
     HIPCHECK(hipGetLastError());
 }
 
 // the smallest supported tile whose tile grid fits the chip (every tile = one co-resident block)
 bool plan_resident(int n0, int n1, int max_tiles, ResidentPlan &rp) {
-    const int shapes[3][3] = {{32, 32, 8}, {64, 64, 8}, {128, 128, 32}};
+    const int shapes[3][3] = {{32, 32, 8}, {64, 64, 8}, {128, 128, RES_SEG128}};
     for (const auto &sh : shapes) {
         if (n0 % sh[0] || n1 % sh[1]) continue;
         const long long nt = (long long)(n0 / sh[0]) * (n1 / sh[1]);
         if (nt > max_tiles) continue;
         rp.TR = sh[0]; rp.TC = sh[1]; rp.SEG = sh[2]; rp.tr = n0 / sh[0]; rp.tc = n1 / sh[1]; rp.ntiles = (int)nt;
         rp.NT = sh[0] * sh[1] / sh[2];
-        rp.lds_bytes = (size_t)((size_t)sh[0] * (sh[1] + 1) + sh[0] + 8 + 5 * (rp.NT / 64 + 1) + 8) * sizeof(double);
         return true;
     }
     return false;
@@ -1101,7 +1109,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             const size_t nt = (size_t)rp.ntiles;
             const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
             const size_t b_w = carve_size(2 * (blr::R + 1) * 8);
-            res_flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 2 * 8) + carve_size(64);
+            res_flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
             ctx->resx.ensure(b_cols + b_rows + b_w + res_flag_bytes);
             char *rc = ctx->resx.as<char>();
             RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
@@ -1109,7 +1117,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             double *d_w = carve<double>(rc, 2 * (blr::R + 1));
             RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
             RQ.flagR = carve<unsigned>(rc, nt);
-            RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 2);
+            RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
             d_res_abort = carve<unsigned>(rc, 16);
             RQ.abort_word = d_res_abort;
             double hw[2 * (blr::R + 1)];
@@ -1264,9 +1272,35 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             HIPCHECK(hipMemsetAsync(RQ.flagC, 0, res_flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
             HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * NRED * res_nblk * 8, st));
             Q.psum = psum;
-            if (bwd) { Q.src0 = d_uniform; Q.post = d_post; Q.store = 1; Q.means = 1; }
-            else { Q.src0 = d_prior; Q.post = evidence_only ? nullptr : d_post; Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0; }
+            // rows of the kept sequence are normalised inside the kernel, `lag` steps behind (what the host then still scales: the
+            // last / first `lag` rows)
+            if (bwd) { Q.src0 = d_uniform; Q.post = d_post; Q.store = 1; Q.means = 1; Q.normalise = 1; }
+            else {
+                Q.src0 = d_prior; Q.post = evidence_only ? nullptr : d_post; Q.store = evidence_only ? 0 : 1;
+                Q.means = forward_only ? 1 : 0; Q.normalise = forward_only ? 1 : 0;
+            }
+#ifdef BLR_PROF
+            ctx->small.ensure(2 * 16 * 16 * 8);
+            HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+            Q.prof = ctx->small.as<unsigned long long>();
+#endif
             launch_resident(st, rp, Q, bwd);
+#ifdef BLR_PROF
+            {   // development build: where a step of one interior tile spends its time (shader-clock cycles between stamps)
+                unsigned long long hh[2 * 16 * 16];
+                HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
+                sync_stream(ctx, st);
+                static const char *names[12] = {"start", "h_pre+bar", "h_walk", "bar", "pubR+v_pre+gather", "arriveR", "bar", "v_walk", "sums", "pubC(+arriveC)", "-", "-"};
+                for (int wv = 0; wv < 2; ++wv) {
+                    const unsigned long long *h = hh + wv * 256;
+                    double acc[12] = {0}; int n = 0;
+                    for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 9] || !h[q * 16]) continue; ++n; for (int i = 1; i < 10; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                    std::fprintf(stderr, "[blr prof %s thread %d] %d steps, cycles per phase:", bwd ? "bwd" : "fwd", wv ? 128 : 0, n);
+                    double tot = 0; for (int i = 1; i < 10; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                    std::fprintf(stderr, " | total %.0f\n", tot);
+                }
+            }
+#endif
         };
         // did a tile time out waiting for a neighbour (not every block co-resident)?  -> this context stops using the path
         auto resident_gave_up = [&]() {
@@ -1429,7 +1463,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     if (prog.has_clamp) refnorm = r[0] / (redF[((size_t)t * B + b) * NRED] * (prog.cmodeB[(size_t)t * B + b] ? r[5] : 1.0));
                     if (!(refnorm > 0.0)) { abort_step[b] = t; abort_phase[b] = 1; logE[b] = -INFINITY; break; }
                     local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
-                    invN[(size_t)b * T + t] = 1.0 / r[0];
+                    invN[(size_t)b * T + t] = (res_now && t >= RQ.lag) ? 1.0 : 1.0 / r[0];          // (resident: normalised in the kernel)
                     for (int k = 0; k < p->ndim; ++k) means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
                 }
             }
@@ -1438,6 +1472,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 for (int64_t t = 0; t < T; ++t) {
                     const double n0 = res_now ? rowsumF[t] : redF[((size_t)t * B + b) * NRED];
                     invN[(size_t)b * T + t] = (n0 != 0.0 && std::isfinite(n0)) ? 1.0 / n0 : 0.0;     // (a signed kernel can leave a negative raw sum)
+                    if (res_now && t <= T - 1 - RQ.lag) invN[(size_t)b * T + t] = 1.0;                // (already normalised by the resident kernel)
                 }
         }
 

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(NTHREADS) void carry_mix_kernel(double *mix, const 
 __global__ __launch_bounds__(NTHREADS) void scale_rows_kernel(double *rows, long long G, const double *inv) {
     const long long t = blockIdx.y;
     const double s = inv[t];
+    if (s == 1.0) return;                            // (rows the time-resident kernel has normalised already)
     double *row = rows + t * G;
     for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS)
         row[c] *= s;

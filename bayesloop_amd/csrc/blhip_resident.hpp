@@ -50,7 +50,6 @@
 namespace blr {
 
 constexpr int R = 8;             // stencil radius bucket of both axes (weights zero-padded)
-constexpr int CHK = 8;           // outputs per chunk of a pass (== R: the window is 3 chunks)
 constexpr int NSLOT = 8;         // ring of granule slots for the lagged sums (>= 2 * max lag)
 constexpr int MAXLAG = 4;
 constexpr int DMAX = 4;          // data dimensions kept in registers
@@ -62,6 +61,9 @@ struct ResParams {
     int T, d, rec_len, lag;
     int store;                   // forward: write every step's state to post (full / forward-only fits)
     int means;                   // forward: also sum a * grid values (forward-only fits)
+    int normalise;               // normalise the rows of post in the kernel, `lag` steps behind (forward-only fits: the filtered
+                                 // distributions; backward: the posteriors) -- the sum of a row is known `lag` steps later; the
+                                 // first / last `lag` rows are left to the host
     const double *src0;          // what the first step consumes instead of a transition: prior (forward) / uniform (backward)
     double *post;                // [T][n0 * n1]: forward: stored states (out); backward: stored states (in) -> posteriors (out)
     const double *w0, *w1;       // R + 1 half-kernel weights per axis, zero-padded; {1, 0, ...} = no filter
@@ -71,9 +73,10 @@ struct ResParams {
     double *cols;                // [2][ntiles][2][R][TR]   raw edge columns of the new state (parity = step & 1)
     double *rows;                // [2][ntiles][2][R][TC]   axis-1-filtered edge rows
     unsigned *flagC, *flagR;     // [ntiles] epochs
-    unsigned long long *gran;    // [NSLOT][ntiles][2] {tag << 32 | half of the double}
+    unsigned long long *gran;    // [NSLOT][ntiles][4] {tag << 32 | half of a double}: the scale sum, the row sum (backward)
     unsigned *abort_word;
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
+    unsigned long long *prof;           // development builds (-DBLR_PROF): [16 steps][16 stamps] shader-clock stamps of one tile
 };
 
 // ---- memory primitives: agent-scope (sc1) accesses on the device, plain ones in the emulation -------------------------------
@@ -90,6 +93,7 @@ BLR_INL void nap() {}
 BLR_INL double ldexp_(double m, int n) { return std::ldexp(m, n); }
 BLR_INL double nan_() { return std::nan(""); }
 BLR_INL double ldu(const double *p, long long i) { return p[i]; }
+BLR_INL int uni(int x) { return x; }
 #else
 typedef unsigned long long __attribute__((address_space(1))) gu64;
 typedef unsigned __attribute__((address_space(1))) gu32;
@@ -114,6 +118,7 @@ BLR_INL double ldexp_(double m, int n) { return ldexp(m, n); }
 BLR_INL double nan_() { return __builtin_nan(""); }
 // wave-uniform read-only values (stencil weights, the step's data record) through the scalar cache: SGPRs, not VGPRs
 BLR_INL double ldu(const double *p, long long i) { return ((const double __attribute__((address_space(4))) *)(unsigned long long)p)[i]; }
+BLR_INL int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }       // a block-uniform value: SGPR
 #endif
 
 // bounded wait for an epoch flag; false = timed out / another block gave up (the caller marks the block dead)
@@ -142,58 +147,66 @@ BLR_INL int tile_of_block(int b, int ntiles) {
     return (ntiles % 8 == 0) ? (b % 8) * (ntiles / 8) + b / 8 : b;
 }
 
-// One thread's in-place pass over its SEG-element line segment.  Positions p = 0 .. SEG-1 in WALKING order live at
-// x0[p * STRIDE] (compile-time stride, negative = towards lower addresses: every access is base + immediate offset);
-// nearv[k] = x(k - 8), the far halo x(SEG + k) comes from far_fetch(f) (registers read before the barrier, or the neighbour
-// tile's strip).  pre8(p0) may start loads the epilogue of the chunk needs; emit8(p0, v) receives the 8 filtered values of
-// positions p0 .. p0+7 and may overwrite x(p0 .. p0+7): the window already holds what later chunks need.
-template <int SEG, int STRIDE, class FarFn, class Pre, class Emit>
-BLR_INL void walk(const double *x0, const double (&nearv)[R], const double (&wk)[R + 1], FarFn &&far_fetch, Pre &&pre8, Emit &&emit8) {
-    static_assert(SEG % CHK == 0 && SEG >= CHK && R == CHK, "segment = whole chunks; window = 3 chunks");
-    double w[3 * CHK];
+// One thread's in-place pass over its SEG-element line segment, C outputs per chunk.  Positions p = 0 .. SEG-1 in WALKING order
+// live at x0[p * STRIDE] (compile-time stride, negative = towards lower addresses: every access is base + immediate offset);
+// nearv[k] = x(k - R); the far halo x(SEG + k) = f[k] was read before the barrier, or far_fetch(f) loads it from the neighbour
+// tile's strip at the top of the first chunk whose NEXT window reaches past the segment.  pre(p0) may start loads
+// the epilogue of the chunk needs; emit(p0, v) receives the C filtered values of positions p0 .. p0+C-1 and may overwrite
+// x(p0 .. p0+C-1): the register window (2 R + C values) already holds what later chunks need.
+//   A one-chunk segment (SEG == C) needs its far halo for every output.  When that halo is a neighbour's strip (`far_is_strip`),
+// the chunk is first evaluated with zeros in the far slots -- everything the thread can do before the hand-off -- and the
+// (R + 1) R / 2 products with the far values are added once they have arrived.
+template <int SEG, int STRIDE, int C, class FarFn, class Pre, class Emit>
+BLR_INL void walk(const double *x0, const double (&nearv)[R], double (&f)[R], bool far_is_strip, const double (&wk)[R + 1], FarFn &&far_fetch,
+                  Pre &&pre, Emit &&emit) {
+    static_assert(SEG % C == 0 && SEG >= C && SEG >= R, "segment = whole chunks, at least one radius long");
+    constexpr int W = 2 * R + C;
+    constexpr bool ONE = SEG == C;                   // single chunk: deferred far halo
+    double w[W];
+    bool have_far = false;                           // f: the far halo; far_fetch(f) completes it when it is a neighbour tile's strip
 #pragma unroll
-    for (int k = 0; k < CHK; ++k) w[k] = nearv[k];
+    for (int k = 0; k < R; ++k) w[k] = nearv[k];
+    if (R + C > SEG && !ONE) { far_fetch(f); have_far = true; }
 #pragma unroll
-    for (int k = 0; k < CHK; ++k) w[CHK + k] = x0[k * STRIDE];
-    if (SEG > CHK) {
+    for (int q = 0; q < R + C; ++q) w[R + q] = q < SEG ? x0[q * STRIDE] : ((ONE && far_is_strip) ? 0.0 : f[q < SEG ? 0 : q - SEG]);
 #pragma unroll
-        for (int k = 0; k < CHK; ++k) w[2 * CHK + k] = x0[(CHK + k) * STRIDE];
-    } else {
-        double f[R];
-        far_fetch(f);
+    for (int p0 = 0; p0 < SEG; p0 += C) {
+        const bool more = p0 + C < SEG;
+        double nx[C];
+        if (more) {                                  // what enters the window for the next chunk: x(p0+C+R .. p0+2C+R-1)
+            if (p0 + 2 * C + R > SEG && !have_far) { far_fetch(f); have_far = true; }
 #pragma unroll
-        for (int k = 0; k < CHK; ++k) w[2 * CHK + k] = f[k];
-    }
-#pragma unroll
-    for (int p0 = 0; p0 < SEG; p0 += CHK) {
-        const bool more = p0 + CHK < SEG;
-        double nx[CHK];
-        if (more) {                                  // what enters the window for the next chunk: x(p0+16 .. p0+23)
-            if (p0 + 2 * CHK < SEG) {
-#pragma unroll
-                for (int k = 0; k < CHK; ++k) nx[k] = x0[(p0 + 2 * CHK + k) * STRIDE];
-            } else {
-                far_fetch(nx);
+            for (int k = 0; k < C; ++k) {
+                const int pos = p0 + C + R + k;
+                nx[k] = pos < SEG ? x0[pos * STRIDE] : f[pos < SEG ? 0 : pos - SEG];
             }
         }
-        pre8(p0);                                    // (loads the epilogue of THIS chunk needs: they fly under the arithmetic below)
-        double v[CHK];
+        pre(p0);                                     // (loads the epilogue of THIS chunk needs: they fly under the arithmetic below)
+        double v[C];
 #pragma unroll
-        for (int j = 0; j < CHK; ++j) v[j] = w[CHK + j] * wk[0];
+        for (int j = 0; j < C; ++j) v[j] = w[R + j] * wk[0];
 #pragma unroll
-        for (int k = R; k >= 1; --k) {               // outermost pair inwards, the 8 outputs interleaved (independent chains)
-            double t[CHK];
+        for (int k = R; k >= 1; --k) {               // outermost pair inwards, the C outputs interleaved (independent chains)
+            double t[C];
 #pragma unroll
-            for (int j = 0; j < CHK; ++j) t[j] = w[CHK + j - k] + w[CHK + j + k];
+            for (int j = 0; j < C; ++j) t[j] = w[R + j - k] + w[R + j + k];
 #pragma unroll
-            for (int j = 0; j < CHK; ++j) v[j] = fma(t[j], wk[k], v[j]);
+            for (int j = 0; j < C; ++j) v[j] = fma(t[j], wk[k], v[j]);
         }
-        emit8(p0, v);
+        if (ONE && far_is_strip) {                   // far element m = x(SEG + m) reaches output j through tap R + m - j (m <= j)
+            far_fetch(f);
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+#pragma unroll
+                for (int j = m; j < C; ++j) v[j] = fma(f[m], wk[R + m - j], v[j]);
+            }
+        }
+        emit(p0, v);
         if (more) {
 #pragma unroll
-            for (int k = 0; k < 2 * CHK; ++k) w[k] = w[k + CHK];
+            for (int k = 0; k < 2 * R; ++k) w[k] = w[k + C];
 #pragma unroll
-            for (int k = 0; k < CHK; ++k) w[2 * CHK + k] = nx[k];
+            for (int k = 0; k < C; ++k) w[2 * R + k] = nx[k];
         }
     }
 }
@@ -207,9 +220,9 @@ BLR_INL int launder(int x) {
     return x;
 }
 
-template <int TR_, int TC_, int SEG_, bool BWD_>
+template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_>
 struct Res {
-    static constexpr int TR = TR_, TC = TC_, SEG = SEG_;
+    static constexpr int TR = TR_, TC = TC_, SEG = SEG_, CHK = CHK_;    // CHK: outputs per chunk of a pass
     static constexpr bool BWD = BWD_;
     static constexpr int P = TC + 1;                 // LDS pitch in doubles: odd => the row-strided accesses of the axis-1 pass
                                                      // and the contiguous ones of the axis-0 pass are both conflict-free
@@ -217,46 +230,67 @@ struct Res {
     static constexpr int NT = TR * NSH;
     static_assert(TR * NSH == TC * NSV, "both passes use every thread");
     static_assert(NSH >= 2 && NSV >= 2, "edge segments need an in-tile neighbour segment on their near side");
-    static_assert(TR % SEG == 0 && TC % SEG == 0 && TR >= 2 * R && TC >= 2 * R, "tile shape");
+    static_assert(TR % SEG == 0 && TC % SEG == 0 && TR >= 2 * R && TC >= 2 * R && ANCHOR % CHK == 0, "tile shape");
+    static constexpr int NW = NT / 64;
+    static_assert(NT % 64 == 0, "whole waves");
+    static constexpr int GPL = (256 / NW + 63) / 64;     // tiles per lane when NW waves share the <= 256 tiles' partial sums
+    static constexpr int NG = BWD ? 2 : 1;               // sums every tile publishes per step: the scale sum (forward: sum a = the row sum;
+                                                         // backward: sum c) and, backward, the row sum of the posterior
     static constexpr int LDS_TILE = TR * P;          // doubles
     static constexpr int LDS_M0 = LDS_TILE;          // TR row coordinates of the tile
-    static constexpr int LDS_MISC = LDS_M0 + TR;     // [0] scale of this step  [1] dead flag  [2] arrival counter  [8..] reduction scratch
-    static constexpr int LDS_DOUBLES = LDS_MISC + 8 + 5 * (NT / 64 + 1) + 8;
+    static constexpr int LDS_COL = LDS_M0 + TR;      // the tile's column constants: [TC] grid value, [TC] cA, [TC] cB
+    static constexpr int LDS_MISC = LDS_COL + 3 * TC;    // [1] dead flag  [2] arrival counter  [8 .. 8+NW) the waves' shares of the lagged sum
+    static constexpr int LDS_RED = LDS_MISC + 8 + 2 * NW;    // reduction scratch of the step's sums  (misc[8 + g NW + w]: wave w's share of sum g)
+    static constexpr int LDS_DOUBLES = LDS_RED + 5 * (NW + 1) + 8;
 
     struct Rec { double mE, mR, mq, iE, iR, iq; int nE, nR, nq; };
+    struct ColC { double g1, cA, cB; };              // a column's grid value and likelihood constants (from LDS, per pass)
+
+    // where a thread works in a pass, derived from its id whenever needed (a few integer operations) instead of being carried
+    // in registers through both passes: far = kind of the far halo (0 neighbour segment in LDS, 1 mirror at the grid edge,
+    // 2 the strip of tile nb, side)
+    struct Geo { int line, seg, far, nb, side; };
 
     struct Thread {
-        // geometry (time-invariant)
-        int tid, tile, ti, tj, i0, j0, tr, tc;
-        int hr, hs, hfar, hnb, hside;                // axis-1 pass: row, segment, far-halo kind (0 LDS neighbour segment, 1 mirror,
-        int vc, vs, vfar, vnb, vside;                //   2 neighbour tile's strip), which tile / side;  axis-0 pass: column, ...
+        int tid, tile, ti, tj, i0, j0, tr, tc;       // (tile .. tc: block-uniform)
         double *lds;
-        double g1, cA, cB;                           // column constants of the axis-0 pass / epilogue
         // registers that live across a barrier
         double nearv[R], farv[R];
         double xd[DMAX];                             // this step's data record (wave-uniform)
         double al8[BWD ? CHK : 1];                   // backward: the stored forward state of the chunk being processed
+        unsigned long long gq[GPL][2 * NG];          // this wave's share of the lagged sums' granules, in flight since the step began
+        double nz8[CHK];                             // the row being normalised: the chunk's cells, `lag` steps back
         double sums[5];
         bool dead;
 
         BLR_INL void init(const ResParams &Q, int block, int tid_, double *lds_) {
             tid = tid_; lds = lds_; dead = false;
-            tr = Q.tr; tc = Q.tc;
-            tile = tile_of_block(block, Q.ntiles);
-            ti = tile / Q.tc; tj = tile - ti * Q.tc;
+            tr = uni(Q.tr); tc = uni(Q.tc);
+            tile = uni(tile_of_block(block, Q.ntiles));
+            ti = uni(tile / Q.tc); tj = uni(tile - ti * Q.tc);
             i0 = ti * TR; j0 = tj * TC;
-            hr = tid % TR; hs = tid / TR;
-            hfar = 0; hnb = tile; hside = 0;
-            if (hs == 0) { if (tj > 0) { hfar = 2; hnb = tile - 1; hside = 1; } else hfar = 1; }
-            else if (hs == NSH - 1) { if (tj < Q.tc - 1) { hfar = 2; hnb = tile + 1; hside = 0; } else hfar = 1; }
-            vc = tid % TC; vs = tid / TC;
-            vfar = 0; vnb = tile; vside = 0;
-            if (vs == 0) { if (ti > 0) { vfar = 2; vnb = tile - Q.tc; vside = 1; } else vfar = 1; }
-            else if (vs == NSV - 1) { if (ti < Q.tr - 1) { vfar = 2; vnb = tile + Q.tc; vside = 0; } else vfar = 1; }
-            const int gj = j0 + vc;
-            g1 = Q.m1[gj]; cA = Q.colA[gj]; cB = Q.colB[gj];
 #pragma unroll
             for (int k = 0; k < DMAX; ++k) xd[k] = nan_();
+#pragma unroll
+            for (int q = 0; q < 5; ++q) sums[q] = 0.0;
+        }
+        // Segments are dealt to the waves edge segments first: 0, last, 1, 2, ...  The edge segments wait for a neighbour tile;
+        // on the first waves they have issue priority (oldest first) over the interior segment that shares their SIMD
+        // (waves w and w + 4 of a 512-thread block), which then fills their stall.
+        BLR_INL static int seg_of(int s, int nseg) { return s == 0 ? 0 : (s == 1 ? nseg - 1 : s - 1); }
+        BLR_INL Geo hgeo() const {                   // axis-1 pass: a row and a segment of its columns
+            const int t = launder(tid);
+            Geo g{t % TR, seg_of(t / TR, NSH), 0, tile, 0};
+            if (g.seg == 0) { if (tj > 0) { g.far = 2; g.nb = tile - 1; g.side = 1; } else g.far = 1; }
+            else if (g.seg == NSH - 1) { if (tj < tc - 1) { g.far = 2; g.nb = tile + 1; g.side = 0; } else g.far = 1; }
+            return g;
+        }
+        BLR_INL Geo vgeo() const {                   // axis-0 pass: a column and a segment of its rows
+            const int t = launder(tid);
+            Geo g{t % TC, seg_of(t / TC, NSV), 0, tile, 0};
+            if (g.seg == 0) { if (ti > 0) { g.far = 2; g.nb = tile - tc; g.side = 1; } else g.far = 1; }
+            else if (g.seg == NSV - 1) { if (ti < tr - 1) { g.far = 2; g.nb = tile + tc; g.side = 0; } else g.far = 1; }
+            return g;
         }
 
         // time index of the k-th executed step
@@ -269,38 +303,125 @@ struct Res {
             const int t = time_of(Q, k);
 #pragma unroll
             for (int q = 0; q < DMAX; ++q) xd[q] = q < Q.d ? ldu(Q.rec, (long long)t * Q.rec_len + q) : nan_();
+            // one-chunk segments: what the epilogue reads from HBM (the stored forward state, the row to normalise) is requested
+            // now and has both passes' worth of time to arrive
+            if (SEG == CHK && Q.post && (BWD || (Q.normalise && k >= Q.lag))) {
+                const Geo vg = vgeo();
+                if (vg.seg == 0) early_loads<-1>(Q, k, vg); else early_loads<1>(Q, k, vg);
+            }
+        }
+        BLR_INL double *row_ptr(const ResParams &Q, int k, int r0, int c) const {
+            return Q.post ? Q.post + (long long)time_of(Q, k) * Q.n0 * Q.n1 + (long long)(i0 + r0) * Q.n1 + (j0 + c) : nullptr;
+        }
+        // the row written `lag` steps ago (time t -+ lag), whose sum arrives with this step's lagged sums
+        BLR_INL double *lagged_row_ptr(const ResParams &Q, int k, double *pt0) const {
+            return (Q.normalise && k >= Q.lag && pt0) ? pt0 + (long long)(BWD ? Q.lag : -Q.lag) * Q.n0 * Q.n1 : nullptr;
+        }
+        template <int DIR>
+        BLR_INL void early_loads(const ResParams &Q, int k, const Geo &vg) {
+            double *pt0 = row_ptr(Q, k, first_pos(vg.seg, DIR), vg.line);
+            load_alpha8<DIR>(pt0, lagged_row_ptr(Q, k, pt0), Q.n1, 0);
+        }
+
+        // ---- the lagged global sums: this wave's share of the tiles' partial sums of step ks (tiles wv * tpw + lane + 64 j) --------
+        // The loads are issued when the step begins and consumed before the axis-0 pass: their latency hides under the axis-1 pass.
+        BLR_INL void gather_issue(const ResParams &Q, int ks) {
+            const int wv = tid >> 6, lane = tid & 63, tpw = (Q.ntiles + NW - 1) / NW;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) sums[q] = 0.0;
+            for (int j = 0; j < GPL; ++j) {
+                const int loc = lane + 64 * j, idx = wv * tpw + loc;
+#pragma unroll
+                for (int q = 0; q < 2 * NG; ++q) gq[j][q] = 0ull;
+                if (loc < tpw && idx < Q.ntiles) {
+                    const unsigned long long *g = Q.gran + ((long long)(ks % NSLOT) * Q.ntiles + idx) * 4;
+#pragma unroll
+                    for (int q = 0; q < 2 * NG; ++q) gq[j][q] = ld_u64(g + q);
+                }
+            }
+        }
+        // -> this lane's part of the sums (fixed order); a granule that has not arrived yet is polled (bounded)
+        BLR_INL void gather_finish(const ResParams &Q, int ks, double (&acc)[NG]) {
+            const int wv = tid >> 6, lane = tid & 63, tpw = (Q.ntiles + NW - 1) / NW;
+            const unsigned long long want = (unsigned long long)(unsigned)(ks + 1);
+#pragma unroll
+            for (int g2 = 0; g2 < NG; ++g2) acc[g2] = 0.0;
+#pragma unroll
+            for (int j = 0; j < GPL; ++j) {
+                const int loc = lane + 64 * j, idx = wv * tpw + loc;
+                if (loc < tpw && idx < Q.ntiles) {
+                    auto tags_ok = [&]() {
+                        bool ok = true;
+#pragma unroll
+                        for (int q = 0; q < 2 * NG; ++q) ok = ok && (gq[j][q] >> 32) == want;
+                        return ok;
+                    };
+#ifdef BLR_EMULATE
+                    assert(tags_ok() && "lagged sum consumed before published");
+#else
+                    if (!tags_ok()) {
+                        const unsigned long long *g = Q.gran + ((long long)(ks % NSLOT) * Q.ntiles + idx) * 4;
+                        const unsigned long long t0 = now_ticks();
+                        for (unsigned spins = 1;; ++spins) {
+#pragma unroll
+                            for (int q = 0; q < 2 * NG; ++q) gq[j][q] = ld_u64(g + q);
+                            if (tags_ok()) break;
+                            nap();
+                            if ((spins & 255u) == 0u) {
+                                if (ld_flag(Q.abort_word) != 0u) { dead = true; break; }
+                                if (now_ticks() - t0 > Q.timeout_ticks) { st_flag(Q.abort_word, 1u); dead = true; break; }
+                            }
+                        }
+                    }
+#endif
+#pragma unroll
+                    for (int g2 = 0; g2 < NG; ++g2) {
+                        const unsigned long long bits = (gq[j][2 * g2] & 0xffffffffull) | (gq[j][2 * g2 + 1] << 32);
+                        double v;
+#ifdef BLR_EMULATE
+                        std::memcpy(&v, &bits, 8);
+#else
+                        v = __longlong_as_double((long long)bits);
+#endif
+                        acc[g2] += v;
+                    }
+                }
+            }
+        }
+        // 1 / (sum g of step k - lag) from the waves' shares (LDS, after the barrier), or 1 while k < lag.  g = 0: the scale of the
+        // step; g = NG - 1: the normaliser of the row written `lag` steps ago (forward: the same number)
+        BLR_INL double lagged_inverse(const ResParams &Q, int k, int g2) const {
+            if (k < Q.lag) return 1.0;
+            double ssum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) ssum += lds[LDS_MISC + 8 + g2 * NW + w];
+            return 1.0 / ssum;
         }
 
         // ---- axis-1 pass ---------------------------------------------------------------------------------------------------------
         template <int DIR>
-        BLR_INL void h_preread_d() {
-            const double *x0 = lds + launder(hr) * P + first_pos(hs, DIR);
+        BLR_INL void h_preread_d(const Geo &hg) {
+            const double *x0 = lds + hg.line * P + first_pos(hg.seg, DIR);
 #pragma unroll
             for (int k = 0; k < R; ++k) nearv[k] = x0[DIR * (k - R)];
-            if (hfar == 0) {
+            if (hg.far == 0) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) farv[k] = x0[DIR * (SEG + k)];
-            } else if (hfar == 1) {                  // grid edge: half-sample mirror = the segment's own last values
+            } else if (hg.far == 1) {                  // grid edge: half-sample mirror = the segment's own last values
 #pragma unroll
                 for (int k = 0; k < R; ++k) farv[k] = x0[DIR * (SEG - 1 - k)];
             }
         }
-        BLR_INL void h_preread() { if (hs == 0) h_preread_d<-1>(); else h_preread_d<1>(); }
+        BLR_INL void h_preread() { const Geo hg = hgeo(); if (hg.seg == 0) h_preread_d<-1>(hg); else h_preread_d<1>(hg); }
 
         template <int DIR>
-        BLR_INL void h_walk_d(const ResParams &Q, int k) {
-            double *x0 = lds + launder(hr) * P + first_pos(hs, DIR);
+        BLR_INL void h_walk_d(const ResParams &Q, int k, const Geo &hg) {
+            double *x0 = lds + hg.line * P + first_pos(hg.seg, DIR);
             auto far_fetch = [&](double (&f)[R]) {
-                if (hfar == 2) {
-                    if (!wait_ge(Q.flagC + hnb, (unsigned)k, Q)) dead = true;
-                    const double *s = Q.cols + (((long long)((k - 1) & 1) * Q.ntiles + hnb) * 2 + hside) * R * TR + hr;
+                if (hg.far == 2) {
+                    if (!wait_ge(Q.flagC + hg.nb, (unsigned)k, Q)) dead = true;
+                    const double *s = Q.cols + (((long long)((k - 1) & 1) * Q.ntiles + hg.nb) * 2 + hg.side) * R * TR + hg.line;
 #pragma unroll
-                    for (int q = 0; q < R; ++q) f[q] = ld_sc1(s + (long long)(hside == 1 ? R - 1 - q : q) * TR);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < R; ++q) f[q] = farv[q];
+                    for (int q = 0; q < R; ++q) f[q] = ld_sc1(s + (long long)(hg.side == 1 ? R - 1 - q : q) * TR);
                 }
             };
             auto emit8 = [&](int p0, const double (&v)[CHK]) {
@@ -310,14 +431,17 @@ struct Res {
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w1, q);
-            walk<SEG, DIR>(x0, nearv, wk, far_fetch, [](int) {}, emit8);
+            walk<SEG, DIR, CHK>(x0, nearv, farv, hg.far == 2, wk, far_fetch, [](int) {}, emit8);
         }
-        BLR_INL void h_walk(const ResParams &Q, int k) { if (hs == 0) h_walk_d<-1>(Q, k); else h_walk_d<1>(Q, k); }
+        BLR_INL void h_walk(const ResParams &Q, int k) { const Geo hg = hgeo(); if (hg.seg == 0) h_walk_d<-1>(Q, k, hg); else h_walk_d<1>(Q, k, hg); }
 
-        // after the axis-1 pass (barrier): the tile's filtered edge rows -> strips of step k, coalesced, every thread takes part
+        // after the axis-1 pass (barrier): the tile's filtered edge rows -> strips of step k  [side][rr][col]; every thread takes
+        // part, a wave stores 512 contiguous bytes per instruction (scattered 8-byte write-through stores out of the walks'
+        // registers were measured: 2 - 3 x slower walks)
         BLR_INL void publish_rows(const ResParams &Q, int k) {
             double *base = Q.rows + ((long long)(k & 1) * Q.ntiles + tile) * 2 * R * TC;
-            for (int idx = tid; idx < 2 * R * TC; idx += NT) {
+            const int t = launder(tid);
+            for (int idx = t; idx < 2 * R * TC; idx += NT) {
                 const int side = idx / (R * TC), rem = idx - side * (R * TC), rr = rem / TC, col = rem - rr * TC;
                 if (side == 0 ? ti > 0 : ti < tr - 1)          // (my top rows are the up neighbour's lower halo)
                     st_sc1(base + idx, lds[(side ? TR - R + rr : rr) * P + col]);
@@ -326,7 +450,8 @@ struct Res {
         // after the axis-0 pass + epilogue (barrier): the new state's edge columns -> strips of step k  [side][cc][row]
         BLR_INL void publish_cols(const ResParams &Q, int k) {
             double *base = Q.cols + ((long long)(k & 1) * Q.ntiles + tile) * 2 * R * TR;
-            for (int idx = tid; idx < 2 * R * TR; idx += NT) {
+            const int t = launder(tid);
+            for (int idx = t; idx < 2 * R * TR; idx += NT) {
                 const int side = idx / (R * TR), rem = idx - side * (R * TR), cc = rem / TR, row = rem - cc * TR;
                 if (side == 0 ? tj > 0 : tj < tc - 1)
                     st_sc1(base + idx, lds[row * P + (side ? TC - R + cc : cc)]);
@@ -335,34 +460,43 @@ struct Res {
 
         // ---- axis-0 pass + epilogue ----------------------------------------------------------------------------------------------
         template <int DIR>
-        BLR_INL void v_preread_d() {
-            const double *x0 = lds + first_pos(vs, DIR) * P + launder(vc);
+        BLR_INL void v_preread_d(const Geo &vg) {
+            const double *x0 = lds + first_pos(vg.seg, DIR) * P + vg.line;
 #pragma unroll
             for (int k = 0; k < R; ++k) nearv[k] = x0[DIR * (k - R) * P];
-            if (vfar == 0) {
+            if (vg.far == 0) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) farv[k] = x0[DIR * (SEG + k) * P];
-            } else if (vfar == 1) {
+            } else if (vg.far == 1) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) farv[k] = x0[DIR * (SEG - 1 - k) * P];
             }
         }
-        BLR_INL void v_preread() { if (vs == 0) v_preread_d<-1>(); else v_preread_d<1>(); }
+        BLR_INL void v_preread() { const Geo vg = vgeo(); if (vg.seg == 0) v_preread_d<-1>(vg); else v_preread_d<1>(vg); }
 
         // backward: the stored forward state alpha_t of positions p0 .. p0+7 (read before the posterior overwrites it in place)
         template <int DIR>
-        BLR_INL void load_alpha8(const double *pt0, long long n1, int p0) {
+        BLR_INL void load_alpha8(const double *pt0, const double *ptn0, long long n1, int p0) {
             if (BWD) {
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) al8[j] = pt0[(long long)(DIR * (p0 + j)) * n1];
+            }
+            if (ptn0) {                              // the row `lag` steps back, to be normalised in this step
+#pragma unroll
+                for (int j = 0; j < CHK; ++j) nz8[j] = ptn0[(long long)(DIR * (p0 + j)) * n1];
             }
         }
 
         // the epilogue of positions p0 .. p0+7 of this thread's column segment: v = transition output (unscaled).
         // x0 / m0p / pt0 point at position 0 of the segment in the LDS tile / the tile's row coordinates / the global row
         template <int DIR>
-        BLR_INL void epilogue8(const ResParams &Q, double *x0, const double *m0p, double *pt0, int p0, const double (&v)[CHK],
-                               double scale, Rec &rc) {
+        BLR_INL void epilogue8(const ResParams &Q, double *x0, const double *m0p, double *pt0, double *ptn0, double invn, int p0,
+                               const double (&v)[CHK], double scale, Rec &rc, const ColC &cc) {
+            const double g1 = cc.g1, cA = cc.cA, cB = cc.cB;
+            if (ptn0) {
+#pragma unroll
+                for (int j = 0; j < CHK; ++j) ptn0[(long long)(DIR * (p0 + j)) * Q.n1] = nz8[j] * invn;
+            }
             if (p0 % ANCHOR == 0) {
                 // arg(r) = sum_q [-(x_q - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50), along the
                 // walking direction: arg(1) - arg(0) = cA (mu_1 - mu_0) sum_q (2 x_q - mu_0 - mu_1); second difference = -2 cA dn step^2
@@ -420,38 +554,43 @@ struct Res {
         }
 
         template <int DIR>
-        BLR_INL void v_walk_d(const ResParams &Q, int k) {
-            const double scale = lds[LDS_MISC];
+        BLR_INL void v_walk_d(const ResParams &Q, int k, const Geo &vg) {
+            const double scale = lagged_inverse(Q, k, 0);
             Rec rc{1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0, 0, 0};
-            const int r0 = first_pos(vs, DIR), c = launder(vc);
+            const int r0 = first_pos(vg.seg, DIR), c = vg.line;
+            const ColC cc{lds[LDS_COL + c], lds[LDS_COL + TC + c], lds[LDS_COL + 2 * TC + c]};
+#pragma unroll
+            for (int q = 0; q < 5; ++q) sums[q] = 0.0;
             double *x0 = lds + r0 * P + c;
             const double *m0p = lds + LDS_M0 + r0;
-            double *pt0 = Q.post ? Q.post + (long long)time_of(Q, k) * Q.n0 * Q.n1 + (long long)(i0 + r0) * Q.n1 + (j0 + c) : nullptr;
+            double *pt0 = row_ptr(Q, k, r0, c);
+            double *ptn0 = lagged_row_ptr(Q, k, pt0);
+            const double invn = ptn0 ? lagged_inverse(Q, k, NG - 1) : 1.0;
             auto far_fetch = [&](double (&f)[R]) {
-                if (vfar == 2) {
-                    if (!wait_ge(Q.flagR + vnb, (unsigned)k, Q)) dead = true;
-                    const double *s = Q.rows + (((long long)(k & 1) * Q.ntiles + vnb) * 2 + vside) * R * TC + vc;
+                if (vg.far == 2) {
+                    if (!wait_ge(Q.flagR + vg.nb, (unsigned)k, Q)) dead = true;
+                    const double *s = Q.rows + (((long long)(k & 1) * Q.ntiles + vg.nb) * 2 + vg.side) * R * TC + vg.line;
 #pragma unroll
-                    for (int q = 0; q < R; ++q) f[q] = ld_sc1(s + (long long)(vside == 1 ? R - 1 - q : q) * TC);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < R; ++q) f[q] = farv[q];
+                    for (int q = 0; q < R; ++q) f[q] = ld_sc1(s + (long long)(vg.side == 1 ? R - 1 - q : q) * TC);
                 }
             };
-            auto pre8 = [&](int p0) { load_alpha8<DIR>(pt0, Q.n1, p0); };
-            auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, p0, v, scale, rc); };
+            auto pre8 = [&](int p0) { if (SEG != CHK) load_alpha8<DIR>(pt0, ptn0, Q.n1, p0); };     // (one chunk: loaded when the step began)
+            auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc); };
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
-            walk<SEG, DIR * P>(x0, nearv, wk, far_fetch, pre8, emit8);
+            walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_fetch, pre8, emit8);
         }
-        BLR_INL void v_walk(const ResParams &Q, int k) { if (vs == 0) v_walk_d<-1>(Q, k); else v_walk_d<1>(Q, k); }
+        BLR_INL void v_walk(const ResParams &Q, int k) { const Geo vg = vgeo(); if (vg.seg == 0) v_walk_d<-1>(Q, k, vg); else v_walk_d<1>(Q, k, vg); }
 
         // the first executed step has no transition: its input is src0 (prior / uniform), scale 1
         template <int DIR>
-        BLR_INL void first_step_d(const ResParams &Q) {
+        BLR_INL void first_step_d(const ResParams &Q, const Geo &vg) {
             Rec rc{1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0, 0, 0};
-            const int r0 = first_pos(vs, DIR), c = launder(vc);
+            const int r0 = first_pos(vg.seg, DIR), c = vg.line;
+            const ColC cc{lds[LDS_COL + c], lds[LDS_COL + TC + c], lds[LDS_COL + 2 * TC + c]};
+#pragma unroll
+            for (int q = 0; q < 5; ++q) sums[q] = 0.0;
             double *x0 = lds + r0 * P + c;
             const double *m0p = lds + LDS_M0 + r0;
             const long long g0 = (long long)(i0 + r0) * Q.n1 + (j0 + c);
@@ -462,15 +601,15 @@ struct Res {
                 double v[CHK];
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) v[j] = s[(long long)(DIR * (p0 + j)) * Q.n1];
-                load_alpha8<DIR>(pt0, Q.n1, p0);
-                epilogue8<DIR>(Q, x0, m0p, pt0, p0, v, 1.0, rc);
+                load_alpha8<DIR>(pt0, nullptr, Q.n1, p0);
+                epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, 1.0, p0, v, 1.0, rc, cc);
             }
         }
-        BLR_INL void first_step(const ResParams &Q) { if (vs == 0) first_step_d<-1>(Q); else first_step_d<1>(Q); }
+        BLR_INL void first_step(const ResParams &Q) { const Geo vg = vgeo(); if (vg.seg == 0) first_step_d<-1>(Q, vg); else first_step_d<1>(Q, vg); }
     };
 
-    // ---- the lagged global sum: publish / gather (one granule pair per tile and step) ----------------------------------------
-    BLR_INL static void publish_sum(const ResParams &Q, int tile, int k, double value) {
+    // ---- the lagged global sums: one tagged granule pair per tile, step and sum -----------------------------------------------------
+    BLR_INL static void publish_sum(const ResParams &Q, int tile, int k, int which, double value) {
         unsigned long long bits;
 #ifdef BLR_EMULATE
         std::memcpy(&bits, &value, 8);
@@ -478,46 +617,9 @@ struct Res {
         bits = (unsigned long long)__double_as_longlong(value);
 #endif
         const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
-        unsigned long long *g = Q.gran + ((long long)(k % NSLOT) * Q.ntiles + tile) * 2;
+        unsigned long long *g = Q.gran + ((long long)(k % NSLOT) * Q.ntiles + tile) * 4 + 2 * which;
         st_u64(g, tag | (bits & 0xffffffffull));
         st_u64(g + 1, tag | (bits >> 32));
-    }
-
-    // sum of the tiles' partials of step ks, tiles lane, lane + nl, ... in this order (nl lanes cooperate); false = timed out
-    BLR_INL static bool gather_partial(const ResParams &Q, int ks, int lane, int nl, double &out) {
-        const unsigned long long want = (unsigned long long)(unsigned)(ks + 1);
-        double acc = 0.0;
-        bool ok = true;
-        for (int idx = lane; idx < Q.ntiles; idx += nl) {
-            const unsigned long long *g = Q.gran + ((long long)(ks % NSLOT) * Q.ntiles + idx) * 2;
-            unsigned long long a = ld_u64(g), b = ld_u64(g + 1);
-#ifdef BLR_EMULATE
-            assert((a >> 32) == want && (b >> 32) == want && "lagged sum consumed before published");
-#else
-            if ((a >> 32) != want || (b >> 32) != want) {
-                const unsigned long long t0 = now_ticks();
-                for (unsigned spins = 1; ok; ++spins) {
-                    nap();
-                    a = ld_u64(g); b = ld_u64(g + 1);
-                    if ((a >> 32) == want && (b >> 32) == want) break;
-                    if ((spins & 255u) == 0u) {
-                        if (ld_flag(Q.abort_word) != 0u) ok = false;
-                        else if (now_ticks() - t0 > Q.timeout_ticks) { st_flag(Q.abort_word, 1u); ok = false; }
-                    }
-                }
-            }
-#endif
-            const unsigned long long bits = (a & 0xffffffffull) | (b << 32);
-            double v;
-#ifdef BLR_EMULATE
-            std::memcpy(&v, &bits, 8);
-#else
-            v = __longlong_as_double((long long)bits);
-#endif
-            acc += v;
-        }
-        out = acc;
-        return ok;
     }
 };
 
@@ -540,71 +642,108 @@ __device__ __forceinline__ void arrive_and_flag(double *misc, unsigned *flag, un
     }
 }
 
-template <int TR, int TC, int SEG, bool BWD>
+template <int TR, int TC, int SEG, int CHK, bool BWD>
 __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Q) {
-    using K = Res<TR, TC, SEG, BWD>;
-    constexpr int NT = K::NT, NW = NT / 64;
+    using K = Res<TR, TC, SEG, CHK, BWD>;
+    constexpr int NT = K::NT, NW = K::NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *misc = lds + K::LDS_MISC;
-    double *red = misc + 8;
+    double *red = lds + K::LDS_RED;
     const int tid = threadIdx.x;
     typename K::Thread th;
     th.init(Q, blockIdx.x, tid, lds);
     for (int e = tid; e < TR; e += NT) lds[K::LDS_M0 + e] = Q.m0[th.i0 + e];
-    if (tid == 0) { misc[0] = 1.0; misc[1] = 0.0; misc[2] = 0.0; }
+    for (int e = tid; e < TC; e += NT) {
+        lds[K::LDS_COL + e] = Q.m1[th.j0 + e]; lds[K::LDS_COL + TC + e] = Q.colA[th.j0 + e]; lds[K::LDS_COL + 2 * TC + e] = Q.colB[th.j0 + e];
+    }
+    if (tid == 0) { misc[1] = 0.0; misc[2] = 0.0; }
     __syncthreads();
 
+#ifdef BLR_PROF
+    const bool prof_me = Q.prof && th.tile == Q.ntiles / 2 + Q.tc / 2 && (tid == 0 || tid == 128);     // an edge wave and a middle one
+#define BLR_STAMP(i) do { if (prof_me && k >= 8 && k < 24) Q.prof[(tid ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BLR_STAMP(i) do { } while (0)
+#endif
+    constexpr bool ONE = SEG == CHK;                  // one-chunk segments: a hand-off is needed the moment a pass begins
     for (int k = 0; k < Q.T; ++k) {
         const int t = K::Thread::time_of(Q, k);
+        BLR_STAMP(0);
         th.begin_step(Q, k);
         if (k == 0) {
             th.first_step(Q);
         } else {
             th.h_preread();
+            // multi-chunk tiles: the edge columns of step k - 1 went out at the end of that step; their acknowledgements had the
+            // LDS reads above to arrive, and the neighbours need them only for their last chunk
+            if (!ONE) arrive_and_flag<NW>(misc, Q.flagC + th.tile, (unsigned)k);
+            if (k >= Q.lag) th.gather_issue(Q, k - Q.lag);
             __syncthreads();
+            BLR_STAMP(1);
             th.h_walk(Q, k);
+            BLR_STAMP(2);
             __syncthreads();
+            BLR_STAMP(3);
             th.publish_rows(Q, k);
             th.v_preread();
-            if (tid < 64) {                           // wave 0: the scale of this step from the sums of step k - lag
-                double s = 1.0;
-                if (k >= Q.lag) {
-                    double part;
-                    if (!K::gather_partial(Q, k - Q.lag, tid, 64, part)) th.dead = true;
-                    s = 1.0 / blk::wave_sum(part);
-                }
-                if (tid == 0) misc[0] = s;
-            }
-            arrive_and_flag<NW>(misc, Q.flagR + th.tile, (unsigned)k);
-            __syncthreads();
-            th.v_walk(Q, k);
-        }
-        // ---- sums of the step: partials for the host, the scale sum for the other tiles ----------------------------------------
-        if (th.dead) misc[1] = 1.0;
-        double *out = Q.psum + (long long)t * NRED * Q.ntiles + th.tile;
-        if (BWD) {
-            double v[5] = {th.sums[0], th.sums[1], th.sums[2], th.sums[3], th.sums[4]};
-            blk::block_sums<5, NW>(v, red);
-            if (tid == 0) {
+            if (k >= Q.lag) {
+                double part[K::NG];
+                th.gather_finish(Q, k - Q.lag, part);
 #pragma unroll
-                for (int q = 0; q < 5; ++q) out[(long long)q * Q.ntiles] = v[q];
-                K::publish_sum(Q, th.tile, k, v[2]);
+                for (int g2 = 0; g2 < K::NG; ++g2) {
+                    const double ws = blk::wave_sum(part[g2]);
+                    if ((tid & 63) == 0) misc[8 + g2 * NW + (tid >> 6)] = ws;
+                }
             }
-        } else if (Q.means) {
-            double v[3] = {th.sums[0], th.sums[3], th.sums[4]};
-            blk::block_sums<3, NW>(v, red);
-            if (tid == 0) {
-                out[0] = v[0]; out[3LL * Q.ntiles] = v[1]; out[4LL * Q.ntiles] = v[2];
-                K::publish_sum(Q, th.tile, k, v[0]);
-            }
-        } else {
-            double v[1] = {th.sums[0]};
-            blk::block_sums<1, NW>(v, red);
-            if (tid == 0) { out[0] = v[0]; K::publish_sum(Q, th.tile, k, v[0]); }
+            BLR_STAMP(4);
+            arrive_and_flag<NW>(misc, Q.flagR + th.tile, (unsigned)k);
+            BLR_STAMP(5);
+            __syncthreads();
+            BLR_STAMP(6);
+            th.v_walk(Q, k);
+            BLR_STAMP(7);
         }
-        // (block_sums ends with a barrier: the tile's new state is complete in LDS)
-        th.publish_cols(Q, k);
-        arrive_and_flag<NW>(misc, Q.flagC + th.tile, (unsigned)(k + 1));
+        // ---- sums of the step: partials for the host, the lagged sums for the other tiles.  ONE barrier: every wave leaves its
+        //      sums in LDS, then all threads copy the edge columns out while thread 0 adds the waves' sums (fixed order) ----------
+        if (th.dead) misc[1] = 1.0;
+        {
+            constexpr int NV = BWD ? 5 : 3;
+            double v[NV];
+            if (BWD) { v[0] = th.sums[0]; v[1] = th.sums[1]; v[2] = th.sums[2]; v[3] = th.sums[3]; v[4] = th.sums[4]; }
+            else { v[0] = th.sums[0]; v[1] = th.sums[3]; v[2] = th.sums[4]; }
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                if (!BWD && q > 0 && !Q.means) break;
+                const double ws = blk::wave_sum(v[q]);
+                if ((tid & 63) == 0) red[(tid >> 6) * NV + q] = ws;
+            }
+            __syncthreads();                          // the tile's new state is complete in LDS, the waves' sums and misc[1] are final
+            BLR_STAMP(8);
+            th.publish_cols(Q, k);
+            if (tid == 0) {
+                double *out = Q.psum + (long long)t * NRED * Q.ntiles + th.tile;
+                double tot[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    tot[q] = 0.0;
+                    if (!BWD && q > 0 && !Q.means) continue;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) tot[q] += red[w * NV + q];
+                }
+                if (BWD) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) out[(long long)q * Q.ntiles] = tot[q];
+                    K::publish_sum(Q, th.tile, k, 0, tot[2]);
+                    K::publish_sum(Q, th.tile, k, 1, tot[0]);
+                } else {
+                    out[0] = tot[0];
+                    if (Q.means) { out[3LL * Q.ntiles] = tot[1]; out[4LL * Q.ntiles] = tot[2]; }
+                    K::publish_sum(Q, th.tile, k, 0, tot[0]);
+                }
+            }
+        }
+        if (ONE) arrive_and_flag<NW>(misc, Q.flagC + th.tile, (unsigned)(k + 1));
+        BLR_STAMP(9);
         if (misc[1] != 0.0) return;                   // a wait timed out somewhere in this block: uniform exit (host falls back)
     }
 }

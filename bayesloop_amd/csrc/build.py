@@ -30,6 +30,17 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps() if os.path.exists(d))
 
 
+def build_variant(name, flags, verbose=True):
+    """Development variants of the library (e.g. -DBLR_PROF: phase stamps of the time-resident kernel), built next to the product
+    as libblhip_<name>.so and selected with BLHIP_LIBRARY=...; never the default."""
+    out = os.path.join(os.path.dirname(HERE), 'libblhip_%s.so' % name)
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-o', out] + list(flags) + SOURCES + ['-ldl']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=HERE)
+    return out
+
+
 def build(force=False, verbose=True):
     if not force and not stale():
         return OUT
@@ -47,4 +58,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--variant' in sys.argv:
+        k = sys.argv.index('--variant')
+        build_variant(sys.argv[k + 1], sys.argv[k + 2:])
+    else:
+        build(force='--force' in sys.argv)

@@ -63,10 +63,10 @@ static std::vector<double> likelihood(const Problem &p, int t) {
     return L;
 }
 
-template <int TR, int TC, int SEG>
+template <int TR, int TC, int SEG, int CHK = 8>
 static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
-    using KF = Res<TR, TC, SEG, false>;
-    using KB = Res<TR, TC, SEG, true>;
+    using KF = Res<TR, TC, SEG, CHK, false>;
+    using KB = Res<TR, TC, SEG, CHK, true>;
     Problem p;
     p.n0 = tr * TR; p.n1 = tc * TC; p.T = T; p.d = 1;
     std::mt19937_64 rng(seed);
@@ -126,7 +126,7 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
     std::vector<double> gpost((size_t)T * G, 0.0), uniform(G, 1.0 / G);
     std::vector<double> cols((size_t)2 * ntiles * 2 * R * TR), rows((size_t)2 * ntiles * 2 * R * TC);
     std::vector<unsigned> flagC(ntiles), flagR(ntiles);
-    std::vector<unsigned long long> gran((size_t)NSLOT * ntiles * 2);
+    std::vector<unsigned long long> gran((size_t)NSLOT * ntiles * 4);
     unsigned abort_word = 0;
     ResParams Q{};
     Q.n0 = p.n0; Q.n1 = p.n1; Q.tr = tr; Q.tc = tc; Q.ntiles = ntiles; Q.T = T; Q.d = 1; Q.rec_len = 1; Q.lag = lag;
@@ -148,7 +148,9 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
                 auto &x = th[(size_t)b * NT + t];
                 x.init(Q, b, t, lds[b].data());
                 for (int e = 0; e < TR; ++e) lds[b][K::LDS_M0 + e] = p.m0[x.i0 + e];
-                lds[b][K::LDS_MISC] = 1.0;
+                for (int e = 0; e < TC; ++e) {
+                    lds[b][K::LDS_COL + e] = p.m1[x.j0 + e]; lds[b][K::LDS_COL + TC + e] = p.colA[x.j0 + e]; lds[b][K::LDS_COL + 2 * TC + e] = p.colB[x.j0 + e];
+                }
             }
         psum.assign((size_t)T * NRED * ntiles, 0.0);
         Q.psum = psum.data();
@@ -159,19 +161,22 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
                 for (auto &x : th) x.first_step(Q);
             } else {
                 for (auto &x : th) x.h_preread();
+                if (k >= lag) for (auto &x : th) x.gather_issue(Q, k - lag);
                 for (auto &x : th) x.h_walk(Q, k);
                 for (auto &x : th) x.publish_rows(Q, k);
                 for (int b = 0; b < ntiles; ++b) flagR[th[(size_t)b * NT].tile] = (unsigned)k;
                 for (auto &x : th) x.v_preread();
-                for (int b = 0; b < ntiles; ++b) {
-                    double s = 1.0;
-                    if (k >= lag) {
-                        double tot = 0.0;
-                        for (int lane = 0; lane < 64; ++lane) { double part; K::gather_partial(Q, k - lag, lane, 64, part); tot += part; }
-                        s = 1.0 / tot;
-                    }
-                    lds[b][K::LDS_MISC] = s;
-                }
+                if (k >= lag)
+                    for (int b = 0; b < ntiles; ++b)
+                        for (int w = 0; w < K::NW; ++w) {
+                            double part[K::NG] = {};
+                            for (int lane = 0; lane < 64; ++lane) {
+                                double a[K::NG];
+                                th[(size_t)b * NT + w * 64 + lane].gather_finish(Q, k - lag, a);
+                                for (int g2 = 0; g2 < K::NG; ++g2) part[g2] += a[g2];
+                            }
+                            for (int g2 = 0; g2 < K::NG; ++g2) lds[b][K::LDS_MISC + 8 + g2 * K::NW + w] = part[g2];
+                        }
                 for (auto &x : th) x.v_walk(Q, k);
             }
             for (int b = 0; b < ntiles; ++b) {
@@ -180,7 +185,8 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
                     for (int q = 0; q < 5; ++q) v[q] += th[(size_t)b * NT + t].sums[q];
                 const int tile = th[(size_t)b * NT].tile;
                 for (int q = 0; q < 5; ++q) psum[((size_t)tt * NRED + q) * ntiles + tile] = v[q];
-                K::publish_sum(Q, tile, k, K::BWD ? v[2] : v[0]);
+                K::publish_sum(Q, tile, k, 0, K::BWD ? v[2] : v[0]);
+                if (K::BWD) K::publish_sum(Q, tile, k, 1, v[0]);
             }
             for (auto &x : th) x.publish_cols(Q, k);
             for (int b = 0; b < ntiles; ++b) flagC[th[(size_t)b * NT].tile] = (unsigned)(k + 1);
@@ -197,7 +203,7 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
         }
     };
     std::vector<double> psF, psB;
-    Q.src0 = p.prior.data(); Q.store = 1; Q.means = 1;
+    Q.src0 = p.prior.data(); Q.store = 1; Q.means = 1; Q.normalise = 0;
     if (!pass(KF{}, psF)) return 1;
     // undo the lag: S_k actual sums; norm_0 = S_0, norm_k = S_k / (S_{k-1} s_k), s_k = k >= lag ? 1 / S_{k-lag} : 1
     std::vector<double> S(T);
@@ -212,13 +218,21 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
         check("mean0", m0 / S[t], mref, 1e-11);
         for (size_t c = 0; c < G; ++c) check("alpha", gpost[(size_t)t * G + c] / S[t], alpha[t][c], 1e-10);
     }
-    Q.src0 = uniform.data();
+    {   // forward-only style: rows normalised in the kernel, `lag` steps behind (the last `lag` rows are left raw)
+        std::vector<double> keep = gpost, psF2;
+        Q.normalise = 1;
+        if (!pass(KF{}, psF2)) return 1;
+        for (int t = 0; t < T; ++t)
+            for (size_t c = 0; c < G; ++c) check("alpha (in-kernel normalisation)", gpost[(size_t)t * G + c] / (t <= T - 1 - lag ? 1.0 : S[t]), alpha[t][c], 1e-10);
+        gpost = keep;
+    }
+    Q.src0 = uniform.data(); Q.normalise = 1;
     if (!pass(KB{}, psB)) return 1;
     for (int t = 0; t < T; ++t) {
         double N = 0.0, Sl = 0.0;
         for (int b = 0; b < ntiles; ++b) { N += psB[((size_t)t * NRED) * ntiles + b]; Sl += psB[((size_t)t * NRED + 1) * ntiles + b]; }
         check("localEvidence", 1.0 / (Sl / N), locB[t], 1e-11);
-        for (size_t c = 0; c < G; ++c) check("posterior", gpost[(size_t)t * G + c] / N, post[t][c], 1e-10);
+        for (size_t c = 0; c < G; ++c) check("posterior", gpost[(size_t)t * G + c] / (t >= lag ? 1.0 : N), post[t][c], 1e-10);
     }
     std::printf("tile %dx%d seg %d, grid %dx%d (%d tiles), T=%d, lag=%d, %s: %s (%d mismatches)\n", TR, TC, SEG, p.n0, p.n1, ntiles, T, lag,
                 one_axis ? "axis 1 only" : "both axes", bad ? "FAIL" : "ok", bad);
@@ -233,6 +247,9 @@ int main() {
     rc |= run<64, 64, 8>(2, 2, 6, 2, 4, false);
     rc |= run<64, 64, 16>(2, 1, 6, 2, 5, false);
     rc |= run<128, 128, 32>(1, 2, 5, 2, 6, false);
+    rc |= run<128, 128, 16, 4>(2, 1, 5, 2, 8, false);  // 1024 threads, 4-output chunks
+    rc |= run<64, 64, 16, 4>(2, 2, 6, 3, 9, false);
+    rc |= run<32, 32, 8, 4>(3, 3, 7, 1, 10, true);
     rc |= run<32, 32, 8>(4, 4, 12, 2, 7, false);      // 16 tiles: the XCD-friendly block -> tile map is a permutation
     return rc;
 }
