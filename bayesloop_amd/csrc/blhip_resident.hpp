@@ -720,7 +720,9 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             __syncthreads();                          // the tile's new state is complete in LDS, the waves' sums and misc[1] are final
             BLR_STAMP(8);
             th.publish_cols(Q, k);
-            if (tid == 0) {
+            // the flag of the edge columns goes out before the bookkeeping stores below: nobody waits for those
+            if (ONE) arrive_and_flag<NW>(misc, Q.flagC + th.tile, (unsigned)(k + 1));
+            if (tid == NT - 64) {                     // (lane 0 of the LAST wave: an interior segment, off the hand-off-critical edge waves)
                 double *out = Q.psum + (long long)t * NRED * Q.ntiles + th.tile;
                 double tot[NV];
 #pragma unroll
@@ -742,7 +744,6 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
                 }
             }
         }
-        if (ONE) arrive_and_flag<NW>(misc, Q.flagC + th.tile, (unsigned)(k + 1));
         BLR_STAMP(9);
         if (misc[1] != 0.0) return;                   // a wait timed out somewhere in this block: uniform exit (host falls back)
     }
