@@ -433,17 +433,20 @@ void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd) {
 void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
     if (rp.TR == 128) launch_resident_t<128, 128, RES_SEG128, RES_CHK128>(s, Q, bwd);
     else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd);
+    else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd);
     else launch_resident_t<32, 32, 8, 8>(s, Q, bwd);
     HIPCHECK(hipGetLastError());
 }
 
 // the smallest supported tile whose tile grid fits the chip (every tile = one co-resident block)
-bool plan_resident(int n0, int n1, int max_tiles, ResidentPlan &rp) {
-    const int shapes[3][3] = {{32, 32, 8}, {64, 64, 8}, {128, 128, RES_SEG128}};
+// (Two 256-thread blocks per CU -- 512 tiles of 32 x 64 for the 1024^2 grid, so that one block computes while the other waits for a
+// strip -- was tried: the 512 blocks were not all co-resident, the hand-off waits timed out and the fit fell back.  One tile per CU.)
+bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp) {
+    const int shapes[4][3] = {{32, 32, 8}, {32, 64, 8}, {64, 64, 8}, {128, 128, RES_SEG128}};
     for (const auto &sh : shapes) {
         if (n0 % sh[0] || n1 % sh[1]) continue;
         const long long nt = (long long)(n0 / sh[0]) * (n1 / sh[1]);
-        if (nt > max_tiles) continue;
+        if (nt > cus) continue;
         rp.TR = sh[0]; rp.TC = sh[1]; rp.SEG = sh[2]; rp.tr = n0 / sh[0]; rp.tc = n1 / sh[1]; rp.ntiles = (int)nt;
         rp.NT = sh[0] * sh[1] / sh[2];
         return true;
@@ -740,9 +743,11 @@ void ensure_post_scaled(blhip_ctx *ctx) {
     HIPCHECK(hipSetDevice(ctx->device));
     const long long G = ctx->post_G;
     const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-    for (int64_t b = 0; b < ctx->post_chains; ++b)
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)ctx->post_T), dim3(NTHREADS), 0, ctx->stream,
-                           ctx->post.as<double>() + (size_t)b * ctx->post_T * G, G, ctx->postinv.as<double>() + b * ctx->post_T);
+    // (rows [post_row0, post_row1) only: the time-resident kernel has normalised the others itself)
+    const int64_t r0 = ctx->post_row0, nrows = ctx->post_row1 - ctx->post_row0;
+    for (int64_t b = 0; b < ctx->post_chains && nrows > 0; ++b)
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, (unsigned)nrows), dim3(NTHREADS), 0, ctx->stream,
+                           ctx->post.as<double>() + ((size_t)b * ctx->post_T + r0) * G, G, ctx->postinv.as<double>() + b * ctx->post_T + r0);
     HIPCHECK(hipGetLastError());
     ctx->post_scaled = true;
 }
@@ -1605,6 +1610,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             HIPCHECK(hipMemcpyAsync(ctx->postinv.p, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
             sync_stream(ctx, st);
             ctx->post_valid = true; ctx->post_scaled = false; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = G;
+            ctx->post_row0 = 0; ctx->post_row1 = T;
+            if (resident && !resident_failed) {      // rows the resident kernel normalised in place (invN = 1 there)
+                if (full) ctx->post_row1 = std::min<int64_t>(T, RQ.lag);
+                else ctx->post_row0 = std::max<int64_t>(0, T - RQ.lag);
+            }
             ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
             // default: normalise now, as part of the fit (core.py:441 is inside Study.fit); option lazy_normalise = 1 defers
             // the pass to the first access of the sequence

@@ -93,6 +93,7 @@ struct blhip_ctx {
     bool post_scaled = true;     // false: the kept rows still carry their raw sums; postinv holds 1 / sum per (chain, step)
     DevBuf postinv;
     int64_t post_chains = 0, post_T = 0, post_G = 0;
+    int64_t post_row0 = 0, post_row1 = 0;        // rows of the kept sequence that still carry their raw sums
     int post_n0 = 1, post_n1 = 1, acc_n0 = 1, acc_n1 = 1;
     // accumulator
     bool acc_active = false, acc_final = false, acc_first = true;

@@ -233,7 +233,7 @@ struct Res {
     static_assert(TR % SEG == 0 && TC % SEG == 0 && TR >= 2 * R && TC >= 2 * R && ANCHOR % CHK == 0, "tile shape");
     static constexpr int NW = NT / 64;
     static_assert(NT % 64 == 0, "whole waves");
-    static constexpr int GPL = (256 / NW + 63) / 64;     // tiles per lane when NW waves share the <= 256 tiles' partial sums
+    static constexpr int GPL = (512 / NW + 63) / 64;     // tiles per lane when NW waves share the <= 512 tiles' partial sums
     static constexpr int NG = BWD ? 2 : 1;               // sums every tile publishes per step: the scale sum (forward: sum a = the row sum;
                                                          // backward: sum c) and, backward, the row sum of the posterior
     static constexpr int LDS_TILE = TR * P;          // doubles

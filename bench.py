@@ -139,22 +139,25 @@ def rel_err(got, want):
     return abs(got - want) / abs(want)
 
 
-def roofline_of(timing, cells_per_launch):
-    """achieved GB/s of the dominant step kernel from the library's HIP-event timing of its own stream."""
+def roofline_of(timing, units):
+    """achieved GB/s of the dominant step kernel from the library's HIP-event timing of its own stream.  `units` = cells x steps x
+    chains this rank's fit processed; a pass moves bytes_per_cell_step x units in the HIP-event time of all its launches, whatever the
+    batch sizes (batches are cut on radius-bucket boundaries and need not be equal).  cells_per_launch = the average logical launch."""
     out = {}
     for key, bytes_per in (('forward', BYTES_FWD), ('backward', BYTES_BWD)):
         n = timing.get(key + '_launches', 0)
         ms = timing.get(key + '_ms', 0.0)
         if n and ms > 0:
             per_launch_s = ms * 1e-3 / n
+            cells_per_launch = units / n
             variant = timing.get('fwd_kernel_variant' if key == 'forward' else 'bwd_kernel_variant', 0)
             kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel', 4: 'bl1f::fused1d_kernel (8 time steps per launch)',
-                     3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)'}.get(variant, 'step_kernel')
-            out[key] = dict(kernel='%s<%s> (one logical step launch = all radius-bucket launches of the batch)' % (kname, key),
-                            launches=int(n), avg_launch_us=per_launch_s * 1e6,
+                     3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)',
+                     5: 'blr::resident_kernel (ONE launch for all time steps; a logical launch = one time step of it)'}.get(variant, 'step_kernel')
+            out[key] = dict(kernel='%s<%s> (one logical step launch = all launches of one time step of a batch)' % (kname, key),
+                            launches=int(n), avg_launch_us=per_launch_s * 1e6, cells_per_launch=cells_per_launch,
                             achieved=bytes_per * cells_per_launch / per_launch_s / 1e9, bytes_per_cell_step=bytes_per)
     return out
-
 
 
 def run_workload(bl, name, steps, warmup, comm, barrier):
@@ -318,7 +321,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = units * args.steps / dt
-        rf = roofline_of(timing, timing.get('cells_per_launch', 0))
+        rf = roofline_of(timing, units / world)
         dom = max(rf.values(), key=lambda r: r['avg_launch_us'] * r['launches']) if rf else None
         roof = None
         if dom:
@@ -330,7 +333,7 @@ def main():
             roof = dict(bound='hbm', achieved=dom['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=dom['achieved'] / HBM_PEAK_GBS, traffic=traffic, traffic_from=src, kernel=dom['kernel'],
                         avg_launch_us=dom['avg_launch_us'], bytes_per_cell_step=dom['bytes_per_cell_step'],
-                        cells_per_launch=int(timing.get('cells_per_launch', 0)),
+                        cells_per_launch=dom['cells_per_launch'],
                         peak_calibrated=peak_cal, frac_calibrated=dom['achieved'] / peak_cal if peak_cal else None,
                         peak_calibrated_from='blhip_bandwidth_probe: 16-B-per-lane streaming copy of 1 GiB, read + write')
         gold = golden_log_evidence(args.workload)
@@ -360,7 +363,7 @@ def main():
                     g2 = golden_log_evidence(name)
                     extra[name] = dict(value=u2 / dt2, ms_per_step=dt2 * 1e3, log_evidence=float(S2.logEvidence),
                                        log_evidence_reference=g2, log_evidence_rel_err=rel_err(float(S2.logEvidence), g2),
-                                       config=d2, kernels=roofline_of(tm, tm.get('cells_per_launch', 0)))
+                                       config=d2, kernels=roofline_of(tm, u2))
                     if name == 'c3':
                         extra[name]['end_to_end'] = end_to_end(bl, S2, dict(silent=True), u2)
                     S2._posterior_pending = None

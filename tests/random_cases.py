@@ -3,6 +3,7 @@
 import numpy as np
 
 import cases
+import tolerances
 
 
 def random_case(seed):
@@ -90,7 +91,7 @@ def random_model_case(seed):
         # a dozen cubic-spline shifts of a distribution that runs into the grid edge leave ringing (negative lobes); the
         # reference then divides by a sum that can be 1e-2 .. 1e-3 of the mass (or negative), which amplifies any rounding
         # difference by that factor per step: seen 8e-10 relative in one of 6000 configurations
-        tol = dict(cases.FFT_TOL, post_rtol=2e-8, logE_rtol=1e-10, small_rtol=2e-8)
+        tol = tolerances.DETERMINISTIC_FUZZ_TOL
     elif kind == 'serial':
         tb = int(rng.integers(1, T - 1)) if T > 2 else 0
         c = dict(study='Study', data=counts, om=pois,

@@ -1,0 +1,48 @@
+"""
+The parity bar and EVERY exception to it, in one place (DESIGN.md section 6 lists the same entries; tests/test_tolerance_registry.py
+fails when a test grants itself a tolerance that is not registered here, or when DESIGN.md does not name a registered exception).
+
+Bar (BASELINE.json / SURVEY.md 8d, float64):  log-evidence 1e-9 relative;  posteriors |dp| <= 1e-12 + 1e-9 p  (compare.GPU_TOL).
+"""
+BAR = dict(logE_rtol=1e-9, post_rtol=1e-9, post_atol=1e-12, small_rtol=1e-9, small_atol=1e-12)
+
+# one backward local-evidence entry of a step whose grid holds DENORMAL likelihood values (see ILL_LOCAL_EVIDENCE below)
+ILL_LOCAL_RTOL = 2e-2
+# the reference's own FFT / recursive-prefilter round-off (~1e-17 ABSOLUTE) -- a floor for the ORACLE-vs-reference comparison (whose
+# absolute tolerance is otherwise 1e-300); on the GPU it is inside the bar (1e-15 < 1e-12)
+FFT_TOL = dict(post_atol=1e-15, post_rtol=1e-9, logE_rtol=1e-12)
+# seeded Deterministic-model fuzz (tests/random_cases.py)
+DETERMINISTIC_FUZZ_TOL = dict(FFT_TOL, post_rtol=2e-8, logE_rtol=1e-10, small_rtol=2e-8)
+# the fixture cases.py: wide_filter_2d
+WIDE_FILTER_2D_TOL = dict(local_rtol=1e-3)
+
+EXCEPTIONS = {
+    'ILL_LOCAL_EVIDENCE': dict(
+        value=dict(local_rtol=ILL_LOCAL_RTOL), above_bar=True,
+        where='tests/test_gpu_parity.py: seeded random configurations / resident-kernel cases, ONLY for steps whose likelihood has '
+              'denormal cells (or the reference itself returns NaN = 0/0), decided by _ill_conditioned_local_evidence()',
+        seeds='3 of 6000 configurations of random_case (e.g. seed 2641): 1.6e-3 relative in ONE backward localEvidence entry',
+        reason='core.py:463 localEvidence = 1 / sum(post / L): a denormal L carries 1..52 significant bits, post / L at such a cell '
+               'can dominate the sum, so the reference value itself is defined to a few digits only; every other number of those '
+               'cases keeps the 1e-9 bar'),
+    'WIDE_FILTER_2D': dict(
+        value=WIDE_FILTER_2D_TOL, above_bar=True,
+        where='tests/cases.py: wide_filter_2d (golden fixture), backward localEvidence only',
+        seeds='fixture wide_filter_2d (std values down to 0.08 put denormal likelihood values on the grid at step 0)',
+        reason='same conditioning as ILL_LOCAL_EVIDENCE: any change of operation order moves the golden value at the 1e-4 level'),
+    'DETERMINISTIC_FUZZ': dict(
+        value=DETERMINISTIC_FUZZ_TOL, above_bar=True,
+        where='tests/random_cases.py: random_model_case(kind == "deterministic") -- posteriors / means / local evidence 2e-8; the '
+              'log-evidence stays at 1e-10',
+        seeds='1 of 12 000 configurations (random_model_case seed 5 + 13 k family) at 8e-10, none above 2e-8',
+        reason='transitionModels.py:581-602: a dozen cubic-spline shifts of a distribution that runs into the grid edge leave ringing; '
+               'the reference renormalises by a sum that is 1e-2 .. 1e-3 of the mass (or negative), which amplifies any rounding '
+               'difference by that factor per step'),
+    'FFT_FLOOR': dict(
+        value=FFT_TOL, above_bar=False,
+        where='tests/cases.py (AlphaStable / Deterministic fixtures), tests/random_cases.py (alphastable): absolute floor 1e-15 of the '
+              'oracle-vs-reference and HIP-vs-golden posterior comparison',
+        seeds='kat_alphastable, alphastable_2d_hyper, alphastable_std, deterministic_* fixtures',
+        reason='scipy.signal.fftconvolve / scipy.ndimage.shift round-off of the reference is ~1e-17 absolute, not relative to the '
+               '(possibly 1e-200) posterior value'),
+}

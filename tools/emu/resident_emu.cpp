@@ -250,6 +250,7 @@ int main() {
     rc |= run<128, 128, 16, 4>(2, 1, 5, 2, 8, false);  // 1024 threads, 4-output chunks
     rc |= run<64, 64, 16, 4>(2, 2, 6, 3, 9, false);
     rc |= run<32, 32, 8, 4>(3, 3, 7, 1, 10, true);
+    rc |= run<32, 64, 8>(3, 2, 7, 2, 11, false);        // rectangular tile (two blocks per CU on the device)
     rc |= run<32, 32, 8>(4, 4, 12, 2, 7, false);      // 16 tiles: the XCD-friendly block -> tile map is a permutation
     return rc;
 }

@@ -57,14 +57,14 @@ if __name__ == '__main__':
     out = {}
     for path in sys.argv[1:]:
         w = os.path.basename(path.rstrip('/')).replace('prof_r02_', '')
-        if w == 'c4':        # bench.py --steps 1 --warmup 1 => 2 fits x T = 256 time steps per direction, cells = all 512 chains of a step
-            out.update(summarise(path, steps=2 * 256, cells=512 * 512 * 512))
-        elif w == 'fwd2048':  # 2 fits x 200 steps in one resident launch each
-            r = summarise(path, steps=2 * 200, cells=2048 * 2048)
+        if w == 'c4':        # bench.py --steps 1 --warmup 1 => 3 fits (warm-up, timed, end-to-end) x T = 256 time steps per direction, cells = all 512 chains of a step
+            out.update(summarise(path, steps=3 * 256, cells=512 * 512 * 512))
+        elif w == 'fwd2048':  # 3 fits x 200 steps in one resident launch each
+            r = summarise(path, steps=3 * 200, cells=2048 * 2048)
             if 'fwd' in r:
                 out['fwd2048'] = dict(r['fwd'], hbm_bytes_per_launch=r['fwd']['hbm_bytes_per_step_launch'])
         elif w == 'c3':
-            r = summarise(path, steps=2 * 2000, cells=1024 * 1024)
+            r = summarise(path, steps=3 * 2000, cells=1024 * 1024)
             out['c3'] = r
     out['source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_r02.sh) on `python bench.py --workload <w> '
                      '--steps 1 --warmup 1 --no-extra --no-cpu`; FETCH_SIZE x2 (gfx950 correction); tools/traffic_r02.py.  C4: per logical '
