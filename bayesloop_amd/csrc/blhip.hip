@@ -798,6 +798,474 @@ std::vector<int64_t> plan_batches(const blhip_problem *p, int64_t n_chains, cons
     return start;
 }
 
+// ---- the phases of a fit: flags, shared tables (upload), memory plan; then per batch: program, geometry, metadata, forward pass +
+//      evidence bookkeeping, backward pass + bookkeeping, carried states / average posterior / kept posterior, results ------------
+struct FitFlags {
+    bool evidence_only, forward_only, full, keep, accumulate, resume, carry;
+};
+
+FitFlags decode_flags(blhip_ctx *ctx, const blhip_problem *p, uint32_t flags, const double *log_w) {
+    FitFlags f{};
+    f.evidence_only = flags & BLHIP_EVIDENCE_ONLY;
+    f.forward_only = (flags & BLHIP_FORWARD_ONLY) && !f.evidence_only;
+    f.full = !f.evidence_only && !f.forward_only;
+    f.keep = (flags & BLHIP_KEEP_POSTERIOR) && !f.evidence_only;
+    f.accumulate = (flags & BLHIP_ACCUMULATE) && !f.evidence_only;
+    f.resume = flags & BLHIP_RESUME;
+    f.carry = flags & BLHIP_CARRY;
+    if (f.resume || f.carry) {
+        if (f.full) fail("BLHIP_RESUME / BLHIP_CARRY need a forward-only or evidence-only fit");
+        if (p->carry_slot < 0) fail("carry_slot must be >= 0");
+    }
+    if (f.accumulate && !ctx->acc_active) fail("BLHIP_ACCUMULATE without blhip_accum_begin");
+    if (f.accumulate && !log_w) fail("BLHIP_ACCUMULATE needs log_chain_weight");
+    return f;
+}
+
+// what every chain of the call shares, resident in HBM for the duration of the call
+struct DeviceTables {
+    double *m0, *m1, *colA, *colB, *rec, *prior, *reset, *uniform, *indep, *lik;
+    int rec_len, d;
+};
+
+// upload: marginal grids, per-column likelihood constants, per-step data records, prior(s); the (T, G) likelihood table of the
+// closed-form table models is built on the device (table_model != 0), a caller-evaluated one (BLHIP_OM_TABLE) is copied
+DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int table_model) {
+    hipStream_t st = ctx->stream;
+    const int64_t T = p->T;
+    const long long G = g.G;
+    DeviceTables D{};
+    std::vector<double> rec;
+    build_records(p, rec, D.rec_len, D.d);
+    std::vector<double> colA(g.n1, 0.0), colB(g.n1, 0.0);
+    const double *mcol = p->ndim == 1 ? p->marginal[0] : p->marginal[1];
+    if (p->obs_model == BLHIP_OM_GAUSSIAN)
+        for (int j = 0; j < g.n1; ++j) {
+            const double s = mcol[j];
+            colA[j] = 1.0 / (2.0 * s * s);
+            colB[j] = 0.5 * std::log(2.0 * M_PI * s * s);
+        }
+    if (p->obs_model == BLHIP_OM_POISSON)
+        for (int j = 0; j < g.n1; ++j) colA[j] = std::exp(-mcol[j]);
+
+    size_t tb = 0;
+    tb += carve_size(sizeof(double) * std::max(1, g.n0)) + 3 * carve_size(sizeof(double) * g.n1);
+    tb += carve_size(sizeof(double) * rec.size()) + 4 * carve_size(sizeof(double) * G);
+    ctx->tables.ensure(tb);
+    char *cur = ctx->tables.as<char>();
+    D.m0 = carve<double>(cur, std::max(1, g.n0));
+    D.m1 = carve<double>(cur, g.n1);
+    D.colA = carve<double>(cur, g.n1);
+    D.colB = carve<double>(cur, g.n1);
+    D.rec = carve<double>(cur, rec.size());
+    D.prior = carve<double>(cur, G);
+    D.reset = carve<double>(cur, G);
+    D.uniform = carve<double>(cur, G);
+    D.indep = carve<double>(cur, G);
+    if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(D.m0, p->marginal[0], sizeof(double) * g.n0, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(D.m1, mcol, sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(D.colA, colA.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(D.colB, colB.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(D.rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(D.prior, p->prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    if (p->reset_prior) HIPCHECK(hipMemcpyAsync(D.reset, p->reset_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    if (p->indep_prior) HIPCHECK(hipMemcpyAsync(D.indep, p->indep_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    if (ff.full) {
+        // beta_T = 1/G   core.py:424-425
+        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, D.uniform, G, 1.0 / (double)G);
+    }
+    D.lik = nullptr;
+    if (p->obs_model == BLHIP_OM_TABLE) {
+        ctx->likbuf.ensure(sizeof(double) * T * G);
+        D.lik = ctx->likbuf.as<double>();
+        if (table_model) {
+            const size_t nd = (size_t)T * p->seg_len * p->data_dim;
+            ctx->databuf.ensure(nd * 8);
+            HIPCHECK(hipMemcpyAsync(ctx->databuf.p, p->data, nd * 8, hipMemcpyHostToDevice, st));
+            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 2048);
+            hipLaunchKernelGGL(lik_table_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, table_model, D.lik, (long long)G, g.n1,
+                               p->ndim, D.m0, D.m1, ctx->databuf.as<double>(), p->seg_len, p->data_dim);
+            HIPCHECK(hipGetLastError());
+        } else {
+            HIPCHECK(hipMemcpyAsync(D.lik, p->lik, sizeof(double) * T * G, hipMemcpyHostToDevice, st));
+        }
+    }
+    sync_stream(ctx, st);   // the host vectors above go out of use
+    return D;
+}
+
+// memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
+int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int64_t n_chains) {
+    const int64_t T = p->T;
+    const long long G = g.G;
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+    const double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap,
+                                   ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
+    const double per_chain = (ff.evidence_only ? 2.0 : (double)T + 2.0) * (double)G * 8.0 +
+                             (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
+    int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
+    Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024));
+    Bmax = std::min<int64_t>(Bmax, 65535);
+    if (ff.keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
+    if ((ff.resume || ff.carry) && n_chains > Bmax) fail("carried states: %lld chains do not fit in one batch", (long long)n_chains);
+    if (ff.resume) {
+        auto it = ctx->carry.find(p->carry_slot);
+        if (it == ctx->carry.end() || !it->second.valid) fail("BLHIP_RESUME: carry slot %d holds no state", p->carry_slot);
+        if (it->second.chains != n_chains || it->second.G != G)
+            fail("BLHIP_RESUME: carry slot %d holds %lld chains x %lld cells, the call has %lld x %lld", p->carry_slot,
+                 (long long)it->second.chains, (long long)it->second.G, (long long)n_chains, (long long)G);
+    }
+    return Bmax;
+}
+
+// which kernel family runs a batch and with what block geometry (segment lengths from a small cost model: long segments read every
+// element once + 2 R0 halo rows per segment, short ones give enough blocks to fill 256 CUs when there are few chains)
+struct GeometryPlan {
+    bool fast = false, persist = false, fused1d = false, use_mfma = false;
+    size_t p1_lds = 0;
+    int64_t fusedK = 1;
+    int f1_TJ = 128;
+    Tile tile{};
+    int fastS = 0, fast_nseg = 1, fast_fnblk = 1, mS = 0, m_nseg = 1, m_tiles_j = 1, m_nblk = 1;
+};
+
+GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const ChainProgram &prog, int64_t B, int d,
+                       bool resume, bool carry) {
+    GeometryPlan gp;
+    const int64_t T = p->T;
+    // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
+    gp.fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
+                      ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
+                      g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
+    gp.p1_lds = ((size_t)2 * (g.n1 + 2 * prog.LW1) + 64 + prog.LW1 + 2) * sizeof(double);
+    gp.persist = p->ndim == 1 && !gp.fast && !prog.has_clamp && !resume && !carry && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
+                         prog.LW1 <= g.n1 && gp.p1_lds <= 150 * 1024 &&
+                         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
+                          p->obs_model == BLHIP_OM_TABLE);
+    // 1-D grids: K time steps per launch (blhip_fused1d.hpp); K = 1 is the same kernel with a launch per step
+    if (p->ndim == 1 && !gp.fast && !gp.persist && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
+        (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
+        gp.f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
+        gp.fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
+        // keep the redundantly recomputed halo (K * LW cells per side) within ~4x the owned cells and the window in LDS
+        while (gp.fusedK > 1 && (gp.fusedK * prog.LW1 > 2 * gp.f1_TJ || (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 > 96 * 1024)) --gp.fusedK;
+        gp.fused1d = (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 + (size_t)gp.fusedK * gp.f1_TJ * 32 + 4096 <= 150 * 1024;
+    }
+    if (gp.fast) {
+        gp.tile.TI = blf::CH; gp.tile.LW0 = prog.LW0; gp.tile.LW1 = prog.LW1 > 0 ? blf::R1MAX : 0;
+        gp.tile.TJ = blf::BW - 2 * gp.tile.LW1;
+        gp.tile.tiles_j = (g.n1 + gp.tile.TJ - 1) / gp.tile.TJ;
+        // rows per block segment: long segments read every element once (+ 2*R0 halo rows per segment), short ones
+        // give enough blocks to fill 256 CUs when there are few chains.  Model: cost = waves * blocks_per_CU * rows.
+        const long long colblocks = (long long)gp.tile.tiles_j * B;
+        const int R0 = prog.LW0 == 0 ? 0 : ((prog.LW0 + 7) / 8) * 8;
+        double best = 1e300;
+        const int forceS = (int)ctx->option("fast_S", 0);
+        for (int k = 1; k <= 4; k *= 2) {
+            const double pen = k == 1 ? 1.6 : (k == 2 ? 1.15 : 1.0);
+            for (int ns = 1; ns <= std::max(1, g.n0 / 16); ++ns) {
+                int S = ((g.n0 + ns - 1) / ns + blf::CH - 1) / blf::CH * blf::CH;
+                const int real = (g.n0 + S - 1) / S;
+                const long long blocks = colblocks * real;
+                const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
+                const double cost = pen * (double)waves * k * (S + 2.0 * R0 + 4.0);
+                if (cost < best - 1e-9) { best = cost; gp.fastS = S; gp.fast_nseg = real; }
+            }
+        }
+        if (forceS > 0) { gp.fastS = (forceS + blf::CH - 1) / blf::CH * blf::CH; gp.fast_nseg = (g.n0 + gp.fastS - 1) / gp.fastS; }
+        gp.tile.tiles_i = gp.fast_nseg;
+        gp.fast_fnblk = gp.tile.tiles_j * gp.fast_nseg;
+        // geometry of the matrix-pipe kernel (64-column strips, segments of mS rows, mS a multiple of 16)
+        {
+            gp.m_tiles_j = (g.n1 + blm::BCOL - 1) / blm::BCOL;
+            const long long mcol = (long long)gp.m_tiles_j * B;
+            double mbest = 1e300;
+            for (int k = 1; k <= 4; ++k) {                     // resident blocks per CU
+                const double pen = k == 1 ? 1.5 : (k == 2 ? 1.15 : 1.0);
+                for (int ns = 1; ns <= std::max(1, g.n0 / 32); ++ns) {
+                    int S = ((g.n0 + ns - 1) / ns + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q;
+                    if (S > blm::MS_MAX) continue;
+                    const int real = (g.n0 + S - 1) / S;
+                    const long long blocks = mcol * real;
+                    const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
+                    const double cost = pen * (double)waves * k * (S + 1.0 * R0 + 24.0);
+                    if (cost < mbest - 1e-9) { mbest = cost; gp.mS = S; gp.m_nseg = real; }
+                }
+            }
+            const int forceM = (int)ctx->option("mfma_S", 0);
+            if (forceM > 0) { gp.mS = std::min(blm::MS_MAX, (forceM + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q); gp.m_nseg = (g.n0 + gp.mS - 1) / gp.mS; }
+            if (gp.mS == 0) { gp.mS = blm::MS_MAX; gp.m_nseg = (g.n0 + gp.mS - 1) / gp.mS; }
+            gp.m_nblk = gp.m_tiles_j * gp.m_nseg;
+        }
+        gp.use_mfma = ctx->option("mfma", 1.0) != 0.0;
+        gp.tile.nblk = gp.use_mfma ? std::max(gp.fast_fnblk, gp.m_nblk) : gp.fast_fnblk;
+        gp.tile.lds_bytes = 0;
+    } else if (gp.fused1d) {
+        gp.tile.TI = 1; gp.tile.TJ = gp.f1_TJ; gp.tile.LW0 = 0; gp.tile.LW1 = prog.LW1; gp.tile.tiles_i = 1;
+        gp.tile.tiles_j = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ; gp.tile.nblk = gp.tile.tiles_j; gp.tile.lds_bytes = 0;
+    } else {
+        gp.tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
+    }
+    return gp;
+}
+
+// per-(step, chain) metadata of a batch in HBM: source kinds, tap-set ids, clamp modes, the per-step launch order of the radius buckets,
+// the tap table; plus scratch the finalisation kernels use
+struct DeviceMeta {
+    unsigned char *kindF, *kindB, *cmodeF, *cmodeB;
+    double *limitF, *limitB;
+    int *tapF0, *tapF1, *tapB0, *tapB1, *orderF, *orderB;
+    double *taps;
+    int *off, *lw, *lw2;
+    double *invN, *w, *dump;
+    // host copies the launch loop reads
+    std::vector<int> h_orderF, h_orderB;
+    std::vector<std::vector<FastRange>> rangesF, rangesB;
+};
+
+void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram &prog, TapTable &taps, int64_t B, bool full, bool fast, int nblk,
+                     DeviceMeta &M) {
+    hipStream_t st = ctx->stream;
+    const int64_t T = p->T;
+    const size_t nT = (size_t)T * B;
+    taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
+    size_t mb = 4 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
+                3 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * 4 * NTHREADS);
+    ctx->meta.ensure(mb);
+    char *cur = ctx->meta.as<char>();
+    M.kindF = carve<unsigned char>(cur, nT); M.kindB = carve<unsigned char>(cur, nT);
+    M.cmodeF = carve<unsigned char>(cur, nT); M.cmodeB = carve<unsigned char>(cur, nT);
+    M.limitF = carve<double>(cur, nT); M.limitB = carve<double>(cur, nT);
+    M.tapF0 = carve<int>(cur, nT); M.tapF1 = carve<int>(cur, nT);
+    M.tapB0 = carve<int>(cur, nT); M.tapB1 = carve<int>(cur, nT);
+    M.orderF = carve<int>(cur, nT); M.orderB = carve<int>(cur, nT);
+    M.taps = carve<double>(cur, taps.w.size() + 1);
+    M.off = carve<int>(cur, taps.off.size() + 1); M.lw = carve<int>(cur, taps.off.size() + 1);
+    M.lw2 = carve<int>(cur, taps.off.size() + 1);
+    M.invN = carve<double>(cur, nT);
+    (void)carve<double>(cur, nT);
+    M.w = carve<double>(cur, B);
+    M.dump = carve<double>(cur, 4 * NTHREADS);   // (the halo wave of an H block spreads its dummy stores over 8 x 64 slots)
+    HIPCHECK(hipMemcpyAsync(M.kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(M.tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(M.tapF1, prog.tapF1.data(), nT * 4, hipMemcpyHostToDevice, st));
+    if (prog.has_clamp) {
+        HIPCHECK(hipMemcpyAsync(M.cmodeF, prog.cmodeF.data(), nT, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.limitF, prog.limitF.data(), nT * 8, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.cmodeB, prog.cmodeB.data(), nT, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.limitB, prog.limitB.data(), nT * 8, hipMemcpyHostToDevice, st));
+    }
+    if (full) {
+        HIPCHECK(hipMemcpyAsync(M.kindB, prog.kindB.data(), nT, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.tapB1, prog.tapB1.data(), nT * 4, hipMemcpyHostToDevice, st));
+    }
+    if (fast) {
+        // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle: a radius bucket with fewer blocks joins the next one
+        const long long min_blocks = (long long)ctx->option("min_bucket_blocks", 128.0);
+        const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)nblk - 1) / nblk);
+        M.h_orderF.resize(nT); M.rangesF.resize(T);
+        for (int64_t t = 0; t < T; ++t)
+            bucket_step(&prog.tapF0[t * B], &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains);
+        HIPCHECK(hipMemcpyAsync(M.orderF, M.h_orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
+        if (full) {
+            M.h_orderB.resize(nT); M.rangesB.resize(T);
+            for (int64_t t = 0; t < T; ++t)
+                bucket_step(&prog.tapB0[t * B], &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains);
+            HIPCHECK(hipMemcpyAsync(M.orderB, M.h_orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
+        }
+    }
+    if (!taps.w.empty()) {
+        HIPCHECK(hipMemcpyAsync(M.taps, taps.w.data(), taps.w.size() * 8, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.off, taps.off.data(), taps.off.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.lw, taps.lw.data(), taps.lw.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(M.lw2, taps.lw2.data(), taps.lw2.size() * 4, hipMemcpyHostToDevice, st));
+    }
+}
+
+// host-side results of one batch of chains
+struct BatchOutcome {
+    std::vector<double> logE, local, means, invN;    // (B,), (B, T), (B, ndim, T), (B, T): 1 / row sum of the stored sequence
+    std::vector<int64_t> abort_step;
+    std::vector<int32_t> abort_phase;
+};
+
+// BLHIP_CARRY: keep every chain's filtered distribution of the last step, normalised (core.py:2173)
+void store_carry(blhip_ctx *ctx, const blhip_problem *p, int64_t B, long long G, const double *redF, const double *fin, long long fstr,
+                 double *d_w, bool has_clamp) {
+    hipStream_t st = ctx->stream;
+    const int64_t T = p->T;
+    blhip_ctx::Carry &cs = ctx->carry[p->carry_slot];
+    cs.buf.ensure((size_t)B * G * 8);
+    std::vector<double> inv(B);
+    for (int64_t b = 0; b < B; ++b) inv[b] = 1.0 / redF[((size_t)(T - 1) * B + b) * NRED];
+    HIPCHECK(hipMemcpyAsync(d_w, inv.data(), B * 8, hipMemcpyHostToDevice, st));
+    const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+    hipLaunchKernelGGL(carry_store_kernel, dim3(gx, (unsigned)B), dim3(NTHREADS), 0, st, cs.buf.as<double>(), fin, fstr, G, d_w);
+    sync_stream(ctx, st);
+    cs.chains = B; cs.G = G; cs.valid = true;
+    cs.maxv.clear();
+    if (has_clamp)                               // clamp batches run the generic kernel, which reports the state maximum
+        for (int64_t b = 0; b < B; ++b) cs.maxv.push_back(redF[((size_t)(T - 1) * B + b) * NRED + 6] * inv[b]);
+}
+
+// fold the batch into the average posterior (core.py:1358-1366): linear accumulator with a running reference exponent
+void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const BatchOutcome &out, const double *log_w_batch, const double *d_post,
+                     double *d_w, double *d_invN) {
+    hipStream_t st = ctx->stream;
+    double newref = ctx->acc_logref;
+    std::vector<double> lw(B, -INFINITY);
+    std::vector<char> valid(B, 0);
+    for (int64_t b = 0; b < B; ++b) {
+        // np.isfinite(logEvidence) guard (core.py:1358); a zero hyper-prior contributes log(0) = -inf, i.e. nothing
+        valid[b] = out.abort_step[b] < 0 && std::isfinite(out.logE[b]) && std::isfinite(log_w_batch[b]);
+        if (!valid[b]) continue;
+        lw[b] = out.logE[b] + log_w_batch[b];
+        if (lw[b] > newref) newref = lw[b];
+    }
+    if (!std::isfinite(newref)) return;
+    std::vector<double> w(B, 0.0);
+    int nfold = 0;
+    for (int64_t b = 0; b < B; ++b)
+        if (valid[b]) { w[b] = std::exp(lw[b] - newref); nfold++; }
+    const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref);
+    HIPCHECK(hipMemcpyAsync(d_w, w.data(), B * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_invN, out.invN.data(), (size_t)T * B * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipEventRecord(ctx->ev[4], st));
+    if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
+        const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
+        hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
+                           (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
+    } else {
+        const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+        hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
+                           (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[5], st));
+    sync_stream(ctx, st);
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+    ctx->timing.accumulate_ms += ms;
+    ctx->timing.accumulate_launches += 1;
+    ctx->acc_logref = newref;
+    ctx->acc_first = false;
+    ctx->acc_folded += nfold;
+}
+
+// the batch's sequence stays on the device as the kept posterior; rows [row0, row1) still carry their raw sums (core.py:389 / :441)
+void keep_posterior(blhip_ctx *ctx, const Geometry &g, int64_t T, int64_t B, const BatchOutcome &out, int64_t row0, int64_t row1) {
+    hipStream_t st = ctx->stream;
+    ctx->postinv.ensure((size_t)T * B * 8);
+    HIPCHECK(hipMemcpyAsync(ctx->postinv.p, out.invN.data(), (size_t)T * B * 8, hipMemcpyHostToDevice, st));
+    sync_stream(ctx, st);
+    ctx->post_valid = true; ctx->post_scaled = false; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = g.G;
+    ctx->post_row0 = row0; ctx->post_row1 = row1;
+    ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
+    // default: normalise now, as part of the fit (core.py:441 is inside Study.fit); option lazy_normalise = 1 defers
+    // the pass to the first access of the sequence
+    if (ctx->option("lazy_normalise", 0.0) == 0.0) { ensure_post_scaled(ctx); sync_stream(ctx, st); }
+}
+
+void write_results(blhip_result *res, const blhip_problem *p, int64_t c0, int64_t B, const BatchOutcome &out, bool with_means) {
+    if (!res) return;
+    const int64_t T = p->T;
+    for (int64_t b = 0; b < B; ++b) {
+        if (res->log_evidence) res->log_evidence[c0 + b] = out.logE[b];
+        if (res->abort_step) res->abort_step[c0 + b] = out.abort_step[b];
+        if (res->abort_phase) res->abort_phase[c0 + b] = out.abort_phase[b];
+        if (res->local_evidence)
+            std::memcpy(res->local_evidence + (size_t)(c0 + b) * T, &out.local[(size_t)b * T], T * 8);
+        if (res->posterior_mean && with_means)
+            std::memcpy(res->posterior_mean + (size_t)(c0 + b) * p->ndim * T, &out.means[(size_t)b * p->ndim * T], (size_t)p->ndim * T * 8);
+    }
+}
+
+// Undo the lagged scale of the time-resident kernel (blhip_resident.hpp): its step k divided by the sum of step k - lag, so its row
+// sums are S_k; the reference's normaliser is norm_k = S_k / (S_{k-1} s_k), s_k = k >= lag ? 1 / S_{k-lag} : 1.  The sums of every step
+// are rewritten to what the launch-per-step kernels (lag 1) would have reported; rowsum keeps S_k, the normaliser of the stored row.
+// false: a sum near the bottom / top of the fp64 range (a run of extreme outliers times the lag) -> the caller falls back to the
+// launch-per-step kernels, whose magnitudes are the reference's.
+bool resident_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum) {
+    rowsum.assign(T, 0.0);
+    for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[(size_t)t * NRED];
+    for (int64_t t = 0; t < T; ++t) {
+        const double St = rowsum[t];
+        if (!(St > 1e-150 && St < 1e150)) return false;
+        const double sk = t >= lag ? 1.0 / rowsum[t - lag] : 1.0;
+        const double norm = t == 0 ? St : St / (rowsum[t - 1] * sk);
+        double *r = &redF[(size_t)t * NRED];
+        r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
+    }
+    return true;
+}
+
+// evidence bookkeeping of the forward pass on the host, in the reference's order (core.py:385-404, 417); K > 1: raw sums of the
+// K-steps-per-launch 1-D kernels.  -> false if such a raw sum came near the bottom of the fp64 range (the caller repeats with K = 1)
+bool forward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, const double *redF, int64_t B, double dV, bool fused1d, int64_t K,
+                         bool evidence_only, bool forward_only, BatchOutcome &O) {
+    const int64_t T = p->T;
+    O.logE.assign(B, 0.0);
+    O.abort_step.assign(B, -1);
+    O.abort_phase.assign(B, 0);
+    O.local.assign((size_t)B * T, 0.0);
+    bool raw_ok = true;
+    for (int64_t b = 0; b < B; ++b) {
+        double le = 0.0;
+        for (int64_t t = 0; t < T; ++t) {
+            double norm = redF[((size_t)t * B + b) * NRED + 0];
+            if (fused1d) {
+                // raw sums of the K-step launches (blhip_fused1d.hpp): inner steps carry the scale of their predecessor
+                if (!(norm > 1e-200)) raw_ok = false;
+                if (t % K != 0 && prog.kindF[(size_t)t * B + b] == SRC_PREV) norm /= redF[((size_t)(t - 1) * B + b) * NRED];
+            }
+            // RegimeSwitch renormalises the clamped prior (transitionModels.py:410): alpha = (u / sum u) L
+            if (prog.has_clamp && prog.cmodeF[(size_t)t * B + b]) norm /= redF[((size_t)t * B + b) * NRED + 1];
+            if (!(norm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 0; le = -INFINITY; break; }
+            le += std::log(norm);
+            O.local[(size_t)b * T + t] = norm * dV;
+        }
+        if (O.abort_step[b] < 0) le += std::log(dV);
+        O.logE[b] = le;
+    }
+    O.means.clear();
+    if (!evidence_only) O.means.assign((size_t)B * p->ndim * T, 0.0);
+    if (forward_only) {
+        for (int64_t b = 0; b < B; ++b)
+            for (int64_t t = 0; t < T; ++t) {
+                const double *r = &redF[((size_t)t * B + b) * NRED];
+                for (int k = 0; k < p->ndim; ++k) O.means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
+            }
+    }
+    return raw_ok;
+}
+
+// bookkeeping of the backward pass (core.py:441-464, 480-483): abort test, local evidence, row normalisers, posterior means.
+// rows_done_from >= 0: rows t >= rows_done_from were normalised by the resident kernel itself (their invN is 1).
+bool backward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, const double *redF, const double *redB, int64_t B, double dV,
+                          bool fused1d, int64_t rows_done_from, BatchOutcome &O) {
+    const int64_t T = p->T;
+    bool raw_ok = true;
+    for (int64_t b = 0; b < B; ++b) {
+        if (O.abort_step[b] >= 0) continue;
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const double *r = &redB[((size_t)t * B + b) * NRED];
+            if (fused1d && !(r[0] > 1e-200)) raw_ok = false;
+            // The reference tests sum(alpha_norm * beta_norm) > 0 (core.py:441).  r[0] is the same sum up to the lazily
+            // dropped normalisers, which are positive -- except with signed kernels (Deterministic's cubic-spline
+            // shift, AlphaStable's FFT kernel): there sum(alpha) = redF[t][0] and sum(beta) = r[5] may be negative and
+            // the reference divides by them, so the sign test has to include them.
+            double refnorm = r[0];
+            if (prog.has_clamp) refnorm = r[0] / (redF[((size_t)t * B + b) * NRED] * (prog.cmodeB[(size_t)t * B + b] ? r[5] : 1.0));
+            if (!(refnorm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 1; O.logE[b] = -INFINITY; break; }
+            O.local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
+            O.invN[(size_t)b * T + t] = (rows_done_from >= 0 && t >= rows_done_from) ? 1.0 : 1.0 / r[0];
+            for (int k = 0; k < p->ndim; ++k) O.means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
+        }
+    }
+    return raw_ok;
+}
+
 void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const double *op_values,
             const double *log_w, uint32_t flags, blhip_result *res) {
     Trace tr(ctx->option("trace", 0.0) != 0.0);
@@ -810,18 +1278,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     const blhip_problem *p = &p_local;
     HIPCHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const bool evidence_only = flags & BLHIP_EVIDENCE_ONLY;
-    const bool forward_only = (flags & BLHIP_FORWARD_ONLY) && !evidence_only;
-    const bool full = !evidence_only && !forward_only;
-    const bool keep = (flags & BLHIP_KEEP_POSTERIOR) && !evidence_only;
-    const bool accumulate = (flags & BLHIP_ACCUMULATE) && !evidence_only;
-    const bool resume = flags & BLHIP_RESUME, carry = flags & BLHIP_CARRY;
-    if (resume || carry) {
-        if (full) fail("BLHIP_RESUME / BLHIP_CARRY need a forward-only or evidence-only fit");
-        if (p->carry_slot < 0) fail("carry_slot must be >= 0");
-    }
-    if (accumulate && !ctx->acc_active) fail("BLHIP_ACCUMULATE without blhip_accum_begin");
-    if (accumulate && !log_w) fail("BLHIP_ACCUMULATE needs log_chain_weight");
+    const FitFlags ff = decode_flags(ctx, p, flags, log_w);
+    const bool evidence_only = ff.evidence_only, forward_only = ff.forward_only, full = ff.full, keep = ff.keep,
+               accumulate = ff.accumulate, resume = ff.resume, carry = ff.carry;
     const int64_t T = p->T;
 
     Geometry g{};
@@ -836,85 +1295,16 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     ctx->post_valid = false;
     ctx->timing = blhip_timing{};
 
-    // ---- shared tables -------------------------------------------------------------------------------------------
-    std::vector<double> rec; int rec_len = 0, d = 1;
-    build_records(p, rec, rec_len, d);
-    std::vector<double> colA(g.n1, 0.0), colB(g.n1, 0.0);
-    const double *mcol = p->ndim == 1 ? p->marginal[0] : p->marginal[1];
-    if (p->obs_model == BLHIP_OM_GAUSSIAN)
-        for (int j = 0; j < g.n1; ++j) {
-            const double s = mcol[j];
-            colA[j] = 1.0 / (2.0 * s * s);
-            colB[j] = 0.5 * std::log(2.0 * M_PI * s * s);
-        }
-    if (p->obs_model == BLHIP_OM_POISSON)
-        for (int j = 0; j < g.n1; ++j) colA[j] = std::exp(-mcol[j]);
-
-    const bool has_reset = p->reset_prior != nullptr;
-    size_t tb = 0;
-    tb += carve_size(sizeof(double) * std::max(1, g.n0)) + 3 * carve_size(sizeof(double) * g.n1);
-    tb += carve_size(sizeof(double) * rec.size()) + 4 * carve_size(sizeof(double) * G);
-    ctx->tables.ensure(tb);
-    char *cur = ctx->tables.as<char>();
-    double *d_m0 = carve<double>(cur, std::max(1, g.n0));
-    double *d_m1 = carve<double>(cur, g.n1);
-    double *d_colA = carve<double>(cur, g.n1);
-    double *d_colB = carve<double>(cur, g.n1);
-    double *d_rec = carve<double>(cur, rec.size());
-    double *d_prior = carve<double>(cur, G);
-    double *d_reset = carve<double>(cur, G);
-    double *d_uniform = carve<double>(cur, G);
-    double *d_indep = carve<double>(cur, G);
-    if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(d_m0, p->marginal[0], sizeof(double) * g.n0, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(d_m1, mcol, sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(d_colA, colA.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(d_colB, colB.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(d_rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(d_prior, p->prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
-    if (has_reset) HIPCHECK(hipMemcpyAsync(d_reset, p->reset_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
-    if (p->indep_prior) HIPCHECK(hipMemcpyAsync(d_indep, p->indep_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
-    if (full) {
-        // beta_T = 1/G   core.py:424-425
-        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);
-    }
-    double *d_lik = nullptr;
-    if (p->obs_model == BLHIP_OM_TABLE) {
-        ctx->likbuf.ensure(sizeof(double) * T * G);
-        d_lik = ctx->likbuf.as<double>();
-        if (table_model) {
-            const size_t nd = (size_t)T * p->seg_len * p->data_dim;
-            ctx->databuf.ensure(nd * 8);
-            HIPCHECK(hipMemcpyAsync(ctx->databuf.p, p->data, nd * 8, hipMemcpyHostToDevice, st));
-            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 2048);
-            hipLaunchKernelGGL(lik_table_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, table_model, d_lik, (long long)G, g.n1,
-                               p->ndim, d_m0, d_m1, ctx->databuf.as<double>(), p->seg_len, p->data_dim);
-            HIPCHECK(hipGetLastError());
-        } else {
-            HIPCHECK(hipMemcpyAsync(d_lik, p->lik, sizeof(double) * T * G, hipMemcpyHostToDevice, st));
-        }
-    }
-    sync_stream(ctx, st);   // host vectors above go out of use
+    // ---- shared tables -> HBM ---------------------------------------------------------------------------------------------------
+    const DeviceTables DT = upload_tables(ctx, p, g, ff, table_model);
+    double *const d_m0 = DT.m0, *const d_m1 = DT.m1, *const d_colA = DT.colA, *const d_colB = DT.colB, *const d_rec = DT.rec;
+    double *const d_prior = DT.prior, *const d_reset = DT.reset, *const d_uniform = DT.uniform, *const d_indep = DT.indep, *const d_lik = DT.lik;
+    const int rec_len = DT.rec_len, d = DT.d;
+    char *cur = nullptr;
     tr.mark("tables + H2D");
 
-    // ---- batching ------------------------------------------------------------------------------------------------
-    size_t free_b = 0, total_b = 0;
-    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
-    const double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap,
-                                   ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
-    const double per_chain = (evidence_only ? 2.0 : (double)T + 2.0) * (double)G * 8.0 +
-                             (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
-    int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
-    Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024));
-    Bmax = std::min<int64_t>(Bmax, 65535);
-    if (keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
-    if ((resume || carry) && n_chains > Bmax) fail("carried states: %lld chains do not fit in one batch", (long long)n_chains);
-    if (resume) {
-        auto it = ctx->carry.find(p->carry_slot);
-        if (it == ctx->carry.end() || !it->second.valid) fail("BLHIP_RESUME: carry slot %d holds no state", p->carry_slot);
-        if (it->second.chains != n_chains || it->second.G != G)
-            fail("BLHIP_RESUME: carry slot %d holds %lld chains x %lld cells, the call has %lld x %lld", p->carry_slot,
-                 (long long)it->second.chains, (long long)it->second.G, (long long)n_chains, (long long)G);
-    }
+    // ---- memory plan ------------------------------------------------------------------------------------------------------------
+    const int64_t Bmax = chains_per_batch(ctx, p, g, ff, n_chains);
     // ---- batches: at most Bmax chains each, cut where the axis-0 radius bucket changes.  A bucket cut by a batch boundary becomes
     //      two under-filled launches per step (round 1: the 107-chain radius-24 bucket of the C4 study ran as 36 + 71 chains at
     //      4.1 TB/s); hyper-grids are usually monotone in the random-walk width, so contiguous cuts suffice.
@@ -934,147 +1324,31 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         tr.mark("batch setup");
         build_program(p, g, c0, B, op_values, taps, prog, resume);
         tr.mark("build_program");
-        // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
-        const bool fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
-                          ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
-                          g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
-        const size_t p1_lds = ((size_t)2 * (g.n1 + 2 * prog.LW1) + 64 + prog.LW1 + 2) * sizeof(double);
-        const bool persist = p->ndim == 1 && !fast && !prog.has_clamp && !resume && !carry && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
-                             prog.LW1 <= g.n1 && p1_lds <= 150 * 1024 &&
-                             (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
-                              p->obs_model == BLHIP_OM_TABLE);
-        // 1-D grids: K time steps per launch (blhip_fused1d.hpp); K = 1 is the same kernel with a launch per step
-        int64_t fusedK = 1;
-        int f1_TJ = 128;
-        bool fused1d = false;
-        if (p->ndim == 1 && !fast && !persist && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
-            (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
-            f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
-            fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
-            // keep the redundantly recomputed halo (K * LW cells per side) within ~4x the owned cells and the window in LDS
-            while (fusedK > 1 && (fusedK * prog.LW1 > 2 * f1_TJ || (size_t)(f1_TJ + 2 * fusedK * prog.LW1) * 32 > 96 * 1024)) --fusedK;
-            fused1d = (size_t)(f1_TJ + 2 * fusedK * prog.LW1) * 32 + (size_t)fusedK * f1_TJ * 32 + 4096 <= 150 * 1024;
-        }
+        const GeometryPlan gp = plan_geometry(ctx, p, g, prog, B, d, resume, carry);
+        const bool fast = gp.fast, persist = gp.persist, fused1d = gp.fused1d, use_mfma = gp.use_mfma;
+        const size_t p1_lds = gp.p1_lds;
+        const int64_t fusedK = gp.fusedK;
+        const int f1_TJ = gp.f1_TJ;
+        Tile tile = gp.tile;
+        const int fastS = gp.fastS, fast_nseg = gp.fast_nseg, fast_fnblk = gp.fast_fnblk, mS = gp.mS, m_nseg = gp.m_nseg, m_tiles_j = gp.m_tiles_j,
+                  m_nblk = gp.m_nblk;
         auto f1_lds = [&](int64_t K) { return (size_t)(4 * (f1_TJ + 2 * K * prog.LW1) + K * f1_TJ + K * (prog.LW1 + 1) + K * rec_len + 4 * 8 + 2 + K + 8 + K * 3 * f1_TJ) * sizeof(double); };
-        Tile tile{};
-        int fastS = 0, fast_nseg = 1, fast_fnblk = 1, mS = 0, m_nseg = 1, m_tiles_j = 1, m_nblk = 1;
-        bool use_mfma = false;
-        if (fast) {
-            tile.TI = blf::CH; tile.LW0 = prog.LW0; tile.LW1 = prog.LW1 > 0 ? blf::R1MAX : 0;
-            tile.TJ = blf::BW - 2 * tile.LW1;
-            tile.tiles_j = (g.n1 + tile.TJ - 1) / tile.TJ;
-            // rows per block segment: long segments read every element once (+ 2*R0 halo rows per segment), short ones
-            // give enough blocks to fill 256 CUs when there are few chains.  Model: cost = waves * blocks_per_CU * rows.
-            const long long colblocks = (long long)tile.tiles_j * B;
-            const int R0 = prog.LW0 == 0 ? 0 : ((prog.LW0 + 7) / 8) * 8;
-            double best = 1e300;
-            const int forceS = (int)ctx->option("fast_S", 0);
-            for (int k = 1; k <= 4; k *= 2) {
-                const double pen = k == 1 ? 1.6 : (k == 2 ? 1.15 : 1.0);
-                for (int ns = 1; ns <= std::max(1, g.n0 / 16); ++ns) {
-                    int S = ((g.n0 + ns - 1) / ns + blf::CH - 1) / blf::CH * blf::CH;
-                    const int real = (g.n0 + S - 1) / S;
-                    const long long blocks = colblocks * real;
-                    const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
-                    const double cost = pen * (double)waves * k * (S + 2.0 * R0 + 4.0);
-                    if (cost < best - 1e-9) { best = cost; fastS = S; fast_nseg = real; }
-                }
-            }
-            if (forceS > 0) { fastS = (forceS + blf::CH - 1) / blf::CH * blf::CH; fast_nseg = (g.n0 + fastS - 1) / fastS; }
-            tile.tiles_i = fast_nseg;
-            fast_fnblk = tile.tiles_j * fast_nseg;
-            // geometry of the matrix-pipe kernel (64-column strips, segments of mS rows, mS a multiple of 16)
-            {
-                m_tiles_j = (g.n1 + blm::BCOL - 1) / blm::BCOL;
-                const long long mcol = (long long)m_tiles_j * B;
-                double mbest = 1e300;
-                for (int k = 1; k <= 4; ++k) {                     // resident blocks per CU
-                    const double pen = k == 1 ? 1.5 : (k == 2 ? 1.15 : 1.0);
-                    for (int ns = 1; ns <= std::max(1, g.n0 / 32); ++ns) {
-                        int S = ((g.n0 + ns - 1) / ns + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q;
-                        if (S > blm::MS_MAX) continue;
-                        const int real = (g.n0 + S - 1) / S;
-                        const long long blocks = mcol * real;
-                        const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
-                        const double cost = pen * (double)waves * k * (S + 1.0 * R0 + 24.0);
-                        if (cost < mbest - 1e-9) { mbest = cost; mS = S; m_nseg = real; }
-                    }
-                }
-                const int forceM = (int)ctx->option("mfma_S", 0);
-                if (forceM > 0) { mS = std::min(blm::MS_MAX, (forceM + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q); m_nseg = (g.n0 + mS - 1) / mS; }
-                if (mS == 0) { mS = blm::MS_MAX; m_nseg = (g.n0 + mS - 1) / mS; }
-                m_nblk = m_tiles_j * m_nseg;
-            }
-            use_mfma = ctx->option("mfma", 1.0) != 0.0;
-            tile.nblk = use_mfma ? std::max(fast_fnblk, m_nblk) : fast_fnblk;
-            tile.lds_bytes = 0;
-        } else if (fused1d) {
-            tile.TI = 1; tile.TJ = f1_TJ; tile.LW0 = 0; tile.LW1 = prog.LW1; tile.tiles_i = 1;
-            tile.tiles_j = (g.n1 + f1_TJ - 1) / f1_TJ; tile.nblk = tile.tiles_j; tile.lds_bytes = 0;
-        } else {
-            tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
-        }
         ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : (persist ? 2 : (fused1d ? 4 : 0));
         ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
 
         // --- device metadata ---
         const size_t nT = (size_t)T * B;
-        taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
-        size_t mb = 4 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
-                    3 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * 4 * NTHREADS);
-        ctx->meta.ensure(mb);
-        cur = ctx->meta.as<char>();
-        unsigned char *d_kindF = carve<unsigned char>(cur, nT), *d_kindB = carve<unsigned char>(cur, nT);
-        unsigned char *d_cmodeF = carve<unsigned char>(cur, nT), *d_cmodeB = carve<unsigned char>(cur, nT);
-        double *d_limitF = carve<double>(cur, nT), *d_limitB = carve<double>(cur, nT);
-        int *d_tapF0 = carve<int>(cur, nT), *d_tapF1 = carve<int>(cur, nT);
-        int *d_tapB0 = carve<int>(cur, nT), *d_tapB1 = carve<int>(cur, nT);
-        int *d_orderF = carve<int>(cur, nT), *d_orderB = carve<int>(cur, nT);
-        double *d_taps = carve<double>(cur, taps.w.size() + 1);
-        int *d_off = carve<int>(cur, taps.off.size() + 1), *d_lw = carve<int>(cur, taps.off.size() + 1);
-        int *d_lw2 = carve<int>(cur, taps.off.size() + 1);
-        double *d_invN = carve<double>(cur, nT);
-        double *d_inv_tmp = carve<double>(cur, nT);
-        double *d_w = carve<double>(cur, B);
-        double *d_dump = carve<double>(cur, 4 * NTHREADS);      // (the halo wave of an H block spreads its dummy stores over 8 x 64 slots)
-        (void)d_inv_tmp;
-        HIPCHECK(hipMemcpyAsync(d_kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_tapF1, prog.tapF1.data(), nT * 4, hipMemcpyHostToDevice, st));
-        if (prog.has_clamp) {
-            HIPCHECK(hipMemcpyAsync(d_cmodeF, prog.cmodeF.data(), nT, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_limitF, prog.limitF.data(), nT * 8, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_cmodeB, prog.cmodeB.data(), nT, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_limitB, prog.limitB.data(), nT * 8, hipMemcpyHostToDevice, st));
-        }
-        if (full) {
-            HIPCHECK(hipMemcpyAsync(d_kindB, prog.kindB.data(), nT, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_tapB1, prog.tapB1.data(), nT * 4, hipMemcpyHostToDevice, st));
-        }
-        std::vector<int> orderF, orderB;
-        std::vector<std::vector<FastRange>> rangesF, rangesB;
-        if (fast) {
-            // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle
-            const long long min_blocks = (long long)ctx->option("min_bucket_blocks", 128.0);     // a radius bucket with fewer blocks per launch joins the next one
-            const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)tile.nblk - 1) / tile.nblk);
-            orderF.resize(nT); rangesF.resize(T);
-            for (int64_t t = 0; t < T; ++t)
-                bucket_step(&prog.tapF0[t * B], &prog.tapF1[t * B], taps.lw, (int)B, &orderF[t * B], rangesF[t], min_chains);
-            HIPCHECK(hipMemcpyAsync(d_orderF, orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
-            if (full) {
-                orderB.resize(nT); rangesB.resize(T);
-                for (int64_t t = 0; t < T; ++t)
-                    bucket_step(&prog.tapB0[t * B], &prog.tapB1[t * B], taps.lw, (int)B, &orderB[t * B], rangesB[t], min_chains);
-                HIPCHECK(hipMemcpyAsync(d_orderB, orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
-            }
-        }
-        if (!taps.w.empty()) {
-            HIPCHECK(hipMemcpyAsync(d_taps, taps.w.data(), taps.w.size() * 8, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_off, taps.off.data(), taps.off.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_lw, taps.lw.data(), taps.lw.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_lw2, taps.lw2.data(), taps.lw2.size() * 4, hipMemcpyHostToDevice, st));
-        }
+        DeviceMeta M;
+        upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M);
+        unsigned char *const d_kindF = M.kindF, *const d_kindB = M.kindB, *const d_cmodeF = M.cmodeF, *const d_cmodeB = M.cmodeB;
+        double *const d_limitF = M.limitF, *const d_limitB = M.limitB;
+        int *const d_tapF0 = M.tapF0, *const d_tapF1 = M.tapF1, *const d_tapB0 = M.tapB0, *const d_tapB1 = M.tapB1;
+        int *const d_orderF = M.orderF, *const d_orderB = M.orderB;
+        double *const d_taps = M.taps;
+        int *const d_off = M.off, *const d_lw = M.lw, *const d_lw2 = M.lw2;
+        double *const d_invN = M.invN, *const d_w = M.w, *const d_dump = M.dump;
+        const std::vector<int> &orderF = M.h_orderF, &orderB = M.h_orderB;
+        const std::vector<std::vector<FastRange>> &rangesF = M.rangesF, &rangesB = M.rangesB;
 
         tr.mark("buckets + metadata H2D");
         // --- state ---
@@ -1280,9 +1554,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             PP.lik = d_lik;
         }
         float ms = 0;
-        std::vector<double> logE, local, means, invN;
-        std::vector<int64_t> abort_step;
-        std::vector<int32_t> abort_phase;
+        BatchOutcome O;
+        std::vector<double> &logE = O.logE, &local = O.local, &means = O.means, &invN = O.invN;
+        std::vector<int64_t> &abort_step = O.abort_step;
+        std::vector<int32_t> &abort_phase = O.abort_phase;
         auto passes = [&](const int64_t K) -> bool {
         bl1f::F1Params F1{};
         if (fused1d) {
@@ -1397,57 +1672,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (res_now) {
             ctx->timing.fwd_kernel_variant = 5;
             if (resident_gave_up()) { resident_failed = true; return false; }
-            // Undo the lagged scale (blhip_resident.hpp): the kernel's step k divided by the sum of step k - lag, so its row sums
-            // are S_k; the reference's normaliser is norm_k = S_k / (S_{k-1} s_k), s_k = k >= lag ? 1 / S_{k-lag} : 1.  The
-            // sums of the step are rewritten to what the launch-per-step kernels (lag 1) would have reported; S_k stays the
-            // normaliser of the stored row.  A sum near the bottom of the fp64 range (a run of extreme outliers times the lag)
-            // falls back to the launch-per-step kernels, whose magnitudes are the reference's.
-            rowsumF.assign(T, 0.0);
-            for (int64_t t = 0; t < T; ++t) rowsumF[t] = redF[(size_t)t * NRED];
-            for (int64_t t = 0; t < T; ++t) {
-                const double St = rowsumF[t];
-                if (!(St > 1e-150 && St < 1e150)) { resident_failed = true; return false; }
-                const double sk = t >= RQ.lag ? 1.0 / rowsumF[t - RQ.lag] : 1.0;
-                const double norm = t == 0 ? St : St / (rowsumF[t - 1] * sk);
-                double *r = &redF[(size_t)t * NRED];
-                r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
-            }
+            if (!resident_unlag(redF, T, RQ.lag, rowsumF)) { resident_failed = true; return false; }
         }
 
-        // --- evidence bookkeeping on the host, in the reference's order (core.py:385-404, 417) ---
-        logE.assign(B, 0.0);
-        abort_step.assign(B, -1);
-        abort_phase.assign(B, 0);
-        local.assign((size_t)B * T, 0.0);
-        bool raw_ok = true;                         // fused 1-D passes: no raw sum near the bottom of the fp64 range
-        for (int64_t b = 0; b < B; ++b) {
-            double le = 0.0;
-            for (int64_t t = 0; t < T; ++t) {
-                double norm = redF[((size_t)t * B + b) * NRED + 0];
-                if (fused1d) {
-                    // raw sums of the K-step launches (blhip_fused1d.hpp): inner steps carry the scale of their predecessor
-                    if (!(norm > 1e-200)) raw_ok = false;
-                    if (t % K != 0 && prog.kindF[(size_t)t * B + b] == SRC_PREV) norm /= redF[((size_t)(t - 1) * B + b) * NRED];
-                }
-                // RegimeSwitch renormalises the clamped prior (transitionModels.py:410): alpha = (u / sum u) L
-                if (prog.has_clamp && prog.cmodeF[(size_t)t * B + b]) norm /= redF[((size_t)t * B + b) * NRED + 1];
-                if (!(norm > 0.0)) { abort_step[b] = t; abort_phase[b] = 0; le = -INFINITY; break; }
-                le += std::log(norm);
-                local[(size_t)b * T + t] = norm * dV;
-            }
-            if (abort_step[b] < 0) le += std::log(dV);
-            logE[b] = le;
-        }
-
-        means.clear();
-        if (!evidence_only) means.assign((size_t)B * p->ndim * T, 0.0);
-        if (forward_only) {
-            for (int64_t b = 0; b < B; ++b)
-                for (int64_t t = 0; t < T; ++t) {
-                    const double *r = &redF[((size_t)t * B + b) * NRED];
-                    for (int k = 0; k < p->ndim; ++k) means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
-                }
-        }
+        bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
 
         // --- backward pass (core.py:424-470) ---
         invN.assign((size_t)B * T, 0.0);
@@ -1504,23 +1732,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) { resident_failed = true; return false; }
                 }
             }
-            for (int64_t b = 0; b < B; ++b) {
-                if (abort_step[b] >= 0) continue;
-                for (int64_t t = T - 1; t >= 0; --t) {
-                    const double *r = &redB[((size_t)t * B + b) * NRED];
-                    if (fused1d && !(r[0] > 1e-200)) raw_ok = false;
-                    // The reference tests sum(alpha_norm * beta_norm) > 0 (core.py:441).  r[0] is the same sum up to the lazily
-                    // dropped normalisers, which are positive -- except with signed kernels (Deterministic's cubic-spline
-                    // shift, AlphaStable's FFT kernel): there sum(alpha) = redF[t][0] and sum(beta) = r[5] may be negative and
-                    // the reference divides by them, so the sign test has to include them.
-                    double refnorm = r[0];
-                    if (prog.has_clamp) refnorm = r[0] / (redF[((size_t)t * B + b) * NRED] * (prog.cmodeB[(size_t)t * B + b] ? r[5] : 1.0));
-                    if (!(refnorm > 0.0)) { abort_step[b] = t; abort_phase[b] = 1; logE[b] = -INFINITY; break; }
-                    local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
-                    invN[(size_t)b * T + t] = (res_now && t >= RQ.lag) ? 1.0 : 1.0 / r[0];          // (resident: normalised in the kernel)
-                    for (int k = 0; k < p->ndim; ++k) means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
-                }
-            }
+            raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? RQ.lag : -1, O) && raw_ok;
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
                 for (int64_t t = 0; t < T; ++t) {
@@ -1544,97 +1756,24 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             } else { usedK = 1; passes(1); }
         }
 
-        // --- BLHIP_CARRY: keep every chain's filtered distribution of the last step, normalised (core.py:2173) ---
+        // --- carried states / average posterior / kept posterior / results ---
         if (carry) {
-            blhip_ctx::Carry &cs = ctx->carry[p->carry_slot];
-            cs.buf.ensure((size_t)B * G * 8);
-            std::vector<double> inv(B);
-            for (int64_t b = 0; b < B; ++b) inv[b] = 1.0 / redF[((size_t)(T - 1) * B + b) * NRED];
-            HIPCHECK(hipMemcpyAsync(d_w, inv.data(), B * 8, hipMemcpyHostToDevice, st));
             const double *fin; long long fstr;
             if (!evidence_only) { fin = d_post + (size_t)(T - 1) * G; fstr = (long long)T * G; }
             else { fin = fused1d ? d_pp[((T - 1) / usedK) & 1] : d_pp[(T - 1) & 1]; fstr = G; }
-            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-            hipLaunchKernelGGL(carry_store_kernel, dim3(gx, (unsigned)B), dim3(NTHREADS), 0, st, cs.buf.as<double>(), fin, fstr, G, d_w);
-            sync_stream(ctx, st);
-            cs.chains = B; cs.G = G; cs.valid = true;
-            cs.maxv.clear();
-            if (prog.has_clamp)                      // clamp batches run the generic kernel, which reports the state maximum
-                for (int64_t b = 0; b < B; ++b) cs.maxv.push_back(redF[((size_t)(T - 1) * B + b) * NRED + 6] * inv[b]);
+            store_carry(ctx, p, B, G, redF, fin, fstr, d_w, prog.has_clamp);
         }
-
-        // --- fold into the average posterior (core.py:1358-1366) ---
-        if (accumulate) {
-            double newref = ctx->acc_logref;
-            std::vector<double> lw(B, -INFINITY);
-            std::vector<char> valid(B, 0);
-            for (int64_t b = 0; b < B; ++b) {
-                // np.isfinite(logEvidence) guard (core.py:1358); a zero hyper-prior contributes log(0) = -inf, i.e. nothing
-                valid[b] = abort_step[b] < 0 && std::isfinite(logE[b]) && std::isfinite(log_w[c0 + b]);
-                if (!valid[b]) continue;
-                lw[b] = logE[b] + log_w[c0 + b];
-                if (lw[b] > newref) newref = lw[b];
-            }
-            if (std::isfinite(newref)) {
-                std::vector<double> w(B, 0.0);
-                int nfold = 0;
-                for (int64_t b = 0; b < B; ++b)
-                    if (valid[b]) { w[b] = std::exp(lw[b] - newref); nfold++; }
-                const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref);
-                HIPCHECK(hipMemcpyAsync(d_w, w.data(), B * 8, hipMemcpyHostToDevice, st));
-                HIPCHECK(hipMemcpyAsync(d_invN, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
-                HIPCHECK(hipEventRecord(ev[4], st));
-                if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
-                    const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
-                    hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
-                                       (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
-                } else {
-                    const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-                    hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
-                                       (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
-                }
-                HIPCHECK(hipEventRecord(ev[5], st));
-                sync_stream(ctx, st);
-                HIPCHECK(hipEventElapsedTime(&ms, ev[4], ev[5]));
-                ctx->timing.accumulate_ms += ms;
-                ctx->timing.accumulate_launches += 1;
-                ctx->acc_logref = newref;
-                ctx->acc_first = false;
-                ctx->acc_folded += nfold;
-            }
-        }
-
-        // --- normalise the kept posterior (core.py:389 / :441, applied lazily) ---
+        if (accumulate) fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN);
         if (keep) {
-            ctx->postinv.ensure(nT * 8);
-            HIPCHECK(hipMemcpyAsync(ctx->postinv.p, invN.data(), nT * 8, hipMemcpyHostToDevice, st));
-            sync_stream(ctx, st);
-            ctx->post_valid = true; ctx->post_scaled = false; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = G;
-            ctx->post_row0 = 0; ctx->post_row1 = T;
-            if (resident && !resident_failed) {      // rows the resident kernel normalised in place (invN = 1 there)
-                if (full) ctx->post_row1 = std::min<int64_t>(T, RQ.lag);
-                else ctx->post_row0 = std::max<int64_t>(0, T - RQ.lag);
+            int64_t row0 = 0, row1 = T;              // rows the resident kernel normalised in place (invN = 1 there) need no pass
+            if (resident && !resident_failed) {
+                if (full) row1 = std::min<int64_t>(T, RQ.lag);
+                else row0 = std::max<int64_t>(0, T - RQ.lag);
             }
-            ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
-            // default: normalise now, as part of the fit (core.py:441 is inside Study.fit); option lazy_normalise = 1 defers
-            // the pass to the first access of the sequence
-            if (ctx->option("lazy_normalise", 0.0) == 0.0) { ensure_post_scaled(ctx); sync_stream(ctx, st); }
+            keep_posterior(ctx, g, T, B, O, row0, row1);
         }
-
         tr.mark("accumulate / keep");
-        // --- results ---
-        if (res) {
-            for (int64_t b = 0; b < B; ++b) {
-                if (res->log_evidence) res->log_evidence[c0 + b] = logE[b];
-                if (res->abort_step) res->abort_step[c0 + b] = abort_step[b];
-                if (res->abort_phase) res->abort_phase[c0 + b] = abort_phase[b];
-                if (res->local_evidence)
-                    std::memcpy(res->local_evidence + (size_t)(c0 + b) * T, &local[(size_t)b * T], T * 8);
-                if (res->posterior_mean && !evidence_only)
-                    std::memcpy(res->posterior_mean + (size_t)(c0 + b) * p->ndim * T,
-                                &means[(size_t)b * p->ndim * T], (size_t)p->ndim * T * 8);
-            }
-        }
+        write_results(res, p, c0, B, O, !evidence_only);
     }
     tr.mark("batches done");
     HIPCHECK(hipEventRecord(ev[7], st));
