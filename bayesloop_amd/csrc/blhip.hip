@@ -1430,19 +1430,22 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
         }
         blr::ResParams RQ{};
+        double *d_res_sfwd = nullptr;
+        std::vector<double> res_sfwd;                          // the forward pass's scales s_k (backward: predicted posterior sums)
         int res_nblk = 0;
         unsigned *d_res_abort = nullptr;
         size_t res_flag_bytes = 0;
         if (resident) {
             const size_t nt = (size_t)rp.ntiles;
             const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
-            const size_t b_w = carve_size(2 * (blr::R + 1) * 8);
+            const size_t b_w = carve_size(2 * (blr::R + 1) * 8) + carve_size((size_t)T * 8);
             res_flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
             ctx->resx.ensure(b_cols + b_rows + b_w + res_flag_bytes);
             char *rc = ctx->resx.as<char>();
             RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
             RQ.rows = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TC);
             double *d_w = carve<double>(rc, 2 * (blr::R + 1));
+            d_res_sfwd = carve<double>(rc, (size_t)T);
             RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
             RQ.flagR = carve<unsigned>(rc, nt);
             RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
@@ -1603,7 +1606,15 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             Q.psum = psum;
             // rows of the kept sequence are normalised inside the kernel, `lag` steps behind (what the host then still scales: the
             // last / first `lag` rows)
-            if (bwd) { Q.src0 = d_uniform; Q.post = d_post; Q.store = 1; Q.means = 1; Q.normalise = 1; }
+            if (bwd) {
+                // the posteriors are stored normalised: their sums follow from the forward scales and the last forward row sum
+                // (blhip_resident.hpp: predicted_sum)
+                res_sfwd.assign(T, 1.0);
+                for (int64_t t = RQ.lag; t < T; ++t) res_sfwd[t] = 1.0 / rowsumF[t - RQ.lag];
+                HIPCHECK(hipMemcpyAsync(d_res_sfwd, res_sfwd.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
+                Q.sfwd = d_res_sfwd; Q.n_first = rowsumF[T - 1] * (1.0 / (double)G);
+                Q.src0 = d_uniform; Q.post = d_post; Q.store = 1; Q.means = 1; Q.normalise = 0;
+            }
             else {
                 Q.src0 = d_prior; Q.post = evidence_only ? nullptr : d_post; Q.store = evidence_only ? 0 : 1;
                 Q.means = forward_only ? 1 : 0; Q.normalise = forward_only ? 1 : 0;
@@ -1731,8 +1742,16 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     const double Ct = redB[(size_t)t * NRED + 2], Nt = redB[(size_t)t * NRED];
                     if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) { resident_failed = true; return false; }
                 }
+                // the kernel stored every posterior divided by its PREDICTED sum: the prediction must reproduce the reduced sums
+                double npred = rowsumF[T - 1] * (1.0 / (double)G);
+                for (int64_t t = T - 1; t >= 0; --t) {
+                    const int64_t k = T - 1 - t;
+                    if (k > 0) npred = (k >= RQ.lag ? 1.0 / redB[(size_t)(t + RQ.lag) * NRED + 2] : 1.0) * npred / res_sfwd[t + 1];
+                    const double Nt = redB[(size_t)t * NRED];
+                    if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) { resident_failed = true; return false; }
+                }
             }
-            raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? RQ.lag : -1, O) && raw_ok;
+            raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O) && raw_ok;
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
                 for (int64_t t = 0; t < T; ++t) {
@@ -1767,7 +1786,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (keep) {
             int64_t row0 = 0, row1 = T;              // rows the resident kernel normalised in place (invN = 1 there) need no pass
             if (resident && !resident_failed) {
-                if (full) row1 = std::min<int64_t>(T, RQ.lag);
+                if (full) row1 = 0;                  // (every posterior row was stored normalised)
                 else row0 = std::max<int64_t>(0, T - RQ.lag);
             }
             keep_posterior(ctx, g, T, B, O, row0, row1);

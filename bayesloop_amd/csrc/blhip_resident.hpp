@@ -61,9 +61,10 @@ struct ResParams {
     int T, d, rec_len, lag;
     int store;                   // forward: write every step's state to post (full / forward-only fits)
     int means;                   // forward: also sum a * grid values (forward-only fits)
-    int normalise;               // normalise the rows of post in the kernel, `lag` steps behind (forward-only fits: the filtered
-                                 // distributions; backward: the posteriors) -- the sum of a row is known `lag` steps later; the
-                                 // first / last `lag` rows are left to the host
+    int normalise;               // FORWARD-ONLY fits: normalise the stored filtered distributions in the kernel, `lag` steps behind (the
+                                 // sum of a row is known `lag` steps later; the last `lag` rows are left to the host)
+    const double *sfwd;          // BACKWARD: the forward pass's scales s_k (T doubles) and the sum of the last step's posterior: the
+    double n_first;              //   posteriors are stored normalised -- their sums follow from scalars (see predicted_sum)
     const double *src0;          // what the first step consumes instead of a transition: prior (forward) / uniform (backward)
     double *post;                // [T][n0 * n1]: forward: stored states (out); backward: stored states (in) -> posteriors (out)
     const double *w0, *w1;       // R + 1 half-kernel weights per axis, zero-padded; {1, 0, ...} = no filter
@@ -234,8 +235,8 @@ struct Res {
     static constexpr int NW = NT / 64;
     static_assert(NT % 64 == 0, "whole waves");
     static constexpr int GPL = (512 / NW + 63) / 64;     // tiles per lane when NW waves share the <= 512 tiles' partial sums
-    static constexpr int NG = BWD ? 2 : 1;               // sums every tile publishes per step: the scale sum (forward: sum a = the row sum;
-                                                         // backward: sum c) and, backward, the row sum of the posterior
+    static constexpr int NG = 1;                         // sums every tile publishes per step: the scale sum (forward: sum a = the row sum
+                                                         // of the stored state; backward: sum c)
     static constexpr int LDS_TILE = TR * P;          // doubles
     static constexpr int LDS_M0 = LDS_TILE;          // TR row coordinates of the tile
     static constexpr int LDS_COL = LDS_M0 + TR;      // the tile's column constants: [TC] grid value, [TC] cA, [TC] cB
@@ -259,7 +260,8 @@ struct Res {
         double xd[DMAX];                             // this step's data record (wave-uniform)
         double al8[BWD ? CHK : 1];                   // backward: the stored forward state of the chunk being processed
         unsigned long long gq[GPL][2 * NG];          // this wave's share of the lagged sums' granules, in flight since the step began
-        double nz8[CHK];                             // the row being normalised: the chunk's cells, `lag` steps back
+        double nz8[BWD ? 1 : CHK];                   // forward-only: the row being normalised (the chunk's cells, `lag` steps back)
+        double npred;                                // backward: the sum of this step's posterior, predicted from scalars
         double sums[5];
         bool dead;
 
@@ -303,26 +305,22 @@ struct Res {
             const int t = time_of(Q, k);
 #pragma unroll
             for (int q = 0; q < DMAX; ++q) xd[q] = q < Q.d ? ldu(Q.rec, (long long)t * Q.rec_len + q) : nan_();
-            // one-chunk segments: what the epilogue reads from HBM (the stored forward state, the row to normalise) is requested
-            // now and has both passes' worth of time to arrive
-            if (SEG == CHK && Q.post && (BWD || (Q.normalise && k >= Q.lag))) {
-                const Geo vg = vgeo();
-                if (vg.seg == 0) early_loads<-1>(Q, k, vg); else early_loads<1>(Q, k, vg);
-            }
         }
         BLR_INL double *row_ptr(const ResParams &Q, int k, int r0, int c) const {
             return Q.post ? Q.post + (long long)time_of(Q, k) * Q.n0 * Q.n1 + (long long)(i0 + r0) * Q.n1 + (j0 + c) : nullptr;
         }
-        // the row written `lag` steps ago (time t -+ lag), whose sum arrives with this step's lagged sums
+        // forward-only: the row written `lag` steps ago (time t - lag), whose sum arrives with this step's lagged sums
         BLR_INL double *lagged_row_ptr(const ResParams &Q, int k, double *pt0) const {
-            return (Q.normalise && k >= Q.lag && pt0) ? pt0 + (long long)(BWD ? Q.lag : -Q.lag) * Q.n0 * Q.n1 : nullptr;
+            return (!BWD && Q.normalise && k >= Q.lag && pt0) ? pt0 - (long long)Q.lag * Q.n0 * Q.n1 : nullptr;
         }
-        template <int DIR>
-        BLR_INL void early_loads(const ResParams &Q, int k, const Geo &vg) {
-            double *pt0 = row_ptr(Q, k, first_pos(vg.seg, DIR), vg.line);
-            load_alpha8<DIR>(pt0, lagged_row_ptr(Q, k, pt0), Q.n1, 0);
+        // backward: N_t = sum_cells alpha_t beta_t WITHOUT a reduction.  beta_t = T(c_{t+1}) s'_t and the reflect-boundary Gaussian
+        // stencil T is self-adjoint, so N_t = s'_t sum T(alpha_t) c_{t+1}; the forward pass made alpha_{t+1} = T(alpha_t) s_{t+1} L_{t+1}
+        // and c_{t+1} = beta_{t+1} L_{t+1}, hence  N_t = s'_t N_{t+1} / s_{t+1}  -- scalars every tile has (s' = this step's lagged
+        // scale, s = the forward scales, N_{T-1} = sum alpha_{T-1} / G).  The posterior is stored normalised right away; the host
+        // compares the prediction with the reduced sums (rounding-level agreement, ~2e-16 per step) and falls back if it ever differs.
+        BLR_INL void predicted_sum(const ResParams &Q, int k, double scale) {
+            if (BWD) npred = k == 0 ? Q.n_first : scale * npred / ldu(Q.sfwd, time_of(Q, k) + 1);
         }
-
         // ---- the lagged global sums: this wave's share of the tiles' partial sums of step ks (tiles wv * tpw + lane + 64 j) --------
         // The loads are issued when the step begins and consumed before the axis-0 pass: their latency hides under the axis-1 pass.
         BLR_INL void gather_issue(const ResParams &Q, int ks) {
@@ -481,7 +479,7 @@ struct Res {
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) al8[j] = pt0[(long long)(DIR * (p0 + j)) * n1];
             }
-            if (ptn0) {                              // the row `lag` steps back, to be normalised in this step
+            if (!BWD && ptn0) {                      // the row `lag` steps back, to be normalised in this step
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) nz8[j] = ptn0[(long long)(DIR * (p0 + j)) * n1];
             }
@@ -493,7 +491,7 @@ struct Res {
         BLR_INL void epilogue8(const ResParams &Q, double *x0, const double *m0p, double *pt0, double *ptn0, double invn, int p0,
                                const double (&v)[CHK], double scale, Rec &rc, const ColC &cc) {
             const double g1 = cc.g1, cA = cc.cA, cB = cc.cB;
-            if (ptn0) {
+            if (!BWD && ptn0) {
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) ptn0[(long long)(DIR * (p0 + j)) * Q.n1] = nz8[j] * invn;
             }
@@ -542,7 +540,7 @@ struct Res {
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
                     const double pl = Lv == 0.0 ? nan_() : ldexp_(pp * rc.iE, -rc.nE);
                     keep = cn;
-                    pt0[(long long)(DIR * p) * Q.n1] = pp;
+                    pt0[(long long)(DIR * p) * Q.n1] = pp * invn;            // (invn = 1 / predicted sum: stored normalised)
                     sums[0] += pp; sums[1] += pl; sums[2] += cn;
                     sums[3] = fma(pp, m0p[DIR * p], sums[3]); sums[4] = fma(pp, g1, sums[4]);
                 }
@@ -565,7 +563,8 @@ struct Res {
             const double *m0p = lds + LDS_M0 + r0;
             double *pt0 = row_ptr(Q, k, r0, c);
             double *ptn0 = lagged_row_ptr(Q, k, pt0);
-            const double invn = ptn0 ? lagged_inverse(Q, k, NG - 1) : 1.0;
+            predicted_sum(Q, k, scale);
+            const double invn = BWD ? 1.0 / npred : (ptn0 ? lagged_inverse(Q, k, 0) : 1.0);
             auto far_fetch = [&](double (&f)[R]) {
                 if (vg.far == 2) {
                     if (!wait_ge(Q.flagR + vg.nb, (unsigned)k, Q)) dead = true;
@@ -574,7 +573,10 @@ struct Res {
                     for (int q = 0; q < R; ++q) f[q] = ld_sc1(s + (long long)(vg.side == 1 ? R - 1 - q : q) * TC);
                 }
             };
-            auto pre8 = [&](int p0) { if (SEG != CHK) load_alpha8<DIR>(pt0, ptn0, Q.n1, p0); };     // (one chunk: loaded when the step began)
+            // (requested right before the chunk's arithmetic.  Requesting the one-chunk shapes' 16 HBM-missing loads per thread earlier --
+            //  when the step begins, or after the axis-1 pass -- was measured: their issue alone holds a wave for ~2.8 k cycles wherever
+            //  it is placed, and the step got slower, 24.4 k / 26.8 k vs 22.6 k cycles backward)
+            auto pre8 = [&](int p0) { load_alpha8<DIR>(pt0, ptn0, Q.n1, p0); };
             auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc); };
             double wk[R + 1];
 #pragma unroll
@@ -586,6 +588,7 @@ struct Res {
         // the first executed step has no transition: its input is src0 (prior / uniform), scale 1
         template <int DIR>
         BLR_INL void first_step_d(const ResParams &Q, const Geo &vg) {
+            predicted_sum(Q, 0, 1.0);
             Rec rc{1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0, 0, 0};
             const int r0 = first_pos(vg.seg, DIR), c = vg.line;
             const ColC cc{lds[LDS_COL + c], lds[LDS_COL + TC + c], lds[LDS_COL + 2 * TC + c]};
@@ -602,7 +605,7 @@ struct Res {
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) v[j] = s[(long long)(DIR * (p0 + j)) * Q.n1];
                 load_alpha8<DIR>(pt0, nullptr, Q.n1, p0);
-                epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, 1.0, p0, v, 1.0, rc, cc);
+                epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, BWD ? 1.0 / Q.n_first : 1.0, p0, v, 1.0, rc, cc);
             }
         }
         BLR_INL void first_step(const ResParams &Q) { const Geo vg = vgeo(); if (vg.seg == 0) first_step_d<-1>(Q, vg); else first_step_d<1>(Q, vg); }
@@ -736,7 +739,6 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
 #pragma unroll
                     for (int q = 0; q < 5; ++q) out[(long long)q * Q.ntiles] = tot[q];
                     K::publish_sum(Q, th.tile, k, 0, tot[2]);
-                    K::publish_sum(Q, th.tile, k, 1, tot[0]);
                 } else {
                     out[0] = tot[0];
                     if (Q.means) { out[3LL * Q.ntiles] = tot[1]; out[4LL * Q.ntiles] = tot[2]; }

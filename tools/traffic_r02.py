@@ -57,8 +57,9 @@ if __name__ == '__main__':
     out = {}
     for path in sys.argv[1:]:
         w = os.path.basename(path.rstrip('/')).replace('prof_r02_', '')
-        if w == 'c4':        # bench.py --steps 1 --warmup 1 => 3 fits (warm-up, timed, end-to-end) x T = 256 time steps per direction, cells = all 512 chains of a step
-            out.update(summarise(path, steps=3 * 256, cells=512 * 512 * 512))
+        if w == 'c4':        # bench.py --steps 1 --warmup 1 => 3 fits (warm-up, timed, end-to-end) x 2 batches x T = 256 logical launches per direction;
+            # cells = the average batch (512 chains / 2) -- the unit bench.py's roofline uses (cells_per_launch = cell-steps of the pass / launches)
+            out.update(summarise(path, steps=3 * 2 * 256, cells=256 * 512 * 512))
         elif w == 'fwd2048':  # 3 fits x 200 steps in one resident launch each
             r = summarise(path, steps=3 * 200, cells=2048 * 2048)
             if 'fwd' in r:
@@ -68,5 +69,5 @@ if __name__ == '__main__':
             out['c3'] = r
     out['source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_r02.sh) on `python bench.py --workload <w> '
                      '--steps 1 --warmup 1 --no-extra --no-cpu`; FETCH_SIZE x2 (gfx950 correction); tools/traffic_r02.py.  C4: per logical '
-                     'step launch of ALL 512 chains (two batches); fwd2048 / c3: the time-resident kernel, per time step')
+                     'step launch of a batch (average batch = 256 chains); fwd2048 / c3: the time-resident kernel, per time step')
     json.dump(out, sys.stdout, indent=1)
