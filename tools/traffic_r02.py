@@ -26,6 +26,28 @@ def stats(out):
     return res
 
 
+def busy_ns(out, d):
+    """Time at least one kernel of direction d was running (union of the dispatch intervals of the kernel trace): the radius buckets
+    of a step run concurrently on separate streams, so the SUM of their durations over-counts the wall time of a logical step."""
+    iv = []
+    for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_trace.csv'), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if direction(row['Kernel_Name']) == d:
+                iv.append((int(row['Start_Timestamp']), int(row['End_Timestamp'])))
+    iv.sort()
+    tot, cur_a, cur_b = 0, None, None
+    for a, b in iv:
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                tot += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    if cur_b is not None:
+        tot += cur_b - cur_a
+    return tot
+
+
 def direction(name):
     if 'resident_kernel<' in name:
         return 'bwd' if name.split('resident_kernel<')[1].split('>')[0].split(',')[-1].strip() in ('true', '1') else 'fwd'
@@ -48,7 +70,8 @@ def summarise(out, steps, cells, bytes_fwd=16, bytes_bwd=32):
         calls = sum(v[0] for k, v in st.items() if direction(k) == d)
         res[d] = dict(hbm_bytes_per_step_launch=(fb + wb) / steps, fetch_bytes_per_step_launch=fb / steps,
                       write_bytes_per_step_launch=wb / steps, algorithmic_bytes_per_step_launch=bpc * cells,
-                      ratio=(fb + wb) / steps / (bpc * cells), kernel_ns_per_step_launch=ns / steps, kernel_launches=calls,
+                      ratio=(fb + wb) / steps / (bpc * cells), kernel_ns_per_step_launch=ns / steps,
+                      kernel_busy_ns_per_step_launch=busy_ns(out, d) / steps, kernel_launches=calls,
                       kernels=sorted(set(k.split('(')[0].replace('void ', '') for k in names)))
     return res
 
