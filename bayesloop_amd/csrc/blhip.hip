@@ -24,6 +24,7 @@
 #include "blhip_fused1d.hpp"
 #include "blhip_persist1d.hpp"
 #include "blhip_resident.hpp"
+#include "blhip_chainres.hpp"
 
 using namespace blk;
 
@@ -435,6 +436,42 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
     else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd);
     else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd);
     else launch_resident_t<32, 32, 8, 8>(s, Q, bwd);
+    HIPCHECK(hipGetLastError());
+}
+
+// ---- chain-resident kernel (blhip_chainres.hpp) ---------------------------------------------------------------------------------
+template <typename KernT>
+void launch_chain_fn(KernT kern, bool &armed, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
+    if (!armed) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); armed = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(Q.nslots * Q.strips)), dim3(blc::NT), lds, s, Q);
+}
+
+template <int NK, int NTW>
+void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
+    static bool armed[3] = {false, false, false};
+    const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
+    if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true>, armed[0], s, Q, lds);
+    else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true>, armed[1], s, Q, lds);
+    else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false>, armed[2], s, Q, lds);
+}
+
+template <int NTW>
+void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
+    switch (nk) {
+        case 8: launch_chain_k<8, NTW>(s, Q, bwd, store); break;
+        case 12: launch_chain_k<12, NTW>(s, Q, bwd, store); break;
+        case 16: launch_chain_k<16, NTW>(s, Q, bwd, store); break;
+        case 20: launch_chain_k<20, NTW>(s, Q, bwd, store); break;
+        case 24: launch_chain_k<24, NTW>(s, Q, bwd, store); break;
+        default: fail("internal: chain-resident kernel with %d band blocks", nk);
+    }
+}
+
+void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 4) launch_chain_w<4>(s, Q, nk, bwd, store);
+    else if (ntw == 2) launch_chain_w<2>(s, Q, nk, bwd, store);
+    else if (ntw == 1) launch_chain_w<1>(s, Q, nk, bwd, store);
+    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
     HIPCHECK(hipGetLastError());
 }
 
@@ -1181,20 +1218,87 @@ void write_results(blhip_result *res, const blhip_problem *p, int64_t c0, int64_
     }
 }
 
+// The chain-resident path (blhip_chainres.hpp): which chains of the batch run together, in which order, with which band width.
+struct ChainResPlan {
+    int ntw = 0, strips = 0, cpr = 0;            // product tiles per wave, strips per chain, chains per launch
+    std::vector<int> order, tap_id;              // chains sorted by stencil radius; the chain's axis-0 kernel (-1: none)
+    std::vector<int> round_start, round_nk;      // launches: order[round_start[r] .. round_start[r + 1]), band blocks NK
+};
+
+// every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
+bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
+    if (g.n0 != 128 && g.n0 != 256 && g.n0 != 512) return false;
+    if (g.n1 % blc::WCOL) return false;
+    cp.strips = g.n1 / blc::WCOL;
+    cp.ntw = g.n0 / (blc::NW * blc::TM);
+    if (cp.strips > blc::MAX_STRIPS || cp.strips > cus) return false;
+    cp.cpr = cus / cp.strips;
+    cp.tap_id.assign(B, -1);
+    std::vector<int> lw(B, 0);
+    for (int64_t b = 0; b < B; ++b) {
+        if (prog.kindF[b] != SRC_PRIOR || prog.tapF0[b] >= 0 || prog.tapF1[b] >= 0) return false;
+        const int k0 = T > 1 ? prog.tapF0[(size_t)B + b] : -1;
+        for (int64_t t = 1; t < T; ++t) {
+            const size_t k = (size_t)t * B + b;
+            if (prog.kindF[k] != SRC_PREV || prog.tapF0[k] != k0 || prog.tapF1[k] >= 0) return false;
+        }
+        if (full) {
+            const size_t kl = (size_t)(T - 1) * B + b;
+            if (prog.kindB[kl] != SRC_UNIFORM || prog.tapB0[kl] >= 0 || prog.tapB1[kl] >= 0) return false;
+            for (int64_t t = 0; t < T - 1; ++t) {
+                const size_t k = (size_t)t * B + b;
+                if (prog.kindB[k] != SRC_PREV || prog.tapB0[k] != k0 || prog.tapB1[k] >= 0) return false;
+            }
+        }
+        cp.tap_id[b] = k0;
+        lw[b] = k0 >= 0 ? taps.lw[k0] : 0;
+        if (lw[b] > 40) return false;
+    }
+    cp.order.resize(B);
+    for (int64_t b = 0; b < B; ++b) cp.order[b] = (int)b;
+    std::stable_sort(cp.order.begin(), cp.order.end(), [&](int a, int c) { return lw[a] < lw[c]; });
+    cp.round_start.clear(); cp.round_nk.clear();
+    for (int64_t s0 = 0; s0 < B; s0 += cp.cpr) {
+        const int64_t s1 = std::min<int64_t>(B, s0 + cp.cpr);
+        const int r0 = std::max(8, (lw[cp.order[s1 - 1]] + 7) / 8 * 8);
+        cp.round_start.push_back((int)s0);
+        cp.round_nk.push_back((blc::TM + 2 * r0) / 4);
+    }
+    cp.round_start.push_back((int)B);
+    return true;
+}
+
 // Undo the lagged scale of the time-resident kernel (blhip_resident.hpp): its step k divided by the sum of step k - lag, so its row
 // sums are S_k; the reference's normaliser is norm_k = S_k / (S_{k-1} s_k), s_k = k >= lag ? 1 / S_{k-lag} : 1.  The sums of every step
 // are rewritten to what the launch-per-step kernels (lag 1) would have reported; rowsum keeps S_k, the normaliser of the stored row.
 // false: a sum near the bottom / top of the fp64 range (a run of extreme outliers times the lag) -> the caller falls back to the
 // launch-per-step kernels, whose magnitudes are the reference's.
-bool resident_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum) {
+bool resident_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B = 1, int64_t b = 0) {
     rowsum.assign(T, 0.0);
-    for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[(size_t)t * NRED];
+    for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[((size_t)t * B + b) * NRED];
     for (int64_t t = 0; t < T; ++t) {
         const double St = rowsum[t];
         if (!(St > 1e-150 && St < 1e150)) return false;
         const double sk = t >= lag ? 1.0 / rowsum[t - lag] : 1.0;
         const double norm = t == 0 ? St : St / (rowsum[t - 1] * sk);
-        double *r = &redF[(size_t)t * NRED];
+        double *r = &redF[((size_t)t * B + b) * NRED];
+        r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
+    }
+    return true;
+}
+
+// The same for the chain-resident kernel (blhip_chainres.hpp), whose step k divides by the normaliser of step k - lag:
+// s_k = S_(k-lag-1) s_(k-lag) / S_(k-lag)  (1 while k < lag; S_(-1) = 1).
+bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B, int64_t b) {
+    rowsum.assign(T, 0.0);
+    for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[((size_t)t * B + b) * NRED];
+    std::vector<double> s(T, 1.0);
+    for (int64_t t = 0; t < T; ++t) {
+        const double St = rowsum[t];
+        if (!(St > 1e-150 && St < 1e150)) return false;
+        if (t >= lag) s[t] = (t - lag - 1 >= 0 ? rowsum[t - lag - 1] : 1.0) * s[t - lag] / rowsum[t - lag];
+        const double norm = t == 0 ? St : St / (rowsum[t - 1] * s[t]);
+        double *r = &redF[((size_t)t * B + b) * NRED];
         r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
     }
     return true;
@@ -1467,6 +1571,39 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             d_psF = ctx->psumF.as<double>();
         }
         std::vector<double> rowsumF;                          // resident forward pass: the actual sums of the stored rows
+
+        // ---- chain-resident path: rounds of chains stay in LDS for a whole pass (blhip_chainres.hpp) ------------------------------------
+        ChainResPlan cp;
+        bool chainres = false;
+        if (!resident && fast && B >= 2 && p->obs_model == BLHIP_OM_GAUSSIAN && FP.use_rec && !resume && !carry && d <= blc::DMAX &&
+            !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
+            chainres = plan_chainres(g, prog, taps, B, T, full, std::min(ctx->num_cus, 256), cp);
+        blc::ChainParams CQ{};
+        int *d_cres_order = nullptr;
+        size_t cres_gran_bytes = 0;
+        std::vector<std::vector<double>> rowsumC;             // chain-resident forward pass: the actual sums of the stored rows, per chain
+        if (chainres) {
+            cres_gran_bytes = carve_size((size_t)blc::NSLOT * cp.cpr * cp.strips * 2 * 8);
+            ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + cres_gran_bytes + carve_size(64));
+            char *rc = ctx->resx.as<char>();
+            d_cres_order = carve<int>(rc, (size_t)B);
+            int *d_tapid = carve<int>(rc, (size_t)B);
+            CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * cp.cpr * cp.strips * 2);
+            d_res_abort = carve<unsigned>(rc, 16);
+            CQ.abort_word = d_res_abort;
+            HIPCHECK(hipMemcpyAsync(d_cres_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+            sync_stream(ctx, st);
+            CQ.n0 = g.n0; CQ.n1 = g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = d; CQ.rec_len = rec_len;
+            CQ.lag = std::max(1, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 3.0)));
+            CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = d_taps; CQ.tap_off = d_off; CQ.tap_lw = d_lw;
+            CQ.post_stride = (long long)T * G;
+            CQ.m0 = d_m0; CQ.m1 = d_m1; CQ.colA = d_colA; CQ.colB = d_colB; CQ.rec = d_rec; CQ.step0 = FP.step0;
+            CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
+            psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
+            ctx->psumF.ensure(psz * 8);
+            d_psF = ctx->psumF.as<double>();
+        }
         bool resident_failed = false;
 
         // bucket streams: fork = every bucket stream waits for the main stream; join = the main stream waits for all of them
@@ -1598,7 +1735,45 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
         }
         const bool res_now = resident && !resident_failed;
-        const int nblk_now = res_now ? res_nblk : tile.nblk;      // partial-sum slots per (step, sum) of this pass
+        const bool cres_now = chainres && !resident_failed;
+        const int nblk_now = res_now ? res_nblk : (cres_now ? cp.strips : tile.nblk);      // partial-sum slots per (step, sum) of this pass
+        // one pass of the chain-resident kernel: the launches of the rounds follow each other on the stream
+        auto chainres_pass = [&](bool bwd, double *psum) {
+            HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * cp.strips * 8, st));
+            HIPCHECK(hipMemsetAsync(d_res_abort, 0, 64, st));
+            for (size_t r = 0; r + 1 < cp.round_start.size(); ++r) {
+                blc::ChainParams Q = CQ;
+                HIPCHECK(hipMemsetAsync(CQ.gran, 0, cres_gran_bytes, st));       // tags restart with every launch
+                Q.chain_ids = d_cres_order + cp.round_start[r];
+                Q.nslots = cp.round_start[r + 1] - cp.round_start[r];
+                Q.psum = psum;
+                Q.src0 = bwd ? d_uniform : d_prior;
+                Q.post = d_post;
+                Q.means = (!bwd && forward_only) ? 1 : 0;
+#ifdef BLC_PROF
+                ctx->small.ensure(2 * 16 * 16 * 8);
+                HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+                Q.prof = ctx->small.as<unsigned long long>();
+#endif
+                launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, bwd || !evidence_only);
+#ifdef BLC_PROF
+                {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
+                    unsigned long long hh[2 * 16 * 16];
+                    HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
+                    sync_stream(ctx, st);
+                    static const char *names[8] = {"start", "ring", "chain0", "scale+anchor", "epi0", "tiles1..", "sums", "barrier"};
+                    for (int wvi = 0; wvi < 2; ++wvi) {
+                        const unsigned long long *h = hh + wvi * 256;
+                        double acc[8] = {0}; int n = 0;
+                        for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                        std::fprintf(stderr, "[blc prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", cp.round_nk[r], wvi ? 2 : 0, n);
+                        double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                        std::fprintf(stderr, " | total %.0f\n", tot);
+                    }
+                }
+#endif
+            }
+        };
         auto resident_launch = [&](bool bwd, double *psum) {
             blr::ResParams Q = RQ;
             HIPCHECK(hipMemsetAsync(RQ.flagC, 0, res_flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
@@ -1651,8 +1826,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             return false;
         };
         if (res_now) { ctx->pinS.ensure(64); resident_launch(false, d_psF); }
+        if (cres_now) { ctx->pinS.ensure(64); chainres_pass(false, d_psF); }
         fork_streams();
-        for (int64_t t = 0; t < T && !persist && !fused1d && !res_now; ++t) {
+        for (int64_t t = 0; t < T && !persist && !fused1d && !res_now && !cres_now; ++t) {
             if (multistream && t > 0 && !same_membership(orderF, rangesF, t - 1, t)) { join_streams(); fork_streams(); }
             const double *srcp; double *dstp; long long sstr, dstr;
             if (evidence_only) {
@@ -1685,6 +1861,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (resident_gave_up()) { resident_failed = true; return false; }
             if (!resident_unlag(redF, T, RQ.lag, rowsumF)) { resident_failed = true; return false; }
         }
+        if (cres_now) {
+            ctx->timing.fwd_kernel_variant = 6;
+            if (resident_gave_up()) { resident_failed = true; return false; }
+            rowsumC.assign(B, std::vector<double>());
+            for (int64_t b = 0; b < B; ++b)
+                if (!chain_unlag(redF, T, CQ.lag, rowsumC[b], B, b)) { resident_failed = true; return false; }
+        }
 
         bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
 
@@ -1714,8 +1897,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 }
             }
             if (res_now) resident_launch(true, d_psB);
+            if (cres_now) chainres_pass(true, d_psB);
             fork_streams();
-            for (int64_t t = T - 1; t >= 0 && !persist && !fused1d && !res_now; --t) {
+            for (int64_t t = T - 1; t >= 0 && !persist && !fused1d && !res_now && !cres_now; --t) {
                 if (multistream && t < T - 1 && !same_membership(orderB, rangesB, t + 1, t)) { join_streams(); fork_streams(); }
                 // reads c_{t+1} and the stored alpha_t, writes c_t and posterior_t
                 run_step(MODE_BWD, t, d_pp[(t + 1) & 1], G, d_pp[t & 1], G, d_post + (size_t)t * G, (long long)T * G,
@@ -1751,11 +1935,20 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) { resident_failed = true; return false; }
                 }
             }
+            if (cres_now) {
+                ctx->timing.bwd_kernel_variant = 6;
+                if (resident_gave_up()) { resident_failed = true; return false; }
+                for (int64_t b = 0; b < B; ++b)
+                    for (int64_t t = 0; t < T; ++t) {         // (the lagged scale of the backward state: same range guard)
+                        const double *r = &redB[((size_t)t * B + b) * NRED];
+                        if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) { resident_failed = true; return false; }
+                    }
+            }
             raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O) && raw_ok;
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
                 for (int64_t t = 0; t < T; ++t) {
-                    const double n0 = res_now ? rowsumF[t] : redF[((size_t)t * B + b) * NRED];
+                    const double n0 = res_now ? rowsumF[t] : (cres_now ? rowsumC[b][t] : redF[((size_t)t * B + b) * NRED]);
                     invN[(size_t)b * T + t] = (n0 != 0.0 && std::isfinite(n0)) ? 1.0 / n0 : 0.0;     // (a signed kernel can leave a negative raw sum)
                     if (res_now && t <= T - 1 - RQ.lag) invN[(size_t)b * T + t] = 1.0;                // (already normalised by the resident kernel)
                 }

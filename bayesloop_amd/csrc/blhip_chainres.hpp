@@ -1,0 +1,358 @@
+// Time-resident step kernel for BATCHES of chains whose transition filters axis 0 only: the hyper-study over the width of one
+// Gaussian random walk (HyperStudy.fit, core.py:1349-1366, with transitionModels.py:107-111 on the first parameter) -- BASELINE C4.
+//
+// Why: with a launch per step (blhip_mfma.hpp) every chain streams its state through HBM twice per step: 16 B per cell forward, 32 B
+// backward, and the backward launches already run at 0.97 of what a streaming copy reaches on the part.  A chain's state is 2 MiB
+// (512 x 512); the LDS of the chip holds 40 MiB.  So a ROUND of chains stays resident:
+//
+//  * a chain is cut into column strips of 16 grid columns x ALL n0 rows (the stencil runs along the rows, so strips never exchange
+//    halos); block = strip = 8 waves; n1 / 16 strips per chain, floor(CUs / strips) chains per launch (C4: 32 strips, 8 chains);
+//    the launch runs all T steps of its chains; the state lives in LDS (two buffers of n0 x 16 doubles, ping-pong: one barrier per
+//    step); the launches of a pass follow each other on one stream, chains sorted by stencil radius;
+//  * per step a wave owns n0 / 8 rows: banded Toeplitz products on the fp64 matrix pipe exactly as in blm::mfma_step_kernel (B
+//    operand = a register ring over the state, here filled from LDS: 512 contiguous bytes per read, conflict-free; A operand = the
+//    weight band, in LDS), the same fused epilogue (lazy normaliser, Gaussian likelihood recurrence with stride 4, sums);
+//  * HBM sees only what the fit has to keep: forward 8 B per cell (the stored filtered distribution; nothing at all for
+//    evidence-only fits), backward 16 B (stored alpha in, posterior out).  The stored alpha of the NEXT step is requested one whole
+//    step ahead, so the loads have a full step (~5 us) to arrive;
+//  * the lazy normaliser is a per-chain sum over its strips.  A step is linear in its input, so its scale may be ANY positive
+//    number the host can reconstruct; it only has to keep the state in range.  Every strip publishes its partial sum of step k as
+//    a data-tagged granule pair (no flag, no fence); step k divides by the NORMALISER of step k - lag, n_j = S_j / (S_(j-1) s_j)
+//    (S = sums over the strips, s = the scales used): s_k = S_(k-lag-1) s_(k-lag) / S_(k-lag).  The state then carries the product
+//    of the last `lag` normalisers -- bounded, whatever the lag.  (Dividing by the lagged SUM, as the single-chain kernel does with
+//    lag 2, is a feedback loop x_k = x_(k-1) - x_(k-lag) + nu in the log domain: marginally stable for lag 2, exponentially unstable
+//    for lag >= 3 -- measured: the C4 study overflowed before step 256.)  lag = 3 and the granules of step k + 1 are requested
+//    when step k begins, a full step after they were published: nobody waits for a sum in the steady state.  The host undoes the
+//    scales (chain_unlag).  Every wave gathers the strips' partial sums itself, in one fixed order: all strips of a chain use
+//    bit-identical scales.
+//
+// Bounded spins + abort word as in blhip_resident.hpp: if the blocks of a launch are not co-resident the fit falls back to the
+// launch-per-step kernels.
+#pragma once
+#include "blhip_mfma.hpp"
+#include "blhip_resident.hpp"
+
+namespace blc {
+
+using blf::exp_mn;
+using blf::reflect1;
+using blf::sldi;
+using blf::DMAX;
+using blk::NRED;
+using blm::d4;
+
+constexpr int NT = 512, NW = 8;   // threads / waves per block
+constexpr int TM = 16;            // rows per product tile (MFMA M)
+constexpr int WCOL = 16;          // columns per strip (MFMA N)
+constexpr int NSLOT = 8;          // ring of granule slots (>= 2 * max lag)
+constexpr int MAXLAG = 4;
+constexpr int MAX_STRIPS = 64;    // strips per chain: one granule per lane
+
+struct ChainParams {
+    int n0, n1, strips;          // n0 == NW * NTW * TM, strips = n1 / 16
+    int T, d, rec_len, lag;
+    int means;                   // forward: also sum a * grid values (forward-only fits)
+    int B;                       // chains of the batch (partial-sum layout)
+    int nslots;                  // chains of this launch
+    int nblk;                    // partial-sum slots per (step, chain, sum)
+    const int *chain_ids;        // [nslots] -> chain of the batch
+    const int *tap_id;           // [B] the chain's axis-0 kernel in the tap table, -1 = none
+    const double *taps; const int *tap_off; const int *tap_lw;
+    const double *src0;          // what the first step consumes instead of a transition: prior (forward) / uniform (backward), (G)
+    double *post; long long post_stride;       // [chain][T][G]: stored states (forward out, backward in) -> posteriors (backward out)
+    const double *m0, *m1, *colA, *colB, *rec;
+    double step0;
+    double *psum;                // [T][B][NRED][nblk]
+    unsigned long long *gran;    // [NSLOT][nslots][strips][2] {tag << 32 | half of a double}
+    unsigned *abort_word;
+    unsigned long long timeout_ticks;
+    unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
+};
+
+template <int NK, int NTW>
+constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 5 + NW * NSLOT + 8; }
+
+#ifdef BLC_PROF
+#define BLC_STAMP(i) do { if (prof_me && k >= 8 && k < 24) P.prof[(wv ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BLC_STAMP(i) do { } while (0)
+#endif
+
+// STORE: the forward pass keeps every step's state (full / forward-only fits); always true backward
+template <int NK, int NTW, bool BWD, bool STORE>
+__global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
+    constexpr int R0 = (4 * NK - TM) / 2;
+    constexpr int N0 = NW * NTW * TM;
+    constexpr int XSZ = N0 * WCOL;
+    static_assert(NK >= 8 && R0 % 4 == 0, "band = 16 + 2 R0 columns, R0 a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *const X = lds;                     // [2][N0][16]
+    double *const As = X + 2 * XSZ;            // [NK][64]   A operand: W[m][k] = w(|k - R0 - m|)
+    double *const m0s = As + NK * 64;          // [N0]       row coordinates
+    double *const red = m0s + N0;              // [2][NW][5] wave sums, double-buffered by step parity
+    double *const shist = red + 2 * NW * 5;    // [NW][NSLOT] the scales of the last steps (every wave keeps its own copy)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cs = blockIdx.x / P.strips, tj = blockIdx.x - cs * P.strips;
+    const int b = sldi(P.chain_ids, cs);
+    const int tap = sldi(P.tap_id, b);
+    const int lw0 = tap >= 0 ? sldi(P.tap_lw, tap) : 0;
+    const long long o0 = tap >= 0 ? sldi(P.tap_off, tap) : 0;
+    const int gj = tj * WCOL + (lane & 15);
+    const long long G = (long long)P.n0 * P.n1;
+
+    // ---- prologue: band, row coordinates, first source -> LDS ---------------------------------------------------------------------
+    // the first step consumes its source unfiltered: it runs with the identity band (exact), the chain's band replaces it afterwards
+    // (one code path for every step: no per-step branches around the ring and the products)
+    for (int e = tid; e < NK * 64; e += NT) As[e] = (4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15)) == 0 ? 1.0 : 0.0;
+    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
+    for (int e = tid; e < XSZ; e += NT) X[e] = P.src0[(long long)(e >> 4) * P.n1 + tj * WCOL + (e & 15)];
+
+    const double g1 = P.m1[gj];
+    const double cA = P.colA[gj], cB = P.colB[gj];
+    double *const pchain = P.post + (long long)b * P.post_stride;
+    const unsigned n1x8 = (unsigned)P.n1 * 8u;
+    const int row0 = wv * (NTW * TM);
+    // The lane's coordinates are re-derived from a laundered lane id wherever they are used: carried through the time loop, every
+    // index expression of the step (ring rows, LDS offsets, byte offsets of the 4 NTW cells) is loop-invariant and the optimiser
+    // parks it in a VGPR -- more than a hundred of them (the time-resident single-chain kernel spilled for the same reason).
+    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto cell_off = [&](int l, int it, int r) { return __umul24(row0 + it * TM + (l >> 4) + 4 * r, n1x8) + (unsigned)(tj * WCOL + (l & 15)) * 8u; };
+
+    const int t_first = BWD ? P.T - 1 : 0;
+    double xd[DMAX], xn[DMAX];
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) xd[q] = q < P.d ? P.rec[(long long)t_first * P.rec_len + q] : __builtin_nan("");
+    double al[NTW][4];                     // backward: the stored alpha of the lane's cells; a slot is re-filled for the NEXT step right
+    if (BWD) {                             // after it has been consumed, i.e. a whole step before its next use
+#pragma unroll
+        for (int it = 0; it < NTW; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) al[it][r] = blm::ld32(pchain + (long long)t_first * G, cell_off(lane, it, r));
+    }
+    bool dead = false;
+    typedef const double __attribute__((address_space(3))) *lds_cp;
+    // the granule of the sum step k + 1 divides by is requested when step k begins (it was published a step before that, lag >= 3:
+    // a load that crosses XCDs takes a few thousand cycles, more than the first product chain of a step would hide)
+    unsigned long long gq0 = 0ull, gq1 = 0ull;
+    double Sprev = 1.0;                            // the sum the previous step's scale was made of
+    double mq = 1.0, iq = 1.0, dn_prev = -1.0;     // exp(second difference of the exponent): changes only with the number of valid data dimensions
+    int nq = 0;
+#ifdef BLC_PROF
+    const bool prof_me = blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 2);
+#endif
+    __syncthreads();
+
+    for (int k = 0; k < P.T; ++k) {
+        const int t = BWD ? P.T - 1 - k : k;
+        const int tn = (k + 1 < P.T) ? (BWD ? t - 1 : t + 1) : t;          // the step after this one (clamped: a harmless re-load)
+        BLC_STAMP(0);
+        // ---- the lagged sum of step k - lag (in gq0 / gq1 since the previous step); the one for step k + 1 is requested now ---------
+        const bool need = k >= P.lag;
+        const unsigned long long *gp = P.gran + ((((long long)((k - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
+        const bool mine = need && lane < P.strips;
+        const unsigned long long hq0 = gq0, hq1 = gq1;
+        if (k + 1 >= P.lag && lane < P.strips) {
+            const unsigned long long *gn = P.gran + ((((long long)((k + 1 - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
+            gq0 = blr::ld_u64(gn); gq1 = blr::ld_u64(gn + 1);
+        }
+        // ---- what the NEXT step needs from HBM: its data record (its stored alpha: see the epilogue) --------------------------------
+        const double *const pnext = pchain + (long long)tn * G;
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
+
+        // ---- ring over the source state -----------------------------------------------------------------------------------------------
+        const double *S = X + (k & 1) * XSZ;
+        double *D = X + ((k + 1) & 1) * XSZ;
+        // (interior waves: consecutive k-blocks are 512 bytes apart -- one address register, immediate offsets; only waves whose
+        //  window reaches beyond the grid edge pay for the reflection)
+        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
+        double Bv[NK];
+        {
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            if (edge) {
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, N0) * WCOL + c];
+            } else {
+                const double *s0 = S + (row0 - R0 + g) * WCOL + c;
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
+            }
+        }
+
+        BLC_STAMP(1);
+        double scale = 1.0;
+        double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
+        int nE = 0, nR = 0;
+        double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
+        double *const pstep = pchain + (long long)t * G;
+
+#pragma unroll
+        for (int it = 0; it < NTW; ++it) {
+            const int i = row0 + it * TM;
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            // ---- axis-0 stencil: NK chained matrix products (k ascending) -----------------------------------------------------------
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            {
+                const unsigned aoff = (unsigned)l * 8u;                 // (the band stays in LDS: hoisted out of the time loop it costs 2 NK VGPRs)
+                lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+            }
+
+            if (it == 0) {
+                BLC_STAMP(2);
+                // ---- the scale: every wave sums the strips' granules itself (one fixed order: identical in every strip) -------------
+                if (need) {
+                    const unsigned long long want = (unsigned long long)(unsigned)(k - P.lag + 1);
+                    unsigned long long q0 = hq0, q1 = hq1;
+                    bool ok = !mine || ((q0 >> 32) == want && (q1 >> 32) == want);
+                    if (!dead && !__all(ok)) {
+                        const unsigned long long t0 = blr::now_ticks();
+                        for (unsigned spins = 1; !__all(ok); ++spins) {
+                            if (!ok) { q0 = blr::ld_u64(gp); q1 = blr::ld_u64(gp + 1); ok = (q0 >> 32) == want && (q1 >> 32) == want; }
+                            blr::nap();
+                            if ((spins & 255u) == 0u) {
+                                if (blr::ld_flag(P.abort_word) != 0u) { dead = true; break; }
+                                if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; break; }
+                            }
+                        }
+                    }
+                    const double v = mine ? __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32))) : 0.0;
+                    const double Sg = blk::wave_sum(v);
+                    scale = dead ? 1.0 : Sprev * shist[wv * NSLOT + ((k - P.lag) & (NSLOT - 1))] / Sg;
+                    Sprev = Sg;
+                }
+                if (lane == 0) shist[wv * NSLOT + (k & (NSLOT - 1))] = scale;
+                // ---- anchor of the stride-4 likelihood recurrence of this lane's rows (blhip_mfma.hpp) -------------------------------
+                // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
+                const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
+                double a0 = 0.0, s1 = 0.0, dn = 0.0;
+#pragma unroll
+                for (int q = 0; q < DMAX; ++q) {
+                    const double x = xd[q];
+                    if (x == x) {
+                        const double dq = x - mu0;
+                        a0 = fma(-(dq * dq), cA, a0) - cB;
+                        s1 += (x - mu0) + (x - mu4);
+                        dn += 1.0;
+                    }
+                }
+                const double d1 = cA * (mu4 - mu0) * s1;
+                const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                exp_mn(a0, mE, nE);
+                exp_mn(d1, mR, nR);
+                if (dn != dn_prev) {                 // (wave-uniform: the records are)
+                    int tmp;
+                    exp_mn(d2, mq, nq);
+                    if (BWD) exp_mn(-d2, iq, tmp);
+                    dn_prev = dn;
+                }
+                if (BWD) {
+                    int tmp;
+                    exp_mn(-a0, iE, tmp);
+                    exp_mn(-d1, iR, tmp);
+                } else {
+                    mE *= scale;                     // forward: the scale rides on the likelihood's mantissa (one product per cell less)
+                }
+                BLC_STAMP(3);
+            }
+
+            // ---- epilogue: the lane's 4 cells (rows i + g + 4 r) ---------------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int li = i + g + 4 * r;
+                const double Lv = ldexp(mE, nE);
+                const unsigned off = cell_off(l, it, r);
+                if (!BWD) {
+                    const double a = acc[r] * Lv;
+                    D[li * WCOL + c] = a;
+                    if (STORE) blm::st32(pstep, off, a);
+                    sN += a;
+                    acc[r] = a;
+                } else {
+                    const double beta = acc[r] * scale;
+                    const double p = al[it][r] * beta;
+                    const double cn = beta * Lv;
+                    // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
+                    const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
+                    D[li * WCOL + c] = cn;
+                    blm::st32(pstep, off, p);
+                    al[it][r] = blm::ld32(pnext, off);
+                    sN += p;
+                    sS += pl;
+                    sC += cn;
+                    sM0 = fma(p, m0s[li], sM0);
+                    sM1 = fma(p, g1, sM1);
+                }
+                mE *= mR; nE += nR;
+                mR *= mq; nR += nq;
+                if (BWD) { iE *= iR; iR *= iq; }
+            }
+
+            if (!BWD && STORE && P.means) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sM0 = fma(acc[r], m0s[i + g + 4 * r], sM0); sM1 = fma(acc[r], g1, sM1); }
+            }
+
+            if (it == 0) BLC_STAMP(4);
+            if (it == NTW - 1) BLC_STAMP(5);
+            // ---- advance the ring by one tile --------------------------------------------------------------------------------------
+            if (it + 1 < NTW) {
+#pragma unroll
+                for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
+                if (edge) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, N0) * WCOL + c];
+                } else {
+                    const double *s1 = S + (i + TM + R0 + g) * WCOL + c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = s1[q * 4 * WCOL];
+                }
+            }
+        }
+
+        // ---- sums: waves -> LDS (this step's parity); after the barrier wave 0 adds them up, writes the partial sums of the strip
+        //      and publishes the one the scale of step k + lag is made of -----------------------------------------------------------------
+        double v[5] = {sN, BWD ? sS : sM0, BWD ? sC : sM1, sM0, sM1};
+        constexpr int NV = BWD ? 5 : 3;
+        const int nv = (BWD || P.means) ? NV : 1;
+        double *rk = red + (k & 1) * (NW * 5);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if (q < nv) {
+                v[q] = blk::wave_sum(v[q]);
+                if (lane == 0) rk[wv * 5 + q] = v[q];
+            }
+        }
+        BLC_STAMP(6);
+        __syncthreads();
+        BLC_STAMP(7);
+        if (k == 0) {                      // the chain's band replaces the identity of the first step
+            for (int e = tid; e < NK * 64; e += NT) {
+                const int a = abs(4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15));
+                As[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);
+            }
+            __syncthreads();
+        }
+        if (wv == NW / 2 && lane < nv) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += rk[w * 5 + lane];
+            const int slot = BWD ? lane : (lane == 0 ? 0 : 2 + lane);          // forward: N, M0, M1 -> slots 0, 3, 4
+            if (BWD || lane == 0 || P.means) P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
+            if (lane == (BWD ? 2 : 0)) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
+                const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
+                unsigned long long *gw = P.gran + ((((long long)(k & (NSLOT - 1)) * P.nslots + cs) * P.strips + tj) << 1);
+                blr::st_u64(gw, tag | (bits & 0xffffffffull));
+                blr::st_u64(gw + 1, tag | (bits >> 32));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q) xd[q] = xn[q];
+    }
+}
+
+}  // namespace blc

@@ -56,6 +56,7 @@ def test_alternative_kernel_paths_match_golden(case, option):
     eng = bl.get_engine()
     eng.set_option(option, 0)
     eng.set_option('resident', 0)          # (single-chain 2-D cases would otherwise take the time-resident kernel, tested below)
+    eng.set_option('chain_resident', 0)    # (and axis-0-only hyper-studies the chain-resident kernel)
     try:
         S = cases.build(bl, case)
         S.fit(**cases.fit_kwargs(case))
@@ -67,6 +68,7 @@ def test_alternative_kernel_paths_match_golden(case, option):
     finally:
         eng.set_option(option, 1)
         eng.set_option('resident', 1)
+        eng.set_option('chain_resident', 1)
 
 
 @pytest.mark.parametrize('case', ['c1_coal', 'c2_small', 'kat_changepoint', 'c1_coal_changepoint', 'kat_gaussianmean',
@@ -789,3 +791,92 @@ def test_bench_workloads_full_fit_against_full_size_reference(name):
         assert np.all(np.abs(got - want) <= 1e-12 + 1e-9 * np.abs(want)), 'posterior row %d' % t
     S._posterior_pending = None
     bl.get_engine().release_posterior()
+
+
+# ---- the chain-resident kernel (blhip_chainres.hpp): hyper-studies over one random-walk width, rounds of chains resident in LDS ------
+
+def _hyper(n0, n1, seed, T, sigmas, kind='series', extra=None, **fit):
+    data = (kind, seed, T) if extra is None else (kind, seed, T, extra)
+    c = dict(study='HyperStudy', data=data, om=_g2(n0, n1), tm=('GRW', 'sigma', sigmas, 'mean', None))
+    if fit:
+        c['fit'] = fit
+    return c
+
+
+CHAINRES = {
+    # 3 strips, 9 widths from 0 (no filter) to radius 32: one launch, band of the widest chain
+    'cres_128x48_full': _hyper(128, 48, 51, 9, ('cint', 0, 1.0, 9)),
+    # 16 strips -> 16 chains per launch: 40 chains = 3 launches with bands of 16 + 2 x {16, 32, 40} columns
+    'cres_128x256_rounds': _hyper(128, 256, 52, 6, ('cint', 0.01, 1.25, 40)),
+    'cres_256x32_evidence': _hyper(256, 32, 53, 12, ('cint', 0, 0.6, 5), evidenceOnly=True),
+    'cres_256x64_forward_only': _hyper(256, 64, 54, 7, ('cint', 0.05, 0.4, 4), forwardOnly=True),
+    # missing data points, the lag reaching over them
+    'cres_512x32_nan': _hyper(512, 32, 55, 11, ('cint', 0, 0.3, 6), kind='series_nan', extra=[0, 4, 5]),
+    # two data dimensions per step (product of likelihoods)
+    'cres_128x64_multidim': dict(study='HyperStudy', data=('series2d', 56, 8), om=_g2(128, 64, -4, 4, 3),
+                                 tm=('GRW', 'sigma', ('cint', 0, 0.5, 5), 'mean', None)),
+    # T = 1 and T = 2 (shorter than the lag)
+    'cres_T1': _hyper(128, 32, 57, 1, ('cint', 0, 0.5, 3)),
+    'cres_T2': _hyper(128, 32, 58, 2, ('cint', 0, 0.5, 3)),
+}
+
+
+@pytest.mark.parametrize('case', list(CHAINRES))
+def test_chain_resident_kernel_matches_oracle(case):
+    c = CHAINRES[case]
+    S = cases.build(bl, c)
+    S.fit(**cases.fit_kwargs(c))
+    kw = cases.fit_kwargs(c)
+    assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming          # the chain-resident path really ran
+    if not kw.get('evidenceOnly') and not kw.get('forwardOnly'):
+        assert S.lastTiming['bwd_kernel_variant'] == 6, S.lastTiming
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
+
+
+@pytest.mark.parametrize('lag', [1, 2, 3, 4])
+def test_chain_resident_kernel_lag_and_determinism(lag):
+    """Against the launch-per-step kernels; the lag of the normaliser only changes intermediate magnitudes; repeated runs are
+    bit-identical (a race on a tagged sum would show as a difference between runs)."""
+    eng = bl.get_engine()
+    c = _hyper(256, 128, 61, 10, ('cint', 0, 0.6, 37))
+    eng.set_option('chain_resident', 0)
+    try:
+        B = cases.build(bl, c); B.fit(silent=True)
+        assert B.lastTiming['fwd_kernel_variant'] != 6
+        base = np.array(B.posteriorSequence)
+    finally:
+        eng.set_option('chain_resident', 1)
+    eng.set_option('chain_resident_lag', lag)
+    try:
+        runs = []
+        for _ in range(3):
+            A = cases.build(bl, c); A.fit(silent=True)
+            assert A.lastTiming['fwd_kernel_variant'] == 6 and A.lastTiming['bwd_kernel_variant'] == 6
+            runs.append((A.logEvidence, np.array(A.posteriorSequence), np.array(A.localEvidence), np.array(A.logEvidenceList)))
+    finally:
+        eng.set_option('chain_resident_lag', 3)
+    for logE, post, loc, lel in runs:
+        assert abs(logE - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
+        np.testing.assert_allclose(lel, np.array(B.logEvidenceList), rtol=1e-11)
+        np.testing.assert_allclose(post, base, rtol=1e-9, atol=1e-14)
+        assert logE == runs[0][0] and np.array_equal(post, runs[0][1]) and np.array_equal(loc, runs[0][2], equal_nan=True)
+
+
+def test_chain_resident_kernel_not_taken_outside_its_envelope():
+    """A walk wider than 40 grid steps, a filter on the second parameter, a grid whose row count is not 128 / 256 / 512: the
+    launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
+    for c in (_hyper(128, 32, 62, 4, ('cint', 0.1, 2.0, 3)),
+              dict(study='HyperStudy', data=('series', 63, 4), om=_g2(128, 32), tm=('GRW', 'sigma', ('cint', 0.1, 0.3, 3), 'std', None)),
+              _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3))):
+        S = cases.build(bl, c); S.fit(silent=True)
+        assert S.lastTiming['fwd_kernel_variant'] != 6
+        with np.errstate(all='ignore'):
+            want = oa.run(c)
+        assert abs(S.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
