@@ -932,14 +932,14 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
 }
 
 // memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
-int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int64_t n_chains) {
+int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int64_t n_chains, int post_buffers) {
     const int64_t T = p->T;
     const long long G = g.G;
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
-    const double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap,
+    const double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap + (double)ctx->post2.cap,
                                    ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
-    const double per_chain = (ff.evidence_only ? 2.0 : (double)T + 2.0) * (double)G * 8.0 +
+    const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * (double)G * 8.0 +
                              (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
     int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
     Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024));
@@ -1147,10 +1147,22 @@ void store_carry(blhip_ctx *ctx, const blhip_problem *p, int64_t B, long long G,
         for (int64_t b = 0; b < B; ++b) cs.maxv.push_back(redF[((size_t)(T - 1) * B + b) * NRED + 6] * inv[b]);
 }
 
-// fold the batch into the average posterior (core.py:1358-1366): linear accumulator with a running reference exponent
-void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const BatchOutcome &out, const double *log_w_batch, const double *d_post,
-                     double *d_w, double *d_invN) {
-    hipStream_t st = ctx->stream;
+// fold the batch into the average posterior (core.py:1358-1366): linear accumulator with a running reference exponent.
+// Two halves, so that the kernel can be launched later than the bookkeeping is done (overlapped folds, see do_fit): prepare_fold
+// turns the batch's evidences into weights (staged in h_w / h_invN, which must stay valid until the launch has consumed them) and
+// advances the accumulator's reference; launch_fold copies them to the device and runs the pass on `st`.
+struct FoldJob {
+    bool pending = false;
+    const double *d_post = nullptr;
+    int64_t B = 0;
+    double *h_w = nullptr, *h_invN = nullptr;        // host staging (B), (T * B)
+    double *d_w = nullptr, *d_invN = nullptr;        // device copies
+    double r = 0.0;                                  // factor of what the accumulator already holds
+    int first = 0;
+    int parity = 0;
+};
+
+bool prepare_fold(blhip_ctx *ctx, int64_t T, int64_t B, const BatchOutcome &out, const double *log_w_batch, FoldJob &job) {
     double newref = ctx->acc_logref;
     std::vector<double> lw(B, -INFINITY);
     std::vector<char> valid(B, 0);
@@ -1161,33 +1173,53 @@ void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const Ba
         lw[b] = out.logE[b] + log_w_batch[b];
         if (lw[b] > newref) newref = lw[b];
     }
-    if (!std::isfinite(newref)) return;
-    std::vector<double> w(B, 0.0);
+    if (!std::isfinite(newref)) return false;
     int nfold = 0;
-    for (int64_t b = 0; b < B; ++b)
-        if (valid[b]) { w[b] = std::exp(lw[b] - newref); nfold++; }
-    const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref);
-    HIPCHECK(hipMemcpyAsync(d_w, w.data(), B * 8, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(d_invN, out.invN.data(), (size_t)T * B * 8, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipEventRecord(ctx->ev[4], st));
-    if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
-        const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
-        hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
-                           (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
-    } else {
-        const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-        hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, d_post,
-                           (long long)T * G, (int)B, G, (int)T, d_w, d_invN, r, ctx->acc_first ? 1 : 0);
+    for (int64_t b = 0; b < B; ++b) {
+        job.h_w[b] = valid[b] ? std::exp(lw[b] - newref) : 0.0;
+        nfold += valid[b] ? 1 : 0;
     }
-    HIPCHECK(hipEventRecord(ctx->ev[5], st));
-    sync_stream(ctx, st);
-    float ms = 0;
-    HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
-    ctx->timing.accumulate_ms += ms;
+    std::memcpy(job.h_invN, out.invN.data(), (size_t)T * B * 8);
+    job.r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref);
+    job.first = ctx->acc_first ? 1 : 0;
+    job.B = B;
     ctx->timing.accumulate_launches += 1;
     ctx->acc_logref = newref;
     ctx->acc_first = false;
     ctx->acc_folded += nfold;
+    return true;
+}
+
+void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+    const int64_t B = job.B;
+    HIPCHECK(hipMemcpyAsync(job.d_w, job.h_w, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(job.d_invN, job.h_invN, (size_t)T * B * 8, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipEventRecord(ev0, st));
+    if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
+        const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
+        hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
+                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
+    } else {
+        const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
+        hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
+                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
+    }
+    HIPCHECK(hipEventRecord(ev1, st));
+}
+
+// the whole fold on the main stream, waited for
+void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const BatchOutcome &out, const double *log_w_batch, const double *d_post,
+                     double *d_w, double *d_invN) {
+    ctx->pinA.ensure(((size_t)B + (size_t)T * B) * 8);
+    FoldJob job;
+    job.h_w = ctx->pinA.as<double>(); job.h_invN = job.h_w + B;
+    job.d_w = d_w; job.d_invN = d_invN; job.d_post = d_post;
+    if (!prepare_fold(ctx, T, B, out, log_w_batch, job)) return;
+    launch_fold(ctx, T, G, job, ctx->stream, ctx->ev[4], ctx->ev[5]);
+    sync_stream(ctx, ctx->stream);
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+    ctx->timing.accumulate_ms += ms;
 }
 
 // the batch's sequence stays on the device as the kept posterior; rows [row0, row1) still carry their raw sums (core.py:389 / :441)
@@ -1408,11 +1440,24 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     tr.mark("tables + H2D");
 
     // ---- memory plan ------------------------------------------------------------------------------------------------------------
-    const int64_t Bmax = chains_per_batch(ctx, p, g, ff, n_chains);
+    // The average posterior of a hyper-study is folded batch by batch (core.py:1358-1366): a pass over the batch's whole sequence at
+    // the memory roof (C4: 2 x 24 ms of a 300 ms fit).  Option accum_overlap = 1 (default 0): two sequence buffers, the fold of batch b
+    // runs on a second stream beside the forward pass of batch b + 1 (~4 batches instead of as few as fit).  Measured on C4: no
+    // gain -- queued behind the pass's launches the fold is not started before they have finished (rocprofv3 time line), queued
+    // ahead of them it slows the pass by about its own duration (13 ms fold: forward 25 -> 35 ms per batch; 1.15e11 either way).
+    const bool overlap_acc = accumulate && full && ctx->option("accum_overlap", 0.0) != 0.0 && n_chains >= 64;
+    if (!overlap_acc) ctx->post2.release();         // (a fit without the second stream gets the memory back)
+    int64_t Bmax = chains_per_batch(ctx, p, g, ff, n_chains, overlap_acc ? 2 : 1);
+    if (overlap_acc) Bmax = std::min<int64_t>(Bmax, std::max<int64_t>(32, ((n_chains + 3) / 4 + 31) / 32 * 32));
     // ---- batches: at most Bmax chains each, cut where the axis-0 radius bucket changes.  A bucket cut by a batch boundary becomes
     //      two under-filled launches per step (round 1: the 107-chain radius-24 bucket of the C4 study ran as 36 + 71 chains at
     //      4.1 TB/s); hyper-grids are usually monotone in the random-walk width, so contiguous cuts suffice.
-    std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, ctx->option("bucket_batches", 1.0) != 0.0);
+    std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && ctx->option("bucket_batches", 1.0) != 0.0);
+    if (overlap_acc) {                     // (equal batches, multiples of 32 chains: whole launches of the chain-resident kernel)
+        batch_start.clear();
+        for (int64_t c = 0; c < n_chains; c += Bmax) batch_start.push_back(c);
+        batch_start.push_back(n_chains);
+    }
     const int64_t nbatch = (int64_t)batch_start.size() - 1;
     ctx->timing.batches = nbatch;
 
@@ -1421,6 +1466,21 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     HIPCHECK(hipEventRecord(ev[6], st));
 
     double *redF = nullptr, *redB = nullptr;   // reduced sums on the host (page-locked staging of the context)
+    std::vector<hipEvent_t> fold_ev;           // overlapped folds: start / end events of every batch (timing)
+    FoldJob fold_job;                          // the fold of the previous batch, launched once this batch's forward pass is queued
+    auto launch_pending_fold = [&]() {
+        if (!fold_job.pending) return;
+        hipEvent_t e0, e1;
+        HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+        fold_ev.push_back(e0); fold_ev.push_back(e1);
+        launch_fold(ctx, T, G, fold_job, ctx->astream, e0, e1);
+        HIPCHECK(hipEventRecord(ctx->aev_done[fold_job.parity], ctx->astream));
+        fold_job.pending = false;
+    };
+    if (overlap_acc && !ctx->astream) {
+        HIPCHECK(hipStreamCreateWithFlags(&ctx->astream, hipStreamNonBlocking));
+        for (auto &e : ctx->aev_done) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     for (int64_t bi = 0; bi < nbatch; ++bi) {
         const int64_t c0 = batch_start[bi], B = batch_start[bi + 1] - c0;
         TapTable taps;
@@ -1465,8 +1525,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         d_pp[0] = ctx->state.as<double>();
         d_pp[1] = d_pp[0] + (size_t)B * G;
         if (!evidence_only) {
-            ctx->post.ensure((size_t)B * T * G * 8);
-            d_post = ctx->post.as<double>();
+            DevBuf &pb = (overlap_acc && (bi & 1)) ? ctx->post2 : ctx->post;
+            pb.ensure((size_t)B * T * G * 8);
+            d_post = pb.as<double>();
+            // the fold of batch bi - 2 read this buffer on the second stream: it has to be through before this batch writes it
+            if (overlap_acc && bi >= 2) HIPCHECK(hipStreamWaitEvent(st, ctx->aev_done[bi & 1], 0));
         }
 
         // BLHIP_RESUME: step 0 reads each chain's carried (normalised) state; its "previous partial sums" add up to 1
@@ -1595,7 +1658,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
             sync_stream(ctx, st);
             CQ.n0 = g.n0; CQ.n1 = g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = d; CQ.rec_len = rec_len;
-            CQ.lag = std::max(1, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 3.0)));
+            CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
             CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = d_taps; CQ.tap_off = d_off; CQ.tap_lw = d_lw;
             CQ.post_stride = (long long)T * G;
             CQ.m0 = d_m0; CQ.m1 = d_m1; CQ.colA = d_colA; CQ.colB = d_colB; CQ.rec = d_rec; CQ.step0 = FP.step0;
@@ -1708,6 +1771,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         }
         tr.mark("state alloc");
         // --- forward pass (core.py:372-411) ---
+        // the previous batch's fold goes to the second stream FIRST: queued behind this pass's launches it was not started before
+        // they had all finished (measured: rocprofv3 time line), queued ahead of them it shares the chip with them
+        launch_pending_fold();
         HIPCHECK(hipEventRecord(ev[0], st));
         if (persist) {
             bl1::P1Params Q = PP;
@@ -1975,7 +2041,22 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             else { fin = fused1d ? d_pp[((T - 1) / usedK) & 1] : d_pp[(T - 1) & 1]; fstr = G; }
             store_carry(ctx, p, B, G, redF, fin, fstr, d_w, prog.has_clamp);
         }
-        if (accumulate) fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN);
+        if (accumulate && overlap_acc) {
+            // private copies of the weights, host (page-locked: the copies must not block the host) and device: the batch metadata
+            // buffers are rewritten by the next batch while the fold is pending / running
+            const size_t wsz = carve_size((size_t)Bmax * 8) + carve_size((size_t)T * Bmax * 8);
+            ctx->accw.ensure(2 * wsz);
+            ctx->pinA.ensure(2 * wsz);
+            char *wc = ctx->accw.as<char>() + (bi & 1) * wsz, *hc = ctx->pinA.as<char>() + (bi & 1) * wsz;
+            fold_job.d_w = carve<double>(wc, (size_t)Bmax); fold_job.d_invN = carve<double>(wc, (size_t)T * Bmax);
+            fold_job.h_w = carve<double>(hc, (size_t)Bmax); fold_job.h_invN = carve<double>(hc, (size_t)T * Bmax);
+            fold_job.d_post = d_post; fold_job.parity = (int)(bi & 1);
+            fold_job.pending = prepare_fold(ctx, T, B, O, log_w + c0, fold_job);
+            // launched behind the NEXT batch's forward pass (see passes); the last batch has nothing to hide behind
+            if (bi == nbatch - 1) launch_pending_fold();
+        } else if (accumulate) {
+            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN);
+        }
         if (keep) {
             int64_t row0 = 0, row1 = T;              // rows the resident kernel normalised in place (invN = 1 there) need no pass
             if (resident && !resident_failed) {
@@ -1986,6 +2067,15 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         }
         tr.mark("accumulate / keep");
         write_results(res, p, c0, B, O, !evidence_only);
+    }
+    if (overlap_acc) {                         // the last fold(s) before anybody reads the accumulator; their time from their events
+        sync_stream(ctx, ctx->astream);
+        for (size_t k = 0; k + 1 < fold_ev.size(); k += 2) {
+            float fms = 0;
+            HIPCHECK(hipEventElapsedTime(&fms, fold_ev[k], fold_ev[k + 1]));
+            ctx->timing.accumulate_ms += fms;
+        }
+        for (hipEvent_t e : fold_ev) (void)hipEventDestroy(e);
     }
     tr.mark("batches done");
     HIPCHECK(hipEventRecord(ev[7], st));
@@ -2044,12 +2134,14 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release();
+    if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
+    for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
                       &ctx->tables, &ctx->likbuf, &ctx->small, &ctx->accum_own, &ctx->stats, &ctx->mix, &ctx->unit, &ctx->databuf, &ctx->postinv})
         b->release();
     for (auto &kv : ctx->carry) kv.second.buf.release();
-    ctx->pinF.release(); ctx->pinB.release(); ctx->pinS.release();
+    ctx->pinF.release(); ctx->pinB.release(); ctx->pinS.release(); ctx->pinA.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &bs : ctx->bstream)
@@ -2154,6 +2246,7 @@ int blhip_posterior_release(blhip_ctx *ctx) {
         HIPCHECK(hipSetDevice(ctx->device));
         ctx->post_valid = false;
         ctx->post.release();
+        ctx->post2.release();
     });
 }
 

@@ -21,10 +21,11 @@
 //    (S = sums over the strips, s = the scales used): s_k = S_(k-lag-1) s_(k-lag) / S_(k-lag).  The state then carries the product
 //    of the last `lag` normalisers -- bounded, whatever the lag.  (Dividing by the lagged SUM, as the single-chain kernel does with
 //    lag 2, is a feedback loop x_k = x_(k-1) - x_(k-lag) + nu in the log domain: marginally stable for lag 2, exponentially unstable
-//    for lag >= 3 -- measured: the C4 study overflowed before step 256.)  lag = 3 and the granules of step k + 1 are requested
-//    when step k begins, a full step after they were published: nobody waits for a sum in the steady state.  The host undoes the
-//    scales (chain_unlag).  Every wave gathers the strips' partial sums itself, in one fixed order: all strips of a chain use
-//    bit-identical scales.
+//    for lag >= 3 -- measured: the C4 study overflowed before step 256.)  One wave per strip turns the sums into scales (a wave
+//    reduction + a division per step; done by every wave it was ~8 % of the vector instructions): during step k it prepares the
+//    scale of step k + 1 from granules it requested when step k - 1 began; with lag = 4 they were published a whole step before
+//    that, so nobody waits for a sum in the steady state.  The strips sum in one fixed order: bit-identical scales across the
+//    strips of a chain.  The host undoes the scales (chain_unlag).
 //
 // Bounded spins + abort word as in blhip_resident.hpp: if the blocks of a launch are not co-resident the fit falls back to the
 // launch-per-step kernels.
@@ -47,6 +48,7 @@ constexpr int WCOL = 16;          // columns per strip (MFMA N)
 constexpr int NSLOT = 8;          // ring of granule slots (>= 2 * max lag)
 constexpr int MAXLAG = 4;
 constexpr int MAX_STRIPS = 64;    // strips per chain: one granule per lane
+constexpr int SCALE_WAVE = 6;     // the wave that turns the strips' sums into the next step's scale (shares its SIMD with no edge wave)
 
 struct ChainParams {
     int n0, n1, strips;          // n0 == NW * NTW * TM, strips = n1 / 16
@@ -70,7 +72,7 @@ struct ChainParams {
 };
 
 template <int NK, int NTW>
-constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 5 + NW * NSLOT + 8; }
+constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 4 * 5 + NSLOT + 8; }
 
 #ifdef BLC_PROF
 #define BLC_STAMP(i) do { if (prof_me && k >= 8 && k < 24) P.prof[(wv ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     double *const X = lds;                     // [2][N0][16]
     double *const As = X + 2 * XSZ;            // [NK][64]   A operand: W[m][k] = w(|k - R0 - m|)
     double *const m0s = As + NK * 64;          // [N0]       row coordinates
-    double *const red = m0s + N0;              // [2][NW][5] wave sums, double-buffered by step parity
-    double *const shist = red + 2 * NW * 5;    // [NW][NSLOT] the scales of the last steps (every wave keeps its own copy)
+    double *const red = m0s + N0;              // [2][NW * 4][5] sums of the waves' rows of 16 lanes, double-buffered by step parity
+    double *const scal = red + 2 * NW * 4 * 5;     // [NSLOT] the scales s_j of the steps around the current one (written by the scale wave)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     // (one code path for every step: no per-step branches around the ring and the products)
     for (int e = tid; e < NK * 64; e += NT) As[e] = (4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15)) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
+    if (tid < NSLOT) scal[tid] = 1.0;
     for (int e = tid; e < XSZ; e += NT) X[e] = P.src0[(long long)(e >> 4) * P.n1 + tj * WCOL + (e & 15)];
 
     const double g1 = P.m1[gj];
@@ -148,13 +151,16 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         const int t = BWD ? P.T - 1 - k : k;
         const int tn = (k + 1 < P.T) ? (BWD ? t - 1 : t + 1) : t;          // the step after this one (clamped: a harmless re-load)
         BLC_STAMP(0);
-        // ---- the lagged sum of step k - lag (in gq0 / gq1 since the previous step); the one for step k + 1 is requested now ---------
-        const bool need = k >= P.lag;
-        const unsigned long long *gp = P.gran + ((((long long)((k - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
+        // ---- the scale wave: the sums the scale of step k + 1 is made of were requested a step ago (gq0 / gq1); those for step k + 2
+        //      are requested now -------------------------------------------------------------------------------------------------------
+        const bool scale_wave = wv == SCALE_WAVE;
+        const int jn = k + 1;                                               // the step whose scale this step prepares
+        const bool need = scale_wave && jn >= P.lag && jn < P.T;
+        const unsigned long long *gp = P.gran + ((((long long)((jn - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
         const bool mine = need && lane < P.strips;
         const unsigned long long hq0 = gq0, hq1 = gq1;
-        if (k + 1 >= P.lag && lane < P.strips) {
-            const unsigned long long *gn = P.gran + ((((long long)((k + 1 - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
+        if (scale_wave && jn + 1 >= P.lag && jn + 1 < P.T && lane < P.strips) {
+            const unsigned long long *gn = P.gran + ((((long long)((jn + 1 - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
             gq0 = blr::ld_u64(gn); gq1 = blr::ld_u64(gn + 1);
         }
         // ---- what the NEXT step needs from HBM: its data record (its stored alpha: see the epilogue) --------------------------------
@@ -203,28 +209,33 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 
             if (it == 0) {
                 BLC_STAMP(2);
-                // ---- the scale: every wave sums the strips' granules itself (one fixed order: identical in every strip) -------------
-                if (need) {
-                    const unsigned long long want = (unsigned long long)(unsigned)(k - P.lag + 1);
-                    unsigned long long q0 = hq0, q1 = hq1;
-                    bool ok = !mine || ((q0 >> 32) == want && (q1 >> 32) == want);
-                    if (!dead && !__all(ok)) {
-                        const unsigned long long t0 = blr::now_ticks();
-                        for (unsigned spins = 1; !__all(ok); ++spins) {
-                            if (!ok) { q0 = blr::ld_u64(gp); q1 = blr::ld_u64(gp + 1); ok = (q0 >> 32) == want && (q1 >> 32) == want; }
-                            blr::nap();
-                            if ((spins & 255u) == 0u) {
-                                if (blr::ld_flag(P.abort_word) != 0u) { dead = true; break; }
-                                if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; break; }
+                // ---- the scale of this step (prepared during the previous one); the scale wave prepares the next one: it sums the
+                //      strips' granules in one fixed order, so every strip of the chain arrives at bit-identical scales ----------------
+                scale = scal[k & (NSLOT - 1)];
+                if (scale_wave) {
+                    double sj = 1.0;
+                    if (need) {
+                        const unsigned long long want = (unsigned long long)(unsigned)(jn - P.lag + 1);
+                        unsigned long long q0 = hq0, q1 = hq1;
+                        bool ok = !mine || ((q0 >> 32) == want && (q1 >> 32) == want);
+                        if (!dead && !__all(ok)) {
+                            const unsigned long long t0 = blr::now_ticks();
+                            for (unsigned spins = 1; !__all(ok); ++spins) {
+                                if (!ok) { q0 = blr::ld_u64(gp); q1 = blr::ld_u64(gp + 1); ok = (q0 >> 32) == want && (q1 >> 32) == want; }
+                                blr::nap();
+                                if ((spins & 255u) == 0u) {
+                                    if (blr::ld_flag(P.abort_word) != 0u) { dead = true; break; }
+                                    if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; break; }
+                                }
                             }
                         }
+                        const double v = mine ? __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32))) : 0.0;
+                        const double Sg = blk::wave_sum(v);
+                        sj = dead ? 1.0 : Sprev * scal[(jn - P.lag) & (NSLOT - 1)] / Sg;
+                        Sprev = Sg;
                     }
-                    const double v = mine ? __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32))) : 0.0;
-                    const double Sg = blk::wave_sum(v);
-                    scale = dead ? 1.0 : Sprev * shist[wv * NSLOT + ((k - P.lag) & (NSLOT - 1))] / Sg;
-                    Sprev = Sg;
+                    if (lane == 0) scal[jn & (NSLOT - 1)] = sj;
                 }
-                if (lane == 0) shist[wv * NSLOT + (k & (NSLOT - 1))] = scale;
                 // ---- anchor of the stride-4 likelihood recurrence of this lane's rows (blhip_mfma.hpp) -------------------------------
                 // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
                 const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
@@ -318,12 +329,18 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         double v[5] = {sN, BWD ? sS : sM0, BWD ? sC : sM1, sM0, sM1};
         constexpr int NV = BWD ? 5 : 3;
         const int nv = (BWD || P.means) ? NV : 1;
-        double *rk = red + (k & 1) * (NW * 5);
+        // (a full wave reduction costs ~45 vector instructions per sum and wave; the waves reduce only within their rows of 16 lanes
+        //  -- 12 instructions -- and one wave adds the 32 row sums of the block after the barrier, in a fixed order)
+        double *rk = red + (k & 1) * (NW * 4 * 5);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             if (q < nv) {
-                v[q] = blk::wave_sum(v[q]);
-                if (lane == 0) rk[wv * 5 + q] = v[q];
+                double x = v[q];
+                x = blk::dpp_add<0x111, 0xf>(x);
+                x = blk::dpp_add<0x112, 0xf>(x);
+                x = blk::dpp_add<0x114, 0xf>(x);
+                x = blk::dpp_add<0x118, 0xf>(x);
+                if ((lane & 15) == 15) rk[(wv * 4 + (lane >> 4)) * 5 + q] = x;
             }
         }
         BLC_STAMP(6);
@@ -336,10 +353,10 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             }
             __syncthreads();
         }
-        if (wv == NW / 2 && lane < nv) {
+        if (wv == 5 && lane < nv) {           // (a wave that shares its SIMD with no edge wave)
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) tot += rk[w * 5 + lane];
+            for (int w = 0; w < NW * 4; ++w) tot += rk[w * 5 + lane];
             const int slot = BWD ? lane : (lane == 0 ? 0 : 2 + lane);          // forward: N, M0, M1 -> slots 0, 3, 4
             if (BWD || lane == 0 || P.means) P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
             if (lane == (BWD ? 2 : 0)) {

@@ -105,6 +105,7 @@ struct blhip_ctx {
     struct Carry { DevBuf buf; int64_t chains = 0, G = 0; bool valid = false; std::vector<double> maxv; };
     std::map<int, Carry> carry;
     DevBuf mix, unit, databuf;
+    PinBuf pinA;                 // weights of the average-posterior folds
     PinBuf pinF, pinB, pinS;     // host staging of the reduced sums (forward, backward) and of small read-backs
     int64_t mix_G = 0;
     // multi-GPU exchange (blhip_comm.hpp): RCCL communicator of this context's device, staging buffers
@@ -116,6 +117,11 @@ struct blhip_ctx {
     DevBuf resx;
     bool resident_ok = true;
     int num_cus = 0;
+    // average posterior folded on a second stream while the next batch's forward pass runs (do_fit): second sequence buffer,
+    // private copies of the per-batch weights, the stream and its events
+    DevBuf post2, accw;
+    hipStream_t astream = nullptr;
+    hipEvent_t aev_done[2] = {nullptr, nullptr};
 
     double option(const char *k, double dflt) const {
         auto it = opt.find(k);

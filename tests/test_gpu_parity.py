@@ -840,7 +840,7 @@ def test_chain_resident_kernel_matches_oracle(case):
     compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
 
 
-@pytest.mark.parametrize('lag', [1, 2, 3, 4])
+@pytest.mark.parametrize('lag', [2, 3, 4])
 def test_chain_resident_kernel_lag_and_determinism(lag):
     """Against the launch-per-step kernels; the lag of the normaliser only changes intermediate magnitudes; repeated runs are
     bit-identical (a race on a tagged sum would show as a difference between runs)."""
@@ -861,7 +861,7 @@ def test_chain_resident_kernel_lag_and_determinism(lag):
             assert A.lastTiming['fwd_kernel_variant'] == 6 and A.lastTiming['bwd_kernel_variant'] == 6
             runs.append((A.logEvidence, np.array(A.posteriorSequence), np.array(A.localEvidence), np.array(A.logEvidenceList)))
     finally:
-        eng.set_option('chain_resident_lag', 3)
+        eng.set_option('chain_resident_lag', 4)
     for logE, post, loc, lel in runs:
         assert abs(logE - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
         np.testing.assert_allclose(lel, np.array(B.logEvidenceList), rtol=1e-11)
@@ -880,3 +880,21 @@ def test_chain_resident_kernel_not_taken_outside_its_envelope():
         with np.errstate(all='ignore'):
             want = oa.run(c)
         assert abs(S.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
+
+
+def test_average_posterior_folded_on_the_second_stream():
+    """accum_overlap = 1: the study is cut into ~4 batches, the fold of a batch runs on a second stream beside the next batch's
+    forward pass (two sequence buffers).  Same results as the default (folds on the main stream) up to the order of the sums."""
+    eng = bl.get_engine()
+    c = _hyper(128, 64, 71, 8, ('cint', 0, 0.9, 80))
+    A = cases.build(bl, c); A.fit(silent=True)
+    eng.set_option('accum_overlap', 1)
+    try:
+        B = cases.build(bl, c); B.fit(silent=True)
+        assert B.lastTiming['batches'] >= 3, B.lastTiming
+    finally:
+        eng.set_option('accum_overlap', 0)
+    assert abs(A.logEvidence - B.logEvidence) <= 1e-12 * abs(A.logEvidence)
+    np.testing.assert_allclose(np.array(B.posteriorSequence), np.array(A.posteriorSequence), rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(B.posteriorMeanValues, A.posteriorMeanValues, rtol=1e-11)
+    np.testing.assert_allclose(B.hyperParameterDistribution, A.hyperParameterDistribution, rtol=1e-11)
