@@ -448,9 +448,10 @@ void launch_chain_fn(KernT kern, bool &armed, hipStream_t s, const blc::ChainPar
 
 template <int NK, int NTW>
 void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
-    static bool armed[3] = {false, false, false};
+    static bool armed[4] = {false, false, false, false};
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
-    if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true>, armed[0], s, Q, lds);
+    if (bwd && !store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false>, armed[3], s, Q, lds);      // posteriors folded, not stored
+    else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true>, armed[0], s, Q, lds);
     else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true>, armed[1], s, Q, lds);
     else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false>, armed[2], s, Q, lds);
 }
@@ -1321,10 +1322,12 @@ bool resident_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsu
 
 // The same for the chain-resident kernel (blhip_chainres.hpp), whose step k divides by the normaliser of step k - lag:
 // s_k = S_(k-lag-1) s_(k-lag) / S_(k-lag)  (1 while k < lag; S_(-1) = 1).
-bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B, int64_t b) {
+bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B, int64_t b, std::vector<double> *scales = nullptr) {
     rowsum.assign(T, 0.0);
     for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[((size_t)t * B + b) * NRED];
-    std::vector<double> s(T, 1.0);
+    std::vector<double> s_local;
+    std::vector<double> &s = scales ? *scales : s_local;
+    s.assign(T, 1.0);
     for (int64_t t = 0; t < T; ++t) {
         const double St = rowsum[t];
         if (!(St > 1e-150 && St < 1e150)) return false;
@@ -1667,6 +1670,23 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->psumF.ensure(psz * 8);
             d_psF = ctx->psumF.as<double>();
         }
+        // fused fold: the backward kernel adds the weighted, normalised posteriors to per-slot partial accumulators instead of
+        // storing them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands
+        // left bandwidth unused: same bytes, one pass)
+        const bool fused_fold = chainres && accumulate && full && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0 && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr;
+        bool fold_done = false;               // this batch's posteriors are in the accumulator already
+        if (fused_fold) {
+            ctx->accpart.ensure((size_t)cp.cpr * T * G * 8);
+            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8));
+            char *wc = ctx->accw.as<char>();
+            d_fold_sfwd = carve<double>(wc, (size_t)T * B);
+            d_fold_w = carve<double>(wc, (size_t)B);
+            d_fold_inf = carve<double>(wc, (size_t)B);
+        }
+        std::vector<std::vector<double>> sfwdC;               // chain-resident forward pass: the scales it used, per chain
+        std::vector<double> fold_lw;                          // fused fold: log weight of every chain of the batch (-inf: none)
+        double fold_ref = -INFINITY;
         bool resident_failed = false;
 
         // bucket streams: fork = every bucket stream waits for the main stream; join = the main stream waits for all of them
@@ -1815,13 +1835,19 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 Q.psum = psum;
                 Q.src0 = bwd ? d_uniform : d_prior;
                 Q.post = d_post;
-                Q.means = (!bwd && forward_only) ? 1 : 0;
+                Q.means = bwd ? ((res && res->posterior_mean) ? 1 : 0) : (forward_only ? 1 : 0);
+                Q.strip_major = fused_fold ? 1 : 0;              // (the stored forward states are private to the fit then)
+                const bool fold_now = bwd && fused_fold;
+                if (fold_now) {
+                    Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
+                    Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * G;
+                }
 #ifdef BLC_PROF
                 ctx->small.ensure(2 * 16 * 16 * 8);
                 HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
                 Q.prof = ctx->small.as<unsigned long long>();
 #endif
-                launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, bwd || !evidence_only);
+                launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, fold_now ? false : (bwd || !evidence_only));
 #ifdef BLC_PROF
                 {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
                     unsigned long long hh[2 * 16 * 16];
@@ -1931,8 +1957,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->timing.fwd_kernel_variant = 6;
             if (resident_gave_up()) { resident_failed = true; return false; }
             rowsumC.assign(B, std::vector<double>());
+            sfwdC.assign(B, std::vector<double>());
             for (int64_t b = 0; b < B; ++b)
-                if (!chain_unlag(redF, T, CQ.lag, rowsumC[b], B, b)) { resident_failed = true; return false; }
+                if (!chain_unlag(redF, T, CQ.lag, rowsumC[b], B, b, &sfwdC[b])) { resident_failed = true; return false; }
         }
 
         bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
@@ -1963,6 +1990,27 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 }
             }
             if (res_now) resident_launch(true, d_psB);
+            if (cres_now && fused_fold) {
+                // weights relative to the batch's own reference (core.py:1358-1366: chains without a finite evidence do not count)
+                fold_lw.assign(B, -INFINITY);
+                fold_ref = -INFINITY;
+                for (int64_t b = 0; b < B; ++b) {
+                    if (O.abort_step[b] >= 0 || !std::isfinite(O.logE[b]) || !std::isfinite(log_w[c0 + b])) continue;
+                    fold_lw[b] = O.logE[b] + log_w[c0 + b];
+                    fold_ref = std::max(fold_ref, fold_lw[b]);
+                }
+                ctx->pinA.ensure(((size_t)T * B + 2 * (size_t)B) * 8);
+                double *h = ctx->pinA.as<double>(), *hw = h + (size_t)T * B, *hi = hw + B;
+                for (int64_t b = 0; b < B; ++b) {
+                    std::memcpy(h + (size_t)b * T, sfwdC[b].data(), (size_t)T * 8);
+                    hw[b] = std::isfinite(fold_lw[b]) ? std::exp(fold_lw[b] - fold_ref) : 0.0;
+                    hi[b] = 1.0 / (rowsumC[b][T - 1] * (1.0 / (double)G));
+                }
+                HIPCHECK(hipMemcpyAsync(d_fold_sfwd, h, (size_t)T * B * 8, hipMemcpyHostToDevice, st));
+                HIPCHECK(hipMemcpyAsync(d_fold_w, hw, (size_t)B * 8, hipMemcpyHostToDevice, st));
+                HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, st));
+                HIPCHECK(hipMemsetAsync(ctx->accpart.p, 0, (size_t)cp.cpr * T * G * 8, st));
+            }
             if (cres_now) chainres_pass(true, d_psB);
             fork_streams();
             for (int64_t t = T - 1; t >= 0 && !persist && !fused1d && !res_now && !cres_now; --t) {
@@ -2010,6 +2058,42 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                         if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) { resident_failed = true; return false; }
                     }
             }
+            if (cres_now && fused_fold) {
+                // the kernel normalised every posterior by its PREDICTED sum: the prediction must reproduce the reduced sums
+                std::vector<double> csum, sb;
+                for (int64_t b = 0; b < B; ++b) {
+                    // the backward scales, in processing order k = T - 1 - t (the kernel's rule, from the sums C of its new states)
+                    csum.assign(T, 0.0); sb.assign(T, 1.0);
+                    for (int64_t k = 0; k < T; ++k) csum[k] = redB[((size_t)(T - 1 - k) * B + b) * NRED + 2];
+                    for (int64_t k = CQ.lag; k < T; ++k) sb[k] = (k - CQ.lag - 1 >= 0 ? csum[k - CQ.lag - 1] : 1.0) * sb[k - CQ.lag] / csum[k - CQ.lag];
+                    double npred = rowsumC[b][T - 1] * (1.0 / (double)G);
+                    for (int64_t k = 0; k < T; ++k) {
+                        const int64_t t = T - 1 - k;
+                        if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
+                        const double Nt = redB[((size_t)t * B + b) * NRED];
+                        if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) { resident_failed = true; return false; }
+                    }
+                }
+                // partial accumulators -> average posterior (running reference exponent as in prepare_fold)
+                if (std::isfinite(fold_ref)) {
+                    const double newref = std::max(ctx->acc_logref, fold_ref);
+                    const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
+                    const long long TG = (long long)T * G;
+                    HIPCHECK(hipEventRecord(ev[4], st));
+                    hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((G / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
+                                       ctx->accpart.as<double>(), TG, std::min<int>(cp.cpr, (int)B), g.n0, g.n1, (int)T, r, rb, ctx->acc_first ? 1 : 0);
+                    HIPCHECK(hipEventRecord(ev[5], st));
+                    sync_stream(ctx, st);
+                    float fms = 0;
+                    HIPCHECK(hipEventElapsedTime(&fms, ev[4], ev[5]));
+                    ctx->timing.accumulate_ms += fms;
+                    ctx->timing.accumulate_launches += 1;
+                    int nfold = 0;
+                    for (int64_t b = 0; b < B; ++b) nfold += std::isfinite(fold_lw[b]) ? 1 : 0;
+                    ctx->acc_logref = newref; ctx->acc_first = false; ctx->acc_folded += nfold;
+                }
+                fold_done = true;
+            }
             raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O) && raw_ok;
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
@@ -2041,7 +2125,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             else { fin = fused1d ? d_pp[((T - 1) / usedK) & 1] : d_pp[(T - 1) & 1]; fstr = G; }
             store_carry(ctx, p, B, G, redF, fin, fstr, d_w, prog.has_clamp);
         }
-        if (accumulate && overlap_acc) {
+        if (accumulate && fold_done) {
+            // (the backward kernel folded this batch)
+        } else if (accumulate && overlap_acc) {
             // private copies of the weights, host (page-locked: the copies must not block the host) and device: the batch metadata
             // buffers are rewritten by the next batch while the fold is pending / running
             const size_t wsz = carve_size((size_t)Bmax * 8) + carve_size((size_t)T * Bmax * 8);
@@ -2134,7 +2220,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,

@@ -53,7 +53,9 @@ constexpr int SCALE_WAVE = 6;     // the wave that turns the strips' sums into t
 struct ChainParams {
     int n0, n1, strips;          // n0 == NW * NTW * TM, strips = n1 / 16
     int T, d, rec_len, lag;
-    int means;                   // forward: also sum a * grid values (forward-only fits)
+    int means;                   // also sum the stored distribution times the grid values (forward-only fits; backward: per-chain means wanted)
+    int strip_major;             // layout of post / part: 0 = [t][row][column] (the API's), 1 = [t][strip][row][16] (private to a fit whose
+                                 // backward pass folds: every wave access is 512 contiguous bytes, a strip's step 64 KB)
     int B;                       // chains of the batch (partial-sum layout)
     int nslots;                  // chains of this launch
     int nblk;                    // partial-sum slots per (step, chain, sum)
@@ -66,13 +68,19 @@ struct ChainParams {
     double step0;
     double *psum;                // [T][B][NRED][nblk]
     unsigned long long *gran;    // [NSLOT][nslots][strips][2] {tag << 32 | half of a double}
+    // backward pass of a hyper-study, fused fold (template STORE = false): instead of storing the posteriors, every chain adds
+    // w_chain * max(posterior / its sum, 1e-300) (core.py:1362-1366) to the partial accumulator of its launch slot
+    const double *sfwd;          // [B][T] the forward pass's scales: the sums of the posteriors follow from scalars (see below)
+    const double *wchain;        // [B] weights (0: the chain does not contribute)
+    const double *infirst;       // [B] 1 / sum of the posterior of the last time step
+    double *part; long long part_stride;       // [slot][T][G]
     unsigned *abort_word;
     unsigned long long timeout_ticks;
     unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
 };
 
 template <int NK, int NTW>
-constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 4 * 5 + NSLOT + 8; }
+constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
 
 #ifdef BLC_PROF
 #define BLC_STAMP(i) do { if (prof_me && k >= 8 && k < 24) P.prof[(wv ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -80,7 +88,12 @@ constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 
 #define BLC_STAMP(i) do { } while (0)
 #endif
 
-// STORE: the forward pass keeps every step's state (full / forward-only fits); always true backward
+// STORE: the forward pass keeps every step's state (full / forward-only fits); backward: true = the posteriors are stored (in place of
+// the forward states), false = they are folded into the average posterior right away.  The fold needs every posterior NORMALISED, and
+// the sum of a step's posterior is complete only after all strips have finished the step -- but it follows from scalars: the
+// stencil is self-adjoint, so  N_t = sum alpha_t beta_t = s'_t N_(t+1) / s_(t+1)  (s' = this pass's scales, s = the forward pass's,
+// N_(T-1) = sum alpha_(T-1) / G).  The host checks the prediction against the reduced sums afterwards (1e-9) and repeats the batch
+// with the launch-per-step kernels if it ever differs (the partial accumulators of a batch are folded only after that check).
 template <int NK, int NTW, bool BWD, bool STORE>
 __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
@@ -93,6 +106,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     double *const m0s = As + NK * 64;          // [N0]       row coordinates
     double *const red = m0s + N0;              // [2][NW * 4][5] sums of the waves' rows of 16 lanes, double-buffered by step parity
     double *const scal = red + 2 * NW * 4 * 5;     // [NSLOT] the scales s_j of the steps around the current one (written by the scale wave)
+    double *const iscal = scal + NSLOT;            // [NSLOT] 1 / s_j
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,19 +123,20 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     // (one code path for every step: no per-step branches around the ring and the products)
     for (int e = tid; e < NK * 64; e += NT) As[e] = (4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15)) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
-    if (tid < NSLOT) scal[tid] = 1.0;
+    if (tid < 2 * NSLOT) scal[tid] = 1.0;
     for (int e = tid; e < XSZ; e += NT) X[e] = P.src0[(long long)(e >> 4) * P.n1 + tj * WCOL + (e & 15)];
 
     const double g1 = P.m1[gj];
     const double cA = P.colA[gj], cB = P.colB[gj];
     double *const pchain = P.post + (long long)b * P.post_stride;
-    const unsigned n1x8 = (unsigned)P.n1 * 8u;
+    const unsigned rowx8 = P.strip_major ? (unsigned)WCOL * 8u : (unsigned)P.n1 * 8u;                        // bytes between rows
+    const unsigned strip0 = P.strip_major ? (unsigned)tj * (unsigned)(P.n0 * WCOL * 8) : (unsigned)tj * (unsigned)(WCOL * 8);   // the strip's first byte
     const int row0 = wv * (NTW * TM);
     // The lane's coordinates are re-derived from a laundered lane id wherever they are used: carried through the time loop, every
     // index expression of the step (ring rows, LDS offsets, byte offsets of the 4 NTW cells) is loop-invariant and the optimiser
     // parks it in a VGPR -- more than a hundred of them (the time-resident single-chain kernel spilled for the same reason).
     auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    auto cell_off = [&](int l, int it, int r) { return __umul24(row0 + it * TM + (l >> 4) + 4 * r, n1x8) + (unsigned)(tj * WCOL + (l & 15)) * 8u; };
+    auto cell_off = [&](int l, int it, int r) { return __umul24(row0 + it * TM + (l >> 4) + 4 * r, rowx8) + strip0 + (unsigned)(l & 15) * 8u; };
 
     const int t_first = BWD ? P.T - 1 : 0;
     double xd[DMAX], xn[DMAX];
@@ -133,6 +148,16 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         for (int it = 0; it < NTW; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) al[it][r] = blm::ld32(pchain + (long long)t_first * G, cell_off(lane, it, r));
+    }
+    constexpr bool FOLD = BWD && !STORE;
+    double *const pslot = FOLD ? P.part + (long long)cs * P.part_stride : nullptr;
+    const double wch = FOLD ? P.wchain[b] : 0.0;
+    double inpred = FOLD ? P.infirst[b] : 0.0;        // 1 / predicted sum of the step's posterior
+    double sfn = 1.0;                                 // the forward scale the NEXT step's prediction needs
+    double pa[4] = {0.0, 0.0, 0.0, 0.0};              // fold: the accumulator cells of the tile in flight, requested one tile ahead
+    if (FOLD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pa[r] = blm::ld32(pslot + (long long)t_first * G, cell_off(lane, 0, r));
     }
     bool dead = false;
     typedef const double __attribute__((address_space(3))) *lds_cp;
@@ -165,6 +190,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         }
         // ---- what the NEXT step needs from HBM: its data record (its stored alpha: see the epilogue) --------------------------------
         const double *const pnext = pchain + (long long)tn * G;
+        const double sf_now = sfn;
+        if (FOLD) sfn = P.sfwd[(long long)b * P.T + min(tn + 1, P.T - 1)];
 #pragma unroll
         for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
 
@@ -193,6 +220,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         int nE = 0, nR = 0;
         double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
         double *const pstep = pchain + (long long)t * G;
+        double *const pslot_t = FOLD ? pslot + (long long)t * G : nullptr;
+        double *const pslot_tn = FOLD ? pslot + (long long)tn * G : nullptr;
+        double wq = 0.0, wfloor = 0.0;                 // w / N_t and w * 1e-300: w max(p / N, 1e-300) = max(p wq, wfloor)
 
 #pragma unroll
         for (int it = 0; it < NTW; ++it) {
@@ -212,6 +242,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 // ---- the scale of this step (prepared during the previous one); the scale wave prepares the next one: it sums the
                 //      strips' granules in one fixed order, so every strip of the chain arrives at bit-identical scales ----------------
                 scale = scal[k & (NSLOT - 1)];
+                if (FOLD && k > 0) inpred *= sf_now * iscal[k & (NSLOT - 1)];      // N_t = s'_t N_(t+1) / s_(t+1)
+                if (FOLD) { wq = wch * inpred; wfloor = wch * 1e-300; }
                 if (scale_wave) {
                     double sj = 1.0;
                     if (need) {
@@ -234,7 +266,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                         sj = dead ? 1.0 : Sprev * scal[(jn - P.lag) & (NSLOT - 1)] / Sg;
                         Sprev = Sg;
                     }
-                    if (lane == 0) scal[jn & (NSLOT - 1)] = sj;
+                    if (lane == 0) { scal[jn & (NSLOT - 1)] = sj; if (BWD && !STORE) iscal[jn & (NSLOT - 1)] = 1.0 / sj; }
                 }
                 // ---- anchor of the stride-4 likelihood recurrence of this lane's rows (blhip_mfma.hpp) -------------------------------
                 // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
@@ -289,20 +321,29 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
                     const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
                     D[li * WCOL + c] = cn;
-                    blm::st32(pstep, off, p);
-                    al[it][r] = blm::ld32(pnext, off);
+                    if (!FOLD) blm::st32(pstep, off, p);
+                    else blm::st32(pslot_t, off, pa[r] + fmax(p * wq, wfloor));      // (nobody else touches the slot's cell during the launch)
                     sN += p;
                     sS += pl;
                     sC += cn;
-                    sM0 = fma(p, m0s[li], sM0);
-                    sM1 = fma(p, g1, sM1);
+                    acc[r] = p;
                 }
                 mE *= mR; nE += nR;
                 mR *= mq; nR += nq;
                 if (BWD) { iE *= iR; iR *= iq; }
             }
 
-            if (!BWD && STORE && P.means) {
+            if (BWD) {
+                // requests, soonest use first (loads return in order): the accumulator cells of the NEXT tile, then the stored alpha
+                // of this tile's cells for the next step
+                if (FOLD) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pa[r] = blm::ld32(it + 1 < NTW ? pslot_t : pslot_tn, cell_off(l, (it + 1) % NTW, r));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) al[it][r] = blm::ld32(pnext, cell_off(l, it, r));
+            }
+            if ((BWD || STORE) && P.means) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sM0 = fma(acc[r], m0s[i + g + 4 * r], sM0); sM1 = fma(acc[r], g1, sM1); }
             }
@@ -328,7 +369,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         //      and publishes the one the scale of step k + lag is made of -----------------------------------------------------------------
         double v[5] = {sN, BWD ? sS : sM0, BWD ? sC : sM1, sM0, sM1};
         constexpr int NV = BWD ? 5 : 3;
-        const int nv = (BWD || P.means) ? NV : 1;
+        const int nv = P.means ? NV : (BWD ? 3 : 1);
         // (a full wave reduction costs ~45 vector instructions per sum and wave; the waves reduce only within their rows of 16 lanes
         //  -- 12 instructions -- and one wave adds the 32 row sums of the block after the barrier, in a fixed order)
         double *rk = red + (k & 1) * (NW * 4 * 5);
@@ -358,7 +399,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 #pragma unroll
             for (int w = 0; w < NW * 4; ++w) tot += rk[w * 5 + lane];
             const int slot = BWD ? lane : (lane == 0 ? 0 : 2 + lane);          // forward: N, M0, M1 -> slots 0, 3, 4
-            if (BWD || lane == 0 || P.means) P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
+            if (lane == 0 || P.means || (BWD && lane < 3)) P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
             if (lane == (BWD ? 2 : 0)) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
                 const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;

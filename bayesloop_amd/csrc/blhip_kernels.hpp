@@ -467,6 +467,30 @@ __global__ __launch_bounds__(NTHREADS) void accumulate_kernel(double *A, const d
     }
 }
 
+// The partial accumulators of a batch whose backward kernel folded the posteriors itself (blhip_chainres.hpp): one per launch slot,
+// already weighted and normalised, in the kernel's strip-major layout [t][strip][row][16]:
+//     A[t][row][col] = r A + rb sum_slots part[slot][t][col / 16][row][col % 16]          (two cells per lane)
+__global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const double *part, long long part_stride, int nslots, int n0, int n1,
+                                                               int T, double r, double rb, int first) {
+    const long long G = (long long)n0 * n1;
+    const long long c = ((long long)blockIdx.x * NTHREADS + threadIdx.x) * 2;
+    const int t = blockIdx.y;
+    if (c >= G) return;
+    const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
+    double2 *ap = reinterpret_cast<double2 *>(A + (long long)t * G + c);
+    double2 acc = first ? make_double2(0.0, 0.0) : *ap;
+    if (!first) { acc.x *= r; acc.y *= r; }
+    const double *src = part + (long long)t * G + ((long long)(col >> 4) * n0 + row) * 16 + (col & 15);
+    double2 sum = make_double2(0.0, 0.0);
+    for (int k = 0; k < nslots; ++k) {
+        const double2 v = *reinterpret_cast<const double2 *>(src + (long long)k * part_stride);
+        sum.x += v.x; sum.y += v.y;
+    }
+    acc.x = fma(rb, sum.x, acc.x);
+    acc.y = fma(rb, sum.y, acc.y);
+    *ap = acc;
+}
+
 // Same, two cells per lane (16-B accesses) and four chains in flight per iteration; needs an even number of cells.
 __global__ __launch_bounds__(NTHREADS) void accumulate2_kernel(double *A, const double *post, long long chain_stride,
                                                                int B, long long G, int T, const double *w,

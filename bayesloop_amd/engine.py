@@ -201,7 +201,9 @@ class HipEngine:
         T, ndim = problem.T, len(problem.marginal)
         logE = np.zeros(n)
         local = np.zeros((n, T))
-        means = None if evidence_only else np.zeros((n, ndim, T))
+        # (per-chain posterior means are not part of a hyper-study's results -- core.py:1416-1419 takes them from the average
+        #  posterior -- and the backward kernels skip their sums when nobody asks)
+        means = None if (evidence_only or accumulate) else np.zeros((n, ndim, T))
         astep = np.full(n, -1, dtype=np.int64)
         aphase = np.zeros(n, dtype=np.int32)
         res = _abi.Result()
