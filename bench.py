@@ -153,7 +153,9 @@ def roofline_of(timing, units):
             variant = timing.get('fwd_kernel_variant' if key == 'forward' else 'bwd_kernel_variant', 0)
             kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel', 4: 'bl1f::fused1d_kernel (8 time steps per launch)',
                      3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)',
-                     5: 'blr::resident_kernel (ONE launch for all time steps; a logical launch = one time step of it)'}.get(variant, 'step_kernel')
+                     5: 'blr::resident_kernel (ONE launch for all time steps; a logical launch = one time step of it)',
+                     6: 'blc::chain_kernel (rounds of 8 chains resident in LDS for a whole pass; a logical launch = one time step of all '
+                        'chains of a batch; the backward kernel of a hyper-study also folds the posteriors into the average posterior)'}.get(variant, 'step_kernel')
             out[key] = dict(kernel='%s<%s> (one logical step launch = all launches of one time step of a batch)' % (kname, key),
                             launches=int(n), avg_launch_us=per_launch_s * 1e6, cells_per_launch=cells_per_launch,
                             achieved=bytes_per * cells_per_launch / per_launch_s / 1e9, bytes_per_cell_step=bytes_per)

@@ -898,3 +898,21 @@ def test_average_posterior_folded_on_the_second_stream():
     np.testing.assert_allclose(np.array(B.posteriorSequence), np.array(A.posteriorSequence), rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(B.posteriorMeanValues, A.posteriorMeanValues, rtol=1e-11)
     np.testing.assert_allclose(B.hyperParameterDistribution, A.hyperParameterDistribution, rtol=1e-11)
+
+
+def test_fused_fold_matches_the_separate_fold():
+    """fuse_accumulate = 0: the backward chain kernel stores the posteriors and the average posterior is folded by a separate pass."""
+    eng = bl.get_engine()
+    c = _hyper(256, 64, 72, 9, ('cint', 0, 0.6, 21))
+    A = cases.build(bl, c); A.fit(silent=True)
+    assert A.lastTiming['bwd_kernel_variant'] == 6
+    eng.set_option('fuse_accumulate', 0)
+    try:
+        B = cases.build(bl, c); B.fit(silent=True)
+        assert B.lastTiming['bwd_kernel_variant'] == 6
+    finally:
+        eng.set_option('fuse_accumulate', 1)
+    assert A.logEvidence == B.logEvidence                      # (the forward pass is the same kernel)
+    np.testing.assert_allclose(np.array(A.posteriorSequence), np.array(B.posteriorSequence), rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(A.posteriorMeanValues, B.posteriorMeanValues, rtol=1e-11)
+    np.testing.assert_allclose(A.localEvidence, B.localEvidence, rtol=1e-11, equal_nan=True)

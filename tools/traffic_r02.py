@@ -51,6 +51,8 @@ def busy_ns(out, d):
 def direction(name):
     if 'resident_kernel<' in name:
         return 'bwd' if name.split('resident_kernel<')[1].split('>')[0].split(',')[-1].strip() in ('true', '1') else 'fwd'
+    if 'chain_kernel<' in name:          # blc::chain_kernel<NK, NTW, BWD, STORE>
+        return 'bwd' if name.split('chain_kernel<')[1].split('>')[0].split(',')[2].strip() in ('true', '1') else 'fwd'
     if 'step_kernel<' in name:
         return 'fwd' if name.split('step_kernel<')[1].split('>')[0].split(',')[1].strip() == '0' else 'bwd'
     return None
