@@ -765,9 +765,9 @@ def test_resident_kernel_full_chip():
         eng.release_posterior()
 
 
-@pytest.mark.parametrize('name', ['c3', 'c4'])
+@pytest.mark.parametrize('name', ['c3', 'c4', 'c5'])
 def test_bench_workloads_full_fit_against_full_size_reference(name):
-    """C3 (T = 2000, 16 GiB posterior) and C4 (512 chains, T = 256) as FULL forward-backward fits against the reference's own
+    """C3 (T = 2000, 16 GiB posterior), C4 (512 chains, T = 256) and C5 (250 change-points, T = 1000) as FULL forward-backward fits against the reference's own
     full-size results (tests/golden/bench_<name>_full.npz): log-evidence, local evidence, posterior means, both marginals of the
     (average) posterior sequence (reduced on the device) and strided posterior rows."""
     import bench
@@ -779,6 +779,9 @@ def test_bench_workloads_full_fit_against_full_size_reference(name):
     assert np.array_equal(np.isnan(S.localEvidence), np.isnan(ge))
     np.testing.assert_allclose(S.localEvidence[~np.isnan(ge)], ge[~np.isnan(ge)], rtol=1e-9, atol=0)
     np.testing.assert_allclose(S.posteriorMeanValues, gold['posteriorMeanValues'], rtol=1e-9, atol=1e-11)
+    if 'hyperParameterDistribution' in gold.files:
+        np.testing.assert_allclose(S.hyperParameterDistribution, gold['hyperParameterDistribution'], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(np.asarray(S.logEvidenceList, dtype=float), gold['logEvidenceList'], rtol=1e-9)
     tidx = gold['marginalTimeIndex'] if 'marginalTimeIndex' in gold.files else np.arange(gold['marginalSequence0'].shape[0])
     names = S.observationModel.parameterNames
     for k in (0, 1):
