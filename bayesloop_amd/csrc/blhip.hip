@@ -459,6 +459,7 @@ void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool sto
 template <int NTW>
 void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
     switch (nk) {
+        case 4: launch_chain_k<4, NTW>(s, Q, bwd, store); break;       // no stencil (change-point studies)
         case 8: launch_chain_k<8, NTW>(s, Q, bwd, store); break;
         case 12: launch_chain_k<12, NTW>(s, Q, bwd, store); break;
         case 16: launch_chain_k<16, NTW>(s, Q, bwd, store); break;
@@ -812,12 +813,15 @@ int chain_bucket(const blhip_problem *p, const double *val) {
 // -> start index of every batch (+ n_chains at the end): equal shares of at most Bmax chains, each cut moved to the nearest change of
 // radius bucket within the slack the memory budget leaves
 std::vector<int64_t> plan_batches(const blhip_problem *p, int64_t n_chains, const double *op_values, int64_t Bmax, bool align) {
+    // batches of a multiple of 8 chains: whole launches of the chain-resident kernel (8 chains per launch on 512-column grids)
+    if (Bmax >= 16) Bmax -= Bmax % 8;
     const int64_t nbatch = (n_chains + Bmax - 1) / Bmax;
-    const int64_t even = (n_chains + nbatch - 1) / nbatch;
+    int64_t even = (n_chains + nbatch - 1) / nbatch;
+    if (nbatch > 1 && even >= 16) even = std::min(Bmax, (even + 7) / 8 * 8);
     std::vector<int64_t> start;
     for (int64_t c = 0; c < n_chains; c += even) start.push_back(c);
     start.push_back(n_chains);
-    if (!align || nbatch < 2 || !op_values || p->n_ops == 0) return start;
+    if (!align || (int64_t)start.size() != nbatch + 1 || nbatch < 2 || !op_values || p->n_ops == 0) return start;
     std::vector<int> bucket(n_chains);
     for (int64_t c = 0; c < n_chains; ++c) {
         bucket[c] = chain_bucket(p, op_values + c * p->n_ops);
@@ -1161,6 +1165,7 @@ struct FoldJob {
     double r = 0.0;                                  // factor of what the accumulator already holds
     int first = 0;
     int parity = 0;
+    int sm_n0 = 0;                                   // > 0: d_post is in the chain-resident kernel's strip-major layout (rows per strip)
 };
 
 bool prepare_fold(blhip_ctx *ctx, int64_t T, int64_t B, const BatchOutcome &out, const double *log_w_batch, FoldJob &job) {
@@ -1199,8 +1204,9 @@ void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hip
     if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
         const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
         hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
-                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
+                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first, job.sm_n0);
     } else {
+        if (job.sm_n0 > 0) fail("internal: strip-major sequences need an even number of cells and a 16-byte aligned accumulator");
         const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
         hipLaunchKernelGGL(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
                            (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
@@ -1210,9 +1216,10 @@ void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hip
 
 // the whole fold on the main stream, waited for
 void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const BatchOutcome &out, const double *log_w_batch, const double *d_post,
-                     double *d_w, double *d_invN) {
+                     double *d_w, double *d_invN, int sm_n0 = 0) {
     ctx->pinA.ensure(((size_t)B + (size_t)T * B) * 8);
     FoldJob job;
+    job.sm_n0 = sm_n0;
     job.h_w = ctx->pinA.as<double>(); job.h_invN = job.h_w + B;
     job.d_w = d_w; job.d_invN = d_invN; job.d_post = d_post;
     if (!prepare_fold(ctx, T, B, out, log_w_batch, job)) return;
@@ -1254,6 +1261,7 @@ void write_results(blhip_result *res, const blhip_problem *p, int64_t c0, int64_
 // The chain-resident path (blhip_chainres.hpp): which chains of the batch run together, in which order, with which band width.
 struct ChainResPlan {
     int ntw = 0, strips = 0, cpr = 0;            // product tiles per wave, strips per chain, chains per launch
+    bool has_reset = false;                      // change points: some steps consume the reset distribution (no-stencil batches only)
     std::vector<int> order, tap_id;              // chains sorted by stencil radius; the chain's axis-0 kernel (-1: none)
     std::vector<int> round_start, round_nk;      // launches: order[round_start[r] .. round_start[r + 1]), band blocks NK
 };
@@ -1270,9 +1278,12 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
     std::vector<int> lw(B, 0);
     for (int64_t b = 0; b < B; ++b) {
         if (prog.kindF[b] != SRC_PRIOR || prog.tapF0[b] >= 0 || prog.tapF1[b] >= 0) return false;
-        const int k0 = T > 1 ? prog.tapF0[(size_t)B + b] : -1;
+        // a batch without any stencil (prog.LW0 == 0: change-point studies) may reset at single steps (transitionModels.py:300-312)
+        const bool resets_ok = prog.LW0 == 0;
+        const int k0 = resets_ok ? -1 : (T > 1 ? prog.tapF0[(size_t)B + b] : -1);
         for (int64_t t = 1; t < T; ++t) {
             const size_t k = (size_t)t * B + b;
+            if (resets_ok && prog.kindF[k] == SRC_RESET && prog.tapF0[k] < 0 && prog.tapF1[k] < 0) { cp.has_reset = true; continue; }
             if (prog.kindF[k] != SRC_PREV || prog.tapF0[k] != k0 || prog.tapF1[k] >= 0) return false;
         }
         if (full) {
@@ -1280,6 +1291,7 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
             if (prog.kindB[kl] != SRC_UNIFORM || prog.tapB0[kl] >= 0 || prog.tapB1[kl] >= 0) return false;
             for (int64_t t = 0; t < T - 1; ++t) {
                 const size_t k = (size_t)t * B + b;
+                if (resets_ok && prog.kindB[k] == SRC_RESET && prog.tapB0[k] < 0 && prog.tapB1[k] < 0) { cp.has_reset = true; continue; }
                 if (prog.kindB[k] != SRC_PREV || prog.tapB0[k] != k0 || prog.tapB1[k] >= 0) return false;
             }
         }
@@ -1295,7 +1307,7 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
         const int64_t s1 = std::min<int64_t>(B, s0 + cp.cpr);
         const int r0 = std::max(8, (lw[cp.order[s1 - 1]] + 7) / 8 * 8);
         cp.round_start.push_back((int)s0);
-        cp.round_nk.push_back((blc::TM + 2 * r0) / 4);
+        cp.round_nk.push_back(prog.LW0 == 0 ? 4 : (blc::TM + 2 * r0) / 4);          // (4: the no-stencil kernel)
     }
     cp.round_start.push_back((int)B);
     return true;
@@ -1322,7 +1334,10 @@ bool resident_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsu
 
 // The same for the chain-resident kernel (blhip_chainres.hpp), whose step k divides by the normaliser of step k - lag:
 // s_k = S_(k-lag-1) s_(k-lag) / S_(k-lag)  (1 while k < lag; S_(-1) = 1).
-bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B, int64_t b, std::vector<double> *scales = nullptr) {
+// kinds (may be null): a step whose source kind is not SRC_PREV consumed a distribution of known mass instead of the previous
+// state: its normaliser is S_k / s_k.
+bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B, int64_t b, std::vector<double> *scales = nullptr,
+                 const unsigned char *kinds = nullptr) {
     rowsum.assign(T, 0.0);
     for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[((size_t)t * B + b) * NRED];
     std::vector<double> s_local;
@@ -1332,7 +1347,8 @@ bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, 
         const double St = rowsum[t];
         if (!(St > 1e-150 && St < 1e150)) return false;
         if (t >= lag) s[t] = (t - lag - 1 >= 0 ? rowsum[t - lag - 1] : 1.0) * s[t - lag] / rowsum[t - lag];
-        const double norm = t == 0 ? St : St / (rowsum[t - 1] * s[t]);
+        const bool fresh = t == 0 || (kinds && kinds[(size_t)t * B + b] != SRC_PREV);
+        const double norm = fresh ? St / s[t] : St / (rowsum[t - 1] * s[t]);
         double *r = &redF[((size_t)t * B + b) * NRED];
         r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
     }
@@ -1455,7 +1471,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     // ---- batches: at most Bmax chains each, cut where the axis-0 radius bucket changes.  A bucket cut by a batch boundary becomes
     //      two under-filled launches per step (round 1: the 107-chain radius-24 bucket of the C4 study ran as 36 + 71 chains at
     //      4.1 TB/s); hyper-grids are usually monotone in the random-walk width, so contiguous cuts suffice.
-    std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && ctx->option("bucket_batches", 1.0) != 0.0);
+    // (cuts on radius-bucket boundaries serve the launch-per-step kernels; grids the chain-resident kernel takes keep whole launches)
+    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && (g.n0 == 128 || g.n0 == 256 || g.n0 == 512) && g.n1 % 16 == 0 &&
+                             ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok;
+    std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && !chain_shape && ctx->option("bucket_batches", 1.0) != 0.0);
     if (overlap_acc) {                     // (equal batches, multiples of 32 chains: whole launches of the chain-resident kernel)
         batch_start.clear();
         for (int64_t c = 0; c < n_chains; c += Bmax) batch_start.push_back(c);
@@ -1641,7 +1660,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         // ---- chain-resident path: rounds of chains stay in LDS for a whole pass (blhip_chainres.hpp) ------------------------------------
         ChainResPlan cp;
         bool chainres = false;
-        if (!resident && fast && B >= 2 && p->obs_model == BLHIP_OM_GAUSSIAN && FP.use_rec && !resume && !carry && d <= blc::DMAX &&
+        if (!resident && fast && p->obs_model == BLHIP_OM_GAUSSIAN && FP.use_rec && !resume && !carry && d <= blc::DMAX &&
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
             chainres = plan_chainres(g, prog, taps, B, T, full, std::min(ctx->num_cus, 256), cp);
         blc::ChainParams CQ{};
@@ -1673,7 +1692,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         // fused fold: the backward kernel adds the weighted, normalised posteriors to per-slot partial accumulators instead of
         // storing them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands
         // left bandwidth unused: same bytes, one pass)
-        const bool fused_fold = chainres && accumulate && full && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0 && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
+        const bool post_private = chainres && accumulate && full && !keep && !carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
+        const bool fused_fold = post_private && !cp.has_reset && ctx->option("fuse_accumulate", 1.0) != 0.0;
         double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr;
         bool fold_done = false;               // this batch's posteriors are in the accumulator already
         if (fused_fold) {
@@ -1834,9 +1855,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 Q.nslots = cp.round_start[r + 1] - cp.round_start[r];
                 Q.psum = psum;
                 Q.src0 = bwd ? d_uniform : d_prior;
+                Q.kinds = cp.has_reset ? (bwd ? d_kindB : d_kindF) : nullptr;
+                Q.reset = d_reset;
                 Q.post = d_post;
                 Q.means = bwd ? ((res && res->posterior_mean) ? 1 : 0) : (forward_only ? 1 : 0);
-                Q.strip_major = fused_fold ? 1 : 0;              // (the stored forward states are private to the fit then)
+                Q.strip_major = post_private ? 1 : 0;            // (the stored sequence is private to the fit then)
                 const bool fold_now = bwd && fused_fold;
                 if (fold_now) {
                     Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
@@ -1959,7 +1982,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             rowsumC.assign(B, std::vector<double>());
             sfwdC.assign(B, std::vector<double>());
             for (int64_t b = 0; b < B; ++b)
-                if (!chain_unlag(redF, T, CQ.lag, rowsumC[b], B, b, &sfwdC[b])) { resident_failed = true; return false; }
+                if (!chain_unlag(redF, T, CQ.lag, rowsumC[b], B, b, &sfwdC[b], cp.has_reset ? prog.kindF.data() : nullptr)) { resident_failed = true; return false; }
         }
 
         bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
@@ -2137,11 +2160,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             fold_job.d_w = carve<double>(wc, (size_t)Bmax); fold_job.d_invN = carve<double>(wc, (size_t)T * Bmax);
             fold_job.h_w = carve<double>(hc, (size_t)Bmax); fold_job.h_invN = carve<double>(hc, (size_t)T * Bmax);
             fold_job.d_post = d_post; fold_job.parity = (int)(bi & 1);
+            fold_job.sm_n0 = (post_private && !resident_failed) ? g.n0 : 0;
             fold_job.pending = prepare_fold(ctx, T, B, O, log_w + c0, fold_job);
             // launched behind the NEXT batch's forward pass (see passes); the last batch has nothing to hide behind
             if (bi == nbatch - 1) launch_pending_fold();
         } else if (accumulate) {
-            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN);
+            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (post_private && !resident_failed) ? g.n0 : 0);
         }
         if (keep) {
             int64_t row0 = 0, row1 = T;              // rows the resident kernel normalised in place (invN = 1 there) need no pass

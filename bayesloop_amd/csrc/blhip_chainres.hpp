@@ -63,6 +63,8 @@ struct ChainParams {
     const int *tap_id;           // [B] the chain's axis-0 kernel in the tap table, -1 = none
     const double *taps; const int *tap_off; const int *tap_lw;
     const double *src0;          // what the first step consumes instead of a transition: prior (forward) / uniform (backward), (G)
+    const unsigned char *kinds;  // NK = 4 (no stencil at all: change-point studies): [T][B] source kind of every step -- blk::SRC_PREV or
+    const double *reset;         //   blk::SRC_RESET = the step consumes `reset` (G) instead of the previous state (transitionModels.py:300-312)
     double *post; long long post_stride;       // [chain][T][G]: stored states (forward out, backward in) -> posteriors (backward out)
     const double *m0, *m1, *colA, *colB, *rec;
     double step0;
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
-    static_assert(NK >= 8 && R0 % 4 == 0, "band = 16 + 2 R0 columns, R0 a multiple of 4");
+    static_assert(NK == 4 || (NK >= 8 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
+    constexpr bool FILTER = NK > 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *const X = lds;                     // [2][N0][16]
     double *const As = X + 2 * XSZ;            // [NK][64]   A operand: W[m][k] = w(|k - R0 - m|)
@@ -121,10 +124,10 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     // ---- prologue: band, row coordinates, first source -> LDS ---------------------------------------------------------------------
     // the first step consumes its source unfiltered: it runs with the identity band (exact), the chain's band replaces it afterwards
     // (one code path for every step: no per-step branches around the ring and the products)
-    for (int e = tid; e < NK * 64; e += NT) As[e] = (4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15)) == 0 ? 1.0 : 0.0;
+    if (FILTER) for (int e = tid; e < NK * 64; e += NT) As[e] = (4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15)) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
     if (tid < 2 * NSLOT) scal[tid] = 1.0;
-    for (int e = tid; e < XSZ; e += NT) X[e] = P.src0[(long long)(e >> 4) * P.n1 + tj * WCOL + (e & 15)];
+    if (FILTER) for (int e = tid; e < XSZ; e += NT) X[e] = P.src0[(long long)(e >> 4) * P.n1 + tj * WCOL + (e & 15)];
 
     const double g1 = P.m1[gj];
     const double cA = P.colA[gj], cB = P.colB[gj];
@@ -149,11 +152,26 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) al[it][r] = blm::ld32(pchain + (long long)t_first * G, cell_off(lane, it, r));
     }
+    // NK = 4 (no stencil): a step is elementwise, so the state of the lane's 4 NTW cells never leaves its registers -- and neither does
+    // the reset distribution a change point restarts from (loaded once).  No LDS traffic, no memory instruction under control flow
+    // (the compiler's wait-count bookkeeping drains every outstanding access where paths with different numbers of them join).
+    double stt[FILTER ? 1 : NTW][4], rst[FILTER ? 1 : NTW][4];
+    if (!FILTER) {
+#pragma unroll
+        for (int it = 0; it < NTW; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long cell = (long long)(row0 + it * TM + (lane >> 4) + 4 * r) * P.n1 + tj * WCOL + (lane & 15);
+                stt[it][r] = P.src0[cell];
+                rst[it][r] = P.kinds ? P.reset[cell] : 0.0;
+            }
+    }
     constexpr bool FOLD = BWD && !STORE;
     double *const pslot = FOLD ? P.part + (long long)cs * P.part_stride : nullptr;
     const double wch = FOLD ? P.wchain[b] : 0.0;
     double inpred = FOLD ? P.infirst[b] : 0.0;        // 1 / predicted sum of the step's posterior
     double sfn = 1.0;                                 // the forward scale the NEXT step's prediction needs
+    int kind_n = blk::SRC_PREV;                      // NK = 4: source kind of the next step (the first step's source is in LDS already)
     double pa[4] = {0.0, 0.0, 0.0, 0.0};              // fold: the accumulator cells of the tile in flight, requested one tile ahead
     if (FOLD) {
 #pragma unroll
@@ -190,6 +208,14 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         }
         // ---- what the NEXT step needs from HBM: its data record (its stored alpha: see the epilogue) --------------------------------
         const double *const pnext = pchain + (long long)tn * G;
+        const int kind = kind_n;
+        if (!FILTER && P.kinds) kind_n = P.kinds[(long long)tn * P.B + b];
+        if (!FILTER && kind != blk::SRC_PREV) {               // a change point: the chain restarts from the reset distribution
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stt[it][r] = rst[it][r];
+        }
         const double sf_now = sfn;
         if (FOLD) sfn = P.sfwd[(long long)b * P.T + min(tn + 1, P.T - 1)];
 #pragma unroll
@@ -202,7 +228,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         //  window reaches beyond the grid edge pay for the reflection)
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
         double Bv[NK];
-        {
+        if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (edge) {
 #pragma unroll
@@ -230,7 +256,10 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             // ---- axis-0 stencil: NK chained matrix products (k ascending) -----------------------------------------------------------
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-            {
+            if (!FILTER) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = stt[it][r];          // no stencil: the product tile IS the state
+            } else {
                 const unsigned aoff = (unsigned)l * 8u;                 // (the band stays in LDS: hoisted out of the time loop it costs 2 NK VGPRs)
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
 #pragma unroll
@@ -310,7 +339,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 const unsigned off = cell_off(l, it, r);
                 if (!BWD) {
                     const double a = acc[r] * Lv;
-                    D[li * WCOL + c] = a;
+                    if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
                     if (STORE) blm::st32(pstep, off, a);
                     sN += a;
                     acc[r] = a;
@@ -320,7 +349,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
                     const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
-                    D[li * WCOL + c] = cn;
+                    if (FILTER) D[li * WCOL + c] = cn; else stt[it][r] = cn;
                     if (!FOLD) blm::st32(pstep, off, p);
                     else blm::st32(pslot_t, off, pa[r] + fmax(p * wq, wfloor));      // (nobody else touches the slot's cell during the launch)
                     sN += p;
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             if (it == 0) BLC_STAMP(4);
             if (it == NTW - 1) BLC_STAMP(5);
             // ---- advance the ring by one tile --------------------------------------------------------------------------------------
-            if (it + 1 < NTW) {
+            if (FILTER && it + 1 < NTW) {
 #pragma unroll
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
                 if (edge) {
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         BLC_STAMP(6);
         __syncthreads();
         BLC_STAMP(7);
-        if (k == 0) {                      // the chain's band replaces the identity of the first step
+        if (FILTER && k == 0) {            // the chain's band replaces the identity of the first step
             for (int e = tid; e < NK * 64; e += NT) {
                 const int a = abs(4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15));
                 As[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);

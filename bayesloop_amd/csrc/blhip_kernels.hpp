@@ -492,16 +492,23 @@ __global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const d
 }
 
 // Same, two cells per lane (16-B accesses) and four chains in flight per iteration; needs an even number of cells.
+// sm_n0 > 0: the sequences are in the chain-resident kernel's strip-major layout [t][column / 16][row][16] (n0 = sm_n0 rows; the
+// accumulator keeps the API's [t][row][column]).
 __global__ __launch_bounds__(NTHREADS) void accumulate2_kernel(double *A, const double *post, long long chain_stride,
                                                                int B, long long G, int T, const double *w,
-                                                               const double *invN, double r, int first) {
+                                                               const double *invN, double r, int first, int sm_n0) {
     const long long t = blockIdx.y;
     const long long c = ((long long)blockIdx.x * NTHREADS + threadIdx.x) * 2;
     if (c >= G) return;
     double2 *ap = reinterpret_cast<double2 *>(A + t * G + c);
     double2 acc = first ? make_double2(0.0, 0.0) : *ap;
     if (!first) { acc.x *= r; acc.y *= r; }
-    const double *pp = post + t * G + c;
+    long long cs = c;
+    if (sm_n0 > 0) {
+        const int n1 = (int)(G / sm_n0), row = (int)(c / n1), col = (int)(c - (long long)row * n1);
+        cs = ((long long)(col >> 4) * sm_n0 + row) * 16 + (col & 15);
+    }
+    const double *pp = post + t * G + cs;
     int b = 0;
     for (; b + 4 <= B; b += 4) {
         double2 v[4];

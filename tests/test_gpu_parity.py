@@ -818,6 +818,11 @@ CHAINRES = {
     # two data dimensions per step (product of likelihoods)
     'cres_128x64_multidim': dict(study='HyperStudy', data=('series2d', 56, 8), om=_g2(128, 64, -4, 4, 3),
                                  tm=('GRW', 'sigma', ('cint', 0, 0.5, 5), 'mean', None)),
+    # no stencil at all + one reset step per chain (change-point studies): the no-filter kernel, posteriors stored, separate fold
+    'cres_changepoints_256x32': dict(study='ChangepointStudy', data=('series_jump', 59, 24, 11, 1.5), om=_g2(256, 32),
+                                     tm=('ChangePoint', 'tChange', ('arange', 1, 23, 2), None)),
+    'cres_changepoints_128x64_evidence': dict(study='ChangepointStudy', data=('series_jump', 60, 17, 8, -2.0), om=_g2(128, 64),
+                                              tm=('ChangePoint', 'tChange', 'all', None), fit=dict(evidenceOnly=True)),
     # T = 1 and T = 2 (shorter than the lag)
     'cres_T1': _hyper(128, 32, 57, 1, ('cint', 0, 0.5, 3)),
     'cres_T2': _hyper(128, 32, 58, 2, ('cint', 0, 0.5, 3)),
