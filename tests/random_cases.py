@@ -204,3 +204,38 @@ def random_online_case(seed):
         w = rng.uniform(0.1, 1.0, nm)
         c['tm_prior'] = [float(x) for x in w / w.sum()]
     return c
+
+
+def random_chain_resident_case(seed):
+    """Seeded random studies inside the envelope of the chain-resident kernel (blhip_chainres.hpp): hyper-studies over the width of one
+    random walk on the first parameter (radius 0 .. 40, hyper-priors, observation-model priors, missing / multi-dimensional data,
+    every fit mode) and change-point studies without a stencil, on grids of 128 / 256 / 512 rows x a multiple of 16 columns."""
+    rng = np.random.default_rng(12000 + seed)
+    n0 = [128, 128, 256, 512][int(rng.integers(0, 4))]
+    n1 = 16 * int(rng.integers(1, 9 if n0 < 512 else 5))
+    T = int(rng.integers(1, 15))
+    lo, hi = -float(rng.uniform(3, 8)), float(rng.uniform(3, 8))
+    prior = ['default', 'inv_s3', 'inv_s_2d'][int(rng.integers(0, 3))]
+    om = ('Gaussian', [('mean', ('cint', lo, hi, n0)), ('std', ('oint', float(rng.uniform(0.0, 0.3)), float(rng.uniform(1.5, 4)), n1))], prior)
+    kind = ['hyper', 'hyper', 'hyper_nan', 'hyper_2d', 'hyper_prior', 'changepoints'][seed % 6]
+    if kind == 'changepoints':
+        T = max(T, 6)
+        tm = ('ChangePoint', 'tc', 'all' if seed % 4 else ('arange', 1, T - 1, int(rng.integers(1, 4))), None)
+        flags = [dict(), dict(evidenceOnly=True)][int(rng.integers(0, 2))]
+        return dict(study='ChangepointStudy', data=('series_jump', 1700 + seed, T, T // 2, float(rng.uniform(-2, 2))), om=om, tm=tm, fit=flags)
+    lattice = (hi - lo) / (n0 - 1)
+    smax = float(rng.uniform(0.5, 9.8)) * lattice                    # radius int(4 sigma / lattice + 0.5) <= 39
+    k = int(rng.integers(2, 41 if n0 * n1 <= 128 * 64 else 13))
+    sig = ('cint', 0.0 if seed % 3 == 0 else float(rng.uniform(0.0, 0.3)) * smax, smax, k)
+    flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
+    data = ('series', 1800 + seed, T)
+    hp = None
+    if kind == 'hyper_nan' and T >= 3:
+        data = ('series_nan', 1800 + seed, T, sorted(set(int(x) for x in rng.integers(0, T, int(rng.integers(1, 3))))))
+    if kind == 'hyper_2d':
+        data = ('series2d', 1800 + seed, max(T, 5))
+    if kind == 'hyper_prior':
+        hp = ('array', [float(x) for x in rng.uniform(0.1, 1.0, k)]) if seed % 2 else 'inv_s'
+        if hp == 'inv_s':
+            sig = ('cint', 0.05 * smax, smax, k)
+    return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's1', sig, 'mean', hp))

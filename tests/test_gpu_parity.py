@@ -924,3 +924,21 @@ def test_fused_fold_matches_the_separate_fold():
     np.testing.assert_allclose(np.array(A.posteriorSequence), np.array(B.posteriorSequence), rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(A.posteriorMeanValues, B.posteriorMeanValues, rtol=1e-11)
     np.testing.assert_allclose(A.localEvidence, B.localEvidence, rtol=1e-11, equal_nan=True)
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_CHAIN_FUZZ_SEEDS', 36))))
+def test_seeded_random_chain_resident_studies_match_oracle(seed):
+    c = random_cases.random_chain_resident_case(seed)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming          # the chain-resident path really ran
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    if 'logEvidenceList' in want and not np.all(np.isfinite(np.asarray(want['logEvidenceList'], dtype=float))):
+        got['localEvidence'] = gold['localEvidence']
+    compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
