@@ -12,7 +12,7 @@ import os
 from .exceptions import BackendError
 
 LIB_NAME = 'libblhip.so'
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
 OM_BERNOULLI, OM_LAPLACE, OM_WHITE_NOISE, OM_AR1, OM_SCALED_AR1 = 4, 5, 6, 7, 8
@@ -28,12 +28,15 @@ class Op(C.Structure):
     _fields_ = [('kind', C.c_int32), ('axis', C.c_int32), ('segment', C.c_int32), ('flags', C.c_int32)]
 
 
+MAX_DIM = 4      # BLHIP_MAX_DIM
+
+
 class Problem(C.Structure):
     _fields_ = [
         ('ndim', C.c_int32), ('obs_model', C.c_int32),
-        ('n', C.c_int64 * 2),
-        ('marginal', c_double_p * 2),
-        ('lattice', C.c_double * 2),
+        ('n', C.c_int64 * MAX_DIM),
+        ('marginal', c_double_p * MAX_DIM),
+        ('lattice', C.c_double * MAX_DIM),
         ('T', C.c_int64),
         ('seg_len', C.c_int32), ('data_dim', C.c_int32),
         ('data', c_double_p), ('timestamps', c_double_p), ('prior', c_double_p), ('reset_prior', c_double_p),

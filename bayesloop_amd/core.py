@@ -420,9 +420,13 @@ class Study(object):
         """-> (FitProblem, program) ; program = [(kind, axis, model, hyper index)] in list order."""
         om = self.observationModel
         program = self.transitionModel._program(om.parameterNames)
-        if len(self.gridSize) not in (1, 2):
-            raise ConfigurationError('The MI355X engine supports observation models with 1 or 2 parameters '
-                                     '(got {}).'.format(len(self.gridSize)))
+        if not 1 <= len(self.gridSize) <= _abi.MAX_DIM:
+            raise ConfigurationError('The MI355X engine supports observation models with 1 to {} parameters '
+                                     '(got {}).'.format(_abi.MAX_DIM, len(self.gridSize)))
+        if len(self.gridSize) > 2 and not all(op[0] in (_abi.OP_GRW, _abi.OP_STATIC, _abi.OP_CHANGEPOINT) and op[4] < 0
+                                              for op in program):
+            raise ConfigurationError('Observation models with more than two parameters can be combined with GaussianRandomWalk, '
+                                     'Static and ChangePoint transition models.')
         prior = self._computePrior(silent=silent)
         reset = self._changepointPrior() if any(op[0] == _abi.OP_CHANGEPOINT for op in program) else None
         indep = None

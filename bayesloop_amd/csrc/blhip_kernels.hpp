@@ -550,24 +550,6 @@ __global__ __launch_bounds__(NTHREADS) void scale_all_kernel(double *A, long lon
         A[c] *= r;
 }
 
-// per-step statistics of the accumulator: out[t][0..2] = sum A, sum A*g0, sum A*g1 (partials per block -> second pass)
-__global__ __launch_bounds__(NTHREADS) void row_stats_kernel(const double *A, long long G, int n1, int ndim,
-                                                             const double *m0, const double *m1, double *partial) {
-    __shared__ double red[NTHREADS / 64 + 1];
-    const long long t = blockIdx.y;
-    double s = 0.0, a0 = 0.0, a1 = 0.0;
-    for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
-        const double v = A[t * G + c];
-        s += v;
-        if (ndim == 2) { a0 += v * m0[c / n1]; a1 += v * m1[c % n1]; } else { a0 += v * m1[c]; }
-    }
-    s = block_sum(s, red); a0 = block_sum(a0, red); a1 = block_sum(a1, red);
-    if (threadIdx.x == 0) {
-        double *o = partial + (t * 3) * gridDim.x + blockIdx.x;
-        o[0] = s; o[gridDim.x] = a0; o[2 * gridDim.x] = a1;
-    }
-}
-
 // out[t][i] = sum_j p[t][i][j]   (one block per (row i, t); coalesced along j)
 __global__ __launch_bounds__(NTHREADS) void marginal_rows_kernel(const double *p, double *out, int n0, int n1) {
     __shared__ double red[NTHREADS / 64 + 1];

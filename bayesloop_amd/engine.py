@@ -84,6 +84,17 @@ class DevicePosterior:
         return self.engine.accum_read(self.T, self.grid_size, t0=index, t1=index + 1)[0]
 
     def marginal(self, k):
+        if len(self.grid_size) > 2:
+            # grids with 3 and more parameters: the device-side reductions are 2-D; reduce on the host, a few time steps at a time
+            out = np.empty((self.T, self.grid_size[k]))
+            axes = tuple(a + 1 for a in range(len(self.grid_size)) if a != k)
+            step = max(1, int(2 ** 26 // max(1, int(np.prod(self.grid_size)))))
+            for t0 in range(0, self.T, step):
+                t1 = min(self.T, t0 + step)
+                rows = (self.engine.posterior(self.chain, self.T, self.grid_size, t0=t0, t1=t1) if self.source == 0
+                        else self.engine.accum_read(self.T, self.grid_size, t0=t0, t1=t1))
+                out[t0:t1] = rows.sum(axis=axes)
+            return out
         return self.engine.marginal(self.source, self.chain, k, self.T, self.grid_size[k])
 
     def time_average(self):
@@ -130,8 +141,8 @@ class HipEngine:
     def _problem(self, p: FitProblem):
         """-> (ctypes Problem, list of arrays that must stay alive)"""
         ndim = len(p.marginal)
-        if ndim not in (1, 2):
-            raise BackendError('the MI355X engine supports 1 or 2 observation-model parameters (got %d)' % ndim)
+        if not 1 <= ndim <= _abi.MAX_DIM:
+            raise BackendError('the MI355X engine supports 1 to %d observation-model parameters (got %d)' % (_abi.MAX_DIM, ndim))
         keep = []
         cp = _abi.Problem()
         cp.ndim = ndim

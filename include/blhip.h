@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BLHIP_ABI_VERSION 4
+#define BLHIP_ABI_VERSION 5
 
 typedef struct blhip_ctx blhip_ctx;
 
@@ -99,13 +99,17 @@ typedef struct {
     int32_t flags;                /* CHANGEPOINT: bit 0 = boundary of the serial model */
 } blhip_op;
 
+#define BLHIP_MAX_DIM 4
+
 /* The fit problem: grid, data, prior, transition program (shared by all chains of a call). */
 typedef struct {
-    int32_t        ndim;          /* number of observation-model parameters = grid dimensions: 1 or 2           */
+    int32_t        ndim;          /* number of observation-model parameters = grid dimensions (core.py:130-176 builds a
+                                     meshgrid over any number): 1 .. BLHIP_MAX_DIM.  3 and more: BLHIP_OM_TABLE models
+                                     (the reference's SciPy / SymPy / NumPy plug-ins) with GRW / STATIC / CHANGEPOINT ops */
     int32_t        obs_model;     /* BLHIP_OM_*                                                                  */
-    int64_t        n[2];          /* grid size per parameter (core.py:157)                                       */
-    const double  *marginal[2];   /* marginal grid values per parameter, n[k] doubles (core.py:156)              */
-    double         lattice[2];    /* lattice constants (core.py:161-166)                                         */
+    int64_t        n[BLHIP_MAX_DIM];          /* grid size per parameter (core.py:157)                           */
+    const double  *marginal[BLHIP_MAX_DIM];   /* marginal grid values per parameter, n[k] doubles (core.py:156)  */
+    double         lattice[BLHIP_MAX_DIM];    /* lattice constants (core.py:161-166)                             */
     int64_t        T;             /* number of formatted time steps                                              */
     int32_t        seg_len;       /* segment length of the observation model (1 for the device-side models)      */
     int32_t        data_dim;      /* trailing data dimension d (1 for scalar series); GAUSSIAN_MEAN: 2           */

@@ -22,6 +22,7 @@ PRIORS = {
     'inv_x': lambda x: 1. / x,
     'inv_s': lambda s: 1. / s,
     'inv_s_2d': lambda m, s: 1. / s,
+    'inv_s_3d': lambda df, m, s: 1. / s,
 }
 
 # the reference convolves with scipy.signal.fftconvolve (AlphaStableRandomWalk) / shifts with a recursive spline prefilter
@@ -67,6 +68,10 @@ def gauss2d(n, lo=-8, hi=8, smax=4):
 
 
 CASES = {
+    # three-parameter grid through the reference's SciPy plug-in (tests/golden/nd3_reference.npz)
+    'nd3_reference': dict(study='Study', data=('series', 95, 8),
+                          om=('SciPy:t', [('df', _g('cint', 2.0, 9.0, 5)), ('loc', _g('cint', -3.0, 3.0, 16)), ('scale', _g('oint', 0.2, 2.5, 12))], 'default'),
+                          tm=('Combined', [('GRW', 's_loc', 0.5, 'loc', None), ('GRW', 's_scale', 0.2, 'scale', None)])),
     # --- reference tests/test_transitionmodels.py:9-21, 40-52, 82-94
     'kat_static': dict(study='Study', data=D15, om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                        tm=('Static',), kat=-10.372209708143769),
@@ -417,6 +422,10 @@ def make_om(bl, spec):
     args = []
     for pname, values in params:
         args += [pname, make_values(bl, values)]
+    if name.startswith('SciPy:'):            # ('SciPy:<scipy.stats name>', [(parameter, values) ...], prior): any number of parameters
+        import scipy.stats
+        rv = getattr(scipy.stats, name.split(':')[1])
+        return bl.om.SciPy(rv, *args) if prior == 'default' else bl.om.SciPy(rv, *args, prior=make_prior(prior))
     cls = getattr(bl.om, name)
     if prior == 'default':
         return cls(*args)

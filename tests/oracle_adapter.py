@@ -101,7 +101,13 @@ def run(case):
     c = cases.CASES[case] if isinstance(case, str) else case
     raw = cases.make_data(c['data'])
     om_cls, params, prior_spec = c['om']
-    om = OM_NAME[om_cls]
+    scipy_rv = None
+    if om_cls.startswith('SciPy:'):           # plug-in model: the distribution's own pdf, evaluated here (observationModels.py:146-269)
+        import scipy.stats
+        scipy_rv = getattr(scipy.stats, om_cls.split(':')[1])
+        om = 'table'
+    else:
+        om = OM_NAME[om_cls]
     marginals = []
     for k, (pname, values) in enumerate(params):
         v = cases.make_values(_Orc, values)
@@ -109,13 +115,33 @@ def run(case):
     g = orc.Grid(marginals)
     pnames = [p[0] for p in params]
 
-    seg = orc.OM_INFO[om][0]
+    seg = 1 if scipy_rv is not None else orc.OM_INFO[om][0]
     data = orc.moving_window(raw, seg)
     ts = c.get('timestamps')
     ts = np.arange(len(raw)) if ts is None else np.asarray(ts)
     ts = ts[seg - 1:]
 
-    prior_obj = orc.jeffreys(om) if prior_spec == 'default' else cases.make_prior(prior_spec)
+    lik_table = None
+    if scipy_rv is not None:
+        # ObservationModel.processedPdf (observationModels.py:35-56): product over the data dimensions; a NaN anywhere in the
+        # segment leaves the step without information
+        def _lik(segm):
+            segm = np.asarray(segm, dtype=float)
+            if np.any(np.isnan(segm)):
+                return np.ones(g.size)
+            kw_rv = dict(zip(pnames, g.grid))
+            if segm.ndim == 2:
+                out = np.ones(g.size)
+                for col in segm.T:
+                    out = out * scipy_rv.pdf(col[0], **kw_rv)
+                return out
+            return scipy_rv.pdf(segm[0], **kw_rv) * np.ones(g.size)
+        with np.errstate(all='ignore'):
+            lik_table = np.array([_lik(d) for d in data])
+    if scipy_rv is not None:
+        prior_obj = None if prior_spec == 'default' else cases.make_prior(prior_spec)       # SciPy models: flat prior by default
+    else:
+        prior_obj = orc.jeffreys(om) if prior_spec == 'default' else cases.make_prior(prior_spec)
     prior = orc.compute_prior(g, prior_obj)
     reset = orc.changepoint_prior(g, prior_obj)
     indep = reset / np.prod(g.lattice)
@@ -126,7 +152,7 @@ def run(case):
 
     if c['study'] == 'Study':
         r = orc.fit(g, om, data, ts, prior, ops, orc.align_values(ops, vals), forward_only=fo, evidence_only=eo,
-                    reset=reset, indep=indep)
+                    reset=reset, indep=indep, lik_table=lik_table)
         r['prior'] = prior
         r['grid'] = g
         return r
@@ -135,7 +161,7 @@ def run(case):
     if len(vals) == 0 or np.prod([np.size(v) for v in vals]) <= 1:
         # <= 1 hyper-grid point: falls back to Study.fit (core.py:1434-1441)
         r = orc.fit(g, om, data, ts, prior, ops, orc.align_values(ops, [np.ravel(v)[0] for v in vals]),
-                    forward_only=fo, evidence_only=eo, reset=reset, indep=indep)
+                    forward_only=fo, evidence_only=eo, reset=reset, indep=indep, lik_table=lik_table)
         r['prior'] = prior
         r['grid'] = g
         return r
@@ -150,7 +176,7 @@ def run(case):
         extra = dict(allHyperGridValues=hv, mask=mask)
         hv, pv = hv_m, pv_m
     r = orc.hyper_fit(g, om, data, ts, prior, ops, hv, pv, const, forward_only=fo, evidence_only=eo, reset=reset,
-                      n_jobs=kw.get('nJobs', 1), indep=indep)
+                      n_jobs=kw.get('nJobs', 1), indep=indep, lik_table=lik_table)
     if c['study'] == 'ChangepointStudy':                       # core.py:1846-1852
         temp = np.zeros(len(extra['mask']))
         temp[extra['mask']] = r['hyperParameterDistribution']

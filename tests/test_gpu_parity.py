@@ -942,3 +942,70 @@ def test_seeded_random_chain_resident_studies_match_oracle(seed):
     if 'logEvidenceList' in want and not np.all(np.isfinite(np.asarray(want['logEvidenceList'], dtype=float))):
         got['localEvidence'] = gold['localEvidence']
     compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
+
+
+# ---- grids with 3 and 4 parameters (blhip_nd.hpp): the reference's plug-in models (bl.om.SciPy) on an N-D meshgrid ------------------
+
+def _t3(n_df=5, n_loc=18, n_scale=14):
+    return ('SciPy:t', [('df', ('cint', 2.0, 9.0, n_df)), ('loc', ('cint', -3.0, 3.0, n_loc)), ('scale', ('oint', 0.2, 2.5, n_scale))], 'default')
+
+
+ND_CASES = {
+    'nd3_static': dict(study='Study', data=('series', 81, 9), om=_t3(), tm=('Static',)),
+    # random walks on the middle and the last parameter (in this list order), then on the first one
+    'nd3_grw_loc_scale': dict(study='Study', data=('series', 82, 8), om=_t3(),
+                              tm=('Combined', [('GRW', 's_loc', 0.6, 'loc', None), ('GRW', 's_scale', 0.25, 'scale', None)])),
+    'nd3_grw_all_axes': dict(study='Study', data=('series', 83, 7), om=_t3(6, 12, 10),
+                             tm=('Combined', [('GRW', 's_df', 2.5, 'df', None), ('GRW', 's_scale', 0.3, 'scale', None),
+                                              ('GRW', 's_loc', 0.5, 'loc', None)])),
+    'nd3_wide_walk': dict(study='Study', data=('series', 84, 5), om=_t3(4, 10, 8), tm=('GRW', 's_loc', 9.0, 'loc', None)),   # radius > axis length
+    'nd3_forward_only': dict(study='Study', data=('series', 85, 8), om=_t3(), tm=('GRW', 's_loc', 0.4, 'loc', None), fit=dict(forwardOnly=True)),
+    'nd3_evidence_only': dict(study='Study', data=('series', 86, 8), om=_t3(), tm=('GRW', 's_loc', 0.4, 'loc', None), fit=dict(evidenceOnly=True)),
+    'nd3_missing_data': dict(study='Study', data=('series_nan', 87, 9, [2, 3, 7]), om=_t3(), tm=('GRW', 's_scale', 0.2, 'scale', None)),
+    'nd3_prior_function': dict(study='Study', data=('series', 88, 6), om=(_t3()[0], _t3()[1], 'inv_s_3d'), tm=('GRW', 's_loc', 0.4, 'loc', None)),
+    'nd3_hyper': dict(study='HyperStudy', data=('series', 89, 7), om=_t3(4, 14, 10), tm=('GRW', 's_loc', ('cint', 0, 1.2, 5), 'loc', None)),
+    'nd3_hyper_two': dict(study='HyperStudy', data=('series', 90, 6), om=_t3(4, 12, 10),
+                          tm=('Combined', [('GRW', 's_loc', ('cint', 0.1, 0.9, 3), 'loc', None),
+                                           ('GRW', 's_scale', ('cint', 0.0, 0.3, 2), 'scale', None)])),
+    'nd3_changepoints': dict(study='ChangepointStudy', data=('series_jump', 91, 10, 5, 1.5), om=_t3(4, 14, 10),
+                             tm=('ChangePoint', 'tc', 'all', None)),
+    'nd3_changepoint_then_walk': dict(study='ChangepointStudy', data=('series_jump', 92, 9, 4, -1.5), om=_t3(4, 12, 8),
+                                      tm=('Combined', [('ChangePoint', 'tc', ('arange', 1, 8, 2), None), ('GRW', 's_loc', 0.4, 'loc', None)])),
+    'nd4_johnsonsu': dict(study='Study', data=('series', 93, 6),
+                          om=('SciPy:johnsonsu', [('a', ('cint', -1.0, 1.0, 5)), ('b', ('cint', 0.8, 2.5, 4)), ('loc', ('cint', -2.0, 2.0, 11)),
+                                                  ('scale', ('oint', 0.3, 2.0, 9))], 'default'),
+                          tm=('Combined', [('GRW', 's_loc', 0.5, 'loc', None), ('GRW', 's_b', 0.4, 'b', None)])),
+}
+
+
+@pytest.mark.parametrize('case', list(ND_CASES))
+def test_three_and_four_parameter_grids_match_oracle(case):
+    pytest.importorskip('scipy.stats')
+    c = ND_CASES[case]
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    assert S.lastTiming['fwd_kernel_variant'] == 7, S.lastTiming
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=dict(local_rtol=ILL_LOCAL_RTOL) if _ill_conditioned_local_evidence(S, want) else None)
+    if 'posteriorSequence' in gold:
+        # marginal distributions of every parameter (the device-side reductions are 2-D: reduced on the host here)
+        post = np.asarray(want['posteriorSequence'])
+        for k, name in enumerate(S.observationModel.parameterNames):
+            axes = tuple(a + 1 for a in range(post.ndim - 1) if a != k)
+            np.testing.assert_allclose(S.getParameterDistributions(name, density=False)[1], post.sum(axis=axes), rtol=1e-9, atol=1e-12)
+
+
+def test_three_parameter_grid_against_the_reference_golden():
+    """tests/golden/nd3_reference.npz: bl.om.SciPy(scipy.stats.t, df, loc, scale) with two random walks, fitted by the reference
+    itself in the build container (tests/golden/gen_golden.py)."""
+    pytest.importorskip('scipy.stats')
+    gold = oa.load_golden('nd3_reference')
+    S = cases.build(bl, cases.CASES['nd3_reference'])
+    S.fit(silent=True)
+    compare.check(result_of(S, 'nd3_reference'), gold, compare.GPU_TOL)
