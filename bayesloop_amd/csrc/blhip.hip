@@ -1657,6 +1657,365 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
     ctx->timing.total_ms = tot;
 }
 
+// ---- what the resident paths of a batch need to know about it -------------------------------------------------------------------------
+struct BatchEnv {
+    blhip_ctx *ctx; const blhip_problem *p; hipStream_t st;
+    Geometry g; long long G; int64_t T, B, c0; int d, rec_len;
+    FitFlags ff;
+    const DeviceTables *DT; const DeviceMeta *M; const ChainProgram *prog; const TapTable *taps;
+    double step0;                 // lattice step of the row axis (likelihood recurrence)
+    double *d_post;               // the batch's sequence buffer (null: evidence-only)
+    const double *log_w;          // log weights of ALL chains of the call (accumulate)
+    bool chain_means;             // the caller asked for per-chain posterior means
+};
+
+// did a block of a resident launch time out waiting for a peer (not every block co-resident)?  -> the context stops using the paths
+bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
+    ctx->pinS.ensure(64);
+    unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
+    HIPCHECK(hipMemcpyAsync(h, d_abort, 4, hipMemcpyDeviceToHost, st));
+    sync_stream(ctx, st);
+    if (*h != 0u) { ctx->resident_ok = false; return true; }
+    return false;
+}
+
+// ---- the time-resident path of a single-chain batch: one launch per pass instead of one per step (blhip_resident.hpp) -----------------
+struct ResidentRun {
+    bool on = false;
+    ResidentPlan rp;
+    blr::ResParams RQ{};
+    int nblk = 0;                                  // partial-sum slots per (step, sum): one per tile
+    std::vector<double> rowsumF;                   // forward pass: the actual sums of the stored rows
+    std::vector<double> sfwd;                      // the forward pass's scales s_k (backward: predicted posterior sums)
+    double *d_sfwd = nullptr;
+    unsigned *d_abort = nullptr;
+    size_t flag_bytes = 0;
+
+    // eligibility (one chain, Gaussian model with the likelihood recurrence, the same radius <= 8 kernels at every step) + buffers
+    void setup(const BatchEnv &E, int64_t n_chains, bool fast, bool use_rec, size_t &psz) {
+        blhip_ctx *ctx = E.ctx;
+        const ChainProgram &prog = *E.prog;
+        const TapTable &taps = *E.taps;
+        const int64_t T = E.T;
+        const bool full = E.ff.full;
+        double w0[blr::R + 1] = {1.0}, w1[blr::R + 1] = {1.0};
+        if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blr::DMAX &&
+            prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
+            plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp)) {
+            on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
+            const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
+            for (int64_t t = 1; t < T && on; ++t)
+                on = prog.kindF[t] == SRC_PREV && prog.tapF0[t] == k0 && prog.tapF1[t] == k1;
+            for (int64_t t = 0; t < T - 1 && on && full; ++t)
+                on = prog.kindB[t] == SRC_PREV && prog.tapB0[t] == k0 && prog.tapB1[t] == k1;
+            if (on) {
+                for (int k = 1; k <= blr::R; ++k) w0[k] = w1[k] = 0.0;
+                if (k0 >= 0) for (int k = 0; k <= taps.lw[k0]; ++k) w0[k] = taps.w[taps.off[k0] + k];
+                if (k1 >= 0) for (int k = 0; k <= taps.lw[k1]; ++k) w1[k] = taps.w[taps.off[k1] + k];
+            }
+        }
+        if (!on) return;
+        const size_t nt = (size_t)rp.ntiles;
+        const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
+        const size_t b_w = carve_size(2 * (blr::R + 1) * 8) + carve_size((size_t)T * 8);
+        flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
+        ctx->resx.ensure(b_cols + b_rows + b_w + flag_bytes);
+        char *rc = ctx->resx.as<char>();
+        RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
+        RQ.rows = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TC);
+        double *d_w = carve<double>(rc, 2 * (blr::R + 1));
+        d_sfwd = carve<double>(rc, (size_t)T);
+        RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
+        RQ.flagR = carve<unsigned>(rc, nt);
+        RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
+        d_abort = carve<unsigned>(rc, 16);
+        RQ.abort_word = d_abort;
+        double hw[2 * (blr::R + 1)];
+        for (int k = 0; k <= blr::R; ++k) { hw[k] = w0[k]; hw[blr::R + 1 + k] = w1[k]; }
+        HIPCHECK(hipMemcpyAsync(d_w, hw, sizeof hw, hipMemcpyHostToDevice, E.st));
+        sync_stream(ctx, E.st);
+        RQ.w0 = d_w; RQ.w1 = d_w + blr::R + 1;
+        RQ.n0 = E.g.n0; RQ.n1 = E.g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = E.d; RQ.rec_len = E.rec_len;
+        RQ.lag = std::max(1, std::min(blr::MAXLAG, (int)ctx->option("resident_lag", 2.0)));
+        RQ.m0 = E.DT->m0; RQ.m1 = E.DT->m1; RQ.colA = E.DT->colA; RQ.colB = E.DT->colB; RQ.rec = E.DT->rec; RQ.step0 = E.step0;
+        RQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
+        // partial-sum slots per step: one per tile (the launch-per-step kernels are the fall-back and keep theirs)
+        nblk = rp.ntiles;
+        psz = std::max(psz, (size_t)T * NRED * nblk);
+    }
+
+    void launch(const BatchEnv &E, bool bwd, double *psum) {
+        blhip_ctx *ctx = E.ctx;
+        (void)ctx;                                     // (only the profiling build touches it here)
+        hipStream_t st = E.st;
+        const int64_t T = E.T;
+        blr::ResParams Q = RQ;
+        HIPCHECK(hipMemsetAsync(RQ.flagC, 0, flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
+        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * NRED * nblk * 8, st));
+        Q.psum = psum;
+        // rows of the kept sequence are normalised inside the kernel, `lag` steps behind (what the host then still scales: the
+        // last / first `lag` rows)
+        if (bwd) {
+            // the posteriors are stored normalised: their sums follow from the forward scales and the last forward row sum
+            // (blhip_resident.hpp: predicted_sum)
+            sfwd.assign(T, 1.0);
+            for (int64_t t = RQ.lag; t < T; ++t) sfwd[t] = 1.0 / rowsumF[t - RQ.lag];
+            HIPCHECK(hipMemcpyAsync(d_sfwd, sfwd.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
+            Q.sfwd = d_sfwd; Q.n_first = rowsumF[T - 1] * (1.0 / (double)E.G);
+            Q.src0 = E.DT->uniform; Q.post = E.d_post; Q.store = 1; Q.means = 1; Q.normalise = 0;
+        } else {
+            Q.src0 = E.DT->prior; Q.post = E.ff.evidence_only ? nullptr : E.d_post; Q.store = E.ff.evidence_only ? 0 : 1;
+            Q.means = E.ff.forward_only ? 1 : 0; Q.normalise = E.ff.forward_only ? 1 : 0;
+        }
+#ifdef BLR_PROF
+        ctx->small.ensure(2 * 16 * 16 * 8);
+        HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+        Q.prof = ctx->small.as<unsigned long long>();
+#endif
+        launch_resident(st, rp, Q, bwd);
+#ifdef BLR_PROF
+        {   // development build: where a step of one interior tile spends its time (shader-clock cycles between stamps)
+            unsigned long long hh[2 * 16 * 16];
+            HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
+            sync_stream(ctx, st);
+            static const char *names[12] = {"start", "h_pre+bar", "h_walk", "bar", "pubR+v_pre+gather", "arriveR", "bar", "v_walk", "sums", "pubC(+arriveC)", "-", "-"};
+            for (int wv = 0; wv < 2; ++wv) {
+                const unsigned long long *h = hh + wv * 256;
+                double acc[12] = {0}; int n = 0;
+                for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 9] || !h[q * 16]) continue; ++n; for (int i = 1; i < 10; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                std::fprintf(stderr, "[blr prof %s thread %d] %d steps, cycles per phase:", bwd ? "bwd" : "fwd", wv ? 128 : 0, n);
+                double tot = 0; for (int i = 1; i < 10; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                std::fprintf(stderr, " | total %.0f\n", tot);
+            }
+        }
+#endif
+    }
+
+    // after the forward pass: every tile made it, and the sums allow the lag to be undone
+    bool forward_ok(const BatchEnv &E, double *redF) {
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        return resident_unlag(redF, E.T, RQ.lag, rowsumF);
+    }
+
+    // after the backward pass: every tile made it, the lagged scale stayed in range, and the PREDICTED sums the kernel normalised
+    // the stored posteriors by reproduce the reduced ones
+    bool backward_ok(const BatchEnv &E, const double *redB) {
+        const int64_t T = E.T;
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        for (int64_t t = 0; t < T; ++t) {
+            const double Ct = redB[(size_t)t * NRED + 2], Nt = redB[(size_t)t * NRED];
+            if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) return false;
+        }
+        double npred = rowsumF[T - 1] * (1.0 / (double)E.G);
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t k = T - 1 - t;
+            if (k > 0) npred = (k >= RQ.lag ? 1.0 / redB[(size_t)(t + RQ.lag) * NRED + 2] : 1.0) * npred / sfwd[t + 1];
+            const double Nt = redB[(size_t)t * NRED];
+            if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
+        }
+        return true;
+    }
+};
+
+// ---- the chain-resident path of a batch: rounds of chains stay in LDS for a whole pass (blhip_chainres.hpp) ---------------------------
+struct ChainRun {
+    bool on = false;
+    ChainResPlan cp;
+    blc::ChainParams CQ{};
+    int *d_order = nullptr;
+    size_t gran_bytes = 0;
+    unsigned *d_abort = nullptr;
+    std::vector<std::vector<double>> rowsumC;      // forward pass: the actual sums of the stored rows, per chain
+    std::vector<std::vector<double>> sfwdC;        // forward pass: the scales it used, per chain
+    // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
+    bool post_private = false;
+    // fused fold: the backward kernel adds the weighted, normalised posteriors to per-slot partial accumulators instead of storing
+    // them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands left
+    // bandwidth unused: same bytes, one pass)
+    bool fused = false;
+    bool fold_done = false;                        // this batch's posteriors are in the accumulator already
+    double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr;
+    std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
+    double fold_ref = -INFINITY;
+
+    void setup(const BatchEnv &E, bool fast, bool use_rec, size_t &psz) {
+        blhip_ctx *ctx = E.ctx;
+        const ChainProgram &prog = *E.prog;
+        const int64_t T = E.T, B = E.B;
+        const long long G = E.G;
+        if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blc::DMAX &&
+            !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
+            on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
+        if (!on) return;
+        gran_bytes = carve_size((size_t)blc::NSLOT * cp.cpr * cp.strips * 2 * 8);
+        ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64));
+        char *rc = ctx->resx.as<char>();
+        d_order = carve<int>(rc, (size_t)B);
+        int *d_tapid = carve<int>(rc, (size_t)B);
+        CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * cp.cpr * cp.strips * 2);
+        d_abort = carve<unsigned>(rc, 16);
+        CQ.abort_word = d_abort;
+        HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
+        sync_stream(ctx, E.st);
+        CQ.n0 = E.g.n0; CQ.n1 = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = E.d; CQ.rec_len = E.rec_len;
+        CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
+        CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
+        CQ.post_stride = (long long)T * G;
+        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.step0 = E.step0;
+        CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
+        psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
+        post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
+        fused = post_private && !cp.has_reset && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        if (fused) {
+            ctx->accpart.ensure((size_t)cp.cpr * T * G * 8);
+            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8));
+            char *wc = ctx->accw.as<char>();
+            d_fold_sfwd = carve<double>(wc, (size_t)T * B);
+            d_fold_w = carve<double>(wc, (size_t)B);
+            d_fold_inf = carve<double>(wc, (size_t)B);
+        }
+    }
+
+    // one pass: the launches of the rounds follow each other on the stream
+    void pass(const BatchEnv &E, bool bwd, double *psum) {
+        blhip_ctx *ctx = E.ctx;
+        hipStream_t st = E.st;
+        const int64_t T = E.T, B = E.B;
+        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * cp.strips * 8, st));
+        HIPCHECK(hipMemsetAsync(d_abort, 0, 64, st));
+        for (size_t r = 0; r + 1 < cp.round_start.size(); ++r) {
+            blc::ChainParams Q = CQ;
+            HIPCHECK(hipMemsetAsync(CQ.gran, 0, gran_bytes, st));       // tags restart with every launch
+            Q.chain_ids = d_order + cp.round_start[r];
+            Q.nslots = cp.round_start[r + 1] - cp.round_start[r];
+            Q.psum = psum;
+            Q.src0 = bwd ? E.DT->uniform : E.DT->prior;
+            Q.kinds = cp.has_reset ? (bwd ? E.M->kindB : E.M->kindF) : nullptr;
+            Q.reset = E.DT->reset;
+            Q.post = E.d_post;
+            Q.means = bwd ? (E.chain_means ? 1 : 0) : (E.ff.forward_only ? 1 : 0);
+            Q.strip_major = post_private ? 1 : 0;            // (the stored sequence is private to the fit then)
+            const bool fold_now = bwd && fused;
+            if (fold_now) {
+                Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
+                Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * E.G;
+            }
+#ifdef BLC_PROF
+            ctx->small.ensure(2 * 16 * 16 * 8);
+            HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+            Q.prof = ctx->small.as<unsigned long long>();
+#endif
+            launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
+#ifdef BLC_PROF
+            {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
+                unsigned long long hh[2 * 16 * 16];
+                HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
+                sync_stream(ctx, st);
+                static const char *names[8] = {"start", "ring", "chain0", "scale+anchor", "epi0", "tiles1..", "sums", "barrier"};
+                for (int wvi = 0; wvi < 2; ++wvi) {
+                    const unsigned long long *h = hh + wvi * 256;
+                    double acc[8] = {0}; int n = 0;
+                    for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                    std::fprintf(stderr, "[blc prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", cp.round_nk[r], wvi ? 2 : 0, n);
+                    double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                    std::fprintf(stderr, " | total %.0f\n", tot);
+                }
+            }
+#endif
+        }
+    }
+
+    // after the forward pass: every strip made it, and the sums of every chain allow the scales to be undone
+    bool forward_ok(const BatchEnv &E, double *redF) {
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        rowsumC.assign(E.B, std::vector<double>());
+        sfwdC.assign(E.B, std::vector<double>());
+        for (int64_t b = 0; b < E.B; ++b)
+            if (!chain_unlag(redF, E.T, CQ.lag, rowsumC[b], E.B, b, &sfwdC[b], cp.has_reset ? E.prog->kindF.data() : nullptr)) return false;
+        return true;
+    }
+
+    // fused fold, before the backward pass: weights relative to the batch's own reference (core.py:1358-1366: chains without a finite
+    // evidence do not count), the forward scales and the sum of the last step's posterior of every chain -> device; partials zeroed
+    void prepare_fold(const BatchEnv &E, const BatchOutcome &O) {
+        blhip_ctx *ctx = E.ctx;
+        const int64_t T = E.T, B = E.B;
+        fold_lw.assign(B, -INFINITY);
+        fold_ref = -INFINITY;
+        for (int64_t b = 0; b < B; ++b) {
+            if (O.abort_step[b] >= 0 || !std::isfinite(O.logE[b]) || !std::isfinite(E.log_w[E.c0 + b])) continue;
+            fold_lw[b] = O.logE[b] + E.log_w[E.c0 + b];
+            fold_ref = std::max(fold_ref, fold_lw[b]);
+        }
+        ctx->pinA.ensure(((size_t)T * B + 2 * (size_t)B) * 8);
+        double *h = ctx->pinA.as<double>(), *hw = h + (size_t)T * B, *hi = hw + B;
+        for (int64_t b = 0; b < B; ++b) {
+            std::memcpy(h + (size_t)b * T, sfwdC[b].data(), (size_t)T * 8);
+            hw[b] = std::isfinite(fold_lw[b]) ? std::exp(fold_lw[b] - fold_ref) : 0.0;
+            hi[b] = 1.0 / (rowsumC[b][T - 1] * (1.0 / (double)E.G));
+        }
+        HIPCHECK(hipMemcpyAsync(d_fold_sfwd, h, (size_t)T * B * 8, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemcpyAsync(d_fold_w, hw, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemsetAsync(ctx->accpart.p, 0, (size_t)cp.cpr * T * E.G * 8, E.st));
+    }
+
+    // after the backward pass: every strip made it and the lagged scale of the backward state stayed in range
+    bool backward_ok(const BatchEnv &E, const double *redB) {
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        for (int64_t b = 0; b < E.B; ++b)
+            for (int64_t t = 0; t < E.T; ++t) {
+                const double *r = &redB[((size_t)t * E.B + b) * NRED];
+                if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) return false;
+            }
+        return true;
+    }
+
+    // fused fold, after the backward pass: the kernel normalised every posterior by its PREDICTED sum -- the prediction must
+    // reproduce the reduced sums (false: the caller repeats the batch with the launch-per-step kernels; the partials are dropped);
+    // then the partial accumulators go into the average posterior (running reference exponent as in prepare_fold)
+    bool fold(const BatchEnv &E, const double *redB) {
+        blhip_ctx *ctx = E.ctx;
+        hipStream_t st = E.st;
+        const int64_t T = E.T, B = E.B;
+        const long long G = E.G;
+        std::vector<double> csum, sb;
+        for (int64_t b = 0; b < B; ++b) {
+            // the backward scales, in processing order k = T - 1 - t (the kernel's rule, from the sums C of its new states)
+            csum.assign(T, 0.0); sb.assign(T, 1.0);
+            for (int64_t k = 0; k < T; ++k) csum[k] = redB[((size_t)(T - 1 - k) * B + b) * NRED + 2];
+            for (int64_t k = CQ.lag; k < T; ++k) sb[k] = (k - CQ.lag - 1 >= 0 ? csum[k - CQ.lag - 1] : 1.0) * sb[k - CQ.lag] / csum[k - CQ.lag];
+            double npred = rowsumC[b][T - 1] * (1.0 / (double)G);
+            for (int64_t k = 0; k < T; ++k) {
+                const int64_t t = T - 1 - k;
+                if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
+                const double Nt = redB[((size_t)t * B + b) * NRED];
+                if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
+            }
+        }
+        if (std::isfinite(fold_ref)) {
+            const double newref = std::max(ctx->acc_logref, fold_ref);
+            const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
+            HIPCHECK(hipEventRecord(ctx->ev[4], st));
+            hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((G / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
+                               ctx->accpart.as<double>(), (long long)T * G, std::min<int>(cp.cpr, (int)B), E.g.n0, E.g.n1, (int)T, r, rb,
+                               ctx->acc_first ? 1 : 0);
+            HIPCHECK(hipEventRecord(ctx->ev[5], st));
+            sync_stream(ctx, st);
+            float fms = 0;
+            HIPCHECK(hipEventElapsedTime(&fms, ctx->ev[4], ctx->ev[5]));
+            ctx->timing.accumulate_ms += fms;
+            ctx->timing.accumulate_launches += 1;
+            int nfold = 0;
+            for (int64_t b = 0; b < B; ++b) nfold += std::isfinite(fold_lw[b]) ? 1 : 0;
+            ctx->acc_logref = newref; ctx->acc_first = false; ctx->acc_folded += nfold;
+        }
+        fold_done = true;
+        return true;
+    }
+};
+
 void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const double *op_values,
             const double *log_w, uint32_t flags, blhip_result *res) {
     Trace tr(ctx->option("trace", 0.0) != 0.0);
@@ -1692,7 +2051,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     double *const d_m0 = DT.m0, *const d_m1 = DT.m1, *const d_colA = DT.colA, *const d_colB = DT.colB, *const d_rec = DT.rec;
     double *const d_prior = DT.prior, *const d_reset = DT.reset, *const d_uniform = DT.uniform, *const d_indep = DT.indep, *const d_lik = DT.lik;
     const int rec_len = DT.rec_len, d = DT.d;
-    char *cur = nullptr;
     tr.mark("tables + H2D");
 
     // ---- memory plan ------------------------------------------------------------------------------------------------------------
@@ -1760,7 +2118,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
 
         // --- device metadata ---
-        const size_t nT = (size_t)T * B;
         DeviceMeta M;
         upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M);
         unsigned char *const d_kindF = M.kindF, *const d_kindB = M.kindB, *const d_cmodeF = M.cmodeF, *const d_cmodeB = M.cmodeB;
@@ -1836,115 +2193,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             FP.step0 = step;
             FP.use_rec = (p->obs_model == BLHIP_OM_GAUSSIAN && dev <= 8.0 * 2.3e-16 * mx && ctx->option("recurrence", 1.0) != 0.0) ? 1 : 0;
         }
-        // ---- time-resident path: one launch per pass instead of one per step (blhip_resident.hpp) ------------------------------------
-        ResidentPlan rp;
-        bool resident = false;
-        double res_w0[blr::R + 1] = {1.0}, res_w1[blr::R + 1] = {1.0};
-        if (fast && n_chains == 1 && p->obs_model == BLHIP_OM_GAUSSIAN && FP.use_rec && !resume && !carry && d <= blr::DMAX &&
-            prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
-            plan_resident(g.n0, g.n1, std::min(ctx->num_cus, 256), rp)) {
-            resident = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
-            const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
-            for (int64_t t = 1; t < T && resident; ++t)
-                resident = prog.kindF[t] == SRC_PREV && prog.tapF0[t] == k0 && prog.tapF1[t] == k1;
-            for (int64_t t = 0; t < T - 1 && resident && full; ++t)
-                resident = prog.kindB[t] == SRC_PREV && prog.tapB0[t] == k0 && prog.tapB1[t] == k1;
-            if (resident) {
-                for (int k = 1; k <= blr::R; ++k) res_w0[k] = res_w1[k] = 0.0;
-                if (k0 >= 0) for (int k = 0; k <= taps.lw[k0]; ++k) res_w0[k] = taps.w[taps.off[k0] + k];
-                if (k1 >= 0) for (int k = 0; k <= taps.lw[k1]; ++k) res_w1[k] = taps.w[taps.off[k1] + k];
-            }
-        }
-        blr::ResParams RQ{};
-        double *d_res_sfwd = nullptr;
-        std::vector<double> res_sfwd;                          // the forward pass's scales s_k (backward: predicted posterior sums)
-        int res_nblk = 0;
-        unsigned *d_res_abort = nullptr;
-        size_t res_flag_bytes = 0;
-        if (resident) {
-            const size_t nt = (size_t)rp.ntiles;
-            const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
-            const size_t b_w = carve_size(2 * (blr::R + 1) * 8) + carve_size((size_t)T * 8);
-            res_flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
-            ctx->resx.ensure(b_cols + b_rows + b_w + res_flag_bytes);
-            char *rc = ctx->resx.as<char>();
-            RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
-            RQ.rows = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TC);
-            double *d_w = carve<double>(rc, 2 * (blr::R + 1));
-            d_res_sfwd = carve<double>(rc, (size_t)T);
-            RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
-            RQ.flagR = carve<unsigned>(rc, nt);
-            RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
-            d_res_abort = carve<unsigned>(rc, 16);
-            RQ.abort_word = d_res_abort;
-            double hw[2 * (blr::R + 1)];
-            for (int k = 0; k <= blr::R; ++k) { hw[k] = res_w0[k]; hw[blr::R + 1 + k] = res_w1[k]; }
-            HIPCHECK(hipMemcpyAsync(d_w, hw, sizeof hw, hipMemcpyHostToDevice, st));
-            sync_stream(ctx, st);
-            RQ.w0 = d_w; RQ.w1 = d_w + blr::R + 1;
-            RQ.n0 = g.n0; RQ.n1 = g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = d; RQ.rec_len = rec_len;
-            RQ.lag = std::max(1, std::min(blr::MAXLAG, (int)ctx->option("resident_lag", 2.0)));
-            RQ.m0 = d_m0; RQ.m1 = d_m1; RQ.colA = d_colA; RQ.colB = d_colB; RQ.rec = d_rec; RQ.step0 = FP.step0;
-            RQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
-            // partial-sum slots per step: one per tile (the launch-per-step kernels are the fall-back and keep theirs)
-            res_nblk = rp.ntiles;
-            psz = std::max(psz, (size_t)T * NRED * res_nblk);
-            ctx->psumF.ensure(psz * 8);
-            d_psF = ctx->psumF.as<double>();
-        }
-        std::vector<double> rowsumF;                          // resident forward pass: the actual sums of the stored rows
-
-        // ---- chain-resident path: rounds of chains stay in LDS for a whole pass (blhip_chainres.hpp) ------------------------------------
-        ChainResPlan cp;
-        bool chainres = false;
-        if (!resident && fast && p->obs_model == BLHIP_OM_GAUSSIAN && FP.use_rec && !resume && !carry && d <= blc::DMAX &&
-            !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
-            chainres = plan_chainres(g, prog, taps, B, T, full, std::min(ctx->num_cus, 256), cp);
-        blc::ChainParams CQ{};
-        int *d_cres_order = nullptr;
-        size_t cres_gran_bytes = 0;
-        std::vector<std::vector<double>> rowsumC;             // chain-resident forward pass: the actual sums of the stored rows, per chain
-        if (chainres) {
-            cres_gran_bytes = carve_size((size_t)blc::NSLOT * cp.cpr * cp.strips * 2 * 8);
-            ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + cres_gran_bytes + carve_size(64));
-            char *rc = ctx->resx.as<char>();
-            d_cres_order = carve<int>(rc, (size_t)B);
-            int *d_tapid = carve<int>(rc, (size_t)B);
-            CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * cp.cpr * cp.strips * 2);
-            d_res_abort = carve<unsigned>(rc, 16);
-            CQ.abort_word = d_res_abort;
-            HIPCHECK(hipMemcpyAsync(d_cres_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-            sync_stream(ctx, st);
-            CQ.n0 = g.n0; CQ.n1 = g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = d; CQ.rec_len = rec_len;
-            CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
-            CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = d_taps; CQ.tap_off = d_off; CQ.tap_lw = d_lw;
-            CQ.post_stride = (long long)T * G;
-            CQ.m0 = d_m0; CQ.m1 = d_m1; CQ.colA = d_colA; CQ.colB = d_colB; CQ.rec = d_rec; CQ.step0 = FP.step0;
-            CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
-            psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
-            ctx->psumF.ensure(psz * 8);
-            d_psF = ctx->psumF.as<double>();
-        }
-        // fused fold: the backward kernel adds the weighted, normalised posteriors to per-slot partial accumulators instead of
-        // storing them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands
-        // left bandwidth unused: same bytes, one pass)
-        // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
-        const bool post_private = chainres && accumulate && full && !keep && !carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
-        const bool fused_fold = post_private && !cp.has_reset && ctx->option("fuse_accumulate", 1.0) != 0.0;
-        double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr;
-        bool fold_done = false;               // this batch's posteriors are in the accumulator already
-        if (fused_fold) {
-            ctx->accpart.ensure((size_t)cp.cpr * T * G * 8);
-            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8));
-            char *wc = ctx->accw.as<char>();
-            d_fold_sfwd = carve<double>(wc, (size_t)T * B);
-            d_fold_w = carve<double>(wc, (size_t)B);
-            d_fold_inf = carve<double>(wc, (size_t)B);
-        }
-        std::vector<std::vector<double>> sfwdC;               // chain-resident forward pass: the scales it used, per chain
-        std::vector<double> fold_lw;                          // fused fold: log weight of every chain of the batch (-inf: none)
-        double fold_ref = -INFINITY;
+        // ---- the resident paths (single chain: blhip_resident.hpp; batches of chains: blhip_chainres.hpp); the launch-per-step kernels
+        //      below are their fall-back ---------------------------------------------------------------------------------------------------
+        BatchEnv E{};
+        E.ctx = ctx; E.p = p; E.st = st; E.g = g; E.G = G; E.T = T; E.B = B; E.c0 = c0; E.d = d; E.rec_len = rec_len; E.ff = ff;
+        E.DT = &DT; E.M = &M; E.prog = &prog; E.taps = &taps; E.step0 = FP.step0; E.d_post = d_post; E.log_w = log_w;
+        E.chain_means = res && res->posterior_mean;
+        ResidentRun RR;
+        RR.setup(E, n_chains, fast, FP.use_rec != 0, psz);
+        ChainRun CR;
+        if (!RR.on) CR.setup(E, fast, FP.use_rec != 0, psz);
+        if (RR.on || CR.on) { ctx->psumF.ensure(psz * 8); d_psF = ctx->psumF.as<double>(); }
+        const bool resident = RR.on, chainres = CR.on;
         bool resident_failed = false;
 
         // bucket streams: fork = every bucket stream waits for the main stream; join = the main stream waits for all of them
@@ -2036,9 +2296,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         }
         float ms = 0;
         BatchOutcome O;
-        std::vector<double> &logE = O.logE, &local = O.local, &means = O.means, &invN = O.invN;
-        std::vector<int64_t> &abort_step = O.abort_step;
-        std::vector<int32_t> &abort_phase = O.abort_phase;
+        std::vector<double> &invN = O.invN;
         auto passes = [&](const int64_t K) -> bool {
         bl1f::F1Params F1{};
         if (fused1d) {
@@ -2080,105 +2338,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         }
         const bool res_now = resident && !resident_failed;
         const bool cres_now = chainres && !resident_failed;
-        const int nblk_now = res_now ? res_nblk : (cres_now ? cp.strips : tile.nblk);      // partial-sum slots per (step, sum) of this pass
-        // one pass of the chain-resident kernel: the launches of the rounds follow each other on the stream
-        auto chainres_pass = [&](bool bwd, double *psum) {
-            HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * cp.strips * 8, st));
-            HIPCHECK(hipMemsetAsync(d_res_abort, 0, 64, st));
-            for (size_t r = 0; r + 1 < cp.round_start.size(); ++r) {
-                blc::ChainParams Q = CQ;
-                HIPCHECK(hipMemsetAsync(CQ.gran, 0, cres_gran_bytes, st));       // tags restart with every launch
-                Q.chain_ids = d_cres_order + cp.round_start[r];
-                Q.nslots = cp.round_start[r + 1] - cp.round_start[r];
-                Q.psum = psum;
-                Q.src0 = bwd ? d_uniform : d_prior;
-                Q.kinds = cp.has_reset ? (bwd ? d_kindB : d_kindF) : nullptr;
-                Q.reset = d_reset;
-                Q.post = d_post;
-                Q.means = bwd ? ((res && res->posterior_mean) ? 1 : 0) : (forward_only ? 1 : 0);
-                Q.strip_major = post_private ? 1 : 0;            // (the stored sequence is private to the fit then)
-                const bool fold_now = bwd && fused_fold;
-                if (fold_now) {
-                    Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
-                    Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * G;
-                }
-#ifdef BLC_PROF
-                ctx->small.ensure(2 * 16 * 16 * 8);
-                HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
-                Q.prof = ctx->small.as<unsigned long long>();
-#endif
-                launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, fold_now ? false : (bwd || !evidence_only));
-#ifdef BLC_PROF
-                {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
-                    unsigned long long hh[2 * 16 * 16];
-                    HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
-                    sync_stream(ctx, st);
-                    static const char *names[8] = {"start", "ring", "chain0", "scale+anchor", "epi0", "tiles1..", "sums", "barrier"};
-                    for (int wvi = 0; wvi < 2; ++wvi) {
-                        const unsigned long long *h = hh + wvi * 256;
-                        double acc[8] = {0}; int n = 0;
-                        for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
-                        std::fprintf(stderr, "[blc prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", cp.round_nk[r], wvi ? 2 : 0, n);
-                        double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
-                        std::fprintf(stderr, " | total %.0f\n", tot);
-                    }
-                }
-#endif
-            }
-        };
-        auto resident_launch = [&](bool bwd, double *psum) {
-            blr::ResParams Q = RQ;
-            HIPCHECK(hipMemsetAsync(RQ.flagC, 0, res_flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
-            HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * NRED * res_nblk * 8, st));
-            Q.psum = psum;
-            // rows of the kept sequence are normalised inside the kernel, `lag` steps behind (what the host then still scales: the
-            // last / first `lag` rows)
-            if (bwd) {
-                // the posteriors are stored normalised: their sums follow from the forward scales and the last forward row sum
-                // (blhip_resident.hpp: predicted_sum)
-                res_sfwd.assign(T, 1.0);
-                for (int64_t t = RQ.lag; t < T; ++t) res_sfwd[t] = 1.0 / rowsumF[t - RQ.lag];
-                HIPCHECK(hipMemcpyAsync(d_res_sfwd, res_sfwd.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
-                Q.sfwd = d_res_sfwd; Q.n_first = rowsumF[T - 1] * (1.0 / (double)G);
-                Q.src0 = d_uniform; Q.post = d_post; Q.store = 1; Q.means = 1; Q.normalise = 0;
-            }
-            else {
-                Q.src0 = d_prior; Q.post = evidence_only ? nullptr : d_post; Q.store = evidence_only ? 0 : 1;
-                Q.means = forward_only ? 1 : 0; Q.normalise = forward_only ? 1 : 0;
-            }
-#ifdef BLR_PROF
-            ctx->small.ensure(2 * 16 * 16 * 8);
-            HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
-            Q.prof = ctx->small.as<unsigned long long>();
-#endif
-            launch_resident(st, rp, Q, bwd);
-#ifdef BLR_PROF
-            {   // development build: where a step of one interior tile spends its time (shader-clock cycles between stamps)
-                unsigned long long hh[2 * 16 * 16];
-                HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
-                sync_stream(ctx, st);
-                static const char *names[12] = {"start", "h_pre+bar", "h_walk", "bar", "pubR+v_pre+gather", "arriveR", "bar", "v_walk", "sums", "pubC(+arriveC)", "-", "-"};
-                for (int wv = 0; wv < 2; ++wv) {
-                    const unsigned long long *h = hh + wv * 256;
-                    double acc[12] = {0}; int n = 0;
-                    for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 9] || !h[q * 16]) continue; ++n; for (int i = 1; i < 10; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
-                    std::fprintf(stderr, "[blr prof %s thread %d] %d steps, cycles per phase:", bwd ? "bwd" : "fwd", wv ? 128 : 0, n);
-                    double tot = 0; for (int i = 1; i < 10; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
-                    std::fprintf(stderr, " | total %.0f\n", tot);
-                }
-            }
-#endif
-        };
-        // did a tile time out waiting for a neighbour (not every block co-resident)?  -> this context stops using the path
-        auto resident_gave_up = [&]() {
-            unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
-            HIPCHECK(hipMemcpyAsync(h, d_res_abort, 4, hipMemcpyDeviceToHost, st));
-            sync_stream(ctx, st);
-            if (*h != 0u) { ctx->resident_ok = false; return true; }
-            return false;
-        };
-        if (res_now) { ctx->pinS.ensure(64); resident_launch(false, d_psF); }
-        if (cres_now) { ctx->pinS.ensure(64); chainres_pass(false, d_psF); }
+        const int nblk_now = res_now ? RR.nblk : (cres_now ? CR.cp.strips : tile.nblk);      // partial-sum slots per (step, sum) of this pass
+        if (res_now) RR.launch(E, false, d_psF);
+        if (cres_now) CR.pass(E, false, d_psF);
         fork_streams();
         for (int64_t t = 0; t < T && !persist && !fused1d && !res_now && !cres_now; ++t) {
             if (multistream && t > 0 && !same_membership(orderF, rangesF, t - 1, t)) { join_streams(); fork_streams(); }
@@ -2210,16 +2372,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (n_mfma[0] > 0 && n_mfma[0] >= n_fast[0]) ctx->timing.fwd_kernel_variant = 3;
         if (res_now) {
             ctx->timing.fwd_kernel_variant = 5;
-            if (resident_gave_up()) { resident_failed = true; return false; }
-            if (!resident_unlag(redF, T, RQ.lag, rowsumF)) { resident_failed = true; return false; }
+            if (!RR.forward_ok(E, redF)) { resident_failed = true; return false; }
         }
         if (cres_now) {
             ctx->timing.fwd_kernel_variant = 6;
-            if (resident_gave_up()) { resident_failed = true; return false; }
-            rowsumC.assign(B, std::vector<double>());
-            sfwdC.assign(B, std::vector<double>());
-            for (int64_t b = 0; b < B; ++b)
-                if (!chain_unlag(redF, T, CQ.lag, rowsumC[b], B, b, &sfwdC[b], cp.has_reset ? prog.kindF.data() : nullptr)) { resident_failed = true; return false; }
+            if (!CR.forward_ok(E, redF)) { resident_failed = true; return false; }
         }
 
         bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
@@ -2249,29 +2406,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     launch_fused1d(st, p->obs_model, Q, true, f1_lds(Q.K));
                 }
             }
-            if (res_now) resident_launch(true, d_psB);
-            if (cres_now && fused_fold) {
-                // weights relative to the batch's own reference (core.py:1358-1366: chains without a finite evidence do not count)
-                fold_lw.assign(B, -INFINITY);
-                fold_ref = -INFINITY;
-                for (int64_t b = 0; b < B; ++b) {
-                    if (O.abort_step[b] >= 0 || !std::isfinite(O.logE[b]) || !std::isfinite(log_w[c0 + b])) continue;
-                    fold_lw[b] = O.logE[b] + log_w[c0 + b];
-                    fold_ref = std::max(fold_ref, fold_lw[b]);
-                }
-                ctx->pinA.ensure(((size_t)T * B + 2 * (size_t)B) * 8);
-                double *h = ctx->pinA.as<double>(), *hw = h + (size_t)T * B, *hi = hw + B;
-                for (int64_t b = 0; b < B; ++b) {
-                    std::memcpy(h + (size_t)b * T, sfwdC[b].data(), (size_t)T * 8);
-                    hw[b] = std::isfinite(fold_lw[b]) ? std::exp(fold_lw[b] - fold_ref) : 0.0;
-                    hi[b] = 1.0 / (rowsumC[b][T - 1] * (1.0 / (double)G));
-                }
-                HIPCHECK(hipMemcpyAsync(d_fold_sfwd, h, (size_t)T * B * 8, hipMemcpyHostToDevice, st));
-                HIPCHECK(hipMemcpyAsync(d_fold_w, hw, (size_t)B * 8, hipMemcpyHostToDevice, st));
-                HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, st));
-                HIPCHECK(hipMemsetAsync(ctx->accpart.p, 0, (size_t)cp.cpr * T * G * 8, st));
-            }
-            if (cres_now) chainres_pass(true, d_psB);
+            if (res_now) RR.launch(E, true, d_psB);
+            if (cres_now && CR.fused) CR.prepare_fold(E, O);
+            if (cres_now) CR.pass(E, true, d_psB);
             fork_streams();
             for (int64_t t = T - 1; t >= 0 && !persist && !fused1d && !res_now && !cres_now; --t) {
                 if (multistream && t < T - 1 && !same_membership(orderB, rangesB, t + 1, t)) { join_streams(); fork_streams(); }
@@ -2295,72 +2432,20 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->timing.backward_launches += T;
             if (res_now) {
                 ctx->timing.bwd_kernel_variant = 5;
-                if (resident_gave_up()) { resident_failed = true; return false; }
-                for (int64_t t = 0; t < T; ++t) {             // (the lagged scale of the backward state: same range guard)
-                    const double Ct = redB[(size_t)t * NRED + 2], Nt = redB[(size_t)t * NRED];
-                    if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) { resident_failed = true; return false; }
-                }
-                // the kernel stored every posterior divided by its PREDICTED sum: the prediction must reproduce the reduced sums
-                double npred = rowsumF[T - 1] * (1.0 / (double)G);
-                for (int64_t t = T - 1; t >= 0; --t) {
-                    const int64_t k = T - 1 - t;
-                    if (k > 0) npred = (k >= RQ.lag ? 1.0 / redB[(size_t)(t + RQ.lag) * NRED + 2] : 1.0) * npred / res_sfwd[t + 1];
-                    const double Nt = redB[(size_t)t * NRED];
-                    if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) { resident_failed = true; return false; }
-                }
+                if (!RR.backward_ok(E, redB)) { resident_failed = true; return false; }
             }
             if (cres_now) {
                 ctx->timing.bwd_kernel_variant = 6;
-                if (resident_gave_up()) { resident_failed = true; return false; }
-                for (int64_t b = 0; b < B; ++b)
-                    for (int64_t t = 0; t < T; ++t) {         // (the lagged scale of the backward state: same range guard)
-                        const double *r = &redB[((size_t)t * B + b) * NRED];
-                        if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) { resident_failed = true; return false; }
-                    }
-            }
-            if (cres_now && fused_fold) {
-                // the kernel normalised every posterior by its PREDICTED sum: the prediction must reproduce the reduced sums
-                std::vector<double> csum, sb;
-                for (int64_t b = 0; b < B; ++b) {
-                    // the backward scales, in processing order k = T - 1 - t (the kernel's rule, from the sums C of its new states)
-                    csum.assign(T, 0.0); sb.assign(T, 1.0);
-                    for (int64_t k = 0; k < T; ++k) csum[k] = redB[((size_t)(T - 1 - k) * B + b) * NRED + 2];
-                    for (int64_t k = CQ.lag; k < T; ++k) sb[k] = (k - CQ.lag - 1 >= 0 ? csum[k - CQ.lag - 1] : 1.0) * sb[k - CQ.lag] / csum[k - CQ.lag];
-                    double npred = rowsumC[b][T - 1] * (1.0 / (double)G);
-                    for (int64_t k = 0; k < T; ++k) {
-                        const int64_t t = T - 1 - k;
-                        if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
-                        const double Nt = redB[((size_t)t * B + b) * NRED];
-                        if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) { resident_failed = true; return false; }
-                    }
-                }
-                // partial accumulators -> average posterior (running reference exponent as in prepare_fold)
-                if (std::isfinite(fold_ref)) {
-                    const double newref = std::max(ctx->acc_logref, fold_ref);
-                    const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
-                    const long long TG = (long long)T * G;
-                    HIPCHECK(hipEventRecord(ev[4], st));
-                    hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((G / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
-                                       ctx->accpart.as<double>(), TG, std::min<int>(cp.cpr, (int)B), g.n0, g.n1, (int)T, r, rb, ctx->acc_first ? 1 : 0);
-                    HIPCHECK(hipEventRecord(ev[5], st));
-                    sync_stream(ctx, st);
-                    float fms = 0;
-                    HIPCHECK(hipEventElapsedTime(&fms, ev[4], ev[5]));
-                    ctx->timing.accumulate_ms += fms;
-                    ctx->timing.accumulate_launches += 1;
-                    int nfold = 0;
-                    for (int64_t b = 0; b < B; ++b) nfold += std::isfinite(fold_lw[b]) ? 1 : 0;
-                    ctx->acc_logref = newref; ctx->acc_first = false; ctx->acc_folded += nfold;
-                }
-                fold_done = true;
+                if (!CR.backward_ok(E, redB)) { resident_failed = true; return false; }
+                if (CR.fused && !CR.fold(E, redB)) { resident_failed = true; return false; }
             }
             raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O) && raw_ok;
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
                 for (int64_t t = 0; t < T; ++t) {
-                    const double n0 = res_now ? rowsumF[t] : (cres_now ? rowsumC[b][t] : redF[((size_t)t * B + b) * NRED]);
+                    const double n0 = res_now ? RR.rowsumF[t] : (cres_now ? CR.rowsumC[b][t] : redF[((size_t)t * B + b) * NRED]);
                     invN[(size_t)b * T + t] = (n0 != 0.0 && std::isfinite(n0)) ? 1.0 / n0 : 0.0;     // (a signed kernel can leave a negative raw sum)
-                    if (res_now && t <= T - 1 - RQ.lag) invN[(size_t)b * T + t] = 1.0;                // (already normalised by the resident kernel)
+                    if (res_now && t <= T - 1 - RR.RQ.lag) invN[(size_t)b * T + t] = 1.0;                // (already normalised by the resident kernel)
                 }
         }
 
@@ -2385,7 +2470,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             else { fin = fused1d ? d_pp[((T - 1) / usedK) & 1] : d_pp[(T - 1) & 1]; fstr = G; }
             store_carry(ctx, p, B, G, redF, fin, fstr, d_w, prog.has_clamp);
         }
-        if (accumulate && fold_done) {
+        if (accumulate && CR.fold_done) {
             // (the backward kernel folded this batch)
         } else if (accumulate && overlap_acc) {
             // private copies of the weights, host (page-locked: the copies must not block the host) and device: the batch metadata
@@ -2397,18 +2482,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             fold_job.d_w = carve<double>(wc, (size_t)Bmax); fold_job.d_invN = carve<double>(wc, (size_t)T * Bmax);
             fold_job.h_w = carve<double>(hc, (size_t)Bmax); fold_job.h_invN = carve<double>(hc, (size_t)T * Bmax);
             fold_job.d_post = d_post; fold_job.parity = (int)(bi & 1);
-            fold_job.sm_n0 = (post_private && !resident_failed) ? g.n0 : 0;
+            fold_job.sm_n0 = (CR.post_private && !resident_failed) ? g.n0 : 0;
             fold_job.pending = prepare_fold(ctx, T, B, O, log_w + c0, fold_job);
             // launched behind the NEXT batch's forward pass (see passes); the last batch has nothing to hide behind
             if (bi == nbatch - 1) launch_pending_fold();
         } else if (accumulate) {
-            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (post_private && !resident_failed) ? g.n0 : 0);
+            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (CR.post_private && !resident_failed) ? g.n0 : 0);
         }
         if (keep) {
             int64_t row0 = 0, row1 = T;              // rows the resident kernel normalised in place (invN = 1 there) need no pass
             if (resident && !resident_failed) {
                 if (full) row1 = 0;                  // (every posterior row was stored normalised)
-                else row0 = std::max<int64_t>(0, T - RQ.lag);
+                else row0 = std::max<int64_t>(0, T - RR.RQ.lag);
             }
             keep_posterior(ctx, g, T, B, O, row0, row1);
         }
