@@ -1675,7 +1675,8 @@ bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
     unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
     HIPCHECK(hipMemcpyAsync(h, d_abort, 4, hipMemcpyDeviceToHost, st));
     sync_stream(ctx, st);
-    if (*h != 0u) { ctx->resident_ok = false; return true; }
+    // (option resident_force_abort: the tests of the fall-back pretend that a block gave up)
+    if (*h != 0u || ctx->option("resident_force_abort", 0.0) != 0.0) { ctx->resident_ok = false; return true; }
     return false;
 }
 
@@ -2596,6 +2597,9 @@ int blhip_device_name(blhip_ctx *ctx, char *buf, int buflen) {
 
 int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
     if (!ctx || !key) return -1;
+    // "resident_ok": the context's memory of a resident launch that gave up (its blocks were not all co-resident) -- settable so that
+    // a caller (the tests of the fall-back) can re-arm the resident paths
+    if (std::strcmp(key, "resident_ok") == 0) { ctx->resident_ok = value != 0.0; return 0; }
     ctx->opt[key] = value;
     return 0;
 }

@@ -1009,3 +1009,32 @@ def test_three_parameter_grid_against_the_reference_golden():
     S = cases.build(bl, cases.CASES['nd3_reference'])
     S.fit(silent=True)
     compare.check(result_of(S, 'nd3_reference'), gold, compare.GPU_TOL)
+
+
+def test_resident_paths_fall_back_when_a_block_gives_up():
+    """A resident launch whose blocks cannot wait for each other (not all co-resident) gives up through the abort word; the batch is
+    repeated with the launch-per-step kernels and the context stops using the resident paths.  (The give-up itself needs blocks that
+    are not co-resident; the test makes the host read the abort word as set.)"""
+    eng = bl.get_engine()
+    c = _hyper(128, 64, 73, 9, ('cint', 0, 0.8, 11))
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    eng.set_option('resident_force_abort', 1)
+    try:
+        S = cases.build(bl, c); S.fit(silent=True)
+        assert S.lastTiming['fwd_kernel_variant'] != 6 and S.lastTiming['bwd_kernel_variant'] != 6, S.lastTiming
+        got = result_of(S, c)
+        gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'], posteriorSequence=np.asarray(want['posteriorSequence']),
+                    posteriorMeanValues=np.asarray(want['posteriorMeanValues']), logEvidenceList=np.asarray(want['logEvidenceList']))
+        compare.check(got, gold, compare.GPU_TOL)
+        eng.set_option('resident_force_abort', 0)
+        S2 = cases.build(bl, c); S2.fit(silent=True)           # the context remembers
+        assert S2.lastTiming['fwd_kernel_variant'] != 6
+        R = cases.build(bl, RESIDENT['res_64x96_full']); R.fit(silent=True)      # ... for the single-chain path too
+        assert R.lastTiming['fwd_kernel_variant'] != 5
+    finally:
+        eng.set_option('resident_force_abort', 0)
+        eng.set_option('resident_ok', 1)
+    S3 = cases.build(bl, c); S3.fit(silent=True)
+    assert S3.lastTiming['fwd_kernel_variant'] == 6
+    assert abs(S3.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
