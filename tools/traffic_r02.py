@@ -89,6 +89,9 @@ if __name__ == '__main__':
             r = summarise(path, steps=3 * 200, cells=2048 * 2048)
             if 'fwd' in r:
                 out['fwd2048'] = dict(r['fwd'], hbm_bytes_per_launch=r['fwd']['hbm_bytes_per_step_launch'])
+        elif w == 'c5':       # 3 fits x 3 batches x 1000 steps; a logical step launch = all launches of one time step of a batch (88 / 88 / 74 chains)
+            r = summarise(path, steps=3 * 3 * 1000, cells=250.0 / 3.0 * 512 * 512)
+            out['c5'] = r
         elif w == 'c3':
             r = summarise(path, steps=3 * 2000, cells=1024 * 1024)
             out['c3'] = r
