@@ -102,6 +102,7 @@ PROTOTYPES = {
     'blhip_carry_mix': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, C.c_int]),
     'blhip_carry_read': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p]),
     'blhip_carry_write': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]),
+    'blhip_host_unlag': (C.c_int, [C.c_int, c_double_p, C.c_int64, C.c_int, C.POINTER(C.c_ubyte), c_double_p]),
     'blhip_carry_release': (C.c_int, [C.c_void_p, C.c_int]),
 }
 

@@ -2595,6 +2595,22 @@ int blhip_device_name(blhip_ctx *ctx, char *buf, int buflen) {
     return 0;
 }
 
+int blhip_host_unlag(int scheme, double *sums, int64_t T, int lag, const unsigned char *kinds, double *scales_out) {
+    if (!sums || T < 1 || lag < 1) return -1;
+    try {
+        std::vector<double> red((size_t)T * NRED, 0.0), rowsum, scales;
+        for (int64_t t = 0; t < T; ++t) red[(size_t)t * NRED] = sums[t];
+        const bool ok = scheme == 0 ? resident_unlag(red.data(), T, lag, rowsum) : chain_unlag(red.data(), T, lag, rowsum, 1, 0, &scales, kinds);
+        if (!ok) return 1;
+        for (int64_t t = 0; t < T; ++t) sums[t] = red[(size_t)t * NRED];
+        if (scales_out)
+            for (int64_t t = 0; t < T; ++t) scales_out[t] = scheme == 0 ? (t >= lag ? 1.0 / rowsum[t - lag] : 1.0) : scales[t];
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
 int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
     if (!ctx || !key) return -1;
     // "resident_ok": the context's memory of a resident launch that gave up (its blocks were not all co-resident) -- settable so that

@@ -222,6 +222,16 @@ int blhip_accum_end(blhip_ctx *ctx);
  * 1416-1419), so every rank can form them from ONE gather.  All zeros if nothing was folded. */
 int blhip_accum_row_stats(blhip_ctx *ctx, const blhip_problem *problem, double *host_out);
 
+/* ---- host-side algebra of the resident kernels, callable without a GPU (unit tests) ------------------------------------------------
+ * The time-resident kernels divide step k not by the sum of step k - 1 but by something older (their sums cross the chip through
+ * HBM); the host reconstructs the reference's normalisers (core.py:385) from the sums S_k they report:
+ *   scheme 0 (blhip_resident.hpp):  s_k = 1 / S_(k-lag)                              norm_k = S_k / (S_(k-1) s_k)
+ *   scheme 1 (blhip_chainres.hpp):  s_k = S_(k-lag-1) s_(k-lag) / S_(k-lag)          (s_k = 1 while k < lag, S_(-1) = 1)
+ * sums: (T) in, the normalisers out (in place).  kinds (scheme 1, may be NULL): (T) source kinds, a step whose kind is not 0
+ * (blk::SRC_PREV) restarted from a distribution of known mass: norm_k = S_k / s_k.  scales_out (may be NULL): (T) the scales s_k.
+ * Returns 0, or 1 if a sum left (1e-150, 1e150) -- the fit then repeats the batch with the launch-per-step kernels. */
+int blhip_host_unlag(int scheme, double *sums, int64_t T, int lag, const unsigned char *kinds, double *scales_out);
+
 /* ---- multi-GPU exchange of a sharded hyper-study (HyperStudy.fit(nJobs > 1), core.py:1307-1340, 1443-1495) -------------
  * One process per GPU, one context per process; each rank fits its share of the hyper-grid points with blhip_fit and
  * no communication, then the ranks exchange results through RCCL (xGMI inside a node), which this library binds

@@ -318,3 +318,68 @@ def test_online_study_survives_pickling():
     with contextlib.redirect_stdout(io.StringIO()):
         A.step(2.0)               # releasing the copy's slots must not touch the original's
     assert np.isfinite(A.logEvidence)
+
+
+# ---- the scale algebra of the resident kernels (include/blhip.h: blhip_host_unlag) -- pure host code of libblhip.so ---------------------
+
+def _simulate_sums(norms, lag, scheme, kinds=None):
+    """What a resident kernel reports: S_k = (S_(k-1) or 1 at a restart) * s_k * n_k with the kernel's rule for s_k."""
+    T = len(norms)
+    S, s = np.zeros(T), np.ones(T)
+    for k in range(T):
+        if k >= lag:
+            s[k] = 1.0 / S[k - lag] if scheme == 0 else (S[k - lag - 1] if k - lag - 1 >= 0 else 1.0) * s[k - lag] / S[k - lag]
+        fresh = k == 0 or (kinds is not None and kinds[k] != 0)
+        S[k] = (1.0 if fresh else S[k - 1]) * s[k] * norms[k]
+    return S, s
+
+
+@pytest.mark.parametrize('scheme,lag', [(0, 1), (0, 2), (1, 2), (1, 3), (1, 4)])
+def test_host_recovers_the_normalisers_from_lagged_sums(scheme, lag):
+    import ctypes
+    from bayesloop_amd import _abi
+    lib = _abi.load()
+    rng = np.random.default_rng(100 * scheme + lag)
+    T = 400
+    norms = np.exp(rng.normal(-3.0, 1.5, T))                    # what core.py:385 would see
+    S, s = _simulate_sums(norms, lag, scheme)
+    sums, scales = S.copy(), np.zeros(T)
+    assert lib.blhip_host_unlag(scheme, _abi.dptr(sums), T, lag, None, _abi.dptr(scales)) == 0
+    np.testing.assert_allclose(sums, norms, rtol=1e-12)
+    np.testing.assert_allclose(scales, s, rtol=1e-12)
+
+
+def test_scale_from_the_lagged_normaliser_stays_bounded_where_the_lagged_sum_diverges():
+    """Dividing by the SUM of step k - lag is a feedback loop x_k = x_(k-1) - x_(k-lag) + nu in the log domain: bounded (period 6) for
+    lag 2, exponentially unstable for lag 3 (|roots of r^3 - r^2 + 1| = 1.15).  Dividing by the NORMALISER of step k - lag leaves
+    the product of the last `lag` normalisers in the state, whatever the lag (blhip_chainres.hpp)."""
+    rng = np.random.default_rng(7)
+    T = 400
+    norms = np.exp(rng.normal(-2.0, 0.3, T))
+    with np.errstate(over='ignore', invalid='ignore', divide='ignore'):
+        S_sum3, _ = _simulate_sums(norms, 3, 0)
+    assert not np.all(np.isfinite(S_sum3)) or np.nanmax(np.abs(np.log(S_sum3[np.isfinite(S_sum3) & (S_sum3 > 0)]))) > 300.0
+    S_sum2, _ = _simulate_sums(norms, 2, 0)
+    assert np.max(np.abs(np.log(S_sum2))) < 40.0
+    for lag in (2, 3, 4):
+        S, _ = _simulate_sums(norms, lag, 1)
+        want = np.array([np.prod(norms[max(0, k - lag + 1):k + 1]) for k in range(T)])
+        np.testing.assert_allclose(S, want, rtol=1e-10)
+
+
+def test_host_unlag_with_restarts_and_out_of_range_sums():
+    import ctypes
+    from bayesloop_amd import _abi
+    lib = _abi.load()
+    rng = np.random.default_rng(11)
+    T, lag = 60, 4
+    norms = np.exp(rng.normal(-3.0, 1.0, T))
+    kinds = np.zeros(T, dtype=np.uint8)
+    kinds[[17, 18, 40]] = 2                                     # blk::SRC_RESET: change points (transitionModels.py:300-312)
+    S, s = _simulate_sums(norms, lag, 1, kinds)
+    sums = S.copy()
+    assert lib.blhip_host_unlag(1, _abi.dptr(sums), T, lag, kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), None) == 0
+    np.testing.assert_allclose(sums, norms, rtol=1e-12)
+    bad = S.copy()
+    bad[30] = 1e-200                                            # a run of extreme outliers: the fit falls back to the launch-per-step kernels
+    assert lib.blhip_host_unlag(1, _abi.dptr(bad), T, lag, None, None) == 1
