@@ -1431,591 +1431,8 @@ bool backward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, cons
     return raw_ok;
 }
 
-// ---- grids with 3 and 4 parameters: the plain formulation (blhip_nd.hpp) ---------------------------------------------------------------
-void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const double *op_values, const double *log_w, uint32_t flags,
-               blhip_result *res) {
-    HIPCHECK(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    const FitFlags ff = decode_flags(ctx, p, flags, log_w);
-    if (ff.resume || ff.carry) fail("streaming fits (BLHIP_RESUME / BLHIP_CARRY) are not available on grids with %d parameters", p->ndim);
-    const int64_t T = p->T;
-    bln::NdGrid ng{};
-    ng.ndim = p->ndim;
-    long long G = 1;
-    for (int k = p->ndim - 1; k >= 0; --k) { ng.n[k] = (int)p->n[k]; ng.stride[k] = G; G *= p->n[k]; }
-    ng.G = G;
-    if (ff.accumulate && (ctx->acc_T != T || ctx->acc_G != G)) fail("accumulator shape mismatch");
-    double dV = 1.0;
-    for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
-    ctx->post_valid = false;
-    ctx->timing = blhip_timing{};
-    hipEvent_t *ev = ctx->ev;
-    HIPCHECK(hipEventRecord(ev[6], st));
-
-    // ---- shared tables: marginals, prior(s), uniform, the likelihood table -------------------------------------------------------
-    size_t msum = 0;
-    for (int k = 0; k < p->ndim; ++k) msum += carve_size(8 * (size_t)p->n[k]);
-    ctx->tables.ensure(msum + 3 * carve_size(8 * (size_t)G));
-    char *cur = ctx->tables.as<char>();
-    for (int k = 0; k < p->ndim; ++k) {
-        double *dm = carve<double>(cur, (size_t)p->n[k]);
-        HIPCHECK(hipMemcpyAsync(dm, p->marginal[k], 8 * (size_t)p->n[k], hipMemcpyHostToDevice, st));
-        ng.m[k] = dm;
-    }
-    double *d_prior = carve<double>(cur, (size_t)G), *d_reset = carve<double>(cur, (size_t)G), *d_uniform = carve<double>(cur, (size_t)G);
-    HIPCHECK(hipMemcpyAsync(d_prior, p->prior, 8 * (size_t)G, hipMemcpyHostToDevice, st));
-    if (p->reset_prior) HIPCHECK(hipMemcpyAsync(d_reset, p->reset_prior, 8 * (size_t)G, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);           // beta_T = 1/G, core.py:424-425
-    ctx->likbuf.ensure(8 * (size_t)T * G);
-    double *d_lik = ctx->likbuf.as<double>();
-    HIPCHECK(hipMemcpyAsync(d_lik, p->lik, 8 * (size_t)T * G, hipMemcpyHostToDevice, st));
-    sync_stream(ctx, st);
-
-    // ---- batches ---------------------------------------------------------------------------------------------------------------------
-    size_t free_b = 0, total_b = 0;
-    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
-    const double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap, 0.70 * (double)total_b) * 0.9;
-    const double per_chain = ((ff.evidence_only ? 0.0 : (double)T) + 3.0) * (double)G * 8.0 + (double)T * NRED * 8.0 * 2 * 256.0;
-    int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
-    Bmax = std::min<int64_t>(std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024)), 65535);
-    if (ff.keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
-    const int nblk = (int)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 256);
-    std::vector<int> grw_ops;                       // the random walks of the program, in list order (transitionModels.py:645-649)
-    bool time_dependent = false;
-    for (int k = 0; k < p->n_ops; ++k) {
-        if (p->ops[k].kind == BLHIP_OP_GRW) grw_ops.push_back(k);
-        if (p->ops[k].kind == BLHIP_OP_CHANGEPOINT) time_dependent = true;
-    }
-    const int npass = (int)grw_ops.size();
-    ChainProgram no_clamp;                           // (the bookkeeping helpers only ask it for clamp modes)
-
-    for (int64_t c0 = 0; c0 < n_chains; c0 += Bmax) {
-        const int64_t B = std::min<int64_t>(Bmax, n_chains - c0);
-        ctx->timing.batches += 1;
-        ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
-        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = 7;
-        // ---- the program of every chain: source kind and the kernel of every pass, per step and direction ------------------------------
-        TapTable taps;
-        const size_t nT = (size_t)T * B;
-        std::vector<unsigned char> kindF(nT, SRC_PREV), kindB(nT, SRC_PREV);
-        std::vector<int> tapF((size_t)std::max(1, npass) * nT, -1), tapB((size_t)std::max(1, npass) * nT, -1);     // [pass][t][b]
-        for (int64_t b = 0; b < B; ++b) {
-            const double *val = op_values ? op_values + (c0 + b) * p->n_ops : nullptr;
-            std::vector<int> op_tap(p->n_ops, -1);
-            for (int k = 0; k < p->n_ops; ++k)
-                if (p->ops[k].kind == BLHIP_OP_GRW) {
-                    const double ns = val[k] / p->lattice[p->ops[k].axis];                    // transitionModels.py:108
-                    if (std::isnan(ns)) fail("chain %lld: GRW sigma is NaN", (long long)(c0 + b));
-                    op_tap[k] = ns > 0.0 ? taps.get(p->ops[k].axis, ns) : -1;                // :110-113
-                }
-            // the transition into a step, evaluated at time stamp tau (list order; a change point restarts from the reset
-            // distribution and drops what the models before it did, transitionModels.py:300-312)
-            auto run = [&](bool have_tau, double tau, unsigned char &kind, int *tp, size_t stride) {
-                kind = SRC_PREV;
-                for (int q = 0; q < npass; ++q) tp[q * stride] = -1;
-                for (int k = 0; k < p->n_ops; ++k) {
-                    const blhip_op &op = p->ops[k];
-                    if (op.kind == BLHIP_OP_GRW) {
-                        for (int q = 0; q < npass; ++q) if (grw_ops[q] == k) tp[q * stride] = op_tap[k];
-                    } else if (op.kind == BLHIP_OP_CHANGEPOINT && have_tau && tau == val[k]) {
-                        kind = SRC_RESET;
-                        for (int q = 0; q < npass; ++q) tp[q * stride] = -1;
-                    }
-                }
-            };
-            for (int64_t t = 0; t < T; ++t) {
-                const size_t k = (size_t)t * B + b;
-                if (t == 0) kindF[k] = SRC_PRIOR;                                       // core.py:363
-                else run(time_dependent, time_dependent ? p->timestamps[t - 1] : 0.0, kindF[k], &tapF[k], nT);          // core.py:411
-                if (t == T - 1) kindB[k] = SRC_UNIFORM;
-                else run(time_dependent, time_dependent ? p->timestamps[t + 1] - 1.0 : 0.0, kindB[k], &tapB[k], nT);    // core.py:467, transitionModels.py:316-317
-            }
-        }
-        taps.w.resize(taps.w.size() + 8, 0.0);
-        // ---- device buffers ----------------------------------------------------------------------------------------------------------
-        ctx->state.ensure((size_t)3 * B * G * 8);
-        double *d_state = ctx->state.as<double>(), *d_tmp[2] = {d_state + (size_t)B * G, d_state + (size_t)2 * B * G};
-        double *d_post = nullptr;
-        if (!ff.evidence_only) { ctx->post.ensure((size_t)B * T * G * 8); d_post = ctx->post.as<double>(); }
-        const size_t psz = (size_t)T * B * NRED * nblk;
-        ctx->psumF.ensure(psz * 8); ctx->redF.ensure(nT * NRED * 8);
-        if (ff.full) { ctx->psumB.ensure(psz * 8); ctx->redB.ensure(nT * NRED * 8); }
-        const size_t ntap = taps.off.size() + 1;
-        size_t mb = 2 * carve_size(nT) + 2 * carve_size(tapF.size() * 4) + carve_size(taps.w.size() * 8) + 2 * carve_size(ntap * 4) +
-                    2 * carve_size(nT * 8) + 3 * carve_size((size_t)B * 8) + carve_size((size_t)B * 8) + carve_size(nT * 8);
-        ctx->meta.ensure(mb);
-        char *mc = ctx->meta.as<char>();
-        unsigned char *d_kindF = carve<unsigned char>(mc, nT), *d_kindB = carve<unsigned char>(mc, nT);
-        int *d_tapF = carve<int>(mc, tapF.size()), *d_tapB = carve<int>(mc, tapB.size());
-        double *d_taps = carve<double>(mc, taps.w.size());
-        int *d_off = carve<int>(mc, ntap), *d_lw = carve<int>(mc, ntap);
-        const double **d_src0F = carve<const double *>(mc, nT), **d_src0B = carve<const double *>(mc, nT);
-        const double **d_ptr_state = carve<const double *>(mc, (size_t)B), **d_ptr_tmp0 = carve<const double *>(mc, (size_t)B),
-                     **d_ptr_tmp1 = carve<const double *>(mc, (size_t)B);
-        double *d_w = carve<double>(mc, (size_t)B), *d_invN = carve<double>(mc, nT);
-        // where a step's input lives: the chain's state, or a shared distribution at a restart
-        std::vector<const double *> src0F(nT), src0B(nT), pst(B), pt0(B), pt1(B);
-        for (int64_t b = 0; b < B; ++b) {
-            pst[b] = d_state + (size_t)b * G; pt0[b] = d_tmp[0] + (size_t)b * G; pt1[b] = d_tmp[1] + (size_t)b * G;
-            for (int64_t t = 0; t < T; ++t) {
-                const size_t k = (size_t)t * B + b;
-                src0F[k] = kindF[k] == SRC_PREV ? pst[b] : (kindF[k] == SRC_PRIOR ? d_prior : d_reset);
-                src0B[k] = kindB[k] == SRC_PREV ? pst[b] : (kindB[k] == SRC_UNIFORM ? d_uniform : d_reset);
-            }
-        }
-        HIPCHECK(hipMemcpyAsync(d_kindF, kindF.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_kindB, kindB.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_tapF, tapF.data(), tapF.size() * 4, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_tapB, tapB.data(), tapB.size() * 4, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_taps, taps.w.data(), taps.w.size() * 8, hipMemcpyHostToDevice, st));
-        if (!taps.off.empty()) {
-            HIPCHECK(hipMemcpyAsync(d_off, taps.off.data(), taps.off.size() * 4, hipMemcpyHostToDevice, st));
-            HIPCHECK(hipMemcpyAsync(d_lw, taps.lw.data(), taps.lw.size() * 4, hipMemcpyHostToDevice, st));
-        }
-        HIPCHECK(hipMemcpyAsync(d_src0F, src0F.data(), nT * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_src0B, src0B.data(), nT * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_ptr_state, pst.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_ptr_tmp0, pt0.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(d_ptr_tmp1, pt1.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
-        sync_stream(ctx, st);
-
-        // one time step: the passes of the transition, then the fused elementwise kernel
-        auto step = [&](bool bwd, int64_t t, const double *ps_prev, double *ps_out) {
-            const double *const *in = (bwd ? d_src0B : d_src0F) + (size_t)t * B;
-            const int *tp = (bwd ? d_tapB : d_tapF) + (size_t)t * B;
-            const std::vector<int> &htp = bwd ? tapB : tapF;
-            int flip = 0;
-            for (int q = 0; q < npass; ++q) {
-                bool any = false;
-                for (int64_t b = 0; b < B && !any; ++b) any = htp[(size_t)q * nT + (size_t)t * B + b] >= 0;
-                if (!any) continue;
-                const int ax = p->ops[grw_ops[q]].axis;
-                hipLaunchKernelGGL(bln::filter_axis_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, d_tmp[flip], in, G, ng.n[ax],
-                                   ng.stride[ax], tp + (size_t)q * nT, d_taps, d_off, d_lw);
-                in = flip ? d_ptr_tmp1 : d_ptr_tmp0;
-                flip ^= 1;
-            }
-            bln::NdStep Q{};
-            Q.g = ng; Q.B = (int)B; Q.T = (int)T; Q.nblk = nblk; Q.srcs = in; Q.kind = (bwd ? d_kindB : d_kindF) + (size_t)t * B;
-            Q.psum_prev = ps_prev; Q.prev_slot = bwd ? 2 : 0; Q.psum_out = ps_out; Q.lik = d_lik + (size_t)t * G; Q.state = d_state;
-            Q.post = d_post ? d_post + (size_t)t * G : nullptr; Q.post_stride = (long long)T * G;
-            if (bwd) hipLaunchKernelGGL(bln::step_kernel<true>, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, Q);
-            else hipLaunchKernelGGL(bln::step_kernel<false>, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, Q);
-        };
-        double *d_psF = ctx->psumF.as<double>();
-        const size_t per_step = (size_t)B * NRED * nblk;
-        float ms = 0;
-        // ---- forward pass (core.py:372-411) ---------------------------------------------------------------------------------------------
-        HIPCHECK(hipEventRecord(ev[0], st));
-        for (int64_t t = 0; t < T; ++t) step(false, t, t > 0 ? d_psF + (size_t)(t - 1) * per_step : d_psF, d_psF + (size_t)t * per_step);
-        HIPCHECK(hipGetLastError());
-        HIPCHECK(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(nT * NRED)), dim3(NTHREADS), 0, st, d_psF, ctx->redF.as<double>(), nblk, 0);      // (0: every slot is a sum -- slot 6 is the 4th parameter's mean here)
-        ctx->pinF.ensure(nT * NRED * 8);
-        double *redF = ctx->pinF.as<double>();
-        HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, nT * NRED * 8, hipMemcpyDeviceToHost, st));
-        sync_stream(ctx, st);
-        HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-        ctx->timing.forward_ms += ms; ctx->timing.forward_launches += T;
-        BatchOutcome O;
-        forward_bookkeeping(p, no_clamp, redF, B, dV, false, 1, ff.evidence_only, ff.forward_only, O);
-        O.invN.assign(nT, 0.0);
-        // ---- backward pass (core.py:424-470) --------------------------------------------------------------------------------------------
-        if (ff.full) {
-            double *d_psB = ctx->psumB.as<double>();
-            HIPCHECK(hipEventRecord(ev[2], st));
-            for (int64_t t = T - 1; t >= 0; --t) step(true, t, t < T - 1 ? d_psB + (size_t)(t + 1) * per_step : d_psB, d_psB + (size_t)t * per_step);
-            HIPCHECK(hipGetLastError());
-            HIPCHECK(hipEventRecord(ev[3], st));
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(nT * NRED)), dim3(NTHREADS), 0, st, d_psB, ctx->redB.as<double>(), nblk, 0);
-            ctx->pinB.ensure(nT * NRED * 8);
-            double *redB = ctx->pinB.as<double>();
-            HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, nT * NRED * 8, hipMemcpyDeviceToHost, st));
-            sync_stream(ctx, st);
-            HIPCHECK(hipEventElapsedTime(&ms, ev[2], ev[3]));
-            ctx->timing.backward_ms += ms; ctx->timing.backward_launches += T;
-            backward_bookkeeping(p, no_clamp, redF, redB, B, dV, false, -1, O);
-        } else if (ff.forward_only) {
-            for (int64_t b = 0; b < B; ++b)
-                for (int64_t t = 0; t < T; ++t) {
-                    const double n0 = redF[((size_t)t * B + b) * NRED];
-                    O.invN[(size_t)b * T + t] = (n0 != 0.0 && std::isfinite(n0)) ? 1.0 / n0 : 0.0;
-                }
-        }
-        if (ff.accumulate) fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN);
-        if (ff.keep) {
-            Geometry g2{};
-            g2.n0 = (int)p->n[0]; g2.n1 = (int)(G / p->n[0]); g2.G = G;
-            keep_posterior(ctx, g2, T, B, O, 0, T);
-        }
-        write_results(res, p, c0, B, O, !ff.evidence_only);
-    }
-    HIPCHECK(hipEventRecord(ev[7], st));
-    HIPCHECK(hipEventSynchronize(ev[7]));
-    float tot = 0;
-    HIPCHECK(hipEventElapsedTime(&tot, ev[6], ev[7]));
-    ctx->timing.total_ms = tot;
-}
-
-// ---- what the resident paths of a batch need to know about it -------------------------------------------------------------------------
-struct BatchEnv {
-    blhip_ctx *ctx; const blhip_problem *p; hipStream_t st;
-    Geometry g; long long G; int64_t T, B, c0; int d, rec_len;
-    FitFlags ff;
-    const DeviceTables *DT; const DeviceMeta *M; const ChainProgram *prog; const TapTable *taps;
-    double step0;                 // lattice step of the row axis (likelihood recurrence)
-    double *d_post;               // the batch's sequence buffer (null: evidence-only)
-    const double *log_w;          // log weights of ALL chains of the call (accumulate)
-    bool chain_means;             // the caller asked for per-chain posterior means
-};
-
-// did a block of a resident launch time out waiting for a peer (not every block co-resident)?  -> the context stops using the paths
-bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
-    ctx->pinS.ensure(64);
-    unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
-    HIPCHECK(hipMemcpyAsync(h, d_abort, 4, hipMemcpyDeviceToHost, st));
-    sync_stream(ctx, st);
-    // (option resident_force_abort: the tests of the fall-back pretend that a block gave up)
-    if (*h != 0u || ctx->option("resident_force_abort", 0.0) != 0.0) { ctx->resident_ok = false; return true; }
-    return false;
-}
-
-// ---- the time-resident path of a single-chain batch: one launch per pass instead of one per step (blhip_resident.hpp) -----------------
-struct ResidentRun {
-    bool on = false;
-    ResidentPlan rp;
-    blr::ResParams RQ{};
-    int nblk = 0;                                  // partial-sum slots per (step, sum): one per tile
-    std::vector<double> rowsumF;                   // forward pass: the actual sums of the stored rows
-    std::vector<double> sfwd;                      // the forward pass's scales s_k (backward: predicted posterior sums)
-    double *d_sfwd = nullptr;
-    unsigned *d_abort = nullptr;
-    size_t flag_bytes = 0;
-
-    // eligibility (one chain, Gaussian model with the likelihood recurrence, the same radius <= 8 kernels at every step) + buffers
-    void setup(const BatchEnv &E, int64_t n_chains, bool fast, bool use_rec, size_t &psz) {
-        blhip_ctx *ctx = E.ctx;
-        const ChainProgram &prog = *E.prog;
-        const TapTable &taps = *E.taps;
-        const int64_t T = E.T;
-        const bool full = E.ff.full;
-        double w0[blr::R + 1] = {1.0}, w1[blr::R + 1] = {1.0};
-        if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blr::DMAX &&
-            prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
-            plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp)) {
-            on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
-            const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
-            for (int64_t t = 1; t < T && on; ++t)
-                on = prog.kindF[t] == SRC_PREV && prog.tapF0[t] == k0 && prog.tapF1[t] == k1;
-            for (int64_t t = 0; t < T - 1 && on && full; ++t)
-                on = prog.kindB[t] == SRC_PREV && prog.tapB0[t] == k0 && prog.tapB1[t] == k1;
-            if (on) {
-                for (int k = 1; k <= blr::R; ++k) w0[k] = w1[k] = 0.0;
-                if (k0 >= 0) for (int k = 0; k <= taps.lw[k0]; ++k) w0[k] = taps.w[taps.off[k0] + k];
-                if (k1 >= 0) for (int k = 0; k <= taps.lw[k1]; ++k) w1[k] = taps.w[taps.off[k1] + k];
-            }
-        }
-        if (!on) return;
-        const size_t nt = (size_t)rp.ntiles;
-        const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
-        const size_t b_w = carve_size(2 * (blr::R + 1) * 8) + carve_size((size_t)T * 8);
-        flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
-        ctx->resx.ensure(b_cols + b_rows + b_w + flag_bytes);
-        char *rc = ctx->resx.as<char>();
-        RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
-        RQ.rows = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TC);
-        double *d_w = carve<double>(rc, 2 * (blr::R + 1));
-        d_sfwd = carve<double>(rc, (size_t)T);
-        RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
-        RQ.flagR = carve<unsigned>(rc, nt);
-        RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
-        d_abort = carve<unsigned>(rc, 16);
-        RQ.abort_word = d_abort;
-        double hw[2 * (blr::R + 1)];
-        for (int k = 0; k <= blr::R; ++k) { hw[k] = w0[k]; hw[blr::R + 1 + k] = w1[k]; }
-        HIPCHECK(hipMemcpyAsync(d_w, hw, sizeof hw, hipMemcpyHostToDevice, E.st));
-        sync_stream(ctx, E.st);
-        RQ.w0 = d_w; RQ.w1 = d_w + blr::R + 1;
-        RQ.n0 = E.g.n0; RQ.n1 = E.g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = E.d; RQ.rec_len = E.rec_len;
-        RQ.lag = std::max(1, std::min(blr::MAXLAG, (int)ctx->option("resident_lag", 2.0)));
-        RQ.m0 = E.DT->m0; RQ.m1 = E.DT->m1; RQ.colA = E.DT->colA; RQ.colB = E.DT->colB; RQ.rec = E.DT->rec; RQ.step0 = E.step0;
-        RQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
-        // partial-sum slots per step: one per tile (the launch-per-step kernels are the fall-back and keep theirs)
-        nblk = rp.ntiles;
-        psz = std::max(psz, (size_t)T * NRED * nblk);
-    }
-
-    void launch(const BatchEnv &E, bool bwd, double *psum) {
-        blhip_ctx *ctx = E.ctx;
-        (void)ctx;                                     // (only the profiling build touches it here)
-        hipStream_t st = E.st;
-        const int64_t T = E.T;
-        blr::ResParams Q = RQ;
-        HIPCHECK(hipMemsetAsync(RQ.flagC, 0, flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
-        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * NRED * nblk * 8, st));
-        Q.psum = psum;
-        // rows of the kept sequence are normalised inside the kernel, `lag` steps behind (what the host then still scales: the
-        // last / first `lag` rows)
-        if (bwd) {
-            // the posteriors are stored normalised: their sums follow from the forward scales and the last forward row sum
-            // (blhip_resident.hpp: predicted_sum)
-            sfwd.assign(T, 1.0);
-            for (int64_t t = RQ.lag; t < T; ++t) sfwd[t] = 1.0 / rowsumF[t - RQ.lag];
-            HIPCHECK(hipMemcpyAsync(d_sfwd, sfwd.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
-            Q.sfwd = d_sfwd; Q.n_first = rowsumF[T - 1] * (1.0 / (double)E.G);
-            Q.src0 = E.DT->uniform; Q.post = E.d_post; Q.store = 1; Q.means = 1; Q.normalise = 0;
-        } else {
-            Q.src0 = E.DT->prior; Q.post = E.ff.evidence_only ? nullptr : E.d_post; Q.store = E.ff.evidence_only ? 0 : 1;
-            Q.means = E.ff.forward_only ? 1 : 0; Q.normalise = E.ff.forward_only ? 1 : 0;
-        }
-#ifdef BLR_PROF
-        ctx->small.ensure(2 * 16 * 16 * 8);
-        HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
-        Q.prof = ctx->small.as<unsigned long long>();
-#endif
-        launch_resident(st, rp, Q, bwd);
-#ifdef BLR_PROF
-        {   // development build: where a step of one interior tile spends its time (shader-clock cycles between stamps)
-            unsigned long long hh[2 * 16 * 16];
-            HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
-            sync_stream(ctx, st);
-            static const char *names[12] = {"start", "h_pre+bar", "h_walk", "bar", "pubR+v_pre+gather", "arriveR", "bar", "v_walk", "sums", "pubC(+arriveC)", "-", "-"};
-            for (int wv = 0; wv < 2; ++wv) {
-                const unsigned long long *h = hh + wv * 256;
-                double acc[12] = {0}; int n = 0;
-                for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 9] || !h[q * 16]) continue; ++n; for (int i = 1; i < 10; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
-                std::fprintf(stderr, "[blr prof %s thread %d] %d steps, cycles per phase:", bwd ? "bwd" : "fwd", wv ? 128 : 0, n);
-                double tot = 0; for (int i = 1; i < 10; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
-                std::fprintf(stderr, " | total %.0f\n", tot);
-            }
-        }
-#endif
-    }
-
-    // after the forward pass: every tile made it, and the sums allow the lag to be undone
-    bool forward_ok(const BatchEnv &E, double *redF) {
-        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
-        return resident_unlag(redF, E.T, RQ.lag, rowsumF);
-    }
-
-    // after the backward pass: every tile made it, the lagged scale stayed in range, and the PREDICTED sums the kernel normalised
-    // the stored posteriors by reproduce the reduced ones
-    bool backward_ok(const BatchEnv &E, const double *redB) {
-        const int64_t T = E.T;
-        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
-        for (int64_t t = 0; t < T; ++t) {
-            const double Ct = redB[(size_t)t * NRED + 2], Nt = redB[(size_t)t * NRED];
-            if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) return false;
-        }
-        double npred = rowsumF[T - 1] * (1.0 / (double)E.G);
-        for (int64_t t = T - 1; t >= 0; --t) {
-            const int64_t k = T - 1 - t;
-            if (k > 0) npred = (k >= RQ.lag ? 1.0 / redB[(size_t)(t + RQ.lag) * NRED + 2] : 1.0) * npred / sfwd[t + 1];
-            const double Nt = redB[(size_t)t * NRED];
-            if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
-        }
-        return true;
-    }
-};
-
-// ---- the chain-resident path of a batch: rounds of chains stay in LDS for a whole pass (blhip_chainres.hpp) ---------------------------
-struct ChainRun {
-    bool on = false;
-    ChainResPlan cp;
-    blc::ChainParams CQ{};
-    int *d_order = nullptr;
-    size_t gran_bytes = 0;
-    unsigned *d_abort = nullptr;
-    std::vector<std::vector<double>> rowsumC;      // forward pass: the actual sums of the stored rows, per chain
-    std::vector<std::vector<double>> sfwdC;        // forward pass: the scales it used, per chain
-    // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
-    bool post_private = false;
-    // fused fold: the backward kernel adds the weighted, normalised posteriors to per-slot partial accumulators instead of storing
-    // them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands left
-    // bandwidth unused: same bytes, one pass)
-    bool fused = false;
-    bool fold_done = false;                        // this batch's posteriors are in the accumulator already
-    double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr;
-    std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
-    double fold_ref = -INFINITY;
-
-    void setup(const BatchEnv &E, bool fast, bool use_rec, size_t &psz) {
-        blhip_ctx *ctx = E.ctx;
-        const ChainProgram &prog = *E.prog;
-        const int64_t T = E.T, B = E.B;
-        const long long G = E.G;
-        if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blc::DMAX &&
-            !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
-            on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
-        if (!on) return;
-        gran_bytes = carve_size((size_t)blc::NSLOT * cp.cpr * cp.strips * 2 * 8);
-        ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64));
-        char *rc = ctx->resx.as<char>();
-        d_order = carve<int>(rc, (size_t)B);
-        int *d_tapid = carve<int>(rc, (size_t)B);
-        CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * cp.cpr * cp.strips * 2);
-        d_abort = carve<unsigned>(rc, 16);
-        CQ.abort_word = d_abort;
-        HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
-        HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
-        sync_stream(ctx, E.st);
-        CQ.n0 = E.g.n0; CQ.n1 = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = E.d; CQ.rec_len = E.rec_len;
-        CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
-        CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
-        CQ.post_stride = (long long)T * G;
-        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.step0 = E.step0;
-        CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
-        psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
-        post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
-        fused = post_private && !cp.has_reset && ctx->option("fuse_accumulate", 1.0) != 0.0;
-        if (fused) {
-            ctx->accpart.ensure((size_t)cp.cpr * T * G * 8);
-            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8));
-            char *wc = ctx->accw.as<char>();
-            d_fold_sfwd = carve<double>(wc, (size_t)T * B);
-            d_fold_w = carve<double>(wc, (size_t)B);
-            d_fold_inf = carve<double>(wc, (size_t)B);
-        }
-    }
-
-    // one pass: the launches of the rounds follow each other on the stream
-    void pass(const BatchEnv &E, bool bwd, double *psum) {
-        blhip_ctx *ctx = E.ctx;
-        hipStream_t st = E.st;
-        const int64_t T = E.T, B = E.B;
-        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * cp.strips * 8, st));
-        HIPCHECK(hipMemsetAsync(d_abort, 0, 64, st));
-        for (size_t r = 0; r + 1 < cp.round_start.size(); ++r) {
-            blc::ChainParams Q = CQ;
-            HIPCHECK(hipMemsetAsync(CQ.gran, 0, gran_bytes, st));       // tags restart with every launch
-            Q.chain_ids = d_order + cp.round_start[r];
-            Q.nslots = cp.round_start[r + 1] - cp.round_start[r];
-            Q.psum = psum;
-            Q.src0 = bwd ? E.DT->uniform : E.DT->prior;
-            Q.kinds = cp.has_reset ? (bwd ? E.M->kindB : E.M->kindF) : nullptr;
-            Q.reset = E.DT->reset;
-            Q.post = E.d_post;
-            Q.means = bwd ? (E.chain_means ? 1 : 0) : (E.ff.forward_only ? 1 : 0);
-            Q.strip_major = post_private ? 1 : 0;            // (the stored sequence is private to the fit then)
-            const bool fold_now = bwd && fused;
-            if (fold_now) {
-                Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
-                Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * E.G;
-            }
-#ifdef BLC_PROF
-            ctx->small.ensure(2 * 16 * 16 * 8);
-            HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
-            Q.prof = ctx->small.as<unsigned long long>();
-#endif
-            launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
-#ifdef BLC_PROF
-            {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
-                unsigned long long hh[2 * 16 * 16];
-                HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
-                sync_stream(ctx, st);
-                static const char *names[8] = {"start", "ring", "chain0", "scale+anchor", "epi0", "tiles1..", "sums", "barrier"};
-                for (int wvi = 0; wvi < 2; ++wvi) {
-                    const unsigned long long *h = hh + wvi * 256;
-                    double acc[8] = {0}; int n = 0;
-                    for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
-                    std::fprintf(stderr, "[blc prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", cp.round_nk[r], wvi ? 2 : 0, n);
-                    double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
-                    std::fprintf(stderr, " | total %.0f\n", tot);
-                }
-            }
-#endif
-        }
-    }
-
-    // after the forward pass: every strip made it, and the sums of every chain allow the scales to be undone
-    bool forward_ok(const BatchEnv &E, double *redF) {
-        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
-        rowsumC.assign(E.B, std::vector<double>());
-        sfwdC.assign(E.B, std::vector<double>());
-        for (int64_t b = 0; b < E.B; ++b)
-            if (!chain_unlag(redF, E.T, CQ.lag, rowsumC[b], E.B, b, &sfwdC[b], cp.has_reset ? E.prog->kindF.data() : nullptr)) return false;
-        return true;
-    }
-
-    // fused fold, before the backward pass: weights relative to the batch's own reference (core.py:1358-1366: chains without a finite
-    // evidence do not count), the forward scales and the sum of the last step's posterior of every chain -> device; partials zeroed
-    void prepare_fold(const BatchEnv &E, const BatchOutcome &O) {
-        blhip_ctx *ctx = E.ctx;
-        const int64_t T = E.T, B = E.B;
-        fold_lw.assign(B, -INFINITY);
-        fold_ref = -INFINITY;
-        for (int64_t b = 0; b < B; ++b) {
-            if (O.abort_step[b] >= 0 || !std::isfinite(O.logE[b]) || !std::isfinite(E.log_w[E.c0 + b])) continue;
-            fold_lw[b] = O.logE[b] + E.log_w[E.c0 + b];
-            fold_ref = std::max(fold_ref, fold_lw[b]);
-        }
-        ctx->pinA.ensure(((size_t)T * B + 2 * (size_t)B) * 8);
-        double *h = ctx->pinA.as<double>(), *hw = h + (size_t)T * B, *hi = hw + B;
-        for (int64_t b = 0; b < B; ++b) {
-            std::memcpy(h + (size_t)b * T, sfwdC[b].data(), (size_t)T * 8);
-            hw[b] = std::isfinite(fold_lw[b]) ? std::exp(fold_lw[b] - fold_ref) : 0.0;
-            hi[b] = 1.0 / (rowsumC[b][T - 1] * (1.0 / (double)E.G));
-        }
-        HIPCHECK(hipMemcpyAsync(d_fold_sfwd, h, (size_t)T * B * 8, hipMemcpyHostToDevice, E.st));
-        HIPCHECK(hipMemcpyAsync(d_fold_w, hw, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
-        HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
-        HIPCHECK(hipMemsetAsync(ctx->accpart.p, 0, (size_t)cp.cpr * T * E.G * 8, E.st));
-    }
-
-    // after the backward pass: every strip made it and the lagged scale of the backward state stayed in range
-    bool backward_ok(const BatchEnv &E, const double *redB) {
-        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
-        for (int64_t b = 0; b < E.B; ++b)
-            for (int64_t t = 0; t < E.T; ++t) {
-                const double *r = &redB[((size_t)t * E.B + b) * NRED];
-                if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) return false;
-            }
-        return true;
-    }
-
-    // fused fold, after the backward pass: the kernel normalised every posterior by its PREDICTED sum -- the prediction must
-    // reproduce the reduced sums (false: the caller repeats the batch with the launch-per-step kernels; the partials are dropped);
-    // then the partial accumulators go into the average posterior (running reference exponent as in prepare_fold)
-    bool fold(const BatchEnv &E, const double *redB) {
-        blhip_ctx *ctx = E.ctx;
-        hipStream_t st = E.st;
-        const int64_t T = E.T, B = E.B;
-        const long long G = E.G;
-        std::vector<double> csum, sb;
-        for (int64_t b = 0; b < B; ++b) {
-            // the backward scales, in processing order k = T - 1 - t (the kernel's rule, from the sums C of its new states)
-            csum.assign(T, 0.0); sb.assign(T, 1.0);
-            for (int64_t k = 0; k < T; ++k) csum[k] = redB[((size_t)(T - 1 - k) * B + b) * NRED + 2];
-            for (int64_t k = CQ.lag; k < T; ++k) sb[k] = (k - CQ.lag - 1 >= 0 ? csum[k - CQ.lag - 1] : 1.0) * sb[k - CQ.lag] / csum[k - CQ.lag];
-            double npred = rowsumC[b][T - 1] * (1.0 / (double)G);
-            for (int64_t k = 0; k < T; ++k) {
-                const int64_t t = T - 1 - k;
-                if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
-                const double Nt = redB[((size_t)t * B + b) * NRED];
-                if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
-            }
-        }
-        if (std::isfinite(fold_ref)) {
-            const double newref = std::max(ctx->acc_logref, fold_ref);
-            const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
-            HIPCHECK(hipEventRecord(ctx->ev[4], st));
-            hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((G / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
-                               ctx->accpart.as<double>(), (long long)T * G, std::min<int>(cp.cpr, (int)B), E.g.n0, E.g.n1, (int)T, r, rb,
-                               ctx->acc_first ? 1 : 0);
-            HIPCHECK(hipEventRecord(ctx->ev[5], st));
-            sync_stream(ctx, st);
-            float fms = 0;
-            HIPCHECK(hipEventElapsedTime(&fms, ctx->ev[4], ctx->ev[5]));
-            ctx->timing.accumulate_ms += fms;
-            ctx->timing.accumulate_launches += 1;
-            int nfold = 0;
-            for (int64_t b = 0; b < B; ++b) nfold += std::isfinite(fold_lw[b]) ? 1 : 0;
-            ctx->acc_logref = newref; ctx->acc_first = false; ctx->acc_folded += nfold;
-        }
-        fold_done = true;
-        return true;
-    }
-};
+#include "blhip_fit_nd.hpp"       // do_fit_nd: grids with 3 and 4 parameters
+#include "blhip_fit_paths.hpp"    // BatchEnv, ResidentRun, ChainRun: the resident paths of a batch
 
 void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const double *op_values,
             const double *log_w, uint32_t flags, blhip_result *res) {

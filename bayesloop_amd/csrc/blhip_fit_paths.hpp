@@ -1,0 +1,364 @@
+// The resident paths of a batch (kernels: blhip_resident.hpp, blhip_chainres.hpp): eligibility, buffers, launches and the host-side
+// checks after each pass, one struct per path.  Included by blhip.hip INSIDE its anonymous namespace, after the helpers it uses
+// (DeviceTables, DeviceMeta, ChainProgram, TapTable, plan_ / launch_ functions, resident_unlag / chain_unlag, BatchOutcome).
+#pragma once
+
+// ---- what the resident paths of a batch need to know about it -------------------------------------------------------------------------
+struct BatchEnv {
+    blhip_ctx *ctx; const blhip_problem *p; hipStream_t st;
+    Geometry g; long long G; int64_t T, B, c0; int d, rec_len;
+    FitFlags ff;
+    const DeviceTables *DT; const DeviceMeta *M; const ChainProgram *prog; const TapTable *taps;
+    double step0;                 // lattice step of the row axis (likelihood recurrence)
+    double *d_post;               // the batch's sequence buffer (null: evidence-only)
+    const double *log_w;          // log weights of ALL chains of the call (accumulate)
+    bool chain_means;             // the caller asked for per-chain posterior means
+};
+
+// did a block of a resident launch time out waiting for a peer (not every block co-resident)?  -> the context stops using the paths
+bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
+    ctx->pinS.ensure(64);
+    unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
+    HIPCHECK(hipMemcpyAsync(h, d_abort, 4, hipMemcpyDeviceToHost, st));
+    sync_stream(ctx, st);
+    // (option resident_force_abort: the tests of the fall-back pretend that a block gave up)
+    if (*h != 0u || ctx->option("resident_force_abort", 0.0) != 0.0) { ctx->resident_ok = false; return true; }
+    return false;
+}
+
+// ---- the time-resident path of a single-chain batch: one launch per pass instead of one per step (blhip_resident.hpp) -----------------
+struct ResidentRun {
+    bool on = false;
+    ResidentPlan rp;
+    blr::ResParams RQ{};
+    int nblk = 0;                                  // partial-sum slots per (step, sum): one per tile
+    std::vector<double> rowsumF;                   // forward pass: the actual sums of the stored rows
+    std::vector<double> sfwd;                      // the forward pass's scales s_k (backward: predicted posterior sums)
+    double *d_sfwd = nullptr;
+    unsigned *d_abort = nullptr;
+    size_t flag_bytes = 0;
+
+    // eligibility (one chain, Gaussian model with the likelihood recurrence, the same radius <= 8 kernels at every step) + buffers
+    void setup(const BatchEnv &E, int64_t n_chains, bool fast, bool use_rec, size_t &psz) {
+        blhip_ctx *ctx = E.ctx;
+        const ChainProgram &prog = *E.prog;
+        const TapTable &taps = *E.taps;
+        const int64_t T = E.T;
+        const bool full = E.ff.full;
+        double w0[blr::R + 1] = {1.0}, w1[blr::R + 1] = {1.0};
+        if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blr::DMAX &&
+            prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
+            plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp)) {
+            on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
+            const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
+            for (int64_t t = 1; t < T && on; ++t)
+                on = prog.kindF[t] == SRC_PREV && prog.tapF0[t] == k0 && prog.tapF1[t] == k1;
+            for (int64_t t = 0; t < T - 1 && on && full; ++t)
+                on = prog.kindB[t] == SRC_PREV && prog.tapB0[t] == k0 && prog.tapB1[t] == k1;
+            if (on) {
+                for (int k = 1; k <= blr::R; ++k) w0[k] = w1[k] = 0.0;
+                if (k0 >= 0) for (int k = 0; k <= taps.lw[k0]; ++k) w0[k] = taps.w[taps.off[k0] + k];
+                if (k1 >= 0) for (int k = 0; k <= taps.lw[k1]; ++k) w1[k] = taps.w[taps.off[k1] + k];
+            }
+        }
+        if (!on) return;
+        const size_t nt = (size_t)rp.ntiles;
+        const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
+        const size_t b_w = carve_size(2 * (blr::R + 1) * 8) + carve_size((size_t)T * 8);
+        flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
+        ctx->resx.ensure(b_cols + b_rows + b_w + flag_bytes);
+        char *rc = ctx->resx.as<char>();
+        RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
+        RQ.rows = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TC);
+        double *d_w = carve<double>(rc, 2 * (blr::R + 1));
+        d_sfwd = carve<double>(rc, (size_t)T);
+        RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
+        RQ.flagR = carve<unsigned>(rc, nt);
+        RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
+        d_abort = carve<unsigned>(rc, 16);
+        RQ.abort_word = d_abort;
+        double hw[2 * (blr::R + 1)];
+        for (int k = 0; k <= blr::R; ++k) { hw[k] = w0[k]; hw[blr::R + 1 + k] = w1[k]; }
+        HIPCHECK(hipMemcpyAsync(d_w, hw, sizeof hw, hipMemcpyHostToDevice, E.st));
+        sync_stream(ctx, E.st);
+        RQ.w0 = d_w; RQ.w1 = d_w + blr::R + 1;
+        RQ.n0 = E.g.n0; RQ.n1 = E.g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = E.d; RQ.rec_len = E.rec_len;
+        RQ.lag = std::max(1, std::min(blr::MAXLAG, (int)ctx->option("resident_lag", 2.0)));
+        RQ.m0 = E.DT->m0; RQ.m1 = E.DT->m1; RQ.colA = E.DT->colA; RQ.colB = E.DT->colB; RQ.rec = E.DT->rec; RQ.step0 = E.step0;
+        RQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
+        // partial-sum slots per step: one per tile (the launch-per-step kernels are the fall-back and keep theirs)
+        nblk = rp.ntiles;
+        psz = std::max(psz, (size_t)T * NRED * nblk);
+    }
+
+    void launch(const BatchEnv &E, bool bwd, double *psum) {
+        blhip_ctx *ctx = E.ctx;
+        (void)ctx;                                     // (only the profiling build touches it here)
+        hipStream_t st = E.st;
+        const int64_t T = E.T;
+        blr::ResParams Q = RQ;
+        HIPCHECK(hipMemsetAsync(RQ.flagC, 0, flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
+        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * NRED * nblk * 8, st));
+        Q.psum = psum;
+        // rows of the kept sequence are normalised inside the kernel, `lag` steps behind (what the host then still scales: the
+        // last / first `lag` rows)
+        if (bwd) {
+            // the posteriors are stored normalised: their sums follow from the forward scales and the last forward row sum
+            // (blhip_resident.hpp: predicted_sum)
+            sfwd.assign(T, 1.0);
+            for (int64_t t = RQ.lag; t < T; ++t) sfwd[t] = 1.0 / rowsumF[t - RQ.lag];
+            HIPCHECK(hipMemcpyAsync(d_sfwd, sfwd.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
+            Q.sfwd = d_sfwd; Q.n_first = rowsumF[T - 1] * (1.0 / (double)E.G);
+            Q.src0 = E.DT->uniform; Q.post = E.d_post; Q.store = 1; Q.means = 1; Q.normalise = 0;
+        } else {
+            Q.src0 = E.DT->prior; Q.post = E.ff.evidence_only ? nullptr : E.d_post; Q.store = E.ff.evidence_only ? 0 : 1;
+            Q.means = E.ff.forward_only ? 1 : 0; Q.normalise = E.ff.forward_only ? 1 : 0;
+        }
+#ifdef BLR_PROF
+        ctx->small.ensure(2 * 16 * 16 * 8);
+        HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+        Q.prof = ctx->small.as<unsigned long long>();
+#endif
+        launch_resident(st, rp, Q, bwd);
+#ifdef BLR_PROF
+        {   // development build: where a step of one interior tile spends its time (shader-clock cycles between stamps)
+            unsigned long long hh[2 * 16 * 16];
+            HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
+            sync_stream(ctx, st);
+            static const char *names[12] = {"start", "h_pre+bar", "h_walk", "bar", "pubR+v_pre+gather", "arriveR", "bar", "v_walk", "sums", "pubC(+arriveC)", "-", "-"};
+            for (int wv = 0; wv < 2; ++wv) {
+                const unsigned long long *h = hh + wv * 256;
+                double acc[12] = {0}; int n = 0;
+                for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 9] || !h[q * 16]) continue; ++n; for (int i = 1; i < 10; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                std::fprintf(stderr, "[blr prof %s thread %d] %d steps, cycles per phase:", bwd ? "bwd" : "fwd", wv ? 128 : 0, n);
+                double tot = 0; for (int i = 1; i < 10; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                std::fprintf(stderr, " | total %.0f\n", tot);
+            }
+        }
+#endif
+    }
+
+    // after the forward pass: every tile made it, and the sums allow the lag to be undone
+    bool forward_ok(const BatchEnv &E, double *redF) {
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        return resident_unlag(redF, E.T, RQ.lag, rowsumF);
+    }
+
+    // after the backward pass: every tile made it, the lagged scale stayed in range, and the PREDICTED sums the kernel normalised
+    // the stored posteriors by reproduce the reduced ones
+    bool backward_ok(const BatchEnv &E, const double *redB) {
+        const int64_t T = E.T;
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        for (int64_t t = 0; t < T; ++t) {
+            const double Ct = redB[(size_t)t * NRED + 2], Nt = redB[(size_t)t * NRED];
+            if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) return false;
+        }
+        double npred = rowsumF[T - 1] * (1.0 / (double)E.G);
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t k = T - 1 - t;
+            if (k > 0) npred = (k >= RQ.lag ? 1.0 / redB[(size_t)(t + RQ.lag) * NRED + 2] : 1.0) * npred / sfwd[t + 1];
+            const double Nt = redB[(size_t)t * NRED];
+            if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
+        }
+        return true;
+    }
+};
+
+// ---- the chain-resident path of a batch: rounds of chains stay in LDS for a whole pass (blhip_chainres.hpp) ---------------------------
+struct ChainRun {
+    bool on = false;
+    ChainResPlan cp;
+    blc::ChainParams CQ{};
+    int *d_order = nullptr;
+    size_t gran_bytes = 0;
+    unsigned *d_abort = nullptr;
+    std::vector<std::vector<double>> rowsumC;      // forward pass: the actual sums of the stored rows, per chain
+    std::vector<std::vector<double>> sfwdC;        // forward pass: the scales it used, per chain
+    // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
+    bool post_private = false;
+    // fused fold: the backward kernel adds the weighted, normalised posteriors to per-slot partial accumulators instead of storing
+    // them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands left
+    // bandwidth unused: same bytes, one pass)
+    bool fused = false;
+    bool fold_done = false;                        // this batch's posteriors are in the accumulator already
+    double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr;
+    std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
+    double fold_ref = -INFINITY;
+
+    void setup(const BatchEnv &E, bool fast, bool use_rec, size_t &psz) {
+        blhip_ctx *ctx = E.ctx;
+        const ChainProgram &prog = *E.prog;
+        const int64_t T = E.T, B = E.B;
+        const long long G = E.G;
+        if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blc::DMAX &&
+            !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
+            on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
+        if (!on) return;
+        gran_bytes = carve_size((size_t)blc::NSLOT * cp.cpr * cp.strips * 2 * 8);
+        ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64));
+        char *rc = ctx->resx.as<char>();
+        d_order = carve<int>(rc, (size_t)B);
+        int *d_tapid = carve<int>(rc, (size_t)B);
+        CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * cp.cpr * cp.strips * 2);
+        d_abort = carve<unsigned>(rc, 16);
+        CQ.abort_word = d_abort;
+        HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
+        sync_stream(ctx, E.st);
+        CQ.n0 = E.g.n0; CQ.n1 = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = E.d; CQ.rec_len = E.rec_len;
+        CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
+        CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
+        CQ.post_stride = (long long)T * G;
+        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.step0 = E.step0;
+        CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
+        psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
+        post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
+        fused = post_private && !cp.has_reset && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        if (fused) {
+            ctx->accpart.ensure((size_t)cp.cpr * T * G * 8);
+            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8));
+            char *wc = ctx->accw.as<char>();
+            d_fold_sfwd = carve<double>(wc, (size_t)T * B);
+            d_fold_w = carve<double>(wc, (size_t)B);
+            d_fold_inf = carve<double>(wc, (size_t)B);
+        }
+    }
+
+    // one pass: the launches of the rounds follow each other on the stream
+    void pass(const BatchEnv &E, bool bwd, double *psum) {
+        blhip_ctx *ctx = E.ctx;
+        hipStream_t st = E.st;
+        const int64_t T = E.T, B = E.B;
+        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * cp.strips * 8, st));
+        HIPCHECK(hipMemsetAsync(d_abort, 0, 64, st));
+        for (size_t r = 0; r + 1 < cp.round_start.size(); ++r) {
+            blc::ChainParams Q = CQ;
+            HIPCHECK(hipMemsetAsync(CQ.gran, 0, gran_bytes, st));       // tags restart with every launch
+            Q.chain_ids = d_order + cp.round_start[r];
+            Q.nslots = cp.round_start[r + 1] - cp.round_start[r];
+            Q.psum = psum;
+            Q.src0 = bwd ? E.DT->uniform : E.DT->prior;
+            Q.kinds = cp.has_reset ? (bwd ? E.M->kindB : E.M->kindF) : nullptr;
+            Q.reset = E.DT->reset;
+            Q.post = E.d_post;
+            Q.means = bwd ? (E.chain_means ? 1 : 0) : (E.ff.forward_only ? 1 : 0);
+            Q.strip_major = post_private ? 1 : 0;            // (the stored sequence is private to the fit then)
+            const bool fold_now = bwd && fused;
+            if (fold_now) {
+                Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
+                Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * E.G;
+            }
+#ifdef BLC_PROF
+            ctx->small.ensure(2 * 16 * 16 * 8);
+            HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+            Q.prof = ctx->small.as<unsigned long long>();
+#endif
+            launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
+#ifdef BLC_PROF
+            {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
+                unsigned long long hh[2 * 16 * 16];
+                HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
+                sync_stream(ctx, st);
+                static const char *names[8] = {"start", "ring", "chain0", "scale+anchor", "epi0", "tiles1..", "sums", "barrier"};
+                for (int wvi = 0; wvi < 2; ++wvi) {
+                    const unsigned long long *h = hh + wvi * 256;
+                    double acc[8] = {0}; int n = 0;
+                    for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                    std::fprintf(stderr, "[blc prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", cp.round_nk[r], wvi ? 2 : 0, n);
+                    double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                    std::fprintf(stderr, " | total %.0f\n", tot);
+                }
+            }
+#endif
+        }
+    }
+
+    // after the forward pass: every strip made it, and the sums of every chain allow the scales to be undone
+    bool forward_ok(const BatchEnv &E, double *redF) {
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        rowsumC.assign(E.B, std::vector<double>());
+        sfwdC.assign(E.B, std::vector<double>());
+        for (int64_t b = 0; b < E.B; ++b)
+            if (!chain_unlag(redF, E.T, CQ.lag, rowsumC[b], E.B, b, &sfwdC[b], cp.has_reset ? E.prog->kindF.data() : nullptr)) return false;
+        return true;
+    }
+
+    // fused fold, before the backward pass: weights relative to the batch's own reference (core.py:1358-1366: chains without a finite
+    // evidence do not count), the forward scales and the sum of the last step's posterior of every chain -> device; partials zeroed
+    void prepare_fold(const BatchEnv &E, const BatchOutcome &O) {
+        blhip_ctx *ctx = E.ctx;
+        const int64_t T = E.T, B = E.B;
+        fold_lw.assign(B, -INFINITY);
+        fold_ref = -INFINITY;
+        for (int64_t b = 0; b < B; ++b) {
+            if (O.abort_step[b] >= 0 || !std::isfinite(O.logE[b]) || !std::isfinite(E.log_w[E.c0 + b])) continue;
+            fold_lw[b] = O.logE[b] + E.log_w[E.c0 + b];
+            fold_ref = std::max(fold_ref, fold_lw[b]);
+        }
+        ctx->pinA.ensure(((size_t)T * B + 2 * (size_t)B) * 8);
+        double *h = ctx->pinA.as<double>(), *hw = h + (size_t)T * B, *hi = hw + B;
+        for (int64_t b = 0; b < B; ++b) {
+            std::memcpy(h + (size_t)b * T, sfwdC[b].data(), (size_t)T * 8);
+            hw[b] = std::isfinite(fold_lw[b]) ? std::exp(fold_lw[b] - fold_ref) : 0.0;
+            hi[b] = 1.0 / (rowsumC[b][T - 1] * (1.0 / (double)E.G));
+        }
+        HIPCHECK(hipMemcpyAsync(d_fold_sfwd, h, (size_t)T * B * 8, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemcpyAsync(d_fold_w, hw, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemsetAsync(ctx->accpart.p, 0, (size_t)cp.cpr * T * E.G * 8, E.st));
+    }
+
+    // after the backward pass: every strip made it and the lagged scale of the backward state stayed in range
+    bool backward_ok(const BatchEnv &E, const double *redB) {
+        if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        for (int64_t b = 0; b < E.B; ++b)
+            for (int64_t t = 0; t < E.T; ++t) {
+                const double *r = &redB[((size_t)t * E.B + b) * NRED];
+                if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) return false;
+            }
+        return true;
+    }
+
+    // fused fold, after the backward pass: the kernel normalised every posterior by its PREDICTED sum -- the prediction must
+    // reproduce the reduced sums (false: the caller repeats the batch with the launch-per-step kernels; the partials are dropped);
+    // then the partial accumulators go into the average posterior (running reference exponent as in prepare_fold)
+    bool fold(const BatchEnv &E, const double *redB) {
+        blhip_ctx *ctx = E.ctx;
+        hipStream_t st = E.st;
+        const int64_t T = E.T, B = E.B;
+        const long long G = E.G;
+        std::vector<double> csum, sb;
+        for (int64_t b = 0; b < B; ++b) {
+            // the backward scales, in processing order k = T - 1 - t (the kernel's rule, from the sums C of its new states)
+            csum.assign(T, 0.0); sb.assign(T, 1.0);
+            for (int64_t k = 0; k < T; ++k) csum[k] = redB[((size_t)(T - 1 - k) * B + b) * NRED + 2];
+            for (int64_t k = CQ.lag; k < T; ++k) sb[k] = (k - CQ.lag - 1 >= 0 ? csum[k - CQ.lag - 1] : 1.0) * sb[k - CQ.lag] / csum[k - CQ.lag];
+            double npred = rowsumC[b][T - 1] * (1.0 / (double)G);
+            for (int64_t k = 0; k < T; ++k) {
+                const int64_t t = T - 1 - k;
+                if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
+                const double Nt = redB[((size_t)t * B + b) * NRED];
+                if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
+            }
+        }
+        if (std::isfinite(fold_ref)) {
+            const double newref = std::max(ctx->acc_logref, fold_ref);
+            const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
+            HIPCHECK(hipEventRecord(ctx->ev[4], st));
+            hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((G / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
+                               ctx->accpart.as<double>(), (long long)T * G, std::min<int>(cp.cpr, (int)B), E.g.n0, E.g.n1, (int)T, r, rb,
+                               ctx->acc_first ? 1 : 0);
+            HIPCHECK(hipEventRecord(ctx->ev[5], st));
+            sync_stream(ctx, st);
+            float fms = 0;
+            HIPCHECK(hipEventElapsedTime(&fms, ctx->ev[4], ctx->ev[5]));
+            ctx->timing.accumulate_ms += fms;
+            ctx->timing.accumulate_launches += 1;
+            int nfold = 0;
+            for (int64_t b = 0; b < B; ++b) nfold += std::isfinite(fold_lw[b]) ? 1 : 0;
+            ctx->acc_logref = newref; ctx->acc_first = false; ctx->acc_folded += nfold;
+        }
+        fold_done = true;
+        return true;
+    }
+};
