@@ -461,10 +461,15 @@ template <int NTW>
 void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
     switch (nk) {
         case 4: launch_chain_k<4, NTW>(s, Q, bwd, store); break;       // no stencil (change-point studies)
+        case 6: launch_chain_k<6, NTW>(s, Q, bwd, store); break;         // band = 16 + 2 R0 columns, R0 = 4, 8, ... 40
         case 8: launch_chain_k<8, NTW>(s, Q, bwd, store); break;
+        case 10: launch_chain_k<10, NTW>(s, Q, bwd, store); break;
         case 12: launch_chain_k<12, NTW>(s, Q, bwd, store); break;
+        case 14: launch_chain_k<14, NTW>(s, Q, bwd, store); break;
         case 16: launch_chain_k<16, NTW>(s, Q, bwd, store); break;
+        case 18: launch_chain_k<18, NTW>(s, Q, bwd, store); break;
         case 20: launch_chain_k<20, NTW>(s, Q, bwd, store); break;
+        case 22: launch_chain_k<22, NTW>(s, Q, bwd, store); break;
         case 24: launch_chain_k<24, NTW>(s, Q, bwd, store); break;
         default: fail("internal: chain-resident kernel with %d band blocks", nk);
     }
@@ -1315,7 +1320,7 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
     cp.round_start.clear(); cp.round_nk.clear();
     for (int64_t s0 = 0; s0 < B; s0 += cp.cpr) {
         const int64_t s1 = std::min<int64_t>(B, s0 + cp.cpr);
-        const int r0 = std::max(8, (lw[cp.order[s1 - 1]] + 7) / 8 * 8);
+        const int r0 = std::max(4, (lw[cp.order[s1 - 1]] + 3) / 4 * 4);             // (a product costs 64 cycles: bands as narrow as the widest chain of the launch allows)
         cp.round_start.push_back((int)s0);
         cp.round_nk.push_back(prog.LW0 == 0 ? 4 : (blc::TM + 2 * r0) / 4);          // (4: the no-stencil kernel)
     }

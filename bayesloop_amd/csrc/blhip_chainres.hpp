@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
-    static_assert(NK == 4 || (NK >= 8 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
+    static_assert(NK == 4 || (NK >= 6 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
     constexpr bool FILTER = NK > 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *const X = lds;                     // [2][N0][16]
