@@ -823,6 +823,8 @@ CHAINRES = {
                                      tm=('ChangePoint', 'tChange', ('arange', 1, 23, 2), None)),
     'cres_changepoints_128x64_evidence': dict(study='ChangepointStudy', data=('series_jump', 60, 17, 8, -2.0), om=_g2(128, 64),
                                               tm=('ChangePoint', 'tChange', 'all', None), fit=dict(evidenceOnly=True)),
+    # 64 strips per chain (every lane of the scale wave gathers one granule), 4 chains per launch
+    'cres_128x1024_64_strips': _hyper(128, 1024, 65, 5, ('cint', 0.05, 0.9, 6)),
     # T = 1 and T = 2 (shorter than the lag)
     'cres_T1': _hyper(128, 32, 57, 1, ('cint', 0, 0.5, 3)),
     'cres_T2': _hyper(128, 32, 58, 2, ('cint', 0, 0.5, 3)),
@@ -882,7 +884,8 @@ def test_chain_resident_kernel_not_taken_outside_its_envelope():
     launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
     for c in (_hyper(128, 32, 62, 4, ('cint', 0.1, 2.0, 3)),
               dict(study='HyperStudy', data=('series', 63, 4), om=_g2(128, 32), tm=('GRW', 'sigma', ('cint', 0.1, 0.3, 3), 'std', None)),
-              _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3))):
+              _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3)),
+              _hyper(128, 1040, 66, 3, ('cint', 0.1, 0.5, 2))):          # 65 strips: more than one granule per lane
         S = cases.build(bl, c); S.fit(silent=True)
         assert S.lastTiming['fwd_kernel_variant'] != 6
         with np.errstate(all='ignore'):
