@@ -1728,7 +1728,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             F1.shared[SRC_UNIFORM] = d_uniform; F1.shared[SRC_INDEP] = d_indep;
             F1.taps = d_taps; F1.tap_off = d_off; F1.tap_lw = d_lw; F1.m1 = d_m1; F1.colA = d_colA; F1.rec = d_rec; F1.lik = d_lik;
         }
-        tr.mark("state alloc");
+        tr.mark("path setup");
         // --- forward pass (core.py:372-411) ---
         // the previous batch's fold goes to the second stream FIRST: queued behind this pass's launches it was not started before
         // they had all finished (measured: rocprofv3 time line), queued ahead of them it shares the chip with them
@@ -1787,7 +1787,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         ctx->pinF.ensure((size_t)T * B * NRED * 8);
         redF = ctx->pinF.as<double>();
         HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
+        tr.mark("forward pass queued");
         sync_stream(ctx, st);
+        tr.mark("forward pass done + sums D2H");
         ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
         ctx->timing.forward_ms += ms;
@@ -1803,6 +1805,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         }
 
         bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
+        tr.mark("forward checks + bookkeeping");
 
         // --- backward pass (core.py:424-470) ---
         invN.assign((size_t)B * T, 0.0);
@@ -1848,7 +1851,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->pinB.ensure((size_t)T * B * NRED * 8);
             redB = ctx->pinB.as<double>();
             HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
+            tr.mark("backward pass queued");
             sync_stream(ctx, st);
+            tr.mark("backward pass done + sums D2H");
             HIPCHECK(hipEventElapsedTime(&ms, ev[2], ev[3]));
             ctx->timing.backward_ms += ms;
             if (n_mfma[1] > 0 && n_mfma[1] >= n_fast[1]) ctx->timing.bwd_kernel_variant = 3;
@@ -1863,6 +1868,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 if (CR.fused && !CR.fold(E, redB)) { resident_failed = true; return false; }
             }
             raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O) && raw_ok;
+            tr.mark("backward checks + fused fold + bookkeeping");
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
                 for (int64_t t = 0; t < T; ++t) {
@@ -1874,7 +1880,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         return raw_ok || K == 1;
         };
-        tr.mark("passes");
         int64_t usedK = fusedK;
         if (!passes(fusedK)) {
             if (resident_failed) {                   // the launch-per-step kernels take over (timing of the failed attempt is dropped)
@@ -1920,7 +1925,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
             keep_posterior(ctx, g, T, B, O, row0, row1);
         }
-        tr.mark("accumulate / keep");
+        tr.mark("fold / keep / carry");
         write_results(res, p, c0, B, O, !evidence_only);
     }
     if (overlap_acc) {                         // the last fold(s) before anybody reads the accumulator; their time from their events

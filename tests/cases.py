@@ -68,6 +68,11 @@ def gauss2d(n, lo=-8, hi=8, smax=4):
 
 
 CASES = {
+    # four-parameter grid (tests/golden/nd4_reference.npz): scipy.stats.johnsonsu(a, b, loc, scale), walks on two of the parameters
+    'nd4_reference': dict(study='Study', data=('series', 96, 6),
+                          om=('SciPy:johnsonsu', [('a', _g('cint', -1.0, 1.0, 5)), ('b', _g('cint', 0.8, 2.5, 4)), ('loc', _g('cint', -2.0, 2.0, 11)),
+                                                  ('scale', _g('oint', 0.3, 2.0, 9))], 'default'),
+                          tm=('Combined', [('GRW', 's_loc', 0.5, 'loc', None), ('GRW', 's_b', 0.4, 'b', None)])),
     # three-parameter grid through the reference's SciPy plug-in (tests/golden/nd3_reference.npz)
     'nd3_reference': dict(study='Study', data=('series', 95, 8),
                           om=('SciPy:t', [('df', _g('cint', 2.0, 9.0, 5)), ('loc', _g('cint', -3.0, 3.0, 16)), ('scale', _g('oint', 0.2, 2.5, 12))], 'default'),

@@ -1004,14 +1004,17 @@ def test_three_and_four_parameter_grids_match_oracle(case):
             np.testing.assert_allclose(S.getParameterDistributions(name, density=False)[1], post.sum(axis=axes), rtol=1e-9, atol=1e-12)
 
 
-def test_three_parameter_grid_against_the_reference_golden():
-    """tests/golden/nd3_reference.npz: bl.om.SciPy(scipy.stats.t, df, loc, scale) with two random walks, fitted by the reference
-    itself in the build container (tests/golden/gen_golden.py)."""
+@pytest.mark.parametrize('case', ['nd3_reference', 'nd4_reference'])
+def test_three_and_four_parameter_grids_against_the_reference_goldens(case):
+    """tests/golden/nd3_reference.npz / nd4_reference.npz: bl.om.SciPy(scipy.stats.t, df, loc, scale) and
+    bl.om.SciPy(scipy.stats.johnsonsu, a, b, loc, scale) with two random walks each, fitted by the reference itself in the build
+    container (tests/golden/gen_golden.py)."""
     pytest.importorskip('scipy.stats')
-    gold = oa.load_golden('nd3_reference')
-    S = cases.build(bl, cases.CASES['nd3_reference'])
+    gold = oa.load_golden(case)
+    S = cases.build(bl, cases.CASES[case])
     S.fit(silent=True)
-    compare.check(result_of(S, 'nd3_reference'), gold, compare.GPU_TOL)
+    assert S.lastTiming['fwd_kernel_variant'] == 7
+    compare.check(result_of(S, case), gold, compare.GPU_TOL)
 
 
 def test_resident_paths_fall_back_when_a_block_gives_up():
