@@ -22,7 +22,13 @@ bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
     HIPCHECK(hipMemcpyAsync(h, d_abort, 4, hipMemcpyDeviceToHost, st));
     sync_stream(ctx, st);
     // (option resident_force_abort: the tests of the fall-back pretend that a block gave up)
-    if (*h != 0u || ctx->option("resident_force_abort", 0.0) != 0.0) { ctx->resident_ok = false; return true; }
+    if (*h != 0u || ctx->option("resident_force_abort", 0.0) != 0.0) {
+        if (ctx->resident_ok && ctx->option("quiet", 0.0) == 0.0)
+            std::fprintf(stderr, "[blhip] a resident launch gave up waiting for a peer block (its blocks were not all co-resident: a shared or "
+                                 "partitioned GPU?); this batch is repeated and the context continues with the launch-per-step kernels\n");
+        ctx->resident_ok = false;
+        return true;
+    }
     return false;
 }
 
