@@ -25,6 +25,9 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.0 < r['frac'] < 1.0
     assert abs(r['achieved'] - r['bytes_per_cell_step'] * r['cells_per_launch'] / (r['avg_launch_us'] * 1e-6) / 1e9) < 1e-6 * r['achieved']
-    assert r['traffic'] is None or r['traffic'] >= 0.9 * r['bytes_per_cell_step'] * r['cells_per_launch']      # HBM bytes per launch (PMC)
+    # HBM bytes per launch (PMC): a resident kernel moves LESS than the streaming formulation's algorithmic bytes (C4 backward + fold:
+    # 24 of 32 B per cell-step), never much more
+    alg = r['bytes_per_cell_step'] * r['cells_per_launch']
+    assert r['traffic'] is None or 0.2 * alg <= r['traffic'] <= 1.3 * alg
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == d['unit'] and c['value'] > 0 and c['sample']
