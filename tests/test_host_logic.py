@@ -383,3 +383,40 @@ def test_host_unlag_with_restarts_and_out_of_range_sums():
     bad = S.copy()
     bad[30] = 1e-200                                            # a run of extreme outliers: the fit falls back to the launch-per-step kernels
     assert lib.blhip_host_unlag(1, _abi.dptr(bad), T, lag, None, None) == 1
+
+
+# ---- observation models with three parameters: the Python surface (grid, program, accessors) through the test double -------------------
+
+def test_three_parameter_models_host_logic():
+    pytest.importorskip('scipy.stats')
+    om = ('SciPy:t', [('df', ('cint', 2.0, 9.0, 5)), ('loc', ('cint', -3.0, 3.0, 12)), ('scale', ('oint', 0.2, 2.5, 10))], 'default')
+    c = dict(study='Study', data=('series', 82, 8), om=om,
+             tm=('Combined', [('GRW', 's_loc', 0.6, 'loc', None), ('GRW', 's_scale', 0.25, 'scale', None)]))
+    S = cases.build(bl, c)
+    S.fit(silent=True)
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    assert list(S.gridSize) == [5, 12, 10] and len(S.grid) == 3 and S.grid[0].shape == (5, 12, 10)
+    assert abs(S.logEvidence - want['logEvidence']) <= 1e-12 * abs(want['logEvidence'])
+    np.testing.assert_allclose(np.asarray(S.posteriorSequence), want['posteriorSequence'], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(S.posteriorMeanValues, want['posteriorMeanValues'], rtol=1e-12)
+    for k, name in enumerate(S.observationModel.parameterNames):           # marginals of every parameter (core.py:915, 979-980)
+        axes = tuple(a + 1 for a in range(3) if a != k)
+        np.testing.assert_allclose(S.getParameterDistributions(name, density=False)[1], want['posteriorSequence'].sum(axis=axes), rtol=1e-12)
+    x, p = S.getParameterDistribution(3, 'loc', density=False)
+    np.testing.assert_allclose(p, want['posteriorSequence'][3].sum(axis=(0, 2)), rtol=1e-12)
+
+    h = dict(study='HyperStudy', data=('series', 89, 7), om=om, tm=('GRW', 's_loc', ('cint', 0, 1.2, 5), 'loc', None))
+    H = cases.build(bl, h)
+    H.fit(silent=True)
+    with np.errstate(all='ignore'):
+        wh = oa.run(h)
+    assert abs(H.logEvidence - wh['logEvidence']) <= 1e-12 * abs(wh['logEvidence'])
+    np.testing.assert_allclose(H.hyperParameterDistribution, wh['hyperParameterDistribution'], rtol=1e-10)
+    np.testing.assert_allclose(H.posteriorMeanValues, wh['posteriorMeanValues'], rtol=1e-10)
+
+    # transition models the N-D path does not run are refused BEFORE any device work (as every configuration problem)
+    bad = dict(study='Study', data=('series', 82, 6), om=om, tm=('RS', 'log10pMin', -4, None))
+    B = cases.build(bl, bad)
+    with pytest.raises(bl.exceptions.ConfigurationError):
+        B.fit(silent=True)
