@@ -76,6 +76,8 @@ struct ChainParams {
     const double *wchain;        // [B] weights (0: the chain does not contribute)
     const double *infirst;       // [B] 1 / sum of the posterior of the last time step
     double *part; long long part_stride;       // [slot][T][G]
+    const double *zeros;         // first launch of a batch (part_fresh): the slots hold nothing yet -- their cells are read from this 4 KB of
+    int part_fresh;              //   zeros instead (same instruction count: no memset of the slots, no HBM read of them in this launch)
     unsigned *abort_word;
     unsigned long long timeout_ticks;
     unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     double pa[4] = {0.0, 0.0, 0.0, 0.0};              // fold: the accumulator cells of the tile in flight, requested one tile ahead
     if (FOLD) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pa[r] = blm::ld32(pslot + (long long)t_first * G, cell_off(lane, 0, r));
+        for (int r = 0; r < 4; ++r) pa[r] = P.part_fresh ? blm::ld32(P.zeros, cell_off(lane, 0, r) & 4088u) : blm::ld32(pslot + (long long)t_first * G, cell_off(lane, 0, r));
     }
     bool dead = false;
     typedef const double __attribute__((address_space(3))) *lds_cp;
@@ -367,7 +369,12 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 // of this tile's cells for the next step
                 if (FOLD) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pa[r] = blm::ld32(it + 1 < NTW ? pslot_t : pslot_tn, cell_off(l, (it + 1) % NTW, r));
+                    for (int r = 0; r < 4; ++r) {
+                        // (one load instruction either way: base and offset are selected, not the instruction)
+                        const double *abase = P.part_fresh ? P.zeros : (it + 1 < NTW ? pslot_t : pslot_tn);
+                        const unsigned aoffs = cell_off(l, (it + 1) % NTW, r);
+                        pa[r] = blm::ld32(abase, P.part_fresh ? (aoffs & 4088u) : aoffs);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) al[it][r] = blm::ld32(pnext, cell_off(l, it, r));

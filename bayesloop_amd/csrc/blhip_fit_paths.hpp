@@ -187,7 +187,7 @@ struct ChainRun {
     // bandwidth unused: same bytes, one pass)
     bool fused = false;
     bool fold_done = false;                        // this batch's posteriors are in the accumulator already
-    double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr;
+    double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr, *d_zeros = nullptr;
     std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
     double fold_ref = -INFINITY;
 
@@ -222,11 +222,12 @@ struct ChainRun {
         fused = post_private && !cp.has_reset && ctx->option("fuse_accumulate", 1.0) != 0.0;
         if (fused) {
             ctx->accpart.ensure((size_t)cp.cpr * T * G * 8);
-            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8));
+            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(4096));
             char *wc = ctx->accw.as<char>();
             d_fold_sfwd = carve<double>(wc, (size_t)T * B);
             d_fold_w = carve<double>(wc, (size_t)B);
             d_fold_inf = carve<double>(wc, (size_t)B);
+            d_zeros = carve<double>(wc, 512);
         }
     }
 
@@ -253,6 +254,7 @@ struct ChainRun {
             if (fold_now) {
                 Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
                 Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * E.G;
+                Q.zeros = d_zeros; Q.part_fresh = r == 0 ? 1 : 0;          // (every slot is first used by the first launch: no memset)
             }
 #ifdef BLC_PROF
             ctx->small.ensure(2 * 16 * 16 * 8);
@@ -311,7 +313,12 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_fold_sfwd, h, (size_t)T * B * 8, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_fold_w, hw, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
-        HIPCHECK(hipMemsetAsync(ctx->accpart.p, 0, (size_t)cp.cpr * T * E.G * 8, E.st));
+        // the slots need no memset: the first launch of the pass reads zeros instead of them (part_fresh) -- except slots it does not
+        // use (a first launch with fewer chains than slots), which later launches may
+        const int first_n = cp.round_start[1] - cp.round_start[0];
+        if (first_n < std::min<int>(cp.cpr, (int)B))
+            HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * E.G, 0, (size_t)(std::min<int>(cp.cpr, (int)B) - first_n) * T * E.G * 8, E.st));
+        HIPCHECK(hipMemsetAsync(d_zeros, 0, 4096, E.st));
     }
 
     // after the backward pass: every strip made it and the lagged scale of the backward state stayed in range
