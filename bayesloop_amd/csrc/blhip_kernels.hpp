@@ -517,7 +517,13 @@ __global__ __launch_bounds__(NTHREADS) void accumulate2_kernel(double *A, const 
         for (int k = 0; k < 4; ++k) {
             wb[k] = w[b + k];
             nb[k] = invN[(long long)(b + k) * T + t];
-            v[k] = wb[k] > 0.0 ? *reinterpret_cast<const double2 *>(pp + (long long)(b + k) * chain_stride) : make_double2(0.0, 0.0);
+            if (wb[k] > 0.0) {                                   // (read once: non-temporal)
+                typedef double dv2 __attribute__((ext_vector_type(2)));
+                const dv2 q = __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(pp + (long long)(b + k) * chain_stride));
+                v[k] = make_double2(q.x, q.y);
+            } else {
+                v[k] = make_double2(0.0, 0.0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
