@@ -95,6 +95,8 @@ BLR_INL double ldexp_(double m, int n) { return std::ldexp(m, n); }
 BLR_INL double nan_() { return std::nan(""); }
 BLR_INL double ldu(const double *p, long long i) { return p[i]; }
 BLR_INL int uni(int x) { return x; }
+BLR_INL double ld_stream(const double *p) { return *p; }
+BLR_INL void st_stream(double *p, double v) { *p = v; }
 #else
 typedef unsigned long long __attribute__((address_space(1))) gu64;
 typedef unsigned __attribute__((address_space(1))) gu32;
@@ -120,6 +122,9 @@ BLR_INL double nan_() { return __builtin_nan(""); }
 // wave-uniform read-only values (stencil weights, the step's data record) through the scalar cache: SGPRs, not VGPRs
 BLR_INL double ldu(const double *p, long long i) { return ((const double __attribute__((address_space(4))) *)(unsigned long long)p)[i]; }
 BLR_INL int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }       // a block-uniform value: SGPR
+// the stored sequence is written / read once per pass (C3: 16 GiB): non-temporal hints keep it from sweeping the caches
+BLR_INL double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
+BLR_INL void st_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
 #endif
 
 // bounded wait for an epoch flag; false = timed out / another block gave up (the caller marks the block dead)
@@ -477,7 +482,7 @@ struct Res {
         BLR_INL void load_alpha8(const double *pt0, const double *ptn0, long long n1, int p0) {
             if (BWD) {
 #pragma unroll
-                for (int j = 0; j < CHK; ++j) al8[j] = pt0[(long long)(DIR * (p0 + j)) * n1];
+                for (int j = 0; j < CHK; ++j) al8[j] = ld_stream(pt0 + (long long)(DIR * (p0 + j)) * n1);
             }
             if (!BWD && ptn0) {                      // the row `lag` steps back, to be normalised in this step
 #pragma unroll
@@ -530,7 +535,7 @@ struct Res {
                 if (!BWD) {
                     const double a = v[j] * scale * Lv;
                     keep = a;
-                    if (Q.store) pt0[(long long)(DIR * p) * Q.n1] = a;
+                    if (Q.store) st_stream(pt0 + (long long)(DIR * p) * Q.n1, a);
                     sums[0] += a;
                     if (Q.means) { sums[3] = fma(a, m0p[DIR * p], sums[3]); sums[4] = fma(a, g1, sums[4]); }
                 } else {
@@ -540,7 +545,7 @@ struct Res {
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
                     const double pl = Lv == 0.0 ? nan_() : ldexp_(pp * rc.iE, -rc.nE);
                     keep = cn;
-                    pt0[(long long)(DIR * p) * Q.n1] = pp * invn;            // (invn = 1 / predicted sum: stored normalised)
+                    st_stream(pt0 + (long long)(DIR * p) * Q.n1, pp * invn);   // (invn = 1 / predicted sum: stored normalised)
                     sums[0] += pp; sums[1] += pl; sums[2] += cn;
                     sums[3] = fma(pp, m0p[DIR * p], sums[3]); sums[4] = fma(pp, g1, sums[4]);
                 }
