@@ -78,6 +78,9 @@ __device__ __forceinline__ double block_sum_w(double v, double *red) {
 // generic addressing / masking was ~30 % of the non-MFMA instructions of a tile.
 __device__ __forceinline__ double ld32(const double *base, unsigned byteoff) { return *(const double *)((const char *)base + byteoff); }
 __device__ __forceinline__ void st32(double *base, unsigned byteoff, double v) { *(double *)((char *)base + byteoff) = v; }
+// the same with a non-temporal hint: what a launch writes or reads ONCE (new state, stored alpha, posterior)
+__device__ __forceinline__ double ld32nt(const double *base, unsigned byteoff) { return __builtin_nontemporal_load((const double *)((const char *)base + byteoff)); }
+__device__ __forceinline__ void st32nt(double *base, unsigned byteoff, double v) { __builtin_nontemporal_store(v, (double *)((char *)base + byteoff)); }
 
 template <int OM, int MODE, int NK, bool REC, bool H, bool LEAN>
 __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastParams P) {
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
             if (BWD) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    al[(u + 1) & 1][r] = LEAN ? ld32(pbase, __umul24(min(i + TM + g + 4 * r, P.n0 - 1), n1x8) + gj8)
+                    al[(u + 1) & 1][r] = LEAN ? ld32nt(pbase, __umul24(min(i + TM + g + 4 * r, P.n0 - 1), n1x8) + gj8)
                                               : pcol[(long long)min(i + TM + g + 4 * r, P.n0 - 1) * rs];
             }
             if (!GAUSS) {
@@ -338,12 +341,12 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
                 if (LEAN) {
                     const unsigned off = __umul24(gi, n1x8) + gj8;
                     if (!BWD) {
-                        st32(dbase, off, st1[r]);
+                        st32nt(dbase, off, st1[r]);
                     } else {
                         // the posterior overwrites the stored alpha IN PLACE: a lane past the last column must not touch
                         // column n1 - 1 (another wave may own it and be at a different tile); the state store is idempotent
-                        *(owner ? (double *)((char *)pbase + off) : dump) = st1[r];
-                        st32(dbase, off, st2[r]);
+                        __builtin_nontemporal_store(st1[r], owner ? (double *)((char *)pbase + off) : dump);
+                        st32nt(dbase, off, st2[r]);
                     }
                 } else {
                     const bool live = gi < i_hi;
