@@ -717,8 +717,8 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
         {
             constexpr int NV = BWD ? 5 : 3;
             double v[NV];
-            if (BWD) { v[0] = th.sums[0]; v[1] = th.sums[1]; v[2] = th.sums[2]; v[3] = th.sums[3]; v[4] = th.sums[4]; }
-            else { v[0] = th.sums[0]; v[1] = th.sums[3]; v[2] = th.sums[4]; }
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] = th.sums[BWD ? q : (q == 0 ? 0 : q + 2)];      // forward: N, M0, M1
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 if (!BWD && q > 0 && !Q.means) break;
