@@ -12,7 +12,7 @@ import os
 from .exceptions import BackendError
 
 LIB_NAME = 'libblhip.so'
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
 OM_BERNOULLI, OM_LAPLACE, OM_WHITE_NOISE, OM_AR1, OM_SCALED_AR1 = 4, 5, 6, 7, 8
@@ -60,6 +60,8 @@ class Timing(C.Structure):
         ('forward_launches', C.c_int64), ('backward_launches', C.c_int64), ('accumulate_launches', C.c_int64),
         ('cells_per_launch', C.c_int64), ('batches', C.c_int64),
         ('fwd_kernel_variant', C.c_int32), ('bwd_kernel_variant', C.c_int32),
+        ('fwd_hbm_bytes', C.c_double), ('bwd_hbm_bytes', C.c_double), ('fwd_flops', C.c_double), ('bwd_flops', C.c_double),
+        ('resident_fallbacks', C.c_int32), ('resident_armed', C.c_int32),
     ]
 
     def as_dict(self):

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <chrono>
 #include <thread>
@@ -33,6 +35,19 @@ using namespace blk;
 #include "blhip_comm.hpp"
 
 namespace {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: a process that drives several GPUs (HyperStudy.fit(nJobs = N):
+// one context and one host thread per device) has to arm every kernel on every device it launches it on
+void arm_kernel(const void *fn, int bytes = 160 * 1024) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> armed;
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (armed.count({dev, fn})) return;
+    HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    armed.insert({dev, fn});
+}
 
 struct TapTable {
     std::vector<double> w;       // concatenated half kernels: w[off + k], k = 0..lw
@@ -195,12 +210,7 @@ Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1) {
 
 template <int OM, int MODE, bool MEANS>
 void launch_step_t(hipStream_t s, const StepParams &P, const Tile &t, int B) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<OM, MODE, MEANS>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    arm_kernel(reinterpret_cast<const void *>(&step_kernel<OM, MODE, MEANS>));
     hipLaunchKernelGGL((step_kernel<OM, MODE, MEANS>), dim3(t.nblk, B), dim3(NTHREADS), t.lds_bytes, s, P);
 }
 
@@ -359,12 +369,10 @@ void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, i
 template <int OM>
 void launch_persist_om(hipStream_t s, const bl1::P1Params &P, bool bwd, size_t lds) {
     if (bwd) {
-        static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        arm_kernel(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, true>));
         hipLaunchKernelGGL((bl1::persist1d_kernel<OM, true>), dim3(P.B), dim3(bl1::NT), lds, s, P);
     } else {
-        static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        arm_kernel(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, false>));
         hipLaunchKernelGGL((bl1::persist1d_kernel<OM, false>), dim3(P.B), dim3(bl1::NT), lds, s, P);
     }
 }
@@ -384,12 +392,10 @@ template <int OM>
 void launch_fused1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
     const dim3 grid(P.nblk, P.B), block(bl1f::NT);
     if (bwd) {
-        static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        arm_kernel(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, true>));
         hipLaunchKernelGGL((bl1f::fused1d_kernel<OM, true>), grid, block, lds, s, P);
     } else {
-        static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        arm_kernel(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, false>));
         hipLaunchKernelGGL((bl1f::fused1d_kernel<OM, false>), grid, block, lds, s, P);
     }
 }
@@ -418,12 +424,10 @@ template <int TR, int TC, int SEG, int CHK>
 void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd) {
     const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, false>::LDS_DOUBLES * sizeof(double);
     if (bwd) {
-        static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, true>));
         hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, true>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
     } else {
-        static bool a = false;
-        if (!a) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a = true; }
+        arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, false>));
         hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, false>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
     }
 }
@@ -442,19 +446,18 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
 
 // ---- chain-resident kernel (blhip_chainres.hpp) ---------------------------------------------------------------------------------
 template <typename KernT>
-void launch_chain_fn(KernT kern, bool &armed, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
-    if (!armed) { HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); armed = true; }
+void launch_chain_fn(KernT kern, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
+    arm_kernel(reinterpret_cast<const void *>(kern));
     hipLaunchKernelGGL(kern, dim3((unsigned)(Q.nslots * Q.strips)), dim3(blc::NT), lds, s, Q);
 }
 
 template <int NK, int NTW>
 void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
-    static bool armed[4] = {false, false, false, false};
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
-    if (bwd && !store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false>, armed[3], s, Q, lds);      // posteriors folded, not stored
-    else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true>, armed[0], s, Q, lds);
-    else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true>, armed[1], s, Q, lds);
-    else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false>, armed[2], s, Q, lds);
+    if (bwd && !store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false>, s, Q, lds);      // posteriors folded, not stored
+    else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true>, s, Q, lds);
+    else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true>, s, Q, lds);
+    else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false>, s, Q, lds);
 }
 
 template <int NTW>
@@ -957,8 +960,14 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
     const long long G = g.G;
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
-    const double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap + (double)ctx->post2.cap,
-                                   ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
+    double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap + (double)ctx->post2.cap,
+                             ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
+    // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per chain of a launch) come out of the same memory
+    if (ff.accumulate && ff.full && g.n1 % blc::WCOL == 0 && g.n1 >= blc::WCOL) {
+        const double slots = std::max(1, std::min(ctx->num_cus, 256) / (g.n1 / blc::WCOL));
+        budget -= std::max(0.0, std::min<double>(slots, (double)n_chains) * (double)T * (double)G * 8.0 - (double)ctx->accpart.cap);
+        budget = std::max(budget, 0.0);
+    }
     const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * (double)G * 8.0 +
                              (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
     int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
@@ -1436,6 +1445,21 @@ bool backward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, cons
     return raw_ok;
 }
 
+// ---- what the launches move and compute BY CONSTRUCTION (blhip_timing: fwd / bwd _hbm_bytes, _flops) ------------------------------------
+// fp64 flop per cell of the fused epilogues (FMA = 2; ldexp, compare and select count 1): forward  a = v L (1), sum (1), the two
+// recurrence products (2), ldexp (1) + the exponentials of the anchors spread over their rows (2 x ~42 flop per 16 rows: 5);
+// backward: beta, p, c (3), p / L by the reciprocal recurrence (2), three sums (3), the fold's product, max, add (3), four recurrence
+// products (4), ldexp (1) + four exponentials per 16 rows (10)
+constexpr double EPI_FWD_FLOP = 10.0, EPI_BWD_FLOP = 26.0;
+// a radius-r stencil pass per cell: on the vector ALU (SciPy's pair order) r adds + 1 product + r FMAs; as a banded product on the
+// matrix pipe (16 output rows per tile) 16 + 2 r products, zeros of the band included
+inline double valu_stencil_flop(int r) { return r > 0 ? 3.0 * r + 1.0 : 0.0; }
+inline double band_stencil_flop(int r) { return 2.0 * (16.0 + 2.0 * r); }
+inline void account(blhip_ctx *ctx, bool bwd, double bytes, double flops) {
+    (bwd ? ctx->timing.bwd_hbm_bytes : ctx->timing.fwd_hbm_bytes) += bytes;
+    (bwd ? ctx->timing.bwd_flops : ctx->timing.fwd_flops) += flops;
+}
+
 #include "blhip_fit_nd.hpp"       // do_fit_nd: grids with 3 and 4 parameters
 #include "blhip_fit_paths.hpp"    // BatchEnv, ResidentRun, ChainRun: the resident paths of a batch
 
@@ -1468,6 +1492,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
     ctx->post_valid = false;
     ctx->timing = blhip_timing{};
+    // a context whose resident launch once gave up tries the resident paths again after a while (one hiccup -- another process
+    // holding CUs -- must not cost 1.4 - 2 x for the life of the process); the wait doubles with every give-up in a row
+    if (!ctx->resident_ok && ++ctx->resident_fits_since >= ctx->resident_retry_after) {
+        ctx->resident_ok = true;
+        ctx->resident_fits_since = 0;
+    }
 
     // ---- shared tables -> HBM ---------------------------------------------------------------------------------------------------
     const DeviceTables DT = upload_tables(ctx, p, g, ff, table_model);
@@ -1622,6 +1652,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         E.ctx = ctx; E.p = p; E.st = st; E.g = g; E.G = G; E.T = T; E.B = B; E.c0 = c0; E.d = d; E.rec_len = rec_len; E.ff = ff;
         E.DT = &DT; E.M = &M; E.prog = &prog; E.taps = &taps; E.step0 = FP.step0; E.d_post = d_post; E.log_w = log_w;
         E.chain_means = res && res->posterior_mean;
+        E.overlap_acc = overlap_acc;
         ResidentRun RR;
         RR.setup(E, n_chains, fast, FP.use_rec != 0, psz);
         ChainRun CR;
@@ -1691,8 +1722,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                         Q.u_t1 = k1; Q.u_lw1 = k1 >= 0 ? taps.lw[k1] : 0; Q.u_off1 = k1 >= 0 ? taps.off[k1] : 0;
                     }
                     hipStream_t ls = multistream ? ctx->bstream[r.key] : st;
-                    if (use_mfma && (r.H ? (mfma_h && (double)r.count * g.n0 * g.n1 <= mfma_h_max_cells) : r.R0 >= mfma_min_r0)) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }
+                    const bool on_pipe = use_mfma && (r.H ? (mfma_h && (double)r.count * g.n0 * g.n1 <= mfma_h_max_cells) : r.R0 >= mfma_min_r0);
+                    if (on_pipe) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }
                     else { launch_fast(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_fast[mode == MODE_FWD ? 0 : 1]; }
+                    // streaming kernels: state in, state out (+ stored alpha in, posterior out backward; + a tabulated likelihood)
+                    const bool bw = mode != MODE_FWD;
+                    const double fl = (on_pipe ? (r.R0 > 0 ? band_stencil_flop(r.R0) : 0.0) + (r.H ? band_stencil_flop(8) : 0.0)
+                                               : valu_stencil_flop(r.R0) + (r.H ? valu_stencil_flop(8) : 0.0)) + (bw ? EPI_BWD_FLOP : EPI_FWD_FLOP);
+                    account(ctx, bw, (double)r.count * G * ((bw ? 32.0 : 16.0) + (d_lik ? 8.0 : 0.0)), (double)r.count * G * fl);
                 }
             } else {
                 StepParams Q = P;
@@ -1706,6 +1743,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 Q.psum_prev = ps_prev; Q.prev_slot = prev_slot; Q.psum_out = ps_out;
                 Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
                 launch_step(st, p->obs_model, Q, tile, (int)B, mode, means);
+                const bool bw = mode != MODE_FWD;
+                account(ctx, bw, (double)B * G * ((bw ? 32.0 : 16.0) + (d_lik ? 8.0 : 0.0)),
+                        (double)B * G * (valu_stencil_flop(prog.LW0) + valu_stencil_flop(prog.LW1) + (bw ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
             }
         };
 
@@ -1759,6 +1799,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 launch_fused1d(st, p->obs_model, Q, false, f1_lds(Q.K));
             }
         }
+        if (persist || fused1d)        // 1-D paths: a row in, a row out per step (the K-steps-per-launch kernel re-reads only halos)
+            account(ctx, false, (double)B * G * T * (16.0 + (d_lik ? 8.0 : 0.0)), (double)B * G * T * (valu_stencil_flop(prog.LW1) + EPI_FWD_FLOP));
         const bool res_now = resident && !resident_failed;
         const bool cres_now = chainres && !resident_failed;
         const int nblk_now = res_now ? RR.nblk : (cres_now ? CR.cp.strips : tile.nblk);      // partial-sum slots per (step, sum) of this pass
@@ -1832,6 +1874,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     launch_fused1d(st, p->obs_model, Q, true, f1_lds(Q.K));
                 }
             }
+            if (persist || fused1d)
+                account(ctx, true, (double)B * G * T * (32.0 + (d_lik ? 8.0 : 0.0)), (double)B * G * T * (valu_stencil_flop(prog.LW1) + EPI_BWD_FLOP));
             if (res_now) RR.launch(E, true, d_psB);
             if (cres_now && CR.fused) CR.prepare_fold(E, O);
             if (cres_now) CR.pass(E, true, d_psB);
@@ -1883,12 +1927,16 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         int64_t usedK = fusedK;
         if (!passes(fusedK)) {
             if (resident_failed) {                   // the launch-per-step kernels take over (timing of the failed attempt is dropped)
+                ctx->timing.resident_fallbacks += 1;
                 ctx->timing.forward_ms = ctx->timing.backward_ms = 0.0;
+                ctx->timing.fwd_hbm_bytes = ctx->timing.bwd_hbm_bytes = ctx->timing.fwd_flops = ctx->timing.bwd_flops = 0.0;
                 ctx->timing.forward_launches = ctx->timing.backward_launches = 0;
                 ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = 1;
                 n_mfma[0] = n_mfma[1] = n_fast[0] = n_fast[1] = 0;
                 if (!passes(fusedK)) fail("internal: the launch-per-step pass failed after the resident pass gave up");
             } else { usedK = 1; passes(1); }
+        } else if (resident || chainres) {
+            ctx->resident_retry_after = 8;           // a resident pass went through: the next give-up starts from the short wait again
         }
 
         // --- carried states / average posterior / kept posterior / results ---
@@ -2042,7 +2090,8 @@ int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
     if (!ctx || !key) return -1;
     // "resident_ok": the context's memory of a resident launch that gave up (its blocks were not all co-resident) -- settable so that
     // a caller (the tests of the fall-back) can re-arm the resident paths
-    if (std::strcmp(key, "resident_ok") == 0) { ctx->resident_ok = value != 0.0; return 0; }
+    if (std::strcmp(key, "resident_ok") == 0) { ctx->resident_ok = value != 0.0; ctx->resident_fits_since = 0; if (value != 0.0) ctx->resident_retry_after = 8; return 0; }
+    if (std::strcmp(key, "resident_retry_after") == 0) { ctx->resident_retry_after = std::max(1, (int)value); return 0; }
     ctx->opt[key] = value;
     return 0;
 }
@@ -2065,7 +2114,7 @@ int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double 
         HIPCHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
         const long long n2 = bytes / 16;
-        DevBuf a, b;
+        ScopedDevBuf a, b;          // (released on every exit path, also when a HIPCHECK below throws)
         a.ensure((size_t)n2 * 16); b.ensure((size_t)n2 * 16);
         hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, a.as<double>(), n2 * 2, 1.0);
         const unsigned gx = (unsigned)((n2 + 4 * NTHREADS - 1) / (4 * NTHREADS));
@@ -2086,13 +2135,13 @@ int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double 
             best = std::max(best, 2.0 * (double)n2 * 16.0 * iterations / ((double)ms * 1e-3) / 1e9);
         }
         *gb_per_s = best;
-        a.release(); b.release();
     });
 }
 
 int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out) {
     if (!ctx || !out) return -1;
     *out = ctx->timing;
+    out->resident_armed = ctx->resident_ok ? 1 : 0;
     return 0;
 }
 

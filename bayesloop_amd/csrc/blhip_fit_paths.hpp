@@ -13,7 +13,14 @@ struct BatchEnv {
     double *d_post;               // the batch's sequence buffer (null: evidence-only)
     const double *log_w;          // log weights of ALL chains of the call (accumulate)
     bool chain_means;             // the caller asked for per-chain posterior means
+    bool overlap_acc;             // folds of earlier batches may still run on the second stream (option accum_overlap)
 };
+
+// The resident backward kernels normalise every posterior by a PREDICTED sum (self-adjoint stencil identity); the host accepts the
+// batch only if the prediction reproduces the reduced sums to this relative tolerance, three decades inside the parity bar of the
+// posteriors (1e-9) -- the prediction is a running product of two rounded factors per step, so its error grows with the number of
+// steps: a few ulp per step at worst (observed ~1e-14 at T = 2000); else: the launch-per-step kernels
+inline double pred_rtol(int64_t T) { return 1e-12 + 2e-15 * (double)T; }
 
 // did a block of a resident launch time out waiting for a peer (not every block co-resident)?  -> the context stops using the paths
 bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
@@ -27,6 +34,9 @@ bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
             std::fprintf(stderr, "[blhip] a resident launch gave up waiting for a peer block (its blocks were not all co-resident: a shared or "
                                  "partitioned GPU?); this batch is repeated and the context continues with the launch-per-step kernels\n");
         ctx->resident_ok = false;
+        ctx->resident_fits_since = 0;
+        ctx->resident_giveups += 1;
+        if (ctx->resident_giveups > 1) ctx->resident_retry_after = std::min(1024, 2 * ctx->resident_retry_after);
         return true;
     }
     return false;
@@ -99,7 +109,6 @@ struct ResidentRun {
 
     void launch(const BatchEnv &E, bool bwd, double *psum) {
         blhip_ctx *ctx = E.ctx;
-        (void)ctx;                                     // (only the profiling build touches it here)
         hipStream_t st = E.st;
         const int64_t T = E.T;
         blr::ResParams Q = RQ;
@@ -126,6 +135,11 @@ struct ResidentRun {
         Q.prof = ctx->small.as<unsigned long long>();
 #endif
         launch_resident(st, rp, Q, bwd);
+        {   // HBM: the halo strips (2 R rows + 2 R columns of every tile, written and read once per step) + what the fit keeps
+            const double halo = 2.0 * 8.0 * 2.0 * blr::R * (rp.TR + rp.TC) / ((double)rp.TR * rp.TC);
+            const double kept = bwd ? 16.0 : (Q.store ? 8.0 : 0.0) + (Q.normalise ? 16.0 : 0.0);
+            account(ctx, bwd, (double)E.G * T * (halo + kept), (double)E.G * T * (2.0 * valu_stencil_flop(blr::R) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
+        }
 #ifdef BLR_PROF
         {   // development build: where a step of one interior tile spends its time (shader-clock cycles between stamps)
             unsigned long long hh[2 * 16 * 16];
@@ -164,7 +178,7 @@ struct ResidentRun {
             const int64_t k = T - 1 - t;
             if (k > 0) npred = (k >= RQ.lag ? 1.0 / redB[(size_t)(t + RQ.lag) * NRED + 2] : 1.0) * npred / sfwd[t + 1];
             const double Nt = redB[(size_t)t * NRED];
-            if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
+            if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) return false;
         }
         return true;
     }
@@ -219,9 +233,11 @@ struct ChainRun {
         CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
         post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
-        fused = post_private && !cp.has_reset && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        // (not beside overlapped folds: a FoldJob of the previous batch may still read ctx->accw and read-modify-write ctx->acc on the
+        //  second stream while this batch re-carves accw and its fused fold writes ctx->acc on the main stream)
+        fused = post_private && !cp.has_reset && !E.overlap_acc && ctx->option("fuse_accumulate", 1.0) != 0.0;
         if (fused) {
-            ctx->accpart.ensure((size_t)cp.cpr * T * G * 8);
+            ctx->accpart.ensure((size_t)std::min<int64_t>(cp.cpr, B) * T * G * 8);
             ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(4096));
             char *wc = ctx->accw.as<char>();
             d_fold_sfwd = carve<double>(wc, (size_t)T * B);
@@ -262,6 +278,13 @@ struct ChainRun {
             Q.prof = ctx->small.as<unsigned long long>();
 #endif
             launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
+            {   // HBM: only what the fit keeps -- forward the stored state (8 B; nothing for evidence-only fits), backward the stored
+                // state in + the posterior out (16 B) or + the read-modify-write of the partial accumulator (24 B)
+                const double cells = (double)Q.nslots * E.G * T;
+                const double bytes = bwd ? (fold_now ? 24.0 : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
+                const int r0 = (4 * cp.round_nk[r] - blc::TM) / 2;
+                account(ctx, bwd, cells * bytes, cells * ((cp.round_nk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
+            }
 #ifdef BLC_PROF
             {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
                 unsigned long long hh[2 * 16 * 16];
@@ -351,7 +374,7 @@ struct ChainRun {
                 const int64_t t = T - 1 - k;
                 if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
                 const double Nt = redB[((size_t)t * B + b) * NRED];
-                if (!(std::fabs(npred - Nt) <= 1e-9 * Nt)) return false;
+                if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) return false;
             }
         }
         if (std::isfinite(fold_ref)) {

@@ -51,6 +51,14 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// a DevBuf that is not a member of the context: released when the scope is left, also by an exception (HIPCHECK throws)
+struct ScopedDevBuf : DevBuf {
+    ScopedDevBuf() = default;
+    ScopedDevBuf(const ScopedDevBuf &) = delete;
+    ScopedDevBuf &operator=(const ScopedDevBuf &) = delete;
+    ~ScopedDevBuf() { release(); }
+};
+
 // page-locked host staging: a hipMemcpyAsync to / from pageable memory is staged by the runtime behind blocking waits whose
 // wake-up is quantised (10-ms steps seen on a 6 KB read-back: 20-27 ms per call instead of 0.5 ms)
 struct PinBuf {
@@ -116,6 +124,10 @@ struct blhip_ctx {
     // time-resident path (blhip_resident.hpp): halo strips / flags, and whether every tile was co-resident so far
     DevBuf resx;
     bool resident_ok = true;
+    // a resident launch that gave up (its blocks were not all co-resident: another process held CUs) parks the resident paths; they
+    // are tried again after `resident_retry_after` further fits, and the wait doubles with every give-up in a row (8, 16, ... 1024)
+    int resident_retry_after = 8, resident_fits_since = 0;
+    long long resident_giveups = 0;
     int num_cus = 0;
     // average posterior folded on a second stream while the next batch's forward pass runs (do_fit): second sequence buffer,
     // private copies of the per-batch weights, the stream and its events

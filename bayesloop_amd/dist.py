@@ -38,60 +38,165 @@ SUM, MAX, MIN = 0, 1, 2
 _comm_counter = 0
 
 
-# ---- rendezvous of the 128-byte RCCL unique id: a file on the node (the ranks of one node share /tmp) ---------------------
-def _rendezvous_path(key=None):
-    """Every rank of one job derives the same path: an explicit key (``BLHIP_RDZV_KEY``; bench.py's self-launch sets a fresh
-    one per run) or, under a generic one-process-per-GPU launcher, the launcher's pid (the parent of all
-    ranks) + MASTER_PORT + restart count; a per-process counter keeps several communicators of one job apart."""
-    global _comm_counter
-    _comm_counter += 1
+# ---- rendezvous of the 128-byte RCCL unique id: files in a PRIVATE directory of this user on the node -----------------------
+# Protocol (every file is created O_EXCL | O_NOFOLLOW with mode 0600 under a temporary name and renamed into place):
+#   rank 0   removes what an earlier job may have left under this key, publishes  id    = [nonce N | unique id]
+#   rank r   draws a token R_r of its own, reads id, publishes                    ack.r = [N | R_r]
+#   rank 0   waits for every ack that carries ITS nonce, publishes                go    = [N | R_1 ... R_(n-1)]
+#   rank r   proceeds only once go carries the nonce it read AND its own token; anything else (a left-over id or go file of a
+#            crashed job with the same key, read before rank 0 replaced it) is ignored and polled past.
+# A stale or planted file therefore never reaches ncclCommInitRank; the communicator init itself is bounded by a timeout.
+NONCE_BYTES = 16
+ID_BYTES = 128
+
+
+def _rendezvous_dir():
+    """A directory only this user can write: $BLHIP_RDZV_DIR, else $XDG_RUNTIME_DIR/blhip, else /tmp/blhip-<uid> (0700, owner and
+    mode verified, symlinks refused)."""
+    d = os.environ.get('BLHIP_RDZV_DIR')
+    if d is None:
+        base = os.environ.get('XDG_RUNTIME_DIR')
+        d = os.path.join(base, 'blhip') if base and os.path.isdir(base) and os.access(base, os.W_OK) else '/tmp/blhip-%d' % os.getuid()
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise BackendError('rendezvous directory %s is not a private directory of this user (owner %d, mode %o)'
+                           % (d, st.st_uid, st.st_mode & 0o777))
+    return d
+
+
+def _rendezvous_key(key=None):
+    """Every rank of one job derives the same key: an explicit one (``BLHIP_RDZV_KEY``; bench.py's self-launch sets a fresh one per
+    run); under a launcher that exports MASTER_ADDR / MASTER_PORT (torch.distributed.run and friends) those + the restart count
+    + the run id; else the parent's pid (ranks forked by one launcher process)."""
     if key is None:
         key = os.environ.get('BLHIP_RDZV_KEY')
+    if key is None and os.environ.get('MASTER_PORT'):
+        key = 'm%s_%s_%s_%s' % (os.environ.get('MASTER_ADDR', 'localhost'), os.environ['MASTER_PORT'],
+                                os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'))
     if key is None:
-        key = 'p%d_%s_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
-    d = os.environ.get('BLHIP_RDZV_DIR', '/tmp')
-    return os.path.join(d, 'blhip_rdzv_%s_%d' % (key, _comm_counter))
+        key = 'p%d' % os.getppid()
+    return ''.join(c if c.isalnum() or c in '-_.' else '_' for c in str(key))
+
+
+def _rendezvous_path(key=None):
+    global _comm_counter
+    _comm_counter += 1              # (a per-process counter keeps several communicators of one job apart)
+    return os.path.join(_rendezvous_dir(), 'rdzv_%s_%d' % (_rendezvous_key(key), _comm_counter))
+
+
+def _publish(path, payload):
+    tmp = '%s.tmp%d' % (path, os.getpid())
+    try:
+        os.unlink(tmp)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+    try:
+        os.write(fd, payload)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def _read(path, nbytes):
+    try:
+        fd = os.open(path, os.O_RDONLY | getattr(os, 'O_NOFOLLOW', 0))
+    except OSError:
+        return None
+    try:
+        raw = os.read(fd, nbytes + 1)
+    finally:
+        os.close(fd)
+    return raw if len(raw) == nbytes else None
 
 
 def exchange_unique_id(lib, rank, world, key=None, timeout=300.0):
-    """Rank 0 creates the id (``blhip_comm_unique_id`` = ncclGetUniqueId) and publishes it atomically; the others poll."""
-    nbytes = 128
+    """Rank 0 creates the id (``blhip_comm_unique_id`` = ncclGetUniqueId); -> (id bytes, list of files rank 0 removes once every
+    rank has joined the communicator)."""
     if world == 1:
-        buf = C.create_string_buffer(nbytes)
+        buf = C.create_string_buffer(ID_BYTES)
         if lib.blhip_comm_unique_id(buf) != 0:
             raise BackendError(lib.blhip_last_error(None).decode())
-        return buf.raw, None
+        return buf.raw, []
     path = _rendezvous_path(key)
+    ack = lambda r: '%s.ack%d' % (path, r)
+    go = path + '.go'
     t_start = time.time()
+
+    def expired(what):
+        if time.time() - t_start > timeout:
+            raise BackendError('rank %d: %s at %s after %.0f s (are all %d ranks running with the same rendezvous key?)'
+                               % (rank, what, path, timeout, world))
+        time.sleep(0.005)
+
     if rank == 0:
-        buf = C.create_string_buffer(nbytes)
+        for f in [path, go] + [ack(r) for r in range(1, world)]:          # left-overs of an earlier job with this key
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        buf = C.create_string_buffer(ID_BYTES)
         if lib.blhip_comm_unique_id(buf) != 0:
             raise BackendError(lib.blhip_last_error(None).decode())
-        tmp = '%s.tmp%d' % (path, os.getpid())
-        with open(tmp, 'wb') as f:
-            f.write(buf.raw)
-        os.replace(tmp, path)
-        return buf.raw, path
+        nonce = os.urandom(NONCE_BYTES)
+        _publish(path, nonce + buf.raw)
+        tokens = {}
+        while len(tokens) < world - 1:
+            for r in range(1, world):
+                if r not in tokens:
+                    raw = _read(ack(r), 2 * NONCE_BYTES)
+                    if raw is not None and raw[:NONCE_BYTES] == nonce:
+                        tokens[r] = raw[NONCE_BYTES:]
+            if len(tokens) < world - 1:
+                expired('only %d of %d ranks answered' % (len(tokens), world - 1))
+        _publish(go, nonce + b''.join(tokens[r] for r in range(1, world)))
+        return buf.raw, [path, go] + [ack(r) for r in range(1, world)]
+    token = os.urandom(NONCE_BYTES)
+    acked = None
     while True:
+        raw = _read(path, NONCE_BYTES + ID_BYTES)
+        if raw is not None:
+            nonce = raw[:NONCE_BYTES]
+            if nonce != acked:
+                _publish(ack(rank), nonce + token)
+                acked = nonce
+            g = _read(go, NONCE_BYTES * world)
+            if g is not None and g[:NONCE_BYTES] == nonce and g[NONCE_BYTES * rank:NONCE_BYTES * (rank + 1)] == token:
+                return raw[NONCE_BYTES:], []
+        expired('no confirmed RCCL unique id')
+
+
+def _bounded(fn, timeout, what):
+    """Run fn() in a helper thread and give up after `timeout` seconds (ncclCommInitRank waits for ever for a rank that never
+    comes); the stuck thread is left behind -- the caller is expected to end the process."""
+    import threading
+    box = {}
+
+    def run():
         try:
-            # a left-over of an earlier job with the same key cannot be newer than this process minus the launch skew
-            if os.path.getmtime(path) >= t_start - 600.0:
-                with open(path, 'rb') as f:
-                    raw = f.read()
-                if len(raw) == nbytes:
-                    return raw, None
-        except OSError:
-            pass
-        if time.time() - t_start > timeout:
-            raise BackendError('rank %d: no RCCL unique id at %s after %.0f s (is rank 0 running?)' % (rank, path, timeout))
-        time.sleep(0.01)
+            box['value'] = fn()
+        except BaseException as e:          # noqa: BLE001 -- handed to the caller
+            box['error'] = e
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        raise BackendError('%s did not return within %.0f s' % (what, timeout))
+    if 'error' in box:
+        raise box['error']
+    return box.get('value')
 
 
 class RcclCommunicator:
     """RCCL communicator of this process's GPU context, one rank per GPU (ranks / world size from the arguments or from the
     launcher's RANK / WORLD_SIZE).  Collective: every rank of the job must construct it."""
 
-    def __init__(self, engine=None, rank=None, world=None, key=None):
+    def __init__(self, engine=None, rank=None, world=None, key=None, uid=None):
         from . import engine as _engine_mod
         self.engine = engine if engine is not None else _engine_mod.get_engine()
         if not hasattr(self.engine, 'lib') or not hasattr(self.engine, 'ctx'):
@@ -99,13 +204,15 @@ class RcclCommunicator:
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
         self.size = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
         lib = self.engine.lib
-        uid, published = exchange_unique_id(lib, self.rank, self.size, key)
-        self.engine._check(lib.blhip_comm_init(self.engine.ctx, uid, self.size, self.rank))
+        uid, published = exchange_unique_id(lib, self.rank, self.size, key) if uid is None else (uid, [])
+        init_timeout = float(os.environ.get('BLHIP_COMM_INIT_TIMEOUT', '300'))
+        _bounded(lambda: self.engine._check(lib.blhip_comm_init(self.engine.ctx, uid, self.size, self.rank)), init_timeout,
+                 'rank %d: ncclCommInitRank (world %d)' % (self.rank, self.size))
         self._open = True
-        self.barrier()                     # everyone has joined: the rendezvous file can go
-        if published:
+        _bounded(self.barrier, init_timeout, 'rank %d: the first collective' % self.rank)     # everyone has joined: the rendezvous files can go
+        for f in published:
             try:
-                os.remove(published)
+                os.remove(f)
             except OSError:
                 pass
 
@@ -153,12 +260,6 @@ class RcclCommunicator:
 def shard_indices(n, size, rank):
     """Hyper-grid points of one rank: rank, rank + size, ... (balances any smooth cost trend over the hyper-grid)."""
     return np.arange(rank, n, size)
-
-
-def chunk_bounds(n, size):
-    """Contiguous near-equal chunks, identical to np.array_split(range(n), size)."""
-    parts = np.array_split(np.arange(n), size)
-    return [(int(p[0]), int(p[-1]) + 1) if len(p) else (0, 0) for p in parts]
 
 
 def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_only=False, evidence_only=False,

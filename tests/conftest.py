@@ -11,3 +11,21 @@ for p in (HERE, ROOT):
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'slow: takes more than a few seconds on CPU')
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How many localEvidence entries the parity comparisons of this session held to the 1e-9 bar, and how many to a registered
+    looser tolerance (tests/tolerances.py: ILL_LOCAL_EVIDENCE / WIDE_FILTER_2D, steps with denormal likelihood cells)."""
+    try:
+        import compare
+    except Exception:
+        return
+    c = compare.COUNTS
+    if c['local_at_bar'] + c['local_loosened'] + c['local_nan']:
+        terminalreporter.write_line('localEvidence entries compared: %d at the 1e-9 bar, %d at a registered looser tolerance, '
+                                    '%d NaN on both sides (0/0 in the reference)' % (c['local_at_bar'], c['local_loosened'], c['local_nan']))
+    out = os.environ.get('BLHIP_PARITY_COUNTS')
+    if out:
+        import json
+        with open(out, 'w') as f:
+            json.dump(c, f)

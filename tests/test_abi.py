@@ -30,7 +30,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_abi.Op) == 16
     assert ctypes.sizeof(_abi.Problem) == 4 + 4 + 3 * 8 * _abi.MAX_DIM + 8 + 4 + 4 + 6 * 8 + 8 + 8 + 8 + 4 + 4      # n, marginal, lattice: [BLHIP_MAX_DIM]
     assert ctypes.sizeof(_abi.Result) == 5 * 8
-    assert ctypes.sizeof(_abi.Timing) == 4 * 8 + 5 * 8 + 2 * 4
+    assert ctypes.sizeof(_abi.Timing) == 4 * 8 + 5 * 8 + 2 * 4 + 4 * 8 + 2 * 4
 
 
 def test_no_gpu_fails_loudly():
@@ -60,3 +60,23 @@ def test_header_is_plain_c_and_the_c_demo_links(tmp_path):
         return
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and 'ABI version %d' % _abi.ABI_VERSION in out.stdout
+
+
+def test_integration_md_ctypes_stub_matches_the_binding():
+    """The reference-side ctypes stub INTEGRATION.md shows a maintainer: its structure definitions, exec'ed as written, must have the
+    sizes and field offsets of bayesloop_amd/_abi.py (i.e. of include/blhip.h)."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = text.split('```python')[1].split('```')[0]
+    struct_src = block.split('lib.blhip_create.restype')[0]
+    struct_src = struct_src.replace("lib = C.CDLL('libblhip.so')", 'lib = None')       # (definitions only: nothing is loaded here)
+    ns = {}
+    exec(struct_src, ns)
+    for name in ('Op', 'Problem', 'Result'):
+        doc, ours = ns[name], getattr(_abi, name)
+        assert ctypes.sizeof(doc) == ctypes.sizeof(ours), name
+        assert [f[0] for f in doc._fields_] == [f[0] for f in ours._fields_], name
+        for field in (f[0] for f in ours._fields_):
+            assert getattr(doc, field).offset == getattr(ours, field).offset, (name, field)
+            assert getattr(doc, field).size == getattr(ours, field).size, (name, field)
+    # the rest of the stub at least parses
+    compile(block, 'INTEGRATION.md', 'exec')

@@ -31,3 +31,67 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r['traffic'] is None or 0.2 * alg <= r['traffic'] <= 1.3 * alg
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == d['unit'] and c['value'] > 0 and c['sample']
+
+
+def _walk(d, path=''):
+    if isinstance(d, dict):
+        for k, v in d.items():
+            yield from _walk(v, path + '/' + str(k))
+    elif isinstance(d, list):
+        for i, v in enumerate(d):
+            yield from _walk(v, path + '/%d' % i)
+    else:
+        yield path, d
+
+
+def test_roofline_accounting_of_a_resident_pass():
+    """bench.roofline_of on a synthetic timing record of the chain-resident kernels (C4: forward 8 B, backward + fold 24 B per
+    cell-step by construction): the HBM figures use the REAL bytes, the streaming-equivalent rate is not called `achieved`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    units = 512 * 512 * 256 * 512
+    timing = dict(forward_ms=93.6, backward_ms=150.5, forward_launches=512, backward_launches=512, fwd_kernel_variant=6,
+                  bwd_kernel_variant=6, fwd_hbm_bytes=8.0 * units, bwd_hbm_bytes=24.0 * units, fwd_flops=130.0 * units,
+                  bwd_flops=146.0 * units)
+    rf = bench.roofline_of(timing, units, peak_cal=5900.0)
+    f, b = rf['forward'], rf['backward']
+    assert abs(b['hbm']['bytes_per_cell_step'] - 24.0) < 1e-12 and abs(f['hbm']['bytes_per_cell_step'] - 8.0) < 1e-12
+    assert abs(b['hbm']['achieved_GBs'] - 24.0 * units / 150.5e-3 / 1e9) < 1e-6
+    assert abs(b['streaming_equiv']['GBs_equiv'] - 32.0 * units / 150.5e-3 / 1e9) < 1e-6
+    assert b['hbm']['frac_calibrated'] <= 1.0 and f['hbm']['frac_calibrated'] <= 1.0
+    assert f['bound'] == 'fp64' and b['bound'] == 'hbm'
+    for path, v in _walk(rf):
+        if path.endswith('achieved_GBs'):
+            assert v <= 8000.0, (path, v)
+        assert not path.endswith('/achieved'), path          # per-kernel objects carry no bare `achieved`
+    # the PMC bytes, when given, replace the designed ones
+    rf2 = bench.roofline_of(timing, units, peak_cal=5900.0,
+                            pmc=dict(backward=dict(bytes=23.8 * units / 512, source='pmc')))
+    assert abs(rf2['backward']['hbm']['bytes_per_cell_step'] - 23.8) < 1e-9 and rf2['backward']['hbm']['source'] == 'pmc'
+
+
+def test_kernel_direction_parser():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    kd = bench.kernel_direction
+    assert kd('void blc::chain_kernel<14, 4, true, false>(blc::ChainParams)') == 'backward'
+    assert kd('void blc::chain_kernel<6, 4, false, true>(blc::ChainParams)') == 'forward'
+    assert kd('void blr::resident_kernel<128, 128, 32, 8, false>(blr::ResParams)') == 'forward'
+    assert kd('void blm::mfma_step_kernel<2, 1, 8, true, false>(blf::FastParams)') == 'backward'
+    assert kd('void blk::reduce_partials_kernel(double const*, double*, int, int)') is None
+
+
+def test_c5_counts_the_chains_it_runs():
+    """np.arange(3, 1000, 4)[:256] holds 250 candidates (BASELINE.json says 256): `units` and config.n_hyper use the real count."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import bayesloop_amd as bl
+    S, kw, units, desc = bench.make_study(bl, 'c5')
+    assert desc['n_hyper'] == 250 == len(np.arange(3, 1000, 4)[:256]) and units == 512 * 512 * 1000 * 250

@@ -73,14 +73,102 @@ def test_sharded_hyperstudy_matches_unsharded(tmp_path, world):
         assert out.count(' ok;') == len(names), out
 
 
-def test_chunks_equal_array_split():
-    from bayesloop_amd.dist import chunk_bounds
-    for n in (1, 2, 7, 16, 512, 513):
-        for size in (1, 2, 3, 4, 8):
-            parts = np.array_split(np.arange(n), size)
-            got = chunk_bounds(n, size)
-            for p, (a, b) in zip(parts, got):
-                assert list(p) == list(range(a, b))
+class _FakeLib:
+    """stands in for libblhip's blhip_comm_unique_id (= ncclGetUniqueId) in the rendezvous tests: 128 random bytes"""
+    def blhip_comm_unique_id(self, buf):
+        import ctypes
+        raw = os.urandom(128)
+        ctypes.memmove(buf, raw, 128)
+        self.made = raw
+        return 0
+
+
+def _rendezvous_world(tmp_path, world, key, plant=None, delay_rank0=0.0):
+    """`world` threads run bayesloop_amd.dist.exchange_unique_id against one private directory -> list of ids by rank"""
+    import threading
+    import time
+    from bayesloop_amd import dist
+    os.environ['BLHIP_RDZV_DIR'] = str(tmp_path / 'rdzv')
+    dist._rendezvous_dir()
+    if plant:
+        plant(dist)
+    lib0 = _FakeLib()
+    out, err = [None] * world, []
+    counter = dist._comm_counter
+
+    def run(r):
+        try:
+            if r == 0 and delay_rank0:
+                time.sleep(delay_rank0)
+            dist._comm_counter = counter            # (threads of ONE process here: every rank must derive the same path)
+            out[r] = dist.exchange_unique_id(lib0 if r == 0 else _FakeLib(), r, world, key=key, timeout=20.0)
+        except Exception as e:      # noqa: BLE001
+            err.append((r, e))
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(30)
+    os.environ.pop('BLHIP_RDZV_DIR', None)
+    assert not err, err
+    return out, lib0
+
+
+def test_rendezvous_hands_every_rank_the_same_fresh_id(tmp_path):
+    out, lib0 = _rendezvous_world(tmp_path, 3, 'k1')
+    assert all(o[0] == lib0.made for o in out)
+    d = tmp_path / 'rdzv'
+    assert (os.stat(d).st_mode & 0o777) == 0o700
+    for f in out[0][1]:                         # rank 0 lists what it removes after the first collective
+        assert os.path.exists(f) and (os.stat(f).st_mode & 0o777) == 0o600
+    assert out[1][1] == [] and out[2][1] == []
+
+
+def test_rendezvous_ignores_left_overs_of_a_crashed_job(tmp_path):
+    """A stale id file AND a stale go file of an earlier job with the same key are present when the ranks start, and rank 0 is
+    late: the other ranks must not proceed with the stale id (the go file has to echo their own fresh token)."""
+    stale_id = os.urandom(128)
+
+    def plant(dist):
+        counter = dist._comm_counter
+        path = dist._rendezvous_path('k2')
+        dist._comm_counter = counter
+        nonce = os.urandom(16)
+        dist._publish(path, nonce + stale_id)
+        dist._publish(path + '.go', nonce + os.urandom(16) * 2)
+    out, lib0 = _rendezvous_world(tmp_path, 3, 'k2', plant=plant, delay_rank0=0.5)
+    assert all(o[0] == lib0.made for o in out) and lib0.made != stale_id
+
+
+def test_rendezvous_refuses_a_directory_others_can_write(tmp_path):
+    from bayesloop_amd import dist
+    from bayesloop_amd.exceptions import BackendError
+    d = tmp_path / 'open'
+    d.mkdir()
+    os.chmod(d, 0o777)
+    os.environ['BLHIP_RDZV_DIR'] = str(d)
+    try:
+        with pytest.raises(BackendError):
+            dist._rendezvous_dir()
+        link = tmp_path / 'link'
+        os.symlink(str(tmp_path), str(link))
+        os.environ['BLHIP_RDZV_DIR'] = str(link)
+        with pytest.raises(BackendError):
+            dist._rendezvous_dir()
+    finally:
+        os.environ.pop('BLHIP_RDZV_DIR', None)
+
+
+def test_rendezvous_key_prefers_the_launchers_master_address(monkeypatch):
+    from bayesloop_amd import dist
+    monkeypatch.delenv('BLHIP_RDZV_KEY', raising=False)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29511')
+    assert dist._rendezvous_key() == 'm127.0.0.1_29511_0_none'          # no parent pid in it: ranks need not share a parent
+    monkeypatch.delenv('MASTER_PORT')
+    assert dist._rendezvous_key() == 'p%d' % os.getppid()
+    monkeypatch.setenv('BLHIP_RDZV_KEY', 'job/7')
+    assert dist._rendezvous_key() == 'job_7'
 
 
 def test_round_robin_shares_partition_the_hyper_grid():
