@@ -82,6 +82,8 @@ PROTOTYPES = {
                             C.POINTER(Result)]),
     'blhip_last_timing': (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     'blhip_bandwidth_probe': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_double_p]),
+    'blhip_host_alloc': (C.c_void_p, [C.c_size_t]),
+    'blhip_host_free': (None, [C.c_void_p]),
     'blhip_posterior_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_double_p]),
     'blhip_posterior_devptr': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'blhip_posterior_release': (C.c_int, [C.c_void_p]),
@@ -100,7 +102,10 @@ PROTOTYPES = {
     'blhip_comm_allgather': (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     'blhip_comm_allreduce': (C.c_int, [C.c_void_p, c_double_p, C.c_int64, C.c_int]),
     'blhip_comm_reduce_accum': (C.c_int, [C.c_void_p, C.c_int]),
+    'blhip_comm_timing': (C.c_int, [C.c_void_p, c_double_p]),
     'blhip_comm_destroy': (C.c_int, [C.c_void_p]),
+    'blhip_accum_peer_reduce': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int64]),
+    'blhip_accum_peer_gather': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'blhip_carry_mix': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p, C.c_int]),
     'blhip_carry_read': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, c_double_p]),
     'blhip_carry_write': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]),

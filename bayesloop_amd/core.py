@@ -795,8 +795,12 @@ class HyperStudy(Study):
     def fit(self, forwardOnly=False, evidenceOnly=False, silent=False, nJobs=1, customHyperGrid=False):
         """
         Fits every hyper-grid point and averages the models with their evidence (reference core.py:1247-1441).
-        ``nJobs`` is accepted for compatibility; parallelism comes from batching on the GPU and, across GPUs, from
-        ``self.communicator``.
+
+        ``nJobs`` (reference core.py:1307-1340: a pool of worker processes over chunks of the hyper-grid): with ``nJobs > 1`` and
+        more than one GPU visible to this process the hyper-grid points are dealt out to min(nJobs, GPUs) devices, one host
+        thread and one library context per device, and the results are merged over xGMI (``bayesloop_amd.dist.LocalGroup``) --
+        no launcher, nothing else to set up.  On ONE GPU all chains are batched on that device whatever ``nJobs`` says.  Under a
+        one-process-per-GPU launcher set ``self.communicator`` (``bl.dist.RcclCommunicator``) instead.
         """
         self.fitWarningCounter = 0
         self._formatData()
@@ -835,9 +839,22 @@ class HyperStudy(Study):
         prior_values = np.asarray(self.flatHyperPriorValues, dtype=float)
 
         from . import dist as _dist
-        out = _dist.sharded_hyper_fit(_engine_mod.get_engine(), problem, op_values, prior_values, self.communicator,
-                                      forward_only=forwardOnly, evidence_only=evidenceOnly, owner=self)
+        root_engine = _engine_mod.get_engine()
+        devices = [getattr(root_engine, 'device', 0)]
+        if self.communicator is None and nJobs and int(nJobs) > 1 and hasattr(root_engine, 'ctx'):
+            devices = _dist.local_devices(int(nJobs), getattr(root_engine, 'device', 0))
+        if len(devices) > 1:
+            engines, seen = [], set()
+            for dev in devices:            # (a repeated ordinal -- BLHIP_NJOBS_DEVICES=0,0, tests -- gets a context of its own)
+                engines.append(_engine_mod.engine_for_device(dev) if dev not in seen else _engine_mod.extra_engine(dev))
+                seen.add(dev)
+            out = _dist.local_sharded_hyper_fit(engines, problem, op_values, prior_values, forward_only=forwardOnly,
+                                                evidence_only=evidenceOnly, owner=self)
+        else:
+            out = _dist.sharded_hyper_fit(root_engine, problem, op_values, prior_values, self.communicator,
+                                          forward_only=forwardOnly, evidence_only=evidenceOnly, owner=self)
         self.lastTiming = out['timing']
+        self.lastTimingPerDevice = out.get('per_rank_timing')
         self.logEvidenceList = list(out['log_evidence'])
         localList = out['local_evidence']
         n_abort = int(np.sum(out['abort_step'] >= 0))

@@ -2145,6 +2145,16 @@ int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out) {
     return 0;
 }
 
+void *blhip_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void blhip_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, double *host_out) {
     return guarded(ctx, [&] {
         if (!ctx->post_valid) fail("no posterior kept (run blhip_fit with BLHIP_KEEP_POSTERIOR)");

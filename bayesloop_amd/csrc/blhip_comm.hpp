@@ -16,6 +16,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "blhip_host.hpp"
 
@@ -30,6 +31,11 @@ struct RcclApi {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
 
@@ -60,6 +66,11 @@ struct RcclApi {
         sym(AllGather, "ncclAllGather");
         sym(AllReduce, "ncclAllReduce");
         sym(Reduce, "ncclReduce");
+        sym(ReduceScatter, "ncclReduceScatter");
+        sym(Send, "ncclSend");
+        sym(Recv, "ncclRecv");
+        sym(GroupStart, "ncclGroupStart");
+        sym(GroupEnd, "ncclGroupEnd");
         sym(GetErrorString, "ncclGetErrorString");
         sym(GetVersion, "ncclGetVersion");
     }
@@ -67,6 +78,8 @@ struct RcclApi {
 
 RcclApi &rccl() {
     static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     api.load();
     return api;
 }
@@ -177,10 +190,125 @@ int blhip_comm_reduce_accum(blhip_ctx *ctx, int root) {
         if (ctx->acc_final) fail("blhip_comm_reduce_accum: the accumulator is already finalised");
         if (root < 0 || root >= ctx->comm_world) fail("blhip_comm_reduce_accum: root %d of %d ranks", root, ctx->comm_world);
         HIPCHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
         const size_t n = (size_t)ctx->acc_T * (size_t)ctx->acc_G;
-        // in place: on the root the sum replaces its own share; the other ranks' buffers keep their (spent) shares
-        RCCLCHECK(rccl().Reduce(ctx->acc, ctx->acc, n, ncclDouble, ncclSum, root, c, ctx->stream));
-        sync_stream(ctx, ctx->stream);
+        const int W = ctx->comm_world;
+        // option comm_reduce_mode: 0 = ONE ncclReduce to the root (a ring: every link carries the whole buffer once);
+        // 1 = reduce-scatter over time slices + the slices sent to the root (xGMI is point-to-point: the root then takes in
+        // (W - 1) / W of ONE buffer over W - 1 links instead of W - 1 whole buffers); needs T divisible by the world size
+        const int mode = (int)ctx->option("comm_reduce_mode", 0.0);
+        HIPCHECK(hipEventRecord(ctx->ev[4], st));
+        if (mode == 1 && W > 1 && ctx->acc_T % W == 0) {
+            const size_t cnt = n / (size_t)W;
+            // in place: rank r's slice of the sums lands where its own slice lives
+            RCCLCHECK(rccl().ReduceScatter(ctx->acc, ctx->acc + (size_t)ctx->comm_rank * cnt, cnt, ncclDouble, ncclSum, c, st));
+            RCCLCHECK(rccl().GroupStart());
+            if (ctx->comm_rank == root) {
+                for (int r = 0; r < W; ++r)
+                    if (r != root) RCCLCHECK(rccl().Recv(ctx->acc + (size_t)r * cnt, cnt, ncclDouble, r, c, st));
+            } else {
+                RCCLCHECK(rccl().Send(ctx->acc + (size_t)ctx->comm_rank * cnt, cnt, ncclDouble, root, c, st));
+            }
+            RCCLCHECK(rccl().GroupEnd());
+        } else {
+            // in place: on the root the sum replaces its own share; the other ranks' buffers keep their (spent) shares
+            RCCLCHECK(rccl().Reduce(ctx->acc, ctx->acc, n, ncclDouble, ncclSum, root, c, st));
+        }
+        HIPCHECK(hipEventRecord(ctx->ev[5], st));
+        sync_stream(ctx, st);
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+        ctx->comm_reduce_ms = ms;
+    });
+}
+
+int blhip_comm_timing(blhip_ctx *ctx, double *reduce_ms) {
+    if (!ctx) return -1;
+    if (reduce_ms) *reduce_ms = ctx->comm_reduce_ms;
+    return 0;
+}
+
+// ---- several GPUs driven by ONE process (HyperStudy.fit(nJobs = N): one context per device, one host thread per context): the
+//      accumulators are merged with peer copies over xGMI, no RCCL.  The caller (bayesloop_amd/dist.py: LocalGroup) brings every
+//      accumulator to the common reference exponent first, synchronises every context and orders the calls with host barriers. -------
+namespace {
+void enable_peer(int self_dev, int peer_dev) {
+    if (self_dev == peer_dev) return;
+    int can = 0;
+    HIPCHECK(hipDeviceCanAccessPeer(&can, self_dev, peer_dev));
+    if (!can) return;                                   // (hipMemcpyPeerAsync then stages through the host)
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_dev, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHECK(e);
+    (void)hipGetLastError();
+}
+void check_peers(blhip_ctx *dst, blhip_ctx *const *srcs, int n) {
+    if (!dst->acc_active || dst->acc_final) fail("peer merge: the destination has no open accumulator");
+    if (n < 0 || n > blhip_ctx::NBS) fail("peer merge: %d sources (at most %d)", n, blhip_ctx::NBS);
+    for (int i = 0; i < n; ++i) {
+        if (!srcs || !srcs[i] || srcs[i] == dst) fail("peer merge: bad source context %d", i);
+        if (!srcs[i]->acc_active || srcs[i]->acc_T != dst->acc_T || srcs[i]->acc_G != dst->acc_G) fail("peer merge: accumulator shapes differ");
+        if (srcs[i]->acc_logref != dst->acc_logref) fail("peer merge: the accumulators are not at a common reference exponent (blhip_accum_rescale)");
+    }
+}
+__global__ void peer_add_kernel(double *__restrict__ acc, const double *__restrict__ stage, int n, long long count) {
+    // acc[i] += stage[0][i] + stage[1][i] + ... in list order (the same sum on every run)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        double v = acc[i];
+        for (int k = 0; k < n; ++k) v += __builtin_nontemporal_load(stage + (long long)k * count + i);
+        acc[i] = v;
+    }
+}
+void copy_rows(blhip_ctx *dst, double *to, blhip_ctx *src, long long off, size_t bytes, hipStream_t s) {
+    if (src->device == dst->device) HIPCHECK(hipMemcpyAsync(to, src->acc + off, bytes, hipMemcpyDeviceToDevice, s));
+    else HIPCHECK(hipMemcpyPeerAsync(to, dst->device, src->acc + off, src->device, bytes, s));
+}
+}  // namespace
+
+int blhip_accum_peer_reduce(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, int64_t row0, int64_t row1) {
+    return guarded(dst, [&] {
+        check_peers(dst, srcs, n_srcs);
+        if (row0 < 0 || row1 > dst->acc_T || row0 > row1) fail("peer reduce: rows [%lld, %lld) of %lld", (long long)row0, (long long)row1, (long long)dst->acc_T);
+        if (n_srcs == 0 || row0 == row1) return;
+        HIPCHECK(hipSetDevice(dst->device));
+        hipStream_t st = dst->stream;
+        const long long cnt = (long long)(row1 - row0) * dst->acc_G, off = (long long)row0 * dst->acc_G;
+        dst->commbuf.ensure((size_t)n_srcs * (size_t)cnt * 8);
+        double *stage = dst->commbuf.as<double>();
+        HIPCHECK(hipEventRecord(dst->fork_ev, st));
+        for (int i = 0; i < n_srcs; ++i) {               // one stream per source: the copies run over different xGMI links at once
+            enable_peer(dst->device, srcs[i]->device);
+            hipStream_t s = dst->bstream[i];
+            HIPCHECK(hipStreamWaitEvent(s, dst->fork_ev, 0));
+            copy_rows(dst, stage + (long long)i * cnt, srcs[i], off, (size_t)cnt * 8, s);
+            HIPCHECK(hipEventRecord(dst->bev[i], s));
+            HIPCHECK(hipStreamWaitEvent(st, dst->bev[i], 0));
+        }
+        hipLaunchKernelGGL(peer_add_kernel, dim3(2048), dim3(256), 0, st, dst->acc + off, stage, n_srcs, cnt);
+        HIPCHECK(hipGetLastError());
+        sync_stream(dst, st);
+    });
+}
+
+int blhip_accum_peer_gather(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, const int64_t *row0, const int64_t *row1) {
+    return guarded(dst, [&] {
+        check_peers(dst, srcs, n_srcs);
+        if (n_srcs == 0) return;
+        if (!row0 || !row1) fail("peer gather: row bounds are NULL");
+        HIPCHECK(hipSetDevice(dst->device));
+        hipStream_t st = dst->stream;
+        HIPCHECK(hipEventRecord(dst->fork_ev, st));
+        for (int i = 0; i < n_srcs; ++i) {
+            if (row0[i] < 0 || row1[i] > dst->acc_T || row0[i] > row1[i]) fail("peer gather: rows [%lld, %lld) of %lld", (long long)row0[i], (long long)row1[i], (long long)dst->acc_T);
+            if (row0[i] == row1[i]) continue;
+            enable_peer(dst->device, srcs[i]->device);
+            hipStream_t s = dst->bstream[i];
+            HIPCHECK(hipStreamWaitEvent(s, dst->fork_ev, 0));
+            const long long off = (long long)row0[i] * dst->acc_G;
+            copy_rows(dst, dst->acc + off, srcs[i], off, (size_t)(row1[i] - row0[i]) * (size_t)dst->acc_G * 8, s);
+            HIPCHECK(hipEventRecord(dst->bev[i], s));
+            HIPCHECK(hipStreamWaitEvent(st, dst->bev[i], 0));
+        }
+        sync_stream(dst, st);
     });
 }
 

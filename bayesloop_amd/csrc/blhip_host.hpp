@@ -119,6 +119,7 @@ struct blhip_ctx {
     // multi-GPU exchange (blhip_comm.hpp): RCCL communicator of this context's device, staging buffers
     void *comm = nullptr;        // ncclComm_t
     int comm_world = 1, comm_rank = 0;
+    double comm_reduce_ms = 0.0;   // HIP-event time of the last blhip_comm_reduce_accum
     DevBuf commbuf;
     PinBuf pinC;
     // time-resident path (blhip_resident.hpp): halo strips / flags, and whether every tile was co-resident so far

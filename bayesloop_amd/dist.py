@@ -20,7 +20,8 @@ The exchange:
      accumulator to rank 0, in place in HBM -- the linear-space equivalent of the reference's ``np.logaddexp`` merge
      (core.py:1339) followed by ``-= amax; exp`` (core.py:1375-1376).
 
-Transports: :class:`RcclCommunicator` (the product: RCCL through libblhip.so).  The host logic in
+Transports: :class:`RcclCommunicator` (one process per GPU: RCCL through libblhip.so) and :class:`LocalGroup` (ONE process driving
+several GPUs with one host thread each -- ``HyperStudy.fit(nJobs=N)``: shared memory + peer copies over xGMI, no RCCL).  The host logic in
 :func:`sharded_hyper_fit` only needs ``rank``, ``size``, ``all_gather(array)`` and ``reduce_accumulator(engine, root)``;
 the CPU tests drive it with a gloo-backed stand-in that lives in tests/ (tests/gloo_comm.py).
 """
@@ -232,6 +233,12 @@ class RcclCommunicator:
             raise BackendError('the accumulator lives in another context than this communicator')
         self.engine._check(self.engine.lib.blhip_comm_reduce_accum(self.engine.ctx, int(root)))
 
+    def reduce_ms(self):
+        """HIP-event time (ms) of this rank's last reduce_accumulator."""
+        ms = C.c_double()
+        self.engine._check(self.engine.lib.blhip_comm_timing(self.engine.ctx, C.byref(ms)))
+        return ms.value
+
     # ---- small host-side collectives (bench.py: barrier, max-over-ranks timing) ------------------------------------------
     def allreduce(self, values, op=SUM):
         v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
@@ -290,8 +297,11 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
     astep = np.full(n_mine, -1.0)
     timing = {}
     if n_mine > 0:
-        res = engine.fit(problem, np.asarray(op_values)[mine], forward_only=forward_only, evidence_only=evidence_only,
-                         keep_posterior=False, accumulate=want_post, log_chain_weight=log_w[mine], owner=owner)
+        # (LocalGroup with two contexts on ONE physical device -- a test configuration: their fits take turns)
+        turn = comm.device_lock(engine) if getattr(getattr(comm, 'group', None), 'shared', False) else _nullcontext()
+        with turn:
+            res = engine.fit(problem, np.asarray(op_values)[mine], forward_only=forward_only, evidence_only=evidence_only,
+                             keep_posterior=False, accumulate=want_post, log_chain_weight=log_w[mine], owner=owner)
         logE, local, astep, timing = res.log_evidence, res.local_evidence, res.abort_step.astype(float), res.timing
 
     ref = -np.inf
@@ -341,3 +351,124 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
 
     return dict(log_evidence=np.asarray(logE), local_evidence=np.asarray(local), abort_step=np.asarray(astep),
                 posterior_mean=means, posterior=posterior, timing=timing)
+
+
+# ---- several GPUs driven by ONE process: HyperStudy.fit(nJobs = N) ------------------------------------------------------------
+class LocalGroup:
+    """The in-process stand-in for the reference's process pool (bayesloop/core.py:1317-1326): N engines (one libblhip context per
+    device), N host threads (ctypes releases the GIL inside blhip_fit, so the N devices compute at the same time), and the same
+    ONE gather + ONE accumulator merge as the multi-process path -- through shared memory and peer copies over xGMI
+    (blhip_accum_peer_reduce / _gather) instead of RCCL.  ``member(r)`` is the communicator object of thread r."""
+
+    def __init__(self, engines):
+        import threading
+        self.engines = list(engines)
+        self.size = len(self.engines)
+        self.barrier = threading.Barrier(self.size)
+        self.slots = [None] * self.size
+        # two contexts on ONE physical device (a test configuration: BLHIP_NJOBS_DEVICES=0,0) must not compute at the same time --
+        # the resident kernels need every CU of the chip
+        self.locks = {}
+        for e in self.engines:
+            self.locks.setdefault(getattr(e, 'device', id(e)), threading.Lock())
+        self.shared = len(self.locks) < self.size
+
+    def member(self, rank):
+        return _LocalMember(self, rank)
+
+
+class _LocalMember:
+    def __init__(self, group, rank):
+        self.group, self.rank, self.size = group, rank, group.size
+        self.collectives = []
+
+    def _wait(self):
+        self.group.barrier.wait(timeout=float(os.environ.get('BLHIP_NJOBS_TIMEOUT', '3600')))
+
+    def device_lock(self, engine):
+        return self.group.locks[getattr(engine, 'device', id(engine))]
+
+    def all_gather(self, a):
+        g = self.group
+        g.slots[self.rank] = np.array(a, dtype=np.float64, copy=True)
+        self._wait()
+        out = [np.array(s, copy=True) for s in g.slots]
+        self._wait()                      # (nobody overwrites a slot before everyone has read it)
+        self.collectives.append(('all_gather', int(np.size(a))))
+        return out
+
+    def reduce_accumulator(self, engine, root=0):
+        """Reduce-scatter over time slices, then the root fetches the slices: every device takes in (N - 1) / N of ONE accumulator
+        over its N - 1 links (xGMI is point-to-point) instead of the root taking in N - 1 whole ones."""
+        g = self.group
+        engine.synchronize()
+        self._wait()                      # every accumulator is rescaled to the common exponent and idle
+        T = engine.accum_shape()[0]
+        bounds = [(int(b[0]), int(b[-1]) + 1) if len(b) else (0, 0) for b in np.array_split(np.arange(T), self.size)]
+        others = [g.engines[j] for j in range(self.size) if j != self.rank]
+        with self.device_lock(engine) if g.shared else _nullcontext():
+            engine.accum_peer_reduce(others, *bounds[self.rank])
+        self._wait()                      # every slice is complete on its owner
+        if self.rank == root:
+            srcs = [j for j in range(self.size) if j != root]
+            engine.accum_peer_gather([g.engines[j] for j in srcs], [bounds[j] for j in srcs])
+        self._wait()                      # (the owners' buffers were read: they may be reused now)
+        self.collectives.append(('reduce', int(T)))
+
+    def barrier(self):
+        self._wait()
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def local_devices(n_jobs, root_device=0):
+    """Devices of an in-process sharded fit: ``BLHIP_NJOBS_DEVICES`` (comma-separated ordinals, duplicates allowed: a test
+    configuration) or the first min(n_jobs, visible) devices starting with the root engine's."""
+    env = os.environ.get('BLHIP_NJOBS_DEVICES')
+    if env:
+        return [int(x) for x in env.split(',') if x.strip() != ''][:max(1, n_jobs)]
+    from . import _abi
+    have = _abi.load().blhip_device_count()
+    devs = [root_device] + [d for d in range(have) if d != root_device]
+    return devs[:max(1, min(n_jobs, have))]
+
+
+def local_sharded_hyper_fit(engines, problem, op_values, prior_values, forward_only=False, evidence_only=False, owner=None):
+    """sharded_hyper_fit on len(engines) devices from ONE process: engines[0] is the root (its context ends up holding the
+    finalised average posterior), one host thread per further engine.  Returns the root's result dict (+ 'per_rank_timing')."""
+    import threading
+    group = LocalGroup(engines)
+    results, errors = [None] * group.size, []
+
+    def work(r):
+        comm = group.member(r)
+        try:
+            results[r] = sharded_hyper_fit(engines[r], problem, op_values, prior_values, comm, forward_only=forward_only,
+                                           evidence_only=evidence_only, owner=owner if r == 0 else None)
+        except BaseException as e:        # noqa: BLE001 -- re-raised in the calling thread
+            errors.append((r, e))
+            group.barrier.abort()         # the others must not wait for this thread for ever
+    threads = [threading.Thread(target=work, args=(r,), name='blhip-njobs-%d' % r) for r in range(1, group.size)]
+    for t in threads:
+        t.start()
+    work(0)
+    for t in threads:
+        t.join()
+    if errors:
+        import threading as _t
+        first = [e for r, e in sorted(errors, key=lambda x: x[0]) if not isinstance(e, _t.BrokenBarrierError)]
+        raise (first[0] if first else errors[0][1])
+    for r in range(1, group.size):        # the other devices' accumulators are spent
+        try:
+            engines[r].accum_end()
+        except Exception:                 # noqa: BLE001
+            pass
+    out = results[0]
+    out['per_rank_timing'] = [res['timing'] if res else {} for res in results]
+    return out

@@ -10,6 +10,7 @@ with the same methods through :func:`set_engine` to exercise the host-side logic
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
@@ -101,6 +102,54 @@ class DevicePosterior:
         return self.engine.time_average(self.source, self.chain, self.grid_size)
 
 
+class _PinnedPool:
+    """Result arrays of the big read-backs (posteriorSequence: (T, *gridSize) float64, 16 GiB for BASELINE C3) in PAGE-LOCKED host
+    memory: the D2H copy is then one DMA at the PCIe rate instead of the runtime's staging through pageable memory (23 GB/s
+    measured).  The arrays are ordinary writable numpy arrays; when the last view of one dies its block comes back here and ONE
+    freed block (the largest) is kept for the next fit -- pinning 16 GiB costs more than copying them."""
+    MIN_BYTES = 32 << 20
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.free = None                 # (ptr, nbytes)
+        self.enabled = os.environ.get('BLHIP_PINNED_RESULTS', '1') != '0'
+
+    def _give_back(self, ptr, nbytes):
+        try:
+            if self.free is None or self.free[1] < nbytes:
+                old, self.free = self.free, (ptr, nbytes)
+            else:
+                old = (ptr, nbytes)
+            if old is not None:
+                self.lib.blhip_host_free(old[0])
+        except Exception:                # interpreter shutdown
+            pass
+
+    def empty(self, shape):
+        shape = [int(x) for x in shape]
+        nbytes = int(np.prod(shape)) * 8
+        if not self.enabled or nbytes < self.MIN_BYTES:
+            return np.empty(shape)
+        ptr = None
+        if self.free is not None and nbytes <= self.free[1] <= 2 * nbytes:
+            (ptr, cap), self.free = self.free, None
+        else:
+            if self.free is not None:
+                self.lib.blhip_host_free(self.free[0])
+                self.free = None
+            ptr, cap = self.lib.blhip_host_alloc(nbytes), nbytes
+        if not ptr:
+            return np.empty(shape)       # (no page-locked memory to be had: the pageable path still works)
+        buf = (C.c_char * cap).from_address(ptr)
+        weakref.finalize(buf, self._give_back, ptr, cap)
+        return np.frombuffer(buf, dtype=np.float64, count=nbytes // 8).reshape(shape)
+
+    def release(self):
+        if self.free is not None:
+            self.lib.blhip_host_free(self.free[0])
+            self.free = None
+
+
 class HipEngine:
     """One libblhip context on one GPU."""
 
@@ -116,9 +165,12 @@ class HipEngine:
             raise BackendError('blhip_create(%d) failed: %s' % (device, self.lib.blhip_last_error(None).decode()))
         self._posterior_owner = None
         self._keep = []
+        self._pinned = _PinnedPool(self.lib)
 
     def __del__(self):
         try:
+            if getattr(self, '_pinned', None) is not None:
+                self._pinned.release()
             if getattr(self, 'ctx', None):
                 self.lib.blhip_destroy(self.ctx)
                 self.ctx = None
@@ -270,7 +322,7 @@ class HipEngine:
         """Normalised posterior sequence of one chain of the last fit(keep_posterior=True) as (T, *grid_size)
         (or the rows t0 .. t1-1 of it)."""
         t1 = T if t1 is None else t1
-        out = np.empty([t1 - t0] + list(grid_size))
+        out = self._pinned.empty([t1 - t0] + list(grid_size))
         self._check(self.lib.blhip_posterior_read(self.ctx, chain, t0, t1, _abi.dptr(out)))
         return out
 
@@ -305,6 +357,7 @@ class HipEngine:
             prev._materialize_posterior()       # the previous study's average posterior still lives in the accumulator
         self._accum_owner = None if owner is None else weakref.ref(owner)
         self._check(self.lib.blhip_accum_begin(self.ctx, T, G, None))
+        self._acc_shape = (int(T), int(G))
 
     def accum_row_stats(self, problem: FitProblem):
         """(T, 1 + ndim) per-step sums [sum A, sum A grid_k] of the not yet finalised accumulator (relative to its
@@ -332,18 +385,53 @@ class HipEngine:
 
     def accum_read(self, T, grid_size, t0=0, t1=None):
         t1 = T if t1 is None else t1
-        out = np.empty([t1 - t0] + list(grid_size))
+        out = self._pinned.empty([t1 - t0] + list(grid_size))
         self._check(self.lib.blhip_accum_read(self.ctx, t0, t1, _abi.dptr(out)))
         return out
 
     def accum_end(self):
         self._check(self.lib.blhip_accum_end(self.ctx))
 
+    def accum_shape(self):
+        return self._acc_shape
+
+    # ---- merge of the accumulators of several contexts of THIS process (dist.LocalGroup) -------------------------------------
+    def accum_peer_reduce(self, others, row0, row1):
+        """acc[row0:row1] += sum of the other engines' acc[row0:row1] (peer copies over xGMI, summed in list order)."""
+        arr = (C.c_void_p * max(1, len(others)))(*[o.ctx for o in others])
+        self._check(self.lib.blhip_accum_peer_reduce(self.ctx, arr, len(others), int(row0), int(row1)))
+
+    def accum_peer_gather(self, others, bounds):
+        """acc[a:b] = other.acc[a:b] for every (other, (a, b))."""
+        n = len(others)
+        arr = (C.c_void_p * max(1, n))(*[o.ctx for o in others])
+        r0 = (C.c_int64 * max(1, n))(*[int(b[0]) for b in bounds])
+        r1 = (C.c_int64 * max(1, n))(*[int(b[1]) for b in bounds])
+        self._check(self.lib.blhip_accum_peer_gather(self.ctx, arr, n, r0, r1))
+
     def synchronize(self):
         self._check(self.lib.blhip_synchronize(self.ctx))
 
 
 _engine = None
+_device_engines = {}
+
+
+def engine_for_device(device):
+    """One engine (libblhip context) per device ordinal and process: the process-wide engine for its own device, further ones
+    created on first use (HyperStudy.fit(nJobs=N) drives one per GPU).  A list entry repeated in BLHIP_NJOBS_DEVICES (a test
+    configuration: two contexts on one GPU) gets a context of its own."""
+    root = get_engine()
+    if device == getattr(root, 'device', None):
+        return root
+    if device not in _device_engines:
+        _device_engines[device] = HipEngine(device)
+    return _device_engines[device]
+
+
+def extra_engine(device):
+    """A further context on `device`, not shared with anybody (tests: several contexts on one GPU)."""
+    return HipEngine(device)
 
 
 def get_engine():

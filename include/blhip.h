@@ -35,6 +35,7 @@
 #ifndef BLHIP_H
 #define BLHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -196,6 +197,13 @@ int blhip_last_timing(blhip_ctx *ctx, blhip_timing *out);
  * lane streaming copy of `bytes` (read + write counted), `iterations` launches timed with HIP events -> GB/s. */
 int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double *gb_per_s);
 
+/* ---- page-locked host memory for the big read-backs -------------------------------------------------------------------------------
+ * posteriorSequence is a HOST array in the reference (core.py:356, 408): (T, G) doubles, 16 GiB for BASELINE C3.  Into pageable
+ * memory the copy is staged by the runtime (23 GB/s measured); into page-locked memory it is ONE DMA at the PCIe rate.  The host
+ * side allocates its result arrays here (bayesloop_amd/engine.py keeps one freed block for the next fit).  NULL on failure. */
+void *blhip_host_alloc(size_t bytes);
+void  blhip_host_free(void *p);
+
 /* ---- posterior sequence of the last blhip_fit(..., BLHIP_KEEP_POSTERIOR) ---------------------------------------- */
 /* Copies the normalised posteriors of steps [t0, t1) of one chain to host memory ((t1-t0) * G doubles). */
 int blhip_posterior_read(blhip_ctx *ctx, int64_t chain, int64_t t0, int64_t t1, double *host_out);
@@ -263,7 +271,19 @@ int blhip_comm_info(blhip_ctx *ctx, int *world, int *rank, int *rccl_version);  
 int blhip_comm_allgather(blhip_ctx *ctx, const double *host_in, int64_t count, double *host_out);
 int blhip_comm_allreduce(blhip_ctx *ctx, double *host_inout, int64_t count, int op);
 int blhip_comm_reduce_accum(blhip_ctx *ctx, int root);
+int blhip_comm_timing(blhip_ctx *ctx, double *reduce_ms);     /* HIP-event time of the last blhip_comm_reduce_accum (ms) */
 int blhip_comm_destroy(blhip_ctx *ctx);
+
+/* ---- the same merge inside ONE process that drives several GPUs (HyperStudy.fit(nJobs = N), core.py:1307-1340: one context per
+ * device, one host thread per context; no RCCL): peer copies over xGMI.  Every accumulator involved must be open, of the same shape
+ * and at the same reference exponent (blhip_accum_rescale), every context idle (blhip_synchronize); the caller orders the calls of
+ * its threads with host barriers.  The merge is a reduce-scatter over time slices followed by a gather:
+ *   blhip_accum_peer_reduce   dst.acc[row0:row1] += sum_i srcs[i].acc[row0:row1]   (rows fetched concurrently, one stream -- one
+ *                             xGMI link -- per source; summed in list order: the same result on every run)
+ *   blhip_accum_peer_gather   dst.acc[row0[i]:row1[i]] = srcs[i].acc[row0[i]:row1[i]]   for every i (concurrent copies)
+ * at most 12 sources per call. */
+int blhip_accum_peer_reduce(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, int64_t row0, int64_t row1);
+int blhip_accum_peer_gather(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, const int64_t *row0, const int64_t *row1);
 
 /* ---- carried states (OnlineStudy.step, core.py:2062-2226) ------------------------------------------------------------
  * A blhip_fit with BLHIP_CARRY leaves every chain's normalised filtered distribution of its last step in slot

@@ -221,3 +221,19 @@ class OracleEngine:
 
     def synchronize(self):
         pass
+
+    # ---- what bayesloop_amd.dist.LocalGroup asks of an engine (HyperStudy.fit(nJobs=N): several engines in one process) ----
+    def accum_shape(self):
+        return self.acc_shape
+
+    def accum_peer_reduce(self, others, row0, row1):
+        T, G = self.acc_shape
+        mine = self.acc_lin.reshape(T, G)
+        for o in others:
+            mine[row0:row1] += o.acc_lin.reshape(T, G)[row0:row1]
+
+    def accum_peer_gather(self, others, bounds):
+        T, G = self.acc_shape
+        mine = self.acc_lin.reshape(T, G)
+        for o, (a, b) in zip(others, bounds):
+            mine[a:b] = o.acc_lin.reshape(T, G)[a:b]

@@ -3,6 +3,8 @@ import glob
 import json
 import os
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -95,3 +97,67 @@ def test_c5_counts_the_chains_it_runs():
     import bayesloop_amd as bl
     S, kw, units, desc = bench.make_study(bl, 'c5')
     assert desc['n_hyper'] == 250 == len(np.arange(3, 1000, 4)[:256]) and units == 512 * 512 * 1000 * 250
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _check_tiny_line(stdout, n):
+    lines = [l for l in stdout.strip().splitlines() if l.strip()]
+    d = json.loads(lines[-1])                                  # the ONE JSON line is the LAST line on stdout
+    assert sum(1 for l in lines if l.lstrip().startswith('{')) == 1
+    assert d['n_gpus'] == n and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'strong'
+    assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 24 * 24 * 10 * 6) < 1e-6 * 24 * 24 * 10 * 6
+    assert np.isfinite(d['log_evidence']) and d['config']['n_hyper'] == 6
+    return d
+
+
+def test_bench_py_under_the_drivers_launcher_two_ranks():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2
+    --steps K --warmup W` exactly as the driver starts it, on the test doubles (oracle engine + gloo): launcher environment,
+    the sharded fit with its ONE gather + ONE reduce, barrier + max-over-ranks timing, rank 0 prints ONE JSON line, last."""
+    import subprocess
+    import sys
+    import pytest
+    pytest.importorskip('torch')
+    env = dict(os.environ, BLHIP_BENCH_TEST_DOUBLE='1', OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--workload', 'tiny', '--no-extra', '--no-cpu', '--no-pmc']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d2 = _check_tiny_line(r.stdout, 2)
+    # the same workload with one rank gives the same evidence
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--workload', 'tiny',
+                         '--no-extra', '--no-cpu', '--no-pmc'], env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    d1 = _check_tiny_line(r1.stdout, 1)
+    assert abs(d1['log_evidence'] - d2['log_evidence']) <= 1e-12 * abs(d1['log_evidence'])
+
+
+def test_bench_py_self_launch_three_ranks():
+    """`python bench.py --gpus 3` without a launcher starts its own ranks (RANK / LOCAL_RANK / WORLD_SIZE / a fresh rendezvous
+    key per run) and passes rank 0's line through."""
+    import subprocess
+    import sys
+    import pytest
+    pytest.importorskip('torch')
+    env = dict(os.environ, BLHIP_BENCH_TEST_DOUBLE='1', OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--steps', '2', '--warmup', '1',
+                        '--workload', 'tiny', '--no-extra', '--no-cpu', '--no-pmc'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    _check_tiny_line(r.stdout, 3)
+    # a launcher / --gpus mismatch is refused loudly
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'tiny'],
+                         env=dict(env, WORLD_SIZE='3', RANK='0'), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and 'WORLD_SIZE=3' in (bad.stderr + bad.stdout)

@@ -241,3 +241,80 @@ def test_sharded_random_hyperstudies_match_oracle(tmp_path, world):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out[-3000:])
         assert 'random hyper-studies ok:' in out, out[-2000:]
+
+
+@pytest.mark.parametrize('n', [2, 3])
+def test_local_group_threads_match_unsharded(n):
+    """HyperStudy.fit(nJobs=N) inside ONE process (bayesloop_amd.dist.LocalGroup: one engine and one host thread per device,
+    one gather through shared memory, the accumulators merged as reduce-scatter over time slices + gather): host logic with N
+    oracle engines against the unsharded goldens."""
+    import bayesloop_amd as bl
+    import cases
+    import compare
+    import oracle_adapter as oa
+    from bayesloop_amd import dist
+    from oracle_engine import OracleEngine
+    prev = bl.set_engine(OracleEngine())
+    try:
+        for case in ['kat_hyper_1hp', 'c4_2hp', 'c4_small_evidence', 'c5_cp_grw']:
+            S = cases.build(bl, case)
+            engines = [OracleEngine() for _ in range(n)]
+            for k, e in enumerate(engines):
+                e.device = k
+            # drive the same host path HyperStudy.fit takes with nJobs > 1
+            real = dist.local_devices
+            import bayesloop_amd.engine as em
+            orig_for, orig_get = em.engine_for_device, em.get_engine
+            em.engine_for_device = lambda d: engines[d]
+            em.get_engine = lambda: engines[0]
+            engines[0].ctx = object()            # (marks a multi-device capable engine for HyperStudy.fit)
+            dist.local_devices = lambda n_jobs, root=0: list(range(n))
+            try:
+                with np.errstate(all='ignore'):
+                    S.fit(nJobs=n, **cases.fit_kwargs(case))
+            finally:
+                dist.local_devices, em.engine_for_device, em.get_engine = real, orig_for, orig_get
+            gold = oa.load_golden(case)
+            res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence, logEvidenceList=np.array(S.logEvidenceList),
+                       hyperParameterDistribution=S.hyperParameterDistribution)
+            if not cases.CASES[case].get('fit', {}).get('evidenceOnly'):
+                res['posteriorMeanValues'] = S.posteriorMeanValues
+                res['posteriorSequence'] = S.posteriorSequence
+            compare.check(res, gold, dict(compare.ORACLE_TOL, post_rtol=1e-10, small_rtol=1e-10))
+            assert sum(e.fits for e in engines) == len(S.logEvidenceList)
+            assert sum(e.fits > 0 for e in engines) == min(n, len(S.logEvidenceList))
+            assert len(S.lastTimingPerDevice) == n
+    finally:
+        bl.set_engine(prev)
+
+
+def test_local_group_propagates_a_failing_thread():
+    """A device thread that raises must not leave the others waiting at a barrier for ever."""
+    from bayesloop_amd import dist
+
+    class Boom(Exception):
+        pass
+
+    class E:
+        def __init__(self, k):
+            self.device = k
+
+        def accum_begin(self, *a, **k):
+            pass
+
+        def fit(self, *a, **k):
+            if self.device == 1:
+                raise Boom('device 1 failed')
+            import types
+            return types.SimpleNamespace(log_evidence=np.zeros(1), local_evidence=np.zeros((1, 2)), abort_step=np.full(1, -1), timing={})
+
+        def accum_log_ref(self):
+            return 0.0, 1
+
+        def accum_row_stats(self, p):
+            return np.zeros((2, 2))
+
+    import types
+    problem = types.SimpleNamespace(T=2, G=4, grid_size=[4])
+    with pytest.raises(Boom):
+        dist.local_sharded_hyper_fit([E(0), E(1)], problem, np.zeros((2, 1)), np.ones(2))
