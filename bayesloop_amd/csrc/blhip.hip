@@ -414,33 +414,37 @@ void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, si
 }
 
 // ---- time-resident path (blhip_resident.hpp): one launch for all time steps of a single-chain 2-D fit ----------------------------
-#ifndef RES_SEG128
-#define RES_SEG128 32
-#define RES_CHK128 8
-#endif
 struct ResidentPlan {
     int TR = 0, TC = 0, SEG = 0, tr = 0, tc = 0, ntiles = 0, NT = 0;
     size_t lds_bytes = 0;
 };
 
+template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID>
+void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
+    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID>::LDS_DOUBLES * sizeof(double);
+    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID>));
+    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+}
+
 template <int TR, int TC, int SEG, int CHK>
 void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd) {
-    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, false>::LDS_DOUBLES * sizeof(double);
-    if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, true>));
-        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, true>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
-    } else {
-        arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, false>));
-        hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, false>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
-    }
+    // forward pass of an evidence-only fit: nothing stored, no means, no rows to normalise -> the flavour with compile-time flags
+    const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
+    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false>(s, Q);
+    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true>(s, Q);
+    else launch_resident_k<TR, TC, SEG, CHK, false, false>(s, Q);
 }
 
 // tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
-// (tools/ubench/fp64_banks.hip), so more waves per SIMD would help -- but the 1024-thread shape of the 128 x 128 tile (segments
-// of 16, chunks of 4: -DRES_SEG128=16 -DRES_CHK128=4) has to live in 128 VGPRs, spills, and measured 18.7 us per 2048^2 step
-// against 13.2 us for 512 threads with 200 VGPRs
+// (tools/ubench/fp64_banks.hip), so more waves per SIMD help.  The 128 x 128 tile has two shapes: 512 threads (segments of 32, chunks
+// of 8, ~200 registers, 2 waves per SIMD) and -- option resident_threads128 = 1024, forward passes of evidence-only fits only -- 1024
+// threads (segments of 16, the whole window in registers before the barrier, 128 registers, 4 waves per SIMD)
 void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
-    if (rp.TR == 128) launch_resident_t<128, 128, RES_SEG128, RES_CHK128>(s, Q, bwd);
+    if (rp.TR == 128 && rp.SEG == 16) {
+        if (bwd || Q.store || Q.means || Q.normalise || Q.post) fail("internal: the 1024-thread resident shape runs evidence-only forward passes only");
+        launch_resident_k<128, 128, 16, 4, false, true>(s, Q);
+    }
+    else if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd);
     else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd);
     else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd);
     else launch_resident_t<32, 32, 8, 8>(s, Q, bwd);
@@ -492,8 +496,8 @@ void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
 // the smallest supported tile whose tile grid fits the chip (every tile = one co-resident block)
 // (Two 256-thread blocks per CU -- 512 tiles of 32 x 64 for the 1024^2 grid, so that one block computes while the other waits for a
 // strip -- was tried: the 512 blocks were not all co-resident, the hand-off waits timed out and the fit fell back.  One tile per CU.)
-bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp) {
-    const int shapes[4][3] = {{32, 32, 8}, {32, 64, 8}, {64, 64, 8}, {128, 128, RES_SEG128}};
+bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp, int seg128 = 32) {
+    const int shapes[4][3] = {{32, 32, 8}, {32, 64, 8}, {64, 64, 8}, {128, 128, seg128}};
     for (const auto &sh : shapes) {
         if (n0 % sh[0] || n1 % sh[1]) continue;
         const long long nt = (long long)(n0 / sh[0]) * (n1 / sh[1]);

@@ -54,7 +54,6 @@ constexpr int NSLOT = 8;         // ring of granule slots for the lagged sums (>
 constexpr int MAXLAG = 4;
 constexpr int DMAX = 4;          // data dimensions kept in registers
 constexpr int NRED = 7;          // == blk::NRED: partial-sum slots per step
-constexpr int ANCHOR = 16;       // rows between exact re-anchorings of the likelihood recurrence
 
 struct ResParams {
     int n0, n1, tr, tc, ntiles;
@@ -217,6 +216,46 @@ BLR_INL void walk(const double *x0, const double (&nearv)[R], double (&f)[R], bo
     }
 }
 
+// The same pass for the many-threads shapes (SEG = 16: 1024 threads per 128 x 128 tile = 4 waves per SIMD, 128 registers per thread):
+// the thread's WHOLE window -- near halo, its own SEG inputs, far halo -- is read before the barrier; the pass itself is
+// arithmetic and stores only (no loads of the next chunk's inputs, no window shifts).  A far halo that is a neighbour tile's
+// strip is fetched at the first chunk that reaches beyond the segment.
+template <int SEG, int C, class FarFn, class Pre, class Emit>
+BLR_INL void walk_full(const double (&nearv)[R], const double (&own)[SEG], double (&f)[R], bool far_is_strip, const double (&wk)[R + 1],
+                       FarFn &&far_fetch, Pre &&pre, Emit &&emit) {
+    static_assert(SEG % C == 0 && SEG >= R, "segment = whole chunks, at least one radius long");
+    constexpr int W = 2 * R + SEG;
+    constexpr int FIRST_FAR = ((SEG - R) / C) * C;   // first chunk with an output p, p + R >= SEG
+    double w[W];
+#pragma unroll
+    for (int k = 0; k < R; ++k) w[k] = nearv[k];
+#pragma unroll
+    for (int q = 0; q < SEG; ++q) w[R + q] = own[q];
+#pragma unroll
+    for (int k = 0; k < R; ++k) w[R + SEG + k] = f[k];
+#pragma unroll
+    for (int p0 = 0; p0 < SEG; p0 += C) {
+        if (p0 == FIRST_FAR && far_is_strip) {
+            far_fetch(f);
+#pragma unroll
+            for (int k = 0; k < R; ++k) w[R + SEG + k] = f[k];
+        }
+        pre(p0);
+        double v[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) v[j] = w[R + p0 + j] * wk[0];
+#pragma unroll
+        for (int k = R; k >= 1; --k) {
+            double t[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) t[j] = w[R + p0 + j - k] + w[R + p0 + j + k];
+#pragma unroll
+            for (int j = 0; j < C; ++j) v[j] = fma(t[j], wk[k], v[j]);
+        }
+        emit(p0, v);
+    }
+}
+
 // keep the optimiser from hoisting a thread's (time-invariant) address arithmetic out of the time loop: hoisted, the
 // addresses of every row / column a thread touches stay live across the whole step and spill (598 spilled VGPRs measured)
 BLR_INL int launder(int x) {
@@ -226,19 +265,31 @@ BLR_INL int launder(int x) {
     return x;
 }
 
-template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_>
+template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, bool EVID_ = false>
 struct Res {
     static constexpr int TR = TR_, TC = TC_, SEG = SEG_, CHK = CHK_;    // CHK: outputs per chunk of a pass
     static constexpr bool BWD = BWD_;
+    // EVID: forward pass of an evidence-only fit -- nothing is stored, no means, no rows to normalise: the flags of ResParams are
+    // compile-time constants (fewer live values: the many-threads shape has 128 registers per thread)
+    static constexpr bool EVID = EVID_;
+    static_assert(!(EVID && BWD), "evidence-only fits have no backward pass");
+    BLR_INL static bool f_store(const ResParams &Q) { return EVID ? false : Q.store != 0; }
+    BLR_INL static bool f_means(const ResParams &Q) { return EVID ? false : Q.means != 0; }
+    BLR_INL static bool f_norm(const ResParams &Q) { return EVID ? false : Q.normalise != 0; }
+    BLR_INL static double *f_post(const ResParams &Q) { return EVID ? nullptr : Q.post; }
     static constexpr int P = TC + 1;                 // LDS pitch in doubles: odd => the row-strided accesses of the axis-1 pass
                                                      // and the contiguous ones of the axis-0 pass are both conflict-free
     static constexpr int NSH = TC / SEG, NSV = TR / SEG;
     static constexpr int NT = TR * NSH;
     static_assert(TR * NSH == TC * NSV, "both passes use every thread");
     static_assert(NSH >= 2 && NSV >= 2, "edge segments need an in-tile neighbour segment on their near side");
-    static_assert(TR % SEG == 0 && TC % SEG == 0 && TR >= 2 * R && TC >= 2 * R && ANCHOR % CHK == 0, "tile shape");
+    // rows between exact re-anchorings of the likelihood recurrence: once per segment, at most 32 rows apart.  The recurrence's
+    // relative error grows like n^2 / 2 ulp in the worst case (n rows since the anchor): 32 rows -> 6e-14, four decades inside the bar
+    static constexpr int ANCHOR = SEG < 32 ? SEG : 32;
+    static_assert(TR % SEG == 0 && TC % SEG == 0 && TR >= 2 * R && TC >= 2 * R && ANCHOR % CHK == 0 && SEG % ANCHOR == 0, "tile shape");
     static constexpr int NW = NT / 64;
     static_assert(NT % 64 == 0, "whole waves");
+    static constexpr bool FULLW = NT > 512;          // many-threads shapes: whole window in registers before the barrier (walk_full)
     static constexpr int GPL = (512 / NW + 63) / 64;     // tiles per lane when NW waves share the <= 512 tiles' partial sums
     static constexpr int NG = 1;                         // sums every tile publishes per step: the scale sum (forward: sum a = the row sum
                                                          // of the stored state; backward: sum c)
@@ -262,16 +313,22 @@ struct Res {
         double *lds;
         // registers that live across a barrier
         double nearv[R], farv[R];
+        double own[FULLW ? SEG : 1];                 // (FULLW) the segment's own inputs, read before the barrier
         double xd[DMAX];                             // this step's data record (wave-uniform)
         double al8[BWD ? CHK : 1];                   // backward: the stored forward state of the chunk being processed
         unsigned long long gq[GPL][2 * NG];          // this wave's share of the lagged sums' granules, in flight since the step began
         double nz8[BWD ? 1 : CHK];                   // forward-only: the row being normalised (the chunk's cells, `lag` steps back)
         double npred;                                // backward: the sum of this step's posterior, predicted from scalars
+        // exp(second difference of the likelihood's exponent along the rows): depends on the thread's column and on the NUMBER of valid
+        // data dimensions of the step only -- recomputed when that number changes (almost never)
+        double mq_c, iq_c, dn_prev;
+        int nq_c;
         double sums[5];
         bool dead;
 
         BLR_INL void init(const ResParams &Q, int block, int tid_, double *lds_) {
             tid = tid_; lds = lds_; dead = false;
+            mq_c = 1.0; iq_c = 1.0; dn_prev = -1.0; nq_c = 0;
             tr = uni(Q.tr); tc = uni(Q.tc);
             tile = uni(tile_of_block(block, Q.ntiles));
             ti = uni(tile / Q.tc); tj = uni(tile - ti * Q.tc);
@@ -312,11 +369,11 @@ struct Res {
             for (int q = 0; q < DMAX; ++q) xd[q] = q < Q.d ? ldu(Q.rec, (long long)t * Q.rec_len + q) : nan_();
         }
         BLR_INL double *row_ptr(const ResParams &Q, int k, int r0, int c) const {
-            return Q.post ? Q.post + (long long)time_of(Q, k) * Q.n0 * Q.n1 + (long long)(i0 + r0) * Q.n1 + (j0 + c) : nullptr;
+            return f_post(Q) ? f_post(Q) + (long long)time_of(Q, k) * Q.n0 * Q.n1 + (long long)(i0 + r0) * Q.n1 + (j0 + c) : nullptr;
         }
         // forward-only: the row written `lag` steps ago (time t - lag), whose sum arrives with this step's lagged sums
         BLR_INL double *lagged_row_ptr(const ResParams &Q, int k, double *pt0) const {
-            return (!BWD && Q.normalise && k >= Q.lag && pt0) ? pt0 - (long long)Q.lag * Q.n0 * Q.n1 : nullptr;
+            return (!BWD && f_norm(Q) && k >= Q.lag && pt0) ? pt0 - (long long)Q.lag * Q.n0 * Q.n1 : nullptr;
         }
         // backward: N_t = sum_cells alpha_t beta_t WITHOUT a reduction.  beta_t = T(c_{t+1}) s'_t and the reflect-boundary Gaussian
         // stencil T is self-adjoint, so N_t = s'_t sum T(alpha_t) c_{t+1}; the forward pass made alpha_{t+1} = T(alpha_t) s_{t+1} L_{t+1}
@@ -406,6 +463,10 @@ struct Res {
             const double *x0 = lds + hg.line * P + first_pos(hg.seg, DIR);
 #pragma unroll
             for (int k = 0; k < R; ++k) nearv[k] = x0[DIR * (k - R)];
+            if (FULLW) {
+#pragma unroll
+                for (int q = 0; q < SEG; ++q) own[q] = x0[DIR * q];
+            }
             if (hg.far == 0) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) farv[k] = x0[DIR * (SEG + k)];
@@ -434,7 +495,8 @@ struct Res {
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w1, q);
-            walk<SEG, DIR, CHK>(x0, nearv, farv, hg.far == 2, wk, far_fetch, [](int) {}, emit8);
+            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, hg.far == 2, wk, far_fetch, [](int) {}, emit8);
+            else walk<SEG, DIR, CHK>(x0, nearv, farv, hg.far == 2, wk, far_fetch, [](int) {}, emit8);
         }
         BLR_INL void h_walk(const ResParams &Q, int k) { const Geo hg = hgeo(); if (hg.seg == 0) h_walk_d<-1>(Q, k, hg); else h_walk_d<1>(Q, k, hg); }
 
@@ -467,6 +529,10 @@ struct Res {
             const double *x0 = lds + first_pos(vg.seg, DIR) * P + vg.line;
 #pragma unroll
             for (int k = 0; k < R; ++k) nearv[k] = x0[DIR * (k - R) * P];
+            if (FULLW) {
+#pragma unroll
+                for (int q = 0; q < SEG; ++q) own[q] = x0[DIR * q * P];
+            }
             if (vg.far == 0) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) farv[k] = x0[DIR * (SEG + k) * P];
@@ -516,15 +582,22 @@ struct Res {
                     }
                 }
                 const double d1 = cA * (mu1 - mu0) * s1;
-                const double d2 = -2.0 * cA * dn * Q.step0 * Q.step0;
                 blmath::exp_mn(a0, rc.mE, rc.nE);
                 blmath::exp_mn(d1, rc.mR, rc.nR);
-                blmath::exp_mn(d2, rc.mq, rc.nq);
+                if (dn != dn_prev) {                 // (wave-uniform: the data record is)
+                    const double d2 = -2.0 * cA * dn * Q.step0 * Q.step0;
+                    int tmp;
+                    blmath::exp_mn(d2, mq_c, nq_c);
+                    if (BWD) blmath::exp_mn(-d2, iq_c, tmp);
+                    dn_prev = dn;
+                }
+                rc.mq = mq_c; rc.nq = nq_c; rc.iq = iq_c;
                 if (BWD) {
                     int tmp;
                     blmath::exp_mn(-a0, rc.iE, tmp);
                     blmath::exp_mn(-d1, rc.iR, tmp);
-                    blmath::exp_mn(-d2, rc.iq, tmp);
+                } else {
+                    rc.mE *= scale;                  // forward: the step's scale rides on the likelihood's mantissa (one product per cell less)
                 }
             }
 #pragma unroll
@@ -533,11 +606,11 @@ struct Res {
                 const double Lv = ldexp_(rc.mE, rc.nE);
                 double keep;                                         // what becomes the tile's new state
                 if (!BWD) {
-                    const double a = v[j] * scale * Lv;
+                    const double a = v[j] * Lv;
                     keep = a;
-                    if (Q.store) st_stream(pt0 + (long long)(DIR * p) * Q.n1, a);
+                    if (f_store(Q)) st_stream(pt0 + (long long)(DIR * p) * Q.n1, a);
                     sums[0] += a;
-                    if (Q.means) { sums[3] = fma(a, m0p[DIR * p], sums[3]); sums[4] = fma(a, g1, sums[4]); }
+                    if (f_means(Q)) { sums[3] = fma(a, m0p[DIR * p], sums[3]); sums[4] = fma(a, g1, sums[4]); }
                 } else {
                     const double beta = v[j] * scale;
                     const double pp = al8[j] * beta;
@@ -586,7 +659,8 @@ struct Res {
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
-            walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_fetch, pre8, emit8);
+            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, vg.far == 2, wk, far_fetch, pre8, emit8);
+            else walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_fetch, pre8, emit8);
         }
         BLR_INL void v_walk(const ResParams &Q, int k) { const Geo vg = vgeo(); if (vg.seg == 0) v_walk_d<-1>(Q, k, vg); else v_walk_d<1>(Q, k, vg); }
 
@@ -602,7 +676,7 @@ struct Res {
             double *x0 = lds + r0 * P + c;
             const double *m0p = lds + LDS_M0 + r0;
             const long long g0 = (long long)(i0 + r0) * Q.n1 + (j0 + c);
-            double *pt0 = Q.post ? Q.post + (long long)time_of(Q, 0) * Q.n0 * Q.n1 + g0 : nullptr;
+            double *pt0 = f_post(Q) ? f_post(Q) + (long long)time_of(Q, 0) * Q.n0 * Q.n1 + g0 : nullptr;
             const double *s = Q.src0 + g0;
 #pragma unroll 1
             for (int p0 = 0; p0 < SEG; p0 += CHK) {
@@ -650,9 +724,9 @@ __device__ __forceinline__ void arrive_and_flag(double *misc, unsigned *flag, un
     }
 }
 
-template <int TR, int TC, int SEG, int CHK, bool BWD>
+template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID = false>
 __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Q) {
-    using K = Res<TR, TC, SEG, CHK, BWD>;
+    using K = Res<TR, TC, SEG, CHK, BWD, EVID>;
     constexpr int NT = K::NT, NW = K::NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *misc = lds + K::LDS_MISC;
@@ -721,7 +795,7 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             for (int q = 0; q < NV; ++q) v[q] = th.sums[BWD ? q : (q == 0 ? 0 : q + 2)];      // forward: N, M0, M1
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                if (!BWD && q > 0 && !Q.means) break;
+                if (!BWD && q > 0 && !K::f_means(Q)) break;
                 const double ws = blk::wave_sum(v[q]);
                 if ((tid & 63) == 0) red[(tid >> 6) * NV + q] = ws;
             }
@@ -736,7 +810,7 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
 #pragma unroll
                 for (int q = 0; q < NV; ++q) {
                     tot[q] = 0.0;
-                    if (!BWD && q > 0 && !Q.means) continue;
+                    if (!BWD && q > 0 && !K::f_means(Q)) continue;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) tot[q] += red[w * NV + q];
                 }
@@ -746,7 +820,7 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
                     K::publish_sum(Q, th.tile, k, 0, tot[2]);
                 } else {
                     out[0] = tot[0];
-                    if (Q.means) { out[3LL * Q.ntiles] = tot[1]; out[4LL * Q.ntiles] = tot[2]; }
+                    if (K::f_means(Q)) { out[3LL * Q.ntiles] = tot[1]; out[4LL * Q.ntiles] = tot[2]; }
                     K::publish_sum(Q, th.tile, k, 0, tot[0]);
                 }
             }
