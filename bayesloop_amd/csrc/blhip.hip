@@ -493,6 +493,40 @@ void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
     HIPCHECK(hipGetLastError());
 }
 
+// backward pass with the fused fold, two chains per block (blc::chain_fold2_kernel)
+template <int NK, int NTW>
+void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q) {
+    const size_t lds = blc::lds_doubles_fold2<NK, NTW>() * sizeof(double);
+    arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW>));
+    hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW>), dim3((unsigned)(((Q.nslots + 1) / 2) * Q.strips)), dim3(blc::NT), lds, s, Q);
+}
+
+template <int NTW>
+void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk) {
+    switch (nk) {
+        case 6: launch_fold2_k<6, NTW>(s, Q); break;
+        case 8: launch_fold2_k<8, NTW>(s, Q); break;
+        case 10: launch_fold2_k<10, NTW>(s, Q); break;
+        case 12: launch_fold2_k<12, NTW>(s, Q); break;
+        case 14: launch_fold2_k<14, NTW>(s, Q); break;
+        case 16: launch_fold2_k<16, NTW>(s, Q); break;
+        case 18: launch_fold2_k<18, NTW>(s, Q); break;
+        case 20: launch_fold2_k<20, NTW>(s, Q); break;
+        case 22: launch_fold2_k<22, NTW>(s, Q); break;
+        case 24: launch_fold2_k<24, NTW>(s, Q); break;
+        default: fail("internal: two-chain fold kernel with %d band blocks", nk);
+    }
+}
+
+bool fold2_shape(int ntw) { return ntw == 4 || ntw == 2; }
+
+void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw) {
+    if (ntw == 4) launch_fold2_w<4>(s, Q, nk);
+    else if (ntw == 2) launch_fold2_w<2>(s, Q, nk);
+    else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
+    HIPCHECK(hipGetLastError());
+}
+
 // the smallest supported tile whose tile grid fits the chip (every tile = one co-resident block)
 // (Two 256-thread blocks per CU -- 512 tiles of 32 x 64 for the 1024^2 grid, so that one block computes while the other waits for a
 // strip -- was tried: the 512 blocks were not all co-resident, the hand-off waits timed out and the fit fell back.  One tile per CU.)

@@ -457,4 +457,344 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     }
 }
 
+
+// ---- backward pass of a hyper-study with the fused fold, TWO chains per block ---------------------------------------------------------
+// The fold is a read-modify-write of the partial accumulator: 16 of the 24 bytes a chain's backward step moves per cell (the other 8:
+// its stored alpha), and the pass runs at the memory roof for all but the widest bands.  Here a block owns one strip of TWO chains:
+// both add their weighted posteriors to the accumulator cell while it is in registers -- 8 + 16 / 2 = 16 B per chain, cell and step.
+//  * LDS has room for one 64 KB buffer per chain, not two: a chain's state (the lane's 4 NTW cells) lives in REGISTERS; LDS is the
+//    exchange buffer the waves read their product rings from.  Per chain and step: the lanes write their cells to the chain's buffer,
+//    ONE barrier, rings + products + epilogue (new cells -> registers).  The chains alternate, so the barrier of one chain's step
+//    also fences the other chain's buffer between its readers and its next writers;
+//  * the stored alpha is requested one CHAIN-step ahead into one register set (the slot a tile's epilogue has just consumed is
+//    re-filled for the other chain); the accumulator cells of a step are requested during the step before, updated by chain 0,
+//    updated and stored by chain 1;
+//  * both chains see the same likelihood: the second one starts its recurrence from the first one's anchors (no exponentials).
+// Everything else -- bands on the matrix pipe, lagged-normaliser scales from data-tagged granules, predicted posterior sums, bounded
+// spins -- is chain_kernel<NK, NTW, true, false>'s.  Launched for rounds of 2 x (CUs / strips) chains when the batch folds.
+template <int NK, int NTW>
+constexpr size_t lds_doubles_fold2() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 64 + NW * NTW * TM + 2 * 2 * NW * 4 * 3 + 4 * NSLOT + 8; }
+
+template <int NK, int NTW>
+__global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P) {
+    constexpr int R0 = (4 * NK - TM) / 2;
+    constexpr int N0 = NW * NTW * TM;
+    constexpr int XSZ = N0 * WCOL;
+    static_assert(NK >= 6 && R0 % 4 == 0, "band = 16 + 2 R0 columns, R0 a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *const X = lds;                          // [2 chains][N0][16]   exchange buffers
+    double *const As = X + 2 * XSZ;                 // [2 chains][NK][64]   A operands
+    double *const m0s = As + 2 * NK * 64;           // [N0]
+    double *const red = m0s + N0;                   // [2 chains][2 parities][NW * 4][3]
+    double *const scal = red + 2 * 2 * NW * 4 * 3;  // [2 chains][NSLOT]
+    double *const iscal = scal + 2 * NSLOT;         // [2 chains][NSLOT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cs2 = blockIdx.x / P.strips, tj = blockIdx.x - cs2 * P.strips;
+    const int nch = min(2, P.nslots - 2 * cs2);                   // chains of this block (the last pair of a launch may be single)
+    int bch[2], tap[2], lw0[2];
+    long long o0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bch[j] = sldi(P.chain_ids, 2 * cs2 + min(j, nch - 1));
+        tap[j] = sldi(P.tap_id, bch[j]);
+        lw0[j] = tap[j] >= 0 ? sldi(P.tap_lw, tap[j]) : 0;
+        o0[j] = tap[j] >= 0 ? sldi(P.tap_off, tap[j]) : 0;
+    }
+    const int gj = tj * WCOL + (lane & 15);
+    const long long G = (long long)P.n0 * P.n1;
+
+    // first step: the source (uniform) is consumed unfiltered -> identity bands; the chains' bands replace them after step 0
+    for (int e = tid; e < 2 * NK * 64; e += NT) { const int q = e % (NK * 64); As[e] = (4 * (q >> 6) + ((q & 63) >> 4) - R0 - (q & 15)) == 0 ? 1.0 : 0.0; }
+    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
+    if (tid < 4 * NSLOT) scal[tid] = 1.0;
+    for (int e = tid; e < 2 * XSZ; e += NT) { const int q = e % XSZ; X[e] = P.src0[(long long)(q >> 4) * P.n1 + tj * WCOL + (q & 15)]; }
+
+    const double cA = P.colA[gj], cB = P.colB[gj];
+    const unsigned rowx8 = (unsigned)WCOL * 8u;                    // (strip-major sequences: the fold is private to the fit)
+    const unsigned strip0 = (unsigned)tj * (unsigned)(P.n0 * WCOL * 8);
+    const int row0 = wv * (NTW * TM);
+    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto cell_off = [&](int l, int it, int r) { return __umul24(row0 + it * TM + (l >> 4) + 4 * r, rowx8) + strip0 + (unsigned)(l & 15) * 8u; };
+
+    const int t_first = P.T - 1;
+    double *const pslot = P.part + (long long)cs2 * P.part_stride;
+    double stt[NTW][4];                             // the state (c = beta L of the lane's cells) the LAST chain-step produced: it goes to
+                                                    // that chain's exchange buffer right after the next barrier (nobody reads it then)
+    double al[NTW][4];                              // stored alpha of the chain-step that runs next
+    double pacc[NTW][4];                            // accumulator cells of the time step in flight
+    {
+        const double *p0 = P.post + (long long)bch[0] * P.post_stride + (long long)t_first * G;
+#pragma unroll
+        for (int it = 0; it < NTW; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                al[it][r] = blm::ld32(p0, cell_off(lane, it, r));
+                pacc[it][r] = P.part_fresh ? blm::ld32(P.zeros, cell_off(lane, it, r) & 4088u) : blm::ld32(pslot + (long long)t_first * G, cell_off(lane, it, r));
+                stt[it][r] = 0.0;
+            }
+    }
+    double wch[2], inpred[2], sfn[2] = {1.0, 1.0};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { wch[j] = j < nch ? P.wchain[bch[j]] : 0.0; inpred[j] = P.infirst[bch[j]]; }
+    if (wv == SCALE_WAVE || wv == 5 || wv == 0 || wv == NW - 1) __builtin_amdgcn_s_setprio(2);
+    bool dead = false;
+    typedef const double __attribute__((address_space(3))) *lds_cp;
+    unsigned long long gq0[2] = {0ull, 0ull}, gq1[2] = {0ull, 0ull};
+    double Sprev[2] = {1.0, 1.0};
+    double mq = 1.0, iq = 1.0, dn_prev = -1.0;
+    int nq = 0;
+    double xd[DMAX];
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) xd[q] = __builtin_nan("");
+    // the first chain's anchors of the step, reused by the second one
+    double a_mE = 1.0, a_mR = 1.0, a_iE = 1.0, a_iR = 1.0;
+    int a_nE = 0, a_nR = 0;
+    int pend_j = -1, pend_k = 0;                   // the chain-step whose row sums wave 5 still has to add up (after the next barrier)
+
+    // wave 5: block totals of a finished chain-step -> partial sums of the strip + the granule the scale of step k + lag is made of
+    auto totals = [&](int j, int k) {
+        if (wv == 5 && lane < 3) {
+            const double *rk = red + (j * 2 + (k & 1)) * (NW * 4 * 3);
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW * 4; ++w) tot += rk[w * 3 + lane];
+            const int t = P.T - 1 - k;
+            P.psum[(((long long)t * P.B + bch[j]) * NRED + lane) * P.nblk + tj] = tot;
+            if (lane == 2) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
+                const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
+                unsigned long long *gw = P.gran + ((((long long)(k & (NSLOT - 1)) * P.nslots + 2 * cs2 + j) * P.strips + tj) << 1);
+                blr::st_u64(gw, tag | (bits & 0xffffffffull));
+                blr::st_u64(gw + 1, tag | (bits >> 32));
+            }
+        }
+    };
+    __syncthreads();
+
+    // ONE body for both chains of the block (j is block-uniform and changes every iteration): the two chain-steps of a time step are
+    // not unrolled into one another -- unrolled, the scheduler interleaves their loads and the kernel spills (measured: 54 - 93 VGPRs)
+    const bool scale_wave = wv == SCALE_WAVE;
+    const int nsteps = P.T * nch;
+#pragma unroll 1
+    for (int cstep = 0; cstep < nsteps; ++cstep) {
+        const int k = nch == 2 ? cstep >> 1 : cstep;
+        const int j = __builtin_amdgcn_readfirstlane(nch == 2 ? cstep & 1 : 0);
+        const int t = P.T - 1 - k;
+        const int tn = (k + 1 < P.T) ? t - 1 : t;
+        const int jn = k + 1;
+        const int bj = j ? bch[1] : bch[0];
+        if (j == 0) {
+#pragma unroll
+            for (int q = 0; q < DMAX; ++q) xd[q] = q < P.d ? P.rec[(long long)t * P.rec_len + q] : __builtin_nan("");
+        }
+        double *const pslot_t = pslot + (long long)t * G;
+        double *const pslot_tn = pslot + (long long)tn * G;
+        double *const Xj = X + j * XSZ;
+        // scale wave: the granules of the sums the scale of step k + 2 of this chain is made of (requested a step ahead)
+        const bool need = scale_wave && jn >= P.lag && jn < P.T;
+        const unsigned long long *gp = P.gran + ((((long long)((jn - P.lag) & (NSLOT - 1)) * P.nslots + 2 * cs2 + j) * P.strips + lane) << 1);
+        const bool mine = need && lane < P.strips;
+        const unsigned long long hq0 = j ? gq0[1] : gq0[0], hq1 = j ? gq1[1] : gq1[0];
+        if (scale_wave && jn + 1 >= P.lag && jn + 1 < P.T && lane < P.strips) {
+            const unsigned long long *gn = P.gran + ((((long long)((jn + 1 - P.lag) & (NSLOT - 1)) * P.nslots + 2 * cs2 + j) * P.strips + lane) << 1);
+            const unsigned long long n0_ = blr::ld_u64(gn), n1_ = blr::ld_u64(gn + 1);
+            if (j) { gq0[1] = n0_; gq1[1] = n1_; } else { gq0[0] = n0_; gq1[0] = n1_; }
+        }
+        const double sf_now = j ? sfn[1] : sfn[0];
+        {
+            const double sfv = P.sfwd[(long long)bj * P.T + min(tn + 1, P.T - 1)];
+            if (j) sfn[1] = sfv; else sfn[0] = sfv;
+        }
+        __syncthreads();                                            // every wave's rows of this chain are in Xj
+        if (pend_j >= 0) {
+            // the previous chain-step's new state -> that chain's exchange buffer: all its readers have passed the barrier above, its
+            // next readers wait at the next one
+            double *const Xp = X + pend_j * XSZ;
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xp[(row0 + it * TM + g + 4 * r) * WCOL + c] = stt[it][r];
+            totals(pend_j, pend_k);
+        }
+        pend_j = j; pend_k = k;
+
+        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
+        double Bv[NK];
+        {
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            if (edge) {
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = Xj[reflect1(row0 - R0 + 4 * kb + g, N0) * WCOL + c];
+            } else {
+                const double *s0 = Xj + (row0 - R0 + g) * WCOL + c;
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
+            }
+        }
+        double scale = 1.0, wq = 0.0, wfloor = 0.0;
+        double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
+        int nE = 0, nR = 0;
+        double sN = 0.0, sS = 0.0, sC = 0.0;
+        // the chain-step that runs after this one: chain 1 of this step, or chain 0 of the next (its stored alpha is requested now)
+        const bool last_chain = j + 1 == nch;
+        const int bnext = last_chain ? bch[0] : bch[1];
+        const double *const pnext = P.post + (long long)bnext * P.post_stride + (long long)(last_chain ? tn : t) * G;
+
+#pragma unroll
+        for (int it = 0; it < NTW; ++it) {
+            const int i = row0 + it * TM;
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            {
+                const unsigned aoff = (unsigned)l * 8u + (unsigned)(j * NK * 64 * 8);
+                lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+            }
+            if (it == 0) {
+                scale = scal[j * NSLOT + (k & (NSLOT - 1))];
+                double ip = j ? inpred[1] : inpred[0];
+                if (k > 0) ip *= sf_now * iscal[j * NSLOT + (k & (NSLOT - 1))];      // N_t = s'_t N_(t+1) / s_(t+1)
+                if (j) inpred[1] = ip; else inpred[0] = ip;
+                const double wc = j ? wch[1] : wch[0];
+                wq = wc * ip; wfloor = wc * 1e-300;
+                if (scale_wave) {
+                    double sj = 1.0;
+                    if (need) {
+                        const unsigned long long want = (unsigned long long)(unsigned)(jn - P.lag + 1);
+                        unsigned long long q0 = hq0, q1 = hq1;
+                        bool ok = !mine || ((q0 >> 32) == want && (q1 >> 32) == want);
+                        if (!dead && !__all(ok)) {
+                            const unsigned long long t0 = blr::now_ticks();
+                            for (unsigned spins = 1; !__all(ok); ++spins) {
+                                if (!ok) { q0 = blr::ld_u64(gp); q1 = blr::ld_u64(gp + 1); ok = (q0 >> 32) == want && (q1 >> 32) == want; }
+                                blr::nap();
+                                if ((spins & 255u) == 0u) {
+                                    if (blr::ld_flag(P.abort_word) != 0u) { dead = true; break; }
+                                    if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; break; }
+                                }
+                            }
+                        }
+                        const double v = mine ? __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32))) : 0.0;
+                        const double Sg = blk::wave_sum(v);
+                        const double sp = j ? Sprev[1] : Sprev[0];
+                        sj = dead ? 1.0 : sp * scal[j * NSLOT + ((jn - P.lag) & (NSLOT - 1))] / Sg;
+                        if (j) Sprev[1] = Sg; else Sprev[0] = Sg;
+                    }
+                    if (lane == 0) { scal[j * NSLOT + (jn & (NSLOT - 1))] = sj; iscal[j * NSLOT + (jn & (NSLOT - 1))] = 1.0 / sj; }
+                }
+                // anchors of the stride-4 likelihood recurrence: both chains see the same likelihood -- the first one computes them
+                if (j == 0) {
+                    const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
+                    double a0 = 0.0, s1 = 0.0, dn = 0.0;
+#pragma unroll
+                    for (int q = 0; q < DMAX; ++q) {
+                        const double x = xd[q];
+                        if (x == x) {
+                            const double dq = x - mu0;
+                            a0 = fma(-(dq * dq), cA, a0) - cB;
+                            s1 += (x - mu0) + (x - mu4);
+                            dn += 1.0;
+                        }
+                    }
+                    const double d1 = cA * (mu4 - mu0) * s1;
+                    int tmp;
+                    exp_mn(a0, a_mE, a_nE);
+                    exp_mn(d1, a_mR, a_nR);
+                    if (dn != dn_prev) {
+                        const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                        exp_mn(d2, mq, nq);
+                        exp_mn(-d2, iq, tmp);
+                        dn_prev = dn;
+                    }
+                    exp_mn(-a0, a_iE, tmp);
+                    exp_mn(-d1, a_iR, tmp);
+                }
+                mE = a_mE; nE = a_nE; mR = a_mR; nR = a_nR; iE = a_iE; iR = a_iR;
+            }
+
+            // ---- epilogue: the lane's 4 cells (rows i + g + 4 r) ---------------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double Lv = ldexp(mE, nE);
+                const double beta = acc[r] * scale;
+                const double p = al[it][r] * beta;
+                const double cn = beta * Lv;
+                const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
+                stt[it][r] = cn;
+                pacc[it][r] += fmax(p * wq, wfloor);
+                sN += p; sS += pl; sC += cn;
+                mE *= mR; nE += nR;
+                mR *= mq; nR += nq;
+                iE *= iR; iR *= iq;
+            }
+            // the last chain of the time step stores the accumulator cells (nobody else touches the slot's cells during the launch) and
+            // requests those of the next time step; every chain-step requests the stored alpha of the chain-step after it (the tile's
+            // slot has just been consumed)
+            if (last_chain) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stnt(pslot_t, cell_off(l, it, r), pacc[it][r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned aoffs = cell_off(l, it, r);
+                    pacc[it][r] = ldnt(P.part_fresh ? P.zeros : pslot_tn, P.part_fresh ? (aoffs & 4088u) : aoffs);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) al[it][r] = ldnt(pnext, cell_off(l, it, r));
+            // ---- advance the ring by one tile --------------------------------------------------------------------------------------
+            if (it + 1 < NTW) {
+#pragma unroll
+                for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
+                if (edge) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = Xj[reflect1(i + TM + R0 + 4 * q + g, N0) * WCOL + c];
+                } else {
+                    const double *s1 = Xj + (i + TM + R0 + g) * WCOL + c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = s1[q * 4 * WCOL];
+                }
+            }
+        }
+
+        // ---- row sums of the chain-step -> LDS (wave 5 adds them up after the next barrier) -------------------------------------------
+        {
+            double v[3] = {sN, sS, sC};
+            double *rk = red + (j * 2 + (k & 1)) * (NW * 4 * 3);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                double x = v[q];
+                x = blk::dpp_add<0x111, 0xf>(x);
+                x = blk::dpp_add<0x112, 0xf>(x);
+                x = blk::dpp_add<0x114, 0xf>(x);
+                x = blk::dpp_add<0x118, 0xf>(x);
+                if ((lane & 15) == 15) rk[(wv * 4 + (lane >> 4)) * 3 + q] = x;
+            }
+        }
+        if (k == 0 && last_chain) {        // the chains' bands replace the identity of the first step
+            __syncthreads();
+            {
+                double *const Xp = X + pend_j * XSZ;
+                const int l = fresh_lane(), g = l >> 4, c = l & 15;
+#pragma unroll
+                for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Xp[(row0 + it * TM + g + 4 * r) * WCOL + c] = stt[it][r];
+                totals(pend_j, pend_k);
+                pend_j = -1;
+            }
+            for (int e = tid; e < 2 * NK * 64; e += NT) {
+                const int jj = e / (NK * 64), q = e - jj * (NK * 64);
+                const int a = abs(4 * (q >> 6) + ((q & 63) >> 4) - R0 - (q & 15));
+                As[e] = a == 0 ? (lw0[jj] > 0 ? P.taps[o0[jj]] : 1.0) : (a <= lw0[jj] ? P.taps[o0[jj] + a] : 0.0);
+            }
+        }
+    }
+    __syncthreads();
+    if (pend_j >= 0) totals(pend_j, pend_k);
+}
+
 }  // namespace blc

@@ -202,6 +202,10 @@ struct ChainRun {
     // bandwidth unused: same bytes, one pass)
     bool fused = false;
     bool fold_done = false;                        // this batch's posteriors are in the accumulator already
+    // fused fold with TWO chains per block (blc::chain_fold2_kernel): the backward pass runs rounds of 2 x cpr chains of its own
+    bool fold2 = false;
+    std::vector<int> round_start_b, round_nk_b;
+    int slots_used = 0;                            // partial accumulators the backward launches write (one per block column)
     double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr, *d_zeros = nullptr;
     std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
     double fold_ref = -INFINITY;
@@ -215,12 +219,13 @@ struct ChainRun {
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
         if (!on) return;
-        gran_bytes = carve_size((size_t)blc::NSLOT * cp.cpr * cp.strips * 2 * 8);
+        // (granule slots for 2 x cpr chains: the two-chain fold kernel runs rounds of that size)
+        gran_bytes = carve_size((size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2 * 8);
         ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64));
         char *rc = ctx->resx.as<char>();
         d_order = carve<int>(rc, (size_t)B);
         int *d_tapid = carve<int>(rc, (size_t)B);
-        CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * cp.cpr * cp.strips * 2);
+        CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2);
         d_abort = carve<unsigned>(rc, 16);
         CQ.abort_word = d_abort;
         HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
@@ -237,8 +242,22 @@ struct ChainRun {
         // (not beside overlapped folds: a FoldJob of the previous batch may still read ctx->accw and read-modify-write ctx->acc on the
         //  second stream while this batch re-carves accw and its fused fold writes ctx->acc on the main stream)
         fused = post_private && !cp.has_reset && !E.overlap_acc && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        slots_used = (int)std::min<int64_t>(cp.cpr, B);
+        if (fused && !E.chain_means && fold2_shape(cp.ntw) && prog.LW0 > 0 && ctx->option("fold2", 1.0) != 0.0) {
+            fold2 = true;
+            const int per = 2 * cp.cpr;
+            for (int64_t s0 = 0; s0 < B; s0 += per) {
+                const int64_t s1 = std::min<int64_t>(B, s0 + per);
+                const int tp = cp.tap_id[cp.order[s1 - 1]];                   // (sorted by radius: the last chain of the round is its widest)
+                const int r0 = std::max(4, ((tp >= 0 ? E.taps->lw[tp] : 0) + 3) / 4 * 4);
+                round_start_b.push_back((int)s0);
+                round_nk_b.push_back((blc::TM + 2 * r0) / 4);
+            }
+            round_start_b.push_back((int)B);
+            slots_used = (int)std::min<int64_t>(cp.cpr, (B + 1) / 2);
+        }
         if (fused) {
-            ctx->accpart.ensure((size_t)std::min<int64_t>(cp.cpr, B) * T * G * 8);
+            ctx->accpart.ensure((size_t)slots_used * T * G * 8);
             ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(4096));
             char *wc = ctx->accw.as<char>();
             d_fold_sfwd = carve<double>(wc, (size_t)T * B);
@@ -255,11 +274,13 @@ struct ChainRun {
         const int64_t T = E.T, B = E.B;
         HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * cp.strips * 8, st));
         HIPCHECK(hipMemsetAsync(d_abort, 0, 64, st));
-        for (size_t r = 0; r + 1 < cp.round_start.size(); ++r) {
+        const bool two = bwd && fused && fold2;
+        const std::vector<int> &rstart = two ? round_start_b : cp.round_start, &rnk = two ? round_nk_b : cp.round_nk;
+        for (size_t r = 0; r + 1 < rstart.size(); ++r) {
             blc::ChainParams Q = CQ;
             HIPCHECK(hipMemsetAsync(CQ.gran, 0, gran_bytes, st));       // tags restart with every launch
-            Q.chain_ids = d_order + cp.round_start[r];
-            Q.nslots = cp.round_start[r + 1] - cp.round_start[r];
+            Q.chain_ids = d_order + rstart[r];
+            Q.nslots = rstart[r + 1] - rstart[r];
             Q.psum = psum;
             Q.src0 = bwd ? E.DT->uniform : E.DT->prior;
             Q.kinds = cp.has_reset ? (bwd ? E.M->kindB : E.M->kindF) : nullptr;
@@ -278,13 +299,15 @@ struct ChainRun {
             HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
             Q.prof = ctx->small.as<unsigned long long>();
 #endif
-            launch_chain(st, Q, cp.round_nk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
+            if (two) launch_fold2(st, Q, rnk[r], cp.ntw);
+            else launch_chain(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
             {   // HBM: only what the fit keeps -- forward the stored state (8 B; nothing for evidence-only fits), backward the stored
-                // state in + the posterior out (16 B) or + the read-modify-write of the partial accumulator (24 B)
+                // state in + the posterior out (16 B) or + the read-modify-write of the partial accumulator (24 B; shared by the two
+                // chains of a block of the two-chain fold kernel: 8 + 16 / 2 = 16 B)
                 const double cells = (double)Q.nslots * E.G * T;
-                const double bytes = bwd ? (fold_now ? 24.0 : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
-                const int r0 = (4 * cp.round_nk[r] - blc::TM) / 2;
-                account(ctx, bwd, cells * bytes, cells * ((cp.round_nk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
+                const double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
+                const int r0 = (4 * rnk[r] - blc::TM) / 2;
+                account(ctx, bwd, cells * bytes, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
             }
 #ifdef BLC_PROF
             {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
@@ -296,7 +319,7 @@ struct ChainRun {
                     const unsigned long long *h = hh + wvi * 256;
                     double acc[8] = {0}; int n = 0;
                     for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
-                    std::fprintf(stderr, "[blc prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", cp.round_nk[r], wvi ? 2 : 0, n);
+                    std::fprintf(stderr, "[blc prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", rnk[r], wvi ? 2 : 0, n);
                     double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
                     std::fprintf(stderr, " | total %.0f\n", tot);
                 }
@@ -339,9 +362,9 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
         // the slots need no memset: the first launch of the pass reads zeros instead of them (part_fresh) -- except slots it does not
         // use (a first launch with fewer chains than slots), which later launches may
-        const int first_n = cp.round_start[1] - cp.round_start[0];
-        if (first_n < std::min<int>(cp.cpr, (int)B))
-            HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * E.G, 0, (size_t)(std::min<int>(cp.cpr, (int)B) - first_n) * T * E.G * 8, E.st));
+        const int first_n = fold2 ? (round_start_b[1] - round_start_b[0] + 1) / 2 : cp.round_start[1] - cp.round_start[0];
+        if (first_n < slots_used)
+            HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * E.G, 0, (size_t)(slots_used - first_n) * T * E.G * 8, E.st));
         HIPCHECK(hipMemsetAsync(d_zeros, 0, 4096, E.st));
     }
 
@@ -383,7 +406,7 @@ struct ChainRun {
             const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
             HIPCHECK(hipEventRecord(ctx->ev[4], st));
             hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((G / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
-                               ctx->accpart.as<double>(), (long long)T * G, std::min<int>(cp.cpr, (int)B), E.g.n0, E.g.n1, (int)T, r, rb,
+                               ctx->accpart.as<double>(), (long long)T * G, slots_used, E.g.n0, E.g.n1, (int)T, r, rb,
                                ctx->acc_first ? 1 : 0);
             HIPCHECK(hipEventRecord(ctx->ev[5], st));
             sync_stream(ctx, st);
