@@ -88,6 +88,46 @@ struct ChainParams {
 __device__ __forceinline__ double ldnt(const double *base, unsigned byteoff) { return __builtin_nontemporal_load((const double *)((const char *)base + byteoff)); }
 __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) { __builtin_nontemporal_store(v, (double *)((char *)base + byteoff)); }
 
+// The banded product of a 16-row tile.  As ONE v_mfma_f64_16x16x4 chain the band is 16 + 2 R0 columns wide: every output row
+// multiplies 16 structural zeros (NK products of 64 cycles).  v_mfma_f64_4x4x4_4b computes four INDEPENDENT 4 x 4 x 4 products per
+// instruction (16 cycles, measured: tools/ubench/mfma_f64_4x4.hip -- 70 TFLOP/s with 8 chains in flight, 60 with 4): the blocks are
+// the strip's four column groups, the four accumulators of a tile its four row groups, and row group rg takes its inputs from ring
+// entries rg + s, s = 0 .. R0 / 2 -- a band of 4 + 2 R0 columns: (NK - 3) x 4 instructions of 16 cycles instead of NK of 64, i.e. 192
+// cycles less per tile whatever the radius.  Same operand layouts: B = the ring (lane (g, c) = X[row + g][c]), D lane (g, c) = rows
+// g + 4 rg of column c; A for shift s: lane (k = l >> 4, i = l & 3) = w(|4 s - R0 + k - i|).
+#ifndef BLC_BAND4
+#define BLC_BAND4 1
+#endif
+typedef const double __attribute__((address_space(3))) *band_cp;
+template <int NK>
+__device__ __forceinline__ d4 band_products(band_cp Al, const double (&Bv)[NK]) {
+#if BLC_BAND4
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NK - 3; ++s) {
+        const double A = Al[s * 64];
+        a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s + 1], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s + 2], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s + 3], a3, 0, 0, 0);
+    }
+    return d4{a0, a1, a2, a3};
+#else
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+    return acc;
+#endif
+}
+// entry e of a band table [NK][64]: the distance |input row - output row| its lane multiplies
+__device__ __forceinline__ int band_distance(int e, int R0) {
+#if BLC_BAND4
+    return abs(4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 3));
+#else
+    return abs(4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15));
+#endif
+}
+
 template <int NK, int NTW>
 constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
 
@@ -131,7 +171,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     // ---- prologue: band, row coordinates, first source -> LDS ---------------------------------------------------------------------
     // the first step consumes its source unfiltered: it runs with the identity band (exact), the chain's band replaces it afterwards
     // (one code path for every step: no per-step branches around the ring and the products)
-    if (FILTER) for (int e = tid; e < NK * 64; e += NT) As[e] = (4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15)) == 0 ? 1.0 : 0.0;
+    if (FILTER) for (int e = tid; e < NK * 64; e += NT) As[e] = band_distance(e, R0) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
     if (tid < 2 * NSLOT) scal[tid] = 1.0;
     if (FILTER) for (int e = tid; e < XSZ; e += NT) X[e] = P.src0[(long long)(e >> 4) * P.n1 + tj * WCOL + (e & 15)];
@@ -272,8 +312,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             } else {
                 const unsigned aoff = (unsigned)l * 8u;                 // (the band stays in LDS: hoisted out of the time loop it costs 2 NK VGPRs)
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
-#pragma unroll
-                for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+                acc = band_products<NK>(Al, Bv);
             }
 
             if (it == 0) {
@@ -433,7 +472,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         BLC_STAMP(7);
         if (FILTER && k == 0) {            // the chain's band replaces the identity of the first step
             for (int e = tid; e < NK * 64; e += NT) {
-                const int a = abs(4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15));
+                const int a = band_distance(e, R0);
                 As[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);
             }
             __syncthreads();
@@ -506,7 +545,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     const long long G = (long long)P.n0 * P.n1;
 
     // first step: the source (uniform) is consumed unfiltered -> identity bands; the chains' bands replace them after step 0
-    for (int e = tid; e < 2 * NK * 64; e += NT) { const int q = e % (NK * 64); As[e] = (4 * (q >> 6) + ((q & 63) >> 4) - R0 - (q & 15)) == 0 ? 1.0 : 0.0; }
+    for (int e = tid; e < 2 * NK * 64; e += NT) As[e] = band_distance(e % (NK * 64), R0) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
     if (tid < 4 * NSLOT) scal[tid] = 1.0;
     for (int e = tid; e < 2 * XSZ; e += NT) { const int q = e % XSZ; X[e] = P.src0[(long long)(q >> 4) * P.n1 + tj * WCOL + (q & 15)]; }
@@ -651,8 +690,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             {
                 const unsigned aoff = (unsigned)l * 8u + (unsigned)(j * NK * 64 * 8);
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
-#pragma unroll
-                for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+                acc = band_products<NK>(Al, Bv);
             }
             if (it == 0) {
                 scale = scal[j * NSLOT + (k & (NSLOT - 1))];
@@ -788,7 +826,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             }
             for (int e = tid; e < 2 * NK * 64; e += NT) {
                 const int jj = e / (NK * 64), q = e - jj * (NK * 64);
-                const int a = abs(4 * (q >> 6) + ((q & 63) >> 4) - R0 - (q & 15));
+                const int a = band_distance(q, R0);
                 As[e] = a == 0 ? (lw0[jj] > 0 ? P.taps[o0[jj]] : 1.0) : (a <= lw0[jj] ? P.taps[o0[jj] + a] : 0.0);
             }
         }
