@@ -504,6 +504,7 @@ void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q) {
 template <int NTW>
 void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk) {
     switch (nk) {
+        case 4: launch_fold2_k<4, NTW>(s, Q); break;          // no stencil (change-point studies)
         case 6: launch_fold2_k<6, NTW>(s, Q); break;
         case 8: launch_fold2_k<8, NTW>(s, Q); break;
         case 10: launch_fold2_k<10, NTW>(s, Q); break;
@@ -1001,13 +1002,14 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
     const long long G = g.G;
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
-    double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap + (double)ctx->post2.cap,
+    // (every reusable buffer of the context counts as available, so that the plan -- and with it the buffer sizes -- is the same from
+    //  fit to fit: a plan that changed between two fits of one study re-allocated the 100-GB sequence buffer, 5 s)
+    double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap + (double)ctx->post2.cap + (double)ctx->accpart.cap,
                              ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
-    // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per chain of a launch) come out of the same memory
+    // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
     if (ff.accumulate && ff.full && g.n1 % blc::WCOL == 0 && g.n1 >= blc::WCOL) {
         const double slots = std::max(1, std::min(ctx->num_cus, 256) / (g.n1 / blc::WCOL));
-        budget -= std::max(0.0, std::min<double>(slots, (double)n_chains) * (double)T * (double)G * 8.0 - (double)ctx->accpart.cap);
-        budget = std::max(budget, 0.0);
+        budget = std::max(0.0, budget - std::min<double>(slots, (double)n_chains) * (double)T * (double)G * 8.0);
     }
     const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * (double)G * 8.0 +
                              (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;

@@ -295,6 +295,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
         int nE = 0, nR = 0;
         double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
+        // forward pass of a change-point batch: the step BEFORE a restart also sums its new state times the reset distribution --
+        // the sum of the posterior at the restart of the backward pass, which the fused fold normalises by (chain_fold2_kernel)
+        const bool want_x = !BWD && !FILTER && P.kinds && kind_n != blk::SRC_PREV;
         double *const pstep = pchain + (long long)t * G;
         double *const pslot_t = FOLD ? pslot + (long long)t * G : nullptr;
         double *const pslot_tn = FOLD ? pslot + (long long)tn * G : nullptr;
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
                     if (STORE) stnt(pstep, off, a);
                     sN += a;
+                    if (!FILTER && want_x) sS = fma(a, rst[it][r], sS);
                     acc[r] = a;
                 } else {
                     const double beta = acc[r] * scale;
@@ -450,9 +454,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 
         // ---- sums: waves -> LDS (this step's parity); after the barrier wave 0 adds them up, writes the partial sums of the strip
         //      and publishes the one the scale of step k + lag is made of -----------------------------------------------------------------
-        double v[5] = {sN, BWD ? sS : sM0, BWD ? sC : sM1, sM0, sM1};
-        constexpr int NV = BWD ? 5 : 3;
-        const int nv = P.means ? NV : (BWD ? 3 : 1);
+        double v[5] = {sN, BWD ? sS : sM0, BWD ? sC : sM1, BWD ? sM0 : sS, sM1};
+        constexpr int NV = BWD ? 5 : 4;                          // forward: N, M0, M1, X (the restart sum, no-stencil batches only)
+        const int nv = BWD ? (P.means ? 5 : 3) : ((!FILTER && P.kinds) ? 4 : (P.means ? 3 : 1));
         // (a full wave reduction costs ~45 vector instructions per sum and wave; the waves reduce only within their rows of 16 lanes
         //  -- 12 instructions -- and one wave adds the 32 row sums of the block after the barrier, in a fixed order)
         double *rk = red + (k & 1) * (NW * 4 * 5);
@@ -481,8 +485,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < NW * 4; ++w) tot += rk[w * 5 + lane];
-            const int slot = BWD ? lane : (lane == 0 ? 0 : 2 + lane);          // forward: N, M0, M1 -> slots 0, 3, 4
-            if (lane == 0 || P.means || (BWD && lane < 3)) P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
+            const int slot = BWD ? lane : (lane == 0 ? 0 : (lane == 3 ? 1 : 2 + lane));          // forward: N, M0, M1, X -> slots 0, 3, 4, 1
+            if (lane == 0 || (BWD ? (P.means || lane < 3) : (lane == 3 || P.means))) P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
             if (lane == (BWD ? 2 : 0)) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
                 const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
@@ -512,14 +516,19 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 // Everything else -- bands on the matrix pipe, lagged-normaliser scales from data-tagged granules, predicted posterior sums, bounded
 // spins -- is chain_kernel<NK, NTW, true, false>'s.  Launched for rounds of 2 x (CUs / strips) chains when the batch folds.
 template <int NK, int NTW>
-constexpr size_t lds_doubles_fold2() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 64 + NW * NTW * TM + 2 * 2 * NW * 4 * 3 + 4 * NSLOT + 8; }
+constexpr size_t lds_doubles_fold2() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 64 + NW * NTW * TM + 2 * 2 * NW * 4 * 3 + 4 * NSLOT + 8; }      // (NK = 4: the band tables stay unused)
 
 template <int NK, int NTW>
 __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
-    static_assert(NK >= 6 && R0 % 4 == 0, "band = 16 + 2 R0 columns, R0 a multiple of 4");
+    static_assert(NK == 4 || (NK >= 6 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
+    // NK = 4: no stencil at all (change-point studies: every chain is Static except for the steps that restart from the reset
+    // distribution, transitionModels.py:300-312).  A step is elementwise: a lane reads and writes only its own cells of the chain's
+    // buffer; at a restart of the backward pass the sum of the posterior is s' sum(alpha reset), which the forward pass has summed
+    // (P.sfwd carries it in place of the forward scale the identity does not need there).
+    constexpr bool FILTER = NK > 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *const X = lds;                          // [2 chains][N0][16]   exchange buffers
     double *const As = X + 2 * XSZ;                 // [2 chains][NK][64]   A operands
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     const long long G = (long long)P.n0 * P.n1;
 
     // first step: the source (uniform) is consumed unfiltered -> identity bands; the chains' bands replace them after step 0
-    for (int e = tid; e < 2 * NK * 64; e += NT) As[e] = band_distance(e % (NK * 64), R0) == 0 ? 1.0 : 0.0;
+    if (FILTER) for (int e = tid; e < 2 * NK * 64; e += NT) As[e] = band_distance(e % (NK * 64), R0) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
     if (tid < 4 * NSLOT) scal[tid] = 1.0;
     for (int e = tid; e < 2 * XSZ; e += NT) { const int q = e % XSZ; X[e] = P.src0[(long long)(q >> 4) * P.n1 + tj * WCOL + (q & 15)]; }
@@ -563,6 +572,14 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                                                     // that chain's exchange buffer right after the next barrier (nobody reads it then)
     double al[NTW][4];                              // stored alpha of the chain-step that runs next
     double pacc[NTW][4];                            // accumulator cells of the time step in flight
+    double rst[FILTER ? 1 : NTW][4];                // NK = 4: the reset distribution of the lane's cells
+    if (!FILTER) {
+#pragma unroll
+        for (int it = 0; it < NTW; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rst[it][r] = P.kinds ? P.reset[(long long)(row0 + it * TM + (lane >> 4) + 4 * r) * P.n1 + tj * WCOL + (lane & 15)] : 0.0;
+    }
     {
         const double *p0 = P.post + (long long)bch[0] * P.post_stride + (long long)t_first * G;
 #pragma unroll
@@ -591,6 +608,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     double a_mE = 1.0, a_mR = 1.0, a_iE = 1.0, a_iR = 1.0;
     int a_nE = 0, a_nR = 0;
     int pend_j = -1, pend_k = 0;                   // the chain-step whose row sums wave 5 still has to add up (after the next barrier)
+    int kind_next = blk::SRC_PREV;                 // NK = 4: source kind of the chain-step after this one (the first steps consume src0)
 
     // wave 5: block totals of a finished chain-step -> partial sums of the strip + the granule the scale of step k + lag is made of
     auto totals = [&](int j, int k) {
@@ -641,6 +659,12 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             const unsigned long long n0_ = blr::ld_u64(gn), n1_ = blr::ld_u64(gn + 1);
             if (j) { gq0[1] = n0_; gq1[1] = n1_; } else { gq0[0] = n0_; gq1[0] = n1_; }
         }
+        const int kind = kind_next;
+        if (!FILTER && P.kinds) {                   // (requested a chain-step ahead: a dependent scalar load in front of the cells costs a round trip)
+            const bool lastc = j + 1 == nch;
+            const int tq = lastc ? tn : t, kq = lastc ? k + 1 : k;          // (the first step of a chain consumes src0, which its buffer holds)
+            kind_next = (kq == 0 || kq >= P.T) ? blk::SRC_PREV : (int)P.kinds[(long long)tq * P.B + (lastc ? bch[0] : bch[1])];
+        }
         const double sf_now = j ? sfn[1] : sfn[0];
         {
             const double sfv = P.sfwd[(long long)bj * P.T + min(tn + 1, P.T - 1)];
@@ -649,20 +673,22 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
         __syncthreads();                                            // every wave's rows of this chain are in Xj
         if (pend_j >= 0) {
             // the previous chain-step's new state -> that chain's exchange buffer: all its readers have passed the barrier above, its
-            // next readers wait at the next one
-            double *const Xp = X + pend_j * XSZ;
-            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            // next readers wait at the next one  (NK = 4: a lane's cells are its own -- written in the epilogue)
+            if (FILTER) {
+                double *const Xp = X + pend_j * XSZ;
+                const int l = fresh_lane(), g = l >> 4, c = l & 15;
 #pragma unroll
-            for (int it = 0; it < NTW; ++it)
+                for (int it = 0; it < NTW; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Xp[(row0 + it * TM + g + 4 * r) * WCOL + c] = stt[it][r];
+                    for (int r = 0; r < 4; ++r) Xp[(row0 + it * TM + g + 4 * r) * WCOL + c] = stt[it][r];
+            }
             totals(pend_j, pend_k);
         }
         pend_j = j; pend_k = k;
 
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
         double Bv[NK];
-        {
+        if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (edge) {
 #pragma unroll
@@ -687,15 +713,20 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             const int i = row0 + it * TM;
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-            {
+            if (FILTER) {
                 const unsigned aoff = (unsigned)l * 8u + (unsigned)(j * NK * 64 * 8);
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
                 acc = band_products<NK>(Al, Bv);
+            } else {
+                // no stencil: the product tile IS the state -- or the reset distribution where the chain restarts
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = kind != blk::SRC_PREV ? rst[it][r] : Xj[(i + g + 4 * r) * WCOL + c];
             }
             if (it == 0) {
                 scale = scal[j * NSLOT + (k & (NSLOT - 1))];
                 double ip = j ? inpred[1] : inpred[0];
-                if (k > 0) ip *= sf_now * iscal[j * NSLOT + (k & (NSLOT - 1))];      // N_t = s'_t N_(t+1) / s_(t+1)
+                // N_t = s'_t N_(t+1) / s_(t+1); at a restart N_t = s'_t sum(alpha_t reset) (sf_now carries that sum)
+                if (k > 0) ip = (!FILTER && kind != blk::SRC_PREV) ? iscal[j * NSLOT + (k & (NSLOT - 1))] / sf_now : ip * sf_now * iscal[j * NSLOT + (k & (NSLOT - 1))];
                 if (j) inpred[1] = ip; else inpred[0] = ip;
                 const double wc = j ? wch[1] : wch[0];
                 wq = wc * ip; wfloor = wc * 1e-300;
@@ -762,7 +793,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 const double p = al[it][r] * beta;
                 const double cn = beta * Lv;
                 const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
-                stt[it][r] = cn;
+                if (FILTER) stt[it][r] = cn; else Xj[(i + g + 4 * r) * WCOL + c] = cn;
                 pacc[it][r] += fmax(p * wq, wfloor);
                 sN += p; sS += pl; sC += cn;
                 mE *= mR; nE += nR;
@@ -783,8 +814,10 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) al[it][r] = ldnt(pnext, cell_off(l, it, r));
+            // (no products to pace the no-stencil variant: without a fence the scheduler interleaves the four tiles' cells and spills)
+            if (!FILTER) __builtin_amdgcn_sched_barrier(0);
             // ---- advance the ring by one tile --------------------------------------------------------------------------------------
-            if (it + 1 < NTW) {
+            if (FILTER && it + 1 < NTW) {
 #pragma unroll
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
                 if (edge) {
@@ -812,7 +845,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 if ((lane & 15) == 15) rk[(wv * 4 + (lane >> 4)) * 3 + q] = x;
             }
         }
-        if (k == 0 && last_chain) {        // the chains' bands replace the identity of the first step
+        if (FILTER && k == 0 && last_chain) {        // the chains' bands replace the identity of the first step
             __syncthreads();
             {
                 double *const Xp = X + pend_j * XSZ;

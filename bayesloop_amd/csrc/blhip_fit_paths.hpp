@@ -205,6 +205,7 @@ struct ChainRun {
     // fused fold with TWO chains per block (blc::chain_fold2_kernel): the backward pass runs rounds of 2 x cpr chains of its own
     bool fold2 = false;
     std::vector<int> round_start_b, round_nk_b;
+    const double *redF_keep = nullptr;             // the forward pass's reduced sums (slot 1: the restart sums of change-point batches)
     int slots_used = 0;                            // partial accumulators the backward launches write (one per block column)
     double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr, *d_zeros = nullptr;
     std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
@@ -241,9 +242,19 @@ struct ChainRun {
         post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
         // (not beside overlapped folds: a FoldJob of the previous batch may still read ctx->accw and read-modify-write ctx->acc on the
         //  second stream while this batch re-carves accw and its fused fold writes ctx->acc on the main stream)
-        fused = post_private && !cp.has_reset && !E.overlap_acc && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        fused = post_private && !E.overlap_acc && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        if (fused && cp.has_reset) {
+            // change-point batches: the predicted sums survive a restart only through the two-chain fold kernel's restart rule, and
+            // only if the two passes restart at the same places (backward step t restarts <=> forward step t + 1 does: unit-spaced
+            // time stamps, transitionModels.py:316-317)
+            bool aligned = !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0 && ctx->option("fold2_cp", 1.0) != 0.0;
+            for (int64_t b = 0; b < B && aligned; ++b)
+                for (int64_t t = 0; t + 1 < T && aligned; ++t)
+                    aligned = (prog.kindB[(size_t)t * B + b] != SRC_PREV) == (prog.kindF[(size_t)(t + 1) * B + b] != SRC_PREV);
+            fused = aligned;
+        }
         slots_used = (int)std::min<int64_t>(cp.cpr, B);
-        if (fused && !E.chain_means && fold2_shape(cp.ntw) && prog.LW0 > 0 && ctx->option("fold2", 1.0) != 0.0) {
+        if (fused && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0) {
             fold2 = true;
             const int per = 2 * cp.cpr;
             for (int64_t s0 = 0; s0 < B; s0 += per) {
@@ -251,7 +262,7 @@ struct ChainRun {
                 const int tp = cp.tap_id[cp.order[s1 - 1]];                   // (sorted by radius: the last chain of the round is its widest)
                 const int r0 = std::max(4, ((tp >= 0 ? E.taps->lw[tp] : 0) + 3) / 4 * 4);
                 round_start_b.push_back((int)s0);
-                round_nk_b.push_back((blc::TM + 2 * r0) / 4);
+                round_nk_b.push_back(prog.LW0 == 0 ? 4 : (blc::TM + 2 * r0) / 4);          // (4: the no-stencil variant)
             }
             round_start_b.push_back((int)B);
             slots_used = (int)std::min<int64_t>(cp.cpr, (B + 1) / 2);
@@ -331,6 +342,7 @@ struct ChainRun {
     // after the forward pass: every strip made it, and the sums of every chain allow the scales to be undone
     bool forward_ok(const BatchEnv &E, double *redF) {
         if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
+        redF_keep = redF;
         rowsumC.assign(E.B, std::vector<double>());
         sfwdC.assign(E.B, std::vector<double>());
         for (int64_t b = 0; b < E.B; ++b)
@@ -354,6 +366,11 @@ struct ChainRun {
         double *h = ctx->pinA.as<double>(), *hw = h + (size_t)T * B, *hi = hw + B;
         for (int64_t b = 0; b < B; ++b) {
             std::memcpy(h + (size_t)b * T, sfwdC[b].data(), (size_t)T * 8);
+            // a restart of the backward pass at step t: the kernel divides by sum(alpha_t reset), which the forward pass left in slot 1
+            // of step t -- handed over where the forward scale of step t + 1 would be (the identity does not use it there)
+            if (cp.has_reset)
+                for (int64_t t = 0; t + 1 < T; ++t)
+                    if (E.prog->kindB[(size_t)t * B + b] != SRC_PREV) h[(size_t)b * T + t + 1] = redF_keep[((size_t)t * B + b) * NRED + 1];
             hw[b] = std::isfinite(fold_lw[b]) ? std::exp(fold_lw[b] - fold_ref) : 0.0;
             hi[b] = 1.0 / (rowsumC[b][T - 1] * (1.0 / (double)E.G));
         }
@@ -396,7 +413,9 @@ struct ChainRun {
             double npred = rowsumC[b][T - 1] * (1.0 / (double)G);
             for (int64_t k = 0; k < T; ++k) {
                 const int64_t t = T - 1 - k;
-                if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
+                const bool restart = cp.has_reset && E.prog->kindB[(size_t)t * B + b] != SRC_PREV && k > 0;
+                if (restart) npred = sb[k] * redF_keep[((size_t)t * B + b) * NRED + 1];
+                else if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
                 const double Nt = redB[((size_t)t * B + b) * NRED];
                 if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) return false;
             }
