@@ -572,14 +572,6 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                                                     // that chain's exchange buffer right after the next barrier (nobody reads it then)
     double al[NTW][4];                              // stored alpha of the chain-step that runs next
     double pacc[NTW][4];                            // accumulator cells of the time step in flight
-    double rst[FILTER ? 1 : NTW][4];                // NK = 4: the reset distribution of the lane's cells
-    if (!FILTER) {
-#pragma unroll
-        for (int it = 0; it < NTW; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                rst[it][r] = P.kinds ? P.reset[(long long)(row0 + it * TM + (lane >> 4) + 4 * r) * P.n1 + tj * WCOL + (lane & 15)] : 0.0;
-    }
     {
         const double *p0 = P.post + (long long)bch[0] * P.post_stride + (long long)t_first * G;
 #pragma unroll
@@ -591,7 +583,10 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 stt[it][r] = 0.0;
             }
     }
-    double wch[2], inpred[2], sfn[2] = {1.0, 1.0};
+    double wch[2], inpred[2];
+    double sf_next = 1.0;                           // the forward scale the NEXT chain-step's prediction needs (requested a chain-step ahead
+                                                    // and not touched before: a value that is used right after its request makes the wave
+                                                    // wait for everything it has in flight)
 #pragma unroll
     for (int j = 0; j < 2; ++j) { wch[j] = j < nch ? P.wchain[bch[j]] : 0.0; inpred[j] = P.infirst[bch[j]]; }
     if (wv == SCALE_WAVE || wv == 5 || wv == 0 || wv == NW - 1) __builtin_amdgcn_s_setprio(2);
@@ -665,10 +660,10 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             const int tq = lastc ? tn : t, kq = lastc ? k + 1 : k;          // (the first step of a chain consumes src0, which its buffer holds)
             kind_next = (kq == 0 || kq >= P.T) ? blk::SRC_PREV : (int)P.kinds[(long long)tq * P.B + (lastc ? bch[0] : bch[1])];
         }
-        const double sf_now = j ? sfn[1] : sfn[0];
+        const double sf_now = sf_next;
         {
-            const double sfv = P.sfwd[(long long)bj * P.T + min(tn + 1, P.T - 1)];
-            if (j) sfn[1] = sfv; else sfn[0] = sfv;
+            const bool lastc = j + 1 == nch;
+            sf_next = P.sfwd[(long long)(lastc ? bch[0] : bch[1]) * P.T + min((lastc ? tn : t) + 1, P.T - 1)];
         }
         __syncthreads();                                            // every wave's rows of this chain are in Xj
         if (pend_j >= 0) {
@@ -685,6 +680,18 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             totals(pend_j, pend_k);
         }
         pend_j = j; pend_k = k;
+        if (!FILTER && kind != blk::SRC_PREV) {
+            // a restart (once per chain and change point): the chain's buffer takes the reset distribution.  A lane's cells are its own
+            // (no barrier); the values are consumed inside the branch -- nothing fetched here is pending where the paths join.  (Held in
+            // registers instead, the 16 values were spilled and re-loaded from scratch before every tile: each re-load drained the
+            // requests in flight -- 62 % of the wave time parked.)
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Xj[(row0 + it * TM + g + 4 * r) * WCOL + c] = P.reset[(long long)(row0 + it * TM + g + 4 * r) * P.n1 + tj * WCOL + c];
+        }
 
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
         double Bv[NK];
@@ -718,9 +725,9 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
                 acc = band_products<NK>(Al, Bv);
             } else {
-                // no stencil: the product tile IS the state -- or the reset distribution where the chain restarts
+                // no stencil: the product tile IS the state (at a restart: the reset distribution, written above)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = kind != blk::SRC_PREV ? rst[it][r] : Xj[(i + g + 4 * r) * WCOL + c];
+                for (int r = 0; r < 4; ++r) acc[r] = Xj[(i + g + 4 * r) * WCOL + c];
             }
             if (it == 0) {
                 scale = scal[j * NSLOT + (k & (NSLOT - 1))];

@@ -82,8 +82,10 @@ def test_kernel_direction_parser():
     kd = bench.kernel_direction
     assert kd('void blc::chain_kernel<14, 4, true, false>(blc::ChainParams)') == 'backward'
     assert kd('void blc::chain_kernel<6, 4, false, true>(blc::ChainParams)') == 'forward'
-    assert kd('void blr::resident_kernel<128, 128, 32, 8, false>(blr::ResParams)') == 'forward'
+    assert kd('void blr::resident_kernel<128, 128, 32, 8, false, true>(blr::ResParams)') == 'forward'
+    assert kd('void blr::resident_kernel<64, 64, 8, 8, true, false>(blr::ResParams)') == 'backward'
     assert kd('void blm::mfma_step_kernel<2, 1, 8, true, false>(blf::FastParams)') == 'backward'
+    assert kd('void blc::chain_fold2_kernel<14, 4>(blc::ChainParams)') == 'backward'
     assert kd('void blk::reduce_partials_kernel(double const*, double*, int, int)') is None
 
 
