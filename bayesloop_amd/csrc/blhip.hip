@@ -27,7 +27,6 @@
 #include "blhip_fast.hpp"
 #include "blhip_mfma.hpp"
 #include "blhip_fused1d.hpp"
-#include "blhip_persist1d.hpp"
 #include "blhip_resident.hpp"
 #include "blhip_chainres.hpp"
 #include "blhip_nd.hpp"
@@ -366,28 +365,6 @@ void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, i
         acc += cnt[k];
     }
     for (int b = 0; b < B; ++b) order[start[key(b)]++] = b;
-}
-
-// ---- persistent 1-D path (blhip_persist1d.hpp): one workgroup per chain for the whole time loop ------------------------
-template <int OM>
-void launch_persist_om(hipStream_t s, const bl1::P1Params &P, bool bwd, size_t lds) {
-    if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, true>));
-        hipLaunchKernelGGL((bl1::persist1d_kernel<OM, true>), dim3(P.B), dim3(bl1::NT), lds, s, P);
-    } else {
-        arm_kernel(reinterpret_cast<const void *>(&bl1::persist1d_kernel<OM, false>));
-        hipLaunchKernelGGL((bl1::persist1d_kernel<OM, false>), dim3(P.B), dim3(bl1::NT), lds, s, P);
-    }
-}
-
-void launch_persist(hipStream_t s, int om, const bl1::P1Params &P, bool bwd, size_t lds) {
-    switch (om) {
-        case BLHIP_OM_POISSON: launch_persist_om<OM_POISSON>(s, P, bwd, lds); break;
-        case BLHIP_OM_GAUSSIAN_MEAN: launch_persist_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
-        case BLHIP_OM_TABLE: launch_persist_om<OM_TABLE>(s, P, bwd, lds); break;
-        default: fail("persistent 1-D path: observation model %d", om);
-    }
-    HIPCHECK(hipGetLastError());
 }
 
 // ---- 1-D path, K time steps per launch (blhip_fused1d.hpp) ---------------------------------------------------------------
@@ -1031,8 +1008,7 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
 // which kernel family runs a batch and with what block geometry (segment lengths from a small cost model: long segments read every
 // element once + 2 R0 halo rows per segment, short ones give enough blocks to fill 256 CUs when there are few chains)
 struct GeometryPlan {
-    bool fast = false, persist = false, fused1d = false, use_mfma = false;
-    size_t p1_lds = 0;
+    bool fast = false, fused1d = false, use_mfma = false;
     int64_t fusedK = 1;
     int f1_TJ = 128;
     Tile tile{};
@@ -1047,13 +1023,7 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
     gp.fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
                       ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
                       g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
-    gp.p1_lds = ((size_t)2 * (g.n1 + 2 * prog.LW1) + 64 + prog.LW1 + 2) * sizeof(double);
-    gp.persist = p->ndim == 1 && !gp.fast && !prog.has_clamp && !resume && !carry && ctx->option("persist1d", 0.0) != 0.0 && g.n1 <= 8192 &&
-                         prog.LW1 <= g.n1 && gp.p1_lds <= 150 * 1024 &&
-                         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN ||
-                          p->obs_model == BLHIP_OM_TABLE);
-    // 1-D grids: K time steps per launch (blhip_fused1d.hpp); K = 1 is the same kernel with a launch per step
-    if (p->ndim == 1 && !gp.fast && !gp.persist && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
+    if (p->ndim == 1 && !gp.fast && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
         gp.f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
         gp.fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
@@ -1602,15 +1572,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         build_program(p, g, c0, B, op_values, taps, prog, resume);
         tr.mark("build_program");
         const GeometryPlan gp = plan_geometry(ctx, p, g, prog, B, d, resume, carry);
-        const bool fast = gp.fast, persist = gp.persist, fused1d = gp.fused1d, use_mfma = gp.use_mfma;
-        const size_t p1_lds = gp.p1_lds;
+        const bool fast = gp.fast, fused1d = gp.fused1d, use_mfma = gp.use_mfma;
         const int64_t fusedK = gp.fusedK;
         const int f1_TJ = gp.f1_TJ;
         Tile tile = gp.tile;
         const int fastS = gp.fastS, fast_nseg = gp.fast_nseg, fast_fnblk = gp.fast_fnblk, mS = gp.mS, m_nseg = gp.m_nseg, m_tiles_j = gp.m_tiles_j,
                   m_nblk = gp.m_nblk;
         auto f1_lds = [&](int64_t K) { return (size_t)(4 * (f1_TJ + 2 * K * prog.LW1) + K * f1_TJ + K * (prog.LW1 + 1) + K * rec_len + 4 * 8 + 2 + K + 8 + K * 3 * f1_TJ) * sizeof(double); };
-        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : (persist ? 2 : (fused1d ? 4 : 0));
+        ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : (fused1d ? 4 : 0);
         ctx->timing.cells_per_launch = std::max<int64_t>(ctx->timing.cells_per_launch, B * G);
 
         // --- device metadata ---
@@ -1792,14 +1761,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
         };
 
-        bl1::P1Params PP{};
-        if (persist) {
-            PP.n = g.n1; PP.T = (int)T; PP.B = (int)B; PP.LW = prog.LW1; PP.d = d; PP.rec_len = rec_len;
-            PP.shared[SRC_PREV] = nullptr; PP.shared[SRC_PRIOR] = d_prior; PP.shared[SRC_RESET] = d_reset;
-            PP.shared[SRC_UNIFORM] = d_uniform; PP.shared[SRC_INDEP] = d_indep; P.shared[SRC_INDEP] = d_indep; PP.post = d_post; PP.post_stride = (long long)T * G;
-            PP.taps = d_taps; PP.tap_off = d_off; PP.tap_lw = d_lw; PP.m1 = d_m1; PP.colA = d_colA; PP.rec = d_rec;
-            PP.lik = d_lik;
-        }
         float ms = 0;
         BatchOutcome O;
         std::vector<double> &invN = O.invN;
@@ -1817,12 +1778,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         // they had all finished (measured: rocprofv3 time line), queued ahead of them it shares the chip with them
         launch_pending_fold();
         HIPCHECK(hipEventRecord(ev[0], st));
-        if (persist) {
-            bl1::P1Params Q = PP;
-            Q.srckind = d_kindF; Q.tap = d_tapF1; Q.red_out = ctx->redF.as<double>();
-            Q.store = evidence_only ? 0 : 1; Q.means = forward_only ? 1 : 0;
-            launch_persist(st, p->obs_model, Q, false, p1_lds);
-        }
         if (fused1d) {
             for (int64_t t = 0; t < T; t += K) {
                 bl1f::F1Params Q = F1;
@@ -1842,7 +1797,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 launch_fused1d(st, p->obs_model, Q, false, f1_lds(Q.K));
             }
         }
-        if (persist || fused1d)        // 1-D paths: a row in, a row out per step (the K-steps-per-launch kernel re-reads only halos)
+        if (fused1d)        // 1-D paths: a row in, a row out per step (the K-steps-per-launch kernel re-reads only halos)
             account(ctx, false, (double)B * G * T * (16.0 + (d_lik ? 8.0 : 0.0)), (double)B * G * T * (valu_stencil_flop(prog.LW1) + EPI_FWD_FLOP));
         const bool res_now = resident && !resident_failed;
         const bool cres_now = chainres && !resident_failed;
@@ -1850,7 +1805,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (res_now) RR.launch(E, false, d_psF);
         if (cres_now) CR.pass(E, false, d_psF);
         fork_streams();
-        for (int64_t t = 0; t < T && !persist && !fused1d && !res_now && !cres_now; ++t) {
+        for (int64_t t = 0; t < T && !fused1d && !res_now && !cres_now; ++t) {
             if (multistream && t > 0 && !same_membership(orderF, rangesF, t - 1, t)) { join_streams(); fork_streams(); }
             const double *srcp; double *dstp; long long sstr, dstr;
             if (evidence_only) {
@@ -1866,8 +1821,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         }
         join_streams();
         HIPCHECK(hipEventRecord(ev[1], st));
-        if (!persist)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
                                ctx->redF.as<double>(), nblk_now, NRED);
         ctx->pinF.ensure((size_t)T * B * NRED * 8);
         redF = ctx->pinF.as<double>();
@@ -1900,11 +1854,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             double *d_psB = ctx->psumB.as<double>();
             if (fused1d && !raw_ok && K > 1) return false;
             HIPCHECK(hipEventRecord(ev[2], st));
-            if (persist) {
-                bl1::P1Params Q = PP;
-                Q.srckind = d_kindB; Q.tap = d_tapB1; Q.red_out = ctx->redB.as<double>(); Q.store = 1; Q.means = 1;
-                launch_persist(st, p->obs_model, Q, true, p1_lds);
-            }
             if (fused1d) {
                 for (int64_t t = T - 1; t >= 0; t -= K) {
                     bl1f::F1Params Q = F1;
@@ -1917,13 +1866,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                     launch_fused1d(st, p->obs_model, Q, true, f1_lds(Q.K));
                 }
             }
-            if (persist || fused1d)
+            if (fused1d)
                 account(ctx, true, (double)B * G * T * (32.0 + (d_lik ? 8.0 : 0.0)), (double)B * G * T * (valu_stencil_flop(prog.LW1) + EPI_BWD_FLOP));
             if (res_now) RR.launch(E, true, d_psB);
             if (cres_now && CR.fused) CR.prepare_fold(E, O);
             if (cres_now) CR.pass(E, true, d_psB);
             fork_streams();
-            for (int64_t t = T - 1; t >= 0 && !persist && !fused1d && !res_now && !cres_now; --t) {
+            for (int64_t t = T - 1; t >= 0 && !fused1d && !res_now && !cres_now; --t) {
                 if (multistream && t < T - 1 && !same_membership(orderB, rangesB, t + 1, t)) { join_streams(); fork_streams(); }
                 // reads c_{t+1} and the stored alpha_t, writes c_t and posterior_t
                 run_step(MODE_BWD, t, d_pp[(t + 1) & 1], G, d_pp[t & 1], G, d_post + (size_t)t * G, (long long)T * G,
@@ -1932,8 +1881,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
             join_streams();
             HIPCHECK(hipEventRecord(ev[3], st));
-            if (!persist)
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
                                    ctx->redB.as<double>(), nblk_now, NRED);
             ctx->pinB.ensure((size_t)T * B * NRED * 8);
             redB = ctx->pinB.as<double>();

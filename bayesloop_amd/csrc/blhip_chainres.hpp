@@ -679,6 +679,9 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             }
             totals(pend_j, pend_k);
         }
+        // a block with ONE chain (the last pair of a round with an odd number of chains) has just written the buffer it is about to read
+        // its rings from: the waves' rows have to be there first.  (With two chains the write went to the OTHER chain's buffer.)
+        if (FILTER && nch == 1 && pend_j >= 0) __syncthreads();
         pend_j = j; pend_k = k;
         if (!FILTER && kind != blk::SRC_PREV) {
             // a restart (once per chain and change point): the chain's buffer takes the reset distribution.  A lane's cells are its own

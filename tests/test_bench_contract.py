@@ -24,15 +24,27 @@ def test_committed_bench_line_has_the_contract_fields():
     assert 'workload' in d['config'] and 'model' not in d['config']
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 512 * 512 * 256 * 512) <= 1e-6 * 512 * 512 * 256 * 512   # cells x steps x chains of one fit
     r = d['roofline']
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert (r['bound'], r['unit'], r['peak']) in (('hbm', 'GB/s', 8000.0), ('mfma', 'TFLOP/s', 78.6))
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.0 < r['frac'] < 1.0
-    assert abs(r['achieved'] - r['bytes_per_cell_step'] * r['cells_per_launch'] / (r['avg_launch_us'] * 1e-6) / 1e9) < 1e-6 * r['achieved']
-    # HBM bytes per launch (PMC): a resident kernel moves LESS than the streaming formulation's algorithmic bytes (C4 backward + fold:
-    # 24 of 32 B per cell-step), never much more
-    alg = r['bytes_per_cell_step'] * r['cells_per_launch']
-    assert r['traffic'] is None or 0.2 * alg <= r['traffic'] <= 1.3 * alg
+    # `achieved` prices the kernel at the bytes it REALLY moves (the state lives in LDS): PMC bytes per logical launch when the
+    # profiler ran, else the designed ones; the two agree; the calibrated copy rate is not exceeded
+    if r['bound'] == 'hbm':
+        assert abs(r['achieved'] - r['bytes_per_cell_step'] * r['cells_per_launch'] / (r['avg_launch_us'] * 1e-6) / 1e9) < 1e-6 * r['achieved']
+        designed = r['hbm']['designed_bytes_per_cell_step'] * r['cells_per_launch']
+        assert r['traffic'] is None or 0.9 * designed <= r['traffic'] <= 1.1 * designed
+    assert r['frac_calibrated'] is None or r['frac_calibrated'] <= 1.0
+    # the SURVEY 8(d) streaming-equivalent rate is there for comparison with earlier rounds, under a name of its own
+    assert r['algorithmic']['bytes_per_cell_step'] in (16.0, 32.0) and r['algorithmic']['GBs_equiv'] > r['achieved'] * (r['bound'] == 'hbm')
+    for p_, v in _walk(d):
+        if p_.endswith('achieved_GBs') or (p_.endswith('/achieved') and d['roofline']['unit'] == 'GB/s'):
+            assert v <= 8000.0, (p_, v)                   # nothing called "achieved" exceeds the HBM peak
+        if p_.endswith('frac_calibrated') and v is not None:
+            assert v <= 1.0, (p_, v)
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == d['unit'] and c['value'] > 0 and c['sample']
+    # C5 counts the chains it runs
+    if 'c5' in d.get('extra', {}) and 'config' in d['extra']['c5']:
+        assert d['extra']['c5']['config']['n_hyper'] == 250
 
 
 def _walk(d, path=''):

@@ -87,21 +87,6 @@ def test_one_launch_per_step_1d_kernels_match_golden(case):
             eng.set_option('fuse1d', 8)
 
 
-@pytest.mark.parametrize('case', ['c1_coal', 'c2_small', 'kat_changepoint', 'c1_coal_changepoint', 'kat_gaussianmean',
-                                  'c1_coal_hyper', 'kat_study_prior_array', 'cp_nonunit_time'])
-def test_persistent_1d_kernel_matches_golden(case):
-    """The experimental one-workgroup-per-chain kernels for 1-D grids (off by default) against the goldens."""
-    eng = bl.get_engine()
-    eng.set_option('persist1d', 1)
-    try:
-        S = cases.build(bl, case)
-        S.fit(**cases.fit_kwargs(case))
-        assert S.lastTiming['fwd_kernel_variant'] == 2
-        compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL)
-    finally:
-        eng.set_option('persist1d', 0)
-
-
 EXTRA = {
     # seeded inputs beyond the fixtures: ragged grid sizes (tile remainders), wide/narrow filters, 1-D and 2-D
     'x_ragged_2d': dict(study='Study', data=('series', 21, 14), om=cases.gauss2d(131, -5, 5, 3),
