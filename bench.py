@@ -506,28 +506,39 @@ def main():
             out['end_to_end'] = dict(error=repr(e))
     S._posterior_pending = None      # results stay on the device; nothing more is copied back
     eng.release_posterior()
+    wedged = False
     if comm is not None and not TEST_DOUBLE and desc.get('mode') == 'full':
         # the accumulator merge on its own, both ways (every rank takes part; zero-filled accumulators of the workload's shape):
-        # what the exchange costs next to one rank's share of the chains -- measured only when the driver runs N > 1
+        # what the exchange costs next to one rank's share of the chains -- measured only when the driver runs N > 1.  A diagnostic:
+        # it runs under a watchdog and whatever happens in it, the line with the timed result is still printed.
+        from bayesloop_amd.dist import _bounded
         exch = dict(reduce_ms_in_last_fit=comm.reduce_ms())
         T_, G_ = int(desc['T']), int(np.prod(desc['grid']))
+
+        def one_mode(mode):
+            eng.set_option('comm_reduce_mode', mode)
+            eng.accum_begin(T_, G_)
+            eng.accum_rescale(0.0)
+            best = None
+            for _ in range(3):
+                comm.barrier()
+                t0 = time.perf_counter()
+                comm.reduce_accumulator(eng, 0)
+                wall = comm.allreduce_max(time.perf_counter() - t0) * 1e3
+                best = wall if best is None else min(best, wall)
+            res = dict(wall_ms_max_over_ranks=best, device_ms_rank0=comm.reduce_ms(), bytes=T_ * G_ * 8)
+            eng.accum_end()
+            return res
         for mode, label in ((0, 'ncclReduce'), (1, 'reduce_scatter_then_send_to_root')):
+            if wedged:
+                break
             try:
-                eng.set_option('comm_reduce_mode', mode)
-                eng.accum_begin(T_, G_)
-                eng.accum_rescale(0.0)
-                best = None
-                for _ in range(3):
-                    comm.barrier()
-                    t0 = time.perf_counter()
-                    comm.reduce_accumulator(eng, 0)
-                    wall = comm.allreduce_max(time.perf_counter() - t0) * 1e3
-                    best = wall if best is None else min(best, wall)
-                exch[label] = dict(wall_ms_max_over_ranks=best, device_ms_rank0=comm.reduce_ms(), bytes=T_ * G_ * 8)
-                eng.accum_end()
+                exch[label] = _bounded(lambda m=mode: one_mode(m), float(os.environ.get('BLHIP_BENCH_DIAG_TIMEOUT', '60')), 'exchange diagnostic')
             except Exception as e:      # a diagnostic must not lose the line
                 exch[label] = dict(error=repr(e))
-        eng.set_option('comm_reduce_mode', 0)
+                wedged = 'did not return' in repr(e)       # a collective hangs: nothing more through this communicator
+        if not wedged:
+            eng.set_option('comm_reduce_mode', 0)
         if rank == 0:
             out['exchange'] = exch
     if rank == 0 and world > 1:
@@ -565,7 +576,7 @@ def main():
         except Exception:
             pass
 
-    if comm is not None:
+    if comm is not None and not wedged:
         drain_c_stdio()                          # every rank, before the barrier: nothing of theirs can follow rank 0's line
         comm.barrier()
         comm.close()
@@ -579,6 +590,10 @@ def main():
         print(json.dumps(out), flush=True)       # the ONE JSON line, last on stdout
         if bad:
             sys.exit('bench.py: log-evidence differs from the reference by more than 1e-9 relative: %s' % bad)
+    if wedged:                                   # a helper thread sits in a collective that will never return: leave without joining it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':
