@@ -436,8 +436,14 @@ void launch_chain_fn(KernT kern, hipStream_t s, const blc::ChainParams &Q, size_
 }
 
 template <int NK, int NTW>
-void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
+void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store, bool pad) {
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
+    if (pad) {                          // grids smaller than the geometry: forward passes only (the backward pass folds: launch_fold2)
+        if (bwd) fail("internal: padded chain-resident launch of a storing backward pass");
+        if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
+        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true>, s, Q, lds);
+        return;
+    }
     if (bwd && !store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false>, s, Q, lds);      // posteriors folded, not stored
     else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true>, s, Q, lds);
     else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true>, s, Q, lds);
@@ -445,62 +451,69 @@ void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool sto
 }
 
 template <int NTW>
-void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
+void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
     switch (nk) {
-        case 4: launch_chain_k<4, NTW>(s, Q, bwd, store); break;       // no stencil (change-point studies)
-        case 6: launch_chain_k<6, NTW>(s, Q, bwd, store); break;         // band = 16 + 2 R0 columns, R0 = 4, 8, ... 40
-        case 8: launch_chain_k<8, NTW>(s, Q, bwd, store); break;
-        case 10: launch_chain_k<10, NTW>(s, Q, bwd, store); break;
-        case 12: launch_chain_k<12, NTW>(s, Q, bwd, store); break;
-        case 14: launch_chain_k<14, NTW>(s, Q, bwd, store); break;
-        case 16: launch_chain_k<16, NTW>(s, Q, bwd, store); break;
-        case 18: launch_chain_k<18, NTW>(s, Q, bwd, store); break;
-        case 20: launch_chain_k<20, NTW>(s, Q, bwd, store); break;
-        case 22: launch_chain_k<22, NTW>(s, Q, bwd, store); break;
-        case 24: launch_chain_k<24, NTW>(s, Q, bwd, store); break;
+        case 4: launch_chain_k<4, NTW>(s, Q, bwd, store, pad); break;       // no stencil (change-point studies)
+        case 6: launch_chain_k<6, NTW>(s, Q, bwd, store, pad); break;         // band = 16 + 2 R0 columns, R0 = 4, 8, ... 40
+        case 8: launch_chain_k<8, NTW>(s, Q, bwd, store, pad); break;
+        case 10: launch_chain_k<10, NTW>(s, Q, bwd, store, pad); break;
+        case 12: launch_chain_k<12, NTW>(s, Q, bwd, store, pad); break;
+        case 14: launch_chain_k<14, NTW>(s, Q, bwd, store, pad); break;
+        case 16: launch_chain_k<16, NTW>(s, Q, bwd, store, pad); break;
+        case 18: launch_chain_k<18, NTW>(s, Q, bwd, store, pad); break;
+        case 20: launch_chain_k<20, NTW>(s, Q, bwd, store, pad); break;
+        case 22: launch_chain_k<22, NTW>(s, Q, bwd, store, pad); break;
+        case 24: launch_chain_k<24, NTW>(s, Q, bwd, store, pad); break;
         default: fail("internal: chain-resident kernel with %d band blocks", nk);
     }
 }
 
-void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
-    if (ntw == 4) launch_chain_w<4>(s, Q, nk, bwd, store);
-    else if (ntw == 2) launch_chain_w<2>(s, Q, nk, bwd, store);
-    else if (ntw == 1) launch_chain_w<1>(s, Q, nk, bwd, store);
+void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
+    if (ntw == 4) launch_chain_w<4>(s, Q, nk, bwd, store, pad);
+    else if (ntw == 2) launch_chain_w<2>(s, Q, nk, bwd, store, pad);
+    else if (ntw == 1) launch_chain_w<1>(s, Q, nk, bwd, store, pad);
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
     HIPCHECK(hipGetLastError());
 }
 
 // backward pass with the fused fold, two chains per block (blc::chain_fold2_kernel)
 template <int NK, int NTW>
-void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q) {
+void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q, bool pad) {
     const size_t lds = blc::lds_doubles_fold2<NK, NTW>() * sizeof(double);
-    arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW>));
-    hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW>), dim3((unsigned)(((Q.nslots + 1) / 2) * Q.strips)), dim3(blc::NT), lds, s, Q);
+    const dim3 grid((unsigned)(((Q.nslots + 1) / 2) * Q.strips));
+    if (pad) {
+        arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, true>));
+        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, true>), grid, dim3(blc::NT), lds, s, Q);
+    } else {
+        arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, false>));
+        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, false>), grid, dim3(blc::NT), lds, s, Q);
+    }
 }
 
 template <int NTW>
-void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk) {
+void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) {
     switch (nk) {
-        case 4: launch_fold2_k<4, NTW>(s, Q); break;          // no stencil (change-point studies)
-        case 6: launch_fold2_k<6, NTW>(s, Q); break;
-        case 8: launch_fold2_k<8, NTW>(s, Q); break;
-        case 10: launch_fold2_k<10, NTW>(s, Q); break;
-        case 12: launch_fold2_k<12, NTW>(s, Q); break;
-        case 14: launch_fold2_k<14, NTW>(s, Q); break;
-        case 16: launch_fold2_k<16, NTW>(s, Q); break;
-        case 18: launch_fold2_k<18, NTW>(s, Q); break;
-        case 20: launch_fold2_k<20, NTW>(s, Q); break;
-        case 22: launch_fold2_k<22, NTW>(s, Q); break;
-        case 24: launch_fold2_k<24, NTW>(s, Q); break;
+        case 4: launch_fold2_k<4, NTW>(s, Q, pad); break;          // no stencil (change-point studies)
+        case 6: launch_fold2_k<6, NTW>(s, Q, pad); break;
+        case 8: launch_fold2_k<8, NTW>(s, Q, pad); break;
+        case 10: launch_fold2_k<10, NTW>(s, Q, pad); break;
+        case 12: launch_fold2_k<12, NTW>(s, Q, pad); break;
+        case 14: launch_fold2_k<14, NTW>(s, Q, pad); break;
+        case 16: launch_fold2_k<16, NTW>(s, Q, pad); break;
+        case 18: launch_fold2_k<18, NTW>(s, Q, pad); break;
+        case 20: launch_fold2_k<20, NTW>(s, Q, pad); break;
+        case 22: launch_fold2_k<22, NTW>(s, Q, pad); break;
+        case 24: launch_fold2_k<24, NTW>(s, Q, pad); break;
         default: fail("internal: two-chain fold kernel with %d band blocks", nk);
     }
 }
 
-bool fold2_shape(int ntw) { return ntw == 4 || ntw == 2; }
+bool fold2_shape(int ntw) { return ntw == 4 || ntw == 2 || ntw == 1; }
 
-void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw) {
-    if (ntw == 4) launch_fold2_w<4>(s, Q, nk);
-    else if (ntw == 2) launch_fold2_w<2>(s, Q, nk);
+void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad = false) {
+    if (ntw == 4) launch_fold2_w<4>(s, Q, nk, pad);
+    else if (ntw == 2) launch_fold2_w<2>(s, Q, nk, pad);
+    else if (ntw == 1) launch_fold2_w<1>(s, Q, nk, pad);
     else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
     HIPCHECK(hipGetLastError());
 }
@@ -983,12 +996,16 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
     //  fit to fit: a plan that changed between two fits of one study re-allocated the 100-GB sequence buffer, 5 s)
     double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap + (double)ctx->post2.cap + (double)ctx->accpart.cap,
                              ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
+    // the chain-resident kernels lay their sequences out on a padded geometry (rows 128 / 256 / 512, columns a multiple of 16)
+    double Gk = (double)G;
+    if (p->ndim == 2 && g.n0 >= 48 && g.n0 <= 512)
+        Gk = (double)(g.n0 <= 128 ? 128 : (g.n0 <= 256 ? 256 : 512)) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
     // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
-    if (ff.accumulate && ff.full && g.n1 % blc::WCOL == 0 && g.n1 >= blc::WCOL) {
-        const double slots = std::max(1, std::min(ctx->num_cus, 256) / (g.n1 / blc::WCOL));
-        budget = std::max(0.0, budget - std::min<double>(slots, (double)n_chains) * (double)T * (double)G * 8.0);
+    if (ff.accumulate && ff.full && p->ndim == 2 && g.n1 >= 1) {
+        const double slots = std::max(1, std::min(ctx->num_cus, 256) / ((g.n1 + blc::WCOL - 1) / blc::WCOL));
+        budget = std::max(0.0, budget - std::min<double>(slots, (double)n_chains) * (double)T * Gk * 8.0);
     }
-    const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * (double)G * 8.0 +
+    const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * Gk * 8.0 +
                              (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
     int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
     Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024));
@@ -1298,6 +1315,8 @@ void write_results(blhip_result *res, const blhip_problem *p, int64_t c0, int64_
 // The chain-resident path (blhip_chainres.hpp): which chains of the batch run together, in which order, with which band width.
 struct ChainResPlan {
     int ntw = 0, strips = 0, cpr = 0;            // product tiles per wave, strips per chain, chains per launch
+    int n0p = 0, n1p = 0;                        // the geometry the kernels work on: rows 128 / 256 / 512, columns a multiple of 16
+    bool pad = false;                            // the grid is smaller than that (padded cells hold zeros; sequences private to the fit only)
     bool has_reset = false;                      // change points: some steps consume the reset distribution (no-stencil batches only)
     std::vector<int> order, tap_id;              // chains sorted by stencil radius; the chain's axis-0 kernel (-1: none)
     std::vector<int> round_start, round_nk;      // launches: order[round_start[r] .. round_start[r + 1]), band blocks NK
@@ -1305,10 +1324,13 @@ struct ChainResPlan {
 
 // every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
 bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
-    if (g.n0 != 128 && g.n0 != 256 && g.n0 != 512) return false;
-    if (g.n1 % blc::WCOL) return false;
-    cp.strips = g.n1 / blc::WCOL;
-    cp.ntw = g.n0 / (blc::NW * blc::TM);
+    // any grid of 48 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 512 rows x a multiple of 16 columns
+    if (g.n0 < 48 || g.n0 > 512) return false;
+    cp.n0p = g.n0 <= 128 ? 128 : (g.n0 <= 256 ? 256 : 512);
+    cp.n1p = (g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL;
+    cp.pad = cp.n0p != g.n0 || cp.n1p != g.n1;
+    cp.strips = cp.n1p / blc::WCOL;
+    cp.ntw = cp.n0p / (blc::NW * blc::TM);
     if (cp.strips > blc::MAX_STRIPS || cp.strips > cus) return false;
     cp.cpr = cus / cp.strips;
     cp.tap_id.assign(B, -1);
@@ -1334,7 +1356,7 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
         }
         cp.tap_id[b] = k0;
         lw[b] = k0 >= 0 ? taps.lw[k0] : 0;
-        if (lw[b] > 40) return false;
+        if (lw[b] > 40 || lw[b] >= g.n0) return false;          // (single-period reflection)
     }
     cp.order.resize(B);
     for (int64_t b = 0; b < B; ++b) cp.order[b] = (int)b;
@@ -1533,7 +1555,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     //      two under-filled launches per step (round 1: the 107-chain radius-24 bucket of the C4 study ran as 36 + 71 chains at
     //      4.1 TB/s); hyper-grids are usually monotone in the random-walk width, so contiguous cuts suffice.
     // (cuts on radius-bucket boundaries serve the launch-per-step kernels; grids the chain-resident kernel takes keep whole launches)
-    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && (g.n0 == 128 || g.n0 == 256 || g.n0 == 512) && g.n1 % 16 == 0 &&
+    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && g.n0 >= 48 && g.n0 <= 512 && g.n1 <= 16 * blc::MAX_STRIPS &&
                              ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok;
     std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && !chain_shape && ctx->option("bucket_batches", 1.0) != 0.0);
     if (overlap_acc) {                     // (equal batches, multiples of 32 chains: whole launches of the chain-resident kernel)
@@ -1670,6 +1692,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         ChainRun CR;
         if (!RR.on) CR.setup(E, fast, FP.use_rec != 0, psz);
         if (RR.on || CR.on) { ctx->psumF.ensure(psz * 8); d_psF = ctx->psumF.as<double>(); }
+        if (CR.on && CR.cp.pad && d_post) {      // the private sequence of a padded chain-resident batch lives on the padded geometry
+            DevBuf &pb = (overlap_acc && (bi & 1)) ? ctx->post2 : ctx->post;
+            pb.ensure((size_t)B * T * CR.Gk * 8);
+            d_post = pb.as<double>();
+            E.d_post = d_post;
+        }
         const bool resident = RR.on, chainres = CR.on;
         bool resident_failed = false;
 

@@ -51,7 +51,9 @@ constexpr int MAX_STRIPS = 64;    // strips per chain: one granule per lane
 constexpr int SCALE_WAVE = 6;     // the wave that turns the strips' sums into the next step's scale (shares its SIMD with no edge wave)
 
 struct ChainParams {
-    int n0, n1, strips;          // n0 == NW * NTW * TM, strips = n1 / 16
+    int n0, n1, strips;          // n0 == NW * NTW * TM, strips = n1 / 16: the geometry the kernels work on
+    int n0t, n1t;                // the grid's TRUE sizes (PAD kernels: n0t <= n0, n1t <= n1; everything the fit itself owns -- states,
+                                 // stored sequences, partial accumulators -- is laid out on the padded geometry, padded cells hold zeros)
     int T, d, rec_len, lag;
     int means;                   // also sum the stored distribution times the grid values (forward-only fits; backward: per-chain means wanted)
     int strip_major;             // layout of post / part: 0 = [t][row][column] (the API's), 1 = [t][strip][row][16] (private to a fit whose
@@ -143,11 +145,17 @@ constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 
 // stencil is self-adjoint, so  N_t = sum alpha_t beta_t = s'_t N_(t+1) / s_(t+1)  (s' = this pass's scales, s = the forward pass's,
 // N_(T-1) = sum alpha_(T-1) / G).  The host checks the prediction against the reduced sums afterwards (1e-9) and repeats the batch
 // with the launch-per-step kernels if it ever differs (the partial accumulators of a batch are folded only after that check).
-template <int NK, int NTW, bool BWD, bool STORE>
+// PAD: the grid is smaller than the geometry (rows not 128 / 256 / 512, columns not a multiple of 16).  The kernel works on the padded
+// geometry; what differs: the stencil reflects at the grid's TRUE last row, cells outside the grid are kept at zero (and out of the
+// sums), the read-only inputs (source distribution, coordinates, column constants) are read with bounds.  Only for sequences private
+// to the fit (strip-major layout on the padded geometry): forward passes here, the backward pass in chain_fold2_kernel.
+template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false>
 __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
+    static_assert(!(PAD && BWD), "padded grids: the backward pass is chain_fold2_kernel's");
+    const int n0t = PAD ? P.n0t : N0, n1t = PAD ? P.n1t : P.n1;      // the grid's true sizes
     static_assert(NK == 4 || (NK >= 6 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
     constexpr bool FILTER = NK > 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -172,12 +180,16 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     // the first step consumes its source unfiltered: it runs with the identity band (exact), the chain's band replaces it afterwards
     // (one code path for every step: no per-step branches around the ring and the products)
     if (FILTER) for (int e = tid; e < NK * 64; e += NT) As[e] = band_distance(e, R0) == 0 ? 1.0 : 0.0;
-    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
+    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[PAD ? min(e, n0t - 1) : e];
     if (tid < 2 * NSLOT) scal[tid] = 1.0;
-    if (FILTER) for (int e = tid; e < XSZ; e += NT) X[e] = P.src0[(long long)(e >> 4) * P.n1 + tj * WCOL + (e & 15)];
-
-    const double g1 = P.m1[gj];
-    const double cA = P.colA[gj], cB = P.colB[gj];
+    if (FILTER) for (int e = tid; e < XSZ; e += NT) {
+        const int row = e >> 4, col = tj * WCOL + (e & 15);
+        X[e] = (!PAD || (row < n0t && col < n1t)) ? P.src0[(long long)row * n1t + col] : 0.0;
+    }
+    const bool colok = !PAD || gj < n1t;
+    const int gjc = PAD ? min(gj, n1t - 1) : gj;
+    const double g1 = P.m1[gjc];
+    const double cA = P.colA[gjc], cB = P.colB[gjc];
     double *const pchain = P.post + (long long)b * P.post_stride;
     const unsigned rowx8 = P.strip_major ? (unsigned)WCOL * 8u : (unsigned)P.n1 * 8u;                        // bytes between rows
     const unsigned strip0 = P.strip_major ? (unsigned)tj * (unsigned)(P.n0 * WCOL * 8) : (unsigned)tj * (unsigned)(WCOL * 8);   // the strip's first byte
@@ -208,9 +220,11 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         for (int it = 0; it < NTW; ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long cell = (long long)(row0 + it * TM + (lane >> 4) + 4 * r) * P.n1 + tj * WCOL + (lane & 15);
-                stt[it][r] = P.src0[cell];
-                rst[it][r] = P.kinds ? P.reset[cell] : 0.0;
+                const int row = row0 + it * TM + (lane >> 4) + 4 * r;
+                const bool in = !PAD || (row < n0t && colok);
+                const long long cell = in ? (long long)row * n1t + gj : 0;
+                stt[it][r] = in ? P.src0[cell] : 0.0;
+                rst[it][r] = (in && P.kinds) ? P.reset[cell] : 0.0;
             }
     }
     constexpr bool FOLD = BWD && !STORE;
@@ -276,13 +290,13 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         double *D = X + ((k + 1) & 1) * XSZ;
         // (interior waves: consecutive k-blocks are 512 bytes apart -- one address register, immediate offsets; only waves whose
         //  window reaches beyond the grid edge pay for the reflection)
-        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
+        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > n0t;          // (the reflection is at the grid's true last row)
         double Bv[NK];
         if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (edge) {
 #pragma unroll
-                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, N0) * WCOL + c];
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, n0t) * WCOL + c];
             } else {
                 const double *s0 = S + (row0 - R0 + g) * WCOL + c;
 #pragma unroll
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 const double Lv = ldexp(mE, nE);
                 const unsigned off = cell_off(l, it, r);
                 if (!BWD) {
-                    const double a = acc[r] * Lv;
+                    const double a = (!PAD || (colok && li < n0t)) ? acc[r] * Lv : 0.0;          // (cells outside the grid stay zero)
                     if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
                     if (STORE) stnt(pstep, off, a);
                     sN += a;
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
                 if (edge) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, N0) * WCOL + c];
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, n0t) * WCOL + c];
                 } else {
                     const double *s1 = S + (i + TM + R0 + g) * WCOL + c;
 #pragma unroll
@@ -518,11 +532,12 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 template <int NK, int NTW>
 constexpr size_t lds_doubles_fold2() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 64 + NW * NTW * TM + 2 * 2 * NW * 4 * 3 + 4 * NSLOT + 8; }      // (NK = 4: the band tables stay unused)
 
-template <int NK, int NTW>
+template <int NK, int NTW, bool PAD = false>
 __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
+    const int n0t = PAD ? P.n0t : N0, n1t = PAD ? P.n1t : P.n1;      // the grid's true sizes (PAD: see chain_kernel)
     static_assert(NK == 4 || (NK >= 6 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
     // NK = 4: no stencil at all (change-point studies: every chain is Static except for the steps that restart from the reset
     // distribution, transitionModels.py:300-312).  A step is elementwise: a lane reads and writes only its own cells of the chain's
@@ -555,11 +570,15 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
 
     // first step: the source (uniform) is consumed unfiltered -> identity bands; the chains' bands replace them after step 0
     if (FILTER) for (int e = tid; e < 2 * NK * 64; e += NT) As[e] = band_distance(e % (NK * 64), R0) == 0 ? 1.0 : 0.0;
-    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
+    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[PAD ? min(e, n0t - 1) : e];
     if (tid < 4 * NSLOT) scal[tid] = 1.0;
-    for (int e = tid; e < 2 * XSZ; e += NT) { const int q = e % XSZ; X[e] = P.src0[(long long)(q >> 4) * P.n1 + tj * WCOL + (q & 15)]; }
-
-    const double cA = P.colA[gj], cB = P.colB[gj];
+    for (int e = tid; e < 2 * XSZ; e += NT) {
+        const int q = e % XSZ, row = q >> 4, col = tj * WCOL + (q & 15);
+        X[e] = (!PAD || (row < n0t && col < n1t)) ? P.src0[(long long)row * n1t + col] : 0.0;
+    }
+    const bool colok = !PAD || gj < n1t;
+    const int gjc = PAD ? min(gj, n1t - 1) : gj;
+    const double cA = P.colA[gjc], cB = P.colB[gjc];
     const unsigned rowx8 = (unsigned)WCOL * 8u;                    // (strip-major sequences: the fold is private to the fit)
     const unsigned strip0 = (unsigned)tj * (unsigned)(P.n0 * WCOL * 8);
     const int row0 = wv * (NTW * TM);
@@ -693,16 +712,20 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             for (int it = 0; it < NTW; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    Xj[(row0 + it * TM + g + 4 * r) * WCOL + c] = P.reset[(long long)(row0 + it * TM + g + 4 * r) * P.n1 + tj * WCOL + c];
+                {
+                    const int row = row0 + it * TM + g + 4 * r;
+                    const bool in = !PAD || (row < n0t && colok);
+                    Xj[row * WCOL + c] = in ? P.reset[(long long)row * n1t + tj * WCOL + c] : 0.0;
+                }
         }
 
-        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
+        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > n0t;          // (the reflection is at the grid's true last row)
         double Bv[NK];
         if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (edge) {
 #pragma unroll
-                for (int kb = 0; kb < NK; ++kb) Bv[kb] = Xj[reflect1(row0 - R0 + 4 * kb + g, N0) * WCOL + c];
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = Xj[reflect1(row0 - R0 + 4 * kb + g, n0t) * WCOL + c];
             } else {
                 const double *s0 = Xj + (row0 - R0 + g) * WCOL + c;
 #pragma unroll
@@ -799,10 +822,11 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double Lv = ldexp(mE, nE);
-                const double beta = acc[r] * scale;
+                const bool in = !PAD || (colok && i + g + 4 * r < n0t);          // (cells outside the grid: state, posterior and p / L stay zero)
+                const double beta = in ? acc[r] * scale : 0.0;
                 const double p = al[it][r] * beta;
                 const double cn = beta * Lv;
-                const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
+                const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));
                 if (FILTER) stt[it][r] = cn; else Xj[(i + g + 4 * r) * WCOL + c] = cn;
                 pacc[it][r] += fmax(p * wq, wfloor);
                 sN += p; sS += pl; sC += cn;
@@ -832,7 +856,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
                 if (edge) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = Xj[reflect1(i + TM + R0 + 4 * q + g, N0) * WCOL + c];
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = Xj[reflect1(i + TM + R0 + 4 * q + g, n0t) * WCOL + c];
                 } else {
                     const double *s1 = Xj + (i + TM + R0 + g) * WCOL + c;
 #pragma unroll

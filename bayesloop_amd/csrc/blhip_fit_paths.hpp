@@ -207,6 +207,7 @@ struct ChainRun {
     std::vector<int> round_start_b, round_nk_b;
     const double *redF_keep = nullptr;             // the forward pass's reduced sums (slot 1: the restart sums of change-point batches)
     int slots_used = 0;                            // partial accumulators the backward launches write (one per block column)
+    long long Gk = 0;                              // cells per distribution on the geometry the kernels work on (padded: >= G)
     double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr, *d_zeros = nullptr;
     std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
     double fold_ref = -INFINITY;
@@ -220,6 +221,7 @@ struct ChainRun {
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
         if (!on) return;
+        Gk = (long long)cp.n0p * cp.n1p;
         // (granule slots for 2 x cpr chains: the two-chain fold kernel runs rounds of that size)
         gran_bytes = carve_size((size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2 * 8);
         ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64));
@@ -232,14 +234,15 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
-        CQ.n0 = E.g.n0; CQ.n1 = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = E.d; CQ.rec_len = E.rec_len;
+        CQ.n0 = cp.n0p; CQ.n1 = cp.n1p; CQ.n0t = E.g.n0; CQ.n1t = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = E.d; CQ.rec_len = E.rec_len;
         CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
         CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
-        CQ.post_stride = (long long)T * G;
+        CQ.post_stride = (long long)T * Gk;
         CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.step0 = E.step0;
         CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
-        post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && (G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0;
+        // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)
+        post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && ((G & 1) == 0 || cp.pad) && ((uintptr_t)ctx->acc & 15) == 0;
         // (not beside overlapped folds: a FoldJob of the previous batch may still read ctx->accw and read-modify-write ctx->acc on the
         //  second stream while this batch re-carves accw and its fused fold writes ctx->acc on the main stream)
         fused = post_private && !E.overlap_acc && ctx->option("fuse_accumulate", 1.0) != 0.0;
@@ -267,8 +270,11 @@ struct ChainRun {
             round_start_b.push_back((int)B);
             slots_used = (int)std::min<int64_t>(cp.cpr, (B + 1) / 2);
         }
+        // a grid smaller than the geometry: only fits whose sequences are private to the fit (strip-major, padded) -- evidence-only fits
+        // and full fits that fold in the backward kernel; everything else keeps the launch-per-step kernels
+        if (cp.pad && !(E.ff.evidence_only || (fused && fold2)) ) { on = false; fused = false; fold2 = false; return; }
         if (fused) {
-            ctx->accpart.ensure((size_t)slots_used * T * G * 8);
+            ctx->accpart.ensure((size_t)slots_used * T * Gk * 8);
             ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(4096));
             char *wc = ctx->accw.as<char>();
             d_fold_sfwd = carve<double>(wc, (size_t)T * B);
@@ -298,11 +304,11 @@ struct ChainRun {
             Q.reset = E.DT->reset;
             Q.post = E.d_post;
             Q.means = bwd ? (E.chain_means ? 1 : 0) : (E.ff.forward_only ? 1 : 0);
-            Q.strip_major = post_private ? 1 : 0;            // (the stored sequence is private to the fit then)
+            Q.strip_major = (post_private || cp.pad) ? 1 : 0;            // (the stored sequence is private to the fit then)
             const bool fold_now = bwd && fused;
             if (fold_now) {
                 Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
-                Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * E.G;
+                Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * Gk;
                 Q.zeros = d_zeros; Q.part_fresh = r == 0 ? 1 : 0;          // (every slot is first used by the first launch: no memset)
             }
 #ifdef BLC_PROF
@@ -310,12 +316,12 @@ struct ChainRun {
             HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
             Q.prof = ctx->small.as<unsigned long long>();
 #endif
-            if (two) launch_fold2(st, Q, rnk[r], cp.ntw);
-            else launch_chain(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
+            if (two) launch_fold2(st, Q, rnk[r], cp.ntw, cp.pad);
+            else launch_chain(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only), cp.pad);
             {   // HBM: only what the fit keeps -- forward the stored state (8 B; nothing for evidence-only fits), backward the stored
                 // state in + the posterior out (16 B) or + the read-modify-write of the partial accumulator (24 B; shared by the two
                 // chains of a block of the two-chain fold kernel: 8 + 16 / 2 = 16 B)
-                const double cells = (double)Q.nslots * E.G * T;
+                const double cells = (double)Q.nslots * Gk * T;
                 const double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
                 const int r0 = (4 * rnk[r] - blc::TM) / 2;
                 account(ctx, bwd, cells * bytes, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
@@ -381,7 +387,7 @@ struct ChainRun {
         // use (a first launch with fewer chains than slots), which later launches may
         const int first_n = fold2 ? (round_start_b[1] - round_start_b[0] + 1) / 2 : cp.round_start[1] - cp.round_start[0];
         if (first_n < slots_used)
-            HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * E.G, 0, (size_t)(slots_used - first_n) * T * E.G * 8, E.st));
+            HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * Gk, 0, (size_t)(slots_used - first_n) * T * Gk * 8, E.st));
         HIPCHECK(hipMemsetAsync(d_zeros, 0, 4096, E.st));
     }
 
@@ -424,9 +430,9 @@ struct ChainRun {
             const double newref = std::max(ctx->acc_logref, fold_ref);
             const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
             HIPCHECK(hipEventRecord(ctx->ev[4], st));
-            hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)((G / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
-                               ctx->accpart.as<double>(), (long long)T * G, slots_used, E.g.n0, E.g.n1, (int)T, r, rb,
-                               ctx->acc_first ? 1 : 0);
+            hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)(((G + 1) / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
+                               ctx->accpart.as<double>(), (long long)T * Gk, slots_used, E.g.n0, E.g.n1, (int)T, r, rb,
+                               ctx->acc_first ? 1 : 0, cp.n0p, Gk);
             HIPCHECK(hipEventRecord(ctx->ev[5], st));
             sync_stream(ctx, st);
             float fms = 0;

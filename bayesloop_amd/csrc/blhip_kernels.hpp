@@ -470,17 +470,33 @@ __global__ __launch_bounds__(NTHREADS) void accumulate_kernel(double *A, const d
 // The partial accumulators of a batch whose backward kernel folded the posteriors itself (blhip_chainres.hpp): one per launch slot,
 // already weighted and normalised, in the kernel's strip-major layout [t][strip][row][16]:
 //     A[t][row][col] = r A + rb sum_slots part[slot][t][col / 16][row][col % 16]          (two cells per lane)
+// (n0p: rows per strip of the partials -- the kernel's padded row count when the grid's is not 128 / 256 / 512; pstep: doubles per time
+//  step of a partial accumulator on that padded geometry)
 __global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const double *part, long long part_stride, int nslots, int n0, int n1,
-                                                               int T, double r, double rb, int first) {
+                                                               int T, double r, double rb, int first, int n0p, long long pstep) {
     const long long G = (long long)n0 * n1;
-    const long long c = ((long long)blockIdx.x * NTHREADS + threadIdx.x) * 2;
     const int t = blockIdx.y;
+    if (n1 & 1) {                          // an odd number of columns: pairs of cells would straddle rows -- one cell per lane
+        for (int h = 0; h < 2; ++h) {
+            const long long c = ((long long)blockIdx.x * NTHREADS + threadIdx.x) * 2 + h;
+            if (c >= G) return;
+            const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
+            double *ap = A + (long long)t * G + c;
+            double acc = first ? 0.0 : *ap * r;
+            const double *src = part + (long long)t * pstep + ((long long)(col >> 4) * n0p + row) * 16 + (col & 15);
+            double sum = 0.0;
+            for (int k = 0; k < nslots; ++k) sum += src[(long long)k * part_stride];
+            *ap = fma(rb, sum, acc);
+        }
+        return;
+    }
+    const long long c = ((long long)blockIdx.x * NTHREADS + threadIdx.x) * 2;
     if (c >= G) return;
     const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
     double2 *ap = reinterpret_cast<double2 *>(A + (long long)t * G + c);
     double2 acc = first ? make_double2(0.0, 0.0) : *ap;
     if (!first) { acc.x *= r; acc.y *= r; }
-    const double *src = part + (long long)t * G + ((long long)(col >> 4) * n0 + row) * 16 + (col & 15);
+    const double *src = part + (long long)t * pstep + ((long long)(col >> 4) * n0p + row) * 16 + (col & 15);
     double2 sum = make_double2(0.0, 0.0);
     for (int k = 0; k < nslots; ++k) {
         const double2 v = *reinterpret_cast<const double2 *>(src + (long long)k * part_stride);

@@ -206,7 +206,7 @@ def random_online_case(seed):
     return c
 
 
-def random_chain_resident_case(seed):
+def random_chain_resident_case(seed, ragged=False):
     """Seeded random studies inside the envelope of the chain-resident kernel (blhip_chainres.hpp): hyper-studies over the width of one
     random walk on the first parameter (radius 0 .. 40, hyper-priors, observation-model priors, missing / multi-dimensional data,
     every fit mode) and change-point studies without a stencil, on grids of 128 / 256 / 512 rows x a multiple of 16 columns."""
@@ -214,6 +214,13 @@ def random_chain_resident_case(seed):
     n0 = [128, 128, 256, 512][int(rng.integers(0, 4))]
     n1 = 16 * int(rng.integers(1, 9 if n0 < 512 else 5))
     T = int(rng.integers(1, 15))
+    if ragged:
+        # any grid of 48 .. 512 rows x any number of columns: the kernels work on the next geometry of 128 / 256 / 512 rows x a multiple
+        # of 16 columns (padded cells hold zeros, the stencil reflects at the grid's true last row)
+        # (>= 64 rows x >= 16 columns: what the launch-per-step column kernels -- the fall-back of the resident paths -- need for a
+        #  radius of up to 40)
+        n0 = int(rng.integers(64, 513)) if seed % 5 else [64, 127, 129, 255, 257, 511][int(rng.integers(0, 6))]
+        n1 = int(rng.integers(16, 130 if n0 <= 256 else 70))
     lo, hi = -float(rng.uniform(3, 8)), float(rng.uniform(3, 8))
     prior = ['default', 'inv_s3', 'inv_s_2d'][int(rng.integers(0, 3))]
     om = ('Gaussian', [('mean', ('cint', lo, hi, n0)), ('std', ('oint', float(rng.uniform(0.0, 0.3)), float(rng.uniform(1.5, 4)), n1))], prior)
@@ -228,6 +235,8 @@ def random_chain_resident_case(seed):
     k = int(rng.integers(2, 41 if n0 * n1 <= 128 * 64 else 13))
     sig = ('cint', 0.0 if seed % 3 == 0 else float(rng.uniform(0.0, 0.3)) * smax, smax, k)
     flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
+    if ragged and flags.get('forwardOnly'):
+        flags = dict()                     # (padded grids: evidence-only fits and full fits that fold in the backward kernel)
     data = ('series', 1800 + seed, T)
     hp = None
     if kind == 'hyper_nan' and T >= 3:

@@ -890,13 +890,14 @@ def test_chain_resident_kernel_lag_and_determinism(lag):
 
 
 def test_chain_resident_kernel_not_taken_outside_its_envelope():
-    """A walk wider than 40 grid steps, a filter on the second parameter, a grid whose row count is not 128 / 256 / 512: the
-    launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
+    """A walk wider than 40 grid steps, a filter on the second parameter, a grid of fewer than 48 rows, a padded grid whose fit
+    keeps its filtered distributions, more than 64 strips: the launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
     for c in (_hyper(128, 32, 62, 4, ('cint', 0.1, 2.0, 3)),
               dict(study='HyperStudy', data=('series', 63, 4), om=_g2(128, 32), tm=('GRW', 'sigma', ('cint', 0.1, 0.3, 3), 'std', None)),
-              _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3)),
+              _hyper(40, 32, 64, 4, ('cint', 0.1, 0.5, 3)),               # fewer than 48 rows
+              _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3), forwardOnly=True),     # padded grid, but the stored sequence is not private to the fit
               _hyper(128, 1040, 66, 3, ('cint', 0.1, 0.5, 2))):          # 65 strips: more than one granule per lane
-        S = cases.build(bl, c); S.fit(silent=True)
+        S = cases.build(bl, c); S.fit(**cases.fit_kwargs(c))
         assert S.lastTiming['fwd_kernel_variant'] != 6
         with np.errstate(all='ignore'):
             want = oa.run(c)
@@ -937,6 +938,57 @@ def test_fused_fold_matches_the_separate_fold():
     np.testing.assert_allclose(np.array(A.posteriorSequence), np.array(B.posteriorSequence), rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(A.posteriorMeanValues, B.posteriorMeanValues, rtol=1e-11)
     np.testing.assert_allclose(A.localEvidence, B.localEvidence, rtol=1e-11, equal_nan=True)
+
+
+RAGGED = {
+    # rows not 128 / 256 / 512 and / or columns not a multiple of 16: the chain-resident kernels on the padded geometry
+    'pad_200x200_full': _hyper(200, 200, 81, 6, ('cint', 0, 0.7, 9)),
+    'pad_100x37_full': _hyper(100, 37, 82, 9, ('cint', 0.02, 0.8, 21)),                 # odd number of columns, 3 strips, odd chain count
+    'pad_48x17_evidence': _hyper(48, 17, 83, 7, ('cint', 0, 0.5, 4), evidenceOnly=True),
+    'pad_511x33_full': _hyper(511, 33, 84, 5, ('cint', 0, 0.25, 5)),
+    'pad_300x1000_evidence': _hyper(300, 1000, 85, 4, ('cint', 0.05, 0.5, 3), evidenceOnly=True),
+    'pad_130x16_nan': _hyper(130, 16, 86, 10, ('cint', 0, 0.6, 8), kind='series_nan', extra=[2, 3]),
+    'pad_cp_150x40': dict(study='ChangepointStudy', data=('series_jump', 87, 12, 6, 1.5), om=_g2(150, 40), tm=('ChangePoint', 'tc', 'all', None)),
+    'pad_cp_60x70_evidence': dict(study='ChangepointStudy', data=('series_jump', 88, 9, 4, -1.0), om=_g2(60, 70), tm=('ChangePoint', 'tc', 'all', None),
+                                  fit=dict(evidenceOnly=True)),
+}
+
+
+@pytest.mark.parametrize('case', list(RAGGED))
+def test_chain_resident_kernels_on_padded_grids_match_oracle(case):
+    c = RAGGED[case]
+    S = cases.build(bl, c)
+    kw = cases.fit_kwargs(c)
+    S.fit(**kw)
+    assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming
+    if not kw.get('evidenceOnly'):
+        assert S.lastTiming['bwd_kernel_variant'] == 6 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_CHAIN_FUZZ_SEEDS', 36))))
+def test_seeded_random_chain_resident_studies_on_padded_grids_match_oracle(seed):
+    c = random_cases.random_chain_resident_case(seed, ragged=True)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming          # the chain-resident path really ran
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    if 'logEvidenceList' in want and not np.all(np.isfinite(np.asarray(want['logEvidenceList'], dtype=float))):
+        got['localEvidence'] = gold['localEvidence']
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
 
 
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_CHAIN_FUZZ_SEEDS', 36))))
