@@ -470,6 +470,7 @@ void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, 
 
 void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
     if (ntw == 4) launch_chain_w<4>(s, Q, nk, bwd, store, pad);
+    else if (ntw == 3) launch_chain_w<3>(s, Q, nk, bwd, store, pad);
     else if (ntw == 2) launch_chain_w<2>(s, Q, nk, bwd, store, pad);
     else if (ntw == 1) launch_chain_w<1>(s, Q, nk, bwd, store, pad);
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
@@ -508,10 +509,11 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
     }
 }
 
-bool fold2_shape(int ntw) { return ntw == 4 || ntw == 2 || ntw == 1; }
+bool fold2_shape(int ntw) { return ntw >= 1 && ntw <= 4; }
 
 void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad = false) {
     if (ntw == 4) launch_fold2_w<4>(s, Q, nk, pad);
+    else if (ntw == 3) launch_fold2_w<3>(s, Q, nk, pad);
     else if (ntw == 2) launch_fold2_w<2>(s, Q, nk, pad);
     else if (ntw == 1) launch_fold2_w<1>(s, Q, nk, pad);
     else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
@@ -999,7 +1001,7 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
     // the chain-resident kernels lay their sequences out on a padded geometry (rows 128 / 256 / 512, columns a multiple of 16)
     double Gk = (double)G;
     if (p->ndim == 2 && g.n0 >= 48 && g.n0 <= 512)
-        Gk = (double)(g.n0 <= 128 ? 128 : (g.n0 <= 256 ? 256 : 512)) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
+        Gk = (double)((g.n0 + 127) / 128 * 128) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
     // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
     if (ff.accumulate && ff.full && p->ndim == 2 && g.n1 >= 1) {
         const double slots = std::max(1, std::min(ctx->num_cus, 256) / ((g.n1 + blc::WCOL - 1) / blc::WCOL));
@@ -1324,9 +1326,9 @@ struct ChainResPlan {
 
 // every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
 bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
-    // any grid of 48 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 512 rows x a multiple of 16 columns
+    // any grid of 48 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns
     if (g.n0 < 48 || g.n0 > 512) return false;
-    cp.n0p = g.n0 <= 128 ? 128 : (g.n0 <= 256 ? 256 : 512);
+    cp.n0p = (g.n0 + 127) / 128 * 128;
     cp.n1p = (g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL;
     cp.pad = cp.n0p != g.n0 || cp.n1p != g.n1;
     cp.strips = cp.n1p / blc::WCOL;

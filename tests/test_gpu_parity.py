@@ -948,6 +948,8 @@ RAGGED = {
     'pad_511x33_full': _hyper(511, 33, 84, 5, ('cint', 0, 0.25, 5)),
     'pad_300x1000_evidence': _hyper(300, 1000, 85, 4, ('cint', 0.05, 0.5, 3), evidenceOnly=True),
     'pad_130x16_nan': _hyper(130, 16, 86, 10, ('cint', 0, 0.6, 8), kind='series_nan', extra=[2, 3]),
+    'pad_300x64_full': _hyper(300, 64, 89, 7, ('cint', 0, 0.5, 10)),                     # the 384-row geometry (3 product tiles per wave)
+    'aligned_384x32_full': _hyper(384, 32, 90, 6, ('cint', 0, 0.4, 6)),
     'pad_cp_150x40': dict(study='ChangepointStudy', data=('series_jump', 87, 12, 6, 1.5), om=_g2(150, 40), tm=('ChangePoint', 'tc', 'all', None)),
     'pad_cp_60x70_evidence': dict(study='ChangepointStudy', data=('series_jump', 88, 9, 4, -1.0), om=_g2(60, 70), tm=('ChangePoint', 'tc', 'all', None),
                                   fit=dict(evidenceOnly=True)),
