@@ -438,9 +438,10 @@ void launch_chain_fn(KernT kern, hipStream_t s, const blc::ChainParams &Q, size_
 template <int NK, int NTW>
 void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store, bool pad) {
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
-    if (pad) {                          // grids smaller than the geometry: forward passes only (the backward pass folds: launch_fold2)
-        if (bwd) fail("internal: padded chain-resident launch of a storing backward pass");
-        if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
+    if (pad) {                          // grids smaller than the geometry (the folding backward pass: launch_fold2)
+        if (bwd && !store) fail("internal: padded chain-resident launch of a folding backward pass");
+        if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true>, s, Q, lds);
+        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
         else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true>, s, Q, lds);
         return;
     }
@@ -1222,6 +1223,8 @@ struct FoldJob {
     int first = 0;
     int parity = 0;
     int sm_n0 = 0;                                   // > 0: d_post is in the chain-resident kernel's strip-major layout (rows per strip)
+    int pad_n0p = 0, pad_n0 = 0, pad_n1 = 0;         // > 0: ... on a padded geometry (rows per strip n0p; the grid's true sizes)
+    long long pad_step = 0;                          //      doubles per time step of a chain's sequence there
 };
 
 bool prepare_fold(blhip_ctx *ctx, int64_t T, int64_t B, const BatchOutcome &out, const double *log_w_batch, FoldJob &job) {
@@ -1257,7 +1260,11 @@ void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hip
     HIPCHECK(hipMemcpyAsync(job.d_w, job.h_w, B * 8, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(job.d_invN, job.h_invN, (size_t)T * B * 8, hipMemcpyHostToDevice, st));
     HIPCHECK(hipEventRecord(ev0, st));
-    if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
+    if (job.pad_n0p > 0) {
+        hipLaunchKernelGGL(accumulate_pad_kernel, dim3((unsigned)((G + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
+                           job.d_post, (long long)T * job.pad_step, (int)B, job.pad_n0, job.pad_n1, (int)T, job.d_w, job.d_invN, job.r, job.first,
+                           job.pad_n0p, job.pad_step);
+    } else if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
         const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
         hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
                            (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first, job.sm_n0);
@@ -1272,9 +1279,10 @@ void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hip
 
 // the whole fold on the main stream, waited for
 void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const BatchOutcome &out, const double *log_w_batch, const double *d_post,
-                     double *d_w, double *d_invN, int sm_n0 = 0) {
+                     double *d_w, double *d_invN, int sm_n0 = 0, const FoldJob *layout = nullptr) {
     ctx->pinA.ensure(((size_t)B + (size_t)T * B) * 8);
     FoldJob job;
+    if (layout) job = *layout;
     job.sm_n0 = sm_n0;
     job.h_w = ctx->pinA.as<double>(); job.h_invN = job.h_w + B;
     job.d_w = d_w; job.d_invN = d_invN; job.d_post = d_post;
@@ -1979,12 +1987,16 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             fold_job.d_w = carve<double>(wc, (size_t)Bmax); fold_job.d_invN = carve<double>(wc, (size_t)T * Bmax);
             fold_job.h_w = carve<double>(hc, (size_t)Bmax); fold_job.h_invN = carve<double>(hc, (size_t)T * Bmax);
             fold_job.d_post = d_post; fold_job.parity = (int)(bi & 1);
-            fold_job.sm_n0 = (CR.post_private && !resident_failed) ? g.n0 : 0;
+            fold_job.sm_n0 = (CR.post_private && !resident_failed && !CR.cp.pad) ? g.n0 : 0;
+            if (CR.on && CR.cp.pad && !resident_failed) { fold_job.pad_n0p = CR.cp.n0p; fold_job.pad_n0 = g.n0; fold_job.pad_n1 = g.n1; fold_job.pad_step = CR.Gk; }
             fold_job.pending = prepare_fold(ctx, T, B, O, log_w + c0, fold_job);
             // launched behind the NEXT batch's forward pass (see passes); the last batch has nothing to hide behind
             if (bi == nbatch - 1) launch_pending_fold();
         } else if (accumulate) {
-            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (CR.post_private && !resident_failed) ? g.n0 : 0);
+            FoldJob lay;
+            const bool padded = CR.on && CR.cp.pad && !resident_failed;
+            if (padded) { lay.pad_n0p = CR.cp.n0p; lay.pad_n0 = g.n0; lay.pad_n1 = g.n1; lay.pad_step = CR.Gk; }
+            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (CR.post_private && !resident_failed && !padded) ? g.n0 : 0, padded ? &lay : nullptr);
         }
         if (keep) {
             int64_t row0 = 0, row1 = T;              // rows the resident kernel normalised in place (invN = 1 there) need no pass

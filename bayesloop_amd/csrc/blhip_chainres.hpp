@@ -148,13 +148,14 @@ constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 
 // PAD: the grid is smaller than the geometry (rows not 128 / 256 / 512, columns not a multiple of 16).  The kernel works on the padded
 // geometry; what differs: the stencil reflects at the grid's TRUE last row, cells outside the grid are kept at zero (and out of the
 // sums), the read-only inputs (source distribution, coordinates, column constants) are read with bounds.  Only for sequences private
-// to the fit (strip-major layout on the padded geometry): forward passes here, the backward pass in chain_fold2_kernel.
+// to the fit (strip-major layout on the padded geometry): forward passes and storing backward passes here, folding backward passes in
+// chain_fold2_kernel.
 template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false>
 __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
-    static_assert(!(PAD && BWD), "padded grids: the backward pass is chain_fold2_kernel's");
+    static_assert(!(PAD && BWD && !STORE), "padded grids: the folding backward pass is chain_fold2_kernel's");
     const int n0t = PAD ? P.n0t : N0, n1t = PAD ? P.n1t : P.n1;      // the grid's true sizes
     static_assert(NK == 4 || (NK >= 6 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
     constexpr bool FILTER = NK > 4;
@@ -411,11 +412,12 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     if (!FILTER && want_x) sS = fma(a, rst[it][r], sS);
                     acc[r] = a;
                 } else {
-                    const double beta = acc[r] * scale;
+                    const bool in = !PAD || (colok && li < n0t);                                 // (cells outside the grid stay zero)
+                    const double beta = in ? acc[r] * scale : 0.0;
                     const double p = al[it][r] * beta;
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
-                    const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);
+                    const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));
                     if (FILTER) D[li * WCOL + c] = cn; else stt[it][r] = cn;
                     if (!FOLD) stnt(pstep, off, p);
                     else stnt(pslot_t, off, pa[r] + fmax(p * wq, wfloor));      // (nobody else touches the slot's cell during the launch)

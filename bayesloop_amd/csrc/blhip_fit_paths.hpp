@@ -271,8 +271,10 @@ struct ChainRun {
             slots_used = (int)std::min<int64_t>(cp.cpr, (B + 1) / 2);
         }
         // a grid smaller than the geometry: only fits whose sequences are private to the fit (strip-major, padded) -- evidence-only fits
-        // and full fits that fold in the backward kernel; everything else keeps the launch-per-step kernels
-        if (cp.pad && !(E.ff.evidence_only || (fused && fold2)) ) { on = false; fused = false; fold2 = false; return; }
+        // and full fits of hyper- / change-point studies (folded in the backward kernel, or stored and folded by accumulate_pad_kernel);
+        // everything else keeps the launch-per-step kernels
+        if (cp.pad && !(E.ff.evidence_only || post_private)) { on = false; fused = false; fold2 = false; return; }
+        if (cp.pad && fused && !fold2) fused = false;      // (the one-chain folding kernel has no padded variant: store + separate fold)
         if (fused) {
             ctx->accpart.ensure((size_t)slots_used * T * Gk * 8);
             ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(4096));

@@ -507,6 +507,29 @@ __global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const d
     *ap = acc;
 }
 
+// The separate fold of a batch whose posteriors sit in the chain-resident kernels' strip-major layout on a PADDED geometry
+// ([t][column / 16][row of n0p][16], pstep doubles per time step, chain_stride per chain): one cell per lane (any number of columns).
+__global__ __launch_bounds__(NTHREADS) void accumulate_pad_kernel(double *A, const double *post, long long chain_stride, int B, int n0, int n1,
+                                                                  int T, const double *w, const double *invN, double r, int first,
+                                                                  int n0p, long long pstep) {
+    const long long G = (long long)n0 * n1;
+    const long long t = blockIdx.y;
+    const long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x;
+    if (c >= G) return;
+    const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
+    double acc = first ? 0.0 : A[t * G + c] * r;
+    const double *pp = post + t * pstep + ((long long)(col >> 4) * n0p + row) * 16 + (col & 15);
+    for (int b = 0; b < B; ++b) {
+        const double wb = w[b];
+        if (wb > 0.0) {
+            double p0 = __builtin_nontemporal_load(pp + (long long)b * chain_stride) * invN[(long long)b * T + t];
+            p0 = p0 < 1e-300 ? 1e-300 : p0;
+            acc = fma(wb, p0, acc);
+        }
+    }
+    A[t * G + c] = acc;
+}
+
 // Same, two cells per lane (16-B accesses) and four chains in flight per iteration; needs an even number of cells.
 // sm_n0 > 0: the sequences are in the chain-resident kernel's strip-major layout [t][column / 16][row][16] (n0 = sm_n0 rows; the
 // accumulator keeps the API's [t][row][column]).

@@ -956,6 +956,31 @@ RAGGED = {
 }
 
 
+@pytest.mark.parametrize('opts', [dict(fold2=0), dict(fuse_accumulate=0), dict(fold2_cp=0)])
+def test_padded_grids_through_the_storing_backward_kernel(opts):
+    """Padded grids without the two-chain fold kernel: the backward chain kernel stores the posteriors on the padded geometry and the
+    separate fold (accumulate_pad_kernel) reads them from there."""
+    eng = bl.get_engine()
+    for case in ('pad_100x37_full', 'pad_cp_150x40', 'pad_300x64_full'):
+        c = RAGGED[case]
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        try:
+            S = cases.build(bl, c); S.fit(**cases.fit_kwargs(c))
+        finally:
+            for k in opts:
+                eng.set_option(k, 1)
+        assert S.lastTiming['fwd_kernel_variant'] == 6 and S.lastTiming['bwd_kernel_variant'] == 6 and S.lastTiming['resident_fallbacks'] == 0
+        with np.errstate(all='ignore'):
+            want = oa.run(c)
+        got = result_of(S, c)
+        gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+        for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+            if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+                gold[k] = np.asarray(want[k])
+        compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+
+
 @pytest.mark.parametrize('case', list(RAGGED))
 def test_chain_resident_kernels_on_padded_grids_match_oracle(case):
     c = RAGGED[case]
