@@ -990,6 +990,8 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
 }
 
 // memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
+constexpr int CHAIN_MIN_ROWS = 32;            // smallest grid (rows) the chain-resident kernels take (on the 128-row geometry)
+
 int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int64_t n_chains, int post_buffers) {
     const int64_t T = p->T;
     const long long G = g.G;
@@ -1001,7 +1003,7 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
                              ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
     // the chain-resident kernels lay their sequences out on a padded geometry (rows 128 / 256 / 512, columns a multiple of 16)
     double Gk = (double)G;
-    if (p->ndim == 2 && g.n0 >= 48 && g.n0 <= 512)
+    if (p->ndim == 2 && g.n0 >= CHAIN_MIN_ROWS && g.n0 <= 512)
         Gk = (double)((g.n0 + 127) / 128 * 128) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
     // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
     if (ff.accumulate && ff.full && p->ndim == 2 && g.n1 >= 1) {
@@ -1327,15 +1329,17 @@ struct ChainResPlan {
     int ntw = 0, strips = 0, cpr = 0;            // product tiles per wave, strips per chain, chains per launch
     int n0p = 0, n1p = 0;                        // the geometry the kernels work on: rows 128 / 256 / 512, columns a multiple of 16
     bool pad = false;                            // the grid is smaller than that (padded cells hold zeros; sequences private to the fit only)
-    bool has_reset = false;                      // change points: some steps consume the reset distribution (no-stencil batches only)
+    bool has_reset = false;                      // change points: some steps consume the reset distribution
+    bool mixed = false;                          // ... in chains that also filter (random walk + change point in one model)
+    std::vector<unsigned char> ckF, ckB;         // [T][B] what a step of the chain kernels consumes: SRC_PREV / SRC_RESET (| 0x80: unfiltered)
     std::vector<int> order, tap_id;              // chains sorted by stencil radius; the chain's axis-0 kernel (-1: none)
     std::vector<int> round_start, round_nk;      // launches: order[round_start[r] .. round_start[r + 1]), band blocks NK
 };
 
 // every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
 bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
-    // any grid of 48 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns
-    if (g.n0 < 48 || g.n0 > 512) return false;
+    // any grid of 32 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns
+    if (g.n0 < CHAIN_MIN_ROWS || g.n0 > 512) return false;
     cp.n0p = (g.n0 + 127) / 128 * 128;
     cp.n1p = (g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL;
     cp.pad = cp.n0p != g.n0 || cp.n1p != g.n1;
@@ -1345,23 +1349,38 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
     cp.cpr = cus / cp.strips;
     cp.tap_id.assign(B, -1);
     std::vector<int> lw(B, 0);
+    cp.ckF.assign((size_t)T * B, (unsigned char)SRC_PREV);
+    cp.ckB.assign((size_t)T * B, (unsigned char)SRC_PREV);
     for (int64_t b = 0; b < B; ++b) {
         if (prog.kindF[b] != SRC_PRIOR || prog.tapF0[b] >= 0 || prog.tapF1[b] >= 0) return false;
-        // a batch without any stencil (prog.LW0 == 0: change-point studies) may reset at single steps (transitionModels.py:300-312)
-        const bool resets_ok = prog.LW0 == 0;
-        const int k0 = resets_ok ? -1 : (T > 1 ? prog.tapF0[(size_t)B + b] : -1);
+        // the chain's band: the kernel of the first step that filters (every filtering step must use the same one)
+        int k0 = -1;
+        for (int64_t t = 1; t < T && k0 < 0; ++t) k0 = prog.tapF0[(size_t)t * B + b];
+        for (int64_t t = 0; t + 1 < T && k0 < 0 && full; ++t) k0 = prog.tapB0[(size_t)t * B + b];
+        // a step either continues from the previous state through the chain's band, or RESTARTS from the reset distribution (a
+        // change point, transitionModels.py:300-312) -- through the band (the change point comes before the random walk in the
+        // combined model's list) or unfiltered (it comes after: the walk's output is discarded)
+        auto classify = [&](unsigned char kind, int t0, int t1, unsigned char &out) {
+            if (t1 >= 0) return false;
+            if (kind == SRC_PREV && t0 == k0) { out = (unsigned char)SRC_PREV; return true; }
+            if (kind == SRC_RESET && (t0 == k0 || t0 < 0)) {
+                out = (unsigned char)(SRC_RESET | ((k0 >= 0 && t0 < 0) ? 0x80 : 0));          // bit 7: no filter at this step
+                cp.has_reset = true;
+                if (k0 >= 0) cp.mixed = true;
+                return true;
+            }
+            return false;
+        };
         for (int64_t t = 1; t < T; ++t) {
             const size_t k = (size_t)t * B + b;
-            if (resets_ok && prog.kindF[k] == SRC_RESET && prog.tapF0[k] < 0 && prog.tapF1[k] < 0) { cp.has_reset = true; continue; }
-            if (prog.kindF[k] != SRC_PREV || prog.tapF0[k] != k0 || prog.tapF1[k] >= 0) return false;
+            if (!classify(prog.kindF[k], prog.tapF0[k], prog.tapF1[k], cp.ckF[k])) return false;
         }
         if (full) {
             const size_t kl = (size_t)(T - 1) * B + b;
             if (prog.kindB[kl] != SRC_UNIFORM || prog.tapB0[kl] >= 0 || prog.tapB1[kl] >= 0) return false;
             for (int64_t t = 0; t < T - 1; ++t) {
                 const size_t k = (size_t)t * B + b;
-                if (resets_ok && prog.kindB[k] == SRC_RESET && prog.tapB0[k] < 0 && prog.tapB1[k] < 0) { cp.has_reset = true; continue; }
-                if (prog.kindB[k] != SRC_PREV || prog.tapB0[k] != k0 || prog.tapB1[k] >= 0) return false;
+                if (!classify(prog.kindB[k], prog.tapB0[k], prog.tapB1[k], cp.ckB[k])) return false;
             }
         }
         cp.tap_id[b] = k0;
@@ -1565,7 +1584,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     //      two under-filled launches per step (round 1: the 107-chain radius-24 bucket of the C4 study ran as 36 + 71 chains at
     //      4.1 TB/s); hyper-grids are usually monotone in the random-walk width, so contiguous cuts suffice.
     // (cuts on radius-bucket boundaries serve the launch-per-step kernels; grids the chain-resident kernel takes keep whole launches)
-    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && g.n0 >= 48 && g.n0 <= 512 && g.n1 <= 16 * blc::MAX_STRIPS &&
+    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && g.n0 >= CHAIN_MIN_ROWS && g.n0 <= 512 && g.n1 <= 16 * blc::MAX_STRIPS &&
                              ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok;
     std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && !chain_shape && ctx->option("bucket_batches", 1.0) != 0.0);
     if (overlap_acc) {                     // (equal batches, multiples of 32 chains: whole launches of the chain-resident kernel)

@@ -273,8 +273,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         }
         // ---- what the NEXT step needs from HBM: its data record (its stored alpha: see the epilogue) --------------------------------
         const double *const pnext = pchain + (long long)tn * G;
-        const int kind = kind_n;
-        if (!FILTER && P.kinds) kind_n = P.kinds[(long long)tn * P.B + b];
+        const int kind = kind_n & 0x7f;                          // what this step consumes; bit 7: ... without the filter
+        const bool nofilter = FILTER && (kind_n & 0x80) != 0;
+        if (P.kinds) kind_n = P.kinds[(long long)tn * P.B + b];
         if (!FILTER && kind != blk::SRC_PREV) {               // a change point: the chain restarts from the reset distribution
 #pragma unroll
             for (int it = 0; it < NTW; ++it)
@@ -287,8 +288,17 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
 
         // ---- ring over the source state -----------------------------------------------------------------------------------------------
-        const double *S = X + (k & 1) * XSZ;
+        double *S = X + (k & 1) * XSZ;
         double *D = X + ((k + 1) & 1) * XSZ;
+        if (FILTER && kind != blk::SRC_PREV && k > 0) {
+            // a change point inside a filtering chain (random walk + change point in one model): this step's source buffer takes the
+            // reset distribution (rare: once per chain and change point; the loads are consumed inside the branch)
+            for (int e = tid; e < XSZ; e += NT) {
+                const int row = e >> 4, col = tj * WCOL + (e & 15);
+                S[e] = (!PAD || (row < n0t && col < n1t)) ? P.reset[(long long)row * n1t + col] : 0.0;
+            }
+            __syncthreads();
+        }
         // (interior waves: consecutive k-blocks are 512 bytes apart -- one address register, immediate offsets; only waves whose
         //  window reaches beyond the grid edge pay for the reflection)
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > n0t;          // (the reflection is at the grid's true last row)
@@ -330,7 +340,12 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             } else {
                 const unsigned aoff = (unsigned)l * 8u;                 // (the band stays in LDS: hoisted out of the time loop it costs 2 NK VGPRs)
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
-                acc = band_products<NK>(Al, Bv);
+                if (nofilter) {                              // (the change point comes after the walk in the model's list: the source unfiltered)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = S[(i + g + 4 * r) * WCOL + c];
+                } else {
+                    acc = band_products<NK>(Al, Bv);
+                }
             }
 
             if (it == 0) {

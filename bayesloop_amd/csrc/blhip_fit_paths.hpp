@@ -191,6 +191,7 @@ struct ChainRun {
     ChainResPlan cp;
     blc::ChainParams CQ{};
     int *d_order = nullptr;
+    unsigned char *d_ckF = nullptr, *d_ckB = nullptr;      // per (step, chain): what the chain kernels consume (ChainResPlan::ckF / ckB)
     size_t gran_bytes = 0;
     unsigned *d_abort = nullptr;
     std::vector<std::vector<double>> rowsumC;      // forward pass: the actual sums of the stored rows, per chain
@@ -224,13 +225,19 @@ struct ChainRun {
         Gk = (long long)cp.n0p * cp.n1p;
         // (granule slots for 2 x cpr chains: the two-chain fold kernel runs rounds of that size)
         gran_bytes = carve_size((size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2 * 8);
-        ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64));
+        ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64) + 2 * carve_size((size_t)T * B));
         char *rc = ctx->resx.as<char>();
         d_order = carve<int>(rc, (size_t)B);
         int *d_tapid = carve<int>(rc, (size_t)B);
         CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2);
         d_abort = carve<unsigned>(rc, 16);
         CQ.abort_word = d_abort;
+        d_ckF = carve<unsigned char>(rc, (size_t)T * B);
+        d_ckB = carve<unsigned char>(rc, (size_t)T * B);
+        if (cp.has_reset) {
+            HIPCHECK(hipMemcpyAsync(d_ckF, cp.ckF.data(), (size_t)T * B, hipMemcpyHostToDevice, E.st));
+            HIPCHECK(hipMemcpyAsync(d_ckB, cp.ckB.data(), (size_t)T * B, hipMemcpyHostToDevice, E.st));
+        }
         HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
@@ -245,7 +252,8 @@ struct ChainRun {
         post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && ((G & 1) == 0 || cp.pad) && ((uintptr_t)ctx->acc & 15) == 0;
         // (not beside overlapped folds: a FoldJob of the previous batch may still read ctx->accw and read-modify-write ctx->acc on the
         //  second stream while this batch re-carves accw and its fused fold writes ctx->acc on the main stream)
-        fused = post_private && !E.overlap_acc && ctx->option("fuse_accumulate", 1.0) != 0.0;
+        // (a restart inside a FILTERING chain would need sum(alpha T(reset)) for the predicted sums: such batches store and fold separately)
+        fused = post_private && !cp.mixed && !E.overlap_acc && ctx->option("fuse_accumulate", 1.0) != 0.0;
         if (fused && cp.has_reset) {
             // change-point batches: the predicted sums survive a restart only through the two-chain fold kernel's restart rule, and
             // only if the two passes restart at the same places (backward step t restarts <=> forward step t + 1 does: unit-spaced
@@ -302,7 +310,7 @@ struct ChainRun {
             Q.nslots = rstart[r + 1] - rstart[r];
             Q.psum = psum;
             Q.src0 = bwd ? E.DT->uniform : E.DT->prior;
-            Q.kinds = cp.has_reset ? (bwd ? E.M->kindB : E.M->kindF) : nullptr;
+            Q.kinds = cp.has_reset ? (bwd ? d_ckB : d_ckF) : nullptr;
             Q.reset = E.DT->reset;
             Q.post = E.d_post;
             Q.means = bwd ? (E.chain_means ? 1 : 0) : (E.ff.forward_only ? 1 : 0);

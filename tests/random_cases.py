@@ -248,3 +248,29 @@ def random_chain_resident_case(seed, ragged=False):
         if hp == 'inv_s':
             sig = ('cint', 0.05 * smax, smax, k)
     return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's1', sig, 'mean', hp))
+
+
+def random_chain_mixed_case(seed):
+    """Seeded random studies with a random walk on the first parameter AND a change point in one combined model (either list order;
+    transitionModels.py:645-649 applies the sub-models in list order in both directions): restarts inside filtering chains of the
+    chain-resident kernels, on aligned and padded grids, full and evidence-only fits, hyper- and change-point studies."""
+    rng = np.random.default_rng(15000 + seed)
+    if seed % 2:
+        n0 = [128, 256, 384, 512][int(rng.integers(0, 4))]
+        n1 = 16 * int(rng.integers(1, 5))
+    else:
+        n0 = int(rng.integers(64, 400))
+        n1 = int(rng.integers(16, 70))
+    T = int(rng.integers(6, 16))
+    lo, hi = -float(rng.uniform(3, 8)), float(rng.uniform(3, 8))
+    om = ('Gaussian', [('mean', ('cint', lo, hi, n0)), ('std', ('oint', float(rng.uniform(0.0, 0.3)), float(rng.uniform(1.5, 4)), n1))], 'default')
+    lattice = (hi - lo) / (n0 - 1)
+    smax = float(rng.uniform(0.5, 9.0)) * lattice
+    nsig = int(rng.integers(1, 5))
+    sig = float(smax) if nsig == 1 else ('cint', float(rng.uniform(0.0, 0.4)) * smax, smax, nsig)
+    grw = ('GRW', 'sigma', sig, 'mean', None)
+    cp = ('ChangePoint', 'tChange', ('arange', int(rng.integers(1, 3)), T - 1, int(rng.integers(1, 4))), None)
+    order = [cp, grw] if rng.integers(0, 2) else [grw, cp]
+    study = 'ChangepointStudy' if seed % 3 else 'HyperStudy'
+    flags = [dict(), dict(), dict(evidenceOnly=True)][int(rng.integers(0, 3))]
+    return dict(study=study, data=('series_jump', 1900 + seed, T, T // 2, float(rng.uniform(-2, 2))), om=om, tm=('Combined', order), fit=flags)

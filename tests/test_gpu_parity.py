@@ -159,6 +159,21 @@ def test_hip_matches_oracle(case):
     compare.check(got, gold, compare.GPU_TOL)
 
 
+def test_reference_fixtures_on_the_chain_resident_path():
+    """Fixtures generated from the reference (and the extra cases above) that the chain-resident kernels take since they accept padded
+    grids and change points inside filtering chains: random walk + change point in one model in both list orders (40 x 40 grid),
+    a hyper-study over walk width x change point (80 x 80), a change-point study over all time steps (50 x 50)."""
+    for name in ('c5_cp_grw', 'c5_grw_cp', 'c5_small', 'c4_small'):
+        S = cases.build(bl, name)
+        S.fit(**cases.fit_kwargs(name))
+        assert S.lastTiming['fwd_kernel_variant'] == 6 and S.lastTiming['bwd_kernel_variant'] == 6, (name, S.lastTiming)
+        compare.check(result_of(S, name), oa.load_golden(name), compare.GPU_TOL)
+    for name in ('x_mfma_cp', 'x_cp_all'):
+        S = cases.build(bl, EXTRA[name])
+        S.fit(silent=True)
+        assert S.lastTiming['fwd_kernel_variant'] == 6 and S.lastTiming['bwd_kernel_variant'] == 6, (name, S.lastTiming)
+
+
 def test_matrix_pipe_kernels_ran():
     """The cases above really go through blm::mfma_step_kernel (timing variant 3), in both directions."""
     for name in ('x_mfma_wide', 'x_mfma_both_ragged'):
@@ -522,11 +537,12 @@ def test_matrix_pipe_lean_kernels_partial_column_blocks():
             for k in opts:
                 eng.set_option(k, 1)
 
-    B = fit(mfma=0)
+    # (chain_resident = 0: the grid is inside the envelope of the chain-resident kernels since they take padded grids)
+    B = fit(mfma=0, chain_resident=0)
     assert B.lastTiming['bwd_kernel_variant'] == 1
     want = np.array(B.posteriorSequence)
     for _ in range(4):
-        A = fit()
+        A = fit(chain_resident=0)
         assert A.lastTiming['bwd_kernel_variant'] == 3
         assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
         np.testing.assert_allclose(A.posteriorSequence, want, rtol=1e-9, atol=1e-14)
@@ -890,11 +906,11 @@ def test_chain_resident_kernel_lag_and_determinism(lag):
 
 
 def test_chain_resident_kernel_not_taken_outside_its_envelope():
-    """A walk wider than 40 grid steps, a filter on the second parameter, a grid of fewer than 48 rows, a padded grid whose fit
+    """A walk wider than 40 grid steps, a filter on the second parameter, a grid of fewer than 32 rows, a padded grid whose fit
     keeps its filtered distributions, more than 64 strips: the launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
     for c in (_hyper(128, 32, 62, 4, ('cint', 0.1, 2.0, 3)),
               dict(study='HyperStudy', data=('series', 63, 4), om=_g2(128, 32), tm=('GRW', 'sigma', ('cint', 0.1, 0.3, 3), 'std', None)),
-              _hyper(40, 32, 64, 4, ('cint', 0.1, 0.5, 3)),               # fewer than 48 rows
+              _hyper(24, 32, 64, 4, ('cint', 0.1, 0.5, 3)),               # fewer than 32 rows
               _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3), forwardOnly=True),     # padded grid, but the stored sequence is not private to the fit
               _hyper(128, 1040, 66, 3, ('cint', 0.1, 0.5, 2))):          # 65 strips: more than one granule per lane
         S = cases.build(bl, c); S.fit(**cases.fit_kwargs(c))
@@ -950,6 +966,16 @@ RAGGED = {
     'pad_130x16_nan': _hyper(130, 16, 86, 10, ('cint', 0, 0.6, 8), kind='series_nan', extra=[2, 3]),
     'pad_300x64_full': _hyper(300, 64, 89, 7, ('cint', 0, 0.5, 10)),                     # the 384-row geometry (3 product tiles per wave)
     'aligned_384x32_full': _hyper(384, 32, 90, 6, ('cint', 0, 0.4, 6)),
+    # random walk + change point in one model (restart inside a filtering chain): both list orders, hyper- and change-point studies
+    'mixed_cp_grw_128x32': dict(study='ChangepointStudy', data=('series_jump', 91, 14, 7, 2.0), om=_g2(128, 32, -4, 6, 3),
+                                tm=('Combined', [('ChangePoint', 'tChange', ('arange', 2, 12, 3), None), ('GRW', 'sigma', ('cint', 0.05, 0.45, 3), 'mean', None)])),
+    'mixed_grw_cp_256x16': dict(study='ChangepointStudy', data=('series_jump', 92, 12, 5, -1.5), om=_g2(256, 16, -4, 6, 3),
+                                tm=('Combined', [('GRW', 'sigma', 0.2, 'mean', None), ('ChangePoint', 'tChange', ('arange', 1, 11, 2), None)])),
+    'mixed_hyper_80x80': dict(study='HyperStudy', data=('series_jump', 93, 16, 8, 2.0), om=_g2(80, 80, -5, 7, 3),
+                              tm=('Combined', [('GRW', 'sigma', ('cint', 0.1, 0.9, 4), 'mean', None), ('ChangePoint', 'tc', ('arange', 4, 14, 5), None)])),
+    'mixed_cp_grw_40x40_evidence': dict(study='ChangepointStudy', data=('series_jump', 94, 20, 9, 2.0), om=_g2(40, 40, -4, 6, 3),
+                                        tm=('Combined', [('ChangePoint', 'tChange', ('arange', 2, 18, 3), None), ('GRW', 'sigma', ('cint', 0.05, 0.25, 3), 'mean', None)]),
+                                        fit=dict(evidenceOnly=True)),
     'pad_cp_150x40': dict(study='ChangepointStudy', data=('series_jump', 87, 12, 6, 1.5), om=_g2(150, 40), tm=('ChangePoint', 'tc', 'all', None)),
     'pad_cp_60x70_evidence': dict(study='ChangepointStudy', data=('series_jump', 88, 9, 4, -1.0), om=_g2(60, 70), tm=('ChangePoint', 'tc', 'all', None),
                                   fit=dict(evidenceOnly=True)),
@@ -1008,6 +1034,27 @@ def test_seeded_random_chain_resident_studies_on_padded_grids_match_oracle(seed)
         S.fit(**cases.fit_kwargs(c))
         want = oa.run(c)
     assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming          # the chain-resident path really ran
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    if 'logEvidenceList' in want and not np.all(np.isfinite(np.asarray(want['logEvidenceList'], dtype=float))):
+        got['localEvidence'] = gold['localEvidence']
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_CHAIN_FUZZ_SEEDS', 36))))
+def test_seeded_random_walk_plus_change_point_studies_match_oracle(seed):
+    c = random_cases.random_chain_mixed_case(seed)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    # (a study left with ONE combination of hyper-parameter values is an ordinary fit that hands its posteriors out: on a padded grid
+    #  that keeps the launch-per-step kernels)
+    if len(S.hyperGridValues) > 1:
+        assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming          # the chain-resident path really ran
     got = result_of(S, c)
     gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
     for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
