@@ -1180,3 +1180,30 @@ def test_resident_paths_fall_back_when_a_block_gives_up():
     S3 = cases.build(bl, c); S3.fit(silent=True)
     assert S3.lastTiming['fwd_kernel_variant'] == 6
     assert abs(S3.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
+
+
+@pytest.mark.parametrize('case', ['pad_100x37_full', 'mixed_cp_grw_128x32', 'pad_cp_150x40'])
+def test_padded_and_restarting_batches_fall_back_too(case):
+    """The same give-up on a padded grid (its sequence buffer is laid out for the padded geometry) and on a batch with restarts
+    inside filtering chains: the repeat through the launch-per-step kernels gives the oracle's results; the context re-arms after
+    `resident_retry_after` further fits (here: at once), reports the give-up in `resident_fallbacks`."""
+    eng = bl.get_engine()
+    c = RAGGED[case]
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    eng.set_option('resident_force_abort', 1)
+    try:
+        S = cases.build(bl, c); S.fit(**cases.fit_kwargs(c))
+        assert S.lastTiming['fwd_kernel_variant'] != 6 and S.lastTiming['resident_fallbacks'] >= 1 and S.lastTiming['resident_armed'] == 0, S.lastTiming
+        got = result_of(S, c)
+        gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'], posteriorSequence=np.asarray(want['posteriorSequence']),
+                    posteriorMeanValues=np.asarray(want['posteriorMeanValues']), logEvidenceList=np.asarray(want['logEvidenceList']))
+        compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+        eng.set_option('resident_force_abort', 0)
+        eng.set_option('resident_retry_after', 2)
+        for want_variant in (False, True, True):         # parked for one more fit, then tried again
+            S2 = cases.build(bl, c); S2.fit(**cases.fit_kwargs(c))
+            assert (S2.lastTiming['fwd_kernel_variant'] == 6) == want_variant, S2.lastTiming
+    finally:
+        eng.set_option('resident_force_abort', 0)
+        eng.set_option('resident_ok', 1)
