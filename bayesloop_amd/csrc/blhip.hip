@@ -2219,6 +2219,19 @@ int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double 
             HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
             best = std::max(best, 2.0 * (double)n2 * 16.0 * iterations / ((double)ms * 1e-3) / 1e9);
         }
+        {   // a store-only stream (what the no-stencil forward chain kernel does) can run above the copy rate: the calibrated peak is
+            // the best of the streams measured
+            hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, b.as<double>(), n2 * 2, 2.0);
+            HIPCHECK(hipEventRecord(ctx->ev[4], st));
+            for (int k = 0; k < iterations; ++k)
+                hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, (k & 1) ? a.as<double>() : b.as<double>(), n2 * 2, 3.0);
+            HIPCHECK(hipEventRecord(ctx->ev[5], st));
+            HIPCHECK(hipGetLastError());
+            sync_stream(ctx, st);
+            float ms = 0;
+            HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+            best = std::max(best, (double)n2 * 16.0 * iterations / ((double)ms * 1e-3) / 1e9);
+        }
         *gb_per_s = best;
     });
 }

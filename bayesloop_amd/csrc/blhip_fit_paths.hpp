@@ -80,17 +80,18 @@ struct ResidentRun {
         }
         if (!on) return;
         const size_t nt = (size_t)rp.ntiles;
-        const size_t b_cols = carve_size(2 * nt * 2 * blr::R * rp.TR * 8), b_rows = carve_size(2 * nt * 2 * blr::R * rp.TC * 8);
+        // the halo strips hold TAGGED 16-byte elements (two doubles' room per value): the tags are what the consumers poll
+        const size_t n_cols = 2 * nt * 2 * blr::R * rp.TR, n_rows = 2 * nt * 2 * blr::R * rp.TC;
+        const size_t b_cols = carve_size(n_cols * 16), b_rows = carve_size(n_rows * 16);
         const size_t b_w = carve_size(2 * (blr::R + 1) * 8) + carve_size((size_t)T * 8);
-        flag_bytes = carve_size(nt * 4) * 2 + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
-        ctx->resx.ensure(b_cols + b_rows + b_w + flag_bytes);
+        flag_bytes = b_cols + b_rows + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
+        ctx->resx.ensure(b_w + flag_bytes);
         char *rc = ctx->resx.as<char>();
-        RQ.cols = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TR);
-        RQ.rows = carve<double>(rc, 2 * nt * 2 * blr::R * rp.TC);
         double *d_w = carve<double>(rc, 2 * (blr::R + 1));
         d_sfwd = carve<double>(rc, (size_t)T);
-        RQ.flagC = carve<unsigned>(rc, nt);               // (the polled words are contiguous: one memset per launch)
-        RQ.flagR = carve<unsigned>(rc, nt);
+        RQ.cols = carve<double>(rc, 2 * n_cols);          // (everything polled is contiguous from here on: one memset per launch)
+        RQ.rows = carve<double>(rc, 2 * n_rows);
+        RQ.cols_bytes = (unsigned)(n_cols * 16); RQ.rows_bytes = (unsigned)(n_rows * 16);
         RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
         d_abort = carve<unsigned>(rc, 16);
         RQ.abort_word = d_abort;
@@ -113,7 +114,7 @@ struct ResidentRun {
         hipStream_t st = E.st;
         const int64_t T = E.T;
         blr::ResParams Q = RQ;
-        HIPCHECK(hipMemsetAsync(RQ.flagC, 0, flag_bytes, st));         // flags, granules, abort word: zero before EVERY launch
+        HIPCHECK(hipMemsetAsync(RQ.cols, 0, flag_bytes, st));          // strip tags, granules, abort word: zero before EVERY launch
         HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * NRED * nblk * 8, st));
         Q.psum = psum;
         // rows of the kept sequence are normalised inside the kernel, `lag` steps behind (what the host then still scales: the
@@ -131,8 +132,8 @@ struct ResidentRun {
             Q.means = E.ff.forward_only ? 1 : 0; Q.normalise = E.ff.forward_only ? 1 : 0;
         }
 #ifdef BLR_PROF
-        ctx->small.ensure(2 * 16 * 16 * 8);
-        HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+        ctx->small.ensure(4 * 16 * 16 * 8);
+        HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 4 * 16 * 16 * 8, st));
         Q.prof = ctx->small.as<unsigned long long>();
 #endif
         launch_resident(st, rp, Q, bwd);
@@ -143,16 +144,17 @@ struct ResidentRun {
         }
 #ifdef BLR_PROF
         {   // development build: where a step of one interior tile spends its time (shader-clock cycles between stamps)
-            unsigned long long hh[2 * 16 * 16];
+            unsigned long long hh[4 * 16 * 16];
             HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
             sync_stream(ctx, st);
-            static const char *names[12] = {"start", "h_pre+bar", "h_walk", "bar", "pubR+v_pre+gather", "arriveR", "bar", "v_walk", "sums", "pubC(+arriveC)", "-", "-"};
-            for (int wv = 0; wv < 2; ++wv) {
+            static const char *names[15] = {"start", "h_pre", "gath_issue", "B1", "h_walk", "book", "gather", "B2", "pubR", "v_pre", "B3", "v_walk", "sums", "B4", "pubC"};
+            static const int tids[4] = {0, 128, 256, -64};
+            for (int wv = 0; wv < 4; ++wv) {
                 const unsigned long long *h = hh + wv * 256;
-                double acc[12] = {0}; int n = 0;
-                for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 9] || !h[q * 16]) continue; ++n; for (int i = 1; i < 10; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
-                std::fprintf(stderr, "[blr prof %s thread %d] %d steps, cycles per phase:", bwd ? "bwd" : "fwd", wv ? 128 : 0, n);
-                double tot = 0; for (int i = 1; i < 10; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                double acc[15] = {0}; int n = 0;
+                for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 14] || !h[q * 16]) continue; ++n; for (int i = 1; i < 15; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                std::fprintf(stderr, "[blr prof %s thread %d] %d steps:", bwd ? "bwd" : "fwd", tids[wv], n);
+                double tot = 0; for (int i = 1; i < 15; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
                 std::fprintf(stderr, " | total %.0f\n", tot);
             }
         }

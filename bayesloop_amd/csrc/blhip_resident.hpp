@@ -13,10 +13,14 @@
 //     neighbouring segment of the same tile are read into registers before anyone writes (one barrier);
 //   * tiles exchange only halos, through HBM-side strips: the raw edge COLUMNS of the new state (consumed by the horizontal
 //     neighbours' axis-1 pass of the next step) and the axis-1-filtered edge ROWS (consumed by the vertical neighbours'
-//     axis-0 pass of the same step).  Point-to-point, no grid-wide barrier: write-through (sc1) payload stores, every
-//     storing wave drains, one lane publishes a monotonic epoch flag; the consumer polls that one word, then reads the strip
-//     with sc1 loads (cdna_hip_programming.md Guideline 16, form R1).  Edge segments walk TOWARDS the tile edge, so the
-//     neighbour's strip is needed only for the last chunk of a pass and the hand-off latency hides under the pass;
+//     axis-0 pass of the same step).  Point-to-point, no grid-wide barrier, no flags, no drains: THE DATA IS THE FLAG
+//     (cdna_hip_programming.md Guideline 16, form R2).  A strip element is 16 bytes {low word, tag, high word, tag} with
+//     tag = producing step + 1, written by ONE write-through (sc1) 16-byte store; each 8-byte half validates itself.  The
+//     consumer requests its 8 elements with sc1 loads when its pass BEGINS, uses them chunks later and re-polls only the
+//     elements whose tags are not there yet (bounded).  Edge segments walk TOWARDS the tile edge, so the neighbour's strip
+//     is needed only for the last chunk of a pass; the hand-off costs one memory round trip that flies under the pass
+//     (the flag form of round 2 cost the producer a drain of its stores' acknowledgements and the consumer two dependent
+//     round trips: flag, then payload);
 //   * the lazy normaliser needs a GLOBAL sum.  A step is linear in its input, so the scale may lag: step k divides by the sum
 //     of step k - LAG (LAG = 2 by default), which every tile published LAG steps earlier as two tagged 8-byte granules; the
 //     host undoes the lag when it forms the per-step normalisers (blhip.hip: resident_unlag).  No tile ever waits for a sum.
@@ -70,9 +74,9 @@ struct ResParams {
     const double *m0, *m1, *colA, *colB, *rec;
     double step0;
     double *psum;                // [T][NRED][ntiles]
-    double *cols;                // [2][ntiles][2][R][TR]   raw edge columns of the new state (parity = step & 1)
-    double *rows;                // [2][ntiles][2][R][TC]   axis-1-filtered edge rows
-    unsigned *flagC, *flagR;     // [ntiles] epochs
+    double *cols;                // [2][ntiles][2][R][TR] tagged 16-byte elements: raw edge columns of the new state (parity = step & 1)
+    double *rows;                // [2][ntiles][2][R][TC] tagged 16-byte elements: axis-1-filtered edge rows
+    unsigned cols_bytes, rows_bytes;
     unsigned long long *gran;    // [NSLOT][ntiles][4] {tag << 32 | half of a double}: the scale sum, the row sum (backward)
     unsigned *abort_word;
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
@@ -96,6 +100,16 @@ BLR_INL double ldu(const double *p, long long i) { return p[i]; }
 BLR_INL int uni(int x) { return x; }
 BLR_INL double ld_stream(const double *p) { return *p; }
 BLR_INL void st_stream(double *p, double v) { *p = v; }
+struct Tq { unsigned lo, t0, hi, t1; };          // a tagged strip element
+typedef char *Rsrc;
+BLR_INL Rsrc strip_rsrc(double *p, unsigned) { return reinterpret_cast<char *>(p); }
+BLR_INL void st_tq(Rsrc r, unsigned off, double v, unsigned tag) {
+    unsigned long long b; std::memcpy(&b, &v, 8);
+    const Tq q{(unsigned)b, tag, (unsigned)(b >> 32), tag};
+    std::memcpy(r + off, &q, 16);
+}
+BLR_INL Tq ld_tq(Rsrc r, unsigned off) { Tq q; std::memcpy(&q, r + off, 16); return q; }
+BLR_INL double tq_value(const Tq &q) { const unsigned long long b = (unsigned long long)q.lo | ((unsigned long long)q.hi << 32); double v; std::memcpy(&v, &b, 8); return v; }
 #else
 typedef unsigned long long __attribute__((address_space(1))) gu64;
 typedef unsigned __attribute__((address_space(1))) gu32;
@@ -124,26 +138,58 @@ BLR_INL int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }       // a 
 // the stored sequence is written / read once per pass (C3: 16 GiB): non-temporal hints keep it from sweeping the caches
 BLR_INL double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
 BLR_INL void st_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
+// tagged strip elements through a buffer descriptor: ONE 16-byte write-through store / ONE 16-byte sc1 load each (aux 16 = sc1)
+struct Tq { unsigned lo, t0, hi, t1; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+BLR_INL Rsrc strip_rsrc(double *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
+BLR_INL void st_tq(Rsrc r, unsigned off, double v, unsigned tag) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const u32x4 q = {(unsigned)b, tag, (unsigned)(b >> 32), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)off, 0, 16);
+}
+BLR_INL Tq ld_tq(Rsrc r, unsigned off) {
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16);
+    return Tq{q.x, q.y, q.z, q.w};
+}
+BLR_INL double tq_value(const Tq &q) { return __longlong_as_double((long long)((unsigned long long)q.lo | ((unsigned long long)q.hi << 32))); }
 #endif
+BLR_INL bool tq_ok(const Tq &q, unsigned tag) { return q.t0 == tag && q.t1 == tag; }
 
-// bounded wait for an epoch flag; false = timed out / another block gave up (the caller marks the block dead)
-BLR_INL bool wait_ge(const unsigned *flag, unsigned epoch, const ResParams &P) {
+// a neighbour's strip: R tagged elements at byte offsets off0 + q * dstep (q = 0 .. R-1 in the consumer's walking order)
+BLR_INL void strip_issue(Rsrc rs, int off0, int dstep, Tq (&fq)[R]) {
+#pragma unroll
+    for (int q = 0; q < R; ++q) fq[q] = ld_tq(rs, (unsigned)(off0 + q * dstep));
+}
+// -> f; elements whose tags are not `tag` yet are requested again (bounded); false = timed out / another block gave up
+BLR_INL bool strip_finish(const ResParams &P, Rsrc rs, int off0, int dstep, unsigned tag, Tq (&fq)[R], double (&f)[R]) {
+    bool alive = true;
+    auto all_there = [&]() {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < R; ++q) ok = ok && tq_ok(fq[q], tag);
+        return ok;
+    };
 #ifdef BLR_EMULATE
-    assert(*flag >= epoch && "hand-off protocol: consumed before published");
-    (void)P;
-    return true;
+    assert(all_there() && "hand-off protocol: consumed before published");
+    (void)P; (void)rs; (void)off0; (void)dstep;
 #else
-    if (ld_flag(flag) >= epoch) return true;
-    const unsigned long long t0 = now_ticks();
-    for (unsigned spins = 1;; ++spins) {
-        nap();
-        if (ld_flag(flag) >= epoch) return true;
-        if ((spins & 255u) == 0u) {
-            if (ld_flag(P.abort_word) != 0u) return false;
-            if (now_ticks() - t0 > P.timeout_ticks) { st_flag(P.abort_word, 1u); return false; }
+    if (!all_there()) {
+        const unsigned long long t0 = now_ticks();
+        for (unsigned spins = 1;; ++spins) {
+            nap();
+            strip_issue(rs, off0, dstep, fq);
+            if (all_there()) break;
+            if ((spins & 255u) == 0u) {
+                if (ld_flag(P.abort_word) != 0u) { alive = false; break; }
+                if (now_ticks() - t0 > P.timeout_ticks) { st_flag(P.abort_word, 1u); alive = false; break; }
+            }
         }
     }
 #endif
+#pragma unroll
+    for (int q = 0; q < R; ++q) f[q] = tq_value(fq[q]);
+    return alive;
 }
 
 // block id -> tile: spatially adjacent tiles on the same XCD where the dispatcher deals blocks round-robin (b % 8); a pure
@@ -154,21 +200,22 @@ BLR_INL int tile_of_block(int b, int ntiles) {
 
 // One thread's in-place pass over its SEG-element line segment, C outputs per chunk.  Positions p = 0 .. SEG-1 in WALKING order
 // live at x0[p * STRIDE] (compile-time stride, negative = towards lower addresses: every access is base + immediate offset);
-// nearv[k] = x(k - R); the far halo x(SEG + k) = f[k] was read before the barrier, or far_fetch(f) loads it from the neighbour
-// tile's strip at the top of the first chunk whose NEXT window reaches past the segment.  pre(p0) may start loads
+// nearv[k] = x(k - R); the far halo x(SEG + k) = f[k] was read before the barrier, or it is a neighbour tile's strip: far_issue()
+// requests it when the pass begins, far_fetch(f) completes it at the top of the first chunk whose NEXT window reaches past the segment.  pre(p0) may start loads
 // the epilogue of the chunk needs; emit(p0, v) receives the C filtered values of positions p0 .. p0+C-1 and may overwrite
 // x(p0 .. p0+C-1): the register window (2 R + C values) already holds what later chunks need.
 //   A one-chunk segment (SEG == C) needs its far halo for every output.  When that halo is a neighbour's strip (`far_is_strip`),
 // the chunk is first evaluated with zeros in the far slots -- everything the thread can do before the hand-off -- and the
 // (R + 1) R / 2 products with the far values are added once they have arrived.
-template <int SEG, int STRIDE, int C, class FarFn, class Pre, class Emit>
-BLR_INL void walk(const double *x0, const double (&nearv)[R], double (&f)[R], bool far_is_strip, const double (&wk)[R + 1], FarFn &&far_fetch,
-                  Pre &&pre, Emit &&emit) {
+template <int SEG, int STRIDE, int C, class FarIssue, class FarFn, class Pre, class Emit>
+BLR_INL void walk(const double *x0, const double (&nearv)[R], double (&f)[R], bool far_is_strip, const double (&wk)[R + 1], FarIssue &&far_issue,
+                  FarFn &&far_fetch, Pre &&pre, Emit &&emit) {
     static_assert(SEG % C == 0 && SEG >= C && SEG >= R, "segment = whole chunks, at least one radius long");
     constexpr int W = 2 * R + C;
     constexpr bool ONE = SEG == C;                   // single chunk: deferred far halo
     double w[W];
     bool have_far = false;                           // f: the far halo; far_fetch(f) completes it when it is a neighbour tile's strip
+    far_issue();                                     // (the strip's elements are requested now and looked at chunks later)
 #pragma unroll
     for (int k = 0; k < R; ++k) w[k] = nearv[k];
     if (R + C > SEG && !ONE) { far_fetch(f); have_far = true; }
@@ -220,13 +267,14 @@ BLR_INL void walk(const double *x0, const double (&nearv)[R], double (&f)[R], bo
 // the thread's WHOLE window -- near halo, its own SEG inputs, far halo -- is read before the barrier; the pass itself is
 // arithmetic and stores only (no loads of the next chunk's inputs, no window shifts).  A far halo that is a neighbour tile's
 // strip is fetched at the first chunk that reaches beyond the segment.
-template <int SEG, int C, class FarFn, class Pre, class Emit>
+template <int SEG, int C, class FarIssue, class FarFn, class Pre, class Emit>
 BLR_INL void walk_full(const double (&nearv)[R], const double (&own)[SEG], double (&f)[R], bool far_is_strip, const double (&wk)[R + 1],
-                       FarFn &&far_fetch, Pre &&pre, Emit &&emit) {
+                       FarIssue &&far_issue, FarFn &&far_fetch, Pre &&pre, Emit &&emit) {
     static_assert(SEG % C == 0 && SEG >= R, "segment = whole chunks, at least one radius long");
     constexpr int W = 2 * R + SEG;
     constexpr int FIRST_FAR = ((SEG - R) / C) * C;   // first chunk with an output p, p + R >= SEG
     double w[W];
+    far_issue();
 #pragma unroll
     for (int k = 0; k < R; ++k) w[k] = nearv[k];
 #pragma unroll
@@ -288,15 +336,26 @@ struct Res {
     static constexpr int ANCHOR = SEG < 32 ? SEG : 32;
     static_assert(TR % SEG == 0 && TC % SEG == 0 && TR >= 2 * R && TC >= 2 * R && ANCHOR % CHK == 0 && SEG % ANCHOR == 0, "tile shape");
     static constexpr int NW = NT / 64;
+    static constexpr bool ONE = SEG == CHK;          // one-chunk segments
     static_assert(NT % 64 == 0, "whole waves");
     static constexpr bool FULLW = NT > 512;          // many-threads shapes: whole window in registers before the barrier (walk_full)
-    static constexpr int GPL = (512 / NW + 63) / 64;     // tiles per lane when NW waves share the <= 512 tiles' partial sums
+    // a neighbour's strip is requested when the pass begins, 2+ chunks before it is used (32 registers per thread in flight; the
+    // multi-chunk backward shape has none to spare and requests it where it needs it)
+    static constexpr bool EARLY = ONE || !BWD;
+    // The lagged global sum is gathered by HALF of the block's waves -- the half that reaches the barrier after the axis-1 pass early
+    // (multi-chunk shapes: the edge segments, dealt to the first waves, have issue priority over their SIMD partners; one-chunk
+    // shapes: the edge waves wait for their neighbours there, the others are early) -- in that slack, not by everybody after it.
+    static constexpr int GW = NW >= 2 ? NW / 2 : 1;
+    static constexpr bool GATHER_FIRST = !ONE;
+    static constexpr int MAX_TILES = 256;                // (one tile per CU)
+    static constexpr int GPL = (MAX_TILES / GW + 63) / 64;   // tiles per lane when GW waves share the tiles' partial sums
     static constexpr int NG = 1;                         // sums every tile publishes per step: the scale sum (forward: sum a = the row sum
                                                          // of the stored state; backward: sum c)
     static constexpr int LDS_TILE = TR * P;          // doubles
     static constexpr int LDS_M0 = LDS_TILE;          // TR row coordinates of the tile
     static constexpr int LDS_COL = LDS_M0 + TR;      // the tile's column constants: [TC] grid value, [TC] cA, [TC] cB
-    static constexpr int LDS_MISC = LDS_COL + 3 * TC;    // [1] dead flag  [2] arrival counter  [8 .. 8+NW) the waves' shares of the lagged sum
+    static constexpr int LDS_MISC = LDS_COL + 3 * TC;    // [1] dead flag  [2] arrival counter of the gathering waves  [7] 1 / lagged sum  [8 .. 8+GW) their shares
+    static_assert(NG == 1, "one lagged sum");
     static constexpr int LDS_RED = LDS_MISC + 8 + 2 * NW;    // reduction scratch of the step's sums  (misc[8 + g NW + w]: wave w's share of sum g)
     static constexpr int LDS_DOUBLES = LDS_RED + 5 * (NW + 1) + 8;
 
@@ -310,6 +369,7 @@ struct Res {
 
     struct Thread {
         int tid, tile, ti, tj, i0, j0, tr, tc;       // (tile .. tc: block-uniform)
+        int whalf;                                   // 1: the second half of the block's waves (wave w and w + NW / 2 share a SIMD)
         double *lds;
         // registers that live across a barrier
         double nearv[R], farv[R];
@@ -328,6 +388,7 @@ struct Res {
 
         BLR_INL void init(const ResParams &Q, int block, int tid_, double *lds_) {
             tid = tid_; lds = lds_; dead = false;
+            whalf = uni((tid_ >> 6) >= NW / 2 ? 1 : 0);
             mq_c = 1.0; iq_c = 1.0; dn_prev = -1.0; nq_c = 0;
             tr = uni(Q.tr); tc = uni(Q.tc);
             tile = uni(tile_of_block(block, Q.ntiles));
@@ -343,15 +404,15 @@ struct Res {
         // (waves w and w + 4 of a 512-thread block), which then fills their stall.
         BLR_INL static int seg_of(int s, int nseg) { return s == 0 ? 0 : (s == 1 ? nseg - 1 : s - 1); }
         BLR_INL Geo hgeo() const {                   // axis-1 pass: a row and a segment of its columns
-            const int t = launder(tid);
-            Geo g{t % TR, seg_of(t / TR, NSH), 0, tile, 0};
+            const unsigned t = (unsigned)launder(tid);
+            Geo g{(int)(t % TR), seg_of((int)(t / TR), NSH), 0, tile, 0};
             if (g.seg == 0) { if (tj > 0) { g.far = 2; g.nb = tile - 1; g.side = 1; } else g.far = 1; }
             else if (g.seg == NSH - 1) { if (tj < tc - 1) { g.far = 2; g.nb = tile + 1; g.side = 0; } else g.far = 1; }
             return g;
         }
         BLR_INL Geo vgeo() const {                   // axis-0 pass: a column and a segment of its rows
-            const int t = launder(tid);
-            Geo g{t % TC, seg_of(t / TC, NSV), 0, tile, 0};
+            const unsigned t = (unsigned)launder(tid);
+            Geo g{(int)(t % TC), seg_of((int)(t / TC), NSV), 0, tile, 0};
             if (g.seg == 0) { if (ti > 0) { g.far = 2; g.nb = tile - tc; g.side = 1; } else g.far = 1; }
             else if (g.seg == NSV - 1) { if (ti < tr - 1) { g.far = 2; g.nb = tile + tc; g.side = 0; } else g.far = 1; }
             return g;
@@ -362,7 +423,7 @@ struct Res {
         // segment s walks towards lower indices when it is the first one (its far side is then the tile's low edge)
         BLR_INL static constexpr int first_pos(int s, int dir) { return dir < 0 ? SEG - 1 : s * SEG; }
 
-        // ---- start of a step: this step's data record ---------------------------------------------------------------------------
+        // ---- the data record of step k (requested a step ahead, see v_walk_d) ---------------------------------------------------
         BLR_INL void begin_step(const ResParams &Q, int k) {
             const int t = time_of(Q, k);
 #pragma unroll
@@ -385,8 +446,13 @@ struct Res {
         }
         // ---- the lagged global sums: this wave's share of the tiles' partial sums of step ks (tiles wv * tpw + lane + 64 j) --------
         // The loads are issued when the step begins and consumed before the axis-0 pass: their latency hides under the axis-1 pass.
+        // index of this wave among the gathering waves, or -1
+        BLR_INL int gather_wave() const {
+            const int wv = uni(tid >> 6);
+            return GATHER_FIRST ? (wv < GW ? wv : -1) : (wv >= NW - GW ? wv - (NW - GW) : -1);
+        }
         BLR_INL void gather_issue(const ResParams &Q, int ks) {
-            const int wv = tid >> 6, lane = tid & 63, tpw = (Q.ntiles + NW - 1) / NW;
+            const int wv = gather_wave(), lane = tid & 63, tpw = (Q.ntiles + GW - 1) / GW;
 #pragma unroll
             for (int j = 0; j < GPL; ++j) {
                 const int loc = lane + 64 * j, idx = wv * tpw + loc;
@@ -401,7 +467,7 @@ struct Res {
         }
         // -> this lane's part of the sums (fixed order); a granule that has not arrived yet is polled (bounded)
         BLR_INL void gather_finish(const ResParams &Q, int ks, double (&acc)[NG]) {
-            const int wv = tid >> 6, lane = tid & 63, tpw = (Q.ntiles + NW - 1) / NW;
+            const int wv = gather_wave(), lane = tid & 63, tpw = (Q.ntiles + GW - 1) / GW;
             const unsigned long long want = (unsigned long long)(unsigned)(ks + 1);
 #pragma unroll
             for (int g2 = 0; g2 < NG; ++g2) acc[g2] = 0.0;
@@ -449,12 +515,15 @@ struct Res {
         }
         // 1 / (sum g of step k - lag) from the waves' shares (LDS, after the barrier), or 1 while k < lag.  g = 0: the scale of the
         // step; g = NG - 1: the normaliser of the row written `lag` steps ago (forward: the same number)
-        BLR_INL double lagged_inverse(const ResParams &Q, int k, int g2) const {
-            if (k < Q.lag) return 1.0;
+        BLR_INL double lagged_inverse(const ResParams &Q, int k, int) const {
+            return k < Q.lag ? 1.0 : lds[LDS_MISC + 7];      // (left there by the last gathering wave, before the barrier after the axis-1 pass)
+        }
+        // the gathering waves' shares (misc[8 + w], fixed order) -> the inverse everybody reads
+        BLR_INL void combine_shares() {
             double ssum = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) ssum += lds[LDS_MISC + 8 + g2 * NW + w];
-            return 1.0 / ssum;
+            for (int w = 0; w < GW; ++w) ssum += lds[LDS_MISC + 8 + w];
+            lds[LDS_MISC + 7] = 1.0 / ssum;
         }
 
         // ---- axis-1 pass ---------------------------------------------------------------------------------------------------------
@@ -480,47 +549,68 @@ struct Res {
         template <int DIR>
         BLR_INL void h_walk_d(const ResParams &Q, int k, const Geo &hg) {
             double *x0 = lds + hg.line * P + first_pos(hg.seg, DIR);
+            // the neighbour's raw edge columns of step k - 1 (tag k): element [(k-1) & 1][nb][side][cc][row], cc towards the far side
+            const Rsrc rs = strip_rsrc(Q.cols, Q.cols_bytes);
+            const int e0 = (((((k - 1) & 1) * Q.ntiles + hg.nb) * 2 + hg.side) * R + (hg.side == 1 ? R - 1 : 0)) * TR + hg.line;
+            const int dstep = (hg.side == 1 ? -TR : TR) * 16;
+            Tq fq[R];
+            auto far_issue = [&]() { if (EARLY && hg.far == 2) strip_issue(rs, e0 * 16, dstep, fq); };
             auto far_fetch = [&](double (&f)[R]) {
                 if (hg.far == 2) {
-                    if (!wait_ge(Q.flagC + hg.nb, (unsigned)k, Q)) dead = true;
-                    const double *s = Q.cols + (((long long)((k - 1) & 1) * Q.ntiles + hg.nb) * 2 + hg.side) * R * TR + hg.line;
-#pragma unroll
-                    for (int q = 0; q < R; ++q) f[q] = ld_sc1(s + (long long)(hg.side == 1 ? R - 1 - q : q) * TR);
+                    if (!EARLY) strip_issue(rs, e0 * 16, dstep, fq);
+                    if (!strip_finish(Q, rs, e0 * 16, dstep, (unsigned)k, fq, f)) dead = true;
                 }
             };
             auto emit8 = [&](int p0, const double (&v)[CHK]) {
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) x0[DIR * (p0 + j)] = v[j];
             };
+            // (weights as scalars.  In vector registers -- read from LDS per pass, to free ~18 SGPRs of the ~100 spilled ones -- the
+            //  128 x 128 kernels ran out of VGPRs instead: 4 / 54 / 271 spilled; measured by compiling, not kept)
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w1, q);
-            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, hg.far == 2, wk, far_fetch, [](int) {}, emit8);
-            else walk<SEG, DIR, CHK>(x0, nearv, farv, hg.far == 2, wk, far_fetch, [](int) {}, emit8);
+            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, hg.far == 2, wk, far_issue, far_fetch, [](int) {}, emit8);
+            else walk<SEG, DIR, CHK>(x0, nearv, farv, hg.far == 2, wk, far_issue, far_fetch, [](int) {}, emit8);
         }
-        BLR_INL void h_walk(const ResParams &Q, int k) { const Geo hg = hgeo(); if (hg.seg == 0) h_walk_d<-1>(Q, k, hg); else h_walk_d<1>(Q, k, hg); }
+        BLR_INL void h_walk(const ResParams &Q, int k) {
+            const Geo hg = hgeo();
+            if (hg.seg == 0) h_walk_d<-1>(Q, k, hg); else h_walk_d<1>(Q, k, hg);
+        }
 
         // after the axis-1 pass (barrier): the tile's filtered edge rows -> strips of step k  [side][rr][col]; every thread takes
         // part, a wave stores 512 contiguous bytes per instruction (scattered 8-byte write-through stores out of the walks'
         // registers were measured: 2 - 3 x slower walks)
-        BLR_INL void publish_rows(const ResParams &Q, int k) {
-            double *base = Q.rows + ((long long)(k & 1) * Q.ntiles + tile) * 2 * R * TC;
-            const int t = launder(tid);
-            for (int idx = t; idx < 2 * R * TC; idx += NT) {
-                const int side = idx / (R * TC), rem = idx - side * (R * TC), rr = rem / TC, col = rem - rr * TC;
-                if (side == 0 ? ti > 0 : ti < tr - 1)          // (my top rows are the up neighbour's lower halo)
-                    st_sc1(base + idx, lds[(side ? TR - R + rr : rr) * P + col]);
+        // Straight-line code: the element <-> thread map is compile-time per iteration (NT divides R * edge length or the other way
+        // round), unsigned arithmetic, the only branch is block-uniform (does that neighbour exist).
+        template <int EDGE, class Src>
+        BLR_INL void publish_strip(Rsrc rs, int base, unsigned tag, bool have0, bool have1, Src &&src) {
+            constexpr int PER = 2 * R * EDGE / NT, HALF = PER / 2;
+            static_assert(PER * NT == 2 * R * EDGE && HALF * 2 == PER && HALF >= 1, "whole iterations per side");
+            const unsigned t = (unsigned)launder(tid);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                if (side == 0 ? have0 : have1) {
+                    double v[HALF];
+#pragma unroll
+                    for (int it = 0; it < HALF; ++it) {
+                        const unsigned rem = (unsigned)(it * NT) + t;
+                        v[it] = src(side, rem / EDGE, rem % EDGE);
+                    }
+#pragma unroll
+                    for (int it = 0; it < HALF; ++it)
+                        st_tq(rs, ((unsigned)(base + side * R * EDGE + it * NT) + t) * 16u, v[it], tag);
+                }
             }
+        }
+        BLR_INL void publish_rows(const ResParams &Q, int k) {          // [side][rr][col]
+            publish_strip<TC>(strip_rsrc(Q.rows, Q.rows_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TC, (unsigned)(k + 1), ti > 0, ti < tr - 1,
+                              [&](int side, unsigned rr, unsigned col) { return lds[((side ? TR - R : 0) + rr) * P + col]; });
         }
         // after the axis-0 pass + epilogue (barrier): the new state's edge columns -> strips of step k  [side][cc][row]
         BLR_INL void publish_cols(const ResParams &Q, int k) {
-            double *base = Q.cols + ((long long)(k & 1) * Q.ntiles + tile) * 2 * R * TR;
-            const int t = launder(tid);
-            for (int idx = t; idx < 2 * R * TR; idx += NT) {
-                const int side = idx / (R * TR), rem = idx - side * (R * TR), cc = rem / TR, row = rem - cc * TR;
-                if (side == 0 ? tj > 0 : tj < tc - 1)
-                    st_sc1(base + idx, lds[row * P + (side ? TC - R + cc : cc)]);
-            }
+            publish_strip<TR>(strip_rsrc(Q.cols, Q.cols_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TR, (unsigned)(k + 1), tj > 0, tj < tc - 1,
+                              [&](int side, unsigned cc, unsigned row) { return lds[row * P + (side ? TC - R : 0) + cc]; });
         }
 
         // ---- axis-0 pass + epilogue ----------------------------------------------------------------------------------------------
@@ -643,26 +733,42 @@ struct Res {
             double *ptn0 = lagged_row_ptr(Q, k, pt0);
             predicted_sum(Q, k, scale);
             const double invn = BWD ? 1.0 / npred : (ptn0 ? lagged_inverse(Q, k, 0) : 1.0);
+            // the neighbour's axis-1-filtered edge rows of THIS step (tag k + 1): element [k & 1][nb][side][rr][col]
+            const Rsrc rs = strip_rsrc(Q.rows, Q.rows_bytes);
+            const int e0 = ((((k & 1) * Q.ntiles + vg.nb) * 2 + vg.side) * R + (vg.side == 1 ? R - 1 : 0)) * TC + vg.line;
+            const int dstep = (vg.side == 1 ? -TC : TC) * 16;
+            Tq fq[R];
+            auto far_issue = [&]() { if (EARLY && vg.far == 2) strip_issue(rs, e0 * 16, dstep, fq); };
             auto far_fetch = [&](double (&f)[R]) {
                 if (vg.far == 2) {
-                    if (!wait_ge(Q.flagR + vg.nb, (unsigned)k, Q)) dead = true;
-                    const double *s = Q.rows + (((long long)(k & 1) * Q.ntiles + vg.nb) * 2 + vg.side) * R * TC + vg.line;
-#pragma unroll
-                    for (int q = 0; q < R; ++q) f[q] = ld_sc1(s + (long long)(vg.side == 1 ? R - 1 - q : q) * TC);
+                    if (!EARLY) strip_issue(rs, e0 * 16, dstep, fq);
+                    if (!strip_finish(Q, rs, e0 * 16, dstep, (unsigned)(k + 1), fq, f)) dead = true;
                 }
             };
             // (requested right before the chunk's arithmetic.  Requesting the one-chunk shapes' 16 HBM-missing loads per thread earlier --
             //  when the step begins, or after the axis-1 pass -- was measured: their issue alone holds a wave for ~2.8 k cycles wherever
             //  it is placed, and the step got slower, 24.4 k / 26.8 k vs 22.6 k cycles backward)
-            auto pre8 = [&](int p0) { load_alpha8<DIR>(pt0, ptn0, Q.n1, p0); };
+            // The NEXT step's data record (scalar loads; first needed by that step's first anchor) is requested under the LAST chunk's
+            // arithmetic of this pass -- no LDS read waits follow it there, so its latency is never waited for.  (Requested when a step
+            // begins, every wave sat out a scalar-cache miss before its first LDS read: ~0.5 k cycles per step.)
+            constexpr bool REC_IN_PASS = !ONE && !FULLW;
+            static_assert(!REC_IN_PASS || (SEG - CHK) % ANCHOR != 0, "the last chunk has no anchor (its epilogue does not read the record)");
+            auto pre8 = [&](int p0) {
+                load_alpha8<DIR>(pt0, ptn0, Q.n1, p0);
+                if (REC_IN_PASS && p0 == SEG - CHK && k + 1 < Q.T) begin_step(Q, k + 1);
+            };
             auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc); };
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
-            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, vg.far == 2, wk, far_fetch, pre8, emit8);
-            else walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_fetch, pre8, emit8);
+            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
+            else walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
+            if (!REC_IN_PASS && k + 1 < Q.T) begin_step(Q, k + 1);
         }
-        BLR_INL void v_walk(const ResParams &Q, int k) { const Geo vg = vgeo(); if (vg.seg == 0) v_walk_d<-1>(Q, k, vg); else v_walk_d<1>(Q, k, vg); }
+        BLR_INL void v_walk(const ResParams &Q, int k) {
+            const Geo vg = vgeo();
+            if (vg.seg == 0) v_walk_d<-1>(Q, k, vg); else v_walk_d<1>(Q, k, vg);
+        }
 
         // the first executed step has no transition: its input is src0 (prior / uniform), scale 1
         template <int DIR>
@@ -686,6 +792,7 @@ struct Res {
                 load_alpha8<DIR>(pt0, nullptr, Q.n1, p0);
                 epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, BWD ? 1.0 / Q.n_first : 1.0, p0, v, 1.0, rc, cc);
             }
+            if (Q.T > 1) begin_step(Q, 1);
         }
         BLR_INL void first_step(const ResParams &Q) { const Geo vg = vgeo(); if (vg.seg == 0) first_step_d<-1>(Q, vg); else first_step_d<1>(Q, vg); }
     };
@@ -712,16 +819,13 @@ struct Res {
 
 namespace blr {
 
-// every wave has drained its strip stores -> the LAST wave to arrive publishes the epoch flag (no block barrier, no wave waits
-// for another one's store acknowledgements)
-template <int NW>
-__device__ __forceinline__ void arrive_and_flag(double *misc, unsigned *flag, unsigned epoch) {
-    drain();
-    if ((threadIdx.x & 63) == 0) {
-        unsigned *cnt = reinterpret_cast<unsigned *>(misc + 2);
-        const unsigned old = atomicAdd(cnt, 1u);      // LDS atomic
-        if (old == NW - 1) { *cnt = 0u; st_flag(flag, epoch); }
-    }
+// block barrier that orders LDS accesses only: the write-through strip stores (and the stored sequence's stores / loads) stay in
+// flight across it.  __syncthreads() would wait for every outstanding store's acknowledgement (vmcnt(0)) -- a memory round trip
+// per barrier, four barriers per step.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID = false>
@@ -739,51 +843,85 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
         lds[K::LDS_COL + e] = Q.m1[th.j0 + e]; lds[K::LDS_COL + TC + e] = Q.colA[th.j0 + e]; lds[K::LDS_COL + 2 * TC + e] = Q.colB[th.j0 + e];
     }
     if (tid == 0) { misc[1] = 0.0; misc[2] = 0.0; }
+    const int gw = th.gather_wave();
     __syncthreads();
 
 #ifdef BLR_PROF
-    const bool prof_me = Q.prof && th.tile == Q.ntiles / 2 + Q.tc / 2 && (tid == 0 || tid == 128);     // an edge wave and a middle one
-#define BLR_STAMP(i) do { if (prof_me && k >= 8 && k < 24) Q.prof[(tid ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+    // development builds: shader-clock stamps of four waves of one interior tile (two edge-segment waves, two interior ones)
+    const int prof_slot = tid == 0 ? 0 : (tid == 128 ? 1 : (tid == 256 ? 2 : (tid == NT - 64 ? 3 : -1)));
+    const bool prof_me = Q.prof && th.tile == Q.ntiles / 2 + Q.tc / 2 && prof_slot >= 0;
+#define BLR_STAMP(i) do { if (prof_me && k >= 8 && k < 24) Q.prof[prof_slot * 256 + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define BLR_STAMP(i) do { } while (0)
 #endif
-    constexpr bool ONE = SEG == CHK;                  // one-chunk segments: a hand-off is needed the moment a pass begins
+    // Bookkeeping of a finished step (one lane): the waves' sums (LDS, complete since the step's last barrier, not overwritten
+    // before the next step's) added in a fixed order -> the host's partial sums, and the tile's lagged sum for the other tiles.
+    // It runs half a step LATER, in a wave that is early at the barrier after the axis-1 pass (multi-chunk shapes: wave 0, an edge
+    // segment with issue priority over its SIMD partner; one-chunk shapes: an interior segment that neither waits for a neighbour nor
+    // gathers the lagged sum).
+    constexpr int BOOK_WAVE = K::ONE ? (NW >= 2 ? NW / 2 - 1 : 0) : 0;
+    const bool booker = (tid >> 6) == BOOK_WAVE;
+    auto book = [&](int kb) {                         // (the whole wave: lane w fetches wave w's sums, one tree adds them)
+        constexpr int NV = BWD ? 5 : 3;
+        const int lane = tid & 63;
+        double tot[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            tot[q] = 0.0;
+            if (!BWD && q > 0 && !K::f_means(Q)) continue;
+            tot[q] = blk::wave_sum(lane < NW ? red[lane * NV + q] : 0.0);
+        }
+        if (lane == 0) {
+            double *out = Q.psum + (long long)K::Thread::time_of(Q, kb) * NRED * Q.ntiles + th.tile;
+            if (BWD) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) out[(long long)q * Q.ntiles] = tot[q];
+                K::publish_sum(Q, th.tile, kb, 0, tot[2]);
+            } else {
+                out[0] = tot[0];
+                if (K::f_means(Q)) { out[3LL * Q.ntiles] = tot[1]; out[4LL * Q.ntiles] = tot[2]; }
+                K::publish_sum(Q, th.tile, kb, 0, tot[0]);
+            }
+        }
+    };
     for (int k = 0; k < Q.T; ++k) {
-        const int t = K::Thread::time_of(Q, k);
         BLR_STAMP(0);
-        th.begin_step(Q, k);
         if (k == 0) {
+            th.begin_step(Q, k);
             th.first_step(Q);
         } else {
             th.h_preread();
-            // multi-chunk tiles: the edge columns of step k - 1 went out at the end of that step; their acknowledgements had the
-            // LDS reads above to arrive, and the neighbours need them only for their last chunk
-            if (!ONE) arrive_and_flag<NW>(misc, Q.flagC + th.tile, (unsigned)k);
-            if (k >= Q.lag) th.gather_issue(Q, k - Q.lag);
-            __syncthreads();
             BLR_STAMP(1);
-            th.h_walk(Q, k);
+            if (k >= Q.lag && gw >= 0) th.gather_issue(Q, k - Q.lag);
             BLR_STAMP(2);
-            __syncthreads();
+            lds_barrier();
             BLR_STAMP(3);
-            th.publish_rows(Q, k);
-            th.v_preread();
-            if (k >= Q.lag) {
+            th.h_walk(Q, k);
+            BLR_STAMP(4);
+            if (booker) book(k - 1);
+            BLR_STAMP(5);
+            if (k >= Q.lag && gw >= 0) {              // (in the early waves' slack before the barrier)
                 double part[K::NG];
                 th.gather_finish(Q, k - Q.lag, part);
-#pragma unroll
-                for (int g2 = 0; g2 < K::NG; ++g2) {
-                    const double ws = blk::wave_sum(part[g2]);
-                    if ((tid & 63) == 0) misc[8 + g2 * NW + (tid >> 6)] = ws;
+                const double ws = blk::wave_sum(part[0]);
+                if ((tid & 63) == 0) {
+                    misc[8 + gw] = ws;
+                    unsigned *cnt = reinterpret_cast<unsigned *>(misc + 2);
+                    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (old == (unsigned)K::GW - 1u) { *cnt = 0u; th.combine_shares(); }       // the last one adds the shares (fixed order)
                 }
             }
-            BLR_STAMP(4);
-            arrive_and_flag<NW>(misc, Q.flagR + th.tile, (unsigned)k);
-            BLR_STAMP(5);
-            __syncthreads();
             BLR_STAMP(6);
-            th.v_walk(Q, k);
+            lds_barrier();
             BLR_STAMP(7);
+            th.publish_rows(Q, k);
+            BLR_STAMP(8);
+            th.v_preread();
+            BLR_STAMP(9);
+            lds_barrier();
+            BLR_STAMP(10);
+            th.v_walk(Q, k);
+            BLR_STAMP(11);
         }
         // ---- sums of the step: partials for the host, the lagged sums for the other tiles.  ONE barrier: every wave leaves its
         //      sums in LDS, then all threads copy the edge columns out while thread 0 adds the waves' sums (fixed order) ----------
@@ -799,35 +937,15 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
                 const double ws = blk::wave_sum(v[q]);
                 if ((tid & 63) == 0) red[(tid >> 6) * NV + q] = ws;
             }
-            __syncthreads();                          // the tile's new state is complete in LDS, the waves' sums and misc[1] are final
-            BLR_STAMP(8);
+            BLR_STAMP(12);
+            lds_barrier();                            // the tile's new state is complete in LDS, the waves' sums and misc[1] are final
+            BLR_STAMP(13);
             th.publish_cols(Q, k);
-            // the flag of the edge columns goes out before the bookkeeping stores below: nobody waits for those
-            if (ONE) arrive_and_flag<NW>(misc, Q.flagC + th.tile, (unsigned)(k + 1));
-            if (tid == NT - 64) {                     // (lane 0 of the LAST wave: an interior segment, off the hand-off-critical edge waves)
-                double *out = Q.psum + (long long)t * NRED * Q.ntiles + th.tile;
-                double tot[NV];
-#pragma unroll
-                for (int q = 0; q < NV; ++q) {
-                    tot[q] = 0.0;
-                    if (!BWD && q > 0 && !K::f_means(Q)) continue;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) tot[q] += red[w * NV + q];
-                }
-                if (BWD) {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) out[(long long)q * Q.ntiles] = tot[q];
-                    K::publish_sum(Q, th.tile, k, 0, tot[2]);
-                } else {
-                    out[0] = tot[0];
-                    if (K::f_means(Q)) { out[3LL * Q.ntiles] = tot[1]; out[4LL * Q.ntiles] = tot[2]; }
-                    K::publish_sum(Q, th.tile, k, 0, tot[0]);
-                }
-            }
+            BLR_STAMP(14);
         }
-        BLR_STAMP(9);
         if (misc[1] != 0.0) return;                   // a wait timed out somewhere in this block: uniform exit (host falls back)
     }
+    if (booker) book(Q.T - 1);
 }
 
 }  // namespace blr

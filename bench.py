@@ -485,7 +485,7 @@ def main():
                         traffic=traffic, traffic_from=(pmc[key]['source'] if traffic is not None else None),
                         hbm=dom['hbm'], fp64=dom['fp64'],
                         peak_calibrated=peak_cal, frac_calibrated=dom['hbm']['frac_calibrated'],
-                        peak_calibrated_from='blhip_bandwidth_probe: 16-B-per-lane streaming copy of 1 GiB, read + write',
+                        peak_calibrated_from='blhip_bandwidth_probe: best of a 16-B-per-lane streaming copy (read + write) and a store-only fill of 1 GiB',
                         algorithmic=dict(dom['streaming_equiv'], note='SURVEY 8(d) accounting: the bytes a kernel that streams the state through '
                                          'HBM would move, divided by this kernel\'s time -- an equivalent rate, may exceed the peak'),
                         kernel=dom['kernel'], avg_launch_us=dom['avg_launch_us'], cells_per_launch=dom['cells_per_launch'])

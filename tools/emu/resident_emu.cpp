@@ -124,21 +124,20 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
     // ---- emulation ---------------------------------------------------------------------------------------------------------------
     const int ntiles = tr * tc;
     std::vector<double> gpost((size_t)T * G, 0.0), uniform(G, 1.0 / G);
-    std::vector<double> cols((size_t)2 * ntiles * 2 * R * TR), rows((size_t)2 * ntiles * 2 * R * TC);
-    std::vector<unsigned> flagC(ntiles), flagR(ntiles);
+    std::vector<double> cols((size_t)2 * 2 * ntiles * 2 * R * TR), rows((size_t)2 * 2 * ntiles * 2 * R * TC);      // tagged 16-byte elements
     std::vector<unsigned long long> gran((size_t)NSLOT * ntiles * 4);
     unsigned abort_word = 0;
     ResParams Q{};
     Q.n0 = p.n0; Q.n1 = p.n1; Q.tr = tr; Q.tc = tc; Q.ntiles = ntiles; Q.T = T; Q.d = 1; Q.rec_len = 1; Q.lag = lag;
     Q.post = gpost.data(); Q.w0 = p.w0.data(); Q.w1 = p.w1.data(); Q.m0 = p.m0.data(); Q.m1 = p.m1.data();
     Q.colA = p.colA.data(); Q.colB = p.colB.data(); Q.rec = p.rec.data(); Q.step0 = p.step0;
-    Q.cols = cols.data(); Q.rows = rows.data(); Q.flagC = flagC.data(); Q.flagR = flagR.data(); Q.gran = gran.data();
+    Q.cols = cols.data(); Q.rows = rows.data(); Q.cols_bytes = (unsigned)(cols.size() * 8); Q.rows_bytes = (unsigned)(rows.size() * 8); Q.gran = gran.data();
     Q.abort_word = &abort_word; Q.timeout_ticks = 0;
 
     auto pass = [&](auto tag, std::vector<double> &psum) {
         using K = decltype(tag);
         constexpr int NT = K::NT;
-        std::fill(flagC.begin(), flagC.end(), 0u); std::fill(flagR.begin(), flagR.end(), 0u);
+        std::fill(cols.begin(), cols.end(), 0.0); std::fill(rows.begin(), rows.end(), 0.0);
         std::fill(gran.begin(), gran.end(), 0ull);
         std::vector<std::vector<double>> lds(ntiles, std::vector<double>(K::LDS_DOUBLES, 0.0));
         std::vector<typename K::Thread> th((size_t)ntiles * NT);
@@ -161,22 +160,25 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
                 for (auto &x : th) x.first_step(Q);
             } else {
                 for (auto &x : th) x.h_preread();
-                if (k >= lag) for (auto &x : th) x.gather_issue(Q, k - lag);
+                if (k >= lag) for (auto &x : th) if (x.gather_wave() >= 0) x.gather_issue(Q, k - lag);
                 for (auto &x : th) x.h_walk(Q, k);
                 for (auto &x : th) x.publish_rows(Q, k);
-                for (int b = 0; b < ntiles; ++b) flagR[th[(size_t)b * NT].tile] = (unsigned)k;
                 for (auto &x : th) x.v_preread();
                 if (k >= lag)
-                    for (int b = 0; b < ntiles; ++b)
+                    for (int b = 0; b < ntiles; ++b) {
                         for (int w = 0; w < K::NW; ++w) {
+                            const int gw = th[(size_t)b * NT + w * 64].gather_wave();
+                            if (gw < 0) continue;
                             double part[K::NG] = {};
                             for (int lane = 0; lane < 64; ++lane) {
                                 double a[K::NG];
                                 th[(size_t)b * NT + w * 64 + lane].gather_finish(Q, k - lag, a);
                                 for (int g2 = 0; g2 < K::NG; ++g2) part[g2] += a[g2];
                             }
-                            for (int g2 = 0; g2 < K::NG; ++g2) lds[b][K::LDS_MISC + 8 + g2 * K::NW + w] = part[g2];
+                            lds[b][K::LDS_MISC + 8 + gw] = part[0];
                         }
+                        th[(size_t)b * NT].combine_shares();
+                    }
                 for (auto &x : th) x.v_walk(Q, k);
             }
             for (int b = 0; b < ntiles; ++b) {
@@ -189,7 +191,6 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
                 if (K::BWD) K::publish_sum(Q, tile, k, 1, v[0]);
             }
             for (auto &x : th) x.publish_cols(Q, k);
-            for (int b = 0; b < ntiles; ++b) flagC[th[(size_t)b * NT].tile] = (unsigned)(k + 1);
             for (auto &x : th) if (x.dead) { std::printf("dead thread\n"); return false; }
         }
         return true;
