@@ -26,6 +26,7 @@
 #include "blhip_kernels.hpp"
 #include "blhip_fast.hpp"
 #include "blhip_mfma.hpp"
+#include "blhip_hwide.hpp"
 #include "blhip_fused1d.hpp"
 #include "blhip_resident.hpp"
 #include "blhip_chainres.hpp"
@@ -317,6 +318,14 @@ void launch_mfma(hipStream_t s, int om, int mode, const blf::FastParams &P, int 
         if (mode == MODE_FWD) launch_mfma_om<OM_TABLE, MODE_FWD>(s, P, R0, H, nchains);
         else launch_mfma_om<OM_TABLE, MODE_BWD>(s, P, R0, H, nchains);
     }
+    HIPCHECK(hipGetLastError());
+}
+
+void launch_hwide(hipStream_t s, const blh::HParams &P, int nchains) {
+    const size_t lds = blh::lds_bytes(P.lwmax);
+    arm_kernel(reinterpret_cast<const void *>(&blh::hwide_kernel));
+    const dim3 grid((unsigned)(((P.n0 + blh::RB - 1) / blh::RB) * P.tiles_j), (unsigned)nchains);
+    hipLaunchKernelGGL(blh::hwide_kernel, grid, dim3(blh::NT), lds, s, P);
     HIPCHECK(hipGetLastError());
 }
 
@@ -1031,6 +1040,7 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
 // element once + 2 R0 halo rows per segment, short ones give enough blocks to fill 256 CUs when there are few chains)
 struct GeometryPlan {
     bool fast = false, fused1d = false, use_mfma = false;
+    bool wideH = false;           // axis-1 walks wider than the fused kernels' halo: row filter as a pre-pass per step (blhip_hwide.hpp)
     int64_t fusedK = 1;
     int f1_TJ = 128;
     Tile tile{};
@@ -1043,8 +1053,10 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
     const int64_t T = p->T;
     // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
     gp.fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
-                      ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX && prog.LW1 <= blf::R1MAX &&
+                      ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX &&
+                      (prog.LW1 <= blf::R1MAX || (prog.LW1 <= blh::HW_MAX && prog.LW1 < g.n1 && ctx->option("wide_h", 1.0) != 0.0)) &&
                       g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
+    gp.wideH = gp.fast && prog.LW1 > blf::R1MAX;
     if (p->ndim == 1 && !gp.fast && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
         gp.f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
@@ -1054,7 +1066,7 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
         gp.fused1d = (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 + (size_t)gp.fusedK * gp.f1_TJ * 32 + 4096 <= 150 * 1024;
     }
     if (gp.fast) {
-        gp.tile.TI = blf::CH; gp.tile.LW0 = prog.LW0; gp.tile.LW1 = prog.LW1 > 0 ? blf::R1MAX : 0;
+        gp.tile.TI = blf::CH; gp.tile.LW0 = prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && !gp.wideH) ? blf::R1MAX : 0;
         gp.tile.TJ = blf::BW - 2 * gp.tile.LW1;
         gp.tile.tiles_j = (g.n1 + gp.tile.TJ - 1) / gp.tile.TJ;
         // rows per block segment: long segments read every element once (+ 2*R0 halo rows per segment), short ones
@@ -1126,7 +1138,7 @@ struct DeviceMeta {
 };
 
 void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram &prog, TapTable &taps, int64_t B, bool full, bool fast, int nblk,
-                     DeviceMeta &M) {
+                     DeviceMeta &M, bool wideH = false) {
     hipStream_t st = ctx->stream;
     const int64_t T = p->T;
     const size_t nT = (size_t)T * B;
@@ -1166,14 +1178,16 @@ void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram 
         // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle: a radius bucket with fewer blocks joins the next one
         const long long min_blocks = (long long)ctx->option("min_bucket_blocks", 128.0);
         const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)nblk - 1) / nblk);
+        // (wideH: the axis-1 filters run in the pre-pass, the fused kernels are launched without theirs)
+        const std::vector<int> no_h(wideH ? (size_t)B : 0, -1);
         M.h_orderF.resize(nT); M.rangesF.resize(T);
         for (int64_t t = 0; t < T; ++t)
-            bucket_step(&prog.tapF0[t * B], &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains);
+            bucket_step(&prog.tapF0[t * B], wideH ? no_h.data() : &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains);
         HIPCHECK(hipMemcpyAsync(M.orderF, M.h_orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
         if (full) {
             M.h_orderB.resize(nT); M.rangesB.resize(T);
             for (int64_t t = 0; t < T; ++t)
-                bucket_step(&prog.tapB0[t * B], &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains);
+                bucket_step(&prog.tapB0[t * B], wideH ? no_h.data() : &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains);
             HIPCHECK(hipMemcpyAsync(M.orderB, M.h_orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
         }
     }
@@ -1635,7 +1649,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         // --- device metadata ---
         DeviceMeta M;
-        upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M);
+        upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M, gp.wideH);
         unsigned char *const d_kindF = M.kindF, *const d_kindB = M.kindB, *const d_cmodeF = M.cmodeF, *const d_cmodeB = M.cmodeB;
         double *const d_limitF = M.limitF, *const d_limitB = M.limitB;
         int *const d_tapF0 = M.tapF0, *const d_tapF1 = M.tapF1, *const d_tapB0 = M.tapB0, *const d_tapB1 = M.tapB1;
@@ -1736,7 +1750,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         size_t max_ranges = 0;
         for (const auto &r : rangesF) max_ranges = std::max(max_ranges, r.size());
         for (const auto &r : rangesB) max_ranges = std::max(max_ranges, r.size());
-        const bool multistream = fast && max_ranges >= 2 && ctx->option("multistream", 1.0) != 0.0;
+        const bool multistream = fast && !gp.wideH && max_ranges >= 2 && ctx->option("multistream", 1.0) != 0.0;
         auto fork_streams = [&]() {
             if (!multistream) return;
             HIPCHECK(hipEventRecord(ctx->fork_ev, st));
@@ -1757,6 +1771,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 if (ranges[ta][k].key != ranges[tb][k].key || ranges[ta][k].count != ranges[tb][k].count) return false;
             return std::equal(order.begin() + ta * B, order.begin() + (ta + 1) * B, order.begin() + tb * B);
         };
+        std::vector<char> any_hF, any_hB;
+        double *d_hsrc = nullptr;
+        if (gp.wideH) {
+            any_hF.assign(T, 0); any_hB.assign(T, 0);
+            for (int64_t t = 0; t < T; ++t)
+                for (int64_t b = 0; b < B; ++b) {
+                    if (prog.tapF1[t * B + b] >= 0) any_hF[t] = 1;
+                    if (full && prog.tapB1[t * B + b] >= 0) any_hB[t] = 1;
+                }
+            ctx->hsrc.ensure((size_t)B * G * 8);
+            d_hsrc = ctx->hsrc.as<double>();
+        }
         const int mfma_min_r0 = (int)ctx->option("mfma_min_r0", 8);
         // both-axes launches: the matrix-pipe kernel wins while the launch is latency-bound (few cells per CU); with the chip
         // full the vector kernel's 2 x 17 FMAs per cell beat 2 x 32 band products (measured: 1024^2 12.7 vs 14.9 us,
@@ -1778,6 +1804,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 Q.psum_prev = ps_prev; Q.prev_slot = prev_slot; Q.psum_out = ps_out;
                 Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
                 const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
+                if (gp.wideH && (mode == MODE_FWD ? any_hF : any_hB)[t]) {
+                    // row filter of every chain of the step -> hsrc; the launches below consume it instead of their sources
+                    blh::HParams HP{};
+                    HP.n0 = g.n0; HP.n1 = g.n1; HP.tiles_j = (g.n1 + blh::CB - 1) / blh::CB; HP.lwmax = prog.LW1; HP.pitch = blh::pitch_for(prog.LW1);
+                    HP.src = srcp; HP.src_stride = src_stride;
+                    for (int k = 0; k < 5; ++k) HP.shared[k] = FP.shared[k];
+                    HP.srckind = Q.srckind; HP.tap1 = Q.tap1; HP.taps = d_taps; HP.tap_off = d_off; HP.tap_lw = d_lw; HP.dst = d_hsrc;
+                    launch_hwide(st, HP, (int)B);
+                    Q.hsrc = d_hsrc;
+                    const bool bw = mode != MODE_FWD;
+                    account(ctx, bw, (double)B * G * 16.0, (double)B * G * 2.0 * (2.0 * prog.LW1 + 8.0));
+                }
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
                     Q.u_valid = 0;

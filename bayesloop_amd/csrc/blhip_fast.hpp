@@ -45,6 +45,7 @@ struct FastParams {
     int ndim, d, means, use_rec;
     double step0;                // lattice step of the row axis (likelihood recurrence)
     const double *src;  long long src_stride;
+    const double *hsrc;          // != nullptr: [chains][n0 * n1] sources already filtered along axis 1 (wide random walks: blhip_hwide.hpp)
     double       *dst;  long long dst_stride;
     double       *post; long long post_stride;
     const double *shared[5];
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void fast_step_kernel(const FastParams
     const int tid = threadIdx.x;
 
     const int kind = cmeta.kind, lw0 = cmeta.lw0;
-    const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
+    // (hsrc: the chain's source after the axis-1 pre-pass, blhip_hwide.hpp -- whatever its kind, which still selects the scale)
+    const double *src = P.hsrc ? P.hsrc + (long long)b * P.n0 * P.n1 : (kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind]);
 
     // ---- this thread's column ------------------------------------------------------------------------------------
     const int jc = j0 - (H ? R1MAX : 0) + tid;                 // grid column (may lie in the halo / outside)

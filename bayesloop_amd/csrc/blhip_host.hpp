@@ -133,6 +133,7 @@ struct blhip_ctx {
     // average posterior folded on a second stream while the next batch's forward pass runs (do_fit): second sequence buffer,
     // private copies of the per-batch weights, the stream and its events
     DevBuf post2, accw;
+    DevBuf hsrc;                 // the axis-1 pre-pass's output of one step (blhip_hwide.hpp)
     DevBuf accpart;              // partial accumulators of the fused fold (one per launch slot of the chain-resident kernel)
     hipStream_t astream = nullptr;
     hipEvent_t aev_done[2] = {nullptr, nullptr};

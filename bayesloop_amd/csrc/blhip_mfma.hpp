@@ -105,7 +105,8 @@ __global__ __launch_bounds__(H ? NT_H : NT_V) void mfma_step_kernel(const FastPa
     const bool mainw = !H || wv < 4;                              // wave-uniform: wave 4 of an H block = halo columns
 
     const int kind = cmeta.kind, lw0 = cmeta.lw0;
-    const double *src = kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind];
+    // (hsrc: the chain's source after the axis-1 pre-pass, blhip_hwide.hpp -- whatever its kind, which still selects the scale)
+    const double *src = P.hsrc ? P.hsrc + (long long)b * P.n0 * P.n1 : (kind == SRC_PREV ? P.src + (long long)b * P.src_stride : P.shared[kind]);
 
     // ---- this lane's column ---------------------------------------------------------------------------------------------
     const int jc = mainw ? tj * BCOL + wv * WCOL + c : (c < R1 ? tj * BCOL - R1 + c : tj * BCOL + BCOL + (c - R1));

@@ -2,7 +2,7 @@
 """
 bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c3|c2|c5|fwd2048] [--no-extra] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c3|c2|c5|fwd2048] [--no-extra] [--no-cpu]
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
@@ -21,6 +21,8 @@ Workloads (synthetic data, seeds fixed):
   c3       Study, 1024 x 1024 grid, T = 2000, GRW x GRW separable stencil, full fit             (N = 1)
   c2       Study, 4096-point 1-D GaussianMean grid, T = 10 000, full fit (latency-bound)       (N = 1)
   fwd2048  Study, 2048 x 2048 grid, T = 200, evidenceOnly: the fused-forward-step roofline point (N = 1)
+  c4_both_axes  HyperStudy, 512 x 512 grid, random walks on BOTH parameters with 64 x 8 width pairs (radii up to 38 / 29 grid steps),
+           T = 256, full fit: the axis-1 pre-pass (blhip_hwide.hpp) + the matrix-pipe step kernels, one launch per step and bucket
 
 Inputs are KBs (the series, the marginal grids) and are uploaded inside fit(); all grid-sized state is created and
 stays in HBM.  The posterior sequence is left on the device (lazy D2H on first access, not part of the timed region).
@@ -73,6 +75,17 @@ def make_study(bl, name, comm=None, scale=1.0):
         return S, dict(silent=True), n * n * T * nh, dict(workload='C4 HyperStudy 512x512 grid x 512 sigma values, T=256, '
                                                            'full fit (forward+backward+average posterior)',
                                                            grid=[n, n], T=T, n_hyper=nh, mode='full')
+    if name == 'c4_both_axes':      # a hyper-study whose random walks act on BOTH parameters (reference: tests/test_hyperstudy.py two-hyper-parameter fits)
+        n, T, nh1, nh2 = 512, 256, 64, 8
+        S = bl.HyperStudy(silent=True)
+        S.loadData(series(4, T), silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
+              bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s1', bl.cint(0, 0.3, nh1), target='mean'),
+                                            bl.tm.GaussianRandomWalk('s2', bl.cint(0, 0.06, nh2), target='std')), silent=True)
+        S.communicator = comm
+        return S, dict(silent=True), n * n * T * nh1 * nh2, dict(
+            workload='HyperStudy 512x512 grid x (64 x 8) sigma pairs, random walks on both parameters, T=256, full fit',
+            grid=[n, n], T=T, n_hyper=nh1 * nh2, mode='full')
     if name == 'tiny':        # not a benchmark: the CPU test of this file's launcher / exchange / JSON logic (tests/test_bench_contract.py)
         n, T, nh = 24, 10, 6
         S = bl.HyperStudy(silent=True)
@@ -408,6 +421,8 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='do not run the two rocprofv3 PMC passes for roofline.traffic')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end (PCIe-inclusive) fit')
+    ap.add_argument('--opt', action='append', default=[], metavar='KEY=VALUE',
+                    help='engine option for an experiment (blhip_set_option), e.g. --opt max_batch=32; recorded in config.engine_options')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -432,6 +447,9 @@ def main():
         eng, comm = bench_double.install(bl, rank, world)
     else:
         eng = bl.get_engine()
+        for kv in args.opt:
+            k, v = kv.split('=', 1)
+            eng.set_option(k, float(v))
         if world > 1 or os.environ.get('BLHIP_FORCE_DIST') == '1':      # (the latter: the RCCL path with a single rank, tests)
             comm = bl.dist.RcclCommunicator(eng, rank=rank, world=world)
 
@@ -494,7 +512,8 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling='strong', vs_baseline=None, dtype='f64', data='synthetic',
                    config=dict(desc, parallelism='hyper-grid points dealt round-robin to %d GPU(s), one RCCL gather + one reduce' % world,
-                               cpu_baseline='sampled (bounded subset of this workload, see cpu_baseline.sample)'),
+                               cpu_baseline='sampled (bounded subset of this workload, see cpu_baseline.sample)',
+                               **({'engine_options': list(args.opt)} if args.opt else {})),
                    log_evidence=float(S.logEvidence), log_evidence_reference=gold,
                    log_evidence_rel_err=rel_err(float(S.logEvidence), gold), roofline=roof, kernels=rf, device=eng.device_name(),
                    resident_fallbacks=int(timing.get('resident_fallbacks', 0)))
@@ -547,7 +566,7 @@ def main():
     if rank == 0:
         if not args.no_extra and world == 1:
             extra = {}
-            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5'):
+            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes'):
                 if name == args.workload:
                     continue
                 try:

@@ -125,6 +125,23 @@ EXTRA = {
     'x_mfma_axis1_only': dict(study='Study', data=('series', 33, 9),
                               om=('Gaussian', [('mean', ('cint', -4, 4, 97)), ('std', ('oint', 0, 3, 111))], 'default'),
                               tm=('GRW', 's2', 0.05, 'std', None)),
+    # random walks on the SECOND parameter wider than the fused kernels' 8-column halo: axis-1 pre-pass (blhip_hwide.hpp) + fused kernels
+    'x_wide_h': dict(study='Study', data=('series', 41, 10), om=cases.gauss2d(96, -6, 6, 3),
+                     tm=('Combined', [('GRW', 's1', 0.25, 'mean', None), ('GRW', 's2', 0.3, 'std', None)])),            # radii 8 / 38
+    'x_wide_h_only': dict(study='Study', data=('series', 42, 8),
+                          om=('Gaussian', [('mean', ('cint', -4, 4, 67)), ('std', ('oint', 0, 3, 301))], 'default'),
+                          tm=('GRW', 's2', 0.15, 'std', None)),                                                           # radius 60, ragged columns
+    'x_wide_h_hyper': dict(study='HyperStudy', data=('series', 43, 12), om=cases.gauss2d(64, -4, 4, 3),
+                           tm=('Combined', [('GRW', 's1', ('cint', 0, 0.4, 3), 'mean', None),
+                                            ('GRW', 's2', ('cint', 0.05, 0.5, 4), 'std', None)])),                          # radii 4 .. 43 in one batch
+    'x_wide_h_hyper_axis1': dict(study='HyperStudy', data=('series', 44, 12), om=cases.gauss2d(80, -4, 4, 3),
+                                 tm=('GRW', 's2', ('cint', 0.02, 0.5, 6), 'std', None)),                                  # walk on the second parameter only
+    'x_wide_h_cp': dict(study='ChangepointStudy', data=('series_jump', 45, 24, 12, 2.0), om=cases.gauss2d(40, -4, 6, 3),
+                        tm=('Combined', [('ChangePoint', 'tChange', ('arange', 2, 22, 3), None),
+                                         ('GRW', 'sigma', 0.4, 'std', None)])),                                             # restarts through the pre-pass
+    'x_wide_h_forward': dict(study='Study', data=('series', 46, 9), om=cases.gauss2d(72, -5, 5, 3),
+                             tm=('Combined', [('GRW', 's1', 0.4, 'mean', None), ('GRW', 's2', 0.5, 'std', None)]),
+                             fit=dict(forwardOnly=True)),
     # edge shapes: a single time step, minimal grids, a first step without data, one hyper-grid point
     'x_single_step': dict(study='Study', data=np.array([2.5]), om=cases.gauss2d(64, -5, 5, 3),
                           tm=('Combined', [('GRW', 's1', 0.3, 'mean', None), ('GRW', 's2', 0.1, 'std', None)])),
@@ -172,6 +189,25 @@ def test_reference_fixtures_on_the_chain_resident_path():
         S = cases.build(bl, EXTRA[name])
         S.fit(silent=True)
         assert S.lastTiming['fwd_kernel_variant'] == 6 and S.lastTiming['bwd_kernel_variant'] == 6, (name, S.lastTiming)
+
+
+def test_wide_axis1_walks_take_the_streaming_kernels():
+    """Axis-1 radii above 8 no longer drop a batch to the generic LDS-tile kernel (variant 0): pre-pass + streaming kernels
+    (variants 1 / 3); wide_h = 0 restores the old routing, with the same results."""
+    eng = bl.get_engine()
+    for name in ('x_wide_h', 'x_wide_h_only', 'x_wide_h_hyper', 'x_wide_h_hyper_axis1', 'x_wide_h_cp', 'x_tall_2d', 'x_hyper_many'):
+        S = cases.build(bl, EXTRA[name])
+        S.fit(silent=True)
+        assert S.lastTiming['fwd_kernel_variant'] in (1, 3) and S.lastTiming['bwd_kernel_variant'] in (1, 3), (name, S.lastTiming)
+        eng.set_option('wide_h', 0)
+        try:
+            S0 = cases.build(bl, EXTRA[name])
+            S0.fit(silent=True)
+            assert S0.lastTiming['fwd_kernel_variant'] == 0, (name, S0.lastTiming)
+        finally:
+            eng.set_option('wide_h', 1)
+        np.testing.assert_allclose(S.logEvidence, S0.logEvidence, rtol=1e-11)
+        np.testing.assert_allclose(S.posteriorMeanValues, S0.posteriorMeanValues, rtol=1e-9, atol=1e-12)
 
 
 def test_matrix_pipe_kernels_ran():
