@@ -2257,12 +2257,16 @@ int blhip_bandwidth_probe(blhip_ctx *ctx, int64_t bytes, int iterations, double 
             HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
             best = std::max(best, 2.0 * (double)n2 * 16.0 * iterations / ((double)ms * 1e-3) / 1e9);
         }
-        {   // a store-only stream (what the no-stencil forward chain kernel does) can run above the copy rate: the calibrated peak is
+        for (int variant = 0; variant < 2; ++variant) {
+            // a store-only stream (what the no-stencil forward chain kernel does) can run above the copy rate: the calibrated peak is
             // the best of the streams measured
-            hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, b.as<double>(), n2 * 2, 2.0);
+            auto go = [&](double2 *dst, double v) {
+                if (variant) hipLaunchKernelGGL(fill16_kernel<true>, dim3(gx), dim3(NTHREADS), 0, st, dst, n2, v);
+                else hipLaunchKernelGGL(fill16_kernel<false>, dim3(gx), dim3(NTHREADS), 0, st, dst, n2, v);
+            };
+            go(b.as<double2>(), 2.0);
             HIPCHECK(hipEventRecord(ctx->ev[4], st));
-            for (int k = 0; k < iterations; ++k)
-                hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, st, (k & 1) ? a.as<double>() : b.as<double>(), n2 * 2, 3.0);
+            for (int k = 0; k < iterations; ++k) go((k & 1) ? a.as<double2>() : b.as<double2>(), 3.0);
             HIPCHECK(hipEventRecord(ctx->ev[5], st));
             HIPCHECK(hipGetLastError());
             sync_stream(ctx, st);

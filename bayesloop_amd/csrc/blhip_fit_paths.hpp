@@ -137,8 +137,8 @@ struct ResidentRun {
         Q.prof = ctx->small.as<unsigned long long>();
 #endif
         launch_resident(st, rp, Q, bwd);
-        {   // HBM: the halo strips (2 R rows + 2 R columns of every tile, written and read once per step) + what the fit keeps
-            const double halo = 2.0 * 8.0 * 2.0 * blr::R * (rp.TR + rp.TC) / ((double)rp.TR * rp.TC);
+        {   // HBM: the halo strips (2 R rows + 2 R columns of every tile, tagged 16-byte elements written and read once per step) + what the fit keeps
+            const double halo = 2.0 * 16.0 * 2.0 * blr::R * (rp.TR + rp.TC) / ((double)rp.TR * rp.TC);
             const double kept = bwd ? 16.0 : (Q.store ? 8.0 : 0.0) + (Q.normalise ? 16.0 : 0.0);
             account(ctx, bwd, (double)E.G * T * (halo + kept), (double)E.G * T * (2.0 * valu_stencil_flop(blr::R) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
         }

@@ -626,6 +626,20 @@ __global__ __launch_bounds__(NTHREADS) void time_average_kernel(const double *p,
     }
 }
 
+// store-only stream, 16 B per lane and access (the other calibration stream: the no-stencil forward chain kernel only writes)
+template <bool NT>
+__global__ __launch_bounds__(NTHREADS) void fill16_kernel(double2 *__restrict__ dst, long long n2, double v) {
+    const long long base = (long long)blockIdx.x * (4 * NTHREADS) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long c = base + k * NTHREADS;
+        if (c < n2) {
+            if (NT) { __builtin_nontemporal_store(v, &dst[c].x); __builtin_nontemporal_store(v, &dst[c].y); }
+            else dst[c] = double2{v, v};
+        }
+    }
+}
+
 // streaming copy, 16 B per lane and access, 4 independent accesses per thread in flight (the calibration of what this part
 // reaches on a pure read + write stream); NT: non-temporal loads / stores
 template <bool NT>

@@ -155,6 +155,33 @@ def measured_traffic(key):
     return None, None
 
 
+def recalibrate(out):
+    """The calibrated peak is the best streaming rate OBSERVED in this run: the probe's, or a kernel's real HBM rate when one beats the
+    probe (a store-only kernel can) -- then every frac_calibrated of the line is re-expressed against that rate, so none exceeds 1."""
+    hbm_blocks = []
+
+    def walk(o):
+        if isinstance(o, dict):
+            if 'achieved_GBs' in o and 'frac_calibrated' in o:
+                hbm_blocks.append(o)
+            for v in o.values():
+                walk(v)
+    walk(out)
+    roof = out.get('roofline') or {}
+    probe = roof.get('peak_calibrated')
+    if not probe or not hbm_blocks:
+        return
+    best = max([probe] + [b['achieved_GBs'] for b in hbm_blocks])
+    if best > probe:
+        for b in hbm_blocks:
+            b['frac_calibrated'] = b['achieved_GBs'] / best
+        roof['peak_calibrated_probe'] = probe
+        roof['peak_calibrated'] = best
+        roof['peak_calibrated_from'] += '; a kernel of this run streamed faster than the probe: its rate is the calibrated peak'
+        if roof.get('frac_calibrated') is not None and roof.get('unit') == 'GB/s':
+            roof['frac_calibrated'] = roof['achieved'] / best
+
+
 def golden_log_evidence(name):
     """logEvidence of the REFERENCE for this exact workload (tests/golden/bench_<name>.npz, generated by importing the reference in
     the build container: tests/golden/gen_bench_golden.py), or None."""
@@ -587,6 +614,7 @@ def main():
             out['extra'] = extra
         if not args.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline()
+        recalibrate(out)
 
     def drain_c_stdio():
         try:

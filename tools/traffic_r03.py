@@ -1,17 +1,23 @@
 """HBM traffic and pipe counters per logical step launch from the rocprofv3 passes of tools/prof_r03.sh (round 3).
 
-usage: python tools/traffic_r03.py gpurun_out/prof_r03_c4 gpurun_out/prof_r03_c5 gpurun_out/prof_r03_c3 gpurun_out/prof_r03_fwd2048 > profiles/r03_traffic.json
+usage: python tools/traffic_r03.py gpurun_out/prof_r03_c4 gpurun_out/prof_r03_c5 gpurun_out/prof_r03_c3 gpurun_out/prof_r03_fwd2048 gpurun_out/prof_r03_c4_both_axes > profiles/r03_traffic.json
 
 FETCH_SIZE and WRITE_SIZE come from separate passes; units KiB per dispatch; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md,
 HBM section).  A "logical step launch" = everything one time step of one pass of one batch runs.  `bench.py --steps 1 --warmup 1
 --no-e2e` runs 2 fits under the profiler."""
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import kernel_direction
+from bench import kernel_direction as _kd
+
+
+def kernel_direction(name):
+    # the axis-1 pre-pass (blhip_hwide.hpp) runs in both passes: its own row, per launch (two launches per time step of a full fit)
+    return 'prepass' if 'hwide_kernel' in name else _kd(name)
 
 FITS = 2
 SHAPES = dict(c4=dict(batches=2, T=256, cells=256 * 512 * 512, alg=(16, 32)), c5=dict(batches=4, T=1000, cells=62.5 * 512 * 512, alg=(16, 32)),
-              c3=dict(batches=1, T=2000, cells=1024 * 1024, alg=(16, 32)), fwd2048=dict(batches=1, T=200, cells=2048 * 2048, alg=(16, 32)))
+              c3=dict(batches=1, T=2000, cells=1024 * 1024, alg=(16, 32)), fwd2048=dict(batches=1, T=200, cells=2048 * 2048, alg=(16, 32)),
+              c4_both_axes=dict(batches=2, T=256, cells=256 * 512 * 512, alg=(16, 32)))
 
 
 def counters(sub):
@@ -47,7 +53,7 @@ for path in sys.argv[1:]:
                 cs[d].update(c)
     st = stats(path)
     res = {}
-    for d, alg in (('forward', sh['alg'][0]), ('backward', sh['alg'][1])):
+    for d, alg in (('forward', sh['alg'][0]), ('backward', sh['alg'][1]), ('prepass', 16)):
         c = cs.get(d)
         if not c:
             continue
