@@ -80,6 +80,11 @@ struct ChainParams {
     double *part; long long part_stride;       // [slot][T][G]
     const double *zeros;         // first launch of a batch (part_fresh): the slots hold nothing yet -- their cells are read from this 4 KB of
     int part_fresh;              //   zeros instead (same instruction count: no memset of the slots, no HBM read of them in this launch)
+    // Change-point batches whose backward pass folds (the stored states are private and never overwritten): every chain repeats the
+    // steps before its FIRST restart bit for bit.  tshare[b] > 0: chain b does not store its states of steps t < tshare[b]; the backward
+    // pass reads them from chain `bprov` of the batch (the chain with the latest first restart, which stores everything).
+    const int *tshare;           // [B] or nullptr
+    int bprov;
     unsigned *abort_word;
     unsigned long long timeout_ticks;
     unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     const long long o0 = tap >= 0 ? sldi(P.tap_off, tap) : 0;
     const int gj = tj * WCOL + (lane & 15);
     const long long G = (long long)P.n0 * P.n1;
+    const int tsh = P.tshare ? sldi(P.tshare, b) : 0;            // steps t < tsh: shared with chain P.bprov (see ChainParams)
 
     // ---- prologue: band, row coordinates, first source -> LDS ---------------------------------------------------------------------
     // the first step consumes its source unfiltered: it runs with the identity band (exact), the chain's band replaces it afterwards
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             gq0 = blr::ld_u64(gn); gq1 = blr::ld_u64(gn + 1);
         }
         // ---- what the NEXT step needs from HBM: its data record (its stored alpha: see the epilogue) --------------------------------
-        const double *const pnext = pchain + (long long)tn * G;
+        const double *const pnext = (BWD && tn < tsh ? P.post + (long long)P.bprov * P.post_stride : pchain) + (long long)tn * G;
         const int kind = kind_n & 0x7f;                          // what this step consumes; bit 7: ... without the filter
         const bool nofilter = FILTER && (kind_n & 0x80) != 0;
         if (P.kinds) kind_n = P.kinds[(long long)tn * P.B + b];
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 if (!BWD) {
                     const double a = (!PAD || (colok && li < n0t)) ? acc[r] * Lv : 0.0;          // (cells outside the grid stay zero)
                     if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
-                    if (STORE) stnt(pstep, off, a);
+                    if (STORE && t >= tsh) stnt(pstep, off, a);
                     sN += a;
                     if (!FILTER && want_x) sS = fma(a, rst[it][r], sS);
                     acc[r] = a;
@@ -573,11 +579,12 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cs2 = blockIdx.x / P.strips, tj = blockIdx.x - cs2 * P.strips;
     const int nch = min(2, P.nslots - 2 * cs2);                   // chains of this block (the last pair of a launch may be single)
-    int bch[2], tap[2], lw0[2];
+    int bch[2], tap[2], lw0[2], tshv[2];
     long long o0[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         bch[j] = sldi(P.chain_ids, 2 * cs2 + min(j, nch - 1));
+        tshv[j] = P.tshare ? sldi(P.tshare, bch[j]) : 0;              // steps t < tshv: the stored states are chain P.bprov's (see ChainParams)
         tap[j] = sldi(P.tap_id, bch[j]);
         lw0[j] = tap[j] >= 0 ? sldi(P.tap_lw, tap[j]) : 0;
         o0[j] = tap[j] >= 0 ? sldi(P.tap_off, tap[j]) : 0;
@@ -756,7 +763,8 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
         // the chain-step that runs after this one: chain 1 of this step, or chain 0 of the next (its stored alpha is requested now)
         const bool last_chain = j + 1 == nch;
         const int bnext = last_chain ? bch[0] : bch[1];
-        const double *const pnext = P.post + (long long)bnext * P.post_stride + (long long)(last_chain ? tn : t) * G;
+        const int tnext = last_chain ? tn : t;
+        const double *const pnext = P.post + (long long)(tnext < (last_chain ? tshv[0] : tshv[1]) ? P.bprov : bnext) * P.post_stride + (long long)tnext * G;
 
 #pragma unroll
         for (int it = 0; it < NTW; ++it) {

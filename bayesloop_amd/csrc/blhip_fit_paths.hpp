@@ -208,6 +208,10 @@ struct ChainRun {
     // fused fold with TWO chains per block (blc::chain_fold2_kernel): the backward pass runs rounds of 2 x cpr chains of its own
     bool fold2 = false;
     std::vector<int> round_start_b, round_nk_b;
+    bool share_prefix = false;                     // change-point batches: states before a chain's first restart are stored once (see setup)
+    long long shared_steps = 0;                    // chain-steps not stored
+    int *d_tshare = nullptr;
+    std::vector<int> h_tshare;
     const double *redF_keep = nullptr;             // the forward pass's reduced sums (slot 1: the restart sums of change-point batches)
     int slots_used = 0;                            // partial accumulators the backward launches write (one per block column)
     long long Gk = 0;                              // cells per distribution on the geometry the kernels work on (padded: >= G)
@@ -227,10 +231,11 @@ struct ChainRun {
         Gk = (long long)cp.n0p * cp.n1p;
         // (granule slots for 2 x cpr chains: the two-chain fold kernel runs rounds of that size)
         gran_bytes = carve_size((size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2 * 8);
-        ctx->resx.ensure(carve_size((size_t)B * 4) * 2 + gran_bytes + carve_size(64) + 2 * carve_size((size_t)T * B));
+        ctx->resx.ensure(carve_size((size_t)B * 4) * 3 + gran_bytes + carve_size(64) + 2 * carve_size((size_t)T * B));
         char *rc = ctx->resx.as<char>();
         d_order = carve<int>(rc, (size_t)B);
         int *d_tapid = carve<int>(rc, (size_t)B);
+        d_tshare = carve<int>(rc, (size_t)B);
         CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2);
         d_abort = carve<unsigned>(rc, 16);
         CQ.abort_word = d_abort;
@@ -285,6 +290,35 @@ struct ChainRun {
         // everything else keeps the launch-per-step kernels
         if (cp.pad && !(E.ff.evidence_only || post_private)) { on = false; fused = false; fold2 = false; return; }
         if (cp.pad && fused && !fold2) fused = false;      // (the one-chain folding kernel has no padded variant: store + separate fold)
+        // Change-point batches without a stencil whose backward pass folds: the chains are identical up to their first restart.  The chain
+        // with the LATEST first restart stores all its states; every other chain stores only from its own first restart on, and the
+        // folding backward pass reads the earlier ones from that chain (same values bit for bit: same kernel, same strips, same lagged
+        // scales).  Halves the forward pass's stores, and the backward pass's reads of those states hit the cache (the chains of a launch
+        // read the same rows at about the same time).  (Only when nothing overwrites the stored states: the fused fold.)
+        share_prefix = false;
+        if (fused && cp.has_reset && prog.LW0 == 0 && !cp.mixed && B >= 2 && ctx->option("share_prefix", 1.0) != 0.0) {
+            std::vector<int> tfirst((size_t)B, (int)T);
+            bool plain = true;
+            for (int64_t b = 0; b < B && plain; ++b) {
+                plain = prog.kindF[b] == SRC_PRIOR && cp.tap_id[b] < 0;
+                for (int64_t t = 1; t < T; ++t)
+                    if (prog.kindF[(size_t)t * B + b] != SRC_PREV) { tfirst[b] = (int)t; break; }
+            }
+            if (plain) {
+                int prov = 0;
+                for (int64_t b = 1; b < B; ++b) if (tfirst[b] > tfirst[prov]) prov = (int)b;
+                std::vector<int> tsh((size_t)B, 0);
+                long long saved = 0;
+                for (int64_t b = 0; b < B; ++b)
+                    if (b != prov) { tsh[b] = std::min(tfirst[b], tfirst[prov]); saved += tsh[b]; }
+                if (saved > 0) {
+                    HIPCHECK(hipMemcpyAsync(d_tshare, tsh.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
+                    sync_stream(ctx, E.st);
+                    share_prefix = true; shared_steps = saved; h_tshare = tsh;
+                    CQ.tshare = d_tshare; CQ.bprov = prov;
+                }
+            }
+        }
         if (fused) {
             ctx->accpart.ensure((size_t)slots_used * T * Gk * 8);
             ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(4096));
@@ -336,7 +370,13 @@ struct ChainRun {
                 const double cells = (double)Q.nslots * Gk * T;
                 const double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
                 const int r0 = (4 * rnk[r] - blc::TM) / 2;
-                account(ctx, bwd, cells * bytes, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
+                double shared = 0.0;                                  // stored states not written (forward) / read once per launch instead of once per chain (backward)
+                if (share_prefix && (bwd ? fold_now : !E.ff.evidence_only)) {
+                    long long sum = 0, mx = 0;
+                    for (int q = rstart[r]; q < rstart[r + 1]; ++q) { const long long v = h_tshare[cp.order[q]]; sum += v; mx = std::max(mx, v); }
+                    shared = (double)(bwd ? sum - mx : sum) * Gk * 8.0;
+                }
+                account(ctx, bwd, cells * bytes - shared, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
             }
 #ifdef BLC_PROF
             {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)

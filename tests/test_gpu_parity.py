@@ -992,6 +992,35 @@ def test_fused_fold_matches_the_separate_fold():
     np.testing.assert_allclose(A.localEvidence, B.localEvidence, rtol=1e-11, equal_nan=True)
 
 
+def test_change_point_chains_share_their_common_prefix():
+    """share_prefix (default on): the states before a chain's first restart are stored by ONE chain of the batch and read from there by
+    the folding backward pass of the others -- same numbers bit for bit as every chain storing its own copy (share_prefix = 0)."""
+    eng = bl.get_engine()
+    study_cases = [cases.CASES['c5_small'], EXTRA['x_cp_all'], RAGGED['pad_cp_150x40'],
+                   dict(study='ChangepointStudy', data=('series_jump', 95, 40, 18, 1.5), om=_g2(128, 48), tm=('ChangePoint', 'tc', ('arange', 1, 39, 2), None)),
+                   # two change points per chain: chains restart at different first steps, some share only a short prefix
+                   dict(study='ChangepointStudy', data=('series_jump', 96, 18, 9, 2.0), om=_g2(128, 16),
+                        tm=('Combined', [('ChangePoint', 't1', ('arange', 2, 16, 4), None), ('ChangePoint', 't2', ('arange', 3, 17, 5), None)]))]
+    for c in study_cases:
+        A = cases.build(bl, c); A.fit(silent=True)
+        assert A.lastTiming['fwd_kernel_variant'] == 6 and A.lastTiming['bwd_kernel_variant'] == 6 and A.lastTiming['resident_fallbacks'] == 0, A.lastTiming
+        eng.set_option('share_prefix', 0)
+        try:
+            B = cases.build(bl, c); B.fit(silent=True)
+        finally:
+            eng.set_option('share_prefix', 1)
+        assert A.logEvidence == B.logEvidence
+        assert np.array_equal(np.array(A.posteriorSequence), np.array(B.posteriorSequence), equal_nan=True)
+        assert np.array_equal(np.array(A.posteriorMeanValues), np.array(B.posteriorMeanValues), equal_nan=True)
+        assert A.lastTiming['bwd_hbm_bytes'] <= B.lastTiming['bwd_hbm_bytes'] and A.lastTiming['fwd_hbm_bytes'] <= B.lastTiming['fwd_hbm_bytes']
+        with np.errstate(all='ignore'):
+            want = oa.run(c)
+        compare.check(dict(logEvidence=A.logEvidence, localEvidence=A.localEvidence, posteriorSequence=A.posteriorSequence,
+                           posteriorMeanValues=A.posteriorMeanValues),
+                      dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'], posteriorSequence=want['posteriorSequence'],
+                           posteriorMeanValues=want['posteriorMeanValues']), compare.GPU_TOL)
+
+
 RAGGED = {
     # rows not 128 / 256 / 512 and / or columns not a multiple of 16: the chain-resident kernels on the padded geometry
     'pad_200x200_full': _hyper(200, 200, 81, 6, ('cint', 0, 0.7, 9)),
