@@ -32,9 +32,10 @@
 // Everything else keeps the launch-per-step kernels.  All tiles must be co-resident (grid <= number of CUs, one block per
 // CU by LDS size); every spin is bounded and a time-out makes the host fall back to the launch-per-step path.
 //
-// Algorithmic HBM traffic per cell and step: forward evidence-only 0 B (halos only: 4 x 8 x tile edge), with posterior
-// storage 8 B (write), backward 16 B (read alpha, write posterior).  bench.py still prices the forward step at the 16 B
-// of the streaming formulation, i.e. `achieved` may exceed what HBM could deliver.
+// HBM traffic per cell and step: the halo strips (2 R rows + 2 R columns of every tile, 16-byte tagged elements written and
+// read once: 8 B per cell at 128 x 128 tiles, 16 B at 64 x 64) + what the fit keeps: nothing (evidence-only), the stored state
+// 8 B (forward), stored state in + posterior out 16 B (backward).  bench.py reports these real bytes per kernel and, beside
+// them, the rate the streaming formulation's 16 / 32 B per cell would need.
 //
 // This header also compiles on the HOST (-DBLR_EMULATE, g++): tools/emu/resident_emu.cpp runs the per-thread phase
 // functions below sequentially to check the index / halo / publish logic against a direct evaluation (development aid).
@@ -369,7 +370,6 @@ struct Res {
 
     struct Thread {
         int tid, tile, ti, tj, i0, j0, tr, tc;       // (tile .. tc: block-uniform)
-        int whalf;                                   // 1: the second half of the block's waves (wave w and w + NW / 2 share a SIMD)
         double *lds;
         // registers that live across a barrier
         double nearv[R], farv[R];
@@ -388,7 +388,6 @@ struct Res {
 
         BLR_INL void init(const ResParams &Q, int block, int tid_, double *lds_) {
             tid = tid_; lds = lds_; dead = false;
-            whalf = uni((tid_ >> 6) >= NW / 2 ? 1 : 0);
             mq_c = 1.0; iq_c = 1.0; dn_prev = -1.0; nq_c = 0;
             tr = uni(Q.tr); tc = uni(Q.tc);
             tile = uni(tile_of_block(block, Q.ntiles));

@@ -197,8 +197,11 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
     };
 
     int bad = 0;
+    // (cells of the normalised distributions: the suite's bar, |dp| <= 1e-12 + 1e-9 p -- a cell 1e-200 of the maximum carries the
+    //  rounding of an exponent of ~ -500, a few 1e-11 relative after a 32-row recurrence; scalars keep their tight relative bars)
     auto check = [&](const char *what, double got, double want, double tol) {
-        if (!(std::fabs(got - want) <= tol * std::fabs(want) + 1e-300) && !(got != got && want != want)) {
+        const bool cell = what[0] == 'a' || what[0] == 'p';
+        if (!(std::fabs(got - want) <= (cell ? 1e-9 : tol) * std::fabs(want) + (cell ? 1e-12 : 1e-300)) && !(got != got && want != want)) {
             if (bad < 10) std::printf("  MISMATCH %s: got %.17g want %.17g\n", what, got, want);
             ++bad;
         }
