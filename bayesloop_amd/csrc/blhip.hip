@@ -1750,7 +1750,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         size_t max_ranges = 0;
         for (const auto &r : rangesF) max_ranges = std::max(max_ranges, r.size());
         for (const auto &r : rangesB) max_ranges = std::max(max_ranges, r.size());
-        const bool multistream = fast && !gp.wideH && max_ranges >= 2 && ctx->option("multistream", 1.0) != 0.0;
+        const bool multistream = fast && max_ranges >= 2 && ctx->option("multistream", 1.0) != 0.0;
         auto fork_streams = [&]() {
             if (!multistream) return;
             HIPCHECK(hipEventRecord(ctx->fork_ev, st));
@@ -1804,18 +1804,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 Q.psum_prev = ps_prev; Q.prev_slot = prev_slot; Q.psum_out = ps_out;
                 Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
                 const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
-                if (gp.wideH && (mode == MODE_FWD ? any_hF : any_hB)[t]) {
-                    // row filter of every chain of the step -> hsrc; the launches below consume it instead of their sources
-                    blh::HParams HP{};
-                    HP.n0 = g.n0; HP.n1 = g.n1; HP.tiles_j = (g.n1 + blh::CB - 1) / blh::CB; HP.lwmax = prog.LW1; HP.pitch = blh::pitch_for(prog.LW1);
-                    HP.src = srcp; HP.src_stride = src_stride;
-                    for (int k = 0; k < 5; ++k) HP.shared[k] = FP.shared[k];
-                    HP.srckind = Q.srckind; HP.tap1 = Q.tap1; HP.taps = d_taps; HP.tap_off = d_off; HP.tap_lw = d_lw; HP.dst = d_hsrc;
-                    launch_hwide(st, HP, (int)B);
-                    Q.hsrc = d_hsrc;
-                    const bool bw = mode != MODE_FWD;
-                    account(ctx, bw, (double)B * G * 16.0, (double)B * G * 2.0 * (2.0 * prog.LW1 + 8.0));
-                }
+                const bool prepass = gp.wideH && (mode == MODE_FWD ? any_hF : any_hB)[t];
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
                     Q.u_valid = 0;
@@ -1829,6 +1818,19 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                         Q.u_t1 = k1; Q.u_lw1 = k1 >= 0 ? taps.lw[k1] : 0; Q.u_off1 = k1 >= 0 ? taps.off[k1] : 0;
                     }
                     hipStream_t ls = multistream ? ctx->bstream[r.key] : st;
+                    if (prepass) {
+                        // row filter of the bucket's chains -> hsrc, on the bucket's stream: the launch below consumes it instead of its
+                        // sources; the buckets' streams overlap one bucket's (HBM-bound) pre-pass with another's (matrix-pipe-bound) step
+                        blh::HParams HP{};
+                        HP.n0 = g.n0; HP.n1 = g.n1; HP.tiles_j = (g.n1 + blh::CB - 1) / blh::CB; HP.lwmax = prog.LW1; HP.pitch = blh::pitch_for(prog.LW1);
+                        HP.src = srcp; HP.src_stride = src_stride;
+                        for (int k = 0; k < 5; ++k) HP.shared[k] = FP.shared[k];
+                        HP.chain_ids = Q.chain_ids;
+                        HP.srckind = Q.srckind; HP.tap1 = Q.tap1; HP.taps = d_taps; HP.tap_off = d_off; HP.tap_lw = d_lw; HP.dst = d_hsrc;
+                        launch_hwide(ls, HP, r.count);
+                        Q.hsrc = d_hsrc;
+                        account(ctx, mode != MODE_FWD, (double)r.count * G * 16.0, (double)r.count * G * 2.0 * (2.0 * prog.LW1 + 8.0));
+                    }
                     const bool on_pipe = use_mfma && (r.H ? (mfma_h && (double)r.count * g.n0 * g.n1 <= mfma_h_max_cells) : r.R0 >= mfma_min_r0);
                     if (on_pipe) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }
                     else { launch_fast(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_fast[mode == MODE_FWD ? 0 : 1]; }

@@ -40,6 +40,7 @@ struct HParams {
     int lwmax;                   // largest radius among the chains of the launch (sizes the LDS tile)
     const double *src; long long src_stride;
     const double *shared[5];
+    const int *chain_ids;        // [gridDim.y] -> chain of the batch (a bucket of the step: its launch follows on the same stream), or nullptr
     const unsigned char *srckind;
     const int *tap1;
     const double *taps; const int *tap_off; const int *tap_lw;
@@ -58,7 +59,7 @@ __device__ __forceinline__ int reflect1(int i, int n) {      // single-period ha
 __global__ __launch_bounds__(NT) void hwide_kernel(const HParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = P.chain_ids ? P.chain_ids[blockIdx.y] : (int)blockIdx.y;
     const int ti = blockIdx.x / P.tiles_j, tj = blockIdx.x - ti * P.tiles_j;
     const int i0 = ti * RB, j0 = tj * CB;
     const int rows = min(RB, P.n0 - i0), cols = min(CB, P.n1 - j0);
