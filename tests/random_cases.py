@@ -274,3 +274,42 @@ def random_chain_mixed_case(seed):
     study = 'ChangepointStudy' if seed % 3 else 'HyperStudy'
     flags = [dict(), dict(), dict(evidenceOnly=True)][int(rng.integers(0, 3))]
     return dict(study=study, data=('series_jump', 1900 + seed, T, T // 2, float(rng.uniform(-2, 2))), om=om, tm=('Combined', order), fit=flags)
+
+
+def random_wide_axis1_case(seed):
+    """Seeded studies whose random walk on the SECOND parameter is wider than the fused kernels' 8-column halo (radius 9 .. 64 grid steps):
+    the axis-1 pre-pass (blhip_hwide.hpp) in front of the streaming kernels -- single fits, hyper-studies over that width (small and wide
+    radii in one batch), walks on both parameters, change points on top, ragged grids, missing data, every fit flag."""
+    rng = np.random.default_rng(9000 + seed)
+    kind = ['study_both', 'study_axis1', 'hyper_both', 'hyper_axis1', 'cp_walk', 'hyper_pairs'][seed % 6]
+    T = int(rng.integers(2, 15))
+    flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
+    nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 3 else []
+    data = ('series_nan', 800 + seed, T, nan_at) if nan_at else ('series', 800 + seed, T)
+    n0, n1 = int(rng.integers(40, 301)), int(rng.integers(24, 421))
+    om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
+
+    def sigma(span, n, radius):
+        return max(radius, 0.3) / 4.0 * span / max(n - 1, 1)
+
+    r1 = int(rng.integers(9, min(64, n1 - 2) + 1))
+    r0 = int(rng.integers(0, 41))
+    s1, s2 = sigma(10, n0, r0), sigma(3, n1 + 2, r1)
+    nh = int(rng.integers(2, 6))
+    if kind == 'study_both':
+        return dict(study='Study', data=data, om=om, fit=flags,
+                    tm=('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)]))
+    if kind == 'study_axis1':
+        return dict(study='Study', data=data, om=om, tm=('GRW', 's2', s2, 'std', None), fit=flags)
+    if kind == 'hyper_both':
+        return dict(study='HyperStudy', data=data, om=om, fit=flags,
+                    tm=('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', ('cint', 0, s2, nh), 'std', None)]))
+    if kind == 'hyper_axis1':
+        return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's2', ('cint', sigma(3, n1 + 2, 2), s2, nh), 'std', None))
+    if kind == 'hyper_pairs':
+        return dict(study='HyperStudy', data=data, om=om, fit=flags,
+                    tm=('Combined', [('GRW', 's1', ('cint', 0, s1, int(rng.integers(2, 4))), 'mean', None),
+                                     ('GRW', 's2', ('cint', 0, s2, int(rng.integers(2, 4))), 'std', None)]))
+    T = max(T, 6)
+    return dict(study='ChangepointStudy', data=('series_jump', 900 + seed, T, T // 2, 2.0), om=om, fit=dict(),
+                tm=('Combined', [('ChangePoint', 'tc', ('arange', 1, T - 1, 2), None), ('GRW', 's2', s2, 'std', None)]))

@@ -662,6 +662,30 @@ def test_seeded_random_model_zoo_matches_oracle(seed):
     compare.check(got, gold, compare.GPU_TOL, case_tol=tol)
 
 
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 36))))
+def test_seeded_random_wide_axis1_walks_match_oracle(seed):
+    """Random walks on the second parameter with stencil radii 9 .. 64: the axis-1 pre-pass in front of the streaming kernels."""
+    c = random_cases.random_wide_axis1_case(seed)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+    # not the generic kernel -- unless the grid is outside the streaming kernels' envelope (rows < rounded axis-0 radius + 16, axis-1 radius > 64)
+    n0, n1 = [int(v) for v in S.gridSize]
+    def radius(tm, name, delta):
+        vals = [np.max(np.atleast_1d(t[2] if not isinstance(t[2], tuple) else t[2][2])) for t in (tm[1] if tm[0] == 'Combined' else [tm]) if t[0] == 'GRW' and t[3] == name]
+        return int(4.0 * max(vals) / delta + 0.5) if vals else 0
+    lw0, lw1 = radius(c['tm'], 'mean', 10.0 / (n0 - 1)), radius(c['tm'], 'std', 3.0 / (n1 + 1))
+    if lw1 <= 64 and n0 >= (lw0 + 7) // 8 * 8 + 16:
+        assert S.lastTiming['fwd_kernel_variant'] in (1, 3), (lw0, lw1, n0, n1, S.lastTiming)
+
+
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 32))))
 def test_seeded_random_hyper_studies_match_oracle(seed):
     c = random_cases.random_hyper_case(seed)
