@@ -17,8 +17,9 @@
 //     for every input x(m) of the 8 + 2 lw a row needs:  out[c] += W[m - c] x(m),  c = 0 .. 7
 // i.e. one LDS read per 8 FMAs instead of two per FMA (the weights W are block-uniform: LDS broadcast reads, 15 per 128 FMAs).
 // Lanes run along ROWS (odd LDS pitch: conflict-free), so results go back to the LDS tile and leave by coalesced stores.
-// Cost per cell: 8 B read + 8 B written (the read mostly from L2 / Infinity Cache: the previous kernel just wrote it) and
-// 2 lw + 8 + (up to 7) FMAs; at lw = 31 the vector pipe and HBM are about balanced (~0.5e12 cells/s each).
+// Cost per cell: 8 B read + 8 B written and 2 lw + 8 + (up to 7) FMAs.  Measured (profiles/r03_notes.md): 16.8 B of HBM traffic per cell
+// (a batch's states are hundreds of MB: nothing of the previous kernel's output is still in a cache) at 4.2 TB/s -- the kernel runs at the
+// memory roof; the host issues it per radius bucket on the bucket's stream, so that it overlaps another bucket's matrix-pipe-bound step.
 #pragma once
 #include <hip/hip_runtime.h>
 
