@@ -7,7 +7,7 @@
 // (blk::step_kernel), ~50 x slower.  Here the row filter runs as its own launch per step and the fused kernels then consume the
 // filtered state with their own axis-1 part switched off:
 //     hsrc[b] = H_b(source of chain b)           this kernel: reflect boundary (half-sample symmetric, scipy mode 'reflect'),
-//                                                runtime radius <= HW_MAX, one launch for all chains of the step
+//                                                runtime radius <= HW_MAX, one launch per radius bucket of the step
 //     state'  = epilogue(V_b(hsrc[b]))           fast / matrix-pipe step kernel with FastParams::hsrc set
 // (axis 1 before axis 0; the reference filters axis 0 first, transitionModels.py:645-649: separable reflect-boundary filters commute
 // exactly in real arithmetic, in floating point the results differ by rounding, ~1e-16, as in the fused kernels).
@@ -33,7 +33,7 @@ constexpr int NT = 256;
 constexpr int RB = 16;          // rows per block
 constexpr int CB = 256;         // columns per block
 constexpr int OC = 8;           // consecutive outputs per thread task
-constexpr int HW_MAX = 64;      // largest radius
+constexpr int HW_MAX = 256;     // largest radius (LDS: 16 rows x (256 + 2 x 256 + 15) doubles = 100 KB)
 
 struct HParams {
     int n0, n1, tiles_j;

@@ -277,7 +277,7 @@ def random_chain_mixed_case(seed):
 
 
 def random_wide_axis1_case(seed):
-    """Seeded studies whose random walk on the SECOND parameter is wider than the fused kernels' 8-column halo (radius 9 .. 64 grid steps):
+    """Seeded studies whose random walk on the SECOND parameter is wider than the fused kernels' 8-column halo (radius 9 .. 64 grid steps here; the kernel takes up to 256):
     the axis-1 pre-pass (blhip_hwide.hpp) in front of the streaming kernels -- single fits, hyper-studies over that width (small and wide
     radii in one batch), walks on both parameters, change points on top, ragged grids, missing data, every fit flag."""
     rng = np.random.default_rng(9000 + seed)

@@ -139,6 +139,9 @@ EXTRA = {
     'x_wide_h_cp': dict(study='ChangepointStudy', data=('series_jump', 45, 24, 12, 2.0), om=cases.gauss2d(40, -4, 6, 3),
                         tm=('Combined', [('ChangePoint', 'tChange', ('arange', 2, 22, 3), None),
                                          ('GRW', 'sigma', 0.4, 'std', None)])),                                             # restarts through the pre-pass
+    'x_wide_h_200': dict(study='Study', data=('series', 47, 6),
+                         om=('Gaussian', [('mean', ('cint', -4, 4, 64)), ('std', ('oint', 0, 3, 520))], 'default'),
+                         tm=('Combined', [('GRW', 's1', 0.3, 'mean', None), ('GRW', 's2', 0.29, 'std', None)])),             # axis-1 radius 201, three column blocks
     'x_wide_h_forward': dict(study='Study', data=('series', 46, 9), om=cases.gauss2d(72, -5, 5, 3),
                              tm=('Combined', [('GRW', 's1', 0.4, 'mean', None), ('GRW', 's2', 0.5, 'std', None)]),
                              fit=dict(forwardOnly=True)),
@@ -195,7 +198,7 @@ def test_wide_axis1_walks_take_the_streaming_kernels():
     """Axis-1 radii above 8 no longer drop a batch to the generic LDS-tile kernel (variant 0): pre-pass + streaming kernels
     (variants 1 / 3); wide_h = 0 restores the old routing, with the same results."""
     eng = bl.get_engine()
-    for name in ('x_wide_h', 'x_wide_h_only', 'x_wide_h_hyper', 'x_wide_h_hyper_axis1', 'x_wide_h_cp', 'x_tall_2d', 'x_hyper_many'):
+    for name in ('x_wide_h', 'x_wide_h_only', 'x_wide_h_hyper', 'x_wide_h_hyper_axis1', 'x_wide_h_cp', 'x_wide_h_200', 'x_tall_2d', 'x_hyper_many'):
         S = cases.build(bl, EXTRA[name])
         S.fit(silent=True)
         assert S.lastTiming['fwd_kernel_variant'] in (1, 3) and S.lastTiming['bwd_kernel_variant'] in (1, 3), (name, S.lastTiming)
@@ -676,13 +679,13 @@ def test_seeded_random_wide_axis1_walks_match_oracle(seed):
         if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
             gold[k] = np.asarray(want[k])
     compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
-    # not the generic kernel -- unless the grid is outside the streaming kernels' envelope (rows < rounded axis-0 radius + 16, axis-1 radius > 64)
+    # not the generic kernel -- unless the grid is outside the streaming kernels' envelope (rows < rounded axis-0 radius + 16, axis-1 radius > 256)
     n0, n1 = [int(v) for v in S.gridSize]
     def radius(tm, name, delta):
         vals = [np.max(np.atleast_1d(t[2] if not isinstance(t[2], tuple) else t[2][2])) for t in (tm[1] if tm[0] == 'Combined' else [tm]) if t[0] == 'GRW' and t[3] == name]
         return int(4.0 * max(vals) / delta + 0.5) if vals else 0
     lw0, lw1 = radius(c['tm'], 'mean', 10.0 / (n0 - 1)), radius(c['tm'], 'std', 3.0 / (n1 + 1))
-    if lw1 <= 64 and n0 >= (lw0 + 7) // 8 * 8 + 16:
+    if lw1 <= 256 and n0 >= (lw0 + 7) // 8 * 8 + 16:
         assert S.lastTiming['fwd_kernel_variant'] in (1, 3), (lw0, lw1, n0, n1, S.lastTiming)
 
 
