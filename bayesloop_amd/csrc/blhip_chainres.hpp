@@ -491,9 +491,11 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 
         // ---- sums: waves -> LDS (this step's parity); after the barrier wave 0 adds them up, writes the partial sums of the strip
         //      and publishes the one the scale of step k + lag is made of -----------------------------------------------------------------
-        double v[5] = {sN, BWD ? sS : sM0, BWD ? sC : sM1, BWD ? sM0 : sS, sM1};
-        constexpr int NV = BWD ? 5 : 4;                          // forward: N, M0, M1, X (the restart sum, no-stencil batches only)
-        const int nv = BWD ? (P.means ? 5 : 3) : ((!FILTER && P.kinds) ? 4 : (P.means ? 3 : 1));
+        double v[5] = {sN, sS, BWD ? sC : sM0, BWD ? sM0 : sM1, sM1};
+        constexpr int NV = BWD ? 5 : 4;                          // forward: N, X (the restart sum, no-stencil batches only), M0, M1
+        // (X sits in front of the means: a change-point batch without means reduces two sums per step, not four -- the four sums were
+        //  1.3 k of the 4.9 k cycles of a no-stencil chain-step)
+        const int nv = BWD ? (P.means ? 5 : 3) : (P.means ? 4 : ((!FILTER && P.kinds) ? 2 : 1));
         // (a full wave reduction costs ~45 vector instructions per sum and wave; the waves reduce only within their rows of 16 lanes
         //  -- 12 instructions -- and one wave adds the 32 row sums of the block after the barrier, in a fixed order)
         double *rk = red + (k & 1) * (NW * 4 * 5);
@@ -522,8 +524,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < NW * 4; ++w) tot += rk[w * 5 + lane];
-            const int slot = BWD ? lane : (lane == 0 ? 0 : (lane == 3 ? 1 : 2 + lane));          // forward: N, M0, M1, X -> slots 0, 3, 4, 1
-            if (lane == 0 || (BWD ? (P.means || lane < 3) : (lane == 3 || P.means))) P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
+            const int slot = BWD ? lane : (lane < 2 ? lane : lane + 1);                          // forward: N, X, M0, M1 -> slots 0, 1, 3, 4
+            if (lane == 0 || (BWD ? (P.means || lane < 3) : (lane == 1 ? (!FILTER && P.kinds != nullptr) : P.means != 0)))
+                P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
             if (lane == (BWD ? 2 : 0)) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
                 const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
