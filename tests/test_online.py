@@ -178,3 +178,19 @@ def test_online_study_seeded_random_models_match_oracle(seed):
     for i in range(len(S.transitionModels)):
         np.testing.assert_allclose(np.asarray([h[i] for h in S.hyperParameterSequence], dtype=float),
                                    np.asarray([h[i] for h in w['hyperParameterSequence']], dtype=float), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.gpu
+def test_online_study_with_wide_walk_on_the_second_parameter_matches_oracle():
+    """The resume path (one forward step per data point from carried states) through the axis-1 pre-pass (blhip_hwide.hpp): walks on 'std'
+    with stencil radii 32 and 81 beside a Static model."""
+    c = dict(om=('Gaussian', [('mean', ('cint', -5, 5, 64)), ('std', ('oint', 0, 3, 120))], 'default'),
+             models=[('wide', ('Combined', [('GRW', 'a', 0.3, 'mean', None), ('GRW', 'b', [0.2, 0.5], 'std', None)])),
+                     ('static', ('Static',))],
+             tm_prior=[0.6, 0.4], data=('series', 61, 8))
+    S = run_product_case(c)
+    with np.errstate(all='ignore'):
+        w = oa.run_online(c)
+    assert abs(S.logEvidence - w['logEvidence']) <= RTOL * abs(w['logEvidence'])
+    for key in ('posteriorSequence', 'posteriorMeanValues', 'transitionModelSequence', 'localTransitionModelSequence'):
+        np.testing.assert_allclose(np.asarray(getattr(S, key), dtype=float), np.asarray(w[key], dtype=float), rtol=RTOL, atol=ATOL, err_msg=key)
