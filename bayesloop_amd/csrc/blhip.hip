@@ -329,6 +329,14 @@ void launch_hwide(hipStream_t s, const blh::HParams &P, int nchains) {
     HIPCHECK(hipGetLastError());
 }
 
+void launch_vwide(hipStream_t s, const blh::HParams &P, int nchains) {
+    const size_t lds = blh::vlds_bytes(P.lwmax);
+    arm_kernel(reinterpret_cast<const void *>(&blh::vwide_kernel));
+    const dim3 grid((unsigned)(((P.n0 + blh::RV - 1) / blh::RV) * P.tiles_j), (unsigned)nchains);
+    hipLaunchKernelGGL(blh::vwide_kernel, grid, dim3(blh::NT), lds, s, P);
+    HIPCHECK(hipGetLastError());
+}
+
 void launch_fast(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, bool H, int nchains) {
     if (om == BLHIP_OM_GAUSSIAN) {
         if (mode == MODE_FWD) launch_fast_om<OM_GAUSSIAN, MODE_FWD>(s, P, R0, H, nchains);
@@ -902,6 +910,35 @@ std::vector<int64_t> plan_batches(const blhip_problem *p, int64_t n_chains, cons
     return start;
 }
 
+// One more cut where the axis-0 radius of a hyper-grid crosses the largest band of the matrix-pipe / chain-resident kernels (40): the
+// chains below it keep those kernels, the chains above it take the column pre-pass (blh::vwide_kernel) -- without the cut ONE wide chain
+// would route its whole batch through the pre-pass.  Only for grids sorted that way (every chain before the cut <= 40 < every chain after).
+void split_wide_axis0(const blhip_problem *p, int64_t n_chains, const double *op_values, std::vector<int64_t> &start) {
+    if (p->ndim != 2 || !op_values || p->n_ops == 0 || n_chains < 2) return;
+    auto radius0 = [&](int64_t c) {
+        int r0 = 0;
+        for (int k = 0; k < p->n_ops; ++k) {
+            const blhip_op &op = p->ops[k];
+            if (op.kind == BLHIP_OP_GRW && op.axis == 0) {
+                const double ns = op_values[c * p->n_ops + k] / p->lattice[0];
+                if (!(ns >= 0.0) || ns > 1e6) return -1;
+                r0 = std::max(r0, (int)(4.0 * ns + 0.5));
+            }
+        }
+        return r0;
+    };
+    int64_t cut = -1;
+    for (int64_t c = 0; c < n_chains; ++c) {
+        const int r = radius0(c);
+        if (r < 0) return;
+        if (r > FAST_R0_MAX) { if (cut < 0) cut = c; }
+        else if (cut >= 0) return;                   // a narrow chain after a wide one: not sorted by radius
+    }
+    if (cut <= 0) return;
+    for (int64_t v : start) if (v == cut) return;
+    start.insert(std::upper_bound(start.begin(), start.end(), cut), cut);
+}
+
 // ---- the phases of a fit: flags, shared tables (upload), memory plan; then per batch: program, geometry, metadata, forward pass +
 //      evidence bookkeeping, backward pass + bookkeeping, carried states / average posterior / kept posterior, results ------------
 struct FitFlags {
@@ -1041,6 +1078,7 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
 struct GeometryPlan {
     bool fast = false, fused1d = false, use_mfma = false;
     bool wideH = false;           // axis-1 walks wider than the fused kernels' halo: row filter as a pre-pass per step (blhip_hwide.hpp)
+    bool wideV = false;           // axis-0 walks wider than the matrix-pipe kernels' largest band: column filter as a pre-pass, no stencil left
     int64_t fusedK = 1;
     int f1_TJ = 128;
     Tile tile{};
@@ -1052,11 +1090,14 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
     GeometryPlan gp;
     const int64_t T = p->T;
     // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
+    const bool wide_h_ok = prog.LW1 <= blh::HW_MAX && prog.LW1 < g.n1 && ctx->option("wide_h", 1.0) != 0.0;
+    const bool wide_v = prog.LW0 > FAST_R0_MAX && prog.LW0 <= blh::VW_MAX && prog.LW0 < g.n0 && wide_h_ok && ctx->option("wide_v", 1.0) != 0.0;
     gp.fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
-                      ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && prog.LW0 <= FAST_R0_MAX &&
-                      (prog.LW1 <= blf::R1MAX || (prog.LW1 <= blh::HW_MAX && prog.LW1 < g.n1 && ctx->option("wide_h", 1.0) != 0.0)) &&
-                      g.n0 >= ((prog.LW0 + 7) / 8) * 8 + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
-    gp.wideH = gp.fast && prog.LW1 > blf::R1MAX;
+                      ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && (prog.LW0 <= FAST_R0_MAX || wide_v) &&
+                      (prog.LW1 <= blf::R1MAX || wide_h_ok) &&
+                      g.n0 >= (wide_v ? 0 : ((prog.LW0 + 7) / 8) * 8) + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
+    gp.wideV = gp.fast && wide_v;
+    gp.wideH = gp.fast && (prog.LW1 > blf::R1MAX || (gp.wideV && prog.LW1 > 0));       // (with a column pre-pass every filter runs as a pre-pass)
     if (p->ndim == 1 && !gp.fast && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
         gp.f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
@@ -1066,13 +1107,13 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
         gp.fused1d = (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 + (size_t)gp.fusedK * gp.f1_TJ * 32 + 4096 <= 150 * 1024;
     }
     if (gp.fast) {
-        gp.tile.TI = blf::CH; gp.tile.LW0 = prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && !gp.wideH) ? blf::R1MAX : 0;
+        gp.tile.TI = blf::CH; gp.tile.LW0 = gp.wideV ? 0 : prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && !gp.wideH) ? blf::R1MAX : 0;
         gp.tile.TJ = blf::BW - 2 * gp.tile.LW1;
         gp.tile.tiles_j = (g.n1 + gp.tile.TJ - 1) / gp.tile.TJ;
         // rows per block segment: long segments read every element once (+ 2*R0 halo rows per segment), short ones
         // give enough blocks to fill 256 CUs when there are few chains.  Model: cost = waves * blocks_per_CU * rows.
         const long long colblocks = (long long)gp.tile.tiles_j * B;
-        const int R0 = prog.LW0 == 0 ? 0 : ((prog.LW0 + 7) / 8) * 8;
+        const int R0 = (prog.LW0 == 0 || gp.wideV) ? 0 : ((prog.LW0 + 7) / 8) * 8;
         double best = 1e300;
         const int forceS = (int)ctx->option("fast_S", 0);
         for (int k = 1; k <= 4; k *= 2) {
@@ -1138,7 +1179,7 @@ struct DeviceMeta {
 };
 
 void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram &prog, TapTable &taps, int64_t B, bool full, bool fast, int nblk,
-                     DeviceMeta &M, bool wideH = false) {
+                     DeviceMeta &M, bool wideH = false, bool wideV = false) {
     hipStream_t st = ctx->stream;
     const int64_t T = p->T;
     const size_t nT = (size_t)T * B;
@@ -1179,15 +1220,15 @@ void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram 
         const long long min_blocks = (long long)ctx->option("min_bucket_blocks", 128.0);
         const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)nblk - 1) / nblk);
         // (wideH: the axis-1 filters run in the pre-pass, the fused kernels are launched without theirs)
-        const std::vector<int> no_h(wideH ? (size_t)B : 0, -1);
+        const std::vector<int> no_h((wideH || wideV) ? (size_t)B : 0, -1);
         M.h_orderF.resize(nT); M.rangesF.resize(T);
         for (int64_t t = 0; t < T; ++t)
-            bucket_step(&prog.tapF0[t * B], wideH ? no_h.data() : &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains);
+            bucket_step(wideV ? no_h.data() : &prog.tapF0[t * B], wideH ? no_h.data() : &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains);
         HIPCHECK(hipMemcpyAsync(M.orderF, M.h_orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
         if (full) {
             M.h_orderB.resize(nT); M.rangesB.resize(T);
             for (int64_t t = 0; t < T; ++t)
-                bucket_step(&prog.tapB0[t * B], wideH ? no_h.data() : &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains);
+                bucket_step(wideV ? no_h.data() : &prog.tapB0[t * B], wideH ? no_h.data() : &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains);
             HIPCHECK(hipMemcpyAsync(M.orderB, M.h_orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
         }
     }
@@ -1606,6 +1647,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         for (int64_t c = 0; c < n_chains; c += Bmax) batch_start.push_back(c);
         batch_start.push_back(n_chains);
     }
+    if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0) split_wide_axis0(p, n_chains, op_values, batch_start);
     const int64_t nbatch = (int64_t)batch_start.size() - 1;
     ctx->timing.batches = nbatch;
 
@@ -1649,7 +1691,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         // --- device metadata ---
         DeviceMeta M;
-        upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M, gp.wideH);
+        upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M, gp.wideH, gp.wideV);
         unsigned char *const d_kindF = M.kindF, *const d_kindB = M.kindB, *const d_cmodeF = M.cmodeF, *const d_cmodeB = M.cmodeB;
         double *const d_limitF = M.limitF, *const d_limitB = M.limitB;
         int *const d_tapF0 = M.tapF0, *const d_tapF1 = M.tapF1, *const d_tapB0 = M.tapB0, *const d_tapB1 = M.tapB1;
@@ -1771,17 +1813,20 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 if (ranges[ta][k].key != ranges[tb][k].key || ranges[ta][k].count != ranges[tb][k].count) return false;
             return std::equal(order.begin() + ta * B, order.begin() + (ta + 1) * B, order.begin() + tb * B);
         };
-        std::vector<char> any_hF, any_hB;
-        double *d_hsrc = nullptr;
-        if (gp.wideH) {
-            any_hF.assign(T, 0); any_hB.assign(T, 0);
+        std::vector<char> any_hF, any_hB, any_vF, any_vB;
+        double *d_hsrc = nullptr, *d_vsrc = nullptr;
+        if (gp.wideH || gp.wideV) {
+            any_hF.assign(T, 0); any_hB.assign(T, 0); any_vF.assign(T, 0); any_vB.assign(T, 0);
             for (int64_t t = 0; t < T; ++t)
                 for (int64_t b = 0; b < B; ++b) {
-                    if (prog.tapF1[t * B + b] >= 0) any_hF[t] = 1;
-                    if (full && prog.tapB1[t * B + b] >= 0) any_hB[t] = 1;
+                    if (gp.wideH && prog.tapF1[t * B + b] >= 0) any_hF[t] = 1;
+                    if (gp.wideH && full && prog.tapB1[t * B + b] >= 0) any_hB[t] = 1;
+                    if (gp.wideV && prog.tapF0[t * B + b] >= 0) any_vF[t] = 1;
+                    if (gp.wideV && full && prog.tapB0[t * B + b] >= 0) any_vB[t] = 1;
                 }
-            ctx->hsrc.ensure((size_t)B * G * 8);
+            ctx->hsrc.ensure((size_t)B * G * 8 * ((gp.wideH && gp.wideV) ? 2 : 1));
             d_hsrc = ctx->hsrc.as<double>();
+            d_vsrc = (gp.wideH && gp.wideV) ? d_hsrc + (size_t)B * G : d_hsrc;
         }
         const int mfma_min_r0 = (int)ctx->option("mfma_min_r0", 8);
         // both-axes launches: the matrix-pipe kernel wins while the launch is latency-bound (few cells per CU); with the chip
@@ -1805,6 +1850,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
                 const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
                 const bool prepass = gp.wideH && (mode == MODE_FWD ? any_hF : any_hB)[t];
+                const bool prepass_v = gp.wideV && (mode == MODE_FWD ? any_vF : any_vB)[t];
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
                     Q.u_valid = 0;
@@ -1830,6 +1876,18 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                         launch_hwide(ls, HP, r.count);
                         Q.hsrc = d_hsrc;
                         account(ctx, mode != MODE_FWD, (double)r.count * G * 16.0, (double)r.count * G * 2.0 * (2.0 * prog.LW1 + 8.0));
+                    }
+                    if (prepass_v) {
+                        // column filter of the bucket's chains (after the row filter, if there is one) -> the launch below runs without a stencil
+                        blh::HParams VP{};
+                        VP.n0 = g.n0; VP.n1 = g.n1; VP.tiles_j = (g.n1 + blh::CV - 1) / blh::CV; VP.lwmax = prog.LW0;
+                        VP.src = srcp; VP.src_stride = src_stride; VP.presrc = Q.hsrc;
+                        for (int k = 0; k < 5; ++k) VP.shared[k] = FP.shared[k];
+                        VP.chain_ids = Q.chain_ids;
+                        VP.srckind = Q.srckind; VP.tap1 = Q.tap0; VP.taps = d_taps; VP.tap_off = d_off; VP.tap_lw = d_lw; VP.dst = d_vsrc;
+                        launch_vwide(ls, VP, r.count);
+                        Q.hsrc = d_vsrc;
+                        account(ctx, mode != MODE_FWD, (double)r.count * G * 16.0, (double)r.count * G * 2.0 * (2.0 * prog.LW0 + 8.0));
                     }
                     const bool on_pipe = use_mfma && (r.H ? (mfma_h && (double)r.count * g.n0 * g.n1 <= mfma_h_max_cells) : r.R0 >= mfma_min_r0);
                     if (on_pipe) { launch_mfma(ls, p->obs_model, mode, Q, r.R0, r.H, r.count); ++n_mfma[mode == MODE_FWD ? 0 : 1]; }

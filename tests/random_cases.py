@@ -281,7 +281,7 @@ def random_wide_axis1_case(seed):
     the axis-1 pre-pass (blhip_hwide.hpp) in front of the streaming kernels -- single fits, hyper-studies over that width (small and wide
     radii in one batch), walks on both parameters, change points on top, ragged grids, missing data, every fit flag."""
     rng = np.random.default_rng(9000 + seed)
-    kind = ['study_both', 'study_axis1', 'hyper_both', 'hyper_axis1', 'cp_walk', 'hyper_pairs'][seed % 6]
+    kind = ['study_both', 'study_axis1', 'hyper_both', 'hyper_axis1', 'cp_walk', 'hyper_pairs', 'study_wide_v', 'hyper_wide_v'][seed % 8]
     T = int(rng.integers(2, 15))
     flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
     nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 3 else []
@@ -294,8 +294,18 @@ def random_wide_axis1_case(seed):
 
     r1 = int(rng.integers(9, min(64, n1 - 2) + 1))
     r0 = int(rng.integers(0, 41))
+    if kind.endswith('wide_v'):              # ... and on the FIRST parameter wider than the matrix-pipe kernels' band: the column pre-pass
+        n0 = int(rng.integers(150, 421))
+        om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
+        r0 = int(rng.integers(41, min(128, n0 - 2) + 1))
+        r1 = int(rng.integers(0, min(64, n1 - 2) + 1))
     s1, s2 = sigma(10, n0, r0), sigma(3, n1 + 2, r1)
     nh = int(rng.integers(2, 6))
+    if kind == 'study_wide_v':
+        return dict(study='Study', data=data, om=om, fit=flags,
+                    tm=('Combined', [('GRW', 's1', sigma(10, n0, r0), 'mean', None), ('GRW', 's2', sigma(3, n1 + 2, r1), 'std', None)]))
+    if kind == 'hyper_wide_v':
+        return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's1', ('cint', 0, sigma(10, n0, r0), nh), 'mean', None))
     if kind == 'study_both':
         return dict(study='Study', data=data, om=om, fit=flags,
                     tm=('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)]))

@@ -145,6 +145,22 @@ EXTRA = {
     'x_wide_h_forward': dict(study='Study', data=('series', 46, 9), om=cases.gauss2d(72, -5, 5, 3),
                              tm=('Combined', [('GRW', 's1', 0.4, 'mean', None), ('GRW', 's2', 0.5, 'std', None)]),
                              fit=dict(forwardOnly=True)),
+    # random walks on the FIRST parameter wider than the matrix-pipe kernels' largest band (radius 40): column pre-pass (blh::vwide_kernel)
+    'x_wide_v': dict(study='Study', data=('series', 51, 9),
+                     om=('Gaussian', [('mean', ('cint', -4, 4, 300)), ('std', ('oint', 0, 3, 40))], 'default'),
+                     tm=('GRW', 's1', 0.516, 'mean', None)),                                                               # radius 77, three row tiles
+    'x_wide_v_hyper': dict(study='HyperStudy', data=('series', 52, 10),
+                           om=('Gaussian', [('mean', ('cint', -5, 5, 400)), ('std', ('oint', 0, 3, 33))], 'default'),
+                           tm=('GRW', 'sigma', ('cint', 0, 0.7, 6), 'mean', None)),                                          # radii 9 .. 103 in one batch
+    'x_wide_both': dict(study='HyperStudy', data=('series', 53, 8),
+                        om=('Gaussian', [('mean', ('cint', -5, 5, 260)), ('std', ('oint', 0, 3, 200))], 'default'),
+                        tm=('Combined', [('GRW', 's1', ('cint', 0.1, 0.6, 3), 'mean', None), ('GRW', 's2', ('cint', 0.02, 0.2, 2), 'std', None)])),   # both pre-passes
+    'x_wide_v_narrow_h': dict(study='Study', data=('series', 54, 8),
+                              om=('Gaussian', [('mean', ('cint', -5, 5, 333)), ('std', ('oint', 0, 3, 70))], 'default'),
+                              tm=('Combined', [('GRW', 's1', 0.45, 'mean', None), ('GRW', 's2', 0.05, 'std', None)]), fit=dict(forwardOnly=True)),
+    'x_wide_v_cp': dict(study='ChangepointStudy', data=('series_jump', 55, 16, 8, 2.0),
+                        om=('Gaussian', [('mean', ('cint', -4, 6, 280)), ('std', ('oint', 0, 3, 24))], 'default'),
+                        tm=('Combined', [('ChangePoint', 'tChange', ('arange', 2, 14, 4), None), ('GRW', 'sigma', 0.5, 'mean', None)])),
     # edge shapes: a single time step, minimal grids, a first step without data, one hyper-grid point
     'x_single_step': dict(study='Study', data=np.array([2.5]), om=cases.gauss2d(64, -5, 5, 3),
                           tm=('Combined', [('GRW', 's1', 0.3, 'mean', None), ('GRW', 's2', 0.1, 'std', None)])),
@@ -209,6 +225,26 @@ def test_wide_axis1_walks_take_the_streaming_kernels():
             assert S0.lastTiming['fwd_kernel_variant'] == 0, (name, S0.lastTiming)
         finally:
             eng.set_option('wide_h', 1)
+        np.testing.assert_allclose(S.logEvidence, S0.logEvidence, rtol=1e-11)
+        np.testing.assert_allclose(S.posteriorMeanValues, S0.posteriorMeanValues, rtol=1e-9, atol=1e-12)
+
+
+def test_wide_axis0_walks_take_the_streaming_kernels():
+    """Axis-0 radii above 40 no longer drop a batch to the generic LDS-tile kernel: column pre-pass + the no-stencil streaming kernel
+    (variant 1); wide_v = 0 restores the old routing, with the same results."""
+    eng = bl.get_engine()
+    for name in ('x_wide_v', 'x_wide_v_hyper', 'x_wide_both', 'x_wide_v_narrow_h', 'x_wide_v_cp'):
+        c = EXTRA[name]
+        S = cases.build(bl, c)
+        S.fit(**cases.fit_kwargs(c))
+        assert S.lastTiming['fwd_kernel_variant'] == 1, (name, S.lastTiming)
+        eng.set_option('wide_v', 0)
+        try:
+            S0 = cases.build(bl, c)
+            S0.fit(**cases.fit_kwargs(c))
+            assert S0.lastTiming['fwd_kernel_variant'] == 0, (name, S0.lastTiming)
+        finally:
+            eng.set_option('wide_v', 1)
         np.testing.assert_allclose(S.logEvidence, S0.logEvidence, rtol=1e-11)
         np.testing.assert_allclose(S.posteriorMeanValues, S0.posteriorMeanValues, rtol=1e-9, atol=1e-12)
 
@@ -685,7 +721,7 @@ def test_seeded_random_wide_axis1_walks_match_oracle(seed):
         vals = [np.max(np.atleast_1d(t[2] if not isinstance(t[2], tuple) else t[2][2])) for t in (tm[1] if tm[0] == 'Combined' else [tm]) if t[0] == 'GRW' and t[3] == name]
         return int(4.0 * max(vals) / delta + 0.5) if vals else 0
     lw0, lw1 = radius(c['tm'], 'mean', 10.0 / (n0 - 1)), radius(c['tm'], 'std', 3.0 / (n1 + 1))
-    if lw1 <= 256 and n0 >= (lw0 + 7) // 8 * 8 + 16:
+    if lw1 <= 256 and (n0 >= (lw0 + 7) // 8 * 8 + 16 if lw0 <= 40 else (lw0 <= 128 and lw0 < n0)):
         assert S.lastTiming['fwd_kernel_variant'] in (1, 3), (lw0, lw1, n0, n1, S.lastTiming)
 
 
