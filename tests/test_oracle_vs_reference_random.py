@@ -78,6 +78,12 @@ def test_oracle_equals_reference_on_random_model_zoo(ref, seed):
     _check(ref, c, tol)
 
 
+@pytest.mark.parametrize('seed', range(24))
+def test_oracle_equals_reference_on_random_wide_walks(ref, seed):
+    """Walks on the second parameter with radii 9 .. 64 and on the first one with radii 41 .. 128 (the pre-pass kernels on the GPU side)."""
+    _check(ref, random_cases.random_wide_axis1_case(seed))
+
+
 @pytest.mark.parametrize('seed', range(40))
 def test_oracle_equals_reference_on_random_hyper_studies(ref, seed):
     _check(ref, random_cases.random_hyper_case(seed))
