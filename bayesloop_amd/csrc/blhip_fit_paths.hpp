@@ -80,18 +80,18 @@ struct ResidentRun {
         }
         if (!on) return;
         const size_t nt = (size_t)rp.ntiles;
-        // the halo strips hold TAGGED 16-byte elements (two doubles' room per value): the tags are what the consumers poll
+        // the halo strips hold TAGGED elements (the value with a one-bit tag in its sign bit): the tags are what the consumers poll
         const size_t n_cols = 2 * nt * 2 * blr::R * rp.TR, n_rows = 2 * nt * 2 * blr::R * rp.TC;
-        const size_t b_cols = carve_size(n_cols * 16), b_rows = carve_size(n_rows * 16);
+        const size_t b_cols = carve_size(n_cols * 8), b_rows = carve_size(n_rows * 8);
         const size_t b_w = carve_size(2 * (blr::R + 1) * 8) + carve_size((size_t)T * 8);
         flag_bytes = b_cols + b_rows + carve_size(blr::NSLOT * nt * 4 * 8) + carve_size(64);
         ctx->resx.ensure(b_w + flag_bytes);
         char *rc = ctx->resx.as<char>();
         double *d_w = carve<double>(rc, 2 * (blr::R + 1));
         d_sfwd = carve<double>(rc, (size_t)T);
-        RQ.cols = carve<double>(rc, 2 * n_cols);          // (everything polled is contiguous from here on: one memset per launch)
-        RQ.rows = carve<double>(rc, 2 * n_rows);
-        RQ.cols_bytes = (unsigned)(n_cols * 16); RQ.rows_bytes = (unsigned)(n_rows * 16);
+        RQ.cols = carve<double>(rc, n_cols);              // (everything polled is contiguous from here on: one memset per launch)
+        RQ.rows = carve<double>(rc, n_rows);
+        RQ.cols_bytes = (unsigned)(n_cols * 8); RQ.rows_bytes = (unsigned)(n_rows * 8);
         RQ.gran = carve<unsigned long long>(rc, blr::NSLOT * nt * 4);
         d_abort = carve<unsigned>(rc, 16);
         RQ.abort_word = d_abort;
@@ -137,8 +137,8 @@ struct ResidentRun {
         Q.prof = ctx->small.as<unsigned long long>();
 #endif
         launch_resident(st, rp, Q, bwd);
-        {   // HBM: the halo strips (2 R rows + 2 R columns of every tile, tagged 16-byte elements written and read once per step) + what the fit keeps
-            const double halo = 2.0 * 16.0 * 2.0 * blr::R * (rp.TR + rp.TC) / ((double)rp.TR * rp.TC);
+        {   // HBM: the halo strips (2 R rows + 2 R columns of every tile, 8-byte tagged elements written and read once per step) + what the fit keeps
+            const double halo = 2.0 * 8.0 * 2.0 * blr::R * (rp.TR + rp.TC) / ((double)rp.TR * rp.TC);
             const double kept = bwd ? 16.0 : (Q.store ? 8.0 : 0.0) + (Q.normalise ? 16.0 : 0.0);
             account(ctx, bwd, (double)E.G * T * (halo + kept), (double)E.G * T * (2.0 * valu_stencil_flop(blr::R) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
         }

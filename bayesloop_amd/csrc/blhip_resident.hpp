@@ -14,8 +14,10 @@
 //   * tiles exchange only halos, through HBM-side strips: the raw edge COLUMNS of the new state (consumed by the horizontal
 //     neighbours' axis-1 pass of the next step) and the axis-1-filtered edge ROWS (consumed by the vertical neighbours'
 //     axis-0 pass of the same step).  Point-to-point, no grid-wide barrier, no flags, no drains: THE DATA IS THE FLAG
-//     (cdna_hip_programming.md Guideline 16, form R2).  A strip element is 16 bytes {low word, tag, high word, tag} with
-//     tag = producing step + 1, written by ONE write-through (sc1) 16-byte store; each 8-byte half validates itself.  The
+//     (cdna_hip_programming.md Guideline 16, form R2).  A strip element is the 8-byte value itself with a ONE-BIT tag in its sign
+//     bit (everything handed over is >= +0; the bit flips with every reuse of a slot, see tag_bit), written by one write-through
+//     (sc1) store; clearing the bit gives the value back exactly.  (Round 3 began with 16-byte elements {low word, tag, high word,
+//     tag}: twice the halo traffic, which is as much as the payload at 64 x 64 tiles.)  The
 //     consumer requests its 8 elements with sc1 loads when its pass BEGINS, uses them chunks later and re-polls only the
 //     elements whose tags are not there yet (bounded).  Edge segments walk TOWARDS the tile edge, so the neighbour's strip
 //     is needed only for the last chunk of a pass; the hand-off costs one memory round trip that flies under the pass
@@ -32,8 +34,8 @@
 // Everything else keeps the launch-per-step kernels.  All tiles must be co-resident (grid <= number of CUs, one block per
 // CU by LDS size); every spin is bounded and a time-out makes the host fall back to the launch-per-step path.
 //
-// HBM traffic per cell and step: the halo strips (2 R rows + 2 R columns of every tile, 16-byte tagged elements written and
-// read once: 8 B per cell at 128 x 128 tiles, 16 B at 64 x 64) + what the fit keeps: nothing (evidence-only), the stored state
+// HBM traffic per cell and step: the halo strips (2 R rows + 2 R columns of every tile, 8-byte tagged elements written and
+// read once: 4 B per cell at 128 x 128 tiles, 8 B at 64 x 64) + what the fit keeps: nothing (evidence-only), the stored state
 // 8 B (forward), stored state in + posterior out 16 B (backward).  bench.py reports these real bytes per kernel and, beside
 // them, the rate the streaming formulation's 16 / 32 B per cell would need.
 //
@@ -75,8 +77,8 @@ struct ResParams {
     const double *m0, *m1, *colA, *colB, *rec;
     double step0;
     double *psum;                // [T][NRED][ntiles]
-    double *cols;                // [2][ntiles][2][R][TR] tagged 16-byte elements: raw edge columns of the new state (parity = step & 1)
-    double *rows;                // [2][ntiles][2][R][TC] tagged 16-byte elements: axis-1-filtered edge rows
+    double *cols;                // [2][ntiles][2][R][TR] tagged elements (8 bytes: the value, the tag in its sign bit): raw edge columns of the new state (parity = step & 1)
+    double *rows;                // [2][ntiles][2][R][TC] tagged elements: axis-1-filtered edge rows
     unsigned cols_bytes, rows_bytes;
     unsigned long long *gran;    // [NSLOT][ntiles][4] {tag << 32 | half of a double}: the scale sum, the row sum (backward)
     unsigned *abort_word;
@@ -101,16 +103,17 @@ BLR_INL double ldu(const double *p, long long i) { return p[i]; }
 BLR_INL int uni(int x) { return x; }
 BLR_INL double ld_stream(const double *p) { return *p; }
 BLR_INL void st_stream(double *p, double v) { *p = v; }
-struct Tq { unsigned lo, t0, hi, t1; };          // a tagged strip element
+typedef unsigned long long Tq;                   // a tagged strip element: the value's bits, the tag in the sign bit
 typedef char *Rsrc;
 BLR_INL Rsrc strip_rsrc(double *p, unsigned) { return reinterpret_cast<char *>(p); }
-BLR_INL void st_tq(Rsrc r, unsigned off, double v, unsigned tag) {
+BLR_INL void st_tq(Rsrc r, unsigned off, double v, unsigned bit) {
     unsigned long long b; std::memcpy(&b, &v, 8);
-    const Tq q{(unsigned)b, tag, (unsigned)(b >> 32), tag};
-    std::memcpy(r + off, &q, 16);
+    assert((b >> 63) == 0 && "strip values are non-negative");
+    b |= (unsigned long long)bit << 63;
+    std::memcpy(r + off, &b, 8);
 }
-BLR_INL Tq ld_tq(Rsrc r, unsigned off) { Tq q; std::memcpy(&q, r + off, 16); return q; }
-BLR_INL double tq_value(const Tq &q) { const unsigned long long b = (unsigned long long)q.lo | ((unsigned long long)q.hi << 32); double v; std::memcpy(&v, &b, 8); return v; }
+BLR_INL Tq ld_tq(Rsrc r, unsigned off) { Tq q; std::memcpy(&q, r + off, 8); return q; }
+BLR_INL double tq_value(Tq q) { q &= ~(1ull << 63); double v; std::memcpy(&v, &q, 8); return v; }
 #else
 typedef unsigned long long __attribute__((address_space(1))) gu64;
 typedef unsigned __attribute__((address_space(1))) gu32;
@@ -139,23 +142,31 @@ BLR_INL int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }       // a 
 // the stored sequence is written / read once per pass (C3: 16 GiB): non-temporal hints keep it from sweeping the caches
 BLR_INL double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
 BLR_INL void st_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
-// tagged strip elements through a buffer descriptor: ONE 16-byte write-through store / ONE 16-byte sc1 load each (aux 16 = sc1)
-struct Tq { unsigned lo, t0, hi, t1; };
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// tagged strip elements through a buffer descriptor: ONE 8-byte write-through store / ONE 8-byte sc1 load each (aux 16 = sc1)
+typedef unsigned long long Tq;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 BLR_INL Rsrc strip_rsrc(double *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
-BLR_INL void st_tq(Rsrc r, unsigned off, double v, unsigned tag) {
+BLR_INL void st_tq(Rsrc r, unsigned off, double v, unsigned bit) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const u32x4 q = {(unsigned)b, tag, (unsigned)(b >> 32), tag};
-    __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)off, 0, 16);
+    const u32x2 q = {(unsigned)b, (unsigned)(b >> 32) | (bit << 31)};
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, (int)off, 0, 16);
 }
 BLR_INL Tq ld_tq(Rsrc r, unsigned off) {
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16);
-    return Tq{q.x, q.y, q.z, q.w};
+    const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 16);
+    return (unsigned long long)q.x | ((unsigned long long)q.y << 32);
 }
-BLR_INL double tq_value(const Tq &q) { return __longlong_as_double((long long)((unsigned long long)q.lo | ((unsigned long long)q.hi << 32))); }
+BLR_INL double tq_value(Tq q) { return __longlong_as_double((long long)(q & ~(1ull << 63))); }
 #endif
-BLR_INL bool tq_ok(const Tq &q, unsigned tag) { return q.t0 == tag && q.t1 == tag; }
+// The tag: ONE bit, in the sign bit of the value.  Everything the tiles hand over -- a state, or a state filtered with positive weights -- is
+// >= +0, so the sign bit is free, and clearing it gives the value back exactly.  A strip slot (step parity) is rewritten every second
+// step and a tile is never more than a step ahead of its neighbour, so the bit only has to tell a step from the one two steps before:
+// it starts at 1 with a slot's first use (the strips are zeroed before every launch) and flips with every reuse.
+BLR_INL unsigned tag_bit(unsigned epoch, bool rows) {               // epoch = producing step + 1 (rows are first produced at step 1)
+    const unsigned ks = epoch - 1u;
+    return 1u - ((((rows ? ks - 1u : ks)) >> 1) & 1u);
+}
+BLR_INL bool tq_ok(Tq q, unsigned bit) { return (unsigned)(q >> 63) == bit; }
 
 // a neighbour's strip: R tagged elements at byte offsets off0 + q * dstep (q = 0 .. R-1 in the consumer's walking order)
 BLR_INL void strip_issue(Rsrc rs, int off0, int dstep, Tq (&fq)[R]) {
@@ -551,13 +562,13 @@ struct Res {
             // the neighbour's raw edge columns of step k - 1 (tag k): element [(k-1) & 1][nb][side][cc][row], cc towards the far side
             const Rsrc rs = strip_rsrc(Q.cols, Q.cols_bytes);
             const int e0 = (((((k - 1) & 1) * Q.ntiles + hg.nb) * 2 + hg.side) * R + (hg.side == 1 ? R - 1 : 0)) * TR + hg.line;
-            const int dstep = (hg.side == 1 ? -TR : TR) * 16;
+            const int dstep = (hg.side == 1 ? -TR : TR) * 8;
             Tq fq[R];
-            auto far_issue = [&]() { if (EARLY && hg.far == 2) strip_issue(rs, e0 * 16, dstep, fq); };
+            auto far_issue = [&]() { if (EARLY && hg.far == 2) strip_issue(rs, e0 * 8, dstep, fq); };
             auto far_fetch = [&](double (&f)[R]) {
                 if (hg.far == 2) {
-                    if (!EARLY) strip_issue(rs, e0 * 16, dstep, fq);
-                    if (!strip_finish(Q, rs, e0 * 16, dstep, (unsigned)k, fq, f)) dead = true;
+                    if (!EARLY) strip_issue(rs, e0 * 8, dstep, fq);
+                    if (!strip_finish(Q, rs, e0 * 8, dstep, tag_bit((unsigned)k, false), fq, f)) dead = true;
                 }
             };
             auto emit8 = [&](int p0, const double (&v)[CHK]) {
@@ -598,17 +609,17 @@ struct Res {
                     }
 #pragma unroll
                     for (int it = 0; it < HALF; ++it)
-                        st_tq(rs, ((unsigned)(base + side * R * EDGE + it * NT) + t) * 16u, v[it], tag);
+                        st_tq(rs, ((unsigned)(base + side * R * EDGE + it * NT) + t) * 8u, v[it], tag);
                 }
             }
         }
         BLR_INL void publish_rows(const ResParams &Q, int k) {          // [side][rr][col]
-            publish_strip<TC>(strip_rsrc(Q.rows, Q.rows_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TC, (unsigned)(k + 1), ti > 0, ti < tr - 1,
+            publish_strip<TC>(strip_rsrc(Q.rows, Q.rows_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TC, tag_bit((unsigned)(k + 1), true), ti > 0, ti < tr - 1,
                               [&](int side, unsigned rr, unsigned col) { return lds[((side ? TR - R : 0) + rr) * P + col]; });
         }
         // after the axis-0 pass + epilogue (barrier): the new state's edge columns -> strips of step k  [side][cc][row]
         BLR_INL void publish_cols(const ResParams &Q, int k) {
-            publish_strip<TR>(strip_rsrc(Q.cols, Q.cols_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TR, (unsigned)(k + 1), tj > 0, tj < tc - 1,
+            publish_strip<TR>(strip_rsrc(Q.cols, Q.cols_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TR, tag_bit((unsigned)(k + 1), false), tj > 0, tj < tc - 1,
                               [&](int side, unsigned cc, unsigned row) { return lds[row * P + (side ? TC - R : 0) + cc]; });
         }
 
@@ -735,13 +746,13 @@ struct Res {
             // the neighbour's axis-1-filtered edge rows of THIS step (tag k + 1): element [k & 1][nb][side][rr][col]
             const Rsrc rs = strip_rsrc(Q.rows, Q.rows_bytes);
             const int e0 = ((((k & 1) * Q.ntiles + vg.nb) * 2 + vg.side) * R + (vg.side == 1 ? R - 1 : 0)) * TC + vg.line;
-            const int dstep = (vg.side == 1 ? -TC : TC) * 16;
+            const int dstep = (vg.side == 1 ? -TC : TC) * 8;
             Tq fq[R];
-            auto far_issue = [&]() { if (EARLY && vg.far == 2) strip_issue(rs, e0 * 16, dstep, fq); };
+            auto far_issue = [&]() { if (EARLY && vg.far == 2) strip_issue(rs, e0 * 8, dstep, fq); };
             auto far_fetch = [&](double (&f)[R]) {
                 if (vg.far == 2) {
-                    if (!EARLY) strip_issue(rs, e0 * 16, dstep, fq);
-                    if (!strip_finish(Q, rs, e0 * 16, dstep, (unsigned)(k + 1), fq, f)) dead = true;
+                    if (!EARLY) strip_issue(rs, e0 * 8, dstep, fq);
+                    if (!strip_finish(Q, rs, e0 * 8, dstep, tag_bit((unsigned)(k + 1), true), fq, f)) dead = true;
                 }
             };
             // (requested right before the chunk's arithmetic.  Requesting the one-chunk shapes' 16 HBM-missing loads per thread earlier --

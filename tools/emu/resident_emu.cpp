@@ -124,7 +124,7 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
     // ---- emulation ---------------------------------------------------------------------------------------------------------------
     const int ntiles = tr * tc;
     std::vector<double> gpost((size_t)T * G, 0.0), uniform(G, 1.0 / G);
-    std::vector<double> cols((size_t)2 * 2 * ntiles * 2 * R * TR), rows((size_t)2 * 2 * ntiles * 2 * R * TC);      // tagged 16-byte elements
+    std::vector<double> cols((size_t)2 * ntiles * 2 * R * TR), rows((size_t)2 * ntiles * 2 * R * TC);      // tagged 8-byte elements
     std::vector<unsigned long long> gran((size_t)NSLOT * ntiles * 4);
     unsigned abort_word = 0;
     ResParams Q{};
