@@ -830,8 +830,9 @@ struct Res {
 namespace blr {
 
 // block barrier that orders LDS accesses only: the write-through strip stores (and the stored sequence's stores / loads) stay in
-// flight across it.  __syncthreads() would wait for every outstanding store's acknowledgement (vmcnt(0)) -- a memory round trip
-// per barrier, four barriers per step.
+// flight across it.  (hipcc 7.2 compiles __syncthreads() to the same `s_waitcnt lgkmcnt(0); s_barrier` in this kernel -- checked in the
+// ISA -- but a fence over all address spaces is allowed to wait for vmcnt(0); the explicit form does not depend on that.  What did
+// wait for the stores' acknowledgements in round 2 was the drain in front of the epoch flags, gone with the flags.)
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
