@@ -166,7 +166,9 @@ BLR_INL unsigned tag_bit(unsigned epoch, bool rows) {               // epoch = p
     const unsigned ks = epoch - 1u;
     return 1u - ((((rows ? ks - 1u : ks)) >> 1) & 1u);
 }
-BLR_INL bool tq_ok(Tq q, unsigned bit) { return (unsigned)(q >> 63) == bit; }
+// (a NaN counts as arrived whatever its sign: a degenerate fit -- zero normaliser, NaN state -- must not spin until the time-out; NaN
+//  states stay NaN, so a stale one is as good as a fresh one, and the host rejects the pass by its sums anyway)
+BLR_INL bool tq_ok(Tq q, unsigned bit) { return (unsigned)(q >> 63) == bit || (q & 0x7fffffffffffffffull) > 0x7ff0000000000000ull; }
 
 // a neighbour's strip: R tagged elements at byte offsets off0 + q * dstep (q = 0 .. R-1 in the consumer's walking order)
 BLR_INL void strip_issue(Rsrc rs, int off0, int dstep, Tq (&fq)[R]) {

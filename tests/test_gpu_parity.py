@@ -834,6 +834,23 @@ def test_resident_kernel_matches_oracle(case):
     compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
 
 
+def test_resident_kernel_degenerate_fit_does_not_stall():
+    """A data point no grid cell can explain (likelihood exactly zero everywhere): the normaliser is zero, the states turn inf / NaN.  The
+    tiles' hand-off (tag = sign bit of the value) accepts NaN elements, the host rejects the pass by its sums and the launch-per-step
+    kernels reproduce the reference's result (logEvidence = -inf, core.py:390-400) -- without waiting for the resident kernel's time-out."""
+    import time
+    x = cases.series(28, 10)
+    x[4] = 1.0e6
+    c = dict(study='Study', data=x, om=_g2(128, 128), tm=_grw2(0.3, 0.1))
+    S = cases.build(bl, c)
+    t0 = time.time()
+    with np.errstate(all='ignore'):
+        S.fit(silent=True)
+        want = oa.run(c)
+    assert time.time() - t0 < 1.5                                   # (resident_timeout_s = 2 is never reached)
+    assert S.logEvidence == want['logEvidence'] == -np.inf
+
+
 @pytest.mark.parametrize('lag', [1, 2, 3, 4])
 def test_resident_kernel_lag_and_determinism(lag):
     """The lagged normaliser (resident_lag = 1 .. 4) only changes intermediate magnitudes; repeated runs are bit-identical
