@@ -356,6 +356,10 @@ struct Res {
     // a neighbour's strip is requested when the pass begins, 2+ chunks before it is used (32 registers per thread in flight; the
     // multi-chunk backward shape has none to spare and requests it where it needs it)
     static constexpr bool EARLY = ONE || !BWD;
+    // a step's data record is requested a step AHEAD (under the last chunk of the previous axis-0 pass, see v_walk_d) -- except by
+    // the multi-chunk backward kernel, which requests it when the step begins: with the record's registers alive across the whole
+    // step that kernel went from 80 to 254 spilled VGPRs and its step from 25.5 to 44.7 us (2048^2 full fit)
+    static constexpr bool REC_AHEAD = !(BWD && !ONE);
     // The lagged global sum is gathered by HALF of the block's waves -- the half that reaches the barrier after the axis-1 pass early
     // (multi-chunk shapes: the edge segments, dealt to the first waves, have issue priority over their SIMD partners; one-chunk
     // shapes: the edge waves wait for their neighbours there, the others are early) -- in that slack, not by everybody after it.
@@ -767,7 +771,7 @@ struct Res {
             static_assert(!REC_IN_PASS || (SEG - CHK) % ANCHOR != 0, "the last chunk has no anchor (its epilogue does not read the record)");
             auto pre8 = [&](int p0) {
                 load_alpha8<DIR>(pt0, ptn0, Q.n1, p0);
-                if (REC_IN_PASS && p0 == SEG - CHK && k + 1 < Q.T) begin_step(Q, k + 1);
+                if (REC_AHEAD && REC_IN_PASS && p0 == SEG - CHK && k + 1 < Q.T) begin_step(Q, k + 1);
             };
             auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc); };
             double wk[R + 1];
@@ -775,7 +779,7 @@ struct Res {
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
             if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
             else walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
-            if (!REC_IN_PASS && k + 1 < Q.T) begin_step(Q, k + 1);
+            if (REC_AHEAD && !REC_IN_PASS && k + 1 < Q.T) begin_step(Q, k + 1);
         }
         BLR_INL void v_walk(const ResParams &Q, int k) {
             const Geo vg = vgeo();
@@ -804,7 +808,7 @@ struct Res {
                 load_alpha8<DIR>(pt0, nullptr, Q.n1, p0);
                 epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, BWD ? 1.0 / Q.n_first : 1.0, p0, v, 1.0, rc, cc);
             }
-            if (Q.T > 1) begin_step(Q, 1);
+            if (REC_AHEAD && Q.T > 1) begin_step(Q, 1);
         }
         BLR_INL void first_step(const ResParams &Q) { const Geo vg = vgeo(); if (vg.seg == 0) first_step_d<-1>(Q, vg); else first_step_d<1>(Q, vg); }
     };
@@ -899,6 +903,7 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
     };
     for (int k = 0; k < Q.T; ++k) {
         BLR_STAMP(0);
+        if (!K::REC_AHEAD && k > 0) th.begin_step(Q, k);
         if (k == 0) {
             th.begin_step(Q, k);
             th.first_step(Q);
