@@ -410,20 +410,27 @@ void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, si
 // ---- time-resident path (blhip_resident.hpp): one launch for all time steps of a single-chain 2-D fit ----------------------------
 struct ResidentPlan {
     int TR = 0, TC = 0, SEG = 0, tr = 0, tc = 0, ntiles = 0, NT = 0;
+    bool pad = false;            // the grid does not fill its last tile row / column (PAD kernels)
     size_t lds_bytes = 0;
 };
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID>
+template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID, bool PAD = false>
 void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
-    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID>::LDS_DOUBLES * sizeof(double);
-    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID>));
-    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID, PAD>::LDS_DOUBLES * sizeof(double);
+    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>));
+    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
 }
 
 template <int TR, int TC, int SEG, int CHK>
-void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd) {
+void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad = false) {
     // forward pass of an evidence-only fit: nothing stored, no means, no rows to normalise -> the flavour with compile-time flags
     const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
+    if (pad) {                   // grids that do not fill their last tile row / column
+        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, true>(s, Q);
+        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, true>(s, Q);
+        else launch_resident_k<TR, TC, SEG, CHK, false, false, true>(s, Q);
+        return;
+    }
     if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false>(s, Q);
     else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true>(s, Q);
     else launch_resident_k<TR, TC, SEG, CHK, false, false>(s, Q);
@@ -438,10 +445,10 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
         if (bwd || Q.store || Q.means || Q.normalise || Q.post) fail("internal: the 1024-thread resident shape runs evidence-only forward passes only");
         launch_resident_k<128, 128, 16, 4, false, true>(s, Q);
     }
-    else if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd);
-    else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd);
-    else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd);
-    else launch_resident_t<32, 32, 8, 8>(s, Q, bwd);
+    else if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd, rp.pad);
+    else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd, rp.pad);
+    else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd, rp.pad);
+    else launch_resident_t<32, 32, 8, 8>(s, Q, bwd, rp.pad);
     HIPCHECK(hipGetLastError());
 }
 
@@ -541,16 +548,24 @@ void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
 // the smallest supported tile whose tile grid fits the chip (every tile = one co-resident block)
 // (Two 256-thread blocks per CU -- 512 tiles of 32 x 64 for the 1024^2 grid, so that one block computes while the other waits for a
 // strip -- was tried: the 512 blocks were not all co-resident, the hand-off waits timed out and the fit fell back.  One tile per CU.)
-bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp, int seg128 = 32) {
+// A grid that does not fill its last tile row / column runs the PAD kernels (blhip_resident.hpp): the remainder of such an axis and the
+// padding behind it must both be at least one stencil radius (the mirror image beyond the true edge lives inside the last tile and is
+// made of that tile's own cells).  Grids whose sizes are multiples of a tile shape are preferred (no masks).
+bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp, int seg128 = 32, bool allow_pad = true) {
     const int shapes[4][3] = {{32, 32, 8}, {32, 64, 8}, {64, 64, 8}, {128, 128, seg128}};
-    for (const auto &sh : shapes) {
-        if (n0 % sh[0] || n1 % sh[1]) continue;
-        const long long nt = (long long)(n0 / sh[0]) * (n1 / sh[1]);
-        if (nt > cus) continue;
-        rp.TR = sh[0]; rp.TC = sh[1]; rp.SEG = sh[2]; rp.tr = n0 / sh[0]; rp.tc = n1 / sh[1]; rp.ntiles = (int)nt;
-        rp.NT = sh[0] * sh[1] / sh[2];
-        return true;
-    }
+    for (int pass = 0; pass < (allow_pad ? 2 : 1); ++pass)
+        for (const auto &sh : shapes) {
+            auto fits = [&](int n, int t) { const int rem = n % t; return rem == 0 || (pass == 1 && n > t && rem >= blr::R && t - rem >= blr::R); };
+            if (!fits(n0, sh[0]) || !fits(n1, sh[1])) continue;
+            if (pass == 1 && sh[2] != sh[0] && sh[0] == 128 && seg128 != 32) continue;       // (the 1024-thread option shape has no PAD variant)
+            const int tr = (n0 + sh[0] - 1) / sh[0], tc = (n1 + sh[1] - 1) / sh[1];
+            const long long nt = (long long)tr * tc;
+            if (nt > cus) continue;
+            rp.TR = sh[0]; rp.TC = sh[1]; rp.SEG = sh[2]; rp.tr = tr; rp.tc = tc; rp.ntiles = (int)nt;
+            rp.NT = sh[0] * sh[1] / sh[2];
+            rp.pad = (n0 % sh[0]) != 0 || (n1 % sh[1]) != 0;
+            return true;
+        }
     return false;
 }
 

@@ -65,7 +65,7 @@ struct ResidentRun {
         if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blr::DMAX &&
             prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
             plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
-                          (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32)) {
+                          (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0)) {
             on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
             const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
             for (int64_t t = 1; t < T && on; ++t)

@@ -318,6 +318,8 @@ BLR_INL void walk_full(const double (&nearv)[R], const double (&own)[SEG], doubl
     }
 }
 
+BLR_INL int min_(int a, int b) { return a < b ? a : b; }
+
 // keep the optimiser from hoisting a thread's (time-invariant) address arithmetic out of the time loop: hoisted, the
 // addresses of every row / column a thread touches stay live across the whole step and spill (598 spilled VGPRs measured)
 BLR_INL int launder(int x) {
@@ -327,10 +329,17 @@ BLR_INL int launder(int x) {
     return x;
 }
 
-template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, bool EVID_ = false>
+template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, bool EVID_ = false, bool PAD_ = false>
 struct Res {
     static constexpr int TR = TR_, TC = TC_, SEG = SEG_, CHK = CHK_;    // CHK: outputs per chunk of a pass
     static constexpr bool BWD = BWD_;
+    // PAD: the grid does not fill its last tile row / column (n0 < tr * TR or n1 < tc * TC; at least R cells of padding where there is
+    // any).  The kernel works on the tiles' geometry: cells outside the grid are kept at ZERO and out of every sum and store, except the
+    // R rows / columns next to the grid's true edge, which hold the MIRROR image of the cells inside (rewritten after every step:
+    // mirror_edges) -- so the plain stencil of the two passes IS the half-sample-reflecting one for every cell of the grid, and the
+    // strips the last tiles hand to their neighbours carry the right values.  Row coordinates continue the lattice beyond the grid (the
+    // likelihood recurrence runs through padded rows).
+    static constexpr bool PAD = PAD_;
     // EVID: forward pass of an evidence-only fit -- nothing is stored, no means, no rows to normalise: the flags of ResParams are
     // compile-time constants (fewer live values: the many-threads shape has 128 registers per thread)
     static constexpr bool EVID = EVID_;
@@ -387,6 +396,7 @@ struct Res {
 
     struct Thread {
         int tid, tile, ti, tj, i0, j0, tr, tc;       // (tile .. tc: block-uniform)
+        int rlim, clim;                              // rows / columns of this tile inside the grid (PAD; else TR / TC)
         double *lds;
         // registers that live across a barrier
         double nearv[R], farv[R];
@@ -410,6 +420,7 @@ struct Res {
             tile = uni(tile_of_block(block, Q.ntiles));
             ti = uni(tile / Q.tc); tj = uni(tile - ti * Q.tc);
             i0 = ti * TR; j0 = tj * TC;
+            rlim = PAD ? uni(min_(TR, Q.n0 - i0)) : TR; clim = PAD ? uni(min_(TC, Q.n1 - j0)) : TC;
 #pragma unroll
             for (int k = 0; k < DMAX; ++k) xd[k] = nan_();
 #pragma unroll
@@ -651,14 +662,14 @@ struct Res {
 
         // backward: the stored forward state alpha_t of positions p0 .. p0+7 (read before the posterior overwrites it in place)
         template <int DIR>
-        BLR_INL void load_alpha8(const double *pt0, const double *ptn0, long long n1, int p0) {
+        BLR_INL void load_alpha8(const double *pt0, const double *ptn0, long long n1, int p0, int r0 = 0, bool colok = true) {
             if (BWD) {
 #pragma unroll
-                for (int j = 0; j < CHK; ++j) al8[j] = ld_stream(pt0 + (long long)(DIR * (p0 + j)) * n1);
+                for (int j = 0; j < CHK; ++j) al8[j] = (!PAD || (colok && r0 + DIR * (p0 + j) < rlim)) ? ld_stream(pt0 + (long long)(DIR * (p0 + j)) * n1) : 0.0;
             }
             if (!BWD && ptn0) {                      // the row `lag` steps back, to be normalised in this step
 #pragma unroll
-                for (int j = 0; j < CHK; ++j) nz8[j] = ptn0[(long long)(DIR * (p0 + j)) * n1];
+                for (int j = 0; j < CHK; ++j) nz8[j] = (!PAD || (colok && r0 + DIR * (p0 + j) < rlim)) ? ptn0[(long long)(DIR * (p0 + j)) * n1] : 0.0;
             }
         }
 
@@ -666,11 +677,12 @@ struct Res {
         // x0 / m0p / pt0 point at position 0 of the segment in the LDS tile / the tile's row coordinates / the global row
         template <int DIR>
         BLR_INL void epilogue8(const ResParams &Q, double *x0, const double *m0p, double *pt0, double *ptn0, double invn, int p0,
-                               const double (&v)[CHK], double scale, Rec &rc, const ColC &cc) {
+                               const double (&v)[CHK], double scale, Rec &rc, const ColC &cc, int r0 = 0, bool colok = true) {
             const double g1 = cc.g1, cA = cc.cA, cB = cc.cB;
             if (!BWD && ptn0) {
 #pragma unroll
-                for (int j = 0; j < CHK; ++j) ptn0[(long long)(DIR * (p0 + j)) * Q.n1] = nz8[j] * invn;
+                for (int j = 0; j < CHK; ++j)
+                    if (!PAD || (colok && r0 + DIR * (p0 + j) < rlim)) ptn0[(long long)(DIR * (p0 + j)) * Q.n1] = nz8[j] * invn;
             }
             if (p0 % ANCHOR == 0) {
                 // arg(r) = sum_q [-(x_q - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50), along the
@@ -710,21 +722,22 @@ struct Res {
             for (int j = 0; j < CHK; ++j) {
                 const int p = p0 + j;
                 const double Lv = ldexp_(rc.mE, rc.nE);
+                const bool in = !PAD || (colok && r0 + DIR * p < rlim);          // (cells outside the grid stay zero, out of sums and stores)
                 double keep;                                         // what becomes the tile's new state
                 if (!BWD) {
-                    const double a = v[j] * Lv;
+                    const double a = in ? v[j] * Lv : 0.0;
                     keep = a;
-                    if (f_store(Q)) st_stream(pt0 + (long long)(DIR * p) * Q.n1, a);
+                    if (f_store(Q) && in) st_stream(pt0 + (long long)(DIR * p) * Q.n1, a);
                     sums[0] += a;
                     if (f_means(Q)) { sums[3] = fma(a, m0p[DIR * p], sums[3]); sums[4] = fma(a, g1, sums[4]); }
                 } else {
-                    const double beta = v[j] * scale;
+                    const double beta = in ? v[j] * scale : 0.0;
                     const double pp = al8[j] * beta;
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
-                    const double pl = Lv == 0.0 ? nan_() : ldexp_(pp * rc.iE, -rc.nE);
+                    const double pl = !in ? 0.0 : (Lv == 0.0 ? nan_() : ldexp_(pp * rc.iE, -rc.nE));
                     keep = cn;
-                    st_stream(pt0 + (long long)(DIR * p) * Q.n1, pp * invn);   // (invn = 1 / predicted sum: stored normalised)
+                    if (in) st_stream(pt0 + (long long)(DIR * p) * Q.n1, pp * invn);   // (invn = 1 / predicted sum: stored normalised)
                     sums[0] += pp; sums[1] += pl; sums[2] += cn;
                     sums[3] = fma(pp, m0p[DIR * p], sums[3]); sums[4] = fma(pp, g1, sums[4]);
                 }
@@ -770,10 +783,10 @@ struct Res {
             constexpr bool REC_IN_PASS = !ONE && !FULLW;
             static_assert(!REC_IN_PASS || (SEG - CHK) % ANCHOR != 0, "the last chunk has no anchor (its epilogue does not read the record)");
             auto pre8 = [&](int p0) {
-                load_alpha8<DIR>(pt0, ptn0, Q.n1, p0);
+                load_alpha8<DIR>(pt0, ptn0, Q.n1, p0, r0, c < clim);
                 if (REC_AHEAD && REC_IN_PASS && p0 == SEG - CHK && k + 1 < Q.T) begin_step(Q, k + 1);
             };
-            auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc); };
+            auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim); };
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
@@ -804,11 +817,31 @@ struct Res {
             for (int p0 = 0; p0 < SEG; p0 += CHK) {
                 double v[CHK];
 #pragma unroll
-                for (int j = 0; j < CHK; ++j) v[j] = s[(long long)(DIR * (p0 + j)) * Q.n1];
-                load_alpha8<DIR>(pt0, nullptr, Q.n1, p0);
-                epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, BWD ? 1.0 / Q.n_first : 1.0, p0, v, 1.0, rc, cc);
+                for (int j = 0; j < CHK; ++j) v[j] = (!PAD || (c < clim && r0 + DIR * (p0 + j) < rlim)) ? s[(long long)(DIR * (p0 + j)) * Q.n1] : 0.0;
+                load_alpha8<DIR>(pt0, nullptr, Q.n1, p0, r0, c < clim);
+                epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, BWD ? 1.0 / Q.n_first : 1.0, p0, v, 1.0, rc, cc, r0, c < clim);
             }
             if (REC_AHEAD && Q.T > 1) begin_step(Q, 1);
+        }
+        // PAD, after the step's last barrier: the R rows / columns beyond the grid's true edge take the mirror image of the new state (half-
+        // sample reflection: cell e + 1 + j <- cell e - j; the corner from both).  Sources are cells of the grid only, so one phase.
+        BLR_INL void mirror_edges() {
+            if (!PAD) return;
+            const unsigned t = (unsigned)launder(tid);
+            if (clim < TC) {                         // columns clim .. clim + R - 1 of rows 0 .. min(TR, rlim + R) - 1
+                const int nr = min_(TR, rlim + R);
+                for (unsigned idx = t; idx < (unsigned)(nr * R); idx += NT) {
+                    const int r = (int)(idx / R), j = (int)(idx % R);
+                    const int rs = r < rlim ? r : 2 * rlim - 1 - r;
+                    if (clim + j < TC && clim - 1 - j >= 0 && rs >= 0) lds[r * P + clim + j] = lds[rs * P + clim - 1 - j];
+                }
+            }
+            if (rlim < TR) {                         // rows rlim .. rlim + R - 1 of the columns inside the grid
+                for (unsigned idx = t; idx < (unsigned)(clim * R); idx += NT) {
+                    const int c = (int)(idx / R), j = (int)(idx % R);
+                    if (rlim + j < TR && rlim - 1 - j >= 0) lds[(rlim + j) * P + c] = lds[(rlim - 1 - j) * P + c];
+                }
+            }
         }
         BLR_INL void first_step(const ResParams &Q) { const Geo vg = vgeo(); if (vg.seg == 0) first_step_d<-1>(Q, vg); else first_step_d<1>(Q, vg); }
     };
@@ -845,9 +878,9 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID = false>
+template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID = false, bool PAD = false>
 __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Q) {
-    using K = Res<TR, TC, SEG, CHK, BWD, EVID>;
+    using K = Res<TR, TC, SEG, CHK, BWD, EVID, PAD>;
     constexpr int NT = K::NT, NW = K::NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *misc = lds + K::LDS_MISC;
@@ -855,10 +888,15 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
     const int tid = threadIdx.x;
     typename K::Thread th;
     th.init(Q, blockIdx.x, tid, lds);
-    for (int e = tid; e < TR; e += NT) lds[K::LDS_M0 + e] = Q.m0[th.i0 + e];
+    // (PAD: row coordinates continue the lattice beyond the grid -- the likelihood recurrence of a column runs through its padded
+    //  rows; padded columns take the last column's constants: their cells are masked)
+    for (int e = tid; e < TR; e += NT)
+        lds[K::LDS_M0 + e] = (!PAD || th.i0 + e < Q.n0) ? Q.m0[th.i0 + e] : Q.m0[Q.n0 - 1] + (double)(th.i0 + e - (Q.n0 - 1)) * Q.step0;
     for (int e = tid; e < TC; e += NT) {
-        lds[K::LDS_COL + e] = Q.m1[th.j0 + e]; lds[K::LDS_COL + TC + e] = Q.colA[th.j0 + e]; lds[K::LDS_COL + 2 * TC + e] = Q.colB[th.j0 + e];
+        const int c = PAD ? min_(th.j0 + e, Q.n1 - 1) : th.j0 + e;
+        lds[K::LDS_COL + e] = Q.m1[c]; lds[K::LDS_COL + TC + e] = Q.colA[c]; lds[K::LDS_COL + 2 * TC + e] = Q.colB[c];
     }
+    if (PAD) for (int e = tid; e < K::LDS_TILE; e += NT) lds[e] = 0.0;       // (cells no pass writes before it reads them)
     if (tid == 0) { misc[1] = 0.0; misc[2] = 0.0; }
     const int gw = th.gather_wave();
     __syncthreads();
@@ -958,6 +996,10 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             BLR_STAMP(12);
             lds_barrier();                            // the tile's new state is complete in LDS, the waves' sums and misc[1] are final
             BLR_STAMP(13);
+            if (PAD && (th.rlim < TR || th.clim < TC)) {        // (block-uniform) the mirror image beyond the grid's edge, before anyone reads the tile again
+                th.mirror_edges();
+                lds_barrier();
+            }
             th.publish_cols(Q, k);
             BLR_STAMP(14);
         }

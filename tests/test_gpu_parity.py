@@ -813,6 +813,14 @@ RESIDENT = {
     'res_2048x256_full': dict(study='Study', data=('series', 32, 4), om=_g2(2048, 256), tm=_grw2(0.015, 0.03)),
     # tiles 32 x 64 (256 tiles)
     'res_512x1024_full': dict(study='Study', data=('series', 33, 5), om=_g2(512, 1024), tm=_grw2(0.06, 0.008)),
+    # grids that do not fill their last tile row / column (PAD kernels: mirror image beyond the true edge, masked cells)
+    'res_pad_200x100_full': dict(study='Study', data=('series', 34, 9), om=_g2(200, 100), tm=_grw2(0.15, 0.07)),                   # 32 x 64 tiles, 7 x 2
+    'res_pad_88x72_nan': dict(study='Study', data=('series_nan', 35, 10, [1, 6]), om=_g2(88, 72), tm=_grw2(0.35, 0.1)),           # smallest padding / remainder
+    'res_pad_300x500_fwdonly': dict(study='Study', data=('series', 36, 7), om=_g2(300, 500), tm=_grw2(0.1, 0.015), fit=dict(forwardOnly=True)),
+    'res_pad_168x120_axis1': dict(study='Study', data=('series', 37, 8), om=_g2(168, 120), tm=('GRW', 's2', 0.06, 'std', None)),
+    'res_pad_1000_evid': dict(study='Study', data=('series', 38, 6), om=_g2(1000, 1000), tm=_grw2(0.03, 0.008), fit=dict(evidenceOnly=True)),   # 64 x 64 tiles, 256
+    'res_pad_1000x520_full': dict(study='Study', data=('series', 39, 4), om=_g2(1000, 520), tm=_grw2(0.03, 0.015)),                # 64 x 64 tiles, 16 x 9
+    'res_pad_2000x1100_full': dict(study='Study', data=('series', 40, 3), om=_g2(2000, 1100), tm=_grw2(0.015, 0.007)),             # 128 x 128 tiles, 16 x 9
 }
 
 

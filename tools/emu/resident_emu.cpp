@@ -63,12 +63,12 @@ static std::vector<double> likelihood(const Problem &p, int t) {
     return L;
 }
 
-template <int TR, int TC, int SEG, int CHK = 8>
-static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
-    using KF = Res<TR, TC, SEG, CHK, false>;
-    using KB = Res<TR, TC, SEG, CHK, true>;
+template <int TR, int TC, int SEG, int CHK = 8, bool PAD = false>
+static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis, int pad0 = 0, int pad1 = 0) {
+    using KF = Res<TR, TC, SEG, CHK, false, false, PAD>;
+    using KB = Res<TR, TC, SEG, CHK, true, false, PAD>;
     Problem p;
-    p.n0 = tr * TR; p.n1 = tc * TC; p.T = T; p.d = 1;
+    p.n0 = tr * TR - pad0; p.n1 = tc * TC - pad1; p.T = T; p.d = 1;              // (PAD: the grid does not fill its last tile row / column)
     std::mt19937_64 rng(seed);
     std::uniform_real_distribution<double> U(0.0, 1.0);
     p.w0 = taps(one_axis ? 0.05 : 1.9); p.w1 = taps(2.05);
@@ -146,9 +146,10 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
             for (int t = 0; t < NT; ++t) {
                 auto &x = th[(size_t)b * NT + t];
                 x.init(Q, b, t, lds[b].data());
-                for (int e = 0; e < TR; ++e) lds[b][K::LDS_M0 + e] = p.m0[x.i0 + e];
+                for (int e = 0; e < TR; ++e) lds[b][K::LDS_M0 + e] = x.i0 + e < p.n0 ? p.m0[x.i0 + e] : p.m0[p.n0 - 1] + (x.i0 + e - (p.n0 - 1)) * p.step0;
                 for (int e = 0; e < TC; ++e) {
-                    lds[b][K::LDS_COL + e] = p.m1[x.j0 + e]; lds[b][K::LDS_COL + TC + e] = p.colA[x.j0 + e]; lds[b][K::LDS_COL + 2 * TC + e] = p.colB[x.j0 + e];
+                    const int c = std::min(x.j0 + e, p.n1 - 1);
+                    lds[b][K::LDS_COL + e] = p.m1[c]; lds[b][K::LDS_COL + TC + e] = p.colA[c]; lds[b][K::LDS_COL + 2 * TC + e] = p.colB[c];
                 }
             }
         psum.assign((size_t)T * NRED * ntiles, 0.0);
@@ -190,6 +191,7 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis) {
                 K::publish_sum(Q, tile, k, 0, K::BWD ? v[2] : v[0]);
                 if (K::BWD) K::publish_sum(Q, tile, k, 1, v[0]);
             }
+            for (auto &x : th) x.mirror_edges();
             for (auto &x : th) x.publish_cols(Q, k);
             for (auto &x : th) if (x.dead) { std::printf("dead thread\n"); return false; }
         }
@@ -260,5 +262,12 @@ int main() {
     rc |= run<32, 32, 8, 4>(3, 3, 7, 1, 10, true);
     rc |= run<32, 64, 8>(3, 2, 7, 2, 11, false);        // rectangular tile (two blocks per CU on the device)
     rc |= run<32, 32, 8>(4, 4, 12, 2, 7, false);      // 16 tiles: the XCD-friendly block -> tile map is a permutation
+    // grids that do not fill their last tile row / column (PAD kernels): mirror image beyond the true edge, masked cells
+    rc |= run<32, 32, 8, 8, true>(3, 2, 8, 2, 12, false, 12, 0);        // 84 x 64: padded rows only
+    rc |= run<32, 32, 8, 8, true>(2, 3, 8, 2, 13, false, 0, 20);        // 64 x 76: padded columns only
+    rc |= run<32, 32, 8, 8, true>(3, 3, 9, 2, 14, false, 8, 24);        // 88 x 72: both, smallest padding / smallest remainder
+    rc |= run<64, 64, 8, 8, true>(2, 2, 7, 3, 15, false, 24, 40);       // 104 x 88
+    rc |= run<32, 64, 8, 8, true>(3, 2, 7, 2, 16, true, 16, 30);        // 80 x 98, rectangular tiles, one filtered axis
+    rc |= run<128, 128, 32, 8, true>(2, 1, 5, 2, 17, false, 56, 28);    // 200 x 100: multi-chunk segments
     return rc;
 }
