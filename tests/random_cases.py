@@ -323,3 +323,42 @@ def random_wide_axis1_case(seed):
     T = max(T, 6)
     return dict(study='ChangepointStudy', data=('series_jump', 900 + seed, T, T // 2, 2.0), om=om, fit=dict(),
                 tm=('Combined', [('ChangePoint', 'tc', ('arange', 1, T - 1, 2), None), ('GRW', 's2', s2, 'std', None)]))
+
+
+def _resident_plan(n0, n1, cus=256):
+    """Python replica of plan_resident (blhip.hip): -> (TR, TC, padded) or None."""
+    shapes = [(32, 32), (32, 64), (64, 64), (128, 128)]
+    for allow_pad in (False, True):
+        for TR, TC in shapes:
+            def fits(n, t):
+                rem = n % t
+                return rem == 0 or (allow_pad and n > t and rem >= 8 and t - rem >= 8)
+            if fits(n0, TR) and fits(n1, TC) and -(-n0 // TR) * -(-n1 // TC) <= cus:
+                return TR, TC, bool(n0 % TR or n1 % TC)
+    return None
+
+
+def random_resident_case(seed):
+    """Seeded single-chain 2-D studies on grids the time-resident kernel takes -- most of them NOT whole tiles (PAD kernels: masked cells,
+    mirror image beyond the true edge): random sizes 64 .. 700, radii 0 .. 8 per axis, every fit flag, missing data."""
+    rng = np.random.default_rng(21000 + seed)
+    while True:
+        n0, n1 = int(rng.integers(64, 701)), int(rng.integers(64, 701))
+        plan = _resident_plan(n0, n1)
+        if plan is not None and (plan[2] or seed % 4 == 0):
+            break
+    T = int(rng.integers(1, 13))
+    flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
+    nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 3 else []
+    data = ('series_nan', 1200 + seed, T, nan_at) if nan_at else ('series', 1200 + seed, T)
+    om = ('Gaussian', [('mean', ('cint', -8, 8, n0)), ('std', ('oint', 0, 4, n1))], 'default')
+    u0, u1 = float(rng.uniform(0.0, 2.0)), float(rng.uniform(0.0, 2.0))      # widths in lattice units: radius int(4 u + 0.5) <= 8
+    s1, s2 = u0 * 16.0 / (n0 - 1), u1 * 4.0 / (n1 + 1)
+    kind = seed % 3
+    if kind == 0:
+        tm = ('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)])
+    elif kind == 1:
+        tm = ('GRW', 's1', s1, 'mean', None)
+    else:
+        tm = ('GRW', 's2', s2, 'std', None)
+    return dict(study='Study', data=data, om=om, tm=tm, fit=flags)

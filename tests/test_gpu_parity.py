@@ -842,6 +842,23 @@ def test_resident_kernel_matches_oracle(case):
     compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
 
 
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 36))))
+def test_seeded_random_resident_grids_match_oracle(seed):
+    """Random single-chain studies on grids of random sizes (most of them not whole tiles: the PAD variants of the time-resident kernel)."""
+    c = random_cases.random_resident_case(seed)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    assert S.lastTiming['fwd_kernel_variant'] == 5 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues'):
+        if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+
+
 def test_resident_kernel_degenerate_fit_does_not_stall():
     """A data point no grid cell can explain (likelihood exactly zero everywhere): the normaliser is zero, the states turn inf / NaN.  The
     tiles' hand-off (tag = sign bit of the value) accepts NaN elements, the host rejects the pass by its sums and the launch-per-step
