@@ -67,6 +67,9 @@ struct ResidentRun {
             plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
                           (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0)) {
             on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
+            // (the padded 128 x 128 BACKWARD kernel spills 231 registers: 2000 x 1100, backward step 40 - 45 us against 26.8 us with one
+            //  launch per step -- full fits of such grids keep the launch-per-step kernels, evidence-only / forward-only fits do not)
+            if (rp.pad && rp.TR == 128 && full) on = false;
             const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
             for (int64_t t = 1; t < T && on; ++t)
                 on = prog.kindF[t] == SRC_PREV && prog.tapF0[t] == k0 && prog.tapF1[t] == k1;

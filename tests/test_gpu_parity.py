@@ -820,9 +820,10 @@ RESIDENT = {
     'res_pad_168x120_axis1': dict(study='Study', data=('series', 37, 8), om=_g2(168, 120), tm=('GRW', 's2', 0.06, 'std', None)),
     'res_pad_1000_evid': dict(study='Study', data=('series', 38, 6), om=_g2(1000, 1000), tm=_grw2(0.03, 0.008), fit=dict(evidenceOnly=True)),   # 64 x 64 tiles, 256
     'res_pad_1000x520_full': dict(study='Study', data=('series', 39, 4), om=_g2(1000, 520), tm=_grw2(0.03, 0.015)),                # 64 x 64 tiles, 16 x 9
-    'res_pad_2060x1100_full': dict(study='Study', data=('series', 41, 3), om=_g2(2060, 1100), tm=_grw2(0.015, 0.007)),             # 128 x 128 tiles, 12 rows in the last tile row: the
+    'res_pad_2060x1100_fwdonly': dict(study='Study', data=('series', 41, 3), om=_g2(2060, 1100), tm=_grw2(0.015, 0.007), fit=dict(forwardOnly=True)),   # 128 x 128 tiles, 12 rows in the last tile row: the
                                                                                                                                     # first segment's walk starts in the padding
-    'res_pad_2000x1100_full': dict(study='Study', data=('series', 40, 3), om=_g2(2000, 1100), tm=_grw2(0.015, 0.007)),             # 128 x 128 tiles, 16 x 9
+    'res_pad_2000x1100_evid': dict(study='Study', data=('series', 40, 3), om=_g2(2000, 1100), tm=_grw2(0.015, 0.007), fit=dict(evidenceOnly=True)),     # 128 x 128 tiles, 16 x 9 (full fits of
+                                                                                                                                    # padded 128 x 128 grids keep the launch-per-step kernels)
 }
 
 
