@@ -551,13 +551,17 @@ void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
 // A grid that does not fill its last tile row / column runs the PAD kernels (blhip_resident.hpp): the remainder of such an axis and the
 // padding behind it must both be at least one stencil radius (the mirror image beyond the true edge lives inside the last tile and is
 // made of that tile's own cells).  Grids whose sizes are multiples of a tile shape are preferred (no masks).
-bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp, int seg128 = 32, bool allow_pad = true) {
-    const int shapes[4][3] = {{32, 32, 8}, {32, 64, 8}, {64, 64, 8}, {128, 128, seg128}};
-    for (int pass = 0; pass < (allow_pad ? 2 : 1); ++pass)
-        for (const auto &sh : shapes) {
-            auto fits = [&](int n, int t) { const int rem = n % t; return rem == 0 || (pass == 1 && n > t && rem >= blr::R && t - rem >= blr::R); };
+bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp, int seg128 = 32, bool allow_pad = true, int min_tile = 32) {
+    // preference: 64 x 64 tiles first (measured on 128^2 .. 512^2 grids, tools/tile_probe.py: 5.7 / 6.7 us per forward / backward step
+    // against 9.0 / 10.1 us with 32 x 32 tiles -- two waves per block are too few to hide the hand-offs -- and 10.8 / 20.8 us with 128 x 128),
+    // whole tiles before a padded last tile row / column of the same shape; 128 x 128 only when the smaller shapes need more than one tile per CU
+    const int shapes[4][3] = {{64, 64, 8}, {32, 64, 8}, {32, 32, 8}, {128, 128, seg128}};
+    for (const auto &sh : shapes)
+        for (int pass = 0; pass < (allow_pad ? 2 : 1); ++pass) {
+            auto fits = [&](int n, int t) { const int rem = n % t; return pass == 0 ? rem == 0 : (rem == 0 || (n > t && rem >= blr::R && t - rem >= blr::R)); };
+            if (sh[0] < min_tile && sh[1] < 2 * min_tile) continue;
             if (!fits(n0, sh[0]) || !fits(n1, sh[1])) continue;
-            if (pass == 1 && sh[2] != sh[0] && sh[0] == 128 && seg128 != 32) continue;       // (the 1024-thread option shape has no PAD variant)
+            if (pass == 1 && sh[0] == 128 && seg128 != 32) continue;       // (the 1024-thread option shape has no PAD variant)
             const int tr = (n0 + sh[0] - 1) / sh[0], tc = (n1 + sh[1] - 1) / sh[1];
             const long long nt = (long long)tr * tc;
             if (nt > cus) continue;

@@ -65,7 +65,7 @@ struct ResidentRun {
         if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blr::DMAX &&
             prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
             plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
-                          (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0)) {
+                          (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0, (int)ctx->option("resident_min_tile", 32.0))) {
             on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
             // (the padded 128 x 128 BACKWARD kernel spills 231 registers: 2000 x 1100, backward step 40 - 45 us against 26.8 us with one
             //  launch per step -- full fits of such grids keep the launch-per-step kernels, evidence-only / forward-only fits do not)
