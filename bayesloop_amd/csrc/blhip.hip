@@ -1499,7 +1499,9 @@ bool resident_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsu
 // kinds (may be null): a step whose source kind is not SRC_PREV consumed a distribution of known mass instead of the previous
 // state: its normaliser is S_k / s_k.
 bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B, int64_t b, std::vector<double> *scales = nullptr,
-                 const unsigned char *kinds = nullptr) {
+                 const unsigned char *kinds = nullptr, int64_t t0 = 0) {
+    // t0 > 0 (blc::ChainParams::skip_prefix): the chain's own pass began at step t0 -- the rows before it are another chain's (same
+    // values, that chain's scale history), the scale history of the rows from t0 on starts there (s = 1 for lag steps, S_(t0 - 1) := 1)
     rowsum.assign(T, 0.0);
     for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[((size_t)t * B + b) * NRED];
     std::vector<double> s_local;
@@ -1508,7 +1510,8 @@ bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, 
     for (int64_t t = 0; t < T; ++t) {
         const double St = rowsum[t];
         if (!(St > 1e-150 && St < 1e150)) return false;
-        if (t >= lag) s[t] = (t - lag - 1 >= 0 ? rowsum[t - lag - 1] : 1.0) * s[t - lag] / rowsum[t - lag];
+        const int64_t base = t >= t0 ? t0 : 0;                                 // first step of the scale history this step belongs to
+        if (t - base >= lag) s[t] = (t - lag - 1 >= base ? rowsum[t - lag - 1] : 1.0) * s[t - lag] / rowsum[t - lag];
         const bool fresh = t == 0 || (kinds && kinds[(size_t)t * B + b] != SRC_PREV);
         const double norm = fresh ? St / s[t] : St / (rowsum[t - 1] * s[t]);
         double *r = &redF[((size_t)t * B + b) * NRED];

@@ -85,6 +85,11 @@ struct ChainParams {
     // pass reads them from chain `bprov` of the batch (the chain with the latest first restart, which stores everything).
     const int *tshare;           // [B] or nullptr
     int bprov;
+    // ... and need not be COMPUTED twice either: a restart consumes the reset distribution, not the chain's past.  skip_prefix != 0: the
+    // forward pass of chain b starts at step tshare[b] (its first restart; lagged scales as for a chain that begins there); the host
+    // copies the sums of the earlier steps from chain bprov, which also sums its state times the reset distribution at EVERY step (the
+    // restart sum of whichever chain restarts next).  Forward passes of no-stencil batches only.
+    int skip_prefix;
     unsigned *abort_word;
     unsigned long long timeout_ticks;
     unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
@@ -207,7 +212,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     auto cell_off = [&](int l, int it, int r) { return __umul24(row0 + it * TM + (l >> 4) + 4 * r, rowx8) + strip0 + (unsigned)(l & 15) * 8u; };
 
-    const int t_first = BWD ? P.T - 1 : 0;
+    const int kb = (!BWD && !FILTER && P.skip_prefix) ? tsh : 0;      // the first step this chain computes (see ChainParams::skip_prefix)
+    if (kb >= P.T) return;                                              // (a chain without a restart that is not the provider: nothing of its own)
+    const int t_first = BWD ? P.T - 1 : kb;
     double xd[DMAX], xn[DMAX];
 #pragma unroll
     for (int q = 0; q < DMAX; ++q) xd[q] = q < P.d ? P.rec[(long long)t_first * P.rec_len + q] : __builtin_nan("");
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     double inpred = FOLD ? P.infirst[b] : 0.0;        // 1 / predicted sum of the step's posterior
     double sfn = 1.0;                                 // the forward scale the NEXT step's prediction needs
     int kind_n = blk::SRC_PREV;                      // NK = 4: source kind of the next step (the first step's source is in LDS already)
+    if (kb > 0) kind_n = P.kinds[(long long)kb * P.B + b];             // (a restart: the step takes the reset distribution)
     double pa[4] = {0.0, 0.0, 0.0, 0.0};              // fold: the accumulator cells of the tile in flight, requested one tile ahead
     if (FOLD) {
 #pragma unroll
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 #endif
     __syncthreads();
 
-    for (int k = 0; k < P.T; ++k) {
+    for (int k = kb; k < P.T; ++k) {
         const int t = BWD ? P.T - 1 - k : k;
         const int tn = (k + 1 < P.T) ? (BWD ? t - 1 : t + 1) : t;          // the step after this one (clamped: a harmless re-load)
         BLC_STAMP(0);
@@ -269,11 +277,11 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         //      are requested now -------------------------------------------------------------------------------------------------------
         const bool scale_wave = wv == SCALE_WAVE;
         const int jn = k + 1;                                               // the step whose scale this step prepares
-        const bool need = scale_wave && jn >= P.lag && jn < P.T;
+        const bool need = scale_wave && jn >= kb + P.lag && jn < P.T;
         const unsigned long long *gp = P.gran + ((((long long)((jn - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
         const bool mine = need && lane < P.strips;
         const unsigned long long hq0 = gq0, hq1 = gq1;
-        if (scale_wave && jn + 1 >= P.lag && jn + 1 < P.T && lane < P.strips) {
+        if (scale_wave && jn + 1 >= kb + P.lag && jn + 1 < P.T && lane < P.strips) {
             const unsigned long long *gn = P.gran + ((((long long)((jn + 1 - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
             gq0 = blr::ld_u64(gn); gq1 = blr::ld_u64(gn + 1);
         }
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
         // forward pass of a change-point batch: the step BEFORE a restart also sums its new state times the reset distribution --
         // the sum of the posterior at the restart of the backward pass, which the fused fold normalises by (chain_fold2_kernel)
-        const bool want_x = !BWD && !FILTER && P.kinds && kind_n != blk::SRC_PREV;
+        const bool want_x = !BWD && !FILTER && P.kinds && (kind_n != blk::SRC_PREV || (P.skip_prefix && b == P.bprov));
         double *const pstep = pchain + (long long)t * G;
         double *const pslot_t = FOLD ? pslot + (long long)t * G : nullptr;
         double *const pslot_tn = FOLD ? pslot + (long long)tn * G : nullptr;

@@ -212,6 +212,8 @@ struct ChainRun {
     bool fold2 = false;
     std::vector<int> round_start_b, round_nk_b;
     bool share_prefix = false;                     // change-point batches: states before a chain's first restart are stored once (see setup)
+    bool skip_prefix = false;                      // ... and computed once: a chain's forward pass begins at its first restart
+    int prov = 0;                                  // the chain that stores / computes everything
     long long shared_steps = 0;                    // chain-steps not stored
     int *d_tshare = nullptr;
     std::vector<int> h_tshare;
@@ -298,8 +300,13 @@ struct ChainRun {
         // folding backward pass reads the earlier ones from that chain (same values bit for bit: same kernel, same strips, same lagged
         // scales).  Halves the forward pass's stores, and the backward pass's reads of those states hit the cache (the chains of a launch
         // read the same rows at about the same time).  (Only when nothing overwrites the stored states: the fused fold.)
-        share_prefix = false;
-        if (fused && cp.has_reset && prog.LW0 == 0 && !cp.mixed && B >= 2 && ctx->option("share_prefix", 1.0) != 0.0) {
+        // The same chains need not COMPUTE that prefix either (a restart consumes the reset distribution, not the chain's past): with
+        // skip_prefix a chain's forward pass begins at its first restart, the sums of its earlier steps are copied from the providing chain
+        // (forward_ok).  Also for evidence-only fits, which store nothing.  C5: 250 chains x 1000 steps -> 125 k chain-steps of 250 k.
+        share_prefix = false; skip_prefix = false;
+        const bool may_share = fused && ctx->option("share_prefix", 1.0) != 0.0;
+        const bool may_skip = (fused || E.ff.evidence_only) && ctx->option("skip_prefix", 1.0) != 0.0;
+        if ((may_share || may_skip) && cp.has_reset && prog.LW0 == 0 && !cp.mixed && B >= 2) {
             std::vector<int> tfirst((size_t)B, (int)T);
             bool plain = true;
             for (int64_t b = 0; b < B && plain; ++b) {
@@ -308,7 +315,7 @@ struct ChainRun {
                     if (prog.kindF[(size_t)t * B + b] != SRC_PREV) { tfirst[b] = (int)t; break; }
             }
             if (plain) {
-                int prov = 0;
+                prov = 0;
                 for (int64_t b = 1; b < B; ++b) if (tfirst[b] > tfirst[prov]) prov = (int)b;
                 std::vector<int> tsh((size_t)B, 0);
                 long long saved = 0;
@@ -317,8 +324,8 @@ struct ChainRun {
                 if (saved > 0) {
                     HIPCHECK(hipMemcpyAsync(d_tshare, tsh.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
                     sync_stream(ctx, E.st);
-                    share_prefix = true; shared_steps = saved; h_tshare = tsh;
-                    CQ.tshare = d_tshare; CQ.bprov = prov;
+                    share_prefix = may_share || may_skip; skip_prefix = may_skip; shared_steps = saved; h_tshare = tsh;
+                    CQ.tshare = d_tshare; CQ.bprov = prov; CQ.skip_prefix = skip_prefix ? 1 : 0;
                 }
             }
         }
@@ -370,7 +377,9 @@ struct ChainRun {
             {   // HBM: only what the fit keeps -- forward the stored state (8 B; nothing for evidence-only fits), backward the stored
                 // state in + the posterior out (16 B) or + the read-modify-write of the partial accumulator (24 B; shared by the two
                 // chains of a block of the two-chain fold kernel: 8 + 16 / 2 = 16 B)
-                const double cells = (double)Q.nslots * Gk * T;
+                double cells = (double)Q.nslots * Gk * T;
+                if (!bwd && skip_prefix)               // (chain-steps the forward pass does not run)
+                    for (int q = rstart[r]; q < rstart[r + 1]; ++q) cells -= (double)h_tshare[cp.order[q]] * Gk;
                 const double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
                 const int r0 = (4 * rnk[r] - blc::TM) / 2;
                 double shared = 0.0;                                  // stored states not written (forward) / read once per launch instead of once per chain (backward)
@@ -406,8 +415,13 @@ struct ChainRun {
         redF_keep = redF;
         rowsumC.assign(E.B, std::vector<double>());
         sfwdC.assign(E.B, std::vector<double>());
+        if (skip_prefix)               // the steps a chain did not compute: the providing chain's sums (raw: before anybody's scales are undone)
+            for (int64_t b = 0; b < E.B; ++b)
+                for (int64_t t = 0; t < h_tshare[b]; ++t)
+                    std::memcpy(&redF[((size_t)t * E.B + b) * NRED], &redF[((size_t)t * E.B + prov) * NRED], NRED * sizeof(double));
         for (int64_t b = 0; b < E.B; ++b)
-            if (!chain_unlag(redF, E.T, CQ.lag, rowsumC[b], E.B, b, &sfwdC[b], cp.has_reset ? E.prog->kindF.data() : nullptr)) return false;
+            if (!chain_unlag(redF, E.T, CQ.lag, rowsumC[b], E.B, b, &sfwdC[b], cp.has_reset ? E.prog->kindF.data() : nullptr,
+                             skip_prefix ? h_tshare[b] : 0)) return false;
         return true;
     }
 

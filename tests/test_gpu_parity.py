@@ -1101,32 +1101,60 @@ def test_fused_fold_matches_the_separate_fold():
 
 
 def test_change_point_chains_share_their_common_prefix():
-    """share_prefix (default on): the states before a chain's first restart are stored by ONE chain of the batch and read from there by
-    the folding backward pass of the others -- same numbers bit for bit as every chain storing its own copy (share_prefix = 0)."""
+    """Change-point batches: every chain repeats the steps before its FIRST restart.
+    share_prefix (default on): those states are stored by ONE chain of the batch and read from there by the folding backward pass of the
+    others -- same numbers bit for bit as every chain storing its own copy (share_prefix = 0).
+    skip_prefix (default on): they are not computed twice either -- a chain's forward pass begins at its first restart, the sums of its
+    earlier steps are the providing chain's.  The lagged scales of such a chain start at its restart, so the results agree with the
+    full-length pass to rounding (asserted at 1e-12), not bit for bit; also for evidence-only fits."""
     eng = bl.get_engine()
     study_cases = [cases.CASES['c5_small'], EXTRA['x_cp_all'], RAGGED['pad_cp_150x40'],
                    dict(study='ChangepointStudy', data=('series_jump', 95, 40, 18, 1.5), om=_g2(128, 48), tm=('ChangePoint', 'tc', ('arange', 1, 39, 2), None)),
                    # two change points per chain: chains restart at different first steps, some share only a short prefix
                    dict(study='ChangepointStudy', data=('series_jump', 96, 18, 9, 2.0), om=_g2(128, 16),
                         tm=('Combined', [('ChangePoint', 't1', ('arange', 2, 16, 4), None), ('ChangePoint', 't2', ('arange', 3, 17, 5), None)]))]
-    for c in study_cases:
-        A = cases.build(bl, c); A.fit(silent=True)
-        assert A.lastTiming['fwd_kernel_variant'] == 6 and A.lastTiming['bwd_kernel_variant'] == 6 and A.lastTiming['resident_fallbacks'] == 0, A.lastTiming
-        eng.set_option('share_prefix', 0)
+
+    def fit_with(c, **opts):
+        for k, v in opts.items():
+            eng.set_option(k, v)
         try:
-            B = cases.build(bl, c); B.fit(silent=True)
+            S = cases.build(bl, c); S.fit(**cases.fit_kwargs(c))
         finally:
-            eng.set_option('share_prefix', 1)
-        assert A.logEvidence == B.logEvidence
-        assert np.array_equal(np.array(A.posteriorSequence), np.array(B.posteriorSequence), equal_nan=True)
-        assert np.array_equal(np.array(A.posteriorMeanValues), np.array(B.posteriorMeanValues), equal_nan=True)
-        assert A.lastTiming['bwd_hbm_bytes'] <= B.lastTiming['bwd_hbm_bytes'] and A.lastTiming['fwd_hbm_bytes'] <= B.lastTiming['fwd_hbm_bytes']
+            for k in opts:
+                eng.set_option(k, 1)
+        assert S.lastTiming['fwd_kernel_variant'] == 6 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
+        return S
+
+    tight = dict(rtol=1e-12, atol=1e-300)
+    for c in study_cases:
+        A = fit_with(c)
+        B = fit_with(c, skip_prefix=0)
+        C = fit_with(c, skip_prefix=0, share_prefix=0)
+        assert A.lastTiming['bwd_kernel_variant'] == 6
+        assert B.logEvidence == C.logEvidence
+        assert np.array_equal(np.array(B.posteriorSequence), np.array(C.posteriorSequence), equal_nan=True)
+        assert np.array_equal(np.array(B.posteriorMeanValues), np.array(C.posteriorMeanValues), equal_nan=True)
+        assert B.lastTiming['bwd_hbm_bytes'] <= C.lastTiming['bwd_hbm_bytes'] and B.lastTiming['fwd_hbm_bytes'] <= C.lastTiming['fwd_hbm_bytes']
+        assert A.lastTiming['fwd_flops'] < B.lastTiming['fwd_flops'], (A.lastTiming, B.lastTiming)       # chain-steps really left out
+        np.testing.assert_allclose(A.logEvidence, B.logEvidence, rtol=1e-13)
+        np.testing.assert_allclose(np.array(A.localEvidence), np.array(B.localEvidence), equal_nan=True, **tight)
+        np.testing.assert_allclose(np.array(A.posteriorSequence), np.array(B.posteriorSequence), equal_nan=True, **tight)
+        np.testing.assert_allclose(np.array(A.hyperParameterDistribution), np.array(B.hyperParameterDistribution), rtol=1e-11, atol=1e-300)
         with np.errstate(all='ignore'):
             want = oa.run(c)
         compare.check(dict(logEvidence=A.logEvidence, localEvidence=A.localEvidence, posteriorSequence=A.posteriorSequence,
                            posteriorMeanValues=A.posteriorMeanValues),
                       dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'], posteriorSequence=want['posteriorSequence'],
                            posteriorMeanValues=want['posteriorMeanValues']), compare.GPU_TOL)
+        # evidence-only fits skip the prefix too (nothing is stored: only the sums are shared)
+        ce = dict(c, fit=dict(evidenceOnly=True))
+        Ae = fit_with(ce)
+        Be = fit_with(ce, skip_prefix=0)
+        assert Ae.lastTiming['fwd_flops'] < Be.lastTiming['fwd_flops'], (Ae.lastTiming, Be.lastTiming)
+        np.testing.assert_allclose(Ae.logEvidence, Be.logEvidence, rtol=1e-13)
+        np.testing.assert_allclose(Ae.logEvidence, want['logEvidence'], rtol=1e-9)
+        np.testing.assert_allclose(np.array(Ae.hyperParameterDistribution), np.array(Be.hyperParameterDistribution), rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(np.array(Ae.localEvidence), np.array(Be.localEvidence), equal_nan=True, **tight)
 
 
 RAGGED = {
