@@ -348,37 +348,41 @@ void launch_fast(hipStream_t s, int om, int mode, const blf::FastParams &P, int 
     HIPCHECK(hipGetLastError());
 }
 
-struct FastRange { int start, count, R0; bool H; int key; };
+struct FastRange { int start, count, R0; bool H; int key; bool pre; };
 
-// chains of one step ordered by (axis-0 radius bucket, axis-1 filter present); one launch per non-empty group
+// chains of one step ordered by (axis-0 radius bucket, axis-1 class); one launch per non-empty group.  Axis-1 classes: 0 = no filter,
+// 1 = a filter the fused kernels apply themselves (radius <= 8), 2 = (h_fused_max >= 0 only) one wider than h_fused_max (0: any): the group
+// runs behind the axis-1 pre-pass (FastRange::pre) and its step kernel without an axis-1 part.
+constexpr int NKEYS = 18;
 void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, int B, int *order, std::vector<FastRange> &ranges,
-                 int min_chains) {
-    int cnt[12] = {0};
-    int promote[12];
-    for (int k = 0; k < 12; ++k) promote[k] = k;
+                 int min_chains, int h_fused_max = -1) {
+    int cnt[NKEYS] = {0};
+    int promote[NKEYS];
+    for (int k = 0; k < NKEYS; ++k) promote[k] = k;
     auto key0 = [&](int b) {
         const int l0 = tap0[b] >= 0 ? lw[tap0[b]] : 0;
         const int bucket = l0 == 0 ? 0 : (l0 + 7) / 8;      // 0..5
-        return bucket * 2 + (tap1[b] >= 0 ? 1 : 0);
+        const int hc = tap1[b] < 0 ? 0 : ((h_fused_max >= 0 && (h_fused_max == 0 || lw[tap1[b]] > h_fused_max)) ? 2 : 1);
+        return bucket * 3 + hc;
     };
     auto key = [&](int b) { int k = key0(b); while (promote[k] != k) k = promote[k]; return k; };
     for (int b = 0; b < B; ++b) cnt[key0(b)]++;
     // a bucket with only a few chains cannot fill the chip: promote its chains to the next larger radius bucket
-    // (zero-padded weights make that exact); keys are bucket*2 + H
-    for (int h = 0; h < 2; ++h)
+    // (zero-padded weights make that exact); keys are bucket * 3 + class
+    for (int h = 0; h < 3; ++h)
         for (int bk = 0; bk < 5; ++bk) {
-            const int k = bk * 2 + h;
+            const int k = bk * 3 + h;
             if (cnt[k] > 0 && cnt[k] < min_chains) {
                 int up = -1;
-                for (int b2 = bk + 1; b2 < 6; ++b2) if (cnt[b2 * 2 + h] > 0) { up = b2 * 2 + h; break; }
+                for (int b2 = bk + 1; b2 < 6; ++b2) if (cnt[b2 * 3 + h] > 0) { up = b2 * 3 + h; break; }
                 if (up >= 0) { promote[k] = up; cnt[up] += cnt[k]; cnt[k] = 0; }
             }
         }
-    int start[12], acc = 0;
+    int start[NKEYS], acc = 0;
     ranges.clear();
-    for (int k = 0; k < 12; ++k) {
+    for (int k = 0; k < NKEYS; ++k) {
         start[k] = acc;
-        if (cnt[k]) ranges.push_back(FastRange{acc, cnt[k], (k / 2) * 8, (k & 1) != 0, k});
+        if (cnt[k]) ranges.push_back(FastRange{acc, cnt[k], (k / 3) * 8, (k % 3) == 1, k, (k % 3) == 2});
         acc += cnt[k];
     }
     for (int b = 0; b < B; ++b) order[start[key(b)]++] = b;
@@ -1098,6 +1102,8 @@ struct GeometryPlan {
     bool fast = false, fused1d = false, use_mfma = false;
     bool wideH = false;           // axis-1 walks wider than the fused kernels' halo: row filter as a pre-pass per step (blhip_hwide.hpp)
     bool wideV = false;           // axis-0 walks wider than the matrix-pipe kernels' largest band: column filter as a pre-pass, no stencil left
+    bool hSplit = false;          // wideH: chains of the batch whose axis-1 filter is absent (or narrow: hFusedMax > 0) keep their fused kernels
+    int hFusedMax = 0;
     int64_t fusedK = 1;
     int f1_TJ = 128;
     Tile tile{};
@@ -1105,7 +1111,7 @@ struct GeometryPlan {
 };
 
 GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const ChainProgram &prog, int64_t B, int d,
-                       bool resume, bool carry) {
+                       bool resume, bool carry, const TapTable *taps = nullptr) {
     GeometryPlan gp;
     const int64_t T = p->T;
     // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
@@ -1117,6 +1123,20 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
                       g.n0 >= (wide_v ? 0 : ((prog.LW0 + 7) / 8) * 8) + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
     gp.wideV = gp.fast && wide_v;
     gp.wideH = gp.fast && (prog.LW1 > blf::R1MAX || (gp.wideV && prog.LW1 > 0));       // (with a column pre-pass every filter runs as a pre-pass)
+    // Chains of such a batch WITHOUT an axis-1 filter (a hyper-grid that includes the width 0) skip the pre-pass: it would be a copy.
+    // wide_h_fused_max = 8: chains with a narrow filter keep the fused kernels' own axis-1 part as well -- 15 % fewer bytes on
+    // extra.c4_both_axes but no faster (the fused both-axes kernels at radii up to 40 are bound by the fp64 pipe: 5.44e10 -> 5.47e10), so
+    // the default sends every filter through the pre-pass.
+    bool any_narrow = false;
+    gp.hFusedMax = std::min(blf::R1MAX, std::max(0, (int)ctx->option("wide_h_fused_max", 0.0)));
+    if (gp.wideH && !gp.wideV && taps && ctx->option("wide_h_split", 1.0) != 0.0) {
+        bool any_none = false;
+        for (size_t e = 0; e < prog.tapF1.size() && !(any_narrow && any_none); ++e) {
+            const int k = prog.tapF1[e];
+            if (k < 0) any_none = true; else if (gp.hFusedMax > 0 && taps->lw[k] <= gp.hFusedMax) any_narrow = true;
+        }
+        gp.hSplit = any_narrow || any_none;
+    }
     if (p->ndim == 1 && !gp.fast && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
         gp.f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
@@ -1126,7 +1146,7 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
         gp.fused1d = (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 + (size_t)gp.fusedK * gp.f1_TJ * 32 + 4096 <= 150 * 1024;
     }
     if (gp.fast) {
-        gp.tile.TI = blf::CH; gp.tile.LW0 = gp.wideV ? 0 : prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && !gp.wideH) ? blf::R1MAX : 0;
+        gp.tile.TI = blf::CH; gp.tile.LW0 = gp.wideV ? 0 : prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && (!gp.wideH || (gp.hSplit && any_narrow))) ? blf::R1MAX : 0;
         gp.tile.TJ = blf::BW - 2 * gp.tile.LW1;
         gp.tile.tiles_j = (g.n1 + gp.tile.TJ - 1) / gp.tile.TJ;
         // rows per block segment: long segments read every element once (+ 2*R0 halo rows per segment), short ones
@@ -1198,7 +1218,7 @@ struct DeviceMeta {
 };
 
 void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram &prog, TapTable &taps, int64_t B, bool full, bool fast, int nblk,
-                     DeviceMeta &M, bool wideH = false, bool wideV = false) {
+                     DeviceMeta &M, bool wideH = false, bool wideV = false, bool h_split = false, int h_fused_max = 0) {
     hipStream_t st = ctx->stream;
     const int64_t T = p->T;
     const size_t nT = (size_t)T * B;
@@ -1238,16 +1258,25 @@ void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram 
         // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle: a radius bucket with fewer blocks joins the next one
         const long long min_blocks = (long long)ctx->option("min_bucket_blocks", 128.0);
         const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)nblk - 1) / nblk);
-        // (wideH: the axis-1 filters run in the pre-pass, the fused kernels are launched without theirs)
+        // (wideH: the axis-1 filters wider than the fused kernels' 8 columns run in the pre-pass, and the fused kernels of those chains are
+        //  launched without an axis-1 part; chains of the same step with a narrow filter or none keep their fused kernels -- unless the
+        //  step also has the axis-0 pre-pass, or with wide_h_split = 0: then every chain of the step goes through the pre-pass)
         const std::vector<int> no_h((wideH || wideV) ? (size_t)B : 0, -1);
+        auto all_pre = [&](std::vector<FastRange> &rs) { if (wideH && !h_split) for (auto &r : rs) r.pre = true; };
         M.h_orderF.resize(nT); M.rangesF.resize(T);
-        for (int64_t t = 0; t < T; ++t)
-            bucket_step(wideV ? no_h.data() : &prog.tapF0[t * B], wideH ? no_h.data() : &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains);
+        for (int64_t t = 0; t < T; ++t) {
+            bucket_step(wideV ? no_h.data() : &prog.tapF0[t * B], (wideH && !h_split) ? no_h.data() : &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains,
+                        h_split ? h_fused_max : -1);
+            all_pre(M.rangesF[t]);
+        }
         HIPCHECK(hipMemcpyAsync(M.orderF, M.h_orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
         if (full) {
             M.h_orderB.resize(nT); M.rangesB.resize(T);
-            for (int64_t t = 0; t < T; ++t)
-                bucket_step(wideV ? no_h.data() : &prog.tapB0[t * B], wideH ? no_h.data() : &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains);
+            for (int64_t t = 0; t < T; ++t) {
+                bucket_step(wideV ? no_h.data() : &prog.tapB0[t * B], (wideH && !h_split) ? no_h.data() : &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains,
+                            h_split ? h_fused_max : -1);
+                all_pre(M.rangesB[t]);
+            }
             HIPCHECK(hipMemcpyAsync(M.orderB, M.h_orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
         }
     }
@@ -1700,7 +1729,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         tr.mark("batch setup");
         build_program(p, g, c0, B, op_values, taps, prog, resume);
         tr.mark("build_program");
-        const GeometryPlan gp = plan_geometry(ctx, p, g, prog, B, d, resume, carry);
+        const GeometryPlan gp = plan_geometry(ctx, p, g, prog, B, d, resume, carry, &taps);
         const bool fast = gp.fast, fused1d = gp.fused1d, use_mfma = gp.use_mfma;
         const int64_t fusedK = gp.fusedK;
         const int f1_TJ = gp.f1_TJ;
@@ -1713,7 +1742,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         // --- device metadata ---
         DeviceMeta M;
-        upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M, gp.wideH, gp.wideV);
+        upload_metadata(ctx, p, prog, taps, B, full, fast, tile.nblk, M, gp.wideH, gp.wideV, gp.hSplit, gp.hFusedMax);
         unsigned char *const d_kindF = M.kindF, *const d_kindB = M.kindB, *const d_cmodeF = M.cmodeF, *const d_cmodeB = M.cmodeB;
         double *const d_limitF = M.limitF, *const d_limitB = M.limitB;
         int *const d_tapF0 = M.tapF0, *const d_tapF1 = M.tapF1, *const d_tapB0 = M.tapB0, *const d_tapB1 = M.tapB1;
@@ -1871,11 +1900,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 Q.psum_prev = ps_prev; Q.prev_slot = prev_slot; Q.psum_out = ps_out;
                 Q.rec = d_rec + t * rec_len; Q.lik = d_lik ? d_lik + (size_t)t * G : nullptr;
                 const int *ord = (mode == MODE_FWD ? d_orderF : d_orderB) + t * B;
-                const bool prepass = gp.wideH && (mode == MODE_FWD ? any_hF : any_hB)[t];
+                const bool prepass_step = gp.wideH && (mode == MODE_FWD ? any_hF : any_hB)[t];
                 const bool prepass_v = gp.wideV && (mode == MODE_FWD ? any_vF : any_vB)[t];
                 for (const FastRange &r : (mode == MODE_FWD ? rangesF[t] : rangesB[t])) {
                     Q.chain_ids = ord + r.start;
                     Q.u_valid = 0;
+                    Q.hsrc = nullptr;
+                    const bool prepass = prepass_step && r.pre;
                     if (r.count == 1 && uniform_launch) {      // single-chain launch: hand the chain's metadata over by value
                         const int64_t tb = t * B;
                         const int cb = (mode == MODE_FWD ? orderF : orderB)[tb + r.start];

@@ -87,7 +87,7 @@ struct blhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     // radius buckets of a batch are independent pipelines: one stream per bucket key, joined with events
-    static constexpr int NBS = 12;
+    static constexpr int NBS = 18;       // (>= the keys of bucket_step)
     hipStream_t bstream[NBS] = {};
     hipEvent_t bev[NBS] = {};
     hipEvent_t fork_ev = nullptr, sync_ev = nullptr;

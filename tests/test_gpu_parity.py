@@ -142,6 +142,9 @@ EXTRA = {
     'x_wide_h_200': dict(study='Study', data=('series', 47, 6),
                          om=('Gaussian', [('mean', ('cint', -4, 4, 64)), ('std', ('oint', 0, 3, 520))], 'default'),
                          tm=('Combined', [('GRW', 's1', 0.3, 'mean', None), ('GRW', 's2', 0.29, 'std', None)])),             # axis-1 radius 201, three column blocks
+    'x_wide_h_with_zero': dict(study='HyperStudy', data=('series', 48, 11), om=cases.gauss2d(64, -4, 4, 3),
+                               tm=('Combined', [('GRW', 's1', ('cint', 0, 0.4, 3), 'mean', None),
+                                                ('GRW', 's2', ('cint', 0, 0.27, 4), 'std', None)])),                       # axis-1 radii 0 (no filter), 8, 16, 23 in one batch
     'x_wide_h_forward': dict(study='Study', data=('series', 46, 9), om=cases.gauss2d(72, -5, 5, 3),
                              tm=('Combined', [('GRW', 's1', 0.4, 'mean', None), ('GRW', 's2', 0.5, 'std', None)]),
                              fit=dict(forwardOnly=True)),
@@ -227,6 +230,37 @@ def test_wide_axis1_walks_take_the_streaming_kernels():
             eng.set_option('wide_h', 1)
         np.testing.assert_allclose(S.logEvidence, S0.logEvidence, rtol=1e-11)
         np.testing.assert_allclose(S.posteriorMeanValues, S0.posteriorMeanValues, rtol=1e-9, atol=1e-12)
+
+
+def test_chains_without_an_axis1_filter_skip_the_pre_pass():
+    """A hyper-grid over the width of a walk on the second parameter usually includes 0: those chains have no axis-1 filter and skip the
+    pre-pass (it would copy their state): same results bit for bit as with wide_h_split = 0, fewer bytes.  wide_h_fused_max = 8 also lets
+    the narrow filters (radius <= 8) run inside the fused kernels (not the default: no faster) -- same results to rounding."""
+    eng = bl.get_engine()
+    c = EXTRA['x_wide_h_with_zero']
+    A = cases.build(bl, c); A.fit(silent=True)
+    assert A.lastTiming['fwd_kernel_variant'] in (1, 3), A.lastTiming
+    eng.set_option('wide_h_split', 0)
+    try:
+        B = cases.build(bl, c); B.fit(silent=True)
+    finally:
+        eng.set_option('wide_h_split', 1)
+    assert A.logEvidence == B.logEvidence
+    assert np.array_equal(np.array(A.posteriorSequence), np.array(B.posteriorSequence), equal_nan=True)
+    assert A.lastTiming['fwd_hbm_bytes'] < B.lastTiming['fwd_hbm_bytes'] and A.lastTiming['bwd_hbm_bytes'] < B.lastTiming['bwd_hbm_bytes']
+    eng.set_option('wide_h_fused_max', 8)
+    try:
+        F = cases.build(bl, c); F.fit(silent=True)
+    finally:
+        eng.set_option('wide_h_fused_max', 0)
+    assert F.lastTiming['fwd_hbm_bytes'] < A.lastTiming['fwd_hbm_bytes']
+    np.testing.assert_allclose(F.logEvidence, A.logEvidence, rtol=1e-12)
+    np.testing.assert_allclose(np.array(F.posteriorSequence), np.array(A.posteriorSequence), rtol=1e-10, atol=1e-300)
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    compare.check(dict(logEvidence=A.logEvidence, localEvidence=A.localEvidence, posteriorSequence=A.posteriorSequence, posteriorMeanValues=A.posteriorMeanValues),
+                  dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'], posteriorSequence=want['posteriorSequence'],
+                       posteriorMeanValues=want['posteriorMeanValues']), compare.GPU_TOL)
 
 
 def test_wide_axis0_walks_take_the_streaming_kernels():
