@@ -540,6 +540,7 @@ def main():
                         bytes_per_cell_step=dom['hbm']['bytes_per_cell_step'], bytes_from=dom['hbm']['source'],
                         traffic=traffic, traffic_from=(pmc[key]['source'] if traffic is not None else None),
                         hbm=dom['hbm'], fp64=dom['fp64'],
+                        frac_hbm_real=dom['hbm']['frac_spec'], frac_fp64=dom['fp64']['frac'], frac_streaming_equiv=dom['streaming_equiv']['frac_spec'],
                         peak_calibrated=peak_cal, frac_calibrated=dom['hbm']['frac_calibrated'],
                         peak_calibrated_from='blhip_bandwidth_probe: best of a 16-B-per-lane streaming copy (read + write) and a store-only fill of 1 GiB',
                         algorithmic=dict(dom['streaming_equiv'], note='SURVEY 8(d) accounting: the bytes a kernel that streams the state through '
