@@ -106,8 +106,9 @@ class _PinnedPool:
     """Result arrays of the big read-backs (posteriorSequence: (T, *gridSize) float64, 16 GiB for BASELINE C3) in PAGE-LOCKED host
     memory: the D2H copy is then one DMA per 256 MiB piece at the PCIe rate (57 GB/s measured) instead of the runtime's staging
     through pageable memory (25 GB/s).  Pinning itself is slow (16 GiB: 1.1 s, more than the pageable copy), so the FIRST big
-    read-back of a size goes to an ordinary array while a block of that size is pinned in the background; later ones get the
-    block.  The arrays are ordinary writable numpy arrays; when the last view of one dies its block comes back here and ONE free
+    read-back of a size goes to an ordinary array, and a block of that size is pinned in the background once that copy is DONE
+    (`copied()`; side by side the two fight over the page tables: the first 16-GiB read-back took 2.2 s instead of 0.7 s); later
+    ones get the block.  The arrays are ordinary writable numpy arrays; when the last view of one dies its block comes back here and ONE free
     block (the largest) is kept."""
     MIN_BYTES = 32 << 20
 
@@ -118,6 +119,7 @@ class _PinnedPool:
         self.enabled = os.environ.get('BLHIP_PINNED_RESULTS', '1') != '0'
         self.lock = threading.Lock()
         self.pending = None              # the background thread pinning a block
+        self.deferred = 0                # bytes of the block to pin once the pageable read-back in flight is done
 
     def _give_back(self, ptr, nbytes):
         try:
@@ -158,11 +160,17 @@ class _PinnedPool:
             if self.free is not None and nbytes <= self.free[1] <= 2 * nbytes:
                 (ptr, cap), self.free = self.free, None
         if not ptr:
-            self._pin_in_background(nbytes)
+            self.deferred = nbytes
             return np.empty(shape)       # this time through pageable memory
         buf = (C.c_char * cap).from_address(ptr)
         weakref.finalize(buf, self._give_back, ptr, cap)
         return np.frombuffer(buf, dtype=np.float64, count=nbytes // 8).reshape(shape)
+
+    def copied(self):
+        """The read-back into the array `empty` handed out last is complete: pin a block for the next one of that size."""
+        nbytes, self.deferred = self.deferred, 0
+        if nbytes:
+            self._pin_in_background(nbytes)
 
     def release(self):
         self.wait_ready(5.0)
@@ -345,7 +353,10 @@ class HipEngine:
         (or the rows t0 .. t1-1 of it)."""
         t1 = T if t1 is None else t1
         out = self._pinned.empty([t1 - t0] + list(grid_size))
-        self._check(self.lib.blhip_posterior_read(self.ctx, chain, t0, t1, _abi.dptr(out)))
+        try:
+            self._check(self.lib.blhip_posterior_read(self.ctx, chain, t0, t1, _abi.dptr(out)))
+        finally:
+            self._pinned.copied()
         return out
 
     def marginal(self, source, chain, keep_axis, T, n_keep):
@@ -408,7 +419,10 @@ class HipEngine:
     def accum_read(self, T, grid_size, t0=0, t1=None):
         t1 = T if t1 is None else t1
         out = self._pinned.empty([t1 - t0] + list(grid_size))
-        self._check(self.lib.blhip_accum_read(self.ctx, t0, t1, _abi.dptr(out)))
+        try:
+            self._check(self.lib.blhip_accum_read(self.ctx, t0, t1, _abi.dptr(out)))
+        finally:
+            self._pinned.copied()
         return out
 
     def accum_end(self):

@@ -232,6 +232,33 @@ def test_wide_axis1_walks_take_the_streaming_kernels():
         np.testing.assert_allclose(S.posteriorMeanValues, S0.posteriorMeanValues, rtol=1e-9, atol=1e-12)
 
 
+def test_big_read_backs_move_to_page_locked_arrays_after_the_first():
+    """engine._PinnedPool: the first read-back of a size goes to an ordinary array and a block of that size is pinned in the background
+    AFTER that copy is done; the next read-back of the size gets the block (same numbers), and the block returns to the pool with the
+    array's last view."""
+    eng = bl.get_engine()
+    pool = eng._pinned
+    if not pool.enabled:
+        pytest.skip('BLHIP_PINNED_RESULTS=0')
+    pool.release()
+    c = dict(study='Study', data=('series', 77, 66), om=cases.gauss2d(256, -6, 6, 3), tm=('GRW', 's1', 0.2, 'mean', None))
+    S = cases.build(bl, c); S.fit(silent=True)
+    assert pool.free is None and pool.deferred == 0
+    a = np.array(S.posteriorSequence)                    # 66 x 256 x 256 doubles = 34.6 MB > MIN_BYTES: pageable this time ...
+    assert pool.deferred == 0 and pool.pending is not None
+    pool.wait_ready()
+    assert pool.free is not None and pool.free[1] >= a.nbytes       # ... and a block of that size is pinned now
+    S2 = cases.build(bl, c); S2.fit(silent=True)
+    b = S2.posteriorSequence
+    assert pool.free is None                              # the block is out: b lives in it
+    assert np.array_equal(a, np.asarray(b))
+    del b
+    S2.posteriorSequence = None
+    S2._posterior_pending = None
+    import gc; gc.collect()
+    assert pool.free is not None                          # back in the pool
+
+
 def test_chains_without_an_axis1_filter_skip_the_pre_pass():
     """A hyper-grid over the width of a walk on the second parameter usually includes 0: those chains have no axis-1 filter and skip the
     pre-pass (it would copy their state): same results bit for bit as with wide_h_split = 0, fewer bytes.  wide_h_fused_max = 8 also lets
