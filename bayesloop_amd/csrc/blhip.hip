@@ -28,6 +28,7 @@
 #include "blhip_mfma.hpp"
 #include "blhip_hwide.hpp"
 #include "blhip_fused1d.hpp"
+#include "blhip_persist1d.hpp"
 #include "blhip_resident.hpp"
 #include "blhip_chainres.hpp"
 #include "blhip_nd.hpp"
@@ -407,6 +408,28 @@ void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, si
         case BLHIP_OM_GAUSSIAN_MEAN: launch_fused1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
         case BLHIP_OM_TABLE: launch_fused1d_om<OM_TABLE>(s, P, bwd, lds); break;
         default: fail("fused 1-D path: observation model %d", om);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+template <int OM>
+void launch_persist1d_om(hipStream_t s, const bl1p::P1Params &P, bool bwd, size_t lds) {
+    const dim3 grid(P.nblk, P.B), block(bl1p::NT);
+    if (bwd) {
+        arm_kernel(reinterpret_cast<const void *>(&bl1p::persist1d_kernel<OM, true>));
+        hipLaunchKernelGGL((bl1p::persist1d_kernel<OM, true>), grid, block, lds, s, P);
+    } else {
+        arm_kernel(reinterpret_cast<const void *>(&bl1p::persist1d_kernel<OM, false>));
+        hipLaunchKernelGGL((bl1p::persist1d_kernel<OM, false>), grid, block, lds, s, P);
+    }
+}
+
+void launch_persist1d(hipStream_t s, int om, const bl1p::P1Params &P, bool bwd, size_t lds) {
+    switch (om) {
+        case BLHIP_OM_POISSON: launch_persist1d_om<OM_POISSON>(s, P, bwd, lds); break;
+        case BLHIP_OM_GAUSSIAN_MEAN: launch_persist1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
+        case BLHIP_OM_TABLE: launch_persist1d_om<OM_TABLE>(s, P, bwd, lds); break;
+        default: fail("persistent 1-D path: observation model %d", om);
     }
     HIPCHECK(hipGetLastError());
 }
@@ -1986,7 +2009,40 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         // they had all finished (measured: rocprofv3 time line), queued ahead of them it shares the chip with them
         launch_pending_fold();
         HIPCHECK(hipEventRecord(ev[0], st));
-        if (fused1d) {
+        // 1-D grids whose blocks all fit on the chip at once: ONE persistent launch per pass (blhip_persist1d.hpp), else a launch per K steps
+        const bool p1d_now = fused1d && !resident_failed && ctx->resident_ok && ctx->option("persist1d", 1.0) != 0.0 &&
+                             (long long)tile.nblk * B <= std::min(ctx->num_cus, 256);
+        bl1p::P1Params P1{};
+        unsigned *d_abort1 = nullptr;
+        size_t p1d_bytes = 0;
+        if (p1d_now) {
+            const size_t xb = carve_size((size_t)2 * B * g.n1 * 16), gb = carve_size((size_t)2 * B * tile.nblk * 16);
+            p1d_bytes = xb + gb + carve_size(64);
+            ctx->p1d.ensure(p1d_bytes);
+            char *pc = ctx->p1d.as<char>();
+            P1.xch = carve<unsigned long long>(pc, (size_t)2 * B * g.n1 * 2);
+            P1.gran = carve<unsigned long long>(pc, (size_t)2 * B * tile.nblk * 2);
+            d_abort1 = carve<unsigned>(pc, 16);
+            P1.abort_word = d_abort1;
+            P1.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
+            P1.n = F1.n; P1.TJ = F1.TJ; P1.nblk = F1.nblk; P1.LW = F1.LW; P1.K = (int)K; P1.T = F1.T; P1.B = F1.B; P1.d = F1.d; P1.rec_len = F1.rec_len;
+            for (int k = 0; k < 5; ++k) P1.shared[k] = F1.shared[k];
+            P1.taps = F1.taps; P1.tap_off = F1.tap_off; P1.tap_lw = F1.tap_lw; P1.m1 = F1.m1; P1.colA = F1.colA; P1.rec = F1.rec; P1.lik = F1.lik;
+        }
+        auto launch_p1d = [&](bool bwd, double *psum) {
+            HIPCHECK(hipMemsetAsync(ctx->p1d.p, 0, p1d_bytes, st));       // tags 0, abort word 0
+            bl1p::P1Params Q = P1;
+            Q.dir = bwd ? -1 : 1; Q.psum = psum; Q.prev_slot = bwd ? 2 : 0;
+            Q.srckind = bwd ? d_kindB : d_kindF; Q.tap = bwd ? d_tapB1 : d_tapF1;
+            Q.store = (bwd || !evidence_only) ? 1 : 0; Q.means = bwd ? 1 : (forward_only ? 1 : 0);
+            Q.post = (bwd || !evidence_only) ? d_post : nullptr; Q.post_stride = (long long)T * G;
+            Q.src0 = (!bwd && resume) ? d_carry_src : nullptr; Q.src0_stride = G;
+            Q.dst = (bwd || evidence_only) ? d_pp[((T - 1) / K) & 1] : nullptr; Q.dst_stride = G;
+            launch_persist1d(st, p->obs_model, Q, bwd, f1_lds(K));
+        };
+        if (p1d_now) {
+            launch_p1d(false, d_psF);
+        } else if (fused1d) {
             for (int64_t t = 0; t < T; t += K) {
                 bl1f::F1Params Q = F1;
                 Q.K = (int)std::min<int64_t>(K, T - t); Q.dir = 1; Q.t_first = (int)t;
@@ -2050,6 +2106,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->timing.fwd_kernel_variant = 6;
             if (!CR.forward_ok(E, redF)) { resident_failed = true; return false; }
         }
+        if (p1d_now) {
+            ctx->timing.fwd_kernel_variant = 8;
+            if (resident_gave_up(ctx, st, d_abort1)) { resident_failed = true; return false; }
+        }
 
         bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
         tr.mark("forward checks + bookkeeping");
@@ -2062,7 +2122,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             double *d_psB = ctx->psumB.as<double>();
             if (fused1d && !raw_ok && K > 1) return false;
             HIPCHECK(hipEventRecord(ev[2], st));
-            if (fused1d) {
+            if (p1d_now) {
+                launch_p1d(true, d_psB);
+            } else if (fused1d) {
                 for (int64_t t = T - 1; t >= 0; t -= K) {
                     bl1f::F1Params Q = F1;
                     Q.K = (int)std::min<int64_t>(K, t + 1); Q.dir = -1; Q.t_first = (int)t;
@@ -2105,6 +2167,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 ctx->timing.bwd_kernel_variant = 5;
                 if (!RR.backward_ok(E, redB)) { resident_failed = true; return false; }
             }
+            if (p1d_now) {
+                ctx->timing.bwd_kernel_variant = 8;
+                if (resident_gave_up(ctx, st, d_abort1)) { resident_failed = true; return false; }
+            }
             if (cres_now) {
                 ctx->timing.bwd_kernel_variant = 6;
                 if (!CR.backward_ok(E, redB)) { resident_failed = true; return false; }
@@ -2130,11 +2196,11 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 ctx->timing.forward_ms = ctx->timing.backward_ms = 0.0;
                 ctx->timing.fwd_hbm_bytes = ctx->timing.bwd_hbm_bytes = ctx->timing.fwd_flops = ctx->timing.bwd_flops = 0.0;
                 ctx->timing.forward_launches = ctx->timing.backward_launches = 0;
-                ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = 1;
+                ctx->timing.fwd_kernel_variant = ctx->timing.bwd_kernel_variant = fast ? 1 : (fused1d ? 4 : 0);
                 n_mfma[0] = n_mfma[1] = n_fast[0] = n_fast[1] = 0;
                 if (!passes(fusedK)) fail("internal: the launch-per-step pass failed after the resident pass gave up");
             } else { usedK = 1; passes(1); }
-        } else if (resident || chainres) {
+        } else if (resident || chainres || ctx->timing.fwd_kernel_variant == 8) {
             ctx->resident_retry_after = 8;           // a resident pass went through: the next give-up starts from the short wait again
         }
 
@@ -2278,7 +2344,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,

@@ -1,0 +1,236 @@
+// 1-D grids, ONE launch per pass: the K-steps-per-launch scheme of blhip_fused1d.hpp with the launch boundary replaced by a
+// point-to-point hand-off inside a persistent kernel (BASELINE C2: 4096 cells, T = 10 000 -- 1250 launches of ~15 us per pass, of
+// which the 8 steps themselves are ~5 us: the rest is launch latency and the dependent loads of a launch's prologue).
+//
+// A "superstep" = what one launch of bl1f::fused1d_kernel does: a block owns TJ cells, loads them plus a halo of K * LW cells per side,
+// advances K steps in LDS (the halo is recomputed redundantly: the valid range shrinks by LW per step), stores the owned cells of every
+// step and the per-step partial sums.  Between supersteps a block needs
+//   * the final state of the cells in its halo (its 1 - 3 neighbours per side), and
+//   * the sum of that state over the WHOLE grid (lazy normalisation: the next superstep starts from state / sum) = nblk partial sums.
+// Both travel as data-tagged granules (two 8-byte words per double, {tag << 32 | half}, tag = producing superstep + 1; write-through
+// stores, sc1 loads: no flag, no fence, no barrier -- as the chain-resident kernels' sums), double-buffered by superstep parity: a block
+// that publishes superstep s + 2 has consumed its neighbours' superstep s + 1, which they published after reading its superstep s.
+// Results are bit-identical to the launch-per-K path (same arithmetic in the same order, the same raw sums for the host's bookkeeping).
+// Bounded spins + abort word as in blhip_resident.hpp; the host falls back to the launch-per-K path when a launch gives up, and uses
+// this kernel only when all blocks of a launch fit on the chip at once (nblk x chains <= CUs).
+#pragma once
+#include "blhip_fused1d.hpp"
+#include "blhip_resident.hpp"
+
+namespace bl1p {
+
+using blk::NRED;
+using blk::SRC_PREV;
+constexpr int NT = bl1f::NT;
+
+struct P1Params {
+    int n, TJ, nblk, LW, K, dir, T, B, d, rec_len, store, means;
+    const double *shared[5];
+    const double *src0; long long src0_stride;     // what the FIRST step consumes if its source kind is SRC_PREV (a resumed / carried state)
+    double *dst; long long dst_stride;             // state after the last step (or nullptr)
+    double *post; long long post_stride;           // (B, T, n) stored rows or nullptr (evidence only)
+    const unsigned char *srckind;                  // [T][B]
+    const int *tap;                                // [T][B] tap-set id, -1 = identity
+    const double *taps; const int *tap_off; const int *tap_lw;
+    int prev_slot;                                 // the sum a superstep's successor normalises by (0: forward, 2: backward)
+    double *psum;                                  // [T][B][NRED][nblk]
+    const double *m1, *colA, *rec, *lik;
+    unsigned long long *xch;                       // [2][B][n][2]    tagged halves of the state after a superstep
+    unsigned long long *gran;                      // [2][B][nblk][2] tagged halves of a block's partial sum of the superstep's last step
+    unsigned *abort_word;
+    unsigned long long timeout_ticks;
+};
+
+// one tagged double: -> value; false = timed out / another block gave up
+__device__ __forceinline__ bool fetch_tagged(const P1Params &P, const unsigned long long *g, unsigned long long want, double &v) {
+    unsigned long long q0 = blr::ld_u64(g), q1 = blr::ld_u64(g + 1);
+    bool alive = true;
+    if ((q0 >> 32) != want || (q1 >> 32) != want) {
+        const unsigned long long t0 = blr::now_ticks();
+        for (unsigned spins = 1;; ++spins) {
+            blr::nap();
+            q0 = blr::ld_u64(g); q1 = blr::ld_u64(g + 1);
+            if ((q0 >> 32) == want && (q1 >> 32) == want) break;
+            if ((spins & 255u) == 0u) {
+                if (blr::ld_flag(P.abort_word) != 0u) { alive = false; break; }
+                if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); alive = false; break; }
+            }
+        }
+    }
+    v = __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32)));
+    return alive;
+}
+__device__ __forceinline__ void publish_tagged(unsigned long long *g, unsigned long long tag, double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    blr::st_u64(g, (tag << 32) | (bits & 0xffffffffull));
+    blr::st_u64(g + 1, (tag << 32) | (bits >> 32));
+}
+
+template <int OM, bool BWD>
+__global__ __launch_bounds__(NT) void persist1d_kernel(const P1Params P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = P.n, halo = P.K * P.LW, W = P.TJ + 2 * halo;
+    double *cur = lds, *nxt = lds + W, *g1s = lds + 2 * W, *cAs = lds + 3 * W, *als = lds + 4 * W;
+    double *wls = als + (BWD ? P.K * P.TJ : 0);                   // [K][LW + 1] stencil weights of the K steps
+    double *recs = wls + P.K * (P.LW + 1);                        // [K][rec_len] data records of the K steps
+    double *red = recs + P.K * P.rec_len;
+    int *meta = (int *)(red + 4 * (NT / 64) + 2);                 // [K] source kind, [K] radius
+    double *part = red + 4 * (NT / 64) + 2 + P.K;                 // [K][3][TJ] per-cell terms of the K steps' sums
+    int *gave_up = (int *)(part + (size_t)P.K * 3 * P.TJ);        // (the allocation's spare words; __syncthreads_or would cost static LDS)
+    const int b = blockIdx.y, blkid = blockIdx.x, tid = threadIdx.x;
+    const int j0 = blkid * P.TJ, tw = min(P.TJ, n - j0);
+    double *post = P.post ? P.post + (long long)b * P.post_stride : nullptr;
+
+    blk::StepParams Q{};
+    Q.d = P.d; Q.n1 = n; Q.m0 = nullptr; Q.m1 = P.m1;
+
+    // per-cell constants of the window: the same for every superstep
+    for (int e = tid; e < W; e += NT) {
+        const int j = blk::reflect(j0 - halo + e, n);
+        g1s[e] = P.m1[j];
+        if (OM == blk::OM_POISSON) cAs[e] = P.colA[j];
+    }
+
+    const int NS = (P.T + P.K - 1) / P.K;
+    for (int s = 0; s < NS; ++s) {
+        const int t_first = P.dir > 0 ? s * P.K : P.T - 1 - s * P.K;
+        const int Ks = min(P.K, P.dir > 0 ? P.T - t_first : t_first + 1);
+        if (tid == 0) *gave_up = 0;
+        __syncthreads();                                           // the previous superstep is done with LDS
+        // ---- metadata, weights, data records (and the stored forward rows) of the superstep's steps: nobody else's data ----------------
+        for (int e = tid; e < Ks * (P.LW + 1); e += NT) {
+            const int st = e / (P.LW + 1), k = e - st * (P.LW + 1);
+            const long long tb = (long long)(t_first + P.dir * st) * P.B + b;
+            const int tp = P.tap[tb];
+            const int lw = tp >= 0 ? P.tap_lw[tp] : 0;
+            wls[e] = k <= lw ? (lw > 0 ? P.taps[P.tap_off[tp] + k] : 1.0) : 0.0;
+            if (k == 0) { meta[st] = P.srckind[tb]; meta[P.K + st] = lw; }
+        }
+        for (int e = tid; e < Ks * P.rec_len; e += NT) {
+            const int st = e / P.rec_len, k = e - st * P.rec_len;
+            recs[e] = P.rec[(long long)(t_first + P.dir * st) * P.rec_len + k];
+        }
+        if (BWD) {
+            for (int e = tid; e < Ks * P.TJ; e += NT) {
+                const int st = e / P.TJ, c = e - st * P.TJ;
+                als[e] = c < tw ? post[(long long)(t_first + P.dir * st) * n + j0 + c] : 0.0;
+            }
+        }
+        // ---- the window of the input state ------------------------------------------------------------------------------------------------
+        const int kind0 = P.srckind[(long long)t_first * P.B + b];
+        bool alive = true;
+        const unsigned long long want = (unsigned long long)(unsigned)s;                 // published by superstep s - 1
+        const int par = (s - 1) & 1;
+        double scale = 1.0;
+        if (s > 0) {
+            // the sums of ALL blocks, also when this superstep restarts from a shared distribution and has no use for them: every block
+            // has then finished reading the buffers of superstep s - 2 before anybody publishes superstep s into them
+            double v[1] = {0.0};
+            for (int k = tid; k < P.nblk; k += NT) {
+                double x;
+                alive = fetch_tagged(P, P.gran + ((((long long)par * P.B + b) * P.nblk + k) << 1), want, x) && alive;
+                v[0] += x;
+            }
+            blk::block_sums<1, NT / 64>(v, red);
+            scale = 1.0 / v[0];
+        }
+        if (s == 0 || kind0 != SRC_PREV) {
+            const double *src = kind0 == SRC_PREV ? P.src0 + (long long)b * P.src0_stride : P.shared[kind0];
+            for (int e = tid; e < W; e += NT) cur[e] = src[blk::reflect(j0 - halo + e, n)];
+        } else {
+            for (int e = tid; e < W; e += NT) {
+                const int j = blk::reflect(j0 - halo + e, n);
+                double x;
+                alive = fetch_tagged(P, P.xch + ((((long long)par * P.B + b) * n + j) << 1), want, x) && alive;
+                cur[e] = x * scale;
+            }
+        }
+        if (!alive) *gave_up = 1;
+        __syncthreads();
+        if (*gave_up) return;                                      // a block gave up (the abort word is set): the host repeats the pass
+
+        for (int st = 0; st < Ks; ++st) {
+            const int t = t_first + P.dir * st;
+            if (st > 0) __syncthreads();                           // previous step's writes of nxt / reads of cur are done
+            const int kind = meta[st], lw = meta[P.K + st];
+            const double *wl = wls + st * (P.LW + 1);
+            if (st > 0 && kind != SRC_PREV) {                      // restart from a shared distribution
+                const double *src = P.shared[kind];
+                for (int e = tid; e < W; e += NT) cur[e] = src[blk::reflect(j0 - halo + e, n)];
+                __syncthreads();
+            }
+            Q.rec = recs + st * P.rec_len;
+            Q.lik = P.lik ? P.lik + (long long)t * n : nullptr;
+            double *row = post ? post + (long long)t * n : nullptr;
+            double *pt = part + (size_t)st * 3 * P.TJ;
+            const int lo = (st + 1) * P.LW, hi = W - (st + 1) * P.LW;    // cells that are still exact after this step
+            for (int e = lo + tid; e < hi; e += NT) {
+                double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
+                int k = lw;
+                for (; k >= 4; k -= 4) {
+                    o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+                    o1 = fma(cur[e - k + 1] + cur[e + k - 1], wl[k - 1], o1);
+                    o2 = fma(cur[e - k + 2] + cur[e + k - 2], wl[k - 2], o2);
+                    o3 = fma(cur[e - k + 3] + cur[e + k - 3], wl[k - 3], o3);
+                }
+                for (; k >= 1; --k) o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+                const double o = (o0 + o1) + (o2 + o3);
+                const double g1 = g1s[e];
+                const double cA = (OM == blk::OM_POISSON) ? cAs[e] : 0.0;
+                const int j = (OM == blk::OM_TABLE) ? blk::reflect(j0 - halo + e, n) : 0;
+                const double L = blk::likelihood<OM>(Q, 0, j, cA, 0.0, g1);
+                const int oc = e - halo;                               // owned cell index of this block (0 <= oc < tw)
+                const bool owned = oc >= 0 && oc < tw;
+                if (!BWD) {
+                    const double a = o * L;
+                    nxt[e] = a;
+                    if (owned) {
+                        if (P.store) row[j0 + oc] = a;
+                        pt[oc] = a;
+                    }
+                } else {
+                    const double cn = o * L;
+                    nxt[e] = cn;
+                    if (owned) {
+                        const double p = als[st * P.TJ + oc] * o;
+                        row[j0 + oc] = p;
+                        pt[oc] = p;
+                        pt[P.TJ + oc] = p / L;                         // 0/0 -> NaN as numpy (core.py:463)
+                        pt[2 * P.TJ + oc] = cn;
+                    }
+                }
+            }
+            double *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        __syncthreads();
+        // ---- hand the superstep's result over: first the state the neighbours wait for, then the sum of its last step ----------------
+        const unsigned long long tag = (unsigned long long)(unsigned)(s + 1);
+        const bool more = s + 1 < NS;
+        if (more) {
+            unsigned long long *x = P.xch + ((((long long)(s & 1) * P.B + b) * n + j0) << 1);
+            for (int c = tid; c < tw; c += NT) publish_tagged(x + 2 * c, tag, cur[halo + c]);
+        }
+        // ---- the sums of the Ks steps: wave w takes the (step, slot) pairs w, w + 8, ...; fixed order -> deterministic ----------------
+        for (int pr = tid >> 6; pr < 4 * Ks; pr += NT / 64) {
+            const int st = pr >> 2, k = pr & 3, lane = tid & 63;
+            if (!(k == 0 || BWD || (k == 3 && P.means))) continue;
+            const double *pt = part + (size_t)st * 3 * P.TJ + (k == 3 ? 0 : k) * P.TJ;
+            double acc = 0.0;
+            if (k == 3) { for (int c = lane; c < tw; c += 64) acc = fma(pt[c], g1s[halo + c], acc); }
+            else { for (int c = lane; c < tw; c += 64) acc += pt[c]; }
+            acc = blk::wave_sum(acc);
+            if (lane == 0) {
+                const long long tb = (long long)(t_first + P.dir * st) * P.B + b;
+                P.psum[(tb * NRED + k) * P.nblk + blkid] = acc;
+                if (more && st == Ks - 1 && k == P.prev_slot)
+                    publish_tagged(P.gran + ((((long long)(s & 1) * P.B + b) * P.nblk + blkid) << 1), tag, acc);
+            }
+        }
+    }
+    if (P.dst) {
+        double *d = P.dst + (long long)b * P.dst_stride + j0;
+        for (int c = tid; c < tw; c += NT) d[c] = cur[halo + c];
+    }
+}
+
+}  // namespace bl1p
