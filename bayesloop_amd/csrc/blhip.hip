@@ -2010,7 +2010,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         launch_pending_fold();
         HIPCHECK(hipEventRecord(ev[0], st));
         // 1-D grids whose blocks all fit on the chip at once: ONE persistent launch per pass (blhip_persist1d.hpp), else a launch per K steps
-        const bool p1d_now = fused1d && !resident_failed && ctx->resident_ok && ctx->option("persist1d", 1.0) != 0.0 &&
+        // (a pass of a single superstep -- OnlineStudy.step, T <= K -- has no launch boundary to save)
+        const bool p1d_now = fused1d && !resident_failed && ctx->resident_ok && ctx->option("persist1d", 1.0) != 0.0 && T > K &&
                              (long long)tile.nblk * B <= std::min(ctx->num_cus, 256);
         bl1p::P1Params P1{};
         unsigned *d_abort1 = nullptr;
