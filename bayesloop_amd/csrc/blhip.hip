@@ -2035,6 +2035,20 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             bl1p::P1Params Q = P1;
             Q.dir = bwd ? -1 : 1; Q.psum = psum; Q.prev_slot = bwd ? 2 : 0;
             Q.srckind = bwd ? d_kindB : d_kindF; Q.tap = bwd ? d_tapB1 : d_tapF1;
+            {   // the pass's weights spelled out per (step, chain): the kernel stages a superstep's weights with ONE load per element
+                const long long TB = (long long)T * B;
+                const size_t wb = carve_size((size_t)TB * (P1.LW + 1) * 8), lb = carve_size((size_t)TB * 4);
+                if (wb + lb <= ((size_t)256 << 20) && ctx->option("persist1d_wtab", 1.0) != 0.0) {
+                    ctx->p1w.ensure(wb + lb);
+                    char *wc = ctx->p1w.as<char>();
+                    double *wtab = carve<double>(wc, (size_t)TB * (P1.LW + 1));
+                    int *lwtab = carve<int>(wc, (size_t)TB);
+                    const long long ne = TB * (P1.LW + 1);
+                    hipLaunchKernelGGL(bl1p::build_wtab_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, Q.tap, d_lw, d_off, d_taps, TB, P1.LW, wtab, lwtab);
+                    HIPCHECK(hipGetLastError());
+                    Q.wtab = wtab; Q.lwtab = lwtab;
+                }
+            }
             Q.store = (bwd || !evidence_only) ? 1 : 0; Q.means = bwd ? 1 : (forward_only ? 1 : 0);
             Q.post = (bwd || !evidence_only) ? d_post : nullptr; Q.post_stride = (long long)T * G;
             Q.src0 = (!bwd && resume) ? d_carry_src : nullptr; Q.src0_stride = G;
@@ -2345,7 +2359,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release(); ctx->p1w.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,

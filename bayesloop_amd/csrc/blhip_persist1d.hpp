@@ -32,6 +32,8 @@ struct P1Params {
     const unsigned char *srckind;                  // [T][B]
     const int *tap;                                // [T][B] tap-set id, -1 = identity
     const double *taps; const int *tap_off; const int *tap_lw;
+    const double *wtab; const int *lwtab;          // [T][B][LW + 1] / [T][B]: the steps' weights and radii spelled out (build_wtab_kernel), or nullptr:
+                                                   //   one load per staged element instead of the chain tap -> tap_lw / tap_off -> taps
     int prev_slot;                                 // the sum a superstep's successor normalises by (0: forward, 2: backward)
     double *psum;                                  // [T][B][NRED][nblk]
     const double *m1, *colA, *rec, *lik;
@@ -41,9 +43,9 @@ struct P1Params {
     unsigned long long timeout_ticks;
 };
 
-// one tagged double: -> value; false = timed out / another block gave up
-__device__ __forceinline__ bool fetch_tagged(const P1Params &P, const unsigned long long *g, unsigned long long want, double &v) {
-    unsigned long long q0 = blr::ld_u64(g), q1 = blr::ld_u64(g + 1);
+// one tagged double (q0, q1: a first attempt requested earlier): -> value; false = timed out / another block gave up
+__device__ __forceinline__ bool finish_tagged(const P1Params &P, const unsigned long long *g, unsigned long long want,
+                                              unsigned long long q0, unsigned long long q1, double &v) {
     bool alive = true;
     if ((q0 >> 32) != want || (q1 >> 32) != want) {
         const unsigned long long t0 = blr::now_ticks();
@@ -60,10 +62,27 @@ __device__ __forceinline__ bool fetch_tagged(const P1Params &P, const unsigned l
     v = __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32)));
     return alive;
 }
+__device__ __forceinline__ bool fetch_tagged(const P1Params &P, const unsigned long long *g, unsigned long long want, double &v) {
+    const unsigned long long q0 = blr::ld_u64(g), q1 = blr::ld_u64(g + 1);
+    return finish_tagged(P, g, want, q0, q1, v);
+}
 __device__ __forceinline__ void publish_tagged(unsigned long long *g, unsigned long long tag, double v) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     blr::st_u64(g, (tag << 32) | (bits & 0xffffffffull));
     blr::st_u64(g + 1, (tag << 32) | (bits >> 32));
+}
+
+// the weights and radii of every (step, chain) spelled out: [TB][LW + 1] / [TB] (the same expression the kernels stage their weights with)
+__global__ void build_wtab_kernel(const int *tap, const int *tap_lw, const int *tap_off, const double *taps, long long TB, int LW,
+                                  double *wtab, int *lwtab) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= TB * (LW + 1)) return;
+    const long long tb = i / (LW + 1);
+    const int k = (int)(i - tb * (LW + 1));
+    const int tp = tap[tb];
+    const int lw = tp >= 0 ? tap_lw[tp] : 0;
+    wtab[i] = k <= lw ? (lw > 0 ? taps[tap_off[tp] + k] : 1.0) : 0.0;
+    if (k == 0) lwtab[tb] = lw;
 }
 
 template <int OM, bool BWD>
@@ -97,8 +116,55 @@ __global__ __launch_bounds__(NT) void persist1d_kernel(const P1Params P) {
         const int Ks = min(P.K, P.dir > 0 ? P.T - t_first : t_first + 1);
         if (tid == 0) *gave_up = 0;
         __syncthreads();                                           // the previous superstep is done with LDS
-        // ---- metadata, weights, data records (and the stored forward rows) of the superstep's steps: nobody else's data ----------------
-        for (int e = tid; e < Ks * (P.LW + 1); e += NT) {
+        // ---- everything the superstep needs from memory is REQUESTED first and consumed afterwards (one round trip, not five): a first
+        //      attempt at what the other blocks publish (this thread's partial sum and window cell of superstep s - 1: requested whatever
+        //      the source kind turns out to be, harmless), then the steps' metadata / weights / data records / stored forward rows -------
+        const unsigned long long want = (unsigned long long)(unsigned)s;                 // published by superstep s - 1
+        const int par = (s - 1) & 1;
+        const unsigned long long *gp = P.gran + ((((long long)par * P.B + b) * P.nblk + min(tid, P.nblk - 1)) << 1);
+        const unsigned long long *xp = P.xch + ((((long long)par * P.B + b) * n + blk::reflect(j0 - halo + min(tid, W - 1), n)) << 1);
+        unsigned long long gq0 = 0ull, gq1 = 0ull, xq0 = 0ull, xq1 = 0ull;
+        if (s > 0) { gq0 = blr::ld_u64(gp); gq1 = blr::ld_u64(gp + 1); xq0 = blr::ld_u64(xp); xq1 = blr::ld_u64(xp + 1); }
+        const int kind0 = P.srckind[(long long)t_first * P.B + b];
+        constexpr int MW = 2, MA = 4;                              // staged elements per thread held in registers (the rest: loaded in place)
+        const int nw = Ks * (P.LW + 1), na = BWD ? Ks * P.TJ : 0;
+        double wreg[MW], areg[MA];
+        int kreg[MW], lreg[MW];
+#pragma unroll
+        for (int r = 0; r < MW; ++r) {
+            const int e = tid + r * NT;
+            wreg[r] = 0.0; kreg[r] = 0; lreg[r] = 0;
+            if (P.wtab && e < nw) {
+                const int st = e / (P.LW + 1), k = e - st * (P.LW + 1);
+                const long long tb = (long long)(t_first + P.dir * st) * P.B + b;
+                wreg[r] = P.wtab[tb * (P.LW + 1) + k];
+                if (k == 0) { kreg[r] = P.srckind[tb]; lreg[r] = P.lwtab[tb]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MA; ++r) {
+            const int e = tid + r * NT;
+            areg[r] = 0.0;
+            if (e < na) {
+                const int st = e / P.TJ, c = e - st * P.TJ;
+                areg[r] = c < tw ? post[(long long)(t_first + P.dir * st) * n + j0 + c] : 0.0;
+            }
+        }
+        for (int e = tid; e < Ks * P.rec_len; e += NT) {
+            const int st = e / P.rec_len, k = e - st * P.rec_len;
+            recs[e] = P.rec[(long long)(t_first + P.dir * st) * P.rec_len + k];
+        }
+        // ---- consume ------------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < MW; ++r) {
+            const int e = tid + r * NT;
+            if (P.wtab && e < nw) {
+                wls[e] = wreg[r];
+                const int st = e / (P.LW + 1);
+                if (e - st * (P.LW + 1) == 0) { meta[st] = kreg[r]; meta[P.K + st] = lreg[r]; }
+            }
+        }
+        for (int e = P.wtab ? tid + MW * NT : tid; e < nw; e += NT) {      // (no table, or more elements than the registers hold)
             const int st = e / (P.LW + 1), k = e - st * (P.LW + 1);
             const long long tb = (long long)(t_first + P.dir * st) * P.B + b;
             const int tp = P.tap[tb];
@@ -106,27 +172,30 @@ __global__ __launch_bounds__(NT) void persist1d_kernel(const P1Params P) {
             wls[e] = k <= lw ? (lw > 0 ? P.taps[P.tap_off[tp] + k] : 1.0) : 0.0;
             if (k == 0) { meta[st] = P.srckind[tb]; meta[P.K + st] = lw; }
         }
-        for (int e = tid; e < Ks * P.rec_len; e += NT) {
-            const int st = e / P.rec_len, k = e - st * P.rec_len;
-            recs[e] = P.rec[(long long)(t_first + P.dir * st) * P.rec_len + k];
-        }
         if (BWD) {
-            for (int e = tid; e < Ks * P.TJ; e += NT) {
+#pragma unroll
+            for (int r = 0; r < MA; ++r) {
+                const int e = tid + r * NT;
+                if (e < na) als[e] = areg[r];
+            }
+            for (int e = tid + MA * NT; e < na; e += NT) {
                 const int st = e / P.TJ, c = e - st * P.TJ;
                 als[e] = c < tw ? post[(long long)(t_first + P.dir * st) * n + j0 + c] : 0.0;
             }
         }
         // ---- the window of the input state ------------------------------------------------------------------------------------------------
-        const int kind0 = P.srckind[(long long)t_first * P.B + b];
         bool alive = true;
-        const unsigned long long want = (unsigned long long)(unsigned)s;                 // published by superstep s - 1
-        const int par = (s - 1) & 1;
         double scale = 1.0;
         if (s > 0) {
             // the sums of ALL blocks, also when this superstep restarts from a shared distribution and has no use for them: every block
             // has then finished reading the buffers of superstep s - 2 before anybody publishes superstep s into them
             double v[1] = {0.0};
-            for (int k = tid; k < P.nblk; k += NT) {
+            if (tid < P.nblk) {
+                double x;
+                alive = finish_tagged(P, gp, want, gq0, gq1, x) && alive;
+                v[0] += x;
+            }
+            for (int k = tid + NT; k < P.nblk; k += NT) {
                 double x;
                 alive = fetch_tagged(P, P.gran + ((((long long)par * P.B + b) * P.nblk + k) << 1), want, x) && alive;
                 v[0] += x;
@@ -138,7 +207,12 @@ __global__ __launch_bounds__(NT) void persist1d_kernel(const P1Params P) {
             const double *src = kind0 == SRC_PREV ? P.src0 + (long long)b * P.src0_stride : P.shared[kind0];
             for (int e = tid; e < W; e += NT) cur[e] = src[blk::reflect(j0 - halo + e, n)];
         } else {
-            for (int e = tid; e < W; e += NT) {
+            if (tid < W) {
+                double x;
+                alive = finish_tagged(P, xp, want, xq0, xq1, x) && alive;
+                cur[tid] = x * scale;
+            }
+            for (int e = tid + NT; e < W; e += NT) {
                 const int j = blk::reflect(j0 - halo + e, n);
                 double x;
                 alive = fetch_tagged(P, P.xch + ((((long long)par * P.B + b) * n + j) << 1), want, x) && alive;
