@@ -1,6 +1,7 @@
 // 1-D grids, ONE launch per pass: the K-steps-per-launch scheme of blhip_fused1d.hpp with the launch boundary replaced by a
-// point-to-point hand-off inside a persistent kernel (BASELINE C2: 4096 cells, T = 10 000 -- 1250 launches of ~15 us per pass, of
-// which the 8 steps themselves are ~5 us: the rest is launch latency and the dependent loads of a launch's prologue).
+// point-to-point hand-off inside a persistent kernel (BASELINE C2: 4096 cells, T = 10 000 -- 1250 launches of ~15 us per pass).
+// Measured: 42.1 -> 36.2 ms per C2 fit (1.86 / 2.07 -> 1.64 / 1.75 us per step); what goes is the launch latency and the dependent
+// loads of a launch's prologue, the ~1.4 us of a step itself (a latency chain with one cell per thread) stay.
 //
 // A "superstep" = what one launch of bl1f::fused1d_kernel does: a block owns TJ cells, loads them plus a halo of K * LW cells per side,
 // advances K steps in LDS (the halo is recomputed redundantly: the valid range shrinks by LW per step), stores the owned cells of every
@@ -9,7 +10,7 @@
 //   * the sum of that state over the WHOLE grid (lazy normalisation: the next superstep starts from state / sum) = nblk partial sums.
 // Both travel as data-tagged granules (two 8-byte words per double, {tag << 32 | half}, tag = producing superstep + 1; write-through
 // stores, sc1 loads: no flag, no fence, no barrier -- as the chain-resident kernels' sums), double-buffered by superstep parity: a block
-// that publishes superstep s + 2 has consumed its neighbours' superstep s + 1, which they published after reading its superstep s.
+// that publishes superstep s + 2 has gathered EVERY block's sum of superstep s + 1, which they published after reading superstep s.
 // Results are bit-identical to the launch-per-K path (same arithmetic in the same order, the same raw sums for the host's bookkeeping).
 // Bounded spins + abort word as in blhip_resident.hpp; the host falls back to the launch-per-K path when a launch gives up, and uses
 // this kernel only when all blocks of a launch fit on the chip at once (nblk x chains <= CUs).
