@@ -40,6 +40,53 @@ struct F1Params {
     const double *m1, *colA, *rec, *lik;
 };
 
+// One step over the cells of a block's window that are still exact after it (lo .. hi - 1): stencil out of LDS, likelihood, new state
+// -> nxt; the owned cells store their row and park the terms of the step's sums in pt[3][TJ].  Shared with the persistent kernel
+// (blhip_persist1d.hpp): the same instructions in the same order, so the two paths agree bit for bit.
+//   wl: the step's weights [LW + 1], lw its radius; als_s: the stored forward row of the step's owned cells (backward only)
+template <int OM, bool BWD>
+__device__ __forceinline__ void advance_cells(const blk::StepParams &Q, int n, int j0, int halo, int tw, int TJ, int lo, int hi, const double *cur,
+                                              double *nxt, const double *g1s, const double *cAs, const double *wl, int lw,
+                                              const double *als_s, double *row, double *pt, bool store, int tid) {
+    for (int e = lo + tid; e < hi; e += NT) {
+        // four interleaved accumulators: a single fp64 FMA chain of 2 lw + 1 links costs ~32 cycles per link
+        double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
+        int k = lw;
+        for (; k >= 4; k -= 4) {
+            o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+            o1 = fma(cur[e - k + 1] + cur[e + k - 1], wl[k - 1], o1);
+            o2 = fma(cur[e - k + 2] + cur[e + k - 2], wl[k - 2], o2);
+            o3 = fma(cur[e - k + 3] + cur[e + k - 3], wl[k - 3], o3);
+        }
+        for (; k >= 1; --k) o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+        const double o = (o0 + o1) + (o2 + o3);
+        const double g1 = g1s[e];
+        const double cA = (OM == blk::OM_POISSON) ? cAs[e] : 0.0;
+        const int j = (OM == blk::OM_TABLE) ? blk::reflect(j0 - halo + e, n) : 0;
+        const double L = blk::likelihood<OM>(Q, 0, j, cA, 0.0, g1);
+        const int oc = e - halo;                               // owned cell index of this block (0 <= oc < tw)
+        const bool owned = oc >= 0 && oc < tw;
+        if (!BWD) {
+            const double a = o * L;
+            nxt[e] = a;
+            if (owned) {
+                if (store) row[j0 + oc] = a;
+                pt[oc] = a;
+            }
+        } else {
+            const double cn = o * L;
+            nxt[e] = cn;
+            if (owned) {
+                const double p = als_s[oc] * o;
+                row[j0 + oc] = p;
+                pt[oc] = p;
+                pt[TJ + oc] = p / L;                           // 0/0 -> NaN as numpy (core.py:463)
+                pt[2 * TJ + oc] = cn;
+            }
+        }
+    }
+}
+
 template <int OM, bool BWD>
 __global__ __launch_bounds__(NT) void fused1d_kernel(const F1Params P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -116,43 +163,7 @@ __global__ __launch_bounds__(NT) void fused1d_kernel(const F1Params P) {
         // cells park their terms in LDS and all K steps are reduced after the loop.  ONE barrier per step (top of the loop).
         double *pt = part + (size_t)s * 3 * P.TJ;
         const int lo = (s + 1) * P.LW, hi = W - (s + 1) * P.LW;    // cells that are still exact after this step
-        for (int e = lo + tid; e < hi; e += NT) {
-            // four interleaved accumulators: a single fp64 FMA chain of 2 lw + 1 links costs ~32 cycles per link
-            double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
-            int k = lw;
-            for (; k >= 4; k -= 4) {
-                o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
-                o1 = fma(cur[e - k + 1] + cur[e + k - 1], wl[k - 1], o1);
-                o2 = fma(cur[e - k + 2] + cur[e + k - 2], wl[k - 2], o2);
-                o3 = fma(cur[e - k + 3] + cur[e + k - 3], wl[k - 3], o3);
-            }
-            for (; k >= 1; --k) o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
-            const double o = (o0 + o1) + (o2 + o3);
-            const double g1 = g1s[e];
-            const double cA = (OM == blk::OM_POISSON) ? cAs[e] : 0.0;
-            const int j = (OM == blk::OM_TABLE) ? blk::reflect(j0 - halo + e, n) : 0;
-            const double L = blk::likelihood<OM>(Q, 0, j, cA, 0.0, g1);
-            const int oc = e - halo;                               // owned cell index of this block (0 <= oc < tw)
-            const bool owned = oc >= 0 && oc < tw;
-            if (!BWD) {
-                const double a = o * L;
-                nxt[e] = a;
-                if (owned) {
-                    if (P.store) row[j0 + oc] = a;
-                    pt[oc] = a;
-                }
-            } else {
-                const double cn = o * L;
-                nxt[e] = cn;
-                if (owned) {
-                    const double p = als[s * P.TJ + oc] * o;
-                    row[j0 + oc] = p;
-                    pt[oc] = p;
-                    pt[P.TJ + oc] = p / L;                         // 0/0 -> NaN as numpy (core.py:463)
-                    pt[2 * P.TJ + oc] = cn;
-                }
-            }
-        }
+        advance_cells<OM, BWD>(Q, n, j0, halo, tw, P.TJ, lo, hi, cur, nxt, g1s, cAs, wl, lw, als + s * P.TJ, row, pt, P.store != 0, tid);
         double *tmp = cur; cur = nxt; nxt = tmp;
     }
     __syncthreads();

@@ -239,42 +239,7 @@ __global__ __launch_bounds__(NT) void persist1d_kernel(const P1Params P) {
             double *row = post ? post + (long long)t * n : nullptr;
             double *pt = part + (size_t)st * 3 * P.TJ;
             const int lo = (st + 1) * P.LW, hi = W - (st + 1) * P.LW;    // cells that are still exact after this step
-            for (int e = lo + tid; e < hi; e += NT) {
-                double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
-                int k = lw;
-                for (; k >= 4; k -= 4) {
-                    o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
-                    o1 = fma(cur[e - k + 1] + cur[e + k - 1], wl[k - 1], o1);
-                    o2 = fma(cur[e - k + 2] + cur[e + k - 2], wl[k - 2], o2);
-                    o3 = fma(cur[e - k + 3] + cur[e + k - 3], wl[k - 3], o3);
-                }
-                for (; k >= 1; --k) o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
-                const double o = (o0 + o1) + (o2 + o3);
-                const double g1 = g1s[e];
-                const double cA = (OM == blk::OM_POISSON) ? cAs[e] : 0.0;
-                const int j = (OM == blk::OM_TABLE) ? blk::reflect(j0 - halo + e, n) : 0;
-                const double L = blk::likelihood<OM>(Q, 0, j, cA, 0.0, g1);
-                const int oc = e - halo;                               // owned cell index of this block (0 <= oc < tw)
-                const bool owned = oc >= 0 && oc < tw;
-                if (!BWD) {
-                    const double a = o * L;
-                    nxt[e] = a;
-                    if (owned) {
-                        if (P.store) row[j0 + oc] = a;
-                        pt[oc] = a;
-                    }
-                } else {
-                    const double cn = o * L;
-                    nxt[e] = cn;
-                    if (owned) {
-                        const double p = als[st * P.TJ + oc] * o;
-                        row[j0 + oc] = p;
-                        pt[oc] = p;
-                        pt[P.TJ + oc] = p / L;                         // 0/0 -> NaN as numpy (core.py:463)
-                        pt[2 * P.TJ + oc] = cn;
-                    }
-                }
-            }
+            bl1f::advance_cells<OM, BWD>(Q, n, j0, halo, tw, P.TJ, lo, hi, cur, nxt, g1s, cAs, wl, lw, als + st * P.TJ, row, pt, P.store != 0, tid);
             double *tmp = cur; cur = nxt; nxt = tmp;
         }
         __syncthreads();
