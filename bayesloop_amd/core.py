@@ -843,14 +843,25 @@ class HyperStudy(Study):
         devices = [getattr(root_engine, 'device', 0)]
         if self.communicator is None and nJobs and int(nJobs) > 1 and hasattr(root_engine, 'ctx'):
             devices = _dist.local_devices(int(nJobs), getattr(root_engine, 'device', 0))
-        if len(devices) > 1:
-            engines, seen = [], set()
-            for dev in devices:            # (a repeated ordinal -- BLHIP_NJOBS_DEVICES=0,0, tests -- gets a context of its own)
-                engines.append(_engine_mod.engine_for_device(dev) if dev not in seen else _engine_mod.extra_engine(dev))
-                seen.add(dev)
-            out = _dist.local_sharded_hyper_fit(engines, problem, op_values, prior_values, forward_only=forwardOnly,
-                                                evidence_only=evidenceOnly, owner=self)
-        else:
+        out = None
+        if len(devices) > 1 and not _dist.multi_gpu_disabled():
+            # Several GPUs from this one process.  The exchange is checked end to end on every fit (the merged accumulator's per-step
+            # sums against the parts', dist.sharded_hyper_fit); if anything on that path fails -- a peer copy, a context on another
+            # device, the checksum -- the fit is repeated on the root device alone and the process stops using the path: the answer
+            # never depends on the multi-device plumbing.  BLHIP_NJOBS_MULTI_GPU=0 switches the path off, =strict re-raises.
+            try:
+                engines, seen = [], set()
+                for dev in devices:        # (a repeated ordinal -- BLHIP_NJOBS_DEVICES=0,0, tests -- gets a context of its own)
+                    engines.append(_engine_mod.engine_for_device(dev) if dev not in seen else _engine_mod.extra_engine(dev))
+                    seen.add(dev)
+                out = _dist.local_sharded_hyper_fit(engines, problem, op_values, prior_values, forward_only=forwardOnly,
+                                                    evidence_only=evidenceOnly, owner=self)
+            except Exception as exc:       # noqa: BLE001 -- anything the multi-device path raises; the single-device path is the reference
+                if _dist.multi_gpu_strict():
+                    raise
+                _dist.disable_multi_gpu('%s: %s' % (type(exc).__name__, exc))
+                out = None
+        if out is None:
             out = _dist.sharded_hyper_fit(root_engine, problem, op_values, prior_values, self.communicator,
                                           forward_only=forwardOnly, evidence_only=evidenceOnly, owner=self)
         self.lastTiming = out['timing']

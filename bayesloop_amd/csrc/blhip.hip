@@ -438,29 +438,30 @@ void launch_persist1d(hipStream_t s, int om, const bl1p::P1Params &P, bool bwd, 
 struct ResidentPlan {
     int TR = 0, TC = 0, SEG = 0, tr = 0, tc = 0, ntiles = 0, NT = 0;
     bool pad = false;            // the grid does not fill its last tile row / column (PAD kernels)
+    bool onex = false;           // 64 x 64 tiles: one hand-off per step (option resident_onex, blhip_resident.hpp: ONEX)
     size_t lds_bytes = 0;
 };
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID, bool PAD = false>
+template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID, bool PAD = false, bool ONEX = false>
 void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
-    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID, PAD>::LDS_DOUBLES * sizeof(double);
-    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>));
-    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID, PAD, ONEX>::LDS_DOUBLES * sizeof(double);
+    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD, ONEX>));
+    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD, ONEX>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
 }
 
-template <int TR, int TC, int SEG, int CHK>
+template <int TR, int TC, int SEG, int CHK, bool ONEX = false>
 void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad = false) {
     // forward pass of an evidence-only fit: nothing stored, no means, no rows to normalise -> the flavour with compile-time flags
     const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
     if (pad) {                   // grids that do not fill their last tile row / column
-        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, true>(s, Q);
-        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, true>(s, Q);
-        else launch_resident_k<TR, TC, SEG, CHK, false, false, true>(s, Q);
+        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, true, ONEX>(s, Q);
+        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, true, ONEX>(s, Q);
+        else launch_resident_k<TR, TC, SEG, CHK, false, false, true, ONEX>(s, Q);
         return;
     }
-    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false>(s, Q);
-    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true>(s, Q);
-    else launch_resident_k<TR, TC, SEG, CHK, false, false>(s, Q);
+    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, false, ONEX>(s, Q);
+    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, false, ONEX>(s, Q);
+    else launch_resident_k<TR, TC, SEG, CHK, false, false, false, ONEX>(s, Q);
 }
 
 // tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
@@ -473,6 +474,7 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
         launch_resident_k<128, 128, 16, 4, false, true>(s, Q);
     }
     else if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd, rp.pad);
+    else if (rp.TR == 64 && rp.onex) launch_resident_t<64, 64, 8, 8, true>(s, Q, bwd, rp.pad);
     else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd, rp.pad);
     else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd, rp.pad);
     else launch_resident_t<32, 32, 8, 8>(s, Q, bwd, rp.pad);

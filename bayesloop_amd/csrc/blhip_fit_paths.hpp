@@ -67,6 +67,7 @@ struct ResidentRun {
             plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
                           (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0, (int)ctx->option("resident_min_tile", 32.0))) {
             on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
+            rp.onex = rp.TR == 64 && rp.TC == 64 && ctx->option("resident_onex", 1.0) != 0.0;
             // (the padded 128 x 128 BACKWARD kernel spills 231 registers: 2000 x 1100, backward step 40 - 45 us against 26.8 us with one
             //  launch per step -- full fits of such grids keep the launch-per-step kernels, evidence-only / forward-only fits do not)
             if (rp.pad && rp.TR == 128 && full) on = false;

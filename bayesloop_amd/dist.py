@@ -342,6 +342,18 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
         if ok and comm is not None:
             engine.accum_rescale(gref)
             comm.reduce_accumulator(engine, root=0)
+            if rank == 0 and size > 1 and gstats is not None:
+                # checksum of the merge: the per-step sums of the merged accumulator must be the sum of the per-step sums every rank
+                # reported BEFORE the exchange (they travelled with the gather).  A peer copy / reduce that dropped, duplicated or
+                # mis-ordered a slice cannot pass; costs one pass over the accumulator on the root.
+                merged = engine.accum_row_stats(problem)
+                want = np.asarray(gstats)
+                bad = ~(np.abs(merged - want) <= 1e-9 * np.abs(want) + 1e-300)
+                if np.any(bad):
+                    from .engine import BackendError
+                    t_bad = int(np.argmax(np.any(bad, axis=1)))
+                    raise BackendError('accumulator merge over %d devices failed its checksum (first bad time step %d: merged %r, '
+                                       'sum of the parts %r)' % (size, t_bad, merged[t_bad].tolist(), want[t_bad].tolist()))
         if ok and rank == 0:
             means = engine.accum_finalize(problem)
             from .engine import DevicePosterior
@@ -427,6 +439,26 @@ class _nullcontext:
         return False
 
 
+_MULTI_GPU_OFF = []          # reasons; non-empty: the in-process multi-GPU path is off for the rest of the process
+
+
+def multi_gpu_strict():
+    return os.environ.get('BLHIP_NJOBS_MULTI_GPU', '').lower() == 'strict'
+
+
+def multi_gpu_disabled():
+    return bool(_MULTI_GPU_OFF) or os.environ.get('BLHIP_NJOBS_MULTI_GPU', '1').lower() in ('0', 'off', 'no')
+
+
+def disable_multi_gpu(reason):
+    """The in-process multi-GPU path failed: say so ONCE on stderr, keep fitting on the root device."""
+    import sys
+    if not _MULTI_GPU_OFF:
+        sys.stderr.write('[bayesloop_amd] fit(nJobs > 1) over several GPUs failed (%s); this fit is repeated on one GPU and the '
+                         'process keeps using one GPU (BLHIP_NJOBS_MULTI_GPU=strict to raise instead)\n' % reason)
+    _MULTI_GPU_OFF.append(str(reason))
+
+
 def local_devices(n_jobs, root_device=0):
     """Devices of an in-process sharded fit: ``BLHIP_NJOBS_DEVICES`` (comma-separated ordinals, duplicates allowed: a test
     configuration) or the first min(n_jobs, visible) devices starting with the root engine's."""
@@ -460,15 +492,15 @@ def local_sharded_hyper_fit(engines, problem, op_values, prior_values, forward_o
     work(0)
     for t in threads:
         t.join()
-    if errors:
-        import threading as _t
-        first = [e for r, e in sorted(errors, key=lambda x: x[0]) if not isinstance(e, _t.BrokenBarrierError)]
-        raise (first[0] if first else errors[0][1])
-    for r in range(1, group.size):        # the other devices' accumulators are spent
+    for r in range(1, group.size):        # the other devices' accumulators are spent -- also when a thread failed (up to 16 GiB each)
         try:
             engines[r].accum_end()
         except Exception:                 # noqa: BLE001
             pass
+    if errors:
+        import threading as _t
+        first = [e for r, e in sorted(errors, key=lambda x: x[0]) if not isinstance(e, _t.BrokenBarrierError)]
+        raise (first[0] if first else errors[0][1])
     out = results[0]
     out['per_rank_timing'] = [res['timing'] if res else {} for res in results]
     return out

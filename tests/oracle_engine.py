@@ -179,8 +179,9 @@ class OracleEngine:
         g = orc.Grid(problem.marginal)
         out = np.zeros((T, 1 + len(g.size)))
         ref = np.amax(self.acc_log)
-        if np.isfinite(ref):
-            lin = np.exp(self.acc_log - ref)
+        if self.acc_lin is not None or np.isfinite(ref):
+            # (after accum_rescale -- and the cross-rank merge -- the linear accumulator is what the device holds)
+            lin = np.array(self.acc_lin, dtype=float).reshape(T, G) if self.acc_lin is not None else np.exp(self.acc_log - ref)
             out[:, 0] = lin.sum(axis=1)
             for k in range(len(g.size)):
                 out[:, 1 + k] = lin @ g.grid[k].ravel()

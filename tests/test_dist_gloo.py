@@ -318,3 +318,71 @@ def test_local_group_propagates_a_failing_thread():
     problem = types.SimpleNamespace(T=2, G=4, grid_size=[4])
     with pytest.raises(Boom):
         dist.local_sharded_hyper_fit([E(0), E(1)], problem, np.zeros((2, 1)), np.ones(2))
+
+
+def _fit_over_fake_devices(case, engines, **env):
+    """HyperStudy.fit(nJobs = len(engines)) of a golden case through the in-process multi-device path on the given (oracle) engines."""
+    import bayesloop_amd as bl
+    import bayesloop_amd.engine as em
+    import cases
+    from bayesloop_amd import dist
+    n = len(engines)
+    for k, e in enumerate(engines):
+        e.device = k
+    engines[0].ctx = object()
+    real, orig_for, orig_get = dist.local_devices, em.engine_for_device, em.get_engine
+    em.engine_for_device = lambda d: engines[d]
+    em.get_engine = lambda: engines[0]
+    dist.local_devices = lambda n_jobs, root=0: list(range(n))
+    prev = bl.set_engine(engines[0])
+    try:
+        S = cases.build(bl, case)
+        with np.errstate(all='ignore'):
+            S.fit(nJobs=n, **cases.fit_kwargs(case))
+        return S
+    finally:
+        bl.set_engine(prev)
+        dist.local_devices, em.engine_for_device, em.get_engine = real, orig_for, orig_get
+
+
+def test_a_broken_accumulator_merge_is_caught_and_the_fit_repeated_on_one_device(capfd, monkeypatch):
+    """Advisor finding (round 3): the cross-device merge had never run on two physical GPUs, yet fit(nJobs = N) takes it by default.  The
+    merge is now checked on EVERY fit (per-step sums of the merged accumulator against the sums the ranks reported before the exchange);
+    a merge that drops a slice fails the check, the fit is repeated on the root device alone -- same answer as the unsharded golden --
+    with one line on stderr, and the process stops using the multi-device path."""
+    import compare
+    import oracle_adapter as oa
+    from bayesloop_amd import dist
+    from oracle_engine import OracleEngine
+
+    class Lossy(OracleEngine):              # a peer reduce that forgets the last source (what a failed peer copy would look like)
+        def accum_peer_reduce(self, others, row0, row1):
+            OracleEngine.accum_peer_reduce(self, others[:-1], row0, row1)
+
+    monkeypatch.setattr(dist, '_MULTI_GPU_OFF', [])
+    monkeypatch.delenv('BLHIP_NJOBS_MULTI_GPU', raising=False)
+    engines = [Lossy() for _ in range(3)]
+    S = _fit_over_fake_devices('kat_hyper_1hp', engines)
+    err = capfd.readouterr().err
+    assert 'failed its checksum' in err and err.count('[bayesloop_amd] fit(nJobs > 1)') == 1
+    assert dist.multi_gpu_disabled()
+    gold = oa.load_golden('kat_hyper_1hp')
+    res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence, logEvidenceList=np.array(S.logEvidenceList),
+               hyperParameterDistribution=S.hyperParameterDistribution, posteriorMeanValues=S.posteriorMeanValues,
+               posteriorSequence=S.posteriorSequence)
+    compare.check(res, gold, dict(compare.ORACLE_TOL, post_rtol=1e-10, small_rtol=1e-10))
+    assert engines[0].fits > len(S.logEvidenceList) // 3          # (the repeat ran every chain on the root device)
+    # the next fit does not try the path again, and says nothing
+    S2 = _fit_over_fake_devices('kat_hyper_1hp', engines)
+    assert capfd.readouterr().err == '' and S2.logEvidence == S.logEvidence
+    # strict mode re-raises instead
+    monkeypatch.setattr(dist, '_MULTI_GPU_OFF', [])
+    monkeypatch.setenv('BLHIP_NJOBS_MULTI_GPU', 'strict')
+    from bayesloop_amd.exceptions import BackendError
+    with pytest.raises(BackendError, match='checksum'):
+        _fit_over_fake_devices('kat_hyper_1hp', [Lossy() for _ in range(3)])
+    # and the opt-out never touches the other devices
+    monkeypatch.setenv('BLHIP_NJOBS_MULTI_GPU', '0')
+    engines = [Lossy() for _ in range(2)]
+    _fit_over_fake_devices('kat_hyper_1hp', engines)
+    assert engines[1].fits == 0

@@ -511,6 +511,30 @@ def test_njobs_in_process_two_contexts_on_one_gpu(monkeypatch):
         compare.check(res, oa.load_golden(case), compare.GPU_TOL)
 
 
+def test_njobs_on_two_physical_gpus_matches_unsharded(monkeypatch):
+    """fit(nJobs = 2) over two DIFFERENT device ordinals (peer access, hipMemcpyPeerAsync between devices, kernels armed per device)
+    against the unsharded fit and the reference's goldens; BLHIP_NJOBS_MULTI_GPU=strict so that nothing can fall back quietly.
+    Skipped on the 1-GPU boxes this suite normally runs on -- the first multi-GPU node to run the suite runs it."""
+    from bayesloop_amd import _abi
+    if _abi.load().blhip_device_count() < 2:
+        pytest.skip('needs two GPUs')
+    monkeypatch.setenv('BLHIP_NJOBS_MULTI_GPU', 'strict')
+    monkeypatch.delenv('BLHIP_NJOBS_DEVICES', raising=False)
+    for case in ('c4_small', 'c4_2hp', 'c5_cp_grw', 'c4_small_evidence'):
+        S1 = cases.build(bl, case)
+        S1.fit(**cases.fit_kwargs(case))
+        S2 = cases.build(bl, case)
+        S2.fit(nJobs=2, **cases.fit_kwargs(case))
+        assert len(S2.lastTimingPerDevice) == 2
+        np.testing.assert_allclose(np.asarray(S2.logEvidenceList), np.asarray(S1.logEvidenceList), rtol=1e-12, atol=0)
+        res = dict(logEvidence=S2.logEvidence, localEvidence=S2.localEvidence, logEvidenceList=np.array(S2.logEvidenceList),
+                   hyperParameterDistribution=S2.hyperParameterDistribution)
+        if not cases.CASES[case].get('fit', {}).get('evidenceOnly'):
+            res.update(posteriorSequence=S2.posteriorSequence, posteriorMeanValues=S2.posteriorMeanValues)
+            np.testing.assert_allclose(S2.posteriorSequence, S1.posteriorSequence, rtol=1e-10, atol=1e-300)
+        compare.check(res, oa.load_golden(case), compare.GPU_TOL)
+
+
 def test_linearity_of_transition_filter_only():
     """The stencil alone: filtering a one-hot distribution reproduces SciPy's reflect-boundary kernel row."""
     from oracle import bl_oracle as orc
@@ -917,6 +941,10 @@ RESIDENT = {
     # tiles 64 x 64 (128 tiles) and 128 x 128 (32 tiles)
     'res_1024x512_full': dict(study='Study', data=('series', 31, 5), om=_g2(1024, 512), tm=_grw2(0.03, 0.016)),
     'res_2048x256_full': dict(study='Study', data=('series', 32, 4), om=_g2(2048, 256), tm=_grw2(0.015, 0.03)),
+    # 64 x 64 tiles: 3 x 3 (an interior tile takes the corners of its halo rows from four diagonal neighbours), one tile row, one tile column
+    'res_192_full': dict(study='Study', data=('series', 42, 7), om=_g2(192, 192), tm=_grw2(0.16, 0.04)),
+    'res_64x256_full': dict(study='Study', data=('series', 43, 6), om=_g2(64, 256), tm=_grw2(0.4, 0.03)),
+    'res_256x64_fwdonly': dict(study='Study', data=('series', 44, 6), om=_g2(256, 64), tm=_grw2(0.1, 0.12), fit=dict(forwardOnly=True)),
     # tiles 32 x 64 (256 tiles)
     'res_512x1024_full': dict(study='Study', data=('series', 33, 5), om=_g2(512, 1024), tm=_grw2(0.06, 0.008)),
     # grids that do not fill their last tile row / column (PAD kernels: mirror image beyond the true edge, masked cells)
@@ -941,6 +969,30 @@ def test_resident_kernel_matches_oracle(case):
     assert S.lastTiming['fwd_kernel_variant'] == 5, S.lastTiming          # the resident path really ran
     if not cases.fit_kwargs(c).get('evidenceOnly') and not cases.fit_kwargs(c).get('forwardOnly'):
         assert S.lastTiming['bwd_kernel_variant'] == 5, S.lastTiming
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues'):
+        if k in want and want[k] is not None and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+
+
+@pytest.mark.parametrize('case', ['res_64x96_full', 'res_96x64_nan', 'res_128_fwdonly', 'res_256x128_evid', 'res_1024x512_full', 'res_pad_1000x520_full',
+                                  'res_pad_300x500_fwdonly', 'res_pad_1000_evid'])
+def test_resident_kernel_two_hand_offs_per_step_matches_oracle(case):
+    """64 x 64 tiles hand over ONCE per step by default (raw edge rows + columns, halo rows filtered by the consumer: blhip_resident.hpp
+    ONEX); the classic scheme (raw columns, then filtered rows) stays selectable (`resident_onex = 0`) and must give the same answers."""
+    eng = bl.get_engine()
+    c = RESIDENT[case]
+    eng.set_option('resident_onex', 0)
+    try:
+        S = cases.build(bl, c)
+        S.fit(**cases.fit_kwargs(c))
+    finally:
+        eng.set_option('resident_onex', 1)
+    assert S.lastTiming['fwd_kernel_variant'] == 5 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
     with np.errstate(all='ignore'):
         want = oa.run(c)
     got = result_of(S, c)
