@@ -12,7 +12,7 @@ import os
 from .exceptions import BackendError
 
 LIB_NAME = 'libblhip.so'
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
 OM_BERNOULLI, OM_LAPLACE, OM_WHITE_NOISE, OM_AR1, OM_SCALED_AR1 = 4, 5, 6, 7, 8
@@ -44,6 +44,7 @@ class Problem(C.Structure):
         ('n_ops', C.c_int32),
         ('ops', C.POINTER(Op)),
         ('resume_time', C.c_double), ('carry_slot', C.c_int32), ('reserved0', C.c_int32),
+        ('backward_init', c_double_p),
     ]
 
 
@@ -62,6 +63,7 @@ class Timing(C.Structure):
         ('fwd_kernel_variant', C.c_int32), ('bwd_kernel_variant', C.c_int32),
         ('fwd_hbm_bytes', C.c_double), ('bwd_hbm_bytes', C.c_double), ('fwd_flops', C.c_double), ('bwd_flops', C.c_double),
         ('resident_fallbacks', C.c_int32), ('resident_armed', C.c_int32),
+        ('resident_fallback_reason', C.c_int32), ('reserved0', C.c_int32),
     ]
 
     def as_dict(self):

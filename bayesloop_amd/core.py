@@ -21,6 +21,7 @@ from .exceptions import ConfigurationError, PostProcessingError
 from .helper import flatten
 from .observationModels import ObservationModel, device_code
 from .preprocessing import movingWindow
+from . import transitionModels as _tm_mod
 from .transitionModels import (TransitionModel, ChangePoint, CombinedTransitionModel, SerialTransitionModel,
                                BivariateRandomWalk, AlphaStableRandomWalk, Deterministic)
 
@@ -513,6 +514,8 @@ class Study(object):
         self._formatData()
         if not silent:
             print('    + Formatted data.')
+        if _tm_mod.needs_host_transition(self.transitionModel):
+            return self._fitHostTransition(forwardOnly=forwardOnly, evidenceOnly=evidenceOnly, silent=silent)
         problem, program = self._compile(silent=silent)
         eng = _engine_mod.get_engine()
         T = len(self.formattedData)
@@ -552,6 +555,126 @@ class Study(object):
         if not silent:
             if not forwardOnly:
                 print('    + Finished backward pass.')
+            print('    + Computed mean parameter values.')
+
+    # ---- the transition-model plug-in boundary: models the library has no program for ------------------------------------------
+    _HOST_SLOT = 0x7fff0002            # carried-state slot of the library context used by the host-transition fit
+    _host_transition_announced = frozenset()      # (model class names already announced on stderr; replaced, not mutated: `set` is a method here)
+
+    def _fitHostTransition(self, forwardOnly=False, evidenceOnly=False, silent=False):
+        """``Study.fit`` (reference core.py:330-486) for a transition model that is applied through the reference's plug-in
+        interface, ``computeForwardPrior(posterior, t)`` / ``computeBackwardPrior(posterior, t)`` (transitionModels.py:49-63; called at
+        core.py:411 and :467): a user-defined model, or a combination containing one.  Per time step the state makes a round trip
+        over PCIe -- D2H, the model's own method on the host, H2D -- which is slow but exactly the reference's recursion; everything
+        else of a step stays on the GPU as one-step problems through the same C-ABI entry point (``blhip_fit``): the likelihood
+        product alpha = prior * L, its normaliser and evidence terms (:375-404), and backwards the posterior alpha_i * beta_i, its
+        normalisation, sum(p / L) and the means (:436-464, :480-483) with the backward message handed over as
+        ``blhip_problem.backward_init``, and beta * L (:467) as a one-step product.  Announced once per model class on stderr."""
+        import sys
+        tm, om = self.transitionModel, self.observationModel
+        tm.study, tm.latticeConstant = self, self.latticeConstant
+        key = type(tm).__name__
+        if key not in Study._host_transition_announced:
+            Study._host_transition_announced = Study._host_transition_announced | {key}
+            sys.stderr.write('[bayesloop_amd] transition model "{}" has no device program: its computeForwardPrior / '
+                             'computeBackwardPrior run on the host, one PCIe round trip of the state per time step (likelihood, '
+                             'normalisation, evidence and means stay on the GPU)\n'.format(tm))
+        gs = list(self.gridSize)
+        if not 1 <= len(gs) <= 2:
+            raise ConfigurationError('User-defined transition models are supported on grids with one or two parameters '
+                                     '(got {}).'.format(len(gs)))
+        eng = _engine_mod.get_engine()
+        T = len(self.formattedData)
+        ts = np.asarray(self.formattedTimestamps, dtype=float)
+        dV = float(np.prod(self.latticeConstant))
+        code = device_code(om)
+        keep = not evidenceOnly
+        full = keep and not forwardOnly
+        if self._posterior_pending is not None:
+            if keep:
+                self._posterior_pending = None
+            else:
+                self._materialize_posterior()
+        no_value = np.full((1, 1), np.nan)
+
+        def step_problem(i, prior, backward_init=None):
+            seg = self.formattedData[i]
+            lik = None
+            if code == _abi.OM_TABLE:
+                lik = np.array([np.asarray(om.processedPdf(self.grid, seg), dtype=float) * np.ones(gs)])
+            return FitProblem(obs_model=code, marginal=self.marginalGrid, lattice=self.latticeConstant,
+                              data=np.asarray([seg], dtype=float), timestamps=ts[i:i + 1], prior=prior,
+                              ops=[(_abi.OP_STATIC, 0, -1, 0)], lik=lik, seg_len=om.segmentLength,
+                              carry_slot=Study._HOST_SLOT, backward_init=backward_init)
+
+        def aborted(phase):
+            self._warnZero(phase)
+            self.logEvidence = -np.inf
+            self._posterior_pending = None
+            if keep:
+                self._posteriorSequence = None
+
+        prior = np.array(self._computePrior(silent=silent), dtype=float).reshape(gs)
+        # full fits keep the distribution ENTERING each step (the backward pass multiplies it with the likelihood again on the
+        # device), forward-only fits the filtered posteriors; the same (T, G) host array receives the posteriors
+        seq = np.empty([T] + gs) if keep else None
+        means = np.empty((len(gs), T)) if keep else []
+        local = np.empty(T)
+        logE = 0.0
+        self.localEvidence = local
+        for i in range(T):                                                            # core.py:372
+            if forwardOnly:
+                res = eng.fit(step_problem(i, prior), no_value, forward_only=True, keep_posterior=True, owner=None)
+            else:
+                res = eng.fit(step_problem(i, prior), no_value, evidence_only=True, carry=True)
+            if res.abort_step[0] >= 0:                                               # :390-400
+                return aborted(0)
+            local[i] = res.local_evidence[0, 0]                                      # :404  norm * dV
+            logE += np.log(local[i] / dV)                                            # :403
+            if forwardOnly:
+                alpha = np.array(eng.posterior(0, 1, gs)[0])
+                seq[i] = alpha                                                       # :408
+                means[:, i] = res.posterior_mean[0, :, 0]
+            else:
+                alpha = eng.carry_read(Study._HOST_SLOT, 0, gs)
+                if full:
+                    seq[i] = prior
+            prior = np.asarray(tm.computeForwardPrior(alpha, ts[i]), dtype=float).reshape(gs)      # :411
+        logE += np.log(dV)                                                           # :417
+        self.logEvidence = float(logE)
+        self.lastTiming = eng.last_timing()
+        if not silent:
+            print('    + Finished forward pass.')
+            print('    + Log10-evidence: {:.5f}'.format(self.logEvidence / np.log(10)))
+        if evidenceOnly:
+            self.posteriorMeanValues = []
+            return
+        if full:
+            beta = np.ones(gs) / float(np.prod(gs))                                  # :424-425
+            for i in range(T - 1, -1, -1):                                           # :434
+                res = eng.fit(step_problem(i, seq[i], backward_init=beta), no_value, keep_posterior=True, owner=None)
+                if res.abort_step[0] >= 0:                                           # :442-452
+                    return aborted(1)
+                local[i] = res.local_evidence[0, 0]                                  # :463-464
+                means[:, i] = res.posterior_mean[0, :, 0]                            # :480-483
+                seq[i] = eng.posterior(0, 1, gs)[0]                                  # :436-441
+                if i == 0:
+                    break
+                r2 = eng.fit(step_problem(i, beta), no_value, evidence_only=True, carry=True)       # beta * L, :467
+                with np.errstate(all='ignore'):
+                    if r2.abort_step[0] >= 0:
+                        c = np.zeros(gs)
+                    else:
+                        c = eng.carry_read(Study._HOST_SLOT, 0, gs) * (r2.local_evidence[0, 0] / dV)
+                    beta = np.asarray(tm.computeBackwardPrior(c, ts[i]), dtype=float).reshape(gs)
+                    beta = beta / np.sum(beta)                                       # :470
+            if not silent:
+                print('    + Finished backward pass.')
+        eng.release_posterior(None)
+        self._posterior_pending = None
+        self._posteriorSequence = seq
+        self.posteriorMeanValues = means
+        if not silent:
             print('    + Computed mean parameter values.')
 
     def optimize(self, parameterList=[], forwardOnly=False, **kwargs):
@@ -718,7 +841,12 @@ class HyperStudy(Study):
         priors = []
         for m, k, name in self._hyperSlots():
             prior = getattr(m, 'prior', None)
-            priors.append(prior[k] if isinstance(m, (SerialTransitionModel, BivariateRandomWalk, AlphaStableRandomWalk, Deterministic)) else prior)
+            per_parameter = isinstance(m, (SerialTransitionModel, BivariateRandomWalk, AlphaStableRandomWalk, Deterministic))
+            if not per_parameter and type(m).__module__ != _tm_mod.__name__ and isinstance(prior, (list, tuple)):
+                # a user-defined model with several hyper-parameters lists one prior per hyper-parameter; the reference flattens the
+                # nested prior list (core.py:1501-1533)
+                per_parameter = len(prior) == len(m.hyperParameterNames) > 1
+            priors.append(prior[k] if per_parameter else prior)
         return priors
 
     def _createHyperGrid(self, silent=False):
@@ -829,6 +957,8 @@ class HyperStudy(Study):
         if not silent:
             print('+ Started new fit.')
             print('    + {} analyses to run.'.format(len(self.hyperGridValues)))
+        if _tm_mod.needs_host_transition(self.transitionModel):
+            return self._fitHostTransitionHyper(forwardOnly, evidenceOnly, silent)
         # one representative value per hyper-parameter while compiling (values come from the hyper-grid rows)
         self._setAllHyperParameters(self.hyperGridValues[0])
         try:
@@ -897,6 +1027,37 @@ class HyperStudy(Study):
         self.localEvidenceList = []
         self._setAllHyperParameters(self.flatHyperParameters)
         if not silent:
+            print('+ Finished fit.')
+
+    def _fitHostTransitionHyper(self, forwardOnly, evidenceOnly, silent):
+        """A hyper-study over a transition model that is applied on the host (Study._fitHostTransition): one evidence-only fit per
+        hyper-grid point (reference core.py:1349-1361), then the hyper-parameter distribution and the evidence of the average model
+        (:1391-1410).  The average posterior sequence is not built for such models (it would be T x G host arithmetic per point)."""
+        if not evidenceOnly:
+            raise ConfigurationError('A HyperStudy over a user-defined transition model (host-side computeForwardPrior) supports '
+                                     'evidenceOnly=True; fit single hyper-parameter values with Study for posteriors.')
+        prior_values = np.asarray(self.flatHyperPriorValues, dtype=float)
+        self.logEvidenceList, localList = [], []
+        try:
+            for row in self.hyperGridValues:
+                self._setAllHyperParameters(row)
+                Study.fit(self, evidenceOnly=True, silent=True)
+                self.logEvidenceList.append(self.logEvidence)
+                localList.append(np.array(self.localEvidence))
+        finally:
+            self._setAllHyperParameters(self.flatHyperParameters)
+        with np.errstate(divide='ignore'):
+            logHPD = np.array(self.logEvidenceList) + np.log(prior_values) + np.sum(np.log(self.hyperGridConstant))
+        scaled = logHPD - np.amax(logHPD)
+        self.hyperParameterDistribution = np.exp(scaled)
+        self.hyperParameterDistribution /= np.sum(self.hyperParameterDistribution)
+        self.hyperParameterDistribution /= np.prod(self.hyperGridConstant)
+        self.logEvidence = float(_logsumexp(logHPD))
+        self.localEvidence = np.sum((np.array(localList).T * prior_values).T, axis=0)
+        self.localEvidenceList = []
+        if not silent:
+            print('    + Computed hyper-parameter distribution')
+            print('    + Log10-evidence of average model: {:.5f}'.format(self.logEvidence / np.log(10)))
             print('+ Finished fit.')
 
     @property

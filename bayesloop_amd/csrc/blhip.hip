@@ -1060,8 +1060,9 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
     if (p->reset_prior) HIPCHECK(hipMemcpyAsync(D.reset, p->reset_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
     if (p->indep_prior) HIPCHECK(hipMemcpyAsync(D.indep, p->indep_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
     if (ff.full) {
-        // beta_T = 1/G   core.py:424-425
-        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, D.uniform, G, 1.0 / (double)G);
+        // beta_T = 1/G   core.py:424-425 -- or the caller's backward message (blhip_problem.backward_init)
+        if (p->backward_init) HIPCHECK(hipMemcpyAsync(D.uniform, p->backward_init, sizeof(double) * G, hipMemcpyHostToDevice, st));
+        else hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, D.uniform, G, 1.0 / (double)G);
     }
     D.lik = nullptr;
     if (p->obs_model == BLHIP_OM_TABLE) {
@@ -1687,6 +1688,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
     ctx->post_valid = false;
     ctx->timing = blhip_timing{};
+    ctx->resident_last_reason = 0;
     // a context whose resident launch once gave up tries the resident paths again after a while (one hiccup -- another process
     // holding CUs -- must not cost 1.4 - 2 x for the life of the process); the wait doubles with every give-up in a row
     if (!ctx->resident_ok && ++ctx->resident_fits_since >= ctx->resident_retry_after) {
@@ -2027,7 +2029,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             P1.gran = carve<unsigned long long>(pc, (size_t)2 * B * tile.nblk * 2);
             d_abort1 = carve<unsigned>(pc, 16);
             P1.abort_word = d_abort1;
-            P1.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
+            P1.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);      // wall_clock64: 100 MHz
             P1.n = F1.n; P1.TJ = F1.TJ; P1.nblk = F1.nblk; P1.LW = F1.LW; P1.K = (int)K; P1.T = F1.T; P1.B = F1.B; P1.d = F1.d; P1.rec_len = F1.rec_len;
             for (int k = 0; k < 5; ++k) P1.shared[k] = F1.shared[k];
             P1.taps = F1.taps; P1.tap_off = F1.tap_off; P1.tap_lw = F1.tap_lw; P1.m1 = F1.m1; P1.colA = F1.colA; P1.rec = F1.rec; P1.lik = F1.lik;
@@ -2210,6 +2212,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (!passes(fusedK)) {
             if (resident_failed) {                   // the launch-per-step kernels take over (timing of the failed attempt is dropped)
                 ctx->timing.resident_fallbacks += 1;
+                ctx->timing.resident_fallback_reason = ctx->resident_last_reason ? ctx->resident_last_reason : BLHIP_FALLBACK_RANGE;
                 ctx->timing.forward_ms = ctx->timing.backward_ms = 0.0;
                 ctx->timing.fwd_hbm_bytes = ctx->timing.bwd_hbm_bytes = ctx->timing.fwd_flops = ctx->timing.bwd_flops = 0.0;
                 ctx->timing.forward_launches = ctx->timing.backward_launches = 0;
@@ -2219,6 +2222,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             } else { usedK = 1; passes(1); }
         } else if (resident || chainres || ctx->timing.fwd_kernel_variant == 8) {
             ctx->resident_retry_after = 8;           // a resident pass went through: the next give-up starts from the short wait again
+            ctx->resident_giveups = 0;               // (the wait doubles with give-ups IN A ROW only)
         }
 
         // --- carried states / average posterior / kept posterior / results ---

@@ -36,7 +36,8 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
     double *d_prior = carve<double>(cur, (size_t)G), *d_reset = carve<double>(cur, (size_t)G), *d_uniform = carve<double>(cur, (size_t)G);
     HIPCHECK(hipMemcpyAsync(d_prior, p->prior, 8 * (size_t)G, hipMemcpyHostToDevice, st));
     if (p->reset_prior) HIPCHECK(hipMemcpyAsync(d_reset, p->reset_prior, 8 * (size_t)G, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);           // beta_T = 1/G, core.py:424-425
+    if (p->backward_init) HIPCHECK(hipMemcpyAsync(d_uniform, p->backward_init, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    else hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);           // beta_T = 1/G, core.py:424-425
     ctx->likbuf.ensure(8 * (size_t)T * G);
     double *d_lik = ctx->likbuf.as<double>();
     HIPCHECK(hipMemcpyAsync(d_lik, p->lik, 8 * (size_t)T * G, hipMemcpyHostToDevice, st));

@@ -22,6 +22,14 @@ struct BatchEnv {
 // steps: a few ulp per step at worst (observed ~1e-14 at T = 2000); else: the launch-per-step kernels
 inline double pred_rtol(int64_t T) { return 1e-12 + 2e-15 * (double)T; }
 
+// Bound of every in-kernel wait of a resident launch.  A block that is not co-resident never arrives, so the bound IS the cost of the
+// failure a user on a shared GPU meets first: it scales with the pass (20 x the predicted pass time at ~15 us per step, at least 50 ms
+// -- a pre-empted block comes back within milliseconds) instead of a flat 2 s.  Option resident_timeout_s > 0 overrides.
+inline double resident_timeout_s(blhip_ctx *ctx, int64_t T) {
+    const double opt = ctx->option("resident_timeout_s", 0.0);
+    return opt > 0.0 ? opt : std::max(0.05, 20.0 * 15e-6 * (double)T);
+}
+
 // did a block of a resident launch time out waiting for a peer (not every block co-resident)?  -> the context stops using the paths
 bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
     ctx->pinS.ensure(64);
@@ -30,6 +38,7 @@ bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
     sync_stream(ctx, st);
     // (option resident_force_abort: the tests of the fall-back pretend that a block gave up)
     if (*h != 0u || ctx->option("resident_force_abort", 0.0) != 0.0) {
+        ctx->resident_last_reason = *h != 0u ? BLHIP_FALLBACK_GAVE_UP : BLHIP_FALLBACK_FORCED;
         if (ctx->resident_ok && ctx->option("quiet", 0.0) == 0.0)
             std::fprintf(stderr, "[blhip] a resident launch gave up waiting for a peer block (its blocks were not all co-resident: a shared or "
                                  "partitioned GPU?); this batch is repeated and the context continues with the launch-per-step kernels\n");
@@ -62,7 +71,8 @@ struct ResidentRun {
         const int64_t T = E.T;
         const bool full = E.ff.full;
         double w0[blr::R + 1] = {1.0}, w1[blr::R + 1] = {1.0};
-        if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blr::DMAX &&
+        // (a caller-supplied backward message: the predicted posterior sums assume the uniform one)
+        if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && !E.p->backward_init && E.d <= blr::DMAX &&
             prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
             plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
                           (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0, (int)ctx->option("resident_min_tile", 32.0))) {
@@ -107,7 +117,7 @@ struct ResidentRun {
         RQ.n0 = E.g.n0; RQ.n1 = E.g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = E.d; RQ.rec_len = E.rec_len;
         RQ.lag = std::max(1, std::min(blr::MAXLAG, (int)ctx->option("resident_lag", 2.0)));
         RQ.m0 = E.DT->m0; RQ.m1 = E.DT->m1; RQ.colA = E.DT->colA; RQ.colB = E.DT->colB; RQ.rec = E.DT->rec; RQ.step0 = E.step0;
-        RQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);      // wall_clock64: 100 MHz
+        RQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);      // wall_clock64: 100 MHz
         // partial-sum slots per step: one per tile (the launch-per-step kernels are the fall-back and keep theirs)
         nblk = rp.ntiles;
         psz = std::max(psz, (size_t)T * NRED * nblk);
@@ -156,7 +166,12 @@ struct ResidentRun {
             for (int wv = 0; wv < 4; ++wv) {
                 const unsigned long long *h = hh + wv * 256;
                 double acc[15] = {0}; int n = 0;
-                for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 14] || !h[q * 16]) continue; ++n; for (int i = 1; i < 15; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                for (int q = 0; q < 16; ++q) {          // (stamps a kernel flavour does not set stay zero: the interval goes to the next one that is set)
+                    if (!h[q * 16 + 14] || !h[q * 16]) continue;
+                    ++n;
+                    unsigned long long last = h[q * 16];
+                    for (int i = 1; i < 15; ++i) if (h[q * 16 + i]) { acc[i] += (double)(h[q * 16 + i] - last); last = h[q * 16 + i]; }
+                }
                 std::fprintf(stderr, "[blr prof %s thread %d] %d steps:", bwd ? "bwd" : "fwd", tids[wv], n);
                 double tot = 0; for (int i = 1; i < 15; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
                 std::fprintf(stderr, " | total %.0f\n", tot);
@@ -168,7 +183,8 @@ struct ResidentRun {
     // after the forward pass: every tile made it, and the sums allow the lag to be undone
     bool forward_ok(const BatchEnv &E, double *redF) {
         if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
-        return resident_unlag(redF, E.T, RQ.lag, rowsumF);
+        if (!resident_unlag(redF, E.T, RQ.lag, rowsumF)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
+        return true;
     }
 
     // after the backward pass: every tile made it, the lagged scale stayed in range, and the PREDICTED sums the kernel normalised
@@ -178,14 +194,14 @@ struct ResidentRun {
         if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
         for (int64_t t = 0; t < T; ++t) {
             const double Ct = redB[(size_t)t * NRED + 2], Nt = redB[(size_t)t * NRED];
-            if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) return false;
+            if (!(Ct > 1e-150 && Ct < 1e150) || !(Nt > 1e-250)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
         }
         double npred = rowsumF[T - 1] * (1.0 / (double)E.G);
         for (int64_t t = T - 1; t >= 0; --t) {
             const int64_t k = T - 1 - t;
             if (k > 0) npred = (k >= RQ.lag ? 1.0 / redB[(size_t)(t + RQ.lag) * NRED + 2] : 1.0) * npred / sfwd[t + 1];
             const double Nt = redB[(size_t)t * NRED];
-            if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) return false;
+            if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_PREDICTION; return false; }
         }
         return true;
     }
@@ -230,7 +246,7 @@ struct ChainRun {
         const ChainProgram &prog = *E.prog;
         const int64_t T = E.T, B = E.B;
         const long long G = E.G;
-        if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && E.d <= blc::DMAX &&
+        if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && !E.p->backward_init && E.d <= blc::DMAX &&
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok)
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
         if (!on) return;
@@ -259,7 +275,7 @@ struct ChainRun {
         CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
         CQ.post_stride = (long long)T * Gk;
         CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.step0 = E.step0;
-        CQ.timeout_ticks = (unsigned long long)(ctx->option("resident_timeout_s", 2.0) * 1e8);
+        CQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
         // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)
         post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && ((G & 1) == 0 || cp.pad) && ((uintptr_t)ctx->acc & 15) == 0;
@@ -422,7 +438,7 @@ struct ChainRun {
                     std::memcpy(&redF[((size_t)t * E.B + b) * NRED], &redF[((size_t)t * E.B + prov) * NRED], NRED * sizeof(double));
         for (int64_t b = 0; b < E.B; ++b)
             if (!chain_unlag(redF, E.T, CQ.lag, rowsumC[b], E.B, b, &sfwdC[b], cp.has_reset ? E.prog->kindF.data() : nullptr,
-                             skip_prefix ? h_tshare[b] : 0)) return false;
+                             skip_prefix ? h_tshare[b] : 0)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
         return true;
     }
 
@@ -467,7 +483,7 @@ struct ChainRun {
         for (int64_t b = 0; b < E.B; ++b)
             for (int64_t t = 0; t < E.T; ++t) {
                 const double *r = &redB[((size_t)t * E.B + b) * NRED];
-                if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) return false;
+                if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
             }
         return true;
     }
@@ -493,7 +509,7 @@ struct ChainRun {
                 if (restart) npred = sb[k] * redF_keep[((size_t)t * B + b) * NRED + 1];
                 else if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
                 const double Nt = redB[((size_t)t * B + b) * NRED];
-                if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) return false;
+                if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_PREDICTION; return false; }
             }
         }
         if (std::isfinite(fold_ref)) {

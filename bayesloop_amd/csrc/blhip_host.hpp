@@ -129,6 +129,7 @@ struct blhip_ctx {
     // are tried again after `resident_retry_after` further fits, and the wait doubles with every give-up in a row (8, 16, ... 1024)
     int resident_retry_after = 8, resident_fits_since = 0;
     long long resident_giveups = 0;
+    int resident_last_reason = 0;                  // BLHIP_FALLBACK_* of the last resident batch that fell back
     int num_cus = 0;
     // average posterior folded on a second stream while the next batch's forward pass runs (do_fit): second sequence buffer,
     // private copies of the per-batch weights, the stream and its events

@@ -36,6 +36,7 @@ class FitProblem:
     seg_len: int = 1
     resume_time: float = -1.0           # BLHIP_RESUME: time stamp the transition into step 0 is evaluated at
     carry_slot: int = 0                 # which carried state of the context (OnlineStudy: one per transition model)
+    backward_init: Optional[np.ndarray] = None  # the backward message entering the last step (None: uniform, core.py:424-425)
 
     @property
     def grid_size(self):
@@ -279,6 +280,12 @@ class HipEngine:
         cp.ops = ops
         cp.resume_time = float(p.resume_time)
         cp.carry_slot = int(p.carry_slot)
+        if p.backward_init is not None:
+            bi = _f64(p.backward_init).ravel()
+            if bi.size != G:
+                raise BackendError('backward_init does not match the grid')
+            keep.append(bi)
+            cp.backward_init = _abi.dptr(bi)
         return cp, keep
 
     def fit(self, problem: FitProblem, op_values, forward_only=False, evidence_only=False, keep_posterior=False,

@@ -32,21 +32,109 @@ from .exceptions import ConfigurationError
 
 
 class TransitionModel:
-    """Base class of all transition models."""
+    """Base class of all transition models.
+
+    The reference's plug-in boundary (bayesloop/transitionModels.py:49-63, called at core.py:411, :467, :2166) is the duck-typed pair
+    ``computeForwardPrior(posterior, t)`` / ``computeBackwardPrior(posterior, t)``.  Both sides of it exist here:
+
+    * the built-in models below answer these calls by running their OWN one-step transition program on the GPU on the distribution
+      they are handed (:func:`_device_transition`), so code written against the reference -- a user-defined model that wraps or
+      combines built-in ones, a notebook that calls ``tm.computeForwardPrior(p, t)`` -- keeps working;
+    * a model the library has no program for (a subclass that defines ``computeForwardPrior`` itself, exactly as the reference
+      documents) is fitted by ``Study.fit`` with the transition applied by THAT method on the host between device steps
+      (``Study._fitHostTransition``: likelihood products, normalisations, sums and means stay on the GPU).
+    """
 
     hyperParameterNames = ()
     hyperParameterValues = ()
 
     def _program(self, parameterNames):
-        """-> list of (op kind, axis, owner model, hyper-parameter index or None, serial segment or -1, flags)"""
-        raise ConfigurationError('Transition model "{}" cannot be compiled for the MI355X engine.'.format(self))
+        """-> list of (op kind, axis, owner model, hyper-parameter index or None, serial segment or -1, flags); None: the library has
+        no program for this model (user-defined: Study.fit calls its computeForwardPrior / computeBackwardPrior on the host)"""
+        return None
 
     def computeForwardPrior(self, posterior, t):
-        raise NotImplementedError('bayesloop_amd executes transition models inside the HIP step kernels; '
-                                  'host-side computeForwardPrior is not part of this build.')
+        return _device_transition(self, posterior, t)
 
     def computeBackwardPrior(self, posterior, t):
         return self.computeForwardPrior(posterior, t - 1)
+
+
+_OWN_MODULE = __name__
+_APPLY_SLOT = 0x7fff0001          # the carried-state slot of the library context the one-step applications go through
+
+
+def needs_host_transition(model):
+    """True if ``model`` (or a sub-model) has to be applied by its own computeForwardPrior / computeBackwardPrior on the host: it is
+    not one of the built-in classes, or it is a subclass of one that overrides either method."""
+    for name in ('computeForwardPrior', 'computeBackwardPrior'):
+        fn = getattr(type(model), name, None)
+        if fn is None or getattr(fn, '__module__', None) != _OWN_MODULE:
+            return True
+    prog = getattr(type(model), '_program', None)
+    if prog is None or getattr(prog, '__module__', None) != _OWN_MODULE or prog is TransitionModel._program:
+        return True
+    return any(needs_host_transition(m) for m in getattr(model, 'models', ()))
+
+
+def _scalar(model, k):
+    v = model.hyperParameterValues[k]
+    if isinstance(v, str) or np.ndim(v) != 0:
+        raise ConfigurationError('Hyper-parameter "{}" holds several values; computeForwardPrior needs one value per '
+                                 'hyper-parameter.'.format(model.hyperParameterNames[k]))
+    return float(v)
+
+
+def _device_transition(model, posterior, t, shift=None):
+    """``model``'s transition of the distribution ``posterior`` at time stamp ``t`` (reference semantics, any input scale), computed
+    on the GPU: the normalised input goes into a carried-state slot of the library context, ONE resumed forward step with a flat
+    likelihood applies the model's own op program to it (the machinery of OnlineStudy.step: BLHIP_RESUME | BLHIP_CARRY), the
+    result comes back with its sum.  Leaf models only (CombinedTransitionModel / SerialTransitionModel delegate like the
+    reference does).  ``shift``: Deterministic's grid shift for this call (its backward shift is not a forward shift at t - 1)."""
+    from . import engine as _engine_mod
+    from .engine import FitProblem
+    study = getattr(model, 'study', None)
+    if study is None or not getattr(study, 'gridSize', None):
+        raise ConfigurationError('Transition model "{}" is not attached to a study with an observation model '
+                                 '(Study.setTransitionModel sets model.study).'.format(model))
+    x = np.asarray(posterior, dtype=float)
+    grid_size = list(study.gridSize)
+    if list(x.shape) != grid_size:
+        raise ConfigurationError('computeForwardPrior: distribution of shape {} on a grid of shape {}.'.format(list(x.shape), grid_size))
+    if len(grid_size) > 2:
+        raise NotImplementedError('computeForwardPrior on the device is limited to grids with one or two parameters.')
+    program = model._program(study.observationModel.parameterNames)
+    if program is None:
+        raise NotImplementedError('Transition model "{}" has no device program; define computeForwardPrior.'.format(model))
+    s = float(np.sum(x))
+    if not (s > 0.0 and np.isfinite(s)):
+        raise ConfigurationError('computeForwardPrior: the distribution has no positive finite mass.')
+    program = study._expandProgram(program, 1)
+    params = {n: _scalar(model, k) for k, n in enumerate(model.hyperParameterNames)}
+    values = np.full((1, max(1, len(program))), np.nan)
+    linear = True                    # homogeneous of degree 1 (the result scales with the input) or normalised output?
+    for j, (kind, axis, owner, k, seg, flg) in enumerate(program):
+        if kind not in (_abi.OP_GRW, _abi.OP_STATIC):
+            linear = False
+        if isinstance(k, tuple):                             # ('shift', q) of a Deterministic model: [forward into step 0, backward]
+            values[0, j] = (owner.shifts(params, [t + 1.0], float(t))[k[1]] if shift is None else shift) if k[1] == 0 else 0.0
+        elif k is not None:
+            values[0, j] = _scalar(owner, k)
+            if kind == _abi.OP_REGIMESWITCH:                  # clamp at 10**v dV of the RAW input = 10**(v - log10 s) dV of x / s
+                values[0, j] -= np.log10(s)
+    eng = _engine_mod.get_engine()
+    dV = float(np.prod(study.latticeConstant))
+    reset = study._changepointPrior() if any(op[0] == _abi.OP_CHANGEPOINT for op in program) else None
+    indep = study._changepointPrior() / dV if any(op[0] == _abi.OP_INDEPENDENT for op in program) else None
+    eng.carry_write(_APPLY_SLOT, (x / s).reshape([1] + grid_size))
+    problem = FitProblem(obs_model=_abi.OM_TABLE, marginal=study.marginalGrid, lattice=study.latticeConstant,
+                         data=np.zeros((1, 1)), timestamps=np.asarray([t + 1.0]), prior=x / s,
+                         ops=[(op[0], op[1], op[4], op[5]) for op in program], reset_prior=reset, indep_prior=indep,
+                         lik=np.ones([1] + grid_size), seg_len=1, resume_time=float(t), carry_slot=_APPLY_SLOT)
+    res = eng.fit(problem, values, evidence_only=True, resume=True, carry=True)
+    norm = float(res.local_evidence[0, 0]) / dV              # sum of T(x / s) before the step's normalisation
+    out = eng.carry_read(_APPLY_SLOT, 0, grid_size)
+    return out * (norm * s if linear else norm)
 
 
 def _as_values(value):
@@ -66,6 +154,9 @@ class Static(TransitionModel):
 
     def __str__(self):
         return 'Static/constant parameter values'
+
+    def computeForwardPrior(self, posterior, t):
+        return posterior                      # (the same array object, as in the reference: transitionModels.py:49-60)
 
     def _program(self, parameterNames):
         return [(_abi.OP_STATIC, 0, self, None, -1, 0)]
@@ -109,6 +200,13 @@ class ChangePoint(TransitionModel):
     def __str__(self):
         return 'Change-point'
 
+    def computeForwardPrior(self, posterior, t):
+        """reference transitionModels.py:289-314: at t == tChange the (re-normalised) prior times the cell volume -- the array the
+        device kernels restart from (Study._changepointPrior) -- else the distribution itself.  No arithmetic on ``posterior``."""
+        if t == _scalar(self, 0):
+            return self.study._changepointPrior()
+        return posterior
+
     def _program(self, parameterNames):
         return [(_abi.OP_CHANGEPOINT, 0, self, 0, -1, 0)]
 
@@ -127,6 +225,28 @@ class CombinedTransitionModel(TransitionModel):
 
     def __str__(self):
         return 'Combined transition model'
+
+    def _propagate(self, m):
+        m.latticeConstant = self.latticeConstant      # reference transitionModels.py:646-648
+        m.study = self.study
+        m.tOffset = self.tOffset
+
+    def computeForwardPrior(self, posterior, t):
+        """reference transitionModels.py:632-649: the sub-models one after the other, in list order (each one through its own
+        computeForwardPrior: built-in ones on the device, user-defined ones on the host)"""
+        newPrior = np.array(posterior, dtype=float)
+        for m in self.models:
+            self._propagate(m)
+            newPrior = m.computeForwardPrior(newPrior, t)
+        return newPrior
+
+    def computeBackwardPrior(self, posterior, t):
+        """reference transitionModels.py:651-662: the SAME list order backwards"""
+        newPrior = np.array(posterior, dtype=float)
+        for m in self.models:
+            self._propagate(m)
+            newPrior = m.computeBackwardPrior(newPrior, t)
+        return newPrior
 
     def _program(self, parameterNames):
         program = []
@@ -215,6 +335,12 @@ class Deterministic(TransitionModel):
         # the 2 T per-step shifts follow this op as DETERMINISTIC_ARG ops (added when the study is compiled, core.py)
         return [(_abi.OP_DETERMINISTIC, list(parameterNames).index(self.selectedParameter), self, None, -1, 0)]
 
+    def computeBackwardPrior(self, posterior, t):
+        """reference transitionModels.py:586-606: shifted by f(t - 1) - f(t) (NOT the forward shift at t - 1)"""
+        params = {n: _scalar(self, k) for k, n in enumerate(self.hyperParameterNames)}
+        d = float(self.function(t - 1 - self.tOffset, **params)) - float(self.function(t - self.tOffset, **params))
+        return _device_transition(self, posterior, t - 1, shift=d)
+
     def shifts(self, params, timestamps, resume_time=-1.0):
         """The 2 T values behind the DETERMINISTIC op (include/blhip.h): forward shift INTO step i, f(t'+1) - f(t') at the
         time stamp t' of step i-1 (entry 0: at ``resume_time``, used by OnlineStudy), then backward shift into step i,
@@ -290,6 +416,10 @@ class Independent(TransitionModel):
     def __str__(self):
         return 'Independent observations model'
 
+    def computeForwardPrior(self, posterior, t):
+        """reference transitionModels.py:339-360: the normalised prior, whatever the posterior"""
+        return self.study._changepointPrior() / np.prod(self.study.latticeConstant)
+
     def _program(self, parameterNames):
         return [(_abi.OP_INDEPENDENT, 0, self, None, -1, 0)]
 
@@ -344,6 +474,30 @@ class SerialTransitionModel(TransitionModel):
 
     def __str__(self):
         return 'Serial transition model'
+
+    def _active(self, t):
+        """the sub-model acting at time stamp t = number of break times <= t (reference transitionModels.py:767-773)"""
+        values = [_scalar(self, k) for k in range(len(self.hyperParameterValues))]
+        k = int(np.sum(np.array(values) <= t)) if values else 0
+        m = self.models[k]
+        m.latticeConstant = self.latticeConstant
+        m.study = self.study
+        m.tOffset = values[k - 1] if k > 0 else 0
+        return m, values
+
+    def _changePointCheck(self, distribution, t, values):
+        """reference transitionModels.py:789-815: a change-point boundary at t restarts from the prior"""
+        if len(values) and t in np.array(values)[self.changePointMask]:
+            return self.study._changepointPrior()
+        return distribution
+
+    def computeForwardPrior(self, posterior, t):
+        m, values = self._active(t)
+        return self._changePointCheck(m.computeForwardPrior(posterior, t), t, values)
+
+    def computeBackwardPrior(self, posterior, t):
+        m, values = self._active(t - 1)
+        return self._changePointCheck(m.computeBackwardPrior(posterior, t), t - 1, values)
 
     def _program(self, parameterNames):
         program = []

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BLHIP_ABI_VERSION 6
+#define BLHIP_ABI_VERSION 7
 
 typedef struct blhip_ctx blhip_ctx;
 
@@ -127,6 +127,12 @@ typedef struct {
                                      (OnlineStudy passes len(formattedData) - 1 = -1, core.py:2164-2165)         */
     int32_t        carry_slot;    /* which carried state (one per transition model of an OnlineStudy), >= 0      */
     int32_t        reserved0;
+    /* (ABI v7) the backward message entering the LAST time step, (G,); NULL: uniform 1 / G (core.py:424-425).  Lets a caller that
+     * applies the transition model ITSELF -- the reference's plug-in boundary TransitionModel.computeBackwardPrior(posterior, t),
+     * transitionModels.py:49-63, for models the library has no op for -- run the backward recursion one step per call: the
+     * likelihood products, normalisations, sums and means of core.py:434-470 stay on the device (bayesloop_amd/core.py:
+     * Study._fitHostTransition).  Fits with a backward_init take the launch-per-step kernels. */
+    const double  *backward_init;
 } blhip_problem;
 
 /* Flags of blhip_fit */
@@ -171,7 +177,17 @@ typedef struct {
     double  bwd_flops;
     int32_t resident_fallbacks;   /* batches of this call a resident launch gave up on (repeated launch-per-step) */
     int32_t resident_armed;       /* 1: the context will try the resident paths on its next eligible fit          */
+    int32_t resident_fallback_reason;   /* (ABI v7) why the LAST such batch fell back: BLHIP_FALLBACK_*             */
+    int32_t reserved0;
 } blhip_timing;
+
+/* blhip_timing.resident_fallback_reason */
+#define BLHIP_FALLBACK_NONE       0
+#define BLHIP_FALLBACK_GAVE_UP    1   /* a block waited longer than the bound for a peer block (blocks not all co-resident: a
+                                         shared or partitioned GPU); the context parks the resident paths (resident_armed = 0) */
+#define BLHIP_FALLBACK_RANGE      2   /* a lagged sum left (1e-150, 1e150) or was not finite (extreme outliers, a zero normaliser) */
+#define BLHIP_FALLBACK_PREDICTION 3   /* the predicted posterior sums did not reproduce the reduced ones                          */
+#define BLHIP_FALLBACK_FORCED     4   /* option resident_force_abort (tests)                                                      */
 
 /* ---- context ------------------------------------------------------------------------------------------------- */
 int         blhip_abi_version(void);

@@ -124,7 +124,7 @@ class OracleEngine:
             with np.errstate(all='ignore'):
                 r = orc.fit(g, om, data, problem.timestamps, np.asarray(problem.prior).reshape(g.size), ops, vals,
                             forward_only=forward_only, evidence_only=evidence_only, reset=reset, lik_table=lik,
-                            indep=self._indep)
+                            indep=self._indep, beta_init=getattr(problem, 'backward_init', None))
             self.fits += 1
             logE[c] = r['logEvidence']
             local[c] = r['localEvidence']

@@ -1,0 +1,189 @@
+"""User-defined transition models written the way the reference documents its plug-in interface (bayesloop/transitionModels.py:34-63
+is the template: attributes ``study``, ``latticeConstant``, ``hyperParameterNames``, ``hyperParameterValues``, ``prior``, ``tOffset``;
+methods ``__str__``, ``computeForwardPrior(posterior, t)``, ``computeBackwardPrior(posterior, t)``), parametrised by the package they
+plug into: ``make(tm_module)`` builds the classes on ``tm_module.TransitionModel`` -- the reference's module in
+tests/golden/gen_plugin_golden.py, ``bayesloop_amd.transitionModels`` in the tests.  The model code is user code: it may use SciPy."""
+import numpy as np
+from scipy.ndimage import gaussian_filter1d
+
+
+def _values(v):
+    """several hyper-parameter values: an array, as the reference's own models store them (transitionModels.py:86-89)"""
+    return np.array(v) if isinstance(v, (list, tuple)) else v
+
+
+def make(tm):
+    class LeakyRandomWalk(tm.TransitionModel):
+        """Gaussian fluctuations of one parameter plus a constant "leak" towards the flat distribution."""
+
+        def __init__(self, name1='sigma', value1=None, name2='leak', value2=None, target=None, prior=(None, None)):
+            self.study = None
+            self.latticeConstant = None
+            self.hyperParameterNames = [name1, name2]
+            self.hyperParameterValues = [_values(value1), _values(value2)]
+            self.prior = prior
+            self.selectedParameter = target
+            self.tOffset = 0
+
+        def __str__(self):
+            return 'Leaky random walk'
+
+        def computeForwardPrior(self, posterior, t):
+            axis = self.study.observationModel.parameterNames.index(self.selectedParameter)
+            sigma = self.hyperParameterValues[0] / self.latticeConstant[axis]
+            leak = self.hyperParameterValues[1]
+            newPrior = gaussian_filter1d(posterior, sigma, axis=axis) if sigma > 0. else posterior.copy()
+            return (1. - leak) * newPrior + leak * np.sum(posterior) / posterior.size
+
+        def computeBackwardPrior(self, posterior, t):
+            return self.computeForwardPrior(posterior, t - 1)
+
+    class CoolingWalk(tm.TransitionModel):
+        """Random walk whose width decays with the time stamp: sigma(t) = sigma0 * exp(-(t - t0) / tau).  (Reads ``t``.)"""
+
+        def __init__(self, name1='sigma0', value1=None, name2='tau', value2=None, t0=0., target=None, prior=(None, None)):
+            self.study = None
+            self.latticeConstant = None
+            self.hyperParameterNames = [name1, name2]
+            self.hyperParameterValues = [value1, value2]
+            self.prior = prior
+            self.selectedParameter = target
+            self.t0 = t0
+            self.tOffset = 0
+
+        def __str__(self):
+            return 'Cooling random walk'
+
+        def computeForwardPrior(self, posterior, t):
+            axis = self.study.observationModel.parameterNames.index(self.selectedParameter)
+            sigma = self.hyperParameterValues[0] * np.exp(-(t - self.t0) / self.hyperParameterValues[1])
+            return gaussian_filter1d(posterior, sigma / self.latticeConstant[axis], axis=axis)
+
+        def computeBackwardPrior(self, posterior, t):
+            return self.computeForwardPrior(posterior, t - 1)
+
+    class CappedRandomWalk(tm.GaussianRandomWalk):
+        """A subclass of a BUILT-IN model that overrides the transition: the built-in walk, then every cell capped at ``cap`` times
+        the mean cell probability and renormalised (non-linear)."""
+        cap = 40.
+
+        def __str__(self):
+            return 'Capped random walk'
+
+        def computeForwardPrior(self, posterior, t):
+            newPrior = tm.GaussianRandomWalk.computeForwardPrior(self, posterior, t)
+            newPrior = np.minimum(newPrior, self.cap * np.sum(newPrior) / newPrior.size)
+            return newPrior / np.sum(newPrior) * np.sum(posterior)
+
+        def computeBackwardPrior(self, posterior, t):
+            return self.computeForwardPrior(posterior, t - 1)
+
+    return dict(LeakyRandomWalk=LeakyRandomWalk, CoolingWalk=CoolingWalk, CappedRandomWalk=CappedRandomWalk)
+
+
+def series(seed, T):
+    rng = np.random.default_rng(seed)
+    mu = np.cumsum(rng.normal(0, 0.1, T))
+    return mu + rng.normal(0, 0.5, T)
+
+
+COAL = np.array([5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4, 4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2, 1, 3, 2, 2,
+                 1, 1, 1, 1, 3, 0, 0, 1, 0, 1, 1, 0, 0, 3, 1, 0, 3, 2, 2, 0], dtype=int)      # first 60 years of the coal-mining counts
+
+
+def studies(bl, M):
+    """name -> (study, fit kwargs): every way a user-defined model reaches Study.fit / HyperStudy.fit"""
+    out = {}
+
+    def study(cls=None):
+        return (cls or bl.Study)(silent=True)
+
+    # 1-D Poisson, custom model alone: full fit / forward-only / evidence-only
+    for mode, kw in (('full', {}), ('fwdonly', dict(forwardOnly=True)), ('evid', dict(evidenceOnly=True))):
+        S = study()
+        S.loadData(COAL, timestamps=np.arange(1852, 1852 + len(COAL)), silent=True)
+        S.set(bl.om.Poisson('rate', bl.oint(0, 6, 120)), M['LeakyRandomWalk']('sigma', 0.25, 'leak', 0.02, target='rate'), silent=True)
+        out['leaky_poisson_' + mode] = (S, kw)
+    # the model reads t (time stamps that are not 0, 1, 2 ...)
+    S = study()
+    S.loadData(COAL[:40], timestamps=np.arange(10, 50), silent=True)
+    S.set(bl.om.Poisson('rate', bl.oint(0, 6, 100)), M['CoolingWalk']('sigma0', 0.5, 'tau', 15., t0=10., target='rate'), silent=True)
+    out['cooling_poisson_full'] = (S, {})
+    # 2-D Gaussian grid, a user-defined model COMBINED with a built-in one (the built-in sub-model is applied through its own
+    # computeForwardPrior) and missing data
+    x = series(7, 24)
+    x[5] = np.nan
+    S = study()
+    S.loadData(x, silent=True)
+    S.set(bl.om.Gaussian('mean', bl.cint(-3, 3, 40), 'std', bl.oint(0, 2, 30)),
+          bl.tm.CombinedTransitionModel(M['LeakyRandomWalk']('sigma', 0.2, 'leak', 0.01, target='mean'),
+                                        bl.tm.GaussianRandomWalk('s2', 0.1, target='std')), silent=True)
+    out['combined_gauss_full'] = (S, {})
+    # a subclass of a built-in model that overrides the transition (and calls the built-in one inside)
+    S = study()
+    S.loadData(series(8, 20), silent=True)
+    # (Study.set of the reference accepts direct subclasses of TransitionModel only, core.py:318: the setters take any object)
+    S.setObservationModel(bl.om.Gaussian('mean', bl.cint(-3, 3, 32), 'std', bl.oint(0, 2, 24)), silent=True)
+    S.setTransitionModel(M['CappedRandomWalk']('sigma', 0.3, target='mean'), silent=True)
+    out['capped_gauss_full'] = (S, {})
+    # a built-in SerialTransitionModel with a user-defined sub-model and a change-point boundary
+    S = study()
+    S.loadData(COAL[:30], silent=True)
+    S.set(bl.om.Poisson('rate', bl.oint(0, 6, 80)),
+          bl.tm.SerialTransitionModel(bl.tm.Static(), bl.tm.ChangePoint('tc', 9), M['LeakyRandomWalk']('sigma', 0.3, 'leak', 0.05, target='rate'),
+                                      bl.tm.BreakPoint('tb', 20), bl.tm.RegimeSwitch('log10pMin', -4)), silent=True)
+    out['serial_poisson_full'] = (S, {})
+    # hyper-study over the user-defined model's hyper-parameters (evidence-only)
+    S = study(bl.HyperStudy)
+    S.loadData(COAL[:36], silent=True)
+    S.set(bl.om.Poisson('rate', bl.oint(0, 6, 90)), M['LeakyRandomWalk']('sigma', bl.cint(0.1, 0.5, 3), 'leak', [0.0, 0.03], target='rate'), silent=True)
+    out['leaky_hyper_evid'] = (S, dict(evidenceOnly=True))
+    return out
+
+
+def direct_calls(bl):
+    """name -> (study the model is attached to, model, [(method, distribution kind, t)]): the built-in models' own
+    computeForwardPrior / computeBackwardPrior called directly, on normalised and un-normalised distributions"""
+    def s1():
+        S = bl.Study(silent=True)
+        S.loadData(COAL[:12], silent=True)
+        S.setObservationModel(bl.om.Poisson('rate', bl.oint(0, 6, 64)), silent=True)
+        return S
+
+    def s2(prior=None):
+        S = bl.Study(silent=True)
+        S.loadData(series(9, 12), silent=True)
+        S.setObservationModel(bl.om.Gaussian('mean', bl.cint(-3, 3, 24), 'std', bl.oint(0, 2, 16), prior=prior), silent=True)
+        return S
+
+    def lin(t, slope=0.07):
+        return slope * t
+
+    calls = [('fwd', 'norm', 3), ('fwd', 'raw', 3), ('bwd', 'raw', 4)]
+    out = {
+        'grw_1d': (s1(), bl.tm.GaussianRandomWalk('sigma', 0.3, target='rate'), calls),
+        'grw_2d_axis0': (s2(), bl.tm.GaussianRandomWalk('sigma', 0.4, target='mean'), calls),
+        'grw_2d_axis1': (s2(), bl.tm.GaussianRandomWalk('sigma', 0.2, target='std'), calls),
+        'static': (s1(), bl.tm.Static(), calls),
+        'regimeswitch': (s2(), bl.tm.RegimeSwitch('log10pMin', -2.5), calls),
+        'notequal': (s1(), bl.tm.NotEqual('log10pMin', -3), calls),
+        'changepoint_at': (s2(lambda m, s: 1. / s), bl.tm.ChangePoint('tc', 3), calls),
+        'changepoint_off': (s1(), bl.tm.ChangePoint('tc', 7), calls),
+        'independent': (s1(), bl.tm.Independent(), calls),
+        'deterministic': (s1(), bl.tm.Deterministic(lin, target='rate'), calls),
+        'alphastable': (s1(), bl.tm.AlphaStableRandomWalk('c', 0.2, 'alpha', 1.5, target='rate'), calls),
+        'bivariate': (s2(), bl.tm.BivariateRandomWalk('sigma1', 0.3, 'sigma2', 0.15, 'rho', 0.4), calls),
+        'combined': (s2(), bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('sigma', 0.3, target='mean'),
+                                                         bl.tm.RegimeSwitch('log10pMin', -3)), calls),
+        'serial': (s1(), bl.tm.SerialTransitionModel(bl.tm.Static(), bl.tm.ChangePoint('tc', 3),
+                                                     bl.tm.GaussianRandomWalk('sigma', 0.3, target='rate'), bl.tm.BreakPoint('tb', 6),
+                                                     bl.tm.RegimeSwitch('log10pMin', -3)),
+                   [('fwd', 'norm', 2), ('fwd', 'raw', 3), ('fwd', 'raw', 4), ('fwd', 'norm', 8), ('bwd', 'raw', 4), ('bwd', 'raw', 5), ('bwd', 'norm', 7)]),
+    }
+    return out
+
+
+def distribution(kind, shape, seed=0):
+    rng = np.random.default_rng(1000 + seed)
+    x = rng.random(shape) ** 3 + 1e-3
+    return x / np.sum(x) if kind == 'norm' else 7.5 * x

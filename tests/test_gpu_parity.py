@@ -1033,7 +1033,8 @@ def test_resident_kernel_degenerate_fit_does_not_stall():
     with np.errstate(all='ignore'):
         S.fit(silent=True)
         want = oa.run(c)
-    assert time.time() - t0 < 1.5                                   # (resident_timeout_s = 2 is never reached)
+    assert time.time() - t0 < 1.5                                   # (no in-kernel wait ran into its bound)
+    assert S.lastTiming['resident_fallbacks'] == 1 and S.lastTiming['resident_fallback_reason'] == 2, S.lastTiming      # BLHIP_FALLBACK_RANGE
     assert S.logEvidence == want['logEvidence'] == -np.inf
 
 
@@ -1554,6 +1555,7 @@ def test_padded_and_restarting_batches_fall_back_too(case):
     try:
         S = cases.build(bl, c); S.fit(**cases.fit_kwargs(c))
         assert S.lastTiming['fwd_kernel_variant'] != 6 and S.lastTiming['resident_fallbacks'] >= 1 and S.lastTiming['resident_armed'] == 0, S.lastTiming
+        assert S.lastTiming['resident_fallback_reason'] == 4, S.lastTiming        # BLHIP_FALLBACK_FORCED (a real give-up reports 1)
         got = result_of(S, c)
         gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'], posteriorSequence=np.asarray(want['posteriorSequence']),
                     posteriorMeanValues=np.asarray(want['posteriorMeanValues']), logEvidenceList=np.asarray(want['logEvidenceList']))
