@@ -63,7 +63,7 @@ class Timing(C.Structure):
         ('fwd_kernel_variant', C.c_int32), ('bwd_kernel_variant', C.c_int32),
         ('fwd_hbm_bytes', C.c_double), ('bwd_hbm_bytes', C.c_double), ('fwd_flops', C.c_double), ('bwd_flops', C.c_double),
         ('resident_fallbacks', C.c_int32), ('resident_armed', C.c_int32),
-        ('resident_fallback_reason', C.c_int32), ('reserved0', C.c_int32),
+        ('resident_fallback_reason', C.c_int32), ('peer_copy_path', C.c_int32),
     ]
 
     def as_dict(self):

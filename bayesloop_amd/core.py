@@ -484,9 +484,26 @@ class Study(object):
             if isinstance(k, tuple):                       # ('shift', q) of a Deterministic model
                 if id(model) not in shift_cache:
                     cols = [i for i, sl in enumerate(slots) if sl[0] is model]
-                    shift_cache[id(model)] = np.array([
-                        model.shifts({model.hyperParameterNames[sl_k]: hyper_rows[c, i] for i, sl_k in
-                                      zip(cols, [slots[i][1] for i in cols])}, ts, resume_time) for c in range(n)])
+                    # inside a serial model the sub-model counts its time from the break-/change-point that starts its segment
+                    # (reference transitionModels.py:770-776): that boundary's value of the SAME chain
+                    seg = [op[4] for op in program if op[0] == _abi.OP_DETERMINISTIC and op[2] is model][0]
+                    off_col = None
+                    if seg > 0:
+                        bounds = [op for op in program if op[0] == _abi.OP_BREAKPOINT or (op[0] == _abi.OP_CHANGEPOINT and op[5] & 1)]
+                        owner, kb = bounds[seg - 1][2], bounds[seg - 1][3]
+                        off_col = [i for i, sl in enumerate(slots) if sl[0] is owner and sl[1] == kb][0]
+                    # (chains that share the model's hyper-parameters and its time offset share the table: a change-point study over
+                    #  two break-points evaluates each (parameters, first break-point) pair once, not once per chain)
+                    names_k = [model.hyperParameterNames[slots[i][1]] for i in cols]
+                    key_cols = cols + ([] if off_col is None else [off_col])
+                    tables, rows = {}, []
+                    for c in range(n):
+                        key = hyper_rows[c, key_cols].tobytes()
+                        if key not in tables:
+                            tables[key] = model.shifts(dict(zip(names_k, hyper_rows[c, cols])), ts, resume_time,
+                                                       t_offset=None if off_col is None else hyper_rows[c, off_col])
+                        rows.append(tables[key])
+                    shift_cache[id(model)] = np.array(rows)
                 out[:, j] = shift_cache[id(model)][:, k[1]]
                 continue
             col = [i for i, sl in enumerate(slots) if sl[0] is model and sl[1] == k][0]

@@ -89,6 +89,27 @@ struct TapTable {
         return id;
     }
 
+    // The same shift for |d| > 12 grid cells per step (1-D grids; the reference's published break-point study shifts by up to 334 cells
+    // per step: docs/source/tutorials/changepointstudy.ipynb).  Beyond its 12 pre-padded samples SciPy extends the spline COEFFICIENTS by
+    // their edge values, which no shift-invariant stencil reproduces: the step kernel then works in the two stages of
+    // oracle/bl_oracle.py: spline_shift_nearest -- prefilter the padded row (symmetric, radius 34, weights below), then evaluate the cubic
+    // B-spline at the shifted coordinates with the coefficient index clamped.  Stored as [d, g(0) .. g(34)]; lw = 12 + 34 is the halo the
+    // row needs, lw2 = -2 marks the layout.
+    std::map<double, int> index_bigshift;
+    int get_bigshift(double d) {
+        auto it = index_bigshift.find(d);
+        if (it != index_bigshift.end()) return it->second;
+        const double pole = std::sqrt(3.0) - 2.0, gain = -6.0 * pole / (1.0 - pole * pole);
+        const int id = (int)off.size();
+        off.push_back((int)w.size());
+        lw.push_back(12 + 34);
+        lw2.push_back(-2);
+        w.push_back(d);
+        for (int m = 0; m <= 34; ++m) w.push_back(gain * std::pow(pole, (double)m));
+        index_bigshift[d] = id;
+        return id;
+    }
+
     // AlphaStableRandomWalk.createKernel (transitionModels.py:196-240) for an axis of n points: k[d], d = 0 .. n-1, of the
     // inverse real DFT (numpy.fft.irfft) of exp(-|c w|^alpha) sampled at m = int(3n/2 + 1) points of [0, pi]; the reference's
     // roll + 3x zero padding + fftconvolve(mode='same') (:233-260) is out[i] = sum_j in[j] k[|i - j|] inside the grid
@@ -182,11 +203,15 @@ size_t lds_need(int TI, int TJ, int LW0, int LW1) {
     return ((size_t)(TI + 2 * LW0) * pitch + (size_t)TI * pitch + 32) * sizeof(double);
 }
 
-Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1) {
+Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1, bool whole_row = false) {
     Tile t{};
-    const size_t cap = (size_t)ctx->option("lds_cap_bytes", 64 * 1024);
+    size_t cap = (size_t)ctx->option("lds_cap_bytes", 64 * 1024);
     int TI, TJ;
-    if (g.n0 == 1) {
+    if (g.n0 == 1 && whole_row) {                // (a two-stage spline shift: one block per chain holds the whole row)
+        TI = 1;
+        TJ = g.n1;
+        cap = 160 * 1024 - 512;
+    } else if (g.n0 == 1) {
         TI = 1;
         TJ = (int)ctx->option("tile_1d", g.n1 <= 65536 ? 256 : 1024);
     } else {
@@ -438,30 +463,29 @@ void launch_persist1d(hipStream_t s, int om, const bl1p::P1Params &P, bool bwd, 
 struct ResidentPlan {
     int TR = 0, TC = 0, SEG = 0, tr = 0, tc = 0, ntiles = 0, NT = 0;
     bool pad = false;            // the grid does not fill its last tile row / column (PAD kernels)
-    bool onex = false;           // 64 x 64 tiles: one hand-off per step (option resident_onex, blhip_resident.hpp: ONEX)
     size_t lds_bytes = 0;
 };
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID, bool PAD = false, bool ONEX = false>
+template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID, bool PAD = false>
 void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
-    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID, PAD, ONEX>::LDS_DOUBLES * sizeof(double);
-    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD, ONEX>));
-    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD, ONEX>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID, PAD>::LDS_DOUBLES * sizeof(double);
+    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>));
+    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
 }
 
-template <int TR, int TC, int SEG, int CHK, bool ONEX = false>
+template <int TR, int TC, int SEG, int CHK>
 void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad = false) {
     // forward pass of an evidence-only fit: nothing stored, no means, no rows to normalise -> the flavour with compile-time flags
     const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
     if (pad) {                   // grids that do not fill their last tile row / column
-        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, true, ONEX>(s, Q);
-        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, true, ONEX>(s, Q);
-        else launch_resident_k<TR, TC, SEG, CHK, false, false, true, ONEX>(s, Q);
+        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, true>(s, Q);
+        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, true>(s, Q);
+        else launch_resident_k<TR, TC, SEG, CHK, false, false, true>(s, Q);
         return;
     }
-    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, false, ONEX>(s, Q);
-    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, false, ONEX>(s, Q);
-    else launch_resident_k<TR, TC, SEG, CHK, false, false, false, ONEX>(s, Q);
+    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false>(s, Q);
+    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true>(s, Q);
+    else launch_resident_k<TR, TC, SEG, CHK, false, false>(s, Q);
 }
 
 // tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
@@ -474,7 +498,6 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
         launch_resident_k<128, 128, 16, 4, false, true>(s, Q);
     }
     else if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd, rp.pad);
-    else if (rp.TR == 64 && rp.onex) launch_resident_t<64, 64, 8, 8, true>(s, Q, bwd, rp.pad);
     else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd, rp.pad);
     else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd, rp.pad);
     else launch_resident_t<32, 32, 8, 8>(s, Q, bwd, rp.pad);
@@ -727,6 +750,7 @@ struct ChainProgram {
     std::vector<double> limitF, limitB;
     int LW0 = 0, LW1 = 0;
     bool has_clamp = false;
+    bool whole_row = false;      // a two-stage spline shift (Deterministic, |d| > 12): a block needs the whole row of a 1-D grid
 };
 
 struct StepProg {
@@ -747,8 +771,16 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
     prog.tapB0.assign(nT, -1); prog.tapB1.assign(nT, -1);
     prog.LW0 = prog.LW1 = 0;
     prog.has_clamp = false;
+    prog.whole_row = false;
     double dV = 1.0;
     for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
+    // the ops a step's program is made of (the *_ARG ops only carry values of the op in front of them: a Deterministic model has 2 T of
+    // them, and the per-(step, chain) walk below would spend its time skipping them -- 23 400 chains x 41 steps x 2 x 87 ops measured)
+    std::vector<int> real_ops;
+    for (int k = 0; k < nops; ++k) {
+        const int kind = p->ops[k].kind;
+        if (kind != BLHIP_OP_DETERMINISTIC_ARG && kind != BLHIP_OP_BIVARIATE_ARG && kind != BLHIP_OP_ALPHASTABLE_ARG) real_ops.push_back(k);
+    }
     for (int64_t b = 0; b < B; ++b) {
         const double *val = op_values ? op_values + (c0 + b) * nops : nullptr;
         // tap ids of this chain's GRW ops
@@ -790,12 +822,12 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
             StepProg sp;
             int seg = 0;                                                   // active sub-model of a serial model (:768)
             if (have_tau)
-                for (int k = 0; k < nops; ++k) {
+                for (int k : real_ops) {
                     const blhip_op &op = p->ops[k];
                     if ((op.kind == BLHIP_OP_BREAKPOINT || (op.kind == BLHIP_OP_CHANGEPOINT && (op.flags & 1))) && val[k] <= tau) seg++;
                 }
             bool filtered = false;
-            for (int k = 0; k < nops; ++k) {
+            for (int k : real_ops) {
                 const blhip_op &op = p->ops[k];
                 if (op.segment >= 0 && op.segment != seg) continue;
                 switch (op.kind) {
@@ -825,14 +857,16 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                         if (step < 0) break;                                      // (the time-independent template program)
                         const double dd = val[k + 1 + (fwd ? step : T + step)] / p->lattice[op.axis];
                         if (std::isnan(dd)) fail("chain %lld: Deterministic shift of step %lld is NaN", (long long)(c0 + b), (long long)step);
-                        if (std::fabs(dd) > 12.0)
-                            fail("chain %lld, step %lld: Deterministic model shifts by %.3g grid cells in one time step; the fused "
-                                 "kernel supports up to 12 (SciPy's pre-padding)", (long long)(c0 + b), (long long)step, dd);
+                        if (std::fabs(dd) > 12.0 && (g.n0 != 1 || (double)g.n1 > 16000.0))
+                            fail("chain %lld, step %lld: Deterministic model shifts by %.3g grid cells in one time step; on grids with two "
+                                 "parameters (and 1-D grids beyond 16000 points) the fused kernel supports up to 12 (SciPy's pre-padding)",
+                                 (long long)(c0 + b), (long long)step, dd);
                         int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
                         if (slot >= 0 || (sp.cmode != 0 && sp.cmode != 6))
                             fail("a Deterministic model combined with another model acting on the same parameter / a clamp is not supported");
                         if (dd != 0.0) {                                          // zero shift: identity (its renormalisation is a no-op)
-                            slot = taps.get_shift(op_axis[k], dd);
+                            if (std::fabs(dd) > 12.0) { slot = taps.get_bigshift(dd); prog.whole_row = true; }
+                            else slot = taps.get_shift(op_axis[k], dd);
                             sp.cmode = 6;
                         }
                         filtered = true;
@@ -869,7 +903,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                 }
             }
             if (have_tau)
-                for (int k = 0; k < nops; ++k) {                                  // serial change-points, :801-813
+                for (int k : real_ops) {                                          // serial change-points, :801-813
                     const blhip_op &op = p->ops[k];
                     if (op.kind == BLHIP_OP_CHANGEPOINT && (op.flags & 1) && tau == val[k]) { sp = StepProg(); sp.kind = SRC_RESET; }
                 }
@@ -1224,7 +1258,8 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
         gp.tile.TI = 1; gp.tile.TJ = gp.f1_TJ; gp.tile.LW0 = 0; gp.tile.LW1 = prog.LW1; gp.tile.tiles_i = 1;
         gp.tile.tiles_j = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ; gp.tile.nblk = gp.tile.tiles_j; gp.tile.lds_bytes = 0;
     } else {
-        gp.tile = choose_tile(ctx, g, prog.LW0, prog.LW1);
+        gp.tile = choose_tile(ctx, g, prog.LW0, prog.LW1, prog.whole_row);
+        if (prog.whole_row && gp.tile.tiles_j != 1) fail("internal: a two-stage spline shift needs the whole row in one tile");
     }
     return gp;
 }

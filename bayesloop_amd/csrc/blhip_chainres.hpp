@@ -95,6 +95,45 @@ struct ChainParams {
     unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
 };
 
+// The kernel arguments arrive as 16-register tuples (s_load_dwordx16) and the register allocator spills and restores a tuple as ONE
+// unit: with ~100 live scalars in the step loop of the two-chain fold kernel a single field of ChainParams cost a 16-lane v_readlane
+// burst per use (ISA, NK = 14: 304 v_readlane of 1473 vector instructions per chain-step, 16-lane bursts repeated 7 times).  Every
+// field that loop uses is therefore copied into a scalar of its own first -- the empty asm makes the copy a separate value the
+// allocator can place, spill or keep on its own (137 v_readlane, 1403 vector instructions).  (The single-chain kernels have few
+// spills -- 35 v_readlane per step -- and do not gain: measured on the ISA, not applied there.)
+template <class T>
+__device__ __forceinline__ T own_sgpr(T v) { asm volatile("" : "+s"(v)); return v; }
+// ... a pointer: copied as an integer and handed back through the GLOBAL address space (behind the asm the compiler no longer sees that
+// the pointer came from a kernel argument and would fall back to flat_load / flat_store)
+template <class T>
+__device__ __forceinline__ T *own_sgpr(T *p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (T *)(T __attribute__((address_space(1))) *)v;
+}
+struct LoopParams {
+    int T, d, rec_len, lag, B, nslots, strips, nblk, part_fresh, bprov;
+    const double *rec, *sfwd, *zeros, *reset;
+    const unsigned char *kinds;
+    double *post, *psum;
+    long long post_stride;
+    unsigned long long *gran;
+    unsigned *abort_word;
+    unsigned long long timeout_ticks;
+    double step0;
+};
+__device__ __forceinline__ LoopParams loop_params(const ChainParams &P) {
+    LoopParams Q;
+    Q.T = own_sgpr(P.T); Q.d = own_sgpr(P.d); Q.rec_len = own_sgpr(P.rec_len); Q.lag = own_sgpr(P.lag); Q.B = own_sgpr(P.B);
+    Q.nslots = own_sgpr(P.nslots); Q.strips = own_sgpr(P.strips); Q.nblk = own_sgpr(P.nblk); Q.part_fresh = own_sgpr(P.part_fresh);
+    Q.bprov = own_sgpr(P.bprov);
+    Q.rec = own_sgpr(P.rec); Q.sfwd = own_sgpr(P.sfwd); Q.zeros = own_sgpr(P.zeros); Q.reset = own_sgpr(P.reset);
+    Q.kinds = own_sgpr(P.kinds); Q.post = own_sgpr(P.post); Q.psum = own_sgpr(P.psum); Q.post_stride = own_sgpr(P.post_stride);
+    Q.gran = own_sgpr(P.gran); Q.abort_word = own_sgpr(P.abort_word); Q.timeout_ticks = own_sgpr(P.timeout_ticks);
+    Q.step0 = P.step0;
+    return Q;
+}
+
 // streaming accesses (every byte of the sequence / the partial accumulators is touched once per launch): non-temporal hints --
 // measured: C4 backward + fold 306 -> 293 us, C5 backward 63.9 -> 59.9 us per logical step
 __device__ __forceinline__ double ldnt(const double *base, unsigned byteoff) { return __builtin_nontemporal_load((const double *)((const char *)base + byteoff)); }
@@ -659,6 +698,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     int pend_j = -1, pend_k = 0;                   // the chain-step whose row sums wave 5 still has to add up (after the next barrier)
     int kind_next = blk::SRC_PREV;                 // NK = 4: source kind of the chain-step after this one (the first steps consume src0)
 
+    const LoopParams Q = loop_params(P);
     // wave 5: block totals of a finished chain-step -> partial sums of the strip + the granule the scale of step k + lag is made of
     auto totals = [&](int j, int k) {
         if (wv == 5 && lane < 3) {
@@ -666,12 +706,12 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < NW * 4; ++w) tot += rk[w * 3 + lane];
-            const int t = P.T - 1 - k;
-            P.psum[(((long long)t * P.B + bch[j]) * NRED + lane) * P.nblk + tj] = tot;
+            const int t = Q.T - 1 - k;
+            Q.psum[(((long long)t * Q.B + bch[j]) * NRED + lane) * Q.nblk + tj] = tot;
             if (lane == 2) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
                 const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
-                unsigned long long *gw = P.gran + ((((long long)(k & (NSLOT - 1)) * P.nslots + 2 * cs2 + j) * P.strips + tj) << 1);
+                unsigned long long *gw = Q.gran + ((((long long)(k & (NSLOT - 1)) * Q.nslots + 2 * cs2 + j) * Q.strips + tj) << 1);
                 blr::st_u64(gw, tag | (bits & 0xffffffffull));
                 blr::st_u64(gw + 1, tag | (bits >> 32));
             }
@@ -682,42 +722,42 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     // ONE body for both chains of the block (j is block-uniform and changes every iteration): the two chain-steps of a time step are
     // not unrolled into one another -- unrolled, the scheduler interleaves their loads and the kernel spills (measured: 54 - 93 VGPRs)
     const bool scale_wave = wv == SCALE_WAVE;
-    const int nsteps = P.T * nch;
+    const int nsteps = Q.T * nch;
 #pragma unroll 1
     for (int cstep = 0; cstep < nsteps; ++cstep) {
         const int k = nch == 2 ? cstep >> 1 : cstep;
         const int j = __builtin_amdgcn_readfirstlane(nch == 2 ? cstep & 1 : 0);
-        const int t = P.T - 1 - k;
-        const int tn = (k + 1 < P.T) ? t - 1 : t;
+        const int t = Q.T - 1 - k;
+        const int tn = (k + 1 < Q.T) ? t - 1 : t;
         const int jn = k + 1;
         const int bj = j ? bch[1] : bch[0];
         if (j == 0) {
 #pragma unroll
-            for (int q = 0; q < DMAX; ++q) xd[q] = q < P.d ? P.rec[(long long)t * P.rec_len + q] : __builtin_nan("");
+            for (int q = 0; q < DMAX; ++q) xd[q] = q < Q.d ? Q.rec[(long long)t * Q.rec_len + q] : __builtin_nan("");
         }
         double *const pslot_t = pslot + (long long)t * G;
         double *const pslot_tn = pslot + (long long)tn * G;
         double *const Xj = X + j * XSZ;
         // scale wave: the granules of the sums the scale of step k + 2 of this chain is made of (requested a step ahead)
-        const bool need = scale_wave && jn >= P.lag && jn < P.T;
-        const unsigned long long *gp = P.gran + ((((long long)((jn - P.lag) & (NSLOT - 1)) * P.nslots + 2 * cs2 + j) * P.strips + lane) << 1);
-        const bool mine = need && lane < P.strips;
+        const bool need = scale_wave && jn >= Q.lag && jn < Q.T;
+        const unsigned long long *gp = Q.gran + ((((long long)((jn - Q.lag) & (NSLOT - 1)) * Q.nslots + 2 * cs2 + j) * Q.strips + lane) << 1);
+        const bool mine = need && lane < Q.strips;
         const unsigned long long hq0 = j ? gq0[1] : gq0[0], hq1 = j ? gq1[1] : gq1[0];
-        if (scale_wave && jn + 1 >= P.lag && jn + 1 < P.T && lane < P.strips) {
-            const unsigned long long *gn = P.gran + ((((long long)((jn + 1 - P.lag) & (NSLOT - 1)) * P.nslots + 2 * cs2 + j) * P.strips + lane) << 1);
+        if (scale_wave && jn + 1 >= Q.lag && jn + 1 < Q.T && lane < Q.strips) {
+            const unsigned long long *gn = Q.gran + ((((long long)((jn + 1 - Q.lag) & (NSLOT - 1)) * Q.nslots + 2 * cs2 + j) * Q.strips + lane) << 1);
             const unsigned long long n0_ = blr::ld_u64(gn), n1_ = blr::ld_u64(gn + 1);
             if (j) { gq0[1] = n0_; gq1[1] = n1_; } else { gq0[0] = n0_; gq1[0] = n1_; }
         }
         const int kind = kind_next;
-        if (!FILTER && P.kinds) {                   // (requested a chain-step ahead: a dependent scalar load in front of the cells costs a round trip)
+        if (!FILTER && Q.kinds) {                   // (requested a chain-step ahead: a dependent scalar load in front of the cells costs a round trip)
             const bool lastc = j + 1 == nch;
             const int tq = lastc ? tn : t, kq = lastc ? k + 1 : k;          // (the first step of a chain consumes src0, which its buffer holds)
-            kind_next = (kq == 0 || kq >= P.T) ? blk::SRC_PREV : (int)P.kinds[(long long)tq * P.B + (lastc ? bch[0] : bch[1])];
+            kind_next = (kq == 0 || kq >= Q.T) ? blk::SRC_PREV : (int)Q.kinds[(long long)tq * Q.B + (lastc ? bch[0] : bch[1])];
         }
         const double sf_now = sf_next;
         {
             const bool lastc = j + 1 == nch;
-            sf_next = P.sfwd[(long long)(lastc ? bch[0] : bch[1]) * P.T + min((lastc ? tn : t) + 1, P.T - 1)];
+            sf_next = Q.sfwd[(long long)(lastc ? bch[0] : bch[1]) * Q.T + min((lastc ? tn : t) + 1, Q.T - 1)];
         }
         __syncthreads();                                            // every wave's rows of this chain are in Xj
         if (pend_j >= 0) {
@@ -750,7 +790,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 {
                     const int row = row0 + it * TM + g + 4 * r;
                     const bool in = !PAD || (row < n0t && colok);
-                    Xj[row * WCOL + c] = in ? P.reset[(long long)row * n1t + tj * WCOL + c] : 0.0;
+                    Xj[row * WCOL + c] = in ? Q.reset[(long long)row * n1t + tj * WCOL + c] : 0.0;
                 }
         }
 
@@ -775,7 +815,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
         const bool last_chain = j + 1 == nch;
         const int bnext = last_chain ? bch[0] : bch[1];
         const int tnext = last_chain ? tn : t;
-        const double *const pnext = P.post + (long long)(tnext < (last_chain ? tshv[0] : tshv[1]) ? P.bprov : bnext) * P.post_stride + (long long)tnext * G;
+        const double *const pnext = Q.post + (long long)(tnext < (last_chain ? tshv[0] : tshv[1]) ? Q.bprov : bnext) * Q.post_stride + (long long)tnext * G;
 
 #pragma unroll
         for (int it = 0; it < NTW; ++it) {
@@ -802,7 +842,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 if (scale_wave) {
                     double sj = 1.0;
                     if (need) {
-                        const unsigned long long want = (unsigned long long)(unsigned)(jn - P.lag + 1);
+                        const unsigned long long want = (unsigned long long)(unsigned)(jn - Q.lag + 1);
                         unsigned long long q0 = hq0, q1 = hq1;
                         bool ok = !mine || ((q0 >> 32) == want && (q1 >> 32) == want);
                         if (!dead && !__all(ok)) {
@@ -811,15 +851,15 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                                 if (!ok) { q0 = blr::ld_u64(gp); q1 = blr::ld_u64(gp + 1); ok = (q0 >> 32) == want && (q1 >> 32) == want; }
                                 blr::nap();
                                 if ((spins & 255u) == 0u) {
-                                    if (blr::ld_flag(P.abort_word) != 0u) { dead = true; break; }
-                                    if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; break; }
+                                    if (blr::ld_flag(Q.abort_word) != 0u) { dead = true; break; }
+                                    if (blr::now_ticks() - t0 > Q.timeout_ticks) { blr::st_flag(Q.abort_word, 1u); dead = true; break; }
                                 }
                             }
                         }
                         const double v = mine ? __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32))) : 0.0;
                         const double Sg = blk::wave_sum(v);
                         const double sp = j ? Sprev[1] : Sprev[0];
-                        sj = dead ? 1.0 : sp * scal[j * NSLOT + ((jn - P.lag) & (NSLOT - 1))] / Sg;
+                        sj = dead ? 1.0 : sp * scal[j * NSLOT + ((jn - Q.lag) & (NSLOT - 1))] / Sg;
                         if (j) Sprev[1] = Sg; else Sprev[0] = Sg;
                     }
                     if (lane == 0) { scal[j * NSLOT + (jn & (NSLOT - 1))] = sj; iscal[j * NSLOT + (jn & (NSLOT - 1))] = 1.0 / sj; }
@@ -843,7 +883,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                     exp_mn(a0, a_mE, a_nE);
                     exp_mn(d1, a_mR, a_nR);
                     if (dn != dn_prev) {
-                        const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                        const double d2 = -32.0 * cA * dn * Q.step0 * Q.step0;
                         exp_mn(d2, mq, nq);
                         exp_mn(-d2, iq, tmp);
                         dn_prev = dn;
@@ -873,17 +913,22 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             // the last chain of the time step stores the accumulator cells (nobody else touches the slot's cells during the launch) and
             // requests those of the next time step; every chain-step requests the stored alpha of the chain-step after it (the tile's
             // slot has just been consumed)
+            // (ONE 64-bit address per array and tile, the four cells at immediate offsets -- rows 4 r are 4 x 128 bytes apart in the
+            //  strip-major layout: a cell_off() per access was ~200 integer instructions per chain-step)
+            const unsigned off_t = cell_off(l, it, 0);
             if (last_chain) {
+                char *const ps = (char *)pslot_t + off_t;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stnt(pslot_t, cell_off(l, it, r), pacc[it][r]);
+                for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(pacc[it][r], (double *)(ps + r * (4 * WCOL * 8)));
+                const char *const pn = Q.part_fresh ? (const char *)Q.zeros + (off_t & 4088u) : (const char *)pslot_tn + off_t;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned aoffs = cell_off(l, it, r);
-                    pacc[it][r] = ldnt(P.part_fresh ? P.zeros : pslot_tn, P.part_fresh ? (aoffs & 4088u) : aoffs);
-                }
+                for (int r = 0; r < 4; ++r) pacc[it][r] = __builtin_nontemporal_load((const double *)(pn + r * (4 * WCOL * 8)));
             }
+            {
+                const char *const pa_ = (const char *)pnext + off_t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) al[it][r] = ldnt(pnext, cell_off(l, it, r));
+                for (int r = 0; r < 4; ++r) al[it][r] = __builtin_nontemporal_load((const double *)(pa_ + r * (4 * WCOL * 8)));
+            }
             // (no products to pace the no-stencil variant: without a fence the scheduler interleaves the four tiles' cells and spills)
             if (!FILTER) __builtin_amdgcn_sched_barrier(0);
             // ---- advance the ring by one tile --------------------------------------------------------------------------------------

@@ -232,14 +232,43 @@ int blhip_comm_timing(blhip_ctx *ctx, double *reduce_ms) {
 //      accumulators are merged with peer copies over xGMI, no RCCL.  The caller (bayesloop_amd/dist.py: LocalGroup) brings every
 //      accumulator to the common reference exponent first, synchronises every context and orders the calls with host barriers. -------
 namespace {
-void enable_peer(int self_dev, int peer_dev) {
-    if (self_dev == peer_dev) return;
+// How a slice of another context's accumulator gets here (reported in blhip_timing.peer_copy_path of the DESTINATION context):
+//   BLHIP_PEER_SAME_DEVICE  both contexts on one GPU (the 1-GPU test configuration): a device-to-device copy
+//   BLHIP_PEER_DIRECT       hipMemcpyPeerAsync over xGMI, peer access enabled
+//   BLHIP_PEER_HOST_STAGED  no peer access between the two devices (hipDeviceCanAccessPeer == 0), a peer copy that FAILED, or option
+//                           peer_copy_mode = 1 (tests: the branch runs on one GPU too): an explicit copy through page-locked host
+//                           memory, 64 MiB at a time -- slow, never wrong; one line on stderr the first time
+std::atomic<bool> g_peer_staging_announced{false};
+std::atomic<bool> g_peer_copy_broken{false};           // a hipMemcpyPeerAsync failed: the process stays on the staged path
+bool peer_direct(blhip_ctx *dst, int self_dev, int peer_dev) {
+    if (self_dev == peer_dev) return true;
+    if (dst->option("peer_copy_mode", 0.0) == 1.0 || g_peer_copy_broken.load()) return false;
     int can = 0;
-    HIPCHECK(hipDeviceCanAccessPeer(&can, self_dev, peer_dev));
-    if (!can) return;                                   // (hipMemcpyPeerAsync then stages through the host)
+    if (hipDeviceCanAccessPeer(&can, self_dev, peer_dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!can) return false;
     const hipError_t e = hipDeviceEnablePeerAccess(peer_dev, 0);
-    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHECK(e);
     (void)hipGetLastError();
+    return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+}
+void staged_copy(blhip_ctx *dst, double *to, blhip_ctx *src, const double *from, size_t bytes, hipStream_t s, const char *why) {
+    if (!g_peer_staging_announced.exchange(true) && dst->option("quiet", 0.0) == 0.0)
+        std::fprintf(stderr, "[blhip] accumulator merge between devices %d and %d goes through host memory (%s): slower than xGMI, same result\n",
+                     src->device, dst->device, why);
+    constexpr size_t CHUNK = 64u << 20;
+    void *host = nullptr;
+    HIPCHECK(hipHostMalloc(&host, std::min(bytes, CHUNK), hipHostMallocDefault));
+    try {
+        for (size_t done = 0; done < bytes; done += CHUNK) {
+            const size_t n = std::min(CHUNK, bytes - done);
+            HIPCHECK(hipSetDevice(src->device));
+            HIPCHECK(hipMemcpy(host, reinterpret_cast<const char *>(from) + done, n, hipMemcpyDeviceToHost));
+            HIPCHECK(hipSetDevice(dst->device));
+            HIPCHECK(hipMemcpyAsync(reinterpret_cast<char *>(to) + done, host, n, hipMemcpyHostToDevice, s));
+            HIPCHECK(hipStreamSynchronize(s));          // (the staging block is reused)
+        }
+    } catch (...) { (void)hipSetDevice(dst->device); (void)hipHostFree(host); throw; }
+    HIPCHECK(hipSetDevice(dst->device));
+    HIPCHECK(hipHostFree(host));
 }
 void check_peers(blhip_ctx *dst, blhip_ctx *const *srcs, int n) {
     if (!dst->acc_active || dst->acc_final) fail("peer merge: the destination has no open accumulator");
@@ -259,8 +288,22 @@ __global__ void peer_add_kernel(double *__restrict__ acc, const double *__restri
     }
 }
 void copy_rows(blhip_ctx *dst, double *to, blhip_ctx *src, long long off, size_t bytes, hipStream_t s) {
-    if (src->device == dst->device) HIPCHECK(hipMemcpyAsync(to, src->acc + off, bytes, hipMemcpyDeviceToDevice, s));
-    else HIPCHECK(hipMemcpyPeerAsync(to, dst->device, src->acc + off, src->device, bytes, s));
+    const bool forced = dst->option("peer_copy_mode", 0.0) == 1.0;
+    if (src->device == dst->device && !forced) {
+        HIPCHECK(hipMemcpyAsync(to, src->acc + off, bytes, hipMemcpyDeviceToDevice, s));
+        dst->timing.peer_copy_path = std::max(dst->timing.peer_copy_path, (int32_t)BLHIP_PEER_SAME_DEVICE);
+        return;
+    }
+    if (!forced && peer_direct(dst, dst->device, src->device)) {
+        const hipError_t e = hipMemcpyPeerAsync(to, dst->device, src->acc + off, src->device, bytes, s);
+        if (e == hipSuccess) { dst->timing.peer_copy_path = std::max(dst->timing.peer_copy_path, (int32_t)BLHIP_PEER_DIRECT); return; }
+        (void)hipGetLastError();
+        g_peer_copy_broken.store(true);
+        staged_copy(dst, to, src, src->acc + off, bytes, s, hipGetErrorString(e));
+    } else {
+        staged_copy(dst, to, src, src->acc + off, bytes, s, forced ? "option peer_copy_mode = 1" : "no peer access between the devices");
+    }
+    dst->timing.peer_copy_path = (int32_t)BLHIP_PEER_HOST_STAGED;
 }
 }  // namespace
 
@@ -276,7 +319,6 @@ int blhip_accum_peer_reduce(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, 
         double *stage = dst->commbuf.as<double>();
         HIPCHECK(hipEventRecord(dst->fork_ev, st));
         for (int i = 0; i < n_srcs; ++i) {               // one stream per source: the copies run over different xGMI links at once
-            enable_peer(dst->device, srcs[i]->device);
             hipStream_t s = dst->bstream[i];
             HIPCHECK(hipStreamWaitEvent(s, dst->fork_ev, 0));
             copy_rows(dst, stage + (long long)i * cnt, srcs[i], off, (size_t)cnt * 8, s);
@@ -300,7 +342,6 @@ int blhip_accum_peer_gather(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, 
         for (int i = 0; i < n_srcs; ++i) {
             if (row0[i] < 0 || row1[i] > dst->acc_T || row0[i] > row1[i]) fail("peer gather: rows [%lld, %lld) of %lld", (long long)row0[i], (long long)row1[i], (long long)dst->acc_T);
             if (row0[i] == row1[i]) continue;
-            enable_peer(dst->device, srcs[i]->device);
             hipStream_t s = dst->bstream[i];
             HIPCHECK(hipStreamWaitEvent(s, dst->fork_ev, 0));
             const long long off = (long long)row0[i] * dst->acc_G;

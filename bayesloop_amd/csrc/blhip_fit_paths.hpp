@@ -23,11 +23,12 @@ struct BatchEnv {
 inline double pred_rtol(int64_t T) { return 1e-12 + 2e-15 * (double)T; }
 
 // Bound of every in-kernel wait of a resident launch.  A block that is not co-resident never arrives, so the bound IS the cost of the
-// failure a user on a shared GPU meets first: it scales with the pass (20 x the predicted pass time at ~15 us per step, at least 50 ms
-// -- a pre-empted block comes back within milliseconds) instead of a flat 2 s.  Option resident_timeout_s > 0 overrides.
+// failure a user on a shared GPU meets first: it scales with the pass (20 x the predicted pass time at ~15 us per step, at least 250 ms)
+// instead of a flat 2 s.  (50 ms was tried: four test processes sharing ONE GPU -- pytest -n 4 -- starve each other's blocks for longer than
+// that and the paths gave up spuriously.)  Option resident_timeout_s > 0 overrides.
 inline double resident_timeout_s(blhip_ctx *ctx, int64_t T) {
     const double opt = ctx->option("resident_timeout_s", 0.0);
-    return opt > 0.0 ? opt : std::max(0.05, 20.0 * 15e-6 * (double)T);
+    return opt > 0.0 ? opt : std::max(0.25, 20.0 * 15e-6 * (double)T);
 }
 
 // did a block of a resident launch time out waiting for a peer (not every block co-resident)?  -> the context stops using the paths
@@ -77,7 +78,6 @@ struct ResidentRun {
             plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
                           (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0, (int)ctx->option("resident_min_tile", 32.0))) {
             on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
-            rp.onex = rp.TR == 64 && rp.TC == 64 && ctx->option("resident_onex", 1.0) != 0.0;
             // (the padded 128 x 128 BACKWARD kernel spills 231 registers: 2000 x 1100, backward step 40 - 45 us against 26.8 us with one
             //  launch per step -- full fits of such grids keep the launch-per-step kernels, evidence-only / forward-only fits do not)
             if (rp.pad && rp.TR == 128 && full) on = false;
@@ -348,12 +348,12 @@ struct ChainRun {
         }
         if (fused) {
             ctx->accpart.ensure((size_t)slots_used * T * Gk * 8);
-            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(4096));
+            ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(8192));
             char *wc = ctx->accw.as<char>();
             d_fold_sfwd = carve<double>(wc, (size_t)T * B);
             d_fold_w = carve<double>(wc, (size_t)B);
             d_fold_inf = carve<double>(wc, (size_t)B);
-            d_zeros = carve<double>(wc, 512);
+            d_zeros = carve<double>(wc, 1024);      // (8 KB: a tile's four cells are read at base + 0 / 512 / 1024 / 1536 bytes, base < 4 KB)
         }
     }
 
@@ -474,7 +474,7 @@ struct ChainRun {
         const int first_n = fold2 ? (round_start_b[1] - round_start_b[0] + 1) / 2 : cp.round_start[1] - cp.round_start[0];
         if (first_n < slots_used)
             HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * Gk, 0, (size_t)(slots_used - first_n) * T * Gk * 8, E.st));
-        HIPCHECK(hipMemsetAsync(d_zeros, 0, 4096, E.st));
+        HIPCHECK(hipMemsetAsync(d_zeros, 0, 8192, E.st));
     }
 
     // after the backward pass: every strip made it and the lagged scale of the backward state stayed in range

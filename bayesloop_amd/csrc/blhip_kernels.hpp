@@ -213,8 +213,12 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     const bool dense = cm == 4;                    // BivariateRandomWalk: tap0 is a dense (2 lw0 + 1) x (2 lw1 + 1) kernel
     // asymmetric tap sets (tap_lw2 == -1: full 2 lw + 1 weights, Deterministic spline shift) and the boundary rule per axis
     const bool asym0 = cm == 6 && P.tap0[b] >= 0 && P.tap_lw2[P.tap0[b]] < 0;
-    const bool asym1 = cm == 6 && P.tap1[b] >= 0 && P.tap_lw2[P.tap1[b]] < 0;
-    const int rule0 = (cm == 4 || cm == 5) ? 1 : (asym0 ? 2 : 0), rule1 = (cm == 4 || cm == 5) ? 1 : (asym1 ? 2 : 0);
+    const bool asym1 = cm == 6 && P.tap1[b] >= 0 && P.tap_lw2[P.tap1[b]] == -1;
+    // tap_lw2 == -2: the two-stage form of the spline shift for |d| > 12 cells (1-D grids, the whole row in this block; blhip.hip:
+    // TapTable::get_bigshift): prefilter the 12-sample-padded row, then evaluate the B-spline at the shifted coordinates with the
+    // coefficient index clamped (scipy.ndimage.shift, mode='nearest'; oracle/bl_oracle.py: spline_shift_nearest)
+    const bool big1 = cm == 6 && P.tap1[b] >= 0 && P.tap_lw2[P.tap1[b]] == -2;
+    const int rule0 = (cm == 4 || cm == 5) ? 1 : (asym0 ? 2 : 0), rule1 = (cm == 4 || cm == 5) ? 1 : ((asym1 || big1) ? 2 : 0);
     const int t0 = P.tap0[b], t1 = dense ? -1 : P.tap1[b];
     const int lw0 = t0 >= 0 ? P.tap_lw[t0] : 0;
     const int lw1 = dense ? P.tap_lw2[t0] : (t1 >= 0 ? P.tap_lw[t1] : 0);
@@ -287,6 +291,19 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
         __syncthreads();
     }
 
+    if (big1) {
+        // spline coefficients of the padded row: position q = 0 .. n + 23 of the padded array = grid coordinate q - 12
+        const double *gw = w1 + 1;
+        const int N = P.n1 + 24;
+        for (int q = threadIdx.x; q < N; q += NTHREADS) {
+            const double *cen = in_tile + (size_t)P.LW0 * pitch + P.LW1 + (q - 12);
+            double acc = gw[0] * cen[0];
+            for (int m = 34; m >= 1; --m) acc = fma(gw[m], cen[-m] + cen[m], acc);
+            v_tile[q] = acc;
+        }
+        __syncthreads();
+    }
+
     // ---- phase 3: filter along axis 1 (cols) + epilogue ---------------------------------------------------------
     double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0, sU = 0.0, sMax = 0.0;
     for (int c = x; c < tw; c += XW) {
@@ -307,6 +324,18 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
                     const double *line = cen + (long long)a * pitch;
                     const double *wl = w0 + (a + lw0) * kw + lw1;
                     for (int q = -lw1; q <= lw1; ++q) o = fma(wl[q], line[q], o);
+                }
+            } else if (big1) {
+                const int N = P.n1 + 24;
+                const double pp = (double)(j0 + c) - w1[0] + 12.0;           // sampled coordinate in the padded array
+                const double fl = floor(pp);
+                const int k0 = (int)fmax(fmin(fl, 1.0e9), -1.0e9);
+                o = 0.0;
+                for (int dk = -1; dk <= 2; ++dk) {
+                    const double a = fabs(pp - (fl + (double)dk));
+                    const double b3 = a < 1.0 ? 2.0 / 3.0 - a * a + a * a * a * 0.5 : (a < 2.0 ? (2.0 - a) * (2.0 - a) * (2.0 - a) / 6.0 : 0.0);
+                    const long long kk = (long long)k0 + dk;
+                    o = fma(b3, v_tile[kk < 0 ? 0 : (kk > N - 1 ? N - 1 : (int)kk)], o);
                 }
             } else if (asym1) {
                 o = 0.0;

@@ -329,16 +329,8 @@ BLR_INL int launder(int x) {
     return x;
 }
 
-template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, bool EVID_ = false, bool PAD_ = false, bool ONEX_ = false>
+template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, bool EVID_ = false, bool PAD_ = false>
 struct Res {
-    // ONEX: ONE hand-off per step (one-chunk 64-column tiles).  The classic scheme hands over twice per step -- raw edge columns for the
-    // axis-1 pass, then axis-1-FILTERED edge rows for the axis-0 pass -- and every hand-off is a memory round trip (~1 - 1.5 us) that a
-    // one-chunk tile has nothing to hide under.  Here a tile publishes the RAW edge rows and columns of its new state once, after the
-    // step; the consumer filters its neighbours' 2 R halo rows itself (two waves, beside the tile's own axis-1 pass; the corners of
-    // the halo rows come from the diagonal neighbours' row strips).  The two passes ping-pong between two LDS buffers (A: the state,
-    // TR rows; B: its axis-1-filtered image, TR + 2 R rows), so nothing is read before a barrier to protect it from an in-place
-    // write: 2 barriers + 1 hand-off per step instead of 5 + 2.
-    static constexpr bool ONEX = ONEX_;
     static constexpr int TR = TR_, TC = TC_, SEG = SEG_, CHK = CHK_;    // CHK: outputs per chunk of a pass
     static constexpr bool BWD = BWD_;
     // PAD: the grid does not fill its last tile row / column (n0 < tr * TR or n1 < tc * TC; at least R cells of padding where there is
@@ -369,8 +361,6 @@ struct Res {
     static constexpr int NW = NT / 64;
     static constexpr bool ONE = SEG == CHK;          // one-chunk segments
     static_assert(NT % 64 == 0, "whole waves");
-    static_assert(!ONEX || (ONE && TC == 64 && NW == 8 && SEG == R), "single hand-off: one-chunk tiles of 64 columns, 8 waves");
-    static constexpr int HALO_WAVE0 = 2;             // (ONEX) waves HALO_WAVE0 + side filter the halo rows of that side
     static constexpr bool FULLW = NT > 512;          // many-threads shapes: whole window in registers before the barrier (walk_full)
     // a neighbour's strip is requested when the pass begins, 2+ chunks before it is used (32 registers per thread in flight; the
     // multi-chunk backward shape has none to spare and requests it where it needs it)
@@ -382,21 +372,14 @@ struct Res {
     // The lagged global sum is gathered by HALF of the block's waves -- the half that reaches the barrier after the axis-1 pass early
     // (multi-chunk shapes: the edge segments, dealt to the first waves, have issue priority over their SIMD partners; one-chunk
     // shapes: the edge waves wait for their neighbours there, the others are early) -- in that slack, not by everybody after it.
-    // (ONEX: waves 0 / 1 own the edge segments of the axis-1 pass, waves 2 / 3 filter the halo rows, wave 5 keeps the books, the last
-    //  two gather)
-    static constexpr int GW = ONEX ? 2 : (NW >= 2 ? NW / 2 : 1);
+    static constexpr int GW = NW >= 2 ? NW / 2 : 1;
     static constexpr bool GATHER_FIRST = !ONE;
     static constexpr int MAX_TILES = 256;                // (one tile per CU)
     static constexpr int GPL = (MAX_TILES / GW + 63) / 64;   // tiles per lane when GW waves share the tiles' partial sums
     static constexpr int NG = 1;                         // sums every tile publishes per step: the scale sum (forward: sum a = the row sum
                                                          // of the stored state; backward: sum c)
     static constexpr int LDS_TILE = TR * P;          // doubles
-    // (ONEX) B: the axis-1-filtered image, rows -R .. TR + R - 1 of the tile (row r of the tile = row r + R of B), and the staging
-    // area of the neighbours' raw halo rows: [side][rr][R corner | TC | R corner] values, pitch SP
-    static constexpr int LDS_B = LDS_TILE;
-    static constexpr int SP = TC + 2 * R + 1;
-    static constexpr int LDS_STAGE = LDS_B + (ONEX ? (TR + 2 * R) * P : 0);
-    static constexpr int LDS_M0 = LDS_STAGE + (ONEX ? 2 * R * SP : 0);          // TR row coordinates of the tile
+    static constexpr int LDS_M0 = LDS_TILE;          // TR row coordinates of the tile
     static constexpr int LDS_COL = LDS_M0 + TR;      // the tile's column constants: [TC] grid value, [TC] cA, [TC] cB
     static constexpr int LDS_MISC = LDS_COL + 3 * TC;    // [1] dead flag  [2] arrival counter of the gathering waves  [7] 1 / lagged sum  [8 .. 8+GW) their shares
     static_assert(NG == 1, "one lagged sum");
@@ -622,130 +605,6 @@ struct Res {
             if (hg.seg == 0) h_walk_d<-1>(Q, k, hg); else h_walk_d<1>(Q, k, hg);
         }
 
-        // ---- ONEX: the axis-1 pass reads the state (buffer A) and writes its filtered image (buffer B, tile row r = B row r + R); nothing
-        //      is overwritten in place, so the segment's near / far halos are read right here, not before a barrier -------------------------
-        template <int DIR>
-        BLR_INL void h1_walk_d(const ResParams &Q, int k, const Geo &hg) {
-            const double *x0 = lds + hg.line * P + first_pos(hg.seg, DIR);
-            double *y0 = lds + LDS_B + (R + hg.line) * P + first_pos(hg.seg, DIR);
-#pragma unroll
-            for (int q = 0; q < R; ++q) nearv[q] = x0[DIR * (q - R)];
-            if (hg.far == 0) {
-#pragma unroll
-                for (int q = 0; q < R; ++q) farv[q] = x0[DIR * (SEG + q)];
-            } else if (hg.far == 1) {
-#pragma unroll
-                for (int q = 0; q < R; ++q) farv[q] = x0[DIR * (SEG - 1 - q)];
-            }
-            const Rsrc rs = strip_rsrc(Q.cols, Q.cols_bytes);
-            const int e0 = (((((k - 1) & 1) * Q.ntiles + hg.nb) * 2 + hg.side) * R + (hg.side == 1 ? R - 1 : 0)) * TR + hg.line;
-            const int dstep = (hg.side == 1 ? -TR : TR) * 8;
-            Tq fq[R];
-            auto far_issue = [&]() { if (hg.far == 2) strip_issue(rs, e0 * 8, dstep, fq); };
-            auto far_fetch = [&](double (&f)[R]) {
-                if (hg.far == 2 && !strip_finish(Q, rs, e0 * 8, dstep, tag_bit((unsigned)k, false), fq, f)) dead = true;
-            };
-            auto emit8 = [&](int p0, const double (&v)[CHK]) {
-#pragma unroll
-                for (int j = 0; j < CHK; ++j) y0[DIR * (p0 + j)] = v[j];
-            };
-            double wk[R + 1];
-#pragma unroll
-            for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w1, q);
-            walk<SEG, DIR, CHK>(x0, nearv, farv, hg.far == 2, wk, far_issue, far_fetch, [](int) {}, emit8);
-        }
-        BLR_INL void h1_walk(const ResParams &Q, int k) {
-            const Geo hg = hgeo();
-            if (hg.seg == 0) h1_walk_d<-1>(Q, k, hg); else h1_walk_d<1>(Q, k, hg);
-        }
-        // ---- ONEX: the 2 R halo rows of B = the axis-1 filter of the vertical neighbours' RAW edge rows of the previous step (their row
-        //      strips; the R columns beyond either end come from the diagonal neighbours' row strips, or are the mirror image at the
-        //      grid's edge).  One wave per side: lane = column requests the R rows (512 contiguous bytes per load), lane = (row, corner
-        //      column) the two corners -- 10 tagged elements per lane, requested when the step begins (halo_issue), completed after the
-        //      wave's own segment (halo_stage: into the staging area), then lane = (row, segment) filters 8 outputs (halo_filter).
-        //      side 0: the rows above the tile (neighbour tile - tc, ITS side 1), side 1: the rows below.
-        BLR_INL int halo_side() const { const int wv = uni(tid >> 6) - HALO_WAVE0; return (wv == 0 || wv == 1) ? wv : -1; }
-        BLR_INL bool halo_exists(int side) const { return side == 0 ? ti > 0 : ti < tr - 1; }
-        // byte offset of element (row rr, column col) of tile nb's row strip `nside`, published after step k - 1
-        BLR_INL static unsigned row_elem(const ResParams &Q, int k, int nb, int nside, int rr, int col) {
-            return (unsigned)((((((k - 1) & 1) * Q.ntiles + nb) * 2 + nside) * R + rr) * TC + col) * 8u;
-        }
-        BLR_INL void halo_offsets(const ResParams &Q, int k, int side, unsigned (&off)[R + 2]) const {
-            const int lane = tid & 63, nb = side == 0 ? tile - tc : tile + tc, nside = 1 - side;
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) off[rr] = row_elem(Q, k, nb, nside, rr, lane);
-            const int rc = lane >> 3, c = lane & 7;       // corners: lane = (row rc, corner column c)
-            off[R] = tj > 0 ? row_elem(Q, k, nb - 1, nside, rc, TC - R + c) : row_elem(Q, k, nb, nside, rc, R - 1 - c);
-            off[R + 1] = tj < tc - 1 ? row_elem(Q, k, nb + 1, nside, rc, c) : row_elem(Q, k, nb, nside, rc, TC - 1 - c);
-        }
-        BLR_INL void halo_issue(const ResParams &Q, int k, Tq (&hq)[R + 2]) {
-            const int side = halo_side();
-            if (side < 0 || !halo_exists(side)) return;
-            const Rsrc rs = strip_rsrc(Q.rows, Q.rows_bytes);
-            unsigned off[R + 2];
-            halo_offsets(Q, k, side, off);
-#pragma unroll
-            for (int q = 0; q < R + 2; ++q) hq[q] = ld_tq(rs, off[q]);
-        }
-        BLR_INL void halo_stage(const ResParams &Q, int k, Tq (&hq)[R + 2]) {
-            const int side = halo_side();
-            if (side < 0 || !halo_exists(side)) return;
-            const unsigned bit = tag_bit((unsigned)k, false);
-            auto all_there = [&]() {
-                bool ok = true;
-#pragma unroll
-                for (int q = 0; q < R + 2; ++q) ok = ok && tq_ok(hq[q], bit);
-                return ok;
-            };
-#ifdef BLR_EMULATE
-            assert(all_there() && "hand-off protocol: halo rows consumed before published");
-#else
-            if (!all_there()) {
-                const Rsrc rs = strip_rsrc(Q.rows, Q.rows_bytes);
-                unsigned off[R + 2];
-                halo_offsets(Q, k, side, off);
-                const unsigned long long t0 = now_ticks();
-                for (unsigned spins = 1;; ++spins) {
-                    nap();
-#pragma unroll
-                    for (int q = 0; q < R + 2; ++q) hq[q] = ld_tq(rs, off[q]);
-                    if (all_there()) break;
-                    if ((spins & 255u) == 0u) {
-                        if (ld_flag(Q.abort_word) != 0u) { dead = true; break; }
-                        if (now_ticks() - t0 > Q.timeout_ticks) { st_flag(Q.abort_word, 1u); dead = true; break; }
-                    }
-                }
-            }
-#endif
-            const int lane = tid & 63;
-            double *st = lds + LDS_STAGE + side * R * SP;
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) st[rr * SP + R + lane] = tq_value(hq[rr]);
-            st[(lane >> 3) * SP + (lane & 7)] = tq_value(hq[R]);
-            st[(lane >> 3) * SP + R + TC + (lane & 7)] = tq_value(hq[R + 1]);
-        }
-        BLR_INL void halo_filter(const ResParams &Q) {
-            const int side = halo_side();
-            if (side < 0 || !halo_exists(side)) return;
-            const int lane = tid & 63, rr = lane >> 3, sg = lane & 7;
-            const double *st = lds + LDS_STAGE + (side * R + rr) * SP + SEG * sg;      // column SEG sg - R of the row
-            double w[2 * R + SEG], v[SEG], wk[R + 1];
-#pragma unroll
-            for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w1, q);
-#pragma unroll
-            for (int q = 0; q < 2 * R + SEG; ++q) w[q] = st[q];
-#pragma unroll
-            for (int j = 0; j < SEG; ++j) v[j] = w[R + j] * wk[0];
-#pragma unroll
-            for (int q = R; q >= 1; --q) {
-#pragma unroll
-                for (int j = 0; j < SEG; ++j) v[j] = fma(w[R + j - q] + w[R + j + q], wk[q], v[j]);
-            }
-            double *y = lds + LDS_B + (side == 0 ? rr : TR + R + rr) * P + SEG * sg;
-#pragma unroll
-            for (int j = 0; j < SEG; ++j) y[j] = v[j];
-        }
-
         // after the axis-1 pass (barrier): the tile's filtered edge rows -> strips of step k  [side][rr][col]; every thread takes
         // part, a wave stores 512 contiguous bytes per instruction (scattered 8-byte write-through stores out of the walks'
         // registers were measured: 2 - 3 x slower walks)
@@ -773,11 +632,6 @@ struct Res {
         }
         BLR_INL void publish_rows(const ResParams &Q, int k) {          // [side][rr][col]
             publish_strip<TC>(strip_rsrc(Q.rows, Q.rows_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TC, tag_bit((unsigned)(k + 1), true), ti > 0, ti < tr - 1,
-                              [&](int side, unsigned rr, unsigned col) { return lds[((side ? TR - R : 0) + rr) * P + col]; });
-        }
-        // ONEX: the RAW edge rows of the new state, published together with the edge columns after the step (same tags as the columns)
-        BLR_INL void publish_rows_raw(const ResParams &Q, int k) {
-            publish_strip<TC>(strip_rsrc(Q.rows, Q.rows_bytes), ((k & 1) * Q.ntiles + tile) * 2 * R * TC, tag_bit((unsigned)(k + 1), false), ti > 0, ti < tr - 1,
                               [&](int side, unsigned rr, unsigned col) { return lds[((side ? TR - R : 0) + rr) * P + col]; });
         }
         // after the axis-0 pass + epilogue (barrier): the new state's edge columns -> strips of step k  [side][cc][row]
@@ -913,19 +767,9 @@ struct Res {
             const int e0 = ((((k & 1) * Q.ntiles + vg.nb) * 2 + vg.side) * R + (vg.side == 1 ? R - 1 : 0)) * TC + vg.line;
             const int dstep = (vg.side == 1 ? -TC : TC) * 8;
             Tq fq[R];
-            // ONEX: the pass reads buffer B (the axis-1-filtered image incl. the halo rows this tile filtered itself) and the epilogue
-            // writes the new state to buffer A: no strips, no pre-read
-            const double *xs = ONEX ? lds + LDS_B + (R + r0) * P + c : x0;
-            if (ONEX) {
-#pragma unroll
-                for (int q = 0; q < R; ++q) nearv[q] = xs[DIR * (q - R) * P];
-#pragma unroll
-                for (int q = 0; q < R; ++q) farv[q] = xs[DIR * (vg.far == 1 ? SEG - 1 - q : SEG + q) * P];
-            }
-            const bool strip_far = !ONEX && vg.far == 2;
-            auto far_issue = [&]() { if (EARLY && strip_far) strip_issue(rs, e0 * 8, dstep, fq); };
+            auto far_issue = [&]() { if (EARLY && vg.far == 2) strip_issue(rs, e0 * 8, dstep, fq); };
             auto far_fetch = [&](double (&f)[R]) {
-                if (strip_far) {
+                if (vg.far == 2) {
                     if (!EARLY) strip_issue(rs, e0 * 8, dstep, fq);
                     if (!strip_finish(Q, rs, e0 * 8, dstep, tag_bit((unsigned)(k + 1), true), fq, f)) dead = true;
                 }
@@ -946,8 +790,8 @@ struct Res {
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
-            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, strip_far, wk, far_issue, far_fetch, pre8, emit8);
-            else walk<SEG, DIR * P, CHK>(xs, nearv, farv, strip_far, wk, far_issue, far_fetch, pre8, emit8);
+            if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
+            else walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
             if (REC_AHEAD && !REC_IN_PASS && k + 1 < Q.T) begin_step(Q, k + 1);
         }
         BLR_INL void v_walk(const ResParams &Q, int k) {
@@ -1034,9 +878,9 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID = false, bool PAD = false, bool ONEX = false>
+template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID = false, bool PAD = false>
 __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Q) {
-    using K = Res<TR, TC, SEG, CHK, BWD, EVID, PAD, ONEX>;
+    using K = Res<TR, TC, SEG, CHK, BWD, EVID, PAD>;
     constexpr int NT = K::NT, NW = K::NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *misc = lds + K::LDS_MISC;
@@ -1070,7 +914,7 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
     // It runs half a step LATER, in a wave that is early at the barrier after the axis-1 pass (multi-chunk shapes: wave 0, an edge
     // segment with issue priority over its SIMD partner; one-chunk shapes: an interior segment that neither waits for a neighbour nor
     // gathers the lagged sum).
-    constexpr int BOOK_WAVE = ONEX ? 5 : (K::ONE ? (NW >= 2 ? NW / 2 - 1 : 0) : 0);
+    constexpr int BOOK_WAVE = K::ONE ? (NW >= 2 ? NW / 2 - 1 : 0) : 0;
     const bool booker = (tid >> 6) == BOOK_WAVE;
     auto book = [&](int kb) {                         // (the whole wave: lane w fetches wave w's sums, one tree adds them)
         constexpr int NV = BWD ? 5 : 3;
@@ -1101,40 +945,6 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
         if (k == 0) {
             th.begin_step(Q, k);
             th.first_step(Q);
-        } else if constexpr (ONEX) {
-            // ONE hand-off per step: A (state) -> axis-1 pass -> B (+ the halo rows, filtered here from the neighbours' raw rows) ->
-            // barrier -> axis-0 pass + epilogue -> A -> barrier -> publish the raw edges of A
-            Tq hq[R + 2];
-            if (k >= Q.lag && gw >= 0) th.gather_issue(Q, k - Q.lag);
-            th.halo_issue(Q, k, hq);
-            BLR_STAMP(1);
-            th.h1_walk(Q, k);
-            BLR_STAMP(2);
-            th.halo_stage(Q, k, hq);
-            BLR_STAMP(3);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");     // (the staging area is written and read by the same wave)
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-            th.halo_filter(Q);
-            BLR_STAMP(4);
-            if (booker) book(k - 1);
-            BLR_STAMP(5);
-            if (k >= Q.lag && gw >= 0) {
-                double part[K::NG];
-                th.gather_finish(Q, k - Q.lag, part);
-                const double ws = blk::wave_sum(part[0]);
-                if ((tid & 63) == 0) {
-                    misc[8 + gw] = ws;
-                    unsigned *cnt = reinterpret_cast<unsigned *>(misc + 2);
-                    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (old == (unsigned)K::GW - 1u) { *cnt = 0u; th.combine_shares(); }
-                }
-            }
-            BLR_STAMP(6);
-            lds_barrier();
-            BLR_STAMP(10);
-            th.v_walk(Q, k);
-            BLR_STAMP(11);
         } else {
             th.h_preread();
             BLR_STAMP(1);
@@ -1191,7 +1001,6 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
                 lds_barrier();
             }
             th.publish_cols(Q, k);
-            if constexpr (ONEX) th.publish_rows_raw(Q, k);
             BLR_STAMP(14);
         }
         if (misc[1] != 0.0) return;                   // a wait timed out somewhere in this block: uniform exit (host falls back)

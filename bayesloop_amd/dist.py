@@ -502,5 +502,10 @@ def local_sharded_hyper_fit(engines, problem, op_values, prior_values, forward_o
         first = [e for r, e in sorted(errors, key=lambda x: x[0]) if not isinstance(e, _t.BrokenBarrierError)]
         raise (first[0] if first else errors[0][1])
     out = results[0]
-    out['per_rank_timing'] = [res['timing'] if res else {} for res in results]
+    out['per_rank_timing'] = [dict(res['timing']) if res else {} for res in results]
+    for r, tm in enumerate(out['per_rank_timing']):      # how each device fetched the others' accumulator slices (set by the merge, after its fit)
+        try:
+            tm['peer_copy_path'] = engines[r].last_timing().get('peer_copy_path', 0)
+        except Exception:                 # noqa: BLE001
+            pass
     return out

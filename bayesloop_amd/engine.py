@@ -197,6 +197,11 @@ class HipEngine:
         self._posterior_owner = None
         self._keep = []
         self._pinned = _PinnedPool(self.lib)
+        # engine options from the environment, e.g. BLHIP_ENGINE_OPTS=resident_timeout_s=2 for processes that SHARE a GPU (the
+        # resident kernels wait for peer blocks that another process's kernels may keep off the chip for a while)
+        for kv in os.environ.get('BLHIP_ENGINE_OPTS', '').split(','):
+            if '=' in kv:
+                self.set_option(kv.split('=')[0].strip(), float(kv.split('=')[1]))
 
     def __del__(self):
         try:

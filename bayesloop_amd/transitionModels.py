@@ -341,16 +341,27 @@ class Deterministic(TransitionModel):
         d = float(self.function(t - 1 - self.tOffset, **params)) - float(self.function(t - self.tOffset, **params))
         return _device_transition(self, posterior, t - 1, shift=d)
 
-    def shifts(self, params, timestamps, resume_time=-1.0):
+    def shifts(self, params, timestamps, resume_time=-1.0, t_offset=None):
         """The 2 T values behind the DETERMINISTIC op (include/blhip.h): forward shift INTO step i, f(t'+1) - f(t') at the
         time stamp t' of step i-1 (entry 0: at ``resume_time``, used by OnlineStudy), then backward shift into step i,
-        f(t'-1) - f(t') at the time stamp t' of step i+1 (reference transitionModels.py:573-577, :592-596)."""
+        f(t'-1) - f(t') at the time stamp t' of step i+1 (reference transitionModels.py:573-577, :592-596).  ``t_offset``: the time
+        the model counts from (inside a SerialTransitionModel: the break-point that starts its segment, :770-776)."""
         ts = np.asarray(timestamps, dtype=float)
         T = len(ts)
-        f = lambda t: float(self.function(t - self.tOffset, **params))
-        fwd = [f(resume_time + 1) - f(resume_time)] + [f(ts[i - 1] + 1) - f(ts[i - 1]) for i in range(1, T)]
-        bwd = [f(ts[i + 1] - 1) - f(ts[i + 1]) for i in range(T - 1)] + [0.0]
-        return np.array(fwd + bwd, dtype=float)
+        off = self.tOffset if t_offset is None else t_offset
+        # the 2 T + 2 time stamps the function is needed at, in one call where the user's function takes arrays (a hyper-study over
+        # break-points evaluates this per chain: tens of thousands of chains)
+        at = np.concatenate(([resume_time + 1, resume_time], ts[:-1] + 1, ts[:-1], ts[1:] - 1, ts[1:])) - off
+        try:
+            v = np.asarray(self.function(at, **params), dtype=float)
+            if v.shape != at.shape:
+                raise ValueError
+        except Exception:                        # noqa: BLE001 -- a function written for scalars only
+            v = np.array([float(self.function(a, **params)) for a in at])
+        n = T - 1
+        fwd = np.concatenate(([v[0] - v[1]], v[2:2 + n] - v[2 + n:2 + 2 * n]))
+        bwd = np.concatenate((v[2 + 2 * n:2 + 3 * n] - v[2 + 3 * n:2 + 4 * n], [0.0]))
+        return np.concatenate((fwd, bwd))
 
 
 class AlphaStableRandomWalk(TransitionModel):
@@ -505,9 +516,8 @@ class SerialTransitionModel(TransitionModel):
             for op in m._program(parameterNames):
                 if op[4] != -1 or op[0] == _abi.OP_BREAKPOINT or (op[0] == _abi.OP_CHANGEPOINT and op[5] & 1):
                     raise ConfigurationError('Nested SerialTransitionModel instances are not supported.')
-                if op[0] == _abi.OP_DETERMINISTIC:
-                    raise ConfigurationError('A Deterministic model inside a SerialTransitionModel (time offset at the '
-                                             'break-points, reference transitionModels.py:770-776) is not supported.')
+                # (a Deterministic sub-model counts its time from the break-point that starts its segment -- reference
+                #  transitionModels.py:770-776 sets tOffset -- which Study._opValueMatrix applies per chain when it evaluates the shifts)
                 program.append((op[0], op[1], op[2], op[3], seg, op[5]))
         for k in range(len(self.hyperParameterNames)):
             if self.changePointMask[k]:

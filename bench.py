@@ -2,7 +2,7 @@
 """
 bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c3|c2|c5|fwd2048] [--no-extra] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c3|c2|c5|fwd2048|coal_breakpoints] [--no-extra] [--no-cpu]
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
@@ -137,6 +137,26 @@ def make_study(bl, name, comm=None, scale=1.0):
         S.communicator = comm
         return S, dict(silent=True), n * n * T * nh, dict(workload='C5 ChangepointStudy 512x512 grid, T=1000, %d candidate '
                                                            'change-points (arange(3, 1000, 4)), full fit' % nh, grid=[n, n], T=T, n_hyper=nh, mode='full')
+    if name == 'coal_breakpoints':
+        # the reference's one published heavy workload (docs/source/tutorials/changepointstudy.ipynb, "Analyzing structural breaks":
+        # "~25000 individual model fits. It may take several minutes"): coal-mining disasters 1870-1910, a constant rate, a linear
+        # decrease with 30 candidate slopes between two break-points at ANY pair of years, a constant rate again -- 23 400 fits
+        n = 1000
+        S = bl.ChangepointStudy(silent=True)
+        S.loadExampleData(silent=True)
+        mask = (S.rawTimestamps >= 1870) * (S.rawTimestamps <= 1910)
+        S.rawTimestamps = S.rawTimestamps[mask]
+        S.rawData = S.rawData[mask]
+        S.set(bl.om.Poisson('accident_rate', bl.oint(0, 6, n)),
+              bl.tm.SerialTransitionModel(bl.tm.Static(), bl.tm.BreakPoint('t_1', 'all'),
+                                          bl.tm.Deterministic(lambda t, slope=np.linspace(-2.0, 0.0, 30): t * slope, target='accident_rate'),
+                                          bl.tm.BreakPoint('t_2', 'all'), bl.tm.Static()), silent=True)
+        S.communicator = comm
+        T, nh = len(S.rawData), 23400
+        return S, dict(silent=True), n * T * nh, dict(
+            workload='ChangepointStudy coal mining 1870-1910 (reference tutorial changepointstudy.ipynb): 1000-pt Poisson grid, T=41, '
+                     'Serial(Static, BreakPoint, Deterministic(30 slopes), BreakPoint, Static), 23400 fits, full fit',
+            grid=[n], T=T, n_hyper=nh, mode='full')
     if name == 'fwd2048':
         n, T = 2048, 200
         S = bl.Study(silent=True)
@@ -605,7 +625,7 @@ def main():
     if rank == 0:
         if not args.no_extra and world == 1:
             extra = {}
-            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024'):
+            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024', 'coal_breakpoints'):
                 if name == args.workload:
                     continue
                 try:
@@ -618,6 +638,26 @@ def main():
                                        resident_fallbacks=int(tm.get('resident_fallbacks', 0)))
                     if name == 'c3':
                         extra[name]['end_to_end'] = end_to_end(bl, S2, dict(silent=True), u2)
+                    if name == 'coal_breakpoints':
+                        # the reference's one published heavy workload ("may take several minutes"): beside the GPU's fit the wall
+                        # time of the REFERENCE ITSELF for the same study, recorded when the fixture was generated in the build
+                        # container (tests/golden/gen_bench_golden.py: 8 worker processes), and the study's published number
+                        gf = np.load(os.path.join(ROOT, 'tests', 'golden', 'bench_coal_breakpoints_full.npz'))
+                        extra[name]['reference'] = dict(seconds=float(gf['reference_seconds']), processes=int(gf['reference_jobs']),
+                                                        where='build container (not this box), reference imported from source',
+                                                        log10_evidence=float(gf['logEvidence']) / np.log(10),
+                                                        log10_evidence_published=-30.63948,
+                                                        published_in='docs/source/tutorials/changepointstudy.ipynb')
+                        extra[name]['speedup_vs_reference_wall'] = float(gf['reference_seconds']) / dt2
+                        # parity per chain (the average model's evidence includes a handful of chains the reference decides by
+                        # rounding noise: tests/tolerances.py COAL_NOISE_CHAINS)
+                        gl, rl = gf['logEvidenceList'], np.asarray(S2.logEvidenceList, dtype=float)
+                        both = np.isfinite(gl) & np.isfinite(rl)
+                        extra[name]['log_evidence_average_model_rel_err'] = extra[name]['log_evidence_rel_err']
+                        extra[name]['log_evidence_rel_err'] = float(np.max(np.abs(rl[both] - gl[both]) / np.abs(gl[both])))
+                        extra[name]['log_evidence_rel_err_is'] = 'max over the %d chains that run through on both sides' % int(both.sum())
+                        extra[name]['chains_stopped'] = dict(reference=int((~np.isfinite(gl)).sum()), here=int((~np.isfinite(rl)).sum()),
+                                                             note='registered exception COAL_NOISE_CHAINS')
                     S2._posterior_pending = None
                     eng.release_posterior()
                     del S2

@@ -178,8 +178,15 @@ typedef struct {
     int32_t resident_fallbacks;   /* batches of this call a resident launch gave up on (repeated launch-per-step) */
     int32_t resident_armed;       /* 1: the context will try the resident paths on its next eligible fit          */
     int32_t resident_fallback_reason;   /* (ABI v7) why the LAST such batch fell back: BLHIP_FALLBACK_*             */
-    int32_t reserved0;
+    int32_t peer_copy_path;       /* (ABI v7) how blhip_accum_peer_reduce / _gather fetched the other contexts' slices since the
+                                     last blhip_fit of THIS context: BLHIP_PEER_* (0: no peer merge)                   */
 } blhip_timing;
+
+/* blhip_timing.peer_copy_path */
+#define BLHIP_PEER_NONE         0
+#define BLHIP_PEER_SAME_DEVICE  1   /* both contexts on one GPU (test configuration): device-to-device copy                       */
+#define BLHIP_PEER_DIRECT       2   /* hipMemcpyPeerAsync over xGMI with peer access                                                */
+#define BLHIP_PEER_HOST_STAGED  3   /* no peer access / a failed peer copy / option peer_copy_mode = 1: through page-locked host memory */
 
 /* blhip_timing.resident_fallback_reason */
 #define BLHIP_FALLBACK_NONE       0

@@ -268,6 +268,15 @@ CASES = {
                                   tm=('Serial', [('GRW', 'sa', 0.1, 'mean', None), ('BreakPoint', 'b1', ('arange', 2, 14, 3), None),
                                                  ('Static',), ('BreakPoint', 'b2', ('arange', 3, 15, 3), None),
                                                  ('Combined', [('GRW', 'sb', 0.4, 'mean', None), ('GRW', 'sc', 0.1, 'std', None)])])),
+    # a Deterministic sub-model INSIDE a serial model counts its time from the break-point that starts its segment (reference
+    # transitionModels.py:770-776): the shape of the reference's published break-point study (docs tutorial changepointstudy.ipynb,
+    # bench.py: coal_breakpoints) in small, and a NON-linear function of time, for which the offset matters
+    'serial_deterministic_bp': dict(study='ChangepointStudy', data=('coal', 14), om=('Poisson', [('rate', _g('oint', 0, 6, 60))], 'default'),
+                                    tm=('Serial', [('Static',), ('BreakPoint', 't_1', 'all', None), ('Deterministic', 'slopes', 'rate'),
+                                                   ('BreakPoint', 't_2', 'all', None), ('Static',)]), tol=FFT_TOL),
+    'serial_deterministic_offset': dict(study='HyperStudy', data=('coal', 12), om=('Poisson', [('rate', _g('oint', 0, 6, 64))], 'default'),
+                                        tm=('Serial', [('GRW', 's', 0.2, 'rate', None), ('BreakPoint', 'tb', [3, 5, 8], None),
+                                                       ('Deterministic', 'quad_off', 'rate')]), tol=FFT_TOL),
     'cp_nonunit_time': dict(study='Study', data=D15, timestamps=np.array([0., 2., 4., 6., 8.]),
                             om=('Poisson', [('rate', _g('oint', 0, 6, 100))], 'default'),
                             tm=('ChangePoint', 't_change', 4., None)),   # forward fires at t=4, backward at t-1: never
@@ -286,7 +295,15 @@ def _drift(t, slope=0.15):
     return slope * t
 
 
-FUNCS = {'linear_kat': _linear_kat, 'quadratic': _quadratic, 'drift': _drift}
+def _slopes(t, slope=np.array([-0.3, -0.1, 0.0])):
+    return t * slope
+
+
+def _quad_off(t, a=np.array([0.004, 0.012])):
+    return -a * t ** 2
+
+
+FUNCS = {'linear_kat': _linear_kat, 'quadratic': _quadratic, 'drift': _drift, 'slopes': _slopes, 'quad_off': _quad_off}
 
 
 # ---- OnlineStudy (reference core.py:1963-2226, tests/test_onlinestudy.py) ----------------------
@@ -359,6 +376,8 @@ def make_data(spec):
         return x
     if kind == 'series_jump':
         return series(spec[1], spec[2], jump_at=spec[3], jump=spec[4])
+    if kind == 'coal':                       # the years 1870 .. of the coal-mining counts (the data of the reference's tutorials)
+        return COAL[18:18 + spec[1]]
     if kind == 'series2d':
         a = series(spec[1], spec[2])
         b = series(spec[1] + 1, spec[2])

@@ -89,7 +89,7 @@ def flatten_tm(spec, param_names):
                 bops.append(('changepoint', None, -1, 1)); bvals.append(cases.make_values(_Orc, s[2])); bpri.append(cases.make_prior(s[3]))
             else:
                 o, v, p = flatten_tm(s, param_names)
-                ops += [(x[0], x[1] if len(x) > 1 else None, seg, 0) for x in o]
+                ops += [(x[0], x[1] if len(x) > 1 else None, seg, 0) + tuple(x[4:]) for x in o]
                 vals += v
                 pri += p
                 seg += 1

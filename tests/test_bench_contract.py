@@ -33,6 +33,15 @@ def test_committed_bench_line_has_the_contract_fields():
         designed = r['hbm']['designed_bytes_per_cell_step'] * r['cells_per_launch']
         assert r['traffic'] is None or 0.9 * designed <= r['traffic'] <= 1.1 * designed
     assert r['frac_calibrated'] is None or r['frac_calibrated'] <= 1.0
+    # the three fractions keep their names and meanings from round to round (round 2's `frac` was the streaming-equivalent one, round
+    # 3's the real-HBM one: the series to compare across rounds is each NAMED field, `frac` is whichever bounds the kernel):
+    #   frac_hbm_real        = real HBM bytes (PMC, else by construction) / time / 8 TB/s
+    #   frac_fp64            = fp64 flop as executed / time / 78.6 TFLOP/s
+    #   frac_streaming_equiv = SURVEY 8(d) bytes (16 forward / 32 backward per cell-step) / time / 8 TB/s -- may exceed 1
+    assert abs(r['frac_hbm_real'] - r['hbm']['achieved_GBs'] / 8000.0) < 1e-12
+    assert abs(r['frac_fp64'] - r['fp64']['achieved_TFLOPs'] / 78.6) < 1e-12
+    assert abs(r['frac_streaming_equiv'] - r['algorithmic']['GBs_equiv'] / 8000.0) < 1e-12
+    assert r['frac'] == (r['frac_hbm_real'] if r['bound'] == 'hbm' else r['frac_fp64'])
     # the SURVEY 8(d) streaming-equivalent rate is there for comparison with earlier rounds, under a name of its own
     assert r['algorithmic']['bytes_per_cell_step'] in (16.0, 32.0) and r['algorithmic']['GBs_equiv'] > r['achieved'] * (r['bound'] == 'hbm')
     for p_, v in _walk(d):

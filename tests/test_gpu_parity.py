@@ -511,6 +511,36 @@ def test_njobs_in_process_two_contexts_on_one_gpu(monkeypatch):
         compare.check(res, oa.load_golden(case), compare.GPU_TOL)
 
 
+def test_njobs_merge_through_host_memory_when_there_is_no_peer_access(monkeypatch, capfd):
+    """Devices without peer access (hipDeviceCanAccessPeer == 0) -- or a peer copy that fails -- merge their accumulators through
+    page-locked host memory: an explicit copy, announced once on stderr, reported per device (peer_copy_path = BLHIP_PEER_HOST_STAGED).
+    Option peer_copy_mode = 1 forces that branch, so it runs on the one GPU of this box too."""
+    eng = bl.get_engine()
+    case = 'c4_small'
+    S1 = cases.build(bl, case)
+    S1.fit(**cases.fit_kwargs(case))
+    monkeypatch.setenv('BLHIP_NJOBS_DEVICES', '0,0,0')
+    monkeypatch.setenv('BLHIP_NJOBS_MULTI_GPU', 'strict')
+    base_opts = os.environ.get('BLHIP_ENGINE_OPTS', '')
+    monkeypatch.setenv('BLHIP_ENGINE_OPTS', 'peer_copy_mode=1,quiet=0' + (',' + base_opts if base_opts else ''))
+    eng.set_option('peer_copy_mode', 1)
+    try:
+        S2 = cases.build(bl, case)
+        S2.fit(nJobs=3, **cases.fit_kwargs(case))
+    finally:
+        eng.set_option('peer_copy_mode', 0)
+    assert [tm['peer_copy_path'] for tm in S2.lastTimingPerDevice] == [3, 3, 3], S2.lastTimingPerDevice
+    assert capfd.readouterr().err.count('goes through host memory') <= 1
+    np.testing.assert_allclose(S2.posteriorSequence, S1.posteriorSequence, rtol=1e-10, atol=1e-300)
+    res = dict(logEvidence=S2.logEvidence, localEvidence=S2.localEvidence, logEvidenceList=np.array(S2.logEvidenceList),
+               hyperParameterDistribution=S2.hyperParameterDistribution, posteriorSequence=S2.posteriorSequence, posteriorMeanValues=S2.posteriorMeanValues)
+    compare.check(res, oa.load_golden(case), compare.GPU_TOL)
+    monkeypatch.setenv('BLHIP_ENGINE_OPTS', base_opts)                     # (further contexts are created with the default again)
+    S3 = cases.build(bl, case)                     # ... and the same-device copies of the default path say so
+    S3.fit(nJobs=2, **cases.fit_kwargs(case))
+    assert all(tm['peer_copy_path'] == 1 for tm in S3.lastTimingPerDevice[:2]), S3.lastTimingPerDevice
+
+
 def test_njobs_on_two_physical_gpus_matches_unsharded(monkeypatch):
     """fit(nJobs = 2) over two DIFFERENT device ordinals (peer access, hipMemcpyPeerAsync between devices, kernels armed per device)
     against the unsharded fit and the reference's goldens; BLHIP_NJOBS_MULTI_GPU=strict so that nothing can fall back quietly.
@@ -783,9 +813,16 @@ def _ill_tol(S):
     only defined to a few digits in the reference itself (see cases.py: wide_filter_2d).  Steps with exact zeros only are NaN (0/0)
     on both sides and need no tolerance; every other entry keeps the 1e-9 bar.  -> case_tol dict, or None if no step qualifies."""
     with np.errstate(all='ignore'):
-        loose = np.array([bool(((L > 0) & (L < 2.2250738585072014e-308)).any())
-                          for L in (np.asarray(S.observationModel.processedPdf(S.grid, seg), dtype=float) for seg in S.formattedData)])
-    return dict(local_rtol=ILL_LOCAL_RTOL, local_loose_steps=loose) if loose.any() else None
+        liks = [np.asarray(S.observationModel.processedPdf(S.grid, seg), dtype=float) for seg in S.formattedData]
+        loose = np.array([bool(((L > 0) & (L < 2.2250738585072014e-308)).any()) for L in liks])
+    if not loose.any():
+        return None
+    out = dict(local_rtol=ILL_LOCAL_RTOL, local_loose_steps=loose)
+    if type(S).__name__ == 'Study':
+        # ... and what the loosened comparison leaves open is pinned at the bar: the SAME sum with the denormal-likelihood cells left
+        # out on both sides (compare.check: `local_lik`), from the stored posteriors and the likelihood of the step
+        out['local_lik'] = {int(t): liks[t] * np.ones(S.gridSize) for t in np.flatnonzero(loose)}
+    return out
 
 
 
@@ -941,7 +978,7 @@ RESIDENT = {
     # tiles 64 x 64 (128 tiles) and 128 x 128 (32 tiles)
     'res_1024x512_full': dict(study='Study', data=('series', 31, 5), om=_g2(1024, 512), tm=_grw2(0.03, 0.016)),
     'res_2048x256_full': dict(study='Study', data=('series', 32, 4), om=_g2(2048, 256), tm=_grw2(0.015, 0.03)),
-    # 64 x 64 tiles: 3 x 3 (an interior tile takes the corners of its halo rows from four diagonal neighbours), one tile row, one tile column
+    # 64 x 64 tiles: 3 x 3 (an interior tile with neighbours on every side), one tile row, one tile column
     'res_192_full': dict(study='Study', data=('series', 42, 7), om=_g2(192, 192), tm=_grw2(0.16, 0.04)),
     'res_64x256_full': dict(study='Study', data=('series', 43, 6), om=_g2(64, 256), tm=_grw2(0.4, 0.03)),
     'res_256x64_fwdonly': dict(study='Study', data=('series', 44, 6), om=_g2(256, 64), tm=_grw2(0.1, 0.12), fit=dict(forwardOnly=True)),
@@ -969,30 +1006,6 @@ def test_resident_kernel_matches_oracle(case):
     assert S.lastTiming['fwd_kernel_variant'] == 5, S.lastTiming          # the resident path really ran
     if not cases.fit_kwargs(c).get('evidenceOnly') and not cases.fit_kwargs(c).get('forwardOnly'):
         assert S.lastTiming['bwd_kernel_variant'] == 5, S.lastTiming
-    with np.errstate(all='ignore'):
-        want = oa.run(c)
-    got = result_of(S, c)
-    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
-    for k in ('posteriorSequence', 'posteriorMeanValues'):
-        if k in want and want[k] is not None and len(np.atleast_1d(want[k])):
-            gold[k] = np.asarray(want[k])
-    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
-
-
-@pytest.mark.parametrize('case', ['res_64x96_full', 'res_96x64_nan', 'res_128_fwdonly', 'res_256x128_evid', 'res_1024x512_full', 'res_pad_1000x520_full',
-                                  'res_pad_300x500_fwdonly', 'res_pad_1000_evid'])
-def test_resident_kernel_two_hand_offs_per_step_matches_oracle(case):
-    """64 x 64 tiles hand over ONCE per step by default (raw edge rows + columns, halo rows filtered by the consumer: blhip_resident.hpp
-    ONEX); the classic scheme (raw columns, then filtered rows) stays selectable (`resident_onex = 0`) and must give the same answers."""
-    eng = bl.get_engine()
-    c = RESIDENT[case]
-    eng.set_option('resident_onex', 0)
-    try:
-        S = cases.build(bl, c)
-        S.fit(**cases.fit_kwargs(c))
-    finally:
-        eng.set_option('resident_onex', 1)
-    assert S.lastTiming['fwd_kernel_variant'] == 5 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
     with np.errstate(all='ignore'):
         want = oa.run(c)
     got = result_of(S, c)
@@ -1034,7 +1047,8 @@ def test_resident_kernel_degenerate_fit_does_not_stall():
         S.fit(silent=True)
         want = oa.run(c)
     assert time.time() - t0 < 1.5                                   # (no in-kernel wait ran into its bound)
-    assert S.lastTiming['resident_fallbacks'] == 1 and S.lastTiming['resident_fallback_reason'] == 2, S.lastTiming      # BLHIP_FALLBACK_RANGE
+    # (a zero normaliser is the reference's ABORT, core.py:390-400, not a fall-back; if the pass was repeated, it says why)
+    assert S.lastTiming['resident_fallbacks'] == 0 or S.lastTiming['resident_fallback_reason'] == 2, S.lastTiming       # BLHIP_FALLBACK_RANGE
     assert S.logEvidence == want['logEvidence'] == -np.inf
 
 
@@ -1092,6 +1106,58 @@ def test_resident_kernel_full_chip():
         for S_ in (A, B):
             S_._posterior_pending = None
         eng.release_posterior()
+
+
+def test_the_references_published_break_point_study_at_full_size():
+    """The one heavy workload the reference publishes (docs/source/tutorials/changepointstudy.ipynb, "Analyzing structural breaks":
+    coal-mining disasters 1870-1910, Serial(Static, BreakPoint, Deterministic(30 slopes), BreakPoint, Static) on a 1000-point Poisson
+    grid: 23 400 fits with shifts of up to 334 grid cells per step) against the reference's own run of it: every chain's evidence, the
+    evidence of the average model, the hyper-parameter distribution over all 48 000 combinations, the distribution of the duration
+    t_2 - t_1 the tutorial reads off, the average posterior sequence and its means.  Registered exception COAL_NOISE_CHAINS
+    (tests/tolerances.py): a handful of chains whose backward message is shifted off the grid are decided by rounding noise in the
+    reference (it renormalises a sum of 1e-75); they may differ in whether they stop, nothing else may."""
+    import bench
+    from scipy.special import logsumexp
+    from tolerances import COAL_NOISE_TOL
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_coal_breakpoints_full.npz'))
+    S, kw, units, desc = bench.make_study(bl, 'coal_breakpoints')
+    with np.errstate(all='ignore'):
+        S.fit(silent=True)
+    gl, rl = gold['logEvidenceList'], np.asarray(S.logEvidenceList, dtype=float)
+    assert len(rl) == 23400
+    both = np.isfinite(gl) & np.isfinite(rl)
+    np.testing.assert_allclose(rl[both], gl[both], rtol=1e-9)                       # every chain that runs through on both sides
+    assert not np.any(np.isfinite(gl) & ~np.isfinite(rl))                           # nothing stops here that runs through in the reference
+    noise = np.isfinite(rl) & ~np.isfinite(gl)
+    assert noise.sum() <= COAL_NOISE_TOL['noise_chains'] and (~np.isfinite(gl)).sum() == 14
+    # evidence of the average model / hyper-parameter distribution (core.py:1391-1405) from the chains with the reference's stop pattern
+    prior = np.asarray(S.flatHyperPriorValues, dtype=float)[S.mask]
+    with np.errstate(divide='ignore'):
+        logHPD = np.where(np.isfinite(gl), rl, -np.inf) + np.log(prior) + np.sum(np.log(S.hyperGridConstant))
+    logE = float(logsumexp(logHPD))
+    assert abs(logE - float(gold['logEvidence'])) <= 1e-9 * abs(float(gold['logEvidence']))
+    assert abs(logE / np.log(10) - (-30.63948)) < 1e-3                              # the number printed in the tutorial (another SciPy)
+    hpd = np.zeros(len(S.allHyperGridValues))
+    hpd[S.mask] = np.exp(logHPD - logHPD.max()) / np.sum(np.exp(logHPD - logHPD.max())) / np.prod(S.hyperGridConstant)
+    np.testing.assert_allclose(hpd, gold['hyperParameterDistribution'], rtol=1e-9, atol=1e-300)
+    names = list(S.flatHyperParameterNames)
+    hv = np.asarray(S.allHyperGridValues, dtype=float)
+    dur = hv[:, names.index('t_2')] - hv[:, names.index('t_1')]
+    dd = np.array([hpd[dur == d].sum() for d in gold['durations']]) / hpd.sum()
+    np.testing.assert_allclose(dd, gold['durationDistribution'], rtol=1e-9, atol=1e-300)
+    # what the study object itself reports includes the noise chains: within THEIR WEIGHT in the average model of the reference --
+    # average = (1 - w) reference average + w (noise renormalised to sum 1: signed, single cells up to ~1.5 observed), so the
+    # difference is bounded by a small multiple of w cell by cell (factor 3; observed 1.5)
+    w = 1.0 - np.exp(logE - S.logEvidence)
+    assert 0.0 <= w <= COAL_NOISE_TOL['noise_weight_max'], w
+    assert abs(S.logEvidence - float(gold['logEvidence'])) <= 2 * w
+    d2, p2 = S.getDurationDistribution(['t_1', 't_2'])
+    keep = np.isin(gold['durations'], d2)
+    ref_dd = gold['durationDistribution'][keep] / gold['durationDistribution'][keep].sum()
+    assert np.all(np.abs(p2 - ref_dd) <= 2 * w * (ref_dd + 1.0))
+    post, want = np.asarray(S.posteriorSequence), gold['posteriorSequence']
+    assert np.all(np.abs(post - want) <= 1e-12 + 3.0 * w * (want + 1.0))
+    assert np.all(np.abs(np.asarray(S.posteriorMeanValues) - gold['posteriorMeanValues']) <= 3.0 * w * 6.0)        # (grid values 0 .. 6)
 
 
 @pytest.mark.parametrize('name', ['c3', 'c4', 'c5', 'c4_both_axes', 'c4_rows1024'])

@@ -7,7 +7,7 @@ Bar (BASELINE.json / SURVEY.md 8d, float64):  log-evidence 1e-9 relative;  poste
 BAR = dict(logE_rtol=1e-9, post_rtol=1e-9, post_atol=1e-12, small_rtol=1e-9, small_atol=1e-12)
 
 # one backward local-evidence entry of a step whose grid holds DENORMAL likelihood values (see ILL_LOCAL_EVIDENCE below)
-ILL_LOCAL_RTOL = 2e-2
+ILL_LOCAL_RTOL = 5e-3
 # the reference's own FFT / recursive-prefilter round-off (~1e-17 ABSOLUTE) -- a floor for the ORACLE-vs-reference comparison (whose
 # absolute tolerance is otherwise 1e-300); on the GPU it is inside the bar (1e-15 < 1e-12)
 FFT_TOL = dict(post_atol=1e-15, post_rtol=1e-9, logE_rtol=1e-12)
@@ -16,13 +16,32 @@ DETERMINISTIC_FUZZ_TOL = dict(FFT_TOL, post_rtol=2e-8, logE_rtol=1e-10, small_rt
 # the fixture cases.py: wide_filter_2d
 WIDE_FILTER_2D_TOL = dict(local_rtol=1e-3)
 
+# the reference's published break-point study (bench.py: coal_breakpoints): see COAL_NOISE_CHAINS below
+COAL_NOISE_TOL = dict(noise_chains=14, noise_weight_max=1e-3)
+
 EXCEPTIONS = {
+    'COAL_NOISE_CHAINS': dict(
+        value=COAL_NOISE_TOL, above_bar=True,
+        where='tests/test_gpu_parity.py: test_the_references_published_break_point_study_at_full_size (and bench.py extra.coal_breakpoints): '
+              'at most 14 of the 23 400 chains may differ in WHETHER they stop with a non-positive normaliser (core.py:442-452); every '
+              'chain that is finite on both sides keeps the 1e-9 bar (observed 6e-16), and so do the evidence of the average model and the '
+              'hyper-parameter / duration distributions formed from the chains with the reference\'s stop pattern; the average posterior and '
+              'its means, which the 11 extra chains enter, may differ cell by cell by those chains\' WEIGHT in the average model (computed in '
+              'the test, observed 5.7e-4, bounded at 1e-3) times (reference value + 1)',
+        seeds='slope -2.0 with break-points 3 .. 5 years apart, slope -1.52 with 1874 / 1878, ...: 14 chains stop in the reference, 3 here',
+        reason='transitionModels.py:586-606: these chains shift their backward message by 250 - 334 grid cells per step, i.e. OFF the grid; '
+               'what scipy.ndimage.shift leaves is rounding noise of its recursive spline prefilter (sum -2.7e-75 in the reference, +1.2e-63 with '
+               'the truncated-response prefilter of the oracle and the kernels, of a message of sum 1) which the reference then RENORMALISES '
+               'to sum 1 (:603): the sign of that noise decides whether sum(alpha * beta) > 0 holds.  No arithmetic but a bit-exact clone of '
+               'SciPy\'s IIR reproduces it; the reference\'s own value for these chains is not defined'),
     'ILL_LOCAL_EVIDENCE': dict(
         value=dict(local_rtol=ILL_LOCAL_RTOL), above_bar=True,
         where='tests/test_gpu_parity.py: seeded random configurations / resident-kernel cases, ONLY the localEvidence entries of steps '
               'whose likelihood has denormal cells (0 < L < 2.2e-308): a per-step mask built by _ill_tol(); steps with exact zeros '
               'only are NaN on both sides; the session summary prints how many entries were compared at which tolerance',
-        seeds='3 of 6000 configurations of random_case (e.g. seed 2641): 1.6e-3 relative in ONE backward localEvidence entry',
+        seeds='3 of 6000 configurations of random_case (e.g. seed 2641): 1.6e-3 relative in ONE backward localEvidence entry -- the '
+              'tolerance is 3 x that (round 3: 2e-2); for single-chain studies the sum over the cells with a NORMAL likelihood value is '
+              'additionally compared at 1e-9 on both sides (compare.check: local_lik), which pins everything but the denormal cells',
         reason='core.py:463 localEvidence = 1 / sum(post / L): a denormal L carries 1..52 significant bits, post / L at such a cell '
                'can dominate the sum, so the reference value itself is defined to a few digits only; every other number of those '
                'cases keeps the 1e-9 bar'),

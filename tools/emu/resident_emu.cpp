@@ -4,7 +4,6 @@
 // index logic and the lag bookkeeping before any GPU time is spent.  Development aid only: nothing ships from here.
 //   g++ -O2 -std=c++17 -DBLR_EMULATE -I bayesloop_amd/csrc tools/emu/resident_emu.cpp -o /tmp/resident_emu && /tmp/resident_emu
 #include <algorithm>
-#include <array>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -64,10 +63,10 @@ static std::vector<double> likelihood(const Problem &p, int t) {
     return L;
 }
 
-template <int TR, int TC, int SEG, int CHK = 8, bool PAD = false, bool ONEX = false>
+template <int TR, int TC, int SEG, int CHK = 8, bool PAD = false>
 static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis, int pad0 = 0, int pad1 = 0) {
-    using KF = Res<TR, TC, SEG, CHK, false, false, PAD, ONEX>;
-    using KB = Res<TR, TC, SEG, CHK, true, false, PAD, ONEX>;
+    using KF = Res<TR, TC, SEG, CHK, false, false, PAD>;
+    using KB = Res<TR, TC, SEG, CHK, true, false, PAD>;
     Problem p;
     p.n0 = tr * TR - pad0; p.n1 = tc * TC - pad1; p.T = T; p.d = 1;              // (PAD: the grid does not fill its last tile row / column)
     std::mt19937_64 rng(seed);
@@ -161,20 +160,11 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis, int
             if (k == 0) {
                 for (auto &x : th) x.first_step(Q);
             } else {
-                if constexpr (K::ONEX) {              // one hand-off per step: A -> axis-1 pass + halo rows -> B -> axis-0 pass -> A
-                    std::vector<std::array<Tq, R + 2>> hq(th.size());
-                    if (k >= lag) for (auto &x : th) if (x.gather_wave() >= 0) x.gather_issue(Q, k - lag);
-                    for (size_t i = 0; i < th.size(); ++i) th[i].halo_issue(Q, k, reinterpret_cast<Tq (&)[R + 2]>(*hq[i].data()));
-                    for (auto &x : th) x.h1_walk(Q, k);
-                    for (size_t i = 0; i < th.size(); ++i) th[i].halo_stage(Q, k, reinterpret_cast<Tq (&)[R + 2]>(*hq[i].data()));
-                    for (auto &x : th) x.halo_filter(Q);
-                } else {
                 for (auto &x : th) x.h_preread();
                 if (k >= lag) for (auto &x : th) if (x.gather_wave() >= 0) x.gather_issue(Q, k - lag);
                 for (auto &x : th) x.h_walk(Q, k);
                 for (auto &x : th) x.publish_rows(Q, k);
                 for (auto &x : th) x.v_preread();
-                }
                 if (k >= lag)
                     for (int b = 0; b < ntiles; ++b) {
                         for (int w = 0; w < K::NW; ++w) {
@@ -203,7 +193,6 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis, int
             }
             for (auto &x : th) x.mirror_edges();
             for (auto &x : th) x.publish_cols(Q, k);
-            if constexpr (K::ONEX) for (auto &x : th) x.publish_rows_raw(Q, k);
             for (auto &x : th) if (x.dead) { std::printf("dead thread\n"); return false; }
         }
         return true;
@@ -255,7 +244,7 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis, int
         for (size_t c = 0; c < G; ++c) check("posterior", gpost[(size_t)t * G + c], post[t][c], 1e-10);
         (void)N;
     }
-    std::printf("%stile %dx%d seg %d, grid %dx%d (%d tiles), T=%d, lag=%d, %s: %s (%d mismatches)\n", ONEX ? "[one hand-off] " : "", TR, TC, SEG, p.n0, p.n1, ntiles, T, lag,
+    std::printf("tile %dx%d seg %d, grid %dx%d (%d tiles), T=%d, lag=%d, %s: %s (%d mismatches)\n", TR, TC, SEG, p.n0, p.n1, ntiles, T, lag,
                 one_axis ? "axis 1 only" : "both axes", bad ? "FAIL" : "ok", bad);
     return bad != 0;
 }
@@ -280,13 +269,5 @@ int main() {
     rc |= run<64, 64, 8, 8, true>(2, 2, 7, 3, 15, false, 24, 40);       // 104 x 88
     rc |= run<32, 64, 8, 8, true>(3, 2, 7, 2, 16, true, 16, 30);        // 80 x 98, rectangular tiles, one filtered axis
     rc |= run<128, 128, 32, 8, true>(2, 1, 5, 2, 17, false, 56, 28);    // 200 x 100: multi-chunk segments
-    // one hand-off per step (ONEX): raw edge rows + columns published once, halo rows filtered by the consumer
-    rc |= run<64, 64, 8, 8, false, true>(2, 2, 6, 2, 20, false);
-    rc |= run<64, 64, 8, 8, false, true>(3, 3, 7, 2, 21, false);         // an interior tile: all four corners from diagonal neighbours
-    rc |= run<64, 64, 8, 8, false, true>(1, 3, 5, 1, 22, false);         // one tile row: no halo rows at all
-    rc |= run<64, 64, 8, 8, false, true>(3, 1, 6, 3, 23, true);          // one tile column: corners are mirror images
-    rc |= run<64, 64, 8, 8, true, true>(2, 2, 7, 3, 24, false, 24, 40);  // 104 x 88
-    rc |= run<64, 64, 8, 8, true, true>(3, 3, 7, 2, 25, false, 8, 56);   // 184 x 136: smallest padding / smallest remainder
-    rc |= run<64, 64, 8, 8, true, true>(3, 2, 6, 2, 26, true, 56, 0);    // padded rows only
     return rc;
 }
