@@ -28,6 +28,7 @@
 #include "blhip_mfma.hpp"
 #include "blhip_hwide.hpp"
 #include "blhip_fused1d.hpp"
+#include "blhip_chain1d.hpp"
 #include "blhip_persist1d.hpp"
 #include "blhip_resident.hpp"
 #include "blhip_chainres.hpp"
@@ -433,6 +434,38 @@ void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, si
         case BLHIP_OM_GAUSSIAN_MEAN: launch_fused1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
         case BLHIP_OM_TABLE: launch_fused1d_om<OM_TABLE>(s, P, bwd, lds); break;
         default: fail("fused 1-D path: observation model %d", om);
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+// ---- 1-D grids, batches of chains: one block per chain, all T steps in one launch (blhip_chain1d.hpp) -------------------------------
+template <int OM>
+void launch_chain1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
+    if (bwd) {
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true>));
+        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, true>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+    } else {
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false>));
+        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, false>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+    }
+}
+
+// the (T, n) likelihood table every chain of a 1-D batch shares (bl1c::lik1d_table_kernel: the in-kernel function, evaluated once)
+void build_lik1d_table(hipStream_t s, int om, const bl1f::F1Params &P, double *out) {
+    const dim3 grid((unsigned)std::min(16, (P.n + 255) / 256), (unsigned)P.T);
+    if (om == BLHIP_OM_POISSON) hipLaunchKernelGGL((bl1c::lik1d_table_kernel<OM_POISSON>), grid, dim3(256), 0, s, P, out);
+    else if (om == BLHIP_OM_GAUSSIAN_MEAN) hipLaunchKernelGGL((bl1c::lik1d_table_kernel<OM_GAUSSIAN_MEAN>), grid, dim3(256), 0, s, P, out);
+    else fail("internal: shared 1-D likelihood table for observation model %d", om);
+    HIPCHECK(hipGetLastError());
+}
+
+void launch_chain1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd) {
+    const size_t lds = bl1c::lds_doubles(P.n, P.LW) * sizeof(double);
+    switch (om) {
+        case BLHIP_OM_POISSON: launch_chain1d_om<OM_POISSON>(s, P, bwd, lds); break;
+        case BLHIP_OM_GAUSSIAN_MEAN: launch_chain1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
+        case BLHIP_OM_TABLE: launch_chain1d_om<OM_TABLE>(s, P, bwd, lds); break;
+        default: fail("chain-resident 1-D path: observation model %d", om);
     }
     HIPCHECK(hipGetLastError());
 }
@@ -1160,6 +1193,7 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
 // element once + 2 R0 halo rows per segment, short ones give enough blocks to fill 256 CUs when there are few chains)
 struct GeometryPlan {
     bool fast = false, fused1d = false, use_mfma = false;
+    bool chain1d = false;         // 1-D batches: one block per chain runs the whole pass (blhip_chain1d.hpp); bookkeeping of a K = 1 fused pass
     bool wideH = false;           // axis-1 walks wider than the fused kernels' halo: row filter as a pre-pass per step (blhip_hwide.hpp)
     bool wideV = false;           // axis-0 walks wider than the matrix-pipe kernels' largest band: column filter as a pre-pass, no stencil left
     bool hSplit = false;          // wideH: chains of the batch whose axis-1 filter is absent (or narrow: hFusedMax > 0) keep their fused kernels
@@ -1204,6 +1238,28 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
         // keep the redundantly recomputed halo (K * LW cells per side) within ~4x the owned cells and the window in LDS
         while (gp.fusedK > 1 && (gp.fusedK * prog.LW1 > 2 * gp.f1_TJ || (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 > 96 * 1024)) --gp.fusedK;
         gp.fused1d = (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 + (size_t)gp.fusedK * gp.f1_TJ * 32 + 4096 <= 150 * 1024;
+        // Batches of chains: one block per chain for the whole pass when that is cheaper per step than the alternatives.  Per step
+        // (shader cycles; measured with tools/probe.py chain1d, profiles/r04_notes.md): the chain's row is filtered out of ONE CU's LDS --
+        // n (2 lw + 1) 16-byte operand pairs at 128 B per clock, ~1 k cycles of barrier / sums / likelihood -- and ceil(B / CUs) blocks
+        // share a CU one after the other; the K-steps-per-launch path costs a launch (~14 k cycles) every K steps, the persistent
+        // one (all blocks of all chains on the chip at once) ~4 k (K > 1) / ~7 k (K = 1: a hand-off per step) per step.
+        const double c1d_mode = ctx->option("chain1d", 1.0);
+        if (gp.fused1d && c1d_mode != 0.0 && !resume && !carry && prog.LW1 < g.n1 && g.n1 <= bl1c::NMAX &&
+            bl1c::lds_doubles(g.n1, prog.LW1) * 8 <= 150 * 1024) {
+            // microseconds per time step of the whole batch, fitted to tools/probe.py chain1d (profiles/r04_notes.md): a block's step =
+            // 1.5 us + 1.0 ns per cell (likelihood from the shared table; 2.2 ns with Poisson's pow() in the kernel) + 44 ps per cell and
+            // tap (the stencil's operand pairs come out of ONE CU's LDS at ~9 per clock), blocks beyond the chip's capacity queue up;
+            // persistent K-step kernel (all blocks of all chains on the chip at once) 1.7 us + 40 ns per cell of radius; a launch per K
+            // steps 1.5 us + (29 + 0.63 radius) ps per cell of the batch
+            const int cus = std::min(ctx->num_cus, 256);
+            const double n = g.n1, lw = prog.LW1;
+            const double est_c1d = (double)((B + cus - 1) / cus) * (1.5 + n * (B >= 4 ? 0.0010 : 0.0022) + n * (2.0 * lw + 1.0) * 4.4e-5);
+            const int nblk_f = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ;
+            const bool p1d_ok = ctx->option("persist1d", 1.0) != 0.0 && (long long)nblk_f * B <= cus && T > gp.fusedK;
+            const double est_other = p1d_ok ? 1.7 + 0.04 * lw : 1.5 + (double)B * n * (29.0 + 0.63 * lw) * 1e-6;
+            gp.chain1d = c1d_mode == 2.0 || (B >= 2 && est_c1d < est_other);
+            if (gp.chain1d) { gp.fusedK = 1; gp.f1_TJ = g.n1; }
+        }
     }
     if (gp.fast) {
         gp.tile.TI = blf::CH; gp.tile.LW0 = gp.wideV ? 0 : prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && (!gp.wideH || (gp.hSplit && any_narrow))) ? blf::R1MAX : 0;
@@ -2050,8 +2106,29 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         HIPCHECK(hipEventRecord(ev[0], st));
         // 1-D grids whose blocks all fit on the chip at once: ONE persistent launch per pass (blhip_persist1d.hpp), else a launch per K steps
         // (a pass of a single superstep -- OnlineStudy.step, T <= K -- has no launch boundary to save)
-        const bool p1d_now = fused1d && !resident_failed && ctx->resident_ok && ctx->option("persist1d", 1.0) != 0.0 && T > K &&
+        const bool c1d_now = gp.chain1d;
+        const bool p1d_now = fused1d && !c1d_now && !resident_failed && ctx->resident_ok && ctx->option("persist1d", 1.0) != 0.0 && T > K &&
                              (long long)tile.nblk * B <= std::min(ctx->num_cus, 256);
+        // (the chains of a batch see the same likelihood: tabulated once per batch by the in-kernel function itself, shared by both passes)
+        const bool c1d_table = c1d_now && B >= 4 && !d_lik && (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN) &&
+                               ctx->option("chain1d_table", 1.0) != 0.0;
+        double *d_lik1 = nullptr;
+        if (c1d_table) {
+            ctx->lik1d.ensure((size_t)T * G * 8);
+            d_lik1 = ctx->lik1d.as<double>();
+            bl1f::F1Params Q = F1;
+            build_lik1d_table(st, p->obs_model, Q, d_lik1);
+        }
+        auto launch_c1d = [&](bool bwd, double *psum) {
+            bl1f::F1Params Q = F1;
+            if (d_lik1) Q.lik = d_lik1;
+            Q.K = 1; Q.dir = bwd ? -1 : 1; Q.t_first = bwd ? (int)(T - 1) : 0; Q.psum = psum; Q.prev_slot = bwd ? 2 : 0;
+            Q.srckind = bwd ? d_kindB : d_kindF; Q.tap = bwd ? d_tapB1 : d_tapF1;
+            Q.store = (bwd || !evidence_only) ? 1 : 0; Q.means = bwd ? 1 : (forward_only ? 1 : 0);
+            Q.post = (bwd || !evidence_only) ? d_post : nullptr; Q.post_stride = (long long)T * G;
+            Q.src = nullptr; Q.src_stride = 0; Q.dst = nullptr; Q.dst_stride = 0;
+            launch_chain1d(st, d_lik1 ? BLHIP_OM_TABLE : p->obs_model, Q, bwd);
+        };
         bl1p::P1Params P1{};
         unsigned *d_abort1 = nullptr;
         size_t p1d_bytes = 0;
@@ -2094,7 +2171,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             Q.dst = (bwd || evidence_only) ? d_pp[((T - 1) / K) & 1] : nullptr; Q.dst_stride = G;
             launch_persist1d(st, p->obs_model, Q, bwd, f1_lds(K));
         };
-        if (p1d_now) {
+        if (c1d_now) {
+            launch_c1d(false, d_psF);
+        } else if (p1d_now) {
             launch_p1d(false, d_psF);
         } else if (fused1d) {
             for (int64_t t = 0; t < T; t += K) {
@@ -2160,6 +2239,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->timing.fwd_kernel_variant = 6;
             if (!CR.forward_ok(E, redF)) { resident_failed = true; return false; }
         }
+        if (c1d_now) ctx->timing.fwd_kernel_variant = 9;
         if (p1d_now) {
             ctx->timing.fwd_kernel_variant = 8;
             if (resident_gave_up(ctx, st, d_abort1)) { resident_failed = true; return false; }
@@ -2176,7 +2256,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             double *d_psB = ctx->psumB.as<double>();
             if (fused1d && !raw_ok && K > 1) return false;
             HIPCHECK(hipEventRecord(ev[2], st));
-            if (p1d_now) {
+            if (c1d_now) {
+                launch_c1d(true, d_psB);
+            } else if (p1d_now) {
                 launch_p1d(true, d_psB);
             } else if (fused1d) {
                 for (int64_t t = T - 1; t >= 0; t -= K) {
@@ -2221,6 +2303,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 ctx->timing.bwd_kernel_variant = 5;
                 if (!RR.backward_ok(E, redB)) { resident_failed = true; return false; }
             }
+            if (c1d_now) ctx->timing.bwd_kernel_variant = 9;
             if (p1d_now) {
                 ctx->timing.bwd_kernel_variant = 8;
                 if (resident_gave_up(ctx, st, d_abort1)) { resident_failed = true; return false; }
@@ -2400,7 +2483,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release(); ctx->p1w.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,

@@ -1,0 +1,164 @@
+// CHAIN-RESIDENT pass for batches of chains on 1-D grids: ONE block per chain runs all T time steps of the forward (or the backward)
+// pass with the chain's state in the LDS of its CU.
+//
+// Why: the fits the reference's tutorials are made of are 1-D -- a Poisson rate on 200 .. 1000 grid points, tens to thousands of chains
+// of a hyper- or change-point study (HyperStudy.fit core.py:1349-1366, ChangepointStudy.fit :1765-1852, each chain = Study.fit
+// :372-411 / :434-470) -- and a 1-D distribution is a few KB.  The K-steps-per-launch kernels (blhip_fused1d.hpp) cut a row into blocks of
+// 128 cells that recompute K lw halo cells per side; with the wide walks such studies use (coal mining: sigma / delta = 6.7 on 200
+// points, 33 on 1000: radius 133) K drops to 1 and a pass is T launches of ~6 us each; the persistent variant (blhip_persist1d.hpp) needs
+// all blocks of all chains on the chip at once (<= 256 blocks).  A chain's whole row (<= 4096 cells here) fits one CU's LDS with any
+// halo, so: block = chain, the time loop runs inside the kernel, ONE barrier per step, no hand-off between blocks at all (the
+// normaliser is a block sum), any number of chains (blocks beyond the chip's capacity simply queue), any radius < n.
+//
+// Same arithmetic and the same conventions as the launch-per-step kernels with K = 1 (bl1f::advance_cells: centre first, pairs from
+// the outside in, four interleaved accumulators; lazy normaliser = 1 / sum of the previous state; partial-sum slots 0 N, 1 sum p / L,
+// 2 sum c, 3 mean; one slot per chain and sum: nblk = 1), so the host's bookkeeping is that of a K = 1 pass.
+#pragma once
+#include "blhip_fused1d.hpp"
+
+namespace bl1c {
+
+using blk::NRED;
+using blk::SRC_PREV;
+constexpr int NT = 512;            // 8 waves
+constexpr int NW = NT / 64;
+constexpr int NMAX = 4096;         // cells per row: at most 8 per thread (the stored forward row of the next step waits in registers)
+constexpr int CPT = NMAX / NT;
+
+// doubles of LDS: two state buffers with halo, grid values, exp(-lambda) (Poisson), weights, the waves' partial sums (two parities)
+inline size_t lds_doubles(int n, int LW) { return (size_t)2 * (n + 2 * LW) + 2 * (size_t)n + (LW + 1) + 2 * NW * 4 + 8; }
+
+// The likelihood of a 1-D batch is the same for every chain (same data, same grid: only the transition differs).  Poisson's pow() per
+// cell and step was most of a short-radius step (n = 4000, radius 8: 11.6 us per step of which ~9 are the likelihood); evaluated ONCE
+// per fit into a (T, n) table -- by the very function the step kernels call, so the values are bit for bit the in-kernel ones -- the
+// chains read it like a tabulated model's (8 bytes per cell and step from L2: T n 8 bytes, e.g. 880 KB for 110 steps x 1000 cells).
+template <int OM>
+__global__ __launch_bounds__(256) void lik1d_table_kernel(const bl1f::F1Params P, double *__restrict__ out) {
+    const int t = blockIdx.y;
+    blk::StepParams Q{};
+    Q.d = P.d; Q.n1 = P.n; Q.m0 = nullptr; Q.m1 = P.m1;
+    Q.rec = P.rec + (long long)t * P.rec_len;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < P.n; j += gridDim.x * 256)
+        out[(long long)t * P.n + j] = blk::likelihood<OM>(Q, 0, j, OM == blk::OM_POISSON ? P.colA[j] : 0.0, 0.0, P.m1[j]);
+}
+
+template <int OM, bool BWD>
+__global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = P.n, LW = P.LW, W = n + 2 * LW;
+    double *cur = lds, *nxt = lds + W, *g1s = lds + 2 * W, *cAs = g1s + n, *wl = cAs + n;
+    double *red = wl + (LW + 1);                   // [2 parities][NW][4] wave sums of a step: N, sum p / L, sum c, mean
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *post = P.post ? P.post + (long long)b * P.post_stride : nullptr;
+    blk::StepParams Q{};
+    Q.d = P.d; Q.n1 = n; Q.m0 = nullptr; Q.m1 = P.m1;
+
+    for (int j = tid; j < n; j += NT) {
+        g1s[j] = P.m1[j];
+        if (OM == blk::OM_POISSON) cAs[j] = P.colA[j];
+    }
+    // a row -> the state buffer incl. its mirror image beyond both ends (half-sample reflection, radius < n: one period)
+    auto put = [&](double *buf, int j, double v) {
+        buf[LW + j] = v;
+        if (j < LW) buf[LW - 1 - j] = v;
+        if (j >= n - LW) buf[LW + n + (n - 1 - j)] = v;
+    };
+    int tap_now = -2, lw = 0;
+    const int t0 = P.t_first;
+    // backward: the stored forward row of the step that runs next waits in registers (requested a step ahead)
+    double al[CPT];
+    if (BWD) {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) { const int j = tid + q * NT; al[q] = j < n ? post[(long long)t0 * n + j] : 0.0; }
+    }
+    __syncthreads();
+
+    for (int s = 0; s < P.T; ++s) {
+        const int t = t0 + P.dir * s;
+        const long long tb = (long long)t * P.B + b;
+        const int kind = P.srckind[tb];
+        const int tp = P.tap[tb];
+        double *rk = red + (s & 1) * (NW * 4), *rp = red + ((s + 1) & 1) * (NW * 4);
+        // ---- the step's weights (block-uniform: re-staged only when the chain's tap set changes) ---------------------------------------
+        const bool staged = tp != tap_now || kind != SRC_PREV || s == 0;
+        if (tp != tap_now) {
+            lw = tp >= 0 ? P.tap_lw[tp] : 0;
+            for (int k = tid; k <= LW; k += NT) wl[k] = k <= lw ? (lw > 0 ? P.taps[P.tap_off[tp] + k] : 1.0) : 0.0;
+            tap_now = tp;
+        }
+        // ---- the source: the previous state (in `cur` since the last barrier), or a shared distribution (prior, restart, uniform) -------
+        double scale = 1.0;
+        if (kind != SRC_PREV || s == 0) {
+            const double *src = (kind == SRC_PREV) ? P.src + (long long)b * P.src_stride : P.shared[kind];
+            for (int j = tid; j < n; j += NT) put(cur, j, src[j]);
+        } else {
+            // lazy normaliser: every thread adds the waves' sums of the previous step in the same order
+            double sN = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sN += rp[w * 4 + (BWD ? 2 : 0)];
+            scale = 1.0 / sN;
+        }
+        // (block-uniform: a barrier only where something was staged -- all reads of the buffer this step overwrites ended before the
+        //  previous step's last barrier)
+        if (staged) __syncthreads();
+        Q.rec = P.rec + (long long)t * P.rec_len;
+        Q.lik = P.lik ? P.lik + (long long)t * n : nullptr;
+        double *row = post ? post + (long long)t * n : nullptr;
+        double aN = 0.0, aS = 0.0, aC = 0.0, aM = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = tid + q * NT;
+            if (j < n) {
+                const int e = LW + j;
+                double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
+                int k = lw;
+                for (; k >= 4; k -= 4) {
+                    o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+                    o1 = fma(cur[e - k + 1] + cur[e + k - 1], wl[k - 1], o1);
+                    o2 = fma(cur[e - k + 2] + cur[e + k - 2], wl[k - 2], o2);
+                    o3 = fma(cur[e - k + 3] + cur[e + k - 3], wl[k - 3], o3);
+                }
+                for (; k >= 1; --k) o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+                const double o = ((o0 + o1) + (o2 + o3)) * scale;
+                const double g1 = g1s[j];
+                const double L = blk::likelihood<OM>(Q, 0, j, OM == blk::OM_POISSON ? cAs[j] : 0.0, 0.0, g1);
+                if (!BWD) {
+                    const double a = o * L;
+                    put(nxt, j, a);
+                    if (P.store) row[j] = a;
+                    aN += a;
+                    if (P.means) aM = fma(a, g1, aM);
+                } else {
+                    const double cn = o * L, p = al[q] * o;
+                    put(nxt, j, cn);
+                    row[j] = p;
+                    aN += p; aS += p / L; aC += cn;          // 0/0 -> NaN as numpy (core.py:463)
+                    aM = fma(p, g1, aM);
+                }
+            }
+        }
+        if (BWD && s + 1 < P.T) {                     // the stored row of the next step: a whole step to arrive
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) { const int j = tid + q * NT; al[q] = j < n ? post[(long long)(t - 1) * n + j] : 0.0; }
+        }
+        // ---- the step's sums: waves -> LDS (this step's parity); the totals go to the host in a fixed order --------------------------
+        aN = blk::wave_sum(aN);
+        if (BWD) { aS = blk::wave_sum(aS); aC = blk::wave_sum(aC); }
+        if (BWD || P.means) aM = blk::wave_sum(aM);
+        if (lane == 0) { rk[wv * 4 + 0] = aN; rk[wv * 4 + 1] = aS; rk[wv * 4 + 2] = aC; rk[wv * 4 + 3] = aM; }
+        __syncthreads();                              // `nxt` and the sums are complete
+        if (tid < 4 && (tid == 0 || BWD || (tid == 3 && P.means))) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += rk[w * 4 + tid];
+            P.psum[(tb * NRED + tid) * P.nblk] = tot;
+        }
+        double *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (P.dst) {
+        double *d = P.dst + (long long)b * P.dst_stride;
+        for (int j = tid; j < n; j += NT) d[j] = cur[LW + j];
+    }
+}
+
+}  // namespace bl1c

@@ -136,6 +136,7 @@ struct blhip_ctx {
     DevBuf post2, accw;
     DevBuf hsrc;                 // the axis-1 pre-pass's output of one step (blhip_hwide.hpp)
     DevBuf p1d, p1w;             // hand-off buffers / weight table of the persistent 1-D kernel (blhip_persist1d.hpp)
+    DevBuf lik1d;                // (T, n) likelihood table the chains of a 1-D batch share (blhip_chain1d.hpp)
     DevBuf accpart;              // partial accumulators of the fused fold (one per launch slot of the chain-resident kernel)
     hipStream_t astream = nullptr;
     hipEvent_t aev_done[2] = {nullptr, nullptr};

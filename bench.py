@@ -233,7 +233,9 @@ KERNEL_NAMES = {0: 'blk::step_kernel', 1: 'blf::fast_step_kernel', 2: 'blf::fast
                 3: 'blm::mfma_step_kernel (+ blf::fast_step_kernel for the radius-0 bucket)',
                 5: 'blr::resident_kernel (ONE launch for all time steps; a logical launch = one time step of it)',
                 6: 'blc::chain_kernel (rounds of 8 chains resident in LDS for a whole pass; a logical launch = one time step of all '
-                   'chains of a batch; the backward kernel of a hyper-study also folds the posteriors into the average posterior)'}
+                   'chains of a batch; the backward kernel of a hyper-study also folds the posteriors into the average posterior)',
+                8: 'bl1p::persist1d_kernel (1-D grids: ONE persistent launch per pass; a logical launch = one time step of it)',
+                9: 'bl1c::chain1d_kernel (1-D batches: one block per chain runs the whole pass; a logical launch = one time step of all chains)'}
 
 
 def roofline_of(timing, units, peak_cal=None, pmc=None):

@@ -76,6 +76,7 @@ def test_alternative_kernel_paths_match_golden(case, option):
 def test_one_launch_per_step_1d_kernels_match_golden(case):
     """1-D cases with the K-steps-per-launch kernel switched off (fuse1d=0: generic kernel) and with K = 1 / K = 3."""
     eng = bl.get_engine()
+    eng.set_option('chain1d', 0)           # (batches of chains would otherwise take the chain-resident 1-D kernel, tested on its own)
     for k, variant in ((0, 0), (1, 4), (3, 4)):
         eng.set_option('fuse1d', k)
         try:
@@ -85,6 +86,7 @@ def test_one_launch_per_step_1d_kernels_match_golden(case):
             compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL)
         finally:
             eng.set_option('fuse1d', 8)
+    eng.set_option('chain1d', 1)
 
 
 @pytest.mark.parametrize('case', ['c1_coal', 'c2_small', 'kat_changepoint', 'c1_coal_changepoint', 'kat_gaussianmean',
@@ -93,6 +95,7 @@ def test_persistent_1d_kernel_is_bit_identical_to_the_launch_per_k_path(case):
     """blhip_persist1d.hpp (kernel variant 8: one launch per pass, supersteps handed over inside the kernel) against
     blhip_fused1d.hpp (variant 4: one launch per K steps): the same arithmetic in the same order -- identical bits; K = 8 and K = 3."""
     eng = bl.get_engine()
+    eng.set_option('chain1d', 0)
     for k in (8, 3):
         eng.set_option('fuse1d', k)
         try:
@@ -106,6 +109,7 @@ def test_persistent_1d_kernel_is_bit_identical_to_the_launch_per_k_path(case):
                 eng.set_option('persist1d', 1)
         finally:
             eng.set_option('fuse1d', 8)
+            eng.set_option('chain1d', 1 if k == 3 else 0)
         # (a pass that fits in one superstep -- T <= K -- has no launch boundary to save and keeps the launch path)
         assert A.lastTiming['fwd_kernel_variant'] in ((8,) if case in ('c1_coal', 'c2_small', 'c1_coal_hyper') else (4, 8)) and A.lastTiming['resident_fallbacks'] == 0, A.lastTiming
         assert B.lastTiming['fwd_kernel_variant'] == 4, B.lastTiming
@@ -1106,6 +1110,29 @@ def test_resident_kernel_full_chip():
         for S_ in (A, B):
             S_._posterior_pending = None
         eng.release_posterior()
+
+
+def test_one_dimensional_batches_on_the_chain_resident_kernel_match_the_goldens():
+    """bl1c::chain1d_kernel (one block per chain runs a whole pass of a 1-D study: blhip_chain1d.hpp), forced (`chain1d = 2`) for every
+    fixture it is eligible for -- the reference's 1-D hyper- / change-point studies and single fits, Poisson / GaussianMean / tabulated
+    likelihoods, random walks, change- and break-points, forward-only and evidence-only fits -- against the reference's goldens."""
+    eng = bl.get_engine()
+    took = []
+    eng.set_option('chain1d', 2)
+    try:
+        for case, c in cases.CASES.items():
+            if len(c['om'][1]) != 1 or c['study'] == 'OnlineStudy':
+                continue
+            S = cases.build(bl, case)
+            with np.errstate(all='ignore'):
+                S.fit(**cases.fit_kwargs(case))
+            if S.lastTiming.get('fwd_kernel_variant') != 9:
+                continue
+            took.append(case)
+            compare.check(result_of(S, case), oa.load_golden(case), compare.GPU_TOL, case_tol=cases.CASES[case].get('tol'))
+    finally:
+        eng.set_option('chain1d', 1)
+    assert len(took) >= 12 and 'c1_coal_hyper' in took and 'c1_coal' in took, took
 
 
 def test_the_references_published_break_point_study_at_full_size():

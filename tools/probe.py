@@ -74,6 +74,24 @@ def hyper(a):
             print('hyper %dx%d x %d T=%d %-40s %s' % (a.n0, a.n1, a.nh, a.T, ','.join('%s=%g' % kv for kv in opts), with_options(opts, run)), flush=True)
 
 
+def chain1d(a):
+    """1-D hyper-studies (Poisson rate, coal-mining counts repeated to T steps): the chain-resident 1-D kernel against the other 1-D paths"""
+    coal = np.array([4, 5, 4, 1, 0, 4, 3, 4, 0, 6, 3, 3, 4, 0, 2, 6, 3, 3, 5, 4, 5, 3, 1, 4, 4, 1, 5, 5, 3, 4, 2, 5, 2, 2, 3, 4, 2, 1, 3, 2])
+    for n in [int(x) for x in a.ns.split(',')]:
+        for lw in [int(x) for x in a.lws.split(',')]:
+            for B in [int(x) for x in a.Bs.split(',')]:
+                for opts in option_sets(a.opts):
+                    def run():
+                        S = bl.HyperStudy(silent=True)
+                        S.loadData(np.resize(coal, a.T), silent=True)
+                        delta = 6.0 / (n + 1)
+                        s_hi = (lw + 0.4) / 4.0 * delta             # radius int(4 sigma / delta + 0.5) = lw for the widest chain
+                        S.set(bl.om.Poisson('rate', bl.oint(0, 6, n)), bl.tm.GaussianRandomWalk('sigma', np.linspace(0.5 * s_hi, s_hi, B), target='rate'), silent=True)
+                        S.fit(silent=True)
+                        return timed(S, {}, a.T)
+                    print('chain1d n=%d lw=%d B=%d T=%d %-28s %s' % (n, lw, B, a.T, ','.join('%s=%g' % kv for kv in opts), with_options(opts, run)), flush=True)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest='cmd', required=True)
@@ -83,5 +101,8 @@ if __name__ == '__main__':
     h = sub.add_parser('hyper')
     h.add_argument('--n0', type=int, default=512); h.add_argument('--n1', type=int, default=512); h.add_argument('--nh', type=int, default=64)
     h.add_argument('--T', type=int, default=128); h.add_argument('--evid', action='store_true'); h.add_argument('--opts', default=''); h.add_argument('--reps', type=int, default=2)
+    c = sub.add_parser('chain1d')
+    c.add_argument('--ns', default='200,1000,4000'); c.add_argument('--lws', default='8,27,133'); c.add_argument('--Bs', default='2,20,256,1000')
+    c.add_argument('--T', type=int, default=110); c.add_argument('--opts', default='chain1d=2;chain1d=0')
     a = ap.parse_args()
-    dict(resident=resident, hyper=hyper)[a.cmd](a)
+    dict(resident=resident, hyper=hyper, chain1d=chain1d)[a.cmd](a)
