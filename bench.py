@@ -2,7 +2,7 @@
 """
 bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c3|c2|c5|fwd2048|coal_breakpoints] [--no-extra] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c3|c2|c5|fwd2048|coal_breakpoints|c1_hyper|coal_hyper1000] [--no-extra] [--no-cpu]
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
@@ -137,6 +137,20 @@ def make_study(bl, name, comm=None, scale=1.0):
         S.communicator = comm
         return S, dict(silent=True), n * n * T * nh, dict(workload='C5 ChangepointStudy 512x512 grid, T=1000, %d candidate '
                                                            'change-points (arange(3, 1000, 4)), full fit' % nh, grid=[n, n], T=T, n_hyper=nh, mode='full')
+    if name in ('c1_hyper', 'coal_hyper1000'):
+        # 1-D batches of chains (bl1c::chain1d_kernel).  c1_hyper: BASELINE config C1 as a hyper-study, SURVEY 8(c)'s anchor (coal mining, 200-pt
+        # Poisson grid, 20 widths cint(0, 1, 20): logE = -172.6703099789132).  coal_hyper1000: the shape of the reference's hyper-study tutorial
+        # (docs/source/tutorials/hyperstudy.ipynb: 1000-pt grid, widths up to 1.0 = 667 grid steps) with 256 widths
+        n, nh = (200, 20) if name == 'c1_hyper' else (1000, 256)
+        S = bl.HyperStudy(silent=True)
+        S.loadExampleData(silent=True)
+        S.set(bl.om.Poisson('accident_rate', bl.oint(0, 6, n)),
+              bl.tm.GaussianRandomWalk('sigma', bl.cint(0, 1, nh), target='accident_rate'), silent=True)
+        S.communicator = comm
+        T = len(S.rawData)
+        return S, dict(silent=True), n * T * nh, dict(
+            workload='HyperStudy coal mining (T=%d), %d-pt Poisson grid x %d random-walk widths cint(0, 1, %d), full fit' % (T, n, nh, nh),
+            grid=[n], T=T, n_hyper=nh, mode='full')
     if name == 'coal_breakpoints':
         # the reference's one published heavy workload (docs/source/tutorials/changepointstudy.ipynb, "Analyzing structural breaks":
         # "~25000 individual model fits. It may take several minutes"): coal-mining disasters 1870-1910, a constant rate, a linear
@@ -216,7 +230,7 @@ def recalibrate(out):
 def golden_log_evidence(name):
     """logEvidence of the REFERENCE for this exact workload (tests/golden/bench_<name>.npz, generated by importing the reference in
     the build container: tests/golden/gen_bench_golden.py), or None."""
-    for cand in ('bench_' + name, 'bench_' + name.replace('_evidence', ''), name + '_full'):
+    for cand in ('bench_' + name, 'bench_' + name.replace('_evidence', ''), 'bench_' + name + '_full', name + '_full'):
         f = os.path.join(ROOT, 'tests', 'golden', cand + '.npz')
         if os.path.exists(f):
             return float(np.load(f)['logEvidence'])
@@ -627,7 +641,7 @@ def main():
     if rank == 0:
         if not args.no_extra and world == 1:
             extra = {}
-            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024', 'coal_breakpoints'):
+            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024', 'coal_breakpoints', 'c1_hyper', 'coal_hyper1000'):
                 if name == args.workload:
                     continue
                 try:

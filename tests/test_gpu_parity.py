@@ -1135,6 +1135,29 @@ def test_one_dimensional_batches_on_the_chain_resident_kernel_match_the_goldens(
     assert len(took) >= 12 and 'c1_coal_hyper' in took and 'c1_coal' in took, took
 
 
+@pytest.mark.parametrize('name', ['c1_hyper', 'coal_hyper1000'])
+def test_one_dimensional_hyper_studies_of_the_bench_against_full_size_reference(name):
+    """bench.py's 1-D hyper-studies (SURVEY 8c's anchor C1-as-HyperStudy; the tutorial's 1000-point grid with 256 widths up to 667 grid
+    steps) on the chain-resident 1-D kernel against the reference's own runs: evidences per chain and of the average model,
+    hyper-parameter distribution, average posterior sequence, means, local evidence."""
+    import bench
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_%s_full.npz' % name))
+    S, kw, units, desc = bench.make_study(bl, name)
+    with np.errstate(all='ignore'):
+        S.fit(silent=True)
+    assert S.lastTiming['fwd_kernel_variant'] == 9 and S.lastTiming['bwd_kernel_variant'] == 9, S.lastTiming
+    assert abs(S.logEvidence - float(gold['logEvidence'])) <= 1e-9 * abs(float(gold['logEvidence']))
+    if name == 'c1_hyper':
+        assert abs(S.logEvidence - (-172.6703099789132)) < 1e-9 * 172.67               # SURVEY.md 8(c)
+    np.testing.assert_allclose(np.asarray(S.logEvidenceList, dtype=float), gold['logEvidenceList'], rtol=1e-9)
+    np.testing.assert_allclose(S.hyperParameterDistribution, gold['hyperParameterDistribution'], rtol=1e-9, atol=1e-300)
+    ge = gold['localEvidence']
+    np.testing.assert_allclose(np.asarray(S.localEvidence)[~np.isnan(ge)], ge[~np.isnan(ge)], rtol=1e-9, atol=0)
+    post, want = np.asarray(S.posteriorSequence), gold['posteriorSequence']
+    assert np.all(np.abs(post - want) <= 1e-12 + 1e-9 * np.abs(want))
+    np.testing.assert_allclose(S.posteriorMeanValues, gold['posteriorMeanValues'], rtol=1e-9, atol=1e-11)
+
+
 def test_the_references_published_break_point_study_at_full_size():
     """The one heavy workload the reference publishes (docs/source/tutorials/changepointstudy.ipynb, "Analyzing structural breaks":
     coal-mining disasters 1870-1910, Serial(Static, BreakPoint, Deterministic(30 slopes), BreakPoint, Static) on a 1000-point Poisson
