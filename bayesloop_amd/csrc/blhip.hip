@@ -1168,9 +1168,12 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
     if (p->ndim == 2 && g.n0 >= CHAIN_MIN_ROWS && g.n0 <= 512)
         Gk = (double)((g.n0 + 127) / 128 * 128) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
     // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
-    if (ff.accumulate && ff.full && p->ndim == 2 && g.n1 >= 1) {
+    // -- only where the chain-resident path can be taken at all (else they are never allocated: a narrow grid with a long series
+    //    gave up its whole budget to 128 slots it never used and ran one chain per batch), and never more than half of the budget
+    if (ff.accumulate && ff.full && p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && g.n0 >= CHAIN_MIN_ROWS && g.n0 <= 512 &&
+        g.n1 >= 1 && g.n1 <= 16 * blc::MAX_STRIPS && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok) {
         const double slots = std::max(1, std::min(ctx->num_cus, 256) / ((g.n1 + blc::WCOL - 1) / blc::WCOL));
-        budget = std::max(0.0, budget - std::min<double>(slots, (double)n_chains) * (double)T * Gk * 8.0);
+        budget -= std::min(0.5 * budget, std::min<double>(slots, (double)n_chains) * (double)T * Gk * 8.0);
     }
     const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * Gk * 8.0 +
                              (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;

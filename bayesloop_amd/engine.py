@@ -121,11 +121,14 @@ class _PinnedPool:
         self.lock = threading.Lock()
         self.pending = None              # the background thread pinning a block
         self.deferred = 0                # bytes of the block to pin once the pageable read-back in flight is done
+        self.released = False            # the engine is gone: blocks that come back are freed, not parked
 
     def _give_back(self, ptr, nbytes):
         try:
             with self.lock:
-                if self.free is None or self.free[1] < nbytes:
+                if self.released:
+                    old = (ptr, nbytes)
+                elif self.free is None or self.free[1] < nbytes:
                     old, self.free = self.free, (ptr, nbytes)
                 else:
                     old = (ptr, nbytes)
@@ -158,7 +161,9 @@ class _PinnedPool:
             return np.empty(shape)
         ptr = None
         with self.lock:
-            if self.free is not None and nbytes <= self.free[1] <= 2 * nbytes:
+            # (any free block that is large enough: pinning a better-fitting one in the background would cost up to ~1 s of
+            #  hipHostRegister only to be freed again when it comes back -- the larger block is the one that is kept)
+            if self.free is not None and nbytes <= self.free[1]:
                 (ptr, cap), self.free = self.free, None
         if not ptr:
             self.deferred = nbytes
@@ -177,6 +182,7 @@ class _PinnedPool:
         self.wait_ready(5.0)
         with self.lock:
             blk, self.free = self.free, None
+            self.released = True
         if blk is not None:
             self.lib.blhip_host_free(blk[0])
 

@@ -304,7 +304,7 @@ int blhip_comm_destroy(blhip_ctx *ctx);
  *   blhip_accum_peer_reduce   dst.acc[row0:row1] += sum_i srcs[i].acc[row0:row1]   (rows fetched concurrently, one stream -- one
  *                             xGMI link -- per source; summed in list order: the same result on every run)
  *   blhip_accum_peer_gather   dst.acc[row0[i]:row1[i]] = srcs[i].acc[row0[i]:row1[i]]   for every i (concurrent copies)
- * at most 12 sources per call. */
+ * at most NBS = 18 sources per call. */
 int blhip_accum_peer_reduce(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, int64_t row0, int64_t row1);
 int blhip_accum_peer_gather(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, const int64_t *row0, const int64_t *row1);
 
