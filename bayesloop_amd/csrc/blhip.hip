@@ -439,15 +439,19 @@ void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, si
 }
 
 // ---- 1-D grids, batches of chains: one block per chain, all T steps in one launch (blhip_chain1d.hpp) -------------------------------
-template <int OM>
-void launch_chain1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
+template <int OM, int M>
+void launch_chain1d_m(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
     if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true>));
-        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, true>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true, M>));
+        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, true, M>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
     } else {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false>));
-        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, false>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false, M>));
+        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, false, M>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
     }
+}
+template <int OM>
+void launch_chain1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds, int m) {
+    if (m == 2) launch_chain1d_m<OM, 2>(s, P, bwd, lds); else launch_chain1d_m<OM, 1>(s, P, bwd, lds);
 }
 
 // the (T, n) likelihood table every chain of a 1-D batch shares (bl1c::lik1d_table_kernel: the in-kernel function, evaluated once)
@@ -459,12 +463,14 @@ void build_lik1d_table(hipStream_t s, int om, const bl1f::F1Params &P, double *o
     HIPCHECK(hipGetLastError());
 }
 
-void launch_chain1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd) {
+// cells per thread: 2 adjacent ones (sharing their stencil operands) for rows longer than a block, else 1 (option chain1d_pair: 0 / 1 force)
+void launch_chain1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, int pair_mode) {
     const size_t lds = bl1c::lds_doubles(P.n, P.LW) * sizeof(double);
+    const int m = pair_mode == 0 ? 1 : ((pair_mode == 1 || P.n > bl1c::NT) ? 2 : 1);
     switch (om) {
-        case BLHIP_OM_POISSON: launch_chain1d_om<OM_POISSON>(s, P, bwd, lds); break;
-        case BLHIP_OM_GAUSSIAN_MEAN: launch_chain1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
-        case BLHIP_OM_TABLE: launch_chain1d_om<OM_TABLE>(s, P, bwd, lds); break;
+        case BLHIP_OM_POISSON: launch_chain1d_om<OM_POISSON>(s, P, bwd, lds, m); break;
+        case BLHIP_OM_GAUSSIAN_MEAN: launch_chain1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds, m); break;
+        case BLHIP_OM_TABLE: launch_chain1d_om<OM_TABLE>(s, P, bwd, lds, m); break;
         default: fail("chain-resident 1-D path: observation model %d", om);
     }
     HIPCHECK(hipGetLastError());
@@ -499,26 +505,29 @@ struct ResidentPlan {
     size_t lds_bytes = 0;
 };
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID, bool PAD = false>
+template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE, bool PAD = false>
 void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
-    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, EVID, PAD>::LDS_DOUBLES * sizeof(double);
-    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>));
-    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, EVID, PAD>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, MODE, PAD>::LDS_DOUBLES * sizeof(double);
+    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD>));
+    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
 }
 
 template <int TR, int TC, int SEG, int CHK>
 void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad = false) {
-    // forward pass of an evidence-only fit: nothing stored, no means, no rows to normalise -> the flavour with compile-time flags
+    // forward pass of an evidence-only fit (nothing stored, no means, no rows to normalise) / of a full fit (every state stored, no
+    // means, no rows to normalise): the flavours with compile-time flags (blr::Res MODE 1 / 2); forward-only fits: flags at run time
     const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
+    const bool fullfwd = !bwd && Q.store && !Q.means && !Q.normalise && Q.post;
     if (pad) {                   // grids that do not fill their last tile row / column
-        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false, true>(s, Q);
-        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true, true>(s, Q);
-        else launch_resident_k<TR, TC, SEG, CHK, false, false, true>(s, Q);
+        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0, true>(s, Q);
+        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1, true>(s, Q);
+        else launch_resident_k<TR, TC, SEG, CHK, false, 0, true>(s, Q);
         return;
     }
-    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, false>(s, Q);
-    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, true>(s, Q);
-    else launch_resident_k<TR, TC, SEG, CHK, false, false>(s, Q);
+    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0>(s, Q);
+    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1>(s, Q);
+    else if (fullfwd) launch_resident_k<TR, TC, SEG, CHK, false, 2>(s, Q);
+    else launch_resident_k<TR, TC, SEG, CHK, false, 0>(s, Q);
 }
 
 // tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
@@ -528,7 +537,7 @@ void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pa
 void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
     if (rp.TR == 128 && rp.SEG == 16) {
         if (bwd || Q.store || Q.means || Q.normalise || Q.post) fail("internal: the 1024-thread resident shape runs evidence-only forward passes only");
-        launch_resident_k<128, 128, 16, 4, false, true>(s, Q);
+        launch_resident_k<128, 128, 16, 4, false, 1>(s, Q);
     }
     else if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd, rp.pad);
     else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd, rp.pad);
@@ -1256,7 +1265,9 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
             // steps 1.5 us + (29 + 0.63 radius) ps per cell of the batch
             const int cus = std::min(ctx->num_cus, 256);
             const double n = g.n1, lw = prog.LW1;
-            const double est_c1d = (double)((B + cus - 1) / cus) * (1.5 + n * (B >= 4 ? 0.0010 : 0.0022) + n * (2.0 * lw + 1.0) * 4.4e-5);
+            // (rows longer than a block: two cells per thread share their operand pairs, 21 ps per cell and tap -- launch_chain1d)
+            const double tap_us = g.n1 > bl1c::NT && ctx->option("chain1d_pair", 2.0) != 0.0 ? 2.1e-5 : 4.4e-5;
+            const double est_c1d = (double)((B + cus - 1) / cus) * (1.5 + n * (B >= 4 ? 0.0010 : 0.0022) + n * (2.0 * lw + 1.0) * tap_us);
             const int nblk_f = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ;
             const bool p1d_ok = ctx->option("persist1d", 1.0) != 0.0 && (long long)nblk_f * B <= cus && T > gp.fusedK;
             const double est_other = p1d_ok ? 1.7 + 0.04 * lw : 1.5 + (double)B * n * (29.0 + 0.63 * lw) * 1e-6;
@@ -2130,7 +2141,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             Q.store = (bwd || !evidence_only) ? 1 : 0; Q.means = bwd ? 1 : (forward_only ? 1 : 0);
             Q.post = (bwd || !evidence_only) ? d_post : nullptr; Q.post_stride = (long long)T * G;
             Q.src = nullptr; Q.src_stride = 0; Q.dst = nullptr; Q.dst_stride = 0;
-            launch_chain1d(st, d_lik1 ? BLHIP_OM_TABLE : p->obs_model, Q, bwd);
+            launch_chain1d(st, d_lik1 ? BLHIP_OM_TABLE : p->obs_model, Q, bwd, (int)ctx->option("chain1d_pair", 2.0));
         };
         bl1p::P1Params P1{};
         unsigned *d_abort1 = nullptr;

@@ -26,7 +26,7 @@ constexpr int NMAX = 4096;         // cells per row: at most 8 per thread (the s
 constexpr int CPT = NMAX / NT;
 
 // doubles of LDS: two state buffers with halo, grid values, exp(-lambda) (Poisson), weights, the waves' partial sums (two parities)
-inline size_t lds_doubles(int n, int LW) { return (size_t)2 * (n + 2 * LW) + 2 * (size_t)n + (LW + 1) + 2 * NW * 4 + 8; }
+inline size_t lds_doubles(int n, int LW) { return (size_t)2 * (n + 1 + 2 * (LW + 1)) + 2 * (size_t)n + (LW + 3) + 2 * NW * 4 + 8; }
 
 // The likelihood of a 1-D batch is the same for every chain (same data, same grid: only the transition differs).  Poisson's pow() per
 // cell and step was most of a short-radius step (n = 4000, radius 8: 11.6 us per step of which ~9 are the likelihood); evaluated ONCE
@@ -42,12 +42,20 @@ __global__ __launch_bounds__(256) void lik1d_table_kernel(const bl1f::F1Params P
         out[(long long)t * P.n + j] = blk::likelihood<OM>(Q, 0, j, OM == blk::OM_POISSON ? P.colA[j] : 0.0, 0.0, P.m1[j]);
 }
 
-template <int OM, bool BWD>
+// M = 2: TWO ADJACENT cells per thread on a plane-interleaved state (even positions in one plane, odd ones in the other: the lanes of a
+// wave still read consecutive 8-byte slots, conflict-free).  At large radii the M = 1 loop is bound by the LDS pipe -- every output reads
+// both operands and the weight of every tap: 3 reads per output and tap.  Two adjacent outputs share their operands (the right operand of
+// output 0 at tap k is the one of output 1 at tap k - 1, likewise on the left) and their weights: per PAIR of taps 4 operand reads + 2
+// weight reads serve 4 output-taps, 1.5 reads per output and tap.  Used for rows of more than NT cells (below, one cell per thread keeps
+// all waves busy).
+template <int OM, bool BWD, int M = 1>
 __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int n = P.n, LW = P.LW, W = n + 2 * LW;
+    const int n = P.n;
+    const int LW = M == 2 ? (P.LW + 1) & ~1 : P.LW;                  // (M = 2: an even halo, so that cell 0 sits in plane 0)
+    const int W = M == 2 ? ((n + 1) & ~1) + 2 * LW : n + 2 * LW, PS = W / 2;
     double *cur = lds, *nxt = lds + W, *g1s = lds + 2 * W, *cAs = g1s + n, *wl = cAs + n;
-    double *red = wl + (LW + 1);                   // [2 parities][NW][4] wave sums of a step: N, sum p / L, sum c, mean
+    double *red = wl + (LW + 2);                   // [2 parities][NW][4] wave sums of a step: N, sum p / L, sum c, mean
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *post = P.post ? P.post + (long long)b * P.post_stride : nullptr;
     blk::StepParams Q{};
@@ -57,19 +65,22 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         g1s[j] = P.m1[j];
         if (OM == blk::OM_POISSON) cAs[j] = P.colA[j];
     }
+    // position e of the extended row (e = LW + cell index) -> slot of the state buffer
+    auto slot = [&](int e) { return M == 2 ? (e & 1) * PS + (e >> 1) : e; };
     // a row -> the state buffer incl. its mirror image beyond both ends (half-sample reflection, radius < n: one period)
     auto put = [&](double *buf, int j, double v) {
-        buf[LW + j] = v;
-        if (j < LW) buf[LW - 1 - j] = v;
-        if (j >= n - LW) buf[LW + n + (n - 1 - j)] = v;
+        buf[slot(LW + j)] = v;
+        if (j < LW) buf[slot(LW - 1 - j)] = v;
+        if (j >= n - LW) buf[slot(LW + n + (n - 1 - j))] = v;
     };
     int tap_now = -2, lw = 0;
     const int t0 = P.t_first;
     // backward: the stored forward row of the step that runs next waits in registers (requested a step ahead)
     double al[CPT];
+    auto cell_of = [&](int q) { return M == 2 ? 2 * (tid + (q >> 1) * NT) + (q & 1) : tid + q * NT; };      // the q-th cell of this thread
     if (BWD) {
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) { const int j = tid + q * NT; al[q] = j < n ? post[(long long)t0 * n + j] : 0.0; }
+        for (int q = 0; q < CPT; ++q) { const int j = cell_of(q); al[q] = j < n ? post[(long long)t0 * n + j] : 0.0; }
     }
     __syncthreads();
 
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         const bool staged = tp != tap_now || kind != SRC_PREV || s == 0;
         if (tp != tap_now) {
             lw = tp >= 0 ? P.tap_lw[tp] : 0;
-            for (int k = tid; k <= LW; k += NT) wl[k] = k <= lw ? (lw > 0 ? P.taps[P.tap_off[tp] + k] : 1.0) : 0.0;
+            for (int k = tid; k <= LW + 1; k += NT) wl[k] = k <= lw ? (lw > 0 ? P.taps[P.tap_off[tp] + k] : 1.0) : 0.0;
             tap_now = tp;
         }
         // ---- the source: the previous state (in `cur` since the last barrier), or a shared distribution (prior, restart, uniform) -------
@@ -105,41 +116,70 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         Q.lik = P.lik ? P.lik + (long long)t * n : nullptr;
         double *row = post ? post + (long long)t * n : nullptr;
         double aN = 0.0, aS = 0.0, aC = 0.0, aM = 0.0;
+        // the epilogue of one cell: o = the transition's output (scaled)
+        auto finish = [&](int j, int q, double o) {
+            const double g1 = g1s[j];
+            const double L = blk::likelihood<OM>(Q, 0, j, OM == blk::OM_POISSON ? cAs[j] : 0.0, 0.0, g1);
+            if (!BWD) {
+                const double a = o * L;
+                put(nxt, j, a);
+                if (P.store) row[j] = a;
+                aN += a;
+                if (P.means) aM = fma(a, g1, aM);
+            } else {
+                const double cn = o * L, p = al[q] * o;
+                put(nxt, j, cn);
+                row[j] = p;
+                aN += p; aS += p / L; aC += cn;          // 0/0 -> NaN as numpy (core.py:463)
+                aM = fma(p, g1, aM);
+            }
+        };
+        if (M == 2) {
+            const double *X0 = cur, *X1 = cur + PS;
+            const int A = (lw + 1) >> 1;                 // pairs of taps (the weight beyond the radius is zero)
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int j = tid + q * NT;
-            if (j < n) {
-                const int e = LW + j;
-                double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
-                int k = lw;
-                for (; k >= 4; k -= 4) {
-                    o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
-                    o1 = fma(cur[e - k + 1] + cur[e + k - 1], wl[k - 1], o1);
-                    o2 = fma(cur[e - k + 2] + cur[e + k - 2], wl[k - 2], o2);
-                    o3 = fma(cur[e - k + 3] + cur[e + k - 3], wl[k - 3], o3);
+            for (int g = 0; g < CPT / 2; ++g) {
+                const int j0 = 2 * (tid + g * NT);
+                if (j0 < n) {
+                    const int s0 = (LW + j0) >> 1;
+                    // four accumulators: even / odd taps of both outputs (independent chains)
+                    double e0 = X0[s0] * wl[0], e1 = X1[s0] * wl[0], d0 = 0.0, d1 = 0.0;
+                    double Rc = X1[s0 + A], Lc = X0[s0 - A];                 // x[e + 1 + 2A], x[e - 2A]
+                    for (int a = A; a >= 1; --a) {
+                        const double R0 = X0[s0 + a], L1 = X1[s0 - a], w2 = wl[2 * a], w1 = wl[2 * a - 1];
+                        e0 = fma(Lc + R0, w2, e0);                           // output 0, tap 2a:     x[e - 2a] + x[e + 2a]
+                        e1 = fma(L1 + Rc, w2, e1);                           // output 1, tap 2a:     x[e + 1 - 2a] + x[e + 1 + 2a]
+                        const double Rn = X1[s0 + a - 1], Ln = X0[s0 - a + 1];
+                        d0 = fma(L1 + Rn, w1, d0);                           // output 0, tap 2a - 1: x[e - 2a + 1] + x[e + 2a - 1]
+                        d1 = fma(Ln + R0, w1, d1);                           // output 1, tap 2a - 1: x[e - 2a + 2] + x[e + 2a]
+                        Rc = Rn; Lc = Ln;
+                    }
+                    finish(j0, 2 * g, (e0 + d0) * scale);
+                    if (j0 + 1 < n) finish(j0 + 1, 2 * g + 1, (e1 + d1) * scale);
                 }
-                for (; k >= 1; --k) o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
-                const double o = ((o0 + o1) + (o2 + o3)) * scale;
-                const double g1 = g1s[j];
-                const double L = blk::likelihood<OM>(Q, 0, j, OM == blk::OM_POISSON ? cAs[j] : 0.0, 0.0, g1);
-                if (!BWD) {
-                    const double a = o * L;
-                    put(nxt, j, a);
-                    if (P.store) row[j] = a;
-                    aN += a;
-                    if (P.means) aM = fma(a, g1, aM);
-                } else {
-                    const double cn = o * L, p = al[q] * o;
-                    put(nxt, j, cn);
-                    row[j] = p;
-                    aN += p; aS += p / L; aC += cn;          // 0/0 -> NaN as numpy (core.py:463)
-                    aM = fma(p, g1, aM);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = tid + q * NT;
+                if (j < n) {
+                    const int e = LW + j;
+                    double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
+                    int k = lw;
+                    for (; k >= 4; k -= 4) {
+                        o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+                        o1 = fma(cur[e - k + 1] + cur[e + k - 1], wl[k - 1], o1);
+                        o2 = fma(cur[e - k + 2] + cur[e + k - 2], wl[k - 2], o2);
+                        o3 = fma(cur[e - k + 3] + cur[e + k - 3], wl[k - 3], o3);
+                    }
+                    for (; k >= 1; --k) o0 = fma(cur[e - k] + cur[e + k], wl[k], o0);
+                    finish(j, q, ((o0 + o1) + (o2 + o3)) * scale);
                 }
             }
         }
         if (BWD && s + 1 < P.T) {                     // the stored row of the next step: a whole step to arrive
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) { const int j = tid + q * NT; al[q] = j < n ? post[(long long)(t - 1) * n + j] : 0.0; }
+            for (int q = 0; q < CPT; ++q) { const int j = cell_of(q); al[q] = j < n ? post[(long long)(t - 1) * n + j] : 0.0; }
         }
         // ---- the step's sums: waves -> LDS (this step's parity); the totals go to the host in a fixed order --------------------------
         aN = blk::wave_sum(aN);
@@ -157,7 +197,7 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
     }
     if (P.dst) {
         double *d = P.dst + (long long)b * P.dst_stride;
-        for (int j = tid; j < n; j += NT) d[j] = cur[LW + j];
+        for (int j = tid; j < n; j += NT) d[j] = cur[slot(LW + j)];
     }
 }
 

@@ -101,16 +101,7 @@ struct ChainParams {
 // field that loop uses is therefore copied into a scalar of its own first -- the empty asm makes the copy a separate value the
 // allocator can place, spill or keep on its own (137 v_readlane, 1403 vector instructions).  (The single-chain kernels have few
 // spills -- 35 v_readlane per step -- and do not gain: measured on the ISA, not applied there.)
-template <class T>
-__device__ __forceinline__ T own_sgpr(T v) { asm volatile("" : "+s"(v)); return v; }
-// ... a pointer: copied as an integer and handed back through the GLOBAL address space (behind the asm the compiler no longer sees that
-// the pointer came from a kernel argument and would fall back to flat_load / flat_store)
-template <class T>
-__device__ __forceinline__ T *own_sgpr(T *p) {
-    unsigned long long v = (unsigned long long)p;
-    asm volatile("" : "+s"(v));
-    return (T *)(T __attribute__((address_space(1))) *)v;
-}
+using blr::own_sgpr;
 struct LoopParams {
     int T, d, rec_len, lag, B, nslots, strips, nblk, part_fresh, bprov;
     const double *rec, *sfwd, *zeros, *reset;

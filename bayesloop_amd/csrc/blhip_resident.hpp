@@ -329,7 +329,7 @@ BLR_INL int launder(int x) {
     return x;
 }
 
-template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, bool EVID_ = false, bool PAD_ = false>
+template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, int MODE_ = 0, bool PAD_ = false>
 struct Res {
     static constexpr int TR = TR_, TC = TC_, SEG = SEG_, CHK = CHK_;    // CHK: outputs per chunk of a pass
     static constexpr bool BWD = BWD_;
@@ -340,13 +340,16 @@ struct Res {
     // strips the last tiles hand to their neighbours carry the right values.  Row coordinates continue the lattice beyond the grid (the
     // likelihood recurrence runs through padded rows).
     static constexpr bool PAD = PAD_;
-    // EVID: forward pass of an evidence-only fit -- nothing is stored, no means, no rows to normalise: the flags of ResParams are
-    // compile-time constants (fewer live values: the many-threads shape has 128 registers per thread)
-    static constexpr bool EVID = EVID_;
-    static_assert(!(EVID && BWD), "evidence-only fits have no backward pass");
-    BLR_INL static bool f_store(const ResParams &Q) { return EVID ? false : Q.store != 0; }
-    BLR_INL static bool f_means(const ResParams &Q) { return EVID ? false : Q.means != 0; }
-    BLR_INL static bool f_norm(const ResParams &Q) { return EVID ? false : Q.normalise != 0; }
+    // MODE 1 (EVID): forward pass of an evidence-only fit -- nothing is stored, no means, no rows to normalise: the flags of ResParams
+    // are compile-time constants (fewer live values: the many-threads shape has 128 registers per thread).  MODE 2 (FULLFWD): forward pass
+    // of a FULL fit -- every state stored, no means, no rows to normalise (the backward pass makes the posteriors).  MODE 0: the flags
+    // are read from ResParams (forward-only fits; the backward kernels have no flags).
+    static constexpr int MODE = MODE_;
+    static constexpr bool EVID = MODE_ == 1, FULLFWD = MODE_ == 2;
+    static_assert(!(MODE_ != 0 && BWD), "the forward flavours");
+    BLR_INL static bool f_store(const ResParams &Q) { return EVID ? false : (FULLFWD ? true : Q.store != 0); }
+    BLR_INL static bool f_means(const ResParams &Q) { return MODE != 0 ? false : Q.means != 0; }
+    BLR_INL static bool f_norm(const ResParams &Q) { return MODE != 0 ? false : Q.normalise != 0; }
     BLR_INL static double *f_post(const ResParams &Q) { return EVID ? nullptr : Q.post; }
     static constexpr int P = TC + 1;                 // LDS pitch in doubles: odd => the row-strided accesses of the axis-1 pass
                                                      // and the contiguous ones of the axis-0 pass are both conflict-free
@@ -369,6 +372,17 @@ struct Res {
     // the multi-chunk backward kernel, which requests it when the step begins: with the record's registers alive across the whole
     // step that kernel went from 80 to 254 spilled VGPRs and its step from 25.5 to 44.7 us (2048^2 full fit)
     static constexpr bool REC_AHEAD = !(BWD && !ONE);
+    // The multi-chunk backward kernel runs its axis-0 pass in TWO phases: the stencil alone (filtered values back into the tile, like the
+    // axis-1 pass), then the epilogue over the thread's SEG cells.  The stored forward state the epilogue multiplies by is requested for
+    // the whole segment BEFORE the stencil phase and consumed after it: a full pass (~2 us) for the loads to arrive, and no load that
+    // queues up behind the previous chunk's posterior stores (one counter orders a wave's vector loads and stores: with a load per
+    // chunk every wait for the state also waited for the stores of the chunk before -- 27 us per step at 2048^2, twice the forward pass).
+    // The window registers and the epilogue's registers are never live together (the fused form spilled 70 VGPRs).
+#ifdef BLR_NO_DEFER                   // (A/B builds)
+    static constexpr bool DEFER = false;
+#else
+    static constexpr bool DEFER = BWD && !ONE && !FULLW;
+#endif
     // The lagged global sum is gathered by HALF of the block's waves -- the half that reaches the barrier after the axis-1 pass early
     // (multi-chunk shapes: the edge segments, dealt to the first waves, have issue priority over their SIMD partners; one-chunk
     // shapes: the edge waves wait for their neighbours there, the others are early) -- in that slack, not by everybody after it.
@@ -393,6 +407,21 @@ struct Res {
     // in registers through both passes: far = kind of the far halo (0 neighbour segment in LDS, 1 mirror at the grid edge,
     // 2 the strip of tile nb, side)
     struct Geo { int line, seg, far, nb, side; };
+    // A wave's 64 lanes share their segment when a line has a multiple of 64 positions (t / TR resp. t / TC is constant over the wave).
+    // Handed to the compiler as a SCALAR (readfirstlane) it turns the far-halo cases and the walking direction into scalar branches;
+    // as a per-lane value they were lane masks the allocator kept -- and spilled -- as 64-bit pairs (most of the ~600 v_readlane of the
+    // step loop restore such masks).  Same box, A/B (profiles/r04_notes.md): 2048^2 forward step 10.35 - 10.48 -> 9.74 - 9.80 us.  Only in
+    // the multi-chunk forward kernels: the one-chunk tiles got 4 % SLOWER with it (C3 5.68 / 6.73 -> 5.93 / 6.94 us) and the multi-chunk
+    // backward kernel, which has no register to spare, spilled more (164 -> 280 bytes of scratch).
+#ifdef BLR_NO_UNIFORM_SEG            // (A/B builds)
+    static constexpr bool WAVE_UNIFORM_SEG_H = false, WAVE_UNIFORM_SEG_V = false;
+#else
+#ifdef BLR_UNIFORM_BWD
+    static constexpr bool WAVE_UNIFORM_SEG_H = TR % 64 == 0 && SEG != CHK, WAVE_UNIFORM_SEG_V = TC % 64 == 0 && SEG != CHK;
+#else
+    static constexpr bool WAVE_UNIFORM_SEG_H = TR % 64 == 0 && SEG != CHK && !BWD, WAVE_UNIFORM_SEG_V = TC % 64 == 0 && SEG != CHK && !BWD;
+#endif
+#endif
 
     struct Thread {
         int tid, tile, ti, tj, i0, j0, tr, tc;       // (tile .. tc: block-uniform)
@@ -403,6 +432,7 @@ struct Res {
         double own[FULLW ? SEG : 1];                 // (FULLW) the segment's own inputs, read before the barrier
         double xd[DMAX];                             // this step's data record (wave-uniform)
         double al8[BWD ? CHK : 1];                   // backward: the stored forward state of the chunk being processed
+        double alS[DEFER ? SEG : 1];                 // (DEFER) ... of the thread's whole column segment, in flight across the stencil phase
         unsigned long long gq[GPL][2 * NG];          // this wave's share of the lagged sums' granules, in flight since the step began
         double nz8[BWD ? 1 : CHK];                   // forward-only: the row being normalised (the chunk's cells, `lag` steps back)
         double npred;                                // backward: the sum of this step's posterior, predicted from scalars
@@ -432,14 +462,14 @@ struct Res {
         BLR_INL static int seg_of(int s, int nseg) { return s == 0 ? 0 : (s == 1 ? nseg - 1 : s - 1); }
         BLR_INL Geo hgeo() const {                   // axis-1 pass: a row and a segment of its columns
             const unsigned t = (unsigned)launder(tid);
-            Geo g{(int)(t % TR), seg_of((int)(t / TR), NSH), 0, tile, 0};
+            Geo g{(int)(t % TR), WAVE_UNIFORM_SEG_H ? uni(seg_of((int)(t / TR), NSH)) : seg_of((int)(t / TR), NSH), 0, tile, 0};
             if (g.seg == 0) { if (tj > 0) { g.far = 2; g.nb = tile - 1; g.side = 1; } else g.far = 1; }
             else if (g.seg == NSH - 1) { if (tj < tc - 1) { g.far = 2; g.nb = tile + 1; g.side = 0; } else g.far = 1; }
             return g;
         }
         BLR_INL Geo vgeo() const {                   // axis-0 pass: a column and a segment of its rows
             const unsigned t = (unsigned)launder(tid);
-            Geo g{(int)(t % TC), seg_of((int)(t / TC), NSV), 0, tile, 0};
+            Geo g{(int)(t % TC), WAVE_UNIFORM_SEG_V ? uni(seg_of((int)(t / TC), NSV)) : seg_of((int)(t / TC), NSV), 0, tile, 0};
             if (g.seg == 0) { if (ti > 0) { g.far = 2; g.nb = tile - tc; g.side = 1; } else g.far = 1; }
             else if (g.seg == NSV - 1) { if (ti < tr - 1) { g.far = 2; g.nb = tile + tc; g.side = 0; } else g.far = 1; }
             return g;
@@ -660,6 +690,20 @@ struct Res {
         }
         BLR_INL void v_preread() { const Geo vg = vgeo(); if (vg.seg == 0) v_preread_d<-1>(vg); else v_preread_d<1>(vg); }
 
+        // (DEFER) the stored forward state of the thread's column segment, requested before the axis-0 stencil phase
+        template <int DIR>
+        BLR_INL void alpha_issue_d(const ResParams &Q, int k, const Geo &vg) {
+            const int r0 = first_pos(vg.seg, DIR), c = vg.line;
+            const double *pt0 = row_ptr(Q, k, r0, c);
+            const bool colok = c < clim;
+#pragma unroll
+            for (int p = 0; p < SEG; ++p)
+                alS[p] = (!PAD || (colok && r0 + DIR * p < rlim)) ? ld_stream(pt0 + (long long)(DIR * p) * Q.n1) : 0.0;
+        }
+        BLR_INL void alpha_issue(const ResParams &Q, int k) {
+            if (DEFER) { const Geo vg = vgeo(); if (vg.seg == 0) alpha_issue_d<-1>(Q, k, vg); else alpha_issue_d<1>(Q, k, vg); }
+        }
+
         // backward: the stored forward state alpha_t of positions p0 .. p0+7 (read before the posterior overwrites it in place)
         template <int DIR>
         BLR_INL void load_alpha8(const double *pt0, const double *ptn0, long long n1, int p0, int r0 = 0, bool colok = true) {
@@ -783,15 +827,31 @@ struct Res {
             constexpr bool REC_IN_PASS = !ONE && !FULLW;
             static_assert(!REC_IN_PASS || (SEG - CHK) % ANCHOR != 0, "the last chunk has no anchor (its epilogue does not read the record)");
             auto pre8 = [&](int p0) {
-                load_alpha8<DIR>(pt0, ptn0, Q.n1, p0, r0, c < clim);
+                if (!DEFER) load_alpha8<DIR>(pt0, ptn0, Q.n1, p0, r0, c < clim);
                 if (REC_AHEAD && REC_IN_PASS && p0 == SEG - CHK && k + 1 < Q.T) begin_step(Q, k + 1);
             };
-            auto emit8 = [&](int p0, const double (&v)[CHK]) { epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim); };
+            auto emit8 = [&](int p0, const double (&v)[CHK]) {
+                if constexpr (DEFER) {               // stencil phase: the filtered values back into the tile
+#pragma unroll
+                    for (int j = 0; j < CHK; ++j) x0[DIR * (p0 + j) * P] = v[j];
+                } else {
+                    epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim);
+                }
+            };
             double wk[R + 1];
 #pragma unroll
             for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
             if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
             else walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
+            if constexpr (DEFER) {                   // epilogue phase: the thread's own cells (nobody else reads them before the step's last barrier)
+#pragma unroll
+                for (int p0 = 0; p0 < SEG; p0 += CHK) {
+                    double v[CHK];
+#pragma unroll
+                    for (int j = 0; j < CHK; ++j) { v[j] = x0[DIR * (p0 + j) * P]; al8[j] = alS[p0 + j]; }
+                    epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim);
+                }
+            }
             if (REC_AHEAD && !REC_IN_PASS && k + 1 < Q.T) begin_step(Q, k + 1);
         }
         BLR_INL void v_walk(const ResParams &Q, int k) {
@@ -878,9 +938,30 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, bool EVID = false, bool PAD = false>
+// The kernel arguments arrive as 16-register tuples (s_load_dwordx16) and the register allocator spills and restores a tuple as ONE unit:
+// with ~100 live scalars in the step loop a single field of the argument struct costs a 16-lane v_readlane burst per use (measured on the
+// two-chain fold kernel, blhip_chainres.hpp: 304 -> 137 v_readlane per chain-step).  own_sgpr() copies a value into a scalar of its own --
+// the empty asm makes the copy a separate value the allocator can place, spill or rematerialise by itself; a pointer is copied as an
+// integer and handed back through the GLOBAL address space (behind the asm the compiler no longer sees that it came from a kernel
+// argument and would fall back to flat loads / stores).
+template <class T>
+__device__ __forceinline__ T own_sgpr(T v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ double own_sgpr(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    asm volatile("" : "+s"(b));
+    return __longlong_as_double((long long)b);
+}
+template <class T>
+__device__ __forceinline__ T *own_sgpr(T *p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (T *)(T __attribute__((address_space(1))) *)v;
+}
+// (Applied to this file's own kernel it changes nothing -- 633 -> 612 v_readlane per step loop: what spills here are lane masks of the
+//  control flow, not argument tuples; measured on the ISA, not kept.)
+template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE = 0, bool PAD = false>
 __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Q) {
-    using K = Res<TR, TC, SEG, CHK, BWD, EVID, PAD>;
+    using K = Res<TR, TC, SEG, CHK, BWD, MODE, PAD>;
     constexpr int NT = K::NT, NW = K::NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *misc = lds + K::LDS_MISC;
@@ -915,7 +996,7 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
     // segment with issue priority over its SIMD partner; one-chunk shapes: an interior segment that neither waits for a neighbour nor
     // gathers the lagged sum).
     constexpr int BOOK_WAVE = K::ONE ? (NW >= 2 ? NW / 2 - 1 : 0) : 0;
-    const bool booker = (tid >> 6) == BOOK_WAVE;
+    const bool booker = K::WAVE_UNIFORM_SEG_H ? uni(tid >> 6) == BOOK_WAVE : (tid >> 6) == BOOK_WAVE;
     auto book = [&](int kb) {                         // (the whole wave: lane w fetches wave w's sums, one tree adds them)
         constexpr int NV = BWD ? 5 : 3;
         const int lane = tid & 63;
@@ -946,6 +1027,9 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             th.begin_step(Q, k);
             th.first_step(Q);
         } else {
+#ifdef BLR_ALPHA_EARLY                 // (A/B builds: the stored state requested before the axis-1 pass)
+            th.alpha_issue(Q, k);
+#endif
             th.h_preread();
             BLR_STAMP(1);
             if (k >= Q.lag && gw >= 0) th.gather_issue(Q, k - Q.lag);
@@ -953,6 +1037,9 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             lds_barrier();
             BLR_STAMP(3);
             th.h_walk(Q, k);
+#ifndef BLR_ALPHA_EARLY
+            th.alpha_issue(Q, k);
+#endif
             BLR_STAMP(4);
             if (booker) book(k - 1);
             BLR_STAMP(5);

@@ -11,7 +11,26 @@ for p in (HERE, ROOT):
 if os.environ.get('PYTEST_XDIST_WORKER'):
     # several test processes share ONE GPU (pytest -n 4): a resident launch may wait long for blocks another process's kernels keep off
     # the chip -- the flat 2-second bound of round 3 instead of the pass-scaled default (resident_timeout_s)
-    os.environ.setdefault('BLHIP_ENGINE_OPTS', 'resident_timeout_s=2')
+    os.environ.setdefault('BLHIP_ENGINE_OPTS', 'resident_timeout_s=4')
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _rearm_resident_paths(request):
+    """A resident launch that gives up (four test processes share the GPU: a block can starve) parks the resident paths of its context
+    for the next 8 fits -- the product's behaviour -- and every following test that asserts WHICH kernel ran would fail with it.  Each
+    GPU test starts from an armed context; the test in which a give-up happens still reports it."""
+    if 'gpu' in request.keywords:
+        try:
+            import bayesloop_amd.engine as em
+            eng = em._engine
+            if eng is not None and hasattr(eng, 'ctx'):
+                eng.set_option('resident_ok', 1)
+        except Exception:
+            pass
+    yield
 
 
 def pytest_configure(config):

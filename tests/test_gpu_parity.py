@@ -290,6 +290,7 @@ def test_big_read_backs_move_to_page_locked_arrays_after_the_first():
     if not pool.enabled:
         pytest.skip('BLHIP_PINNED_RESULTS=0')
     pool.release()
+    pool.released = False                                 # (release() is the engine's teardown: re-open the pool for this test)
     c = dict(study='Study', data=('series', 77, 66), om=cases.gauss2d(256, -6, 6, 3), tm=('GRW', 's1', 0.2, 'mean', None))
     S = cases.build(bl, c); S.fit(silent=True)
     assert pool.free is None and pool.deferred == 0

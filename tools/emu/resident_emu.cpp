@@ -163,6 +163,7 @@ static int run(int tr, int tc, int T, int lag, unsigned seed, bool one_axis, int
                 for (auto &x : th) x.h_preread();
                 if (k >= lag) for (auto &x : th) if (x.gather_wave() >= 0) x.gather_issue(Q, k - lag);
                 for (auto &x : th) x.h_walk(Q, k);
+                for (auto &x : th) x.alpha_issue(Q, k);
                 for (auto &x : th) x.publish_rows(Q, k);
                 for (auto &x : th) x.v_preread();
                 if (k >= lag)
