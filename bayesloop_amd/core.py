@@ -496,14 +496,12 @@ class Study(object):
                     #  two break-points evaluates each (parameters, first break-point) pair once, not once per chain)
                     names_k = [model.hyperParameterNames[slots[i][1]] for i in cols]
                     key_cols = cols + ([] if off_col is None else [off_col])
-                    tables, rows = {}, []
-                    for c in range(n):
-                        key = hyper_rows[c, key_cols].tobytes()
-                        if key not in tables:
-                            tables[key] = model.shifts(dict(zip(names_k, hyper_rows[c, cols])), ts, resume_time,
-                                                       t_offset=None if off_col is None else hyper_rows[c, off_col])
-                        rows.append(tables[key])
-                    shift_cache[id(model)] = np.array(rows)
+                    keys = hyper_rows[:, key_cols]
+                    uniq, inv = (np.unique(keys, axis=0, return_inverse=True) if key_cols
+                                 else (np.zeros((1, 0)), np.zeros(n, dtype=np.intp)))
+                    tables = np.array([model.shifts(dict(zip(names_k, u[:len(cols)])), ts, resume_time,
+                                                    t_offset=None if off_col is None else u[-1]) for u in uniq])
+                    shift_cache[id(model)] = tables[np.asarray(inv).reshape(-1)]      # (n_chains, 2 T): one gather
                 out[:, j] = shift_cache[id(model)][:, k[1]]
                 continue
             col = [i for i, sl in enumerate(slots) if sl[0] is model and sl[1] == k][0]

@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <exception>
 #include <map>
+#include <memory>
+#include <unordered_map>
 #include <mutex>
 #include <set>
 #include <string>
@@ -65,7 +68,9 @@ struct TapTable {
     // (prefilter impulse response x B-spline), |m| <= ceil|d| + 34, over the extension blk::extend_index(rule 2) builds.
     // Exact for |d| <= 12 (beyond, SciPy extends the COEFFICIENTS by their edge values: oracle/bl_oracle.py).  Stored with all
     // 2 lw + 1 weights; lw2 = -1 marks the asymmetric layout.
-    std::map<std::pair<int, double>, int> index_shift;
+    struct PairHash { size_t operator()(const std::pair<int, double> &k) const { unsigned long long b; std::memcpy(&b, &k.second, 8); return (size_t)((b * 0x9E3779B97F4A7C15ull) >> 7) ^ (size_t)k.first; } };
+    struct DblHash { size_t operator()(double d) const { unsigned long long b; std::memcpy(&b, &d, 8); return (size_t)((b * 0x9E3779B97F4A7C15ull) >> 7); } };
+    std::unordered_map<std::pair<int, double>, int, PairHash> index_shift;      // (looked up once per step and chain inside a Deterministic segment)
     int get_shift(int axis, double d) {
         auto key = std::make_pair(axis, d);
         auto it = index_shift.find(key);
@@ -96,7 +101,7 @@ struct TapTable {
     // oracle/bl_oracle.py: spline_shift_nearest -- prefilter the padded row (symmetric, radius 34, weights below), then evaluate the cubic
     // B-spline at the shifted coordinates with the coefficient index clamped.  Stored as [d, g(0) .. g(34)]; lw = 12 + 34 is the halo the
     // row needs, lw2 = -2 marks the layout.
-    std::map<double, int> index_bigshift;
+    std::unordered_map<double, int, DblHash> index_bigshift;
     int get_bigshift(double d) {
         auto it = index_bigshift.find(d);
         if (it != index_bigshift.end()) return it->second;
@@ -450,8 +455,20 @@ void launch_chain1d_m(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t l
     }
 }
 template <int OM>
+void launch_chain1d_shift(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {       // programs with Deterministic steps
+    if (bwd) {
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true, 1, true>));
+        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, true, 1, true>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+    } else {
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false, 1, true>));
+        hipLaunchKernelGGL((bl1c::chain1d_kernel<OM, false, 1, true>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+    }
+}
+template <int OM>
 void launch_chain1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds, int m) {
-    if (m == 2) launch_chain1d_m<OM, 2>(s, P, bwd, lds); else launch_chain1d_m<OM, 1>(s, P, bwd, lds);
+    if (P.cmode) launch_chain1d_shift<OM>(s, P, bwd, lds);
+    else if (m == 2) launch_chain1d_m<OM, 2>(s, P, bwd, lds);
+    else launch_chain1d_m<OM, 1>(s, P, bwd, lds);
 }
 
 // the (T, n) likelihood table every chain of a 1-D batch shares (bl1c::lik1d_table_kernel: the in-kernel function, evaluated once)
@@ -465,7 +482,7 @@ void build_lik1d_table(hipStream_t s, int om, const bl1f::F1Params &P, double *o
 
 // cells per thread: 2 adjacent ones (sharing their stencil operands) for rows longer than a block, else 1 (option chain1d_pair: 0 / 1 force)
 void launch_chain1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, int pair_mode) {
-    const size_t lds = bl1c::lds_doubles(P.n, P.LW) * sizeof(double);
+    const size_t lds = bl1c::lds_doubles(P.n, P.LW, P.cmode != nullptr) * sizeof(double);
     const int m = pair_mode == 0 ? 1 : ((pair_mode == 1 || P.n > bl1c::NT) ? 2 : 1);
     switch (om) {
         case BLHIP_OM_POISSON: launch_chain1d_om<OM_POISSON>(s, P, bwd, lds, m); break;
@@ -515,9 +532,10 @@ void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
 template <int TR, int TC, int SEG, int CHK>
 void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad = false) {
     // forward pass of an evidence-only fit (nothing stored, no means, no rows to normalise) / of a full fit (every state stored, no
-    // means, no rows to normalise): the flavours with compile-time flags (blr::Res MODE 1 / 2); forward-only fits: flags at run time
+    // means, no rows to normalise): / of a forward-only fit: the flavours with compile-time flags (blr::Res MODE 1 / 2 / 3); padded grids: flags at run time
     const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
     const bool fullfwd = !bwd && Q.store && !Q.means && !Q.normalise && Q.post;
+    const bool fwdonly = !bwd && Q.store && Q.means && Q.normalise && Q.post;
     if (pad) {                   // grids that do not fill their last tile row / column
         if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0, true>(s, Q);
         else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1, true>(s, Q);
@@ -527,7 +545,12 @@ void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pa
     if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0>(s, Q);
     else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1>(s, Q);
     else if (fullfwd) launch_resident_k<TR, TC, SEG, CHK, false, 2>(s, Q);
-    else launch_resident_k<TR, TC, SEG, CHK, false, 0>(s, Q);
+    else {
+        if constexpr (SEG == CHK) {               // (the multi-chunk shape spills 48 VGPRs with it, 6 without)
+            if (fwdonly) { launch_resident_k<TR, TC, SEG, CHK, false, 3>(s, Q); return; }
+        }
+        launch_resident_k<TR, TC, SEG, CHK, false, 0>(s, Q);
+    }
 }
 
 // tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
@@ -793,6 +816,7 @@ struct ChainProgram {
     int LW0 = 0, LW1 = 0;
     bool has_clamp = false;
     bool whole_row = false;      // a two-stage spline shift (Deterministic, |d| > 12): a block needs the whole row of a 1-D grid
+    bool other_clamp = false;    // has_clamp for another reason than a Deterministic model's shift (mode 6)
 };
 
 struct StepProg {
@@ -814,6 +838,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
     prog.LW0 = prog.LW1 = 0;
     prog.has_clamp = false;
     prog.whole_row = false;
+    prog.other_clamp = false;
     double dV = 1.0;
     for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
     // the ops a step's program is made of (the *_ARG ops only carry values of the op in front of them: a Deterministic model has 2 T of
@@ -823,10 +848,26 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
         const int kind = p->ops[k].kind;
         if (kind != BLHIP_OP_DETERMINISTIC_ARG && kind != BLHIP_OP_BIVARIATE_ARG && kind != BLHIP_OP_ALPHASTABLE_ARG) real_ops.push_back(k);
     }
+    // (a chain's T steps are T entries B apart in each of the ten arrays: written chain by chain that is one cache line per entry --
+    //  half of the 30 ms this function took for the 23 400 chains x 41 steps of the published break-point study.  The steps of GROUP
+    //  chains are collected first and written out as runs of GROUP consecutive entries)
+    constexpr int GROUP = 64;
+    std::vector<StepProg> gF((size_t)GROUP * T), gB((size_t)GROUP * T);
+    auto flush_group = [&](int64_t b0, int64_t nb) {
+        for (int64_t t = 0; t < T; ++t) {
+            const size_t k0 = (size_t)t * B + b0;
+            for (int64_t q = 0; q < nb; ++q) {
+                const StepProg &f = gF[(size_t)q * T + t], &r = gB[(size_t)q * T + t];
+                prog.kindF[k0 + q] = f.kind; prog.tapF0[k0 + q] = f.t0; prog.tapF1[k0 + q] = f.t1; prog.cmodeF[k0 + q] = f.cmode; prog.limitF[k0 + q] = f.limit;
+                prog.kindB[k0 + q] = r.kind; prog.tapB0[k0 + q] = r.t0; prog.tapB1[k0 + q] = r.t1; prog.cmodeB[k0 + q] = r.cmode; prog.limitB[k0 + q] = r.limit;
+            }
+        }
+    };
+    std::vector<int> op_tap(nops, -1), op_axis(nops, -1);
     for (int64_t b = 0; b < B; ++b) {
         const double *val = op_values ? op_values + (c0 + b) * nops : nullptr;
         // tap ids of this chain's GRW ops
-        std::vector<int> op_tap(nops, -1), op_axis(nops, -1);
+        std::fill(op_tap.begin(), op_tap.end(), -1); std::fill(op_axis.begin(), op_axis.end(), -1);
         bool time_dependent = false;
         for (int k = 0; k < nops; ++k) {
             const blhip_op &op = p->ops[k];
@@ -839,7 +880,7 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
             } else if (op.kind == BLHIP_OP_CHANGEPOINT || op.kind == BLHIP_OP_BREAKPOINT) {
                 time_dependent = true;
             } else if (op.kind == BLHIP_OP_REGIMESWITCH || op.kind == BLHIP_OP_NOTEQUAL) {
-                prog.has_clamp = true;
+                prog.has_clamp = true; prog.other_clamp = true;
             } else if (op.kind == BLHIP_OP_DETERMINISTIC) {
                 time_dependent = true;                       // a different shift at every step
                 op_axis[k] = g.axis_map[op.axis];
@@ -849,14 +890,14 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                 if (std::isnan(c) || std::isnan(alpha)) fail("chain %lld: AlphaStableRandomWalk parameters are NaN", (long long)(c0 + b));
                 op_axis[k] = g.axis_map[op.axis];
                 op_tap[k] = taps.get_alphastable(op_axis[k], c, alpha, (int)p->n[op.axis]);
-                prog.has_clamp = true;                       // (mode 5 of the generic kernel: zero boundary + renormalisation)
+                prog.has_clamp = true; prog.other_clamp = true;      // (mode 5 of the generic kernel: zero boundary + renormalisation)
             } else if (op.kind == BLHIP_OP_BIVARIATE) {
                 // transitionModels.py:881-885; a singular covariance makes scipy.stats.multivariate_normal raise in the reference
                 const double n1 = val[k] / p->lattice[0], n2 = val[k + 1] / p->lattice[1], rho = val[k + 2];
                 if (!(n1 > 0.0) || !(n2 > 0.0) || !(std::fabs(rho) < 1.0))
                     fail("chain %lld: BivariateRandomWalk needs sigma1, sigma2 > 0 and |rho| < 1", (long long)(c0 + b));
                 op_tap[k] = taps.get2d(n1, n2, rho);
-                prog.has_clamp = true;                       // (mode 4 of the generic kernel: dense kernel + renormalisation)
+                prog.has_clamp = true; prog.other_clamp = true;      // (mode 4 of the generic kernel: dense kernel + renormalisation)
             }
         }
         // the transition from one step to the next, evaluated at time stamp tau (list order, transitionModels.py:645-649)
@@ -963,10 +1004,9 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
             // backward step t consumes T_bwd(beta_{t+1} L_{t+1}, ts[t+1]) = T_fwd(., ts[t+1] - 1)   core.py:467, transitionModels.py:316-317
             StepProg r; r.kind = SRC_UNIFORM;
             if (t < T - 1) r = time_dependent ? run(p->timestamps[t + 1] - 1.0, true, t, false) : stat;
-            const size_t k = (size_t)t * B + b;
-            prog.kindF[k] = f.kind; prog.tapF0[k] = f.t0; prog.tapF1[k] = f.t1; prog.cmodeF[k] = f.cmode; prog.limitF[k] = f.limit;
-            prog.kindB[k] = r.kind; prog.tapB0[k] = r.t0; prog.tapB1[k] = r.t1; prog.cmodeB[k] = r.cmode; prog.limitB[k] = r.limit;
+            gF[(size_t)(b % GROUP) * T + t] = f; gB[(size_t)(b % GROUP) * T + t] = r;
         }
+        if (b % GROUP == GROUP - 1 || b == B - 1) flush_group(b - b % GROUP, b % GROUP + 1);
     }
 }
 
@@ -1204,6 +1244,7 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
 // which kernel family runs a batch and with what block geometry (segment lengths from a small cost model: long segments read every
 // element once + 2 R0 halo rows per segment, short ones give enough blocks to fill 256 CUs when there are few chains)
 struct GeometryPlan {
+    bool shift1d = false;        // the chain-resident 1-D kernel's flavour with spline shifts (Deterministic steps)
     bool fast = false, fused1d = false, use_mfma = false;
     bool chain1d = false;         // 1-D batches: one block per chain runs the whole pass (blhip_chain1d.hpp); bookkeeping of a K = 1 fused pass
     bool wideH = false;           // axis-1 walks wider than the fused kernels' halo: row filter as a pre-pass per step (blhip_hwide.hpp)
@@ -1243,7 +1284,10 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
         }
         gp.hSplit = any_narrow || any_none;
     }
-    if (p->ndim == 1 && !gp.fast && !prog.has_clamp && ctx->option("fuse1d", 8.0) >= 1.0 &&
+    // (programs whose only clamp mode is a Deterministic model's spline shift: the chain-resident kernel has a flavour for them
+    //  -- bl1c::chain1d_kernel SHIFT --, the K-steps-per-launch and persistent kernels have not: chain1d or the generic kernel)
+    const bool shift1d = p->ndim == 1 && prog.has_clamp && !prog.other_clamp && ctx->option("chain1d_shift", 1.0) != 0.0;
+    if (p->ndim == 1 && !gp.fast && (!prog.has_clamp || shift1d) && ctx->option("fuse1d", 8.0) >= 1.0 &&
         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
         gp.f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
         gp.fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
@@ -1256,8 +1300,9 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
         // share a CU one after the other; the K-steps-per-launch path costs a launch (~14 k cycles) every K steps, the persistent
         // one (all blocks of all chains on the chip at once) ~4 k (K > 1) / ~7 k (K = 1: a hand-off per step) per step.
         const double c1d_mode = ctx->option("chain1d", 1.0);
+        if (shift1d) gp.fused1d = true;              // (decided below: without the chain-resident kernel the batch keeps the generic one)
         if (gp.fused1d && c1d_mode != 0.0 && !resume && !carry && prog.LW1 < g.n1 && g.n1 <= bl1c::NMAX &&
-            bl1c::lds_doubles(g.n1, prog.LW1) * 8 <= 150 * 1024) {
+            bl1c::lds_doubles(g.n1, prog.LW1, shift1d) * 8 <= 150 * 1024) {
             // microseconds per time step of the whole batch, fitted to tools/probe.py chain1d (profiles/r04_notes.md): a block's step =
             // 1.5 us + 1.0 ns per cell (likelihood from the shared table; 2.2 ns with Poisson's pow() in the kernel) + 44 ps per cell and
             // tap (the stencil's operand pairs come out of ONE CU's LDS at ~9 per clock), blocks beyond the chip's capacity queue up;
@@ -1271,9 +1316,11 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
             const int nblk_f = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ;
             const bool p1d_ok = ctx->option("persist1d", 1.0) != 0.0 && (long long)nblk_f * B <= cus && T > gp.fusedK;
             const double est_other = p1d_ok ? 1.7 + 0.04 * lw : 1.5 + (double)B * n * (29.0 + 0.63 * lw) * 1e-6;
-            gp.chain1d = c1d_mode == 2.0 || (B >= 2 && est_c1d < est_other);
+            gp.chain1d = c1d_mode == 2.0 || (B >= 2 && (shift1d || est_c1d < est_other));     // (shift1d: the alternative is a launch per step)
             if (gp.chain1d) { gp.fusedK = 1; gp.f1_TJ = g.n1; }
         }
+        if (shift1d && !gp.chain1d) gp.fused1d = false;
+        gp.shift1d = shift1d && gp.chain1d;
     }
     if (gp.fast) {
         gp.tile.TI = blf::CH; gp.tile.LW0 = gp.wideV ? 0 : prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && (!gp.wideH || (gp.hSplit && any_narrow))) ? blf::R1MAX : 0;
@@ -1500,6 +1547,9 @@ void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hip
         hipLaunchKernelGGL(accumulate_pad_kernel, dim3((unsigned)((G + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
                            job.d_post, (long long)T * job.pad_step, (int)B, job.pad_n0, job.pad_n1, (int)T, job.d_w, job.d_invN, job.r, job.first,
                            job.pad_n0p, job.pad_step);
+    } else if (job.sm_n0 == 0 && B >= 16 && ((G / 2 + NTHREADS - 1) / NTHREADS) * T < 1024) {        // small grids: too few blocks with a thread per cell
+        hipLaunchKernelGGL(accumulate_small_kernel, dim3((unsigned)((G + 63) / 64), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
+                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
     } else if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
         const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
         hipLaunchKernelGGL(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
@@ -1690,24 +1740,30 @@ bool forward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, const
     O.abort_phase.assign(B, 0);
     O.local.assign((size_t)B * T, 0.0);
     bool raw_ok = true;
-    for (int64_t b = 0; b < B; ++b) {
-        double le = 0.0;
-        for (int64_t t = 0; t < T; ++t) {
-            double norm = redF[((size_t)t * B + b) * NRED + 0];
+    // (step by step over all chains: the sums of a step are B consecutive records -- chain by chain every read was a cache line of
+    //  its own, 8 ms of the published break-point study's 23 batches of 1017 chains x 41 steps.  Per chain the order of the
+    //  operations is the one of the reference's loop)
+    std::vector<double> &le = O.logE;
+    for (int64_t t = 0; t < T; ++t) {
+        const double *rt = redF + (size_t)t * B * NRED;
+        for (int64_t b = 0; b < B; ++b) {
+            if (O.abort_step[b] >= 0) continue;
+            double norm = rt[b * NRED + 0];
             if (fused1d) {
                 // raw sums of the K-step launches (blhip_fused1d.hpp): inner steps carry the scale of their predecessor
                 if (!(norm > 1e-200)) raw_ok = false;
                 if (t % K != 0 && prog.kindF[(size_t)t * B + b] == SRC_PREV) norm /= redF[((size_t)(t - 1) * B + b) * NRED];
             }
             // RegimeSwitch renormalises the clamped prior (transitionModels.py:410): alpha = (u / sum u) L
-            if (prog.has_clamp && prog.cmodeF[(size_t)t * B + b]) norm /= redF[((size_t)t * B + b) * NRED + 1];
-            if (!(norm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 0; le = -INFINITY; break; }
-            le += std::log(norm);
+            if (prog.has_clamp && prog.cmodeF[(size_t)t * B + b]) norm /= rt[b * NRED + 1];
+            if (!(norm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 0; le[b] = -INFINITY; continue; }
+            le[b] += std::log(norm);
             O.local[(size_t)b * T + t] = norm * dV;
         }
-        if (O.abort_step[b] < 0) le += std::log(dV);
-        O.logE[b] = le;
     }
+    const double ldv = std::log(dV);
+    for (int64_t b = 0; b < B; ++b)
+        if (O.abort_step[b] < 0) le[b] += ldv;
     O.means.clear();
     if (!evidence_only) O.means.assign((size_t)B * p->ndim * T, 0.0);
     if (forward_only) {
@@ -1726,9 +1782,9 @@ bool backward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, cons
                           bool fused1d, int64_t rows_done_from, BatchOutcome &O) {
     const int64_t T = p->T;
     bool raw_ok = true;
-    for (int64_t b = 0; b < B; ++b) {
-        if (O.abort_step[b] >= 0) continue;
-        for (int64_t t = T - 1; t >= 0; --t) {
+    for (int64_t t = T - 1; t >= 0; --t) {           // (step by step over all chains: see forward_bookkeeping)
+        for (int64_t b = 0; b < B; ++b) {
+            if (O.abort_step[b] >= 0) continue;
             const double *r = &redB[((size_t)t * B + b) * NRED];
             if (fused1d && !(r[0] > 1e-200)) raw_ok = false;
             // The reference tests sum(alpha_norm * beta_norm) > 0 (core.py:441).  r[0] is the same sum up to the lazily
@@ -1737,7 +1793,7 @@ bool backward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, cons
             // the reference divides by them, so the sign test has to include them.
             double refnorm = r[0];
             if (prog.has_clamp) refnorm = r[0] / (redF[((size_t)t * B + b) * NRED] * (prog.cmodeB[(size_t)t * B + b] ? r[5] : 1.0));
-            if (!(refnorm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 1; O.logE[b] = -INFINITY; break; }
+            if (!(refnorm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 1; O.logE[b] = -INFINITY; continue; }
             O.local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
             O.invN[(size_t)b * T + t] = (rows_done_from >= 0 && t >= rows_done_from) ? 1.0 : 1.0 / r[0];
             for (int k = 0; k < p->ndim; ++k) O.means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
@@ -1854,12 +1910,27 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         HIPCHECK(hipStreamCreateWithFlags(&ctx->astream, hipStreamNonBlocking));
         for (auto &e : ctx->aev_done) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    // The per-(step, chain) programs of batch bi + 1 are built on the host while the GPU runs the forward pass of batch bi (the
+    // reference's published break-point study: 23 batches of 1017 chains x 41 steps, 30 ms of build_program of a 130-ms fit).  A failure
+    // of the early build is raised where the build used to be: at the top of that batch.
+    struct BatchProgram { TapTable taps; ChainProgram prog; bool ready = false; std::exception_ptr err; };
+    std::unique_ptr<BatchProgram> bprog[2];
+    auto build_batch = [&](int64_t bj) {
+        std::unique_ptr<BatchProgram> &N = bprog[bj & 1];
+        N.reset(new BatchProgram());
+        try { build_program(p, g, batch_start[bj], batch_start[bj + 1] - batch_start[bj], op_values, N->taps, N->prog, resume); }
+        catch (...) { N->err = std::current_exception(); }
+        N->ready = true;
+    };
     for (int64_t bi = 0; bi < nbatch; ++bi) {
         const int64_t c0 = batch_start[bi], B = batch_start[bi + 1] - c0;
-        TapTable taps;
-        ChainProgram prog;
         tr.mark("batch setup");
-        build_program(p, g, c0, B, op_values, taps, prog, resume);
+        if (!bprog[bi & 1] || !bprog[bi & 1]->ready) build_batch(bi);
+        BatchProgram &BP = *bprog[bi & 1];
+        BP.ready = false;                        // (consumed: the slot is rebuilt for batch bi + 2)
+        if (BP.err) std::rethrow_exception(BP.err);
+        TapTable &taps = BP.taps;
+        ChainProgram &prog = BP.prog;
         tr.mark("build_program");
         const GeometryPlan gp = plan_geometry(ctx, p, g, prog, B, d, resume, carry, &taps);
         const bool fast = gp.fast, fused1d = gp.fused1d, use_mfma = gp.use_mfma;
@@ -2111,6 +2182,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             F1.shared[SRC_PREV] = nullptr; F1.shared[SRC_PRIOR] = d_prior; F1.shared[SRC_RESET] = d_reset;
             F1.shared[SRC_UNIFORM] = d_uniform; F1.shared[SRC_INDEP] = d_indep;
             F1.taps = d_taps; F1.tap_off = d_off; F1.tap_lw = d_lw; F1.m1 = d_m1; F1.colA = d_colA; F1.rec = d_rec; F1.lik = d_lik;
+            F1.cmode = nullptr; F1.tap_lw2 = d_lw2;
         }
         tr.mark("path setup");
         // --- forward pass (core.py:372-411) ---
@@ -2138,6 +2210,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (d_lik1) Q.lik = d_lik1;
             Q.K = 1; Q.dir = bwd ? -1 : 1; Q.t_first = bwd ? (int)(T - 1) : 0; Q.psum = psum; Q.prev_slot = bwd ? 2 : 0;
             Q.srckind = bwd ? d_kindB : d_kindF; Q.tap = bwd ? d_tapB1 : d_tapF1;
+            if (gp.shift1d) Q.cmode = bwd ? d_cmodeB : d_cmodeF;
             Q.store = (bwd || !evidence_only) ? 1 : 0; Q.means = bwd ? 1 : (forward_only ? 1 : 0);
             Q.post = (bwd || !evidence_only) ? d_post : nullptr; Q.post_stride = (long long)T * G;
             Q.src = nullptr; Q.src_stride = 0; Q.dst = nullptr; Q.dst_stride = 0;
@@ -2238,6 +2311,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         redF = ctx->pinF.as<double>();
         HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
         tr.mark("forward pass queued");
+        if (bi + 1 < nbatch) { build_batch(bi + 1); tr.mark("next batch's program"); }
         sync_stream(ctx, st);
         tr.mark("forward pass done + sums D2H");
         ms = 0;
@@ -2259,7 +2333,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (resident_gave_up(ctx, st, d_abort1)) { resident_failed = true; return false; }
         }
 
-        bool raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
+        // (the launch-per-step backward pass of a batch of chains needs nothing of the forward pass's host bookkeeping: it is done
+        //  while the GPU runs that pass -- 11 ms of the published break-point study's fit, 23 batches of 1017 chains)
+        const bool late_fb = full && !fused1d && !res_now && !cres_now && !p1d_now && B >= 64;
+        bool raw_ok = late_fb ? true : forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
         tr.mark("forward checks + bookkeeping");
 
         // --- backward pass (core.py:424-470) ---
@@ -2307,6 +2384,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             redB = ctx->pinB.as<double>();
             HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
             tr.mark("backward pass queued");
+            if (late_fb) { raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O); tr.mark("forward bookkeeping (behind the backward pass)"); }
             sync_stream(ctx, st);
             tr.mark("backward pass done + sums D2H");
             HIPCHECK(hipEventElapsedTime(&ms, ev[2], ev[3]));

@@ -25,8 +25,12 @@ constexpr int NW = NT / 64;
 constexpr int NMAX = 4096;         // cells per row: at most 8 per thread (the stored forward row of the next step waits in registers)
 constexpr int CPT = NMAX / NT;
 
-// doubles of LDS: two state buffers with halo, grid values, exp(-lambda) (Poisson), weights, the waves' partial sums (two parities)
-inline size_t lds_doubles(int n, int LW) { return (size_t)2 * (n + 1 + 2 * (LW + 1)) + 2 * (size_t)n + (LW + 3) + 2 * NW * 4 + 8; }
+constexpr int NS = 5;              // sums of a step per wave: N, sum p / L, sum c, mean, mass of the shifted distribution (SHIFT)
+// doubles of LDS: two state buffers with halo, grid values, exp(-lambda) (Poisson), weights, the waves' partial sums (two parities);
+// shift: + the other half of an asymmetric tap set and the spline coefficients of the 12-padded row (two-stage shifts)
+inline size_t lds_doubles(int n, int LW, bool shift = false) {
+    return (size_t)2 * (n + 1 + 2 * (LW + 1)) + 2 * (size_t)n + (LW + 3) + 2 * NW * NS + 8 + (shift ? (size_t)LW + 40 + n + 24 : 0);
+}
 
 // The likelihood of a 1-D batch is the same for every chain (same data, same grid: only the transition differs).  Poisson's pow() per
 // cell and step was most of a short-radius step (n = 4000, radius 8: 11.6 us per step of which ~9 are the likelihood); evaluated ONCE
@@ -48,14 +52,22 @@ __global__ __launch_bounds__(256) void lik1d_table_kernel(const bl1f::F1Params P
 // output 0 at tap k is the one of output 1 at tap k - 1, likewise on the left) and their weights: per PAIR of taps 4 operand reads + 2
 // weight reads serve 4 output-taps, 1.5 reads per output and tap.  Used for rows of more than NT cells (below, one cell per thread keeps
 // all waves busy).
-template <int OM, bool BWD, int M = 1>
+// SHIFT: the batch's programs contain Deterministic steps (clamp mode 6; transitionModels.py:571-602): scipy.ndimage.shift(order = 3,
+// mode = 'nearest') of the row, as in the launch-per-step kernel (blk::step_kernel, modes asym1 / big1) -- an asymmetric stencil of
+// 2 lw + 1 weights over the extension SciPy works on (12 edge samples, then half-sample reflection: blk::extend_index rule 2) for
+// |d| <= 12 cells, the two-stage form beyond (prefilter of the padded row, cubic B-spline at the shifted coordinates with the coefficient
+// index clamped).  The reference renormalises the shifted distribution: its mass goes to the host as one more sum per step (slot 1
+// forward, slot 5 backward, as the launch-per-step kernel's).  One cell per thread and pass over the row (M = 1).
+template <int OM, bool BWD, int M = 1, bool SHIFT = false>
 __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
+    static_assert(!(SHIFT && M != 1), "spline shifts: one cell per thread");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = P.n;
     const int LW = M == 2 ? (P.LW + 1) & ~1 : P.LW;                  // (M = 2: an even halo, so that cell 0 sits in plane 0)
     const int W = M == 2 ? ((n + 1) & ~1) + 2 * LW : n + 2 * LW, PS = W / 2;
     double *cur = lds, *nxt = lds + W, *g1s = lds + 2 * W, *cAs = g1s + n, *wl = cAs + n;
-    double *red = wl + (LW + 2);                   // [2 parities][NW][4] wave sums of a step: N, sum p / L, sum c, mean
+    double *red = wl + (LW + 2) + (SHIFT ? LW + 40 : 0);     // [2 parities][NW][NS] wave sums of a step
+    double *vt = red + 2 * NW * NS + 8;                      // (SHIFT) [n + 24] spline coefficients of the padded row
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *post = P.post ? P.post + (long long)b * P.post_stride : nullptr;
     blk::StepParams Q{};
@@ -89,12 +101,19 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         const long long tb = (long long)t * P.B + b;
         const int kind = P.srckind[tb];
         const int tp = P.tap[tb];
-        double *rk = red + (s & 1) * (NW * 4), *rp = red + ((s + 1) & 1) * (NW * 4);
+        double *rk = red + (s & 1) * (NW * NS), *rp = red + ((s + 1) & 1) * (NW * NS);
+        const int l2 = (SHIFT && tp >= 0 && P.cmode[tb] == 6) ? P.tap_lw2[tp] : 0;
+        const bool asym = SHIFT && l2 == -1, big = SHIFT && l2 == -2, shift = asym || big;
         // ---- the step's weights (block-uniform: re-staged only when the chain's tap set changes) ---------------------------------------
         const bool staged = tp != tap_now || kind != SRC_PREV || s == 0;
         if (tp != tap_now) {
             lw = tp >= 0 ? P.tap_lw[tp] : 0;
-            for (int k = tid; k <= LW + 1; k += NT) wl[k] = k <= lw ? (lw > 0 ? P.taps[P.tap_off[tp] + k] : 1.0) : 0.0;
+            if (shift) {                             // asymmetric: w[k + lw], k = -lw .. lw; two-stage: [d, g(0) .. g(34)]
+                const int nw = asym ? 2 * lw + 1 : 36;
+                for (int k = tid; k < nw; k += NT) wl[k] = P.taps[P.tap_off[tp] + k];
+            } else {
+                for (int k = tid; k <= LW + 1; k += NT) wl[k] = k <= lw ? (lw > 0 ? P.taps[P.tap_off[tp] + k] : 1.0) : 0.0;
+            }
             tap_now = tp;
         }
         // ---- the source: the previous state (in `cur` since the last barrier), or a shared distribution (prior, restart, uniform) -------
@@ -106,16 +125,34 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
             // lazy normaliser: every thread adds the waves' sums of the previous step in the same order
             double sN = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) sN += rp[w * 4 + (BWD ? 2 : 0)];
+            for (int w = 0; w < NW; ++w) sN += rp[w * NS + (BWD ? 2 : 0)];
             scale = 1.0 / sN;
         }
         // (block-uniform: a barrier only where something was staged -- all reads of the buffer this step overwrites ended before the
         //  previous step's last barrier)
         if (staged) __syncthreads();
+        if (shift) {
+            // the halo of a shifted row follows SciPy's extension, not the mirror image put() leaves there (sources: cells of the row)
+            for (int h = tid; h < 2 * lw; h += NT) {
+                const int i = h < lw ? h - lw : n + (h - lw);
+                cur[LW + i] = cur[LW + blk::extend_index(i, n, 2)];
+            }
+            __syncthreads();
+            if (big) {                               // spline coefficients of the padded row: position q = grid coordinate q - 12
+                const double *gw = wl + 1;
+                for (int q = tid; q < n + 24; q += NT) {
+                    const double *cen = cur + LW + (q - 12);
+                    double acc = gw[0] * cen[0];
+                    for (int m = 34; m >= 1; --m) acc = fma(gw[m], cen[-m] + cen[m], acc);
+                    vt[q] = acc;
+                }
+                __syncthreads();
+            }
+        }
         Q.rec = P.rec + (long long)t * P.rec_len;
         Q.lik = P.lik ? P.lik + (long long)t * n : nullptr;
         double *row = post ? post + (long long)t * n : nullptr;
-        double aN = 0.0, aS = 0.0, aC = 0.0, aM = 0.0;
+        double aN = 0.0, aS = 0.0, aC = 0.0, aM = 0.0, aU = 0.0;
         // the epilogue of one cell: o = the transition's output (scaled)
         auto finish = [&](int j, int q, double o) {
             const double g1 = g1s[j];
@@ -164,6 +201,26 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
                 const int j = tid + q * NT;
                 if (j < n) {
                     const int e = LW + j;
+                    if (SHIFT && shift) {
+                        double o = 0.0;
+                        if (big) {                   // cubic B-spline at the shifted coordinate of the padded array, index clamped
+                            const int N = n + 24;
+                            const double pp = (double)j - wl[0] + 12.0, fl = floor(pp);
+                            const int k0 = (int)fmax(fmin(fl, 1.0e9), -1.0e9);
+                            for (int dk = -1; dk <= 2; ++dk) {
+                                const double a = fabs(pp - (fl + (double)dk));
+                                const double b3 = a < 1.0 ? 2.0 / 3.0 - a * a + a * a * a * 0.5 : (a < 2.0 ? (2.0 - a) * (2.0 - a) * (2.0 - a) / 6.0 : 0.0);
+                                const long long kk = (long long)k0 + dk;
+                                o = fma(b3, vt[kk < 0 ? 0 : (kk > N - 1 ? N - 1 : (int)kk)], o);
+                            }
+                        } else {                     // out[i] = sum_m w[m + lw] in[i + m]
+                            for (int k = -lw; k <= lw; ++k) o = fma(wl[k + lw], cur[e + k], o);
+                        }
+                        const double u = o * scale;
+                        aU += u;
+                        finish(j, q, u);
+                        continue;
+                    }
                     double o0 = cur[e] * wl[0], o1 = 0.0, o2 = 0.0, o3 = 0.0;
                     int k = lw;
                     for (; k >= 4; k -= 4) {
@@ -185,13 +242,20 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         aN = blk::wave_sum(aN);
         if (BWD) { aS = blk::wave_sum(aS); aC = blk::wave_sum(aC); }
         if (BWD || P.means) aM = blk::wave_sum(aM);
-        if (lane == 0) { rk[wv * 4 + 0] = aN; rk[wv * 4 + 1] = aS; rk[wv * 4 + 2] = aC; rk[wv * 4 + 3] = aM; }
+        if (SHIFT) aU = blk::wave_sum(aU);
+        if (lane == 0) { rk[wv * NS + 0] = aN; rk[wv * NS + 1] = aS; rk[wv * NS + 2] = aC; rk[wv * NS + 3] = aM; if (SHIFT) rk[wv * NS + 4] = aU; }
         __syncthreads();                              // `nxt` and the sums are complete
         if (tid < 4 && (tid == 0 || BWD || (tid == 3 && P.means))) {
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) tot += rk[w * 4 + tid];
+            for (int w = 0; w < NW; ++w) tot += rk[w * NS + tid];
             P.psum[(tb * NRED + tid) * P.nblk] = tot;
+        }
+        if (SHIFT && tid == 4) {                      // the shifted distribution's mass (steps without a shift: unused by the host)
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += rk[w * NS + 4];
+            P.psum[(tb * NRED + (BWD ? 5 : 1)) * P.nblk] = tot;
         }
         double *tmp = cur; cur = nxt; nxt = tmp;
     }

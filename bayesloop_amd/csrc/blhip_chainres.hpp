@@ -216,7 +216,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     const long long o0 = tap >= 0 ? sldi(P.tap_off, tap) : 0;
     const int gj = tj * WCOL + (lane & 15);
     const long long G = (long long)P.n0 * P.n1;
-    const int tsh = P.tshare ? sldi(P.tshare, b) : 0;            // steps t < tsh: shared with chain P.bprov (see ChainParams)
+    // steps t < tsh: shared with chain P.bprov (see ChainParams).  Only batches WITHOUT a stencil share prefixes (blhip_fit_paths.hpp): in the
+    // filtering kernels the test is compile-time (it was a scalar branch around every store of the epilogue)
+    const int tsh = (!FILTER && P.tshare) ? sldi(P.tshare, b) : 0;
 
     // ---- prologue: band, row coordinates, first source -> LDS ---------------------------------------------------------------------
     // the first step consumes its source unfiltered: it runs with the identity band (exact), the chain's band replaces it afterwards

@@ -38,6 +38,9 @@ struct F1Params {
     const double *psum_prev; int prev_slot;        // partial sums of the step before t_first (nullptr: scale 1)
     double *psum;                                  // [T][B][NRED][nblk]
     const double *m1, *colA, *rec, *lik;
+    // chain-resident kernel with spline shifts (blhip_chain1d.hpp, SHIFT): clamp mode of every step (6 = Deterministic's shift) and the
+    // layout marks of the tap sets (-1: all 2 lw + 1 weights, -2: two-stage form)
+    const unsigned char *cmode; const int *tap_lw2;
 };
 
 // One step over the cells of a block's window that are still exact after it (lo .. hi - 1): stencil out of LDS, likelihood, new state

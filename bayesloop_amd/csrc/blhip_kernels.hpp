@@ -496,6 +496,37 @@ __global__ __launch_bounds__(NTHREADS) void accumulate_kernel(double *A, const d
     }
 }
 
+// The same fold for SMALL grids (1-D studies: a thousand cells, tens of steps, thousands of chains): with a thread per cell the launch is
+// a few dozen blocks that each walk all B chains one after the other (the published break-point study: 82 blocks, 0.39 ms per batch of
+// 1017 chains = 0.85 TB/s).  Here a block is 64 cells x 4 groups of chains (chains g, g + 4, ...: a wave reads 512 contiguous bytes of
+// a chain's row), the groups' sums are added in a fixed order.
+__global__ __launch_bounds__(NTHREADS) void accumulate_small_kernel(double *A, const double *post, long long chain_stride, int B, long long G, int T,
+                                                                    const double *w, const double *invN, double r, int first) {
+    __shared__ double part[NTHREADS / 64][64];
+    const long long t = blockIdx.y;
+    const int cl = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + cl;
+    double acc = 0.0;
+    if (c < G) {
+        for (int b = gq; b < B; b += NTHREADS / 64) {
+            const double wb = w[b];
+            if (wb > 0.0) {
+                double p = post[(long long)b * chain_stride + t * G + c] * invN[(long long)b * T + t];
+                p = p < 1e-300 ? 1e-300 : p;
+                acc += wb * p;
+            }
+        }
+    }
+    part[gq][cl] = acc;
+    __syncthreads();
+    if (gq == 0 && c < G) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < NTHREADS / 64; ++q) sum += part[q][cl];
+        A[t * G + c] = (first ? 0.0 : A[t * G + c] * r) + sum;
+    }
+}
+
 // The partial accumulators of a batch whose backward kernel folded the posteriors itself (blhip_chainres.hpp): one per launch slot,
 // already weighted and normalised, in the kernel's strip-major layout [t][strip][row][16]:
 //     A[t][row][col] = r A + rb sum_slots part[slot][t][col / 16][row][col % 16]          (two cells per lane)

@@ -342,14 +342,16 @@ struct Res {
     static constexpr bool PAD = PAD_;
     // MODE 1 (EVID): forward pass of an evidence-only fit -- nothing is stored, no means, no rows to normalise: the flags of ResParams
     // are compile-time constants (fewer live values: the many-threads shape has 128 registers per thread).  MODE 2 (FULLFWD): forward pass
-    // of a FULL fit -- every state stored, no means, no rows to normalise (the backward pass makes the posteriors).  MODE 0: the flags
-    // are read from ResParams (forward-only fits; the backward kernels have no flags).
+    // of a FULL fit -- every state stored, no means, no rows to normalise (the backward pass makes the posteriors).  MODE 3 (FWDONLY): forward-only fit -- stored,
+    // means, rows normalised `lag` steps behind.  MODE 0: the flags are read from ResParams (padded grids; the backward kernels have none).
+    // Measured (profiles/r04_notes.md): with the flags at run time the epilogue carries a scalar branch per cell and flag and the kernel
+    // spills twice the scalars -- C3's forward pass 5.65 -> 5.21 us per step, the storing 2048^2 forward pass 13.1 -> 11.6 us with MODE 2.
     static constexpr int MODE = MODE_;
-    static constexpr bool EVID = MODE_ == 1, FULLFWD = MODE_ == 2;
+    static constexpr bool EVID = MODE_ == 1, FULLFWD = MODE_ == 2, FWDONLY = MODE_ == 3;
     static_assert(!(MODE_ != 0 && BWD), "the forward flavours");
-    BLR_INL static bool f_store(const ResParams &Q) { return EVID ? false : (FULLFWD ? true : Q.store != 0); }
-    BLR_INL static bool f_means(const ResParams &Q) { return MODE != 0 ? false : Q.means != 0; }
-    BLR_INL static bool f_norm(const ResParams &Q) { return MODE != 0 ? false : Q.normalise != 0; }
+    BLR_INL static bool f_store(const ResParams &Q) { return EVID ? false : ((FULLFWD || FWDONLY) ? true : Q.store != 0); }
+    BLR_INL static bool f_means(const ResParams &Q) { return FWDONLY ? true : (MODE != 0 ? false : Q.means != 0); }
+    BLR_INL static bool f_norm(const ResParams &Q) { return FWDONLY ? true : (MODE != 0 ? false : Q.normalise != 0); }
     BLR_INL static double *f_post(const ResParams &Q) { return EVID ? nullptr : Q.post; }
     static constexpr int P = TC + 1;                 // LDS pitch in doubles: odd => the row-strided accesses of the axis-1 pass
                                                      // and the contiguous ones of the axis-0 pass are both conflict-free

@@ -1136,6 +1136,34 @@ def test_one_dimensional_batches_on_the_chain_resident_kernel_match_the_goldens(
     assert len(took) >= 12 and 'c1_coal_hyper' in took and 'c1_coal' in took, took
 
 
+@pytest.mark.parametrize('case', ['kat_deterministic', 'serial_deterministic_bp', 'serial_deterministic_offset'])
+def test_deterministic_steps_on_the_chain_resident_kernel(case):
+    """Batches of 1-D chains whose programs contain Deterministic steps (spline shifts: clamp mode 6) run on the chain-resident
+    kernel's SHIFT flavour (bl1c::chain1d_kernel<.., SHIFT>: asymmetric stencil over SciPy's 'nearest' extension, two-stage form
+    beyond 12 cells, the shifted mass as one more sum per step); `chain1d_shift = 0` keeps them on the launch-per-step kernel.  Both
+    against the reference's golden, and against each other."""
+    eng = bl.get_engine()
+    A = cases.build(bl, case)
+    with np.errstate(all='ignore'):
+        A.fit(**cases.fit_kwargs(case))
+    assert A.lastTiming['fwd_kernel_variant'] == 9, A.lastTiming
+    if not cases.fit_kwargs(case).get('evidenceOnly'):
+        assert A.lastTiming['bwd_kernel_variant'] == 9, A.lastTiming
+    compare.check(result_of(A, case), oa.load_golden(case), compare.GPU_TOL, case_tol=cases.CASES[case].get('tol'))
+    eng.set_option('chain1d_shift', 0)
+    try:
+        B = cases.build(bl, case)
+        with np.errstate(all='ignore'):
+            B.fit(**cases.fit_kwargs(case))
+    finally:
+        eng.set_option('chain1d_shift', 1)
+    assert B.lastTiming['fwd_kernel_variant'] == 0, B.lastTiming
+    la, lb = np.asarray(A.logEvidenceList, dtype=float), np.asarray(B.logEvidenceList, dtype=float)
+    assert np.array_equal(np.isfinite(la), np.isfinite(lb))
+    np.testing.assert_allclose(la[np.isfinite(la)], lb[np.isfinite(lb)], rtol=1e-11)
+    assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(B.logEvidence)
+
+
 @pytest.mark.parametrize('name', ['c1_hyper', 'coal_hyper1000'])
 def test_one_dimensional_hyper_studies_of_the_bench_against_full_size_reference(name):
     """bench.py's 1-D hyper-studies (SURVEY 8c's anchor C1-as-HyperStudy; the tutorial's 1000-point grid with 256 widths up to 667 grid
@@ -1174,6 +1202,7 @@ def test_the_references_published_break_point_study_at_full_size():
     S, kw, units, desc = bench.make_study(bl, 'coal_breakpoints')
     with np.errstate(all='ignore'):
         S.fit(silent=True)
+    assert S.lastTiming['fwd_kernel_variant'] == 9 and S.lastTiming['bwd_kernel_variant'] == 9, S.lastTiming      # (bl1c::chain1d_kernel, SHIFT)
     gl, rl = gold['logEvidenceList'], np.asarray(S.logEvidenceList, dtype=float)
     assert len(rl) == 23400
     both = np.isfinite(gl) & np.isfinite(rl)
