@@ -1236,29 +1236,20 @@ class OnlineStudy(HyperStudy):
     def __init__(self, storeHistory=False, silent=False):
         super(OnlineStudy, self).__init__(silent=silent)
         self.firstStep = True
-        self.transitionModels = []
-        self.transitionModelNames = []
-        self.tmCount = None
-        self.tmCounts = []
-        self.hyperParameterValues = []
-        self.allFlatHyperParameterValues = []
-        self.hyperParameterNames = []
-        self.hyperGridConstants = []
-        self.logEvidenceList = None
-        self.hyperLogEvidenceList = None
-        self.hyperPrior = []
-        self.hyperPriorValues = []
-        self.transitionModelPrior = None
-        self.marginalizedPosterior = None
-        self.hyperParameterDistribution = None
-        self.transitionModelDistribution = None
-        self.localTransitionModelDistribution = None
         self.storeHistory = storeHistory
+        # the competing transition models and what the hyper-grid machinery produced for each of them (lists, one entry per model)
+        for per_model in ('transitionModels', 'transitionModelNames', 'tmCounts', 'hyperParameterValues', 'allFlatHyperParameterValues',
+                          'hyperParameterNames', 'hyperGridConstants', 'hyperPrior', 'hyperPriorValues'):
+            setattr(self, per_model, [])
+        # what a step updates (None until the first one) ...
+        for updated in ('tmCount', 'logEvidenceList', 'hyperLogEvidenceList', 'transitionModelPrior', 'marginalizedPosterior',
+                        'hyperParameterDistribution', 'transitionModelDistribution', 'localTransitionModelDistribution'):
+            setattr(self, updated, None)
+        # ... and the histories it appends to (storeHistory)
         self.posteriorMeanValues = []
         self._posteriorSequence = []
-        self.hyperParameterSequence = []
-        self.transitionModelSequence = []
-        self.localTransitionModelSequence = []
+        for history in ('hyperParameterSequence', 'transitionModelSequence', 'localTransitionModelSequence'):
+            setattr(self, history, [])
         self._slots = []            # carry slot of every transition model in the engine's context
         self._device = []           # per transition model: (ops, op_values, reset prior, indep prior)
         if not silent:
@@ -1308,23 +1299,22 @@ class OnlineStudy(HyperStudy):
 
     # ---- configuration (reference core.py:2007-2060) -------------------------------------------------------------------
     def addTransitionModel(self, name, transitionModel):
+        """One more competing transition model (reference core.py:1986-2026): its hyper-grid is built once, by the HyperStudy machinery,
+        and filed per model; a model without hyper-parameters counts as one chain."""
         self.setTransitionModel(transitionModel, silent=True)
         self._createHyperGrid(silent=True)
-        self.transitionModels.append(transitionModel)
-        self.transitionModelNames.append(name)
-        self.hyperParameterValues.append(self.hyperGridValues[:])
-        self.allFlatHyperParameterValues.append(self.flatHyperParameters)
-        self.hyperParameterNames.append(self.flatHyperParameterNames[:])
-        self.hyperGridConstants.append(self.hyperGridConstant[:])
-        self.hyperPrior.append(self.flatHyperPriors[:])
-        self.hyperPriorValues.append(self.flatHyperPriorValues[:])
-        self.tmCounts = [len(hpv) if len(hpv) > 0 else 1 for hpv in self.hyperParameterValues]
+        filed = ((self.transitionModels, transitionModel), (self.transitionModelNames, name),
+                 (self.hyperParameterValues, self.hyperGridValues[:]), (self.allFlatHyperParameterValues, self.flatHyperParameters),
+                 (self.hyperParameterNames, self.flatHyperParameterNames[:]), (self.hyperGridConstants, self.hyperGridConstant[:]),
+                 (self.hyperPrior, self.flatHyperPriors[:]), (self.hyperPriorValues, self.flatHyperPriorValues[:]))
+        for per_model, entry in filed:
+            per_model.append(entry)
+        self.tmCounts = [max(len(values), 1) for values in self.hyperParameterValues]
         self.tmCount = int(np.sum(self.tmCounts))
-        if len(self.hyperGridValues) > 0:
-            print('+ Added transition model: {} ({} combination(s) of the following hyper-parameters: {})'
-                  .format(name, len(self.hyperGridValues), self.hyperParameterNames[-1]))
-        else:
-            print('+ Added transition model: {} (no hyper-parameters)'.format(name))
+        n_comb = len(self.hyperGridValues)
+        print('+ Added transition model: {} ({} combination(s) of the following hyper-parameters: {})'
+              .format(name, n_comb, self.hyperParameterNames[-1]) if n_comb > 0
+              else '+ Added transition model: {} (no hyper-parameters)'.format(name))
 
     def addTM(self, name, transitionModel):
         self.addTransitionModel(name, transitionModel)
@@ -1365,27 +1355,30 @@ class OnlineStudy(HyperStudy):
             OnlineStudy._slot_counter[0] += 1
             self._slots.append(OnlineStudy._slot_counter[0])
 
+    def _takeDataPoint(self, dataPoint):
+        """The stream's bookkeeping of one call of ``step`` (reference core.py:2069-2096): a transition model that was only `set` joins
+        the list of competing models; the first data point starts the raw series (after the duplicate-name and consistency checks), every
+        later one is appended; time stamps count the data points from 0."""
+        if self.tmCount is None:
+            if self.transitionModel is None:
+                raise ConfigurationError('No transition model set or added.')
+            self.addTransitionModel('transition model', self.transitionModel)
+        point = np.array(dataPoint if isinstance(dataPoint, list) else [dataPoint])
+        if len(self.rawData) > 0:
+            self.rawData = np.append(self.rawData, point, axis=0)
+            self.rawTimestamps = np.append(self.rawTimestamps, self.rawTimestamps[-1] + 1)
+            return
+        print('+ Start model fit')
+        names = list(flatten(self.hyperParameterNames))
+        if len(set(names)) != len(names):
+            raise ConfigurationError('Detected duplicate hyper-parameter names. Choose unique identifiers.')
+        self.rawData = point
+        Study._checkConsistency(self)
+        self.rawTimestamps, self.formattedTimestamps = np.array([0]), []
+
     def step(self, dataPoint):
         """Update every chain with a new data point (float, int, or 1-D array for multi-dimensional data)."""
-        if (self.tmCount is None) and (self.transitionModel is None):
-            raise ConfigurationError('No transition model set or added.')
-        if (self.tmCount is None) and (self.transitionModel is not None):
-            self.addTransitionModel('transition model', self.transitionModel)
-        if not isinstance(dataPoint, list):
-            dataPoint = [dataPoint]
-
-        if len(self.rawData) == 0:
-            print('+ Start model fit')
-            allNames = list(flatten(self.hyperParameterNames))
-            if len(allNames) != len(np.unique(allNames)):
-                raise ConfigurationError('Detected duplicate hyper-parameter names. Choose unique identifiers.')
-            self.rawData = np.array(dataPoint)
-            Study._checkConsistency(self)
-            self.rawTimestamps = np.array([0])
-            self.formattedTimestamps = []
-        else:
-            self.rawData = np.append(self.rawData, np.array(dataPoint), axis=0)
-            self.rawTimestamps = np.append(self.rawTimestamps, self.rawTimestamps[-1] + 1)
+        self._takeDataPoint(dataPoint)
 
         om = self.observationModel
         if len(self.rawData) < om.segmentLength:
