@@ -653,20 +653,6 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
 
 bool fold2_shape(int ntw) { return ntw >= 1 && ntw <= 4; }
 
-// backward pass with the fused fold of a no-stencil batch, FOUR chains per block of 256 rows (blc::chain_foldn_kernel): grids of 256 / 512
-// rows (1 / 2 row blocks per strip), at most blc::MAX_STRIPS partial sums per chain and step
-constexpr int FOLD4_ROWS = blc::NW * 2 * blc::TM;
-bool fold4_shape(int n0p, int strips, bool pad) {
-    return !pad && (n0p == FOLD4_ROWS || n0p == 2 * FOLD4_ROWS) && strips * (n0p / FOLD4_ROWS) <= blc::MAX_STRIPS;
-}
-void launch_fold4(hipStream_t s, const blc::ChainParams &Q) {
-    const size_t lds = blc::lds_doubles_foldn<4, 2>() * sizeof(double);
-    const int vstrips = Q.strips * (Q.n0 / FOLD4_ROWS);
-    arm_kernel(reinterpret_cast<const void *>(&blc::chain_foldn_kernel<4, 2>));
-    hipLaunchKernelGGL((blc::chain_foldn_kernel<4, 2>), dim3((unsigned)(((Q.nslots + 3) / 4) * vstrips)), dim3(blc::NT), lds, s, Q);
-    HIPCHECK(hipGetLastError());
-}
-
 void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad = false) {
     if (ntw == 4) launch_fold2_w<4>(s, Q, nk, pad);
     else if (ntw == 3) launch_fold2_w<3>(s, Q, nk, pad);
@@ -2300,7 +2286,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         const bool res_now = resident && !resident_failed;
         const bool cres_now = chainres && !resident_failed;
         const int nblk_now = res_now ? RR.nblk : (cres_now ? CR.cp.strips : tile.nblk);      // partial-sum slots per (step, sum) of this pass
-        const int nblk_bwd = cres_now ? CR.nblk_bwd() : nblk_now;                             // (the four-chain fold kernel: strips x row blocks)
         if (res_now) RR.launch(E, false, d_psF);
         if (cres_now) CR.pass(E, false, d_psF);
         fork_streams();
@@ -2394,7 +2379,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             join_streams();
             HIPCHECK(hipEventRecord(ev[3], st));
             hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
-                                   ctx->redB.as<double>(), nblk_bwd, NRED);
+                                   ctx->redB.as<double>(), nblk_now, NRED);
             ctx->pinB.ensure((size_t)T * B * NRED * 8);
             redB = ctx->pinB.as<double>();
             HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));

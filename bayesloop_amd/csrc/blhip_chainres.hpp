@@ -976,326 +976,4 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     if (pend_j >= 0) totals(pend_j, pend_k);
 }
 
-
-__device__ __forceinline__ double uniform_d(double v) {          // a block- / wave-uniform double -> scalar registers
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-// ---- no-stencil batches (change-point studies), folding backward pass with FOUR chains per block -------------------------------------
-// The no-stencil variant of chain_fold2_kernel is at the memory roof (C5: 12.3 B per chain, cell and step at 0.8 of the calibrated
-// rate), and 8 of its 16 bytes are the read-modify-write of the partial accumulator shared by the block's two chains.  Without a stencil
-// the rows of a strip are independent, so a block may own HALF a strip (NTW = 2 tiles per wave = 256 rows) of FOUR chains with the same
-// 128 KB of LDS: 8 + 16 / 4 = 12 B.  What differs from the two-chain kernel:
-//  * ONE body per TIME step that walks the block's chains (compile-time chain index: the chains' small state lives in statically
-//    indexed registers), one barrier per time step; the chains see the same likelihood, so the recurrence that makes it (and its
-//    reciprocal) runs once per CELL and the chains' products follow -- 13 instead of 21 vector instructions per cell and chain.  A first version kept the two-chain kernel's protocol -- one body and one barrier
-//    per CHAIN-step, the chain number block-uniform at run time: chain-steps of two tiles cost ~2.8 us whatever they moved (barrier, the
-//    scale wave's sums, wave 5's totals), and the kernel was SLOWER than the two-chain one with two thirds of its bytes (45 - 49 vs 40 us
-//    per logical step of C5);
-//  * the stored alpha of a time step is requested a whole time step ahead (the slot a tile's epilogue has just consumed is re-filled for
-//    the same chain's next step); the chains' weighted posteriors are summed in registers and added to the accumulator cells when the
-//    last chain is done, so the cells requested at the end of the previous step are not needed before that;
-//  * a chain's sums are made of strips x row-blocks partial sums ("virtual strips": psum / granule index vs = strip * RB + row block; at
-//    most MAX_STRIPS of them).
-// Lagged scales from data-tagged granules, predicted posterior sums, restarts and shared prefixes as in chain_fold2_kernel.
-template <int NCH, int NTW>
-constexpr size_t lds_doubles_foldn() { return (size_t)NCH * NW * NTW * TM * WCOL + NW * NTW * TM + (size_t)NCH * 2 * NW * 4 * 3 + 2 * NCH * NSLOT + NCH * (2 * 64 + 1) + 8; }
-
-template <int NCH, int NTW>
-__global__ __launch_bounds__(NT, 1) void chain_foldn_kernel(const ChainParams P) {
-    constexpr int N0 = NW * NTW * TM;               // rows of a block
-    constexpr int XSZ = N0 * WCOL;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *const X = lds;                          // [NCH chains][N0][16]   the chains' states (a lane's cells are its own)
-    double *const m0s = X + NCH * XSZ;              // [N0]
-    double *const red = m0s + N0;                   // [NCH][2 parities][NW * 4][3]
-    double *const scal = red + NCH * 2 * NW * 4 * 3;    // [NCH][NSLOT]
-    double *const iscal = scal + NCH * NSLOT;           // [NCH][NSLOT]
-    // the scale wave's own state (one wave reads and writes it; in registers it cost every wave of the kernel 24 VGPRs)
-    unsigned long long *const gql = reinterpret_cast<unsigned long long *>(iscal + NCH * NSLOT);   // [NCH][2][64] granules in flight, per lane
-    double *const sprev = reinterpret_cast<double *>(gql + NCH * 2 * 64);                              // [NCH] the sum the previous scale was made of
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int RB = P.n0 / N0, vstrips = P.strips * RB;                 // row blocks per strip; partial sums per chain and step
-    const int csn = blockIdx.x / vstrips, vs = blockIdx.x - csn * vstrips, tj = vs / RB, rb = vs - tj * RB;
-    const int nch = min(NCH, P.nslots - NCH * csn);                  // chains of this block (the last group of a launch may be short)
-    int bch[NCH], tshv[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        bch[j] = sldi(P.chain_ids, NCH * csn + min(j, nch - 1));
-        tshv[j] = P.tshare ? sldi(P.tshare, bch[j]) : 0;
-    }
-    const int gj = tj * WCOL + (lane & 15);
-    const long long G = (long long)P.n0 * P.n1;
-    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[rb * N0 + e];
-    if (tid < 2 * NCH * NSLOT) scal[tid] = 1.0;
-    for (int e = tid; e < NCH * XSZ; e += NT) {
-        const int q = e % XSZ, row = rb * N0 + (q >> 4), col = tj * WCOL + (q & 15);
-        X[e] = P.src0[(long long)row * P.n1 + col];
-    }
-    const double cA = P.colA[gj], cB = P.colB[gj];
-    const unsigned rowx8 = (unsigned)WCOL * 8u;                    // (strip-major sequences: the fold is private to the fit)
-    const unsigned strip0 = (unsigned)tj * (unsigned)(P.n0 * WCOL * 8);
-    const int row0 = wv * (NTW * TM), grow0 = rb * N0 + row0;      // the wave's first row in the block / in the strip
-    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    auto cell_off = [&](int l, int it, int r) { return __umul24(grow0 + it * TM + (l >> 4) + 4 * r, rowx8) + strip0 + (unsigned)(l & 15) * 8u; };
-
-    const LoopParams Q = loop_params(P);
-    // the stored forward state of chain j at the time step with running index kk (clamped: a harmless re-load past the end); steps a
-    // chain shares with the providing chain are read from that chain's copy
-    auto stored_row = [&](int j, int kk) -> const double * {
-        const int tt = max(Q.T - 1 - kk, 0);
-        return Q.post + (long long)(tt < tshv[j] ? Q.bprov : bch[j]) * Q.post_stride + (long long)tt * G;
-    };
-    double *const pslot = P.part + (long long)csn * P.part_stride;
-    double al[NCH][NTW][4];                         // stored alpha of the time step that runs next, per chain
-    double pacc[NTW][4];                            // accumulator cells of the time step in flight
-#pragma unroll
-    for (int it = 0; it < NTW; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned off = cell_off(lane, it, r);
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) al[j][it][r] = blm::ld32(stored_row(j, 0), off);
-            pacc[it][r] = P.part_fresh ? blm::ld32(P.zeros, off & 4088u) : blm::ld32(pslot + (long long)(Q.T - 1) * G, off);
-        }
-    double wch[NCH], inpred[NCH], sfn[NCH];         // (block-uniform: scalar registers)
-    int kindn[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        wch[j] = uniform_d(j < nch ? P.wchain[bch[j]] : 0.0); inpred[j] = uniform_d(P.infirst[bch[j]]);
-        sfn[j] = 1.0; kindn[j] = blk::SRC_PREV;
-    }
-    if (tid < NCH) sprev[tid] = 1.0;
-    for (int e = tid; e < NCH * 2 * 64; e += NT) gql[e] = 0ull;
-    if (wv == SCALE_WAVE || wv == 5) __builtin_amdgcn_s_setprio(2);
-    bool dead = false;
-    double mq = 1.0, iq = 1.0, dn_prev = -1.0;
-    int nq = 0;
-    // wave 5: block totals of a finished time step -> partial sums of the virtual strip + the granules the scales of step k + lag are made of
-    auto totals = [&](int k) {
-        if (wv == 5 && lane < 3) {
-            const int t = Q.T - 1 - k;
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                if (j < nch) {
-                    const double *rk = red + (j * 2 + (k & 1)) * (NW * 4 * 3);
-                    double tot = 0.0;
-#pragma unroll
-                    for (int w = 0; w < NW * 4; ++w) tot += rk[w * 3 + lane];
-                    Q.psum[(((long long)t * Q.B + bch[j]) * NRED + lane) * Q.nblk + vs] = tot;
-                    if (lane == 2) {
-                        const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
-                        const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
-                        unsigned long long *gw = Q.gran + ((((long long)(k & (NSLOT - 1)) * Q.nslots + NCH * csn + j) * vstrips + vs) << 1);
-                        blr::st_u64(gw, tag | (bits & 0xffffffffull));
-                        blr::st_u64(gw + 1, tag | (bits >> 32));
-                    }
-                }
-            }
-        }
-    };
-    __syncthreads();
-
-    const bool scale_wave = wv == SCALE_WAVE;
-#pragma unroll 1
-    for (int k = 0; k < Q.T; ++k) {
-        const int t = Q.T - 1 - k;
-        const int tn = (k + 1 < Q.T) ? t - 1 : t;
-        const int jn = k + 1;
-        double xd[DMAX];
-#pragma unroll
-        for (int q = 0; q < DMAX; ++q) xd[q] = q < Q.d ? Q.rec[(long long)t * Q.rec_len + q] : __builtin_nan("");
-        double *const pslot_t = pslot + (long long)t * G;
-        double *const pslot_tn = pslot + (long long)tn * G;
-        // (what a step consumes -- source kind, forward scale, the scale wave's granules -- was requested during the previous step, right
-        //  after that step had consumed its own)
-        const bool need = scale_wave && jn >= Q.lag && jn < Q.T;
-        const bool mine = need && lane < vstrips;
-        __syncthreads();                                            // the previous step's row sums and this step's scales are in LDS
-        if (k > 0) totals(k - 1);
-
-        // anchors of the stride-4 likelihood recurrence of the lane's rows, per tile: all chains see the same likelihood
-        // (one anchor per lane: the recurrence runs on through the wave's tiles, 16 rows = 4 links apart)
-        double a_mE, a_mR, a_iE, a_iR;
-        int a_nE, a_nR;
-        {
-            const int l = fresh_lane(), g = l >> 4;
-            {
-                const int i = row0;
-                const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
-                double a0 = 0.0, s1 = 0.0, dn = 0.0;
-#pragma unroll
-                for (int q = 0; q < DMAX; ++q) {
-                    const double x = xd[q];
-                    if (x == x) {
-                        const double dq = x - mu0;
-                        a0 = fma(-(dq * dq), cA, a0) - cB;
-                        s1 += (x - mu0) + (x - mu4);
-                        dn += 1.0;
-                    }
-                }
-                const double d1 = cA * (mu4 - mu0) * s1;
-                int tmp;
-                exp_mn(a0, a_mE, a_nE);
-                exp_mn(d1, a_mR, a_nR);
-                if (dn != dn_prev) {
-                    const double d2 = -32.0 * cA * dn * Q.step0 * Q.step0;
-                    exp_mn(d2, mq, nq);
-                    exp_mn(-d2, iq, tmp);
-                    dn_prev = dn;
-                }
-                exp_mn(-a0, a_iE, tmp);
-                exp_mn(-d1, a_iR, tmp);
-            }
-        }
-        double padd[NTW][4];                        // the chains' weighted posteriors of this step
-#pragma unroll
-        for (int it = 0; it < NTW; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) padd[it][r] = 0.0;
-
-        // ---- per chain: restart, scale, predicted sum, weight; the scale wave prepares the chain's next scale ----------------------------
-        double scale[NCH], wq[NCH], wfloor[NCH];
-        const double *pnext[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            scale[j] = 1.0; wq[j] = 0.0; wfloor[j] = 0.0; pnext[j] = stored_row(j, k + 1);
-            if (j < nch) {
-                double *const Xj = X + j * XSZ;
-                const bool restart = k > 0 && kindn[j] != blk::SRC_PREV;
-                if (restart) {
-                    // a restart (once per chain and change point): the chain's buffer takes the reset distribution.  A lane's cells are
-                    // its own (no barrier); the values are consumed inside the branch
-                    const int l = fresh_lane(), g = l >> 4, c = l & 15;
-#pragma unroll
-                    for (int it = 0; it < NTW; ++it)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = row0 + it * TM + g + 4 * r;
-                            Xj[row * WCOL + c] = Q.reset[(long long)(rb * N0 + row) * P.n1 + tj * WCOL + c];
-                        }
-                }
-                scale[j] = scal[j * NSLOT + (k & (NSLOT - 1))];
-                // N_t = s'_t N_(t+1) / s_(t+1); at a restart N_t = s'_t sum(alpha_t reset) (sfn carries that sum)
-                if (k > 0) inpred[j] = uniform_d(restart ? iscal[j * NSLOT + (k & (NSLOT - 1))] / sfn[j] : inpred[j] * sfn[j] * iscal[j * NSLOT + (k & (NSLOT - 1))]);
-                if (Q.kinds) kindn[j] = k + 1 < Q.T ? (int)Q.kinds[(long long)tn * Q.B + bch[j]] : blk::SRC_PREV;
-                sfn[j] = Q.sfwd[(long long)bch[j] * Q.T + min(tn + 1, Q.T - 1)];
-                // (block-uniform values: scalar registers)
-                scale[j] = uniform_d(scale[j]); wq[j] = uniform_d(wch[j] * inpred[j]); wfloor[j] = uniform_d(wch[j] * 1e-300);
-                if (scale_wave) {                   // the scale of this chain's NEXT step, from the sums published `lag` steps before it
-                    double sj = 1.0;
-                    if (need) {
-                        const unsigned long long want = (unsigned long long)(unsigned)(jn - Q.lag + 1);
-                        const unsigned long long *gp = Q.gran + ((((long long)((jn - Q.lag) & (NSLOT - 1)) * Q.nslots + NCH * csn + j) * vstrips + lane) << 1);
-                        unsigned long long q0 = gql[(j * 2 + 0) * 64 + lane], q1 = gql[(j * 2 + 1) * 64 + lane];
-                        bool ok = !mine || ((q0 >> 32) == want && (q1 >> 32) == want);
-                        if (!dead && !__all(ok)) {
-                            const unsigned long long t0 = blr::now_ticks();
-                            for (unsigned spins = 1; !__all(ok); ++spins) {
-                                if (!ok) { q0 = blr::ld_u64(gp); q1 = blr::ld_u64(gp + 1); ok = (q0 >> 32) == want && (q1 >> 32) == want; }
-                                blr::nap();
-                                if ((spins & 255u) == 0u) {
-                                    if (blr::ld_flag(Q.abort_word) != 0u) { dead = true; break; }
-                                    if (blr::now_ticks() - t0 > Q.timeout_ticks) { blr::st_flag(Q.abort_word, 1u); dead = true; break; }
-                                }
-                            }
-                        }
-                        const double v = mine ? __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32))) : 0.0;
-                        const double Sg = blk::wave_sum(v);
-                        sj = dead ? 1.0 : sprev[j] * scal[j * NSLOT + ((jn - Q.lag) & (NSLOT - 1))] / Sg;
-                        if (lane == 0) sprev[j] = Sg;
-                    }
-                    if (lane == 0) { scal[j * NSLOT + (jn & (NSLOT - 1))] = sj; iscal[j * NSLOT + (jn & (NSLOT - 1))] = 1.0 / sj; }
-                    if (jn + 1 >= Q.lag && jn + 1 < Q.T && lane < vstrips) {        // the granules the scale after that one is made of
-                        const unsigned long long *gn = Q.gran + ((((long long)((jn + 1 - Q.lag) & (NSLOT - 1)) * Q.nslots + NCH * csn + j) * vstrips + lane) << 1);
-                        gql[(j * 2 + 0) * 64 + lane] = blr::ld_u64(gn); gql[(j * 2 + 1) * 64 + lane] = blr::ld_u64(gn + 1);
-                    }
-                }
-            }
-        }
-        // ---- the cells: the likelihood of a cell and its reciprocal are the same for every chain -- one recurrence link per CELL, then
-        //      the chains (a group with fewer than NCH chains repeats its last one with weight zero: no branches here) ---------------------
-        double sN[NCH], sS[NCH], sC[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) { sN[j] = 0.0; sS[j] = 0.0; sC[j] = 0.0; }
-        {
-            const int l = fresh_lane(), g = l >> 4, c = l & 15;
-            double mE = a_mE, mR = a_mR, iE = a_iE, iR = a_iR;
-            int nE = a_nE, nR = a_nR;
-#pragma unroll
-            for (int it = 0; it < NTW; ++it) {
-                const int i = row0 + it * TM;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double Lv = ldexp(mE, nE);
-                    const bool lz = Lv == 0.0;
-                    const int cell = (i + g + 4 * r) * WCOL + c;
-#pragma unroll
-                    for (int j = 0; j < NCH; ++j) {
-                        const double beta = X[j * XSZ + cell] * scale[j];      // no stencil: the state IS the step's input
-                        const double p = al[j][it][r] * beta;
-                        const double cn = beta * Lv;
-                        const double pl = lz ? __builtin_nan("") : ldexp(p * iE, -nE);       // 0/0 -> NaN (core.py:463)
-                        X[j * XSZ + cell] = cn;
-                        padd[it][r] += fmax(p * wq[j], wfloor[j]);
-                        sN[j] += p; sS[j] += pl; sC[j] += cn;
-                    }
-                    mE *= mR; nE += nR;
-                    mR *= mq; nR += nq;
-                    iE *= iR; iR *= iq;
-                }
-                // (the sums are consumed in the chains' reduction blocks below: without an anchor in this block the compiler SINKS every
-                //  chain's products and sums into its reduction block -- all cells' betas and the consumed alphas stay live: 237 spills.
-                //  Once per tile: per cell the anchors serialised the LDS reads, 32 exposed round trips per step)
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(sN[j]), "+v"(sS[j]), "+v"(sC[j]));
-                // the tile's slots have been consumed: re-filled for the same chains' next step
-                // (ONE 64-bit address per array and tile, the four cells at immediate offsets: rows 4 r are 4 x 128 bytes apart)
-                const unsigned off_t = cell_off(l, it, 0);
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    const char *const pa_ = (const char *)pnext[j] + off_t;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) al[j][it][r] = __builtin_nontemporal_load((const double *)(pa_ + r * (4 * WCOL * 8)));
-                }
-                __builtin_amdgcn_sched_barrier(0);  // (nothing paces the tiles: unfenced, the scheduler interleaves their cells and spills)
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            double v[3] = {sN[j], sS[j], sC[j]};
-            double *rk = red + (j * 2 + (k & 1)) * (NW * 4 * 3);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                double x = v[q];
-                x = blk::dpp_add<0x111, 0xf>(x);
-                x = blk::dpp_add<0x112, 0xf>(x);
-                x = blk::dpp_add<0x114, 0xf>(x);
-                x = blk::dpp_add<0x118, 0xf>(x);
-                if ((lane & 15) == 15) rk[(wv * 4 + (lane >> 4)) * 3 + q] = x;
-            }
-        }
-        // the accumulator cells of this step (requested a step ago; nobody else touches the slot's cells during the launch) + what the
-        // block's chains add; then those of the next step
-        {
-            const int l = fresh_lane();
-#pragma unroll
-            for (int it = 0; it < NTW; ++it) {
-                const unsigned off_t = cell_off(l, it, 0);
-                char *const ps = (char *)pslot_t + off_t;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(pacc[it][r] + padd[it][r], (double *)(ps + r * (4 * WCOL * 8)));
-                const char *const pn = Q.part_fresh ? (const char *)Q.zeros + (off_t & 4088u) : (const char *)pslot_tn + off_t;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pacc[it][r] = __builtin_nontemporal_load((const double *)(pn + r * (4 * WCOL * 8)));
-            }
-        }
-    }
-    __syncthreads();
-    totals(Q.T - 1);
-}
-
 }  // namespace blc

@@ -227,10 +227,6 @@ struct ChainRun {
     bool fold_done = false;                        // this batch's posteriors are in the accumulator already
     // fused fold with TWO chains per block (blc::chain_fold2_kernel): the backward pass runs rounds of 2 x cpr chains of its own
     bool fold2 = false;
-    // ... of a no-stencil batch with FOUR chains per block of 256 rows (blc::chain_foldn_kernel): 8 + 16 / 4 bytes per chain, cell and step
-    bool fold4 = false;
-    int vstrips = 0;                               // partial sums per chain and step of that kernel: strips x row blocks
-    int nblk_bwd() const { return fold4 ? vstrips : cp.strips; }
     std::vector<int> round_start_b, round_nk_b;
     bool share_prefix = false;                     // change-point batches: states before a chain's first restart are stored once (see setup)
     bool skip_prefix = false;                      // ... and computed once: a chain's forward pass begins at its first restart
@@ -256,14 +252,13 @@ struct ChainRun {
         if (!on) return;
         Gk = (long long)cp.n0p * cp.n1p;
         // (granule slots for 2 x cpr chains: the two-chain fold kernel runs rounds of that size)
-        // (the four-chain kernel: up to 4 x (CUs / vstrips) chains per round with vstrips <= 2 x strips sums each -- twice the granules)
-        gran_bytes = carve_size((size_t)blc::NSLOT * 4 * cp.cpr * cp.strips * 2 * 8);
+        gran_bytes = carve_size((size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2 * 8);
         ctx->resx.ensure(carve_size((size_t)B * 4) * 3 + gran_bytes + carve_size(64) + 2 * carve_size((size_t)T * B));
         char *rc = ctx->resx.as<char>();
         d_order = carve<int>(rc, (size_t)B);
         int *d_tapid = carve<int>(rc, (size_t)B);
         d_tshare = carve<int>(rc, (size_t)B);
-        CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * 4 * cp.cpr * cp.strips * 2);
+        CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2);
         d_abort = carve<unsigned>(rc, 16);
         CQ.abort_word = d_abort;
         d_ckF = carve<unsigned char>(rc, (size_t)T * B);
@@ -311,22 +306,11 @@ struct ChainRun {
             }
             round_start_b.push_back((int)B);
             slots_used = (int)std::min<int64_t>(cp.cpr, (B + 1) / 2);
-            // no stencil (change-point studies), 256 / 512 rows: four chains per block of 256 rows -- half the partial accumulators
-            fold4 = prog.LW0 == 0 && cp.has_reset && fold4_shape(cp.n0p, cp.strips, cp.pad) && ctx->option("fold4", 1.0) != 0.0;
-            if (fold4) {
-                vstrips = cp.strips * (cp.n0p / FOLD4_ROWS);
-                const int cpr4 = std::max(1, std::min(ctx->num_cus, 256) / vstrips), per4 = 4 * cpr4;
-                round_start_b.clear(); round_nk_b.clear();
-                for (int64_t s0 = 0; s0 < B; s0 += per4) { round_start_b.push_back((int)s0); round_nk_b.push_back(4); }
-                round_start_b.push_back((int)B);
-                slots_used = (int)std::min<int64_t>(cpr4, (B + 3) / 4);
-                psz = std::max(psz, (size_t)T * B * NRED * vstrips);
-            }
         }
         // a grid smaller than the geometry: only fits whose sequences are private to the fit (strip-major, padded) -- evidence-only fits
         // and full fits of hyper- / change-point studies (folded in the backward kernel, or stored and folded by accumulate_pad_kernel);
         // everything else keeps the launch-per-step kernels
-        if (cp.pad && !(E.ff.evidence_only || post_private)) { on = false; fused = false; fold2 = false; fold4 = false; return; }
+        if (cp.pad && !(E.ff.evidence_only || post_private)) { on = false; fused = false; fold2 = false; return; }
         if (cp.pad && fused && !fold2) fused = false;      // (the one-chain folding kernel has no padded variant: store + separate fold)
         // Change-point batches without a stencil whose backward pass folds: the chains are identical up to their first restart.  The chain
         // with the LATEST first restart stores all its states; every other chain stores only from its own first restart on, and the
@@ -378,10 +362,9 @@ struct ChainRun {
         blhip_ctx *ctx = E.ctx;
         hipStream_t st = E.st;
         const int64_t T = E.T, B = E.B;
-        const bool two = bwd && fused && fold2;
-        const bool four = two && fold4;
-        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * (four ? vstrips : cp.strips) * 8, st));
+        HIPCHECK(hipMemsetAsync(psum, 0, (size_t)T * B * NRED * cp.strips * 8, st));
         HIPCHECK(hipMemsetAsync(d_abort, 0, 64, st));
+        const bool two = bwd && fused && fold2;
         const std::vector<int> &rstart = two ? round_start_b : cp.round_start, &rnk = two ? round_nk_b : cp.round_nk;
         for (size_t r = 0; r + 1 < rstart.size(); ++r) {
             blc::ChainParams Q = CQ;
@@ -406,8 +389,7 @@ struct ChainRun {
             HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
             Q.prof = ctx->small.as<unsigned long long>();
 #endif
-            if (four) { Q.nblk = vstrips; launch_fold4(st, Q); }
-            else if (two) launch_fold2(st, Q, rnk[r], cp.ntw, cp.pad);
+            if (two) launch_fold2(st, Q, rnk[r], cp.ntw, cp.pad);
             else launch_chain(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only), cp.pad);
             {   // HBM: only what the fit keeps -- forward the stored state (8 B; nothing for evidence-only fits), backward the stored
                 // state in + the posterior out (16 B) or + the read-modify-write of the partial accumulator (24 B; shared by the two
@@ -415,8 +397,7 @@ struct ChainRun {
                 double cells = (double)Q.nslots * Gk * T;
                 if (!bwd && skip_prefix)               // (chain-steps the forward pass does not run)
                     for (int q = rstart[r]; q < rstart[r + 1]; ++q) cells -= (double)h_tshare[cp.order[q]] * Gk;
-                const double bytes = bwd ? (fold_now ? (four ? 8.0 + 16.0 * ((Q.nslots + 3) / 4) / (double)Q.nslots :
-                                                        (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0)) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
+                const double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
                 const int r0 = (4 * rnk[r] - blc::TM) / 2;
                 double shared = 0.0;                                  // stored states not written (forward) / read once per launch instead of once per chain (backward)
                 if (share_prefix && (bwd ? fold_now : !E.ff.evidence_only)) {
@@ -490,8 +471,7 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_fold_inf, hi, (size_t)B * 8, hipMemcpyHostToDevice, E.st));
         // the slots need no memset: the first launch of the pass reads zeros instead of them (part_fresh) -- except slots it does not
         // use (a first launch with fewer chains than slots), which later launches may
-        const int first_n = fold4 ? (round_start_b[1] - round_start_b[0] + 3) / 4 :
-                            (fold2 ? (round_start_b[1] - round_start_b[0] + 1) / 2 : cp.round_start[1] - cp.round_start[0]);
+        const int first_n = fold2 ? (round_start_b[1] - round_start_b[0] + 1) / 2 : cp.round_start[1] - cp.round_start[0];
         if (first_n < slots_used)
             HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * Gk, 0, (size_t)(slots_used - first_n) * T * Gk * 8, E.st));
         HIPCHECK(hipMemsetAsync(d_zeros, 0, 8192, E.st));
