@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/ab_r04.sh <workload> <lib> [<lib> ...]  -- the same bench workload on several builds of the library
+# usage (on the GPU box): tools/ab.sh <workload> <lib> [<lib> ...]  -- the same bench workload on several builds of the library
 # (bayesloop_amd/libblhip_<lib>.so; "new" = the product build) inside ONE call (same box), interleaved twice
 w=$1; shift
 for rep in 1 2; do for lib in "$@"; do

@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box): tools/prof_r03.sh <workload> [bench args]  -- kernel trace/stats + the two HBM-traffic PMC passes (separate runs,
-# as MI355X_MICROARCH.md prescribes) of `python bench.py --workload <w> --steps 1 --warmup 1` into gpurun_out/prof_r03_<w>/
+# usage (on the GPU box): tools/prof_workload.sh <workload> [bench args]  -- kernel trace/stats + the two HBM-traffic PMC passes (separate runs,
+# as MI355X_MICROARCH.md prescribes) of `python bench.py --workload <w> --steps 1 --warmup 1` into gpurun_out/prof_<w>/
 w=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/prof_r03_$w
+out=gpurun_out/prof_$w
 mkdir -p $out
 args="--workload $w --steps 1 --warmup 1 --no-extra --no-cpu --no-pmc --no-e2e $@"
 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o t -- python bench.py $args > $out/trace.log 2>&1
