@@ -186,7 +186,7 @@ def make_study(bl, name, comm=None, scale=1.0):
 
 
 def measured_traffic(key):
-    """HBM bytes per logical step launch from the committed rocprofv3 PMC passes (separate --pmc runs, tools/prof.sh), newest
+    """HBM bytes per logical step launch from the committed rocprofv3 PMC passes (separate --pmc runs, tools/prof_workload.sh), newest
     round first; -> (bytes or None, source file or None).  bench.py does not run the profiler itself."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
