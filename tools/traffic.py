@@ -44,7 +44,7 @@ def stats(out):
 
 out = {}
 for path in sys.argv[1:]:
-    w = os.path.basename(path.rstrip('/')).replace('prof_r04_', '')
+    w = os.path.basename(path.rstrip('/')).replace('prof_', '')
     sh = SHAPES[w]
     steps = FITS * sh['batches'] * sh['T']
     cs = collections.defaultdict(dict)
@@ -72,6 +72,6 @@ for path in sys.argv[1:]:
                            note='SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; 2 waves per SIMD')
         res[d] = r
     out[w] = res
-out['source'] = ('tools/prof_r04.sh <w>: rocprofv3 --kernel-trace --stats, then separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters) on '
+out['source'] = ('tools/prof_workload.sh <w>: rocprofv3 --kernel-trace --stats, then separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters) on '
                  '`python bench.py --workload <w> --steps 1 --warmup 1 --no-extra --no-cpu --no-pmc --no-e2e`; FETCH_SIZE x 2 (gfx950); tools/traffic.py')
 json.dump(out, sys.stdout, indent=1, default=list)
