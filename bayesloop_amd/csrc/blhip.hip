@@ -1941,9 +1941,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         HIPCHECK(hipStreamCreateWithFlags(&ctx->astream, hipStreamNonBlocking));
         for (auto &e : ctx->aev_done) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    // The per-(step, chain) programs of batch bi + 1 are built on the host while the GPU runs the forward pass of batch bi (the
-    // reference's published break-point study: 23 batches of 1017 chains x 41 steps, 30 ms of build_program of a 130-ms fit).  A failure
-    // of the early build is raised where the build used to be: at the top of that batch.
+    // The per-(step, chain) programs of batch bi + 1 are built by a second host thread while batch bi runs -- its passes on the GPU, its
+    // bookkeeping on this thread (the reference's published break-point study: 23 batches of 1017 chains x 41 steps, 23 - 30 ms of
+    // build_program of a 90 - 130-ms fit; the builder touches only its own BatchProgram and the caller's read-only inputs, no HIP call).
+    // A failure of the early build is raised where the build used to be: at the top of that batch.
     struct BatchProgram { TapTable taps; ChainProgram prog; bool ready = false; std::exception_ptr err; };
     std::unique_ptr<BatchProgram> bprog[2];
     auto build_batch = [&](int64_t bj) {
@@ -1953,15 +1954,20 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         catch (...) { N->err = std::current_exception(); }
         N->ready = true;
     };
+    std::thread builder;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } builder_guard{builder};      // (also when a batch throws)
+    const bool build_ahead = nbatch > 1 && ctx->option("build_ahead", 1.0) != 0.0;
     for (int64_t bi = 0; bi < nbatch; ++bi) {
         const int64_t c0 = batch_start[bi], B = batch_start[bi + 1] - c0;
         tr.mark("batch setup");
+        if (builder.joinable()) builder.join();
         if (!bprog[bi & 1] || !bprog[bi & 1]->ready) build_batch(bi);
         BatchProgram &BP = *bprog[bi & 1];
         BP.ready = false;                        // (consumed: the slot is rebuilt for batch bi + 2)
         if (BP.err) std::rethrow_exception(BP.err);
         TapTable &taps = BP.taps;
         ChainProgram &prog = BP.prog;
+        if (build_ahead && bi + 1 < nbatch) builder = std::thread(build_batch, bi + 1);
         tr.mark("build_program");
         const GeometryPlan gp = plan_geometry(ctx, p, g, prog, B, d, resume, carry, &taps);
         const bool fast = gp.fast, fused1d = gp.fused1d, use_mfma = gp.use_mfma;
@@ -2342,7 +2348,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         redF = ctx->pinF.as<double>();
         HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
         tr.mark("forward pass queued");
-        if (bi + 1 < nbatch) { build_batch(bi + 1); tr.mark("next batch's program"); }
         sync_stream(ctx, st);
         tr.mark("forward pass done + sums D2H");
         ms = 0;
@@ -2366,7 +2371,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         // (the launch-per-step backward pass of a batch of chains needs nothing of the forward pass's host bookkeeping: it is done
         //  while the GPU runs that pass -- 11 ms of the published break-point study's fit, 23 batches of 1017 chains)
-        const bool late_fb = full && !fused1d && !res_now && !cres_now && !p1d_now && B >= 64;
+        const bool late_fb = full && (!fused1d || c1d_now) && !res_now && !cres_now && !p1d_now && B >= 64;
         bool raw_ok = late_fb ? true : forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
         tr.mark("forward checks + bookkeeping");
 
