@@ -1595,8 +1595,11 @@ void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hip
 }
 
 // the whole fold on the main stream, waited for
+// (later_ev: do not wait -- the fold stays in front of whatever the stream runs next, e.g. the next batch's metadata uploads and forward
+//  pass; its two timing events are appended for the caller to read after the stream has drained.  The page-locked staging of the weights is
+//  reused by the next batch's fold only after that batch's passes have been waited for, on the same stream.)
 void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const BatchOutcome &out, const double *log_w_batch, const double *d_post,
-                     double *d_w, double *d_invN, int sm_n0 = 0, const FoldJob *layout = nullptr) {
+                     double *d_w, double *d_invN, int sm_n0 = 0, const FoldJob *layout = nullptr, std::vector<hipEvent_t> *later_ev = nullptr) {
     ctx->pinA.ensure(((size_t)B + (size_t)T * B) * 8);
     FoldJob job;
     if (layout) job = *layout;
@@ -1604,6 +1607,13 @@ void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const Ba
     job.h_w = ctx->pinA.as<double>(); job.h_invN = job.h_w + B;
     job.d_w = d_w; job.d_invN = d_invN; job.d_post = d_post;
     if (!prepare_fold(ctx, T, B, out, log_w_batch, job)) return;
+    if (later_ev) {
+        hipEvent_t e0, e1;
+        HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+        later_ev->push_back(e0); later_ev->push_back(e1);
+        launch_fold(ctx, T, G, job, ctx->stream, e0, e1);
+        return;
+    }
     launch_fold(ctx, T, G, job, ctx->stream, ctx->ev[4], ctx->ev[5]);
     sync_stream(ctx, ctx->stream);
     float ms = 0;
@@ -2499,7 +2509,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             FoldJob lay;
             const bool padded = CR.on && CR.cp.pad && !resident_failed;
             if (padded) { lay.pad_n0p = CR.cp.n0p; lay.pad_n0 = g.n0; lay.pad_n1 = g.n1; lay.pad_step = CR.Gk; }
-            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (CR.post_private && !resident_failed && !padded) ? g.n0 : 0, padded ? &lay : nullptr);
+            // (many small batches: nobody waits for a batch's fold; the last one is waited for with the stream below)
+            fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (CR.post_private && !resident_failed && !padded) ? g.n0 : 0, padded ? &lay : nullptr,
+                            (nbatch >= 4 && !keep && !carry) ? &fold_ev : nullptr);
         }
         if (keep) {
             int64_t row0 = 0, row1 = T;              // rows the resident kernel normalised in place (invN = 1 there) need no pass
@@ -2512,8 +2524,8 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         tr.mark("fold / keep / carry");
         write_results(res, p, c0, B, O, !evidence_only);
     }
-    if (overlap_acc) {                         // the last fold(s) before anybody reads the accumulator; their time from their events
-        sync_stream(ctx, ctx->astream);
+    if (overlap_acc || !fold_ev.empty()) {     // the last fold(s) before anybody reads the accumulator; their time from their events
+        sync_stream(ctx, overlap_acc ? ctx->astream : st);
         for (size_t k = 0; k + 1 < fold_ev.size(); k += 2) {
             float fms = 0;
             HIPCHECK(hipEventElapsedTime(&fms, fold_ev[k], fold_ev[k + 1]));
