@@ -21,6 +21,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <system_error>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -1977,7 +1978,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (BP.err) std::rethrow_exception(BP.err);
         TapTable &taps = BP.taps;
         ChainProgram &prog = BP.prog;
-        if (build_ahead && bi + 1 < nbatch) builder = std::thread(build_batch, bi + 1);
+        if (build_ahead && bi + 1 < nbatch) {
+            try { builder = std::thread(build_batch, bi + 1); }
+            catch (const std::system_error &) {}        // (no thread to be had: the batch is built at its own top, as before)
+        }
         tr.mark("build_program");
         const GeometryPlan gp = plan_geometry(ctx, p, g, prog, B, d, resume, carry, &taps);
         const bool fast = gp.fast, fused1d = gp.fused1d, use_mfma = gp.use_mfma;
