@@ -210,7 +210,10 @@ int         blhip_synchronize(blhip_ctx *ctx);
 /* Runs n_chains independent forward(-backward) passes that share `problem` and differ in the hyper-parameter value
  * of each op: op_values is (n_chains, n_ops), row-major; entries of STATIC ops are ignored.
  * log_chain_weight (n_chains,) is only read with BLHIP_ACCUMULATE: log of the hyper-prior value of each chain
- * (core.py:1366); the library adds the chain's log-evidence itself. */
+ * (core.py:1366); the library adds the chain's log-evidence itself.
+ * Threads: a call with several batches of chains starts ONE helper thread that prepares the next batch's per-step programs
+ * from `problem` / `op_values` (read-only, no HIP call) and is joined before the call returns -- also on errors; option
+ * build_ahead = 0 keeps everything on the calling thread.  One context must not be used by two threads at once. */
 int blhip_fit(blhip_ctx *ctx, const blhip_problem *problem, int64_t n_chains, const double *op_values,
               const double *log_chain_weight, uint32_t flags, blhip_result *result);
 
