@@ -581,10 +581,14 @@ template <int NK, int NTW>
 void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store, bool pad) {
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
     if (pad) {                          // grids smaller than the geometry (the folding backward pass: launch_fold2)
-        if (bwd && !store) fail("internal: padded chain-resident launch of a folding backward pass");
-        if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true>, s, Q, lds);
-        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
-        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true>, s, Q, lds);
+        if constexpr (NTW <= 4) {
+            if (bwd && !store) fail("internal: padded chain-resident launch of a folding backward pass");
+            if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true>, s, Q, lds);
+            else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
+            else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true>, s, Q, lds);
+        } else {
+            fail("internal: the 1024-row chain-resident kernels have no padded variant");
+        }
         return;
     }
     if (bwd && !store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false>, s, Q, lds);      // posteriors folded, not stored
@@ -596,7 +600,10 @@ void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool sto
 template <int NTW>
 void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
     switch (nk) {
-        case 4: launch_chain_k<4, NTW>(s, Q, bwd, store, pad); break;       // no stencil (change-point studies)
+        case 4:                                                               // no stencil (change-point studies)
+            if constexpr (NTW <= 4) launch_chain_k<4, NTW>(s, Q, bwd, store, pad);
+            else fail("internal: the 1024-row chain-resident kernels need a stencil");
+            break;
         case 6: launch_chain_k<6, NTW>(s, Q, bwd, store, pad); break;         // band = 16 + 2 R0 columns, R0 = 4, 8, ... 40
         case 8: launch_chain_k<8, NTW>(s, Q, bwd, store, pad); break;
         case 10: launch_chain_k<10, NTW>(s, Q, bwd, store, pad); break;
@@ -613,6 +620,7 @@ void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, 
 
 void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
     if (ntw == 4) launch_chain_w<4>(s, Q, nk, bwd, store, pad);
+    else if (ntw == 8) launch_chain_w<8>(s, Q, nk, bwd, store, pad);          // 1024 rows: one copy of the strip in LDS (blc::chain_kernel TALL)
     else if (ntw == 3) launch_chain_w<3>(s, Q, nk, bwd, store, pad);
     else if (ntw == 2) launch_chain_w<2>(s, Q, nk, bwd, store, pad);
     else if (ntw == 1) launch_chain_w<1>(s, Q, nk, bwd, store, pad);
@@ -1234,6 +1242,8 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
 
 // memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
 constexpr int CHAIN_MIN_ROWS = 32;            // smallest grid (rows) the chain-resident kernels take (on the 128-row geometry)
+constexpr int CHAIN_TALL_ROWS = 1024;         // ... and the one geometry beyond 512 rows (option chain_tall = 0: off)
+inline bool chain_rows_ok(int n0) { return (n0 >= CHAIN_MIN_ROWS && n0 <= 512) || n0 == CHAIN_TALL_ROWS; }
 
 int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int64_t n_chains, int post_buffers) {
     const int64_t T = p->T;
@@ -1246,12 +1256,12 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
                              ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
     // the chain-resident kernels lay their sequences out on a padded geometry (rows 128 / 256 / 512, columns a multiple of 16)
     double Gk = (double)G;
-    if (p->ndim == 2 && g.n0 >= CHAIN_MIN_ROWS && g.n0 <= 512)
+    if (p->ndim == 2 && chain_rows_ok(g.n0))
         Gk = (double)((g.n0 + 127) / 128 * 128) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
     // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
     // -- only where the chain-resident path can be taken at all (else they are never allocated: a narrow grid with a long series
     //    gave up its whole budget to 128 slots it never used and ran one chain per batch), and never more than half of the budget
-    if (ff.accumulate && ff.full && p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && g.n0 >= CHAIN_MIN_ROWS && g.n0 <= 512 &&
+    if (ff.accumulate && ff.full && p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && chain_rows_ok(g.n0) &&
         g.n1 >= 1 && g.n1 <= 16 * blc::MAX_STRIPS && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok) {
         const double slots = std::max(1, std::min(ctx->num_cus, 256) / ((g.n1 + blc::WCOL - 1) / blc::WCOL));
         budget -= std::min(0.5 * budget, std::min<double>(slots, (double)n_chains) * (double)T * Gk * 8.0);
@@ -1664,11 +1674,13 @@ struct ChainResPlan {
 
 // every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
 bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
-    // any grid of 32 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns
-    if (g.n0 < CHAIN_MIN_ROWS || g.n0 > 512) return false;
+    // any grid of 32 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns;
+    // 1024 rows x a multiple of 16 columns exactly (one copy of the strip in LDS: blc::chain_kernel TALL; filtering chains only)
+    if (!chain_rows_ok(g.n0)) return false;
     cp.n0p = (g.n0 + 127) / 128 * 128;
     cp.n1p = (g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL;
     cp.pad = cp.n0p != g.n0 || cp.n1p != g.n1;
+    if (g.n0 == CHAIN_TALL_ROWS && (cp.pad || prog.LW0 == 0)) return false;
     cp.strips = cp.n1p / blc::WCOL;
     cp.ntw = cp.n0p / (blc::NW * blc::TM);
     if (cp.strips > blc::MAX_STRIPS || cp.strips > cus) return false;
@@ -1920,7 +1932,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     //      two under-filled launches per step (round 1: the 107-chain radius-24 bucket of the C4 study ran as 36 + 71 chains at
     //      4.1 TB/s); hyper-grids are usually monotone in the random-walk width, so contiguous cuts suffice.
     // (cuts on radius-bucket boundaries serve the launch-per-step kernels; grids the chain-resident kernel takes keep whole launches)
-    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && g.n0 >= CHAIN_MIN_ROWS && g.n0 <= 512 && g.n1 <= 16 * blc::MAX_STRIPS &&
+    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && chain_rows_ok(g.n0) && g.n1 <= 16 * blc::MAX_STRIPS &&
                              ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok;
     std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && !chain_shape && ctx->option("bucket_batches", 1.0) != 0.0);
     if (overlap_acc) {                     // (equal batches, multiples of 32 chains: whole launches of the chain-resident kernel)

@@ -171,7 +171,7 @@ __device__ __forceinline__ int band_distance(int e, int R0) {
 }
 
 template <int NK, int NTW>
-constexpr size_t lds_doubles() { return (size_t)2 * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
+constexpr size_t lds_doubles() { return (size_t)(NTW > 4 ? 1 : 2) * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
 
 #ifdef BLC_PROF
 #define BLC_STAMP(i) do { if (prof_me && k >= 8 && k < 24) P.prof[(wv ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -199,9 +199,14 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     const int n0t = PAD ? P.n0t : N0, n1t = PAD ? P.n1t : P.n1;      // the grid's true sizes
     static_assert(NK == 4 || (NK >= 6 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
     constexpr bool FILTER = NK > 4;
+    // TALL (NTW = 8: 1024 rows): LDS holds ONE copy of the strip (128 KB), not two.  A step's new state waits in registers until every
+    // wave has read its rings (the step's barrier), is written then, and a second barrier releases the next step -- the scheme of
+    // chain_fold2_kernel.  (Exact geometry only: no padded variant; the folding backward pass is the single-chain one.)
+    constexpr bool TALL = NTW > 4;
+    static_assert(!(TALL && PAD), "1024 rows: the exact geometry only");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *const X = lds;                     // [2][N0][16]
-    double *const As = X + 2 * XSZ;            // [NK][64]   A operand: W[m][k] = w(|k - R0 - m|)
+    double *const X = lds;                     // [2][N0][16]   (TALL: [1][N0][16])
+    double *const As = X + (TALL ? 1 : 2) * XSZ;   // [NK][64]   A operand: W[m][k] = w(|k - R0 - m|)
     double *const m0s = As + NK * 64;          // [N0]       row coordinates
     double *const red = m0s + N0;              // [2][NW * 4][5] sums of the waves' rows of 16 lanes, double-buffered by step parity
     double *const scal = red + 2 * NW * 4 * 5;     // [NSLOT] the scales s_j of the steps around the current one (written by the scale wave)
@@ -250,12 +255,14 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     double xd[DMAX], xn[DMAX];
 #pragma unroll
     for (int q = 0; q < DMAX; ++q) xd[q] = q < P.d ? P.rec[(long long)t_first * P.rec_len + q] : __builtin_nan("");
-    double al[NTW][4];                     // backward: the stored alpha of the lane's cells; a slot is re-filled for the NEXT step right
+    // (TALL: 1024 rows leave no room for a whole step of stored alpha beside the new state -- a ring of ALD tiles, re-filled ALD tiles ahead)
+    constexpr int ALD = NTW > 4 ? 2 : NTW;        // (a divisor of NTW: a tile keeps its slot from step to step)
+    double al[ALD][4];                     // backward: the stored alpha of the lane's cells; a slot is re-filled for the NEXT step right
     if (BWD) {                             // after it has been consumed, i.e. a whole step before its next use
 #pragma unroll
         for (int it = 0; it < NTW; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) al[it][r] = blm::ld32(pchain + (long long)t_first * G, cell_off(lane, it, r));
+            for (int r = 0; r < 4; ++r) if (it < ALD) al[it][r] = blm::ld32(pchain + (long long)t_first * G, cell_off(lane, it, r));
     }
     // NK = 4 (no stencil): a step is elementwise, so the state of the lane's 4 NTW cells never leaves its registers -- and neither does
     // the reset distribution a change point restarts from (loaded once).  No LDS traffic, no memory instruction under control flow
@@ -334,8 +341,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
 
         // ---- ring over the source state -----------------------------------------------------------------------------------------------
-        double *S = X + (k & 1) * XSZ;
-        double *D = X + ((k + 1) & 1) * XSZ;
+        double *S = TALL ? X : X + (k & 1) * XSZ;
+        double *D = TALL ? X : X + ((k + 1) & 1) * XSZ;
+        double nst[(TALL && FILTER) ? NTW : 1][4];     // (TALL) the step's new state, written after the barrier
         if (FILTER && kind != blk::SRC_PREV && k > 0) {
             // a change point inside a filtering chain (random walk + change point in one model): this step's source buffer takes the
             // reset distribution (rare: once per chain and change point; the loads are consumed inside the branch)
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 const unsigned off = cell_off(l, it, r);
                 if (!BWD) {
                     const double a = (!PAD || (colok && li < n0t)) ? acc[r] * Lv : 0.0;          // (cells outside the grid stay zero)
-                    if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
+                    if (TALL && FILTER) nst[it][r] = a; else if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
                     if (STORE && t >= tsh) stnt(pstep, off, a);
                     sN += a;
                     if (!FILTER && want_x) sS = fma(a, rst[it][r], sS);
@@ -475,11 +483,11 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 } else {
                     const bool in = !PAD || (colok && li < n0t);                                 // (cells outside the grid stay zero)
                     const double beta = in ? acc[r] * scale : 0.0;
-                    const double p = al[it][r] * beta;
+                    const double p = al[it % ALD][r] * beta;
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
                     const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));
-                    if (FILTER) D[li * WCOL + c] = cn; else stt[it][r] = cn;
+                    if (TALL && FILTER) nst[it][r] = cn; else if (FILTER) D[li * WCOL + c] = cn; else stt[it][r] = cn;
                     if (!FOLD) stnt(pstep, off, p);
                     else stnt(pslot_t, off, pa[r] + fmax(p * wq, wfloor));      // (nobody else touches the slot's cell during the launch)
                     sN += p;
@@ -505,7 +513,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) al[it][r] = ldnt(pnext, cell_off(l, it, r));
+                for (int r = 0; r < 4; ++r)         // the slot's next use: this tile of the next step -- or, TALL, the tile ALD further on
+                    al[it % ALD][r] = (it + ALD < NTW) ? ldnt(pstep, cell_off(l, it + ALD, r)) : ldnt(pnext, cell_off(l, it + ALD - NTW, r));
             }
             if ((BWD || STORE) && P.means) {
 #pragma unroll
@@ -553,13 +562,20 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         BLC_STAMP(6);
         __syncthreads();
         BLC_STAMP(7);
+        if (TALL && FILTER) {              // every ring of this step has been read: the new state takes the strip's place
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) D[(row0 + it * TM + g + 4 * r) * WCOL + c] = nst[it][r];
+        }
         if (FILTER && k == 0) {            // the chain's band replaces the identity of the first step
             for (int e = tid; e < NK * 64; e += NT) {
                 const int a = band_distance(e, R0);
                 As[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);
             }
-            __syncthreads();
         }
+        if (FILTER && (TALL || k == 0)) __syncthreads();
         if (wv == 5 && lane < nv) {           // (a wave that shares its SIMD with no edge wave)
             double tot = 0.0;
 #pragma unroll

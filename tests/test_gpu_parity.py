@@ -1300,6 +1300,11 @@ CHAINRES = {
                                               tm=('ChangePoint', 'tChange', 'all', None), fit=dict(evidenceOnly=True)),
     # 64 strips per chain (every lane of the scale wave gathers one granule), 4 chains per launch
     'cres_128x1024_64_strips': _hyper(128, 1024, 65, 5, ('cint', 0.05, 0.9, 6)),
+    # 1024 rows: ONE copy of the strip in LDS, the new state waits in registers for the step's barrier (blc::chain_kernel TALL); the
+    # stored alpha of the backward pass in a ring of two tiles; full fit (single-chain fused fold), evidence-only, widest band (radius 40)
+    'cres_1024x32_tall': _hyper(1024, 32, 66, 6, ('cint', 0.01, 0.15, 6)),
+    'cres_1024x48_tall_evidence': _hyper(1024, 48, 67, 5, ('cint', 0.02, 0.12, 4), evidenceOnly=True),
+    'cres_1024x16_tall_r40': _hyper(1024, 16, 68, 7, ('cint', 0.15, 0.156, 2)),
     # T = 1 and T = 2 (shorter than the lag)
     'cres_T1': _hyper(128, 32, 57, 1, ('cint', 0, 0.5, 3)),
     'cres_T2': _hyper(128, 32, 58, 2, ('cint', 0, 0.5, 3)),
