@@ -458,9 +458,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     dn_prev = dn;
                 }
                 if (BWD) {
-                    int tmp;
-                    exp_mn(-a0, iE, tmp);
-                    exp_mn(-d1, iR, tmp);
+                    iE = blmath::inv_m(mE); iR = blmath::inv_m(mR);      // (exp(-a0), exp(-d1): same exponents, reciprocal mantissas)
                 } else {
                     mE *= scale;                     // forward: the scale rides on the likelihood's mantissa (one product per cell less)
                 }

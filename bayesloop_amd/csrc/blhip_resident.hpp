@@ -768,9 +768,7 @@ struct Res {
                 }
                 rc.mq = mq_c; rc.nq = nq_c; rc.iq = iq_c;
                 if (BWD) {
-                    int tmp;
-                    blmath::exp_mn(-a0, rc.iE, tmp);
-                    blmath::exp_mn(-d1, rc.iR, tmp);
+                    rc.iE = blmath::inv_m(rc.mE); rc.iR = blmath::inv_m(rc.mR);      // (exp(-a0), exp(-d1): same exponents, reciprocal mantissas)
                 } else {
                     rc.mE *= scale;                  // forward: the step's scale rides on the likelihood's mantissa (one product per cell less)
                 }
