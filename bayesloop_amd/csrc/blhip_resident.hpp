@@ -391,11 +391,7 @@ struct Res {
     // queues up behind the previous chunk's posterior stores (one counter orders a wave's vector loads and stores: with a load per
     // chunk every wait for the state also waited for the stores of the chunk before -- 27 us per step at 2048^2, twice the forward pass).
     // The window registers and the epilogue's registers are never live together (the fused form spilled 70 VGPRs).
-#ifdef BLR_NO_DEFER                   // (A/B builds)
-    static constexpr bool DEFER = false;
-#else
     static constexpr bool DEFER = BWD && !ONE && !FULLW;
-#endif
     // The lagged global sum is gathered by HALF of the block's waves -- the half that reaches the barrier after the axis-1 pass early
     // (multi-chunk shapes: the edge segments, dealt to the first waves, have issue priority over their SIMD partners; one-chunk
     // shapes: the edge waves wait for their neighbours there, the others are early) -- in that slack, not by everybody after it.
@@ -425,16 +421,8 @@ struct Res {
     // as a per-lane value they were lane masks the allocator kept -- and spilled -- as 64-bit pairs (most of the ~600 v_readlane of the
     // step loop restore such masks).  Same box, A/B (profiles/r04_notes.md): 2048^2 forward step 10.35 - 10.48 -> 9.74 - 9.80 us.  Only in
     // the multi-chunk forward kernels: the one-chunk tiles got 4 % SLOWER with it (C3 5.68 / 6.73 -> 5.93 / 6.94 us) and the multi-chunk
-    // backward kernel, which has no register to spare, spilled more (164 -> 280 bytes of scratch).
-#ifdef BLR_NO_UNIFORM_SEG            // (A/B builds)
-    static constexpr bool WAVE_UNIFORM_SEG_H = false, WAVE_UNIFORM_SEG_V = false;
-#else
-#ifdef BLR_UNIFORM_BWD
-    static constexpr bool WAVE_UNIFORM_SEG_H = TR % 64 == 0 && SEG != CHK, WAVE_UNIFORM_SEG_V = TC % 64 == 0 && SEG != CHK;
-#else
+    // backward kernel measured slower with it, before and after its two-phase axis-0 pass (21.7 - 22.1 vs 20.8 - 21.3 us).
     static constexpr bool WAVE_UNIFORM_SEG_H = TR % 64 == 0 && SEG != CHK && !BWD, WAVE_UNIFORM_SEG_V = TC % 64 == 0 && SEG != CHK && !BWD;
-#endif
-#endif
 
     struct Thread {
         int tid, tile, ti, tj, i0, j0, tr, tc;       // (tile .. tc: block-uniform)
@@ -1038,9 +1026,6 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             th.begin_step(Q, k);
             th.first_step(Q);
         } else {
-#ifdef BLR_ALPHA_EARLY                 // (A/B builds: the stored state requested before the axis-1 pass)
-            th.alpha_issue(Q, k);
-#endif
             th.h_preread();
             BLR_STAMP(1);
             if (k >= Q.lag && gw >= 0) th.gather_issue(Q, k - Q.lag);
@@ -1048,9 +1033,7 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             lds_barrier();
             BLR_STAMP(3);
             th.h_walk(Q, k);
-#ifndef BLR_ALPHA_EARLY
-            th.alpha_issue(Q, k);
-#endif
+            th.alpha_issue(Q, k);                     // (requested BEFORE the axis-1 pass instead: 21.9 - 22.2 vs 20.8 - 21.3 us, profiles/r04_notes.md)
             BLR_STAMP(4);
             if (booker) book(k - 1);
             BLR_STAMP(5);
