@@ -141,23 +141,25 @@ __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) {
 #define BLC_BAND4 1
 #endif
 typedef const double __attribute__((address_space(3))) *band_cp;
-template <int NK>
-__device__ __forceinline__ d4 band_products(band_cp Al, const double (&Bv)[NK]) {
+// (Bv: a ring of NR >= OFF + NK entries, the tile's window begins at entry OFF -- compile-time, so the entries stay registers)
+template <int NK, int OFF = 0, int NR = NK>
+__device__ __forceinline__ d4 band_products(band_cp Al, const double (&Bv)[NR]) {
+    static_assert(OFF + NK <= NR, "the tile's window lies inside the ring");
 #if BLC_BAND4
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
     for (int s = 0; s < NK - 3; ++s) {
         const double A = Al[s * 64];
-        a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s + 1], a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s + 2], a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[s + 3], a3, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[OFF + s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[OFF + s + 1], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[OFF + s + 2], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[OFF + s + 3], a3, 0, 0, 0);
     }
     return d4{a0, a1, a2, a3};
 #else
     d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[kb], acc, 0, 0, 0);
+    for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[OFF + kb], acc, 0, 0, 0);
     return acc;
 #endif
 }
@@ -356,16 +358,26 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         // (interior waves: consecutive k-blocks are 512 bytes apart -- one address register, immediate offsets; only waves whose
         //  window reaches beyond the grid edge pay for the reflection)
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > n0t;          // (the reflection is at the grid's true last row)
-        double Bv[NK];
+        // WHOLE_RING (forward kernels of <= 512 rows): the ring entries of ALL the wave's tiles are read when the step begins (NK + 4 (NTW - 1)
+        // registers instead of NK) and a tile's products take their window at a compile-time offset -- no ring shift, no reads and no
+        // edge test between the tiles.  (The sliding ring cost 20 v_mov per tile where its edge / interior load paths joined: a fifth of the
+        // forward kernel's vector instructions were moves.  The backward kernels have no registers for it.)
+#ifdef BLC_NO_WHOLE_RING
+        constexpr bool WHOLE_RING = false;
+#else
+        constexpr bool WHOLE_RING = FILTER && !BWD && NTW <= 4;
+#endif
+        constexpr int NRING = WHOLE_RING ? NK + 4 * (NTW - 1) : NK;
+        double Bv[NRING];
         if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (edge) {
 #pragma unroll
-                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, n0t) * WCOL + c];
+                for (int kb = 0; kb < NRING; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, n0t) * WCOL + c];
             } else {
                 const double *s0 = S + (row0 - R0 + g) * WCOL + c;
 #pragma unroll
-                for (int kb = 0; kb < NK; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
+                for (int kb = 0; kb < NRING; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
             }
         }
 
@@ -397,6 +409,10 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 if (nofilter) {                              // (the change point comes after the walk in the model's list: the source unfiltered)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = S[(i + g + 4 * r) * WCOL + c];
+                } else if constexpr (WHOLE_RING) {
+                    // (`it` is a compile-time constant of the unrolled loop: one instantiation per tile)
+                    acc = it == 0 ? band_products<NK, 0, NRING>(Al, Bv) : (it == 1 ? band_products<NK, (NTW > 1 ? 4 : 0), NRING>(Al, Bv) :
+                          (it == 2 ? band_products<NK, (NTW > 2 ? 8 : 0), NRING>(Al, Bv) : band_products<NK, (NTW > 3 ? 12 : 0), NRING>(Al, Bv)));
                 } else {
                     acc = band_products<NK>(Al, Bv);
                 }
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             if (it == 0) BLC_STAMP(4);
             if (it == NTW - 1) BLC_STAMP(5);
             // ---- advance the ring by one tile --------------------------------------------------------------------------------------
-            if (FILTER && it + 1 < NTW) {
+            if (FILTER && !WHOLE_RING && it + 1 < NTW) {
 #pragma unroll
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
                 if (edge) {
