@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         // WHOLE_RING (forward kernels of <= 512 rows): the ring entries of ALL the wave's tiles are read when the step begins (NK + 4 (NTW - 1)
         // registers instead of NK) and a tile's products take their window at a compile-time offset -- no ring shift, no reads and no
         // edge test between the tiles.  (The sliding ring cost 20 v_mov per tile where its edge / interior load paths joined: a fifth of the
-        // forward kernel's vector instructions were moves.  The backward kernels have no registers for it.)
+        // forward kernel's vector instructions were moves.  The two-chain backward kernel fits it too and does not gain: profiles/r04_notes.md.)
 #ifdef BLC_NO_WHOLE_RING
         constexpr bool WHOLE_RING = false;
 #else
