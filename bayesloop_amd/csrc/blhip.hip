@@ -614,7 +614,25 @@ void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, 
         case 20: launch_chain_k<20, NTW>(s, Q, bwd, store, pad); break;
         case 22: launch_chain_k<22, NTW>(s, Q, bwd, store, pad); break;
         case 24: launch_chain_k<24, NTW>(s, Q, bwd, store, pad); break;
-        default: fail("internal: chain-resident kernel with %d band blocks", nk);
+        default:
+            // 1024 rows: bands up to 16 + 2 x 80 columns (a strip of 1024 rows at twice the resolution carries twice the radius; the ring
+            // of 44 entries fits the 256 registers of two waves per SIMD, the band table the 32 KB of LDS beside the strip)
+            if constexpr (NTW == 8) {
+                switch (nk) {
+                    case 26: launch_chain_k<26, NTW>(s, Q, bwd, store, pad); return;
+                    case 28: launch_chain_k<28, NTW>(s, Q, bwd, store, pad); return;
+                    case 30: launch_chain_k<30, NTW>(s, Q, bwd, store, pad); return;
+                    case 32: launch_chain_k<32, NTW>(s, Q, bwd, store, pad); return;
+                    case 34: launch_chain_k<34, NTW>(s, Q, bwd, store, pad); return;
+                    case 36: launch_chain_k<36, NTW>(s, Q, bwd, store, pad); return;
+                    case 38: launch_chain_k<38, NTW>(s, Q, bwd, store, pad); return;
+                    case 40: launch_chain_k<40, NTW>(s, Q, bwd, store, pad); return;
+                    case 42: launch_chain_k<42, NTW>(s, Q, bwd, store, pad); return;
+                    case 44: launch_chain_k<44, NTW>(s, Q, bwd, store, pad); return;
+                    default: break;
+                }
+            }
+            fail("internal: chain-resident kernel with %d band blocks", nk);
     }
 }
 
@@ -1117,7 +1135,7 @@ std::vector<int64_t> plan_batches(const blhip_problem *p, int64_t n_chains, cons
 // One more cut where the axis-0 radius of a hyper-grid crosses the largest band of the matrix-pipe / chain-resident kernels (40): the
 // chains below it keep those kernels, the chains above it take the column pre-pass (blh::vwide_kernel) -- without the cut ONE wide chain
 // would route its whole batch through the pre-pass.  Only for grids sorted that way (every chain before the cut <= 40 < every chain after).
-void split_wide_axis0(const blhip_problem *p, int64_t n_chains, const double *op_values, std::vector<int64_t> &start) {
+void split_wide_axis0(const blhip_problem *p, int64_t n_chains, const double *op_values, std::vector<int64_t> &start, int r_max) {
     if (p->ndim != 2 || !op_values || p->n_ops == 0 || n_chains < 2) return;
     auto radius0 = [&](int64_t c) {
         int r0 = 0;
@@ -1135,7 +1153,7 @@ void split_wide_axis0(const blhip_problem *p, int64_t n_chains, const double *op
     for (int64_t c = 0; c < n_chains; ++c) {
         const int r = radius0(c);
         if (r < 0) return;
-        if (r > FAST_R0_MAX) { if (cut < 0) cut = c; }
+        if (r > r_max) { if (cut < 0) cut = c; }
         else if (cut >= 0) return;                   // a narrow chain after a wide one: not sorted by radius
     }
     if (cut <= 0) return;
@@ -1242,6 +1260,7 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
 
 // memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
 constexpr int CHAIN_MIN_ROWS = 32;            // smallest grid (rows) the chain-resident kernels take (on the 128-row geometry)
+constexpr int CHAIN_TALL_R0_MAX = 80;          // widest band of the 1024-row kernels (blc::chain_kernel<44, 8, ...>); every other geometry: FAST_R0_MAX
 constexpr int CHAIN_TALL_ROWS = 1024;         // ... and the one geometry beyond 512 rows (option chain_tall = 0: off)
 inline bool chain_rows_ok(int n0) { return (n0 >= CHAIN_MIN_ROWS && n0 <= 512) || n0 == CHAIN_TALL_ROWS; }
 
@@ -1665,6 +1684,7 @@ struct ChainResPlan {
     int ntw = 0, strips = 0, cpr = 0;            // product tiles per wave, strips per chain, chains per launch
     int n0p = 0, n1p = 0;                        // the geometry the kernels work on: rows 128 / 256 / 512, columns a multiple of 16
     bool pad = false;                            // the grid is smaller than that (padded cells hold zeros; sequences private to the fit only)
+    int r0_max = 40;                             // widest axis-0 radius the launch may carry (set by the caller: 80 for 1024 rows)
     bool has_reset = false;                      // change points: some steps consume the reset distribution
     bool mixed = false;                          // ... in chains that also filter (random walk + change point in one model)
     std::vector<unsigned char> ckF, ckB;         // [T][B] what a step of the chain kernels consumes: SRC_PREV / SRC_RESET (| 0x80: unfiltered)
@@ -1723,7 +1743,7 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
         }
         cp.tap_id[b] = k0;
         lw[b] = k0 >= 0 ? taps.lw[k0] : 0;
-        if (lw[b] > 40 || lw[b] >= g.n0) return false;          // (single-period reflection)
+        if (lw[b] > cp.r0_max || lw[b] >= g.n0) return false;          // (single-period reflection)
     }
     cp.order.resize(B);
     for (int64_t b = 0; b < B; ++b) cp.order[b] = (int)b;
@@ -1940,7 +1960,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         for (int64_t c = 0; c < n_chains; c += Bmax) batch_start.push_back(c);
         batch_start.push_back(n_chains);
     }
-    if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0) split_wide_axis0(p, n_chains, op_values, batch_start);
+    // (the cut: 40; 1024-row grids the chain-resident kernels take: 80)
+    const bool tall_wide = chain_shape && g.n0 == CHAIN_TALL_ROWS && ctx->option("chain_tall", 1.0) != 0.0 && ctx->option("chain_tall_wide", 1.0) != 0.0;
+    if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0)
+        split_wide_axis0(p, n_chains, op_values, batch_start, tall_wide ? CHAIN_TALL_R0_MAX : FAST_R0_MAX);
     const int64_t nbatch = (int64_t)batch_start.size() - 1;
     ctx->timing.batches = nbatch;
 

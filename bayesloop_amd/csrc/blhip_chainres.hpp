@@ -142,14 +142,16 @@ __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) {
 #endif
 typedef const double __attribute__((address_space(3))) *band_cp;
 // (Bv: a ring of NR >= OFF + NK entries, the tile's window begins at entry OFF -- compile-time, so the entries stay registers)
-template <int NK, int OFF = 0, int NR = NK>
+// (AST: doubles between the tables of two shifts.  64 = one entry per lane; 16 = one entry per (k, i) pair, read by the four lanes
+//  that share it -- the four column groups multiply the same band: a quarter of the LDS, same-address reads are broadcasts)
+template <int NK, int OFF = 0, int NR = NK, int AST = 64>
 __device__ __forceinline__ d4 band_products(band_cp Al, const double (&Bv)[NR]) {
     static_assert(OFF + NK <= NR, "the tile's window lies inside the ring");
 #if BLC_BAND4
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
     for (int s = 0; s < NK - 3; ++s) {
-        const double A = Al[s * 64];
+        const double A = Al[s * AST];
         a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[OFF + s], a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[OFF + s + 1], a1, 0, 0, 0);
         a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[OFF + s + 2], a2, 0, 0, 0);
@@ -157,6 +159,7 @@ __device__ __forceinline__ d4 band_products(band_cp Al, const double (&Bv)[NR]) 
     }
     return d4{a0, a1, a2, a3};
 #else
+    static_assert(AST == 64, "the 16x16x4 form: one entry per lane");
     d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[OFF + kb], acc, 0, 0, 0);
@@ -171,9 +174,11 @@ __device__ __forceinline__ int band_distance(int e, int R0) {
     return abs(4 * (e >> 6) + ((e & 63) >> 4) - R0 - (e & 15));
 #endif
 }
+// ... of a compact table [NK][16] (entry 4 k + i of a shift)
+__device__ __forceinline__ int band_distance16(int e, int R0) { return abs(4 * (e >> 4) + ((e & 15) >> 2) - R0 - (e & 3)); }
 
 template <int NK, int NTW>
-constexpr size_t lds_doubles() { return (size_t)(NTW > 4 ? 1 : 2) * NW * NTW * TM * WCOL + NK * 64 + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
+constexpr size_t lds_doubles() { return (size_t)(NTW > 4 ? 1 : 2) * NW * NTW * TM * WCOL + NK * (NTW > 4 ? 16 : 64) + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
 
 #ifdef BLC_PROF
 #define BLC_STAMP(i) do { if (prof_me && k >= 8 && k < 24) P.prof[(wv ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -208,8 +213,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     static_assert(!(TALL && PAD), "1024 rows: the exact geometry only");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *const X = lds;                     // [2][N0][16]   (TALL: [1][N0][16])
-    double *const As = X + (TALL ? 1 : 2) * XSZ;   // [NK][64]   A operand: W[m][k] = w(|k - R0 - m|)
-    double *const m0s = As + NK * 64;          // [N0]       row coordinates
+    constexpr int AST = (TALL && BLC_BAND4) ? 16 : 64;     // (TALL: the compact band table -- the strip leaves 32 KB, the widest band has 44 shifts)
+    double *const As = X + (TALL ? 1 : 2) * XSZ;   // [NK][AST]  A operand: W[m][k] = w(|k - R0 - m|)
+    double *const m0s = As + NK * AST;         // [N0]       row coordinates
     double *const red = m0s + N0;              // [2][NW * 4][5] sums of the waves' rows of 16 lanes, double-buffered by step parity
     double *const scal = red + 2 * NW * 4 * 5;     // [NSLOT] the scales s_j of the steps around the current one (written by the scale wave)
     double *const iscal = scal + NSLOT;            // [NSLOT] 1 / s_j
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     // ---- prologue: band, row coordinates, first source -> LDS ---------------------------------------------------------------------
     // the first step consumes its source unfiltered: it runs with the identity band (exact), the chain's band replaces it afterwards
     // (one code path for every step: no per-step branches around the ring and the products)
-    if (FILTER) for (int e = tid; e < NK * 64; e += NT) As[e] = band_distance(e, R0) == 0 ? 1.0 : 0.0;
+    if (FILTER) for (int e = tid; e < NK * AST; e += NT) As[e] = (AST == 16 ? band_distance16(e, R0) : band_distance(e, R0)) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[PAD ? min(e, n0t - 1) : e];
     if (tid < 2 * NSLOT) scal[tid] = 1.0;
     if (FILTER) for (int e = tid; e < XSZ; e += NT) {
@@ -404,17 +410,18 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[r] = stt[it][r];          // no stencil: the product tile IS the state
             } else {
-                const unsigned aoff = (unsigned)l * 8u;                 // (the band stays in LDS: hoisted out of the time loop it costs 2 NK VGPRs)
+                // (the band stays in LDS: hoisted out of the time loop it costs 2 NK VGPRs)
+                const unsigned aoff = AST == 16 ? (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u : (unsigned)l * 8u;
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
                 if (nofilter) {                              // (the change point comes after the walk in the model's list: the source unfiltered)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = S[(i + g + 4 * r) * WCOL + c];
                 } else if constexpr (WHOLE_RING) {
                     // (`it` is a compile-time constant of the unrolled loop: one instantiation per tile)
-                    acc = it == 0 ? band_products<NK, 0, NRING>(Al, Bv) : (it == 1 ? band_products<NK, (NTW > 1 ? 4 : 0), NRING>(Al, Bv) :
-                          (it == 2 ? band_products<NK, (NTW > 2 ? 8 : 0), NRING>(Al, Bv) : band_products<NK, (NTW > 3 ? 12 : 0), NRING>(Al, Bv)));
+                    acc = it == 0 ? band_products<NK, 0, NRING, AST>(Al, Bv) : (it == 1 ? band_products<NK, (NTW > 1 ? 4 : 0), NRING, AST>(Al, Bv) :
+                          (it == 2 ? band_products<NK, (NTW > 2 ? 8 : 0), NRING, AST>(Al, Bv) : band_products<NK, (NTW > 3 ? 12 : 0), NRING, AST>(Al, Bv)));
                 } else {
-                    acc = band_products<NK>(Al, Bv);
+                    acc = band_products<NK, 0, NK, AST>(Al, Bv);
                 }
             }
 
@@ -584,8 +591,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 for (int r = 0; r < 4; ++r) D[(row0 + it * TM + g + 4 * r) * WCOL + c] = nst[it][r];
         }
         if (FILTER && k == 0) {            // the chain's band replaces the identity of the first step
-            for (int e = tid; e < NK * 64; e += NT) {
-                const int a = band_distance(e, R0);
+            for (int e = tid; e < NK * AST; e += NT) {
+                const int a = AST == 16 ? band_distance16(e, R0) : band_distance(e, R0);
                 As[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);
             }
         }

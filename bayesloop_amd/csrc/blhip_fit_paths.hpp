@@ -248,8 +248,10 @@ struct ChainRun {
         const long long G = E.G;
         if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && !E.p->backward_init && E.d <= blc::DMAX &&
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
-            (E.g.n0 != CHAIN_TALL_ROWS || ctx->option("chain_tall", 1.0) != 0.0))
+            (E.g.n0 != CHAIN_TALL_ROWS || ctx->option("chain_tall", 1.0) != 0.0)) {
+            cp.r0_max = (E.g.n0 == CHAIN_TALL_ROWS && ctx->option("chain_tall_wide", 1.0) != 0.0) ? CHAIN_TALL_R0_MAX : FAST_R0_MAX;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
+        }
         if (!on) return;
         Gk = (long long)cp.n0p * cp.n1p;
         // (granule slots for 2 x cpr chains: the two-chain fold kernel runs rounds of that size)

@@ -1305,6 +1305,11 @@ CHAINRES = {
     'cres_1024x32_tall': _hyper(1024, 32, 66, 6, ('cint', 0.01, 0.15, 6)),
     'cres_1024x48_tall_evidence': _hyper(1024, 48, 67, 5, ('cint', 0.02, 0.12, 4), evidenceOnly=True),
     'cres_1024x16_tall_r40': _hyper(1024, 16, 68, 7, ('cint', 0.15, 0.156, 2)),
+    # ... and the bands only the 1024-row kernels carry (radius 41 .. 80: rings of 26 .. 44 entries): narrow and wide chains in one study,
+    # the widest band evidence-only, a forward-only fit
+    'cres_1024x32_tall_wide': _hyper(1024, 32, 69, 6, ('cint', 0.1, 0.31, 7)),
+    'cres_1024x16_tall_r80_evidence': _hyper(1024, 16, 70, 9, ('cint', 0.3, 0.312, 2), evidenceOnly=True),
+    'cres_1024x16_tall_wide_forward_only': _hyper(1024, 16, 71, 5, ('cint', 0.2, 0.3, 3), forwardOnly=True),
     # T = 1 and T = 2 (shorter than the lag)
     'cres_T1': _hyper(128, 32, 57, 1, ('cint', 0, 0.5, 3)),
     'cres_T2': _hyper(128, 32, 58, 2, ('cint', 0, 0.5, 3)),
