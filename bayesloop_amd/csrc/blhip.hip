@@ -36,6 +36,7 @@
 #include "blhip_persist1d.hpp"
 #include "blhip_resident.hpp"
 #include "blhip_chainres.hpp"
+#include "blhip_chain_launch.hpp"
 #include "blhip_nd.hpp"
 
 using namespace blk;
@@ -44,19 +45,6 @@ using namespace blk;
 #include "blhip_comm.hpp"
 
 namespace {
-
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: a process that drives several GPUs (HyperStudy.fit(nJobs = N):
-// one context and one host thread per device) has to arm every kernel on every device it launches it on
-void arm_kernel(const void *fn, int bytes = 160 * 1024) {
-    static std::mutex mu;
-    static std::set<std::pair<int, const void *>> armed;
-    int dev = 0;
-    HIPCHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    if (armed.count({dev, fn})) return;
-    HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    armed.insert({dev, fn});
-}
 
 struct TapTable {
     std::vector<double> w;       // concatenated half kernels: w[off + k], k = 0..lw
@@ -570,122 +558,25 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
     HIPCHECK(hipGetLastError());
 }
 
-// ---- chain-resident kernel (blhip_chainres.hpp) ---------------------------------------------------------------------------------
-template <typename KernT>
-void launch_chain_fn(KernT kern, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
-    arm_kernel(reinterpret_cast<const void *>(kern));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(Q.nslots * Q.strips)), dim3(blc::NT), lds, s, Q);
-}
-
-template <int NK, int NTW>
-void launch_chain_k(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store, bool pad) {
-    const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
-    if (pad) {                          // grids smaller than the geometry (the folding backward pass: launch_fold2)
-        if constexpr (NTW <= 4) {
-            if (bwd && !store) fail("internal: padded chain-resident launch of a folding backward pass");
-            if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true>, s, Q, lds);
-            else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
-            else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true>, s, Q, lds);
-        } else {
-            fail("internal: the 1024-row chain-resident kernels have no padded variant");
-        }
-        return;
-    }
-    if (bwd && !store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false>, s, Q, lds);      // posteriors folded, not stored
-    else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true>, s, Q, lds);
-    else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true>, s, Q, lds);
-    else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false>, s, Q, lds);
-}
-
-template <int NTW>
-void launch_chain_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
-    switch (nk) {
-        case 4:                                                               // no stencil (change-point studies)
-            if constexpr (NTW <= 4) launch_chain_k<4, NTW>(s, Q, bwd, store, pad);
-            else fail("internal: the 1024-row chain-resident kernels need a stencil");
-            break;
-        case 6: launch_chain_k<6, NTW>(s, Q, bwd, store, pad); break;         // band = 16 + 2 R0 columns, R0 = 4, 8, ... 40
-        case 8: launch_chain_k<8, NTW>(s, Q, bwd, store, pad); break;
-        case 10: launch_chain_k<10, NTW>(s, Q, bwd, store, pad); break;
-        case 12: launch_chain_k<12, NTW>(s, Q, bwd, store, pad); break;
-        case 14: launch_chain_k<14, NTW>(s, Q, bwd, store, pad); break;
-        case 16: launch_chain_k<16, NTW>(s, Q, bwd, store, pad); break;
-        case 18: launch_chain_k<18, NTW>(s, Q, bwd, store, pad); break;
-        case 20: launch_chain_k<20, NTW>(s, Q, bwd, store, pad); break;
-        case 22: launch_chain_k<22, NTW>(s, Q, bwd, store, pad); break;
-        case 24: launch_chain_k<24, NTW>(s, Q, bwd, store, pad); break;
-        default:
-            // 1024 rows: bands up to 16 + 2 x 80 columns (a strip of 1024 rows at twice the resolution carries twice the radius; the ring
-            // of 44 entries fits the 256 registers of two waves per SIMD, the band table the 32 KB of LDS beside the strip)
-            if constexpr (NTW == 8) {
-                switch (nk) {
-                    case 26: launch_chain_k<26, NTW>(s, Q, bwd, store, pad); return;
-                    case 28: launch_chain_k<28, NTW>(s, Q, bwd, store, pad); return;
-                    case 30: launch_chain_k<30, NTW>(s, Q, bwd, store, pad); return;
-                    case 32: launch_chain_k<32, NTW>(s, Q, bwd, store, pad); return;
-                    case 34: launch_chain_k<34, NTW>(s, Q, bwd, store, pad); return;
-                    case 36: launch_chain_k<36, NTW>(s, Q, bwd, store, pad); return;
-                    case 38: launch_chain_k<38, NTW>(s, Q, bwd, store, pad); return;
-                    case 40: launch_chain_k<40, NTW>(s, Q, bwd, store, pad); return;
-                    case 42: launch_chain_k<42, NTW>(s, Q, bwd, store, pad); return;
-                    case 44: launch_chain_k<44, NTW>(s, Q, bwd, store, pad); return;
-                    default: break;
-                }
-            }
-            fail("internal: chain-resident kernel with %d band blocks", nk);
-    }
-}
-
+// ---- chain-resident kernels (blhip_chainres.hpp): compiled as slices of blhip_chain_tu.hip (blhip_chain_launch.hpp) -----------------------
 void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
-    if (ntw == 4) launch_chain_w<4>(s, Q, nk, bwd, store, pad);
-    else if (ntw == 8) launch_chain_w<8>(s, Q, nk, bwd, store, pad);          // 1024 rows: one copy of the strip in LDS (blc::chain_kernel TALL)
-    else if (ntw == 3) launch_chain_w<3>(s, Q, nk, bwd, store, pad);
-    else if (ntw == 2) launch_chain_w<2>(s, Q, nk, bwd, store, pad);
-    else if (ntw == 1) launch_chain_w<1>(s, Q, nk, bwd, store, pad);
+    if (ntw == 4) { if (bwd) blcl::chain_ntw4_bwd(s, Q, nk, store, pad); else blcl::chain_ntw4_fwd(s, Q, nk, store, pad); }
+    else if (ntw == 8) {                 // 1024 rows: one copy of the strip in LDS (blc::chain_kernel TALL); bands up to radius 80 (NK = 44)
+        if (nk <= 24) { if (bwd) blcl::chain_ntw8_bwd_narrow(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_narrow(s, Q, nk, store, pad); }
+        else { if (bwd) blcl::chain_ntw8_bwd_wide(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_wide(s, Q, nk, store, pad); }
+    }
+    else if (ntw == 3) blcl::chain_ntw3(s, Q, nk, bwd, store, pad);
+    else if (ntw == 2) blcl::chain_ntw2(s, Q, nk, bwd, store, pad);
+    else if (ntw == 1) blcl::chain_ntw1(s, Q, nk, bwd, store, pad);
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
     HIPCHECK(hipGetLastError());
 }
 
 // backward pass with the fused fold, two chains per block (blc::chain_fold2_kernel)
-template <int NK, int NTW>
-void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q, bool pad) {
-    const size_t lds = blc::lds_doubles_fold2<NK, NTW>() * sizeof(double);
-    const dim3 grid((unsigned)(((Q.nslots + 1) / 2) * Q.strips));
-    if (pad) {
-        arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, true>));
-        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, true>), grid, dim3(blc::NT), lds, s, Q);
-    } else {
-        arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, false>));
-        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, false>), grid, dim3(blc::NT), lds, s, Q);
-    }
-}
-
-template <int NTW>
-void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) {
-    switch (nk) {
-        case 4: launch_fold2_k<4, NTW>(s, Q, pad); break;          // no stencil (change-point studies)
-        case 6: launch_fold2_k<6, NTW>(s, Q, pad); break;
-        case 8: launch_fold2_k<8, NTW>(s, Q, pad); break;
-        case 10: launch_fold2_k<10, NTW>(s, Q, pad); break;
-        case 12: launch_fold2_k<12, NTW>(s, Q, pad); break;
-        case 14: launch_fold2_k<14, NTW>(s, Q, pad); break;
-        case 16: launch_fold2_k<16, NTW>(s, Q, pad); break;
-        case 18: launch_fold2_k<18, NTW>(s, Q, pad); break;
-        case 20: launch_fold2_k<20, NTW>(s, Q, pad); break;
-        case 22: launch_fold2_k<22, NTW>(s, Q, pad); break;
-        case 24: launch_fold2_k<24, NTW>(s, Q, pad); break;
-        default: fail("internal: two-chain fold kernel with %d band blocks", nk);
-    }
-}
-
 bool fold2_shape(int ntw) { return ntw >= 1 && ntw <= 4; }
 
 void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad = false) {
-    if (ntw == 4) launch_fold2_w<4>(s, Q, nk, pad);
-    else if (ntw == 3) launch_fold2_w<3>(s, Q, nk, pad);
-    else if (ntw == 2) launch_fold2_w<2>(s, Q, nk, pad);
-    else if (ntw == 1) launch_fold2_w<1>(s, Q, nk, pad);
-    else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
+    if (ntw >= 3) blcl::fold2_ntw34(s, Q, nk, ntw, pad); else blcl::fold2_ntw12(s, Q, nk, ntw, pad);
     HIPCHECK(hipGetLastError());
 }
 
@@ -1261,8 +1152,9 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
 // memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
 constexpr int CHAIN_MIN_ROWS = 32;            // smallest grid (rows) the chain-resident kernels take (on the 128-row geometry)
 constexpr int CHAIN_TALL_R0_MAX = 80;          // widest band of the 1024-row kernels (blc::chain_kernel<44, 8, ...>); every other geometry: FAST_R0_MAX
-constexpr int CHAIN_TALL_ROWS = 1024;         // ... and the one geometry beyond 512 rows (option chain_tall = 0: off)
-inline bool chain_rows_ok(int n0) { return (n0 >= CHAIN_MIN_ROWS && n0 <= 512) || n0 == CHAIN_TALL_ROWS; }
+constexpr int CHAIN_TALL_ROWS = 1024;         // ... and the one geometry beyond 512 rows: grids of 513 .. 1024 rows (option chain_tall = 0: off)
+inline bool chain_rows_ok(int n0) { return n0 >= CHAIN_MIN_ROWS && n0 <= CHAIN_TALL_ROWS; }
+inline bool chain_tall(int n0) { return n0 > 512 && n0 <= CHAIN_TALL_ROWS; }
 
 int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int64_t n_chains, int post_buffers) {
     const int64_t T = p->T;
@@ -1695,12 +1587,13 @@ struct ChainResPlan {
 // every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
 bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
     // any grid of 32 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns;
-    // 1024 rows x a multiple of 16 columns exactly (one copy of the strip in LDS: blc::chain_kernel TALL; filtering chains only)
+    // 513 .. 1024 rows: 1024 rows x a multiple of 16 columns (one copy of the strip in LDS: blc::chain_kernel TALL; filtering chains only)
     if (!chain_rows_ok(g.n0)) return false;
     cp.n0p = (g.n0 + 127) / 128 * 128;
     cp.n1p = (g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL;
+    if (chain_tall(g.n0)) cp.n0p = CHAIN_TALL_ROWS;
     cp.pad = cp.n0p != g.n0 || cp.n1p != g.n1;
-    if (g.n0 == CHAIN_TALL_ROWS && (cp.pad || prog.LW0 == 0)) return false;
+    if (chain_tall(g.n0) && prog.LW0 == 0) return false;
     cp.strips = cp.n1p / blc::WCOL;
     cp.ntw = cp.n0p / (blc::NW * blc::TM);
     if (cp.strips > blc::MAX_STRIPS || cp.strips > cus) return false;
@@ -1961,7 +1854,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         batch_start.push_back(n_chains);
     }
     // (the cut: 40; 1024-row grids the chain-resident kernels take: 80)
-    const bool tall_wide = chain_shape && g.n0 == CHAIN_TALL_ROWS && ctx->option("chain_tall", 1.0) != 0.0 && ctx->option("chain_tall_wide", 1.0) != 0.0;
+    const bool tall_wide = chain_shape && chain_tall(g.n0) && ctx->option("chain_tall", 1.0) != 0.0 && ctx->option("chain_tall_wide", 1.0) != 0.0;
     if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0)
         split_wide_axis0(p, n_chains, op_values, batch_start, tall_wide ? CHAIN_TALL_R0_MAX : FAST_R0_MAX);
     const int64_t nbatch = (int64_t)batch_start.size() - 1;

@@ -1,0 +1,27 @@
+// Launchers of the chain-resident kernels (blhip_chainres.hpp).  The kernels are a few hundred template instantiations -- ring length NK x
+// tiles per wave NTW x pass flavour -- and most of the library's compile time, so they are compiled as SLICES of blhip_chain_tu.hip in
+// parallel (build.py: one object per BLC_TU value) and linked beside blhip.hip, which only sees these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "blhip_chainres.hpp"
+
+namespace blcl {
+
+// one chain per block: forward (store: every step's state is kept) / backward (store: posteriors kept; else folded into the partial accumulators)
+void chain_ntw1(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad);
+void chain_ntw2(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad);
+void chain_ntw3(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad);
+void chain_ntw4_fwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);
+void chain_ntw4_bwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);
+void chain_ntw8_fwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);      // NK <= 24
+void chain_ntw8_bwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);
+void chain_ntw8_fwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);        // NK = 26 .. 44
+void chain_ntw8_bwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);
+// backward pass with the fused fold, two chains per block (blc::chain_fold2_kernel)
+void fold2_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
+void fold2_ntw34(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
+
+constexpr int N_SLICES = 9;      // BLC_TU = 1 .. N_SLICES (blhip_chain_tu.hip)
+
+}   // namespace blcl

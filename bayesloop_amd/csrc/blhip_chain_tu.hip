@@ -1,0 +1,134 @@
+// One SLICE of the chain-resident kernels per compilation: -DBLC_TU=1 .. blcl::N_SLICES (build.py compiles the slices in parallel).
+// Which instantiations a slice holds is decided here and nowhere else; blhip.hip dispatches on (tiles per wave, pass, ring length).
+#include "blhip_chain_launch.hpp"
+#include "blhip_err.hpp"
+
+#ifndef BLC_TU
+#error "compile with -DBLC_TU=<slice>"
+#endif
+
+namespace {
+
+using blerr::arm_kernel;
+using blerr::fail;
+
+template <typename KernT>
+void launch_chain_fn(KernT kern, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
+    arm_kernel(reinterpret_cast<const void *>(kern));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(Q.nslots * Q.strips)), dim3(blc::NT), lds, s, Q);
+}
+
+// the flavours of one (ring length, tiles per wave, direction).  Padded grids: forward and storing backward passes of <= 512 rows (the
+// folding backward pass of a padded grid is the two-chain kernel's); 1024 rows: forward and FOLDING backward passes
+template <int NK, int NTW, bool BWD>
+void launch_k(hipStream_t s, const blc::ChainParams &Q, bool store, bool pad) {
+    const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
+    if constexpr (!BWD) {
+        if (pad && store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
+        else if (pad) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true>, s, Q, lds);
+        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, false>, s, Q, lds);
+        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, false>, s, Q, lds);
+    } else if constexpr (NTW <= 4) {
+        if (pad && !store) fail("internal: padded chain-resident launch of a folding backward pass");
+        if (pad) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true>, s, Q, lds);
+        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false>, s, Q, lds);
+        else launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false>, s, Q, lds);
+    } else {
+        if (pad && store) fail("internal: the 1024-row chain-resident kernels store posteriors on the exact geometry only");
+        if (pad) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, true>, s, Q, lds);
+        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false>, s, Q, lds);
+        else launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false>, s, Q, lds);
+    }
+}
+
+// ring lengths LO .. HI (even; 4 = the no-stencil kernels of change-point studies: <= 512 rows only).  band = 16 + 2 R0 columns,
+// R0 = 4, 8, ... 40 (NK = 6 .. 24); 1024 rows: up to R0 = 80 (NK = 44) -- a strip of twice the rows carries twice the radius
+#define BLC_CASE(NKV)                                                                                  \
+    case NKV:                                                                                          \
+        if constexpr (NKV >= LO && NKV <= HI) { launch_k<NKV, NTW, BWD>(s, Q, store, pad); return; }   \
+        break;
+template <int NTW, bool BWD, int LO, int HI>
+void launch_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) {
+    switch (nk) {
+        BLC_CASE(4) BLC_CASE(6) BLC_CASE(8) BLC_CASE(10) BLC_CASE(12) BLC_CASE(14) BLC_CASE(16) BLC_CASE(18) BLC_CASE(20) BLC_CASE(22) BLC_CASE(24)
+        BLC_CASE(26) BLC_CASE(28) BLC_CASE(30) BLC_CASE(32) BLC_CASE(34) BLC_CASE(36) BLC_CASE(38) BLC_CASE(40) BLC_CASE(42) BLC_CASE(44)
+        default: break;
+    }
+    fail("internal: chain-resident kernel with %d band blocks, %d tiles per wave", nk, NTW);
+}
+#undef BLC_CASE
+
+template <int NK, int NTW>
+void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q, bool pad) {
+    const size_t lds = blc::lds_doubles_fold2<NK, NTW>() * sizeof(double);
+    const dim3 grid((unsigned)(((Q.nslots + 1) / 2) * Q.strips));
+    if (pad) {
+        arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, true>));
+        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, true>), grid, dim3(blc::NT), lds, s, Q);
+    } else {
+        arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, false>));
+        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, false>), grid, dim3(blc::NT), lds, s, Q);
+    }
+}
+
+template <int NTW>
+void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) {
+    switch (nk) {
+        case 4: launch_fold2_k<4, NTW>(s, Q, pad); break;          // no stencil (change-point studies)
+        case 6: launch_fold2_k<6, NTW>(s, Q, pad); break;
+        case 8: launch_fold2_k<8, NTW>(s, Q, pad); break;
+        case 10: launch_fold2_k<10, NTW>(s, Q, pad); break;
+        case 12: launch_fold2_k<12, NTW>(s, Q, pad); break;
+        case 14: launch_fold2_k<14, NTW>(s, Q, pad); break;
+        case 16: launch_fold2_k<16, NTW>(s, Q, pad); break;
+        case 18: launch_fold2_k<18, NTW>(s, Q, pad); break;
+        case 20: launch_fold2_k<20, NTW>(s, Q, pad); break;
+        case 22: launch_fold2_k<22, NTW>(s, Q, pad); break;
+        case 24: launch_fold2_k<24, NTW>(s, Q, pad); break;
+        default: fail("internal: two-chain fold kernel with %d band blocks", nk);
+    }
+}
+
+}   // namespace
+
+namespace blcl {
+
+#if BLC_TU == 1
+void chain_ntw1(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
+    if (bwd) launch_w<1, true, 4, 24>(s, Q, nk, store, pad); else launch_w<1, false, 4, 24>(s, Q, nk, store, pad);
+}
+void chain_ntw2(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
+    if (bwd) launch_w<2, true, 4, 24>(s, Q, nk, store, pad); else launch_w<2, false, 4, 24>(s, Q, nk, store, pad);
+}
+#elif BLC_TU == 2
+void chain_ntw3(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
+    if (bwd) launch_w<3, true, 4, 24>(s, Q, nk, store, pad); else launch_w<3, false, 4, 24>(s, Q, nk, store, pad);
+}
+#elif BLC_TU == 3
+void chain_ntw4_fwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<4, false, 4, 24>(s, Q, nk, store, pad); }
+#elif BLC_TU == 4
+void chain_ntw4_bwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<4, true, 4, 24>(s, Q, nk, store, pad); }
+void fold2_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad) {
+    if (ntw == 2) launch_fold2_w<2>(s, Q, nk, pad);
+    else if (ntw == 1) launch_fold2_w<1>(s, Q, nk, pad);
+    else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 5
+void chain_ntw8_fwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, false, 6, 24>(s, Q, nk, store, pad); }
+#elif BLC_TU == 6
+void chain_ntw8_bwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, true, 6, 24>(s, Q, nk, store, pad); }
+#elif BLC_TU == 7
+void chain_ntw8_fwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, false, 26, 44>(s, Q, nk, store, pad); }
+#elif BLC_TU == 8
+void chain_ntw8_bwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, true, 26, 44>(s, Q, nk, store, pad); }
+#elif BLC_TU == 9
+void fold2_ntw34(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad) {
+    if (ntw == 4) launch_fold2_w<4>(s, Q, nk, pad);
+    else if (ntw == 3) launch_fold2_w<3>(s, Q, nk, pad);
+    else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
+}
+#else
+#error "BLC_TU out of range"
+#endif
+
+}   // namespace blcl

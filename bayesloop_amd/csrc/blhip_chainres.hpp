@@ -196,21 +196,22 @@ constexpr size_t lds_doubles() { return (size_t)(NTW > 4 ? 1 : 2) * NW * NTW * T
 // geometry; what differs: the stencil reflects at the grid's TRUE last row, cells outside the grid are kept at zero (and out of the
 // sums), the read-only inputs (source distribution, coordinates, column constants) are read with bounds.  Only for sequences private
 // to the fit (strip-major layout on the padded geometry): forward passes and storing backward passes here, folding backward passes in
-// chain_fold2_kernel.
+// chain_fold2_kernel (<= 512 rows) / here (1024 rows).
 template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false>
 __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
-    static_assert(!(PAD && BWD && !STORE), "padded grids: the folding backward pass is chain_fold2_kernel's");
+    static_assert(!(PAD && BWD && !STORE) || NTW > 4, "padded grids of <= 512 rows: the folding backward pass is chain_fold2_kernel's");
+    static_assert(!(PAD && BWD && STORE && NTW > 4), "padded grids of 1024 rows: posteriors are folded, never stored");
     const int n0t = PAD ? P.n0t : N0, n1t = PAD ? P.n1t : P.n1;      // the grid's true sizes
     static_assert(NK == 4 || (NK >= 6 && R0 % 4 == 0), "band = 16 + 2 R0 columns, R0 a multiple of 4; NK = 4: no stencil");
     constexpr bool FILTER = NK > 4;
     // TALL (NTW = 8: 1024 rows): LDS holds ONE copy of the strip (128 KB), not two.  A step's new state waits in registers until every
     // wave has read its rings (the step's barrier), is written then, and a second barrier releases the next step -- the scheme of
-    // chain_fold2_kernel.  (Exact geometry only: no padded variant; the folding backward pass is the single-chain one.)
+    // chain_fold2_kernel.  (The folding backward pass is the single-chain one -- also on padded grids, 513 .. 1023 rows: the partial
+    // accumulators live on the padded geometry and fold_parts_kernel reads the grid's cells out of them.)
     constexpr bool TALL = NTW > 4;
-    static_assert(!(TALL && PAD), "1024 rows: the exact geometry only");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *const X = lds;                     // [2][N0][16]   (TALL: [1][N0][16])
     constexpr int AST = (TALL && BLC_BAND4) ? 16 : 64;     // (TALL: the compact band table -- the strip leaves 32 KB, the widest band has 44 shifts)

@@ -279,7 +279,7 @@ void check_peers(blhip_ctx *dst, blhip_ctx *const *srcs, int n) {
         if (srcs[i]->acc_logref != dst->acc_logref) fail("peer merge: the accumulators are not at a common reference exponent (blhip_accum_rescale)");
     }
 }
-__global__ void peer_add_kernel(double *__restrict__ acc, const double *__restrict__ stage, int n, long long count) {
+static __global__ void peer_add_kernel(double *__restrict__ acc, const double *__restrict__ stage, int n, long long count) {
     // acc[i] += stage[0][i] + stage[1][i] + ... in list order (the same sum on every run)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
         double v = acc[i];

@@ -248,8 +248,8 @@ struct ChainRun {
         const long long G = E.G;
         if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && !E.p->backward_init && E.d <= blc::DMAX &&
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
-            (E.g.n0 != CHAIN_TALL_ROWS || ctx->option("chain_tall", 1.0) != 0.0)) {
-            cp.r0_max = (E.g.n0 == CHAIN_TALL_ROWS && ctx->option("chain_tall_wide", 1.0) != 0.0) ? CHAIN_TALL_R0_MAX : FAST_R0_MAX;
+            (!chain_tall(E.g.n0) || ctx->option("chain_tall", 1.0) != 0.0)) {
+            cp.r0_max = (chain_tall(E.g.n0) && ctx->option("chain_tall_wide", 1.0) != 0.0) ? CHAIN_TALL_R0_MAX : FAST_R0_MAX;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
         }
         if (!on) return;
@@ -314,7 +314,9 @@ struct ChainRun {
         // and full fits of hyper- / change-point studies (folded in the backward kernel, or stored and folded by accumulate_pad_kernel);
         // everything else keeps the launch-per-step kernels
         if (cp.pad && !(E.ff.evidence_only || post_private)) { on = false; fused = false; fold2 = false; return; }
-        if (cp.pad && fused && !fold2) fused = false;      // (the one-chain folding kernel has no padded variant: store + separate fold)
+        // (<= 512 rows: the one-chain folding kernel has no padded variant -- store + separate fold; 1024 rows: it is the only padded backward kernel)
+        if (cp.pad && fused && !fold2 && cp.ntw <= 4) fused = false;
+        if (cp.pad && cp.ntw > 4 && E.ff.full && !fused) { on = false; fold2 = false; return; }
         // Change-point batches without a stencil whose backward pass folds: the chains are identical up to their first restart.  The chain
         // with the LATEST first restart stores all its states; every other chain stores only from its own first restart on, and the
         // folding backward pass reads the earlier ones from that chain (same values bit for bit: same kernel, same strips, same lagged

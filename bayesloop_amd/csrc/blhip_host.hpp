@@ -7,32 +7,21 @@
 #include <cstdio>
 #include <limits>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/blhip.h"
 
+#include "blhip_err.hpp"
+
 namespace {
 
-struct Fail {
-    std::string msg;
-};
-
-[[noreturn]] void fail(const char *fmt, ...) {
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    throw Fail{buf};
-}
-
-#define HIPCHECK(expr)                                                                                        \
-    do {                                                                                                      \
-        hipError_t e_ = (expr);                                                                               \
-        if (e_ != hipSuccess) fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+using blerr::Fail;
+using blerr::fail;
+using blerr::arm_kernel;
 
 struct DevBuf {
     void *p = nullptr;

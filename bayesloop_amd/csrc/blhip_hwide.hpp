@@ -58,7 +58,7 @@ __device__ __forceinline__ int reflect1(int i, int n) {      // single-period ha
     return min(max(i, 0), n - 1);
 }
 
-__global__ __launch_bounds__(NT) void hwide_kernel(const HParams P) {
+static __global__ __launch_bounds__(NT) void hwide_kernel(const HParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     const int b = P.chain_ids ? P.chain_ids[blockIdx.y] : (int)blockIdx.y;
@@ -173,7 +173,7 @@ constexpr int VW_MAX = 128;     // largest radius (LDS: (128 + 256 + 15) x 33 do
 
 inline size_t vlds_bytes(int lwmax) { return ((size_t)(RV + 2 * lwmax + 15) * PV + 2 * (size_t)lwmax + 32) * sizeof(double); }
 
-__global__ __launch_bounds__(NT) void vwide_kernel(const HParams P) {
+static __global__ __launch_bounds__(NT) void vwide_kernel(const HParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     const int b = P.chain_ids ? P.chain_ids[blockIdx.y] : (int)blockIdx.y;

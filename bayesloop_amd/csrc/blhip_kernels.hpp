@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
 }
 
 // out[k] = sum of nblk partials, k over (step, chain, slot); same summation order as sum_partials in the step kernel.
-__global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double *psum, double *out, int nblk, int period) {
+static __global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double *psum, double *out, int nblk, int period) {
     __shared__ double red[NTHREADS / 64 + 1];
     const long long k = blockIdx.x;
     if (period > 0 && k % period == 6) {           // step-kernel partials (period = NRED): slot 6 holds block MAXIMA
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(NTHREADS) void reduce_partials_kernel(const double 
 
 // Likelihood table of the closed-form models without an in-kernel path: lik[t][cell] = processedPdf(grid, segment_t)
 // (observationModels.py:35-56: product over the data dimensions; a dimension whose segment holds a NaN counts as 1).  grid = (blockIdx.x chunks, T).
-__global__ __launch_bounds__(NTHREADS) void lik_table_kernel(int om, double *lik, long long G, int n1, int ndim, const double *m0,
+static __global__ __launch_bounds__(NTHREADS) void lik_table_kernel(int om, double *lik, long long G, int n1, int ndim, const double *m0,
                                                              const double *m1, const double *data, int seg, int d) {
     const long long t = blockIdx.y;
     const double *x = data + t * seg * d;              // (seg, d); a NaN makes its data DIMENSION a factor of 1 (:49-54)
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(NTHREADS) void lik_table_kernel(int om, double *lik
 }
 
 // dst[b][c] = src[b * stride + c] * inv[b]   (BLHIP_CARRY: the filtered distribution of the last step, normalised)
-__global__ __launch_bounds__(NTHREADS) void carry_store_kernel(double *dst, const double *src, long long stride, long long G,
+static __global__ __launch_bounds__(NTHREADS) void carry_store_kernel(double *dst, const double *src, long long stride, long long G,
                                                                const double *inv) {
     const long long b = blockIdx.y;
     const double s = inv[b];
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NTHREADS) void carry_store_kernel(double *dst, cons
 }
 
 // mix[c] = (accumulate ? mix[c] : 0) + sum_b w[b] * states[b][c]   (OnlineStudy: core.py:2196-2212)
-__global__ __launch_bounds__(NTHREADS) void carry_mix_kernel(double *mix, const double *states, long long G, int B, const double *w,
+static __global__ __launch_bounds__(NTHREADS) void carry_mix_kernel(double *mix, const double *states, long long G, int B, const double *w,
                                                              int accumulate) {
     for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
         double s = accumulate ? mix[c] : 0.0;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NTHREADS) void carry_mix_kernel(double *mix, const 
 }
 
 // rows[t][cell] *= inv[t]   (normalisation of stored posteriors, core.py:389 / :441 applied lazily)
-__global__ __launch_bounds__(NTHREADS) void scale_rows_kernel(double *rows, long long G, const double *inv) {
+static __global__ __launch_bounds__(NTHREADS) void scale_rows_kernel(double *rows, long long G, const double *inv) {
     const long long t = blockIdx.y;
     const double s = inv[t];
     if (s == 1.0) return;                            // (rows the time-resident kernel has normalised already)
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NTHREADS) void scale_rows_kernel(double *rows, long
 }
 
 // A[t][cell] = A[t][cell] * r + sum_b w[b] * max(post[b][t][cell] * invN[b][t], 1e-300)   (core.py:1362-1366, linear space)
-__global__ __launch_bounds__(NTHREADS) void accumulate_kernel(double *A, const double *post, long long chain_stride,
+static __global__ __launch_bounds__(NTHREADS) void accumulate_kernel(double *A, const double *post, long long chain_stride,
                                                               int B, long long G, int T, const double *w,
                                                               const double *invN, double r, int first) {
     const long long t = blockIdx.y;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NTHREADS) void accumulate_kernel(double *A, const d
 // a few dozen blocks that each walk all B chains one after the other (the published break-point study: 82 blocks, 0.39 ms per batch of
 // 1017 chains = 0.85 TB/s).  Here a block is 64 cells x 4 groups of chains (chains g, g + 4, ...: a wave reads 512 contiguous bytes of
 // a chain's row), the groups' sums are added in a fixed order.
-__global__ __launch_bounds__(NTHREADS) void accumulate_small_kernel(double *A, const double *post, long long chain_stride, int B, long long G, int T,
+static __global__ __launch_bounds__(NTHREADS) void accumulate_small_kernel(double *A, const double *post, long long chain_stride, int B, long long G, int T,
                                                                     const double *w, const double *invN, double r, int first) {
     __shared__ double part[NTHREADS / 64][64];
     const long long t = blockIdx.y;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(NTHREADS) void accumulate_small_kernel(double *A, c
 //     A[t][row][col] = r A + rb sum_slots part[slot][t][col / 16][row][col % 16]          (two cells per lane)
 // (n0p: rows per strip of the partials -- the kernel's padded row count when the grid's is not 128 / 256 / 512; pstep: doubles per time
 //  step of a partial accumulator on that padded geometry)
-__global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const double *part, long long part_stride, int nslots, int n0, int n1,
+static __global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const double *part, long long part_stride, int nslots, int n0, int n1,
                                                                int T, double r, double rb, int first, int n0p, long long pstep) {
     const long long G = (long long)n0 * n1;
     const int t = blockIdx.y;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const d
 
 // The separate fold of a batch whose posteriors sit in the chain-resident kernels' strip-major layout on a PADDED geometry
 // ([t][column / 16][row of n0p][16], pstep doubles per time step, chain_stride per chain): one cell per lane (any number of columns).
-__global__ __launch_bounds__(NTHREADS) void accumulate_pad_kernel(double *A, const double *post, long long chain_stride, int B, int n0, int n1,
+static __global__ __launch_bounds__(NTHREADS) void accumulate_pad_kernel(double *A, const double *post, long long chain_stride, int B, int n0, int n1,
                                                                   int T, const double *w, const double *invN, double r, int first,
                                                                   int n0p, long long pstep) {
     const long long G = (long long)n0 * n1;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(NTHREADS) void accumulate_pad_kernel(double *A, con
 // Same, two cells per lane (16-B accesses) and four chains in flight per iteration; needs an even number of cells.
 // sm_n0 > 0: the sequences are in the chain-resident kernel's strip-major layout [t][column / 16][row][16] (n0 = sm_n0 rows; the
 // accumulator keeps the API's [t][row][column]).
-__global__ __launch_bounds__(NTHREADS) void accumulate2_kernel(double *A, const double *post, long long chain_stride,
+static __global__ __launch_bounds__(NTHREADS) void accumulate2_kernel(double *A, const double *post, long long chain_stride,
                                                                int B, long long G, int T, const double *w,
                                                                const double *invN, double r, int first, int sm_n0) {
     const long long t = blockIdx.y;
@@ -650,13 +650,13 @@ __global__ __launch_bounds__(NTHREADS) void accumulate2_kernel(double *A, const 
     *ap = acc;
 }
 
-__global__ __launch_bounds__(NTHREADS) void scale_all_kernel(double *A, long long n, double r) {
+static __global__ __launch_bounds__(NTHREADS) void scale_all_kernel(double *A, long long n, double r) {
     for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < n; c += (long long)gridDim.x * NTHREADS)
         A[c] *= r;
 }
 
 // out[t][i] = sum_j p[t][i][j]   (one block per (row i, t); coalesced along j)
-__global__ __launch_bounds__(NTHREADS) void marginal_rows_kernel(const double *p, double *out, int n0, int n1) {
+static __global__ __launch_bounds__(NTHREADS) void marginal_rows_kernel(const double *p, double *out, int n0, int n1) {
     __shared__ double red[NTHREADS / 64 + 1];
     const long long t = blockIdx.y, i = blockIdx.x;
     const double *row = p + (t * n0 + i) * n1;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(NTHREADS) void marginal_rows_kernel(const double *p
 }
 
 // out[t][j] = sum_i p[t][i][j]   (a thread owns a column; coalesced along j)
-__global__ __launch_bounds__(NTHREADS) void marginal_cols_kernel(const double *p, double *out, int n0, int n1) {
+static __global__ __launch_bounds__(NTHREADS) void marginal_cols_kernel(const double *p, double *out, int n0, int n1) {
     const long long t = blockIdx.y;
     const int j = blockIdx.x * NTHREADS + threadIdx.x;
     if (j >= n1) return;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(NTHREADS) void marginal_cols_kernel(const double *p
 }
 
 // out[c] = (1/T) sum_t p[t][c]
-__global__ __launch_bounds__(NTHREADS) void time_average_kernel(const double *p, double *out, long long G, int T) {
+static __global__ __launch_bounds__(NTHREADS) void time_average_kernel(const double *p, double *out, long long G, int T) {
     for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {
         double s = 0.0;
         for (int t = 0; t < T; ++t) s += p[(long long)t * G + c];
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(NTHREADS) void copy16_kernel(const double2 *__restr
     }
 }
 
-__global__ void fill_kernel(double *p, long long n, double v) {
+static __global__ void fill_kernel(double *p, long long n, double v) {
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (long long)gridDim.x * blockDim.x)
         p[c] = v;
 }

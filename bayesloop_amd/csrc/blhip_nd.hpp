@@ -34,7 +34,7 @@ __device__ __forceinline__ int reflect_any(long long i, int n) {
 // One axis of the separable transition (scipy.ndimage.gaussian_filter1d -> correlate1d, symmetric weights, pairs added from the
 // OUTERMOST one inward: SURVEY 8 a-5).  blockIdx.y = chain of the batch; a chain without a kernel on this axis copies.
 //   srcs[b]: where chain b's input lives (its state, or a shared distribution at a restart); dst: [B][G]
-__global__ __launch_bounds__(NTHREADS) void filter_axis_kernel(double *dst, const double *const *srcs, long long G, int n, long long inner,
+static __global__ __launch_bounds__(NTHREADS) void filter_axis_kernel(double *dst, const double *const *srcs, long long G, int n, long long inner,
                                                                 const int *tap_id, const double *taps, const int *tap_off, const int *tap_lw) {
     const int b = blockIdx.y;
     const double *src = srcs[b];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const NdStep P) {
 }
 
 // per-step sums of an (T, G) array times the grid values: out[t][0] = sum A, out[t][1 + k] = sum A grid_k  (partials per block)
-__global__ __launch_bounds__(NTHREADS) void row_stats_kernel(const double *A, const NdGrid g, double *partial) {
+static __global__ __launch_bounds__(NTHREADS) void row_stats_kernel(const double *A, const NdGrid g, double *partial) {
     __shared__ double red[(NTHREADS / 64) * 5 + 1];
     const long long t = blockIdx.y;
     double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};

@@ -74,7 +74,7 @@ __device__ __forceinline__ void publish_tagged(unsigned long long *g, unsigned l
 }
 
 // the weights and radii of every (step, chain) spelled out: [TB][LW + 1] / [TB] (the same expression the kernels stage their weights with)
-__global__ void build_wtab_kernel(const int *tap, const int *tap_lw, const int *tap_off, const double *taps, long long TB, int LW,
+static __global__ void build_wtab_kernel(const int *tap, const int *tap_lw, const int *tap_off, const double *taps, long long TB, int LW,
                                   double *wtab, int *lwtab) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= TB * (LW + 1)) return;

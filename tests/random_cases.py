@@ -206,7 +206,7 @@ def random_online_case(seed):
     return c
 
 
-def random_chain_resident_case(seed, ragged=False):
+def random_chain_resident_case(seed, ragged=False, tall=False):
     """Seeded random studies inside the envelope of the chain-resident kernel (blhip_chainres.hpp): hyper-studies over the width of one
     random walk on the first parameter (radius 0 .. 40, hyper-priors, observation-model priors, missing / multi-dimensional data,
     every fit mode) and change-point studies without a stencil, on grids of 128 / 256 / 512 rows x a multiple of 16 columns."""
@@ -221,10 +221,18 @@ def random_chain_resident_case(seed, ragged=False):
         #  radius of up to 40)
         n0 = int(rng.integers(64, 513)) if seed % 5 else [64, 127, 129, 255, 257, 511][int(rng.integers(0, 6))]
         n1 = int(rng.integers(16, 130 if n0 <= 256 else 70))
+    if tall:
+        # 513 .. 1024 rows: the 1024-row geometry (one copy of the strip in LDS), bands up to radius 80; hyper-studies only (the kernels
+        # of that geometry always filter), exact (1024 x a multiple of 16) every fourth seed
+        n0 = 1024 if seed % 4 == 0 else int(rng.integers(513, 1025))
+        n1 = 16 * int(rng.integers(1, 4)) if seed % 4 == 0 else int(rng.integers(16, 50))
+        T = int(rng.integers(1, 9))
     lo, hi = -float(rng.uniform(3, 8)), float(rng.uniform(3, 8))
     prior = ['default', 'inv_s3', 'inv_s_2d'][int(rng.integers(0, 3))]
     om = ('Gaussian', [('mean', ('cint', lo, hi, n0)), ('std', ('oint', float(rng.uniform(0.0, 0.3)), float(rng.uniform(1.5, 4)), n1))], prior)
     kind = ['hyper', 'hyper', 'hyper_nan', 'hyper_2d', 'hyper_prior', 'changepoints'][seed % 6]
+    if tall and kind == 'changepoints':
+        kind = 'hyper'
     if kind == 'changepoints':
         T = max(T, 6)
         tm = ('ChangePoint', 'tc', 'all' if seed % 4 else ('arange', 1, T - 1, int(rng.integers(1, 4))), None)
@@ -233,9 +241,12 @@ def random_chain_resident_case(seed, ragged=False):
     lattice = (hi - lo) / (n0 - 1)
     smax = float(rng.uniform(0.5, 9.8)) * lattice                    # radius int(4 sigma / lattice + 0.5) <= 39
     k = int(rng.integers(2, 41 if n0 * n1 <= 128 * 64 else 13))
+    if tall:
+        smax = float(rng.uniform(0.5, 19.8)) * lattice               # ... <= 79
+        k = int(rng.integers(2, 8))
     sig = ('cint', 0.0 if seed % 3 == 0 else float(rng.uniform(0.0, 0.3)) * smax, smax, k)
     flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
-    if ragged and flags.get('forwardOnly'):
+    if (ragged or (tall and (n0 != 1024 or n1 % 16))) and flags.get('forwardOnly'):
         flags = dict()                     # (padded grids: evidence-only fits and full fits that fold in the backward kernel)
     data = ('series', 1800 + seed, T)
     hp = None
