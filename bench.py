@@ -185,18 +185,22 @@ def make_study(bl, name, comm=None, scale=1.0):
 
 
 
-def measured_traffic(key):
+def measured_traffic(workload, direction):
     """HBM bytes per logical step launch from the committed rocprofv3 PMC passes (separate --pmc runs, tools/prof_workload.sh), newest
-    round first; -> (bytes or None, source file or None).  bench.py does not run the profiler itself."""
+    round first; -> (bytes or None, source file or None).  Used when the profiler cannot run inside the bench (--no-pmc, no rocprofv3).
+    (Layouts: {workload: {direction: {...}}} since round 3; rounds 1 - 2: 'fwd' / 'bwd' for C4, the workload's name otherwise.)"""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
         try:
             d = json.load(open(f))
-            v = d[key].get('hbm_bytes_per_step_launch', d[key].get('hbm_bytes_per_launch'))
-            if v is not None:
-                return v, os.path.relpath(f, ROOT)
         except Exception:
             continue
+        for blk in ((d.get(workload) or {}).get(direction), d.get({'forward': 'fwd', 'backward': 'bwd'}[direction]) if workload == 'c4' else None,
+                    d.get(workload) if direction == 'forward' else None):
+            if isinstance(blk, dict):
+                v = blk.get('hbm_bytes_per_step_launch', blk.get('hbm_bytes_per_launch'))
+                if v is not None:
+                    return v, os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -558,8 +562,8 @@ def main():
             pmc = pmc_traffic_in_run(args.workload, per_dir)
         if pmc is None and world == 1 and args.workload in ('c4', 'fwd2048'):
             pmc = {}
-            for key, tag in (('forward', 'fwd'), ('backward', 'bwd')):
-                v, src = measured_traffic(tag if args.workload == 'c4' else 'fwd2048')
+            for key in ('forward', 'backward'):
+                v, src = measured_traffic(args.workload, key)
                 if v is not None and (args.workload == 'c4' or key == 'forward'):
                     pmc[key] = dict(bytes=v, source='committed PMC passes: ' + src)
         rf = roofline_of(timing, my_units, peak_cal, pmc)
