@@ -2010,7 +2010,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         ChainRun CR;
         if (!RR.on) CR.setup(E, fast, FP.use_rec != 0, psz);
         if (RR.on || CR.on) { ctx->psumF.ensure(psz * 8); d_psF = ctx->psumF.as<double>(); }
-        if (CR.on && CR.cp.pad && d_post) {      // the private sequence of a padded chain-resident batch lives on the padded geometry
+        if (CR.on && CR.depad) {                 // a padded batch that hands its posteriors out: scratch sequence for the kernels, d_post stays the result
+            ctx->postpad.ensure((size_t)B * T * CR.Gk * 8);
+            E.d_post = ctx->postpad.as<double>();
+        } else if (CR.on && CR.cp.pad && d_post) {      // the private sequence of a padded chain-resident batch lives on the padded geometry
             DevBuf &pb = (overlap_acc && (bi & 1)) ? ctx->post2 : ctx->post;
             pb.ensure((size_t)B * T * CR.Gk * 8);
             d_post = pb.as<double>();
@@ -2413,6 +2416,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             ctx->resident_giveups = 0;               // (the wait doubles with give-ups IN A ROW only)
         }
 
+        if (CR.on && CR.depad && !resident_failed && !evidence_only) {
+            hipLaunchKernelGGL(depad_kernel, dim3((unsigned)((G + NTHREADS - 1) / NTHREADS), (unsigned)(B * T)), dim3(NTHREADS), 0, st, d_post,
+                               ctx->postpad.as<double>(), g.n0, g.n1, CR.cp.n0p, CR.Gk);
+            HIPCHECK(hipGetLastError());
+        }
+
         // --- carried states / average posterior / kept posterior / results ---
         if (carry) {
             const double *fin; long long fstr;
@@ -2433,13 +2442,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             fold_job.h_w = carve<double>(hc, (size_t)Bmax); fold_job.h_invN = carve<double>(hc, (size_t)T * Bmax);
             fold_job.d_post = d_post; fold_job.parity = (int)(bi & 1);
             fold_job.sm_n0 = (CR.post_private && !resident_failed && !CR.cp.pad) ? g.n0 : 0;
-            if (CR.on && CR.cp.pad && !resident_failed) { fold_job.pad_n0p = CR.cp.n0p; fold_job.pad_n0 = g.n0; fold_job.pad_n1 = g.n1; fold_job.pad_step = CR.Gk; }
+            if (CR.on && CR.cp.pad && !CR.depad && !resident_failed) { fold_job.pad_n0p = CR.cp.n0p; fold_job.pad_n0 = g.n0; fold_job.pad_n1 = g.n1; fold_job.pad_step = CR.Gk; }
             fold_job.pending = prepare_fold(ctx, T, B, O, log_w + c0, fold_job);
             // launched behind the NEXT batch's forward pass (see passes); the last batch has nothing to hide behind
             if (bi == nbatch - 1) launch_pending_fold();
         } else if (accumulate) {
             FoldJob lay;
-            const bool padded = CR.on && CR.cp.pad && !resident_failed;
+            const bool padded = CR.on && CR.cp.pad && !CR.depad && !resident_failed;
             if (padded) { lay.pad_n0p = CR.cp.n0p; lay.pad_n0 = g.n0; lay.pad_n1 = g.n1; lay.pad_step = CR.Gk; }
             // (many small batches: nobody waits for a batch's fold; the last one is waited for with the stream below)
             fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (CR.post_private && !resident_failed && !padded) ? g.n0 : 0, padded ? &lay : nullptr,
@@ -2555,7 +2564,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->postpad.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,

@@ -220,6 +220,9 @@ struct ChainRun {
     std::vector<std::vector<double>> sfwdC;        // forward pass: the scales it used, per chain
     // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
     bool post_private = false;
+    // a padded grid whose sequence is NOT private (an ordinary fit that keeps its posteriors): the kernels work on a scratch sequence on
+    // the padded geometry (blhip_ctx::postpad), depad_kernel writes the grid's rows into the sequence everybody else reads
+    bool depad = false;
     // fused fold: the backward kernel adds the weighted, normalised posteriors to per-slot partial accumulators instead of storing
     // them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands left
     // bandwidth unused: same bytes, one pass)
@@ -313,7 +316,17 @@ struct ChainRun {
         // a grid smaller than the geometry: only fits whose sequences are private to the fit (strip-major, padded) -- evidence-only fits
         // and full fits of hyper- / change-point studies (folded in the backward kernel, or stored and folded by accumulate_pad_kernel);
         // everything else keeps the launch-per-step kernels
-        if (cp.pad && !(E.ff.evidence_only || post_private)) { on = false; fused = false; fold2 = false; return; }
+        if (cp.pad && !(E.ff.evidence_only || post_private)) {
+            // ... or, at the price of a second sequence in memory, any fit: the posteriors are copied out of the padded layout afterwards
+            // (<= 512 rows: every flavour has a padded storing kernel; 1024 rows: forward passes only)
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            const double need = (double)B * (double)T * (double)Gk * 8.0;
+            depad = ctx->option("chain_depad", 1.0) != 0.0 && !E.overlap_acc && (cp.ntw <= 4 || !E.ff.full) &&
+                    need < 0.8 * ((double)free_b + (double)ctx->postpad.cap);
+            if (!depad) { on = false; fused = false; fold2 = false; return; }
+            fused = false; fold2 = false;
+        }
         // (<= 512 rows: the one-chain folding kernel has no padded variant -- store + separate fold; 1024 rows: it is the only padded backward kernel)
         if (cp.pad && fused && !fold2 && cp.ntw <= 4) fused = false;
         if (cp.pad && cp.ntw > 4 && E.ff.full && !fused) { on = false; fold2 = false; return; }

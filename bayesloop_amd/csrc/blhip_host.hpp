@@ -123,6 +123,7 @@ struct blhip_ctx {
     // average posterior folded on a second stream while the next batch's forward pass runs (do_fit): second sequence buffer,
     // private copies of the per-batch weights, the stream and its events
     DevBuf post2, accw;
+    DevBuf postpad;              // padded strip-major sequence of a chain-resident batch whose posteriors are handed out (de-padded into post)
     DevBuf hsrc;                 // the axis-1 pre-pass's output of one step (blhip_hwide.hpp)
     DevBuf p1d, p1w;             // hand-off buffers / weight table of the persistent 1-D kernel (blhip_persist1d.hpp)
     DevBuf lik1d;                // (T, n) likelihood table the chains of a 1-D batch share (blhip_chain1d.hpp)

@@ -677,6 +677,17 @@ static __global__ __launch_bounds__(NTHREADS) void marginal_cols_kernel(const do
     out[t * n1 + j] = s;
 }
 
+// A sequence the chain-resident kernels left in their strip-major layout on a PADDED geometry ([t][column / 16][row of n0p][16], pstep
+// doubles per time step) -> the row-major sequence of the grid itself ([t][n0][n1]) that every consumer outside the fit reads.
+// blockIdx.y = chain * T + t; lanes run along the destination (coalesced stores, 128-byte runs of the source).
+static __global__ __launch_bounds__(NTHREADS) void depad_kernel(double *dst, const double *src, int n0, int n1, int n0p, long long pstep) {
+    const long long G = (long long)n0 * n1;
+    const long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x;
+    if (c >= G) return;
+    const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
+    dst[(long long)blockIdx.y * G + c] = __builtin_nontemporal_load(src + (long long)blockIdx.y * pstep + ((long long)(col >> 4) * n0p + row) * 16 + (col & 15));
+}
+
 // out[c] = (1/T) sum_t p[t][c]
 static __global__ __launch_bounds__(NTHREADS) void time_average_kernel(const double *p, double *out, long long G, int T) {
     for (long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x; c < G; c += (long long)gridDim.x * NTHREADS) {

@@ -246,8 +246,8 @@ def random_chain_resident_case(seed, ragged=False, tall=False):
         k = int(rng.integers(2, 8))
     sig = ('cint', 0.0 if seed % 3 == 0 else float(rng.uniform(0.0, 0.3)) * smax, smax, k)
     flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
-    if (ragged or (tall and (n0 != 1024 or n1 % 16))) and flags.get('forwardOnly'):
-        flags = dict()                     # (padded grids: evidence-only fits and full fits that fold in the backward kernel)
+    # (padded grids: evidence-only fits and full fits fold in the backward kernel; forward-only fits hand their filtered distributions out
+    #  through the de-padding copy)
     data = ('series', 1800 + seed, T)
     hp = None
     if kind == 'hyper_nan' and T >= 3:

@@ -361,11 +361,19 @@ def test_wide_axis0_walks_take_the_streaming_kernels():
 
 
 def test_matrix_pipe_kernels_ran():
-    """The cases above really go through blm::mfma_step_kernel (timing variant 3), in both directions."""
+    """The cases above really go through blm::mfma_step_kernel (timing variant 3), in both directions -- the one-axis walk on its padded
+    grid since round 4 only with the chain-resident kernels' de-padding path off (they are its fall-back)."""
+    eng = bl.get_engine()
     for name in ('x_mfma_wide', 'x_mfma_both_ragged'):
-        S = cases.build(bl, EXTRA[name])
-        S.fit(silent=True)
+        eng.set_option('chain_depad', 0)
+        try:
+            S = cases.build(bl, EXTRA[name])
+            S.fit(silent=True)
+        finally:
+            eng.set_option('chain_depad', 1)
         assert S.lastTiming['fwd_kernel_variant'] == 3 and S.lastTiming['bwd_kernel_variant'] == 3, S.lastTiming
+        want = cases.build(bl, EXTRA[name]); want.fit(silent=True)
+        np.testing.assert_allclose(np.asarray(S.posteriorSequence), np.asarray(want.posteriorSequence), rtol=1e-9, atol=1e-14)
 
 
 def test_matrix_pipe_table_likelihood_and_forced_both_axes():
@@ -1371,12 +1379,11 @@ def test_chain_resident_kernel_lag_and_determinism(lag):
 
 
 def test_chain_resident_kernel_not_taken_outside_its_envelope():
-    """A walk wider than 40 grid steps, a filter on the second parameter, a grid of fewer than 32 rows, a padded grid whose fit
-    keeps its filtered distributions, more than 64 strips: the launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
+    """A walk wider than 40 grid steps, a filter on the second parameter, a grid of fewer than 32 rows, more than 64 strips: the
+    launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
     for c in (_hyper(128, 32, 62, 4, ('cint', 0.1, 2.0, 3)),
               dict(study='HyperStudy', data=('series', 63, 4), om=_g2(128, 32), tm=('GRW', 'sigma', ('cint', 0.1, 0.3, 3), 'std', None)),
               _hyper(24, 32, 64, 4, ('cint', 0.1, 0.5, 3)),               # fewer than 32 rows
-              _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3), forwardOnly=True),     # padded grid, but the stored sequence is not private to the fit
               _hyper(128, 1040, 66, 3, ('cint', 0.1, 0.5, 2))):          # 65 strips: more than one granule per lane
         S = cases.build(bl, c); S.fit(**cases.fit_kwargs(c))
         assert S.lastTiming['fwd_kernel_variant'] != 6
@@ -1504,6 +1511,48 @@ RAGGED = {
 }
 
 
+DEPAD = {
+    # ordinary fits (one chain, the posterior sequence is the result) and forward-only hyper-studies on grids the chain-resident kernels
+    # pad: the kernels work on a scratch sequence on the padded geometry, depad_kernel writes the grid's rows into the sequence handed out
+    'depad_study_200x200_full': dict(study='Study', data=('series', 95, 12), om=_g2(200, 200), tm=('GRW', 'sigma', 0.25, 'mean', None)),
+    'depad_study_100x37_forward_only': dict(study='Study', data=('series', 96, 9), om=_g2(100, 37), tm=('GRW', 'sigma', 0.6, 'mean', None),
+                                            fit=dict(forwardOnly=True)),
+    'depad_study_500x30_nan': dict(study='Study', data=('series_nan', 97, 10, [3, 4]), om=_g2(500, 30), tm=('GRW', 'sigma', 0.1, 'mean', None)),
+    'depad_hyper_96x32_forward_only': _hyper(96, 32, 64, 4, ('cint', 0.1, 0.5, 3), forwardOnly=True),
+    'depad_hyper_1000x20_forward_only': _hyper(1000, 20, 98, 4, ('cint', 0.05, 0.3, 3), forwardOnly=True),      # the 1024-row geometry: forward passes only
+    'depad_study_cp_150x40': dict(study='Study', data=('series_jump', 99, 12, 6, 1.5), om=_g2(150, 40), tm=('ChangePoint', 'tc', 6, None)),
+}
+
+
+@pytest.mark.parametrize('case', list(DEPAD))
+def test_padded_chain_resident_fits_hand_their_posteriors_out(case):
+    c = DEPAD[case]
+    S = cases.build(bl, c)
+    kw = cases.fit_kwargs(c)
+    S.fit(**kw)
+    assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming
+    if not kw.get('forwardOnly'):
+        assert S.lastTiming['bwd_kernel_variant'] == 6 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    assert 'posteriorSequence' in gold
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+    # ... and the same fit with the option off (launch-per-step kernels) hands out the same sequence
+    eng = bl.get_engine()
+    eng.set_option('chain_depad', 0)
+    try:
+        R = cases.build(bl, c); R.fit(**kw)
+    finally:
+        eng.set_option('chain_depad', 1)
+    assert R.lastTiming['fwd_kernel_variant'] != 6
+    np.testing.assert_allclose(np.asarray(S.posteriorSequence), np.asarray(R.posteriorSequence), rtol=1e-9, atol=1e-14)
+
+
 @pytest.mark.parametrize('opts', [dict(fold2=0), dict(fuse_accumulate=0), dict(fold2_cp=0)])
 def test_padded_grids_through_the_storing_backward_kernel(opts):
     """Padded grids without the two-chain fold kernel: the backward chain kernel stores the posteriors on the padded geometry and the
@@ -1593,10 +1642,7 @@ def test_seeded_random_walk_plus_change_point_studies_match_oracle(seed):
     with np.errstate(all='ignore'):
         S.fit(**cases.fit_kwargs(c))
         want = oa.run(c)
-    # (a study left with ONE combination of hyper-parameter values is an ordinary fit that hands its posteriors out: on a padded grid
-    #  that keeps the launch-per-step kernels)
-    if len(S.hyperGridValues) > 1:
-        assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming          # the chain-resident path really ran
+    assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming          # the chain-resident path really ran
     got = result_of(S, c)
     gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
     for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
