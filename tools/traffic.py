@@ -17,7 +17,7 @@ def kernel_direction(name):
 FITS = 2
 SHAPES = dict(c4=dict(batches=2, T=256, cells=256 * 512 * 512, alg=(16, 32)), c5=dict(batches=4, T=1000, cells=62.5 * 512 * 512, alg=(16, 32)),
               c3=dict(batches=1, T=2000, cells=1024 * 1024, alg=(16, 32)), fwd2048=dict(batches=1, T=200, cells=2048 * 2048, alg=(16, 32)),
-              c4_both_axes=dict(batches=2, T=256, cells=256 * 512 * 512, alg=(16, 32)),
+              c4_both_axes=dict(batches=2, T=256, cells=256 * 512 * 512, alg=(16, 32)), c4_rows1024=dict(batches=1, T=128, cells=128 * 1024 * 512, alg=(16, 32)),
               coal_hyper1000=dict(batches=1, T=110, cells=256 * 1000, alg=(16, 32)), coal_breakpoints=dict(batches=23, T=41, cells=23400 / 23 * 1000, alg=(16, 32)))
 
 
