@@ -560,15 +560,20 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
 
 // ---- chain-resident kernels (blhip_chainres.hpp): compiled as slices of blhip_chain_tu.hip (blhip_chain_launch.hpp) -----------------------
 void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
-    if (ntw == 4) { if (bwd) blcl::chain_ntw4_bwd(s, Q, nk, store, pad); else blcl::chain_ntw4_fwd(s, Q, nk, store, pad); }
-    else if (ntw == 8) {                 // 1024 rows: one copy of the strip in LDS (blc::chain_kernel TALL); bands up to radius 80 (NK = 44)
-        if (nk <= 24) { if (bwd) blcl::chain_ntw8_bwd_narrow(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_narrow(s, Q, nk, store, pad); }
-        else { if (bwd) blcl::chain_ntw8_bwd_wide(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_wide(s, Q, nk, store, pad); }
-    }
-    else if (ntw == 3) blcl::chain_ntw3(s, Q, nk, bwd, store, pad);
-    else if (ntw == 2) blcl::chain_ntw2(s, Q, nk, bwd, store, pad);
-    else if (ntw == 1) blcl::chain_ntw1(s, Q, nk, bwd, store, pad);
-    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
+    const bool wide = nk > 24;           // bands beyond radius 40 (NK = 26 .. 44): slices of their own
+    if (ntw == 4) {
+        if (wide) { if (bwd) blcl::chain_ntw4_bwd_wide(s, Q, nk, store, pad); else blcl::chain_ntw4_fwd_wide(s, Q, nk, store, pad); }
+        else { if (bwd) blcl::chain_ntw4_bwd(s, Q, nk, store, pad); else blcl::chain_ntw4_fwd(s, Q, nk, store, pad); }
+    } else if (ntw == 8) {               // 1024 rows: one copy of the strip in LDS (blc::chain_kernel TALL)
+        if (wide) { if (bwd) blcl::chain_ntw8_bwd_wide(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_wide(s, Q, nk, store, pad); }
+        else { if (bwd) blcl::chain_ntw8_bwd_narrow(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_narrow(s, Q, nk, store, pad); }
+    } else if (ntw == 3) {
+        if (wide) blcl::chain_ntw3_wide(s, Q, nk, bwd, store, pad); else blcl::chain_ntw3(s, Q, nk, bwd, store, pad);
+    } else if (ntw == 2 || ntw == 1) {
+        if (wide) blcl::chain_ntw12_wide(s, Q, nk, ntw, bwd, store, pad);
+        else if (ntw == 2) blcl::chain_ntw2(s, Q, nk, bwd, store, pad);
+        else blcl::chain_ntw1(s, Q, nk, bwd, store, pad);
+    } else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
     HIPCHECK(hipGetLastError());
 }
 
@@ -576,7 +581,9 @@ void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
 bool fold2_shape(int ntw) { return ntw >= 1 && ntw <= 4; }
 
 void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad = false) {
-    if (ntw >= 3) blcl::fold2_ntw34(s, Q, nk, ntw, pad); else blcl::fold2_ntw12(s, Q, nk, ntw, pad);
+    if (nk > 24) { if (ntw >= 3) blcl::fold2_ntw34_wide(s, Q, nk, ntw, pad); else blcl::fold2_ntw12_wide(s, Q, nk, ntw, pad); }
+    else if (ntw >= 3) blcl::fold2_ntw34(s, Q, nk, ntw, pad);
+    else blcl::fold2_ntw12(s, Q, nk, ntw, pad);
     HIPCHECK(hipGetLastError());
 }
 
@@ -1151,7 +1158,7 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
 
 // memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
 constexpr int CHAIN_MIN_ROWS = 32;            // smallest grid (rows) the chain-resident kernels take (on the 128-row geometry)
-constexpr int CHAIN_TALL_R0_MAX = 80;          // widest band of the 1024-row kernels (blc::chain_kernel<44, 8, ...>); every other geometry: FAST_R0_MAX
+constexpr int CHAIN_R0_MAX = 80;               // widest band of the chain-resident kernels (ring of 44 entries); option chain_wide = 0: FAST_R0_MAX
 constexpr int CHAIN_TALL_ROWS = 1024;         // ... and the one geometry beyond 512 rows: grids of 513 .. 1024 rows (option chain_tall = 0: off)
 inline bool chain_rows_ok(int n0) { return n0 >= CHAIN_MIN_ROWS && n0 <= CHAIN_TALL_ROWS; }
 inline bool chain_tall(int n0) { return n0 > 512 && n0 <= CHAIN_TALL_ROWS; }
@@ -1853,10 +1860,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         for (int64_t c = 0; c < n_chains; c += Bmax) batch_start.push_back(c);
         batch_start.push_back(n_chains);
     }
-    // (the cut: 40; 1024-row grids the chain-resident kernels take: 80)
-    const bool tall_wide = chain_shape && chain_tall(g.n0) && ctx->option("chain_tall", 1.0) != 0.0 && ctx->option("chain_tall_wide", 1.0) != 0.0;
+    // (the cut: 40; grids the chain-resident kernels take: 80)
+    const bool chain_wide = chain_shape && (!chain_tall(g.n0) || ctx->option("chain_tall", 1.0) != 0.0) && ctx->option("chain_wide", 1.0) != 0.0;
     if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0)
-        split_wide_axis0(p, n_chains, op_values, batch_start, tall_wide ? CHAIN_TALL_R0_MAX : FAST_R0_MAX);
+        split_wide_axis0(p, n_chains, op_values, batch_start, chain_wide ? CHAIN_R0_MAX : FAST_R0_MAX);
     const int64_t nbatch = (int64_t)batch_start.size() - 1;
     ctx->timing.batches = nbatch;
 

@@ -21,7 +21,14 @@ void chain_ntw8_bwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool 
 // backward pass with the fused fold, two chains per block (blc::chain_fold2_kernel)
 void fold2_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
 void fold2_ntw34(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
+// ... the same shapes with the wide bands (radius 41 .. 80, NK = 26 .. 44)
+void chain_ntw12_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad);
+void chain_ntw3_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad);
+void chain_ntw4_fwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);
+void chain_ntw4_bwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad);
+void fold2_ntw12_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
+void fold2_ntw34_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
 
-constexpr int N_SLICES = 9;      // BLC_TU = 1 .. N_SLICES (blhip_chain_tu.hip)
+constexpr int N_SLICES = 15;      // BLC_TU = 1 .. N_SLICES (blhip_chain_tu.hip)
 
 }   // namespace blcl

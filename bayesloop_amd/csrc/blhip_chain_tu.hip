@@ -42,7 +42,7 @@ void launch_k(hipStream_t s, const blc::ChainParams &Q, bool store, bool pad) {
 }
 
 // ring lengths LO .. HI (even; 4 = the no-stencil kernels of change-point studies: <= 512 rows only).  band = 16 + 2 R0 columns,
-// R0 = 4, 8, ... 40 (NK = 6 .. 24); 1024 rows: up to R0 = 80 (NK = 44) -- a strip of twice the rows carries twice the radius
+// R0 = 4, 8, ... 80 (NK = 6 .. 44; the slices hold NK <= 24 and NK >= 26 apart: the wide bands are the longer compilations)
 #define BLC_CASE(NKV)                                                                                  \
     case NKV:                                                                                          \
         if constexpr (NKV >= LO && NKV <= HI) { launch_k<NKV, NTW, BWD>(s, Q, store, pad); return; }   \
@@ -71,23 +71,20 @@ void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q, bool pad) {
     }
 }
 
-template <int NTW>
+#define BLC_CASE(NKV)                                                                       \
+    case NKV:                                                                               \
+        if constexpr (NKV >= LO && NKV <= HI) { launch_fold2_k<NKV, NTW>(s, Q, pad); return; }   \
+        break;
+template <int NTW, int LO, int HI>
 void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) {
     switch (nk) {
-        case 4: launch_fold2_k<4, NTW>(s, Q, pad); break;          // no stencil (change-point studies)
-        case 6: launch_fold2_k<6, NTW>(s, Q, pad); break;
-        case 8: launch_fold2_k<8, NTW>(s, Q, pad); break;
-        case 10: launch_fold2_k<10, NTW>(s, Q, pad); break;
-        case 12: launch_fold2_k<12, NTW>(s, Q, pad); break;
-        case 14: launch_fold2_k<14, NTW>(s, Q, pad); break;
-        case 16: launch_fold2_k<16, NTW>(s, Q, pad); break;
-        case 18: launch_fold2_k<18, NTW>(s, Q, pad); break;
-        case 20: launch_fold2_k<20, NTW>(s, Q, pad); break;
-        case 22: launch_fold2_k<22, NTW>(s, Q, pad); break;
-        case 24: launch_fold2_k<24, NTW>(s, Q, pad); break;
-        default: fail("internal: two-chain fold kernel with %d band blocks", nk);
+        BLC_CASE(4) BLC_CASE(6) BLC_CASE(8) BLC_CASE(10) BLC_CASE(12) BLC_CASE(14) BLC_CASE(16) BLC_CASE(18) BLC_CASE(20) BLC_CASE(22) BLC_CASE(24)
+        BLC_CASE(26) BLC_CASE(28) BLC_CASE(30) BLC_CASE(32) BLC_CASE(34) BLC_CASE(36) BLC_CASE(38) BLC_CASE(40) BLC_CASE(42) BLC_CASE(44)
+        default: break;
     }
+    fail("internal: two-chain fold kernel with %d band blocks, %d tiles per wave", nk, NTW);
 }
+#undef BLC_CASE
 
 }   // namespace
 
@@ -109,8 +106,8 @@ void chain_ntw4_fwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store
 #elif BLC_TU == 4
 void chain_ntw4_bwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<4, true, 4, 24>(s, Q, nk, store, pad); }
 void fold2_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad) {
-    if (ntw == 2) launch_fold2_w<2>(s, Q, nk, pad);
-    else if (ntw == 1) launch_fold2_w<1>(s, Q, nk, pad);
+    if (ntw == 2) launch_fold2_w<2, 4, 24>(s, Q, nk, pad);
+    else if (ntw == 1) launch_fold2_w<1, 4, 24>(s, Q, nk, pad);
     else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
 }
 #elif BLC_TU == 5
@@ -123,8 +120,34 @@ void chain_ntw8_fwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool 
 void chain_ntw8_bwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, true, 26, 44>(s, Q, nk, store, pad); }
 #elif BLC_TU == 9
 void fold2_ntw34(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad) {
-    if (ntw == 4) launch_fold2_w<4>(s, Q, nk, pad);
-    else if (ntw == 3) launch_fold2_w<3>(s, Q, nk, pad);
+    if (ntw == 4) launch_fold2_w<4, 4, 24>(s, Q, nk, pad);
+    else if (ntw == 3) launch_fold2_w<3, 4, 24>(s, Q, nk, pad);
+    else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 10
+void chain_ntw12_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad) {
+    if (ntw == 2) { if (bwd) launch_w<2, true, 26, 44>(s, Q, nk, store, pad); else launch_w<2, false, 26, 44>(s, Q, nk, store, pad); }
+    else if (ntw == 1) { if (bwd) launch_w<1, true, 26, 44>(s, Q, nk, store, pad); else launch_w<1, false, 26, 44>(s, Q, nk, store, pad); }
+    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 11
+void chain_ntw3_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
+    if (bwd) launch_w<3, true, 26, 44>(s, Q, nk, store, pad); else launch_w<3, false, 26, 44>(s, Q, nk, store, pad);
+}
+#elif BLC_TU == 12
+void chain_ntw4_fwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<4, false, 26, 44>(s, Q, nk, store, pad); }
+#elif BLC_TU == 13
+void chain_ntw4_bwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<4, true, 26, 44>(s, Q, nk, store, pad); }
+#elif BLC_TU == 14
+void fold2_ntw12_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad) {
+    if (ntw == 2) launch_fold2_w<2, 26, 44>(s, Q, nk, pad);
+    else if (ntw == 1) launch_fold2_w<1, 26, 44>(s, Q, nk, pad);
+    else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 15
+void fold2_ntw34_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad) {
+    if (ntw == 4) launch_fold2_w<4, 26, 44>(s, Q, nk, pad);
+    else if (ntw == 3) launch_fold2_w<3, 26, 44>(s, Q, nk, pad);
     else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
 }
 #else

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 // Everything else -- bands on the matrix pipe, lagged-normaliser scales from data-tagged granules, predicted posterior sums, bounded
 // spins -- is chain_kernel<NK, NTW, true, false>'s.  Launched for rounds of 2 x (CUs / strips) chains when the batch folds.
 template <int NK, int NTW>
-constexpr size_t lds_doubles_fold2() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 64 + NW * NTW * TM + 2 * 2 * NW * 4 * 3 + 4 * NSLOT + 8; }      // (NK = 4: the band tables stay unused)
+constexpr size_t lds_doubles_fold2() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * (NK > 24 ? 16 : 64) + NW * NTW * TM + 2 * 2 * NW * 4 * 3 + 4 * NSLOT + 8; }      // (NK = 4: the band tables stay unused)
 
 template <int NK, int NTW, bool PAD = false>
 __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P) {
@@ -650,8 +650,10 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     constexpr bool FILTER = NK > 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *const X = lds;                          // [2 chains][N0][16]   exchange buffers
-    double *const As = X + 2 * XSZ;                 // [2 chains][NK][64]   A operands
-    double *const m0s = As + 2 * NK * 64;           // [N0]
+    // (bands beyond radius 40 -- NK > 24 -- keep the compact table of band_products: two tables of 44 x 64 doubles would not fit beside the buffers)
+    constexpr int AST = (NK > 24 && BLC_BAND4) ? 16 : 64;
+    double *const As = X + 2 * XSZ;                 // [2 chains][NK][AST]  A operands
+    double *const m0s = As + 2 * NK * AST;          // [N0]
     double *const red = m0s + N0;                   // [2 chains][2 parities][NW * 4][3]
     double *const scal = red + 2 * 2 * NW * 4 * 3;  // [2 chains][NSLOT]
     double *const iscal = scal + 2 * NSLOT;         // [2 chains][NSLOT]
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     const long long G = (long long)P.n0 * P.n1;
 
     // first step: the source (uniform) is consumed unfiltered -> identity bands; the chains' bands replace them after step 0
-    if (FILTER) for (int e = tid; e < 2 * NK * 64; e += NT) As[e] = band_distance(e % (NK * 64), R0) == 0 ? 1.0 : 0.0;
+    if (FILTER) for (int e = tid; e < 2 * NK * AST; e += NT) As[e] = (AST == 16 ? band_distance16(e % (NK * AST), R0) : band_distance(e % (NK * AST), R0)) == 0 ? 1.0 : 0.0;
     for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[PAD ? min(e, n0t - 1) : e];
     if (tid < 4 * NSLOT) scal[tid] = 1.0;
     for (int e = tid; e < 2 * XSZ; e += NT) {
@@ -854,9 +856,9 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             if (FILTER) {
-                const unsigned aoff = (unsigned)l * 8u + (unsigned)(j * NK * 64 * 8);
+                const unsigned aoff = (AST == 16 ? (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u : (unsigned)l * 8u) + (unsigned)(j * NK * AST * 8);
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
-                acc = band_products<NK>(Al, Bv);
+                acc = band_products<NK, 0, NK, AST>(Al, Bv);
             } else {
                 // no stencil: the product tile IS the state (at a restart: the reset distribution, written above)
 #pragma unroll
@@ -1003,9 +1005,9 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 totals(pend_j, pend_k);
                 pend_j = -1;
             }
-            for (int e = tid; e < 2 * NK * 64; e += NT) {
-                const int jj = e / (NK * 64), q = e - jj * (NK * 64);
-                const int a = band_distance(q, R0);
+            for (int e = tid; e < 2 * NK * AST; e += NT) {
+                const int jj = e / (NK * AST), q = e - jj * (NK * AST);
+                const int a = AST == 16 ? band_distance16(q, R0) : band_distance(q, R0);
                 As[e] = a == 0 ? (lw0[jj] > 0 ? P.taps[o0[jj]] : 1.0) : (a <= lw0[jj] ? P.taps[o0[jj] + a] : 0.0);
             }
         }

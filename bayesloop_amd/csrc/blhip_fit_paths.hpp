@@ -252,7 +252,7 @@ struct ChainRun {
         if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && !E.p->backward_init && E.d <= blc::DMAX &&
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
             (!chain_tall(E.g.n0) || ctx->option("chain_tall", 1.0) != 0.0)) {
-            cp.r0_max = (chain_tall(E.g.n0) && ctx->option("chain_tall_wide", 1.0) != 0.0) ? CHAIN_TALL_R0_MAX : FAST_R0_MAX;
+            cp.r0_max = ctx->option("chain_wide", 1.0) != 0.0 ? CHAIN_R0_MAX : FAST_R0_MAX;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
         }
         if (!on) return;

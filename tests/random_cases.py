@@ -208,7 +208,7 @@ def random_online_case(seed):
 
 def random_chain_resident_case(seed, ragged=False, tall=False):
     """Seeded random studies inside the envelope of the chain-resident kernel (blhip_chainres.hpp): hyper-studies over the width of one
-    random walk on the first parameter (radius 0 .. 40, hyper-priors, observation-model priors, missing / multi-dimensional data,
+    random walk on the first parameter (radius 0 .. 40; every fourth study up to 79, hyper-priors, observation-model priors, missing / multi-dimensional data,
     every fit mode) and change-point studies without a stencil, on grids of 128 / 256 / 512 rows x a multiple of 16 columns."""
     rng = np.random.default_rng(12000 + seed)
     n0 = [128, 128, 256, 512][int(rng.integers(0, 4))]
@@ -244,6 +244,9 @@ def random_chain_resident_case(seed, ragged=False, tall=False):
     if tall:
         smax = float(rng.uniform(0.5, 19.8)) * lattice               # ... <= 79
         k = int(rng.integers(2, 8))
+    elif seed % 4 == 3 and n0 > 90:
+        smax = float(rng.uniform(10.0, 19.8)) * lattice              # (every fourth study: the wide bands, radius 41 .. 79)
+        k = min(k, 9)
     sig = ('cint', 0.0 if seed % 3 == 0 else float(rng.uniform(0.0, 0.3)) * smax, smax, k)
     flags = [dict(), dict(), dict(forwardOnly=True), dict(evidenceOnly=True)][int(rng.integers(0, 4))]
     # (padded grids: evidence-only fits and full fits fold in the backward kernel; forward-only fits hand their filtered distributions out

@@ -341,23 +341,32 @@ def test_chains_without_an_axis1_filter_skip_the_pre_pass():
 
 
 def test_wide_axis0_walks_take_the_streaming_kernels():
-    """Axis-0 radii above 40 no longer drop a batch to the generic LDS-tile kernel: column pre-pass + the no-stencil streaming kernel
-    (variant 1); wide_v = 0 restores the old routing, with the same results."""
+    """Axis-0 radii above 40 do not drop a batch to the generic LDS-tile kernel: column pre-pass + the no-stencil streaming kernel
+    (variant 1) -- for walks on the first parameter only up to radius 80 that is the fall-back of the chain-resident kernels since round 4
+    (chain_wide = 0 here); wide_v = 0 restores the old routing, with the same results; and the default routing agrees with both."""
     eng = bl.get_engine()
     for name in ('x_wide_v', 'x_wide_v_hyper', 'x_wide_both', 'x_wide_v_narrow_h', 'x_wide_v_cp'):
         c = EXTRA[name]
-        S = cases.build(bl, c)
-        S.fit(**cases.fit_kwargs(c))
-        assert S.lastTiming['fwd_kernel_variant'] == 1, (name, S.lastTiming)
-        eng.set_option('wide_v', 0)
+        eng.set_option('chain_wide', 0)
         try:
-            S0 = cases.build(bl, c)
-            S0.fit(**cases.fit_kwargs(c))
-            assert S0.lastTiming['fwd_kernel_variant'] == 0, (name, S0.lastTiming)
+            S = cases.build(bl, c)
+            S.fit(**cases.fit_kwargs(c))
+            assert S.lastTiming['fwd_kernel_variant'] == 1, (name, S.lastTiming)
+            eng.set_option('wide_v', 0)
+            try:
+                S0 = cases.build(bl, c)
+                S0.fit(**cases.fit_kwargs(c))
+                assert S0.lastTiming['fwd_kernel_variant'] == 0, (name, S0.lastTiming)
+            finally:
+                eng.set_option('wide_v', 1)
         finally:
-            eng.set_option('wide_v', 1)
-        np.testing.assert_allclose(S.logEvidence, S0.logEvidence, rtol=1e-11)
-        np.testing.assert_allclose(S.posteriorMeanValues, S0.posteriorMeanValues, rtol=1e-9, atol=1e-12)
+            eng.set_option('chain_wide', 1)
+        D = cases.build(bl, c)
+        D.fit(**cases.fit_kwargs(c))
+        assert D.lastTiming['fwd_kernel_variant'] in (1, 6), (name, D.lastTiming)
+        for A in (S0, D):
+            np.testing.assert_allclose(S.logEvidence, A.logEvidence, rtol=1e-11)
+            np.testing.assert_allclose(S.posteriorMeanValues, A.posteriorMeanValues, rtol=1e-9, atol=1e-12)
 
 
 def test_matrix_pipe_kernels_ran():
@@ -902,7 +911,8 @@ def test_seeded_random_wide_axis1_walks_match_oracle(seed):
         return int(4.0 * max(vals) / delta + 0.5) if vals else 0
     lw0, lw1 = radius(c['tm'], 'mean', 10.0 / (n0 - 1)), radius(c['tm'], 'std', 3.0 / (n1 + 1))
     if lw1 <= 256 and (n0 >= (lw0 + 7) // 8 * 8 + 16 if lw0 <= 40 else (lw0 <= 128 and lw0 < n0)):
-        assert S.lastTiming['fwd_kernel_variant'] in (1, 3), (lw0, lw1, n0, n1, S.lastTiming)
+        # (6: no walk on the second parameter in this draw and the one on the first fits the chain-resident kernels' bands)
+        assert S.lastTiming['fwd_kernel_variant'] in (1, 3) or (lw1 == 0 and S.lastTiming['fwd_kernel_variant'] == 6), (lw0, lw1, n0, n1, S.lastTiming)
 
 
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 32))))
@@ -1324,6 +1334,17 @@ CHAINRES = {
     'cres_1000x500_tall_pad': _hyper(1000, 500, 72, 4, ('cint', 0.02, 0.3, 4)),
     'cres_600x40_tall_pad_evidence': _hyper(600, 40, 73, 6, ('cint', 0.05, 0.45, 3), evidenceOnly=True),
     'cres_1024x40_tall_pad_columns': _hyper(1024, 40, 74, 5, ('cint', 0.0, 0.2, 5)),
+    # bands beyond radius 40 on the geometries of <= 512 rows (rings of 26 .. 44 entries; the two-chain kernel keeps its band tables in the
+    # compact form there): narrow and wide chains in one study, every geometry, padded grids, evidence-only / forward-only fits, a
+    # change point inside wide filtering chains
+    'cres_512x32_wide': _hyper(512, 32, 75, 6, ('cint', 0.1, 0.62, 9)),
+    'cres_256x48_wide_r80': _hyper(256, 48, 76, 7, ('cint', 1.2, 1.25, 2)),
+    'cres_128x32_wide_evidence': _hyper(128, 32, 77, 9, ('cint', 0.5, 2.4, 5), evidenceOnly=True),
+    'cres_384x16_wide_forward_only': _hyper(384, 16, 78, 5, ('cint', 0.3, 0.8, 4), forwardOnly=True),
+    'cres_300x40_wide_pad': _hyper(300, 40, 79, 6, ('cint', 0.2, 1.0, 7)),
+    'cres_500x20_wide_pad_evidence': _hyper(500, 20, 80, 5, ('cint', 0.3, 0.6, 3), evidenceOnly=True),
+    'cres_wide_mixed_cp_256x16': dict(study='ChangepointStudy', data=('series_jump', 81, 12, 5, -1.5), om=_g2(256, 16, -4, 6, 3),
+                                      tm=('Combined', [('GRW', 'sigma', 0.6, 'mean', None), ('ChangePoint', 'tChange', ('arange', 1, 11, 2), None)])),
     # T = 1 and T = 2 (shorter than the lag)
     'cres_T1': _hyper(128, 32, 57, 1, ('cint', 0, 0.5, 3)),
     'cres_T2': _hyper(128, 32, 58, 2, ('cint', 0, 0.5, 3)),
@@ -1379,9 +1400,9 @@ def test_chain_resident_kernel_lag_and_determinism(lag):
 
 
 def test_chain_resident_kernel_not_taken_outside_its_envelope():
-    """A walk wider than 40 grid steps, a filter on the second parameter, a grid of fewer than 32 rows, more than 64 strips: the
+    """A walk wider than 80 grid steps, a filter on the second parameter, a grid of fewer than 32 rows, more than 64 strips: the
     launch-per-step kernels run (and the results are the oracle's: covered by the golden and fuzz tests)."""
-    for c in (_hyper(128, 32, 62, 4, ('cint', 0.1, 2.0, 3)),
+    for c in (_hyper(128, 32, 62, 4, ('cint', 0.1, 3.0, 3)),
               dict(study='HyperStudy', data=('series', 63, 4), om=_g2(128, 32), tm=('GRW', 'sigma', ('cint', 0.1, 0.3, 3), 'std', None)),
               _hyper(24, 32, 64, 4, ('cint', 0.1, 0.5, 3)),               # fewer than 32 rows
               _hyper(128, 1040, 66, 3, ('cint', 0.1, 0.5, 2))):          # 65 strips: more than one granule per lane
