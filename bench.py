@@ -2,7 +2,7 @@
 """
 bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c3|c2|c5|fwd2048|coal_breakpoints|c1_hyper|coal_hyper1000] [--no-extra] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c4_wide|c3|c2|c5|fwd2048|coal_breakpoints|c1_hyper|coal_hyper1000] [--no-extra] [--no-cpu]
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
@@ -23,8 +23,10 @@ Workloads (synthetic data, seeds fixed):
   fwd2048  Study, 2048 x 2048 grid, T = 200, evidenceOnly: the fused-forward-step roofline point (N = 1)
   c4_both_axes  HyperStudy, 512 x 512 grid, random walks on BOTH parameters with 64 x 8 width pairs (radii up to 38 / 29 grid steps),
            T = 256, full fit: the axis-1 pre-pass (blhip_hwide.hpp) + the matrix-pipe step kernels, one launch per step and bucket
-  c4_rows1024   HyperStudy, 1024 x 512 grid, 128 widths cint(0, 0.3) on 'mean' (axis-0 radii up to 77), T = 128, full fit: the chains up to
-           radius 40 on the matrix pipe, the wider ones behind the axis-0 pre-pass
+  c4_rows1024   HyperStudy, 1024 x 512 grid, 128 widths cint(0, 0.3) on 'mean' (axis-0 radii up to 77), T = 128, full fit: chain-resident
+           kernels of the 1024-row geometry (one copy of the strip in LDS, rings of up to 44 entries)
+  c4_wide  HyperStudy, 512 x 512 grid, 256 widths cint(0, 0.6) on 'mean' (axis-0 radii up to 77), T = 128, full fit: the same ring
+           lengths on the headline's geometry
 
 Inputs are KBs (the series, the marginal grids) and are uploaded inside fit(); all grid-sized state is created and
 stays in HBM.  The posterior sequence is left on the device (lazy D2H on first access, not part of the timed region).
@@ -97,6 +99,15 @@ def make_study(bl, name, comm=None, scale=1.0):
         S.communicator = comm
         return S, dict(silent=True), n0 * n1 * T * nh, dict(
             workload='HyperStudy 1024x512 grid x 128 sigma values (radii up to 77), T=128, full fit', grid=[n0, n1], T=T, n_hyper=nh, mode='full')
+    if name == 'c4_wide':           # the C4 grid with widths twice as wide: axis-0 radii up to 77 on 512 rows (rings of up to 44 entries on the 512-row geometry)
+        n, T, nh = 512, 128, 256
+        S = bl.HyperStudy(silent=True)
+        S.loadData(series(4, T), silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, n), 'std', bl.oint(0, 4, n)),
+              bl.tm.GaussianRandomWalk('sigma', bl.cint(0, 0.6, nh), target='mean'), silent=True)
+        S.communicator = comm
+        return S, dict(silent=True), n * n * T * nh, dict(
+            workload='HyperStudy 512x512 grid x 256 sigma values cint(0, 0.6) (radii up to 77), T=128, full fit', grid=[n, n], T=T, n_hyper=nh, mode='full')
     if name == 'tiny':        # not a benchmark: the CPU test of this file's launcher / exchange / JSON logic (tests/test_bench_contract.py)
         n, T, nh = 24, 10, 6
         S = bl.HyperStudy(silent=True)
@@ -648,7 +659,7 @@ def main():
     if rank == 0:
         if not args.no_extra and world == 1:
             extra = {}
-            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024', 'coal_breakpoints', 'c1_hyper', 'coal_hyper1000'):
+            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024', 'c4_wide', 'coal_breakpoints', 'c1_hyper', 'coal_hyper1000'):
                 if name == args.workload:
                     continue
                 try:
