@@ -4,7 +4,7 @@
 #include "blhip_err.hpp"
 
 #ifndef BLC_TU
-#error "compile with -DBLC_TU=<slice>"
+#define BLC_TU 0        // (no slice selected -- a bare `hipcc -c` of this file: an empty object; build.py passes -DBLC_TU=1 .. N_SLICES)
 #endif
 
 namespace {
@@ -90,7 +90,8 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
 
 namespace blcl {
 
-#if BLC_TU == 1
+#if BLC_TU == 0
+#elif BLC_TU == 1
 void chain_ntw1(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store, bool pad) {
     if (bwd) launch_w<1, true, 4, 24>(s, Q, nk, store, pad); else launch_w<1, false, 4, 24>(s, Q, nk, store, pad);
 }
