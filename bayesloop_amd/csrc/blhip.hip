@@ -1594,13 +1594,12 @@ struct ChainResPlan {
 // every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
 bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
     // any grid of 32 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns;
-    // 513 .. 1024 rows: 1024 rows x a multiple of 16 columns (one copy of the strip in LDS: blc::chain_kernel TALL; filtering chains only)
+    // 513 .. 1024 rows: 1024 rows x a multiple of 16 columns (one copy of the strip in LDS: blc::chain_kernel TALL; change-point batches keep their state in registers there too)
     if (!chain_rows_ok(g.n0)) return false;
     cp.n0p = (g.n0 + 127) / 128 * 128;
     cp.n1p = (g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL;
     if (chain_tall(g.n0)) cp.n0p = CHAIN_TALL_ROWS;
     cp.pad = cp.n0p != g.n0 || cp.n1p != g.n1;
-    if (chain_tall(g.n0) && prog.LW0 == 0) return false;
     cp.strips = cp.n1p / blc::WCOL;
     cp.ntw = cp.n0p / (blc::NW * blc::TM);
     if (cp.strips > blc::MAX_STRIPS || cp.strips > cus) return false;

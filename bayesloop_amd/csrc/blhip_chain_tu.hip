@@ -41,7 +41,7 @@ void launch_k(hipStream_t s, const blc::ChainParams &Q, bool store, bool pad) {
     }
 }
 
-// ring lengths LO .. HI (even; 4 = the no-stencil kernels of change-point studies: <= 512 rows only).  band = 16 + 2 R0 columns,
+// ring lengths LO .. HI (even; 4 = the no-stencil kernels of change-point studies).  band = 16 + 2 R0 columns,
 // R0 = 4, 8, ... 80 (NK = 6 .. 44; the slices hold NK <= 24 and NK >= 26 apart: the wide bands are the longer compilations)
 #define BLC_CASE(NKV)                                                                                  \
     case NKV:                                                                                          \
@@ -112,9 +112,9 @@ void fold2_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool
     else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
 }
 #elif BLC_TU == 5
-void chain_ntw8_fwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, false, 6, 24>(s, Q, nk, store, pad); }
+void chain_ntw8_fwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, false, 4, 24>(s, Q, nk, store, pad); }
 #elif BLC_TU == 6
-void chain_ntw8_bwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, true, 6, 24>(s, Q, nk, store, pad); }
+void chain_ntw8_bwd_narrow(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, true, 4, 24>(s, Q, nk, store, pad); }
 #elif BLC_TU == 7
 void chain_ntw8_fwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool store, bool pad) { launch_w<8, false, 26, 44>(s, Q, nk, store, pad); }
 #elif BLC_TU == 8

@@ -1334,6 +1334,12 @@ CHAINRES = {
     'cres_1000x500_tall_pad': _hyper(1000, 500, 72, 4, ('cint', 0.02, 0.3, 4)),
     'cres_600x40_tall_pad_evidence': _hyper(600, 40, 73, 6, ('cint', 0.05, 0.45, 3), evidenceOnly=True),
     'cres_1024x40_tall_pad_columns': _hyper(1024, 40, 74, 5, ('cint', 0.0, 0.2, 5)),
+    # change-point studies on the 1024-row geometry (no stencil: the state of a lane's 32 cells stays in registers; posteriors stored and
+    # folded separately -- the two-chain fold kernel stops at 512 rows), evidence-only also on a padded grid
+    'cres_changepoints_1024x32': dict(study='ChangepointStudy', data=('series_jump', 82, 14, 6, 1.5), om=_g2(1024, 32),
+                                      tm=('ChangePoint', 'tChange', ('arange', 1, 13, 2), None)),
+    'cres_changepoints_700x24_evidence': dict(study='ChangepointStudy', data=('series_jump', 83, 11, 5, -2.0), om=_g2(700, 24),
+                                              tm=('ChangePoint', 'tChange', 'all', None), fit=dict(evidenceOnly=True)),
     # bands beyond radius 40 on the geometries of <= 512 rows (rings of 26 .. 44 entries; the two-chain kernel keeps its band tables in the
     # compact form there): narrow and wide chains in one study, every geometry, padded grids, evidence-only / forward-only fits, a
     # change point inside wide filtering chains
