@@ -45,3 +45,28 @@ def test_no_build_products_are_tracked():
                 if fh.read(4) == b'\x7fELF':
                     bad.append(f)
     assert not bad, 'build products in git: %s' % bad
+
+
+def test_the_slices_of_the_chain_kernels_cover_every_declared_launcher():
+    """build.py compiles blhip_chain_tu.hip once per slice (-DBLC_TU=k, k = 1 .. blcl::N_SLICES): every launcher the header declares is
+    defined in exactly one slice, and the slice count the build reads is the header's."""
+    import re
+    from bayesloop_amd.csrc import build
+    here = os.path.join(ROOT, 'bayesloop_amd', 'csrc')
+    hdr = open(os.path.join(here, 'blhip_chain_launch.hpp')).read()
+    tu = open(os.path.join(here, 'blhip_chain_tu.hip')).read()
+    n = int(re.search(r'constexpr int N_SLICES = (\d+);', hdr).group(1))
+    units = build.slices()
+    assert len(units) == n + 1 and units[0][1] == 'blhip.hip'
+    assert [u[2] for u in units[1:]] == [['-DBLC_TU=%d' % k] for k in range(1, n + 1)]
+    declared = re.findall(r'^void (\w+)\(hipStream_t', hdr, flags=re.M)
+    assert len(declared) == len(set(declared)) and len(declared) >= n
+    body = tu[tu.index('namespace blcl {'):]
+    sections = re.split(r'#(?:el)?if BLC_TU == (\d+)', body)          # [pre, k1, text1, k2, text2, ...]
+    defined = {}
+    for k, text in zip(sections[1::2], sections[2::2]):
+        for name in re.findall(r'^void (\w+)\(hipStream_t', text, flags=re.M):
+            assert name not in defined, '%s defined in slices %s and %s' % (name, defined[name], k)
+            defined[name] = int(k)
+    assert set(defined) == set(declared), (set(declared) ^ set(defined))
+    assert set(defined.values()) == set(range(1, n + 1))               # (no empty slice: every compilation earns its place)
