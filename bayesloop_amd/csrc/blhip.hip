@@ -560,6 +560,12 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
 
 // ---- chain-resident kernels (blhip_chainres.hpp): compiled as slices of blhip_chain_tu.hip (blhip_chain_launch.hpp) -----------------------
 void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
+    if (Q.lik) {                         // tabulated likelihood (blc::chain_kernel TAB): exact geometries of <= 512 rows, radius <= 40
+        if (pad || nk > 24 || ntw > 4) fail("internal: chain-resident launch with a likelihood table outside its envelope");
+        if (ntw >= 3) blcl::chain_ntw34_tab(s, Q, nk, ntw, bwd, store); else blcl::chain_ntw12_tab(s, Q, nk, ntw, bwd, store);
+        HIPCHECK(hipGetLastError());
+        return;
+    }
     const bool wide = nk > 24;           // bands beyond radius 40 (NK = 26 .. 44): slices of their own
     if (ntw == 4) {
         if (wide) { if (bwd) blcl::chain_ntw4_bwd_wide(s, Q, nk, store, pad); else blcl::chain_ntw4_fwd_wide(s, Q, nk, store, pad); }
@@ -1851,7 +1857,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     //      two under-filled launches per step (round 1: the 107-chain radius-24 bucket of the C4 study ran as 36 + 71 chains at
     //      4.1 TB/s); hyper-grids are usually monotone in the random-walk width, so contiguous cuts suffice.
     // (cuts on radius-bucket boundaries serve the launch-per-step kernels; grids the chain-resident kernel takes keep whole launches)
-    const bool chain_shape = p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && chain_rows_ok(g.n0) && g.n1 <= 16 * blc::MAX_STRIPS &&
+    const bool chain_shape = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || (p->obs_model == BLHIP_OM_TABLE && g.n0 <= 512)) && chain_rows_ok(g.n0) && g.n1 <= 16 * blc::MAX_STRIPS &&
                              ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok;
     std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && !chain_shape && ctx->option("bucket_batches", 1.0) != 0.0);
     if (overlap_acc) {                     // (equal batches, multiples of 32 chains: whole launches of the chain-resident kernel)
@@ -1860,7 +1866,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         batch_start.push_back(n_chains);
     }
     // (the cut: 40; grids the chain-resident kernels take: 80)
-    const bool chain_wide = chain_shape && (!chain_tall(g.n0) || ctx->option("chain_tall", 1.0) != 0.0) && ctx->option("chain_wide", 1.0) != 0.0;
+    const bool chain_wide = chain_shape && p->obs_model == BLHIP_OM_GAUSSIAN && (!chain_tall(g.n0) || ctx->option("chain_tall", 1.0) != 0.0) && ctx->option("chain_wide", 1.0) != 0.0;
     if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0)
         split_wide_axis0(p, n_chains, op_values, batch_start, chain_wide ? CHAIN_R0_MAX : FAST_R0_MAX);
     const int64_t nbatch = (int64_t)batch_start.size() - 1;

@@ -41,6 +41,33 @@ void launch_k(hipStream_t s, const blc::ChainParams &Q, bool store, bool pad) {
     }
 }
 
+// tabulated likelihood: forward (stored / evidence-only), backward (stored / folded)
+template <int NK, int NTW>
+void launch_k_tab(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
+    const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
+    if (bwd && store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false, true>, s, Q, lds);
+    else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false, true>, s, Q, lds);
+    else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, false, true>, s, Q, lds);
+    else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, false, true>, s, Q, lds);
+}
+template <int NTW>
+void launch_w_tab(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
+    switch (nk) {
+        case 4: launch_k_tab<4, NTW>(s, Q, bwd, store); break;
+        case 6: launch_k_tab<6, NTW>(s, Q, bwd, store); break;
+        case 8: launch_k_tab<8, NTW>(s, Q, bwd, store); break;
+        case 10: launch_k_tab<10, NTW>(s, Q, bwd, store); break;
+        case 12: launch_k_tab<12, NTW>(s, Q, bwd, store); break;
+        case 14: launch_k_tab<14, NTW>(s, Q, bwd, store); break;
+        case 16: launch_k_tab<16, NTW>(s, Q, bwd, store); break;
+        case 18: launch_k_tab<18, NTW>(s, Q, bwd, store); break;
+        case 20: launch_k_tab<20, NTW>(s, Q, bwd, store); break;
+        case 22: launch_k_tab<22, NTW>(s, Q, bwd, store); break;
+        case 24: launch_k_tab<24, NTW>(s, Q, bwd, store); break;
+        default: fail("internal: chain-resident kernel (tabulated likelihood) with %d band blocks", nk);
+    }
+}
+
 // ring lengths LO .. HI (even; 4 = the no-stencil kernels of change-point studies).  band = 16 + 2 R0 columns,
 // R0 = 4, 8, ... 80 (NK = 6 .. 44; the slices hold NK <= 24 and NK >= 26 apart: the wide bands are the longer compilations)
 #define BLC_CASE(NKV)                                                                                  \
@@ -150,6 +177,18 @@ void fold2_ntw34_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw,
     if (ntw == 4) launch_fold2_w<4, 26, 44>(s, Q, nk, pad);
     else if (ntw == 3) launch_fold2_w<3, 26, 44>(s, Q, nk, pad);
     else fail("internal: two-chain fold kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 16
+void chain_ntw12_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 2) launch_w_tab<2>(s, Q, nk, bwd, store);
+    else if (ntw == 1) launch_w_tab<1>(s, Q, nk, bwd, store);
+    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 17
+void chain_ntw34_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 4) launch_w_tab<4>(s, Q, nk, bwd, store);
+    else if (ntw == 3) launch_w_tab<3>(s, Q, nk, bwd, store);
+    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
 }
 #else
 #error "BLC_TU out of range"

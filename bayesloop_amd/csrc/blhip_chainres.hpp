@@ -93,6 +93,8 @@ struct ChainParams {
     unsigned *abort_word;
     unsigned long long timeout_ticks;
     unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
+    // (last: the fields above keep their offsets -- the two-chain kernel's register allocation is sensitive to how the argument block loads)
+    const double *lik;           // TAB kernels: the likelihood of every step, [T][n0 * n1] row-major (table models: built on the device or by the caller)
 };
 
 // The kernel arguments arrive as 16-register tuples (s_load_dwordx16) and the register allocator spills and restores a tuple as ONE
@@ -197,8 +199,12 @@ constexpr size_t lds_doubles() { return (size_t)(NTW > 4 ? 1 : 2) * NW * NTW * T
 // sums), the read-only inputs (source distribution, coordinates, column constants) are read with bounds.  Only for sequences private
 // to the fit (strip-major layout on the padded geometry): forward passes and storing backward passes here, folding backward passes in
 // chain_fold2_kernel (<= 512 rows) / here (1024 rows).
-template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false>
+template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false, bool TAB = false>
 __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
+    // TAB: the likelihood comes out of a table (every observation model but the Gaussian on a 2-D grid: Laplace, AR1, a caller's own pdf)
+    // instead of the recurrence -- one more 8-byte read per cell and step, shared by the chains of a launch (they read the same rows
+    // at about the same time); exact geometries of <= 512 rows
+    static_assert(!TAB || (!PAD && NTW <= 4), "tabulated likelihood: exact geometries of <= 512 rows");
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     const bool colok = !PAD || gj < n1t;
     const int gjc = PAD ? min(gj, n1t - 1) : gj;
     const double g1 = P.m1[gjc];
-    const double cA = P.colA[gjc], cB = P.colB[gjc];
+    const double cA = TAB ? 0.0 : P.colA[gjc], cB = TAB ? 0.0 : P.colB[gjc];
     double *const pchain = P.post + (long long)b * P.post_stride;
     const unsigned rowx8 = P.strip_major ? (unsigned)WCOL * 8u : (unsigned)P.n1 * 8u;                        // bytes between rows
     const unsigned strip0 = P.strip_major ? (unsigned)tj * (unsigned)(P.n0 * WCOL * 8) : (unsigned)tj * (unsigned)(WCOL * 8);   // the strip's first byte
@@ -388,6 +394,18 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             }
         }
 
+        // (TAB) the likelihood of the lane's cells at this step: requested in front of the products, consumed by the epilogues
+        double lk[TAB ? NTW : 1][4];
+        if (TAB) {
+            const double *const lrow = P.lik + (long long)t * G;
+            const int l = fresh_lane();
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lk[TAB ? it : 0][r] = blm::ld32(lrow, __umul24(row0 + it * TM + (l >> 4) + 4 * r, (unsigned)P.n1 * 8u) + (unsigned)(tj * WCOL + (l & 15)) * 8u);
+        }
+
         BLC_STAMP(1);
         double scale = 1.0;
         double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
@@ -459,6 +477,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 }
                 // ---- anchor of the stride-4 likelihood recurrence of this lane's rows (blhip_mfma.hpp) -------------------------------
                 // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
+                if constexpr (!TAB) {
                 const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
                 double a0 = 0.0, s1 = 0.0, dn = 0.0;
 #pragma unroll
@@ -486,6 +505,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 } else {
                     mE *= scale;                     // forward: the scale rides on the likelihood's mantissa (one product per cell less)
                 }
+                }
                 BLC_STAMP(3);
             }
 
@@ -493,7 +513,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int li = i + g + 4 * r;
-                const double Lv = ldexp(mE, nE);
+                const double Lv = TAB ? (BWD ? lk[TAB ? it : 0][r] : lk[TAB ? it : 0][r] * scale) : ldexp(mE, nE);
                 const unsigned off = cell_off(l, it, r);
                 if (!BWD) {
                     const double a = (!PAD || (colok && li < n0t)) ? acc[r] * Lv : 0.0;          // (cells outside the grid stay zero)
@@ -508,7 +528,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     const double p = al[it % ALD][r] * beta;
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
-                    const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));
+                    const double pl = !in ? 0.0 : (TAB ? p / Lv : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)));      // (0 / 0 -> NaN either way)
                     if (TALL && FILTER) nst[it][r] = cn; else if (FILTER) D[li * WCOL + c] = cn; else stt[it][r] = cn;
                     if (!FOLD) stnt(pstep, off, p);
                     else stnt(pslot_t, off, pa[r] + fmax(p * wq, wfloor));      // (nobody else touches the slot's cell during the launch)
@@ -517,9 +537,11 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     sC += cn;
                     acc[r] = p;
                 }
-                mE *= mR; nE += nR;
-                mR *= mq; nR += nq;
-                if (BWD) { iE *= iR; iR *= iq; }
+                if constexpr (!TAB) {
+                    mE *= mR; nE += nR;
+                    mR *= mq; nR += nq;
+                    if (BWD) { iE *= iR; iR *= iq; }
+                }
             }
 
             if (BWD) {

@@ -220,6 +220,7 @@ struct ChainRun {
     std::vector<std::vector<double>> sfwdC;        // forward pass: the scales it used, per chain
     // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
     bool post_private = false;
+    bool tab = false;                              // the likelihood comes out of a table (blc::chain_kernel TAB)
     // a padded grid whose sequence is NOT private (an ordinary fit that keeps its posteriors): the kernels work on a scratch sequence on
     // the padded geometry (blhip_ctx::postpad), depad_kernel writes the grid's rows into the sequence everybody else reads
     bool depad = false;
@@ -249,11 +250,16 @@ struct ChainRun {
         const ChainProgram &prog = *E.prog;
         const int64_t T = E.T, B = E.B;
         const long long G = E.G;
-        if (fast && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && !E.p->backward_init && E.d <= blc::DMAX &&
+        // the likelihood: the Gaussian recurrence, or a table (every other model on a 2-D grid -- built on the device for the closed-form
+        // ones, evaluated by the caller otherwise: blc::chain_kernel TAB, exact geometries of <= 512 rows, radius <= 40, one chain per block)
+        const bool gauss = E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && E.d <= blc::DMAX;
+        tab = E.p->obs_model == BLHIP_OM_TABLE && E.DT->lik != nullptr && ctx->option("chain_table", 1.0) != 0.0;
+        if (fast && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
             !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
             (!chain_tall(E.g.n0) || ctx->option("chain_tall", 1.0) != 0.0)) {
-            cp.r0_max = ctx->option("chain_wide", 1.0) != 0.0 ? CHAIN_R0_MAX : FAST_R0_MAX;
+            cp.r0_max = (!tab && ctx->option("chain_wide", 1.0) != 0.0) ? CHAIN_R0_MAX : FAST_R0_MAX;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
+            if (on && tab && (cp.pad || cp.ntw > 4)) on = false;
         }
         if (!on) return;
         Gk = (long long)cp.n0p * cp.n1p;
@@ -276,11 +282,11 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
-        CQ.n0 = cp.n0p; CQ.n1 = cp.n1p; CQ.n0t = E.g.n0; CQ.n1t = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = E.d; CQ.rec_len = E.rec_len;
+        CQ.n0 = cp.n0p; CQ.n1 = cp.n1p; CQ.n0t = E.g.n0; CQ.n1t = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = tab ? 0 : E.d; CQ.rec_len = E.rec_len;
         CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
         CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
         CQ.post_stride = (long long)T * Gk;
-        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.step0 = E.step0;
+        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.lik = tab ? E.DT->lik : nullptr; CQ.step0 = E.step0;
         CQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
         // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)
@@ -293,14 +299,14 @@ struct ChainRun {
             // change-point batches: the predicted sums survive a restart only through the two-chain fold kernel's restart rule, and
             // only if the two passes restart at the same places (backward step t restarts <=> forward step t + 1 does: unit-spaced
             // time stamps, transitionModels.py:316-317)
-            bool aligned = !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0 && ctx->option("fold2_cp", 1.0) != 0.0;
+            bool aligned = !tab && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0 && ctx->option("fold2_cp", 1.0) != 0.0;
             for (int64_t b = 0; b < B && aligned; ++b)
                 for (int64_t t = 0; t + 1 < T && aligned; ++t)
                     aligned = (prog.kindB[(size_t)t * B + b] != SRC_PREV) == (prog.kindF[(size_t)(t + 1) * B + b] != SRC_PREV);
             fused = aligned;
         }
         slots_used = (int)std::min<int64_t>(cp.cpr, B);
-        if (fused && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0) {
+        if (fused && !tab && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0) {      // (the two-chain kernel has no table flavour)
             fold2 = true;
             const int per = 2 * cp.cpr;
             for (int64_t s0 = 0; s0 < B; s0 += per) {
@@ -423,7 +429,9 @@ struct ChainRun {
                     for (int q = rstart[r]; q < rstart[r + 1]; ++q) { const long long v = h_tshare[cp.order[q]]; sum += v; mx = std::max(mx, v); }
                     shared = (double)(bwd ? sum - mx : sum) * Gk * 8.0;
                 }
-                account(ctx, bwd, cells * bytes - shared, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
+                // (tabulated likelihood: the table of the pass is read once per launch -- its chains read the same rows at about the same time)
+                const double table = tab ? (double)T * Gk * 8.0 : 0.0;
+                account(ctx, bwd, cells * bytes - shared + table, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
             }
 #ifdef BLC_PROF
             {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)

@@ -1538,6 +1538,57 @@ RAGGED = {
 }
 
 
+def _om2(name, p0, p1):
+    return (name, [p0, p1], 'default')
+
+
+CHAINTAB = {
+    # observation models other than the Gaussian on the chain-resident kernels (blc::chain_kernel TAB: the likelihood of every step out of
+    # the (T, G) table the launch-per-step kernels use too): Laplace / AR1 / ScaledAR1 hyper-studies over the width of a walk on the first
+    # parameter -- full fits (single-chain fused fold), evidence-only, forward-only --, a change-point study (no stencil), a plain Study
+    'ctab_laplace_128x32_full': dict(study='HyperStudy', data=('series', 101, 9), om=_om2('Laplace', ('mu', ('cint', -5, 5, 128)), ('b', ('oint', 0, 3, 32))),
+                                     tm=('GRW', 'sigma', ('cint', 0, 0.7, 7), 'mu', None)),
+    'ctab_ar1_256x48_evidence': dict(study='HyperStudy', data=('series', 102, 12), om=_om2('AR1', ('rho', ('oint', -1, 1, 256)), ('sigma', ('oint', 0, 3, 48))),
+                                     tm=('GRW', 's', ('cint', 0.005, 0.07, 5), 'rho', None), fit=dict(evidenceOnly=True)),
+    'ctab_scaled_ar1_512x16_full': dict(study='HyperStudy', data=('series', 103, 8), om=_om2('ScaledAR1', ('rho', ('oint', -1, 1, 512)), ('sigma', ('oint', 0, 3, 16))),
+                                        tm=('GRW', 's', ('cint', 0.0, 0.035, 4), 'rho', None)),
+    'ctab_laplace_384x32_forward_only': dict(study='HyperStudy', data=('series', 104, 7), om=_om2('Laplace', ('mu', ('cint', -5, 5, 384)), ('b', ('oint', 0, 3, 32))),
+                                             tm=('GRW', 'sigma', ('cint', 0.05, 0.25, 3), 'mu', None), fit=dict(forwardOnly=True)),
+    'ctab_laplace_changepoints_128x48': dict(study='ChangepointStudy', data=('series_jump', 105, 14, 7, 1.5),
+                                             om=_om2('Laplace', ('mu', ('cint', -5, 5, 128)), ('b', ('oint', 0, 3, 48))), tm=('ChangePoint', 'tc', 'all', None)),
+    'ctab_laplace_study_256x64': dict(study='Study', data=('series', 106, 10), om=_om2('Laplace', ('mu', ('cint', -5, 5, 256)), ('b', ('oint', 0, 3, 64))),
+                                      tm=('GRW', 'sigma', 0.3, 'mu', None)),
+}
+
+
+@pytest.mark.parametrize('case', list(CHAINTAB))
+def test_chain_resident_kernels_with_a_tabulated_likelihood_match_oracle(case):
+    c = CHAINTAB[case]
+    S = cases.build(bl, c)
+    kw = cases.fit_kwargs(c)
+    S.fit(**kw)
+    assert S.lastTiming['fwd_kernel_variant'] == 6, S.lastTiming
+    if not kw.get('evidenceOnly') and not kw.get('forwardOnly'):
+        assert S.lastTiming['bwd_kernel_variant'] == 6 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+    # ... and the launch-per-step kernels (option off) agree
+    eng = bl.get_engine()
+    eng.set_option('chain_table', 0)
+    try:
+        R = cases.build(bl, c); R.fit(**kw)
+    finally:
+        eng.set_option('chain_table', 1)
+    assert R.lastTiming['fwd_kernel_variant'] != 6
+    assert abs(S.logEvidence - R.logEvidence) <= 1e-10 * abs(R.logEvidence)
+
+
 DEPAD = {
     # ordinary fits (one chain, the posterior sequence is the result) and forward-only hyper-studies on grids the chain-resident kernels
     # pad: the kernels work on a scratch sequence on the padded geometry, depad_kernel writes the grid's rows into the sequence handed out
