@@ -560,9 +560,10 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
 
 // ---- chain-resident kernels (blhip_chainres.hpp): compiled as slices of blhip_chain_tu.hip (blhip_chain_launch.hpp) -----------------------
 void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
-    if (Q.lik) {                         // tabulated likelihood (blc::chain_kernel TAB): exact geometries of <= 512 rows, radius <= 40
-        if (pad || nk > 24 || ntw > 4) fail("internal: chain-resident launch with a likelihood table outside its envelope");
-        if (ntw >= 3) blcl::chain_ntw34_tab(s, Q, nk, ntw, bwd, store); else blcl::chain_ntw12_tab(s, Q, nk, ntw, bwd, store);
+    if (Q.lik) {                         // tabulated likelihood (blc::chain_kernel TAB): geometries of <= 512 rows, radius <= 40
+        if (nk > 24 || ntw > 4) fail("internal: chain-resident launch with a likelihood table outside its envelope");
+        if (pad) { if (ntw >= 3) blcl::chain_ntw34_tab_pad(s, Q, nk, ntw, bwd, store); else blcl::chain_ntw12_tab_pad(s, Q, nk, ntw, bwd, store); }
+        else if (ntw >= 3) blcl::chain_ntw34_tab(s, Q, nk, ntw, bwd, store); else blcl::chain_ntw12_tab(s, Q, nk, ntw, bwd, store);
         HIPCHECK(hipGetLastError());
         return;
     }

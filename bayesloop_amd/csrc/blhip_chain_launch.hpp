@@ -29,10 +29,12 @@ void chain_ntw4_bwd_wide(hipStream_t s, const blc::ChainParams &Q, int nk, bool 
 void fold2_ntw12_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
 void fold2_ntw34_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad);
 
-// ... and with the likelihood out of a table (blc::chain_kernel TAB: exact geometries of <= 512 rows, radius <= 40)
+// ... and with the likelihood out of a table (blc::chain_kernel TAB: geometries of <= 512 rows, radius <= 40)
 void chain_ntw12_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);
 void chain_ntw34_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);
+void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);
+void chain_ntw34_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);
 
-constexpr int N_SLICES = 17;      // BLC_TU = 1 .. N_SLICES (blhip_chain_tu.hip)
+constexpr int N_SLICES = 19;      // BLC_TU = 1 .. N_SLICES (blhip_chain_tu.hip)
 
 }   // namespace blcl

@@ -42,28 +42,35 @@ void launch_k(hipStream_t s, const blc::ChainParams &Q, bool store, bool pad) {
 }
 
 // tabulated likelihood: forward (stored / evidence-only), backward (stored / folded)
-template <int NK, int NTW>
+template <int NK, int NTW, bool PAD>
 void launch_k_tab(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
-    if (bwd && store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false, true>, s, Q, lds);
-    else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false, true>, s, Q, lds);
-    else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, false, true>, s, Q, lds);
-    else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, false, true>, s, Q, lds);
+    if constexpr (PAD) {                 // (padded grids: the folding backward pass would be the two-chain kernel's, which has no table flavour)
+        if (bwd && !store) fail("internal: padded chain-resident launch of a folding backward pass (tabulated likelihood)");
+        if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true, true>, s, Q, lds);
+        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true, true>, s, Q, lds);
+        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true, true>, s, Q, lds);
+    } else {
+        if (bwd && store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false, true>, s, Q, lds);
+        else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false, true>, s, Q, lds);
+        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, false, true>, s, Q, lds);
+        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, false, true>, s, Q, lds);
+    }
 }
-template <int NTW>
+template <int NTW, bool PAD>
 void launch_w_tab(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
     switch (nk) {
-        case 4: launch_k_tab<4, NTW>(s, Q, bwd, store); break;
-        case 6: launch_k_tab<6, NTW>(s, Q, bwd, store); break;
-        case 8: launch_k_tab<8, NTW>(s, Q, bwd, store); break;
-        case 10: launch_k_tab<10, NTW>(s, Q, bwd, store); break;
-        case 12: launch_k_tab<12, NTW>(s, Q, bwd, store); break;
-        case 14: launch_k_tab<14, NTW>(s, Q, bwd, store); break;
-        case 16: launch_k_tab<16, NTW>(s, Q, bwd, store); break;
-        case 18: launch_k_tab<18, NTW>(s, Q, bwd, store); break;
-        case 20: launch_k_tab<20, NTW>(s, Q, bwd, store); break;
-        case 22: launch_k_tab<22, NTW>(s, Q, bwd, store); break;
-        case 24: launch_k_tab<24, NTW>(s, Q, bwd, store); break;
+        case 4: launch_k_tab<4, NTW, PAD>(s, Q, bwd, store); break;
+        case 6: launch_k_tab<6, NTW, PAD>(s, Q, bwd, store); break;
+        case 8: launch_k_tab<8, NTW, PAD>(s, Q, bwd, store); break;
+        case 10: launch_k_tab<10, NTW, PAD>(s, Q, bwd, store); break;
+        case 12: launch_k_tab<12, NTW, PAD>(s, Q, bwd, store); break;
+        case 14: launch_k_tab<14, NTW, PAD>(s, Q, bwd, store); break;
+        case 16: launch_k_tab<16, NTW, PAD>(s, Q, bwd, store); break;
+        case 18: launch_k_tab<18, NTW, PAD>(s, Q, bwd, store); break;
+        case 20: launch_k_tab<20, NTW, PAD>(s, Q, bwd, store); break;
+        case 22: launch_k_tab<22, NTW, PAD>(s, Q, bwd, store); break;
+        case 24: launch_k_tab<24, NTW, PAD>(s, Q, bwd, store); break;
         default: fail("internal: chain-resident kernel (tabulated likelihood) with %d band blocks", nk);
     }
 }
@@ -180,14 +187,26 @@ void fold2_ntw34_wide(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw,
 }
 #elif BLC_TU == 16
 void chain_ntw12_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
-    if (ntw == 2) launch_w_tab<2>(s, Q, nk, bwd, store);
-    else if (ntw == 1) launch_w_tab<1>(s, Q, nk, bwd, store);
+    if (ntw == 2) launch_w_tab<2, false>(s, Q, nk, bwd, store);
+    else if (ntw == 1) launch_w_tab<1, false>(s, Q, nk, bwd, store);
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
 }
 #elif BLC_TU == 17
 void chain_ntw34_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
-    if (ntw == 4) launch_w_tab<4>(s, Q, nk, bwd, store);
-    else if (ntw == 3) launch_w_tab<3>(s, Q, nk, bwd, store);
+    if (ntw == 4) launch_w_tab<4, false>(s, Q, nk, bwd, store);
+    else if (ntw == 3) launch_w_tab<3, false>(s, Q, nk, bwd, store);
+    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 18
+void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 2) launch_w_tab<2, true>(s, Q, nk, bwd, store);
+    else if (ntw == 1) launch_w_tab<1, true>(s, Q, nk, bwd, store);
+    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 19
+void chain_ntw34_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 4) launch_w_tab<4, true>(s, Q, nk, bwd, store);
+    else if (ntw == 3) launch_w_tab<3, true>(s, Q, nk, bwd, store);
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
 }
 #else

@@ -203,8 +203,8 @@ template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false, bool TAB = fa
 __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     // TAB: the likelihood comes out of a table (every observation model but the Gaussian on a 2-D grid: Laplace, AR1, a caller's own pdf)
     // instead of the recurrence -- one more 8-byte read per cell and step, shared by the chains of a launch (they read the same rows
-    // at about the same time); exact geometries of <= 512 rows
-    static_assert(!TAB || (!PAD && NTW <= 4), "tabulated likelihood: exact geometries of <= 512 rows");
+    // at about the same time); geometries of <= 512 rows (PAD: the table lives on the grid's true sizes, cells outside read as zero)
+    static_assert(!TAB || NTW <= 4, "tabulated likelihood: geometries of <= 512 rows");
     constexpr int R0 = (4 * NK - TM) / 2;
     constexpr int N0 = NW * NTW * TM;
     constexpr int XSZ = N0 * WCOL;
@@ -397,13 +397,17 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         // (TAB) the likelihood of the lane's cells at this step: requested in front of the products, consumed by the epilogues
         double lk[TAB ? NTW : 1][4];
         if (TAB) {
-            const double *const lrow = P.lik + (long long)t * G;
+            const double *const lrow = P.lik + (long long)t * n0t * n1t;
             const int l = fresh_lane();
 #pragma unroll
             for (int it = 0; it < NTW; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    lk[TAB ? it : 0][r] = blm::ld32(lrow, __umul24(row0 + it * TM + (l >> 4) + 4 * r, (unsigned)P.n1 * 8u) + (unsigned)(tj * WCOL + (l & 15)) * 8u);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + it * TM + (l >> 4) + 4 * r;
+                    const unsigned off = __umul24(PAD ? min(row, n0t - 1) : row, (unsigned)n1t * 8u) + (unsigned)(PAD ? min(tj * WCOL + (l & 15), n1t - 1) : tj * WCOL + (l & 15)) * 8u;
+                    const double v = blm::ld32(lrow, off);
+                    lk[TAB ? it : 0][r] = (!PAD || (row < n0t && colok)) ? v : 0.0;
+                }
         }
 
         BLC_STAMP(1);

@@ -251,7 +251,7 @@ struct ChainRun {
         const int64_t T = E.T, B = E.B;
         const long long G = E.G;
         // the likelihood: the Gaussian recurrence, or a table (every other model on a 2-D grid -- built on the device for the closed-form
-        // ones, evaluated by the caller otherwise: blc::chain_kernel TAB, exact geometries of <= 512 rows, radius <= 40, one chain per block)
+        // ones, evaluated by the caller otherwise: blc::chain_kernel TAB, geometries of <= 512 rows -- padded grids too --, radius <= 40, one chain per block)
         const bool gauss = E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && E.d <= blc::DMAX;
         tab = E.p->obs_model == BLHIP_OM_TABLE && E.DT->lik != nullptr && ctx->option("chain_table", 1.0) != 0.0;
         if (fast && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
@@ -259,7 +259,7 @@ struct ChainRun {
             (!chain_tall(E.g.n0) || ctx->option("chain_tall", 1.0) != 0.0)) {
             cp.r0_max = (!tab && ctx->option("chain_wide", 1.0) != 0.0) ? CHAIN_R0_MAX : FAST_R0_MAX;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
-            if (on && tab && (cp.pad || cp.ntw > 4)) on = false;
+            if (on && tab && cp.ntw > 4) on = false;
         }
         if (!on) return;
         Gk = (long long)cp.n0p * cp.n1p;
@@ -334,6 +334,7 @@ struct ChainRun {
             fused = false; fold2 = false;
         }
         // (<= 512 rows: the one-chain folding kernel has no padded variant -- store + separate fold; 1024 rows: it is the only padded backward kernel)
+        // (tabulated likelihood on a padded grid: no fold2 -> store + separate fold as well)
         if (cp.pad && fused && !fold2 && cp.ntw <= 4) fused = false;
         if (cp.pad && cp.ntw > 4 && E.ff.full && !fused) { on = false; fold2 = false; return; }
         // Change-point batches without a stencil whose backward pass folds: the chains are identical up to their first restart.  The chain

@@ -387,10 +387,12 @@ def test_matrix_pipe_kernels_ran():
 
 def test_matrix_pipe_table_likelihood_and_forced_both_axes():
     """Tabulated likelihood through the matrix-pipe kernels, and the both-axes variant forced on a launch larger than its
-    default size limit: both equal the vector-ALU kernels (mfma=0) to rounding."""
+    default size limit: both equal the vector-ALU kernels (mfma=0) to rounding.  (chain_table = 0: the one-axis walk would take the
+    chain-resident kernels' table flavour since round 4 -- these kernels are its fall-back.)"""
     eng = bl.get_engine()
 
     def fit(n0, n1, s1, s2, **opts):
+        opts = dict(opts, chain_table=0)
         for k, v in opts.items():
             eng.set_option(k, v)
         try:
@@ -1556,6 +1558,16 @@ CHAINTAB = {
                                              tm=('GRW', 'sigma', ('cint', 0.05, 0.25, 3), 'mu', None), fit=dict(forwardOnly=True)),
     'ctab_laplace_changepoints_128x48': dict(study='ChangepointStudy', data=('series_jump', 105, 14, 7, 1.5),
                                              om=_om2('Laplace', ('mu', ('cint', -5, 5, 128)), ('b', ('oint', 0, 3, 48))), tm=('ChangePoint', 'tc', 'all', None)),
+    # ... on padded grids: hyper-study (posteriors stored on the padded geometry, folded by accumulate_pad_kernel), evidence-only, a plain Study
+    # (de-padding copy), a change-point study
+    'ctab_pad_laplace_200x50_full': dict(study='HyperStudy', data=('series', 107, 8), om=_om2('Laplace', ('mu', ('cint', -5, 5, 200)), ('b', ('oint', 0, 3, 50))),
+                                         tm=('GRW', 'sigma', ('cint', 0, 0.45, 6), 'mu', None)),
+    'ctab_pad_ar1_100x37_evidence': dict(study='HyperStudy', data=('series', 108, 10), om=_om2('AR1', ('rho', ('oint', -1, 1, 100)), ('sigma', ('oint', 0, 3, 37))),
+                                         tm=('GRW', 's', ('cint', 0.01, 0.18, 4), 'rho', None), fit=dict(evidenceOnly=True)),
+    'ctab_pad_scaled_ar1_study_200x200': dict(study='Study', data=('series', 109, 9), om=_om2('ScaledAR1', ('rho', ('oint', -1, 1, 200)), ('sigma', ('oint', 0, 3, 200))),
+                                              tm=('GRW', 's', 0.08, 'rho', None)),
+    'ctab_pad_laplace_changepoints_150x40': dict(study='ChangepointStudy', data=('series_jump', 110, 12, 6, 1.5),
+                                                 om=_om2('Laplace', ('mu', ('cint', -5, 5, 150)), ('b', ('oint', 0, 3, 40))), tm=('ChangePoint', 'tc', 'all', None)),
     'ctab_laplace_study_256x64': dict(study='Study', data=('series', 106, 10), om=_om2('Laplace', ('mu', ('cint', -5, 5, 256)), ('b', ('oint', 0, 3, 64))),
                                       tm=('GRW', 'sigma', 0.3, 'mu', None)),
 }
