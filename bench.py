@@ -2,7 +2,7 @@
 """
 bench.py -- grid-cells x timesteps / second of fit() on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c4_wide|c3|c2|c5|fwd2048|coal_breakpoints|c1_hyper|coal_hyper1000] [--no-extra] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c4_evidence|c4_both_axes|c4_rows1024|c4_wide|c4_laplace|c3|c2|c5|fwd2048|coal_breakpoints|c1_hyper|coal_hyper1000] [--no-extra] [--no-cpu]
 
 A "step" is one complete pass of the hot path over one batch of synthetic input: one whole ``fit()`` of the workload.
 
@@ -27,6 +27,8 @@ Workloads (synthetic data, seeds fixed):
            kernels of the 1024-row geometry (one copy of the strip in LDS, rings of up to 44 entries)
   c4_wide  HyperStudy, 512 x 512 grid, 256 widths cint(0, 0.6) on 'mean' (axis-0 radii up to 77), T = 128, full fit: the same ring
            lengths on the headline's geometry
+  c4_laplace  HyperStudy, 512 x 512 grid, Laplace model, 128 widths cint(0, 0.3) on 'mu', T = 128, full fit: chain-resident kernels with the
+           likelihood out of the (T, G) table
 
 Inputs are KBs (the series, the marginal grids) and are uploaded inside fit(); all grid-sized state is created and
 stays in HBM.  The posterior sequence is left on the device (lazy D2H on first access, not part of the timed region).
@@ -108,6 +110,15 @@ def make_study(bl, name, comm=None, scale=1.0):
         S.communicator = comm
         return S, dict(silent=True), n * n * T * nh, dict(
             workload='HyperStudy 512x512 grid x 256 sigma values cint(0, 0.6) (radii up to 77), T=128, full fit', grid=[n, n], T=T, n_hyper=nh, mode='full')
+    if name == 'c4_laplace':        # a hyper-study on the C4 grid with an observation model other than the Gaussian: the likelihood out of a table
+        n, T, nh = 512, 128, 128
+        S = bl.HyperStudy(silent=True)
+        S.loadData(series(4, T), silent=True)
+        S.set(bl.om.Laplace('mu', bl.cint(-8, 8, n), 'b', bl.oint(0, 4, n)),
+              bl.tm.GaussianRandomWalk('sigma', bl.cint(0, 0.3, nh), target='mu'), silent=True)
+        S.communicator = comm
+        return S, dict(silent=True), n * n * T * nh, dict(
+            workload='HyperStudy 512x512 grid, Laplace observation model, 128 sigma values cint(0, 0.3), T=128, full fit', grid=[n, n], T=T, n_hyper=nh, mode='full')
     if name == 'tiny':        # not a benchmark: the CPU test of this file's launcher / exchange / JSON logic (tests/test_bench_contract.py)
         n, T, nh = 24, 10, 6
         S = bl.HyperStudy(silent=True)
@@ -659,7 +670,7 @@ def main():
     if rank == 0:
         if not args.no_extra and world == 1:
             extra = {}
-            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024', 'c4_wide', 'coal_breakpoints', 'c1_hyper', 'coal_hyper1000'):
+            for name in ('c4_evidence', 'fwd2048', 'c3', 'c2', 'c5', 'c4_both_axes', 'c4_rows1024', 'c4_wide', 'c4_laplace', 'coal_breakpoints', 'c1_hyper', 'coal_hyper1000'):
                 if name == args.workload:
                     continue
                 try:

@@ -664,7 +664,7 @@ def test_accumulator_row_stats_give_the_merged_means():
     eng.accum_end()
 
 
-@pytest.mark.parametrize('name', ['fwd2048', 'c3', 'c4', 'c5', 'c4_both_axes', 'c4_rows1024', 'c4_wide'])
+@pytest.mark.parametrize('name', ['fwd2048', 'c3', 'c4', 'c5', 'c4_both_axes', 'c4_rows1024', 'c4_wide', 'c4_laplace'])
 def test_bench_workloads_against_full_size_reference(name):
     """The workloads bench.py times, at FULL size, evidence-only, against the reference run at the same size
     (tests/golden/bench_*.npz from tests/golden/gen_bench_golden.py): logEvidence, forward localEvidence, per-point
@@ -1260,7 +1260,7 @@ def test_the_references_published_break_point_study_at_full_size():
     assert np.all(np.abs(np.asarray(S.posteriorMeanValues) - gold['posteriorMeanValues']) <= 3.0 * w * 6.0)        # (grid values 0 .. 6)
 
 
-@pytest.mark.parametrize('name', ['c3', 'c4', 'c5', 'c4_both_axes', 'c4_rows1024', 'c4_wide'])
+@pytest.mark.parametrize('name', ['c3', 'c4', 'c5', 'c4_both_axes', 'c4_rows1024', 'c4_wide', 'c4_laplace'])
 def test_bench_workloads_full_fit_against_full_size_reference(name):
     """C3 (T = 2000, 16 GiB posterior), C4 (512 chains, T = 256) and C5 (250 change-points, T = 1000) as FULL forward-backward fits against the reference's own
     full-size results (tests/golden/bench_<name>_full.npz): log-evidence, local evidence, posterior means, both marginals of the
