@@ -511,11 +511,26 @@ struct ResidentPlan {
     size_t lds_bytes = 0;
 };
 
-template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE, bool PAD = false>
+template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE, bool PAD = false, bool TAB = false>
 void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
-    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, MODE, PAD>::LDS_DOUBLES * sizeof(double);
-    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD>));
-    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>::LDS_DOUBLES * sizeof(double);
+    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>));
+    hipLaunchKernelGGL((blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
+}
+
+// tabulated likelihood (blr::Res TAB; the one-chunk shapes): backward, evidence-only forward, every other forward pass (flags at run time)
+template <int TR, int TC, int SEG, int CHK>
+void launch_resident_tab(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad) {
+    const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
+    if (pad) {
+        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0, true, true>(s, Q);
+        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1, true, true>(s, Q);
+        else launch_resident_k<TR, TC, SEG, CHK, false, 0, true, true>(s, Q);
+    } else {
+        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0, false, true>(s, Q);
+        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1, false, true>(s, Q);
+        else launch_resident_k<TR, TC, SEG, CHK, false, 0, false, true>(s, Q);
+    }
 }
 
 template <int TR, int TC, int SEG, int CHK>
@@ -547,6 +562,14 @@ void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pa
 // of 8, ~200 registers, 2 waves per SIMD) and -- option resident_threads128 = 1024, forward passes of evidence-only fits only -- 1024
 // threads (segments of 16, the whole window in registers before the barrier, 128 registers, 4 waves per SIMD)
 void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
+    if (Q.lik) {
+        if (rp.TR == 64) launch_resident_tab<64, 64, 8, 8>(s, Q, bwd, rp.pad);
+        else if (rp.TR == 32 && rp.TC == 64) launch_resident_tab<32, 64, 8, 8>(s, Q, bwd, rp.pad);
+        else if (rp.TR == 32) launch_resident_tab<32, 32, 8, 8>(s, Q, bwd, rp.pad);
+        else fail("internal: time-resident launch with a likelihood table on a %d x %d tile", rp.TR, rp.TC);
+        HIPCHECK(hipGetLastError());
+        return;
+    }
     if (rp.TR == 128 && rp.SEG == 16) {
         if (bwd || Q.store || Q.means || Q.normalise || Q.post) fail("internal: the 1024-thread resident shape runs evidence-only forward passes only");
         launch_resident_k<128, 128, 16, 4, false, 1>(s, Q);

@@ -73,7 +73,10 @@ struct ResidentRun {
         const bool full = E.ff.full;
         double w0[blr::R + 1] = {1.0}, w1[blr::R + 1] = {1.0};
         // (a caller-supplied backward message: the predicted posterior sums assume the uniform one)
-        if (fast && n_chains == 1 && E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && !E.ff.resume && !E.ff.carry && !E.p->backward_init && E.d <= blr::DMAX &&
+        // (the likelihood: the Gaussian recurrence, or -- every other model -- the (T, G) table: blr::Res TAB, tiles of up to 64 x 64)
+        const bool gauss = E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && E.d <= blr::DMAX;
+        const bool tab = E.p->obs_model == BLHIP_OM_TABLE && E.DT->lik != nullptr && ctx->option("resident_table", 1.0) != 0.0;
+        if (fast && n_chains == 1 && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
             prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
             plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
                           (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0, (int)ctx->option("resident_min_tile", 32.0))) {
@@ -81,6 +84,7 @@ struct ResidentRun {
             // (the padded 128 x 128 BACKWARD kernel spills 231 registers: 2000 x 1100, backward step 40 - 45 us against 26.8 us with one
             //  launch per step -- full fits of such grids keep the launch-per-step kernels, evidence-only / forward-only fits do not)
             if (rp.pad && rp.TR == 128 && full) on = false;
+            if (tab && rp.TR == 128) on = false;
             const int k0 = T > 1 ? prog.tapF0[1] : -1, k1 = T > 1 ? prog.tapF1[1] : -1;
             for (int64_t t = 1; t < T && on; ++t)
                 on = prog.kindF[t] == SRC_PREV && prog.tapF0[t] == k0 && prog.tapF1[t] == k1;
@@ -114,7 +118,8 @@ struct ResidentRun {
         HIPCHECK(hipMemcpyAsync(d_w, hw, sizeof hw, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
         RQ.w0 = d_w; RQ.w1 = d_w + blr::R + 1;
-        RQ.n0 = E.g.n0; RQ.n1 = E.g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = E.d; RQ.rec_len = E.rec_len;
+        RQ.n0 = E.g.n0; RQ.n1 = E.g.n1; RQ.tr = rp.tr; RQ.tc = rp.tc; RQ.ntiles = rp.ntiles; RQ.T = (int)T; RQ.d = tab ? 0 : E.d; RQ.rec_len = E.rec_len;
+        RQ.lik = tab ? E.DT->lik : nullptr;
         RQ.lag = std::max(1, std::min(blr::MAXLAG, (int)ctx->option("resident_lag", 2.0)));
         RQ.m0 = E.DT->m0; RQ.m1 = E.DT->m1; RQ.colA = E.DT->colA; RQ.colB = E.DT->colB; RQ.rec = E.DT->rec; RQ.step0 = E.step0;
         RQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);      // wall_clock64: 100 MHz

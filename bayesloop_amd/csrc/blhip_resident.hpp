@@ -84,6 +84,8 @@ struct ResParams {
     unsigned *abort_word;
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
     unsigned long long *prof;           // development builds (-DBLR_PROF): [16 steps][16 stamps] shader-clock stamps of one tile
+    // (last: the fields above keep their offsets)
+    const double *lik;                  // TAB kernels: the likelihood of every step, [T][n0 * n1] (observation models other than the Gaussian)
 };
 
 // ---- memory primitives: agent-scope (sc1) accesses on the device, plain ones in the emulation -------------------------------
@@ -340,10 +342,14 @@ BLR_INL int launder(int x) {
     return x;
 }
 
-template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, int MODE_ = 0, bool PAD_ = false>
+template <int TR_, int TC_, int SEG_, int CHK_, bool BWD_, int MODE_ = 0, bool PAD_ = false, bool TAB_ = false>
 struct Res {
     static constexpr int TR = TR_, TC = TC_, SEG = SEG_, CHK = CHK_;    // CHK: outputs per chunk of a pass
     static constexpr bool BWD = BWD_;
+    // TAB: the likelihood of a cell comes out of the (T, G) table (every observation model but the Gaussian: Laplace, AR1, ScaledAR1, a
+    // caller's pdf) instead of the recurrence along the column -- 8 more bytes read per cell and step; one-chunk shapes only
+    static constexpr bool TAB = TAB_;
+    static_assert(!TAB || SEG_ == CHK_, "tabulated likelihood: the one-chunk tile shapes");
     // PAD: the grid does not fill its last tile row / column (n0 < tr * TR or n1 < tc * TC; at least R cells of padding where there is
     // any).  The kernel works on the tiles' geometry: cells outside the grid are kept at ZERO and out of every sum and store, except the
     // R rows / columns next to the grid's true edge, which hold the MIRROR image of the cells inside (rewritten after every step:
@@ -722,14 +728,21 @@ struct Res {
         // x0 / m0p / pt0 point at position 0 of the segment in the LDS tile / the tile's row coordinates / the global row
         template <int DIR>
         BLR_INL void epilogue8(const ResParams &Q, double *x0, const double *m0p, double *pt0, double *ptn0, double invn, int p0,
-                               const double (&v)[CHK], double scale, Rec &rc, const ColC &cc, int r0 = 0, bool colok = true) {
+                               const double (&v)[CHK], double scale, Rec &rc, const ColC &cc, int r0 = 0, bool colok = true,
+                               const double *lt0 = nullptr) {
             const double g1 = cc.g1, cA = cc.cA, cB = cc.cB;
+            double lk8[TAB ? CHK : 1];           // (TAB) the table's values of the chunk's cells; lt0 = position 0 of the segment in the step's table
+            if constexpr (TAB) {
+#pragma unroll
+                for (int j = 0; j < CHK; ++j)
+                    lk8[j] = (!PAD || (colok && r0 + DIR * (p0 + j) < rlim)) ? lt0[(long long)(DIR * (p0 + j)) * Q.n1] : 0.0;
+            }
             if (!BWD && ptn0) {
 #pragma unroll
                 for (int j = 0; j < CHK; ++j)
                     if (!PAD || (colok && r0 + DIR * (p0 + j) < rlim)) ptn0[(long long)(DIR * (p0 + j)) * Q.n1] = nz8[j] * invn;
             }
-            if (p0 % ANCHOR == 0) {
+            if (!TAB && p0 % ANCHOR == 0) {
                 // arg(r) = sum_q [-(x_q - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50), along the
                 // walking direction: arg(1) - arg(0) = cA (mu_1 - mu_0) sum_q (2 x_q - mu_0 - mu_1); second difference = -2 cA dn step^2
                 const double mu0 = m0p[DIR * p0], mu1 = m0p[DIR * (p0 + 1)];
@@ -764,7 +777,7 @@ struct Res {
 #pragma unroll
             for (int j = 0; j < CHK; ++j) {
                 const int p = p0 + j;
-                const double Lv = ldexp_(rc.mE, rc.nE);
+                const double Lv = TAB ? (BWD ? lk8[TAB ? j : 0] : lk8[TAB ? j : 0] * scale) : ldexp_(rc.mE, rc.nE);
                 const bool in = !PAD || (colok && r0 + DIR * p < rlim);          // (cells outside the grid stay zero, out of sums and stores)
                 double keep;                                         // what becomes the tile's new state
                 if (!BWD) {
@@ -778,17 +791,23 @@ struct Res {
                     const double pp = al8[j] * beta;
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
-                    const double pl = !in ? 0.0 : (Lv == 0.0 ? nan_() : ldexp_(pp * rc.iE, -rc.nE));
+                    const double pl = !in ? 0.0 : (TAB ? pp / Lv : (Lv == 0.0 ? nan_() : ldexp_(pp * rc.iE, -rc.nE)));      // (0 / 0 -> NaN either way)
                     keep = cn;
                     if (in) st_stream(pt0 + (long long)(DIR * p) * Q.n1, pp * invn);   // (invn = 1 / predicted sum: stored normalised)
                     sums[0] += pp; sums[1] += pl; sums[2] += cn;
                     sums[3] = fma(pp, m0p[DIR * p], sums[3]); sums[4] = fma(pp, g1, sums[4]);
                 }
                 x0[DIR * p * P] = keep;
-                rc.mE *= rc.mR; rc.nE += rc.nR;
-                rc.mR *= rc.mq; rc.nR += rc.nq;
-                if (BWD) { rc.iE *= rc.iR; rc.iR *= rc.iq; }
+                if constexpr (!TAB) {
+                    rc.mE *= rc.mR; rc.nE += rc.nR;
+                    rc.mR *= rc.mq; rc.nR += rc.nq;
+                    if (BWD) { rc.iE *= rc.iR; rc.iR *= rc.iq; }
+                }
             }
+        }
+        // (TAB) position 0 of the thread's segment in the table of step k
+        BLR_INL const double *lik_ptr(const ResParams &Q, int k, int r0, int c) const {
+            return TAB ? Q.lik + (long long)time_of(Q, k) * Q.n0 * Q.n1 + (long long)(i0 + r0) * Q.n1 + (j0 + c) : nullptr;
         }
 
         template <int DIR>
@@ -803,6 +822,7 @@ struct Res {
             const double *m0p = lds + LDS_M0 + r0;
             double *pt0 = row_ptr(Q, k, r0, c);
             double *ptn0 = lagged_row_ptr(Q, k, pt0);
+            const double *lt0 = lik_ptr(Q, k, r0, c);
             predicted_sum(Q, k, scale);
             const double invn = BWD ? 1.0 / npred : (ptn0 ? lagged_inverse(Q, k, 0) : 1.0);
             // the neighbour's axis-1-filtered edge rows of THIS step (tag k + 1): element [k & 1][nb][side][rr][col]
@@ -834,7 +854,7 @@ struct Res {
 #pragma unroll
                     for (int j = 0; j < CHK; ++j) x0[DIR * (p0 + j) * P] = v[j];
                 } else {
-                    epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim);
+                    epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim, lt0);
                 }
             };
             double wk[R + 1];
@@ -848,7 +868,7 @@ struct Res {
                     double v[CHK];
 #pragma unroll
                     for (int j = 0; j < CHK; ++j) { v[j] = x0[DIR * (p0 + j) * P]; al8[j] = alS[p0 + j]; }
-                    epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim);
+                    epilogue8<DIR>(Q, x0, m0p, pt0, ptn0, invn, p0, v, scale, rc, cc, r0, c < clim, lt0);
                 }
             }
             if (REC_AHEAD && !REC_IN_PASS && k + 1 < Q.T) begin_step(Q, k + 1);
@@ -872,13 +892,14 @@ struct Res {
             const long long g0 = (long long)(i0 + r0) * Q.n1 + (j0 + c);
             double *pt0 = f_post(Q) ? f_post(Q) + (long long)time_of(Q, 0) * Q.n0 * Q.n1 + g0 : nullptr;
             const double *s = Q.src0 + g0;
+            const double *lt0 = TAB ? Q.lik + (long long)time_of(Q, 0) * Q.n0 * Q.n1 + g0 : nullptr;
 #pragma unroll 1
             for (int p0 = 0; p0 < SEG; p0 += CHK) {
                 double v[CHK];
 #pragma unroll
                 for (int j = 0; j < CHK; ++j) v[j] = (!PAD || (c < clim && r0 + DIR * (p0 + j) < rlim)) ? s[(long long)(DIR * (p0 + j)) * Q.n1] : 0.0;
                 load_alpha8<DIR>(pt0, nullptr, Q.n1, p0, r0, c < clim);
-                epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, BWD ? 1.0 / Q.n_first : 1.0, p0, v, 1.0, rc, cc, r0, c < clim);
+                epilogue8<DIR>(Q, x0, m0p, pt0, nullptr, BWD ? 1.0 / Q.n_first : 1.0, p0, v, 1.0, rc, cc, r0, c < clim, lt0);
             }
             if (REC_AHEAD && Q.T > 1) begin_step(Q, 1);
         }
@@ -958,9 +979,9 @@ __device__ __forceinline__ T *own_sgpr(T *p) {
 }
 // (Applied to this file's own kernel it changes nothing -- 633 -> 612 v_readlane per step loop: what spills here are lane masks of the
 //  control flow, not argument tuples; measured on the ISA, not kept.)
-template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE = 0, bool PAD = false>
+template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE = 0, bool PAD = false, bool TAB = false>
 __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Q) {
-    using K = Res<TR, TC, SEG, CHK, BWD, MODE, PAD>;
+    using K = Res<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>;
     constexpr int NT = K::NT, NW = K::NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *misc = lds + K::LDS_MISC;

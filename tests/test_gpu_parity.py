@@ -1601,6 +1601,50 @@ def test_chain_resident_kernels_with_a_tabulated_likelihood_match_oracle(case):
     assert abs(S.logEvidence - R.logEvidence) <= 1e-10 * abs(R.logEvidence)
 
 
+RESTAB = {
+    # observation models other than the Gaussian on the time-resident kernel (blr::Res TAB: likelihood out of the (T, G) table): walks on
+    # both parameters with radius <= 8 -- ScaledAR1 (the reference's showcase model) on a padded 200 x 200 grid, AR1 / Laplace on whole
+    # tiles, evidence-only and forward-only fits, a walk on one parameter only
+    'rtab_scaled_ar1_200x200_full': dict(study='Study', data=('series', 111, 12), om=_om2('ScaledAR1', ('rho', ('oint', -1, 1, 200)), ('sigma', ('oint', 0, 3, 200))),
+                                         tm=('Combined', [('GRW', 's1', 0.018, 'rho', None), ('GRW', 's2', 0.025, 'sigma', None)])),
+    'rtab_ar1_128x128_full': dict(study='Study', data=('series', 112, 10), om=_om2('AR1', ('rho', ('oint', -1, 1, 128)), ('sigma', ('oint', 0, 3, 128))),
+                                  tm=('Combined', [('GRW', 's1', 0.03, 'rho', None), ('GRW', 's2', 0.04, 'sigma', None)])),
+    'rtab_laplace_64x96_evidence': dict(study='Study', data=('series', 113, 14), om=_om2('Laplace', ('mu', ('cint', -5, 5, 64)), ('b', ('oint', 0, 3, 96))),
+                                        tm=('Combined', [('GRW', 's1', 0.3, 'mu', None), ('GRW', 's2', 0.05, 'b', None)]), fit=dict(evidenceOnly=True)),
+    'rtab_laplace_150x80_forward_only': dict(study='Study', data=('series', 114, 9), om=_om2('Laplace', ('mu', ('cint', -5, 5, 150)), ('b', ('oint', 0, 3, 80))),
+                                             tm=('Combined', [('GRW', 's1', 0.12, 'mu', None), ('GRW', 's2', 0.07, 'b', None)]), fit=dict(forwardOnly=True)),
+    'rtab_laplace_96x96_nan': dict(study='Study', data=('series_nan', 115, 11, [4, 5]), om=_om2('Laplace', ('mu', ('cint', -5, 5, 96)), ('b', ('oint', 0, 3, 96))),
+                                   tm=('Combined', [('GRW', 's1', 0.2, 'mu', None), ('GRW', 's2', 0.06, 'b', None)])),
+}
+
+
+@pytest.mark.parametrize('case', list(RESTAB))
+def test_time_resident_kernel_with_a_tabulated_likelihood_matches_oracle(case):
+    c = RESTAB[case]
+    S = cases.build(bl, c)
+    kw = cases.fit_kwargs(c)
+    S.fit(**kw)
+    assert S.lastTiming['fwd_kernel_variant'] == 5, S.lastTiming
+    if not kw.get('evidenceOnly') and not kw.get('forwardOnly'):
+        assert S.lastTiming['bwd_kernel_variant'] == 5 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues'):
+        if k in want and want[k] is not None and k in got and len(np.atleast_1d(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+    eng = bl.get_engine()
+    eng.set_option('resident_table', 0)
+    try:
+        R = cases.build(bl, c); R.fit(**kw)
+    finally:
+        eng.set_option('resident_table', 1)
+    assert R.lastTiming['fwd_kernel_variant'] != 5
+    assert abs(S.logEvidence - R.logEvidence) <= 1e-10 * abs(R.logEvidence)
+
+
 DEPAD = {
     # ordinary fits (one chain, the posterior sequence is the result) and forward-only hyper-studies on grids the chain-resident kernels
     # pad: the kernels work on a scratch sequence on the padded geometry, depad_kernel writes the grid's rows into the sequence handed out
