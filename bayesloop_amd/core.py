@@ -477,32 +477,47 @@ class Study(object):
         n = hyper_rows.shape[0]
         out = np.full((n, max(1, len(program))), np.nan)
         ts = self.formattedTimestamps if timestamps is None else timestamps
-        shift_cache = {}
+        done = set()
         for j, (kind, axis, model, k, seg, flg) in enumerate(program):
             if k is None:
                 continue
             if isinstance(k, tuple):                       # ('shift', q) of a Deterministic model
-                if id(model) not in shift_cache:
-                    cols = [i for i, sl in enumerate(slots) if sl[0] is model]
-                    # inside a serial model the sub-model counts its time from the break-/change-point that starts its segment
-                    # (reference transitionModels.py:770-776): that boundary's value of the SAME chain
-                    seg = [op[4] for op in program if op[0] == _abi.OP_DETERMINISTIC and op[2] is model][0]
-                    off_col = None
-                    if seg > 0:
-                        bounds = [op for op in program if op[0] == _abi.OP_BREAKPOINT or (op[0] == _abi.OP_CHANGEPOINT and op[5] & 1)]
-                        owner, kb = bounds[seg - 1][2], bounds[seg - 1][3]
-                        off_col = [i for i, sl in enumerate(slots) if sl[0] is owner and sl[1] == kb][0]
-                    # (chains that share the model's hyper-parameters and its time offset share the table: a change-point study over
-                    #  two break-points evaluates each (parameters, first break-point) pair once, not once per chain)
-                    names_k = [model.hyperParameterNames[slots[i][1]] for i in cols]
-                    key_cols = cols + ([] if off_col is None else [off_col])
-                    keys = hyper_rows[:, key_cols]
-                    uniq, inv = (np.unique(keys, axis=0, return_inverse=True) if key_cols
-                                 else (np.zeros((1, 0)), np.zeros(n, dtype=np.intp)))
-                    tables = np.array([model.shifts(dict(zip(names_k, u[:len(cols)])), ts, resume_time,
-                                                    t_offset=None if off_col is None else u[-1]) for u in uniq])
-                    shift_cache[id(model)] = tables[np.asarray(inv).reshape(-1)]      # (n_chains, 2 T): one gather
-                out[:, j] = shift_cache[id(model)][:, k[1]]
+                if id(model) in done:
+                    continue
+                done.add(id(model))
+                cols = [i for i, sl in enumerate(slots) if sl[0] is model]
+                # inside a serial model the sub-model counts its time from the break-/change-point that starts its segment
+                # (reference transitionModels.py:770-776): that boundary's value of the SAME chain
+                seg = [op[4] for op in program if op[0] == _abi.OP_DETERMINISTIC and op[2] is model][0]
+                off_col = None
+                if seg > 0:
+                    bounds = [op for op in program if op[0] == _abi.OP_BREAKPOINT or (op[0] == _abi.OP_CHANGEPOINT and op[5] & 1)]
+                    owner, kb = bounds[seg - 1][2], bounds[seg - 1][3]
+                    off_col = [i for i, sl in enumerate(slots) if sl[0] is owner and sl[1] == kb][0]
+                # (chains that share the model's hyper-parameters and its time offset share the table: a change-point study over
+                #  two break-points evaluates each (parameters, first break-point) pair once, not once per chain)
+                names_k = [model.hyperParameterNames[slots[i][1]] for i in cols]
+                key_cols = cols + ([] if off_col is None else [off_col])
+                if key_cols:
+                    # rows of equal keys: per-column codes (1-D unique: a sort of n scalars each) combined into one integer code per chain
+                    # -- np.unique(keys, axis=0) sorted n structured rows, a quarter of the host time of the reference's break-point study
+                    code = np.zeros(n, dtype=np.int64)
+                    for cidx in key_cols:
+                        vals, inv_c = np.unique(hyper_rows[:, cidx], return_inverse=True)
+                        code = code * len(vals) + np.asarray(inv_c).reshape(-1)
+                    _, first, inv = np.unique(code, return_index=True, return_inverse=True)
+                    uniq = hyper_rows[first][:, key_cols]
+                else:
+                    uniq, inv = np.zeros((1, 0)), np.zeros(n, dtype=np.intp)
+                tables = model.shifts_many(names_k, uniq[:, :len(cols)], ts, resume_time, t_offsets=None if off_col is None else uniq[:, -1])
+                # the model's 2 T columns in one gather + one scatter
+                js = [jj for jj, op in enumerate(program) if isinstance(op[3], tuple) and op[2] is model]
+                qs = [program[jj][3][1] for jj in js]
+                inv = np.asarray(inv).reshape(-1)
+                if js == list(range(js[0], js[0] + len(js))) and qs == list(range(tables.shape[1])):
+                    out[:, js[0]:js[0] + len(js)] = tables[inv]           # (the usual layout: the 2 T columns follow their op in order)
+                else:
+                    out[:, js] = tables[inv][:, qs]
                 continue
             col = [i for i, sl in enumerate(slots) if sl[0] is model and sl[1] == k][0]
             out[:, j] = hyper_rows[:, col]

@@ -363,6 +363,34 @@ class Deterministic(TransitionModel):
         bwd = np.concatenate((v[2 + 2 * n:2 + 3 * n] - v[2 + 3 * n:2 + 4 * n], [0.0]))
         return np.concatenate((fwd, bwd))
 
+    def shifts_many(self, names, rows, timestamps, resume_time=-1.0, t_offsets=None):
+        """``shifts`` for many parameter sets at once: ``rows`` (U, len(names)) hyper-parameter values, ``t_offsets`` (U,) or None ->
+        (U, 2 T).  One broadcast call of the user's function where it takes arrays in every argument (checked against the per-set
+        evaluation on the first and the last row: a function that does not broadcast falls back to one call per set)."""
+        rows = np.asarray(rows, dtype=float).reshape(len(rows), len(names))
+        U = rows.shape[0]
+        one = lambda u: self.shifts(dict(zip(names, rows[u])), timestamps, resume_time, t_offset=None if t_offsets is None else t_offsets[u])
+        if U <= 2:
+            return np.array([one(u) for u in range(U)])
+        ts = np.asarray(timestamps, dtype=float)
+        T = len(ts)
+        n = T - 1
+        off = np.full((U, 1), float(self.tOffset)) if t_offsets is None else np.asarray(t_offsets, dtype=float).reshape(U, 1)
+        at = np.concatenate(([resume_time + 1, resume_time], ts[:-1] + 1, ts[:-1], ts[1:] - 1, ts[1:]))[None, :] - off
+        try:
+            with np.errstate(all='ignore'):
+                v = np.asarray(self.function(at, **{nm: rows[:, [i]] for i, nm in enumerate(names)}), dtype=float)
+            if v.shape != at.shape:
+                raise ValueError
+            out = np.concatenate((v[:, [0]] - v[:, [1]], v[:, 2:2 + n] - v[:, 2 + n:2 + 2 * n],
+                                  v[:, 2 + 2 * n:2 + 3 * n] - v[:, 2 + 3 * n:2 + 4 * n], np.zeros((U, 1))), axis=1)
+            for u in (0, U - 1):
+                if not np.array_equal(out[u], one(u), equal_nan=True):
+                    raise ValueError
+            return out
+        except Exception:                        # noqa: BLE001 -- a function that does not broadcast over its parameters
+            return np.array([one(u) for u in range(U)])
+
 
 class AlphaStableRandomWalk(TransitionModel):
     """Heavy-tailed fluctuations of one parameter: convolution with a symmetric alpha-stable density of scale c and tail
