@@ -420,3 +420,32 @@ def test_three_parameter_models_host_logic():
     B = cases.build(bl, bad)
     with pytest.raises(bl.exceptions.ConfigurationError):
         B.fit(silent=True)
+
+
+def test_deterministic_shifts_of_many_parameter_sets_equal_the_per_set_evaluation():
+    """Deterministic.shifts_many (one broadcast call of the user's function over parameter sets x time stamps: what a hyper-study over
+    break-points evaluates per unique (parameters, offset) pair) returns exactly what shifts() returns per set -- for a function that
+    broadcasts, and, through the fall-back, for one written for scalars only (reference transitionModels.py:573-577, :592-596, :770-776)."""
+    import numpy as np
+    import bayesloop_amd as bl
+    rng = np.random.default_rng(5)
+    ts = np.arange(1851., 1892.)
+
+    def linear(t, slope=0.0):
+        return slope * t
+
+    def scalar_only(t, slope=0.0, level=0.0):
+        if np.ndim(t) != 0 or np.ndim(slope) != 0:          # (a function that refuses arrays)
+            raise TypeError('scalars only')
+        return level + slope * max(t, 0.0)
+
+    for fn, names in ((linear, ['slope']), (scalar_only, ['slope', 'level'])):
+        m = bl.tm.Deterministic(fn, target='rate')
+        rows = rng.uniform(-2, 2, size=(7, len(names)))
+        offs = rng.integers(1855, 1880, 7).astype(float)
+        for t_offsets in (None, offs):
+            many = m.shifts_many(names, rows, ts, -1.0, t_offsets=t_offsets)
+            assert many.shape == (7, 2 * len(ts))
+            for u in range(7):
+                one = m.shifts(dict(zip(names, rows[u])), ts, -1.0, t_offset=None if t_offsets is None else t_offsets[u])
+                assert np.array_equal(many[u], one, equal_nan=True)
