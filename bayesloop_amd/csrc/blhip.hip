@@ -1306,7 +1306,9 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
             const int nblk_f = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ;
             const bool p1d_ok = ctx->option("persist1d", 1.0) != 0.0 && (long long)nblk_f * B <= cus && T > gp.fusedK;
             const double est_other = p1d_ok ? 1.7 + 0.04 * lw : 1.5 + (double)B * n * (29.0 + 0.63 * lw) * 1e-6;
-            gp.chain1d = c1d_mode == 2.0 || (B >= 2 && (shift1d || est_c1d < est_other));     // (shift1d: the alternative is a launch per step)
+            // (shift1d: the alternative is a launch per step.  A single chain takes the kernel too when the model says so -- rows of a few
+            //  hundred cells with a narrow stencil: 200 cells, radius 27: 2.4 against 2.8 us per step)
+            gp.chain1d = c1d_mode == 2.0 || (B >= 2 && shift1d) || (!shift1d && est_c1d < est_other);
             if (gp.chain1d) { gp.fusedK = 1; gp.f1_TJ = g.n1; }
         }
         if (shift1d && !gp.chain1d) gp.fused1d = false;
