@@ -263,6 +263,16 @@ def golden_log_evidence(name):
     return None
 
 
+def registered_bound(name):
+    """The bound the parity gate holds `log_evidence_rel_err` (the user-visible S.logEvidence) of a workload to: 1e-9, or the bound
+    tests/tolerances.py registers for it with its reason (one entry: the published break-point study, COAL_NOISE_CHAINS)."""
+    try:
+        import tolerances
+        return float(getattr(tolerances, 'BENCH_LOG_EVIDENCE_BOUND', {}).get(name, 1e-9))
+    except Exception:
+        return 1e-9
+
+
 def rel_err(got, want):
     if want is None:
         return None
@@ -471,6 +481,125 @@ def cpu_baseline(nh=8, T=160, n=512, max_procs=16):
             out['all_cores'] = dict(error=repr(e))
     return out
 
+
+LINE_LIMIT = 8192          # the driver parses the LAST stdout line; round 4's 35 KB line was not parsed: the line is kept under this
+
+
+def _sig(x, n=6):
+    """Numbers of the compact line at n significant digits (the full-precision record is bench_detail.json)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if not np.isfinite(x):
+            return None
+        return float('%.*g' % (n, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _kernel_brief(rf):
+    """{'fwd_us', 'bwd_us', 'frac_hbm_real', 'frac_streaming_equiv', 'frac_fp64'} of the slower pass (per-pass detail: bench_detail.json)."""
+    out = {}
+    for key, short in (('forward', 'fwd'), ('backward', 'bwd')):
+        if key in (rf or {}):
+            out[short + '_us'] = rf[key]['avg_launch_us']
+    if rf:
+        dom = max(rf.values(), key=lambda r: r['avg_launch_us'] * r['launches'])
+        out.update(frac_hbm_real=dom['hbm']['frac_spec'], frac_streaming_equiv=dom['streaming_equiv']['frac_spec'], frac_fp64=dom['fp64']['frac'])
+    return out
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract fields, `roofline` and `cpu_baseline` in full meaning but short form, one small record per
+    extra workload.  Everything else (per-pass kernel records, configs of the extras, the exchange diagnostic's detail) is in
+    bench_detail.json.  Always < LINE_LIMIT characters (asserted; tests/test_bench_contract.py)."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'config', 'log_evidence', 'log_evidence_reference', 'log_evidence_rel_err', 'resident_fallbacks', 'device')
+    line = {k: out[k] for k in keep if k in out}
+    line['device'] = str(line.get('device', ''))[:48]
+    r = out.get('roofline')
+    if r:
+        line['roofline'] = {k: r.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_hbm_real', 'frac_fp64',
+                                                   'frac_streaming_equiv', 'peak_calibrated', 'frac_calibrated', 'bytes_per_cell_step',
+                                                   'avg_launch_us', 'cells_per_launch')}
+        kname = str(r.get('kernel', ''))
+        line['roofline']['kernel'] = kname.split(' (')[0].replace('<forward>', '').replace('<backward>', '') + ('<backward>' if '<backward>' in kname else '<forward>')
+        line['roofline']['traffic_from'] = 'pmc in this run' if 'inside this bench run' in str(r.get('traffic_from')) else (
+            'committed pmc pass' if r.get('traffic') is not None else None)
+    else:
+        line['roofline'] = None
+    line['kernels'] = _kernel_brief(out.get('kernels'))
+    c = out.get('cpu_baseline')
+    if c:
+        line['cpu_baseline'] = {k: c.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+        if isinstance(c.get('one_core'), dict):
+            line['cpu_baseline']['one_core_value'] = c['one_core'].get('value')
+    e = out.get('end_to_end')
+    if e:
+        line['end_to_end'] = {k: e.get(k) for k in ('ms', 'cold_ms', 'value', 'd2h_bytes', 'error') if e.get(k) is not None}
+    if 'exchange' in out:
+        x = out['exchange']
+        line['exchange'] = {k: (v if not isinstance(v, dict) else {kk: v.get(kk) for kk in ('wall_ms_max_over_ranks', 'device_ms_rank0', 'bytes', 'error')
+                                                                   if v.get(kk) is not None}) for k, v in x.items()}
+    if 'per_rank' in out:
+        line['per_rank'] = {k: v for k, v in out['per_rank'].items() if k != 'note'}
+    if 'extra' in out:
+        ex = {}
+        for name, v in out['extra'].items():
+            if 'error' in v:
+                ex[name] = dict(error=str(v['error'])[:120])
+                continue
+            b = dict(value=v['value'], ms_per_step=v['ms_per_step'], log_evidence_rel_err=v.get('log_evidence_rel_err'),
+                     resident_fallbacks=v.get('resident_fallbacks'))
+            b.update(_kernel_brief(v.get('kernels')))
+            for k in ('log_evidence_rel_err_per_chain', 'log_evidence_rel_err_bound', 'speedup_vs_reference_wall', 'host_ms', 'kernel_ms'):
+                if v.get(k) is not None:
+                    b[k] = v[k]
+            if isinstance(v.get('end_to_end'), dict) and 'value' in v['end_to_end']:
+                b['end_to_end_value'] = v['end_to_end']['value']
+            ex[name] = b
+        line['extra'] = ex
+    line['detail'] = 'bench_detail.json'
+    line = _sig(line)
+    # full-precision where the driver or the parity gate reads it
+    for k in ('value', 'ms_per_step', 'log_evidence', 'log_evidence_reference', 'log_evidence_rel_err'):
+        if k in out:
+            line[k] = out[k]
+    text = json.dumps(line, separators=(',', ':'))
+    if len(text) >= LINE_LIMIT:                # never lose the headline: drop the side records, largest first
+        for k in ('extra', 'exchange', 'end_to_end', 'kernels'):
+            if k in line:
+                line[k] = 'see ' + line['detail']
+                text = json.dumps(line, separators=(',', ':'))
+                if len(text) < LINE_LIMIT:
+                    break
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(out):
+    """The full record: bench_detail.json beside this file (and under gpurun_out/ when that directory exists, so a gpurun call brings it
+    back)."""
+    text = json.dumps(out, indent=1)
+    where = []
+    for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, 'bench_detail.json'), 'w') as f:
+                    f.write(text + '\n')
+                where.append(os.path.join(d, 'bench_detail.json'))
+            except OSError:
+                pass
+    # (stderr carries one short note only: the driver stores a bounded tail of stdout + stderr, and a 35 KB record there could push
+    #  the line out of it)
+    try:
+        sys.stderr.write('bench.py: full record in %s\n' % (', '.join(os.path.relpath(w, ROOT) for w in where) or 'nowhere (read-only tree)'))
+        sys.stderr.flush()
+    except Exception:
+        pass
 
 
 def self_launch(args):
@@ -703,9 +832,11 @@ def main():
                         # rounding noise: tests/tolerances.py COAL_NOISE_CHAINS)
                         gl, rl = gf['logEvidenceList'], np.asarray(S2.logEvidenceList, dtype=float)
                         both = np.isfinite(gl) & np.isfinite(rl)
-                        extra[name]['log_evidence_average_model_rel_err'] = extra[name]['log_evidence_rel_err']
-                        extra[name]['log_evidence_rel_err'] = float(np.max(np.abs(rl[both] - gl[both]) / np.abs(gl[both])))
-                        extra[name]['log_evidence_rel_err_is'] = 'max over the %d chains that run through on both sides' % int(both.sum())
+                        # `log_evidence_rel_err` stays the user-visible figure (S.logEvidence of the average model) for every workload;
+                        # the per-chain maximum has a name of its own
+                        extra[name]['log_evidence_rel_err_per_chain'] = float(np.max(np.abs(rl[both] - gl[both]) / np.abs(gl[both])))
+                        extra[name]['log_evidence_rel_err_per_chain_is'] = 'max over the %d chains that run through on both sides' % int(both.sum())
+                        extra[name]['log_evidence_rel_err_bound'] = registered_bound(name)
                         extra[name]['chains_stopped'] = dict(reference=int((~np.isfinite(gl)).sum()), here=int((~np.isfinite(rl)).sum()),
                                                              note='registered exception COAL_NOISE_CHAINS')
                     S2._posterior_pending = None
@@ -734,9 +865,12 @@ def main():
     drain_c_stdio()
     if rank == 0:
         bad = [k for k, v in [(args.workload, out)] + list(out.get('extra', {}).items())
-               if isinstance(v, dict) and v.get('log_evidence_rel_err') is not None and v['log_evidence_rel_err'] > 1e-9]
+               if isinstance(v, dict) and v.get('log_evidence_rel_err') is not None and v['log_evidence_rel_err'] > registered_bound(k)]
+        bad += [k + ' (per chain)' for k, v in out.get('extra', {}).items()
+                if isinstance(v, dict) and v.get('log_evidence_rel_err_per_chain') is not None and v['log_evidence_rel_err_per_chain'] > 1e-9]
+        write_detail(out)
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)       # the ONE JSON line, last on stdout
+        print(compact_line(out), flush=True)     # the ONE JSON line, last on stdout, < LINE_LIMIT characters
         if bad:
             sys.exit('bench.py: log-evidence differs from the reference by more than 1e-9 relative: %s' % bad)
     if wedged:                                   # a helper thread sits in a collective that will never return: leave without joining it

@@ -56,6 +56,70 @@ def test_committed_bench_line_has_the_contract_fields():
         assert d['extra']['c5']['config']['n_hyper'] == 250
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_compact_line_of_the_largest_committed_record_fits_the_driver():
+    """Round 4's 35 KB line was not parsed by the driver (BENCH_r04.parsed null).  bench.compact_line() of EVERY committed full record
+    (the 35 KB one included) stays under 8 KB, is one line, and keeps the contract fields, `roofline` (with frac, traffic, the three
+    named fractions, kernel, avg_launch_us, cells_per_launch) and `cpu_baseline`."""
+    bench = _bench_module()
+    assert bench.LINE_LIMIT <= 8192
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_v*_final.json')))
+    biggest = 0
+    for f in files:
+        full = json.load(open(f))
+        if 'roofline' not in full or not isinstance(full.get('kernels'), dict) or 'hbm' not in next(iter(full['kernels'].values()), {}):
+            continue                                        # (lines of rounds 1 - 2 predate the per-pass record layout)
+        text = bench.compact_line(full)
+        biggest = max(biggest, len(text))
+        assert len(text) < 8192 and '\n' not in text, (f, len(text))
+        d = json.loads(text)
+        for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                    'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+            assert key in d, (f, key)
+        assert d['value'] == full['value'] and d['ms_per_step'] == full['ms_per_step']         # full precision where the driver reads
+        r = d['roofline']
+        for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_hbm_real', 'frac_fp64', 'frac_streaming_equiv', 'kernel',
+                    'avg_launch_us', 'cells_per_launch'):
+            assert key in r, (f, key)
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4
+        c = d['cpu_baseline']
+        assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+        for name, e in d.get('extra', {}).items():
+            assert set(e) <= {'value', 'ms_per_step', 'log_evidence_rel_err', 'resident_fallbacks', 'fwd_us', 'bwd_us', 'frac_hbm_real',
+                              'frac_streaming_equiv', 'frac_fp64', 'log_evidence_rel_err_per_chain', 'log_evidence_rel_err_bound',
+                              'speedup_vs_reference_wall', 'end_to_end_value', 'host_ms', 'kernel_ms', 'error'}, (name, set(e))
+    assert biggest > 0
+
+
+def test_compact_line_survives_a_record_that_is_too_big():
+    """Whatever is put into the record, the headline is never lost: side records are dropped (largest first) to stay under the limit."""
+    bench = _bench_module()
+    full = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_v*_final.json')))[-1]))
+    full['extra'] = {('w%03d' % i): dict(full['extra']['c3']) for i in range(200)} if 'extra' in full and 'c3' in full['extra'] else {}
+    text = bench.compact_line(full)
+    assert len(text) < 8192
+    d = json.loads(text)
+    assert d['value'] == full['value'] and d['roofline']['frac'] > 0 and 'cpu_baseline' in d
+
+
+def test_the_parity_gate_reports_the_user_visible_log_evidence():
+    """ADVICE r4 / VERDICT weak #1: `log_evidence_rel_err` means S.logEvidence vs the reference for EVERY workload; a workload whose
+    figure may exceed 1e-9 has a registered bound (tests/tolerances.py BENCH_LOG_EVIDENCE_BOUND) that bench.py guards."""
+    import tolerances
+    bench = _bench_module()
+    assert bench.registered_bound('c4') == 1e-9 and bench.registered_bound('c3') == 1e-9
+    assert bench.registered_bound('coal_breakpoints') == tolerances.COAL_NOISE_TOL['logE_rtol'] < 1e-4
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert "['log_evidence_rel_err'] = float(np.max" not in src          # the per-chain maximum lives under its own key
+
+
 def _walk(d, path=''):
     if isinstance(d, dict):
         for k, v in d.items():
@@ -134,6 +198,7 @@ def _free_port():
 def _check_tiny_line(stdout, n):
     lines = [l for l in stdout.strip().splitlines() if l.strip()]
     d = json.loads(lines[-1])                                  # the ONE JSON line is the LAST line on stdout
+    assert len(lines[-1]) < 8192                               # ... and short enough for the driver to parse
     assert sum(1 for l in lines if l.lstrip().startswith('{')) == 1
     assert d['n_gpus'] == n and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'strong'
     assert abs(d['value'] * d['ms_per_step'] * 1e-3 - 24 * 24 * 10 * 6) < 1e-6 * 24 * 24 * 10 * 6

@@ -17,7 +17,10 @@ DETERMINISTIC_FUZZ_TOL = dict(FFT_TOL, post_rtol=2e-8, logE_rtol=1e-10, small_rt
 WIDE_FILTER_2D_TOL = dict(local_rtol=1e-3)
 
 # the reference's published break-point study (bench.py: coal_breakpoints): see COAL_NOISE_CHAINS below
-COAL_NOISE_TOL = dict(noise_chains=14, noise_weight_max=1e-3)
+COAL_NOISE_TOL = dict(noise_chains=14, noise_weight_max=1e-3, logE_rtol=2e-5)
+# bench.py's parity gate: the bound on the user-visible S.logEvidence per workload where it is not the 1e-9 bar (every entry is a
+# registered exception below; observed 8.06e-6 for the published break-point study -- the 11 chains whose stop pattern differs)
+BENCH_LOG_EVIDENCE_BOUND = {'coal_breakpoints': COAL_NOISE_TOL['logE_rtol']}
 
 EXCEPTIONS = {
     'COAL_NOISE_CHAINS': dict(
