@@ -348,7 +348,10 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
                 # mis-ordered a slice cannot pass; costs one pass over the accumulator on the root.
                 merged = engine.accum_row_stats(problem)
                 want = np.asarray(gstats)
-                bad = ~(np.abs(merged - want) <= 1e-9 * np.abs(want) + 1e-300)
+                # column 0 (sum A > 0) relatively; the mean columns (sum A grid_k) against the scale sum A x max|grid_k|: on a grid
+                # symmetric about 0 they cancel to rounding noise, which two summation orders do not reproduce relatively
+                gmax = np.array([1.0] + [max(float(np.max(np.abs(m))), 1e-300) for m in problem.marginal])
+                bad = ~(np.abs(merged - want) <= 1e-9 * np.abs(want[:, :1]) * gmax[None, :] + 1e-300)
                 if np.any(bad):
                     from .engine import BackendError
                     t_bad = int(np.argmax(np.any(bad, axis=1)))

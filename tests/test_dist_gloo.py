@@ -386,3 +386,52 @@ def test_a_broken_accumulator_merge_is_caught_and_the_fit_repeated_on_one_device
     engines = [Lossy() for _ in range(2)]
     _fit_over_fake_devices('kat_hyper_1hp', engines)
     assert engines[1].fits == 0
+
+
+def test_merge_checksum_accepts_cancelling_mean_sums_on_a_symmetric_grid(monkeypatch, capfd):
+    """Advisor finding (round 4): on a grid symmetric about 0 with symmetric data the per-step sums sum(A grid_k) cancel to rounding noise;
+    a checksum relative to |want| then rejects a CORRECT merge (different summation order).  The mean columns are held to
+    1e-9 x sum(A) x max|grid_k| instead: the correct merge passes (no repeat, nothing on stderr), the lossy one is still caught."""
+    import bayesloop_amd as bl
+    import bayesloop_amd.engine as em
+    from bayesloop_amd import dist
+    from oracle_engine import OracleEngine
+
+    def fit(engines):
+        n = len(engines)
+        for k, e in enumerate(engines):
+            e.device = k
+        engines[0].ctx = object()
+        real, orig_for, orig_get = dist.local_devices, em.engine_for_device, em.get_engine
+        em.engine_for_device = lambda d: engines[d]
+        em.get_engine = lambda: engines[0]
+        dist.local_devices = lambda n_jobs, root=0: list(range(n))
+        prev = bl.set_engine(engines[0])
+        try:
+            S = bl.HyperStudy(silent=True)
+            S.loadData(np.zeros(6), silent=True)       # data at the grid's centre of symmetry: every posterior is symmetric in 'mean'
+            S.set(bl.om.Gaussian('mean', bl.cint(-3, 3, 31), 'std', bl.oint(0, 2, 12)),     # grid symmetric about 0 on axis 0
+                  bl.tm.GaussianRandomWalk('sigma', bl.cint(0.0, 0.4, 7), target='mean'), silent=True)
+            with np.errstate(all='ignore'):
+                S.fit(nJobs=n, silent=True)
+            return S
+        finally:
+            bl.set_engine(prev)
+            dist.local_devices, em.engine_for_device, em.get_engine = real, orig_for, orig_get
+
+    monkeypatch.setattr(dist, '_MULTI_GPU_OFF', [])
+    monkeypatch.setenv('BLHIP_NJOBS_MULTI_GPU', 'strict')
+    S3 = fit([OracleEngine() for _ in range(3)])
+    assert capfd.readouterr().err == ''
+    S1 = fit([OracleEngine()])
+    assert abs(S3.logEvidence - S1.logEvidence) <= 1e-12 * abs(S1.logEvidence)
+    # the means of axis 0 really are rounding noise against the grid's extent: the case exercises the cancelling sums
+    assert np.max(np.abs(S1.posteriorMeanValues[0])) < 1e-13
+    assert np.allclose(S3.posteriorMeanValues, S1.posteriorMeanValues, rtol=0, atol=1e-12)
+
+    class Lossy(OracleEngine):
+        def accum_peer_reduce(self, others, row0, row1):
+            OracleEngine.accum_peer_reduce(self, others[:-1], row0, row1)
+    from bayesloop_amd.exceptions import BackendError
+    with pytest.raises(BackendError, match='checksum'):
+        fit([Lossy() for _ in range(3)])
