@@ -509,7 +509,11 @@ class Study(object):
                     uniq = hyper_rows[first][:, key_cols]
                 else:
                     uniq, inv = np.zeros((1, 0)), np.zeros(n, dtype=np.intp)
-                tables = model.shifts_many(names_k, uniq[:, :len(cols)], ts, resume_time, t_offsets=None if off_col is None else uniq[:, -1])
+                # (first segment of a serial model: the offset is 0 by definition (reference transitionModels.py:772), whatever a
+                #  computeForwardPrior call through SerialTransitionModel._active left in the mutable model.tOffset; a stand-alone
+                #  model (seg -1) reads its own attribute as in the reference)
+                t_offs = uniq[:, -1] if off_col is not None else (np.zeros(len(uniq)) if seg == 0 else None)
+                tables = model.shifts_many(names_k, uniq[:, :len(cols)], ts, resume_time, t_offsets=t_offs)
                 # the model's 2 T columns in one gather + one scatter
                 js = [jj for jj, op in enumerate(program) if isinstance(op[3], tuple) and op[2] is model]
                 qs = [program[jj][3][1] for jj in js]
@@ -1358,6 +1362,12 @@ class OnlineStudy(HyperStudy):
         self._device = []
         for tm, hpv in zip(self.transitionModels, self.hyperParameterValues):
             self.setTransitionModel(tm, silent=True)
+            if _tm_mod.needs_host_transition(tm):
+                # (Study.fit / HyperStudy.fit apply such a model on the host between device steps; the batched online step has no
+                #  host path: refuse loudly instead of running a built-in base class's program in place of the user's override)
+                raise ConfigurationError('OnlineStudy: transition model {} defines computeForwardPrior / computeBackwardPrior itself (or '
+                                         'contains such a model); user-defined transition models are supported by Study.fit and '
+                                         'HyperStudy.fit only.'.format(type(tm).__name__))
             program = self._expandProgram(tm._program(om.parameterNames), 1)
             # every step is a one-step problem resumed at t = -1 (core.py:2164-2165): the op values never change
             op_values = self._opValueMatrix(program, np.asarray(hpv, dtype=float) if len(hpv) > 0 else np.zeros((1, 0)),

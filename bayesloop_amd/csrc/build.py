@@ -38,34 +38,86 @@ def slices():
     return [('blhip', 'blhip.hip', [])] + [('chain_tu%d' % k, 'blhip_chain_tu.hip', ['-DBLC_TU=%d' % k]) for k in range(1, n + 1)]
 
 
+BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+
+
+def toolchain_key(flags=()):
+    """What an object depends on beside the sources: the compiler (its --version text: a ROCm upgrade or another HIPCC changes it) and the
+    flags.  Kept in <objdir>/STAMP; objects built under another key are never reused."""
+    import hashlib
+    try:
+        ver = subprocess.run([hipcc(), '--version'], capture_output=True, text=True, timeout=60).stdout
+    except Exception:           # noqa: BLE001 -- no compiler: the key still separates flag sets
+        ver = 'unknown'
+    return hashlib.sha256((hipcc() + '\n' + ver + '\n' + ' '.join(BASE_FLAGS + list(flags))).encode()).hexdigest()[:16]
+
+
+class _BuildLock:
+    """One build of an object directory at a time (pytest -n 4, N ranks starting with a stale library): an exclusive flock on
+    <objdir>/LOCK held for the whole compile + link."""
+    def __init__(self, objdir):
+        self.path = os.path.join(objdir, 'LOCK')
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.path, 'w')
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
 def compile_and_link(out, objdir, flags=(), force=False, verbose=True):
     """Objects in parallel (one hipcc per unit, as many at a time as there are cores), then one link.  An object is reused when it is
-    newer than every source / header (a change of blhip.hip alone recompiles one unit)."""
+    newer than every source / header AND was built by the same compiler with the same flags (STAMP); every output (objects, the
+    library) is written to a temporary name and renamed into place, so an interrupted hipcc leaves nothing that looks finished."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(objdir, exist_ok=True)
-    newest = max(os.path.getmtime(d) for d in deps() if os.path.exists(d))
-    jobs, objs = [], []
-    for name, src, defs in slices():
-        obj = os.path.join(objdir, name + '.o')
-        objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            jobs.append([hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj] + list(defs) + list(flags))
+    with _BuildLock(objdir):
+        key = toolchain_key(flags)
+        stamp = os.path.join(objdir, 'STAMP')
+        same_tools = os.path.exists(stamp) and open(stamp).read().strip() == key
+        newest = max(os.path.getmtime(d) for d in deps() if os.path.exists(d))
+        jobs, objs = [], []
+        for name, src, defs in slices():
+            obj = os.path.join(objdir, name + '.o')
+            objs.append(obj)
+            if force or not same_tools or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+                jobs.append((obj, [hipcc()] + BASE_FLAGS + ['-c', src] + list(defs) + list(flags)))
 
-    def run(cmd):
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=HERE)
+        def run(job):
+            target, cmd = job
+            tmp = '%s.tmp%d' % (target, os.getpid())
+            if verbose:
+                print(' '.join(cmd + ['-o', target]), flush=True)
+            try:
+                subprocess.check_call(cmd + ['-o', tmp], cwd=HERE)
+                os.replace(tmp, target)
+            finally:
+                for junk in glob.glob(tmp + '*'):
+                    try:
+                        os.remove(junk)
+                    except OSError:
+                        pass
 
-    if jobs:
-        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
-            list(pool.map(run, jobs))
-    # librccl is NOT linked: the communicator entry points (blhip_comm_*) dlopen it on first use
-    run([hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs + ['-ldl'])
-    for junk in glob.glob(out + '.*'):      # offload-bundle side files some hipcc versions leave behind
-        try:
-            os.remove(junk)
-        except OSError:
-            pass
+        if jobs:
+            if not same_tools and os.path.exists(stamp):
+                os.remove(stamp)                    # (objects of two toolchains are never mixed, also after an interrupted build)
+            with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+                list(pool.map(run, jobs))
+            with open(stamp + '.tmp', 'w') as f:
+                f.write(key + '\n')
+            os.replace(stamp + '.tmp', stamp)
+        # librccl is NOT linked: the communicator entry points (blhip_comm_*) dlopen it on first use
+        run((out, [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-ldl']))
+        for junk in glob.glob(out + '.*'):      # offload-bundle side files some hipcc versions leave behind
+            try:
+                os.remove(junk)
+            except OSError:
+                pass
     return out
 
 
@@ -76,9 +128,16 @@ def build_variant(name, flags, verbose=True):
     return compile_and_link(out, os.path.join(HERE, '_obj', name), flags, force=True, verbose=verbose)
 
 
+LAST_ACTION = [None]        # 'reused' / 'compiled': what the last build() call did (__graft_entry__.build prints it)
+
+
 def build(force=False, verbose=True):
+    """-> path of libblhip.so.  The binary is git-ignored and travels with a push of the working tree: where it is present and newer than
+    every source this is a no-op ('reused'); on a fresh clone it is a ~2-minute compile of 20 translation units ('compiled')."""
     if not force and not stale():
+        LAST_ACTION[0] = 'reused'
         return OUT
+    LAST_ACTION[0] = 'compiled'
     return compile_and_link(OUT, os.path.join(HERE, '_obj', 'product'), (), force=force, verbose=verbose)
 
 

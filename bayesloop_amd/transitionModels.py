@@ -356,7 +356,12 @@ class Deterministic(TransitionModel):
             v = np.asarray(self.function(at, **params), dtype=float)
             if v.shape != at.shape:
                 raise ValueError
-        except Exception:                        # noqa: BLE001 -- a function written for scalars only
+            # a function that accepts arrays need not be elementwise (np.cumsum, t.mean(), t[0] ...): the reference calls it per
+            # scalar (transitionModels.py:573-577), so the array result must agree with scalar calls -- checked at three entries
+            for i in {0, len(at) // 2, len(at) - 1}:
+                if not np.array_equal(v[i], float(self.function(at[i], **params)), equal_nan=True):
+                    raise ValueError
+        except Exception:                        # noqa: BLE001 -- a function written for scalars only, or not elementwise
             v = np.array([float(self.function(a, **params)) for a in at])
         n = T - 1
         fwd = np.concatenate(([v[0] - v[1]], v[2:2 + n] - v[2 + n:2 + 2 * n]))

@@ -807,7 +807,10 @@ def main():
                     #  it measures the clocks' ramp, not the path; the value is the mean of the timed fits, the kernel times the last one's)
                     few = name in ('fwd2048', 'c1_hyper', 'coal_hyper1000', 'c2', 'coal_breakpoints')
                     n_fit = 3 if few else 1
-                    S2, u2, d2, dt2 = run_workload(bl, name, n_fit, n_fit, None, lambda: None)
+                    import contextlib
+                    import io
+                    with contextlib.redirect_stdout(io.StringIO()):      # (the study classes print the reference's warnings: stdout carries the line only)
+                        S2, u2, d2, dt2 = run_workload(bl, name, n_fit, n_fit, None, lambda: None)
                     dt2 /= n_fit
                     tm = dict(S2.lastTiming)
                     g2 = golden_log_evidence(name)

@@ -70,3 +70,44 @@ def test_the_slices_of_the_chain_kernels_cover_every_declared_launcher():
             defined[name] = int(k)
     assert set(defined) == set(declared), (set(declared) ^ set(defined))
     assert set(defined.values()) == set(range(1, n + 1))               # (no empty slice: every compilation earns its place)
+
+
+def test_objects_are_keyed_on_the_toolchain_and_written_atomically(tmp_path, monkeypatch):
+    """Advisor finding (round 4): objects were reused on mtime alone.  A fake hipcc records its calls: a second build with the same
+    compiler reuses every object, another compiler (other --version text) or other flags recompile all of them, every output is written
+    under a temporary name first, and an interrupted compile leaves no object behind."""
+    import stat
+    from bayesloop_amd.csrc import build
+    log = tmp_path / 'calls.log'
+    fake = tmp_path / 'hipcc'
+    fake.write_text('#!/bin/sh\n'
+                    'if [ "$1" = "--version" ]; then echo "fake hipcc $FAKE_VER"; exit 0; fi\n'
+                    'echo "$@" >> %s\n'
+                    'out=""; prev=""; for a in "$@"; do if [ "$prev" = "-o" ]; then out="$a"; fi; prev="$a"; done\n'
+                    'case "$out" in *.tmp*) ;; *) echo "NOT-TEMPORARY $out" >> %s;; esac\n'
+                    'if [ -n "$FAKE_FAIL" ]; then echo partial > "$out"; exit 1; fi\n'
+                    'echo obj > "$out"\n' % (log, log))
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv('HIPCC', str(fake))
+    monkeypatch.setenv('FAKE_VER', '1')
+    objdir, out = str(tmp_path / 'obj'), str(tmp_path / 'lib.so')
+    n_units = len(build.slices())
+
+    def calls():
+        return [l for l in log.read_text().splitlines() if ' -c ' in l] if log.exists() else []
+    build.compile_and_link(out, objdir, verbose=False)
+    assert len(calls()) == n_units and os.path.exists(out)
+    build.compile_and_link(out, objdir, verbose=False)
+    assert len(calls()) == n_units                                  # same toolchain, nothing newer: every object reused
+    monkeypatch.setenv('FAKE_VER', '2')                             # another compiler
+    build.compile_and_link(out, objdir, verbose=False)
+    assert len(calls()) == 2 * n_units
+    build.compile_and_link(out, objdir, flags=['-DX=1'], verbose=False)   # other flags
+    assert len(calls()) == 3 * n_units
+    assert 'NOT-TEMPORARY' not in log.read_text()
+    # an interrupted compile: no object under its final name, no stamp
+    monkeypatch.setenv('FAKE_FAIL', '1')
+    with pytest.raises(subprocess.CalledProcessError):
+        build.compile_and_link(out, objdir, force=True, flags=['-DX=2'], verbose=False)
+    assert not os.path.exists(os.path.join(objdir, 'STAMP'))
+    assert not [f for f in os.listdir(objdir) if '.tmp' in f]

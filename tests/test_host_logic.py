@@ -449,3 +449,42 @@ def test_deterministic_shifts_of_many_parameter_sets_equal_the_per_set_evaluatio
             for u in range(7):
                 one = m.shifts(dict(zip(names, rows[u])), ts, -1.0, t_offset=None if t_offsets is None else t_offsets[u])
                 assert np.array_equal(many[u], one, equal_nan=True)
+
+
+def test_deterministic_function_that_takes_arrays_but_is_not_elementwise():
+    """Advisor finding (round 4): a user function that accepts an array of time stamps need not be elementwise (here it subtracts the
+    FIRST stamp it is handed).  The reference calls it per scalar (transitionModels.py:573-577): the vectorised evaluation is cross-checked
+    against scalar calls and falls back to them."""
+    def f(t, slope=0.0):
+        t = np.asarray(t, dtype=float)
+        return slope * (t - t.ravel()[0]) + slope * t          # array input: depends on the batch; scalar input: slope * t
+    m = bl.tm.Deterministic(f, target='rate')
+    ts = np.arange(10.)
+    got = m.shifts({'slope': 0.5}, ts, -1.0, t_offset=0.0)
+    ref = bl.tm.Deterministic(lambda t, slope=0.0: slope * t, target='rate').shifts({'slope': 0.5}, ts, -1.0, t_offset=0.0)
+    assert np.array_equal(got, ref)
+
+
+def test_online_study_refuses_user_defined_transition_models():
+    """Advisor finding (round 4): OnlineStudy has no host-transition path; a user-defined model (or a built-in subclass that overrides
+    computeForwardPrior) must raise ConfigurationError, not TypeError / silently run the base class's device program."""
+    from bayesloop_amd.exceptions import ConfigurationError
+
+    class Mine(bl.tm.TransitionModel):
+        hyperParameterNames = []
+        hyperParameterValues = []
+
+        def computeForwardPrior(self, posterior, t):
+            return posterior
+
+    class Override(bl.tm.GaussianRandomWalk):
+        def computeForwardPrior(self, posterior, t):
+            return posterior
+    import contextlib, io
+    for tm in (Mine(), Override('sigma', 0.1, target='rate'), bl.tm.CombinedTransitionModel(bl.tm.Static(), Override('sigma', 0.1, target='rate'))):
+        with contextlib.redirect_stdout(io.StringIO()):
+            O = bl.OnlineStudy(storeHistory=True, silent=True)
+            O.set(bl.om.Poisson('rate', bl.oint(0, 6, 20)), silent=True)
+            O.add('m', tm)
+            with pytest.raises(ConfigurationError, match='user-defined'):
+                O.step(1.0)
