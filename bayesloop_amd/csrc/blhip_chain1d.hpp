@@ -86,6 +86,8 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         if (j >= n - LW) buf[slot(LW + n + (n - 1 - j))] = v;
     };
     int tap_now = -2, lw = 0;
+    blk::SplineConsts SK{};
+    if (SHIFT && wv == 0) SK = blk::spline_consts(n + 24, lane);
     const int t0 = P.t_first;
     // backward: the stored forward row of the step that runs next waits in registers (requested a step ahead)
     double al[CPT];
@@ -138,14 +140,11 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
                 cur[LW + i] = cur[LW + blk::extend_index(i, n, 2)];
             }
             __syncthreads();
-            if (big) {                               // spline coefficients of the padded row: position q = grid coordinate q - 12
-                const double *gw = wl + 1;
-                for (int q = tid; q < n + 24; q += NT) {
-                    const double *cen = cur + LW + (q - 12);
-                    double acc = gw[0] * cen[0];
-                    for (int m = 34; m >= 1; --m) acc = fma(gw[m], cen[-m] + cen[m], acc);
-                    vt[q] = acc;
-                }
+            if (big) {                               // spline coefficients of the padded row (position q = grid coordinate q - 12, the 12
+                for (int q = tid; q < n + 24; q += NT)   // cells beyond either end repeat the edge sample) by SciPy's recursion
+                    vt[q] = blk::SPLINE_GAIN * cur[LW + min(max(q - 12, 0), n - 1)];
+                __syncthreads();
+                if (wv == 0) blk::spline_prefilter_wave(vt, n + 24, lane, SK);
                 __syncthreads();
             }
         }

@@ -100,6 +100,98 @@ __device__ __forceinline__ double wave_sum(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// ---- SciPy's cubic-spline prefilter as the recursion it is (transitionModels.py:581, :600 -> scipy.ndimage.shift(order = 3,
+// mode = 'nearest') -> ni_splines.c: apply_filter with _init_causal_reflect / _init_anticausal_reflect; restated bit for bit in
+// oracle/spline_iir.c) ------------------------------------------------------------------------------------------------------------------
+//     c *= gain;  c[0] <- c0 + z / (1 - z^2N) sum_i z^i (c[i] + z^N c[N-1-i]);  c[i] += z c[i-1];  c[N-1] *= z / (z - 1);  c[i] = z (c[i+1] - c[i])
+// Rounds 1 - 4 applied its impulse response truncated at 34 cells (below fp64 resolution wherever the row has mass).  But the
+// recursion's tail A z^k keeps decaying -- alternating in sign -- down to the denormals, and that tail is ALL that is left of a
+// distribution shifted off the grid, which the reference then renormalises (:603): its sign decides whether a chain of the reference's
+// published break-point study stops (14 of 23 400 do; the truncated response stopped 3).
+// One wave runs the two first-order recursions over the row v[0 .. N) in LDS as segmented scans: a lane owns a chunk of C (odd: the
+// lanes' accesses fall into different banks) consecutive elements, runs the recursion over it with a zero carry-in, the carries are
+// resolved by a 6-step DPP scan of the affine maps (carry -> z^len carry + end value) across the lanes, and the recursion runs again
+// from the true carry-in: every element is produced by SciPy's own operation  c[i] + z c[i-1]  /  z (c[i+1] - c[i])  from a carry that
+// is exact to rounding.  Four sweeps of C dependent multiply-adds + two scans.  Call with ALL lanes of ONE wave; v holds gain x row.
+constexpr double SPLINE_POLE = -0.2679491924311227;            // SciPy's literal (sqrt(3.) - 2. in double arithmetic is two ulp away)
+constexpr double SPLINE_GAIN = (1.0 - SPLINE_POLE) * (1.0 - 1.0 / SPLINE_POLE);
+__device__ __forceinline__ double pow_pole(int k) {           // z^k, k >= 0
+    const double m = pow(-SPLINE_POLE, (double)k);
+    return (k & 1) ? -m : m;
+}
+// the value of this lane's DPP source lane; `ident` where there is none (row_shr beyond the row's first lanes, rows outside ROW_MASK)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_src(double v, double ident) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// inclusive scan, low lanes first, of the affine maps  carry -> A carry + B  (composition: this lane's map after the lower lanes'):
+// four row_shr steps inside the rows of 16 lanes, row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3 -- no LDS round trips
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void affine_step(double &A, double &B) {
+    const double Ap = dpp_src<CTRL, ROW_MASK>(A, 1.0), Bp = dpp_src<CTRL, ROW_MASK>(B, 0.0);
+    B = fma(A, Bp, B);
+    A *= Ap;
+}
+__device__ __forceinline__ void affine_scan(double &A, double &B) {
+    affine_step<0x111, 0xf>(A, B);
+    affine_step<0x112, 0xf>(A, B);
+    affine_step<0x114, 0xf>(A, B);
+    affine_step<0x118, 0xf>(A, B);
+    affine_step<0x142, 0xa>(A, B);
+    affine_step<0x143, 0xc>(A, B);
+}
+// (what depends on the row length and the lane only: computed once per kernel)
+// causal pass: lane l owns chunk l; anti-causal pass: lane l owns chunk 63 - l (so that both scans run low lanes first)
+struct SplineConsts { double z_n, zlenF, zlenB, zb0; int b0F, b1F, b0B, b1B; };
+__device__ __forceinline__ SplineConsts spline_consts(int N, int lane) {
+    SplineConsts K;
+    const int C = ((N + 63) >> 6) | 1;               // odd: the lanes' accesses fall into different banks
+    K.b0F = min(lane * C, N); K.b1F = min(K.b0F + C, N);
+    K.b0B = min((63 - lane) * C, N); K.b1B = min(K.b0B + C, N);
+    K.z_n = pow_pole(N); K.zlenF = pow_pole(K.b1F - K.b0F); K.zlenB = pow_pole(K.b1B - K.b0B); K.zb0 = pow_pole(K.b0F);      // (zlen = 1 for the empty chunks behind the row)
+    return K;
+}
+__device__ __forceinline__ void spline_prefilter_wave(double *v, int N, int lane, const SplineConsts &K) {
+    const double z = SPLINE_POLE;
+    if (N < 2) return;
+    const double z_n = K.z_n;
+    // ---- causal initialisation (the whole row enters c[0]) + the chunk's causal recursion with a zero carry-in, one sweep --------------
+    double A = K.zlenF, B = 0.0;
+    {
+        double zi = K.zb0, part = 0.0;
+        for (int i = K.b0F; i < K.b1F; ++i) {
+            const double x = v[i];
+            part += zi * (x + z_n * v[N - 1 - i]);
+            zi *= z;
+            B = x + z * B;
+        }
+        const double S = wave_sum(part);
+        if (lane == 0) {                              // c[0] <- c0 + z / (1 - z^2N) S: the chunk's end value moves by z^(len - 1) times the change
+            const double delta = S * (z / (1.0 - z_n * z_n));
+            B = fma(K.zlenF / z, delta, B);
+            v[0] = delta + v[0];
+        }
+    }
+    // ---- causal pass: y[i] = c[i] + z y[i-1] from the true carry-in ---------------------------------------------------------------------
+    affine_scan(A, B);
+    double t = dpp_src<0x138, 0xf>(B, 0.0);           // wave_shr:1 -- the true value in front of the chunk (lane 0: none)
+    for (int i = K.b0F; i < K.b1F; ++i) { t = v[i] + z * t; v[i] = t; }
+    __builtin_amdgcn_wave_barrier();
+    // ---- anti-causal pass: u[N-1] = y[N-1] z / (z - 1);  u[i] = z (u[i+1] - y[i]) --------------------------------------------------------
+    const bool top = K.b0B < N && K.b1B == N;         // the lane whose chunk holds the last element: the recursion starts there
+    const double uN1 = v[N - 1] * (z / (z - 1.0));
+    const int hi = top ? K.b1B - 2 : K.b1B - 1;
+    A = top ? 0.0 : K.zlenB; B = top ? uN1 : 0.0;
+    for (int i = hi; i >= K.b0B; --i) B = z * (B - v[i]);
+    affine_scan(A, B);
+    t = dpp_src<0x138, 0xf>(B, 0.0);                   // the true value behind the chunk
+    if (top) { t = uN1; v[N - 1] = uN1; }
+    for (int i = hi; i >= K.b0B; --i) { t = z * (t - v[i]); v[i] = t; }
+}
+
+
 // Sum over the block; result valid in every thread.  `red` = NTHREADS/64 doubles of LDS scratch (+1).
 __device__ __forceinline__ double block_sum(double v, double *red) {
     v = wave_sum(v);
@@ -292,15 +384,13 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
     }
 
     if (big1) {
-        // spline coefficients of the padded row: position q = 0 .. n + 23 of the padded array = grid coordinate q - 12
-        const double *gw = w1 + 1;
+        // spline coefficients of the padded row: position q = 0 .. n + 23 of the padded array = grid coordinate q - 12 (12 edge samples on
+        // both sides), by SciPy's recursion (spline_prefilter_wave)
         const int N = P.n1 + 24;
-        for (int q = threadIdx.x; q < N; q += NTHREADS) {
-            const double *cen = in_tile + (size_t)P.LW0 * pitch + P.LW1 + (q - 12);
-            double acc = gw[0] * cen[0];
-            for (int m = 34; m >= 1; --m) acc = fma(gw[m], cen[-m] + cen[m], acc);
-            v_tile[q] = acc;
-        }
+        for (int q = threadIdx.x; q < N; q += NTHREADS)
+            v_tile[q] = SPLINE_GAIN * in_tile[(size_t)P.LW0 * pitch + P.LW1 + min(max(q - 12, 0), P.n1 - 1)];
+        __syncthreads();
+        if (threadIdx.x < 64) spline_prefilter_wave(v_tile, N, threadIdx.x, spline_consts(N, threadIdx.x));
         __syncthreads();
     }
 

@@ -73,3 +73,37 @@ def test_alphastable_convolution_against_scipy():
         want = signal.fftconvolve(padded, kernel, mode='same')[n:2 * n]
         got = orc.convolve_axis_zero(x, orc.alphastable_kernel(c, alpha, n), 0)
         assert np.max(np.abs(want - got)) < 1e-13
+
+
+@pytest.mark.parametrize('n', [2, 3, 5, 24, 100, 224, 1024, 4120])
+def test_spline_prefilter_recursion_is_scipys_bit_for_bit(n):
+    """oracle/spline_iir.c (and its pure-Python twin) = scipy.ndimage.spline_filter1d(x, 3, mode='nearest') to the last bit: SciPy's
+    recursion (ni_splines.c: gain, _init_causal_reflect, causal pass, _init_anticausal_reflect, anti-causal pass) with SciPy's pole
+    literal -0.2679491924311227 -- rows of every magnitude, incl. tails that decay into the denormals."""
+    rng = np.random.default_rng(n)
+    x = np.arange(n)
+    rows = np.stack([rng.random(n), rng.random(n) * np.exp(rng.normal(0, 40, n)), np.exp(-0.5 * ((x - 0.6 * n) / 3.0) ** 2),
+                     np.exp(-x / 2.0), 1e-300 * rng.random(n), np.where(x == n // 2, 1.0, 0.0)])
+    want = scipy_ndimage.spline_filter1d(rows, 3, axis=1, mode='nearest')
+    got = orc.spline_prefilter_reflect(rows.copy())
+    assert np.array_equal(got, want)
+    # the fall-back without a C compiler: the same recursion in numpy, the same bits
+    lib, orc._SPLINE_LIB[:] = list(orc._SPLINE_LIB), [None]
+    try:
+        assert np.array_equal(orc.spline_prefilter_reflect(rows.copy()), want)
+    finally:
+        orc._SPLINE_LIB[:] = lib
+
+
+def test_spline_shift_off_the_grid_keeps_the_recursions_tail():
+    """A distribution shifted off the grid: what is left is the prefilter's tail (here ~1e-130 of the mass), alternating in sign --
+    the restatement agrees with SciPy in every cell to rounding RELATIVE TO THE CELL; the truncated response of rounds 1 - 4 left
+    exact zeros there."""
+    n = 200
+    x = np.exp(-0.5 * ((np.arange(n) - 150.0) / 1.5) ** 2)
+    x /= x.sum()
+    for d in (-260.3, 255.0):
+        want = scipy_ndimage.shift(x, d, order=3, mode='nearest')
+        got = orc.spline_shift_nearest(x, d, 0)
+        assert np.max(np.abs(want)) < 1e-20 and np.all(want != 0.0)
+        assert np.all(np.abs(got - want) <= 1e-12 * np.abs(want))
