@@ -29,7 +29,7 @@ constexpr int NS = 5;              // sums of a step per wave: N, sum p / L, sum
 // doubles of LDS: two state buffers with halo, grid values, exp(-lambda) (Poisson), weights, the waves' partial sums (two parities);
 // shift: + the other half of an asymmetric tap set and the spline coefficients of the 12-padded row (two-stage shifts)
 inline size_t lds_doubles(int n, int LW, bool shift = false) {
-    return (size_t)2 * (n + 1 + 2 * (LW + 1)) + 2 * (size_t)n + (LW + 3) + 2 * NW * NS + 8 + (shift ? (size_t)LW + 40 + n + 24 : 0);
+    return (size_t)2 * (n + 1 + 2 * (LW + 1)) + 2 * (size_t)n + (LW + 3) + 2 * NW * NS + 8 + (shift ? (size_t)LW + 40 + n + 24 + blk::SPLINE_CONST_DOUBLES : 0);
 }
 
 // The likelihood of a 1-D batch is the same for every chain (same data, same grid: only the transition differs).  Poisson's pow() per
@@ -86,8 +86,7 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         if (j >= n - LW) buf[slot(LW + n + (n - 1 - j))] = v;
     };
     int tap_now = -2, lw = 0;
-    blk::SplineConsts SK{};
-    if (SHIFT && wv == 0) SK = blk::spline_consts(n + 24, lane);
+    if (SHIFT && wv == 0) blk::spline_consts(vt + n + 24, n + 24, lane);      // (read by wave 0 only: no barrier)
     const int t0 = P.t_first;
     // backward: the stored forward row of the step that runs next waits in registers (requested a step ahead)
     double al[CPT];
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
                 for (int q = tid; q < n + 24; q += NT)   // cells beyond either end repeat the edge sample) by SciPy's recursion
                     vt[q] = blk::SPLINE_GAIN * cur[LW + min(max(q - 12, 0), n - 1)];
                 __syncthreads();
-                if (wv == 0) blk::spline_prefilter_wave(vt, n + 24, lane, SK);
+                if (wv == 0) blk::spline_prefilter_wave(vt, n + 24, lane, blk::spline_k_load(vt + n + 24, lane));
                 __syncthreads();
             }
         }

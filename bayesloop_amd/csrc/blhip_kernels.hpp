@@ -142,20 +142,31 @@ __device__ __forceinline__ void affine_scan(double &A, double &B) {
     affine_step<0x142, 0xa>(A, B);
     affine_step<0x143, 0xc>(A, B);
 }
-// (what depends on the row length and the lane only: computed once per kernel)
+// (what depends on the row length and the lane only -- three pow() calls -- is computed once per kernel into 4 x 64 doubles of LDS)
 // causal pass: lane l owns chunk l; anti-causal pass: lane l owns chunk 63 - l (so that both scans run low lanes first)
-struct SplineConsts { double z_n, zlenF, zlenB, zb0; int b0F, b1F, b0B, b1B; };
-__device__ __forceinline__ SplineConsts spline_consts(int N, int lane) {
-    SplineConsts K;
-    const int C = ((N + 63) >> 6) | 1;               // odd: the lanes' accesses fall into different banks
-    K.b0F = min(lane * C, N); K.b1F = min(K.b0F + C, N);
-    K.b0B = min((63 - lane) * C, N); K.b1B = min(K.b0B + C, N);
-    K.z_n = pow_pole(N); K.zlenF = pow_pole(K.b1F - K.b0F); K.zlenB = pow_pole(K.b1B - K.b0B); K.zb0 = pow_pole(K.b0F);      // (zlen = 1 for the empty chunks behind the row)
-    return K;
+constexpr int SPLINE_CONST_DOUBLES = 4 * 64;
+__device__ __forceinline__ int spline_chunk(int N) { return ((N + 63) >> 6) | 1; }       // odd: the lanes' accesses fall into different banks
+__device__ __forceinline__ void spline_consts(double *K, int N, int lane) {
+    const int C = spline_chunk(N);
+    const int b0F = min(lane * C, N), b1F = min(b0F + C, N), b0B = min((63 - lane) * C, N), b1B = min(b0B + C, N);
+    K[lane] = pow_pole(N); K[64 + lane] = pow_pole(b1F - b0F); K[128 + lane] = pow_pole(b1B - b0B); K[192 + lane] = pow_pole(b0F);   // (z^len = 1 for the empty chunks behind the row)
 }
-__device__ __forceinline__ void spline_prefilter_wave(double *v, int N, int lane, const SplineConsts &K) {
+struct SplineK { double z_n, zlenF, zlenB, zb0; };       // z^N, z^(length of the lane's causal / anti-causal chunk), z^(first index of the causal chunk)
+__device__ __forceinline__ SplineK spline_k_compute(int N, int lane) {
+    const int C = spline_chunk(N);
+    const int b0F = min(lane * C, N), b1F = min(b0F + C, N), b0B = min((63 - lane) * C, N), b1B = min(b0B + C, N);
+    return SplineK{pow_pole(N), pow_pole(b1F - b0F), pow_pole(b1B - b0B), pow_pole(b0F)};
+}
+__device__ __forceinline__ SplineK spline_k_load(const double *Kc, int lane) { return SplineK{Kc[lane], Kc[64 + lane], Kc[128 + lane], Kc[192 + lane]}; }
+__device__ __forceinline__ void spline_prefilter_wave(double *v, int N, int lane, const SplineK Kd) {
     const double z = SPLINE_POLE;
     if (N < 2) return;
+    struct { double z_n, zlenF, zlenB, zb0; int b0F, b1F, b0B, b1B; } K;
+    {
+        const int C = spline_chunk(N);
+        K.b0F = min(lane * C, N); K.b1F = min(K.b0F + C, N); K.b0B = min((63 - lane) * C, N); K.b1B = min(K.b0B + C, N);
+        K.z_n = Kd.z_n; K.zlenF = Kd.zlenF; K.zlenB = Kd.zlenB; K.zb0 = Kd.zb0;
+    }
     const double z_n = K.z_n;
     // ---- causal initialisation (the whole row enters c[0]) + the chunk's causal recursion with a zero carry-in, one sweep --------------
     double A = K.zlenF, B = 0.0;
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS) void step_kernel(const StepParams P) {
         for (int q = threadIdx.x; q < N; q += NTHREADS)
             v_tile[q] = SPLINE_GAIN * in_tile[(size_t)P.LW0 * pitch + P.LW1 + min(max(q - 12, 0), P.n1 - 1)];
         __syncthreads();
-        if (threadIdx.x < 64) spline_prefilter_wave(v_tile, N, threadIdx.x, spline_consts(N, threadIdx.x));
+        if (threadIdx.x < 64) spline_prefilter_wave(v_tile, N, threadIdx.x, spline_k_compute(N, threadIdx.x));
         __syncthreads();
     }
 
