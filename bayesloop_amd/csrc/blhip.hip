@@ -806,8 +806,11 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
     // (a chain's T steps are T entries B apart in each of the ten arrays: written chain by chain that is one cache line per entry --
     //  half of the 30 ms this function took for the 23 400 chains x 41 steps of the published break-point study.  The steps of GROUP
     //  chains are collected first and written out as runs of GROUP consecutive entries)
+    // (no more entries than the batch has chains: constructing 64 x T records for the ONE chain of a long single-chain fit -- C2: T = 10 000,
+    //  2 x 15 MB -- was 8 ms of its 43-ms fit)
     constexpr int GROUP = 64;
-    std::vector<StepProg> gF((size_t)GROUP * T), gB((size_t)GROUP * T);
+    const size_t group_rows = (size_t)std::min<int64_t>(GROUP, std::max<int64_t>(B, 1));
+    std::vector<StepProg> gF(group_rows * T), gB(group_rows * T);
     auto flush_group = [&](int64_t b0, int64_t nb) {
         for (int64_t t = 0; t < T; ++t) {
             const size_t k0 = (size_t)t * B + b0;

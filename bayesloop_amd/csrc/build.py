@@ -70,6 +70,24 @@ class _BuildLock:
         self.f.close()
 
 
+def unit_newest(depfile, fallback):
+    """Newest modification time among the files a unit's last compilation read (make-style dependency file of hipcc -MD; system headers
+    outside this tree are skipped); `fallback` when there is no such file or one of its entries has disappeared."""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return fallback
+    newest = 0.0
+    for tok in text.replace('\\\n', ' ').split():
+        if tok.endswith(':') or tok.startswith(('/opt/', '/usr/')):
+            continue
+        path = tok if os.path.isabs(tok) else os.path.join(HERE, tok)
+        if not os.path.exists(path):
+            return fallback
+        newest = max(newest, os.path.getmtime(path))
+    return newest or fallback
+
+
 def compile_and_link(out, objdir, flags=(), force=False, verbose=True):
     """Objects in parallel (one hipcc per unit, as many at a time as there are cores), then one link.  An object is reused when it is
     newer than every source / header AND was built by the same compiler with the same flags (STAMP); every output (objects, the
@@ -80,13 +98,16 @@ def compile_and_link(out, objdir, flags=(), force=False, verbose=True):
         key = toolchain_key(flags)
         stamp = os.path.join(objdir, 'STAMP')
         same_tools = os.path.exists(stamp) and open(stamp).read().strip() == key
-        newest = max(os.path.getmtime(d) for d in deps() if os.path.exists(d))
+        newest_all = max(os.path.getmtime(d) for d in deps() if os.path.exists(d))
         jobs, objs = [], []
         for name, src, defs in slices():
             obj = os.path.join(objdir, name + '.o')
             objs.append(obj)
+            # an object depends on the files its own compilation read (the compiler's dependency file, written beside it: a header only
+            # some units include recompiles those units only); no dependency file: on every source / header
+            newest = unit_newest(obj + '.d', newest_all)
             if force or not same_tools or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-                jobs.append((obj, [hipcc()] + BASE_FLAGS + ['-c', src] + list(defs) + list(flags)))
+                jobs.append((obj, [hipcc()] + BASE_FLAGS + ['-c', src, '-MD', '-MF', obj + '.d'] + list(defs) + list(flags)))
 
         def run(job):
             target, cmd = job
@@ -94,7 +115,14 @@ def compile_and_link(out, objdir, flags=(), force=False, verbose=True):
             if verbose:
                 print(' '.join(cmd + ['-o', target]), flush=True)
             try:
+                dep = None
+                if '-MF' in cmd:                        # the dependency file is renamed into place with its object
+                    cmd = list(cmd)
+                    dep = cmd[cmd.index('-MF') + 1]
+                    cmd[cmd.index('-MF') + 1] = tmp + '.d'
                 subprocess.check_call(cmd + ['-o', tmp], cwd=HERE)
+                if dep and os.path.exists(tmp + '.d'):
+                    os.replace(tmp + '.d', dep)
                 os.replace(tmp, target)
             finally:
                 for junk in glob.glob(tmp + '*'):
