@@ -607,6 +607,13 @@ void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
     HIPCHECK(hipGetLastError());
 }
 
+// walks on both parameters (blc::chainax_kernel, blhip_chainax.hpp)
+void launch_chainax(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 4) { if (bwd) blcl::chainax_ntw4_bwd(s, Q, nk, store); else blcl::chainax_ntw4_fwd(s, Q, nk, store); }
+    else blcl::chainax_ntw12(s, Q, nk, ntw, bwd, store);
+    HIPCHECK(hipGetLastError());
+}
+
 // backward pass with the fused fold, two chains per block (blc::chain_fold2_kernel)
 bool fold2_shape(int ntw) { return ntw >= 1 && ntw <= 4; }
 
@@ -1623,6 +1630,9 @@ struct ChainResPlan {
     bool mixed = false;                          // ... in chains that also filter (random walk + change point in one model)
     std::vector<unsigned char> ckF, ckB;         // [T][B] what a step of the chain kernels consumes: SRC_PREV / SRC_RESET (| 0x80: unfiltered)
     std::vector<int> order, tap_id;              // chains sorted by stencil radius; the chain's axis-0 kernel (-1: none)
+    bool allow_ax1 = false;                      // (set by the caller) walks on the second parameter too may be planned: blc::chainax_kernel
+    bool ax1 = false;                            // ... and some chain has one: the batch runs the transposing kernels (square exact geometry)
+    std::vector<int> tap_id1;                    // the chain's axis-1 kernel (-1: none)
     std::vector<int> round_start, round_nk;      // launches: order[round_start[r] .. round_start[r + 1]), band blocks NK
 };
 
@@ -1640,20 +1650,29 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
     if (cp.strips > blc::MAX_STRIPS || cp.strips > cus) return false;
     cp.cpr = cus / cp.strips;
     cp.tap_id.assign(B, -1);
+    cp.tap_id1.assign(B, -1);
+    cp.ax1 = false;
+    // walks on both parameters (blhip_chainax.hpp): an exact square geometry (the blocks of a chain change between column strips and row strips)
+    const bool ax1_geom = cp.allow_ax1 && !cp.pad && g.n0 == g.n1 && (cp.ntw == 1 || cp.ntw == 2 || cp.ntw == 4) && cp.strips == 8 * cp.ntw;
     std::vector<int> lw(B, 0);
     cp.ckF.assign((size_t)T * B, (unsigned char)SRC_PREV);
     cp.ckB.assign((size_t)T * B, (unsigned char)SRC_PREV);
     for (int64_t b = 0; b < B; ++b) {
         if (prog.kindF[b] != SRC_PRIOR || prog.tapF0[b] >= 0 || prog.tapF1[b] >= 0) return false;
         // the chain's band: the kernel of the first step that filters (every filtering step must use the same one)
-        int k0 = -1;
+        int k0 = -1, k1 = -1;
         for (int64_t t = 1; t < T && k0 < 0; ++t) k0 = prog.tapF0[(size_t)t * B + b];
         for (int64_t t = 0; t + 1 < T && k0 < 0 && full; ++t) k0 = prog.tapB0[(size_t)t * B + b];
+        if (ax1_geom) {
+            for (int64_t t = 1; t < T && k1 < 0; ++t) k1 = prog.tapF1[(size_t)t * B + b];
+            for (int64_t t = 0; t + 1 < T && k1 < 0 && full; ++t) k1 = prog.tapB1[(size_t)t * B + b];
+        }
         // a step either continues from the previous state through the chain's band, or RESTARTS from the reset distribution (a
         // change point, transitionModels.py:300-312) -- through the band (the change point comes before the random walk in the
         // combined model's list) or unfiltered (it comes after: the walk's output is discarded)
         auto classify = [&](unsigned char kind, int t0, int t1, unsigned char &out) {
-            if (t1 >= 0) return false;
+            if (t1 != k1) return false;                       // (k1 = -1 unless the both-axes kernels may be planned)
+            if (k1 >= 0 && kind != SRC_PREV) return false;    // (no restarts in the transposing kernels)
             if (kind == SRC_PREV && t0 == k0) { out = (unsigned char)SRC_PREV; return true; }
             if (kind == SRC_RESET && (t0 == k0 || t0 < 0)) {
                 out = (unsigned char)(SRC_RESET | ((k0 >= 0 && t0 < 0) ? 0x80 : 0));          // bit 7: no filter at this step
@@ -1676,8 +1695,19 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
             }
         }
         cp.tap_id[b] = k0;
+        cp.tap_id1[b] = k1;
         lw[b] = k0 >= 0 ? taps.lw[k0] : 0;
         if (lw[b] > cp.r0_max || lw[b] >= g.n0) return false;          // (single-period reflection)
+        if (k1 >= 0) {
+            cp.ax1 = true;
+            if (taps.lw[k1] >= g.n1) return false;
+            lw[b] = std::max(lw[b], taps.lw[k1]);                       // (one ring length for both filters: the wider walk's)
+        }
+    }
+    if (cp.ax1) {
+        // the transposing kernels: bands of radius <= 40 on either axis (ring lengths 8 .. 24 in steps of 4), no restarts
+        if (cp.has_reset) return false;
+        for (int64_t b = 0; b < B; ++b) if (lw[b] > FAST_R0_MAX) return false;
     }
     cp.order.resize(B);
     for (int64_t b = 0; b < B; ++b) cp.order[b] = (int)b;
@@ -1685,9 +1715,10 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
     cp.round_start.clear(); cp.round_nk.clear();
     for (int64_t s0 = 0; s0 < B; s0 += cp.cpr) {
         const int64_t s1 = std::min<int64_t>(B, s0 + cp.cpr);
-        const int r0 = std::max(4, (lw[cp.order[s1 - 1]] + 3) / 4 * 4);             // (a product costs 64 cycles: bands as narrow as the widest chain of the launch allows)
+        int r0 = std::max(4, (lw[cp.order[s1 - 1]] + 3) / 4 * 4);             // (a product costs 64 cycles: bands as narrow as the widest chain of the launch allows)
+        if (cp.ax1) r0 = std::max(8, (r0 + 7) / 8 * 8);                        // (ring lengths 8, 12, .. 24)
         cp.round_start.push_back((int)s0);
-        cp.round_nk.push_back(prog.LW0 == 0 ? 4 : (blc::TM + 2 * r0) / 4);          // (4: the no-stencil kernel)
+        cp.round_nk.push_back((prog.LW0 == 0 && !cp.ax1) ? 4 : (blc::TM + 2 * r0) / 4);          // (4: the no-stencil kernel)
     }
     cp.round_start.push_back((int)B);
     return true;
@@ -2605,7 +2636,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->postpad.release(); ctx->accw.release(); ctx->accpart.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->postpad.release(); ctx->accw.release(); ctx->accpart.release(); ctx->xch.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,

@@ -6,6 +6,9 @@
 #ifndef BLC_TU
 #define BLC_TU 0        // (no slice selected -- a bare `hipcc -c` of this file: an empty object; build.py passes -DBLC_TU=1 .. N_SLICES)
 #endif
+#if BLC_TU >= 20
+#include "blhip_chainax.hpp"      // (only the slices that hold its kernels: an edit of that header recompiles three units)
+#endif
 
 namespace {
 
@@ -120,6 +123,46 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
 }
 #undef BLC_CASE
 
+#if BLC_TU >= 20
+// walks on both parameters: forward (stored / evidence-only), backward (stored / folded); ring lengths 8 .. 24 in steps of 4
+template <int NK, int NTW>
+void launch_k_ax(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
+    const size_t lds = blc::lds_doubles_ax<NK, NTW>() * sizeof(double);
+    if (bwd && store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, true>, s, Q, lds);
+    else if (bwd) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, false>, s, Q, lds);
+    else if (store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, true>, s, Q, lds);
+    else launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, false>, s, Q, lds);
+}
+template <int NTW>
+void launch_w_ax(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
+    switch (nk) {
+        case 8: launch_k_ax<8, NTW>(s, Q, bwd, store); break;
+        case 12: launch_k_ax<12, NTW>(s, Q, bwd, store); break;
+        case 16: launch_k_ax<16, NTW>(s, Q, bwd, store); break;
+        case 20: launch_k_ax<20, NTW>(s, Q, bwd, store); break;
+        case 24: launch_k_ax<24, NTW>(s, Q, bwd, store); break;
+        default: fail("internal: both-axes chain-resident kernel with %d band blocks", nk);
+    }
+}
+template <int NK, bool BWD>
+void launch_k_ax4(hipStream_t s, const blc::ChainParams &Q, bool store) {
+    const size_t lds = blc::lds_doubles_ax<NK, 4>() * sizeof(double);
+    if (store) launch_chain_fn(&blc::chainax_kernel<NK, 4, BWD, true>, s, Q, lds);
+    else launch_chain_fn(&blc::chainax_kernel<NK, 4, BWD, false>, s, Q, lds);
+}
+template <bool BWD>
+void launch_w_ax4(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) {
+    switch (nk) {
+        case 8: launch_k_ax4<8, BWD>(s, Q, store); break;
+        case 12: launch_k_ax4<12, BWD>(s, Q, store); break;
+        case 16: launch_k_ax4<16, BWD>(s, Q, store); break;
+        case 20: launch_k_ax4<20, BWD>(s, Q, store); break;
+        case 24: launch_k_ax4<24, BWD>(s, Q, store); break;
+        default: fail("internal: both-axes chain-resident kernel with %d band blocks", nk);
+    }
+}
+#endif
+
 }   // namespace
 
 namespace blcl {
@@ -209,6 +252,16 @@ void chain_ntw34_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int n
     else if (ntw == 3) launch_w_tab<3, true>(s, Q, nk, bwd, store);
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
 }
+#elif BLC_TU == 20
+void chainax_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 2) launch_w_ax<2>(s, Q, nk, bwd, store);
+    else if (ntw == 1) launch_w_ax<1>(s, Q, nk, bwd, store);
+    else fail("internal: both-axes chain-resident kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 21
+void chainax_ntw4_fwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) { launch_w_ax4<false>(s, Q, nk, store); }
+#elif BLC_TU == 22
+void chainax_ntw4_bwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) { launch_w_ax4<true>(s, Q, nk, store); }
 #else
 #error "BLC_TU out of range"
 #endif

@@ -1,0 +1,469 @@
+// Chain-resident pass for batches of chains whose transition filters BOTH parameters: a hyper-study over the widths of two Gaussian random
+// walks (HyperStudy.fit, core.py:1349-1366, with CombinedTransitionModel(GRW on parameter 1, GRW on parameter 2), transitionModels.py:
+// 632-662 -> :107-111 per axis) -- the shape of the reference's own two-hyper-parameter tests (tests/test_hyperstudy.py:61-103).
+//
+// Why: rounds 1 - 4 ran these studies with a launch per step and a row PRE-PASS per step (blhip_hwide.hpp + blhip_mfma.hpp): the state
+// streams through HBM three times per step, 78 B per cell-step against 24 of the single-axis headline, at 4.4 TB/s.  Here the state
+// stays on the chip for the whole pass, as in blc::chain_kernel (blhip_chainres.hpp), whose scheme this kernel extends:
+//
+//  * block = one strip of 16 grid columns x ALL rows of one chain (layout A), state in LDS, the axis-0 stencil as banded Toeplitz products
+//    on v_mfma_f64_4x4x4_4b -- unchanged;
+//  * the axis-1 stencil runs along the rows of the grid, i.e. ACROSS the strips.  Instead of exchanging halos (the walks of a
+//    hyper-study are as wide as two strips) the blocks of a chain TRANSPOSE the distribution between the two filters: on a square
+//    geometry (rows = columns = 16 x strips) block j, which owns columns 16 j .. 16 j + 15 in layout A, owns ROWS 16 j .. 16 j + 15 in
+//    layout B, stored [column][16 rows] -- the same LDS shape, so the axis-1 filter is the SAME banded product with the other band.
+//    Per step:   P1  ring + products along axis 0 (layout A)        -> published, element by element, into the strips of layout B
+//                    every block gathers its layout-B strip into its second LDS buffer, barrier
+//                P2  ring + products along axis 1 (layout B)        -> published into the strips of layout A
+//                P3  every lane reads its OWN cells back (registers) -> the fused epilogue of chain_kernel (scale, likelihood
+//                    recurrence, sums, stores / fold), new state -> first LDS buffer, barrier;
+//  * the exchange goes through an L2- / Infinity-Cache-resident buffer (2 MiB per chain and phase, two parities) and THE DATA IS THE
+//    FLAG (blhip_resident.hpp): every element is the 8-byte value with a one-bit tag in its sign bit (everything handed over is >= +0),
+//    written by one write-through store, read by sc1 loads; a consumer whose elements do not carry the step's tag yet asks again
+//    (bounded; abort word as in the other resident kernels).  A producer scatters its tile so that every CONSUMER access is a
+//    contiguous 512 bytes per wave (the gather is a plain copy into LDS, the read-back of P3 is the lane's own cell order);
+//  * HBM sees what chain_kernel's passes see: 8 B per cell forward (stored state), 16 / 24 B backward (store / fold).
+// The filters are applied in the list order of the reference (axis 0, then axis 1) in both directions (transitionModels.py:645-649, :656-660).
+#pragma once
+#include "blhip_chainres.hpp"
+
+namespace blc {
+
+template <int NK, int NTW>
+constexpr size_t lds_doubles_ax() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 16 + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
+
+// 16-byte tagged accesses (two elements each): an 8-byte write-through store costs 2.7 x a 16-byte one per byte on this part
+// (MI355X_MICROARCH.md: "scalar sc1 stores are one fabric write each"), and a consumer should keep >= 8 wide loads in flight
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Tq2 { blr::Tq a, b; };
+__device__ __forceinline__ void st_tq2(blr::Rsrc r, unsigned off, double v0, double v1, unsigned bit) {
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1);
+    const u32x4 q = {(unsigned)b0, (unsigned)(b0 >> 32) | (bit << 31), (unsigned)b1, (unsigned)(b1 >> 32) | (bit << 31)};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)off, 0, 16);
+}
+__device__ __forceinline__ void st_tq2_plain(blr::Rsrc r, unsigned off, double v0, double v1, unsigned bit) {
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1);
+    const u32x4 q = {(unsigned)b0, (unsigned)(b0 >> 32) | (bit << 31), (unsigned)b1, (unsigned)(b1 >> 32) | (bit << 31)};
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ Tq2 ld_tq2(blr::Rsrc r, unsigned off) {
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16);
+    return Tq2{(unsigned long long)q.x | ((unsigned long long)q.y << 32), (unsigned long long)q.z | ((unsigned long long)q.w << 32)};
+}
+// v_permlane16_swap on a pair of doubles: rows 1 / 3 of `x` change places with rows 0 / 2 of `y` (rows of 16 lanes; measured:
+// tools/ubench/permlane16.hip).  With x = the tile's values of register r, y = those of register r + 1 (lane (g, c): row g + 4 r of
+// column c) a lane of an EVEN row g then holds rows g, g + 1 of register r in (x, y), a lane of an ODD row rows g - 1, g of register
+// r + 1: two consecutive rows each -- one 16-byte element pair.  Its own inverse.
+__device__ __forceinline__ void swap_rows(double &x, double &y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// the tag of the elements step k publishes: a buffer (parity k & 1) is rewritten every second step, zeroed before the launch
+__device__ __forceinline__ unsigned ax_tag(int k) { return 1u - (((unsigned)k >> 1) & 1u); }
+
+template <int NK, int NTW, bool BWD, bool STORE>
+__global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
+    static_assert(NTW == 1 || NTW == 2 || NTW == 4, "square geometries of 128 / 256 / 512 rows and columns");
+    constexpr int R0 = (4 * NK - TM) / 2;
+    static_assert(NK >= 6 && R0 % 4 == 0, "band = 16 + 2 R0 columns, R0 a multiple of 4");
+    constexpr int N0 = NW * NTW * TM;             // rows = columns of the geometry
+    constexpr int XSZ = N0 * WCOL;                // doubles of a strip
+    constexpr int AST = 16;                       // compact band tables (band_products)
+    constexpr bool FOLD = BWD && !STORE;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *const X0 = lds;                       // [N0][16]  the state, layout A (rows x the strip's 16 columns)
+    double *const X1 = lds + XSZ;                 // [N0][16]  the axis-0-filtered distribution, layout B (columns x the strip's 16 rows)
+    double *const As0 = X1 + XSZ;                 // [NK][16]  band of axis 0
+    double *const As1 = As0 + NK * AST;           // [NK][16]  band of axis 1
+    double *const m0s = As1 + NK * AST;           // [N0]      row coordinates
+    double *const red = m0s + N0;                 // [2][NW * 4][5]
+    double *const scal = red + 2 * NW * 4 * 5;    // [NSLOT]
+    double *const iscal = scal + NSLOT;           // [NSLOT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (xch_mode bit 0: chain = block % chains of the launch -- with 8 chains the 32 blocks of a chain run on ONE XCD, observed dispatch order)
+    const int cs = (P.xch_mode & 1) ? (int)(blockIdx.x % (unsigned)P.nslots) : (int)(blockIdx.x / (unsigned)P.strips);
+    const int tj = (P.xch_mode & 1) ? (int)(blockIdx.x / (unsigned)P.nslots) : (int)(blockIdx.x - cs * P.strips);
+    const int b = sldi(P.chain_ids, cs);
+    const int tap0 = sldi(P.tap_id, b), tap1 = sldi(P.tap_id1, b);
+    const int lw0 = tap0 >= 0 ? sldi(P.tap_lw, tap0) : 0, lw1 = tap1 >= 0 ? sldi(P.tap_lw, tap1) : 0;
+    const long long o0 = tap0 >= 0 ? sldi(P.tap_off, tap0) : 0, o1 = tap1 >= 0 ? sldi(P.tap_off, tap1) : 0;
+    const int gj = tj * WCOL + (lane & 15);
+    const long long G = (long long)N0 * N0;
+
+    // ---- prologue (the first step consumes its source unfiltered: identity bands, replaced after step 0) -------------------------------
+    for (int e = tid; e < 2 * NK * AST; e += NT) As0[e] = band_distance16(e % (NK * AST), R0) == 0 ? 1.0 : 0.0;
+    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
+    if (tid < 2 * NSLOT) scal[tid] = 1.0;
+    for (int e = tid; e < XSZ; e += NT) X0[e] = P.src0[(long long)(e >> 4) * N0 + tj * WCOL + (e & 15)];
+    const double g1 = P.m1[gj];
+    const double cA = P.colA[gj], cB = P.colB[gj];
+    double *const pchain = P.post + (long long)b * P.post_stride;
+    const unsigned rowx8 = P.strip_major ? (unsigned)WCOL * 8u : (unsigned)N0 * 8u;
+    const unsigned strip0 = P.strip_major ? (unsigned)tj * (unsigned)(XSZ * 8) : (unsigned)tj * (unsigned)(WCOL * 8);
+    const int row0 = wv * (NTW * TM);
+    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto cell_off = [&](int l, int it, int r) { return __umul24(row0 + it * TM + (l >> 4) + 4 * r, rowx8) + strip0 + (unsigned)(l & 15) * 8u; };
+    // the exchange buffers of this chain slot: [phase][parity][strip][N0][16] tagged elements, one descriptor
+    const blr::Rsrc xr = blr::strip_rsrc(P.xch + (long long)cs * P.xch_chain, (unsigned)(4u * (unsigned)(G * 8)));
+    auto xbuf = [&](int phase, int k) { return (unsigned)(2 * phase + (k & 1)) * (unsigned)(G * 8); };
+    // where a product tile's elements go: the consumer strip is the tile's 16 rows, inside it [this strip's column][row in 16].  After
+    // swap_rows a lane holds two consecutive rows (g & ~1, + 1) of register 2 rp + (g & 1), rp = 0 / 1: one 16-byte store each
+    auto pub_off = [&](int l, int it, int rp) {
+        const int g = l >> 4;
+        return (unsigned)(wv * NTW + it) * (unsigned)(XSZ * 8) + (unsigned)tj * 2048u + (unsigned)(l & 15) * 128u +
+               (unsigned)((g & 2) + 4 * (2 * rp + (g & 1))) * 8u;
+    };
+    // the lane's own cells come back as 16-byte pairs too: a pair = two neighbouring COLUMNS of one row.  The lane of the even column
+    // reads the pairs of its rows g, g + 4 (registers 0, 1), its neighbour those of rows g + 8, g + 12 (registers 2, 3); the two lanes
+    // then hand each other the halves they read for the other (one DPP quad_perm each)
+    auto own_off = [&](int l, int it, int j) {
+        const int c = l & 15, r = 2 * (c & 1) + j;
+        return (unsigned)tj * (unsigned)(XSZ * 8) + (unsigned)(row0 + it * TM + (l >> 4) + 4 * r) * 128u + (unsigned)(c & ~1) * 8u;
+    };
+
+    const int t_first = BWD ? P.T - 1 : 0;
+    double xd[DMAX], xn[DMAX];
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) xd[q] = q < P.d ? P.rec[(long long)t_first * P.rec_len + q] : __builtin_nan("");
+    // backward: the stored alpha of the lane's cells at this step -- requested when the step begins, like the accumulator cells (a request
+    // between the tiles of the epilogue makes the next tile wait for it: the compiler cannot count the accesses in flight across the loop)
+    double al[BWD ? NTW : 1][4];
+    double *const pslot = FOLD ? P.part + (long long)cs * P.part_stride : nullptr;
+    const double wch = FOLD ? P.wchain[b] : 0.0;
+    double inpred = FOLD ? P.infirst[b] : 0.0;
+    double sfn = 1.0;
+    // fold: the accumulator cells of the lane's cells at this step -- requested when the step begins (the two filter phases hide the
+    // latency; between the tiles of the epilogue there is no work that would)
+    double pa[FOLD ? NTW : 1][4];
+    if (wv == SCALE_WAVE || wv == 5 || wv == 0 || wv == NW - 1) __builtin_amdgcn_s_setprio(2);
+    bool dead = false;
+    typedef const double __attribute__((address_space(3))) *lds_cp;
+    unsigned long long gq0 = 0ull, gq1 = 0ull;
+    double Sprev = 1.0;
+    double mq = 1.0, iq = 1.0, dn_prev = -1.0;
+    int nq = 0;
+    __syncthreads();
+
+    // a bounded wait: `again` re-requests what is missing and returns true when everything carries the tag
+    auto wait_for = [&](auto &&all_there, auto &&again) {
+        if (dead || all_there()) return;
+        const unsigned long long t0 = blr::now_ticks();
+        for (unsigned spins = 1;; ++spins) {
+            blr::nap();
+            again();
+            if (all_there()) return;
+            if ((spins & 255u) == 0u) {
+                if (blr::ld_flag(P.abort_word) != 0u) { dead = true; return; }
+                if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; return; }
+            }
+        }
+    };
+    const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
+    // the banded products of the wave's NTW tiles over the strip in `S` (band table `Ab`), each tile published into buffer `dst`
+    auto filter_and_publish = [&](const double *S, const double *Ab, unsigned dst, unsigned bit) {
+        double Bv[NK];
+        {
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            if (edge) {
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, N0) * WCOL + c];
+            } else {
+                const double *s0 = S + (row0 - R0 + g) * WCOL + c;
+#pragma unroll
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NTW; ++it) {
+            const int i = row0 + it * TM;
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            const unsigned aoff = (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u;
+            lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)Ab + aoff);
+            const d4 acc = band_products<NK, 0, NK, AST>(Al, Bv);
+            {
+                double a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+                swap_rows(a0, a1);
+                swap_rows(a2, a3);
+                if (P.xch_mode & 2) {
+                    st_tq2_plain(xr, dst + pub_off(l, it, 0), a0, a1, bit);
+                    st_tq2_plain(xr, dst + pub_off(l, it, 1), a2, a3, bit);
+                } else {
+                    st_tq2(xr, dst + pub_off(l, it, 0), a0, a1, bit);
+                    st_tq2(xr, dst + pub_off(l, it, 1), a2, a3, bit);
+                }
+            }
+            if (it + 1 < NTW) {
+#pragma unroll
+                for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
+                if (edge) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, N0) * WCOL + c];
+                } else {
+                    const double *s1 = S + (i + TM + R0 + g) * WCOL + c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = s1[q * 4 * WCOL];
+                }
+            }
+        }
+    };
+
+    // (option chain_prof: shader-clock stamps of block 0, waves 0 and 2, steps 8 .. 23 -- where a step spends its time)
+    const bool prof_me = P.prof != nullptr && blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 2);
+#define BLX_STAMP(i) do { if (prof_me && k >= 8 && k < 24) P.prof[(wv ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+    for (int k = 0; k < P.T; ++k) {
+        const int t = BWD ? P.T - 1 - k : k;
+        const int tn = (k + 1 < P.T) ? (BWD ? t - 1 : t + 1) : t;
+        const unsigned bit = ax_tag(k);
+        BLX_STAMP(0);
+        // ---- the scale wave's requests (chain_kernel: the sums the scale of step k + 1 is made of were requested a step ago) ------------
+        const bool scale_wave = wv == SCALE_WAVE;
+        const int jn = k + 1;
+        const bool need = scale_wave && jn >= P.lag && jn < P.T;
+        const unsigned long long *gp = P.gran + ((((long long)((jn - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
+        const bool mine = need && lane < P.strips;
+        const unsigned long long hq0 = gq0, hq1 = gq1;
+        if (scale_wave && jn + 1 >= P.lag && jn + 1 < P.T && lane < P.strips) {
+            const unsigned long long *gn = P.gran + ((((long long)((jn + 1 - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
+            gq0 = blr::ld_u64(gn); gq1 = blr::ld_u64(gn + 1);
+        }
+        const double sf_now = sfn;
+        if (FOLD) sfn = P.sfwd[(long long)b * P.T + min(tn + 1, P.T - 1)];
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
+
+        // ---- P1: axis 0 in layout A -> the strips of layout B -----------------------------------------------------------------------------
+        filter_and_publish(X0, As0, xbuf(0, k), bit);
+        BLX_STAMP(1);
+        // ---- this block's layout-B strip -> X1 (a plain copy: XSZ elements, 512 contiguous bytes per wave access) --------------------------
+        {
+            constexpr int NG = XSZ / NT / 2;      // 16-byte pairs per thread: 2 (128 rows) .. 8 (512 rows), all in flight at once
+            Tq2 fq[NG];
+            const unsigned base = xbuf(0, k) + (unsigned)tj * (unsigned)(XSZ * 8) + (unsigned)tid * 16u;
+            auto issue = [&]() {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) fq[j] = ld_tq2(xr, base + (unsigned)j * (unsigned)(NT * 16));
+            };
+            auto there = [&]() {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) ok = ok && blr::tq_ok(fq[j].a, bit) && blr::tq_ok(fq[j].b, bit);
+                return ok;
+            };
+            issue();
+            wait_for(there, issue);
+            BLX_STAMP(2);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                X1[2 * (tid + j * NT)] = blr::tq_value(fq[j].a);
+                X1[2 * (tid + j * NT) + 1] = blr::tq_value(fq[j].b);
+            }
+        }
+        // (the stored alpha / accumulator cells of this step: requested HERE -- behind the gather, whose tagged loads must not queue behind
+        //  HBM loads (loads return in order), and a whole filter phase ahead of the epilogue that consumes them)
+        if (BWD) {
+            const int l = fresh_lane();
+            const double *const pnow = pchain + (long long)t * G;
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) al[BWD ? it : 0][r] = ldnt(pnow, cell_off(l, it, r));
+        }
+        if (FOLD) {
+            const int l = fresh_lane();
+            const double *abase = P.part_fresh ? P.zeros : pslot + (long long)t * G;
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned aoffs = cell_off(l, it, r);
+                    pa[FOLD ? it : 0][r] = ldnt(abase, P.part_fresh ? (aoffs & 4088u) : aoffs);
+                }
+        }
+        __syncthreads();
+        BLX_STAMP(3);
+        // ---- P2: axis 1 in layout B -> the strips of layout A -----------------------------------------------------------------------------
+        filter_and_publish(X1, As1, xbuf(1, k), bit);
+        BLX_STAMP(4);
+
+        // ---- P3: the lane's own cells back + the fused epilogue (chain_kernel's) -----------------------------------------------------------
+        Tq2 oq[NTW][2];
+        auto issue_own = [&]() {
+            const int l = fresh_lane();
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) oq[it][j] = ld_tq2(xr, xbuf(1, k) + own_off(l, it, j));
+        };
+        issue_own();
+        // the scale of this step; the scale wave prepares the next one (see chain_kernel)
+        const double scale = scal[k & (NSLOT - 1)];
+        if (FOLD && k > 0) inpred *= sf_now * iscal[k & (NSLOT - 1)];
+        const double wq = FOLD ? wch * inpred : 0.0, wfloor = FOLD ? wch * 1e-300 : 0.0;
+        if (scale_wave) {
+            double sj = 1.0;
+            if (need) {
+                const unsigned long long want = (unsigned long long)(unsigned)(jn - P.lag + 1);
+                unsigned long long q0 = hq0, q1 = hq1;
+                bool ok = !mine || ((q0 >> 32) == want && (q1 >> 32) == want);
+                if (!dead && !__all(ok)) {
+                    const unsigned long long t0 = blr::now_ticks();
+                    for (unsigned spins = 1; !__all(ok); ++spins) {
+                        if (!ok) { q0 = blr::ld_u64(gp); q1 = blr::ld_u64(gp + 1); ok = (q0 >> 32) == want && (q1 >> 32) == want; }
+                        blr::nap();
+                        if ((spins & 255u) == 0u) {
+                            if (blr::ld_flag(P.abort_word) != 0u) { dead = true; break; }
+                            if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; break; }
+                        }
+                    }
+                }
+                const double v = mine ? __longlong_as_double((long long)((q0 & 0xffffffffull) | (q1 << 32))) : 0.0;
+                const double Sg = blk::wave_sum(v);
+                sj = dead ? 1.0 : Sprev * scal[(jn - P.lag) & (NSLOT - 1)] / Sg;
+                Sprev = Sg;
+            }
+            if (lane == 0) { scal[jn & (NSLOT - 1)] = sj; if (FOLD) iscal[jn & (NSLOT - 1)] = 1.0 / sj; }
+        }
+        double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
+        double *const pstep = pchain + (long long)t * G;
+        double *const pslot_t = FOLD ? pslot + (long long)t * G : nullptr;
+        {
+            auto there = [&]() {
+                bool ok = true;
+#pragma unroll
+                for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) ok = ok && blr::tq_ok(oq[it][j].a, bit) && blr::tq_ok(oq[it][j].b, bit);
+                return ok;
+            };
+            wait_for(there, issue_own);
+        }
+        BLX_STAMP(5);
+        double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
+        int nE = 0, nR = 0;
+#pragma unroll
+        for (int it = 0; it < NTW; ++it) {
+            const int i = row0 + it * TM;
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            double acc[4];
+            {
+                const bool odd = (c & 1) != 0;
+                const double k0 = blr::tq_value(odd ? oq[it][0].b : oq[it][0].a), k1 = blr::tq_value(odd ? oq[it][1].b : oq[it][1].a);     // the lane's own column
+                const double s0 = blr::tq_value(odd ? oq[it][0].a : oq[it][0].b), s1 = blr::tq_value(odd ? oq[it][1].a : oq[it][1].b);     // its neighbour's
+                const double r0 = blk::dpp_src<0xB1, 0xf>(s0, 0.0), r1 = blk::dpp_src<0xB1, 0xf>(s1, 0.0);                              // quad_perm [1, 0, 3, 2]
+                acc[0] = odd ? r0 : k0; acc[1] = odd ? r1 : k1; acc[2] = odd ? k0 : r0; acc[3] = odd ? k1 : r1;
+            }
+            if (it == 0) {
+                // anchor of the stride-4 likelihood recurrence of this lane's rows (observationModels.py:566-567; blhip_mfma.hpp)
+                const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
+                double a0 = 0.0, s1 = 0.0, dn = 0.0;
+#pragma unroll
+                for (int q = 0; q < DMAX; ++q) {
+                    const double x = xd[q];
+                    if (x == x) {
+                        const double dq = x - mu0;
+                        a0 = fma(-(dq * dq), cA, a0) - cB;
+                        s1 += (x - mu0) + (x - mu4);
+                        dn += 1.0;
+                    }
+                }
+                const double d1 = cA * (mu4 - mu0) * s1;
+                const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                exp_mn(a0, mE, nE);
+                exp_mn(d1, mR, nR);
+                if (dn != dn_prev) {
+                    int tmp;
+                    exp_mn(d2, mq, nq);
+                    if (BWD) exp_mn(-d2, iq, tmp);
+                    dn_prev = dn;
+                }
+                if (BWD) { iE = blmath::inv_m(mE); iR = blmath::inv_m(mR); }
+                else mE *= scale;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int li = i + g + 4 * r;
+                const double Lv = ldexp(mE, nE);
+                const unsigned off = cell_off(l, it, r);
+                if (!BWD) {
+                    const double a = acc[r] * Lv;
+                    X0[li * WCOL + c] = a;
+                    if (STORE) stnt(pstep, off, a);
+                    sN += a;
+                    acc[r] = a;
+                } else {
+                    const double beta = acc[r] * scale;
+                    const double p = al[BWD ? it : 0][r] * beta;
+                    const double cn = beta * Lv;
+                    const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);      // p / L; 0 / 0 -> NaN (core.py:463)
+                    X0[li * WCOL + c] = cn;
+                    if (!FOLD) stnt(pstep, off, p);
+                    else stnt(pslot_t, off, pa[FOLD ? it : 0][r] + fmax(p * wq, wfloor));
+                    sN += p;
+                    sS += pl;
+                    sC += cn;
+                    acc[r] = p;
+                }
+                mE *= mR; nE += nR;
+                mR *= mq; nR += nq;
+                if (BWD) { iE *= iR; iR *= iq; }
+            }
+            if ((BWD || STORE) && P.means) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sM0 = fma(acc[r], m0s[i + g + 4 * r], sM0); sM1 = fma(acc[r], g1, sM1); }
+            }
+        }
+
+        BLX_STAMP(6);
+        // ---- sums: waves -> LDS; after the barrier wave 5 adds them up, writes the strip's partial sums, publishes the granule ------------
+        double v[5] = {sN, sS, BWD ? sC : sM0, BWD ? sM0 : sM1, sM1};
+        constexpr int NV = BWD ? 5 : 4;
+        const int nv = BWD ? (P.means ? 5 : 3) : (P.means ? 4 : 1);
+        double *rk = red + (k & 1) * (NW * 4 * 5);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if (q < nv) {
+                double x = v[q];
+                x = blk::dpp_add<0x111, 0xf>(x);
+                x = blk::dpp_add<0x112, 0xf>(x);
+                x = blk::dpp_add<0x114, 0xf>(x);
+                x = blk::dpp_add<0x118, 0xf>(x);
+                if ((lane & 15) == 15) rk[(wv * 4 + (lane >> 4)) * 5 + q] = x;
+            }
+        }
+        __syncthreads();
+        BLX_STAMP(7);
+        if (k == 0) {            // the chain's bands replace the identities of the first step
+            for (int e = tid; e < NK * AST; e += NT) {
+                const int a = band_distance16(e, R0);
+                As0[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);
+                As1[e] = a == 0 ? (lw1 > 0 ? P.taps[o1] : 1.0) : (a <= lw1 ? P.taps[o1 + a] : 0.0);
+            }
+            __syncthreads();
+        }
+        if (wv == 5 && lane < nv) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW * 4; ++w) tot += rk[w * 5 + lane];
+            const int slot = BWD ? lane : (lane < 2 ? lane : lane + 1);
+            if (lane == 0 || (BWD ? (P.means || lane < 3) : (lane != 1 && P.means != 0)))
+                P.psum[(((long long)t * P.B + b) * NRED + slot) * P.nblk + tj] = tot;
+            if (lane == (BWD ? 2 : 0)) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
+                const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
+                unsigned long long *gw = P.gran + ((((long long)(k & (NSLOT - 1)) * P.nslots + cs) * P.strips + tj) << 1);
+                blr::st_u64(gw, tag | (bits & 0xffffffffull));
+                blr::st_u64(gw + 1, tag | (bits >> 32));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q) xd[q] = xn[q];
+    }
+#undef BLX_STAMP
+}
+
+}  // namespace blc

@@ -95,6 +95,11 @@ struct ChainParams {
     unsigned long long *prof;    // development builds (-DBLC_PROF): [2 waves][16 steps][16 stamps] shader-clock stamps of block 0
     // (last: the fields above keep their offsets -- the two-chain kernel's register allocation is sensitive to how the argument block loads)
     const double *lik;           // TAB kernels: the likelihood of every step, [T][n0 * n1] row-major (table models: built on the device or by the caller)
+    // blc::chainax_kernel (blhip_chainax.hpp: walks on BOTH parameters, the distribution is transposed between the two filters)
+    const int *tap_id1;          // [B] the chain's axis-1 kernel in the tap table, -1 = none
+    double *xch;                 // [nslots][2 phases][2 parities][n0 * n1] tagged elements: the exchange buffers (zeroed before every launch)
+    long long xch_chain;         // doubles between the buffers of two chain slots (4 n0 n1)
+    int xch_mode;                // experiments (option chain_ax1_mode): bit 0 = the blocks of a chain share an XCD (block b runs on XCD b % 8), bit 1 = plain publishing stores
 };
 
 // The kernel arguments arrive as 16-register tuples (s_load_dwordx16) and the register allocator spills and restores a tuple as ONE

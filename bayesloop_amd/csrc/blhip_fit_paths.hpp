@@ -226,6 +226,9 @@ struct ChainRun {
     // the batch's sequence buffer is read only by this fit's own backward pass / fold: free to use the kernel's strip-major layout
     bool post_private = false;
     bool tab = false;                              // the likelihood comes out of a table (blc::chain_kernel TAB)
+    bool ax1 = false;                              // walks on both parameters: blc::chainax_kernel (the distribution is transposed between the filters)
+    size_t xch_bytes = 0;
+    int ax_mode = -1;                              // option chain_ax1_mode (-1: per launch, see pass())
     // a padded grid whose sequence is NOT private (an ordinary fit that keeps its posteriors): the kernels work on a scratch sequence on
     // the padded geometry (blhip_ctx::postpad), depad_kernel writes the grid's rows into the sequence everybody else reads
     bool depad = false;
@@ -259,21 +262,27 @@ struct ChainRun {
         // ones, evaluated by the caller otherwise: blc::chain_kernel TAB, geometries of <= 512 rows -- padded grids too --, radius <= 40, one chain per block)
         const bool gauss = E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && E.d <= blc::DMAX;
         tab = E.p->obs_model == BLHIP_OM_TABLE && E.DT->lik != nullptr && ctx->option("chain_table", 1.0) != 0.0;
+        // walks on the second parameter too: the transposing kernels (blc::chainax_kernel; Gaussian recurrence, exact square geometries)
+        const bool may_ax1 = gauss && !tab && prog.LW1 > 0 && ctx->option("chain_ax1", 1.0) != 0.0;
         if (fast && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
-            !prog.has_clamp && prog.LW1 == 0 && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
+            !prog.has_clamp && (prog.LW1 == 0 || may_ax1) && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
             (!chain_tall(E.g.n0) || ctx->option("chain_tall", 1.0) != 0.0)) {
             cp.r0_max = (!tab && ctx->option("chain_wide", 1.0) != 0.0) ? CHAIN_R0_MAX : FAST_R0_MAX;
+            cp.allow_ax1 = may_ax1;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
             if (on && tab && cp.ntw > 4) on = false;
+            if (on && prog.LW1 > 0 && !cp.ax1) on = false;
         }
         if (!on) return;
+        ax1 = cp.ax1;
         Gk = (long long)cp.n0p * cp.n1p;
         // (granule slots for 2 x cpr chains: the two-chain fold kernel runs rounds of that size)
         gran_bytes = carve_size((size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2 * 8);
-        ctx->resx.ensure(carve_size((size_t)B * 4) * 3 + gran_bytes + carve_size(64) + 2 * carve_size((size_t)T * B));
+        ctx->resx.ensure(carve_size((size_t)B * 4) * 4 + gran_bytes + carve_size(64) + 2 * carve_size((size_t)T * B));
         char *rc = ctx->resx.as<char>();
         d_order = carve<int>(rc, (size_t)B);
         int *d_tapid = carve<int>(rc, (size_t)B);
+        int *d_tapid1 = carve<int>(rc, (size_t)B);
         d_tshare = carve<int>(rc, (size_t)B);
         CQ.gran = carve<unsigned long long>(rc, (size_t)blc::NSLOT * 2 * cp.cpr * cp.strips * 2);
         d_abort = carve<unsigned>(rc, 16);
@@ -286,7 +295,14 @@ struct ChainRun {
         }
         HIPCHECK(hipMemcpyAsync(d_order, cp.order.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
+        HIPCHECK(hipMemcpyAsync(d_tapid1, cp.tap_id1.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
+        if (ax1) {               // the exchange buffers of a launch's chain slots: [slot][2 phases][2 parities][G] tagged elements
+            xch_bytes = (size_t)cp.cpr * 4 * (size_t)Gk * 8;
+            ctx->xch.ensure(xch_bytes);
+            CQ.xch = ctx->xch.as<double>(); CQ.xch_chain = 4 * Gk; CQ.tap_id1 = d_tapid1;
+            ax_mode = (int)ctx->option("chain_ax1_mode", -1.0);
+        }
         CQ.n0 = cp.n0p; CQ.n1 = cp.n1p; CQ.n0t = E.g.n0; CQ.n1t = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = tab ? 0 : E.d; CQ.rec_len = E.rec_len;
         CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
         CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
@@ -311,7 +327,7 @@ struct ChainRun {
             fused = aligned;
         }
         slots_used = (int)std::min<int64_t>(cp.cpr, B);
-        if (fused && !tab && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0) {      // (the two-chain kernel has no table flavour)
+        if (fused && !tab && !ax1 && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0) {      // (the two-chain kernel has no table / both-axes flavour)
             fold2 = true;
             const int per = 2 * cp.cpr;
             for (int64_t s0 = 0; s0 < B; s0 += per) {
@@ -419,7 +435,35 @@ struct ChainRun {
             HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
             Q.prof = ctx->small.as<unsigned long long>();
 #endif
-            if (two) launch_fold2(st, Q, rnk[r], cp.ntw, cp.pad);
+            if (ax1) {
+                HIPCHECK(hipMemsetAsync(CQ.xch, 0, xch_bytes, st));           // (tags restart with every launch)
+                // a launch of 8 chains: the 32 blocks of a chain on ONE XCD (block b runs on XCD b % 8 -- observed, for speed only) and plain
+                // publishing stores, which keep the lines in that XCD's L2 for the consumers (write-through stores drop them: MI355X_MICROARCH.md);
+                // any other launch: write-through stores, whose visibility does not depend on the placement
+                Q.xch_mode = ax_mode >= 0 ? ax_mode : (Q.nslots == 8 ? 3 : 0);
+                const bool prof = ctx->option("chain_prof", 0.0) != 0.0;
+                if (prof) {
+                    ctx->small.ensure(2 * 16 * 16 * 8);
+                    HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
+                    Q.prof = ctx->small.as<unsigned long long>();
+                }
+                launch_chainax(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
+                if (prof) {          // where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
+                    unsigned long long hh[2 * 16 * 16];
+                    HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
+                    sync_stream(ctx, st);
+                    static const char *names[8] = {"start", "P1+publish", "gather", "barrier", "P2+publish", "own cells", "epilogue", "sums+barrier"};
+                    for (int wvi = 0; wvi < 2; ++wvi) {
+                        const unsigned long long *h = hh + wvi * 256;
+                        double acc[8] = {0}; int n = 0;
+                        for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                        std::fprintf(stderr, "[blc ax prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", rnk[r], wvi ? 2 : 0, n);
+                        double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                        std::fprintf(stderr, " | total %.0f\n", tot);
+                    }
+                }
+            }
+            else if (two) launch_fold2(st, Q, rnk[r], cp.ntw, cp.pad);
             else launch_chain(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only), cp.pad);
             {   // HBM: only what the fit keeps -- forward the stored state (8 B; nothing for evidence-only fits), backward the stored
                 // state in + the posterior out (16 B) or + the read-modify-write of the partial accumulator (24 B; shared by the two
@@ -427,7 +471,10 @@ struct ChainRun {
                 double cells = (double)Q.nslots * Gk * T;
                 if (!bwd && skip_prefix)               // (chain-steps the forward pass does not run)
                     for (int q = rstart[r]; q < rstart[r + 1]; ++q) cells -= (double)h_tshare[cp.order[q]] * Gk;
-                const double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
+                double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
+                // (both-axes kernels: the two transposing exchanges of a step leave the XCD's L2 as well -- 2 x (8 written + 8 read);
+                //  with the blocks of a chain on one XCD the reads mostly hit that L2: the PMC counters say what really moves)
+                if (ax1) bytes += 32.0;
                 const int r0 = (4 * rnk[r] - blc::TM) / 2;
                 double shared = 0.0;                                  // stored states not written (forward) / read once per launch instead of once per chain (backward)
                 if (share_prefix && (bwd ? fold_now : !E.ff.evidence_only)) {
@@ -437,7 +484,7 @@ struct ChainRun {
                 }
                 // (tabulated likelihood: the table of the pass is read once per launch -- its chains read the same rows at about the same time)
                 const double table = tab ? (double)T * Gk * 8.0 : 0.0;
-                account(ctx, bwd, cells * bytes - shared + table, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
+                account(ctx, bwd, cells * bytes - shared + table, cells * ((rnk[r] > 4 ? band_stencil_flop(r0) * (ax1 ? 2.0 : 1.0) : 0.0) + (bwd ? EPI_BWD_FLOP : EPI_FWD_FLOP)));
             }
 #ifdef BLC_PROF
             {   // development build: where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)

@@ -917,6 +917,39 @@ def test_seeded_random_wide_axis1_walks_match_oracle(seed):
         assert S.lastTiming['fwd_kernel_variant'] in (1, 3) or (lw1 == 0 and S.lastTiming['fwd_kernel_variant'] == 6), (lw0, lw1, n0, n1, S.lastTiming)
 
 
+@pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 24))))
+def test_seeded_random_both_axes_walks_on_square_grids_take_the_transposing_chain_kernels(seed):
+    """Random walks on BOTH parameters of a square grid (128 / 256 points per axis, radii up to 40): blc::chainax_kernel keeps the chains
+    resident and transposes the distribution between the two filters (blhip_chainax.hpp) -- against the oracle at the parity bar, and
+    against the launch-per-step path (option chain_ax1 = 0: pre-pass + streaming kernels) of the same build."""
+    c = random_cases.random_both_axes_square_case(seed)
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    tm = S.lastTiming
+    ok = (6,) if c['study'] == 'HyperStudy' else (5, 6)          # (a single chain with radii <= 8 on both axes: the time-resident kernel)
+    assert tm['fwd_kernel_variant'] in ok and tm['resident_fallbacks'] == 0, tm
+    if not (c['fit'].get('evidenceOnly') or c['fit'].get('forwardOnly')):
+        assert tm['bwd_kernel_variant'] in ok, tm
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+    eng = bl.get_engine()
+    eng.set_option('chain_ax1', 0)
+    try:
+        S0 = cases.build(bl, c)
+        with np.errstate(all='ignore'):
+            S0.fit(**cases.fit_kwargs(c))
+        assert S0.lastTiming['fwd_kernel_variant'] != 6, S0.lastTiming
+    finally:
+        eng.set_option('chain_ax1', 1)
+    np.testing.assert_allclose(S.logEvidence, S0.logEvidence, rtol=1e-11)
+
+
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 32))))
 def test_seeded_random_hyper_studies_match_oracle(seed):
     c = random_cases.random_hyper_case(seed)
@@ -1273,6 +1306,8 @@ def test_bench_workloads_full_fit_against_full_size_reference(name):
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_%s_full.npz' % name))
     S, kw, units, desc = bench.make_study(bl, name)
     S.fit(silent=True)
+    if name == 'c4_both_axes':           # (round 5: the transposing chain-resident kernels, blhip_chainax.hpp)
+        assert S.lastTiming['fwd_kernel_variant'] == 6 and S.lastTiming['bwd_kernel_variant'] == 6 and S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
     assert abs(S.logEvidence - float(gold['logEvidence'])) <= 1e-9 * abs(float(gold['logEvidence']))
     ge = gold['localEvidence']
     assert np.array_equal(np.isnan(S.localEvidence), np.isnan(ge))
