@@ -200,7 +200,7 @@ size_t lds_need(int TI, int TJ, int LW0, int LW1) {
 
 Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1, bool whole_row = false) {
     Tile t{};
-    size_t cap = (size_t)ctx->option("lds_cap_bytes", 64 * 1024);
+    size_t cap = (size_t)64 * 1024;
     int TI, TJ;
     if (g.n0 == 1 && whole_row) {                // (a two-stage spline shift: one block per chain holds the whole row)
         TI = 1;
@@ -208,10 +208,10 @@ Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1, bool
         cap = 160 * 1024 - 512;
     } else if (g.n0 == 1) {
         TI = 1;
-        TJ = (int)ctx->option("tile_1d", g.n1 <= 65536 ? 256 : 1024);
+        TJ = g.n1 <= 65536 ? 256 : 1024;
     } else {
-        TI = (int)ctx->option("tile_i", 16);
-        TJ = (int)ctx->option("tile_j", 128);
+        TI = 16;
+        TJ = 128;
     }
     TI = std::max(1, std::min(TI, g.n0));
     TJ = std::max(1, std::min(TJ, g.n1));
@@ -558,9 +558,9 @@ void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pa
 }
 
 // tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
-// (tools/ubench/fp64_banks.hip), so more waves per SIMD help.  The 128 x 128 tile has two shapes: 512 threads (segments of 32, chunks
-// of 8, ~200 registers, 2 waves per SIMD) and -- option resident_threads128 = 1024, forward passes of evidence-only fits only -- 1024
-// threads (segments of 16, the whole window in registers before the barrier, 128 registers, 4 waves per SIMD)
+// (tools/ubench/fp64_banks.hip), so more waves per SIMD help.  The 128 x 128 tile runs with 512 threads (segments of 32, chunks of 8,
+// ~200 registers, 2 waves per SIMD).  (A 1024-thread shape -- option resident_threads128 -- was never selected by a test or a workload
+// and measured no faster: pruned in round 5, profiles/r05_kernel_census.txt.)
 void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
     if (Q.lik) {
         if (rp.TR == 64) launch_resident_tab<64, 64, 8, 8>(s, Q, bwd, rp.pad);
@@ -570,11 +570,7 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
         HIPCHECK(hipGetLastError());
         return;
     }
-    if (rp.TR == 128 && rp.SEG == 16) {
-        if (bwd || Q.store || Q.means || Q.normalise || Q.post) fail("internal: the 1024-thread resident shape runs evidence-only forward passes only");
-        launch_resident_k<128, 128, 16, 4, false, 1>(s, Q);
-    }
-    else if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd, rp.pad);
+    if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd, rp.pad);
     else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd, rp.pad);
     else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd, rp.pad);
     else launch_resident_t<32, 32, 8, 8>(s, Q, bwd, rp.pad);
@@ -585,7 +581,7 @@ void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams
 void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
     if (Q.lik) {                         // tabulated likelihood (blc::chain_kernel TAB): geometries of <= 512 rows, radius <= 40
         if (nk > 24 || ntw > 4) fail("internal: chain-resident launch with a likelihood table outside its envelope");
-        if (pad) { if (ntw >= 3) blcl::chain_ntw34_tab_pad(s, Q, nk, ntw, bwd, store); else blcl::chain_ntw12_tab_pad(s, Q, nk, ntw, bwd, store); }
+        if (pad) { if (ntw >= 3) fail("internal: padded chain-resident launch with a likelihood table on %d tiles per wave", ntw); else blcl::chain_ntw12_tab_pad(s, Q, nk, ntw, bwd, store); }
         else if (ntw >= 3) blcl::chain_ntw34_tab(s, Q, nk, ntw, bwd, store); else blcl::chain_ntw12_tab(s, Q, nk, ntw, bwd, store);
         HIPCHECK(hipGetLastError());
         return;
@@ -630,7 +626,9 @@ void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
 // A grid that does not fill its last tile row / column runs the PAD kernels (blhip_resident.hpp): the remainder of such an axis and the
 // padding behind it must both be at least one stencil radius (the mirror image beyond the true edge lives inside the last tile and is
 // made of that tile's own cells).  Grids whose sizes are multiples of a tile shape are preferred (no masks).
-bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp, int seg128 = 32, bool allow_pad = true, int min_tile = 32) {
+bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp) {
+    constexpr int seg128 = 32, min_tile = 32;
+    constexpr bool allow_pad = true;
     // preference: 64 x 64 tiles first (measured on 128^2 .. 512^2 grids, tools/tile_probe.py: 5.7 / 6.7 us per forward / backward step
     // against 9.0 / 10.1 us with 32 x 32 tiles -- two waves per block are too few to hide the hand-offs -- and 10.8 / 20.8 us with 128 x 128),
     // whole tiles before a padded last tile row / column of the same shape; 128 x 128 only when the smaller shapes need more than one tile per CU
@@ -640,7 +638,6 @@ bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp, int seg128 = 32, b
             auto fits = [&](int n, int t) { const int rem = n % t; return pass == 0 ? rem == 0 : (rem == 0 || (n > t && rem >= blr::R && t - rem >= blr::R)); };
             if (sh[0] < min_tile && sh[1] < 2 * min_tile) continue;
             if (!fits(n0, sh[0]) || !fits(n1, sh[1])) continue;
-            if (pass == 1 && sh[0] == 128 && seg128 != 32) continue;       // (the 1024-thread option shape has no PAD variant)
             const int tr = (n0 + sh[0] - 1) / sh[0], tc = (n1 + sh[1] - 1) / sh[1];
             const long long nt = (long long)tr * tc;
             if (nt > cus) continue;
@@ -1289,7 +1286,7 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
     const bool shift1d = p->ndim == 1 && prog.has_clamp && !prog.other_clamp && ctx->option("chain1d_shift", 1.0) != 0.0;
     if (p->ndim == 1 && !gp.fast && (!prog.has_clamp || shift1d) && ctx->option("fuse1d", 8.0) >= 1.0 &&
         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
-        gp.f1_TJ = std::max(32, (int)ctx->option("fuse1d_tj", 128));
+        gp.f1_TJ = 128;
         gp.fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
         // keep the redundantly recomputed halo (K * LW cells per side) within ~4x the owned cells and the window in LDS
         while (gp.fusedK > 1 && (gp.fusedK * prog.LW1 > 2 * gp.f1_TJ || (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 > 96 * 1024)) --gp.fusedK;
@@ -1436,7 +1433,7 @@ void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram 
     }
     if (fast) {
         // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle: a radius bucket with fewer blocks joins the next one
-        const long long min_blocks = (long long)ctx->option("min_bucket_blocks", 128.0);
+        const long long min_blocks = 128;
         const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)nblk - 1) / nblk);
         // (wideH: the axis-1 filters wider than the fused kernels' 8 columns run in the pre-pass, and the fused kernels of those chains are
         //  launched without an axis-1 part; chains of the same step with a narrow filter or none keep their fused kernels -- unless the
@@ -1919,14 +1916,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     // (cuts on radius-bucket boundaries serve the launch-per-step kernels; grids the chain-resident kernel takes keep whole launches)
     const bool chain_shape = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || (p->obs_model == BLHIP_OM_TABLE && g.n0 <= 512)) && chain_rows_ok(g.n0) && g.n1 <= 16 * blc::MAX_STRIPS &&
                              ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok;
-    std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && !chain_shape && ctx->option("bucket_batches", 1.0) != 0.0);
+    std::vector<int64_t> batch_start = plan_batches(p, n_chains, op_values, Bmax, !overlap_acc && !chain_shape);
     if (overlap_acc) {                     // (equal batches, multiples of 32 chains: whole launches of the chain-resident kernel)
         batch_start.clear();
         for (int64_t c = 0; c < n_chains; c += Bmax) batch_start.push_back(c);
         batch_start.push_back(n_chains);
     }
     // (the cut: 40; grids the chain-resident kernels take: 80)
-    const bool chain_wide = chain_shape && p->obs_model == BLHIP_OM_GAUSSIAN && (!chain_tall(g.n0) || ctx->option("chain_tall", 1.0) != 0.0) && ctx->option("chain_wide", 1.0) != 0.0;
+    const bool chain_wide = chain_shape && p->obs_model == BLHIP_OM_GAUSSIAN && ctx->option("chain_wide", 1.0) != 0.0;
     if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0)
         split_wide_axis0(p, n_chains, op_values, batch_start, chain_wide ? CHAIN_R0_MAX : FAST_R0_MAX);
     const int64_t nbatch = (int64_t)batch_start.size() - 1;
@@ -1967,7 +1964,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     };
     std::thread builder;
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } builder_guard{builder};      // (also when a batch throws)
-    const bool build_ahead = nbatch > 1 && ctx->option("build_ahead", 1.0) != 0.0;
+    const bool build_ahead = nbatch > 1;
     for (int64_t bi = 0; bi < nbatch; ++bi) {
         const int64_t c0 = batch_start[bi], B = batch_start[bi + 1] - c0;
         tr.mark("batch setup");
@@ -2295,7 +2292,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             {   // the pass's weights spelled out per (step, chain): the kernel stages a superstep's weights with ONE load per element
                 const long long TB = (long long)T * B;
                 const size_t wb = carve_size((size_t)TB * (P1.LW + 1) * 8), lb = carve_size((size_t)TB * 4);
-                if (wb + lb <= ((size_t)256 << 20) && ctx->option("persist1d_wtab", 1.0) != 0.0) {
+                if (wb + lb <= ((size_t)256 << 20)) {
                     ctx->p1w.ensure(wb + lb);
                     char *wc = ctx->p1w.as<char>();
                     double *wtab = carve<double>(wc, (size_t)TB * (P1.LW + 1));

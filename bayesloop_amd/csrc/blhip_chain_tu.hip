@@ -6,7 +6,7 @@
 #ifndef BLC_TU
 #define BLC_TU 0        // (no slice selected -- a bare `hipcc -c` of this file: an empty object; build.py passes -DBLC_TU=1 .. N_SLICES)
 #endif
-#if BLC_TU >= 20
+#if BLC_TU >= 19
 #include "blhip_chainax.hpp"      // (only the slices that hold its kernels: an edit of that header recompiles three units)
 #endif
 
@@ -123,7 +123,7 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
 }
 #undef BLC_CASE
 
-#if BLC_TU >= 20
+#if BLC_TU >= 19
 // walks on both parameters: forward (stored / evidence-only), backward (stored / folded); ring lengths 8 .. 24 in steps of 4
 template <int NK, int NTW>
 void launch_k_ax(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
@@ -247,20 +247,14 @@ void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int n
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
 }
 #elif BLC_TU == 19
-void chain_ntw34_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
-    if (ntw == 4) launch_w_tab<4, true>(s, Q, nk, bwd, store);
-    else if (ntw == 3) launch_w_tab<3, true>(s, Q, nk, bwd, store);
-    else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
-}
-#elif BLC_TU == 20
 void chainax_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
     if (ntw == 2) launch_w_ax<2>(s, Q, nk, bwd, store);
     else if (ntw == 1) launch_w_ax<1>(s, Q, nk, bwd, store);
     else fail("internal: both-axes chain-resident kernel with %d tiles per wave", ntw);
 }
-#elif BLC_TU == 21
+#elif BLC_TU == 20
 void chainax_ntw4_fwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) { launch_w_ax4<false>(s, Q, nk, store); }
-#elif BLC_TU == 22
+#elif BLC_TU == 21
 void chainax_ntw4_bwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) { launch_w_ax4<true>(s, Q, nk, store); }
 #else
 #error "BLC_TU out of range"

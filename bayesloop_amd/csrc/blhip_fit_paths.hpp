@@ -78,8 +78,7 @@ struct ResidentRun {
         const bool tab = E.p->obs_model == BLHIP_OM_TABLE && E.DT->lik != nullptr && ctx->option("resident_table", 1.0) != 0.0;
         if (fast && n_chains == 1 && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
             prog.LW0 <= blr::R && prog.LW1 <= blr::R && ctx->option("resident", 1.0) != 0.0 && ctx->resident_ok &&
-            plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp,
-                          (E.ff.evidence_only && ctx->option("resident_threads128", 512.0) == 1024.0) ? 16 : 32, ctx->option("resident_pad", 1.0) != 0.0, (int)ctx->option("resident_min_tile", 32.0))) {
+            plan_resident(E.g.n0, E.g.n1, std::min(ctx->num_cus, 256), rp)) {
             on = prog.kindF[0] == SRC_PRIOR && (!full || prog.kindB[T - 1] == SRC_UNIFORM);
             // (the padded 128 x 128 BACKWARD kernel spills 231 registers: 2000 x 1100, backward step 40 - 45 us against 26.8 us with one
             //  launch per step -- full fits of such grids keep the launch-per-step kernels, evidence-only / forward-only fits do not)
@@ -266,11 +265,12 @@ struct ChainRun {
         const bool may_ax1 = gauss && !tab && prog.LW1 > 0 && ctx->option("chain_ax1", 1.0) != 0.0;
         if (fast && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
             !prog.has_clamp && (prog.LW1 == 0 || may_ax1) && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
-            (!chain_tall(E.g.n0) || ctx->option("chain_tall", 1.0) != 0.0)) {
+            true) {
             cp.r0_max = (!tab && ctx->option("chain_wide", 1.0) != 0.0) ? CHAIN_R0_MAX : FAST_R0_MAX;
             cp.allow_ax1 = may_ax1;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
             if (on && tab && cp.ntw > 4) on = false;
+            if (on && tab && cp.pad && cp.ntw >= 3) on = false;      // (padded 384 / 512-row geometries with a likelihood table: no kernel -- never selected by a test or workload, pruned in round 5)
             if (on && prog.LW1 > 0 && !cp.ax1) on = false;
         }
         if (!on) return;

@@ -154,7 +154,6 @@ struct Trace {
 };
 
 void sync_stream(blhip_ctx *ctx, hipStream_t st) {
-    if (ctx->option("spin_sync", 1.0) == 0.0) { HIPCHECK(hipStreamSynchronize(st)); return; }
     HIPCHECK(hipEventRecord(ctx->sync_ev, st));
     for (;;) {
         const hipError_t e = hipEventQuery(ctx->sync_ev);

@@ -374,6 +374,8 @@ def kernel_direction(name):
             return 'backward' if targ('resident_kernel<', 4) in ('true', '1') else 'forward'
         if 'chain_fold2_kernel<' in name:              # blc::chain_fold2_kernel<NK, NTW>: backward pass + fused fold, two chains per block
             return 'backward'
+        if 'chainax_kernel<' in name:                  # blc::chainax_kernel<NK, NTW, BWD, STORE>: walks on both parameters (blhip_chainax.hpp)
+            return 'backward' if targ('chainax_kernel<', 2) in ('true', '1') else 'forward'
         if 'chain_kernel<' in name:                    # blc::chain_kernel<NK, NTW, BWD, STORE>
             return 'backward' if targ('chain_kernel<', 2) in ('true', '1') else 'forward'
         if 'fused1d_kernel<' in name:
