@@ -604,8 +604,9 @@ void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
 }
 
 // walks on both parameters (blc::chainax_kernel, blhip_chainax.hpp)
-void launch_chainax(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
-    if (ntw == 4) { if (bwd) blcl::chainax_ntw4_bwd(s, Q, nk, store); else blcl::chainax_ntw4_fwd(s, Q, nk, store); }
+void launch_chainax(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad) {
+    if (ntw == 4) { if (pad) blcl::chainax_ntw4_pad(s, Q, nk, bwd, store); else blcl::chainax_ntw4(s, Q, nk, bwd, store); }
+    else if (pad) blcl::chainax_ntw12_pad(s, Q, nk, ntw, bwd, store);
     else blcl::chainax_ntw12(s, Q, nk, ntw, bwd, store);
     HIPCHECK(hipGetLastError());
 }
@@ -1213,6 +1214,15 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
     double Gk = (double)G;
     if (p->ndim == 2 && chain_rows_ok(g.n0))
         Gk = (double)((g.n0 + 127) / 128 * 128) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
+    {   // walks on both parameters: the transposing kernels lay their sequences out on a SQUARE geometry (blhip_chainax.hpp)
+        bool w0 = false, w1 = false;
+        for (int k = 0; k < p->n_ops; ++k)
+            if (p->ops[k].kind == BLHIP_OP_GRW) { if (g.axis_map[p->ops[k].axis] == 0) w0 = true; else w1 = true; }
+        if (p->ndim == 2 && w0 && w1 && std::max(g.n0, g.n1) <= 512) {
+            const double n = std::max(g.n0, g.n1) <= 128 ? 128.0 : (std::max(g.n0, g.n1) <= 256 ? 256.0 : 512.0);
+            Gk = std::max(Gk, n * n);
+        }
+    }
     // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
     // -- only where the chain-resident path can be taken at all (else they are never allocated: a narrow grid with a long series
     //    gave up its whole budget to 128 slots it never used and ran one chain per batch), and never more than half of the budget
@@ -1650,7 +1660,9 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
     cp.tap_id1.assign(B, -1);
     cp.ax1 = false;
     // walks on both parameters (blhip_chainax.hpp): an exact square geometry (the blocks of a chain change between column strips and row strips)
-    const bool ax1_geom = cp.allow_ax1 && !cp.pad && g.n0 == g.n1 && (cp.ntw == 1 || cp.ntw == 2 || cp.ntw == 4) && cp.strips == 8 * cp.ntw;
+    // -- the next square geometry of 128 / 256 / 512 rows = columns that holds the grid (PAD kernels where it is larger)
+    const int ax_n = std::max(g.n0, g.n1) <= 128 ? 128 : (std::max(g.n0, g.n1) <= 256 ? 256 : 512);
+    const bool ax1_geom = cp.allow_ax1 && std::max(g.n0, g.n1) <= 512 && g.n0 >= 32 && g.n1 >= 32 && ax_n / blc::WCOL <= cus;
     std::vector<int> lw(B, 0);
     cp.ckF.assign((size_t)T * B, (unsigned char)SRC_PREV);
     cp.ckB.assign((size_t)T * B, (unsigned char)SRC_PREV);
@@ -1702,9 +1714,15 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
         }
     }
     if (cp.ax1) {
-        // the transposing kernels: bands of radius <= 40 on either axis (ring lengths 8 .. 24 in steps of 4), no restarts
+        // the transposing kernels: bands of radius <= 40 on either axis (ring lengths 8 .. 24 in steps of 4; the band's rounded radius inside
+        // the grid: single-period reflection), no restarts; the square geometry replaces the strip geometry planned above
         if (cp.has_reset) return false;
-        for (int64_t b = 0; b < B; ++b) if (lw[b] > FAST_R0_MAX) return false;
+        for (int64_t b = 0; b < B; ++b) if (lw[b] > FAST_R0_MAX || (std::max(8, (lw[b] + 7) / 8 * 8)) >= std::min(g.n0, g.n1)) return false;
+        cp.n0p = cp.n1p = ax_n;
+        cp.strips = ax_n / blc::WCOL;
+        cp.ntw = ax_n / (blc::NW * blc::TM);
+        cp.pad = ax_n != g.n0 || ax_n != g.n1;
+        cp.cpr = cus / cp.strips;
     }
     cp.order.resize(B);
     for (int64_t b = 0; b < B; ++b) cp.order[b] = (int)b;

@@ -34,12 +34,13 @@ void chain_ntw12_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, 
 void chain_ntw34_tab(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);
 void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);
 
-// ... walks on both parameters (blc::chainax_kernel: square geometries of 128 / 256 / 512 rows and columns; band blocks 8 / 12 / 16 / 20 / 24
+// ... walks on both parameters (blc::chainax_kernel: square geometries of 128 / 256 / 512 rows and columns, grids of any size inside them; band blocks 8 / 12 / 16 / 20 / 24
 // = radius <= 8 .. 40 on either axis)
 void chainax_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);
-void chainax_ntw4_fwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store);
-void chainax_ntw4_bwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store);
+void chainax_ntw4(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store);
+void chainax_ntw12_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);      // grids smaller than the square geometry
+void chainax_ntw4_pad(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store);
 
-constexpr int N_SLICES = 21;      // BLC_TU = 1 .. N_SLICES (blhip_chain_tu.hip)
+constexpr int N_SLICES = 22;      // BLC_TU = 1 .. N_SLICES (blhip_chain_tu.hip)
 
 }   // namespace blcl

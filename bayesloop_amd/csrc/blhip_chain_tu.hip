@@ -125,39 +125,22 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
 
 #if BLC_TU >= 19
 // walks on both parameters: forward (stored / evidence-only), backward (stored / folded); ring lengths 8 .. 24 in steps of 4
-template <int NK, int NTW>
+template <int NK, int NTW, bool PAD>
 void launch_k_ax(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
     const size_t lds = blc::lds_doubles_ax<NK, NTW>() * sizeof(double);
-    if (bwd && store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, true>, s, Q, lds);
-    else if (bwd) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, false>, s, Q, lds);
-    else if (store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, true>, s, Q, lds);
-    else launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, false>, s, Q, lds);
+    if (bwd && store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, true, PAD>, s, Q, lds);
+    else if (bwd) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, false, PAD>, s, Q, lds);
+    else if (store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, true, PAD>, s, Q, lds);
+    else launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, false, PAD>, s, Q, lds);
 }
-template <int NTW>
+template <int NTW, bool PAD>
 void launch_w_ax(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
     switch (nk) {
-        case 8: launch_k_ax<8, NTW>(s, Q, bwd, store); break;
-        case 12: launch_k_ax<12, NTW>(s, Q, bwd, store); break;
-        case 16: launch_k_ax<16, NTW>(s, Q, bwd, store); break;
-        case 20: launch_k_ax<20, NTW>(s, Q, bwd, store); break;
-        case 24: launch_k_ax<24, NTW>(s, Q, bwd, store); break;
-        default: fail("internal: both-axes chain-resident kernel with %d band blocks", nk);
-    }
-}
-template <int NK, bool BWD>
-void launch_k_ax4(hipStream_t s, const blc::ChainParams &Q, bool store) {
-    const size_t lds = blc::lds_doubles_ax<NK, 4>() * sizeof(double);
-    if (store) launch_chain_fn(&blc::chainax_kernel<NK, 4, BWD, true>, s, Q, lds);
-    else launch_chain_fn(&blc::chainax_kernel<NK, 4, BWD, false>, s, Q, lds);
-}
-template <bool BWD>
-void launch_w_ax4(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) {
-    switch (nk) {
-        case 8: launch_k_ax4<8, BWD>(s, Q, store); break;
-        case 12: launch_k_ax4<12, BWD>(s, Q, store); break;
-        case 16: launch_k_ax4<16, BWD>(s, Q, store); break;
-        case 20: launch_k_ax4<20, BWD>(s, Q, store); break;
-        case 24: launch_k_ax4<24, BWD>(s, Q, store); break;
+        case 8: launch_k_ax<8, NTW, PAD>(s, Q, bwd, store); break;
+        case 12: launch_k_ax<12, NTW, PAD>(s, Q, bwd, store); break;
+        case 16: launch_k_ax<16, NTW, PAD>(s, Q, bwd, store); break;
+        case 20: launch_k_ax<20, NTW, PAD>(s, Q, bwd, store); break;
+        case 24: launch_k_ax<24, NTW, PAD>(s, Q, bwd, store); break;
         default: fail("internal: both-axes chain-resident kernel with %d band blocks", nk);
     }
 }
@@ -248,14 +231,20 @@ void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int n
 }
 #elif BLC_TU == 19
 void chainax_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
-    if (ntw == 2) launch_w_ax<2>(s, Q, nk, bwd, store);
-    else if (ntw == 1) launch_w_ax<1>(s, Q, nk, bwd, store);
+    if (ntw == 2) launch_w_ax<2, false>(s, Q, nk, bwd, store);
+    else if (ntw == 1) launch_w_ax<1, false>(s, Q, nk, bwd, store);
     else fail("internal: both-axes chain-resident kernel with %d tiles per wave", ntw);
 }
 #elif BLC_TU == 20
-void chainax_ntw4_fwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) { launch_w_ax4<false>(s, Q, nk, store); }
+void chainax_ntw4(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) { launch_w_ax<4, false>(s, Q, nk, bwd, store); }
 #elif BLC_TU == 21
-void chainax_ntw4_bwd(hipStream_t s, const blc::ChainParams &Q, int nk, bool store) { launch_w_ax4<true>(s, Q, nk, store); }
+void chainax_ntw12_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
+    if (ntw == 2) launch_w_ax<2, true>(s, Q, nk, bwd, store);
+    else if (ntw == 1) launch_w_ax<1, true>(s, Q, nk, bwd, store);
+    else fail("internal: both-axes chain-resident kernel with %d tiles per wave", ntw);
+}
+#elif BLC_TU == 22
+void chainax_ntw4_pad(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) { launch_w_ax<4, true>(s, Q, nk, bwd, store); }
 #else
 #error "BLC_TU out of range"
 #endif

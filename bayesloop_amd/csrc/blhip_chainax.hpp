@@ -64,7 +64,11 @@ __device__ __forceinline__ void swap_rows(double &x, double &y) {
 // the tag of the elements step k publishes: a buffer (parity k & 1) is rewritten every second step, zeroed before the launch
 __device__ __forceinline__ unsigned ax_tag(int k) { return 1u - (((unsigned)k >> 1) & 1u); }
 
-template <int NK, int NTW, bool BWD, bool STORE>
+// PAD: the grid is smaller than the square geometry (any n0, n1 <= 512: the geometry is the next of 128 / 256 / 512 that holds both).  As in
+// chain_kernel: the stencils reflect at the grid's TRUE last row / column, cells outside the grid are kept at zero and out of every sum,
+// read-only inputs are read with bounds; sequences live on the padded geometry (strip-major, private to the fit or de-padded afterwards).
+// Rows beyond the grid pick up mirrored values in P1 (and keep them through P2: the filters act along one axis each): the epilogue drops them.
+template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false>
 __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     static_assert(NTW == 1 || NTW == 2 || NTW == 4, "square geometries of 128 / 256 / 512 rows and columns");
     constexpr int R0 = (4 * NK - TM) / 2;
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     constexpr int XSZ = N0 * WCOL;                // doubles of a strip
     constexpr int AST = 16;                       // compact band tables (band_products)
     constexpr bool FOLD = BWD && !STORE;
+    const int n0t = PAD ? P.n0t : N0, n1t = PAD ? P.n1t : N0;          // the grid's true sizes
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *const X0 = lds;                       // [N0][16]  the state, layout A (rows x the strip's 16 columns)
     double *const X1 = lds + XSZ;                 // [N0][16]  the axis-0-filtered distribution, layout B (columns x the strip's 16 rows)
@@ -97,11 +102,16 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
 
     // ---- prologue (the first step consumes its source unfiltered: identity bands, replaced after step 0) -------------------------------
     for (int e = tid; e < 2 * NK * AST; e += NT) As0[e] = band_distance16(e % (NK * AST), R0) == 0 ? 1.0 : 0.0;
-    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[e];
+    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[PAD ? min(e, n0t - 1) : e];
     if (tid < 2 * NSLOT) scal[tid] = 1.0;
-    for (int e = tid; e < XSZ; e += NT) X0[e] = P.src0[(long long)(e >> 4) * N0 + tj * WCOL + (e & 15)];
-    const double g1 = P.m1[gj];
-    const double cA = P.colA[gj], cB = P.colB[gj];
+    for (int e = tid; e < XSZ; e += NT) {
+        const int row = e >> 4, col = tj * WCOL + (e & 15);
+        X0[e] = (!PAD || (row < n0t && col < n1t)) ? P.src0[(long long)row * n1t + col] : 0.0;
+    }
+    const bool colok = !PAD || gj < n1t;
+    const int gjc = PAD ? min(gj, n1t - 1) : gj;
+    const double g1 = P.m1[gjc];
+    const double cA = P.colA[gjc], cB = P.colB[gjc];
     double *const pchain = P.post + (long long)b * P.post_stride;
     const unsigned rowx8 = P.strip_major ? (unsigned)WCOL * 8u : (unsigned)N0 * 8u;
     const unsigned strip0 = P.strip_major ? (unsigned)tj * (unsigned)(XSZ * 8) : (unsigned)tj * (unsigned)(WCOL * 8);
@@ -163,15 +173,15 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
             }
         }
     };
-    const bool edge = row0 < R0 || row0 + NTW * TM + R0 > N0;
     // the banded products of the wave's NTW tiles over the strip in `S` (band table `Ab`), each tile published into buffer `dst`
-    auto filter_and_publish = [&](const double *S, const double *Ab, unsigned dst, unsigned bit) {
+    auto filter_and_publish = [&](const double *S, const double *Ab, unsigned dst, unsigned bit, int nlim) {
+        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > nlim;      // (the reflection is at the true last row / column)
         double Bv[NK];
         {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (edge) {
 #pragma unroll
-                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, N0) * WCOL + c];
+                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, nlim) * WCOL + c];
             } else {
                 const double *s0 = S + (row0 - R0 + g) * WCOL + c;
 #pragma unroll
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
                 if (edge) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, N0) * WCOL + c];
+                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, nlim) * WCOL + c];
                 } else {
                     const double *s1 = S + (i + TM + R0 + g) * WCOL + c;
 #pragma unroll
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
 
         // ---- P1: axis 0 in layout A -> the strips of layout B -----------------------------------------------------------------------------
-        filter_and_publish(X0, As0, xbuf(0, k), bit);
+        filter_and_publish(X0, As0, xbuf(0, k), bit, n0t);
         BLX_STAMP(1);
         // ---- this block's layout-B strip -> X1 (a plain copy: XSZ elements, 512 contiguous bytes per wave access) --------------------------
         {
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         __syncthreads();
         BLX_STAMP(3);
         // ---- P2: axis 1 in layout B -> the strips of layout A -----------------------------------------------------------------------------
-        filter_and_publish(X1, As1, xbuf(1, k), bit);
+        filter_and_publish(X1, As1, xbuf(1, k), bit, n1t);
         BLX_STAMP(4);
 
         // ---- P3: the lane's own cells back + the fused epilogue (chain_kernel's) -----------------------------------------------------------
@@ -389,17 +399,18 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                 const int li = i + g + 4 * r;
                 const double Lv = ldexp(mE, nE);
                 const unsigned off = cell_off(l, it, r);
+                const bool in = !PAD || (colok && li < n0t);          // (cells outside the grid stay zero)
                 if (!BWD) {
-                    const double a = acc[r] * Lv;
+                    const double a = in ? acc[r] * Lv : 0.0;
                     X0[li * WCOL + c] = a;
                     if (STORE) stnt(pstep, off, a);
                     sN += a;
                     acc[r] = a;
                 } else {
-                    const double beta = acc[r] * scale;
+                    const double beta = in ? acc[r] * scale : 0.0;
                     const double p = al[BWD ? it : 0][r] * beta;
                     const double cn = beta * Lv;
-                    const double pl = Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE);      // p / L; 0 / 0 -> NaN (core.py:463)
+                    const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));      // p / L; 0 / 0 -> NaN (core.py:463)
                     X0[li * WCOL + c] = cn;
                     if (!FOLD) stnt(pstep, off, p);
                     else stnt(pslot_t, off, pa[FOLD ? it : 0][r] + fmax(p * wq, wfloor));

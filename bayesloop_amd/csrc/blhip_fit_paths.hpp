@@ -356,7 +356,7 @@ struct ChainRun {
         }
         // (<= 512 rows: the one-chain folding kernel has no padded variant -- store + separate fold; 1024 rows: it is the only padded backward kernel)
         // (tabulated likelihood on a padded grid: no fold2 -> store + separate fold as well)
-        if (cp.pad && fused && !fold2 && cp.ntw <= 4) fused = false;
+        if (cp.pad && fused && !fold2 && cp.ntw <= 4 && !ax1) fused = false;      // (the both-axes kernels fold on padded grids too)
         if (cp.pad && cp.ntw > 4 && E.ff.full && !fused) { on = false; fold2 = false; return; }
         // Change-point batches without a stencil whose backward pass folds: the chains are identical up to their first restart.  The chain
         // with the LATEST first restart stores all its states; every other chain stores only from its own first restart on, and the
@@ -447,7 +447,7 @@ struct ChainRun {
                     HIPCHECK(hipMemsetAsync(ctx->small.p, 0, 2 * 16 * 16 * 8, st));
                     Q.prof = ctx->small.as<unsigned long long>();
                 }
-                launch_chainax(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only));
+                launch_chainax(st, Q, rnk[r], cp.ntw, bwd, fold_now ? false : (bwd || !E.ff.evidence_only), cp.pad);
                 if (prof) {          // where a step of strip 0 spends its time (shader-clock cycles between stamps; waves 0 and 2)
                     unsigned long long hh[2 * 16 * 16];
                     HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));

@@ -380,22 +380,27 @@ def random_resident_case(seed):
 
 
 def random_both_axes_square_case(seed):
-    """Seeded studies with random walks on BOTH parameters of a SQUARE grid of 128 or 256 points per axis (radii 0 .. 40 on either axis): the
+    """Seeded studies with random walks on BOTH parameters (radii 0 .. 40 on either axis) of a square grid of 128 or 256 points per axis -- or
+    of any grid of 48 .. 300 points per axis, which runs padded inside the next square geometry: the
     shapes the transposing chain-resident kernels take (blhip_chainax.hpp: blc::chainax_kernel) -- single fits, hyper-studies over one
     width, over both (pairs), a walk on the second parameter only, missing data, every fit flag."""
     rng = np.random.default_rng(12000 + seed)
     kind = ['study_both', 'hyper_pairs', 'hyper_both', 'hyper_axis1', 'study_axis1', 'hyper_pairs'][seed % 6]
     n = [128, 256, 128][seed % 3]
-    T = int(rng.integers(3, 9 if n == 256 else 13))
+    n0 = n1 = n
+    if seed % 4 >= 2:                       # ragged grids inside the square geometry (PAD kernels): any sizes, also very different ones
+        n0, n1 = int(rng.integers(48, 300)), int(rng.integers(48, 300))
+        n = max(n0, n1)
+    T = int(rng.integers(3, 9 if n > 128 else 13))
     flags = [dict(), dict(forwardOnly=True), dict(evidenceOnly=True), dict()][int(rng.integers(0, 4))]
     nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 3 else []
     data = ('series_nan', 1300 + seed, T, nan_at) if nan_at else ('series', 1300 + seed, T)
-    om = ('Gaussian', [('mean', ('cint', -5, 5, n)), ('std', ('oint', 0, 3, n))], 'default')
+    om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
 
     def sigma(span, npts, radius):
         return max(radius, 0.3) / 4.0 * span / max(npts - 1, 1)
     r0, r1 = int(rng.integers(0, 41)), int(rng.integers(1, 41))
-    s1, s2 = sigma(10, n, r0), sigma(3, n + 2, r1)
+    s1, s2 = sigma(10, n0, r0), sigma(3, n1 + 2, r1)
     nh = int(rng.integers(2, 5))
     if kind == 'study_both':
         tm = ('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)])
@@ -406,7 +411,7 @@ def random_both_axes_square_case(seed):
         return dict(study='HyperStudy', data=data, om=om, fit=flags,
                     tm=('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', ('cint', 0, s2, nh), 'std', None)]))
     if kind == 'hyper_axis1':
-        return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's2', ('cint', sigma(3, n + 2, 2), s2, nh), 'std', None))
+        return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's2', ('cint', sigma(3, n1 + 2, 2), s2, nh), 'std', None))
     return dict(study='HyperStudy', data=data, om=om, fit=flags,
                 tm=('Combined', [('GRW', 's1', ('cint', 0, s1, int(rng.integers(2, 4))), 'mean', None),
                                  ('GRW', 's2', ('cint', 0, s2, int(rng.integers(2, 4))), 'std', None)]))
