@@ -18,7 +18,9 @@ using blerr::fail;
 template <typename KernT>
 void launch_chain_fn(KernT kern, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
     arm_kernel(reinterpret_cast<const void *>(kern));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(Q.nslots * Q.strips)), dim3(blc::NT), lds, s, Q);
+    // (xch_mode bit 0 -- blc::chainax_kernel only: one XCD per chain, 8 x strips x ceil(chains / 8) blocks of which nslots x strips work)
+    const unsigned blocks = (Q.xch_mode & 1) ? 8u * (unsigned)Q.strips * (unsigned)((Q.nslots + 7) / 8) : (unsigned)(Q.nslots * Q.strips);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(blc::NT), lds, s, Q);
 }
 
 // the flavours of one (ring length, tiles per wave, direction).  Padded grids: forward and storing backward passes of <= 512 rows (the

@@ -90,9 +90,13 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // (xch_mode bit 0: chain = block % chains of the launch -- with 8 chains the 32 blocks of a chain run on ONE XCD, observed dispatch order)
-    const int cs = (P.xch_mode & 1) ? (int)(blockIdx.x % (unsigned)P.nslots) : (int)(blockIdx.x / (unsigned)P.strips);
-    const int tj = (P.xch_mode & 1) ? (int)(blockIdx.x / (unsigned)P.nslots) : (int)(blockIdx.x - cs * P.strips);
+    // xch_mode bit 0: the blocks of a chain share an XCD (block b runs on XCD b % 8 -- observed dispatch order, used for speed only):
+    // the launch has 8 x strips x ceil(chains / 8) blocks, XCD x = b % 8 works on chains x, x + 8, ...; blocks without a chain leave
+    const unsigned xl = blockIdx.x >> 3;
+    const int cs = (P.xch_mode & 1) ? (int)((blockIdx.x & 7u) + 8u * (xl / (unsigned)P.strips)) : (int)(blockIdx.x / (unsigned)P.strips);
+    const int tj = (P.xch_mode & 1) ? (int)(xl % (unsigned)P.strips) : (int)(blockIdx.x - cs * P.strips);
+    if (cs >= P.nslots) return;
+    const unsigned bid = (unsigned)(cs * P.strips + tj);
     const int b = sldi(P.chain_ids, cs);
     const int tap0 = sldi(P.tap_id, b), tap1 = sldi(P.tap_id1, b);
     const int lw0 = tap0 >= 0 ? sldi(P.tap_lw, tap0) : 0, lw1 = tap1 >= 0 ? sldi(P.tap_lw, tap1) : 0;
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     };
 
     // (option chain_prof: shader-clock stamps of block 0, waves 0 and 2, steps 8 .. 23 -- where a step spends its time)
-    const bool prof_me = P.prof != nullptr && blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 2);
+    const bool prof_me = P.prof != nullptr && bid == 0 && lane == 0 && (wv == 0 || wv == 2);
 #define BLX_STAMP(i) do { if (prof_me && k >= 8 && k < 24) P.prof[(wv ? 256 : 0) + (k - 8) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
     for (int k = 0; k < P.T; ++k) {
         const int t = BWD ? P.T - 1 - k : k;

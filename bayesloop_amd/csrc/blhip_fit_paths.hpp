@@ -437,10 +437,10 @@ struct ChainRun {
 #endif
             if (ax1) {
                 HIPCHECK(hipMemsetAsync(CQ.xch, 0, xch_bytes, st));           // (tags restart with every launch)
-                // a launch of 8 chains: the 32 blocks of a chain on ONE XCD (block b runs on XCD b % 8 -- observed, for speed only) and plain
-                // publishing stores, which keep the lines in that XCD's L2 for the consumers (write-through stores drop them: MI355X_MICROARCH.md);
-                // any other launch: write-through stores, whose visibility does not depend on the placement
-                Q.xch_mode = ax_mode >= 0 ? ax_mode : (Q.nslots == 8 ? 3 : 0);
+                // the blocks of a chain on ONE XCD (block b runs on XCD b % 8 -- observed, for speed only) and plain publishing stores, which
+                // keep the lines in that XCD's L2 (write-through stores drop them: MI355X_MICROARCH.md); chain_ax1_mode = 0: write-through
+                // stores and the dispatch order of the other chain kernels -- nothing then depends on the placement, not even the speed
+                Q.xch_mode = ax_mode >= 0 ? ax_mode : 3;
                 const bool prof = ctx->option("chain_prof", 0.0) != 0.0;
                 if (prof) {
                     ctx->small.ensure(2 * 16 * 16 * 8);

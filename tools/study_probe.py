@@ -2,7 +2,7 @@ import sys, time, numpy as np
 sys.path.insert(0,'.')
 import bayesloop_amd as bl, bench
 eng=bl.get_engine()
-for n,r in ((128,20),(256,20),(128,8),(256,30)):
+for n,r in ((200,20),(128,20),(256,20),(300,30),(500,20)):
     T=1000
     d0=16.0/(n-1); d1=4.0/(n+1)
     for mode in (1,0):
