@@ -1680,13 +1680,13 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
         // change point, transitionModels.py:300-312) -- through the band (the change point comes before the random walk in the
         // combined model's list) or unfiltered (it comes after: the walk's output is discarded)
         auto classify = [&](unsigned char kind, int t0, int t1, unsigned char &out) {
-            if (t1 != k1) return false;                       // (k1 = -1 unless the both-axes kernels may be planned)
-            if (k1 >= 0 && kind != SRC_PREV) return false;    // (no restarts in the transposing kernels)
-            if (kind == SRC_PREV && t0 == k0) { out = (unsigned char)SRC_PREV; return true; }
-            if (kind == SRC_RESET && (t0 == k0 || t0 < 0)) {
-                out = (unsigned char)(SRC_RESET | ((k0 >= 0 && t0 < 0) ? 0x80 : 0));          // bit 7: no filter at this step
+            // (k1 = -1 unless the both-axes kernels may be planned; a restart passes through BOTH of the chain's bands or through none)
+            if (kind == SRC_PREV && t0 == k0 && t1 == k1) { out = (unsigned char)SRC_PREV; return true; }
+            if (kind == SRC_RESET && ((t0 == k0 && t1 == k1) || (t0 < 0 && t1 < 0))) {
+                const bool filters = k0 >= 0 || k1 >= 0;
+                out = (unsigned char)(SRC_RESET | ((filters && t0 < 0 && t1 < 0) ? 0x80 : 0));          // bit 7: no filter at this step
                 cp.has_reset = true;
-                if (k0 >= 0) cp.mixed = true;
+                if (filters) cp.mixed = true;
                 return true;
             }
             return false;
@@ -1715,8 +1715,7 @@ bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &
     }
     if (cp.ax1) {
         // the transposing kernels: bands of radius <= 40 on either axis (ring lengths 8 .. 24 in steps of 4; the band's rounded radius inside
-        // the grid: single-period reflection), no restarts; the square geometry replaces the strip geometry planned above
-        if (cp.has_reset) return false;
+        // the grid: single-period reflection); the square geometry replaces the strip geometry planned above
         for (int64_t b = 0; b < B; ++b) if (lw[b] > FAST_R0_MAX || (std::max(8, (lw[b] + 7) / 8 * 8)) >= std::min(g.n0, g.n1)) return false;
         cp.n0p = cp.n1p = ax_n;
         cp.strips = ax_n / blc::WCOL;

@@ -156,6 +156,9 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     double pa[FOLD ? NTW : 1][4];
     if (wv == SCALE_WAVE || wv == 5 || wv == 0 || wv == NW - 1) __builtin_amdgcn_s_setprio(2);
     bool dead = false;
+    // change points (transitionModels.py:300-312): a step may consume the reset distribution instead of the previous state -- through
+    // both bands (the change point stands in front of the walks in the combined model's list) or unfiltered (behind them: bit 7)
+    int kind_n = blk::SRC_PREV;
     typedef const double __attribute__((address_space(3))) *lds_cp;
     unsigned long long gq0 = 0ull, gq1 = 0ull;
     double Sprev = 1.0;
@@ -244,6 +247,17 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         if (scale_wave && jn + 1 >= P.lag && jn + 1 < P.T && lane < P.strips) {
             const unsigned long long *gn = P.gran + ((((long long)((jn + 1 - P.lag) & (NSLOT - 1)) * P.nslots + cs) * P.strips + lane) << 1);
             gq0 = blr::ld_u64(gn); gq1 = blr::ld_u64(gn + 1);
+        }
+        const int kind = kind_n & 0x7f;
+        const bool nofilter = (kind_n & 0x80) != 0;
+        if (P.kinds) kind_n = P.kinds[(long long)tn * P.B + b];
+        if (kind != blk::SRC_PREV && k > 0) {          // (rare: once per chain and change point)
+            for (int e = tid; e < XSZ; e += NT) {
+                const int row = e >> 4, col = tj * WCOL + (e & 15);
+                X0[e] = (!PAD || (row < n0t && col < n1t)) ? P.reset[(long long)row * n1t + col] : 0.0;
+            }
+            if (nofilter) for (int e = tid; e < 2 * NK * AST; e += NT) As0[e] = band_distance16(e % (NK * AST), R0) == 0 ? 1.0 : 0.0;
+            __syncthreads();
         }
         const double sf_now = sfn;
         if (FOLD) sfn = P.sfwd[(long long)b * P.T + min(tn + 1, P.T - 1)];
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         }
         __syncthreads();
         BLX_STAMP(7);
-        if (k == 0) {            // the chain's bands replace the identities of the first step
+        if (k == 0 || (nofilter && kind != blk::SRC_PREV)) {            // the chain's bands replace the identities of the first step / of an unfiltered restart
             for (int e = tid; e < NK * AST; e += NT) {
                 const int a = band_distance16(e, R0);
                 As0[e] = a == 0 ? (lw0 > 0 ? P.taps[o0] : 1.0) : (a <= lw0 ? P.taps[o0 + a] : 0.0);

@@ -385,7 +385,7 @@ def random_both_axes_square_case(seed):
     shapes the transposing chain-resident kernels take (blhip_chainax.hpp: blc::chainax_kernel) -- single fits, hyper-studies over one
     width, over both (pairs), a walk on the second parameter only, missing data, every fit flag."""
     rng = np.random.default_rng(12000 + seed)
-    kind = ['study_both', 'hyper_pairs', 'hyper_both', 'hyper_axis1', 'study_axis1', 'hyper_pairs'][seed % 6]
+    kind = ['study_both', 'hyper_pairs', 'hyper_both', 'hyper_axis1', 'study_axis1', 'hyper_pairs', 'cp_both', 'study_cp_after', 'cp_both_after'][seed % 9]
     n = [128, 256, 128][seed % 3]
     n0 = n1 = n
     if seed % 4 >= 2:                       # ragged grids inside the square geometry (PAD kernels): any sizes, also very different ones
@@ -405,6 +405,17 @@ def random_both_axes_square_case(seed):
     if kind == 'study_both':
         tm = ('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)])
         return dict(study='Study', data=data, om=om, fit=flags, tm=tm)
+    if kind in ('cp_both', 'cp_both_after', 'study_cp_after'):
+        # change points (transitionModels.py:289-317) beside the two walks: in front of them the restart passes through both bands,
+        # behind them it is consumed unfiltered; as a ChangepointStudy over every time step, or one fixed change point in a Study
+        T = max(T, 6)
+        walks = [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)]
+        if kind == 'study_cp_after':
+            return dict(study='Study', data=('series_jump', 1300 + seed, T, T // 2, 2.0), om=om, fit=flags,
+                        tm=('Combined', walks + [('ChangePoint', 'tc', float(T // 2), None)]))
+        cp = ('ChangePoint', 'tc', ('arange', 1, T - 1, 2), None)
+        return dict(study='ChangepointStudy', data=('series_jump', 1300 + seed, T, T // 2, 2.0), om=om, fit=dict(),
+                    tm=('Combined', [cp] + walks if kind == 'cp_both' else walks + [cp]))
     if kind == 'study_axis1':
         return dict(study='Study', data=data, om=om, fit=flags, tm=('GRW', 's2', s2, 'std', None))
     if kind == 'hyper_both':
