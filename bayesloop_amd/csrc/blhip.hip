@@ -1516,6 +1516,7 @@ struct FoldJob {
     int parity = 0;
     int sm_n0 = 0;                                   // > 0: d_post is in the chain-resident kernel's strip-major layout (rows per strip)
     int pad_n0p = 0, pad_n0 = 0, pad_n1 = 0;         // > 0: ... on a padded geometry (rows per strip n0p; the grid's true sizes)
+    int pad_ax = 0;                                  //      ... in the alternating layouts of the both-axes kernels (blk::ax_layout_b)
     long long pad_step = 0;                          //      doubles per time step of a chain's sequence there
 };
 
@@ -1555,7 +1556,7 @@ void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hip
     if (job.pad_n0p > 0) {
         hipLaunchKernelGGL(accumulate_pad_kernel, dim3((unsigned)((G + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
                            job.d_post, (long long)T * job.pad_step, (int)B, job.pad_n0, job.pad_n1, (int)T, job.d_w, job.d_invN, job.r, job.first,
-                           job.pad_n0p, job.pad_step);
+                           job.pad_n0p, job.pad_step, job.pad_ax);
     } else if (job.sm_n0 == 0 && B >= 16 && ((G / 2 + NTHREADS - 1) / NTHREADS) * T < 1024) {        // small grids: too few blocks with a thread per cell
         hipLaunchKernelGGL(accumulate_small_kernel, dim3((unsigned)((G + 63) / 64), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
                            (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
@@ -2099,7 +2100,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (CR.on && CR.depad) {                 // a padded batch that hands its posteriors out: scratch sequence for the kernels, d_post stays the result
             ctx->postpad.ensure((size_t)B * T * CR.Gk * 8);
             E.d_post = ctx->postpad.as<double>();
-        } else if (CR.on && CR.cp.pad && d_post) {      // the private sequence of a padded chain-resident batch lives on the padded geometry
+        } else if (CR.on && (CR.cp.pad || CR.ax1) && d_post) {      // the private sequence of a padded chain-resident batch lives on the padded geometry
             DevBuf &pb = (overlap_acc && (bi & 1)) ? ctx->post2 : ctx->post;
             pb.ensure((size_t)B * T * CR.Gk * 8);
             d_post = pb.as<double>();
@@ -2504,7 +2505,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
 
         if (CR.on && CR.depad && !resident_failed && !evidence_only) {
             hipLaunchKernelGGL(depad_kernel, dim3((unsigned)((G + NTHREADS - 1) / NTHREADS), (unsigned)(B * T)), dim3(NTHREADS), 0, st, d_post,
-                               ctx->postpad.as<double>(), g.n0, g.n1, CR.cp.n0p, CR.Gk);
+                               ctx->postpad.as<double>(), g.n0, g.n1, CR.cp.n0p, CR.Gk, (int)T, CR.ax1 ? 1 : 0);
             HIPCHECK(hipGetLastError());
         }
 
@@ -2527,15 +2528,15 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             fold_job.d_w = carve<double>(wc, (size_t)Bmax); fold_job.d_invN = carve<double>(wc, (size_t)T * Bmax);
             fold_job.h_w = carve<double>(hc, (size_t)Bmax); fold_job.h_invN = carve<double>(hc, (size_t)T * Bmax);
             fold_job.d_post = d_post; fold_job.parity = (int)(bi & 1);
-            fold_job.sm_n0 = (CR.post_private && !resident_failed && !CR.cp.pad) ? g.n0 : 0;
-            if (CR.on && CR.cp.pad && !CR.depad && !resident_failed) { fold_job.pad_n0p = CR.cp.n0p; fold_job.pad_n0 = g.n0; fold_job.pad_n1 = g.n1; fold_job.pad_step = CR.Gk; }
+            fold_job.sm_n0 = (CR.post_private && !resident_failed && !CR.cp.pad && !CR.ax1) ? g.n0 : 0;
+            if (CR.on && (CR.cp.pad || CR.ax1) && !CR.depad && !resident_failed) { fold_job.pad_n0p = CR.cp.n0p; fold_job.pad_n0 = g.n0; fold_job.pad_n1 = g.n1; fold_job.pad_step = CR.Gk; fold_job.pad_ax = CR.ax1 ? 1 : 0; }
             fold_job.pending = prepare_fold(ctx, T, B, O, log_w + c0, fold_job);
             // launched behind the NEXT batch's forward pass (see passes); the last batch has nothing to hide behind
             if (bi == nbatch - 1) launch_pending_fold();
         } else if (accumulate) {
             FoldJob lay;
-            const bool padded = CR.on && CR.cp.pad && !CR.depad && !resident_failed;
-            if (padded) { lay.pad_n0p = CR.cp.n0p; lay.pad_n0 = g.n0; lay.pad_n1 = g.n1; lay.pad_step = CR.Gk; }
+            const bool padded = CR.on && (CR.cp.pad || CR.ax1) && !CR.depad && !resident_failed;
+            if (padded) { lay.pad_n0p = CR.cp.n0p; lay.pad_n0 = g.n0; lay.pad_n1 = g.n1; lay.pad_step = CR.Gk; lay.pad_ax = CR.ax1 ? 1 : 0; }
             // (many small batches: nobody waits for a batch's fold; the last one is waited for with the stream below)
             fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN, (CR.post_private && !resident_failed && !padded) ? g.n0 : 0, padded ? &lay : nullptr,
                             (nbatch >= 4 && !keep && !carry) ? &fold_ev : nullptr);

@@ -1,36 +1,43 @@
 // Chain-resident pass for batches of chains whose transition filters BOTH parameters: a hyper-study over the widths of two Gaussian random
 // walks (HyperStudy.fit, core.py:1349-1366, with CombinedTransitionModel(GRW on parameter 1, GRW on parameter 2), transitionModels.py:
-// 632-662 -> :107-111 per axis) -- the shape of the reference's own two-hyper-parameter tests (tests/test_hyperstudy.py:61-103).
+// 632-662 -> :107-111 per axis) -- the shape of the reference's own two-hyper-parameter tests (tests/test_hyperstudy.py:61-103) -- and any
+// single fit with such walks wider than the time-resident kernel's 8 grid steps.
 //
 // Why: rounds 1 - 4 ran these studies with a launch per step and a row PRE-PASS per step (blhip_hwide.hpp + blhip_mfma.hpp): the state
 // streams through HBM three times per step, 78 B per cell-step against 24 of the single-axis headline, at 4.4 TB/s.  Here the state
 // stays on the chip for the whole pass, as in blc::chain_kernel (blhip_chainres.hpp), whose scheme this kernel extends:
 //
-//  * block = one strip of 16 grid columns x ALL rows of one chain (layout A), state in LDS, the axis-0 stencil as banded Toeplitz products
-//    on v_mfma_f64_4x4x4_4b -- unchanged;
+//  * layout A = chain_kernel's: block = one strip of 16 grid columns x ALL rows of one chain, state in LDS [row][16], the axis-0 stencil as
+//    banded Toeplitz products on v_mfma_f64_4x4x4_4b;
 //  * the axis-1 stencil runs along the rows of the grid, i.e. ACROSS the strips.  Instead of exchanging halos (the walks of a
 //    hyper-study are as wide as two strips) the blocks of a chain TRANSPOSE the distribution between the two filters: on a square
 //    geometry (rows = columns = 16 x strips) block j, which owns columns 16 j .. 16 j + 15 in layout A, owns ROWS 16 j .. 16 j + 15 in
-//    layout B, stored [column][16 rows] -- the same LDS shape, so the axis-1 filter is the SAME banded product with the other band.
-//    Per step:   P1  ring + products along axis 0 (layout A)        -> published, element by element, into the strips of layout B
-//                    every block gathers its layout-B strip into its second LDS buffer, barrier
-//                P2  ring + products along axis 1 (layout B)        -> published into the strips of layout A
-//                P3  every lane reads its OWN cells back (registers) -> the fused epilogue of chain_kernel (scale, likelihood
-//                    recurrence, sums, stores / fold), new state -> first LDS buffer, barrier;
-//  * the exchange goes through an L2- / Infinity-Cache-resident buffer (2 MiB per chain and phase, two parities) and THE DATA IS THE
-//    FLAG (blhip_resident.hpp): every element is the 8-byte value with a one-bit tag in its sign bit (everything handed over is >= +0),
-//    written by one write-through store, read by sc1 loads; a consumer whose elements do not carry the step's tag yet asks again
-//    (bounded; abort word as in the other resident kernels).  A producer scatters its tile so that every CONSUMER access is a
-//    contiguous 512 bytes per wave (the gather is a plain copy into LDS, the read-back of P3 is the lane's own cell order);
+//    layout B, stored [column][16 rows] -- the same LDS shape, so the axis-1 filter is the SAME banded product with the other band;
+//  * ONE exchange per step: the two filters commute (separable; to rounding in floating point), so a step applies first the filter of the
+//    layout its state is in, transposes, and applies the other filter FUSED WITH THE EPILOGUE (scale, likelihood, sums, store / fold)
+//    in the other layout -- where the next step then starts.  The layouts alternate with the time index: everything a step keeps for time
+//    t (stored state, posterior, partial accumulator) is in layout B for even t and in layout A for odd t, in both passes, so the
+//    backward pass finds the forward pass's states in the layout its own epilogue of that time works in.  (The two-exchange form --
+//    axis 0, transpose, axis 1, transpose back, epilogue in layout A -- was built first and measured: the exchanges, not the products,
+//    are the step; profiles/r05_notes.md.)  The epilogue of layout A runs the likelihood recurrence along the rows (chain_kernel's); in
+//    layout B a lane walks along the SECOND parameter, where the Gaussian has no such recurrence: one exp per cell there (mantissa /
+//    exponent form, p / L from the reciprocal mantissa);
+//  * the exchange goes through a cache-resident buffer (2 MiB per chain and step parity) and THE DATA IS THE FLAG (blhip_resident.hpp):
+//    every element is the 8-byte value with a one-bit tag in its sign bit (everything handed over is >= +0), written as 16-byte pairs
+//    (a tile's registers hold rows g, g + 4, ...: one v_permlane16_swap per register pair gives a lane two CONSECUTIVE rows), read by
+//    16-byte sc1 loads: the gather is a plain copy of 512 contiguous bytes per wave access into LDS; a consumer whose elements do not
+//    carry the step's tag yet asks again (bounded; abort word as in the other resident kernels);
 //  * HBM sees what chain_kernel's passes see: 8 B per cell forward (stored state), 16 / 24 B backward (store / fold).
-// The filters are applied in the list order of the reference (axis 0, then axis 1) in both directions (transitionModels.py:645-649, :656-660).
+// Sequences are always strip-major on the square geometry (private to the fit, or de-layouted afterwards: blk::depad_kernel).
 #pragma once
 #include "blhip_chainres.hpp"
 
 namespace blc {
 
 template <int NK, int NTW>
-constexpr size_t lds_doubles_ax() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 16 + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
+constexpr size_t lds_doubles_ax() { return (size_t)2 * NW * NTW * TM * WCOL + 2 * NK * 16 + 4 * NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
+
+using blk::ax_layout_b;       // layout of everything kept for time t (and of the epilogue that produces it): B for even t, A for odd t
 
 // 16-byte tagged accesses (two elements each): an 8-byte write-through store costs 2.7 x a 16-byte one per byte on this part
 // (MI355X_MICROARCH.md: "scalar sc1 stores are one fabric write each"), and a consumer should keep >= 8 wide loads in flight
@@ -66,8 +73,8 @@ __device__ __forceinline__ unsigned ax_tag(int k) { return 1u - (((unsigned)k >>
 
 // PAD: the grid is smaller than the square geometry (any n0, n1 <= 512: the geometry is the next of 128 / 256 / 512 that holds both).  As in
 // chain_kernel: the stencils reflect at the grid's TRUE last row / column, cells outside the grid are kept at zero and out of every sum,
-// read-only inputs are read with bounds; sequences live on the padded geometry (strip-major, private to the fit or de-padded afterwards).
-// Rows beyond the grid pick up mirrored values in P1 (and keep them through P2: the filters act along one axis each): the epilogue drops them.
+// read-only inputs are read with bounds.  Lines beyond the grid pick up mirrored values in the first filter (and keep them through the
+// second: the filters act along one axis each): the epilogue drops them.
 template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false>
 __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     static_assert(NTW == 1 || NTW == 2 || NTW == 4, "square geometries of 128 / 256 / 512 rows and columns");
@@ -79,12 +86,15 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     constexpr bool FOLD = BWD && !STORE;
     const int n0t = PAD ? P.n0t : N0, n1t = PAD ? P.n1t : N0;          // the grid's true sizes
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *const X0 = lds;                       // [N0][16]  the state, layout A (rows x the strip's 16 columns)
-    double *const X1 = lds + XSZ;                 // [N0][16]  the axis-0-filtered distribution, layout B (columns x the strip's 16 rows)
+    double *const X0 = lds;                       // [N0][16]  the state at the beginning of a step (layout A or B)
+    double *const X1 = lds + XSZ;                 // [N0][16]  after the first filter, transposed into the other layout
     double *const As0 = X1 + XSZ;                 // [NK][16]  band of axis 0
     double *const As1 = As0 + NK * AST;           // [NK][16]  band of axis 1
-    double *const m0s = As1 + NK * AST;           // [N0]      row coordinates
-    double *const red = m0s + N0;                 // [2][NW * 4][5]
+    double *const m0s = As1 + NK * AST;           // [N0]      coordinates of the first parameter (rows)
+    double *const m1s = m0s + N0;                 // [N0]      ... of the second (columns)
+    double *const cAs = m1s + N0;                 // [N0]      the columns' likelihood constants (layout B: a lane walks along the columns)
+    double *const cBs = cAs + N0;                 // [N0]
+    double *const red = cBs + N0;                 // [2][NW * 4][5]
     double *const scal = red + 2 * NW * 4 * 5;    // [NSLOT]
     double *const iscal = scal + NSLOT;           // [NSLOT]
 
@@ -101,59 +111,60 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     const int tap0 = sldi(P.tap_id, b), tap1 = sldi(P.tap_id1, b);
     const int lw0 = tap0 >= 0 ? sldi(P.tap_lw, tap0) : 0, lw1 = tap1 >= 0 ? sldi(P.tap_lw, tap1) : 0;
     const long long o0 = tap0 >= 0 ? sldi(P.tap_off, tap0) : 0, o1 = tap1 >= 0 ? sldi(P.tap_off, tap1) : 0;
-    const int gj = tj * WCOL + (lane & 15);
+    const int gj = tj * WCOL + (lane & 15);       // layout A: the lane's grid column; layout B: its grid ROW
     const long long G = (long long)N0 * N0;
 
+    // a distribution (prior, uniform, reset: row-major on the grid's true sizes) -> X0 in layout A / B
+    auto load_dist = [&](const double *src, bool lay_b) {
+        for (int e = tid; e < XSZ; e += NT) {
+            const int line = e >> 4, own = tj * WCOL + (e & 15);
+            const int row = lay_b ? own : line, col = lay_b ? line : own;
+            X0[e] = (!PAD || (row < n0t && col < n1t)) ? src[(long long)row * n1t + col] : 0.0;
+        }
+    };
     // ---- prologue (the first step consumes its source unfiltered: identity bands, replaced after step 0) -------------------------------
+    const int t_first = BWD ? P.T - 1 : 0;
     for (int e = tid; e < 2 * NK * AST; e += NT) As0[e] = band_distance16(e % (NK * AST), R0) == 0 ? 1.0 : 0.0;
-    for (int e = tid; e < N0; e += NT) m0s[e] = P.m0[PAD ? min(e, n0t - 1) : e];
-    if (tid < 2 * NSLOT) scal[tid] = 1.0;
-    for (int e = tid; e < XSZ; e += NT) {
-        const int row = e >> 4, col = tj * WCOL + (e & 15);
-        X0[e] = (!PAD || (row < n0t && col < n1t)) ? P.src0[(long long)row * n1t + col] : 0.0;
+    for (int e = tid; e < N0; e += NT) {
+        m0s[e] = P.m0[PAD ? min(e, n0t - 1) : e];
+        m1s[e] = P.m1[PAD ? min(e, n1t - 1) : e];
+        cAs[e] = P.colA[PAD ? min(e, n1t - 1) : e];
+        cBs[e] = P.colB[PAD ? min(e, n1t - 1) : e];
     }
-    const bool colok = !PAD || gj < n1t;
-    const int gjc = PAD ? min(gj, n1t - 1) : gj;
-    const double g1 = P.m1[gjc];
-    const double cA = P.colA[gjc], cB = P.colB[gjc];
+    if (tid < 2 * NSLOT) scal[tid] = 1.0;
+    load_dist(P.src0, !ax_layout_b(t_first));     // (a step STARTS in the layout its epilogue does not work in)
+    // layout A: the lane's column constants; layout B: its row's coordinate
+    const bool okA = !PAD || gj < n1t, okB = !PAD || gj < n0t;
+    const double g1 = P.m1[PAD ? min(gj, n1t - 1) : gj];
+    const double cA = P.colA[PAD ? min(gj, n1t - 1) : gj], cB = P.colB[PAD ? min(gj, n1t - 1) : gj];
+    const double mub = P.m0[PAD ? min(gj, n0t - 1) : gj];
     double *const pchain = P.post + (long long)b * P.post_stride;
-    const unsigned rowx8 = P.strip_major ? (unsigned)WCOL * 8u : (unsigned)N0 * 8u;
-    const unsigned strip0 = P.strip_major ? (unsigned)tj * (unsigned)(XSZ * 8) : (unsigned)tj * (unsigned)(WCOL * 8);
     const int row0 = wv * (NTW * TM);
     auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    auto cell_off = [&](int l, int it, int r) { return __umul24(row0 + it * TM + (l >> 4) + 4 * r, rowx8) + strip0 + (unsigned)(l & 15) * 8u; };
-    // the exchange buffers of this chain slot: [phase][parity][strip][N0][16] tagged elements, one descriptor
-    const blr::Rsrc xr = blr::strip_rsrc(P.xch + (long long)cs * P.xch_chain, (unsigned)(4u * (unsigned)(G * 8)));
-    auto xbuf = [&](int phase, int k) { return (unsigned)(2 * phase + (k & 1)) * (unsigned)(G * 8); };
-    // where a product tile's elements go: the consumer strip is the tile's 16 rows, inside it [this strip's column][row in 16].  After
-    // swap_rows a lane holds two consecutive rows (g & ~1, + 1) of register 2 rp + (g & 1), rp = 0 / 1: one 16-byte store each
+    // the lane's cells in its strip of a stored sequence / partial accumulator (strip-major, either layout: [strip][line][16])
+    auto cell_off = [&](int l, int it, int r) { return (unsigned)tj * (unsigned)(XSZ * 8) + (unsigned)(row0 + it * TM + (l >> 4) + 4 * r) * 128u + (unsigned)(l & 15) * 8u; };
+    // the exchange buffers of this chain slot: [parity][strip][N0][16] tagged elements, one descriptor
+    const blr::Rsrc xr = blr::strip_rsrc(P.xch + (long long)cs * P.xch_chain, (unsigned)(2u * (unsigned)(G * 8)));
+    auto xbuf = [&](int k) { return (unsigned)(k & 1) * (unsigned)(G * 8); };
+    // where a product tile's elements go: the consumer strip is the tile's 16 lines, inside it [this strip's own index][line in 16].  After
+    // swap_rows a lane holds two consecutive lines (g & ~1, + 1) of register 2 rp + (g & 1), rp = 0 / 1: one 16-byte store each
     auto pub_off = [&](int l, int it, int rp) {
         const int g = l >> 4;
         return (unsigned)(wv * NTW + it) * (unsigned)(XSZ * 8) + (unsigned)tj * 2048u + (unsigned)(l & 15) * 128u +
                (unsigned)((g & 2) + 4 * (2 * rp + (g & 1))) * 8u;
     };
-    // the lane's own cells come back as 16-byte pairs too: a pair = two neighbouring COLUMNS of one row.  The lane of the even column
-    // reads the pairs of its rows g, g + 4 (registers 0, 1), its neighbour those of rows g + 8, g + 12 (registers 2, 3); the two lanes
-    // then hand each other the halves they read for the other (one DPP quad_perm each)
-    auto own_off = [&](int l, int it, int j) {
-        const int c = l & 15, r = 2 * (c & 1) + j;
-        return (unsigned)tj * (unsigned)(XSZ * 8) + (unsigned)(row0 + it * TM + (l >> 4) + 4 * r) * 128u + (unsigned)(c & ~1) * 8u;
-    };
 
-    const int t_first = BWD ? P.T - 1 : 0;
     double xd[DMAX], xn[DMAX];
 #pragma unroll
     for (int q = 0; q < DMAX; ++q) xd[q] = q < P.d ? P.rec[(long long)t_first * P.rec_len + q] : __builtin_nan("");
-    // backward: the stored alpha of the lane's cells at this step -- requested when the step begins, like the accumulator cells (a request
-    // between the tiles of the epilogue makes the next tile wait for it: the compiler cannot count the accesses in flight across the loop)
+    // backward: the stored alpha / fold: the accumulator cells of the lane's cells at this step -- requested behind the gather (whose tagged
+    // loads must not queue behind HBM loads: loads return in order), a whole filter phase ahead of the epilogue that consumes them
     double al[BWD ? NTW : 1][4];
+    double pa[FOLD ? NTW : 1][4];
     double *const pslot = FOLD ? P.part + (long long)cs * P.part_stride : nullptr;
     const double wch = FOLD ? P.wchain[b] : 0.0;
     double inpred = FOLD ? P.infirst[b] : 0.0;
     double sfn = 1.0;
-    // fold: the accumulator cells of the lane's cells at this step -- requested when the step begins (the two filter phases hide the
-    // latency; between the tiles of the epilogue there is no work that would)
-    double pa[FOLD ? NTW : 1][4];
     if (wv == SCALE_WAVE || wv == 5 || wv == 0 || wv == NW - 1) __builtin_amdgcn_s_setprio(2);
     bool dead = false;
     // change points (transitionModels.py:300-312): a step may consume the reset distribution instead of the previous state -- through
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     int nq = 0;
     __syncthreads();
 
-    // a bounded wait: `again` re-requests what is missing and returns true when everything carries the tag
+    // a bounded wait: `again` re-requests what is missing
     auto wait_for = [&](auto &&all_there, auto &&again) {
         if (dead || all_there()) return;
         const unsigned long long t0 = blr::now_ticks();
@@ -180,53 +191,34 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
             }
         }
     };
-    // the banded products of the wave's NTW tiles over the strip in `S` (band table `Ab`), each tile published into buffer `dst`
-    auto filter_and_publish = [&](const double *S, const double *Ab, unsigned dst, unsigned bit, int nlim) {
-        const bool edge = row0 < R0 || row0 + NTW * TM + R0 > nlim;      // (the reflection is at the true last row / column)
-        double Bv[NK];
-        {
-            const int l = fresh_lane(), g = l >> 4, c = l & 15;
-            if (edge) {
+    // the wave's product ring over the strip in `S`: fill / advance by one tile (reflection at the true last line `nlim`)
+    auto ring_fill = [&](const double *S, double (&Bv)[NK], bool edge, int nlim) {
+        const int l = fresh_lane(), g = l >> 4, c = l & 15;
+        if (edge) {
 #pragma unroll
-                for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, nlim) * WCOL + c];
-            } else {
-                const double *s0 = S + (row0 - R0 + g) * WCOL + c;
+            for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, nlim) * WCOL + c];
+        } else {
+            const double *s0 = S + (row0 - R0 + g) * WCOL + c;
 #pragma unroll
-                for (int kb = 0; kb < NK; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
-            }
+            for (int kb = 0; kb < NK; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
         }
+    };
+    auto ring_next = [&](const double *S, double (&Bv)[NK], bool edge, int nlim, int i) {
+        const int l = fresh_lane(), g = l >> 4, c = l & 15;
 #pragma unroll
-        for (int it = 0; it < NTW; ++it) {
-            const int i = row0 + it * TM;
-            const int l = fresh_lane(), g = l >> 4, c = l & 15;
-            const unsigned aoff = (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u;
-            lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)Ab + aoff);
-            const d4 acc = band_products<NK, 0, NK, AST>(Al, Bv);
-            {
-                double a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
-                swap_rows(a0, a1);
-                swap_rows(a2, a3);
-                if (P.xch_mode & 2) {
-                    st_tq2_plain(xr, dst + pub_off(l, it, 0), a0, a1, bit);
-                    st_tq2_plain(xr, dst + pub_off(l, it, 1), a2, a3, bit);
-                } else {
-                    st_tq2(xr, dst + pub_off(l, it, 0), a0, a1, bit);
-                    st_tq2(xr, dst + pub_off(l, it, 1), a2, a3, bit);
-                }
-            }
-            if (it + 1 < NTW) {
+        for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
+        if (edge) {
 #pragma unroll
-                for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
-                if (edge) {
+            for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, nlim) * WCOL + c];
+        } else {
+            const double *s1 = S + (i + TM + R0 + g) * WCOL + c;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, nlim) * WCOL + c];
-                } else {
-                    const double *s1 = S + (i + TM + R0 + g) * WCOL + c;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = s1[q * 4 * WCOL];
-                }
-            }
+            for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = s1[q * 4 * WCOL];
         }
+    };
+    auto band_ptr = [&](const double *Ab, int l) {
+        const unsigned aoff = (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u;
+        return (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)Ab + aoff);
     };
 
     // (option chain_prof: shader-clock stamps of block 0, waves 0 and 2, steps 8 .. 23 -- where a step spends its time)
@@ -236,6 +228,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         const int t = BWD ? P.T - 1 - k : k;
         const int tn = (k + 1 < P.T) ? (BWD ? t - 1 : t + 1) : t;
         const unsigned bit = ax_tag(k);
+        const bool lay_b = ax_layout_b(t);                 // the layout of this step's epilogue; the step starts in the other one
         BLX_STAMP(0);
         // ---- the scale wave's requests (chain_kernel: the sums the scale of step k + 1 is made of were requested a step ago) ------------
         const bool scale_wave = wv == SCALE_WAVE;
@@ -252,10 +245,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         const bool nofilter = (kind_n & 0x80) != 0;
         if (P.kinds) kind_n = P.kinds[(long long)tn * P.B + b];
         if (kind != blk::SRC_PREV && k > 0) {          // (rare: once per chain and change point)
-            for (int e = tid; e < XSZ; e += NT) {
-                const int row = e >> 4, col = tj * WCOL + (e & 15);
-                X0[e] = (!PAD || (row < n0t && col < n1t)) ? P.reset[(long long)row * n1t + col] : 0.0;
-            }
+            load_dist(P.reset, !lay_b);
             if (nofilter) for (int e = tid; e < 2 * NK * AST; e += NT) As0[e] = band_distance16(e % (NK * AST), R0) == 0 ? 1.0 : 0.0;
             __syncthreads();
         }
@@ -264,14 +254,37 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
 #pragma unroll
         for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
 
-        // ---- P1: axis 0 in layout A -> the strips of layout B -----------------------------------------------------------------------------
-        filter_and_publish(X0, As0, xbuf(0, k), bit, n0t);
+        // ---- the first filter, along the lines of the layout the state is in -> the strips of the other layout ----------------------------
+        // (state in layout A: axis 0 along the rows; in layout B: axis 1 along the columns)
+        {
+            const double *Ab = lay_b ? As0 : As1;
+            const int nlim = lay_b ? n0t : n1t;
+            const bool edge = row0 < R0 || row0 + NTW * TM + R0 > nlim;
+            double Bv[NK];
+            ring_fill(X0, Bv, edge, nlim);
+#pragma unroll
+            for (int it = 0; it < NTW; ++it) {
+                const int l = fresh_lane();
+                const d4 acc = band_products<NK, 0, NK, AST>(band_ptr(Ab, l), Bv);
+                double a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+                swap_rows(a0, a1);
+                swap_rows(a2, a3);
+                if (P.xch_mode & 2) {
+                    st_tq2_plain(xr, xbuf(k) + pub_off(l, it, 0), a0, a1, bit);
+                    st_tq2_plain(xr, xbuf(k) + pub_off(l, it, 1), a2, a3, bit);
+                } else {
+                    st_tq2(xr, xbuf(k) + pub_off(l, it, 0), a0, a1, bit);
+                    st_tq2(xr, xbuf(k) + pub_off(l, it, 1), a2, a3, bit);
+                }
+                if (it + 1 < NTW) ring_next(X0, Bv, edge, nlim, row0 + it * TM);
+            }
+        }
         BLX_STAMP(1);
-        // ---- this block's layout-B strip -> X1 (a plain copy: XSZ elements, 512 contiguous bytes per wave access) --------------------------
+        // ---- this block's strip of the other layout -> X1 (a plain copy: XSZ elements, 512 contiguous bytes per wave access) ---------------
         {
             constexpr int NG = XSZ / NT / 2;      // 16-byte pairs per thread: 2 (128 rows) .. 8 (512 rows), all in flight at once
             Tq2 fq[NG];
-            const unsigned base = xbuf(0, k) + (unsigned)tj * (unsigned)(XSZ * 8) + (unsigned)tid * 16u;
+            const unsigned base = xbuf(k) + (unsigned)tj * (unsigned)(XSZ * 8) + (unsigned)tid * 16u;
             auto issue = [&]() {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) fq[j] = ld_tq2(xr, base + (unsigned)j * (unsigned)(NT * 16));
@@ -291,19 +304,18 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                 X1[2 * (tid + j * NT) + 1] = blr::tq_value(fq[j].b);
             }
         }
-        // (the stored alpha / accumulator cells of this step: requested HERE -- behind the gather, whose tagged loads must not queue behind
-        //  HBM loads (loads return in order), and a whole filter phase ahead of the epilogue that consumes them)
+        double *const pstep = pchain + (long long)t * G;
+        double *const pslot_t = FOLD ? pslot + (long long)t * G : nullptr;
         if (BWD) {
             const int l = fresh_lane();
-            const double *const pnow = pchain + (long long)t * G;
 #pragma unroll
             for (int it = 0; it < NTW; ++it)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) al[BWD ? it : 0][r] = ldnt(pnow, cell_off(l, it, r));
+                for (int r = 0; r < 4; ++r) al[BWD ? it : 0][r] = ldnt(pstep, cell_off(l, it, r));
         }
         if (FOLD) {
             const int l = fresh_lane();
-            const double *abase = P.part_fresh ? P.zeros : pslot + (long long)t * G;
+            const double *abase = P.part_fresh ? P.zeros : pslot_t;
 #pragma unroll
             for (int it = 0; it < NTW; ++it)
 #pragma unroll
@@ -314,21 +326,8 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         }
         __syncthreads();
         BLX_STAMP(3);
-        // ---- P2: axis 1 in layout B -> the strips of layout A -----------------------------------------------------------------------------
-        filter_and_publish(X1, As1, xbuf(1, k), bit, n1t);
-        BLX_STAMP(4);
 
-        // ---- P3: the lane's own cells back + the fused epilogue (chain_kernel's) -----------------------------------------------------------
-        Tq2 oq[NTW][2];
-        auto issue_own = [&]() {
-            const int l = fresh_lane();
-#pragma unroll
-            for (int it = 0; it < NTW; ++it)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) oq[it][j] = ld_tq2(xr, xbuf(1, k) + own_off(l, it, j));
-        };
-        issue_own();
-        // the scale of this step; the scale wave prepares the next one (see chain_kernel)
+        // ---- the scale of this step; the scale wave prepares the next one (see chain_kernel) ------------------------------------------------
         const double scale = scal[k & (NSLOT - 1)];
         if (FOLD && k > 0) inpred *= sf_now * iscal[k & (NSLOT - 1)];
         const double wq = FOLD ? wch * inpred : 0.0, wfloor = FOLD ? wch * 1e-300 : 0.0;
@@ -356,98 +355,100 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
             }
             if (lane == 0) { scal[jn & (NSLOT - 1)] = sj; if (FOLD) iscal[jn & (NSLOT - 1)] = 1.0 / sj; }
         }
+
+        // ---- the second filter, fused with the epilogue in this step's layout -----------------------------------------------------------------
         double sN = 0.0, sS = 0.0, sC = 0.0, sM0 = 0.0, sM1 = 0.0;
-        double *const pstep = pchain + (long long)t * G;
-        double *const pslot_t = FOLD ? pslot + (long long)t * G : nullptr;
         {
-            auto there = [&]() {
-                bool ok = true;
-#pragma unroll
-                for (int it = 0; it < NTW; ++it)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) ok = ok && blr::tq_ok(oq[it][j].a, bit) && blr::tq_ok(oq[it][j].b, bit);
-                return ok;
-            };
-            wait_for(there, issue_own);
-        }
-        BLX_STAMP(5);
-        double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
-        int nE = 0, nR = 0;
-#pragma unroll
-        for (int it = 0; it < NTW; ++it) {
-            const int i = row0 + it * TM;
-            const int l = fresh_lane(), g = l >> 4, c = l & 15;
-            double acc[4];
-            {
-                const bool odd = (c & 1) != 0;
-                const double k0 = blr::tq_value(odd ? oq[it][0].b : oq[it][0].a), k1 = blr::tq_value(odd ? oq[it][1].b : oq[it][1].a);     // the lane's own column
-                const double s0 = blr::tq_value(odd ? oq[it][0].a : oq[it][0].b), s1 = blr::tq_value(odd ? oq[it][1].a : oq[it][1].b);     // its neighbour's
-                const double r0 = blk::dpp_src<0xB1, 0xf>(s0, 0.0), r1 = blk::dpp_src<0xB1, 0xf>(s1, 0.0);                              // quad_perm [1, 0, 3, 2]
-                acc[0] = odd ? r0 : k0; acc[1] = odd ? r1 : k1; acc[2] = odd ? k0 : r0; acc[3] = odd ? k1 : r1;
-            }
-            if (it == 0) {
-                // anchor of the stride-4 likelihood recurrence of this lane's rows (observationModels.py:566-567; blhip_mfma.hpp)
-                const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
-                double a0 = 0.0, s1 = 0.0, dn = 0.0;
+            const double *Ab = lay_b ? As1 : As0;
+            const int nlim = lay_b ? n1t : n0t;
+            const bool edge = row0 < R0 || row0 + NTW * TM + R0 > nlim;
+            double Bv[NK];
+            ring_fill(X1, Bv, edge, nlim);
+            // layout A: anchors of the stride-4 likelihood recurrence along the lane's rows; layout B: the row's squared distances
+            double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
+            int nE = 0, nR = 0;
+            double s2 = 0.0, dnb = 0.0;
+            if (lay_b) {
 #pragma unroll
                 for (int q = 0; q < DMAX; ++q) {
                     const double x = xd[q];
-                    if (x == x) {
-                        const double dq = x - mu0;
-                        a0 = fma(-(dq * dq), cA, a0) - cB;
-                        s1 += (x - mu0) + (x - mu4);
-                        dn += 1.0;
+                    if (x == x) { const double dq = x - mub; s2 = fma(dq, dq, s2); dnb += 1.0; }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NTW; ++it) {
+                const int i = row0 + it * TM;
+                const int l = fresh_lane(), g = l >> 4, c = l & 15;
+                d4 acc = band_products<NK, 0, NK, AST>(band_ptr(Ab, l), Bv);
+                if (it == 0 && !lay_b) {
+                    // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50; blhip_mfma.hpp)
+                    const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
+                    double a0 = 0.0, s1 = 0.0, dn = 0.0;
+#pragma unroll
+                    for (int q = 0; q < DMAX; ++q) {
+                        const double x = xd[q];
+                        if (x == x) {
+                            const double dq = x - mu0;
+                            a0 = fma(-(dq * dq), cA, a0) - cB;
+                            s1 += (x - mu0) + (x - mu4);
+                            dn += 1.0;
+                        }
+                    }
+                    const double d1 = cA * (mu4 - mu0) * s1;
+                    const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                    exp_mn(a0, mE, nE);
+                    exp_mn(d1, mR, nR);
+                    if (dn != dn_prev) {
+                        int tmp;
+                        exp_mn(d2, mq, nq);
+                        if (BWD) exp_mn(-d2, iq, tmp);
+                        dn_prev = dn;
+                    }
+                    if (BWD) { iE = blmath::inv_m(mE); iR = blmath::inv_m(mR); }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int li = i + g + 4 * r;                       // layout A: the cell's row; layout B: its column
+                    if (lay_b) {                                         // one exponential per cell: -(sum (x - mu)^2) cA(column) - n cB(column)
+                        exp_mn(fma(-s2, cAs[li], -dnb * cBs[li]), mE, nE);
+                        if (BWD) iE = blmath::inv_m(mE);
+                    }
+                    const bool in = !PAD || (lay_b ? (okB && li < n1t) : (okA && li < n0t));          // (cells outside the grid stay zero)
+                    const double Lv = ldexp(mE, nE);
+                    const unsigned off = cell_off(l, it, r);
+                    if (!BWD) {
+                        const double a = in ? acc[r] * scale * Lv : 0.0;
+                        X0[li * WCOL + c] = a;
+                        if (STORE) stnt(pstep, off, a);
+                        sN += a;
+                        acc[r] = a;
+                    } else {
+                        const double beta = in ? acc[r] * scale : 0.0;
+                        const double p = al[BWD ? it : 0][r] * beta;
+                        const double cn = beta * Lv;
+                        const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));      // p / L; 0 / 0 -> NaN (core.py:463)
+                        X0[li * WCOL + c] = cn;
+                        if (!FOLD) stnt(pstep, off, p);
+                        else stnt(pslot_t, off, pa[FOLD ? it : 0][r] + fmax(p * wq, wfloor));
+                        sN += p;
+                        sS += pl;
+                        sC += cn;
+                        acc[r] = p;
+                    }
+                    if (!lay_b) {
+                        mE *= mR; nE += nR;
+                        mR *= mq; nR += nq;
+                        if (BWD) { iE *= iR; iR *= iq; }
+                    }
+                    if ((BWD || STORE) && P.means) {
+                        sM0 = fma(acc[r], lay_b ? mub : m0s[li], sM0);
+                        sM1 = fma(acc[r], lay_b ? m1s[li] : g1, sM1);
                     }
                 }
-                const double d1 = cA * (mu4 - mu0) * s1;
-                const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
-                exp_mn(a0, mE, nE);
-                exp_mn(d1, mR, nR);
-                if (dn != dn_prev) {
-                    int tmp;
-                    exp_mn(d2, mq, nq);
-                    if (BWD) exp_mn(-d2, iq, tmp);
-                    dn_prev = dn;
-                }
-                if (BWD) { iE = blmath::inv_m(mE); iR = blmath::inv_m(mR); }
-                else mE *= scale;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int li = i + g + 4 * r;
-                const double Lv = ldexp(mE, nE);
-                const unsigned off = cell_off(l, it, r);
-                const bool in = !PAD || (colok && li < n0t);          // (cells outside the grid stay zero)
-                if (!BWD) {
-                    const double a = in ? acc[r] * Lv : 0.0;
-                    X0[li * WCOL + c] = a;
-                    if (STORE) stnt(pstep, off, a);
-                    sN += a;
-                    acc[r] = a;
-                } else {
-                    const double beta = in ? acc[r] * scale : 0.0;
-                    const double p = al[BWD ? it : 0][r] * beta;
-                    const double cn = beta * Lv;
-                    const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));      // p / L; 0 / 0 -> NaN (core.py:463)
-                    X0[li * WCOL + c] = cn;
-                    if (!FOLD) stnt(pstep, off, p);
-                    else stnt(pslot_t, off, pa[FOLD ? it : 0][r] + fmax(p * wq, wfloor));
-                    sN += p;
-                    sS += pl;
-                    sC += cn;
-                    acc[r] = p;
-                }
-                mE *= mR; nE += nR;
-                mR *= mq; nR += nq;
-                if (BWD) { iE *= iR; iR *= iq; }
-            }
-            if ((BWD || STORE) && P.means) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { sM0 = fma(acc[r], m0s[i + g + 4 * r], sM0); sM1 = fma(acc[r], g1, sM1); }
+                if (it + 1 < NTW) ring_next(X1, Bv, edge, nlim, i);
             }
         }
-
-        BLX_STAMP(6);
+        BLX_STAMP(4);
         // ---- sums: waves -> LDS; after the barrier wave 5 adds them up, writes the strip's partial sums, publishes the granule ------------
         double v[5] = {sN, sS, BWD ? sC : sM0, BWD ? sM0 : sM1, sM1};
         constexpr int NV = BWD ? 5 : 4;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
             }
         }
         __syncthreads();
-        BLX_STAMP(7);
+        BLX_STAMP(5);
         if (k == 0 || (nofilter && kind != blk::SRC_PREV)) {            // the chain's bands replace the identities of the first step / of an unfiltered restart
             for (int e = tid; e < NK * AST; e += NT) {
                 const int a = band_distance16(e, R0);

@@ -298,9 +298,9 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_tapid1, cp.tap_id1.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
         if (ax1) {               // the exchange buffers of a launch's chain slots: [slot][2 phases][2 parities][G] tagged elements
-            xch_bytes = (size_t)cp.cpr * 4 * (size_t)Gk * 8;
+            xch_bytes = (size_t)cp.cpr * 2 * (size_t)Gk * 8;
             ctx->xch.ensure(xch_bytes);
-            CQ.xch = ctx->xch.as<double>(); CQ.xch_chain = 4 * Gk; CQ.tap_id1 = d_tapid1;
+            CQ.xch = ctx->xch.as<double>(); CQ.xch_chain = 2 * Gk; CQ.tap_id1 = d_tapid1;
             ax_mode = (int)ctx->option("chain_ax1_mode", -1.0);
         }
         CQ.n0 = cp.n0p; CQ.n1 = cp.n1p; CQ.n0t = E.g.n0; CQ.n1t = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = tab ? 0 : E.d; CQ.rec_len = E.rec_len;
@@ -311,7 +311,7 @@ struct ChainRun {
         CQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
         // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)
-        post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && ((G & 1) == 0 || cp.pad) && ((uintptr_t)ctx->acc & 15) == 0;
+        post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && ((G & 1) == 0 || cp.pad || ax1) && ((uintptr_t)ctx->acc & 15) == 0;
         // (not beside overlapped folds: a FoldJob of the previous batch may still read ctx->accw and read-modify-write ctx->acc on the
         //  second stream while this batch re-carves accw and its fused fold writes ctx->acc on the main stream)
         // (a restart inside a FILTERING chain would need sum(alpha T(reset)) for the predicted sums: such batches store and fold separately)
@@ -343,7 +343,8 @@ struct ChainRun {
         // a grid smaller than the geometry: only fits whose sequences are private to the fit (strip-major, padded) -- evidence-only fits
         // and full fits of hyper- / change-point studies (folded in the backward kernel, or stored and folded by accumulate_pad_kernel);
         // everything else keeps the launch-per-step kernels
-        if (cp.pad && !(E.ff.evidence_only || post_private)) {
+        // (the both-axes kernels keep their sequences in two alternating strip-major layouts: never the API's, also on an exact geometry)
+        if ((cp.pad || ax1) && !(E.ff.evidence_only || post_private)) {
             // ... or, at the price of a second sequence in memory, any fit: the posteriors are copied out of the padded layout afterwards
             // (<= 512 rows: every flavour has a padded storing kernel; 1024 rows: forward passes only)
             size_t free_b = 0, total_b = 0;
@@ -423,7 +424,7 @@ struct ChainRun {
             Q.reset = E.DT->reset;
             Q.post = E.d_post;
             Q.means = bwd ? (E.chain_means ? 1 : 0) : (E.ff.forward_only ? 1 : 0);
-            Q.strip_major = (post_private || cp.pad) ? 1 : 0;            // (the stored sequence is private to the fit then)
+            Q.strip_major = (post_private || cp.pad || ax1) ? 1 : 0;            // (the stored sequence is private to the fit then)
             const bool fold_now = bwd && fused;
             if (fold_now) {
                 Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
@@ -452,13 +453,13 @@ struct ChainRun {
                     unsigned long long hh[2 * 16 * 16];
                     HIPCHECK(hipMemcpyAsync(hh, ctx->small.p, sizeof hh, hipMemcpyDeviceToHost, st));
                     sync_stream(ctx, st);
-                    static const char *names[8] = {"start", "P1+publish", "gather", "barrier", "P2+publish", "own cells", "epilogue", "sums+barrier"};
+                    static const char *names[6] = {"start", "filter 1 + publish", "gather", "barrier", "filter 2 + epilogue", "sums + barrier"};
                     for (int wvi = 0; wvi < 2; ++wvi) {
                         const unsigned long long *h = hh + wvi * 256;
-                        double acc[8] = {0}; int n = 0;
-                        for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 7] || !h[q * 16]) continue; ++n; for (int i = 1; i < 8; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
+                        double acc[6] = {0}; int n = 0;
+                        for (int q = 0; q < 16; ++q) { if (!h[q * 16 + 5] || !h[q * 16]) continue; ++n; for (int i = 1; i < 6; ++i) acc[i] += (double)(h[q * 16 + i] - h[q * 16 + i - 1]); }
                         std::fprintf(stderr, "[blc ax prof %s NK %d wave %d] %d steps:", bwd ? "bwd" : "fwd", rnk[r], wvi ? 2 : 0, n);
-                        double tot = 0; for (int i = 1; i < 8; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
+                        double tot = 0; for (int i = 1; i < 6; ++i) { std::fprintf(stderr, " %s %.0f", names[i], n ? acc[i] / n : 0.0); tot += n ? acc[i] / n : 0.0; }
                         std::fprintf(stderr, " | total %.0f\n", tot);
                     }
                 }
@@ -472,9 +473,9 @@ struct ChainRun {
                 if (!bwd && skip_prefix)               // (chain-steps the forward pass does not run)
                     for (int q = rstart[r]; q < rstart[r + 1]; ++q) cells -= (double)h_tshare[cp.order[q]] * Gk;
                 double bytes = bwd ? (fold_now ? (two ? 8.0 + 16.0 * ((Q.nslots + 1) / 2) / (double)Q.nslots : 24.0) : 16.0) : (E.ff.evidence_only ? 0.0 : 8.0);
-                // (both-axes kernels: the two transposing exchanges of a step leave the XCD's L2 as well -- 2 x (8 written + 8 read);
+                // (both-axes kernels: the transposing exchange of a step leaves the XCD's L2 as well -- 8 written + 8 read;
                 //  with the blocks of a chain on one XCD the reads mostly hit that L2: the PMC counters say what really moves)
-                if (ax1) bytes += 32.0;
+                if (ax1) bytes += 16.0;
                 const int r0 = (4 * rnk[r] - blc::TM) / 2;
                 double shared = 0.0;                                  // stored states not written (forward) / read once per launch instead of once per chain (backward)
                 if (share_prefix && (bwd ? fold_now : !E.ff.evidence_only)) {
@@ -597,7 +598,7 @@ struct ChainRun {
             HIPCHECK(hipEventRecord(ctx->ev[4], st));
             hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)(((G + 1) / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
                                ctx->accpart.as<double>(), (long long)T * Gk, slots_used, E.g.n0, E.g.n1, (int)T, r, rb,
-                               ctx->acc_first ? 1 : 0, cp.n0p, Gk);
+                               ctx->acc_first ? 1 : 0, cp.n0p, Gk, ax1 ? 1 : 0);
             HIPCHECK(hipEventRecord(ctx->ev[5], st));
             sync_stream(ctx, st);
             float fms = 0;

@@ -77,6 +77,16 @@ __device__ __forceinline__ int extend_index(int i, int n, int rule) {
     return reflect(i, n);
 }
 
+// The both-axes chain-resident kernels (blhip_chainax.hpp) keep what belongs to time t -- stored state, posterior, partial accumulator -- in
+// one of two strip-major layouts on their SQUARE geometry of n0p rows = columns, alternating with t:
+//   layout A (odd t):  [strip = column / 16][row][column % 16]          (chain_kernel's)
+//   layout B (even t): [strip = row / 16][column][row % 16]             (the transposed one)
+__host__ __device__ __forceinline__ bool ax_layout_b(int t) { return (t & 1) == 0; }
+// doubles from the beginning of a time step's slice to cell (row, col); ax = 0: always layout A (every other chain-resident kernel)
+__device__ __forceinline__ long long strip_major_index(int row, int col, int n0p, int t, int ax) {
+    return (ax && ax_layout_b(t)) ? ((long long)(row >> 4) * n0p + col) * 16 + (row & 15) : ((long long)(col >> 4) * n0p + row) * 16 + (col & 15);
+}
+
 // Wave-wide sum on the DPP cross-lane path (no LDS round trips): 4 row_shr steps inside each row of 16 lanes, then
 // row_bcast:15 / row_bcast:31 fold the four rows; the total lands in lane 63 and is broadcast through an SGPR.
 // (__shfl_down on a double is 2 ds_bpermute_b32 per step: ~1200 cycles per sum vs ~100 here -- per block that was 1-2 us
@@ -634,9 +644,23 @@ static __global__ __launch_bounds__(NTHREADS) void accumulate_small_kernel(doubl
 // (n0p: rows per strip of the partials -- the kernel's padded row count when the grid's is not 128 / 256 / 512; pstep: doubles per time
 //  step of a partial accumulator on that padded geometry)
 static __global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, const double *part, long long part_stride, int nslots, int n0, int n1,
-                                                               int T, double r, double rb, int first, int n0p, long long pstep) {
+                                                               int T, double r, double rb, int first, int n0p, long long pstep, int ax) {
     const long long G = (long long)n0 * n1;
     const int t = blockIdx.y;
+    if (ax && ax_layout_b(t)) {            // the transposed layout of the both-axes kernels: one cell per lane
+        for (int h = 0; h < 2; ++h) {
+            const long long c = ((long long)blockIdx.x * NTHREADS + threadIdx.x) * 2 + h;
+            if (c >= G) return;
+            const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
+            double *ap = A + (long long)t * G + c;
+            const double acc = first ? 0.0 : *ap * r;
+            const double *src = part + (long long)t * pstep + strip_major_index(row, col, n0p, t, 1);
+            double sum = 0.0;
+            for (int k = 0; k < nslots; ++k) sum += src[(long long)k * part_stride];
+            *ap = fma(rb, sum, acc);
+        }
+        return;
+    }
     if (n1 & 1) {                          // an odd number of columns: pairs of cells would straddle rows -- one cell per lane
         for (int h = 0; h < 2; ++h) {
             const long long c = ((long long)blockIdx.x * NTHREADS + threadIdx.x) * 2 + h;
@@ -672,14 +696,14 @@ static __global__ __launch_bounds__(NTHREADS) void fold_parts_kernel(double *A, 
 // ([t][column / 16][row of n0p][16], pstep doubles per time step, chain_stride per chain): one cell per lane (any number of columns).
 static __global__ __launch_bounds__(NTHREADS) void accumulate_pad_kernel(double *A, const double *post, long long chain_stride, int B, int n0, int n1,
                                                                   int T, const double *w, const double *invN, double r, int first,
-                                                                  int n0p, long long pstep) {
+                                                                  int n0p, long long pstep, int ax) {
     const long long G = (long long)n0 * n1;
     const long long t = blockIdx.y;
     const long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x;
     if (c >= G) return;
     const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
     double acc = first ? 0.0 : A[t * G + c] * r;
-    const double *pp = post + t * pstep + ((long long)(col >> 4) * n0p + row) * 16 + (col & 15);
+    const double *pp = post + t * pstep + strip_major_index(row, col, n0p, (int)t, ax);
     for (int b = 0; b < B; ++b) {
         const double wb = w[b];
         if (wb > 0.0) {
@@ -781,12 +805,12 @@ static __global__ __launch_bounds__(NTHREADS) void marginal_cols_kernel(const do
 // A sequence the chain-resident kernels left in their strip-major layout on a PADDED geometry ([t][column / 16][row of n0p][16], pstep
 // doubles per time step) -> the row-major sequence of the grid itself ([t][n0][n1]) that every consumer outside the fit reads.
 // blockIdx.y = chain * T + t; lanes run along the destination (coalesced stores, 128-byte runs of the source).
-static __global__ __launch_bounds__(NTHREADS) void depad_kernel(double *dst, const double *src, int n0, int n1, int n0p, long long pstep) {
+static __global__ __launch_bounds__(NTHREADS) void depad_kernel(double *dst, const double *src, int n0, int n1, int n0p, long long pstep, int T, int ax) {
     const long long G = (long long)n0 * n1;
     const long long c = (long long)blockIdx.x * NTHREADS + threadIdx.x;
     if (c >= G) return;
     const int row = (int)(c / n1), col = (int)(c - (long long)row * n1);
-    dst[(long long)blockIdx.y * G + c] = __builtin_nontemporal_load(src + (long long)blockIdx.y * pstep + ((long long)(col >> 4) * n0p + row) * 16 + (col & 15));
+    dst[(long long)blockIdx.y * G + c] = __builtin_nontemporal_load(src + (long long)blockIdx.y * pstep + strip_major_index(row, col, n0p, (int)(blockIdx.y % (unsigned)T), ax));
 }
 
 // out[c] = (1/T) sum_t p[t][c]
