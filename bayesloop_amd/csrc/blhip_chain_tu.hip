@@ -1,5 +1,6 @@
 // One SLICE of the chain-resident kernels per compilation: -DBLC_TU=1 .. blcl::N_SLICES (build.py compiles the slices in parallel).
 // Which instantiations a slice holds is decided here and nowhere else; blhip.hip dispatches on (tiles per wave, pass, ring length).
+#include <algorithm>
 #include "blhip_chain_launch.hpp"
 #include "blhip_err.hpp"
 
@@ -236,6 +237,11 @@ void chainax_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bo
     if (ntw == 2) launch_w_ax<2, false>(s, Q, nk, bwd, store);
     else if (ntw == 1) launch_w_ax<1, false>(s, Q, nk, bwd, store);
     else fail("internal: both-axes chain-resident kernel with %d tiles per wave", ntw);
+}
+void chainax_lik_table(hipStream_t s, int n0p, int n0t, int n1t, int T, int d, int rec_len, const double *m0, const double *colA, const double *colB, const double *rec, double *out) {
+    blc::AxLikParams L{n0p, n0t, n1t, T, d, rec_len, m0, colA, colB, rec, out};
+    const long long G = (long long)n0p * n0p;
+    hipLaunchKernelGGL(blc::ax_lik_table_kernel, dim3((unsigned)std::min<long long>((G + 255) / 256, 1024), (unsigned)((T + 1) / 2)), dim3(256), 0, s, L);
 }
 #elif BLC_TU == 20
 void chainax_ntw4(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) { launch_w_ax<4, false>(s, Q, nk, bwd, store); }

@@ -71,6 +71,31 @@ __device__ __forceinline__ void swap_rows(double &x, double &y) {
 // the tag of the elements step k publishes: a buffer (parity k & 1) is rewritten every second step, zeroed before the launch
 __device__ __forceinline__ unsigned ax_tag(int k) { return 1u - (((unsigned)k >> 1) & 1u); }
 
+// The likelihood of the EVEN time steps (the ones whose epilogue works in layout B, where a lane walks along the second parameter and the
+// Gaussian has no recurrence: one exp per cell was 16 x 35 fp64 instructions per lane and step -- a quarter of such a step), tabulated once
+// per batch in that layout: out[t / 2][strip = row / 16][column][row % 16], zero outside the grid.  Same formula as the kernel's own
+// -(sum_d (x_d - mu)^2) cA(column) - n cB(column) (observationModels.py:566-567, product over the data dimensions :49-50).
+struct AxLikParams { int n0p, n0t, n1t, T, d, rec_len; const double *m0, *colA, *colB, *rec; double *out; };
+static __global__ __launch_bounds__(256) void ax_lik_table_kernel(const AxLikParams P) {
+    const int te = blockIdx.y, t = 2 * te;
+    const long long G = (long long)P.n0p * P.n0p;
+    double *o = P.out + (long long)te * G;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < G; e += (long long)gridDim.x * 256) {
+        const int rr = (int)(e & 15), col = (int)((e >> 4) % P.n0p), row = (int)(e / ((long long)P.n0p * 16)) * 16 + rr;
+        double v = 0.0;
+        if (row < P.n0t && col < P.n1t) {
+            const double mu = P.m0[row];
+            double s2 = 0.0, dn = 0.0;
+            for (int q = 0; q < P.d; ++q) {
+                const double x = P.rec[(long long)t * P.rec_len + q];
+                if (x == x) { const double dq = x - mu; s2 = fma(dq, dq, s2); dn += 1.0; }
+            }
+            v = exp(fma(-s2, P.colA[col], -dn * P.colB[col]));
+        }
+        o[e] = v;
+    }
+}
+
 // PAD: the grid is smaller than the square geometry (any n0, n1 <= 512: the geometry is the next of 128 / 256 / 512 that holds both).  As in
 // chain_kernel: the stencils reflect at the grid's TRUE last row / column, cells outside the grid are kept at zero and out of every sum,
 // read-only inputs are read with bounds.  Lines beyond the grid pick up mirrored values in the first filter (and keep them through the
@@ -324,6 +349,17 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                     pa[FOLD ? it : 0][r] = ldnt(abase, P.part_fresh ? (aoffs & 4088u) : aoffs);
                 }
         }
+        // (layout-B steps: the likelihood of the lane's cells out of the table, where there is one)
+        double lk[NTW][4];
+        const bool tabled = lay_b && P.lik != nullptr;
+        if (tabled) {
+            const int l = fresh_lane();
+            const double *lrow = P.lik + (long long)(t >> 1) * G;
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lk[it][r] = blm::ld32(lrow, cell_off(l, it, r));
+        }
         __syncthreads();
         BLX_STAMP(3);
 
@@ -409,12 +445,12 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int li = i + g + 4 * r;                       // layout A: the cell's row; layout B: its column
-                    if (lay_b) {                                         // one exponential per cell: -(sum (x - mu)^2) cA(column) - n cB(column)
+                    if (lay_b && !tabled) {                              // one exponential per cell: -(sum (x - mu)^2) cA(column) - n cB(column)
                         exp_mn(fma(-s2, cAs[li], -dnb * cBs[li]), mE, nE);
                         if (BWD) iE = blmath::inv_m(mE);
                     }
                     const bool in = !PAD || (lay_b ? (okB && li < n1t) : (okA && li < n0t));          // (cells outside the grid stay zero)
-                    const double Lv = ldexp(mE, nE);
+                    const double Lv = tabled ? lk[it][r] : ldexp(mE, nE);
                     const unsigned off = cell_off(l, it, r);
                     if (!BWD) {
                         const double a = in ? acc[r] * scale * Lv : 0.0;
@@ -426,7 +462,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                         const double beta = in ? acc[r] * scale : 0.0;
                         const double p = al[BWD ? it : 0][r] * beta;
                         const double cn = beta * Lv;
-                        const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));      // p / L; 0 / 0 -> NaN (core.py:463)
+                        const double pl = !in ? 0.0 : (tabled ? p / Lv : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)));      // p / L; 0 / 0 -> NaN (core.py:463)
                         X0[li * WCOL + c] = cn;
                         if (!FOLD) stnt(pstep, off, p);
                         else stnt(pslot_t, off, pa[FOLD ? it : 0][r] + fmax(p * wq, wfloor));

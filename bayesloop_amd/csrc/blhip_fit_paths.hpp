@@ -302,12 +302,24 @@ struct ChainRun {
             ctx->xch.ensure(xch_bytes);
             CQ.xch = ctx->xch.as<double>(); CQ.xch_chain = 2 * Gk; CQ.tap_id1 = d_tapid1;
             ax_mode = (int)ctx->option("chain_ax1_mode", -1.0);
+            // the likelihood of the even time steps (epilogue in the transposed layout) as a table: an exp per cell there otherwise.  Measured
+            // (profiles/r05_notes.md): single fits are latency-bound and gain (200 x 200, radius 20: 7.9 -> 7.5 us per step); launches of
+            // eight chains sit on eight XCDs, every one of which fetches the table through the fabric the exchange already saturates
+            // (c4_both_axes 553 -> 578 ms): one or two chains only (chain_ax1_table = 2: always, 0: never)
+            const double tab_bytes = (double)((T + 1) / 2) * (double)Gk * 8.0;
+            const double tab_opt = ctx->option("chain_ax1_table", 1.0);
+            if (tab_opt != 0.0 && (B <= 2 || tab_opt == 2.0) && tab_bytes < 8.0e9) {
+                ctx->axlik.ensure((size_t)tab_bytes);
+                blcl::chainax_lik_table(E.st, cp.n0p, E.g.n0, E.g.n1, (int)T, E.d, E.rec_len, E.DT->m0, E.DT->colA, E.DT->colB, E.DT->rec, ctx->axlik.as<double>());
+                HIPCHECK(hipGetLastError());
+                CQ.lik = ctx->axlik.as<double>();
+            }
         }
         CQ.n0 = cp.n0p; CQ.n1 = cp.n1p; CQ.n0t = E.g.n0; CQ.n1t = E.g.n1; CQ.strips = cp.strips; CQ.T = (int)T; CQ.d = tab ? 0 : E.d; CQ.rec_len = E.rec_len;
         CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
         CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
         CQ.post_stride = (long long)T * Gk;
-        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; CQ.lik = tab ? E.DT->lik : nullptr; CQ.step0 = E.step0;
+        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; if (tab) CQ.lik = E.DT->lik; CQ.step0 = E.step0;      // (both-axes kernels: CQ.lik is their table of the even steps, set above)
         CQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
         // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)
