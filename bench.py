@@ -431,6 +431,22 @@ def end_to_end(bl, S, kw, units):
                          'second and later read-backs of a size), cold_ms: the first one, into a pageable array')
 
 
+def cold_first_fit(workload='c4', timeout=300):
+    """Wall time of the FIRST fit of a workload in a fresh process (library load + code-object load of ~1500 kernels + buffer
+    allocation + the fit) and of the second one: what a user's first call pays.  -> dict or None."""
+    import subprocess
+    code = ("import sys, time, json; sys.path.insert(0, %r); import bench; import bayesloop_amd as bl\n"
+            "t0 = time.perf_counter(); eng = bl.get_engine(); S, kw, u, d = bench.make_study(bl, %r)\n"
+            "S.fit(**kw); eng.synchronize(); t1 = time.perf_counter()\n"
+            "S.fit(**kw); eng.synchronize(); t2 = time.perf_counter()\n"
+            "print(json.dumps(dict(first_fit_ms=(t1 - t0) * 1e3, second_fit_ms=(t2 - t1) * 1e3)))" % (ROOT, workload))
+    try:
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        return json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else dict(error=(r.stderr or '')[-200:])
+    except Exception as e:     # noqa: BLE001 -- a diagnostic
+        return dict(error=repr(e))
+
+
 def _cpu_share(args):
     """One worker of the CPU baseline: the oracle's hyper_fit over its share of the sigma values -> seconds of compute."""
     n, T, sigmas = args
@@ -564,6 +580,8 @@ def compact_line(out):
                 b['end_to_end_value'] = v['end_to_end']['value']
             ex[name] = b
         line['extra'] = ex
+    if isinstance(out.get('cold_first_fit'), dict) and 'first_fit_ms' in out['cold_first_fit']:
+        line['cold_first_fit_ms'] = out['cold_first_fit']['first_fit_ms']
     line['detail'] = 'bench_detail.json'
     line = _sig(line)
     # full-precision where the driver or the parity gate reads it
@@ -850,6 +868,8 @@ def main():
                 except Exception as e:     # a failed side workload must not lose the headline line
                     extra[name] = dict(error=repr(e))
             out['extra'] = extra
+        if not args.no_extra and world == 1 and not TEST_DOUBLE:
+            out['cold_first_fit'] = cold_first_fit(args.workload)
         if not args.no_cpu and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         recalibrate(out)
