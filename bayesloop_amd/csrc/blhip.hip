@@ -1234,7 +1234,9 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
     const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * Gk * 8.0 +
                              (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
     int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
-    Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024));
+    // (1-D grids: a chain is a few KB and a batch of the chain-resident 1-D kernel costs a fixed ~1 ms of launches, syncs and read-backs --
+    //  the reference's published break-point study, 23 400 chains: 61 ms with batches of 1024, 52 with 4096, 54 with 8192)
+    Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", p->ndim == 1 ? 4096 : 1024));
     Bmax = std::min<int64_t>(Bmax, 65535);
     if (ff.keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
     if ((ff.resume || ff.carry) && n_chains > Bmax) fail("carried states: %lld chains do not fit in one batch", (long long)n_chains);
