@@ -1973,6 +1973,38 @@ def test_resident_paths_fall_back_when_a_block_gives_up():
     assert abs(S3.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3, 6, 7, 13, 16])
+def test_both_axes_batches_fall_back_too(seed):
+    """The give-up of a batch of the transposing chain-resident kernels (blhip_chainax.hpp): its sequences live in the two alternating
+    strip-major layouts of a square geometry, private to the fit or de-layouted afterwards -- the repeat through the launch-per-step
+    kernels must find buffers of the right shape and give the oracle's results (hyper-studies that fold, ragged grids, change points,
+    plain fits that hand their posteriors out)."""
+    eng = bl.get_engine()
+    c = random_cases.random_both_axes_square_case(seed)
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    eng.set_option('resident_force_abort', 1)
+    try:
+        S = cases.build(bl, c)
+        with np.errstate(all='ignore'):
+            S.fit(**cases.fit_kwargs(c))
+        assert S.lastTiming['fwd_kernel_variant'] not in (5, 6) and S.lastTiming['resident_fallbacks'] >= 1, S.lastTiming
+        got = result_of(S, c)
+        gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+        for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+            if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+                gold[k] = np.asarray(want[k])
+        compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+    finally:
+        eng.set_option('resident_force_abort', 0)
+        eng.set_option('resident_ok', 1)
+    S3 = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S3.fit(**cases.fit_kwargs(c))
+    assert S3.lastTiming['fwd_kernel_variant'] in (5, 6), S3.lastTiming
+    assert abs(S3.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
+
+
 @pytest.mark.parametrize('case', ['pad_100x37_full', 'mixed_cp_grw_128x32', 'pad_cp_150x40'])
 def test_padded_and_restarting_batches_fall_back_too(case):
     """The same give-up on a padded grid (its sequence buffer is laid out for the padded geometry) and on a batch with restarts
