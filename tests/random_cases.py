@@ -400,6 +400,8 @@ def random_both_axes_square_case(seed):
     def sigma(span, npts, radius):
         return max(radius, 0.3) / 4.0 * span / max(npts - 1, 1)
     r0, r1 = int(rng.integers(0, 41)), int(rng.integers(1, 41))
+    if kind == 'hyper_axis1':
+        r1 = max(r1, 3)                      # (the hyper-grid of that kind starts at radius 2: an ascending grid)
     s1, s2 = sigma(10, n0, r0), sigma(3, n1 + 2, r1)
     nh = int(rng.integers(2, 5))
     if kind == 'study_both':

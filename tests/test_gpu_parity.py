@@ -958,9 +958,11 @@ def test_seeded_random_both_axes_walks_on_square_grids_take_the_transposing_chai
         want = oa.run(c)
     tm = S.lastTiming
     ok = (6,) if c['study'] != 'Study' else (5, 6)          # (a single chain with radii <= 8 on both axes: the time-resident kernel)
-    assert tm['fwd_kernel_variant'] in ok and tm['resident_fallbacks'] == 0, tm
-    if not (c['fit'].get('evidenceOnly') or c['fit'].get('forwardOnly')):
-        assert tm['bwd_kernel_variant'] in ok, tm
+    n0, n1 = [int(v) for v in S.gridSize]
+    if min(n0, n1) >= 72:          # (smaller grids with walks of radius ~40 are outside the streaming / resident kernels' envelope altogether)
+        assert tm['fwd_kernel_variant'] in ok and tm['resident_fallbacks'] == 0, tm
+        if not (c['fit'].get('evidenceOnly') or c['fit'].get('forwardOnly')):
+            assert tm['bwd_kernel_variant'] in ok, tm
     got = result_of(S, c)
     gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
     for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
@@ -973,10 +975,17 @@ def test_seeded_random_both_axes_walks_on_square_grids_take_the_transposing_chai
         S0 = cases.build(bl, c)
         with np.errstate(all='ignore'):
             S0.fit(**cases.fit_kwargs(c))
-        assert S0.lastTiming['fwd_kernel_variant'] != 6, S0.lastTiming
+        assert S0.lastTiming['fwd_kernel_variant'] != 6 or c['study'] == 'Study', S0.lastTiming
     finally:
         eng.set_option('chain_ax1', 1)
     np.testing.assert_allclose(S.logEvidence, S0.logEvidence, rtol=1e-11)
+    if seed % 5 == 0:              # bit-stable from run to run (fixed summation orders, no atomics; the exchange carries values, not sums)
+        S1 = cases.build(bl, c)
+        with np.errstate(all='ignore'):
+            S1.fit(**cases.fit_kwargs(c))
+        assert S1.logEvidence == S.logEvidence and np.array_equal(np.asarray(S1.localEvidence), np.asarray(S.localEvidence), equal_nan=True)
+        if 'posteriorSequence' in got:
+            assert np.array_equal(np.asarray(S1.posteriorSequence), np.asarray(got['posteriorSequence']), equal_nan=True)
 
 
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 32))))
