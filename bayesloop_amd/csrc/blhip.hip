@@ -606,8 +606,7 @@ void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, boo
 // walks on both parameters (blc::chainax_kernel, blhip_chainax.hpp)
 void launch_chainax(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad) {
     if (ntw == 4) { if (pad) blcl::chainax_ntw4_pad(s, Q, nk, bwd, store); else blcl::chainax_ntw4(s, Q, nk, bwd, store); }
-    else if (pad) blcl::chainax_ntw12_pad(s, Q, nk, ntw, bwd, store);
-    else blcl::chainax_ntw12(s, Q, nk, ntw, bwd, store);
+    else blcl::chainax_ntw12_pad(s, Q, nk, ntw, bwd, store);      // (these kernels take exact 128 / 256 grids too)
     HIPCHECK(hipGetLastError());
 }
 

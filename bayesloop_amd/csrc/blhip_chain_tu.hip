@@ -233,11 +233,6 @@ void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int n
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
 }
 #elif BLC_TU == 19
-void chainax_ntw12(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
-    if (ntw == 2) launch_w_ax<2, false>(s, Q, nk, bwd, store);
-    else if (ntw == 1) launch_w_ax<1, false>(s, Q, nk, bwd, store);
-    else fail("internal: both-axes chain-resident kernel with %d tiles per wave", ntw);
-}
 void chainax_lik_table(hipStream_t s, int n0p, int n0t, int n1t, int T, int d, int rec_len, const double *m0, const double *colA, const double *colB, const double *rec, double *out) {
     blc::AxLikParams L{n0p, n0t, n1t, T, d, rec_len, m0, colA, colB, rec, out};
     const long long G = (long long)n0p * n0p;
@@ -246,6 +241,7 @@ void chainax_lik_table(hipStream_t s, int n0p, int n0t, int n1t, int T, int d, i
 #elif BLC_TU == 20
 void chainax_ntw4(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) { launch_w_ax<4, false>(s, Q, nk, bwd, store); }
 #elif BLC_TU == 21
+// (128 / 256 rows = columns: the PAD kernels also take the grids that fill their geometry -- no exact variants: 40 kernels less)
 void chainax_ntw12_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store) {
     if (ntw == 2) launch_w_ax<2, true>(s, Q, nk, bwd, store);
     else if (ntw == 1) launch_w_ax<1, true>(s, Q, nk, bwd, store);
