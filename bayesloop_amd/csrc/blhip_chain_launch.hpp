@@ -37,6 +37,7 @@ void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int n
 // ... walks on both parameters (blc::chainax_kernel: square geometries of 128 / 256 / 512 rows and columns, grids of any size inside them; band blocks 8 / 12 / 16 / 20 / 24
 // = radius <= 8 .. 40 on either axis)
 // (the likelihood of the even time steps in the transposed layout: out = ceil(T / 2) x n0p^2 doubles)
+void chainax_lik_transpose(hipStream_t s, const double *lik, double *out, int n0p, int n0t, int n1t, int T);      // ... of a tabulated model
 void chainax_lik_table(hipStream_t s, int n0p, int n0t, int n1t, int T, int d, int rec_len, const double *m0, const double *colA, const double *colB, const double *rec, double *out);
 void chainax_ntw4(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store);
 void chainax_ntw12_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store);      // grids smaller than the square geometry

@@ -233,6 +233,10 @@ void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int n
     else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
 }
 #elif BLC_TU == 19
+void chainax_lik_transpose(hipStream_t s, const double *lik, double *out, int n0p, int n0t, int n1t, int T) {
+    const long long G = (long long)n0p * n0p;
+    hipLaunchKernelGGL(blc::ax_lik_transpose_kernel, dim3((unsigned)std::min<long long>((G + 255) / 256, 1024), (unsigned)((T + 1) / 2)), dim3(256), 0, s, lik, out, n0p, n0t, n1t);
+}
 void chainax_lik_table(hipStream_t s, int n0p, int n0t, int n1t, int T, int d, int rec_len, const double *m0, const double *colA, const double *colB, const double *rec, double *out) {
     blc::AxLikParams L{n0p, n0t, n1t, T, d, rec_len, m0, colA, colB, rec, out};
     const long long G = (long long)n0p * n0p;

@@ -96,6 +96,19 @@ static __global__ __launch_bounds__(256) void ax_lik_table_kernel(const AxLikPar
     }
 }
 
+// ... and for every other observation model (Laplace, AR1, ScaledAR1, a caller's pdf: the (T, G) table the other kernels read, row-major on the
+// grid's true sizes): its even time steps copied into the transposed layout
+static __global__ __launch_bounds__(256) void ax_lik_transpose_kernel(const double *lik, double *out, int n0p, int n0t, int n1t) {
+    const int te = blockIdx.y, t = 2 * te;
+    const long long G = (long long)n0p * n0p;
+    const double *src = lik + (long long)t * n0t * n1t;
+    double *o = out + (long long)te * G;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < G; e += (long long)gridDim.x * 256) {
+        const int rr = (int)(e & 15), col = (int)((e >> 4) % n0p), row = (int)(e / ((long long)n0p * 16)) * 16 + rr;
+        o[e] = (row < n0t && col < n1t) ? src[(long long)row * n1t + col] : 0.0;
+    }
+}
+
 // PAD: the grid is smaller than the square geometry (any n0, n1 <= 512: the geometry is the next of 128 / 256 / 512 that holds both).  As in
 // chain_kernel: the stencils reflect at the grid's TRUE last row / column, cells outside the grid are kept at zero and out of every sum,
 // read-only inputs are read with bounds.  Lines beyond the grid pick up mirrored values in the first filter (and keep them through the
@@ -349,16 +362,28 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                     pa[FOLD ? it : 0][r] = ldnt(abase, P.part_fresh ? (aoffs & 4088u) : aoffs);
                 }
         }
-        // (layout-B steps: the likelihood of the lane's cells out of the table, where there is one)
+        // (the likelihood of the lane's cells out of a table: layout-B steps where there is one -- the Gaussian's exponentials otherwise --,
+        //  every step of the other observation models, whose layout-A steps read the row-major table the other kernels read)
         double lk[NTW][4];
-        const bool tabled = lay_b && P.lik != nullptr;
-        if (tabled) {
+        const bool tabled = lay_b ? P.lik != nullptr : P.lik_nat != nullptr;
+        if (tabled && lay_b) {
             const int l = fresh_lane();
             const double *lrow = P.lik + (long long)(t >> 1) * G;
 #pragma unroll
             for (int it = 0; it < NTW; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) lk[it][r] = blm::ld32(lrow, cell_off(l, it, r));
+        } else if (tabled) {
+            const int l = fresh_lane();
+            const double *lrow = P.lik_nat + (long long)t * n0t * n1t;
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + it * TM + (l >> 4) + 4 * r;
+                    const unsigned off = __umul24(PAD ? min(row, n0t - 1) : row, (unsigned)n1t * 8u) + (unsigned)(PAD ? min(gj, n1t - 1) : gj) * 8u;
+                    lk[it][r] = blm::ld32(lrow, off);
+                }
         }
         __syncthreads();
         BLX_STAMP(3);
@@ -416,7 +441,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                 const int i = row0 + it * TM;
                 const int l = fresh_lane(), g = l >> 4, c = l & 15;
                 d4 acc = band_products<NK, 0, NK, AST>(band_ptr(Ab, l), Bv);
-                if (it == 0 && !lay_b) {
+                if (it == 0 && !lay_b && !tabled) {
                     // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50; blhip_mfma.hpp)
                     const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
                     double a0 = 0.0, s1 = 0.0, dn = 0.0;
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                         sC += cn;
                         acc[r] = p;
                     }
-                    if (!lay_b) {
+                    if (!lay_b && !tabled) {
                         mE *= mR; nE += nR;
                         mR *= mq; nR += nq;
                         if (BWD) { iE *= iR; iR *= iq; }

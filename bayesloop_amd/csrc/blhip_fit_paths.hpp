@@ -262,7 +262,7 @@ struct ChainRun {
         const bool gauss = E.p->obs_model == BLHIP_OM_GAUSSIAN && use_rec && E.d <= blc::DMAX;
         tab = E.p->obs_model == BLHIP_OM_TABLE && E.DT->lik != nullptr && ctx->option("chain_table", 1.0) != 0.0;
         // walks on the second parameter too: the transposing kernels (blc::chainax_kernel; Gaussian recurrence, exact square geometries)
-        const bool may_ax1 = gauss && !tab && prog.LW1 > 0 && ctx->option("chain_ax1", 1.0) != 0.0;
+        const bool may_ax1 = (gauss || tab) && prog.LW1 > 0 && ctx->option("chain_ax1", 1.0) != 0.0;
         if (fast && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
             !prog.has_clamp && (prog.LW1 == 0 || may_ax1) && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
             true) {
@@ -270,7 +270,7 @@ struct ChainRun {
             cp.allow_ax1 = may_ax1;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
             if (on && tab && cp.ntw > 4) on = false;
-            if (on && tab && cp.pad && cp.ntw >= 3) on = false;      // (padded 384 / 512-row geometries with a likelihood table: no kernel -- never selected by a test or workload, pruned in round 5)
+            if (on && tab && cp.pad && cp.ntw >= 3 && !cp.ax1) on = false;      // (padded 384 / 512-row geometries with a likelihood table: no kernel -- never selected by a test or workload, pruned in round 5)
             if (on && prog.LW1 > 0 && !cp.ax1) on = false;
         }
         if (!on) return;
@@ -308,7 +308,13 @@ struct ChainRun {
             // (c4_both_axes 553 -> 578 ms): one or two chains only (chain_ax1_table = 2: always, 0: never)
             const double tab_bytes = (double)((T + 1) / 2) * (double)Gk * 8.0;
             const double tab_opt = ctx->option("chain_ax1_table", 1.0);
-            if (tab_opt != 0.0 && (B <= 2 || tab_opt == 2.0) && tab_bytes < 8.0e9) {
+            if (tab) {          // a tabulated model: every step reads its likelihood -- the even ones out of a transposed copy
+                if (tab_bytes >= 8.0e9) { on = false; return; }
+                ctx->axlik.ensure((size_t)tab_bytes);
+                blcl::chainax_lik_transpose(E.st, E.DT->lik, ctx->axlik.as<double>(), cp.n0p, E.g.n0, E.g.n1, (int)T);
+                HIPCHECK(hipGetLastError());
+                CQ.lik = ctx->axlik.as<double>(); CQ.lik_nat = E.DT->lik;
+            } else if (tab_opt != 0.0 && (B <= 2 || tab_opt == 2.0) && tab_bytes < 8.0e9) {
                 ctx->axlik.ensure((size_t)tab_bytes);
                 blcl::chainax_lik_table(E.st, cp.n0p, E.g.n0, E.g.n1, (int)T, E.d, E.rec_len, E.DT->m0, E.DT->colA, E.DT->colB, E.DT->rec, ctx->axlik.as<double>());
                 HIPCHECK(hipGetLastError());
@@ -319,7 +325,7 @@ struct ChainRun {
         CQ.lag = std::max(2, std::min(blc::MAXLAG, (int)ctx->option("chain_resident_lag", 4.0)));      // (lag 1 would need the sum of the step in flight)
         CQ.B = (int)B; CQ.nblk = cp.strips; CQ.tap_id = d_tapid; CQ.taps = E.M->taps; CQ.tap_off = E.M->off; CQ.tap_lw = E.M->lw;
         CQ.post_stride = (long long)T * Gk;
-        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; if (tab) CQ.lik = E.DT->lik; CQ.step0 = E.step0;      // (both-axes kernels: CQ.lik is their table of the even steps, set above)
+        CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; if (tab && !ax1) CQ.lik = E.DT->lik; CQ.step0 = E.step0;      // (both-axes kernels: CQ.lik is their table of the even steps, set above)
         CQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
         // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)

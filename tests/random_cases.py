@@ -396,6 +396,10 @@ def random_both_axes_square_case(seed):
     nan_at = sorted(set(int(x) for x in rng.integers(0, T, size=int(rng.integers(0, 3))))) if T > 3 else []
     data = ('series_nan', 1300 + seed, T, nan_at) if nan_at else ('series', 1300 + seed, T)
     om = ('Gaussian', [('mean', ('cint', -5, 5, n0)), ('std', ('oint', 0, 3, n1))], 'default')
+    names = ('mean', 'std')
+    if seed % 7 == 5:                       # another observation model: its likelihood comes out of a table in both layouts
+        om = ('Laplace', [('mu', ('cint', -5, 5, n0)), ('b', ('oint', 0, 3, n1))], 'default')
+        names = ('mu', 'b')
 
     def sigma(span, npts, radius):
         return max(radius, 0.3) / 4.0 * span / max(npts - 1, 1)
@@ -405,13 +409,13 @@ def random_both_axes_square_case(seed):
     s1, s2 = sigma(10, n0, r0), sigma(3, n1 + 2, r1)
     nh = int(rng.integers(2, 5))
     if kind == 'study_both':
-        tm = ('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)])
+        tm = ('Combined', [('GRW', 's1', s1, names[0], None), ('GRW', 's2', s2, names[1], None)])
         return dict(study='Study', data=data, om=om, fit=flags, tm=tm)
     if kind in ('cp_both', 'cp_both_after', 'study_cp_after'):
         # change points (transitionModels.py:289-317) beside the two walks: in front of them the restart passes through both bands,
         # behind them it is consumed unfiltered; as a ChangepointStudy over every time step, or one fixed change point in a Study
         T = max(T, 6)
-        walks = [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', s2, 'std', None)]
+        walks = [('GRW', 's1', s1, names[0], None), ('GRW', 's2', s2, names[1], None)]
         if kind == 'study_cp_after':
             return dict(study='Study', data=('series_jump', 1300 + seed, T, T // 2, 2.0), om=om, fit=flags,
                         tm=('Combined', walks + [('ChangePoint', 'tc', float(T // 2), None)]))
@@ -419,12 +423,12 @@ def random_both_axes_square_case(seed):
         return dict(study='ChangepointStudy', data=('series_jump', 1300 + seed, T, T // 2, 2.0), om=om, fit=dict(),
                     tm=('Combined', [cp] + walks if kind == 'cp_both' else walks + [cp]))
     if kind == 'study_axis1':
-        return dict(study='Study', data=data, om=om, fit=flags, tm=('GRW', 's2', s2, 'std', None))
+        return dict(study='Study', data=data, om=om, fit=flags, tm=('GRW', 's2', s2, names[1], None))
     if kind == 'hyper_both':
         return dict(study='HyperStudy', data=data, om=om, fit=flags,
-                    tm=('Combined', [('GRW', 's1', s1, 'mean', None), ('GRW', 's2', ('cint', 0, s2, nh), 'std', None)]))
+                    tm=('Combined', [('GRW', 's1', s1, names[0], None), ('GRW', 's2', ('cint', 0, s2, nh), names[1], None)]))
     if kind == 'hyper_axis1':
-        return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's2', ('cint', sigma(3, n1 + 2, 2), s2, nh), 'std', None))
+        return dict(study='HyperStudy', data=data, om=om, fit=flags, tm=('GRW', 's2', ('cint', sigma(3, n1 + 2, 2), s2, nh), names[1], None))
     return dict(study='HyperStudy', data=data, om=om, fit=flags,
-                tm=('Combined', [('GRW', 's1', ('cint', 0, s1, int(rng.integers(2, 4))), 'mean', None),
-                                 ('GRW', 's2', ('cint', 0, s2, int(rng.integers(2, 4))), 'std', None)]))
+                tm=('Combined', [('GRW', 's1', ('cint', 0, s1, int(rng.integers(2, 4))), names[0], None),
+                                 ('GRW', 's2', ('cint', 0, s2, int(rng.integers(2, 4))), names[1], None)]))
