@@ -2375,11 +2375,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         }
         join_streams();
         HIPCHECK(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
+        // (one slot per sum -- the kernels that give a chain ONE block: nothing to add up, the partials ARE the sums.  The published
+        //  break-point study: 2 x 6 launches of T * B * NRED = 1.3 M one-value blocks, 0.48 ms each, 5.7 of a 44-ms fit)
+        if (nblk_now > 1)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psF,
                                ctx->redF.as<double>(), nblk_now, NRED);
         ctx->pinF.ensure((size_t)T * B * NRED * 8);
         redF = ctx->pinF.as<double>();
-        HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(redF, nblk_now > 1 ? ctx->redF.p : (const void *)d_psF, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
         tr.mark("forward pass queued");
         sync_stream(ctx, st);
         tr.mark("forward pass done + sums D2H");
@@ -2447,11 +2450,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             }
             join_streams();
             HIPCHECK(hipEventRecord(ev[3], st));
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
+            if (nblk_now > 1)
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(T * B * NRED)), dim3(NTHREADS), 0, st, d_psB,
                                    ctx->redB.as<double>(), nblk_now, NRED);
             ctx->pinB.ensure((size_t)T * B * NRED * 8);
             redB = ctx->pinB.as<double>();
-            HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipMemcpyAsync(redB, nblk_now > 1 ? ctx->redB.p : (const void *)d_psB, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
             tr.mark("backward pass queued");
             if (late_fb) { raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O); tr.mark("forward bookkeeping (behind the backward pass)"); }
             sync_stream(ctx, st);
