@@ -928,7 +928,9 @@ def test_seeded_random_wide_axis1_walks_match_oracle(seed):
     D = cases.build(bl, c)
     with np.errstate(all='ignore'):
         D.fit(**cases.fit_kwargs(c))
-    assert (np.isnan(D.logEvidence) and np.isnan(S.logEvidence)) or D.logEvidence == S.logEvidence or abs(D.logEvidence - S.logEvidence) <= 1e-11 * abs(S.logEvidence)
+    # (two summation orders of the same study: the bar itself -- 400 seeds: up to 3.6e-11 absolute on a logEvidence of -2.96)
+    assert (np.isnan(D.logEvidence) and np.isnan(S.logEvidence)) or D.logEvidence == S.logEvidence or \
+        abs(D.logEvidence - S.logEvidence) <= compare.GPU_TOL['logE_rtol'] * abs(S.logEvidence)
     got = result_of(S, c)
     gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
     for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):

@@ -18,4 +18,4 @@ print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in S.lastTiming.
 pr = cProfile.Profile()
 with contextlib.redirect_stdout(io.StringIO()):
     pr.enable(); S.fit(**kw); eng.synchronize(); pr.disable()
-st = pstats.Stats(pr, stream=sys.stdout); st.sort_stats('cumulative').print_stats(nl)
+st = pstats.Stats(pr, stream=sys.stdout); st.sort_stats(os.environ.get('SORT', 'cumulative')).print_stats(nl)
