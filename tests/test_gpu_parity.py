@@ -990,6 +990,32 @@ def test_seeded_random_both_axes_walks_on_square_grids_take_the_transposing_chai
             assert np.array_equal(np.asarray(S1.posteriorSequence), np.asarray(got['posteriorSequence']), equal_nan=True)
 
 
+@pytest.mark.parametrize('T', [1, 2])
+@pytest.mark.parametrize('kind', ['study', 'hyper', 'hyper_evidence', 'study_forward_only'])
+def test_both_axes_walks_over_one_and_two_time_steps(T, kind):
+    """The transposing kernels alternate their layout with the time index (blk::ax_layout_b): series of ONE step (no transition at all) and of
+    TWO (one exchange; the backward pass starts in the other layout than the forward pass ended in)."""
+    om = ('Gaussian', [('mean', ('cint', -5, 5, 128)), ('std', ('oint', 0, 3, 128))], 'default')
+    s1, s2 = 20 / 4.0 * 10 / 127, 14 / 4.0 * 3 / 129
+    walks = lambda a, b: ('Combined', [('GRW', 's1', a, 'mean', None), ('GRW', 's2', b, 'std', None)])
+    c = dict(study='Study', data=('series', 4242, T), om=om, fit=dict(), tm=walks(s1, s2))
+    if kind.startswith('hyper'):
+        c = dict(c, study='HyperStudy', tm=walks(('cint', 0, s1, 3), ('cint', 0, s2, 3)), fit=dict(evidenceOnly=True) if kind == 'hyper_evidence' else dict())
+    if kind == 'study_forward_only':
+        c = dict(c, fit=dict(forwardOnly=True))
+    S = cases.build(bl, c)
+    with np.errstate(all='ignore'):
+        S.fit(**cases.fit_kwargs(c))
+        want = oa.run(c)
+    assert S.lastTiming['resident_fallbacks'] == 0, S.lastTiming
+    got = result_of(S, c)
+    gold = dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'])
+    for k in ('posteriorSequence', 'posteriorMeanValues', 'logEvidenceList', 'hyperParameterDistribution'):
+        if k in want and want[k] is not None and k in got and (k != 'posteriorMeanValues' or len(want[k])):
+            gold[k] = np.asarray(want[k])
+    compare.check(got, gold, compare.GPU_TOL, case_tol=_ill_tol(S))
+
+
 @pytest.mark.parametrize('seed', range(int(os.environ.get('BLHIP_FUZZ_SEEDS', 32))))
 def test_seeded_random_hyper_studies_match_oracle(seed):
     c = random_cases.random_hyper_case(seed)
