@@ -1046,7 +1046,7 @@ class HyperStudy(Study):
 
         # hyper-parameter distribution and evidence of the average model (reference core.py:1391-1410)
         with np.errstate(divide='ignore'):
-            logHPD = np.array(self.logEvidenceList) + np.log(prior_values) + np.sum(np.log(self.hyperGridConstant))
+            logHPD = np.asarray(out['log_evidence'], dtype=float) + np.log(prior_values) + np.sum(np.log(self.hyperGridConstant))
         scaled = logHPD - np.amax(logHPD)
         self.hyperParameterDistribution = np.exp(scaled)
         self.hyperParameterDistribution /= np.sum(self.hyperParameterDistribution)
@@ -1055,7 +1055,7 @@ class HyperStudy(Study):
         if not silent:
             print('    + Computed hyper-parameter distribution')
             print('    + Log10-evidence of average model: {:.5f}'.format(self.logEvidence / np.log(10)))
-        self.localEvidence = np.sum((np.array(localList).T * prior_values).T, axis=0)
+        self.localEvidence = np.sum((np.asarray(localList).T * prior_values).T, axis=0)
         if not evidenceOnly:
             self.posteriorMeanValues = out['posterior_mean']
         self.localEvidenceList = []

@@ -300,8 +300,10 @@ def sharded_hyper_fit(engine, problem, op_values, prior_values, comm, forward_on
         # (LocalGroup with two contexts on ONE physical device -- a test configuration: their fits take turns)
         turn = comm.device_lock(engine) if getattr(getattr(comm, 'group', None), 'shared', False) else _nullcontext()
         with turn:
-            res = engine.fit(problem, np.asarray(op_values)[mine], forward_only=forward_only, evidence_only=evidence_only,
-                             keep_posterior=False, accumulate=want_post, log_chain_weight=log_w[mine], owner=owner)
+            # (one rank: its share is the whole hyper-grid -- no gather of a 16-MB op-value matrix through an index array)
+            ops = np.asarray(op_values)
+            res = engine.fit(problem, ops if size == 1 else ops[mine], forward_only=forward_only, evidence_only=evidence_only,
+                             keep_posterior=False, accumulate=want_post, log_chain_weight=log_w if size == 1 else log_w[mine], owner=owner)
         logE, local, astep, timing = res.log_evidence, res.local_evidence, res.abort_step.astype(float), res.timing
 
     ref = -np.inf
