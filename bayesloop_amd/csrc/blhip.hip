@@ -1319,7 +1319,7 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
             const int cus = std::min(ctx->num_cus, 256);
             const double n = g.n1, lw = prog.LW1;
             // (rows longer than a block: two cells per thread share their operand pairs, 21 ps per cell and tap -- launch_chain1d)
-            const double tap_us = g.n1 > bl1c::NT && ctx->option("chain1d_pair", 2.0) != 0.0 ? 2.1e-5 : 4.4e-5;
+            const double tap_us = g.n1 > bl1c::NT && true ? 2.1e-5 : 4.4e-5;
             const double est_c1d = (double)((B + cus - 1) / cus) * (1.5 + n * (B >= 4 ? 0.0010 : 0.0022) + n * (2.0 * lw + 1.0) * tap_us);
             const int nblk_f = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ;
             const bool p1d_ok = ctx->option("persist1d", 1.0) != 0.0 && (long long)nblk_f * B <= cus && T > gp.fusedK;
@@ -1610,9 +1610,8 @@ void keep_posterior(blhip_ctx *ctx, const Geometry &g, int64_t T, int64_t B, con
     ctx->post_valid = true; ctx->post_scaled = false; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = g.G;
     ctx->post_row0 = row0; ctx->post_row1 = row1;
     ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
-    // default: normalise now, as part of the fit (core.py:441 is inside Study.fit); option lazy_normalise = 1 defers
-    // the pass to the first access of the sequence
-    if (ctx->option("lazy_normalise", 0.0) == 0.0) { ensure_post_scaled(ctx); sync_stream(ctx, st); }
+    // normalised now, as part of the fit (core.py:441 is inside Study.fit)
+    ensure_post_scaled(ctx); sync_stream(ctx, st);
 }
 
 void write_results(blhip_result *res, const blhip_problem *p, int64_t c0, int64_t B, const BatchOutcome &out, bool with_means) {
@@ -2068,8 +2067,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             FP.n0 = g.n0; FP.n1 = g.n1; FP.TJ = tile.TJ; FP.S = fastS; FP.nseg = fast_nseg;
             FP.tiles_j = tile.tiles_j; FP.nblk = tile.nblk; FP.fnblk = fast_fnblk;
             FP.dump = d_dump;
-            FP.mlean = (g.n0 % mS == 0 && (double)G * 8.0 < 4.0e9 && g.n1 < (1 << 20) && g.n0 < (1 << 24) &&
-                        ctx->option("mfma_lean", 1.0) != 0.0) ? 1 : 0;
+            FP.mlean = (g.n0 % mS == 0 && (double)G * 8.0 < 4.0e9 && g.n1 < (1 << 20) && g.n0 < (1 << 24)) ? 1 : 0;
             FP.mS = mS; FP.mnseg = m_nseg; FP.mtiles_j = m_tiles_j; FP.mnblk = m_nblk;
             FP.ndim = p->ndim; FP.d = d; FP.means = forward_only ? 1 : 0;
             FP.shared[SRC_PREV] = nullptr; FP.shared[SRC_PRIOR] = d_prior; FP.shared[SRC_RESET] = d_reset;
@@ -2116,7 +2114,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         size_t max_ranges = 0;
         for (const auto &r : rangesF) max_ranges = std::max(max_ranges, r.size());
         for (const auto &r : rangesB) max_ranges = std::max(max_ranges, r.size());
-        const bool multistream = fast && max_ranges >= 2 && ctx->option("multistream", 1.0) != 0.0;
+        const bool multistream = fast && max_ranges >= 2;
         auto fork_streams = [&]() {
             if (!multistream) return;
             HIPCHECK(hipEventRecord(ctx->fork_ev, st));
@@ -2152,14 +2150,14 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             d_hsrc = ctx->hsrc.as<double>();
             d_vsrc = (gp.wideH && gp.wideV) ? d_hsrc + (size_t)B * G : d_hsrc;
         }
-        const int mfma_min_r0 = (int)ctx->option("mfma_min_r0", 8);
+        constexpr int mfma_min_r0 = 8;
         // both-axes launches: the matrix-pipe kernel wins while the launch is latency-bound (few cells per CU); with the chip
         // full the vector kernel's 2 x 17 FMAs per cell beat 2 x 32 band products (measured: 1024^2 12.7 vs 14.9 us,
         // 2048^2 30.0 vs 27.7 us, 4096^2 97 vs 77 us per forward step)
         const bool mfma_h = ctx->option("mfma_h", 1.0) != 0.0;
         const double mfma_h_max_cells = ctx->option("mfma_h_max_cells", 2.5e6);
         long long n_mfma[2] = {0, 0}, n_fast[2] = {0, 0};
-        const bool uniform_launch = ctx->option("uniform_launch", 1.0) != 0.0;
+        constexpr bool uniform_launch = true;
         auto run_step = [&](int mode, int64_t t, const double *srcp, long long src_stride, double *dstp, long long dst_stride,
                             double *postp, long long post_stride, const double *ps_prev, int prev_slot, double *ps_out,
                             bool means) {
@@ -2266,8 +2264,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         const bool p1d_now = fused1d && !c1d_now && !resident_failed && ctx->resident_ok && ctx->option("persist1d", 1.0) != 0.0 && T > K &&
                              (long long)tile.nblk * B <= std::min(ctx->num_cus, 256);
         // (the chains of a batch see the same likelihood: tabulated once per batch by the in-kernel function itself, shared by both passes)
-        const bool c1d_table = c1d_now && B >= 4 && !d_lik && (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN) &&
-                               ctx->option("chain1d_table", 1.0) != 0.0;
+        const bool c1d_table = c1d_now && B >= 4 && !d_lik && (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN);
         double *d_lik1 = nullptr;
         if (c1d_table) {
             ctx->lik1d.ensure((size_t)T * G * 8);
@@ -2284,7 +2281,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             Q.store = (bwd || !evidence_only) ? 1 : 0; Q.means = bwd ? 1 : (forward_only ? 1 : 0);
             Q.post = (bwd || !evidence_only) ? d_post : nullptr; Q.post_stride = (long long)T * G;
             Q.src = nullptr; Q.src_stride = 0; Q.dst = nullptr; Q.dst_stride = 0;
-            launch_chain1d(st, d_lik1 ? BLHIP_OM_TABLE : p->obs_model, Q, bwd, (int)ctx->option("chain1d_pair", 2.0));
+            launch_chain1d(st, d_lik1 ? BLHIP_OM_TABLE : p->obs_model, Q, bwd, 2);
         };
         bl1p::P1Params P1{};
         unsigned *d_abort1 = nullptr;

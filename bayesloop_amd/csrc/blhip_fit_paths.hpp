@@ -227,7 +227,7 @@ struct ChainRun {
     bool tab = false;                              // the likelihood comes out of a table (blc::chain_kernel TAB)
     bool ax1 = false;                              // walks on both parameters: blc::chainax_kernel (the distribution is transposed between the filters)
     size_t xch_bytes = 0;
-    int ax_mode = -1;                              // option chain_ax1_mode (-1: per launch, see pass())
+    int ax_mode = -1;                              // exchange mode (-1: per launch, see pass())
     // a padded grid whose sequence is NOT private (an ordinary fit that keeps its posteriors): the kernels work on a scratch sequence on
     // the padded geometry (blhip_ctx::postpad), depad_kernel writes the grid's rows into the sequence everybody else reads
     bool depad = false;
@@ -301,13 +301,13 @@ struct ChainRun {
             xch_bytes = (size_t)cp.cpr * 2 * (size_t)Gk * 8;
             ctx->xch.ensure(xch_bytes);
             CQ.xch = ctx->xch.as<double>(); CQ.xch_chain = 2 * Gk; CQ.tap_id1 = d_tapid1;
-            ax_mode = (int)ctx->option("chain_ax1_mode", -1.0);
+            ax_mode = -1;             // (development: 0 write-through stores on any XCD, 1 one XCD per chain, 2 plain stores, 3 both = the default)
             // the likelihood of the even time steps (epilogue in the transposed layout) as a table: an exp per cell there otherwise.  Measured
             // (profiles/r05_notes.md): single fits are latency-bound and gain (200 x 200, radius 20: 7.9 -> 7.5 us per step); launches of
             // eight chains sit on eight XCDs, every one of which fetches the table through the fabric the exchange already saturates
-            // (c4_both_axes 553 -> 578 ms): one or two chains only (chain_ax1_table = 2: always, 0: never)
+            // (c4_both_axes 553 -> 578 ms): one or two chains only
             const double tab_bytes = (double)((T + 1) / 2) * (double)Gk * 8.0;
-            const double tab_opt = ctx->option("chain_ax1_table", 1.0);
+            constexpr double tab_opt = 1.0;
             if (tab) {          // a tabulated model: every step reads its likelihood -- the even ones out of a transposed copy
                 if (tab_bytes >= 8.0e9) { on = false; return; }
                 ctx->axlik.ensure((size_t)tab_bytes);

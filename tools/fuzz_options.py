@@ -7,14 +7,11 @@ import bayesloop_amd as bl, cases, compare, oracle_adapter as oa, random_cases
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 eng = bl.get_engine()
-OPTS = [dict(), dict(fast=0), dict(mfma=0), dict(mfma_h=0), dict(recurrence=0), dict(mfma_lean=0), dict(uniform_launch=0),
-        dict(fuse1d=0), dict(fuse1d=1), dict(fuse1d=3), dict(multistream=0), dict(mfma_min_r0=16),
-        dict(mfma_S=32), dict(fast_S=16), dict(lazy_normalise=1), dict(max_batch=2)]
-DEFAULTS = dict(fast=1, mfma=1, mfma_h=1, recurrence=1, mfma_lean=1, uniform_launch=1, fuse1d=8, multistream=1,
-                mfma_min_r0=8, mfma_S=0, fast_S=0, lazy_normalise=0, max_batch=1024, chain1d=1, chain1d_pair=2, chain1d_shift=1, chain1d_table=1)
+OPTS = [dict(), dict(fast=0), dict(mfma=0), dict(mfma_h=0), dict(recurrence=0),
+        dict(fuse1d=0), dict(fuse1d=1), dict(fuse1d=3), dict(max_batch=2)]
+DEFAULTS = dict(fast=1, mfma=1, mfma_h=1, recurrence=1, fuse1d=8, max_batch=1024, chain1d=1, chain1d_shift=1)
 if os.environ.get('FUZZ_OPTS') == 'chain1d':       # round 4: the chain-resident 1-D kernel's flavours (pairs, spline shifts, shared table)
-    OPTS = [dict(), dict(chain1d=2), dict(chain1d=2, chain1d_pair=1), dict(chain1d=2, chain1d_pair=0, chain1d_table=0), dict(chain1d=0),
-            dict(chain1d=2, chain1d_shift=0), dict(chain1d=2, max_batch=2)]
+    OPTS = [dict(), dict(chain1d=2), dict(chain1d=0), dict(chain1d=2, chain1d_shift=0), dict(chain1d=2, max_batch=2)]
 
 def result_of(S, c):
     res = dict(logEvidence=S.logEvidence, localEvidence=S.localEvidence)
