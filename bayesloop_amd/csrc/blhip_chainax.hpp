@@ -216,15 +216,16 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
     __syncthreads();
 
     // a bounded wait: `again` re-requests what is missing
+    // (the wave waits as one -- blr::wave_all: scalar branches; lane by lane the loop is a stack of lane masks in scalar registers)
     auto wait_for = [&](auto &&all_there, auto &&again) {
-        if (dead || all_there()) return;
+        if (dead || blr::wave_all(all_there())) return;
         const unsigned long long t0 = blr::now_ticks();
         for (unsigned spins = 1;; ++spins) {
             blr::nap();
             again();
-            if (all_there()) return;
+            if (blr::wave_all(all_there())) return;
             if ((spins & 255u) == 0u) {
-                if (blr::ld_flag(P.abort_word) != 0u) { dead = true; return; }
+                if (blr::uni((int)blr::ld_flag(P.abort_word)) != 0) { dead = true; return; }
                 if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); dead = true; return; }
             }
         }
@@ -327,11 +328,20 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) fq[j] = ld_tq2(xr, base + (unsigned)j * (unsigned)(NT * 16));
             };
+            // (all tag bits at once first -- AND / OR of the high words; element by element, branch-free, only when that fails: a NaN
+            //  counts as arrived whatever its sign, blr::tq_ok)
             auto there = [&]() {
-                bool ok = true;
+                unsigned hand = 0xffffffffu, hor = 0u;
 #pragma unroll
-                for (int j = 0; j < NG; ++j) ok = ok && blr::tq_ok(fq[j].a, bit) && blr::tq_ok(fq[j].b, bit);
-                return ok;
+                for (int j = 0; j < NG; ++j) {
+                    const unsigned ha = (unsigned)(fq[j].a >> 32), hb = (unsigned)(fq[j].b >> 32);
+                    hand &= ha & hb; hor |= ha | hb;
+                }
+                if (blr::wave_all(bit ? (hand >> 31) != 0u : (hor >> 31) == 0u)) return true;
+                unsigned ok = 1u;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) ok &= blr::tq_ok_bits(fq[j].a, bit) & blr::tq_ok_bits(fq[j].b, bit);
+                return ok != 0u;
             };
             issue();
             wait_for(there, issue);

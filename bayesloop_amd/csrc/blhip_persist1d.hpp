@@ -48,14 +48,16 @@ struct P1Params {
 __device__ __forceinline__ bool finish_tagged(const P1Params &P, const unsigned long long *g, unsigned long long want,
                                               unsigned long long q0, unsigned long long q1, double &v) {
     bool alive = true;
-    if ((q0 >> 32) != want || (q1 >> 32) != want) {
+    // (the wave waits as one: blr::wave_all)
+    auto there = [&]() { return ((unsigned)((q0 >> 32) == want) & (unsigned)((q1 >> 32) == want)) != 0u; };
+    if (!blr::wave_all(there())) {
         const unsigned long long t0 = blr::now_ticks();
         for (unsigned spins = 1;; ++spins) {
             blr::nap();
             q0 = blr::ld_u64(g); q1 = blr::ld_u64(g + 1);
-            if ((q0 >> 32) == want && (q1 >> 32) == want) break;
+            if (blr::wave_all(there())) break;
             if ((spins & 255u) == 0u) {
-                if (blr::ld_flag(P.abort_word) != 0u) { alive = false; break; }
+                if (blr::uni((int)blr::ld_flag(P.abort_word)) != 0) { alive = false; break; }
                 if (blr::now_ticks() - t0 > P.timeout_ticks) { blr::st_flag(P.abort_word, 1u); alive = false; break; }
             }
         }

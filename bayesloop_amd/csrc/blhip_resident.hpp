@@ -170,6 +170,19 @@ BLR_INL unsigned tag_bit(unsigned epoch, bool rows) {               // epoch = p
 }
 // (a NaN counts as arrived whatever its sign: a degenerate fit -- zero normaliser, NaN state -- must not spin until the time-out; NaN
 //  states stay NaN, so a stale one is as good as a fresh one, and the host rejects the pass by its sums anyway)
+// every active lane of the wave (a scalar condition: the waits below branch on it as a wave, not lane by lane -- a loop some lanes leave
+// early is a stack of lane masks in scalar registers, which the allocator takes from the values that live across the step)
+#ifdef BLR_EMULATE
+BLR_INL bool wave_all(bool x) { return x; }
+#else
+BLR_INL bool wave_all(bool x) { return __all(x ? 1 : 0) != 0; }
+#endif
+// tq_ok without a branch: 1 / 0
+BLR_INL unsigned tq_ok_bits(Tq q, unsigned bit) {
+    const unsigned hi = (unsigned)(q >> 32), lo = (unsigned)q, mag = hi & 0x7fffffffu;
+    const unsigned isnan_ = (unsigned)(mag > 0x7ff00000u) | ((unsigned)(mag == 0x7ff00000u) & (unsigned)(lo != 0u));
+    return ((hi >> 31) ^ bit ^ 1u) | isnan_;
+}
 BLR_INL bool tq_ok(Tq q, unsigned bit) { return (unsigned)(q >> 63) == bit || (q & 0x7fffffffffffffffull) > 0x7ff0000000000000ull; }
 
 // a neighbour's strip: R tagged elements at byte offsets off0 + q * dstep (q = 0 .. R-1 in the consumer's walking order)
@@ -190,25 +203,27 @@ BLR_INL bool strip_finish(const ResParams &P, Rsrc rs, int off0, int dstep, unsi
             unsigned hand = 0xffffffffu, hor = 0u;
 #pragma unroll
             for (int q = 0; q < R; ++q) { const unsigned hi = (unsigned)(fq[q] >> 32); hand &= hi; hor |= hi; }
-            if (tag ? (hand >> 31) != 0u : (hor >> 31) == 0u) return true;
+            if (wave_all(tag ? (hand >> 31) != 0u : (hor >> 31) == 0u)) return true;      // (a scalar branch)
         }
-        bool ok = true;
+        // (branch-free: a short-circuit chain of eight tests is eight nested lane masks, whose scalar registers the allocator takes from
+        //  the values that live across the step -- and reloads those in the walks)
+        unsigned ok = 1u;
 #pragma unroll
-        for (int q = 0; q < R; ++q) ok = ok && tq_ok(fq[q], tag);
-        return ok;
+        for (int q = 0; q < R; ++q) ok &= tq_ok_bits(fq[q], tag);
+        return ok != 0u;
     };
 #ifdef BLR_EMULATE
     assert(all_there() && "hand-off protocol: consumed before published");
     (void)P; (void)rs; (void)off0; (void)dstep;
 #else
-    if (!all_there()) {
+    if (!wave_all(all_there())) {                  // (the wave waits as one: every lane requests its strip again until all have theirs)
         const unsigned long long t0 = now_ticks();
         for (unsigned spins = 1;; ++spins) {
             nap();
             strip_issue(rs, off0, dstep, fq);
-            if (all_there()) break;
+            if (wave_all(all_there())) break;
             if ((spins & 255u) == 0u) {
-                if (ld_flag(P.abort_word) != 0u) { alive = false; break; }
+                if (uni((int)ld_flag(P.abort_word)) != 0) { alive = false; break; }
                 if (now_ticks() - t0 > P.timeout_ticks) { st_flag(P.abort_word, 1u); alive = false; break; }
             }
         }
@@ -331,6 +346,27 @@ BLR_INL void walk_full(const double (&nearv)[R], const double (&own)[SEG], doubl
     }
 }
 
+// A block-uniform pointer the optimiser cannot see through: what is loaded through it is loaded where the code says, every time -- not
+// once before the time loop, to live in scalar registers for the whole kernel (the two passes' weights: 2 x 18 of ~100; with more
+// invariants than registers the allocator parks them in vector-register lanes and fetches them back with v_readlane inside the walks)
+template <class T>
+BLR_INL const T *launder_uniform(const T *p) {
+#ifndef BLR_EMULATE
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (const T *)v;
+#else
+    return p;
+#endif
+}
+// ... and a block-uniform integer: conditions derived from it (is there a neighbour tile on this side, is this data dimension in use) are
+// evaluated where they are needed by the scalar unit -- hoisted out of the time loop each of them is a 64-bit lane mask the allocator keeps
+BLR_INL int launder_uniform(int x) {
+#ifndef BLR_EMULATE
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
 BLR_INL int min_(int a, int b) { return a < b ? a : b; }
 
 // keep the optimiser from hoisting a thread's (time-invariant) address arithmetic out of the time loop: hoisted, the
@@ -490,8 +526,9 @@ struct Res {
         // ---- the data record of step k (requested a step ahead, see v_walk_d) ---------------------------------------------------
         BLR_INL void begin_step(const ResParams &Q, int k) {
             const int t = time_of(Q, k);
+            const int d = ONE ? launder_uniform(Q.d) : Q.d;
 #pragma unroll
-            for (int q = 0; q < DMAX; ++q) xd[q] = q < Q.d ? ldu(Q.rec, (long long)t * Q.rec_len + q) : nan_();
+            for (int q = 0; q < DMAX; ++q) xd[q] = q < d ? ldu(Q.rec, (long long)t * Q.rec_len + q) : nan_();
         }
         BLR_INL double *row_ptr(const ResParams &Q, int k, int r0, int c) const {
             return f_post(Q) ? f_post(Q) + (long long)time_of(Q, k) * Q.n0 * Q.n1 + (long long)(i0 + r0) * Q.n1 + (j0 + c) : nullptr;
@@ -538,31 +575,34 @@ struct Res {
 #pragma unroll
             for (int j = 0; j < GPL; ++j) {
                 const int loc = lane + 64 * j, idx = wv * tpw + loc;
-                if (loc < tpw && idx < Q.ntiles) {
-                    auto tags_ok = [&]() {
-                        bool ok = true;
+                const bool mine = loc < tpw && idx < Q.ntiles;
+                auto tags_ok = [&]() {               // (lanes without a tile of their own: nothing to wait for)
+                    unsigned ok = 1u;
 #pragma unroll
-                        for (int q = 0; q < 2 * NG; ++q) ok = ok && (gq[j][q] >> 32) == want;
-                        return ok;
-                    };
+                    for (int q = 0; q < 2 * NG; ++q) ok &= (unsigned)((gq[j][q] >> 32) == want);
+                    return !mine || ok != 0u;
+                };
 #ifdef BLR_EMULATE
-                    assert(tags_ok() && "lagged sum consumed before published");
+                assert(tags_ok() && "lagged sum consumed before published");
 #else
-                    if (!tags_ok()) {
-                        const unsigned long long *g = Q.gran + ((long long)(ks % NSLOT) * Q.ntiles + idx) * 4;
-                        const unsigned long long t0 = now_ticks();
-                        for (unsigned spins = 1;; ++spins) {
+                if (!wave_all(tags_ok())) {          // (the wave waits as one, see wave_all)
+                    const unsigned long long *g = Q.gran + ((long long)(ks % NSLOT) * Q.ntiles + (mine ? idx : 0)) * 4;
+                    const unsigned long long t0 = now_ticks();
+                    for (unsigned spins = 1;; ++spins) {
+                        if (mine) {
 #pragma unroll
                             for (int q = 0; q < 2 * NG; ++q) gq[j][q] = ld_u64(g + q);
-                            if (tags_ok()) break;
-                            nap();
-                            if ((spins & 255u) == 0u) {
-                                if (ld_flag(Q.abort_word) != 0u) { dead = true; break; }
-                                if (now_ticks() - t0 > Q.timeout_ticks) { st_flag(Q.abort_word, 1u); dead = true; break; }
-                            }
+                        }
+                        if (wave_all(tags_ok())) break;
+                        nap();
+                        if ((spins & 255u) == 0u) {
+                            if (uni((int)ld_flag(Q.abort_word)) != 0) { dead = true; break; }
+                            if (now_ticks() - t0 > Q.timeout_ticks) { st_flag(Q.abort_word, 1u); dead = true; break; }
                         }
                     }
+                }
 #endif
+                if (mine) {
 #pragma unroll
                     for (int g2 = 0; g2 < NG; ++g2) {
                         const unsigned long long bits = (gq[j][2 * g2] & 0xffffffffull) | (gq[j][2 * g2 + 1] << 32);
@@ -632,8 +672,9 @@ struct Res {
             // (weights as scalars.  In vector registers -- read from LDS per pass, to free ~18 SGPRs of the ~100 spilled ones -- the
             //  128 x 128 kernels ran out of VGPRs instead: 4 / 54 / 271 spilled; measured by compiling, not kept)
             double wk[R + 1];
+            const double *const w1p = launder_uniform(Q.w1);
 #pragma unroll
-            for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w1, q);
+            for (int q = 0; q <= R; ++q) wk[q] = ldu(w1p, q);
             if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, hg.far == 2, wk, far_issue, far_fetch, [](int) {}, emit8);
             else walk<SEG, DIR, CHK>(x0, nearv, farv, hg.far == 2, wk, far_issue, far_fetch, [](int) {}, emit8);
         }
@@ -858,8 +899,9 @@ struct Res {
                 }
             };
             double wk[R + 1];
+            const double *const w0p = launder_uniform(Q.w0);
 #pragma unroll
-            for (int q = 0; q <= R; ++q) wk[q] = ldu(Q.w0, q);
+            for (int q = 0; q <= R; ++q) wk[q] = ldu(w0p, q);
             if constexpr (FULLW) walk_full<SEG, CHK>(nearv, own, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
             else walk<SEG, DIR * P, CHK>(x0, nearv, farv, vg.far == 2, wk, far_issue, far_fetch, pre8, emit8);
             if constexpr (DEFER) {                   // epilogue phase: the thread's own cells (nobody else reads them before the step's last barrier)
@@ -1042,6 +1084,9 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
     };
     for (int k = 0; k < Q.T; ++k) {
         BLR_STAMP(0);
+        // (see launder_uniform; the one-chunk tiles only -- static v_readlane of the step loop, 64 x 64 forward 144 -> 82, C3's forward step
+        //  4.73 -> 4.65 us; the 128 x 128 forward kernel answers with MORE of them: 323 -> 490, 1.90 -> 1.95 ms per 200 steps)
+        if constexpr (K::ONE) { th.ti = launder_uniform(th.ti); th.tj = launder_uniform(th.tj); th.tile = launder_uniform(th.tile); }
         if (!K::REC_AHEAD && k > 0) th.begin_step(Q, k);
         if (k == 0) {
             th.begin_step(Q, k);
