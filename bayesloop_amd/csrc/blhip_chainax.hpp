@@ -497,7 +497,16 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
                         const double beta = in ? acc[r] * scale : 0.0;
                         const double p = al[BWD ? it : 0][r] * beta;
                         const double cn = beta * Lv;
-                        const double pl = !in ? 0.0 : (tabled ? p / Lv : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)));      // p / L; 0 / 0 -> NaN (core.py:463)
+                        // p / L; 0 / 0 -> NaN (core.py:463).  (The recurrence's quotient is computed for every cell and SELECTED: written as one
+                        //  conditional expression with the table's division in it, each of the lane's 16 cells got a branch of its own -- 16 lane
+                        //  masks per chain-step in the epilogue)
+                        double pl;
+                        if (tabled) pl = in ? p / Lv : 0.0;
+                        else {
+                            const double quot = ldexp(p * iE, -nE);
+                            pl = Lv == 0.0 ? __builtin_nan("") : quot;
+                            if (PAD) pl = in ? pl : 0.0;
+                        }
                         X0[li * WCOL + c] = cn;
                         if (!FOLD) stnt(pstep, off, p);
                         else stnt(pslot_t, off, pa[FOLD ? it : 0][r] + fmax(p * wq, wfloor));
