@@ -1021,9 +1021,35 @@ __device__ __forceinline__ T *own_sgpr(T *p) {
 }
 // (Applied to this file's own kernel it changes nothing -- 633 -> 612 v_readlane per step loop: what spills here are lane masks of the
 //  control flow, not argument tuples; measured on the ISA, not kept.)
+// The kernel's arguments, read AGAIN from the kernel-argument segment through a pointer the optimiser cannot see through.  Called at the
+// top of every step: nothing of the ~50 dwords is loop-invariant then, nothing has to be kept across the loop -- which the allocator does
+// by parking it in vector-register lanes and fetching it back with v_readlane (a vector-ALU slot each) inside the walks.  Four scalar loads
+// per step instead.  Static v_readlane of the step loop / vector instructions: 128 x 128 forward 323 -> 123 / 4754 -> 4537 (applied), 128 x 128
+// backward 700 -> 200 (no measurable gain), 64 x 64 forward 82 -> 35 (slower), 64 x 64 backward 190 -> 433.
+template <bool RELOAD>
+BLR_INL ResParams step_args(const ResParams &a) {
+#ifndef BLR_EMULATE
+    if constexpr (RELOAD) {
+        static_assert(sizeof(ResParams) % 4 == 0, "copied as dwords");
+        typedef const unsigned __attribute__((address_space(4))) *ka_t;      // (the constant address space: scalar loads)
+        unsigned long long kav = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kav));
+        const ka_t src = (ka_t)kav;
+        ResParams r;
+        unsigned *const dst = reinterpret_cast<unsigned *>(&r);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(ResParams) / 4; ++i) dst[i] = src[i];
+        return r;
+    }
+#endif
+    return a;
+}
+
 template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE = 0, bool PAD = false, bool TAB = false>
-__global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Q) {
+__global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams Qarg) {
     using K = Res<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>;
+    constexpr bool RELOAD_ARGS = !K::ONE && !BWD;     // (measured, same box: 2048^2 forward step 8.89 -> 8.78 us; the one-chunk forward kernels LOSE 2.6 % with it -- C3 4.60 -> 4.72 us -- although their static reloads drop 82 -> 35: four scalar loads + a wait at the top of a 4.6-us step)
+    const ResParams &Q = Qarg;                        // (set-up and the lambdas below; the step loop has its own, see step_args)
     constexpr int NT = K::NT, NW = K::NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *misc = lds + K::LDS_MISC;
@@ -1082,7 +1108,10 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
             }
         }
     };
-    for (int k = 0; k < Q.T; ++k) {
+    const int n_steps = Q.T;
+    for (int k = 0; k < n_steps; ++k) {
+        const ResParams Qstep = step_args<RELOAD_ARGS>(Qarg);
+        const ResParams &Q = Qstep;                   // (hides the outer one inside the step)
         BLR_STAMP(0);
         // (see launder_uniform; the one-chunk tiles only -- static v_readlane of the step loop, 64 x 64 forward 144 -> 82, C3's forward step
         //  4.73 -> 4.65 us; the 128 x 128 forward kernel answers with MORE of them: 323 -> 490, 1.90 -> 1.95 ms per 200 steps)
