@@ -1026,19 +1026,19 @@ __device__ __forceinline__ T *own_sgpr(T *p) {
 // by parking it in vector-register lanes and fetching it back with v_readlane (a vector-ALU slot each) inside the walks.  Four scalar loads
 // per step instead.  Static v_readlane of the step loop / vector instructions: 128 x 128 forward 323 -> 123 / 4754 -> 4537 (applied), 128 x 128
 // backward 700 -> 200 (no measurable gain), 64 x 64 forward 82 -> 35 (slower), 64 x 64 backward 190 -> 433.
-template <bool RELOAD>
-BLR_INL ResParams step_args(const ResParams &a) {
+template <bool RELOAD, class ARGS>
+BLR_INL ARGS step_args(const ARGS &a) {         // (ARGS: the kernel's ONE by-value argument, at offset 0 of the segment)
 #ifndef BLR_EMULATE
     if constexpr (RELOAD) {
-        static_assert(sizeof(ResParams) % 4 == 0, "copied as dwords");
+        static_assert(sizeof(ARGS) % 4 == 0, "copied as dwords");
         typedef const unsigned __attribute__((address_space(4))) *ka_t;      // (the constant address space: scalar loads)
         unsigned long long kav = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kav));
         const ka_t src = (ka_t)kav;
-        ResParams r;
+        ARGS r;
         unsigned *const dst = reinterpret_cast<unsigned *>(&r);
 #pragma unroll
-        for (unsigned i = 0; i < sizeof(ResParams) / 4; ++i) dst[i] = src[i];
+        for (unsigned i = 0; i < sizeof(ARGS) / 4; ++i) dst[i] = src[i];
         return r;
     }
 #endif
