@@ -12,7 +12,7 @@ import os
 from .exceptions import BackendError
 
 LIB_NAME = 'libblhip.so'
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OM_POISSON, OM_GAUSSIAN, OM_GAUSSIAN_MEAN, OM_TABLE = 1, 2, 3, 100
 OM_BERNOULLI, OM_LAPLACE, OM_WHITE_NOISE, OM_AR1, OM_SCALED_AR1 = 4, 5, 6, 7, 8
@@ -74,6 +74,7 @@ class Timing(C.Structure):
 PROTOTYPES = {
     'blhip_abi_version': (C.c_int, []),
     'blhip_device_count': (C.c_int, []),
+    'blhip_kernel_census': (C.c_int64, [C.c_char_p, C.c_int64]),
     'blhip_create': (C.c_void_p, [C.c_int]),
     'blhip_destroy': (None, [C.c_void_p]),
     'blhip_last_error': (C.c_char_p, [C.c_void_p]),

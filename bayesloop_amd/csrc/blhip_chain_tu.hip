@@ -16,34 +16,36 @@ namespace {
 using blerr::arm_kernel;
 using blerr::fail;
 
-template <typename KernT>
-void launch_chain_fn(KernT kern, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
-    arm_kernel(reinterpret_cast<const void *>(kern));
+template <auto KERN>
+void launch_chain_fn(hipStream_t s, const blc::ChainParams &Q, size_t lds) {
+    arm_kernel(reinterpret_cast<const void *>(KERN));
     // (xch_mode bit 0 -- blc::chainax_kernel only: one XCD per chain, 8 x strips x ceil(chains / 8) blocks of which nslots x strips work)
     const unsigned blocks = (Q.xch_mode & 1) ? 8u * (unsigned)Q.strips * (unsigned)((Q.nslots + 7) / 8) : (unsigned)(Q.nslots * Q.strips);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(blc::NT), lds, s, Q);
+    blreg::hit<KERN>();
+    hipLaunchKernelGGL(KERN, dim3(blocks), dim3(blc::NT), lds, s, Q);
 }
 
-// the flavours of one (ring length, tiles per wave, direction).  Padded grids: forward and storing backward passes of <= 512 rows (the
-// folding backward pass of a padded grid is the two-chain kernel's); 1024 rows: forward and FOLDING backward passes
+// the flavours of one (ring length, tiles per wave, direction).  <= 512 rows: forward and STORING backward passes, exact and padded (the
+// folding backward pass is the two-chain kernel's); 1024 rows: forward, storing (exact) and FOLDING (exact, padded) backward passes
 template <int NK, int NTW, bool BWD>
 void launch_k(hipStream_t s, const blc::ChainParams &Q, bool store, bool pad) {
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
     if constexpr (!BWD) {
-        if (pad && store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true>, s, Q, lds);
-        else if (pad) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true>, s, Q, lds);
-        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, false>, s, Q, lds);
-        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, false>, s, Q, lds);
+        if (pad && store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, true>>(s, Q, lds);
+        else if (pad) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, true>>(s, Q, lds);
+        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, false>>(s, Q, lds);
+        else launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, false>>(s, Q, lds);
     } else if constexpr (NTW <= 4) {
-        if (pad && !store) fail("internal: padded chain-resident launch of a folding backward pass");
-        if (pad) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true>, s, Q, lds);
-        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false>, s, Q, lds);
-        else launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false>, s, Q, lds);
+        // (<= 512 rows: the folding backward pass is the two-chain kernel's -- blc::chain_fold2_kernel, which also takes an odd chain out;
+        //  the one-chain folding flavour was reachable through a development option only and was pruned in round 6: 84 kernels)
+        if (!store) fail("internal: chain-resident launch of a folding backward pass on <= 512 rows (the two-chain kernel folds there)");
+        if (pad) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, true>>(s, Q, lds);
+        else launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, false>>(s, Q, lds);
     } else {
         if (pad && store) fail("internal: the 1024-row chain-resident kernels store posteriors on the exact geometry only");
-        if (pad) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, true>, s, Q, lds);
-        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false>, s, Q, lds);
-        else launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false>, s, Q, lds);
+        if (pad) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, false, true>>(s, Q, lds);
+        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, false>>(s, Q, lds);
+        else launch_chain_fn<&blc::chain_kernel<NK, NTW, true, false, false>>(s, Q, lds);
     }
 }
 
@@ -53,14 +55,14 @@ void launch_k_tab(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
     if constexpr (PAD) {                 // (padded grids: the folding backward pass would be the two-chain kernel's, which has no table flavour)
         if (bwd && !store) fail("internal: padded chain-resident launch of a folding backward pass (tabulated likelihood)");
-        if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, true, true>, s, Q, lds);
-        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, true, true>, s, Q, lds);
-        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, true, true>, s, Q, lds);
+        if (bwd) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, true, true>>(s, Q, lds);
+        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, true, true>>(s, Q, lds);
+        else launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, true, true>>(s, Q, lds);
     } else {
-        if (bwd && store) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, true, false, true>, s, Q, lds);
-        else if (bwd) launch_chain_fn(&blc::chain_kernel<NK, NTW, true, false, false, true>, s, Q, lds);
-        else if (store) launch_chain_fn(&blc::chain_kernel<NK, NTW, false, true, false, true>, s, Q, lds);
-        else launch_chain_fn(&blc::chain_kernel<NK, NTW, false, false, false, true>, s, Q, lds);
+        if (bwd && store) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, false, true>>(s, Q, lds);
+        else if (bwd) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, false, false, true>>(s, Q, lds);
+        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, false, true>>(s, Q, lds);
+        else launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, false, true>>(s, Q, lds);
     }
 }
 template <int NTW, bool PAD>
@@ -104,10 +106,10 @@ void launch_fold2_k(hipStream_t s, const blc::ChainParams &Q, bool pad) {
     const dim3 grid((unsigned)(((Q.nslots + 1) / 2) * Q.strips));
     if (pad) {
         arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, true>));
-        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, true>), grid, dim3(blc::NT), lds, s, Q);
+        BL_LAUNCH((blc::chain_fold2_kernel<NK, NTW, true>), grid, dim3(blc::NT), lds, s, Q);
     } else {
         arm_kernel(reinterpret_cast<const void *>(&blc::chain_fold2_kernel<NK, NTW, false>));
-        hipLaunchKernelGGL((blc::chain_fold2_kernel<NK, NTW, false>), grid, dim3(blc::NT), lds, s, Q);
+        BL_LAUNCH((blc::chain_fold2_kernel<NK, NTW, false>), grid, dim3(blc::NT), lds, s, Q);
     }
 }
 
@@ -131,10 +133,10 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
 template <int NK, int NTW, bool PAD>
 void launch_k_ax(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
     const size_t lds = blc::lds_doubles_ax<NK, NTW>() * sizeof(double);
-    if (bwd && store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, true, PAD>, s, Q, lds);
-    else if (bwd) launch_chain_fn(&blc::chainax_kernel<NK, NTW, true, false, PAD>, s, Q, lds);
-    else if (store) launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, true, PAD>, s, Q, lds);
-    else launch_chain_fn(&blc::chainax_kernel<NK, NTW, false, false, PAD>, s, Q, lds);
+    if (bwd && store) launch_chain_fn<&blc::chainax_kernel<NK, NTW, true, true, PAD>>(s, Q, lds);
+    else if (bwd) launch_chain_fn<&blc::chainax_kernel<NK, NTW, true, false, PAD>>(s, Q, lds);
+    else if (store) launch_chain_fn<&blc::chainax_kernel<NK, NTW, false, true, PAD>>(s, Q, lds);
+    else launch_chain_fn<&blc::chainax_kernel<NK, NTW, false, false, PAD>>(s, Q, lds);
 }
 template <int NTW, bool PAD>
 void launch_w_ax(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {
@@ -235,12 +237,12 @@ void chain_ntw12_tab_pad(hipStream_t s, const blc::ChainParams &Q, int nk, int n
 #elif BLC_TU == 19
 void chainax_lik_transpose(hipStream_t s, const double *lik, double *out, int n0p, int n0t, int n1t, int T) {
     const long long G = (long long)n0p * n0p;
-    hipLaunchKernelGGL(blc::ax_lik_transpose_kernel, dim3((unsigned)std::min<long long>((G + 255) / 256, 1024), (unsigned)((T + 1) / 2)), dim3(256), 0, s, lik, out, n0p, n0t, n1t);
+    BL_LAUNCH(blc::ax_lik_transpose_kernel, dim3((unsigned)std::min<long long>((G + 255) / 256, 1024), (unsigned)((T + 1) / 2)), dim3(256), 0, s, lik, out, n0p, n0t, n1t);
 }
 void chainax_lik_table(hipStream_t s, int n0p, int n0t, int n1t, int T, int d, int rec_len, const double *m0, const double *colA, const double *colB, const double *rec, double *out) {
     blc::AxLikParams L{n0p, n0t, n1t, T, d, rec_len, m0, colA, colB, rec, out};
     const long long G = (long long)n0p * n0p;
-    hipLaunchKernelGGL(blc::ax_lik_table_kernel, dim3((unsigned)std::min<long long>((G + 255) / 256, 1024), (unsigned)((T + 1) / 2)), dim3(256), 0, s, L);
+    BL_LAUNCH(blc::ax_lik_table_kernel, dim3((unsigned)std::min<long long>((G + 255) / 256, 1024), (unsigned)((T + 1) / 2)), dim3(256), 0, s, L);
 }
 #elif BLC_TU == 20
 void chainax_ntw4(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) { launch_w_ax<4, false>(s, Q, nk, bwd, store); }

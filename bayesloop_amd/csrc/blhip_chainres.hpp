@@ -97,8 +97,8 @@ struct ChainParams {
     const double *lik;           // TAB kernels: the likelihood of every step, [T][n0 * n1] row-major (table models: built on the device or by the caller)
     // blc::chainax_kernel (blhip_chainax.hpp: walks on BOTH parameters, the distribution is transposed between the two filters)
     const int *tap_id1;          // [B] the chain's axis-1 kernel in the tap table, -1 = none
-    double *xch;                 // [nslots][2 phases][2 parities][n0 * n1] tagged elements: the exchange buffers (zeroed before every launch)
-    long long xch_chain;         // doubles between the buffers of two chain slots (4 n0 n1)
+    double *xch;                 // [nslots][2 step parities][n0 * n1] tagged elements: the exchange buffers (zeroed before every launch)
+    long long xch_chain;         // doubles between the buffers of two chain slots (2 n0 n1)
     const double *lik_nat;       // blc::chainax_kernel: tabulated likelihood (every model but the Gaussian), [T][n0t * n1t] row-major, for the steps whose
                                  //   epilogue works in layout A; `lik` then holds the even steps in the transposed layout
     int xch_mode;                // experiments (option chain_ax1_mode): bit 0 = the blocks of a chain share an XCD (block b runs on XCD b % 8), bit 1 = plain publishing stores

@@ -325,7 +325,7 @@ int blhip_accum_peer_reduce(blhip_ctx *dst, blhip_ctx *const *srcs, int n_srcs, 
             HIPCHECK(hipEventRecord(dst->bev[i], s));
             HIPCHECK(hipStreamWaitEvent(st, dst->bev[i], 0));
         }
-        hipLaunchKernelGGL(peer_add_kernel, dim3(2048), dim3(256), 0, st, dst->acc + off, stage, n_srcs, cnt);
+        BL_LAUNCH(peer_add_kernel, dim3(2048), dim3(256), 0, st, dst->acc + off, stage, n_srcs, cnt);
         HIPCHECK(hipGetLastError());
         sync_stream(dst, st);
     });

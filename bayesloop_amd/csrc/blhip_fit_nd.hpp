@@ -37,7 +37,7 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
     HIPCHECK(hipMemcpyAsync(d_prior, p->prior, 8 * (size_t)G, hipMemcpyHostToDevice, st));
     if (p->reset_prior) HIPCHECK(hipMemcpyAsync(d_reset, p->reset_prior, 8 * (size_t)G, hipMemcpyHostToDevice, st));
     if (p->backward_init) HIPCHECK(hipMemcpyAsync(d_uniform, p->backward_init, sizeof(double) * G, hipMemcpyHostToDevice, st));
-    else hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);           // beta_T = 1/G, core.py:424-425
+    else BL_LAUNCH(fill_kernel, dim3(256), dim3(256), 0, st, d_uniform, G, 1.0 / (double)G);           // beta_T = 1/G, core.py:424-425
     ctx->likbuf.ensure(8 * (size_t)T * G);
     double *d_lik = ctx->likbuf.as<double>();
     HIPCHECK(hipMemcpyAsync(d_lik, p->lik, 8 * (size_t)T * G, hipMemcpyHostToDevice, st));
@@ -162,7 +162,7 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
                 for (int64_t b = 0; b < B && !any; ++b) any = htp[(size_t)q * nT + (size_t)t * B + b] >= 0;
                 if (!any) continue;
                 const int ax = p->ops[grw_ops[q]].axis;
-                hipLaunchKernelGGL(bln::filter_axis_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, d_tmp[flip], in, G, ng.n[ax],
+                BL_LAUNCH(bln::filter_axis_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, d_tmp[flip], in, G, ng.n[ax],
                                    ng.stride[ax], tp + (size_t)q * nT, d_taps, d_off, d_lw);
                 in = flip ? d_ptr_tmp1 : d_ptr_tmp0;
                 flip ^= 1;
@@ -171,8 +171,8 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
             Q.g = ng; Q.B = (int)B; Q.T = (int)T; Q.nblk = nblk; Q.srcs = in; Q.kind = (bwd ? d_kindB : d_kindF) + (size_t)t * B;
             Q.psum_prev = ps_prev; Q.prev_slot = bwd ? 2 : 0; Q.psum_out = ps_out; Q.lik = d_lik + (size_t)t * G; Q.state = d_state;
             Q.post = d_post ? d_post + (size_t)t * G : nullptr; Q.post_stride = (long long)T * G;
-            if (bwd) hipLaunchKernelGGL(bln::step_kernel<true>, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, Q);
-            else hipLaunchKernelGGL(bln::step_kernel<false>, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, Q);
+            if (bwd) BL_LAUNCH(bln::step_kernel<true>, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, Q);
+            else BL_LAUNCH(bln::step_kernel<false>, dim3((unsigned)nblk, (unsigned)B), dim3(NTHREADS), 0, st, Q);
         };
         double *d_psF = ctx->psumF.as<double>();
         const size_t per_step = (size_t)B * NRED * nblk;
@@ -182,7 +182,7 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
         for (int64_t t = 0; t < T; ++t) step(false, t, t > 0 ? d_psF + (size_t)(t - 1) * per_step : d_psF, d_psF + (size_t)t * per_step);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(nT * NRED)), dim3(NTHREADS), 0, st, d_psF, ctx->redF.as<double>(), nblk, 0);      // (0: every slot is a sum -- slot 6 is the 4th parameter's mean here)
+        BL_LAUNCH(reduce_partials_kernel, dim3((unsigned)(nT * NRED)), dim3(NTHREADS), 0, st, d_psF, ctx->redF.as<double>(), nblk, 0);      // (0: every slot is a sum -- slot 6 is the 4th parameter's mean here)
         ctx->pinF.ensure(nT * NRED * 8);
         double *redF = ctx->pinF.as<double>();
         HIPCHECK(hipMemcpyAsync(redF, ctx->redF.p, nT * NRED * 8, hipMemcpyDeviceToHost, st));
@@ -199,7 +199,7 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
             for (int64_t t = T - 1; t >= 0; --t) step(true, t, t < T - 1 ? d_psB + (size_t)(t + 1) * per_step : d_psB, d_psB + (size_t)t * per_step);
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipEventRecord(ev[3], st));
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(nT * NRED)), dim3(NTHREADS), 0, st, d_psB, ctx->redB.as<double>(), nblk, 0);
+            BL_LAUNCH(reduce_partials_kernel, dim3((unsigned)(nT * NRED)), dim3(NTHREADS), 0, st, d_psB, ctx->redB.as<double>(), nblk, 0);
             ctx->pinB.ensure(nT * NRED * 8);
             double *redB = ctx->pinB.as<double>();
             HIPCHECK(hipMemcpyAsync(redB, ctx->redB.p, nT * NRED * 8, hipMemcpyDeviceToHost, st));

@@ -297,8 +297,16 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_tapid1, cp.tap_id1.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
-        if (ax1) {               // the exchange buffers of a launch's chain slots: [slot][2 phases][2 parities][G] tagged elements
+        if (ax1) {               // the exchange buffers of a launch's chain slots: [slot][2 step parities][Gk] tagged elements
             xch_bytes = (size_t)cp.cpr * 2 * (size_t)Gk * 8;
+            {   // the exchange buffers and the likelihood table of the even steps are not part of chains_per_batch's budget: a long series
+                // on a large geometry declines the path here instead of failing in the allocator
+                const bool want_tab = tab || B <= 2;
+                const double need = (double)xch_bytes + (want_tab ? (double)((T + 1) / 2) * (double)Gk * 8.0 : 0.0);
+                size_t free_b = 0, total_b = 0;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                if (need > 0.8 * ((double)free_b + (double)ctx->xch.cap + (double)ctx->axlik.cap)) { on = false; ax1 = false; Gk = 0; return; }
+            }
             ctx->xch.ensure(xch_bytes);
             CQ.xch = ctx->xch.as<double>(); CQ.xch_chain = 2 * Gk; CQ.tap_id1 = d_tapid1;
             ax_mode = -1;             // (development: 0 write-through stores on any XCD, 1 one XCD per chain, 2 plain stores, 3 both = the default)
@@ -309,7 +317,7 @@ struct ChainRun {
             const double tab_bytes = (double)((T + 1) / 2) * (double)Gk * 8.0;
             constexpr double tab_opt = 1.0;
             if (tab) {          // a tabulated model: every step reads its likelihood -- the even ones out of a transposed copy
-                if (tab_bytes >= 8.0e9) { on = false; return; }
+                if (tab_bytes >= 8.0e9) { on = false; ax1 = false; Gk = 0; return; }
                 ctx->axlik.ensure((size_t)tab_bytes);
                 blcl::chainax_lik_transpose(E.st, E.DT->lik, ctx->axlik.as<double>(), cp.n0p, E.g.n0, E.g.n1, (int)T);
                 HIPCHECK(hipGetLastError());
@@ -338,7 +346,8 @@ struct ChainRun {
             // change-point batches: the predicted sums survive a restart only through the two-chain fold kernel's restart rule, and
             // only if the two passes restart at the same places (backward step t restarts <=> forward step t + 1 does: unit-spaced
             // time stamps, transitionModels.py:316-317)
-            bool aligned = !tab && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0 && ctx->option("fold2_cp", 1.0) != 0.0;
+            // (the both-axes kernels' fold has no restart rule: such batches store and fold separately -- ADVICE r05)
+            bool aligned = !tab && !ax1 && !E.chain_means && fold2_shape(cp.ntw) && ctx->option("fold2", 1.0) != 0.0 && ctx->option("fold2_cp", 1.0) != 0.0;
             for (int64_t b = 0; b < B && aligned; ++b)
                 for (int64_t t = 0; t + 1 < T && aligned; ++t)
                     aligned = (prog.kindB[(size_t)t * B + b] != SRC_PREV) == (prog.kindF[(size_t)(t + 1) * B + b] != SRC_PREV);
@@ -373,9 +382,10 @@ struct ChainRun {
             if (!depad) { on = false; fused = false; fold2 = false; return; }
             fused = false; fold2 = false;
         }
-        // (<= 512 rows: the one-chain folding kernel has no padded variant -- store + separate fold; 1024 rows: it is the only padded backward kernel)
-        // (tabulated likelihood on a padded grid: no fold2 -> store + separate fold as well)
-        if (cp.pad && fused && !fold2 && cp.ntw <= 4 && !ax1) fused = false;      // (the both-axes kernels fold on padded grids too)
+        // (<= 512 rows: what the two-chain kernel does not fold -- per-chain means asked for through the C-ABI, option fold2 = 0 -- is stored and
+        //  folded separately: the Gaussian one-chain kernel has no folding flavour there (round 6).  The tabulated one has, on exact
+        //  geometries; 1024 rows: the one-chain kernel is the only folding one, exact and padded; the both-axes kernels fold on padded grids too)
+        if (fused && !fold2 && cp.ntw <= 4 && !ax1 && (cp.pad || !tab)) fused = false;
         if (cp.pad && cp.ntw > 4 && E.ff.full && !fused) { on = false; fold2 = false; return; }
         // Change-point batches without a stencil whose backward pass folds: the chains are identical up to their first restart.  The chain
         // with the LATEST first restart stores all its states; every other chain stores only from its own first restart on, and the
@@ -388,11 +398,11 @@ struct ChainRun {
         share_prefix = false; skip_prefix = false;
         const bool may_share = fused && ctx->option("share_prefix", 1.0) != 0.0;
         const bool may_skip = (fused || E.ff.evidence_only) && ctx->option("skip_prefix", 1.0) != 0.0;
-        if ((may_share || may_skip) && cp.has_reset && prog.LW0 == 0 && !cp.mixed && B >= 2) {
+        if ((may_share || may_skip) && cp.has_reset && prog.LW0 == 0 && !cp.mixed && !ax1 && B >= 2) {      // (blc::chainax_kernel reads neither tshare nor skip_prefix)
             std::vector<int> tfirst((size_t)B, (int)T);
             bool plain = true;
             for (int64_t b = 0; b < B && plain; ++b) {
-                plain = prog.kindF[b] == SRC_PRIOR && cp.tap_id[b] < 0;
+                plain = prog.kindF[b] == SRC_PRIOR && cp.tap_id[b] < 0 && cp.tap_id1[b] < 0;
                 for (int64_t t = 1; t < T; ++t)
                     if (prog.kindF[(size_t)t * B + b] != SRC_PREV) { tfirst[b] = (int)t; break; }
             }
@@ -614,7 +624,7 @@ struct ChainRun {
             const double newref = std::max(ctx->acc_logref, fold_ref);
             const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
             HIPCHECK(hipEventRecord(ctx->ev[4], st));
-            hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)(((G + 1) / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
+            BL_LAUNCH(fold_parts_kernel, dim3((unsigned)(((G + 1) / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
                                ctx->accpart.as<double>(), (long long)T * Gk, slots_used, E.g.n0, E.g.n1, (int)T, r, rb,
                                ctx->acc_first ? 1 : 0, cp.n0p, Gk, ax1 ? 1 : 0);
             HIPCHECK(hipEventRecord(ctx->ev[5], st));

@@ -129,7 +129,7 @@ struct blhip_ctx {
     DevBuf lik1d;                // (T, n) likelihood table the chains of a 1-D batch share (blhip_chain1d.hpp)
     DevBuf accpart;              // partial accumulators of the fused fold (one per launch slot of the chain-resident kernel)
     DevBuf axlik;                // ... its likelihood table of the even time steps (transposed layout): ceil(T / 2) x n0p^2 doubles
-    DevBuf xch;                  // exchange buffers of the both-axes chain-resident kernel (blhip_chainax.hpp): [slot][2 phases][2 parities][G]
+    DevBuf xch;                  // exchange buffers of the both-axes chain-resident kernel (blhip_chainax.hpp): [slot][2 step parities][Gk]
     hipStream_t astream = nullptr;
     hipEvent_t aev_done[2] = {nullptr, nullptr};
 

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BLHIP_ABI_VERSION 7
+#define BLHIP_ABI_VERSION 8
 
 typedef struct blhip_ctx blhip_ctx;
 
@@ -199,6 +199,12 @@ typedef struct {
 /* ---- context ------------------------------------------------------------------------------------------------- */
 int         blhip_abi_version(void);
 int         blhip_device_count(void);
+/* Diagnostics / test infrastructure (needs no GPU, no context): the kernel instantiations this library holds -- every __global__
+ * function it can launch registers itself when the library is loaded -- and how often THIS PROCESS has launched each.  Text, one
+ * line per instantiation, sorted by name: "<launches>\t<kernel name with its template arguments>\n".  Writes at most cap - 1 bytes
+ * + NUL into buf (buf may be NULL); returns the length of the whole text (call again with a larger buffer if >= cap), < 0 on error.
+ * The -m gpu suite asserts that no line starts with "0": every kernel that ships has been compared with the oracle. */
+int64_t     blhip_kernel_census(char *buf, int64_t cap);
 blhip_ctx  *blhip_create(int device);
 void        blhip_destroy(blhip_ctx *ctx);
 const char *blhip_last_error(blhip_ctx *ctx);        /* ctx may be NULL for errors of blhip_create              */

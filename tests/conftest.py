@@ -56,3 +56,50 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         import json
         with open(out, 'w') as f:
             json.dump(c, f)
+
+
+def kernel_census():
+    """[(launches in this process, kernel instantiation)] of libblhip.so (blhip_kernel_census, include/blhip.h)."""
+    import ctypes
+    from bayesloop_amd import _abi
+    lib = _abi.load()
+    n = lib.blhip_kernel_census(None, 0)
+    buf = ctypes.create_string_buffer(n + 1)
+    lib.blhip_kernel_census(buf, n + 1)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        cnt, name = line.split('\t', 1)
+        rows.append((int(cnt), name))
+    return rows
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """After a session that launched kernels: which instantiations of the library ran, which did not (gpurun_out/kernel_census.txt;
+    the round's copy is profiles/rNN_kernel_census.txt)."""
+    try:
+        rows = kernel_census()
+    except Exception:
+        return
+    if not any(c for c, _ in rows):
+        return
+    try:
+        import collections
+        import re
+        out = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        fam = collections.OrderedDict()
+        for c, name in rows:
+            f = fam.setdefault(re.sub(r'<.*', '', name), [0, 0, 0])
+            f[0] += 1; f[1] += 1 if c else 0; f[2] += c
+        lib = os.path.join(ROOT, 'bayesloop_amd', 'libblhip.so')
+        with open(os.path.join(out, 'kernel_census.txt'), 'w') as f:
+            f.write('library: %d kernel instantiations in %d families, %.1f MB\n' % (len(rows), len(fam), os.path.getsize(lib) / 1e6))
+            f.write('this session: %d launched (%d launches), %d never launched\n\n' % (sum(1 for c, _ in rows if c), sum(c for c, _ in rows), sum(1 for c, _ in rows if not c)))
+            for name, (n, hit, launches) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+                f.write('%-36s %5d instantiations, %5d launched, %9d launches\n' % (name, n, hit, launches))
+            f.write('\nnever launched:\n')
+            for c, name in rows:
+                if not c:
+                    f.write('  %s\n' % name)
+    except Exception:
+        pass

@@ -39,7 +39,7 @@ def test_test_sources_define_no_private_tolerances():
     `tol = dict(...)` literals with numbers in them outside the registry."""
     pat = re.compile(r'(case_tol|tol)\s*=\s*dict\(([^)]*)\)')
     allowed = {'local_rtol=ILL_LOCAL_RTOL', 'local_rtol=ILL_LOCAL_RTOL, local_loose_steps=loose'}
-    for fn in ('test_gpu_parity.py', 'test_online.py', 'test_optimize.py', 'test_reference_expectations.py', 'random_cases.py', 'cases.py'):
+    for fn in ('test_gpu_parity.py', 'test_online.py', 'test_optimize.py', 'test_reference_expectations.py', 'random_cases.py', 'cases.py', 'test_kernel_sweep.py'):
         src = open(os.path.join(ROOT, 'tests', fn)).read()
         for m in pat.finditer(src):
             body = m.group(2).strip()
