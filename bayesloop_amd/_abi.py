@@ -45,6 +45,7 @@ class Problem(C.Structure):
         ('ops', C.POINTER(Op)),
         ('resume_time', C.c_double), ('carry_slot', C.c_int32), ('reserved0', C.c_int32),
         ('backward_init', c_double_p),
+        ('prior_token', C.c_uint64),
     ]
 
 

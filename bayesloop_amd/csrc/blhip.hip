@@ -1174,7 +1174,10 @@ DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometr
     HIPCHECK(hipMemcpyAsync(D.colA, colA.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(D.colB, colB.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(D.rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(D.prior, p->prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    // (the prior of a study that is fitted again: the caller's token says the content is the one this place already holds)
+    const bool prior_resident = p->prior_token != 0 && p->prior_token == ctx->prior_token && D.prior == ctx->prior_dev && G == ctx->prior_G;
+    if (!prior_resident) HIPCHECK(hipMemcpyAsync(D.prior, p->prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
+    ctx->prior_token = p->prior_token; ctx->prior_dev = D.prior; ctx->prior_G = G;
     if (p->reset_prior) HIPCHECK(hipMemcpyAsync(D.reset, p->reset_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
     if (p->indep_prior) HIPCHECK(hipMemcpyAsync(D.indep, p->indep_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
     if (ff.full) {
@@ -1887,7 +1890,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             const double *log_w, uint32_t flags, blhip_result *res) {
     Trace tr(ctx->option("trace", 0.0) != 0.0);
     validate(p_in, n_chains, op_values);
-    if (p_in->ndim > 2) { do_fit_nd(ctx, p_in, n_chains, op_values, log_w, flags, res); return; }
+    if (p_in->ndim > 2) { ctx->prior_token = 0; do_fit_nd(ctx, p_in, n_chains, op_values, log_w, flags, res); return; }      // (that path lays the tables buffer out its own way)
     // closed-form models without an in-kernel likelihood: their (T, G) table is built on the device, the step kernels
     // then see a tabulated likelihood
     blhip_problem p_local = *p_in;

@@ -16,12 +16,14 @@ namespace {
 using blerr::arm_kernel;
 using blerr::fail;
 
-template <auto KERN>
-void launch_chain_fn(hipStream_t s, const blc::ChainParams &Q, size_t lds) {
+// (ONE host function for all kernels of a signature -- the kernel arrives as a pointer --, the registry entry counted at the call site:
+//  a launcher per instantiation was 2 KB of host code each, 3 MB of the library)
+#define launch_chain_fn(K, s, Q, lds) (blreg::hit<&K>(), launch_chain_ptr(&K, s, Q, lds))
+template <typename KernT>
+void launch_chain_ptr(KernT KERN, hipStream_t s, const blc::ChainParams &Q, size_t lds) {
     arm_kernel(reinterpret_cast<const void *>(KERN));
     // (xch_mode bit 0 -- blc::chainax_kernel only: one XCD per chain, 8 x strips x ceil(chains / 8) blocks of which nslots x strips work)
     const unsigned blocks = (Q.xch_mode & 1) ? 8u * (unsigned)Q.strips * (unsigned)((Q.nslots + 7) / 8) : (unsigned)(Q.nslots * Q.strips);
-    blreg::hit<KERN>();
     hipLaunchKernelGGL(KERN, dim3(blocks), dim3(blc::NT), lds, s, Q);
 }
 
@@ -31,21 +33,21 @@ template <int NK, int NTW, bool BWD>
 void launch_k(hipStream_t s, const blc::ChainParams &Q, bool store, bool pad) {
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
     if constexpr (!BWD) {
-        if (pad && store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, true>>(s, Q, lds);
-        else if (pad) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, true>>(s, Q, lds);
-        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, false>>(s, Q, lds);
-        else launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, false>>(s, Q, lds);
+        if (pad && store) launch_chain_fn((blc::chain_kernel<NK, NTW, false, true, true>), s, Q, lds);
+        else if (pad) launch_chain_fn((blc::chain_kernel<NK, NTW, false, false, true>), s, Q, lds);
+        else if (store) launch_chain_fn((blc::chain_kernel<NK, NTW, false, true, false>), s, Q, lds);
+        else launch_chain_fn((blc::chain_kernel<NK, NTW, false, false, false>), s, Q, lds);
     } else if constexpr (NTW <= 4) {
         // (<= 512 rows: the folding backward pass is the two-chain kernel's -- blc::chain_fold2_kernel, which also takes an odd chain out;
         //  the one-chain folding flavour was reachable through a development option only and was pruned in round 6: 84 kernels)
         if (!store) fail("internal: chain-resident launch of a folding backward pass on <= 512 rows (the two-chain kernel folds there)");
-        if (pad) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, true>>(s, Q, lds);
-        else launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, false>>(s, Q, lds);
+        if (pad) launch_chain_fn((blc::chain_kernel<NK, NTW, true, true, true>), s, Q, lds);
+        else launch_chain_fn((blc::chain_kernel<NK, NTW, true, true, false>), s, Q, lds);
     } else {
         if (pad && store) fail("internal: the 1024-row chain-resident kernels store posteriors on the exact geometry only");
-        if (pad) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, false, true>>(s, Q, lds);
-        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, false>>(s, Q, lds);
-        else launch_chain_fn<&blc::chain_kernel<NK, NTW, true, false, false>>(s, Q, lds);
+        if (pad) launch_chain_fn((blc::chain_kernel<NK, NTW, true, false, true>), s, Q, lds);
+        else if (store) launch_chain_fn((blc::chain_kernel<NK, NTW, true, true, false>), s, Q, lds);
+        else launch_chain_fn((blc::chain_kernel<NK, NTW, true, false, false>), s, Q, lds);
     }
 }
 
@@ -55,14 +57,14 @@ void launch_k_tab(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store
     const size_t lds = blc::lds_doubles<NK, NTW>() * sizeof(double);
     if constexpr (PAD) {                 // (padded grids: the folding backward pass would be the two-chain kernel's, which has no table flavour)
         if (bwd && !store) fail("internal: padded chain-resident launch of a folding backward pass (tabulated likelihood)");
-        if (bwd) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, true, true>>(s, Q, lds);
-        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, true, true>>(s, Q, lds);
-        else launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, true, true>>(s, Q, lds);
+        if (bwd) launch_chain_fn((blc::chain_kernel<NK, NTW, true, true, true, true>), s, Q, lds);
+        else if (store) launch_chain_fn((blc::chain_kernel<NK, NTW, false, true, true, true>), s, Q, lds);
+        else launch_chain_fn((blc::chain_kernel<NK, NTW, false, false, true, true>), s, Q, lds);
     } else {
-        if (bwd && store) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, true, false, true>>(s, Q, lds);
-        else if (bwd) launch_chain_fn<&blc::chain_kernel<NK, NTW, true, false, false, true>>(s, Q, lds);
-        else if (store) launch_chain_fn<&blc::chain_kernel<NK, NTW, false, true, false, true>>(s, Q, lds);
-        else launch_chain_fn<&blc::chain_kernel<NK, NTW, false, false, false, true>>(s, Q, lds);
+        if (bwd && store) launch_chain_fn((blc::chain_kernel<NK, NTW, true, true, false, true>), s, Q, lds);
+        else if (bwd) launch_chain_fn((blc::chain_kernel<NK, NTW, true, false, false, true>), s, Q, lds);
+        else if (store) launch_chain_fn((blc::chain_kernel<NK, NTW, false, true, false, true>), s, Q, lds);
+        else launch_chain_fn((blc::chain_kernel<NK, NTW, false, false, false, true>), s, Q, lds);
     }
 }
 template <int NTW, bool PAD>
@@ -133,10 +135,10 @@ void launch_fold2_w(hipStream_t s, const blc::ChainParams &Q, int nk, bool pad) 
 template <int NK, int NTW, bool PAD>
 void launch_k_ax(hipStream_t s, const blc::ChainParams &Q, bool bwd, bool store) {
     const size_t lds = blc::lds_doubles_ax<NK, NTW>() * sizeof(double);
-    if (bwd && store) launch_chain_fn<&blc::chainax_kernel<NK, NTW, true, true, PAD>>(s, Q, lds);
-    else if (bwd) launch_chain_fn<&blc::chainax_kernel<NK, NTW, true, false, PAD>>(s, Q, lds);
-    else if (store) launch_chain_fn<&blc::chainax_kernel<NK, NTW, false, true, PAD>>(s, Q, lds);
-    else launch_chain_fn<&blc::chainax_kernel<NK, NTW, false, false, PAD>>(s, Q, lds);
+    if (bwd && store) launch_chain_fn((blc::chainax_kernel<NK, NTW, true, true, PAD>), s, Q, lds);
+    else if (bwd) launch_chain_fn((blc::chainax_kernel<NK, NTW, true, false, PAD>), s, Q, lds);
+    else if (store) launch_chain_fn((blc::chainax_kernel<NK, NTW, false, true, PAD>), s, Q, lds);
+    else launch_chain_fn((blc::chainax_kernel<NK, NTW, false, false, PAD>), s, Q, lds);
 }
 template <int NTW, bool PAD>
 void launch_w_ax(hipStream_t s, const blc::ChainParams &Q, int nk, bool bwd, bool store) {

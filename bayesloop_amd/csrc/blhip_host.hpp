@@ -132,6 +132,10 @@ struct blhip_ctx {
     DevBuf xch;                  // exchange buffers of the both-axes chain-resident kernel (blhip_chainax.hpp): [slot][2 step parities][Gk]
     hipStream_t astream = nullptr;
     hipEvent_t aev_done[2] = {nullptr, nullptr};
+    // the prior the tables buffer holds (blhip_problem.prior_token): uploaded again only when the caller's token, the grid or the place changes
+    unsigned long long prior_token = 0;
+    const double *prior_dev = nullptr;
+    long long prior_G = 0;
 
     double option(const char *k, double dflt) const {
         auto it = opt.find(k);

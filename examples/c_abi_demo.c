@@ -44,7 +44,7 @@ int main(void) {
     p.lattice[0] = grid[1] - grid[0]; p.lattice[1] = 1.0;
     p.T = T; p.seg_len = 1; p.data_dim = 1; p.data = coal; p.timestamps = ts;
     p.prior = prior; p.reset_prior = NULL; p.indep_prior = NULL; p.lik = NULL;
-    p.n_ops = 1; p.ops = &op; p.resume_time = -1.0; p.carry_slot = 0; p.reserved0 = 0; p.backward_init = NULL;
+    p.n_ops = 1; p.ops = &op; p.resume_time = -1.0; p.carry_slot = 0; p.reserved0 = 0; p.backward_init = NULL; p.prior_token = 0;
     r.log_evidence = &logE; r.local_evidence = local; r.posterior_mean = means;
     r.abort_step = &abort_step; r.abort_phase = &abort_phase;
 

@@ -133,6 +133,12 @@ typedef struct {
      * likelihood products, normalisations, sums and means of core.py:434-470 stay on the device (bayesloop_amd/core.py:
      * Study._fitHostTransition).  Fits with a backward_init take the launch-per-step kernels. */
     const double  *backward_init;
+    /* (ABI v8) 0, or the caller's name for the CONTENT of `prior`: a caller that passes the same non-zero token again promises that the
+     * array holds the same values as when it last passed that token.  The library then skips the upload when the context still holds
+     * that prior (same token, same grid, nothing uploaded over it since) -- the prior of a 2048 x 2048 grid is 32 MiB, 0.6 ms of PCIe per
+     * fit of a study that is fitted again and again (Study.optimize, core.py:488-565; repeated fit() calls).  bayesloop_amd passes a
+     * token for the read-only prior arrays it caches per study (bayesloop_amd/core.py: _computePrior). */
+    uint64_t       prior_token;
 } blhip_problem;
 
 /* Flags of blhip_fit */

@@ -2068,3 +2068,38 @@ def test_padded_and_restarting_batches_fall_back_too(case):
     finally:
         eng.set_option('resident_force_abort', 0)
         eng.set_option('resident_ok', 1)
+
+
+def test_prior_stays_resident_between_fits_of_a_study_and_is_replaced_when_it_changes():
+    """blhip_problem.prior_token (ABI v8): the read-only prior array a study caches is uploaded once; a study with ANOTHER prior on the
+    same grid, fitted on the same context in between, gets its own (no stale prior), and so does the first study afterwards."""
+    def study(prior):
+        S = bl.Study(silent=True)
+        S.loadData(cases.series(77, 6), silent=True)
+        S.set(bl.om.Gaussian('mean', bl.cint(-8, 8, 64), 'std', bl.oint(0, 4, 64), prior=prior),
+              bl.tm.CombinedTransitionModel(bl.tm.GaussianRandomWalk('s1', 0.3, target='mean'), bl.tm.GaussianRandomWalk('s2', 0.1, target='std')), silent=True)
+        return S
+    A, Bs = study(lambda m, s: 1.0 / s ** 2), study(lambda m, s: np.exp(-0.5 * m ** 2) / s)
+    A.fit(silent=True)
+    first = (A.logEvidence, np.array(A.posteriorSequence))
+    A.fit(silent=True)                         # (the token says: same content -- not uploaded again)
+    assert A.logEvidence == first[0] and np.array_equal(np.array(A.posteriorSequence), first[1])
+    Bs.fit(silent=True)
+    assert abs(Bs.logEvidence - first[0]) > 1e-3 * abs(first[0])
+    Bs.fit(silent=True); lb = Bs.logEvidence
+    A.fit(silent=True)
+    assert A.logEvidence == first[0] and np.array_equal(np.array(A.posteriorSequence), first[1])
+    Bs.fit(silent=True)
+    assert Bs.logEvidence == lb
+    # an ndarray prior may be modified in place between fits: never cached (token 0)
+    pr = np.ones((64, 64))
+    C = study(pr)
+    C.fit(silent=True); l0 = C.logEvidence
+    pr[:, :32] = 3.0
+    C.fit(silent=True)
+    assert C.logEvidence != l0
+    c = dict(study='Study', data=('series', 77, 6), om=('Gaussian', [('mean', ('cint', -8, 8, 64)), ('std', ('oint', 0, 4, 64))], ('array', pr.tolist())),
+             tm=_grw2(0.3, 0.1))
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    assert abs(C.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])

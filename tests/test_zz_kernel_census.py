@@ -38,6 +38,8 @@ def test_no_launch_site_bypasses_the_registry():
         for m in re.finditer(r'hipLaunchKernelGGL\(|<<<', text):
             line = text[:m.start()].count('\n') + 1
             ctx = text[max(0, m.start() - 200):m.start()]
+            if text[m.end():m.end() + 5] == 'KERN,':        # (blhip_chain_tu.hip: launch_chain_ptr -- its callers count, see the launch_chain_fn macro)
+                continue
             assert 'blreg::hit<' in ctx, '%s:%d launches a kernel the registry does not count (use BL_LAUNCH)' % (fn, line)
 
 
