@@ -65,6 +65,7 @@ class Timing(C.Structure):
         ('fwd_hbm_bytes', C.c_double), ('bwd_hbm_bytes', C.c_double), ('fwd_flops', C.c_double), ('bwd_flops', C.c_double),
         ('resident_fallbacks', C.c_int32), ('resident_armed', C.c_int32),
         ('resident_fallback_reason', C.c_int32), ('peer_copy_path', C.c_int32),
+        ('resident_probe', C.c_int32), ('xcd_order', C.c_int32),
     ]
 
     def as_dict(self):
@@ -96,6 +97,7 @@ PROTOTYPES = {
     'blhip_accum_begin': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'blhip_accum_state': (C.c_int, [C.c_void_p, c_double_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     'blhip_accum_rescale': (C.c_int, [C.c_void_p, C.c_double]),
+    'blhip_accum_fold_host': (C.c_int, [C.c_void_p, c_double_p, C.c_double]),
     'blhip_accum_finalize': (C.c_int, [C.c_void_p, C.POINTER(Problem), c_double_p]),
     'blhip_accum_read': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_double_p]),
     'blhip_accum_end': (C.c_int, [C.c_void_p]),

@@ -1064,22 +1064,48 @@ class HyperStudy(Study):
             print('+ Finished fit.')
 
     def _fitHostTransitionHyper(self, forwardOnly, evidenceOnly, silent):
-        """A hyper-study over a transition model that is applied on the host (Study._fitHostTransition): one evidence-only fit per
-        hyper-grid point (reference core.py:1349-1361), then the hyper-parameter distribution and the evidence of the average model
-        (:1391-1410).  The average posterior sequence is not built for such models (it would be T x G host arithmetic per point)."""
-        if not evidenceOnly:
-            raise ConfigurationError('A HyperStudy over a user-defined transition model (host-side computeForwardPrior) supports '
-                                     'evidenceOnly=True; fit single hyper-parameter values with Study for posteriors.')
+        """A hyper-study over a transition model that is applied on the host (Study._fitHostTransition): one fit per hyper-grid point
+        (reference core.py:1349-1361); unless ``evidenceOnly`` every finite chain's posterior sequence -- which the per-step round trips
+        of that fit have left on the host -- is folded into the device accumulator with its weight (:1362-1366,
+        ``blhip_accum_fold_host``), normalised and reduced there (:1375-1382, :1416-1419); then the hyper-parameter distribution and
+        the evidence of the average model (:1391-1410)."""
         prior_values = np.asarray(self.flatHyperPriorValues, dtype=float)
         self.logEvidenceList, localList = [], []
+        eng = _engine_mod.get_engine()
+        want_post = not evidenceOnly
+        n_fold, begun = 0, False
         try:
-            for row in self.hyperGridValues:
+            for k, row in enumerate(self.hyperGridValues):
                 self._setAllHyperParameters(row)
-                Study.fit(self, evidenceOnly=True, silent=True)
+                Study.fit(self, forwardOnly=forwardOnly, evidenceOnly=evidenceOnly, silent=True)
                 self.logEvidenceList.append(self.logEvidence)
                 localList.append(np.array(self.localEvidence))
+                if want_post and np.isfinite(self.logEvidence) and self._posteriorSequence is not None:
+                    seq = np.asarray(self._posteriorSequence, dtype=float)
+                    if not begun:
+                        eng.accum_begin(seq.shape[0], int(np.prod(seq.shape[1:])), owner=self)
+                        begun = True
+                    with np.errstate(divide='ignore'):
+                        eng.accum_fold_host(seq, self.logEvidence + np.log(prior_values[k]))
+                    n_fold += 1 if prior_values[k] > 0 else 0
         finally:
             self._setAllHyperParameters(self.flatHyperParameters)
+        if want_post:
+            self._posteriorSequence = None
+            self._posterior_pending = None
+            self.averagePosteriorSequence = None
+            self.posteriorMeanValues = []
+            if n_fold > 0:
+                # (marginal grids and lattice are all accum_finalize reads of the problem: per-step normalisation and the means of the average)
+                T = len(self.formattedData)
+                shell = FitProblem(obs_model=device_code(self.observationModel), marginal=self.marginalGrid, lattice=self.latticeConstant,
+                                   data=np.zeros((T, 1)), timestamps=np.zeros(T), prior=np.ones(int(np.prod(self.gridSize))), ops=[])
+                self.posteriorMeanValues = eng.accum_finalize(shell)
+                self._posterior_pending = DevicePosterior(eng, 1, T, list(self.gridSize))
+                if hasattr(eng, 'accum_set_owner'):          # (the per-point fits released the engine's results: the average is this study's)
+                    eng.accum_set_owner(self)
+                if not silent:
+                    print('    + Computed average posterior sequence')
         with np.errstate(divide='ignore'):
             logHPD = np.array(self.logEvidenceList) + np.log(prior_values) + np.sum(np.log(self.hyperGridConstant))
         scaled = logHPD - np.amax(logHPD)

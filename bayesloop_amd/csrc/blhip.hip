@@ -1921,7 +1921,10 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     if (!ctx->resident_ok && ++ctx->resident_fits_since >= ctx->resident_retry_after) {
         ctx->resident_ok = true;
         ctx->resident_fits_since = 0;
+        ctx->probe_last = -1.0;                      // (re-armed: ask the chip first)
     }
+    probe_residency(ctx);
+    ctx->timing.xcd_order = ctx->xcd_order_ok ? 1 : 0;
 
     // ---- shared tables -> HBM ---------------------------------------------------------------------------------------------------
     const DeviceTables DT = upload_tables(ctx, p, g, ff, table_model);
@@ -2704,7 +2707,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->postpad.release(); ctx->accw.release(); ctx->accpart.release(); ctx->xch.release(); ctx->axlik.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->postpad.release(); ctx->accw.release(); ctx->accpart.release(); ctx->xch.release(); ctx->axlik.release(); ctx->probebuf.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,
@@ -2752,14 +2755,15 @@ int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
     if (!ctx || !key) return -1;
     // "resident_ok": the context's memory of a resident launch that gave up (its blocks were not all co-resident) -- settable so that
     // a caller (the tests of the fall-back) can re-arm the resident paths
-    if (std::strcmp(key, "resident_ok") == 0) { ctx->resident_ok = value != 0.0; ctx->resident_fits_since = 0; if (value != 0.0) ctx->resident_retry_after = 8; return 0; }
+    if (std::strcmp(key, "resident_ok") == 0) { ctx->resident_ok = value != 0.0; ctx->resident_fits_since = 0; if (value != 0.0) { ctx->resident_retry_after = 8; ctx->resident_giveups = 0; } return 0; }
     if (std::strcmp(key, "resident_retry_after") == 0) { ctx->resident_retry_after = std::max(1, (int)value); return 0; }
     // (a key the library never reads is an error, not a silent no-op: an A/B run over a removed option measured nothing -- ADVICE r05)
     static const char *const known[] = {
         "accum_overlap", "chain1d", "chain1d_shift", "chain_ax1", "chain_depad", "chain_prof", "chain_resident", "chain_resident_lag",
         "chain_table", "chain_wide", "comm_reduce_mode", "fast", "fast_S", "fold2", "fold2_cp", "fuse1d", "fuse_accumulate", "max_batch",
         "mem_budget_bytes", "mfma", "mfma_S", "mfma_h", "mfma_h_max_cells", "peer_copy_mode", "persist1d", "quiet", "recurrence", "resident",
-        "resident_force_abort", "resident_lag", "resident_table", "resident_timeout_s", "share_prefix", "skip_prefix", "trace", "wide_h",
+        "resident_force_abort", "resident_lag", "resident_probe", "resident_probe_force_busy", "resident_probe_interval_s", "resident_probe_timeout_s",
+        "resident_table", "resident_timeout_s", "share_prefix", "skip_prefix", "trace", "wide_h",
         "wide_h_fused_max", "wide_h_split", "wide_v"};
     bool ok = false;
     for (const char *k : known) ok = ok || std::strcmp(key, k) == 0;
@@ -3097,6 +3101,34 @@ int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref) {
         }
         ctx->acc_logref = new_log_ref;
         sync_stream(ctx, ctx->stream);
+    });
+}
+
+int blhip_accum_fold_host(blhip_ctx *ctx, const double *posterior, double log_weight) {
+    return guarded(ctx, [&] {
+        if (!ctx->acc_active) fail("blhip_accum_fold_host without blhip_accum_begin");
+        if (ctx->acc_final) fail("blhip_accum_fold_host: the accumulator is finalised");
+        if (!posterior) fail("posterior is NULL");
+        if (!std::isfinite(log_weight)) return;                 // np.isfinite(logEvidence) guard, a zero hyper-prior (core.py:1358, :1364)
+        HIPCHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const int64_t T = ctx->acc_T;
+        const long long G = ctx->acc_G;
+        ctx->post_valid = false;                                  // (the sequence buffer is the staging area)
+        ctx->post.ensure((size_t)T * G * 8);
+        for_pinned_pieces(const_cast<double *>(posterior), (size_t)T * G * 8, [&](char *src, size_t n) {
+            HIPCHECK(hipMemcpyAsync(ctx->post.as<char>() + (src - (const char *)posterior), src, n, hipMemcpyHostToDevice, st));
+        });
+        BatchOutcome O;
+        O.logE.assign(1, log_weight);
+        O.abort_step.assign(1, -1);
+        O.abort_phase.assign(1, 0);
+        O.invN.assign((size_t)T, 1.0);                             // (rows arrive normalised)
+        const double zero = 0.0;
+        ctx->small.ensure(carve_size(8) + carve_size((size_t)T * 8));
+        char *cur = ctx->small.as<char>();
+        double *d_w = carve<double>(cur, 1), *d_invN = carve<double>(cur, (size_t)T);
+        fold_accumulate(ctx, T, G, 1, O, &zero, ctx->post.as<double>(), d_w, d_invN);
     });
 }
 

@@ -52,6 +52,52 @@ bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
     return false;
 }
 
+// Is the chip ours?  A grid of one block per CU with the resident kernels' footprint; every block counts itself in and waits (bounded)
+// for the others.  -> false: not all of them were on the chip together -- another process holds CUs, or the device is partitioned: a
+// resident launch would sit out its time-out (>= 0.25 s) before the fit fell back.  ~15 us when the chip is free.
+bool chip_is_ours(blhip_ctx *ctx) {
+    hipStream_t st = ctx->stream;
+    ctx->pinS.ensure(64);
+    unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
+    DevBuf &d = ctx->probebuf;
+    d.ensure(64);
+    HIPCHECK(hipMemsetAsync(d.p, 0, 64, st));
+    const unsigned nb = (unsigned)std::min(ctx->num_cus, 256);
+    const size_t lds = 150 * 1024;
+    arm_kernel(reinterpret_cast<const void *>(&blr::residency_probe_kernel<0>));
+    const unsigned long long ticks = (unsigned long long)(std::max(1e-4, ctx->option("resident_probe_timeout_s", 0.002)) * 1e8);
+    BL_LAUNCH(blr::residency_probe_kernel<0>, dim3(nb), dim3(512), lds, st, d.as<unsigned>(), nb, ticks);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, st));
+    sync_stream(ctx, st);
+    ctx->xcd_order_ok = h[2] == 0u;
+    return h[0] == nb && h[1] == 0u && ctx->option("resident_probe_force_busy", 0.0) == 0.0;
+}
+
+// Before a fit that may take a resident path: on the context's first fit, when the paths are re-armed after a give-up, and at most once
+// per resident_probe_interval_s (1 s) otherwise.  A busy chip parks the resident paths exactly as a give-up does (retry after 8, 16, ..
+// fits) -- at the price of the probe's bound (2 ms), not of a launch's.
+void probe_residency(blhip_ctx *ctx) {
+    if (!ctx->resident_ok || ctx->option("resident_probe", 1.0) == 0.0) return;
+    const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (ctx->probe_last >= 0.0 && now - ctx->probe_last < ctx->option("resident_probe_interval_s", 1.0)) return;
+    ctx->probe_last = now;
+    const bool ours = chip_is_ours(ctx);
+    ctx->timing.resident_probe = ours ? 1 : 2;
+    if (ours) return;
+    if (!ctx->probe_announced && ctx->option("quiet", 0.0) == 0.0)
+        std::fprintf(stderr, "[blhip] the GPU is not exclusively ours (a one-block-per-CU probe did not get all its blocks onto the chip within "
+                             "%.1f ms: another process, or a partitioned device); fits run on the launch-per-step kernels until a later probe finds it free\n",
+                     1e3 * std::max(1e-4, ctx->option("resident_probe_timeout_s", 0.002)));
+    ctx->probe_announced = true;
+    ctx->resident_ok = false;
+    ctx->resident_fits_since = 0;
+    ctx->resident_giveups += 1;
+    ctx->resident_last_reason = BLHIP_FALLBACK_BUSY;
+    ctx->timing.resident_fallback_reason = BLHIP_FALLBACK_BUSY;
+    if (ctx->resident_giveups > 1) ctx->resident_retry_after = std::min(1024, 2 * ctx->resident_retry_after);
+}
+
 // ---- the time-resident path of a single-chain batch: one launch per pass instead of one per step (blhip_resident.hpp) -----------------
 struct ResidentRun {
     bool on = false;
@@ -469,7 +515,9 @@ struct ChainRun {
                 // the blocks of a chain on ONE XCD (block b runs on XCD b % 8 -- observed, for speed only) and plain publishing stores, which
                 // keep the lines in that XCD's L2 (write-through stores drop them: MI355X_MICROARCH.md); chain_ax1_mode = 0: write-through
                 // stores and the dispatch order of the other chain kernels -- nothing then depends on the placement, not even the speed
-                Q.xch_mode = ax_mode >= 0 ? ax_mode : 3;
+                // (the placement is checked by the co-residency probe: where block b was NOT seen on XCD b % 8 -- another partition mode, a CU
+                //  mask -- the plain stores' lines would never reach a consumer on another XCD: write-through stores in dispatch order then)
+                Q.xch_mode = ax_mode >= 0 ? ax_mode : (ctx->xcd_order_ok ? 3 : 0);
                 const bool prof = ctx->option("chain_prof", 0.0) != 0.0;
                 if (prof) {
                     ctx->small.ensure(2 * 16 * 16 * 8);

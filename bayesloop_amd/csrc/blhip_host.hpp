@@ -132,6 +132,11 @@ struct blhip_ctx {
     DevBuf xch;                  // exchange buffers of the both-axes chain-resident kernel (blhip_chainax.hpp): [slot][2 step parities][Gk]
     hipStream_t astream = nullptr;
     hipEvent_t aev_done[2] = {nullptr, nullptr};
+    // the co-residency probe (blr::residency_probe_kernel): when it last ran (steady-clock seconds, < 0: never / run it again), what it saw
+    DevBuf probebuf;
+    double probe_last = -1.0;
+    bool xcd_order_ok = true;
+    bool probe_announced = false;
     // the prior the tables buffer holds (blhip_problem.prior_token): uploaded again only when the caller's token, the grid or the place changes
     unsigned long long prior_token = 0;
     const double *prior_dev = nullptr;

@@ -1184,5 +1184,33 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
     if (booker) book(Q.T - 1);
 }
 
+
+#ifndef BLR_EMULATE
+// ---- is the chip ours?  The resident kernels need EVERY block of a launch on the chip at the same time: one block of 512 threads
+// with up to 256 registers and up to 160 KB of LDS per CU.  On a GPU another process is using (or a partitioned one) some never
+// arrive; a launch then sits out its whole time-out before the fit falls back (>= 0.25 s -- a 1000 x cliff for a millisecond fit).
+// This probe asks the question in microseconds: a grid of one block per CU with the resident kernels' footprint (512 threads, the whole
+// register file -- the empty asm touches v255 --, `lds` bytes of dynamic LDS); lane 0 of every block counts itself in and waits until
+// all have, at most `timeout_ticks`.  out[0] = blocks that arrived, out[1] = 1 if a block gave up, out[2] = blocks NOT on XCD
+// blockIdx % 8 (the placement the both-axes kernels' plain-store exchange relies on for liveness: ADVICE r05).
+template <int FOOTPRINT = 0>          // (a template: this header is part of every translation unit of the library, the kernel of the one that launches it)
+__global__ __launch_bounds__(512, 1) void residency_probe_kernel(unsigned *out, unsigned nblocks, unsigned long long timeout_ticks) {
+    extern __shared__ __attribute__((aligned(16))) double lds_probe[];
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    if (threadIdx.x == 0) {
+        lds_probe[0] = 0.0;
+        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;          // HW_REG_XCC_ID, 4 bits
+        if (xcc != (blockIdx.x & 7u)) atomicAdd(&out[2], 1u);
+        __hip_atomic_fetch_add((gu32 *)(unsigned long long)&out[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = now_ticks();
+        while (ld_flag(&out[0]) < nblocks) {
+            if (ld_flag(&out[1]) != 0u) break;
+            if (now_ticks() - t0 > timeout_ticks) { st_flag(&out[1], 1u); break; }
+            nap();
+        }
+    }
+}
+#endif
+
 }  // namespace blr
 #endif

@@ -446,6 +446,19 @@ class HipEngine:
     def accum_rescale(self, new_log_ref):
         self._check(self.lib.blhip_accum_rescale(self.ctx, float(new_log_ref)))
 
+    def accum_set_owner(self, owner):
+        """Whose results the accumulator holds (brought to the host before another study's fit reuses it)."""
+        self._accum_owner = None if owner is None else weakref.ref(owner)
+
+    def accum_fold_host(self, posterior, log_weight):
+        """Folds one chain whose (T, *gridSize) posterior sequence lives on the host (a hyper-grid point fitted through the transition-model
+        plug-in interface) into the open accumulator, weight exp(log_weight) (reference core.py:1358-1366)."""
+        post = _f64(posterior)
+        T, G = self._acc_shape
+        if post.size != T * G:
+            raise BackendError('accum_fold_host: the sequence has %d values, the accumulator %d x %d' % (post.size, T, G))
+        self._check(self.lib.blhip_accum_fold_host(self.ctx, _abi.dptr(post), float(log_weight)))
+
     def accum_finalize(self, problem: FitProblem):
         cp, keep = self._problem(problem)
         ndim = len(problem.marginal)

@@ -186,6 +186,12 @@ typedef struct {
     int32_t resident_fallback_reason;   /* (ABI v7) why the LAST such batch fell back: BLHIP_FALLBACK_*             */
     int32_t peer_copy_path;       /* (ABI v7) how blhip_accum_peer_reduce / _gather fetched the other contexts' slices since the
                                      last blhip_fit of THIS context: BLHIP_PEER_* (0: no peer merge)                   */
+    int32_t resident_probe;       /* (ABI v8) the co-residency probe of this call: 0 = none ran (it runs on a context's first fit, when
+                                     the resident paths are re-armed and at most once per second), 1 = every block of a one-block-per-CU
+                                     grid with the resident kernels' footprint was on the chip at once, 2 = not (another process holds
+                                     CUs, a partitioned GPU): the resident paths are parked WITHOUT paying a launch's time-out     */
+    int32_t xcd_order;            /* (ABI v8) 1: the probe saw block b on XCD b % 8 (the both-axes kernels publish their exchange with
+                                     plain stores that stay in that XCD's L2); 0: it did not -- write-through exchange instead    */
 } blhip_timing;
 
 /* blhip_timing.peer_copy_path */
@@ -201,6 +207,7 @@ typedef struct {
 #define BLHIP_FALLBACK_RANGE      2   /* a lagged sum left (1e-150, 1e150) or was not finite (extreme outliers, a zero normaliser) */
 #define BLHIP_FALLBACK_PREDICTION 3   /* the predicted posterior sums did not reproduce the reduced ones                          */
 #define BLHIP_FALLBACK_FORCED     4   /* option resident_force_abort (tests)                                                      */
+#define BLHIP_FALLBACK_BUSY       5   /* (ABI v8) no launch was tried: the co-residency probe found the chip shared (resident_probe = 2) */
 
 /* ---- context ------------------------------------------------------------------------------------------------- */
 int         blhip_abi_version(void);
@@ -267,6 +274,12 @@ int blhip_accum_state(blhip_ctx *ctx, double *log_ref, void **devptr, int64_t *n
 /* Re-express the accumulator against a new reference exponent (>= current), e.g. the maximum over ranks, so that
  * accumulators of several GPUs can be summed (core.py:1339). */
 int blhip_accum_rescale(blhip_ctx *ctx, double new_log_ref);
+/* (ABI v8) Folds ONE chain whose posterior sequence the CALLER holds -- a hyper-grid point fitted through the transition-model plug-in
+ * interface, where the state crosses the host at every step anyway (bayesloop_amd/core.py: Study._fitHostTransition) -- into the open
+ * accumulator: posterior is (T, G) on the host, every row normalised; log_weight = logEvidence + log(hyper-prior value) of the chain
+ * (core.py:1358-1366: acc = logaddexp(acc, log(max(post, 1e-300)) + log_weight); a non-finite log_weight contributes nothing).  The
+ * sequence is uploaded and folded by the kernels that fold a stored batch. */
+int blhip_accum_fold_host(blhip_ctx *ctx, const double *posterior, double log_weight);
 /* Per-step normalisation (core.py:1379-1382) and posterior means (core.py:1416-1419); the normalised average stays
  * on the device and is read with blhip_accum_read.  posterior_mean: (ndim, T) or NULL. */
 int blhip_accum_finalize(blhip_ctx *ctx, const blhip_problem *problem, double *posterior_mean);

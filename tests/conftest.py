@@ -11,7 +11,9 @@ for p in (HERE, ROOT):
 if os.environ.get('PYTEST_XDIST_WORKER'):
     # several test processes share ONE GPU (pytest -n 4): a resident launch may wait long for blocks another process's kernels keep off
     # the chip -- the flat 2-second bound of round 3 instead of the pass-scaled default (resident_timeout_s)
-    os.environ.setdefault('BLHIP_ENGINE_OPTS', 'resident_timeout_s=4')
+    # ... and no co-residency probe (blhip_timing.resident_probe): its 2-ms bound would park the resident paths whenever another worker's
+    # kernel is on the chip, and the tests that assert WHICH kernel ran would fail with it
+    os.environ.setdefault('BLHIP_ENGINE_OPTS', 'resident_timeout_s=4,resident_probe=0')
 
 
 import pytest  # noqa: E402

@@ -173,6 +173,12 @@ class OracleEngine:
         self.acc_log = np.zeros((T, G)) - np.inf
         self.acc_lin = None
 
+    def accum_fold_host(self, posterior, log_weight):
+        """as HipEngine.accum_fold_host: one chain whose posterior sequence the caller holds (log_weight = logEvidence + log prior value)"""
+        if np.isfinite(log_weight):
+            post = np.array(posterior, dtype=float).reshape(self.acc_log.shape)
+            self.acc_log = orc.hyper_accumulate(self.acc_log, dict(posteriorSequence=post, logEvidence=0.0), log_weight)
+
     def accum_row_stats(self, problem):
         """as HipEngine.accum_row_stats: per-step sums of exp(acc_log - own reference exponent)"""
         T, G = self.acc_shape

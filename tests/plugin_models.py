@@ -138,6 +138,19 @@ def studies(bl, M):
     S.loadData(COAL[:36], silent=True)
     S.set(bl.om.Poisson('rate', bl.oint(0, 6, 90)), M['LeakyRandomWalk']('sigma', bl.cint(0.1, 0.5, 3), 'leak', [0.0, 0.03], target='rate'), silent=True)
     out['leaky_hyper_evid'] = (S, dict(evidenceOnly=True))
+    # ... and with its average posterior sequence (core.py:1362-1382): full fit, forward-only, a zero hyper-prior value
+    for mode, kw in (('full', {}), ('fwdonly', dict(forwardOnly=True))):
+        S = study(bl.HyperStudy)
+        S.loadData(COAL[:36], silent=True)
+        S.set(bl.om.Poisson('rate', bl.oint(0, 6, 90)), M['LeakyRandomWalk']('sigma', bl.cint(0.1, 0.5, 3), 'leak', [0.0, 0.03], target='rate'), silent=True)
+        out['leaky_hyper_' + mode] = (S, kw)
+    # 2-D Gaussian grid: a hyper-study over a combination of the user-defined model and a built-in walk
+    S = study(bl.HyperStudy)
+    S.loadData(series(9, 14), silent=True)
+    S.set(bl.om.Gaussian('mean', bl.cint(-3, 3, 24), 'std', bl.oint(0, 2, 20)),
+          bl.tm.CombinedTransitionModel(M['LeakyRandomWalk']('sigma', [0.15, 0.3, 0.45], 'leak', 0.01, target='mean'),
+                                        bl.tm.GaussianRandomWalk('s2', [0.05, 0.12], target='std')), silent=True)
+    out['combined_gauss_hyper_full'] = (S, {})
     return out
 
 

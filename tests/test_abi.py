@@ -30,7 +30,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_abi.Op) == 16
     assert ctypes.sizeof(_abi.Problem) == 4 + 4 + 3 * 8 * _abi.MAX_DIM + 8 + 4 + 4 + 6 * 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8      # n, marginal, lattice: [BLHIP_MAX_DIM]; ... backward_init, prior_token
     assert ctypes.sizeof(_abi.Result) == 5 * 8
-    assert ctypes.sizeof(_abi.Timing) == 4 * 8 + 5 * 8 + 2 * 4 + 4 * 8 + 4 * 4
+    assert ctypes.sizeof(_abi.Timing) == 4 * 8 + 5 * 8 + 2 * 4 + 4 * 8 + 6 * 4
 
 
 def test_no_gpu_fails_loudly():

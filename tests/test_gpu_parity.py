@@ -2103,3 +2103,79 @@ def test_prior_stays_resident_between_fits_of_a_study_and_is_replaced_when_it_ch
     with np.errstate(all='ignore'):
         want = oa.run(c)
     assert abs(C.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
+
+
+def test_co_residency_probe_routes_a_busy_chip_to_the_launch_per_step_kernels(capfd):
+    """blhip_timing.resident_probe (ABI v8): before a fit may take a resident path the library asks whether a one-block-per-CU grid with the
+    resident kernels' footprint gets onto the chip at once.  Free chip: the resident kernel runs.  Busy chip (forced here): the paths are parked
+    up front -- no launch, no time-out, no fall-back batch --, the launch-per-step kernels give the same results, and a later probe re-arms."""
+    eng = bl.get_engine()
+    c = RESIDENT['res_64x96_full']
+    eng.set_option('resident_probe_interval_s', 0)          # (every fit asks)
+    try:
+        A = cases.build(bl, c); A.fit(silent=True)
+        assert A.lastTiming['resident_probe'] == 1 and A.lastTiming['fwd_kernel_variant'] == 5, A.lastTiming
+        assert A.lastTiming['xcd_order'] in (0, 1)
+        eng.set_option('resident_probe_force_busy', 1)
+        try:
+            t0 = __import__('time').perf_counter()
+            B = cases.build(bl, c); B.fit(silent=True)
+            dt = __import__('time').perf_counter() - t0
+        finally:
+            eng.set_option('resident_probe_force_busy', 0)
+        assert B.lastTiming['resident_probe'] == 2 and B.lastTiming['resident_armed'] == 0, B.lastTiming
+        assert B.lastTiming['fwd_kernel_variant'] != 5 and B.lastTiming['resident_fallbacks'] == 0, B.lastTiming
+        assert B.lastTiming['resident_fallback_reason'] == 5            # BLHIP_FALLBACK_BUSY
+        assert dt < 0.2, dt                                               # (a launch that sat out its time-out: >= 0.25 s)
+        assert 'not exclusively ours' in capfd.readouterr().err
+        assert abs(A.logEvidence - B.logEvidence) <= 1e-11 * abs(A.logEvidence)
+        np.testing.assert_allclose(np.asarray(B.posteriorSequence), np.asarray(A.posteriorSequence), rtol=1e-9, atol=1e-14)
+        eng.set_option('resident_ok', 1)
+        C = cases.build(bl, c); C.fit(silent=True)
+        assert C.lastTiming['resident_probe'] == 1 and C.lastTiming['fwd_kernel_variant'] == 5, C.lastTiming
+    finally:
+        eng.set_option('resident_probe_interval_s', 1)
+        eng.set_option('resident_ok', 1)
+
+
+def test_fits_beside_another_contexts_kernels_do_not_sit_out_time_outs():
+    """A second context keeps the GPU busy with streaming kernels from another host thread (blhip_bandwidth_probe) while this one fits a
+    resident-eligible study again and again: whatever the probe decides each time, every fit is right and none pays a launch's time-out."""
+    import threading
+    import time
+    from bayesloop_amd import engine as em
+    eng = bl.get_engine()
+    hog = em.extra_engine(getattr(eng, 'device', 0))
+    stop = threading.Event()
+
+    def run():
+        while not stop.is_set():
+            hog.bandwidth_probe(1 << 28, 40)
+
+    c = RESIDENT['res_192_full']
+    ref = cases.build(bl, c); ref.fit(silent=True)
+    want = (ref.logEvidence, np.array(ref.posteriorSequence))
+    eng.set_option('resident_probe_interval_s', 0)
+    eng.set_option('quiet', 1)
+    th = threading.Thread(target=run)
+    th.start()
+    try:
+        time.sleep(0.05)
+        worst, probes = 0.0, []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            S = cases.build(bl, c); S.fit(silent=True)
+            worst = max(worst, time.perf_counter() - t0)
+            probes.append(S.lastTiming['resident_probe'])
+            assert abs(S.logEvidence - want[0]) <= 1e-11 * abs(want[0])
+            np.testing.assert_allclose(np.asarray(S.posteriorSequence), want[1], rtol=1e-9, atol=1e-14)
+            eng.set_option('resident_ok', 1)
+    finally:
+        stop.set()
+        th.join()
+        eng.set_option('resident_probe_interval_s', 1)
+        eng.set_option('quiet', 0)
+        eng.set_option('resident_ok', 1)
+        del hog
+    print('probe results beside the hog:', probes, 'slowest fit %.1f ms' % (worst * 1e3))
+    assert worst < 0.2, (worst, probes)
