@@ -447,19 +447,27 @@ void launch_chain1d_m(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t l
         BL_LAUNCH((bl1c::chain1d_kernel<OM, false, M>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
     }
 }
-template <int OM>
-void launch_chain1d_shift(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {       // programs with Deterministic steps
+template <int OM, int CL, int M = 1>
+void launch_chain1d_cl(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
     if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true, 1, true>));
-        BL_LAUNCH((bl1c::chain1d_kernel<OM, true, 1, true>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true, M, CL>));
+        BL_LAUNCH((bl1c::chain1d_kernel<OM, true, M, CL>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
     } else {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false, 1, true>));
-        BL_LAUNCH((bl1c::chain1d_kernel<OM, false, 1, true>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
+        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false, M, CL>));
+        BL_LAUNCH((bl1c::chain1d_kernel<OM, false, M, CL>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
     }
+}
+// programs with Deterministic steps (CL 1) / with RegimeSwitch, NotEqual clamps too (CL 2; without a Deterministic step: rows longer than a
+// block with two cells per thread, as the plain flavour)
+template <int OM>
+void launch_chain1d_shift(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds, int m) {
+    if (!P.limit) launch_chain1d_cl<OM, 1>(s, P, bwd, lds);
+    else if (m == 2 && P.no_shift) launch_chain1d_cl<OM, 2, 2>(s, P, bwd, lds);
+    else launch_chain1d_cl<OM, 2>(s, P, bwd, lds);
 }
 template <int OM>
 void launch_chain1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds, int m) {
-    if (P.cmode) launch_chain1d_shift<OM>(s, P, bwd, lds);
+    if (P.cmode) launch_chain1d_shift<OM>(s, P, bwd, lds, m);
     else if (m == 2) launch_chain1d_m<OM, 2>(s, P, bwd, lds);
     else launch_chain1d_m<OM, 1>(s, P, bwd, lds);
 }
@@ -785,6 +793,8 @@ struct ChainProgram {
     bool has_clamp = false;
     bool whole_row = false;      // a two-stage spline shift (Deterministic, |d| > 12): a block needs the whole row of a 1-D grid
     bool other_clamp = false;    // has_clamp for another reason than a Deterministic model's shift (mode 6)
+    bool dense_clamp = false;    // ... than a shift or the clamps of RegimeSwitch / NotEqual: AlphaStable- / BivariateRandomWalk (modes 5 / 4: zero boundary, dense kernels)
+    bool has_shift = false;      // a Deterministic model
 };
 
 struct StepProg {
@@ -807,6 +817,8 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
     prog.has_clamp = false;
     prog.whole_row = false;
     prog.other_clamp = false;
+    prog.dense_clamp = false;
+    prog.has_shift = false;
     double dV = 1.0;
     for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
     // the ops a step's program is made of (the *_ARG ops only carry values of the op in front of them: a Deterministic model has 2 T of
@@ -862,19 +874,20 @@ void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_
                 time_dependent = true;                       // a different shift at every step
                 op_axis[k] = g.axis_map[op.axis];
                 prog.has_clamp = true;                       // (mode 6 of the generic kernel)
+                prog.has_shift = true;
             } else if (op.kind == BLHIP_OP_ALPHASTABLE) {
                 const double c = val[k] / p->lattice[op.axis], alpha = val[k + 1];          // transitionModels.py:170-176
                 if (std::isnan(c) || std::isnan(alpha)) fail("chain %lld: AlphaStableRandomWalk parameters are NaN", (long long)(c0 + b));
                 op_axis[k] = g.axis_map[op.axis];
                 op_tap[k] = taps.get_alphastable(op_axis[k], c, alpha, (int)p->n[op.axis]);
-                prog.has_clamp = true; prog.other_clamp = true;      // (mode 5 of the generic kernel: zero boundary + renormalisation)
+                prog.has_clamp = true; prog.other_clamp = true; prog.dense_clamp = true;      // (mode 5 of the generic kernel: zero boundary + renormalisation)
             } else if (op.kind == BLHIP_OP_BIVARIATE) {
                 // transitionModels.py:881-885; a singular covariance makes scipy.stats.multivariate_normal raise in the reference
                 const double n1 = val[k] / p->lattice[0], n2 = val[k + 1] / p->lattice[1], rho = val[k + 2];
                 if (!(n1 > 0.0) || !(n2 > 0.0) || !(std::fabs(rho) < 1.0))
                     fail("chain %lld: BivariateRandomWalk needs sigma1, sigma2 > 0 and |rho| < 1", (long long)(c0 + b));
                 op_tap[k] = taps.get2d(n1, n2, rho);
-                prog.has_clamp = true; prog.other_clamp = true;      // (mode 4 of the generic kernel: dense kernel + renormalisation)
+                prog.has_clamp = true; prog.other_clamp = true; prog.dense_clamp = true;      // (mode 4 of the generic kernel: dense kernel + renormalisation)
             }
         }
         // the transition from one step to the next, evaluated at time stamp tau (list order, transitionModels.py:645-649)
@@ -1264,7 +1277,8 @@ int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry 
 // which kernel family runs a batch and with what block geometry (segment lengths from a small cost model: long segments read every
 // element once + 2 R0 halo rows per segment, short ones give enough blocks to fill 256 CUs when there are few chains)
 struct GeometryPlan {
-    bool shift1d = false;        // the chain-resident 1-D kernel's flavour with spline shifts (Deterministic steps)
+    bool shift1d = false;        // the chain-resident 1-D kernel's flavours with spline shifts (Deterministic steps) / clamps (RegimeSwitch, NotEqual)
+    bool clamp1d = false;        // ... the one with clamps (CL = 2)
     bool fast = false, fused1d = false, use_mfma = false;
     bool chain1d = false;         // 1-D batches: one block per chain runs the whole pass (blhip_chain1d.hpp); bookkeeping of a K = 1 fused pass
     bool wideH = false;           // axis-1 walks wider than the fused kernels' halo: row filter as a pre-pass per step (blhip_hwide.hpp)
@@ -1306,7 +1320,10 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
     }
     // (programs whose only clamp mode is a Deterministic model's spline shift: the chain-resident kernel has a flavour for them
     //  -- bl1c::chain1d_kernel SHIFT --, the K-steps-per-launch and persistent kernels have not: chain1d or the generic kernel)
-    const bool shift1d = p->ndim == 1 && prog.has_clamp && !prog.other_clamp && ctx->option("chain1d_shift", 1.0) != 0.0;
+    // (round 6: ... and the one with the clamps of RegimeSwitch / NotEqual -- bl1c::chain1d_kernel CL = 2; the dense zero-boundary kernels of
+    //  the AlphaStable walk keep the generic kernel)
+    const bool shift1d = p->ndim == 1 && prog.has_clamp && !prog.dense_clamp && ctx->option("chain1d_shift", 1.0) != 0.0 &&
+                         (!prog.other_clamp || ctx->option("chain1d_clamp", 1.0) != 0.0);
     if (p->ndim == 1 && !gp.fast && (!prog.has_clamp || shift1d) && ctx->option("fuse1d", 8.0) >= 1.0 &&
         (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
         gp.f1_TJ = 128;
@@ -1338,11 +1355,14 @@ GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometr
             const double est_other = p1d_ok ? 1.7 + 0.04 * lw : 1.5 + (double)B * n * (29.0 + 0.63 * lw) * 1e-6;
             // (shift1d: the alternative is a launch per step.  A single chain takes the kernel too when the model says so -- rows of a few
             //  hundred cells with a narrow stencil: 200 cells, radius 27: 2.4 against 2.8 us per step)
-            gp.chain1d = c1d_mode == 2.0 || (B >= 2 && shift1d) || (!shift1d && est_c1d < est_other);
+            // (clamps without a Deterministic model -- the reference's regime-switch tutorial is ONE such chain: a step of a few hundred cells
+            //  costs the block ~2 us against a launch of the generic kernel)
+            gp.chain1d = c1d_mode == 2.0 || (shift1d && (B >= 2 || !prog.has_shift)) || (!shift1d && est_c1d < est_other);
             if (gp.chain1d) { gp.fusedK = 1; gp.f1_TJ = g.n1; }
         }
         if (shift1d && !gp.chain1d) gp.fused1d = false;
         gp.shift1d = shift1d && gp.chain1d;
+        gp.clamp1d = gp.shift1d && prog.other_clamp;
     }
     if (gp.fast) {
         gp.tile.TI = blf::CH; gp.tile.LW0 = gp.wideV ? 0 : prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && (!gp.wideH || (gp.hSplit && any_narrow))) ? blf::R1MAX : 0;
@@ -2293,6 +2313,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             Q.K = 1; Q.dir = bwd ? -1 : 1; Q.t_first = bwd ? (int)(T - 1) : 0; Q.psum = psum; Q.prev_slot = bwd ? 2 : 0;
             Q.srckind = bwd ? d_kindB : d_kindF; Q.tap = bwd ? d_tapB1 : d_tapF1;
             if (gp.shift1d) Q.cmode = bwd ? d_cmodeB : d_cmodeF;
+            if (gp.clamp1d) { Q.limit = bwd ? d_limitB : d_limitF; Q.no_shift = prog.has_shift ? 0 : 1; }
             Q.store = (bwd || !evidence_only) ? 1 : 0; Q.means = bwd ? 1 : (forward_only ? 1 : 0);
             Q.post = (bwd || !evidence_only) ? d_post : nullptr; Q.post_stride = (long long)T * G;
             Q.src = nullptr; Q.src_stride = 0; Q.dst = nullptr; Q.dst_stride = 0;
@@ -2759,7 +2780,7 @@ int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
     if (std::strcmp(key, "resident_retry_after") == 0) { ctx->resident_retry_after = std::max(1, (int)value); return 0; }
     // (a key the library never reads is an error, not a silent no-op: an A/B run over a removed option measured nothing -- ADVICE r05)
     static const char *const known[] = {
-        "accum_overlap", "chain1d", "chain1d_shift", "chain_ax1", "chain_depad", "chain_prof", "chain_resident", "chain_resident_lag",
+        "accum_overlap", "chain1d", "chain1d_clamp", "chain1d_shift", "chain_ax1", "chain_depad", "chain_prof", "chain_resident", "chain_resident_lag",
         "chain_table", "chain_wide", "comm_reduce_mode", "fast", "fast_S", "fold2", "fold2_cp", "fuse1d", "fuse_accumulate", "max_batch",
         "mem_budget_bytes", "mfma", "mfma_S", "mfma_h", "mfma_h_max_cells", "peer_copy_mode", "persist1d", "quiet", "recurrence", "resident",
         "resident_force_abort", "resident_lag", "resident_probe", "resident_probe_force_busy", "resident_probe_interval_s", "resident_probe_timeout_s",

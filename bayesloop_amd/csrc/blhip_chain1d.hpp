@@ -25,7 +25,7 @@ constexpr int NW = NT / 64;
 constexpr int NMAX = 4096;         // cells per row: at most 8 per thread (the stored forward row of the next step waits in registers)
 constexpr int CPT = NMAX / NT;
 
-constexpr int NS = 5;              // sums of a step per wave: N, sum p / L, sum c, mean, mass of the shifted distribution (SHIFT)
+constexpr int NS = 6;              // sums of a step per wave: N, sum p / L, sum c, mean, mass of the shifted / clamped distribution, maximum of the new state (clamps)
 // doubles of LDS: two state buffers with halo, grid values, exp(-lambda) (Poisson), weights, the waves' partial sums (two parities);
 // shift: + the other half of an asymmetric tap set and the spline coefficients of the 12-padded row (two-stage shifts)
 inline size_t lds_doubles(int n, int LW, bool shift = false) {
@@ -58,9 +58,18 @@ __global__ __launch_bounds__(256) void lik1d_table_kernel(const bl1f::F1Params P
 // |d| <= 12 cells, the two-stage form beyond (prefilter of the padded row, cubic B-spline at the shifted coordinates with the coefficient
 // index clamped).  The reference renormalises the shifted distribution: its mass goes to the host as one more sum per step (slot 1
 // forward, slot 5 backward, as the launch-per-step kernel's).  One cell per thread and pass over the row (M = 1).
-template <int OM, bool BWD, int M = 1, bool SHIFT = false>
+// CL = 2: ... and programs with the clamps of RegimeSwitch (transitionModels.py:394-415: clamp from below at 10^pMin dV, renormalise -- on the
+// step's source when the model stands in front of a walk, after the stencil when it follows one) and NotEqual (:450-474: invert around the
+// maximum, renormalise, clamp, renormalise), with the launch-per-step kernel's arithmetic and sum slots (blk::step_kernel, clamp modes
+// 1 / 2 / 3): the clamp acts on the NORMALISED distribution, so the backward pass of such a batch scales by 1 / sum(beta) of the producing
+// step (slot 5) and carries kappa = sum(beta) / sum(c) into its products; the mass of the clamped distribution leaves as slot 1 (forward) /
+// slot 5 (backward), the maximum of the new state (NotEqual inverts around it) as slot 6.  Block = chain: every one of these sums is a
+// block sum of the previous step -- no hand-off, which is what the 2-D resident kernels would need for it.  (CL = 1 keeps the arithmetic
+// of the shift-only flavour bit for bit: the published break-point study's borderline chains, DESIGN 6 COAL_NOISE_CHAINS.)
+template <int OM, bool BWD, int M = 1, int CL = 0>
 __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
-    static_assert(!(SHIFT && M != 1), "spline shifts: one cell per thread");
+    constexpr bool SHIFT = CL != 0, CLAMP = CL == 2;
+    static_assert(!(CL == 1 && M != 1), "spline shifts: one cell per thread");      // (CL = 2 with M = 2: programs with clamps but WITHOUT Deterministic steps -- the host's choice)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = P.n;
     const int LW = M == 2 ? (P.LW + 1) & ~1 : P.LW;                  // (M = 2: an even halo, so that cell 0 sits in plane 0)
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         const int kind = P.srckind[tb];
         const int tp = P.tap[tb];
         double *rk = red + (s & 1) * (NW * NS), *rp = red + ((s + 1) & 1) * (NW * NS);
-        const int l2 = (SHIFT && tp >= 0 && P.cmode[tb] == 6) ? P.tap_lw2[tp] : 0;
+        const int l2 = (SHIFT && M == 1 && tp >= 0 && P.cmode[tb] == 6) ? P.tap_lw2[tp] : 0;
         const bool asym = SHIFT && l2 == -1, big = SHIFT && l2 == -2, shift = asym || big;
         // ---- the step's weights (block-uniform: re-staged only when the chain's tap set changes) ---------------------------------------
         const bool staged = tp != tap_now || kind != SRC_PREV || s == 0;
@@ -118,7 +127,10 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
             tap_now = tp;
         }
         // ---- the source: the previous state (in `cur` since the last barrier), or a shared distribution (prior, restart, uniform) -------
-        double scale = 1.0;
+        double scale = 1.0, kappa = 1.0;
+        const int cm = CLAMP ? (int)P.cmode[tb] : 0;                 // 1 / 2: RegimeSwitch before / after the stencil, 3: NotEqual (0, 6: none here)
+        const double lim = (CLAMP && cm >= 1 && cm <= 3) ? P.limit[tb] : 0.0;
+        double ne_max = 0.0, ne_inv = 0.0;
         if (kind != SRC_PREV || s == 0) {
             const double *src = (kind == SRC_PREV) ? P.src + (long long)b * P.src_stride : P.shared[kind];
             for (int j = tid; j < n; j += NT) put(cur, j, src[j]);
@@ -128,10 +140,35 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) sN += rp[w * NS + (BWD ? 2 : 0)];
             scale = 1.0 / sN;
+            if (CLAMP && cm == 3) {                                   // (max - x) / (n max - sum x), transitionModels.py:465-466
+                double mx = -1.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) mx = fmax(mx, rp[w * NS + 5]);
+                ne_max = mx;
+                ne_inv = 1.0 / ((double)n * mx - sN);
+            }
+            if (CLAMP && BWD) {                                       // (blk::step_kernel: "RegimeSwitch clamps F(beta_norm * L)")
+                double sb = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sb += rp[w * NS + 4];
+                kappa = sb * scale;
+                scale = 1.0 / sb;
+            }
         }
         // (block-uniform: a barrier only where something was staged -- all reads of the buffer this step overwrites ended before the
         //  previous step's last barrier)
         if (staged) __syncthreads();
+        if (CLAMP && (cm == 1 || cm == 3)) {
+            // a clamp on the step's SOURCE: the whole buffer, mirror image included (the mirror of the clamped row is the clamped mirror)
+            for (int e = tid; e < W; e += NT) {
+                double v = cur[e];
+                v = cm == 1 ? v * scale : (ne_max - v) * ne_inv;
+                cur[e] = v < lim ? lim : v;
+            }
+            scale = 1.0;
+            if (cm == 3) kappa = 1.0;                                 // (NotEqual is scale-invariant in its input)
+            __syncthreads();
+        }
         if (shift) {
             // the halo of a shifted row follows SciPy's extension, not the mirror image put() leaves there (sources: cells of the row)
             for (int h = tid; h < 2 * lw; h += NT) {
@@ -150,22 +187,30 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         Q.rec = P.rec + (long long)t * P.rec_len;
         Q.lik = P.lik ? P.lik + (long long)t * n : nullptr;
         double *row = post ? post + (long long)t * n : nullptr;
-        double aN = 0.0, aS = 0.0, aC = 0.0, aM = 0.0, aU = 0.0;
+        double aN = 0.0, aS = 0.0, aC = 0.0, aM = 0.0, aU = 0.0, aX = 0.0;
         // the epilogue of one cell: o = the transition's output (scaled)
         auto finish = [&](int j, int q, double o) {
             const double g1 = g1s[j];
             const double L = blk::likelihood<OM>(Q, 0, j, OM == blk::OM_POISSON ? cAs[j] : 0.0, 0.0, g1);
+            if (CLAMP) {
+                if (cm == 2) o = o < lim ? lim : o;      // RegimeSwitch after the stencil
+                // mass of the clamped distribution (the reference renormalises by it, transitionModels.py:410); steps with a shift add theirs below
+                if (cm != 6) aU += (cm == 1 || cm == 3) ? cur[slot(LW + j)] : o;
+                o *= kappa;                              // backward: beta_used
+            }
             if (!BWD) {
                 const double a = o * L;
                 put(nxt, j, a);
                 if (P.store) row[j] = a;
                 aN += a;
+                if (CLAMP) aX = fmax(aX, a);
                 if (P.means) aM = fma(a, g1, aM);
             } else {
                 const double cn = o * L, p = al[q] * o;
                 put(nxt, j, cn);
                 row[j] = p;
                 aN += p; aS += p / L; aC += cn;          // 0/0 -> NaN as numpy (core.py:463)
+                if (CLAMP) aX = fmax(aX, cn);
                 aM = fma(p, g1, aM);
             }
         };
@@ -241,7 +286,11 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
         if (BWD) { aS = blk::wave_sum(aS); aC = blk::wave_sum(aC); }
         if (BWD || P.means) aM = blk::wave_sum(aM);
         if (SHIFT) aU = blk::wave_sum(aU);
-        if (lane == 0) { rk[wv * NS + 0] = aN; rk[wv * NS + 1] = aS; rk[wv * NS + 2] = aC; rk[wv * NS + 3] = aM; if (SHIFT) rk[wv * NS + 4] = aU; }
+        if (CLAMP) {
+            aU *= kappa;                                  // (backward: sum of beta_used, what the next step normalises by)
+            for (int off = 32; off >= 1; off >>= 1) aX = fmax(aX, __shfl_xor(aX, off));
+        }
+        if (lane == 0) { rk[wv * NS + 0] = aN; rk[wv * NS + 1] = aS; rk[wv * NS + 2] = aC; rk[wv * NS + 3] = aM; if (SHIFT) rk[wv * NS + 4] = aU; if (CLAMP) rk[wv * NS + 5] = aX; }
         __syncthreads();                              // `nxt` and the sums are complete
         if (tid < 4 && (tid == 0 || BWD || (tid == 3 && P.means))) {
             double tot = 0.0;
@@ -254,6 +303,12 @@ __global__ __launch_bounds__(NT) void chain1d_kernel(const bl1f::F1Params P) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += rk[w * NS + 4];
             P.psum[(tb * NRED + (BWD ? 5 : 1)) * P.nblk] = tot;
+        }
+        if (CLAMP && tid == 5) {                      // the maximum of the new state (NotEqual inverts around it; carried states)
+            double mx = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mx = fmax(mx, rk[w * NS + 5]);
+            P.psum[(tb * NRED + 6) * P.nblk] = mx;
         }
         double *tmp = cur; cur = nxt; nxt = tmp;
     }

@@ -41,6 +41,8 @@ struct F1Params {
     // chain-resident kernel with spline shifts (blhip_chain1d.hpp, SHIFT): clamp mode of every step (6 = Deterministic's shift) and the
     // layout marks of the tap sets (-1: all 2 lw + 1 weights, -2: two-stage form)
     const unsigned char *cmode; const int *tap_lw2;
+    const double *limit;                           // ... CL = 2 (programs with RegimeSwitch / NotEqual clamps): [T][B] the clamp level of every step
+    int no_shift;                                  // ... and none of its steps is a Deterministic shift: long rows may take two cells per thread (M = 2)
 };
 
 // One step over the cells of a block's window that are still exact after it (lo .. hi - 1): stencil out of LDS, likelihood, new state

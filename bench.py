@@ -380,7 +380,7 @@ def kernel_direction(name):
             return 'backward' if targ('chain_kernel<', 2) in ('true', '1') else 'forward'
         if 'fused1d_kernel<' in name:
             return 'backward' if targ('fused1d_kernel<', -1) in ('true', '1') else 'forward'
-        if 'chain1d_kernel<' in name or 'persist1d_kernel<' in name:      # bl1c::chain1d_kernel<OM, BWD, M, SHIFT>, bl1p::persist1d_kernel<OM, BWD>
+        if 'chain1d_kernel<' in name or 'persist1d_kernel<' in name:      # bl1c::chain1d_kernel<OM, BWD, M, CL>, bl1p::persist1d_kernel<OM, BWD>
             tag = 'chain1d_kernel<' if 'chain1d_kernel<' in name else 'persist1d_kernel<'
             return 'backward' if targ(tag, 1) in ('true', '1') else 'forward'
         if 'step_kernel<' in name:                     # <OM, MODE, ...>: MODE 0 = forward

@@ -272,7 +272,8 @@ def test_launch_per_step_2d_kernel_instantiations(model, r0, h):
 
 
 # ---- the generic LDS-tile kernel (blhip_kernels.hpp; selector: launch_step): observation model x {forward, forward with the means of a forward-only
-#      fit, backward}; it runs what no other kernel takes -- here a RegimeSwitch clamp (transitionModels.py:394-415) ----------------------------------------
+#      fit, backward}; it runs what no other kernel takes -- here the dense zero-boundary kernel of an AlphaStableRandomWalk (transitionModels.py:158-260)
+#      on 1-D grids and a RegimeSwitch clamp (:394-415) on a 2-D one ------------------------------------------------------------------------------------
 
 GENERIC = {
     1: dict(om=('Poisson', [('rate', ('oint', 0, 6, 60))], 'default'), data=('coal', 9), target='rate'),
@@ -286,12 +287,72 @@ GENERIC = {
 @pytest.mark.parametrize('kind', ['full', 'forward'])
 def test_generic_step_kernel_instantiations(om, kind):
     g = GENERIC[om]
-    c = dict(study='Study', data=g['data'], om=g['om'], tm=('Combined', [('GRW', 's', 0.3, g['target'], None), ('RS', 'log10pMin', -7, None)]))
+    if om == 2:
+        tm, tol = ('Combined', [('GRW', 's', 0.3, g['target'], None), ('RS', 'log10pMin', -7, None)]), None
+    else:
+        tm, tol = ('AlphaStable', 'c', 0.2, 'alpha', 1.5, g['target']), dict(cases.FFT_TOL)
+    c = dict(study='Study', data=g['data'], om=g['om'], tm=tm)
     k = 'blk::step_kernel<%d, %%d, %%s>' % om
     if kind == 'forward':
-        run(dict(c, fit=dict(forwardOnly=True)), [k % (0, 'true')])
+        run(dict(c, fit=dict(forwardOnly=True)), [k % (0, 'true')], tol=tol)
     else:
-        run(c, [k % (0, 'false'), k % (1, 'true')])
+        run(c, [k % (0, 'false'), k % (1, 'true')], tol=tol)
+
+
+# ---- clamps on 1-D grids inside the chain-resident kernel (blhip_chain1d.hpp CL = 2; selector: plan_geometry shift1d / clamp1d): RegimeSwitch in
+#      front of and behind a walk (clamp modes 1 / 2), NotEqual (mode 3), one chain and a batch, every observation-model flavour of the kernel ----------
+
+CLAMP1D = {
+    1: dict(om=('Poisson', [('rate', ('oint', 0, 6, 70))], 'default'), data=('coal', 12), target='rate', s=0.25),
+    3: dict(om=('GaussianMean', [('mean', ('cint', -4, 4, 90))], 'default'), data=('gm', 9721, 9), target='mean', s=0.3),
+    100: dict(om=('Bernoulli', [('p', ('oint', 0, 1, 50))], 'default'), data=np.array([1, 0, 1, 1, 0, 1, 1, 1, 0], dtype=float), target='p', s=0.05),
+}
+CLAMP_MODELS = {
+    'walk_then_switch': lambda g: ('Combined', [('GRW', 's', g['s'], g['target'], None), ('RS', 'log10pMin', -5, None)]),      # clamp after the stencil
+    'switch_then_walk': lambda g: ('Combined', [('RS', 'log10pMin', -5, None), ('GRW', 's', g['s'], g['target'], None)]),      # clamp on the source
+    'switch_alone': lambda g: ('RS', 'log10pMin', -4, None),
+    'not_equal': lambda g: ('NE', 'log10pMin', -6, None),
+}
+
+
+@pytest.mark.parametrize('model', sorted(CLAMP_MODELS))
+@pytest.mark.parametrize('om', sorted(CLAMP1D))
+def test_clamps_inside_the_one_dimensional_chain_resident_kernel(om, model):
+    g = CLAMP1D[om]
+    k = 'bl1c::chain1d_kernel<%d, %%s, 1, 2>' % om
+    c = dict(study='Study', data=g['data'], om=g['om'], tm=CLAMP_MODELS[model](g))
+    S = run(c, [k % 'false', k % 'true'])
+    assert S.lastTiming['fwd_kernel_variant'] == 9 and S.lastTiming['bwd_kernel_variant'] == 9, S.lastTiming
+    run(dict(c, fit=dict(forwardOnly=True)), [k % 'false'])
+
+
+CLAMP1D_LONG = {      # rows longer than a block: two adjacent cells per thread (M = 2), even and odd lengths
+    1: dict(om=('Poisson', [('rate', ('oint', 0, 6, 701))], 'default'), data=('coal', 10), target='rate', s=0.12),
+    3: dict(om=('GaussianMean', [('mean', ('cint', -4, 4, 600))], 'default'), data=('gm', 9731, 8), target='mean', s=0.2),
+    100: dict(om=('Bernoulli', [('p', ('oint', 0, 1, 1023))], 'default'), data=np.array([1, 0, 1, 1, 0, 1, 1], dtype=float), target='p', s=0.02),
+}
+
+
+@pytest.mark.parametrize('model', ['walk_then_switch', 'switch_then_walk', 'not_equal'])
+@pytest.mark.parametrize('om', sorted(CLAMP1D_LONG))
+def test_clamps_on_long_rows_two_cells_per_thread(om, model):
+    g = CLAMP1D_LONG[om]
+    k = 'bl1c::chain1d_kernel<%d, %%s, 2, 2>' % om
+    run(dict(study='Study', data=g['data'], om=g['om'], tm=CLAMP_MODELS[model](g)), [k % 'false', k % 'true'])
+
+
+def test_clamped_batches_on_the_one_dimensional_chain_resident_kernel():
+    """Hyper-studies over the clamp level and the walk's width: a batch of chains (five and more share one likelihood table: the kernel's
+    tabulated flavour), evidence-only too."""
+    g = CLAMP1D[1]
+    k = 'bl1c::chain1d_kernel<100, %s, 1, 2>'
+    c = dict(study='HyperStudy', data=('coal', 20), om=g['om'],
+             tm=('Combined', [('GRW', 's', ('cint', 0.1, 0.5, 3), 'rate', None), ('RS', 'log10pMin', [-7, -4], None)]))
+    S = run(c, [k % 'false', k % 'true'])
+    assert S.lastTiming['fwd_kernel_variant'] == 9 and S.lastTiming['bwd_kernel_variant'] == 9, S.lastTiming
+    run(dict(c, fit=dict(evidenceOnly=True)), [k % 'false'])
+    c = dict(study='HyperStudy', data=('coal', 16), om=g['om'], tm=('NE', 'log10pMin', ('cint', -7, -3, 5), None))
+    run(c, [k % 'false', k % 'true'])
 
 
 # ---- 1-D batches (blhip_chain1d.hpp; selector: plan_geometry chain1d, launch_chain1d): the shared likelihood table of a GaussianMean batch, and
@@ -301,11 +362,11 @@ def test_one_dimensional_gaussian_mean_batches():
     om = ('GaussianMean', [('mean', ('cint', -4, 4, 300))], 'default')
     # five widths: the batch shares ONE (T, n) likelihood table, built by lik1d_table_kernel<GaussianMean>
     run(dict(study='HyperStudy', data=('gm', 9711, 12), om=om, tm=('GRW', 'sigma', ('cint', 0.05, 0.4, 5), 'mean', None)),
-        ['bl1c::lik1d_table_kernel<3>', 'bl1c::chain1d_kernel<100, false, 1, false>', 'bl1c::chain1d_kernel<100, true, 1, false>'])
+        ['bl1c::lik1d_table_kernel<3>', 'bl1c::chain1d_kernel<100, false, 1, 0>', 'bl1c::chain1d_kernel<100, true, 1, 0>'])
     # two chains with a drift (a break point at two candidate positions): spline shifts, the likelihood evaluated in the kernel
     run(dict(study='ChangepointStudy', data=('gm', 9712, 10), om=om,
              tm=('Serial', [('Static',), ('BreakPoint', 't_break', [3, 6], None), ('Deterministic', 'drift', 'mean')])),
-        ['bl1c::chain1d_kernel<3, false, 1, true>', 'bl1c::chain1d_kernel<3, true, 1, true>'], tol=dict(cases.FFT_TOL))
+        ['bl1c::chain1d_kernel<3, false, 1, 1>', 'bl1c::chain1d_kernel<3, true, 1, 1>'], tol=dict(cases.FFT_TOL))
 
 
 def test_bandwidth_probe_kernels():
