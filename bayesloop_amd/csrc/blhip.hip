@@ -48,1861 +48,10 @@ using namespace blk;
 
 namespace {
 
-struct TapTable {
-    std::vector<double> w;       // concatenated half kernels: w[off + k], k = 0..lw
-    std::vector<int> off, lw, lw2;   // lw2: axis-1 radius of a dense 2-D kernel (0 for 1-D tap sets)
-    std::map<std::pair<int, double>, int> index;   // (internal axis, normed sigma) -> id
-    std::map<std::tuple<double, double, double>, int> index2;   // dense kernels: (ns1, ns2, rho) -> id
-
-    // Deterministic (transitionModels.py:581, :600): scipy.ndimage.shift(order=3, mode='nearest') by d grid cells = stencil
-    // out[i] = sum_m K[m] ext[i + m], K[m] = eta(-d - m) with the cardinal cubic spline eta(u) = sum_n sqrt(3) pole^|n| beta3(u - n)
-    // (prefilter impulse response x B-spline), |m| <= ceil|d| + 34, over the extension blk::extend_index(rule 2) builds.
-    // Exact for |d| <= 12 (beyond, SciPy extends the COEFFICIENTS by their edge values: oracle/bl_oracle.py).  Stored with all
-    // 2 lw + 1 weights; lw2 = -1 marks the asymmetric layout.
-    struct PairHash { size_t operator()(const std::pair<int, double> &k) const { unsigned long long b; std::memcpy(&b, &k.second, 8); return (size_t)((b * 0x9E3779B97F4A7C15ull) >> 7) ^ (size_t)k.first; } };
-    struct DblHash { size_t operator()(double d) const { unsigned long long b; std::memcpy(&b, &d, 8); return (size_t)((b * 0x9E3779B97F4A7C15ull) >> 7); } };
-    std::unordered_map<std::pair<int, double>, int, PairHash> index_shift;      // (looked up once per step and chain inside a Deterministic segment)
-    int get_shift(int axis, double d) {
-        auto key = std::make_pair(axis, d);
-        auto it = index_shift.find(key);
-        if (it != index_shift.end()) return it->second;
-        const double pole = std::sqrt(3.0) - 2.0, gain = -6.0 * pole / (1.0 - pole * pole);
-        const int r = (int)std::ceil(std::fabs(d)) + 34;
-        const int id = (int)off.size();
-        off.push_back((int)w.size());
-        lw.push_back(r);
-        lw2.push_back(-1);
-        for (int m = -r; m <= r; ++m) {
-            const double u = -d - (double)m, n0 = std::floor(u);
-            double eta = 0.0;
-            for (int k = -1; k <= 2; ++k) {
-                const double n = n0 + k, a = std::fabs(u - n);
-                const double b3 = a < 1.0 ? 2.0 / 3.0 - a * a + a * a * a / 2.0 : (a < 2.0 ? (2.0 - a) * (2.0 - a) * (2.0 - a) / 6.0 : 0.0);
-                eta += gain * std::pow(pole, std::fabs(n)) * b3;
-            }
-            w.push_back(eta);
-        }
-        index_shift[key] = id;
-        return id;
-    }
-
-    // The same shift for |d| > 12 grid cells per step (1-D grids; the reference's published break-point study shifts by up to 334 cells
-    // per step: docs/source/tutorials/changepointstudy.ipynb).  Beyond its 12 pre-padded samples SciPy extends the spline COEFFICIENTS by
-    // their edge values, which no shift-invariant stencil reproduces: the step kernel then works in the two stages of
-    // oracle/bl_oracle.py: spline_shift_nearest -- prefilter the padded row (symmetric, radius 34, weights below), then evaluate the cubic
-    // B-spline at the shifted coordinates with the coefficient index clamped.  Stored as [d, g(0) .. g(34)]; lw = 12 + 34 is the halo the
-    // row needs, lw2 = -2 marks the layout.
-    std::unordered_map<double, int, DblHash> index_bigshift;
-    int get_bigshift(double d) {
-        auto it = index_bigshift.find(d);
-        if (it != index_bigshift.end()) return it->second;
-        const double pole = std::sqrt(3.0) - 2.0, gain = -6.0 * pole / (1.0 - pole * pole);
-        const int id = (int)off.size();
-        off.push_back((int)w.size());
-        lw.push_back(12 + 34);
-        lw2.push_back(-2);
-        w.push_back(d);
-        for (int m = 0; m <= 34; ++m) w.push_back(gain * std::pow(pole, (double)m));
-        index_bigshift[d] = id;
-        return id;
-    }
-
-    // AlphaStableRandomWalk.createKernel (transitionModels.py:196-240) for an axis of n points: k[d], d = 0 .. n-1, of the
-    // inverse real DFT (numpy.fft.irfft) of exp(-|c w|^alpha) sampled at m = int(3n/2 + 1) points of [0, pi]; the reference's
-    // roll + 3x zero padding + fftconvolve(mode='same') (:233-260) is out[i] = sum_j in[j] k[|i - j|] inside the grid
-    std::map<std::tuple<int, double, double, int>, int> index_as;
-    int get_alphastable(int axis, double c, double alpha, int n) {
-        auto key = std::make_tuple(axis, c, alpha, n);
-        auto it = index_as.find(key);
-        if (it != index_as.end()) return it->second;
-        const int m = (int)(3.0 * n / 2.0 + 1.0), K = 2 * (m - 1);
-        std::vector<double> X(m);
-        for (int q = 0; q < m; ++q) X[q] = std::exp(-std::pow(std::fabs(c * (M_PI * q / (m - 1))), alpha));
-        const int id = (int)off.size();
-        off.push_back((int)w.size());
-        lw.push_back(n - 1);
-        lw2.push_back(0);
-        for (int j = 0; j < n; ++j) {
-            long double acc = X[0] + ((j & 1) ? -X[m - 1] : X[m - 1]);
-            for (int q = 1; q < m - 1; ++q)
-                acc += 2.0L * X[q] * std::cos(2.0L * (long double)M_PIl * (long double)(((long long)j * q) % K) / (long double)K);
-            w.push_back((double)(acc / K));
-        }
-        index_as[key] = id;
-        return id;
-    }
-
-    // BivariateRandomWalk.createKernel (transitionModels.py:898-911): bivariate normal density on the integer lattice
-    // |x| <= 3 ceil(ns1), |y| <= 3 ceil(ns2), normalised to sum 1 (the density's own constant cancels); row-major
-    int get2d(double ns1, double ns2, double rho) {
-        auto key = std::make_tuple(ns1, ns2, rho);
-        auto it = index2.find(key);
-        if (it != index2.end()) return it->second;
-        const int r0 = 3 * (int)std::ceil(ns1), r1 = 3 * (int)std::ceil(ns2);
-        std::vector<double> k((size_t)(2 * r0 + 1) * (2 * r1 + 1));
-        double sum = 0.0;
-        for (int a = -r0; a <= r0; ++a)
-            for (int b = -r1; b <= r1; ++b) {
-                const double x = a, y = b;
-                const double q = (x * x / (ns1 * ns1) - 2.0 * rho * x * y / (ns1 * ns2) + y * y / (ns2 * ns2)) / (2.0 * (1.0 - rho * rho));
-                const double v = std::exp(-q);
-                k[(size_t)(a + r0) * (2 * r1 + 1) + (b + r1)] = v;
-                sum += v;
-            }
-        const int id = (int)off.size();
-        off.push_back((int)w.size());
-        lw.push_back(r0);
-        lw2.push_back(r1);
-        for (double v : k) w.push_back(v / sum);
-        index2[key] = id;
-        return id;
-    }
-
-    // SciPy's kernel: lw = int(4 sd + 0.5); phi = exp(-0.5/sd^2 x^2); phi / sum(phi)   (_filters.py, gaussian_filter1d)
-    int get(int axis, double ns) {
-        auto key = std::make_pair(axis, ns);
-        auto it = index.find(key);
-        if (it != index.end()) return it->second;
-        const int r = (int)(4.0 * ns + 0.5);
-        int id = -1;
-        if (r > 0) {
-            std::vector<double> phi(2 * r + 1);
-            const double s2 = ns * ns;
-            double sum = 0.0;
-            for (int k = -r; k <= r; ++k) {
-                phi[k + r] = std::exp(-0.5 / s2 * (double)(k * k));
-                sum += phi[k + r];
-            }
-            id = (int)off.size();
-            off.push_back((int)w.size());
-            lw.push_back(r);
-            lw2.push_back(0);
-            for (int k = 0; k <= r; ++k) w.push_back(phi[r + k] / sum);
-        }
-        index[key] = id;
-        return id;
-    }
-};
-
-struct Geometry {
-    int n0, n1;          // internal rows / cols
-    int axis_map[2];     // ABI parameter index -> internal axis
-    long long G;
-};
-
-struct Tile {
-    int TI, TJ, LW0, LW1, tiles_i, tiles_j, nblk;
-    size_t lds_bytes;
-};
-
-size_t lds_need(int TI, int TJ, int LW0, int LW1) {
-    const size_t pitch = (size_t)TJ + 2 * LW1;
-    return ((size_t)(TI + 2 * LW0) * pitch + (size_t)TI * pitch + 32) * sizeof(double);
-}
-
-Tile choose_tile(const blhip_ctx *ctx, const Geometry &g, int LW0, int LW1, bool whole_row = false) {
-    Tile t{};
-    size_t cap = (size_t)64 * 1024;
-    int TI, TJ;
-    if (g.n0 == 1 && whole_row) {                // (a two-stage spline shift: one block per chain holds the whole row)
-        TI = 1;
-        TJ = g.n1;
-        cap = 160 * 1024 - 512;
-    } else if (g.n0 == 1) {
-        TI = 1;
-        TJ = g.n1 <= 65536 ? 256 : 1024;
-    } else {
-        TI = 16;
-        TJ = 128;
-    }
-    TI = std::max(1, std::min(TI, g.n0));
-    TJ = std::max(1, std::min(TJ, g.n1));
-    while (lds_need(TI, TJ, LW0, LW1) > cap) {
-        if (TI > 4 && (TI >= TJ / 4 || TJ <= 32)) TI = (TI + 1) / 2;
-        else if (TJ > 16) TJ = (TJ + 1) / 2;
-        else if (TI > 1) TI = (TI + 1) / 2;
-        else break;
-    }
-    if (lds_need(TI, TJ, LW0, LW1) > 160 * 1024 - 512)
-        fail("filter radius (%d, %d) too large for the fused step kernel (needs %zu B of LDS)", LW0, LW1,
-             lds_need(TI, TJ, LW0, LW1));
-    t.TI = TI; t.TJ = TJ; t.LW0 = LW0; t.LW1 = LW1;
-    t.tiles_i = (g.n0 + TI - 1) / TI;
-    t.tiles_j = (g.n1 + TJ - 1) / TJ;
-    t.nblk = t.tiles_i * t.tiles_j;
-    t.lds_bytes = lds_need(TI, TJ, LW0, LW1);
-    return t;
-}
-
-template <int OM, int MODE, bool MEANS>
-void launch_step_t(hipStream_t s, const StepParams &P, const Tile &t, int B) {
-    arm_kernel(reinterpret_cast<const void *>(&step_kernel<OM, MODE, MEANS>));
-    BL_LAUNCH((step_kernel<OM, MODE, MEANS>), dim3(t.nblk, B), dim3(NTHREADS), t.lds_bytes, s, P);
-}
-
-template <int OM>
-void launch_step_om(hipStream_t s, const StepParams &P, const Tile &t, int B, int mode, bool means) {
-    if (mode == MODE_FWD) {
-        if (means) launch_step_t<OM, MODE_FWD, true>(s, P, t, B);
-        else launch_step_t<OM, MODE_FWD, false>(s, P, t, B);
-    } else if (mode == MODE_BWD) {
-        launch_step_t<OM, MODE_BWD, true>(s, P, t, B);
-    } else {
-        // (blk::MODE_FILTER -- the transition alone -- has no caller: the models' plug-in calls run a resumed forward step with a flat
-        //  likelihood; its four instantiations were pruned in round 6)
-        fail("internal: generic step kernel launched in mode %d", mode);
-    }
-}
-
-void launch_step(hipStream_t s, int om, const StepParams &P, const Tile &t, int B, int mode, bool means) {
-    switch (om) {
-        case BLHIP_OM_POISSON: launch_step_om<OM_POISSON>(s, P, t, B, mode, means); break;
-        case BLHIP_OM_GAUSSIAN: launch_step_om<OM_GAUSSIAN>(s, P, t, B, mode, means); break;
-        case BLHIP_OM_GAUSSIAN_MEAN: launch_step_om<OM_GAUSSIAN_MEAN>(s, P, t, B, mode, means); break;
-        case BLHIP_OM_TABLE: launch_step_om<OM_TABLE>(s, P, t, B, mode, means); break;
-        default: fail("unknown observation model %d", om);
-    }
-    HIPCHECK(hipGetLastError());
-}
-
-
-// ---- fast path (blhip_fast.hpp): 2-D grids, axis-0 radius <= 40, axis-1 radius <= 8 -------------------------------
-constexpr int FAST_R0_MAX = 40;
-
-template <int OM, int MODE, int R0>
-void launch_fast_r(hipStream_t s, const blf::FastParams &P, bool H, int nchains) {
-    constexpr bool G = OM == OM_GAUSSIAN;
-    const dim3 grid(P.fnblk, nchains), block(NTHREADS);
-    if (G && P.use_rec) {
-        if (H) BL_LAUNCH((blf::fast_step_kernel<OM, MODE, R0, true, G>), grid, block, 0, s, P);
-        else BL_LAUNCH((blf::fast_step_kernel<OM, MODE, R0, false, G>), grid, block, 0, s, P);
-    } else {
-        if (H) BL_LAUNCH((blf::fast_step_kernel<OM, MODE, R0, true, false>), grid, block, 0, s, P);
-        else BL_LAUNCH((blf::fast_step_kernel<OM, MODE, R0, false, false>), grid, block, 0, s, P);
-    }
-}
-
-template <int OM, int MODE>
-void launch_fast_om(hipStream_t s, const blf::FastParams &P, int R0, bool H, int nchains) {
-    switch (R0) {
-        case 0: launch_fast_r<OM, MODE, 0>(s, P, H, nchains); break;
-        case 8: launch_fast_r<OM, MODE, 8>(s, P, H, nchains); break;
-        case 16: launch_fast_r<OM, MODE, 16>(s, P, H, nchains); break;
-        case 24: launch_fast_r<OM, MODE, 24>(s, P, H, nchains); break;
-        case 32: launch_fast_r<OM, MODE, 32>(s, P, H, nchains); break;
-        case 40: launch_fast_r<OM, MODE, 40>(s, P, H, nchains); break;
-        default: fail("fast path: bad radius bucket %d", R0);
-    }
-}
-
-// ---- matrix-pipe path (blhip_mfma.hpp): stencils as banded products on v_mfma_f64_16x16x4, K = 16 + 2*R0 = 4*NK ----------
-template <int OM, int MODE, int NK, bool H>
-void launch_mfma_k(hipStream_t s, const blf::FastParams &P, int nchains) {
-    const dim3 grid(P.mnblk, nchains), block(H ? blm::NT_H : blm::NT_V);
-    constexpr bool G = OM == OM_GAUSSIAN;
-    if constexpr (!H) {
-        if (P.mlean) {     // whole tile groups inside the grid, 32-bit offsets (blhip_mfma.hpp: LEAN)
-            if (G && P.use_rec) BL_LAUNCH((blm::mfma_step_kernel<OM, MODE, NK, G, false, true>), grid, block, 0, s, P);
-            else BL_LAUNCH((blm::mfma_step_kernel<OM, MODE, NK, false, false, true>), grid, block, 0, s, P);
-            return;
-        }
-    }
-    if (G && P.use_rec) BL_LAUNCH((blm::mfma_step_kernel<OM, MODE, NK, G, H, false>), grid, block, 0, s, P);
-    else BL_LAUNCH((blm::mfma_step_kernel<OM, MODE, NK, false, H, false>), grid, block, 0, s, P);
-}
-
-template <int OM, int MODE>
-void launch_mfma_om(hipStream_t s, const blf::FastParams &P, int R0, bool H, int nchains) {
-    if (H) {
-        switch (R0) {
-            case 0: launch_mfma_k<OM, MODE, 4, true>(s, P, nchains); break;
-            case 8: launch_mfma_k<OM, MODE, 8, true>(s, P, nchains); break;
-            case 16: launch_mfma_k<OM, MODE, 12, true>(s, P, nchains); break;
-            case 24: launch_mfma_k<OM, MODE, 16, true>(s, P, nchains); break;
-            case 32: launch_mfma_k<OM, MODE, 20, true>(s, P, nchains); break;
-            case 40: launch_mfma_k<OM, MODE, 24, true>(s, P, nchains); break;
-            default: fail("mfma path: bad radius bucket %d", R0);
-        }
-    } else {
-        switch (R0) {
-            case 8: launch_mfma_k<OM, MODE, 8, false>(s, P, nchains); break;
-            case 16: launch_mfma_k<OM, MODE, 12, false>(s, P, nchains); break;
-            case 24: launch_mfma_k<OM, MODE, 16, false>(s, P, nchains); break;
-            case 32: launch_mfma_k<OM, MODE, 20, false>(s, P, nchains); break;
-            case 40: launch_mfma_k<OM, MODE, 24, false>(s, P, nchains); break;
-            default: fail("mfma path: bad radius bucket %d", R0);
-        }
-    }
-}
-
-void launch_mfma(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, bool H, int nchains) {
-    if (om == BLHIP_OM_GAUSSIAN) {
-        if (mode == MODE_FWD) launch_mfma_om<OM_GAUSSIAN, MODE_FWD>(s, P, R0, H, nchains);
-        else launch_mfma_om<OM_GAUSSIAN, MODE_BWD>(s, P, R0, H, nchains);
-    } else {
-        if (mode == MODE_FWD) launch_mfma_om<OM_TABLE, MODE_FWD>(s, P, R0, H, nchains);
-        else launch_mfma_om<OM_TABLE, MODE_BWD>(s, P, R0, H, nchains);
-    }
-    HIPCHECK(hipGetLastError());
-}
-
-void launch_hwide(hipStream_t s, const blh::HParams &P, int nchains) {
-    const size_t lds = blh::lds_bytes(P.lwmax);
-    arm_kernel(reinterpret_cast<const void *>(&blh::hwide_kernel));
-    const dim3 grid((unsigned)(((P.n0 + blh::RB - 1) / blh::RB) * P.tiles_j), (unsigned)nchains);
-    BL_LAUNCH(blh::hwide_kernel, grid, dim3(blh::NT), lds, s, P);
-    HIPCHECK(hipGetLastError());
-}
-
-void launch_vwide(hipStream_t s, const blh::HParams &P, int nchains) {
-    const size_t lds = blh::vlds_bytes(P.lwmax);
-    arm_kernel(reinterpret_cast<const void *>(&blh::vwide_kernel));
-    const dim3 grid((unsigned)(((P.n0 + blh::RV - 1) / blh::RV) * P.tiles_j), (unsigned)nchains);
-    BL_LAUNCH(blh::vwide_kernel, grid, dim3(blh::NT), lds, s, P);
-    HIPCHECK(hipGetLastError());
-}
-
-void launch_fast(hipStream_t s, int om, int mode, const blf::FastParams &P, int R0, bool H, int nchains) {
-    if (om == BLHIP_OM_GAUSSIAN) {
-        if (mode == MODE_FWD) launch_fast_om<OM_GAUSSIAN, MODE_FWD>(s, P, R0, H, nchains);
-        else launch_fast_om<OM_GAUSSIAN, MODE_BWD>(s, P, R0, H, nchains);
-    } else {
-        if (mode == MODE_FWD) launch_fast_om<OM_TABLE, MODE_FWD>(s, P, R0, H, nchains);
-        else launch_fast_om<OM_TABLE, MODE_BWD>(s, P, R0, H, nchains);
-    }
-    HIPCHECK(hipGetLastError());
-}
-
-struct FastRange { int start, count, R0; bool H; int key; bool pre; };
-
-// chains of one step ordered by (axis-0 radius bucket, axis-1 class); one launch per non-empty group.  Axis-1 classes: 0 = no filter,
-// 1 = a filter the fused kernels apply themselves (radius <= 8), 2 = (h_fused_max >= 0 only) one wider than h_fused_max (0: any): the group
-// runs behind the axis-1 pre-pass (FastRange::pre) and its step kernel without an axis-1 part.
-constexpr int NKEYS = 18;
-void bucket_step(const int *tap0, const int *tap1, const std::vector<int> &lw, int B, int *order, std::vector<FastRange> &ranges,
-                 int min_chains, int h_fused_max = -1) {
-    int cnt[NKEYS] = {0};
-    int promote[NKEYS];
-    for (int k = 0; k < NKEYS; ++k) promote[k] = k;
-    auto key0 = [&](int b) {
-        const int l0 = tap0[b] >= 0 ? lw[tap0[b]] : 0;
-        const int bucket = l0 == 0 ? 0 : (l0 + 7) / 8;      // 0..5
-        const int hc = tap1[b] < 0 ? 0 : ((h_fused_max >= 0 && (h_fused_max == 0 || lw[tap1[b]] > h_fused_max)) ? 2 : 1);
-        return bucket * 3 + hc;
-    };
-    auto key = [&](int b) { int k = key0(b); while (promote[k] != k) k = promote[k]; return k; };
-    for (int b = 0; b < B; ++b) cnt[key0(b)]++;
-    // a bucket with only a few chains cannot fill the chip: promote its chains to the next larger radius bucket
-    // (zero-padded weights make that exact); keys are bucket * 3 + class
-    for (int h = 0; h < 3; ++h)
-        for (int bk = 0; bk < 5; ++bk) {
-            const int k = bk * 3 + h;
-            if (cnt[k] > 0 && cnt[k] < min_chains) {
-                int up = -1;
-                for (int b2 = bk + 1; b2 < 6; ++b2) if (cnt[b2 * 3 + h] > 0) { up = b2 * 3 + h; break; }
-                if (up >= 0) { promote[k] = up; cnt[up] += cnt[k]; cnt[k] = 0; }
-            }
-        }
-    int start[NKEYS], acc = 0;
-    ranges.clear();
-    for (int k = 0; k < NKEYS; ++k) {
-        start[k] = acc;
-        if (cnt[k]) ranges.push_back(FastRange{acc, cnt[k], (k / 3) * 8, (k % 3) == 1, k, (k % 3) == 2});
-        acc += cnt[k];
-    }
-    for (int b = 0; b < B; ++b) order[start[key(b)]++] = b;
-}
-
-// ---- 1-D path, K time steps per launch (blhip_fused1d.hpp) ---------------------------------------------------------------
-template <int OM>
-void launch_fused1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
-    const dim3 grid(P.nblk, P.B), block(bl1f::NT);
-    if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, true>));
-        BL_LAUNCH((bl1f::fused1d_kernel<OM, true>), grid, block, lds, s, P);
-    } else {
-        arm_kernel(reinterpret_cast<const void *>(&bl1f::fused1d_kernel<OM, false>));
-        BL_LAUNCH((bl1f::fused1d_kernel<OM, false>), grid, block, lds, s, P);
-    }
-}
-
-void launch_fused1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, size_t lds) {
-    switch (om) {
-        case BLHIP_OM_POISSON: launch_fused1d_om<OM_POISSON>(s, P, bwd, lds); break;
-        case BLHIP_OM_GAUSSIAN_MEAN: launch_fused1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
-        case BLHIP_OM_TABLE: launch_fused1d_om<OM_TABLE>(s, P, bwd, lds); break;
-        default: fail("fused 1-D path: observation model %d", om);
-    }
-    HIPCHECK(hipGetLastError());
-}
-
-// ---- 1-D grids, batches of chains: one block per chain, all T steps in one launch (blhip_chain1d.hpp) -------------------------------
-template <int OM, int M>
-void launch_chain1d_m(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
-    if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true, M>));
-        BL_LAUNCH((bl1c::chain1d_kernel<OM, true, M>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
-    } else {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false, M>));
-        BL_LAUNCH((bl1c::chain1d_kernel<OM, false, M>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
-    }
-}
-template <int OM, int CL, int M = 1>
-void launch_chain1d_cl(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds) {
-    if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, true, M, CL>));
-        BL_LAUNCH((bl1c::chain1d_kernel<OM, true, M, CL>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
-    } else {
-        arm_kernel(reinterpret_cast<const void *>(&bl1c::chain1d_kernel<OM, false, M, CL>));
-        BL_LAUNCH((bl1c::chain1d_kernel<OM, false, M, CL>), dim3((unsigned)P.B), dim3(bl1c::NT), lds, s, P);
-    }
-}
-// programs with Deterministic steps (CL 1) / with RegimeSwitch, NotEqual clamps too (CL 2; without a Deterministic step: rows longer than a
-// block with two cells per thread, as the plain flavour)
-template <int OM>
-void launch_chain1d_shift(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds, int m) {
-    if (!P.limit) launch_chain1d_cl<OM, 1>(s, P, bwd, lds);
-    else if (m == 2 && P.no_shift) launch_chain1d_cl<OM, 2, 2>(s, P, bwd, lds);
-    else launch_chain1d_cl<OM, 2>(s, P, bwd, lds);
-}
-template <int OM>
-void launch_chain1d_om(hipStream_t s, const bl1f::F1Params &P, bool bwd, size_t lds, int m) {
-    if (P.cmode) launch_chain1d_shift<OM>(s, P, bwd, lds, m);
-    else if (m == 2) launch_chain1d_m<OM, 2>(s, P, bwd, lds);
-    else launch_chain1d_m<OM, 1>(s, P, bwd, lds);
-}
-
-// the (T, n) likelihood table every chain of a 1-D batch shares (bl1c::lik1d_table_kernel: the in-kernel function, evaluated once)
-void build_lik1d_table(hipStream_t s, int om, const bl1f::F1Params &P, double *out) {
-    const dim3 grid((unsigned)std::min(16, (P.n + 255) / 256), (unsigned)P.T);
-    if (om == BLHIP_OM_POISSON) BL_LAUNCH((bl1c::lik1d_table_kernel<OM_POISSON>), grid, dim3(256), 0, s, P, out);
-    else if (om == BLHIP_OM_GAUSSIAN_MEAN) BL_LAUNCH((bl1c::lik1d_table_kernel<OM_GAUSSIAN_MEAN>), grid, dim3(256), 0, s, P, out);
-    else fail("internal: shared 1-D likelihood table for observation model %d", om);
-    HIPCHECK(hipGetLastError());
-}
-
-// cells per thread: 2 adjacent ones (sharing their stencil operands) for rows longer than a block, else 1 (option chain1d_pair: 0 / 1 force)
-void launch_chain1d(hipStream_t s, int om, const bl1f::F1Params &P, bool bwd, int pair_mode) {
-    const size_t lds = bl1c::lds_doubles(P.n, P.LW, P.cmode != nullptr) * sizeof(double);
-    const int m = pair_mode == 0 ? 1 : ((pair_mode == 1 || P.n > bl1c::NT) ? 2 : 1);
-    switch (om) {
-        case BLHIP_OM_POISSON: launch_chain1d_om<OM_POISSON>(s, P, bwd, lds, m); break;
-        case BLHIP_OM_GAUSSIAN_MEAN: launch_chain1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds, m); break;
-        case BLHIP_OM_TABLE: launch_chain1d_om<OM_TABLE>(s, P, bwd, lds, m); break;
-        default: fail("chain-resident 1-D path: observation model %d", om);
-    }
-    HIPCHECK(hipGetLastError());
-}
-
-template <int OM>
-void launch_persist1d_om(hipStream_t s, const bl1p::P1Params &P, bool bwd, size_t lds) {
-    const dim3 grid(P.nblk, P.B), block(bl1p::NT);
-    if (bwd) {
-        arm_kernel(reinterpret_cast<const void *>(&bl1p::persist1d_kernel<OM, true>));
-        BL_LAUNCH((bl1p::persist1d_kernel<OM, true>), grid, block, lds, s, P);
-    } else {
-        arm_kernel(reinterpret_cast<const void *>(&bl1p::persist1d_kernel<OM, false>));
-        BL_LAUNCH((bl1p::persist1d_kernel<OM, false>), grid, block, lds, s, P);
-    }
-}
-
-void launch_persist1d(hipStream_t s, int om, const bl1p::P1Params &P, bool bwd, size_t lds) {
-    switch (om) {
-        case BLHIP_OM_POISSON: launch_persist1d_om<OM_POISSON>(s, P, bwd, lds); break;
-        case BLHIP_OM_GAUSSIAN_MEAN: launch_persist1d_om<OM_GAUSSIAN_MEAN>(s, P, bwd, lds); break;
-        case BLHIP_OM_TABLE: launch_persist1d_om<OM_TABLE>(s, P, bwd, lds); break;
-        default: fail("persistent 1-D path: observation model %d", om);
-    }
-    HIPCHECK(hipGetLastError());
-}
-
-// ---- time-resident path (blhip_resident.hpp): one launch for all time steps of a single-chain 2-D fit ----------------------------
-struct ResidentPlan {
-    int TR = 0, TC = 0, SEG = 0, tr = 0, tc = 0, ntiles = 0, NT = 0;
-    bool pad = false;            // the grid does not fill its last tile row / column (PAD kernels)
-    size_t lds_bytes = 0;
-};
-
-template <int TR, int TC, int SEG, int CHK, bool BWD, int MODE, bool PAD = false, bool TAB = false>
-void launch_resident_k(hipStream_t s, const blr::ResParams &Q) {
-    const size_t lds = (size_t)blr::Res<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>::LDS_DOUBLES * sizeof(double);
-    arm_kernel(reinterpret_cast<const void *>(&blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>));
-    BL_LAUNCH((blr::resident_kernel<TR, TC, SEG, CHK, BWD, MODE, PAD, TAB>), dim3(Q.ntiles), dim3(TR * TC / SEG), lds, s, Q);
-}
-
-// tabulated likelihood (blr::Res TAB; the one-chunk shapes): backward, evidence-only forward, every other forward pass (flags at run time)
-template <int TR, int TC, int SEG, int CHK>
-void launch_resident_tab(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad) {
-    const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
-    if (pad) {
-        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0, true, true>(s, Q);
-        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1, true, true>(s, Q);
-        else launch_resident_k<TR, TC, SEG, CHK, false, 0, true, true>(s, Q);
-    } else {
-        if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0, false, true>(s, Q);
-        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1, false, true>(s, Q);
-        else launch_resident_k<TR, TC, SEG, CHK, false, 0, false, true>(s, Q);
-    }
-}
-
-template <int TR, int TC, int SEG, int CHK>
-void launch_resident_t(hipStream_t s, const blr::ResParams &Q, bool bwd, bool pad = false) {
-    // forward pass of an evidence-only fit (nothing stored, no means, no rows to normalise) / of a full fit (every state stored, no
-    // means, no rows to normalise): / of a forward-only fit: the flavours with compile-time flags (blr::Res MODE 1 / 2 / 3); padded grids: flags at run time
-    const bool evid = !bwd && !Q.store && !Q.means && !Q.normalise && !Q.post;
-    const bool fullfwd = !bwd && Q.store && !Q.means && !Q.normalise && Q.post;
-    const bool fwdonly = !bwd && Q.store && Q.means && Q.normalise && Q.post;
-    if (pad) {                   // grids that do not fill their last tile row / column
-        if (bwd) {
-            // (full fits of padded 128 x 128 grids keep the launch-per-step kernels -- ResidentRun::setup: the kernel spilled 231 registers
-            //  and lost to them; it is not instantiated any more, round 6)
-            if constexpr (SEG != CHK) fail("internal: time-resident backward launch on a padded grid of 128 x 128 tiles");
-            else launch_resident_k<TR, TC, SEG, CHK, true, 0, true>(s, Q);
-        }
-        else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1, true>(s, Q);
-        else launch_resident_k<TR, TC, SEG, CHK, false, 0, true>(s, Q);
-        return;
-    }
-    if (bwd) launch_resident_k<TR, TC, SEG, CHK, true, 0>(s, Q);
-    else if (evid) launch_resident_k<TR, TC, SEG, CHK, false, 1>(s, Q);
-    else if (fullfwd) launch_resident_k<TR, TC, SEG, CHK, false, 2>(s, Q);
-    else if (fwdonly) {
-        // (the multi-chunk shape spills 48 VGPRs with the compile-time flavour, 6 without: it keeps the flags at run time)
-        if constexpr (SEG == CHK) launch_resident_k<TR, TC, SEG, CHK, false, 3>(s, Q);
-        else launch_resident_k<TR, TC, SEG, CHK, false, 0>(s, Q);
-    }
-    else fail("internal: time-resident forward launch that is neither evidence-only, nor storing, nor forward-only");      // (the run-time flavour of the one-chunk shapes had no caller: pruned in round 6)
-}
-
-// tile shapes: {rows, columns, segment length, outputs per chunk}.  One wave issues an fp64 instruction only every ~12 cycles
-// (tools/ubench/fp64_banks.hip), so more waves per SIMD help.  The 128 x 128 tile runs with 512 threads (segments of 32, chunks of 8,
-// ~200 registers, 2 waves per SIMD).  (A 1024-thread shape -- option resident_threads128 -- was never selected by a test or a workload
-// and measured no faster: pruned in round 5, profiles/r05_kernel_census.txt.)
-void launch_resident(hipStream_t s, const ResidentPlan &rp, const blr::ResParams &Q, bool bwd) {
-    if (Q.lik) {
-        if (rp.TR == 64) launch_resident_tab<64, 64, 8, 8>(s, Q, bwd, rp.pad);
-        else if (rp.TR == 32 && rp.TC == 64) launch_resident_tab<32, 64, 8, 8>(s, Q, bwd, rp.pad);
-        else if (rp.TR == 32) launch_resident_tab<32, 32, 8, 8>(s, Q, bwd, rp.pad);
-        else fail("internal: time-resident launch with a likelihood table on a %d x %d tile", rp.TR, rp.TC);
-        HIPCHECK(hipGetLastError());
-        return;
-    }
-    if (rp.TR == 128) launch_resident_t<128, 128, 32, 8>(s, Q, bwd, rp.pad);
-    else if (rp.TR == 64) launch_resident_t<64, 64, 8, 8>(s, Q, bwd, rp.pad);
-    else if (rp.TC == 64) launch_resident_t<32, 64, 8, 8>(s, Q, bwd, rp.pad);
-    else launch_resident_t<32, 32, 8, 8>(s, Q, bwd, rp.pad);
-    HIPCHECK(hipGetLastError());
-}
-
-// ---- chain-resident kernels (blhip_chainres.hpp): compiled as slices of blhip_chain_tu.hip (blhip_chain_launch.hpp) -----------------------
-void launch_chain(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad = false) {
-    if (Q.lik) {                         // tabulated likelihood (blc::chain_kernel TAB): geometries of <= 512 rows, radius <= 40
-        if (nk > 24 || ntw > 4) fail("internal: chain-resident launch with a likelihood table outside its envelope");
-        if (pad) { if (ntw >= 3) fail("internal: padded chain-resident launch with a likelihood table on %d tiles per wave", ntw); else blcl::chain_ntw12_tab_pad(s, Q, nk, ntw, bwd, store); }
-        else if (ntw >= 3) blcl::chain_ntw34_tab(s, Q, nk, ntw, bwd, store); else blcl::chain_ntw12_tab(s, Q, nk, ntw, bwd, store);
-        HIPCHECK(hipGetLastError());
-        return;
-    }
-    const bool wide = nk > 24;           // bands beyond radius 40 (NK = 26 .. 44): slices of their own
-    if (ntw == 4) {
-        if (wide) { if (bwd) blcl::chain_ntw4_bwd_wide(s, Q, nk, store, pad); else blcl::chain_ntw4_fwd_wide(s, Q, nk, store, pad); }
-        else { if (bwd) blcl::chain_ntw4_bwd(s, Q, nk, store, pad); else blcl::chain_ntw4_fwd(s, Q, nk, store, pad); }
-    } else if (ntw == 8) {               // 1024 rows: one copy of the strip in LDS (blc::chain_kernel TALL)
-        if (wide) { if (bwd) blcl::chain_ntw8_bwd_wide(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_wide(s, Q, nk, store, pad); }
-        else { if (bwd) blcl::chain_ntw8_bwd_narrow(s, Q, nk, store, pad); else blcl::chain_ntw8_fwd_narrow(s, Q, nk, store, pad); }
-    } else if (ntw == 3) {
-        if (wide) blcl::chain_ntw3_wide(s, Q, nk, bwd, store, pad); else blcl::chain_ntw3(s, Q, nk, bwd, store, pad);
-    } else if (ntw == 2 || ntw == 1) {
-        if (wide) blcl::chain_ntw12_wide(s, Q, nk, ntw, bwd, store, pad);
-        else if (ntw == 2) blcl::chain_ntw2(s, Q, nk, bwd, store, pad);
-        else blcl::chain_ntw1(s, Q, nk, bwd, store, pad);
-    } else fail("internal: chain-resident kernel with %d tiles per wave", ntw);
-    HIPCHECK(hipGetLastError());
-}
-
-// walks on both parameters (blc::chainax_kernel, blhip_chainax.hpp)
-void launch_chainax(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool bwd, bool store, bool pad) {
-    if (ntw == 4) { if (pad) blcl::chainax_ntw4_pad(s, Q, nk, bwd, store); else blcl::chainax_ntw4(s, Q, nk, bwd, store); }
-    else blcl::chainax_ntw12_pad(s, Q, nk, ntw, bwd, store);      // (these kernels take exact 128 / 256 grids too)
-    HIPCHECK(hipGetLastError());
-}
-
-// backward pass with the fused fold, two chains per block (blc::chain_fold2_kernel)
-bool fold2_shape(int ntw) { return ntw >= 1 && ntw <= 4; }
-
-void launch_fold2(hipStream_t s, const blc::ChainParams &Q, int nk, int ntw, bool pad = false) {
-    if (nk > 24) { if (ntw >= 3) blcl::fold2_ntw34_wide(s, Q, nk, ntw, pad); else blcl::fold2_ntw12_wide(s, Q, nk, ntw, pad); }
-    else if (ntw >= 3) blcl::fold2_ntw34(s, Q, nk, ntw, pad);
-    else blcl::fold2_ntw12(s, Q, nk, ntw, pad);
-    HIPCHECK(hipGetLastError());
-}
-
-// the smallest supported tile whose tile grid fits the chip (every tile = one co-resident block)
-// (Two 256-thread blocks per CU -- 512 tiles of 32 x 64 for the 1024^2 grid, so that one block computes while the other waits for a
-// strip -- was tried: the 512 blocks were not all co-resident, the hand-off waits timed out and the fit fell back.  One tile per CU.)
-// A grid that does not fill its last tile row / column runs the PAD kernels (blhip_resident.hpp): the remainder of such an axis and the
-// padding behind it must both be at least one stencil radius (the mirror image beyond the true edge lives inside the last tile and is
-// made of that tile's own cells).  Grids whose sizes are multiples of a tile shape are preferred (no masks).
-bool plan_resident(int n0, int n1, int cus, ResidentPlan &rp) {
-    constexpr int seg128 = 32, min_tile = 32;
-    constexpr bool allow_pad = true;
-    // preference: 64 x 64 tiles first (measured on 128^2 .. 512^2 grids, tools/tile_probe.py: 5.7 / 6.7 us per forward / backward step
-    // against 9.0 / 10.1 us with 32 x 32 tiles -- two waves per block are too few to hide the hand-offs -- and 10.8 / 20.8 us with 128 x 128),
-    // whole tiles before a padded last tile row / column of the same shape; 128 x 128 only when the smaller shapes need more than one tile per CU
-    const int shapes[4][3] = {{64, 64, 8}, {32, 64, 8}, {32, 32, 8}, {128, 128, seg128}};
-    for (const auto &sh : shapes)
-        for (int pass = 0; pass < (allow_pad ? 2 : 1); ++pass) {
-            auto fits = [&](int n, int t) { const int rem = n % t; return pass == 0 ? rem == 0 : (rem == 0 || (n > t && rem >= blr::R && t - rem >= blr::R)); };
-            if (sh[0] < min_tile && sh[1] < 2 * min_tile) continue;
-            if (!fits(n0, sh[0]) || !fits(n1, sh[1])) continue;
-            const int tr = (n0 + sh[0] - 1) / sh[0], tc = (n1 + sh[1] - 1) / sh[1];
-            const long long nt = (long long)tr * tc;
-            if (nt > cus) continue;
-            rp.TR = sh[0]; rp.TC = sh[1]; rp.SEG = sh[2]; rp.tr = tr; rp.tc = tc; rp.ntiles = (int)nt;
-            rp.NT = sh[0] * sh[1] / sh[2];
-            rp.pad = (n0 % sh[0]) != 0 || (n1 % sh[1]) != 0;
-            return true;
-        }
-    return false;
-}
-
-void validate(const blhip_problem *p, int64_t n_chains, const double *op_values) {
-    if (!p) fail("problem is NULL");
-    if (p->ndim < 1 || p->ndim > BLHIP_MAX_DIM) fail("ndim must be 1 .. %d (got %d)", BLHIP_MAX_DIM, p->ndim);
-    if (p->ndim > 2) {            // the plain N-D path (blhip_nd.hpp)
-        if (p->obs_model != BLHIP_OM_TABLE) fail("grids with %d parameters need a caller-evaluated likelihood table (BLHIP_OM_TABLE)", p->ndim);
-        for (int k = 0; k < p->n_ops; ++k) {
-            const blhip_op &op = p->ops[k];
-            const bool ok = op.kind == BLHIP_OP_GRW || op.kind == BLHIP_OP_STATIC || (op.kind == BLHIP_OP_CHANGEPOINT && !(op.flags & 1));
-            if (!ok || op.segment >= 0)
-                fail("grids with %d parameters support GaussianRandomWalk / Static / ChangePoint transition models (op %d has kind %d)", p->ndim, k, op.kind);
-        }
-    }
-    for (int k = 0; k < p->ndim; ++k) {
-        if (p->n[k] < 1) fail("grid size n[%d] = %lld", k, (long long)p->n[k]);
-        if (!p->marginal[k]) fail("marginal[%d] is NULL", k);
-        if (p->n[k] > (1ll << 30)) fail("grid axis too long");
-    }
-    if (p->T < 1) fail("T must be >= 1");
-    if (!p->data || !p->timestamps || !p->prior) fail("data / timestamps / prior must not be NULL");
-    if (n_chains < 1) fail("n_chains must be >= 1");
-    if (p->n_ops < 0 || (p->n_ops > 0 && !p->ops)) fail("bad transition program");
-    if (p->n_ops > 0 && !op_values) fail("op_values is NULL");
-    bool has_cp = false;
-    for (int k = 0; k < p->n_ops; ++k) {
-        const blhip_op &op = p->ops[k];
-        if (op.kind == BLHIP_OP_GRW) {
-            if (op.axis < 0 || op.axis >= p->ndim) fail("GRW op %d: axis %d out of range", k, op.axis);
-        } else if (op.kind == BLHIP_OP_CHANGEPOINT) {
-            has_cp = true;
-        } else if (op.kind == BLHIP_OP_INDEPENDENT) {
-            if (!p->indep_prior) fail("INDEPENDENT op needs indep_prior");
-        } else if (op.kind == BLHIP_OP_DETERMINISTIC) {
-            if (op.axis < 0 || op.axis >= p->ndim) fail("DETERMINISTIC op %d: axis %d out of range", k, op.axis);
-            for (int64_t q = 1; q <= 2 * p->T; ++q)
-                if (k + q >= p->n_ops || p->ops[k + q].kind != BLHIP_OP_DETERMINISTIC_ARG)
-                    fail("DETERMINISTIC op %d must be followed by 2 T = %lld DETERMINISTIC_ARG ops (the shifts per step)", k, (long long)(2 * p->T));
-        } else if (op.kind == BLHIP_OP_ALPHASTABLE) {
-            if (op.axis < 0 || op.axis >= p->ndim) fail("ALPHASTABLE op %d: axis %d out of range", k, op.axis);
-            if (k + 1 >= p->n_ops || p->ops[k + 1].kind != BLHIP_OP_ALPHASTABLE_ARG)
-                fail("ALPHASTABLE op %d must be followed by an ALPHASTABLE_ARG op (alpha)", k);
-        } else if (op.kind == BLHIP_OP_BIVARIATE) {
-            if (p->ndim != 2) fail("BIVARIATE op %d needs a 2-parameter grid", k);
-            if (k + 2 >= p->n_ops || p->ops[k + 1].kind != BLHIP_OP_BIVARIATE_ARG || p->ops[k + 2].kind != BLHIP_OP_BIVARIATE_ARG)
-                fail("BIVARIATE op %d must be followed by two BIVARIATE_ARG ops (sigma2, rho)", k);
-        } else if (op.kind != BLHIP_OP_STATIC && op.kind != BLHIP_OP_REGIMESWITCH && op.kind != BLHIP_OP_BREAKPOINT &&
-                   op.kind != BLHIP_OP_NOTEQUAL && op.kind != BLHIP_OP_BIVARIATE_ARG && op.kind != BLHIP_OP_ALPHASTABLE_ARG &&
-                   op.kind != BLHIP_OP_DETERMINISTIC_ARG) {
-            fail("op %d: unknown kind %d", k, op.kind);
-        }
-    }
-    if (has_cp && !p->reset_prior) fail("CHANGEPOINT op needs reset_prior");
-    switch (p->obs_model) {
-        case BLHIP_OM_POISSON:
-            if (p->ndim != 1) fail("Poisson model has 1 parameter");
-            if (p->seg_len != 1) fail("Poisson model has segment length 1");
-            break;
-        case BLHIP_OM_GAUSSIAN:
-            if (p->ndim != 2) fail("Gaussian model has 2 parameters");
-            if (p->seg_len != 1) fail("Gaussian model has segment length 1");
-            break;
-        case BLHIP_OM_GAUSSIAN_MEAN:
-            if (p->ndim != 1) fail("GaussianMean model has 1 parameter");
-            if (p->seg_len != 1 || p->data_dim != 2) fail("GaussianMean data must be (T, 1, 2)");
-            break;
-        case BLHIP_OM_TABLE:
-            if (!p->lik) fail("BLHIP_OM_TABLE needs lik");
-            break;
-        case BLHIP_OM_BERNOULLI: case BLHIP_OM_WHITE_NOISE:
-            if (p->ndim != 1 || p->seg_len != 1) fail("Bernoulli / white-noise models have 1 parameter and segment length 1");
-            break;
-        case BLHIP_OM_LAPLACE:
-            if (p->ndim != 2 || p->seg_len != 1) fail("Laplace model has 2 parameters and segment length 1");
-            break;
-        case BLHIP_OM_AR1: case BLHIP_OM_SCALED_AR1:
-            if (p->ndim != 2 || p->seg_len != 2) fail("AR1 models have 2 parameters and segment length 2");
-            break;
-        default: fail("unknown observation model %d", p->obs_model);
-    }
-    if (p->data_dim < 1) fail("data_dim must be >= 1");
-}
-
-// per-step records consumed by blk::likelihood<>
-void build_records(const blhip_problem *p, std::vector<double> &rec, int &rec_len, int &d) {
-    const int64_t T = p->T;
-    const int dd = p->data_dim;
-    if (p->obs_model == BLHIP_OM_GAUSSIAN) {
-        d = dd; rec_len = dd;
-        rec.assign(p->data, p->data + T * dd);
-    } else if (p->obs_model == BLHIP_OM_GAUSSIAN_MEAN) {
-        d = 1; rec_len = 3;
-        rec.resize(T * 3);
-        for (int64_t t = 0; t < T; ++t) {
-            const double x = p->data[t * 2], s = p->data[t * 2 + 1];
-            const bool miss = std::isnan(x) || std::isnan(s);
-            rec[t * 3 + 0] = miss ? std::numeric_limits<double>::quiet_NaN() : x;
-            rec[t * 3 + 1] = 1.0 / (2.0 * s * s);
-            rec[t * 3 + 2] = 0.5 * std::log(2.0 * M_PI * s * s);
-        }
-    } else if (p->obs_model == BLHIP_OM_POISSON) {
-        d = dd; rec_len = 2 * dd;
-        rec.resize(T * 2 * dd);
-        for (int64_t t = 0; t < T; ++t)
-            for (int k = 0; k < dd; ++k) {
-                const double c = p->data[t * dd + k];
-                double f = 1.0;
-                if (!std::isnan(c)) {
-                    if (c < 0 || c != std::floor(c)) fail("Poisson data must be non-negative integers (step %lld)", (long long)t);
-                    for (double q = 2.0; q <= c; q += 1.0) f *= q;
-                }
-                rec[(t * dd + k) * 2] = c;
-                rec[(t * dd + k) * 2 + 1] = f;
-            }
-    } else {
-        d = 1; rec_len = 1;
-        rec.assign(T, 0.0);
-    }
-}
-
-struct ChainProgram {
-    // per (step, chain): source kind, tap ids per internal axis, clamp mode/limit (RegimeSwitch); forward and backward
-    std::vector<unsigned char> kindF, kindB, cmodeF, cmodeB;
-    std::vector<int> tapF0, tapF1, tapB0, tapB1;
-    std::vector<double> limitF, limitB;
-    int LW0 = 0, LW1 = 0;
-    bool has_clamp = false;
-    bool whole_row = false;      // a two-stage spline shift (Deterministic, |d| > 12): a block needs the whole row of a 1-D grid
-    bool other_clamp = false;    // has_clamp for another reason than a Deterministic model's shift (mode 6)
-    bool dense_clamp = false;    // ... than a shift or the clamps of RegimeSwitch / NotEqual: AlphaStable- / BivariateRandomWalk (modes 5 / 4: zero boundary, dense kernels)
-    bool has_shift = false;      // a Deterministic model
-};
-
-struct StepProg {
-    unsigned char kind = SRC_PREV, cmode = 0;   // cmode: 0 none, 1 clamp the source (before the stencil), 2 clamp after it
-    int t0 = -1, t1 = -1;
-    double limit = 0.0;
-};
-
-void build_program(const blhip_problem *p, const Geometry &g, int64_t c0, int64_t B, const double *op_values,
-                   TapTable &taps, ChainProgram &prog, bool resume) {
-    const int64_t T = p->T;
-    const int nops = p->n_ops;
-    const size_t nT = (size_t)T * B;
-    prog.kindF.assign(nT, SRC_PREV); prog.kindB.assign(nT, SRC_PREV);
-    prog.cmodeF.assign(nT, 0); prog.cmodeB.assign(nT, 0);
-    prog.limitF.assign(nT, 0.0); prog.limitB.assign(nT, 0.0);
-    prog.tapF0.assign(nT, -1); prog.tapF1.assign(nT, -1);
-    prog.tapB0.assign(nT, -1); prog.tapB1.assign(nT, -1);
-    prog.LW0 = prog.LW1 = 0;
-    prog.has_clamp = false;
-    prog.whole_row = false;
-    prog.other_clamp = false;
-    prog.dense_clamp = false;
-    prog.has_shift = false;
-    double dV = 1.0;
-    for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
-    // the ops a step's program is made of (the *_ARG ops only carry values of the op in front of them: a Deterministic model has 2 T of
-    // them, and the per-(step, chain) walk below would spend its time skipping them -- 23 400 chains x 41 steps x 2 x 87 ops measured)
-    std::vector<int> real_ops;
-    for (int k = 0; k < nops; ++k) {
-        const int kind = p->ops[k].kind;
-        if (kind != BLHIP_OP_DETERMINISTIC_ARG && kind != BLHIP_OP_BIVARIATE_ARG && kind != BLHIP_OP_ALPHASTABLE_ARG) real_ops.push_back(k);
-    }
-    // (a chain's T steps are T entries B apart in each of the ten arrays: written chain by chain that is one cache line per entry --
-    //  half of the 30 ms this function took for the 23 400 chains x 41 steps of the published break-point study.  The steps of GROUP
-    //  chains are collected first and written out as runs of GROUP consecutive entries)
-    // (no more entries than the batch has chains: constructing 64 x T records for the ONE chain of a long single-chain fit -- C2: T = 10 000,
-    //  2 x 15 MB -- was 8 ms of its 43-ms fit)
-    constexpr int GROUP = 64;
-    const size_t group_rows = (size_t)std::min<int64_t>(GROUP, std::max<int64_t>(B, 1));
-    std::vector<StepProg> gF(group_rows * T), gB(group_rows * T);
-    auto flush_group = [&](int64_t b0, int64_t nb) {
-        for (int64_t t = 0; t < T; ++t) {
-            const size_t k0 = (size_t)t * B + b0;
-            for (int64_t q = 0; q < nb; ++q) {
-                const StepProg &f = gF[(size_t)q * T + t], &r = gB[(size_t)q * T + t];
-                prog.kindF[k0 + q] = f.kind; prog.tapF0[k0 + q] = f.t0; prog.tapF1[k0 + q] = f.t1; prog.cmodeF[k0 + q] = f.cmode; prog.limitF[k0 + q] = f.limit;
-                prog.kindB[k0 + q] = r.kind; prog.tapB0[k0 + q] = r.t0; prog.tapB1[k0 + q] = r.t1; prog.cmodeB[k0 + q] = r.cmode; prog.limitB[k0 + q] = r.limit;
-            }
-        }
-    };
-    std::vector<int> op_tap(nops, -1), op_axis(nops, -1);
-    // (see `at` below) the ops that bound segments or fire at a time stamp; per chain: the program of each segment, walked once
-    std::vector<int> bound_ops;
-    for (int k : real_ops)
-        if (p->ops[k].kind == BLHIP_OP_BREAKPOINT || p->ops[k].kind == BLHIP_OP_CHANGEPOINT) bound_ops.push_back(k);
-    std::vector<StepProg> seg_prog(bound_ops.size() + 1);
-    std::vector<char> seg_cached(bound_ops.size() + 1, 0), det_in_seg(bound_ops.size() + 1, 0);
-    for (int64_t b = 0; b < B; ++b) {
-        const double *val = op_values ? op_values + (c0 + b) * nops : nullptr;
-        // tap ids of this chain's GRW ops
-        std::fill(op_tap.begin(), op_tap.end(), -1); std::fill(op_axis.begin(), op_axis.end(), -1);
-        bool time_dependent = false;
-        for (int k = 0; k < nops; ++k) {
-            const blhip_op &op = p->ops[k];
-            if (op.kind == BLHIP_OP_GRW) {
-                const int ax = g.axis_map[op.axis];
-                const double ns = val[k] / p->lattice[op.axis];            // transitionModels.py:108
-                op_axis[k] = ax;
-                op_tap[k] = (ns > 0.0) ? taps.get(ax, ns) : -1;            // :110-113 (sigma <= 0: copy)
-                if (std::isnan(ns)) fail("chain %lld: GRW sigma is NaN", (long long)(c0 + b));
-            } else if (op.kind == BLHIP_OP_CHANGEPOINT || op.kind == BLHIP_OP_BREAKPOINT) {
-                time_dependent = true;
-            } else if (op.kind == BLHIP_OP_REGIMESWITCH || op.kind == BLHIP_OP_NOTEQUAL) {
-                prog.has_clamp = true; prog.other_clamp = true;
-            } else if (op.kind == BLHIP_OP_DETERMINISTIC) {
-                time_dependent = true;                       // a different shift at every step
-                op_axis[k] = g.axis_map[op.axis];
-                prog.has_clamp = true;                       // (mode 6 of the generic kernel)
-                prog.has_shift = true;
-            } else if (op.kind == BLHIP_OP_ALPHASTABLE) {
-                const double c = val[k] / p->lattice[op.axis], alpha = val[k + 1];          // transitionModels.py:170-176
-                if (std::isnan(c) || std::isnan(alpha)) fail("chain %lld: AlphaStableRandomWalk parameters are NaN", (long long)(c0 + b));
-                op_axis[k] = g.axis_map[op.axis];
-                op_tap[k] = taps.get_alphastable(op_axis[k], c, alpha, (int)p->n[op.axis]);
-                prog.has_clamp = true; prog.other_clamp = true; prog.dense_clamp = true;      // (mode 5 of the generic kernel: zero boundary + renormalisation)
-            } else if (op.kind == BLHIP_OP_BIVARIATE) {
-                // transitionModels.py:881-885; a singular covariance makes scipy.stats.multivariate_normal raise in the reference
-                const double n1 = val[k] / p->lattice[0], n2 = val[k + 1] / p->lattice[1], rho = val[k + 2];
-                if (!(n1 > 0.0) || !(n2 > 0.0) || !(std::fabs(rho) < 1.0))
-                    fail("chain %lld: BivariateRandomWalk needs sigma1, sigma2 > 0 and |rho| < 1", (long long)(c0 + b));
-                op_tap[k] = taps.get2d(n1, n2, rho);
-                prog.has_clamp = true; prog.other_clamp = true; prog.dense_clamp = true;      // (mode 4 of the generic kernel: dense kernel + renormalisation)
-            }
-        }
-        // the transition from one step to the next, evaluated at time stamp tau (list order, transitionModels.py:645-649)
-        auto run = [&](double tau, bool have_tau, int64_t step = -1, bool fwd = true) {
-            StepProg sp;
-            int seg = 0;                                                   // active sub-model of a serial model (:768)
-            if (have_tau)
-                for (int k : real_ops) {
-                    const blhip_op &op = p->ops[k];
-                    if ((op.kind == BLHIP_OP_BREAKPOINT || (op.kind == BLHIP_OP_CHANGEPOINT && (op.flags & 1))) && val[k] <= tau) seg++;
-                }
-            bool filtered = false;
-            for (int k : real_ops) {
-                const blhip_op &op = p->ops[k];
-                if (op.segment >= 0 && op.segment != seg) continue;
-                switch (op.kind) {
-                    case BLHIP_OP_GRW: {
-                        if (op_tap[k] < 0) break;
-                        if (sp.cmode == 2) fail("a GaussianRandomWalk after a RegimeSwitch in one combined model is not supported");
-                        if (sp.cmode == 4 || sp.cmode == 5)
-                            fail("a GaussianRandomWalk combined with a Bivariate- / AlphaStableRandomWalk is not supported");
-                        if (sp.cmode == 6 && (op_axis[k] == 0 ? sp.t0 : sp.t1) >= 0)
-                            fail("a GaussianRandomWalk and a Deterministic model on the same parameter are not supported");
-                        int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
-                        if (slot >= 0)
-                            fail("two GaussianRandomWalk ops on the same parameter in one combined model are not supported");
-                        slot = op_tap[k];
-                        filtered = true;
-                        break;
-                    }
-                    case BLHIP_OP_CHANGEPOINT:
-                        if (!(op.flags & 1) && have_tau && tau == val[k]) {      // transitionModels.py:300-312
-                            sp = StepProg(); sp.kind = SRC_RESET; filtered = false;
-                        }
-                        break;
-                    case BLHIP_OP_INDEPENDENT:                                    // transitionModels.py:351-360
-                        sp = StepProg(); sp.kind = SRC_INDEP; filtered = false;
-                        break;
-                    case BLHIP_OP_DETERMINISTIC: {                                // transitionModels.py:571-583, :585-602
-                        if (step < 0) break;                                      // (the time-independent template program)
-                        const double dd = val[k + 1 + (fwd ? step : T + step)] / p->lattice[op.axis];
-                        if (std::isnan(dd)) fail("chain %lld: Deterministic shift of step %lld is NaN", (long long)(c0 + b), (long long)step);
-                        if (std::fabs(dd) > 12.0 && (g.n0 != 1 || (double)g.n1 > 16000.0))
-                            fail("chain %lld, step %lld: Deterministic model shifts by %.3g grid cells in one time step; on grids with two "
-                                 "parameters (and 1-D grids beyond 16000 points) the fused kernel supports up to 12 (SciPy's pre-padding)",
-                                 (long long)(c0 + b), (long long)step, dd);
-                        int &slot = op_axis[k] == 0 ? sp.t0 : sp.t1;
-                        if (slot >= 0 || (sp.cmode != 0 && sp.cmode != 6))
-                            fail("a Deterministic model combined with another model acting on the same parameter / a clamp is not supported");
-                        if (dd != 0.0) {                                          // zero shift: identity (its renormalisation is a no-op)
-                            if (std::fabs(dd) > 12.0) { slot = taps.get_bigshift(dd); prog.whole_row = true; }
-                            else slot = taps.get_shift(op_axis[k], dd);
-                            sp.cmode = 6;
-                        }
-                        filtered = true;
-                        break;
-                    }
-                    case BLHIP_OP_ALPHASTABLE: {                                  // transitionModels.py:167-187
-                        if (sp.cmode != 0 || filtered)
-                            fail("an AlphaStableRandomWalk combined with another model acting on the same step is not supported");
-                        sp.cmode = 5;
-                        (op_axis[k] == 0 ? sp.t0 : sp.t1) = op_tap[k];
-                        filtered = true;
-                        break;
-                    }
-                    case BLHIP_OP_BIVARIATE:                                      // transitionModels.py:880-891
-                        if (sp.cmode != 0 || filtered)
-                            fail("a BivariateRandomWalk combined with another model acting on the same step is not supported");
-                        sp.cmode = 4;
-                        sp.t0 = op_tap[k];
-                        filtered = true;
-                        break;
-                    case BLHIP_OP_NOTEQUAL:                                       // transitionModels.py:462-471
-                        if (sp.cmode != 0 || filtered)
-                            fail("a NotEqual model after another model acting on the same step is not supported");
-                        if (sp.kind != SRC_PREV) fail("a NotEqual model right after a change-point / independent restart is not supported");
-                        sp.cmode = 3;
-                        sp.limit = std::pow(10.0, val[k]) * dV;
-                        break;
-                    case BLHIP_OP_REGIMESWITCH:                                   // transitionModels.py:405-410
-                        if (sp.cmode != 0) fail("two RegimeSwitch models acting at the same time are not supported");
-                        sp.cmode = filtered ? 2 : 1;
-                        sp.limit = std::pow(10.0, val[k]) * dV;
-                        break;
-                    default: break;
-                }
-            }
-            if (have_tau)
-                for (int k : real_ops) {                                          // serial change-points, :801-813
-                    const blhip_op &op = p->ops[k];
-                    if (op.kind == BLHIP_OP_CHANGEPOINT && (op.flags & 1) && tau == val[k]) { sp = StepProg(); sp.kind = SRC_RESET; }
-                }
-            if (sp.t0 >= 0) prog.LW0 = std::max(prog.LW0, taps.lw[sp.t0]);
-            if (sp.cmode == 4) prog.LW1 = std::max(prog.LW1, taps.lw2[sp.t0]);
-            if (sp.t1 >= 0) prog.LW1 = std::max(prog.LW1, taps.lw[sp.t1]);
-            return sp;
-        };
-        const StepProg stat = run(0.0, false);       // the program when nothing depends on the time stamp
-        // A step's program depends on its time stamp through (1) the active sub-model of a serial model = how many break- / serial
-        // change-points lie at or before it, (2) a change-point AT it, (3) the step index of a Deterministic model in the active part.
-        // Steps that share (1), have no (2) and no (3) share their program: it is walked once per chain and segment -- two thirds of the
-        // (chain, step) pairs of the published break-point study sit in Static segments (build_program 28 -> 15 ms of a 92-ms fit).
-        auto at = [&](double tau, int64_t step, bool fwd) -> StepProg {
-            int seg = 0;
-            bool event = false;
-            for (int k : bound_ops) {
-                const blhip_op &op = p->ops[k];
-                const bool serial = op.kind == BLHIP_OP_BREAKPOINT || (op.flags & 1);
-                if (serial && val[k] <= tau) seg++;
-                if (op.kind == BLHIP_OP_CHANGEPOINT && tau == val[k]) event = true;
-            }
-            if (event || det_in_seg[seg]) return run(tau, true, step, fwd);
-            if (!seg_cached[seg]) { seg_prog[seg] = run(tau, true, step, fwd); seg_cached[seg] = 1; }
-            return seg_prog[seg];
-        };
-        if (time_dependent) {
-            std::fill(seg_cached.begin(), seg_cached.end(), 0);
-            std::fill(det_in_seg.begin(), det_in_seg.end(), 0);
-            for (int k : real_ops)
-                if (p->ops[k].kind == BLHIP_OP_DETERMINISTIC)
-                    for (size_t sg = 0; sg < det_in_seg.size(); ++sg)
-                        if (p->ops[k].segment < 0 || (size_t)p->ops[k].segment == sg) det_in_seg[sg] = 1;
-        }
-        for (int64_t t = 0; t < T; ++t) {
-            // forward step t consumes T_fwd(post_{t-1}, ts[t-1])   core.py:411
-            StepProg f; f.kind = SRC_PRIOR;
-            if (t > 0) f = time_dependent ? at(p->timestamps[t - 1], t, true) : stat;
-            else if (resume) f = run(p->resume_time, true, 0, true);   // continues a carried state (OnlineStudy.step, core.py:2164-2165)
-            // backward step t consumes T_bwd(beta_{t+1} L_{t+1}, ts[t+1]) = T_fwd(., ts[t+1] - 1)   core.py:467, transitionModels.py:316-317
-            StepProg r; r.kind = SRC_UNIFORM;
-            if (t < T - 1) r = time_dependent ? at(p->timestamps[t + 1] - 1.0, t, false) : stat;
-            gF[(size_t)(b % GROUP) * T + t] = f; gB[(size_t)(b % GROUP) * T + t] = r;
-        }
-        if (b % GROUP == GROUP - 1 || b == B - 1) flush_group(b - b % GROUP, b % GROUP + 1);
-    }
-}
-
-// normalise the kept posterior rows (core.py:389 / :441) (eagerly at the end of the fit, or on first access with option lazy_normalise)
-void ensure_post_scaled(blhip_ctx *ctx) {
-    if (!ctx->post_valid || ctx->post_scaled) return;
-    HIPCHECK(hipSetDevice(ctx->device));
-    const long long G = ctx->post_G;
-    const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-    // (rows [post_row0, post_row1) only: the time-resident kernel has normalised the others itself)
-    const int64_t r0 = ctx->post_row0, nrows = ctx->post_row1 - ctx->post_row0;
-    for (int64_t b = 0; b < ctx->post_chains && nrows > 0; ++b)
-        BL_LAUNCH(scale_rows_kernel, dim3(gx, (unsigned)nrows), dim3(NTHREADS), 0, ctx->stream,
-                           ctx->post.as<double>() + ((size_t)b * ctx->post_T + r0) * G, G, ctx->postinv.as<double>() + b * ctx->post_T + r0);
-    HIPCHECK(hipGetLastError());
-    ctx->post_scaled = true;
-}
-
-// axis-0 radius bucket of a chain as bucket_step() will see it (0: no filter, k: radius in (8 (k - 1), 8 k]); -1 if it cannot be told
-// from the op values alone
-int chain_bucket(const blhip_problem *p, const double *val) {
-    int r0 = 0;
-    for (int k = 0; k < p->n_ops; ++k) {
-        const blhip_op &op = p->ops[k];
-        if (op.kind == BLHIP_OP_GRW) {
-            if (p->ndim == 2 && op.axis == 0) {
-                const double ns = val[k] / p->lattice[0];
-                if (!(ns >= 0.0) || ns > 1e6) return -1;
-                r0 = std::max(r0, (int)(4.0 * ns + 0.5));
-            }
-        } else if (op.kind != BLHIP_OP_STATIC) {
-            return -1;                               // (other models: their launches are not bucketed by radius)
-        }
-    }
-    return r0 == 0 ? 0 : (r0 + 7) / 8;
-}
-
-// -> start index of every batch (+ n_chains at the end): equal shares of at most Bmax chains, each cut moved to the nearest change of
-// radius bucket within the slack the memory budget leaves
-std::vector<int64_t> plan_batches(const blhip_problem *p, int64_t n_chains, const double *op_values, int64_t Bmax, bool align) {
-    // batches of a multiple of 8 chains: whole launches of the chain-resident kernel (8 chains per launch on 512-column grids)
-    if (Bmax >= 16) Bmax -= Bmax % 8;
-    const int64_t nbatch = (n_chains + Bmax - 1) / Bmax;
-    int64_t even = (n_chains + nbatch - 1) / nbatch;
-    if (nbatch > 1 && even >= 16) even = std::min(Bmax, (even + 7) / 8 * 8);
-    std::vector<int64_t> start;
-    for (int64_t c = 0; c < n_chains; c += even) start.push_back(c);
-    start.push_back(n_chains);
-    if (!align || (int64_t)start.size() != nbatch + 1 || nbatch < 2 || !op_values || p->n_ops == 0) return start;
-    std::vector<int> bucket(n_chains);
-    for (int64_t c = 0; c < n_chains; ++c) {
-        bucket[c] = chain_bucket(p, op_values + c * p->n_ops);
-        if (bucket[c] < 0) return start;
-    }
-    for (int64_t b = 1; b < nbatch; ++b) {
-        // candidates: bucket changes between the previous cut and the next one; the batches on both sides must stay <= Bmax
-        int64_t best = -1;
-        for (int64_t c = start[b - 1] + 1; c < start[b + 1]; ++c) {
-            if (bucket[c] == bucket[c - 1]) continue;
-            if (c - start[b - 1] > Bmax || start[b + 1] - c > Bmax) continue;
-            if (best < 0 || std::llabs(c - start[b]) < std::llabs(best - start[b])) best = c;
-        }
-        if (best >= 0) start[b] = best;
-    }
-    return start;
-}
-
-// One more cut where the axis-0 radius of a hyper-grid crosses the largest band of the matrix-pipe / chain-resident kernels (40): the
-// chains below it keep those kernels, the chains above it take the column pre-pass (blh::vwide_kernel) -- without the cut ONE wide chain
-// would route its whole batch through the pre-pass.  Only for grids sorted that way (every chain before the cut <= 40 < every chain after).
-void split_wide_axis0(const blhip_problem *p, int64_t n_chains, const double *op_values, std::vector<int64_t> &start, int r_max) {
-    if (p->ndim != 2 || !op_values || p->n_ops == 0 || n_chains < 2) return;
-    auto radius0 = [&](int64_t c) {
-        int r0 = 0;
-        for (int k = 0; k < p->n_ops; ++k) {
-            const blhip_op &op = p->ops[k];
-            if (op.kind == BLHIP_OP_GRW && op.axis == 0) {
-                const double ns = op_values[c * p->n_ops + k] / p->lattice[0];
-                if (!(ns >= 0.0) || ns > 1e6) return -1;
-                r0 = std::max(r0, (int)(4.0 * ns + 0.5));
-            }
-        }
-        return r0;
-    };
-    int64_t cut = -1;
-    for (int64_t c = 0; c < n_chains; ++c) {
-        const int r = radius0(c);
-        if (r < 0) return;
-        if (r > r_max) { if (cut < 0) cut = c; }
-        else if (cut >= 0) return;                   // a narrow chain after a wide one: not sorted by radius
-    }
-    if (cut <= 0) return;
-    for (int64_t v : start) if (v == cut) return;
-    start.insert(std::upper_bound(start.begin(), start.end(), cut), cut);
-}
-
-// ---- the phases of a fit: flags, shared tables (upload), memory plan; then per batch: program, geometry, metadata, forward pass +
-//      evidence bookkeeping, backward pass + bookkeeping, carried states / average posterior / kept posterior, results ------------
-struct FitFlags {
-    bool evidence_only, forward_only, full, keep, accumulate, resume, carry;
-};
-
-FitFlags decode_flags(blhip_ctx *ctx, const blhip_problem *p, uint32_t flags, const double *log_w) {
-    FitFlags f{};
-    f.evidence_only = flags & BLHIP_EVIDENCE_ONLY;
-    f.forward_only = (flags & BLHIP_FORWARD_ONLY) && !f.evidence_only;
-    f.full = !f.evidence_only && !f.forward_only;
-    f.keep = (flags & BLHIP_KEEP_POSTERIOR) && !f.evidence_only;
-    f.accumulate = (flags & BLHIP_ACCUMULATE) && !f.evidence_only;
-    f.resume = flags & BLHIP_RESUME;
-    f.carry = flags & BLHIP_CARRY;
-    if (f.resume || f.carry) {
-        if (f.full) fail("BLHIP_RESUME / BLHIP_CARRY need a forward-only or evidence-only fit");
-        if (p->carry_slot < 0) fail("carry_slot must be >= 0");
-    }
-    if (f.accumulate && !ctx->acc_active) fail("BLHIP_ACCUMULATE without blhip_accum_begin");
-    if (f.accumulate && !log_w) fail("BLHIP_ACCUMULATE needs log_chain_weight");
-    return f;
-}
-
-// what every chain of the call shares, resident in HBM for the duration of the call
-struct DeviceTables {
-    double *m0, *m1, *colA, *colB, *rec, *prior, *reset, *uniform, *indep, *lik;
-    int rec_len, d;
-};
-
-// upload: marginal grids, per-column likelihood constants, per-step data records, prior(s); the (T, G) likelihood table of the
-// closed-form table models is built on the device (table_model != 0), a caller-evaluated one (BLHIP_OM_TABLE) is copied
-DeviceTables upload_tables(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int table_model) {
-    hipStream_t st = ctx->stream;
-    const int64_t T = p->T;
-    const long long G = g.G;
-    DeviceTables D{};
-    std::vector<double> rec;
-    build_records(p, rec, D.rec_len, D.d);
-    std::vector<double> colA(g.n1, 0.0), colB(g.n1, 0.0);
-    const double *mcol = p->ndim == 1 ? p->marginal[0] : p->marginal[1];
-    if (p->obs_model == BLHIP_OM_GAUSSIAN)
-        for (int j = 0; j < g.n1; ++j) {
-            const double s = mcol[j];
-            colA[j] = 1.0 / (2.0 * s * s);
-            colB[j] = 0.5 * std::log(2.0 * M_PI * s * s);
-        }
-    if (p->obs_model == BLHIP_OM_POISSON)
-        for (int j = 0; j < g.n1; ++j) colA[j] = std::exp(-mcol[j]);
-
-    size_t tb = 0;
-    tb += carve_size(sizeof(double) * std::max(1, g.n0)) + 3 * carve_size(sizeof(double) * g.n1);
-    tb += carve_size(sizeof(double) * rec.size()) + 4 * carve_size(sizeof(double) * G);
-    ctx->tables.ensure(tb);
-    char *cur = ctx->tables.as<char>();
-    D.m0 = carve<double>(cur, std::max(1, g.n0));
-    D.m1 = carve<double>(cur, g.n1);
-    D.colA = carve<double>(cur, g.n1);
-    D.colB = carve<double>(cur, g.n1);
-    D.rec = carve<double>(cur, rec.size());
-    D.prior = carve<double>(cur, G);
-    D.reset = carve<double>(cur, G);
-    D.uniform = carve<double>(cur, G);
-    D.indep = carve<double>(cur, G);
-    if (p->ndim == 2) HIPCHECK(hipMemcpyAsync(D.m0, p->marginal[0], sizeof(double) * g.n0, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(D.m1, mcol, sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(D.colA, colA.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(D.colB, colB.data(), sizeof(double) * g.n1, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(D.rec, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, st));
-    // (the prior of a study that is fitted again: the caller's token says the content is the one this place already holds)
-    const bool prior_resident = p->prior_token != 0 && p->prior_token == ctx->prior_token && D.prior == ctx->prior_dev && G == ctx->prior_G;
-    if (!prior_resident) HIPCHECK(hipMemcpyAsync(D.prior, p->prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
-    ctx->prior_token = p->prior_token; ctx->prior_dev = D.prior; ctx->prior_G = G;
-    if (p->reset_prior) HIPCHECK(hipMemcpyAsync(D.reset, p->reset_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
-    if (p->indep_prior) HIPCHECK(hipMemcpyAsync(D.indep, p->indep_prior, sizeof(double) * G, hipMemcpyHostToDevice, st));
-    if (ff.full) {
-        // beta_T = 1/G   core.py:424-425 -- or the caller's backward message (blhip_problem.backward_init)
-        if (p->backward_init) HIPCHECK(hipMemcpyAsync(D.uniform, p->backward_init, sizeof(double) * G, hipMemcpyHostToDevice, st));
-        else BL_LAUNCH(fill_kernel, dim3(256), dim3(256), 0, st, D.uniform, G, 1.0 / (double)G);
-    }
-    D.lik = nullptr;
-    if (p->obs_model == BLHIP_OM_TABLE) {
-        ctx->likbuf.ensure(sizeof(double) * T * G);
-        D.lik = ctx->likbuf.as<double>();
-        if (table_model) {
-            const size_t nd = (size_t)T * p->seg_len * p->data_dim;
-            ctx->databuf.ensure(nd * 8);
-            HIPCHECK(hipMemcpyAsync(ctx->databuf.p, p->data, nd * 8, hipMemcpyHostToDevice, st));
-            const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 2048);
-            BL_LAUNCH(lik_table_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, table_model, D.lik, (long long)G, g.n1,
-                               p->ndim, D.m0, D.m1, ctx->databuf.as<double>(), p->seg_len, p->data_dim);
-            HIPCHECK(hipGetLastError());
-        } else {
-            HIPCHECK(hipMemcpyAsync(D.lik, p->lik, sizeof(double) * T * G, hipMemcpyHostToDevice, st));
-        }
-    }
-    sync_stream(ctx, st);   // the host vectors above go out of use
-    return D;
-}
-
-// memory plan: how many chains fit one batch (state ping-pong + the stored sequence + partial sums per chain within the budget)
-constexpr int CHAIN_MIN_ROWS = 32;            // smallest grid (rows) the chain-resident kernels take (on the 128-row geometry)
-constexpr int CHAIN_R0_MAX = 80;               // widest band of the chain-resident kernels (ring of 44 entries); option chain_wide = 0: FAST_R0_MAX
-constexpr int CHAIN_TALL_ROWS = 1024;         // ... and the one geometry beyond 512 rows: grids of 513 .. 1024 rows (option chain_tall = 0: off)
-inline bool chain_rows_ok(int n0) { return n0 >= CHAIN_MIN_ROWS && n0 <= CHAIN_TALL_ROWS; }
-inline bool chain_tall(int n0) { return n0 > 512 && n0 <= CHAIN_TALL_ROWS; }
-
-int64_t chains_per_batch(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const FitFlags &ff, int64_t n_chains, int post_buffers) {
-    const int64_t T = p->T;
-    const long long G = g.G;
-    size_t free_b = 0, total_b = 0;
-    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
-    // (every reusable buffer of the context counts as available, so that the plan -- and with it the buffer sizes -- is the same from
-    //  fit to fit: a plan that changed between two fits of one study re-allocated the 100-GB sequence buffer, 5 s)
-    double budget = std::min((double)free_b + (double)ctx->state.cap + (double)ctx->post.cap + (double)ctx->post2.cap + (double)ctx->accpart.cap,
-                             ctx->option("mem_budget_bytes", 0.70 * (double)total_b)) * 0.9;
-    // the chain-resident kernels lay their sequences out on a padded geometry (rows 128 / 256 / 512, columns a multiple of 16)
-    double Gk = (double)G;
-    if (p->ndim == 2 && chain_rows_ok(g.n0))
-        Gk = (double)((g.n0 + 127) / 128 * 128) * (double)((g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL);
-    {   // walks on both parameters: the transposing kernels lay their sequences out on a SQUARE geometry (blhip_chainax.hpp)
-        bool w0 = false, w1 = false;
-        for (int k = 0; k < p->n_ops; ++k)
-            if (p->ops[k].kind == BLHIP_OP_GRW) { if (g.axis_map[p->ops[k].axis] == 0) w0 = true; else w1 = true; }
-        if (p->ndim == 2 && w0 && w1 && std::max(g.n0, g.n1) <= 512) {
-            const double n = std::max(g.n0, g.n1) <= 128 ? 128.0 : (std::max(g.n0, g.n1) <= 256 ? 256.0 : 512.0);
-            Gk = std::max(Gk, n * n);
-        }
-    }
-    // the partial accumulators of the fused fold (ChainRun::setup: one (T, G) slot per block column of a launch) come out of the same memory
-    // -- only where the chain-resident path can be taken at all (else they are never allocated: a narrow grid with a long series
-    //    gave up its whole budget to 128 slots it never used and ran one chain per batch), and never more than half of the budget
-    if (ff.accumulate && ff.full && p->ndim == 2 && p->obs_model == BLHIP_OM_GAUSSIAN && chain_rows_ok(g.n0) &&
-        g.n1 >= 1 && g.n1 <= 16 * blc::MAX_STRIPS && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok) {
-        const double slots = std::max(1, std::min(ctx->num_cus, 256) / ((g.n1 + blc::WCOL - 1) / blc::WCOL));
-        budget -= std::min(0.5 * budget, std::min<double>(slots, (double)n_chains) * (double)T * Gk * 8.0);
-    }
-    const double per_chain = (ff.evidence_only ? 2.0 : (double)post_buffers * (double)T + 2.0) * Gk * 8.0 +
-                             (double)T * NRED * 8.0 * 2 * 64.0 /*partials, rough*/;
-    int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
-    // (1-D grids: a chain is a few KB and a batch of the chain-resident 1-D kernel costs a fixed ~1 ms of launches, syncs and read-backs --
-    //  the reference's published break-point study, 23 400 chains: 61 ms with batches of 1024, 52 with 4096, 54 with 8192)
-    Bmax = std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", p->ndim == 1 ? 4096 : 1024));
-    Bmax = std::min<int64_t>(Bmax, 65535);
-    if (ff.keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
-    if ((ff.resume || ff.carry) && n_chains > Bmax) fail("carried states: %lld chains do not fit in one batch", (long long)n_chains);
-    if (ff.resume) {
-        auto it = ctx->carry.find(p->carry_slot);
-        if (it == ctx->carry.end() || !it->second.valid) fail("BLHIP_RESUME: carry slot %d holds no state", p->carry_slot);
-        if (it->second.chains != n_chains || it->second.G != G)
-            fail("BLHIP_RESUME: carry slot %d holds %lld chains x %lld cells, the call has %lld x %lld", p->carry_slot,
-                 (long long)it->second.chains, (long long)it->second.G, (long long)n_chains, (long long)G);
-    }
-    return Bmax;
-}
-
-// which kernel family runs a batch and with what block geometry (segment lengths from a small cost model: long segments read every
-// element once + 2 R0 halo rows per segment, short ones give enough blocks to fill 256 CUs when there are few chains)
-struct GeometryPlan {
-    bool shift1d = false;        // the chain-resident 1-D kernel's flavours with spline shifts (Deterministic steps) / clamps (RegimeSwitch, NotEqual)
-    bool clamp1d = false;        // ... the one with clamps (CL = 2)
-    bool fast = false, fused1d = false, use_mfma = false;
-    bool chain1d = false;         // 1-D batches: one block per chain runs the whole pass (blhip_chain1d.hpp); bookkeeping of a K = 1 fused pass
-    bool wideH = false;           // axis-1 walks wider than the fused kernels' halo: row filter as a pre-pass per step (blhip_hwide.hpp)
-    bool wideV = false;           // axis-0 walks wider than the matrix-pipe kernels' largest band: column filter as a pre-pass, no stencil left
-    bool hSplit = false;          // wideH: chains of the batch whose axis-1 filter is absent (or narrow: hFusedMax > 0) keep their fused kernels
-    int hFusedMax = 0;
-    int64_t fusedK = 1;
-    int f1_TJ = 128;
-    Tile tile{};
-    int fastS = 0, fast_nseg = 1, fast_fnblk = 1, mS = 0, m_nseg = 1, m_tiles_j = 1, m_nblk = 1;
-};
-
-GeometryPlan plan_geometry(blhip_ctx *ctx, const blhip_problem *p, const Geometry &g, const ChainProgram &prog, int64_t B, int d,
-                       bool resume, bool carry, const TapTable *taps = nullptr) {
-    GeometryPlan gp;
-    const int64_t T = p->T;
-    // fast path (blhip_fast.hpp) when the whole batch qualifies, otherwise the generic LDS-tile kernel
-    const bool wide_h_ok = prog.LW1 <= blh::HW_MAX && prog.LW1 < g.n1 && ctx->option("wide_h", 1.0) != 0.0;
-    const bool wide_v = prog.LW0 > FAST_R0_MAX && prog.LW0 <= blh::VW_MAX && prog.LW0 < g.n0 && wide_h_ok && ctx->option("wide_v", 1.0) != 0.0;
-    gp.fast = p->ndim == 2 && (p->obs_model == BLHIP_OM_GAUSSIAN || p->obs_model == BLHIP_OM_TABLE) &&
-                      ctx->option("fast", 1.0) != 0.0 && !prog.has_clamp && (prog.LW0 <= FAST_R0_MAX || wide_v) &&
-                      (prog.LW1 <= blf::R1MAX || wide_h_ok) &&
-                      g.n0 >= (wide_v ? 0 : ((prog.LW0 + 7) / 8) * 8) + 2 * blf::CH && g.n1 >= 2 * blf::R1MAX && d <= blf::DMAX;
-    gp.wideV = gp.fast && wide_v;
-    gp.wideH = gp.fast && (prog.LW1 > blf::R1MAX || (gp.wideV && prog.LW1 > 0));       // (with a column pre-pass every filter runs as a pre-pass)
-    // Chains of such a batch WITHOUT an axis-1 filter (a hyper-grid that includes the width 0) skip the pre-pass: it would be a copy.
-    // wide_h_fused_max = 8: chains with a narrow filter keep the fused kernels' own axis-1 part as well -- 15 % fewer bytes on
-    // extra.c4_both_axes but no faster (the fused both-axes kernels at radii up to 40 are bound by the fp64 pipe: 5.44e10 -> 5.47e10), so
-    // the default sends every filter through the pre-pass.
-    bool any_narrow = false;
-    gp.hFusedMax = std::min(blf::R1MAX, std::max(0, (int)ctx->option("wide_h_fused_max", 0.0)));
-    if (gp.wideH && !gp.wideV && taps && ctx->option("wide_h_split", 1.0) != 0.0) {
-        bool any_none = false;
-        for (size_t e = 0; e < prog.tapF1.size() && !(any_narrow && any_none); ++e) {
-            const int k = prog.tapF1[e];
-            if (k < 0) any_none = true; else if (gp.hFusedMax > 0 && taps->lw[k] <= gp.hFusedMax) any_narrow = true;
-        }
-        gp.hSplit = any_narrow || any_none;
-    }
-    // (programs whose only clamp mode is a Deterministic model's spline shift: the chain-resident kernel has a flavour for them
-    //  -- bl1c::chain1d_kernel SHIFT --, the K-steps-per-launch and persistent kernels have not: chain1d or the generic kernel)
-    // (round 6: ... and the one with the clamps of RegimeSwitch / NotEqual -- bl1c::chain1d_kernel CL = 2; the dense zero-boundary kernels of
-    //  the AlphaStable walk keep the generic kernel)
-    const bool shift1d = p->ndim == 1 && prog.has_clamp && !prog.dense_clamp && ctx->option("chain1d_shift", 1.0) != 0.0 &&
-                         (!prog.other_clamp || ctx->option("chain1d_clamp", 1.0) != 0.0);
-    if (p->ndim == 1 && !gp.fast && (!prog.has_clamp || shift1d) && ctx->option("fuse1d", 8.0) >= 1.0 &&
-        (p->obs_model == BLHIP_OM_POISSON || p->obs_model == BLHIP_OM_GAUSSIAN_MEAN || p->obs_model == BLHIP_OM_TABLE)) {
-        gp.f1_TJ = 128;
-        gp.fusedK = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->option("fuse1d", 8.0), T));
-        // keep the redundantly recomputed halo (K * LW cells per side) within ~4x the owned cells and the window in LDS
-        while (gp.fusedK > 1 && (gp.fusedK * prog.LW1 > 2 * gp.f1_TJ || (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 > 96 * 1024)) --gp.fusedK;
-        gp.fused1d = (size_t)(gp.f1_TJ + 2 * gp.fusedK * prog.LW1) * 32 + (size_t)gp.fusedK * gp.f1_TJ * 32 + 4096 <= 150 * 1024;
-        // Batches of chains: one block per chain for the whole pass when that is cheaper per step than the alternatives.  Per step
-        // (shader cycles; measured with tools/probe.py chain1d, profiles/r04_notes.md): the chain's row is filtered out of ONE CU's LDS --
-        // n (2 lw + 1) 16-byte operand pairs at 128 B per clock, ~1 k cycles of barrier / sums / likelihood -- and ceil(B / CUs) blocks
-        // share a CU one after the other; the K-steps-per-launch path costs a launch (~14 k cycles) every K steps, the persistent
-        // one (all blocks of all chains on the chip at once) ~4 k (K > 1) / ~7 k (K = 1: a hand-off per step) per step.
-        const double c1d_mode = ctx->option("chain1d", 1.0);
-        if (shift1d) gp.fused1d = true;              // (decided below: without the chain-resident kernel the batch keeps the generic one)
-        if (gp.fused1d && c1d_mode != 0.0 && !resume && !carry && prog.LW1 < g.n1 && g.n1 <= bl1c::NMAX &&
-            bl1c::lds_doubles(g.n1, prog.LW1, shift1d) * 8 <= 150 * 1024) {
-            // microseconds per time step of the whole batch, fitted to tools/probe.py chain1d (profiles/r04_notes.md): a block's step =
-            // 1.5 us + 1.0 ns per cell (likelihood from the shared table; 2.2 ns with Poisson's pow() in the kernel) + 44 ps per cell and
-            // tap (the stencil's operand pairs come out of ONE CU's LDS at ~9 per clock), blocks beyond the chip's capacity queue up;
-            // persistent K-step kernel (all blocks of all chains on the chip at once) 1.7 us + 40 ns per cell of radius; a launch per K
-            // steps 1.5 us + (29 + 0.63 radius) ps per cell of the batch
-            const int cus = std::min(ctx->num_cus, 256);
-            const double n = g.n1, lw = prog.LW1;
-            // (rows longer than a block: two cells per thread share their operand pairs, 21 ps per cell and tap -- launch_chain1d)
-            const double tap_us = g.n1 > bl1c::NT && true ? 2.1e-5 : 4.4e-5;
-            const double est_c1d = (double)((B + cus - 1) / cus) * (1.5 + n * (B >= 4 ? 0.0010 : 0.0022) + n * (2.0 * lw + 1.0) * tap_us);
-            const int nblk_f = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ;
-            const bool p1d_ok = ctx->option("persist1d", 1.0) != 0.0 && (long long)nblk_f * B <= cus && T > gp.fusedK;
-            const double est_other = p1d_ok ? 1.7 + 0.04 * lw : 1.5 + (double)B * n * (29.0 + 0.63 * lw) * 1e-6;
-            // (shift1d: the alternative is a launch per step.  A single chain takes the kernel too when the model says so -- rows of a few
-            //  hundred cells with a narrow stencil: 200 cells, radius 27: 2.4 against 2.8 us per step)
-            // (clamps without a Deterministic model -- the reference's regime-switch tutorial is ONE such chain: a step of a few hundred cells
-            //  costs the block ~2 us against a launch of the generic kernel)
-            gp.chain1d = c1d_mode == 2.0 || (shift1d && (B >= 2 || !prog.has_shift)) || (!shift1d && est_c1d < est_other);
-            if (gp.chain1d) { gp.fusedK = 1; gp.f1_TJ = g.n1; }
-        }
-        if (shift1d && !gp.chain1d) gp.fused1d = false;
-        gp.shift1d = shift1d && gp.chain1d;
-        gp.clamp1d = gp.shift1d && prog.other_clamp;
-    }
-    if (gp.fast) {
-        gp.tile.TI = blf::CH; gp.tile.LW0 = gp.wideV ? 0 : prog.LW0; gp.tile.LW1 = (prog.LW1 > 0 && (!gp.wideH || (gp.hSplit && any_narrow))) ? blf::R1MAX : 0;
-        gp.tile.TJ = blf::BW - 2 * gp.tile.LW1;
-        gp.tile.tiles_j = (g.n1 + gp.tile.TJ - 1) / gp.tile.TJ;
-        // rows per block segment: long segments read every element once (+ 2*R0 halo rows per segment), short ones
-        // give enough blocks to fill 256 CUs when there are few chains.  Model: cost = waves * blocks_per_CU * rows.
-        const long long colblocks = (long long)gp.tile.tiles_j * B;
-        const int R0 = (prog.LW0 == 0 || gp.wideV) ? 0 : ((prog.LW0 + 7) / 8) * 8;
-        double best = 1e300;
-        const int forceS = (int)ctx->option("fast_S", 0);
-        for (int k = 1; k <= 4; k *= 2) {
-            const double pen = k == 1 ? 1.6 : (k == 2 ? 1.15 : 1.0);
-            for (int ns = 1; ns <= std::max(1, g.n0 / 16); ++ns) {
-                int S = ((g.n0 + ns - 1) / ns + blf::CH - 1) / blf::CH * blf::CH;
-                const int real = (g.n0 + S - 1) / S;
-                const long long blocks = colblocks * real;
-                const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
-                const double cost = pen * (double)waves * k * (S + 2.0 * R0 + 4.0);
-                if (cost < best - 1e-9) { best = cost; gp.fastS = S; gp.fast_nseg = real; }
-            }
-        }
-        if (forceS > 0) { gp.fastS = (forceS + blf::CH - 1) / blf::CH * blf::CH; gp.fast_nseg = (g.n0 + gp.fastS - 1) / gp.fastS; }
-        gp.tile.tiles_i = gp.fast_nseg;
-        gp.fast_fnblk = gp.tile.tiles_j * gp.fast_nseg;
-        // geometry of the matrix-pipe kernel (64-column strips, segments of mS rows, mS a multiple of 16)
-        {
-            gp.m_tiles_j = (g.n1 + blm::BCOL - 1) / blm::BCOL;
-            const long long mcol = (long long)gp.m_tiles_j * B;
-            double mbest = 1e300;
-            for (int k = 1; k <= 4; ++k) {                     // resident blocks per CU
-                const double pen = k == 1 ? 1.5 : (k == 2 ? 1.15 : 1.0);
-                for (int ns = 1; ns <= std::max(1, g.n0 / 32); ++ns) {
-                    int S = ((g.n0 + ns - 1) / ns + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q;
-                    if (S > blm::MS_MAX) continue;
-                    const int real = (g.n0 + S - 1) / S;
-                    const long long blocks = mcol * real;
-                    const long long waves = (blocks + 256LL * k - 1) / (256LL * k);
-                    const double cost = pen * (double)waves * k * (S + 1.0 * R0 + 24.0);
-                    if (cost < mbest - 1e-9) { mbest = cost; gp.mS = S; gp.m_nseg = real; }
-                }
-            }
-            const int forceM = (int)ctx->option("mfma_S", 0);
-            if (forceM > 0) { gp.mS = std::min(blm::MS_MAX, (forceM + blm::SEG_Q - 1) / blm::SEG_Q * blm::SEG_Q); gp.m_nseg = (g.n0 + gp.mS - 1) / gp.mS; }
-            if (gp.mS == 0) { gp.mS = blm::MS_MAX; gp.m_nseg = (g.n0 + gp.mS - 1) / gp.mS; }
-            gp.m_nblk = gp.m_tiles_j * gp.m_nseg;
-        }
-        gp.use_mfma = ctx->option("mfma", 1.0) != 0.0;
-        gp.tile.nblk = gp.use_mfma ? std::max(gp.fast_fnblk, gp.m_nblk) : gp.fast_fnblk;
-        gp.tile.lds_bytes = 0;
-    } else if (gp.fused1d) {
-        gp.tile.TI = 1; gp.tile.TJ = gp.f1_TJ; gp.tile.LW0 = 0; gp.tile.LW1 = prog.LW1; gp.tile.tiles_i = 1;
-        gp.tile.tiles_j = (g.n1 + gp.f1_TJ - 1) / gp.f1_TJ; gp.tile.nblk = gp.tile.tiles_j; gp.tile.lds_bytes = 0;
-    } else {
-        gp.tile = choose_tile(ctx, g, prog.LW0, prog.LW1, prog.whole_row);
-        if (prog.whole_row && gp.tile.tiles_j != 1) fail("internal: a two-stage spline shift needs the whole row in one tile");
-    }
-    return gp;
-}
-
-// per-(step, chain) metadata of a batch in HBM: source kinds, tap-set ids, clamp modes, the per-step launch order of the radius buckets,
-// the tap table; plus scratch the finalisation kernels use
-struct DeviceMeta {
-    unsigned char *kindF, *kindB, *cmodeF, *cmodeB;
-    double *limitF, *limitB;
-    int *tapF0, *tapF1, *tapB0, *tapB1, *orderF, *orderB;
-    double *taps;
-    int *off, *lw, *lw2;
-    double *invN, *w, *dump;
-    // host copies the launch loop reads
-    std::vector<int> h_orderF, h_orderB;
-    std::vector<std::vector<FastRange>> rangesF, rangesB;
-};
-
-void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram &prog, TapTable &taps, int64_t B, bool full, bool fast, int nblk,
-                     DeviceMeta &M, bool wideH = false, bool wideV = false, bool h_split = false, int h_fused_max = 0) {
-    hipStream_t st = ctx->stream;
-    const int64_t T = p->T;
-    const size_t nT = (size_t)T * B;
-    taps.w.resize(taps.w.size() + 64, 0.0);      // zero padding: the fast kernels read up to R0 weights per tap set
-    size_t mb = 4 * carve_size(nT) + 6 * carve_size(nT * sizeof(int)) + carve_size(taps.w.size() * 8 + 8) +
-                3 * carve_size(taps.off.size() * 4 + 4) + 4 * carve_size(sizeof(double) * nT) + carve_size(8 * B) + carve_size(8 * 4 * NTHREADS);
-    ctx->meta.ensure(mb);
-    char *cur = ctx->meta.as<char>();
-    M.kindF = carve<unsigned char>(cur, nT); M.kindB = carve<unsigned char>(cur, nT);
-    M.cmodeF = carve<unsigned char>(cur, nT); M.cmodeB = carve<unsigned char>(cur, nT);
-    M.limitF = carve<double>(cur, nT); M.limitB = carve<double>(cur, nT);
-    M.tapF0 = carve<int>(cur, nT); M.tapF1 = carve<int>(cur, nT);
-    M.tapB0 = carve<int>(cur, nT); M.tapB1 = carve<int>(cur, nT);
-    M.orderF = carve<int>(cur, nT); M.orderB = carve<int>(cur, nT);
-    M.taps = carve<double>(cur, taps.w.size() + 1);
-    M.off = carve<int>(cur, taps.off.size() + 1); M.lw = carve<int>(cur, taps.off.size() + 1);
-    M.lw2 = carve<int>(cur, taps.off.size() + 1);
-    M.invN = carve<double>(cur, nT);
-    (void)carve<double>(cur, nT);
-    M.w = carve<double>(cur, B);
-    M.dump = carve<double>(cur, 4 * NTHREADS);   // (the halo wave of an H block spreads its dummy stores over 8 x 64 slots)
-    HIPCHECK(hipMemcpyAsync(M.kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(M.tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(M.tapF1, prog.tapF1.data(), nT * 4, hipMemcpyHostToDevice, st));
-    if (prog.has_clamp) {
-        HIPCHECK(hipMemcpyAsync(M.cmodeF, prog.cmodeF.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.limitF, prog.limitF.data(), nT * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.cmodeB, prog.cmodeB.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.limitB, prog.limitB.data(), nT * 8, hipMemcpyHostToDevice, st));
-    }
-    if (full) {
-        HIPCHECK(hipMemcpyAsync(M.kindB, prog.kindB.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.tapB1, prog.tapB1.data(), nT * 4, hipMemcpyHostToDevice, st));
-    }
-    if (fast) {
-        // a launch with fewer than ~128 blocks leaves most of the 256 CUs idle: a radius bucket with fewer blocks joins the next one
-        const long long min_blocks = 128;
-        const int min_chains = (int)std::min<long long>(B, (min_blocks + (long long)nblk - 1) / nblk);
-        // (wideH: the axis-1 filters wider than the fused kernels' 8 columns run in the pre-pass, and the fused kernels of those chains are
-        //  launched without an axis-1 part; chains of the same step with a narrow filter or none keep their fused kernels -- unless the
-        //  step also has the axis-0 pre-pass, or with wide_h_split = 0: then every chain of the step goes through the pre-pass)
-        const std::vector<int> no_h((wideH || wideV) ? (size_t)B : 0, -1);
-        auto all_pre = [&](std::vector<FastRange> &rs) { if (wideH && !h_split) for (auto &r : rs) r.pre = true; };
-        M.h_orderF.resize(nT); M.rangesF.resize(T);
-        for (int64_t t = 0; t < T; ++t) {
-            bucket_step(wideV ? no_h.data() : &prog.tapF0[t * B], (wideH && !h_split) ? no_h.data() : &prog.tapF1[t * B], taps.lw, (int)B, &M.h_orderF[t * B], M.rangesF[t], min_chains,
-                        h_split ? h_fused_max : -1);
-            all_pre(M.rangesF[t]);
-        }
-        HIPCHECK(hipMemcpyAsync(M.orderF, M.h_orderF.data(), nT * 4, hipMemcpyHostToDevice, st));
-        if (full) {
-            M.h_orderB.resize(nT); M.rangesB.resize(T);
-            for (int64_t t = 0; t < T; ++t) {
-                bucket_step(wideV ? no_h.data() : &prog.tapB0[t * B], (wideH && !h_split) ? no_h.data() : &prog.tapB1[t * B], taps.lw, (int)B, &M.h_orderB[t * B], M.rangesB[t], min_chains,
-                            h_split ? h_fused_max : -1);
-                all_pre(M.rangesB[t]);
-            }
-            HIPCHECK(hipMemcpyAsync(M.orderB, M.h_orderB.data(), nT * 4, hipMemcpyHostToDevice, st));
-        }
-    }
-    if (!taps.w.empty()) {
-        HIPCHECK(hipMemcpyAsync(M.taps, taps.w.data(), taps.w.size() * 8, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.off, taps.off.data(), taps.off.size() * 4, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.lw, taps.lw.data(), taps.lw.size() * 4, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.lw2, taps.lw2.data(), taps.lw2.size() * 4, hipMemcpyHostToDevice, st));
-    }
-}
-
-// host-side results of one batch of chains
-struct BatchOutcome {
-    std::vector<double> logE, local, means, invN;    // (B,), (B, T), (B, ndim, T), (B, T): 1 / row sum of the stored sequence
-    std::vector<int64_t> abort_step;
-    std::vector<int32_t> abort_phase;
-};
-
-// BLHIP_CARRY: keep every chain's filtered distribution of the last step, normalised (core.py:2173)
-void store_carry(blhip_ctx *ctx, const blhip_problem *p, int64_t B, long long G, const double *redF, const double *fin, long long fstr,
-                 double *d_w, bool has_clamp) {
-    hipStream_t st = ctx->stream;
-    const int64_t T = p->T;
-    blhip_ctx::Carry &cs = ctx->carry[p->carry_slot];
-    cs.buf.ensure((size_t)B * G * 8);
-    std::vector<double> inv(B);
-    for (int64_t b = 0; b < B; ++b) inv[b] = 1.0 / redF[((size_t)(T - 1) * B + b) * NRED];
-    HIPCHECK(hipMemcpyAsync(d_w, inv.data(), B * 8, hipMemcpyHostToDevice, st));
-    const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-    BL_LAUNCH(carry_store_kernel, dim3(gx, (unsigned)B), dim3(NTHREADS), 0, st, cs.buf.as<double>(), fin, fstr, G, d_w);
-    sync_stream(ctx, st);
-    cs.chains = B; cs.G = G; cs.valid = true;
-    cs.maxv.clear();
-    if (has_clamp)                               // clamp batches run the generic kernel, which reports the state maximum
-        for (int64_t b = 0; b < B; ++b) cs.maxv.push_back(redF[((size_t)(T - 1) * B + b) * NRED + 6] * inv[b]);
-}
-
-// fold the batch into the average posterior (core.py:1358-1366): linear accumulator with a running reference exponent.
-// Two halves, so that the kernel can be launched later than the bookkeeping is done (overlapped folds, see do_fit): prepare_fold
-// turns the batch's evidences into weights (staged in h_w / h_invN, which must stay valid until the launch has consumed them) and
-// advances the accumulator's reference; launch_fold copies them to the device and runs the pass on `st`.
-struct FoldJob {
-    bool pending = false;
-    const double *d_post = nullptr;
-    int64_t B = 0;
-    double *h_w = nullptr, *h_invN = nullptr;        // host staging (B), (T * B)
-    double *d_w = nullptr, *d_invN = nullptr;        // device copies
-    double r = 0.0;                                  // factor of what the accumulator already holds
-    int first = 0;
-    int parity = 0;
-    int sm_n0 = 0;                                   // > 0: d_post is in the chain-resident kernel's strip-major layout (rows per strip)
-    int pad_n0p = 0, pad_n0 = 0, pad_n1 = 0;         // > 0: ... on a padded geometry (rows per strip n0p; the grid's true sizes)
-    int pad_ax = 0;                                  //      ... in the alternating layouts of the both-axes kernels (blk::ax_layout_b)
-    long long pad_step = 0;                          //      doubles per time step of a chain's sequence there
-};
-
-bool prepare_fold(blhip_ctx *ctx, int64_t T, int64_t B, const BatchOutcome &out, const double *log_w_batch, FoldJob &job) {
-    double newref = ctx->acc_logref;
-    std::vector<double> lw(B, -INFINITY);
-    std::vector<char> valid(B, 0);
-    for (int64_t b = 0; b < B; ++b) {
-        // np.isfinite(logEvidence) guard (core.py:1358); a zero hyper-prior contributes log(0) = -inf, i.e. nothing
-        valid[b] = out.abort_step[b] < 0 && std::isfinite(out.logE[b]) && std::isfinite(log_w_batch[b]);
-        if (!valid[b]) continue;
-        lw[b] = out.logE[b] + log_w_batch[b];
-        if (lw[b] > newref) newref = lw[b];
-    }
-    if (!std::isfinite(newref)) return false;
-    int nfold = 0;
-    for (int64_t b = 0; b < B; ++b) {
-        job.h_w[b] = valid[b] ? std::exp(lw[b] - newref) : 0.0;
-        nfold += valid[b] ? 1 : 0;
-    }
-    std::memcpy(job.h_invN, out.invN.data(), (size_t)T * B * 8);
-    job.r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref);
-    job.first = ctx->acc_first ? 1 : 0;
-    job.B = B;
-    ctx->timing.accumulate_launches += 1;
-    ctx->acc_logref = newref;
-    ctx->acc_first = false;
-    ctx->acc_folded += nfold;
-    return true;
-}
-
-void launch_fold(blhip_ctx *ctx, int64_t T, long long G, const FoldJob &job, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-    const int64_t B = job.B;
-    HIPCHECK(hipMemcpyAsync(job.d_w, job.h_w, B * 8, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(job.d_invN, job.h_invN, (size_t)T * B * 8, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipEventRecord(ev0, st));
-    if (job.pad_n0p > 0) {
-        BL_LAUNCH(accumulate_pad_kernel, dim3((unsigned)((G + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
-                           job.d_post, (long long)T * job.pad_step, (int)B, job.pad_n0, job.pad_n1, (int)T, job.d_w, job.d_invN, job.r, job.first,
-                           job.pad_n0p, job.pad_step, job.pad_ax);
-    } else if (job.sm_n0 == 0 && B >= 16 && ((G / 2 + NTHREADS - 1) / NTHREADS) * T < 1024) {        // small grids: too few blocks with a thread per cell
-        BL_LAUNCH(accumulate_small_kernel, dim3((unsigned)((G + 63) / 64), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
-                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
-    } else if ((G & 1) == 0 && ((uintptr_t)ctx->acc & 15) == 0) {
-        const unsigned gx2 = (unsigned)((G / 2 + NTHREADS - 1) / NTHREADS);
-        BL_LAUNCH(accumulate2_kernel, dim3(gx2, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
-                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first, job.sm_n0);
-    } else {
-        if (job.sm_n0 > 0) fail("internal: strip-major sequences need an even number of cells and a 16-byte aligned accumulator");
-        const unsigned gx = (unsigned)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 4096);
-        BL_LAUNCH(accumulate_kernel, dim3(gx, (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc, job.d_post,
-                           (long long)T * G, (int)B, G, (int)T, job.d_w, job.d_invN, job.r, job.first);
-    }
-    HIPCHECK(hipEventRecord(ev1, st));
-}
-
-// the whole fold on the main stream, waited for
-// (later_ev: do not wait -- the fold stays in front of whatever the stream runs next, e.g. the next batch's metadata uploads and forward
-//  pass; its two timing events are appended for the caller to read after the stream has drained.  The page-locked staging of the weights is
-//  reused by the next batch's fold only after that batch's passes have been waited for, on the same stream.)
-void fold_accumulate(blhip_ctx *ctx, int64_t T, long long G, int64_t B, const BatchOutcome &out, const double *log_w_batch, const double *d_post,
-                     double *d_w, double *d_invN, int sm_n0 = 0, const FoldJob *layout = nullptr, std::vector<hipEvent_t> *later_ev = nullptr) {
-    ctx->pinA.ensure(((size_t)B + (size_t)T * B) * 8);
-    FoldJob job;
-    if (layout) job = *layout;
-    job.sm_n0 = sm_n0;
-    job.h_w = ctx->pinA.as<double>(); job.h_invN = job.h_w + B;
-    job.d_w = d_w; job.d_invN = d_invN; job.d_post = d_post;
-    if (!prepare_fold(ctx, T, B, out, log_w_batch, job)) return;
-    if (later_ev) {
-        hipEvent_t e0, e1;
-        HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
-        later_ev->push_back(e0); later_ev->push_back(e1);
-        launch_fold(ctx, T, G, job, ctx->stream, e0, e1);
-        return;
-    }
-    launch_fold(ctx, T, G, job, ctx->stream, ctx->ev[4], ctx->ev[5]);
-    sync_stream(ctx, ctx->stream);
-    float ms = 0;
-    HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
-    ctx->timing.accumulate_ms += ms;
-}
-
-// the batch's sequence stays on the device as the kept posterior; rows [row0, row1) still carry their raw sums (core.py:389 / :441)
-void keep_posterior(blhip_ctx *ctx, const Geometry &g, int64_t T, int64_t B, const BatchOutcome &out, int64_t row0, int64_t row1) {
-    hipStream_t st = ctx->stream;
-    ctx->postinv.ensure((size_t)T * B * 8);
-    HIPCHECK(hipMemcpyAsync(ctx->postinv.p, out.invN.data(), (size_t)T * B * 8, hipMemcpyHostToDevice, st));
-    sync_stream(ctx, st);
-    ctx->post_valid = true; ctx->post_scaled = false; ctx->post_chains = B; ctx->post_T = T; ctx->post_G = g.G;
-    ctx->post_row0 = row0; ctx->post_row1 = row1;
-    ctx->post_n0 = g.n0; ctx->post_n1 = g.n1;
-    // normalised now, as part of the fit (core.py:441 is inside Study.fit)
-    ensure_post_scaled(ctx); sync_stream(ctx, st);
-}
-
-void write_results(blhip_result *res, const blhip_problem *p, int64_t c0, int64_t B, const BatchOutcome &out, bool with_means) {
-    if (!res) return;
-    const int64_t T = p->T;
-    for (int64_t b = 0; b < B; ++b) {
-        if (res->log_evidence) res->log_evidence[c0 + b] = out.logE[b];
-        if (res->abort_step) res->abort_step[c0 + b] = out.abort_step[b];
-        if (res->abort_phase) res->abort_phase[c0 + b] = out.abort_phase[b];
-        if (res->local_evidence)
-            std::memcpy(res->local_evidence + (size_t)(c0 + b) * T, &out.local[(size_t)b * T], T * 8);
-        if (res->posterior_mean && with_means)
-            std::memcpy(res->posterior_mean + (size_t)(c0 + b) * p->ndim * T, &out.means[(size_t)b * p->ndim * T], (size_t)p->ndim * T * 8);
-    }
-}
-
-// The chain-resident path (blhip_chainres.hpp): which chains of the batch run together, in which order, with which band width.
-struct ChainResPlan {
-    int ntw = 0, strips = 0, cpr = 0;            // product tiles per wave, strips per chain, chains per launch
-    int n0p = 0, n1p = 0;                        // the geometry the kernels work on: rows 128 / 256 / 512, columns a multiple of 16
-    bool pad = false;                            // the grid is smaller than that (padded cells hold zeros; sequences private to the fit only)
-    int r0_max = 40;                             // widest axis-0 radius the launch may carry (set by the caller: 80 for 1024 rows)
-    bool has_reset = false;                      // change points: some steps consume the reset distribution
-    bool mixed = false;                          // ... in chains that also filter (random walk + change point in one model)
-    std::vector<unsigned char> ckF, ckB;         // [T][B] what a step of the chain kernels consumes: SRC_PREV / SRC_RESET (| 0x80: unfiltered)
-    std::vector<int> order, tap_id;              // chains sorted by stencil radius; the chain's axis-0 kernel (-1: none)
-    bool allow_ax1 = false;                      // (set by the caller) walks on the second parameter too may be planned: blc::chainax_kernel
-    bool ax1 = false;                            // ... and some chain has one: the batch runs the transposing kernels (square exact geometry)
-    std::vector<int> tap_id1;                    // the chain's axis-1 kernel (-1: none)
-    std::vector<int> round_start, round_nk;      // launches: order[round_start[r] .. round_start[r + 1]), band blocks NK
-};
-
-// every chain: prior, then the SAME axis-0 kernel at every step, nothing on axis 1 (forward; mirrored backward)
-bool plan_chainres(const Geometry &g, const ChainProgram &prog, const TapTable &taps, int64_t B, int64_t T, bool full, int cus, ChainResPlan &cp) {
-    // any grid of 32 .. 512 rows: the kernels work on the next geometry of 128 / 256 / 384 / 512 rows x a multiple of 16 columns;
-    // 513 .. 1024 rows: 1024 rows x a multiple of 16 columns (one copy of the strip in LDS: blc::chain_kernel TALL; change-point batches keep their state in registers there too)
-    if (!chain_rows_ok(g.n0)) return false;
-    cp.n0p = (g.n0 + 127) / 128 * 128;
-    cp.n1p = (g.n1 + blc::WCOL - 1) / blc::WCOL * blc::WCOL;
-    if (chain_tall(g.n0)) cp.n0p = CHAIN_TALL_ROWS;
-    cp.pad = cp.n0p != g.n0 || cp.n1p != g.n1;
-    cp.strips = cp.n1p / blc::WCOL;
-    cp.ntw = cp.n0p / (blc::NW * blc::TM);
-    if (cp.strips > blc::MAX_STRIPS || cp.strips > cus) return false;
-    cp.cpr = cus / cp.strips;
-    cp.tap_id.assign(B, -1);
-    cp.tap_id1.assign(B, -1);
-    cp.ax1 = false;
-    // walks on both parameters (blhip_chainax.hpp): an exact square geometry (the blocks of a chain change between column strips and row strips)
-    // -- the next square geometry of 128 / 256 / 512 rows = columns that holds the grid (PAD kernels where it is larger)
-    const int ax_n = std::max(g.n0, g.n1) <= 128 ? 128 : (std::max(g.n0, g.n1) <= 256 ? 256 : 512);
-    const bool ax1_geom = cp.allow_ax1 && std::max(g.n0, g.n1) <= 512 && g.n0 >= 32 && g.n1 >= 32 && ax_n / blc::WCOL <= cus;
-    std::vector<int> lw(B, 0);
-    cp.ckF.assign((size_t)T * B, (unsigned char)SRC_PREV);
-    cp.ckB.assign((size_t)T * B, (unsigned char)SRC_PREV);
-    for (int64_t b = 0; b < B; ++b) {
-        if (prog.kindF[b] != SRC_PRIOR || prog.tapF0[b] >= 0 || prog.tapF1[b] >= 0) return false;
-        // the chain's band: the kernel of the first step that filters (every filtering step must use the same one)
-        int k0 = -1, k1 = -1;
-        for (int64_t t = 1; t < T && k0 < 0; ++t) k0 = prog.tapF0[(size_t)t * B + b];
-        for (int64_t t = 0; t + 1 < T && k0 < 0 && full; ++t) k0 = prog.tapB0[(size_t)t * B + b];
-        if (ax1_geom) {
-            for (int64_t t = 1; t < T && k1 < 0; ++t) k1 = prog.tapF1[(size_t)t * B + b];
-            for (int64_t t = 0; t + 1 < T && k1 < 0 && full; ++t) k1 = prog.tapB1[(size_t)t * B + b];
-        }
-        // a step either continues from the previous state through the chain's band, or RESTARTS from the reset distribution (a
-        // change point, transitionModels.py:300-312) -- through the band (the change point comes before the random walk in the
-        // combined model's list) or unfiltered (it comes after: the walk's output is discarded)
-        auto classify = [&](unsigned char kind, int t0, int t1, unsigned char &out) {
-            // (k1 = -1 unless the both-axes kernels may be planned; a restart passes through BOTH of the chain's bands or through none)
-            if (kind == SRC_PREV && t0 == k0 && t1 == k1) { out = (unsigned char)SRC_PREV; return true; }
-            if (kind == SRC_RESET && ((t0 == k0 && t1 == k1) || (t0 < 0 && t1 < 0))) {
-                const bool filters = k0 >= 0 || k1 >= 0;
-                out = (unsigned char)(SRC_RESET | ((filters && t0 < 0 && t1 < 0) ? 0x80 : 0));          // bit 7: no filter at this step
-                cp.has_reset = true;
-                if (filters) cp.mixed = true;
-                return true;
-            }
-            return false;
-        };
-        for (int64_t t = 1; t < T; ++t) {
-            const size_t k = (size_t)t * B + b;
-            if (!classify(prog.kindF[k], prog.tapF0[k], prog.tapF1[k], cp.ckF[k])) return false;
-        }
-        if (full) {
-            const size_t kl = (size_t)(T - 1) * B + b;
-            if (prog.kindB[kl] != SRC_UNIFORM || prog.tapB0[kl] >= 0 || prog.tapB1[kl] >= 0) return false;
-            for (int64_t t = 0; t < T - 1; ++t) {
-                const size_t k = (size_t)t * B + b;
-                if (!classify(prog.kindB[k], prog.tapB0[k], prog.tapB1[k], cp.ckB[k])) return false;
-            }
-        }
-        cp.tap_id[b] = k0;
-        cp.tap_id1[b] = k1;
-        lw[b] = k0 >= 0 ? taps.lw[k0] : 0;
-        if (lw[b] > cp.r0_max || lw[b] >= g.n0) return false;          // (single-period reflection)
-        if (k1 >= 0) {
-            cp.ax1 = true;
-            if (taps.lw[k1] >= g.n1) return false;
-            lw[b] = std::max(lw[b], taps.lw[k1]);                       // (one ring length for both filters: the wider walk's)
-        }
-    }
-    if (cp.ax1) {
-        // the transposing kernels: bands of radius <= 40 on either axis (ring lengths 8 .. 24 in steps of 4; the band's rounded radius inside
-        // the grid: single-period reflection); the square geometry replaces the strip geometry planned above
-        for (int64_t b = 0; b < B; ++b) if (lw[b] > FAST_R0_MAX || (std::max(8, (lw[b] + 7) / 8 * 8)) >= std::min(g.n0, g.n1)) return false;
-        cp.n0p = cp.n1p = ax_n;
-        cp.strips = ax_n / blc::WCOL;
-        cp.ntw = ax_n / (blc::NW * blc::TM);
-        cp.pad = ax_n != g.n0 || ax_n != g.n1;
-        cp.cpr = cus / cp.strips;
-    }
-    cp.order.resize(B);
-    for (int64_t b = 0; b < B; ++b) cp.order[b] = (int)b;
-    std::stable_sort(cp.order.begin(), cp.order.end(), [&](int a, int c) { return lw[a] < lw[c]; });
-    cp.round_start.clear(); cp.round_nk.clear();
-    for (int64_t s0 = 0; s0 < B; s0 += cp.cpr) {
-        const int64_t s1 = std::min<int64_t>(B, s0 + cp.cpr);
-        int r0 = std::max(4, (lw[cp.order[s1 - 1]] + 3) / 4 * 4);             // (a product costs 64 cycles: bands as narrow as the widest chain of the launch allows)
-        if (cp.ax1) r0 = std::max(8, (r0 + 7) / 8 * 8);                        // (ring lengths 8, 12, .. 24)
-        cp.round_start.push_back((int)s0);
-        cp.round_nk.push_back((prog.LW0 == 0 && !cp.ax1) ? 4 : (blc::TM + 2 * r0) / 4);          // (4: the no-stencil kernel)
-    }
-    cp.round_start.push_back((int)B);
-    return true;
-}
-
-// Undo the lagged scale of the time-resident kernel (blhip_resident.hpp): its step k divided by the sum of step k - lag, so its row
-// sums are S_k; the reference's normaliser is norm_k = S_k / (S_{k-1} s_k), s_k = k >= lag ? 1 / S_{k-lag} : 1.  The sums of every step
-// are rewritten to what the launch-per-step kernels (lag 1) would have reported; rowsum keeps S_k, the normaliser of the stored row.
-// false: a sum near the bottom / top of the fp64 range (a run of extreme outliers times the lag) -> the caller falls back to the
-// launch-per-step kernels, whose magnitudes are the reference's.
-bool resident_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B = 1, int64_t b = 0) {
-    rowsum.assign(T, 0.0);
-    for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[((size_t)t * B + b) * NRED];
-    for (int64_t t = 0; t < T; ++t) {
-        const double St = rowsum[t];
-        if (!(St > 1e-150 && St < 1e150)) return false;
-        const double sk = t >= lag ? 1.0 / rowsum[t - lag] : 1.0;
-        const double norm = t == 0 ? St : St / (rowsum[t - 1] * sk);
-        double *r = &redF[((size_t)t * B + b) * NRED];
-        r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
-    }
-    return true;
-}
-
-// The same for the chain-resident kernel (blhip_chainres.hpp), whose step k divides by the normaliser of step k - lag:
-// s_k = S_(k-lag-1) s_(k-lag) / S_(k-lag)  (1 while k < lag; S_(-1) = 1).
-// kinds (may be null): a step whose source kind is not SRC_PREV consumed a distribution of known mass instead of the previous
-// state: its normaliser is S_k / s_k.
-bool chain_unlag(double *redF, int64_t T, int lag, std::vector<double> &rowsum, int64_t B, int64_t b, std::vector<double> *scales = nullptr,
-                 const unsigned char *kinds = nullptr, int64_t t0 = 0) {
-    // t0 > 0 (blc::ChainParams::skip_prefix): the chain's own pass began at step t0 -- the rows before it are another chain's (same
-    // values, that chain's scale history), the scale history of the rows from t0 on starts there (s = 1 for lag steps, S_(t0 - 1) := 1)
-    rowsum.assign(T, 0.0);
-    for (int64_t t = 0; t < T; ++t) rowsum[t] = redF[((size_t)t * B + b) * NRED];
-    std::vector<double> s_local;
-    std::vector<double> &s = scales ? *scales : s_local;
-    s.assign(T, 1.0);
-    for (int64_t t = 0; t < T; ++t) {
-        const double St = rowsum[t];
-        if (!(St > 1e-150 && St < 1e150)) return false;
-        const int64_t base = t >= t0 ? t0 : 0;                                 // first step of the scale history this step belongs to
-        if (t - base >= lag) s[t] = (t - lag - 1 >= base ? rowsum[t - lag - 1] : 1.0) * s[t - lag] / rowsum[t - lag];
-        const bool fresh = t == 0 || (kinds && kinds[(size_t)t * B + b] != SRC_PREV);
-        const double norm = fresh ? St / s[t] : St / (rowsum[t - 1] * s[t]);
-        double *r = &redF[((size_t)t * B + b) * NRED];
-        r[0] = norm; r[3] *= norm / St; r[4] *= norm / St;
-    }
-    return true;
-}
-
-// evidence bookkeeping of the forward pass on the host, in the reference's order (core.py:385-404, 417); K > 1: raw sums of the
-// K-steps-per-launch 1-D kernels.  -> false if such a raw sum came near the bottom of the fp64 range (the caller repeats with K = 1)
-bool forward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, const double *redF, int64_t B, double dV, bool fused1d, int64_t K,
-                         bool evidence_only, bool forward_only, BatchOutcome &O) {
-    const int64_t T = p->T;
-    O.logE.assign(B, 0.0);
-    O.abort_step.assign(B, -1);
-    O.abort_phase.assign(B, 0);
-    O.local.assign((size_t)B * T, 0.0);
-    bool raw_ok = true;
-    // (step by step over all chains: the sums of a step are B consecutive records -- chain by chain every read was a cache line of
-    //  its own, 8 ms of the published break-point study's 23 batches of 1017 chains x 41 steps.  Per chain the order of the
-    //  operations is the one of the reference's loop)
-    std::vector<double> &le = O.logE;
-    for (int64_t t = 0; t < T; ++t) {
-        const double *rt = redF + (size_t)t * B * NRED;
-        for (int64_t b = 0; b < B; ++b) {
-            if (O.abort_step[b] >= 0) continue;
-            double norm = rt[b * NRED + 0];
-            if (fused1d) {
-                // raw sums of the K-step launches (blhip_fused1d.hpp): inner steps carry the scale of their predecessor
-                if (!(norm > 1e-200)) raw_ok = false;
-                if (t % K != 0 && prog.kindF[(size_t)t * B + b] == SRC_PREV) norm /= redF[((size_t)(t - 1) * B + b) * NRED];
-            }
-            // RegimeSwitch renormalises the clamped prior (transitionModels.py:410): alpha = (u / sum u) L
-            if (prog.has_clamp && prog.cmodeF[(size_t)t * B + b]) norm /= rt[b * NRED + 1];
-            if (!(norm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 0; le[b] = -INFINITY; continue; }
-            le[b] += std::log(norm);
-            O.local[(size_t)b * T + t] = norm * dV;
-        }
-    }
-    const double ldv = std::log(dV);
-    for (int64_t b = 0; b < B; ++b)
-        if (O.abort_step[b] < 0) le[b] += ldv;
-    O.means.clear();
-    if (!evidence_only) O.means.assign((size_t)B * p->ndim * T, 0.0);
-    if (forward_only) {
-        for (int64_t b = 0; b < B; ++b)
-            for (int64_t t = 0; t < T; ++t) {
-                const double *r = &redF[((size_t)t * B + b) * NRED];
-                for (int k = 0; k < p->ndim; ++k) O.means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
-            }
-    }
-    return raw_ok;
-}
-
-// bookkeeping of the backward pass (core.py:441-464, 480-483): abort test, local evidence, row normalisers, posterior means.
-// rows_done_from >= 0: rows t >= rows_done_from were normalised by the resident kernel itself (their invN is 1).
-bool backward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, const double *redF, const double *redB, int64_t B, double dV,
-                          bool fused1d, int64_t rows_done_from, BatchOutcome &O) {
-    const int64_t T = p->T;
-    bool raw_ok = true;
-    for (int64_t t = T - 1; t >= 0; --t) {           // (step by step over all chains: see forward_bookkeeping)
-        for (int64_t b = 0; b < B; ++b) {
-            if (O.abort_step[b] >= 0) continue;
-            const double *r = &redB[((size_t)t * B + b) * NRED];
-            if (fused1d && !(r[0] > 1e-200)) raw_ok = false;
-            // The reference tests sum(alpha_norm * beta_norm) > 0 (core.py:441).  r[0] is the same sum up to the lazily
-            // dropped normalisers, which are positive -- except with signed kernels (Deterministic's cubic-spline
-            // shift, AlphaStable's FFT kernel): there sum(alpha) = redF[t][0] and sum(beta) = r[5] may be negative and
-            // the reference divides by them, so the sign test has to include them.
-            double refnorm = r[0];
-            if (prog.has_clamp) refnorm = r[0] / (redF[((size_t)t * B + b) * NRED] * (prog.cmodeB[(size_t)t * B + b] ? r[5] : 1.0));
-            if (!(refnorm > 0.0)) { O.abort_step[b] = t; O.abort_phase[b] = 1; O.logE[b] = -INFINITY; continue; }
-            O.local[(size_t)b * T + t] = 1.0 / ((r[1] / r[0]) * dV);                      // core.py:463-464
-            O.invN[(size_t)b * T + t] = (rows_done_from >= 0 && t >= rows_done_from) ? 1.0 : 1.0 / r[0];
-            for (int k = 0; k < p->ndim; ++k) O.means[((size_t)b * p->ndim + k) * T + t] = r[3 + k] / r[0];
-        }
-    }
-    return raw_ok;
-}
-
-// ---- what the launches move and compute BY CONSTRUCTION (blhip_timing: fwd / bwd _hbm_bytes, _flops) ------------------------------------
-// fp64 flop per cell of the fused epilogues (FMA = 2; ldexp, compare and select count 1): forward  a = v L (1), sum (1), the two
-// recurrence products (2), ldexp (1) + the exponentials of the anchors spread over their rows (2 x ~42 flop per 16 rows: 5);
-// backward: beta, p, c (3), p / L by the reciprocal recurrence (2), three sums (3), the fold's product, max, add (3), four recurrence
-// products (4), ldexp (1) + four exponentials per 16 rows (10)
-constexpr double EPI_FWD_FLOP = 10.0, EPI_BWD_FLOP = 26.0;
-// a radius-r stencil pass per cell: on the vector ALU (SciPy's pair order) r adds + 1 product + r FMAs; as a banded product on the
-// matrix pipe (16 output rows per tile) 16 + 2 r products, zeros of the band included
-inline double valu_stencil_flop(int r) { return r > 0 ? 3.0 * r + 1.0 : 0.0; }
-inline double band_stencil_flop(int r) { return 2.0 * (16.0 + 2.0 * r); }
-inline void account(blhip_ctx *ctx, bool bwd, double bytes, double flops) {
-    (bwd ? ctx->timing.bwd_hbm_bytes : ctx->timing.fwd_hbm_bytes) += bytes;
-    (bwd ? ctx->timing.bwd_flops : ctx->timing.fwd_flops) += flops;
-}
-
+#include "blhip_program.hpp"   // TapTable, Geometry, validate, build_records, build_program
+#include "blhip_launch.hpp"    // Tile, launch_* (the launch tables), plan_resident
+#include "blhip_batch.hpp"     // plan_batches, upload_tables / _metadata, chains_per_batch, plan_geometry, plan_chainres, folds, results
+#include "blhip_book.hpp"      // resident_unlag / chain_unlag, forward_ / backward_bookkeeping, account
 #include "blhip_fit_nd.hpp"       // do_fit_nd: grids with 3 and 4 parameters
 #include "blhip_fit_paths.hpp"    // BatchEnv, ResidentRun, ChainRun: the resident paths of a batch
 

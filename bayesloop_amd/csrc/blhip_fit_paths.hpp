@@ -57,20 +57,26 @@ bool resident_gave_up(blhip_ctx *ctx, hipStream_t st, const unsigned *d_abort) {
 // resident launch would sit out its time-out (>= 0.25 s) before the fit fell back.  ~15 us when the chip is free.
 bool chip_is_ours(blhip_ctx *ctx) {
     hipStream_t st = ctx->stream;
-    ctx->pinS.ensure(64);
+    ctx->pinS.ensure((8 + 256) * sizeof(unsigned));
     unsigned *h = reinterpret_cast<unsigned *>(ctx->pinS.as<char>());
     DevBuf &d = ctx->probebuf;
-    d.ensure(64);
-    HIPCHECK(hipMemsetAsync(d.p, 0, 64, st));
+    const size_t pbytes = (8 + 256) * sizeof(unsigned);
+    d.ensure(pbytes);
+    HIPCHECK(hipMemsetAsync(d.p, 0, pbytes, st));
     const unsigned nb = (unsigned)std::min(ctx->num_cus, 256);
     const size_t lds = 150 * 1024;
     arm_kernel(reinterpret_cast<const void *>(&blr::residency_probe_kernel<0>));
     const unsigned long long ticks = (unsigned long long)(std::max(1e-4, ctx->option("resident_probe_timeout_s", 0.002)) * 1e8);
     BL_LAUNCH(blr::residency_probe_kernel<0>, dim3(nb), dim3(512), lds, st, d.as<unsigned>(), nb, ticks);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(h, d.p, pbytes, hipMemcpyDeviceToHost, st));
     sync_stream(ctx, st);
-    ctx->xcd_order_ok = h[2] == 0u;
+    // the dispatch order the both-axes kernels count on: blocks b, b + 8, b + 16, ... on ONE XCD, eight different ones for b = 0 .. 7
+    bool order = nb >= 8;
+    for (unsigned b = 0; b < nb && order; ++b) order = h[8 + b] != 0u && h[8 + b] == h[8 + (b & 7u)];
+    for (unsigned a = 0; a < 8 && order; ++a)
+        for (unsigned c = a + 1; c < 8 && order; ++c) order = h[8 + a] != h[8 + c];
+    ctx->xcd_order_ok = order;
     return h[0] == nb && h[1] == 0u && ctx->option("resident_probe_force_busy", 0.0) == 0.0;
 }
 

@@ -1191,8 +1191,8 @@ __global__ __launch_bounds__(TR *TC / SEG) void resident_kernel(const ResParams 
 // arrive; a launch then sits out its whole time-out before the fit falls back (>= 0.25 s -- a 1000 x cliff for a millisecond fit).
 // This probe asks the question in microseconds: a grid of one block per CU with the resident kernels' footprint (512 threads, the whole
 // register file -- the empty asm touches v255 --, `lds` bytes of dynamic LDS); lane 0 of every block counts itself in and waits until
-// all have, at most `timeout_ticks`.  out[0] = blocks that arrived, out[1] = 1 if a block gave up, out[2] = blocks NOT on XCD
-// blockIdx % 8 (the placement the both-axes kernels' plain-store exchange relies on for liveness: ADVICE r05).
+// all have, at most `timeout_ticks`.  out[0] = blocks that arrived, out[1] = 1 if a block gave up, out[8 + b] = 1 + the XCD block b ran
+// on (HW_REG_XCC_ID): the both-axes kernels' plain-store exchange relies on blocks b, b + 8, b + 16, .. sharing an XCD.
 template <int FOOTPRINT = 0>          // (a template: this header is part of every translation unit of the library, the kernel of the one that launches it)
 __global__ __launch_bounds__(512, 1) void residency_probe_kernel(unsigned *out, unsigned nblocks, unsigned long long timeout_ticks) {
     extern __shared__ __attribute__((aligned(16))) double lds_probe[];
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(512, 1) void residency_probe_kernel(unsigned *out, 
     if (threadIdx.x == 0) {
         lds_probe[0] = 0.0;
         const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;          // HW_REG_XCC_ID, 4 bits
-        if (xcc != (blockIdx.x & 7u)) atomicAdd(&out[2], 1u);
+        out[8 + blockIdx.x] = xcc + 1u;                       // (the host compares the blocks of a residue class: the ids need not BE the residues)
         __hip_atomic_fetch_add((gu32 *)(unsigned long long)&out[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = now_ticks();
         while (ld_flag(&out[0]) < nblocks) {
