@@ -161,7 +161,7 @@ LAST_ACTION = [None]        # 'reused' / 'compiled': what the last build() call 
 
 def build(force=False, verbose=True):
     """-> path of libblhip.so.  The binary is git-ignored and travels with a push of the working tree: where it is present and newer than
-    every source this is a no-op ('reused'); on a fresh clone it is a ~2-minute compile of 20 translation units ('compiled')."""
+    every source this is a no-op ('reused'); on a fresh clone it is a ~2-minute compile of 23 translation units ('compiled')."""
     if not force and not stale():
         LAST_ACTION[0] = 'reused'
         return OUT
