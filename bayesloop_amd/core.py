@@ -1395,6 +1395,9 @@ class OnlineStudy(HyperStudy):
                                          'contains such a model); user-defined transition models are supported by Study.fit and '
                                          'HyperStudy.fit only.'.format(type(tm).__name__))
             program = self._expandProgram(tm._program(om.parameterNames), 1)
+            if len(self.gridSize) > 2 and not all(op[0] in (_abi.OP_GRW, _abi.OP_STATIC, _abi.OP_CHANGEPOINT) and op[4] < 0 for op in program):
+                raise ConfigurationError('Observation models with more than two parameters can be combined with GaussianRandomWalk, '
+                                         'Static and ChangePoint transition models.')
             # every step is a one-step problem resumed at t = -1 (core.py:2164-2165): the op values never change
             op_values = self._opValueMatrix(program, np.asarray(hpv, dtype=float) if len(hpv) > 0 else np.zeros((1, 0)),
                                             timestamps=[0.0], resume_time=-1.0)
@@ -1440,9 +1443,9 @@ class OnlineStudy(HyperStudy):
         nTM = len(self.transitionModels)
 
         if self.firstStep:
-            if len(self.gridSize) not in (1, 2):
-                raise ConfigurationError('The MI355X engine supports observation models with 1 or 2 parameters '
-                                         '(got {}).'.format(len(self.gridSize)))
+            if not 1 <= len(self.gridSize) <= _abi.MAX_DIM:
+                raise ConfigurationError('The MI355X engine supports observation models with 1 to {} parameters '
+                                         '(got {}).'.format(_abi.MAX_DIM, len(self.gridSize)))
             self._prior = self._computePrior(silent=False)
             if self.transitionModelPrior is None:
                 self.transitionModelPrior = np.ones(nTM) / nTM

@@ -8,7 +8,8 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
     HIPCHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const FitFlags ff = decode_flags(ctx, p, flags, log_w);
-    if (ff.resume || ff.carry) fail("streaming fits (BLHIP_RESUME / BLHIP_CARRY) are not available on grids with %d parameters", p->ndim);
+    // (streaming fits -- OnlineStudy.step, core.py:2062-2226, which has no limit on the grid's dimensions: step 0 consumes the chains'
+    //  carried states through the transition evaluated at resume_time, the last step's filtered distributions are kept normalised)
     const int64_t T = p->T;
     bln::NdGrid ng{};
     ng.ndim = p->ndim;
@@ -51,6 +52,16 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
     int64_t Bmax = (int64_t)std::max(1.0, std::floor(budget / per_chain));
     Bmax = std::min<int64_t>(std::min<int64_t>(Bmax, (int64_t)ctx->option("max_batch", 1024)), 65535);
     if (ff.keep && n_chains > Bmax) fail("BLHIP_KEEP_POSTERIOR: %lld chains do not fit in device memory at once", (long long)n_chains);
+    if ((ff.resume || ff.carry) && n_chains > Bmax) fail("carried states: %lld chains do not fit in one batch", (long long)n_chains);
+    const double *d_carry_src = nullptr;
+    if (ff.resume) {
+        auto it = ctx->carry.find(p->carry_slot);
+        if (it == ctx->carry.end() || !it->second.valid) fail("BLHIP_RESUME: carry slot %d holds no state", p->carry_slot);
+        if (it->second.chains != n_chains || it->second.G != G)
+            fail("BLHIP_RESUME: carry slot %d holds %lld chains x %lld cells, the call has %lld x %lld", p->carry_slot,
+                 (long long)it->second.chains, (long long)it->second.G, (long long)n_chains, (long long)G);
+        d_carry_src = it->second.buf.as<double>();
+    }
     const int nblk = (int)std::min<long long>((G + NTHREADS - 1) / NTHREADS, 256);
     std::vector<int> grw_ops;                       // the random walks of the program, in list order (transitionModels.py:645-649)
     bool time_dependent = false;
@@ -97,7 +108,8 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
             };
             for (int64_t t = 0; t < T; ++t) {
                 const size_t k = (size_t)t * B + b;
-                if (t == 0) kindF[k] = SRC_PRIOR;                                       // core.py:363
+                if (t == 0 && ff.resume) run(true, p->resume_time, kindF[k], &tapF[k], nT);       // continues a carried state (core.py:2164-2165)
+                else if (t == 0) kindF[k] = SRC_PRIOR;                                  // core.py:363
                 else run(time_dependent, time_dependent ? p->timestamps[t - 1] : 0.0, kindF[k], &tapF[k], nT);          // core.py:411
                 if (t == T - 1) kindB[k] = SRC_UNIFORM;
                 else run(time_dependent, time_dependent ? p->timestamps[t + 1] - 1.0 : 0.0, kindB[k], &tapB[k], nT);    // core.py:467, transitionModels.py:316-317
@@ -131,7 +143,7 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
             pst[b] = d_state + (size_t)b * G; pt0[b] = d_tmp[0] + (size_t)b * G; pt1[b] = d_tmp[1] + (size_t)b * G;
             for (int64_t t = 0; t < T; ++t) {
                 const size_t k = (size_t)t * B + b;
-                src0F[k] = kindF[k] == SRC_PREV ? pst[b] : (kindF[k] == SRC_PRIOR ? d_prior : d_reset);
+                src0F[k] = kindF[k] == SRC_PREV ? ((t == 0 && ff.resume) ? d_carry_src + (size_t)b * G : pst[b]) : (kindF[k] == SRC_PRIOR ? d_prior : d_reset);
                 src0B[k] = kindB[k] == SRC_PREV ? pst[b] : (kindB[k] == SRC_UNIFORM ? d_uniform : d_reset);
             }
         }
@@ -177,9 +189,19 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
         double *d_psF = ctx->psumF.as<double>();
         const size_t per_step = (size_t)B * NRED * nblk;
         float ms = 0;
+        // BLHIP_RESUME: the carried states are normalised -- the "partial sums of the step before" add up to 1
+        const double *d_unit = nullptr;
+        if (ff.resume) {
+            std::vector<double> unit(per_step, 0.0);
+            for (int64_t b = 0; b < B; ++b) unit[(size_t)b * NRED * nblk] = 1.0;
+            ctx->unit.ensure(unit.size() * 8);
+            HIPCHECK(hipMemcpyAsync(ctx->unit.p, unit.data(), unit.size() * 8, hipMemcpyHostToDevice, st));
+            sync_stream(ctx, st);
+            d_unit = ctx->unit.as<double>();
+        }
         // ---- forward pass (core.py:372-411) ---------------------------------------------------------------------------------------------
         HIPCHECK(hipEventRecord(ev[0], st));
-        for (int64_t t = 0; t < T; ++t) step(false, t, t > 0 ? d_psF + (size_t)(t - 1) * per_step : d_psF, d_psF + (size_t)t * per_step);
+        for (int64_t t = 0; t < T; ++t) step(false, t, t > 0 ? d_psF + (size_t)(t - 1) * per_step : (d_unit ? d_unit : d_psF), d_psF + (size_t)t * per_step);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(ev[1], st));
         BL_LAUNCH(reduce_partials_kernel, dim3((unsigned)(nT * NRED)), dim3(NTHREADS), 0, st, d_psF, ctx->redF.as<double>(), nblk, 0);      // (0: every slot is a sum -- slot 6 is the 4th parameter's mean here)
@@ -214,6 +236,8 @@ void do_fit_nd(blhip_ctx *ctx, const blhip_problem *p, int64_t n_chains, const d
                     O.invN[(size_t)b * T + t] = (n0 != 0.0 && std::isfinite(n0)) ? 1.0 / n0 : 0.0;
                 }
         }
+        // BLHIP_CARRY: every chain's filtered distribution of the last step, normalised (core.py:2173)
+        if (ff.carry) store_carry(ctx, p, B, G, redF, d_post ? d_post + (size_t)(T - 1) * G : d_state, d_post ? (long long)T * G : G, d_w, false);
         if (ff.accumulate) fold_accumulate(ctx, T, G, B, O, log_w + c0, d_post, d_w, d_invN);
         if (ff.keep) {
             Geometry g2{};

@@ -335,6 +335,12 @@ ONLINE_CASES = {
     'online_deterministic': dict(om=('Poisson', [('rate', _g('oint', 0, 6, 120))], 'default'),
                                  models=[('static', ('Static',)), ('drift', ('Deterministic', 'quadratic', 'rate'))],
                                  data=COAL[60:75].tolist()),
+    # three parameters (the reference's SciPy plug-in: Student's t with df, loc, scale; core.py:2062-2226 has no limit on the grid's dimensions)
+    'online_scipy_t3': dict(om=('SciPy:t', [('df', _g('cint', 2.0, 8.0, 4)), ('loc', _g('cint', -3.0, 3.0, 14)), ('scale', _g('oint', 0.2, 2.5, 10))], 'default'),
+                            models=[('static', ('Static',)),
+                                    ('walks', ('Combined', [('GRW', 's_loc', [0.3, 0.6], 'loc', None), ('GRW', 's_scale', 0.2, 'scale', None)])),
+                                    ('cp', ('ChangePoint', 'tc', [-1, 2], None))],
+                            tm_prior=[0.4, 0.4, 0.2], data=('series', 97, 7)),
     'online_ar1_wait': dict(om=('AR1', [('rho', _g('oint', -1, 1, 30)), ('sigma', _g('oint', 0, 1, 25))], 'default'),
                             models=[('static', ('Static',)), ('walk', ('GRW', 's', [0.05, 0.1], 'rho', None))],
                             data=[1, 0, 1, 0, 0, 1]),

@@ -200,10 +200,19 @@ def run_online(case):
     """The oracle's restatement of OnlineStudy.step over an ONLINE_CASES entry -> per-step results like the golden file."""
     c = cases.ONLINE_CASES[case] if isinstance(case, str) else case
     om_cls, params, prior_spec = c['om']
-    om = OM_NAME[om_cls]
+    scipy_rv = None
+    if om_cls.startswith('SciPy:'):           # plug-in model (any number of parameters): the distribution's own pdf, flat prior by default
+        import scipy.stats
+        scipy_rv = getattr(scipy.stats, om_cls.split(':')[1])
+        om = 'table'
+    else:
+        om = OM_NAME[om_cls]
     g = orc.Grid([cases.make_values(_Orc, v) for _, v in params])
     pnames = [p[0] for p in params]
-    prior_obj = orc.jeffreys(om) if prior_spec == 'default' else cases.make_prior(prior_spec)
+    if scipy_rv is not None:
+        prior_obj = None if prior_spec == 'default' else cases.make_prior(prior_spec)
+    else:
+        prior_obj = orc.jeffreys(om) if prior_spec == 'default' else cases.make_prior(prior_spec)
     prior = orc.compute_prior(g, prior_obj)
     reset = orc.changepoint_prior(g, prior_obj)
     specs = c.get('models') or [('transition model', c['set_tm'])]
@@ -225,7 +234,7 @@ def run_online(case):
         models.append(dict(ops=ops, values=[orc.align_values(ops, row) for row in hv], prior_values=pv, grid_constants=const,
                            reset=reset, indep=reset / np.prod(g.lattice)))
     state = orc.OnlineState(g, prior, models, c.get('tm_prior'))
-    seg = orc.OM_INFO[om][0]
+    seg = 1 if scipy_rv is not None else orc.OM_INFO[om][0]
     raw = np.asarray(cases.online_data(c), dtype=float)
     out = dict(posteriorSequence=[], posteriorMeanValues=[], transitionModelSequence=[], localTransitionModelSequence=[],
                hyperParameterSequence=[])
@@ -233,7 +242,11 @@ def run_online(case):
         if k + 1 < seg:
             continue
         with np.errstate(all='ignore'):
-            r = orc.online_step(state, om, raw[k + 1 - seg:k + 1])
+            lik = None
+            if scipy_rv is not None:           # ObservationModel.processedPdf (observationModels.py:35-56): a NaN leaves the step without information
+                x = raw[k]
+                lik = np.ones(g.size) if np.isnan(x) else scipy_rv.pdf(x, **dict(zip(pnames, g.grid))) * np.ones(g.size)
+            r = orc.online_step(state, om, raw[k + 1 - seg:k + 1], lik=lik)
         out['posteriorSequence'].append(r['marginalizedPosterior'])
         out['posteriorMeanValues'].append(r['posteriorMeanValues'])
         out['transitionModelSequence'].append(r['transitionModelDistribution'])
