@@ -62,6 +62,8 @@ def check(res, gold, tol, aborted_ok=True, case_tol=None):
         n_loose = int(np.isfinite(want_l[..., loose]).sum())
         COUNTS['local_loosened'] += n_loose
         COUNTS['local_at_bar'] += int(np.isfinite(want_l).sum()) - n_loose
+        if (case_tol or {}).get('local_pinned'):        # hyper-studies: every chain's sum over the well-conditioned cells was compared at the bar (the caller did it)
+            COUNTS['local_partial'] += n_loose
         # What the loosened entries leave open, pinned at the bar: localEvidence = 1 / (sum(post / L) dV) (core.py:463) is ill-conditioned
         # only through the cells whose likelihood is DENORMAL (1 .. 52 significant bits); the sum over all other cells, formed the
         # same way on both sides from the step's posterior and likelihood, must agree to 1e-9.
