@@ -439,17 +439,28 @@ void upload_metadata(blhip_ctx *ctx, const blhip_problem *p, const ChainProgram 
     M.w = carve<double>(cur, B);
     M.dump = carve<double>(cur, 4 * NTHREADS);   // (the halo wave of an H block spreads its dummy stores over 8 x 64 slots)
     HIPCHECK(hipMemcpyAsync(M.kindF, prog.kindF.data(), nT, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(M.tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
+    // (what a batch does not use is not copied: on 1-D grids every walk acts on the internal column axis -- the row-axis tap ids are all -1, a
+    //  memset --, and the clamp levels exist only for RegimeSwitch / NotEqual: the published break-point study, 23 400 chains x 41 steps with
+    //  Deterministic shifts only, uploaded 6.7 MB of metadata per batch from pageable memory, 0.9 ms each, 2.7 MB of it zeros)
+    const bool one_d = p->ndim == 1;
+    if (one_d) HIPCHECK(hipMemsetAsync(M.tapF0, 0xFF, nT * 4, st));
+    else HIPCHECK(hipMemcpyAsync(M.tapF0, prog.tapF0.data(), nT * 4, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(M.tapF1, prog.tapF1.data(), nT * 4, hipMemcpyHostToDevice, st));
     if (prog.has_clamp) {
         HIPCHECK(hipMemcpyAsync(M.cmodeF, prog.cmodeF.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.limitF, prog.limitF.data(), nT * 8, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(M.cmodeB, prog.cmodeB.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.limitB, prog.limitB.data(), nT * 8, hipMemcpyHostToDevice, st));
+        if (prog.other_clamp) {
+            HIPCHECK(hipMemcpyAsync(M.limitF, prog.limitF.data(), nT * 8, hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(M.limitB, prog.limitB.data(), nT * 8, hipMemcpyHostToDevice, st));
+        } else {
+            HIPCHECK(hipMemsetAsync(M.limitF, 0, nT * 8, st));
+            HIPCHECK(hipMemsetAsync(M.limitB, 0, nT * 8, st));
+        }
     }
     if (full) {
         HIPCHECK(hipMemcpyAsync(M.kindB, prog.kindB.data(), nT, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(M.tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
+        if (one_d) HIPCHECK(hipMemsetAsync(M.tapB0, 0xFF, nT * 4, st));
+        else HIPCHECK(hipMemcpyAsync(M.tapB0, prog.tapB0.data(), nT * 4, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(M.tapB1, prog.tapB1.data(), nT * 4, hipMemcpyHostToDevice, st));
     }
     if (fast) {

@@ -74,7 +74,20 @@ class DevicePosterior:
     def __init__(self, engine, source, T, grid_size, chain=0):
         self.engine, self.source, self.T, self.grid_size, self.chain = engine, source, T, list(grid_size), chain
 
+    _hinted = [False]
+
     def __call__(self):
+        # The whole (T, *gridSize) array crosses PCIe here (BASELINE C3: 16 GiB, 14 x the time of the fit itself).  What the reference's
+        # users do with posteriorSequence next is almost always a reduction the device has already (getParameterDistributions / plot:
+        # marginals; getParameterMeanValues; simulate: time average; getParameterDistribution(t, ...): one row) -- say so once.
+        nbytes = 8 * self.T * int(np.prod(self.grid_size))
+        if nbytes >= (1 << 30) and not DevicePosterior._hinted[0] and os.environ.get('BLHIP_QUIET', '') != '1':
+            DevicePosterior._hinted[0] = True
+            import sys
+            sys.stderr.write('[bayesloop_amd] copying a %.1f-GiB posteriorSequence from the GPU to the host.  getParameterDistributions / '
+                             'getParameterDistribution(t, ...) / getParameterMeanValues / simulate / plot reduce it ON the device and copy only '
+                             'their result -- touch S.posteriorSequence itself only if the whole array is needed (BLHIP_QUIET=1 silences this).\n'
+                             % (nbytes / 2.0 ** 30))
         if self.source == 0:
             return self.engine.posterior(self.chain, self.T, self.grid_size)
         return self.engine.accum_read(self.T, self.grid_size)

@@ -838,6 +838,11 @@ def main():
                                        log_evidence_reference=g2, log_evidence_rel_err=rel_err(float(S2.logEvidence), g2),
                                        config=d2, kernels=roofline_of(tm, u2, peak_cal),
                                        resident_fallbacks=int(tm.get('resident_fallbacks', 0)))
+                    # what of a fit() is kernels (HIP events on the library's stream: forward + backward + fold launches) and what is the rest -- host
+                    # code on both sides of the C-ABI, uploads, read-backs of the sums, launch gaps
+                    k_ms = float(tm.get('forward_ms', 0.0)) + float(tm.get('backward_ms', 0.0)) + float(tm.get('accumulate_ms', 0.0))
+                    extra[name]['kernel_ms'] = k_ms
+                    extra[name]['host_ms'] = dt2 * 1e3 - k_ms
                     if name == 'c3':
                         extra[name]['end_to_end'] = end_to_end(bl, S2, dict(silent=True), u2)
                     if name == 'coal_breakpoints':
