@@ -877,7 +877,7 @@ void blhip_destroy(blhip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)blhip_comm_destroy(ctx);
-    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->postpad.release(); ctx->accw.release(); ctx->accpart.release(); ctx->xch.release(); ctx->axlik.release(); ctx->probebuf.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
+    ctx->commbuf.release(); ctx->pinC.release(); ctx->resx.release(); ctx->post2.release(); ctx->postpad.release(); ctx->accw.release(); ctx->accpart.release(); ctx->xch.release(); ctx->axlik.release(); ctx->anchbuf.release(); ctx->probebuf.release(); ctx->p1d.release(); ctx->p1w.release(); ctx->lik1d.release();
     if (ctx->astream) { (void)hipStreamSynchronize(ctx->astream); (void)hipStreamDestroy(ctx->astream); }
     for (auto &e : ctx->aev_done) if (e) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->state, &ctx->post, &ctx->psumF, &ctx->psumB, &ctx->redF, &ctx->redB, &ctx->meta,

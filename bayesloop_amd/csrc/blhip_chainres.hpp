@@ -102,7 +102,74 @@ struct ChainParams {
     const double *lik_nat;       // blc::chainax_kernel: tabulated likelihood (every model but the Gaussian), [T][n0t * n1t] row-major, for the steps whose
                                  //   epilogue works in layout A; `lik` then holds the even steps in the transposed layout
     int xch_mode;                // experiments (option chain_ax1_mode): bit 0 = the blocks of a chain share an XCD (block b runs on XCD b % 8), bit 1 = plain publishing stores
+    // (round 6) the anchors of the likelihood recurrence, tabulated once per fit (anchor_table_kernel below): [T][NW waves][strips][64 lanes] x
+    // {mantissa E, mantissa R, exponents (nE, nR) as two ints, pad} = 32 bytes per lane and step.  The Gaussian kernels of this file read
+    // them a step ahead instead of evaluating two exponentials per lane and step -- every chain of a hyper-study sees the SAME likelihood, so
+    // the 512 chains of BASELINE C4 repeated each anchor 512 times (5.6 % of its forward pass, 2.8 % of the folding backward pass)
+    const double *anch;
 };
+
+// ---- the anchors of the stride-4 likelihood recurrence (blhip_mfma.hpp) of a lane's rows at one time step --------------------------------------
+// arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50): a0 = arg at the lane's first row,
+// d1 = arg(+4 rows) - arg, dn = valid data dimensions (the second difference is -32 cA dn step0^2, constant in time while dn is)
+// (the data record as four scalars: an array handed over by reference was kept in scratch memory by the no-stencil kernels -- 72 bytes per
+//  lane, C5's forward pass 46.6 -> 61.2 ms)
+static_assert(DMAX == 4, "anchor_terms takes the record's four slots as scalars");
+__device__ __forceinline__ void anchor_terms(double x0, double x1, double x2, double x3, double mu0, double mu4, double cA, double cB, double &a0, double &d1,
+                                             double &dn) {
+    double s1 = 0.0, a = 0.0, n = 0.0;
+    auto slot = [&](double x) {
+        if (x == x) {
+            const double dq = x - mu0;
+            a = fma(-(dq * dq), cA, a) - cB;
+            s1 += (x - mu0) + (x - mu4);
+            n += 1.0;
+        }
+    };
+    slot(x0); slot(x1); slot(x2); slot(x3);
+    a0 = a; dn = n;
+    d1 = cA * (mu4 - mu0) * s1;
+}
+
+struct AnchorParams {
+    int T, d, rec_len, strips, rows_per_wave, n0t, n1t;       // rows_per_wave = NTW * 16; n0t, n1t: the grid's true sizes (padded geometries clamp)
+    const double *m0, *colA, *colB, *rec;
+    double *out;                                              // [T][NW][strips][64][4]
+};
+__device__ __forceinline__ long long anchor_index(int t, int wv, int strips, int tj, int lane) { return ((((long long)t * NW + wv) * strips + tj) * 64 + lane) * 4; }
+
+// one block per (strip, time step): thread (wave wv, lane) computes what lane `lane` of wave `wv` of that strip's blocks needs at that step --
+// with the very operations the kernels used to run, so the tabulated anchors are bit for bit the in-kernel ones
+static __global__ __launch_bounds__(NT) void anchor_table_kernel(const AnchorParams A) {
+    const int tj = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, gj = tj * WCOL + (lane & 15), gjc = min(gj, A.n1t - 1);
+    const int i = wv * A.rows_per_wave;
+    const double mu0 = A.m0[min(i + g, A.n0t - 1)], mu4 = A.m0[min(i + g + 4, A.n0t - 1)];
+    const double cA = A.colA[gjc], cB = A.colB[gjc];
+    double xd[DMAX];
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) xd[q] = q < A.d ? A.rec[(long long)t * A.rec_len + q] : __builtin_nan("");
+    double a0, d1, dn, mE, mR;
+    int nE, nR;
+    anchor_terms(xd[0], xd[1], xd[2], xd[3], mu0, mu4, cA, cB, a0, d1, dn);
+    exp_mn(a0, mE, nE);
+    exp_mn(d1, mR, nR);
+    double *o = A.out + anchor_index(t, wv, A.strips, tj, lane);
+    o[0] = mE; o[1] = mR;
+    o[2] = __longlong_as_double((long long)(((unsigned long long)(unsigned)nR << 32) | (unsigned long long)(unsigned)nE));
+    o[3] = dn;
+}
+// a lane's entry, requested a step ahead: two 16-byte loads
+struct AnchorEntry { double mE, mR, n, dn; };
+__device__ __forceinline__ AnchorEntry anchor_load(const double *anch, int t, int wv, int strips, int tj, int lane) {
+    const double2 *p = reinterpret_cast<const double2 *>(anch + anchor_index(t, wv, strips, tj, lane));
+    const double2 a = p[0], b = p[1];
+    return AnchorEntry{a.x, a.y, b.x, b.y};
+}
+__device__ __forceinline__ void anchor_unpack(const AnchorEntry &e, double &mE, int &nE, double &mR, int &nR) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(e.n);
+    mE = e.mE; mR = e.mR; nE = (int)(unsigned)(u & 0xffffffffull); nR = (int)(unsigned)(u >> 32);
+}
 
 // The kernel arguments arrive as 16-register tuples (s_load_dwordx16) and the register allocator spills and restores a tuple as ONE
 // unit: with ~100 live scalars in the step loop of the two-chain fold kernel a single field of ChainParams cost a 16-lane v_readlane
@@ -113,7 +180,7 @@ struct ChainParams {
 using blr::own_sgpr;
 struct LoopParams {
     int T, d, rec_len, lag, B, nslots, strips, nblk, part_fresh, bprov;
-    const double *rec, *sfwd, *zeros, *reset;
+    const double *rec, *sfwd, *zeros, *reset, *anch;
     const unsigned char *kinds;
     double *post, *psum;
     long long post_stride;
@@ -127,7 +194,7 @@ __device__ __forceinline__ LoopParams loop_params(const ChainParams &P) {
     Q.T = own_sgpr(P.T); Q.d = own_sgpr(P.d); Q.rec_len = own_sgpr(P.rec_len); Q.lag = own_sgpr(P.lag); Q.B = own_sgpr(P.B);
     Q.nslots = own_sgpr(P.nslots); Q.strips = own_sgpr(P.strips); Q.nblk = own_sgpr(P.nblk); Q.part_fresh = own_sgpr(P.part_fresh);
     Q.bprov = own_sgpr(P.bprov);
-    Q.rec = own_sgpr(P.rec); Q.sfwd = own_sgpr(P.sfwd); Q.zeros = own_sgpr(P.zeros); Q.reset = own_sgpr(P.reset);
+    Q.rec = own_sgpr(P.rec); Q.sfwd = own_sgpr(P.sfwd); Q.zeros = own_sgpr(P.zeros); Q.reset = own_sgpr(P.reset); Q.anch = own_sgpr(P.anch);
     Q.kinds = own_sgpr(P.kinds); Q.post = own_sgpr(P.post); Q.psum = own_sgpr(P.psum); Q.post_stride = own_sgpr(P.post_stride);
     Q.gran = own_sgpr(P.gran); Q.abort_word = own_sgpr(P.abort_word); Q.timeout_ticks = own_sgpr(P.timeout_ticks);
     Q.step0 = P.step0;
@@ -325,6 +392,12 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     double Sprev = 1.0;                            // the sum the previous step's scale was made of
     double mq = 1.0, iq = 1.0, dn_prev = -1.0;     // exp(second difference of the exponent): changes only with the number of valid data dimensions
     int nq = 0;
+    // the anchors of the step in flight (ChainParams::anch), requested a whole step ahead
+    // (the filtering kernels; the no-stencil ones -- change-point batches: a chain-step is a few hundred cycles, chains of a launch run at
+    //  different time steps once prefixes are skipped -- evaluate their anchors themselves: C5's forward pass lost 30 % with the table)
+    constexpr bool ANCT = !TAB && FILTER;
+    AnchorEntry anc{1.0, 1.0, 0.0, 0.0};
+    if constexpr (ANCT) anc = anchor_load(P.anch, t_first, wv, P.strips, tj, lane);
 #ifdef BLC_PROF
     const bool prof_me = blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 2);
 #endif
@@ -361,6 +434,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         if (FOLD) sfn = P.sfwd[(long long)b * P.T + min(tn + 1, P.T - 1)];
 #pragma unroll
         for (int q = 0; q < DMAX; ++q) xn[q] = q < P.d ? P.rec[(long long)tn * P.rec_len + q] : __builtin_nan("");
+        AnchorEntry anc_next{1.0, 1.0, 0.0, 0.0};
+        if constexpr (ANCT) anc_next = anchor_load(P.anch, tn, wv, P.strips, tj, fresh_lane());
 
         // ---- ring over the source state -----------------------------------------------------------------------------------------------
         double *S = TALL ? X : X + (k & 1) * XSZ;
@@ -489,33 +564,28 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 // ---- anchor of the stride-4 likelihood recurrence of this lane's rows (blhip_mfma.hpp) -------------------------------
                 // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50)
                 if constexpr (!TAB) {
-                const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
-                double a0 = 0.0, s1 = 0.0, dn = 0.0;
-#pragma unroll
-                for (int q = 0; q < DMAX; ++q) {
-                    const double x = xd[q];
-                    if (x == x) {
-                        const double dq = x - mu0;
-                        a0 = fma(-(dq * dq), cA, a0) - cB;
-                        s1 += (x - mu0) + (x - mu4);
-                        dn += 1.0;
+                    double dn;
+                    if constexpr (ANCT) {                // (tabulated once per fit: anchor_table_kernel -- the same operations, bit for bit)
+                        anchor_unpack(anc, mE, nE, mR, nR);
+                        dn = anc.dn;
+                    } else {
+                        double a0, d1;
+                        anchor_terms(xd[0], xd[1], xd[2], xd[3], m0s[i + g], m0s[i + g + 4], cA, cB, a0, d1, dn);
+                        exp_mn(a0, mE, nE);
+                        exp_mn(d1, mR, nR);
                     }
-                }
-                const double d1 = cA * (mu4 - mu0) * s1;
-                const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
-                exp_mn(a0, mE, nE);
-                exp_mn(d1, mR, nR);
-                if (dn != dn_prev) {                 // (wave-uniform: the records are)
-                    int tmp;
-                    exp_mn(d2, mq, nq);
-                    if (BWD) exp_mn(-d2, iq, tmp);
-                    dn_prev = dn;
-                }
-                if (BWD) {
-                    iE = blmath::inv_m(mE); iR = blmath::inv_m(mR);      // (exp(-a0), exp(-d1): same exponents, reciprocal mantissas)
-                } else {
-                    mE *= scale;                     // forward: the scale rides on the likelihood's mantissa (one product per cell less)
-                }
+                    if (dn != dn_prev) {                 // (wave-uniform: the records are)
+                        const double d2 = -32.0 * cA * dn * P.step0 * P.step0;
+                        int tmp;
+                        exp_mn(d2, mq, nq);
+                        if (BWD) exp_mn(-d2, iq, tmp);
+                        dn_prev = dn;
+                    }
+                    if (BWD) {
+                        iE = blmath::inv_m(mE); iR = blmath::inv_m(mR);      // (exp(-a0), exp(-d1): same exponents, reciprocal mantissas)
+                    } else {
+                        mE *= scale;                     // forward: the scale rides on the likelihood's mantissa (one product per cell less)
+                    }
                 }
                 BLC_STAMP(3);
             }
@@ -648,6 +718,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         }
 #pragma unroll
         for (int q = 0; q < DMAX; ++q) xd[q] = xn[q];
+        if constexpr (ANCT) anc = anc_next;
     }
 }
 
@@ -755,12 +826,11 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     double Sprev[2] = {1.0, 1.0};
     double mq = 1.0, iq = 1.0, dn_prev = -1.0;
     int nq = 0;
-    double xd[DMAX];
-#pragma unroll
-    for (int q = 0; q < DMAX; ++q) xd[q] = __builtin_nan("");
     // the first chain's anchors of the step, reused by the second one
     double a_mE = 1.0, a_mR = 1.0, a_iE = 1.0, a_iR = 1.0;
     int a_nE = 0, a_nR = 0;
+    // ... from the table of the fit (ChainParams::anch), requested a whole time step ahead
+    AnchorEntry anc_next = anchor_load(P.anch, t_first, wv, P.strips, tj, lane);
     int pend_j = -1, pend_k = 0;                   // the chain-step whose row sums wave 5 still has to add up (after the next barrier)
     int kind_next = blk::SRC_PREV;                 // NK = 4: source kind of the chain-step after this one (the first steps consume src0)
 
@@ -797,10 +867,6 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
         const int tn = (k + 1 < Q.T) ? t - 1 : t;
         const int jn = k + 1;
         const int bj = j ? bch[1] : bch[0];
-        if (j == 0) {
-#pragma unroll
-            for (int q = 0; q < DMAX; ++q) xd[q] = q < Q.d ? Q.rec[(long long)t * Q.rec_len + q] : __builtin_nan("");
-        }
         double *const pslot_t = pslot + (long long)t * G;
         double *const pslot_tn = pslot + (long long)tn * G;
         double *const Xj = X + j * XSZ;
@@ -932,30 +998,17 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 }
                 // anchors of the stride-4 likelihood recurrence: both chains see the same likelihood -- the first one computes them
                 if (j == 0) {
-                    const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];
-                    double a0 = 0.0, s1 = 0.0, dn = 0.0;
-#pragma unroll
-                    for (int q = 0; q < DMAX; ++q) {
-                        const double x = xd[q];
-                        if (x == x) {
-                            const double dq = x - mu0;
-                            a0 = fma(-(dq * dq), cA, a0) - cB;
-                            s1 += (x - mu0) + (x - mu4);
-                            dn += 1.0;
-                        }
-                    }
-                    const double d1 = cA * (mu4 - mu0) * s1;
-                    int tmp;
-                    exp_mn(a0, a_mE, a_nE);
-                    exp_mn(d1, a_mR, a_nR);
+                    anchor_unpack(anc_next, a_mE, a_nE, a_mR, a_nR);
+                    const double dn = anc_next.dn;
                     if (dn != dn_prev) {
                         const double d2 = -32.0 * cA * dn * Q.step0 * Q.step0;
+                        int tmp;
                         exp_mn(d2, mq, nq);
                         exp_mn(-d2, iq, tmp);
                         dn_prev = dn;
                     }
-                    exp_mn(-a0, a_iE, tmp);
-                    exp_mn(-d1, a_iR, tmp);
+                    a_iE = blmath::inv_m(a_mE); a_iR = blmath::inv_m(a_mR);      // (exp(-a0), exp(-d1): same exponents, reciprocal mantissas)
+                    anc_next = anchor_load(Q.anch, tn, wv, Q.strips, tj, fresh_lane());          // (the next time step's: consumed a whole time step from now)
                 }
                 mE = a_mE; nE = a_nE; mR = a_mR; nR = a_nR; iE = a_iE; iR = a_iR;
             }

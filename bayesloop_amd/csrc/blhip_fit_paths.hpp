@@ -388,6 +388,21 @@ struct ChainRun {
         CQ.m0 = E.DT->m0; CQ.m1 = E.DT->m1; CQ.colA = E.DT->colA; CQ.colB = E.DT->colB; CQ.rec = E.DT->rec; if (tab && !ax1) CQ.lik = E.DT->lik; CQ.step0 = E.step0;      // (both-axes kernels: CQ.lik is their table of the even steps, set above)
         CQ.timeout_ticks = (unsigned long long)(resident_timeout_s(ctx, T) * 1e8);
         psz = std::max(psz, (size_t)T * B * NRED * cp.strips);
+        if (!tab && !ax1 && (prog.LW0 > 0 || E.ff.full)) {          // (no-stencil batches: only their folding backward pass reads it)
+            // the anchors of the likelihood recurrence: the same for every chain of the batch (same data, same grid) -- tabulated once, 32 bytes
+            // per lane and step (C4: 134 MB), read by the kernels a step ahead (ChainParams::anch)
+            const size_t ab = (size_t)T * blc::NW * cp.strips * 64 * 4 * sizeof(double);
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            if ((double)ab > 0.5 * ((double)free_b + (double)ctx->anchbuf.cap)) { on = false; return; }
+            ctx->anchbuf.ensure(ab);
+            blc::AnchorParams AP{};
+            AP.T = (int)T; AP.d = E.d; AP.rec_len = E.rec_len; AP.strips = cp.strips; AP.rows_per_wave = cp.ntw * blc::TM; AP.n0t = E.g.n0; AP.n1t = E.g.n1;
+            AP.m0 = E.DT->m0; AP.colA = E.DT->colA; AP.colB = E.DT->colB; AP.rec = E.DT->rec; AP.out = ctx->anchbuf.as<double>();
+            BL_LAUNCH(blc::anchor_table_kernel, dim3((unsigned)cp.strips, (unsigned)T), dim3(blc::NT), 0, E.st, AP);
+            HIPCHECK(hipGetLastError());
+            CQ.anch = ctx->anchbuf.as<double>();
+        }
         // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)
         post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && ((G & 1) == 0 || cp.pad || ax1) && ((uintptr_t)ctx->acc & 15) == 0;
         // (not beside overlapped folds: a FoldJob of the previous batch may still read ctx->accw and read-modify-write ctx->acc on the

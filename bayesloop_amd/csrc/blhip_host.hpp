@@ -128,6 +128,7 @@ struct blhip_ctx {
     DevBuf p1d, p1w;             // hand-off buffers / weight table of the persistent 1-D kernel (blhip_persist1d.hpp)
     DevBuf lik1d;                // (T, n) likelihood table the chains of a 1-D batch share (blhip_chain1d.hpp)
     DevBuf accpart;              // partial accumulators of the fused fold (one per launch slot of the chain-resident kernel)
+    DevBuf anchbuf;              // the anchors of the likelihood recurrence of a chain-resident batch, tabulated once per batch (blc::anchor_table_kernel)
     DevBuf axlik;                // ... its likelihood table of the even time steps (transposed layout): ceil(T / 2) x n0p^2 doubles
     DevBuf xch;                  // exchange buffers of the both-axes chain-resident kernel (blhip_chainax.hpp): [slot][2 step parities][Gk]
     hipStream_t astream = nullptr;
