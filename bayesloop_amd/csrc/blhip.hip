@@ -580,6 +580,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         if (cres_now) {
             ctx->timing.fwd_kernel_variant = 6;
             if (!CR.forward_ok(E, redF)) { resident_failed = true; return false; }
+            tr.mark("  forward_ok");
         }
         if (c1d_now) ctx->timing.fwd_kernel_variant = 9;
         if (p1d_now) {
@@ -620,7 +621,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (fused1d)
                 account(ctx, true, (double)B * G * T * (32.0 + (d_lik ? 8.0 : 0.0)), (double)B * G * T * (valu_stencil_flop(prog.LW1) + EPI_BWD_FLOP));
             if (res_now) RR.launch(E, true, d_psB);
-            if (cres_now && CR.fused) CR.prepare_fold(E, O);
+            if (cres_now && CR.fused) { CR.prepare_fold(E, O); tr.mark("  prepare_fold"); }
             if (cres_now) CR.pass(E, true, d_psB);
             fork_streams();
             for (int64_t t = T - 1; t >= 0 && !fused1d && !res_now && !cres_now; --t) {
@@ -658,9 +659,13 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (cres_now) {
                 ctx->timing.bwd_kernel_variant = 6;
                 if (!CR.backward_ok(E, redB)) { resident_failed = true; return false; }
-                if (CR.fused && !CR.fold(E, redB)) { resident_failed = true; return false; }
+                tr.mark("  backward_ok");
+                if (CR.fused && !CR.fold(E, redB, fold_ev)) { resident_failed = true; return false; }
+                tr.mark("  prediction check + fold queued");
             }
-            raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O) && raw_ok;
+            // (a batch the backward kernel folded: nobody reads its row normalisers; means only where the caller asked for them)
+            raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O, !(cres_now && CR.fold_done),
+                                          !(cres_now && CR.fold_done) || E.chain_means) && raw_ok;
             tr.mark("backward checks + fused fold + bookkeeping");
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)

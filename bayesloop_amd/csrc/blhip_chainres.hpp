@@ -177,7 +177,21 @@ __device__ __forceinline__ void anchor_unpack(const AnchorEntry &e, double &mE, 
 // field that loop uses is therefore copied into a scalar of its own first -- the empty asm makes the copy a separate value the
 // allocator can place, spill or keep on its own (137 v_readlane, 1403 vector instructions).  (The single-chain kernels have few
 // spills -- 35 v_readlane per step -- and do not gain: measured on the ISA, not applied there.)
+// (round 6: with an EMPTY asm the copy was coalesced back into the tuple's sub-register wherever the allocator liked -- the fold kernel's
+//  step loop reloaded a whole 16-register tuple six times for `gran`, `psum` and `step0`; a real s_mov defines a register of its own)
+#ifndef BLC_OWN_MOV
+#define BLC_OWN_MOV 1
+#endif
+#if BLC_OWN_MOV
+__device__ __forceinline__ int own_sgpr(int v) { int r; asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(v)); return r; }
+__device__ __forceinline__ unsigned long long own_sgpr(unsigned long long v) { unsigned long long r; asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(v)); return r; }
+__device__ __forceinline__ long long own_sgpr(long long v) { return (long long)own_sgpr((unsigned long long)v); }
+__device__ __forceinline__ double own_sgpr(double v) { return __longlong_as_double((long long)own_sgpr((unsigned long long)__double_as_longlong(v))); }
+template <class T>
+__device__ __forceinline__ T *own_sgpr(T *p) { return (T *)(T __attribute__((address_space(1))) *)own_sgpr((unsigned long long)p); }
+#else
 using blr::own_sgpr;
+#endif
 struct LoopParams {
     int T, d, rec_len, lag, B, nslots, strips, nblk, part_fresh, bprov;
     const double *rec, *sfwd, *zeros, *reset, *anch;
@@ -197,7 +211,7 @@ __device__ __forceinline__ LoopParams loop_params(const ChainParams &P) {
     Q.rec = own_sgpr(P.rec); Q.sfwd = own_sgpr(P.sfwd); Q.zeros = own_sgpr(P.zeros); Q.reset = own_sgpr(P.reset); Q.anch = own_sgpr(P.anch);
     Q.kinds = own_sgpr(P.kinds); Q.post = own_sgpr(P.post); Q.psum = own_sgpr(P.psum); Q.post_stride = own_sgpr(P.post_stride);
     Q.gran = own_sgpr(P.gran); Q.abort_word = own_sgpr(P.abort_word); Q.timeout_ticks = own_sgpr(P.timeout_ticks);
-    Q.step0 = P.step0;
+    Q.step0 = own_sgpr(P.step0);
     return Q;
 }
 
@@ -215,6 +229,9 @@ __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) {
 // g + 4 rg of column c; A for shift s: lane (k = l >> 4, i = l & 3) = w(|4 s - R0 + k - i|).
 #ifndef BLC_BAND4
 #define BLC_BAND4 1
+#endif
+#ifndef BLC_FASTEDGE
+#define BLC_FASTEDGE 1
 #endif
 typedef const double __attribute__((address_space(3))) *band_cp;
 // (Bv: a ring of NR >= OFF + NK entries, the tile's window begins at entry OFF -- compile-time, so the entries stay registers)
@@ -252,6 +269,39 @@ __device__ __forceinline__ int band_distance(int e, int R0) {
 }
 // ... of a compact table [NK][16] (entry 4 k + i of a shift)
 __device__ __forceinline__ int band_distance16(int e, int R0) { return abs(4 * (e >> 4) + ((e & 15) >> 2) - R0 - (e & 3)); }
+
+
+// ---- the product ring of the waves at the grid's edges (exact geometries) ---------------------------------------------------------------------
+// SciPy's 'reflect' extension (row -1 - q = row q, row n0 + q = row n0 - 1 - q) costs ~8 integer instructions per ring entry (reflect1), 26
+// entries per step in the forward kernels of a 512-row strip: the two edge waves of a block ran a third more vector instructions than the
+// six interior ones, and the step's barrier waits for them.  On an exact geometry (no PAD) whose waves own at least R0 rows only the first
+// and the last wave reach beyond the grid, and WHICH of their entries do is known at compile time (entries begin at multiples of 4 rows, R0
+// is one): the mirrored entries are read at immediate offsets from ONE mirrored base address, the others from the usual one -- an edge
+// wave's ring then costs what an interior wave's does.
+// Entries [k0, k0 + cnt) of the ring Bv; entry k0 + q begins rel0 + 4 q rows from the wave's first row (lane (g, c) holds row + g, column c).
+// (k0, cnt, rel0 are constants at every call site once the tile loop is unrolled: the selections below fold away)
+template <int NR>
+__device__ __forceinline__ void ring_fill_first_wave(double (&Bv)[NR], const double *S, int g, int c, int k0, int cnt, int rel0) {      // (row0 = 0)
+    const double *sm = S + (3 - g) * WCOL + c;          // mirrored at the first row: row -1 - (rel + g); rel = -4 -> row 3 - g
+    const double *s0 = S + g * WCOL + c;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int rel = rel0 + 4 * q;
+        if (q < cnt) Bv[k0 + q] = rel < 0 ? sm[(-rel - 4) * WCOL] : s0[rel * WCOL];
+    }
+}
+template <int N0, int ROWS_W, int NR>
+__device__ __forceinline__ void ring_fill_last_wave(double (&Bv)[NR], const double *S, int g, int c, int k0, int cnt, int rel0) {       // (row0 = N0 - ROWS_W)
+    constexpr int row0 = N0 - ROWS_W;
+    const int relmax = rel0 + 4 * (cnt - 1);
+    const double *sm = S + (2 * N0 - 1 - row0 - relmax - g) * WCOL + c;      // mirrored at the last row: row 2 N0 - 1 - (row0 + rel + g)
+    const double *s0 = S + (row0 + rel0 + g) * WCOL + c;                      // (row0 + rel0 >= 0: the last wave's ring begins inside the grid)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int rel = rel0 + 4 * q;
+        if (q < cnt) Bv[k0 + q] = rel >= ROWS_W ? sm[(relmax - rel) * WCOL] : s0[(rel - rel0) * WCOL];
+    }
+}
 
 template <int NK, int NTW>
 constexpr size_t lds_doubles() { return (size_t)(NTW > 4 ? 1 : 2) * NW * NTW * TM * WCOL + NK * (NTW > 4 ? 16 : 64) + NW * NTW * TM + 2 * NW * 4 * 5 + 2 * NSLOT + 8; }
@@ -453,6 +503,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         // (interior waves: consecutive k-blocks are 512 bytes apart -- one address register, immediate offsets; only waves whose
         //  window reaches beyond the grid edge pay for the reflection)
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > n0t;          // (the reflection is at the grid's true last row)
+        // (exact geometries whose waves own >= R0 rows: only the first / last wave reflect, at compile-time entries -- ring_fill_*_wave)
+        constexpr bool FASTEDGE = BLC_FASTEDGE && FILTER && !PAD && NTW * TM >= R0;
         // WHOLE_RING (forward kernels of <= 512 rows): the ring entries of ALL the wave's tiles are read when the step begins (NK + 4 (NTW - 1)
         // registers instead of NK) and a tile's products take their window at a compile-time offset -- no ring shift, no reads and no
         // edge test between the tiles.  (The sliding ring cost 20 v_mov per tile where its edge / interior load paths joined: a fifth of the
@@ -466,7 +518,9 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         double Bv[NRING];
         if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
-            if (edge) {
+            if (FASTEDGE && wv == 0) ring_fill_first_wave(Bv, S, g, c, 0, NRING, -R0);
+            else if (FASTEDGE && wv == NW - 1) ring_fill_last_wave<N0, NTW * TM>(Bv, S, g, c, 0, NRING, -R0);
+            else if (!FASTEDGE && edge) {
 #pragma unroll
                 for (int kb = 0; kb < NRING; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, n0t) * WCOL + c];
             } else {
@@ -652,7 +706,8 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
             if (FILTER && !WHOLE_RING && it + 1 < NTW) {
 #pragma unroll
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
-                if (edge) {
+                if (FASTEDGE && wv == NW - 1 && (it + 1) * TM + R0 + 12 >= NTW * TM) ring_fill_last_wave<N0, NTW * TM>(Bv, S, g, c, NK - 4, 4, (it + 1) * TM + R0);
+                else if (!FASTEDGE && edge) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, n0t) * WCOL + c];
                 } else {
@@ -834,6 +889,12 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
     int pend_j = -1, pend_k = 0;                   // the chain-step whose row sums wave 5 still has to add up (after the next barrier)
     int kind_next = blk::SRC_PREV;                 // NK = 4: source kind of the chain-step after this one (the first steps consume src0)
 
+#ifdef BLC_PROF
+    const bool prof_me = blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 2);
+#define BLC_STAMP2(i) do { if (prof_me && cstep >= 16 && cstep < 32) P.prof[(wv ? 256 : 0) + (cstep - 16) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BLC_STAMP2(i) do { } while (0)
+#endif
     const LoopParams Q = loop_params(P);
     // wave 5: block totals of a finished chain-step -> partial sums of the strip + the granule the scale of step k + lag is made of
     auto totals = [&](int j, int k) {
@@ -867,6 +928,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
         const int tn = (k + 1 < Q.T) ? t - 1 : t;
         const int jn = k + 1;
         const int bj = j ? bch[1] : bch[0];
+        BLC_STAMP2(0);
         double *const pslot_t = pslot + (long long)t * G;
         double *const pslot_tn = pslot + (long long)tn * G;
         double *const Xj = X + j * XSZ;
@@ -892,6 +954,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             sf_next = Q.sfwd[(long long)(lastc ? bch[0] : bch[1]) * Q.T + min((lastc ? tn : t) + 1, Q.T - 1)];
         }
         __syncthreads();                                            // every wave's rows of this chain are in Xj
+        BLC_STAMP2(1);
         if (pend_j >= 0) {
             // the previous chain-step's new state -> that chain's exchange buffer: all its readers have passed the barrier above, its
             // next readers wait at the next one  (NK = 4: a lane's cells are its own -- written in the epilogue)
@@ -927,10 +990,13 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
         }
 
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > n0t;          // (the reflection is at the grid's true last row)
+        constexpr bool FASTEDGE = BLC_FASTEDGE && FILTER && !PAD && NTW * TM >= R0;       // (see ring_fill_first_wave)
         double Bv[NK];
         if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
-            if (edge) {
+            if (FASTEDGE && wv == 0) ring_fill_first_wave(Bv, Xj, g, c, 0, NK, -R0);
+            else if (FASTEDGE && wv == NW - 1 && R0 + 12 >= NTW * TM) ring_fill_last_wave<N0, NTW * TM>(Bv, Xj, g, c, 0, NK, -R0);
+            else if (!FASTEDGE && edge) {
 #pragma unroll
                 for (int kb = 0; kb < NK; ++kb) Bv[kb] = Xj[reflect1(row0 - R0 + 4 * kb + g, n0t) * WCOL + c];
             } else {
@@ -939,6 +1005,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 for (int kb = 0; kb < NK; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
             }
         }
+        BLC_STAMP2(2);
         double scale = 1.0, wq = 0.0, wfloor = 0.0;
         double mE = 1.0, mR = 1.0, iE = 1.0, iR = 1.0;
         int nE = 0, nR = 0;
@@ -964,6 +1031,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 for (int r = 0; r < 4; ++r) acc[r] = Xj[(i + g + 4 * r) * WCOL + c];
             }
             if (it == 0) {
+                BLC_STAMP2(3);
                 scale = scal[j * NSLOT + (k & (NSLOT - 1))];
                 double ip = j ? inpred[1] : inpred[0];
                 // N_t = s'_t N_(t+1) / s_(t+1); at a restart N_t = s'_t sum(alpha_t reset) (sf_now carries that sum)
@@ -1011,6 +1079,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                     anc_next = anchor_load(Q.anch, tn, wv, Q.strips, tj, fresh_lane());          // (the next time step's: consumed a whole time step from now)
                 }
                 mE = a_mE; nE = a_nE; mR = a_mR; nR = a_nR; iE = a_iE; iR = a_iR;
+                BLC_STAMP2(4);
             }
 
             // ---- epilogue: the lane's 4 cells (rows i + g + 4 r) ---------------------------------------------------------------------
@@ -1050,11 +1119,13 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             }
             // (no products to pace the no-stencil variant: without a fence the scheduler interleaves the four tiles' cells and spills)
             if (!FILTER) __builtin_amdgcn_sched_barrier(0);
+            if (it == 0) BLC_STAMP2(5);
             // ---- advance the ring by one tile --------------------------------------------------------------------------------------
             if (FILTER && it + 1 < NTW) {
 #pragma unroll
                 for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
-                if (edge) {
+                if (FASTEDGE && wv == NW - 1 && (it + 1) * TM + R0 + 12 >= NTW * TM) ring_fill_last_wave<N0, NTW * TM>(Bv, Xj, g, c, NK - 4, 4, (it + 1) * TM + R0);
+                else if (!FASTEDGE && edge) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = Xj[reflect1(i + TM + R0 + 4 * q + g, n0t) * WCOL + c];
                 } else {
@@ -1065,6 +1136,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             }
         }
 
+        BLC_STAMP2(6);
         // ---- row sums of the chain-step -> LDS (wave 5 adds them up after the next barrier) -------------------------------------------
         {
             double v[3] = {sN, sS, sC};
@@ -1079,6 +1151,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 if ((lane & 15) == 15) rk[(wv * 4 + (lane >> 4)) * 3 + q] = x;
             }
         }
+        BLC_STAMP2(7);
         if (FILTER && k == 0 && last_chain) {        // the chains' bands replace the identity of the first step
             __syncthreads();
             {

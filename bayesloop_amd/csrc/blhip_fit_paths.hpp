@@ -607,15 +607,12 @@ struct ChainRun {
     bool forward_ok(const BatchEnv &E, double *redF) {
         if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
         redF_keep = redF;
-        rowsumC.assign(E.B, std::vector<double>());
-        sfwdC.assign(E.B, std::vector<double>());
         if (skip_prefix)               // the steps a chain did not compute: the providing chain's sums (raw: before anybody's scales are undone)
             for (int64_t b = 0; b < E.B; ++b)
                 for (int64_t t = 0; t < h_tshare[b]; ++t)
                     std::memcpy(&redF[((size_t)t * E.B + b) * NRED], &redF[((size_t)t * E.B + prov) * NRED], NRED * sizeof(double));
-        for (int64_t b = 0; b < E.B; ++b)
-            if (!chain_unlag(redF, E.T, CQ.lag, rowsumC[b], E.B, b, &sfwdC[b], cp.has_reset ? E.prog->kindF.data() : nullptr,
-                             skip_prefix ? h_tshare[b] : 0)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
+        if (chain_unlag_batch(redF, E.T, CQ.lag, E.B, rowsumC, sfwdC, cp.has_reset ? E.prog->kindF.data() : nullptr,
+                              skip_prefix ? h_tshare.data() : nullptr) >= 0) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
         return true;
     }
 
@@ -657,50 +654,58 @@ struct ChainRun {
     // after the backward pass: every strip made it and the lagged scale of the backward state stayed in range
     bool backward_ok(const BatchEnv &E, const double *redB) {
         if (resident_gave_up(E.ctx, E.st, d_abort)) return false;
-        for (int64_t b = 0; b < E.B; ++b)
-            for (int64_t t = 0; t < E.T; ++t) {
-                const double *r = &redB[((size_t)t * E.B + b) * NRED];
-                if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
-            }
+        const size_t n = (size_t)E.T * E.B;             // (every record of the pass, in memory order)
+        for (size_t q = 0; q < n; ++q) {
+            const double *r = &redB[q * NRED];
+            if (!(r[2] > 1e-150 && r[2] < 1e150) || !(r[0] > 1e-250)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_RANGE; return false; }
+        }
         return true;
     }
 
     // fused fold, after the backward pass: the kernel normalised every posterior by its PREDICTED sum -- the prediction must
     // reproduce the reduced sums (false: the caller repeats the batch with the launch-per-step kernels; the partials are dropped);
     // then the partial accumulators go into the average posterior (running reference exponent as in prepare_fold)
-    bool fold(const BatchEnv &E, const double *redB) {
+    // (later_ev: the fold kernel's start / end events -- nobody waits for it here: the host's bookkeeping of this batch and the next batch's
+    //  setup run beside it, do_fit reads the events after its last batch)
+    bool fold(const BatchEnv &E, const double *redB, std::vector<hipEvent_t> &later_ev) {
         blhip_ctx *ctx = E.ctx;
         hipStream_t st = E.st;
         const int64_t T = E.T, B = E.B;
         const long long G = E.G;
-        std::vector<double> csum, sb;
-        for (int64_t b = 0; b < B; ++b) {
-            // the backward scales, in processing order k = T - 1 - t (the kernel's rule, from the sums C of its new states)
-            csum.assign(T, 0.0); sb.assign(T, 1.0);
-            for (int64_t k = 0; k < T; ++k) csum[k] = redB[((size_t)(T - 1 - k) * B + b) * NRED + 2];
-            for (int64_t k = CQ.lag; k < T; ++k) sb[k] = (k - CQ.lag - 1 >= 0 ? csum[k - CQ.lag - 1] : 1.0) * sb[k - CQ.lag] / csum[k - CQ.lag];
-            double npred = rowsumC[b][T - 1] * (1.0 / (double)G);
+        {
+            // the backward scales, in processing order k = T - 1 - t (the kernel's rule, from the sums C of its new states), and the predicted
+            // sums they lead to -- step by step over all chains (the records of a step are consecutive; chain by chain every read was a
+            // cache line of its own: 0.4 ms per batch of 256 x 256 beside an idle GPU); per chain the operations and their order are unchanged
+            const int lag = CQ.lag;
+            std::vector<double> csum((size_t)T * B), sb((size_t)T * B, 1.0), npred((size_t)B);      // [k][b]
+            const double rtol = pred_rtol(T);
             for (int64_t k = 0; k < T; ++k) {
                 const int64_t t = T - 1 - k;
-                const bool restart = cp.has_reset && E.prog->kindB[(size_t)t * B + b] != SRC_PREV && k > 0;
-                if (restart) npred = sb[k] * redF_keep[((size_t)t * B + b) * NRED + 1];
-                else if (k > 0) npred = sb[k] * npred / sfwdC[b][t + 1];
-                const double Nt = redB[((size_t)t * B + b) * NRED];
-                if (!(std::fabs(npred - Nt) <= pred_rtol(T) * Nt)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_PREDICTION; return false; }
+                const double *rt = redB + (size_t)t * B * NRED;
+                double *ck = &csum[(size_t)k * B], *sk = &sb[(size_t)k * B];
+                for (int64_t b = 0; b < B; ++b) {
+                    ck[b] = rt[b * NRED + 2];
+                    if (k >= lag) sk[b] = (k - lag - 1 >= 0 ? csum[(size_t)(k - lag - 1) * B + b] : 1.0) * sb[(size_t)(k - lag) * B + b] / csum[(size_t)(k - lag) * B + b];
+                    const bool restart = cp.has_reset && E.prog->kindB[(size_t)t * B + b] != SRC_PREV && k > 0;
+                    if (k == 0) npred[b] = rowsumC[b][T - 1] * (1.0 / (double)G);
+                    else if (restart) npred[b] = sk[b] * redF_keep[((size_t)t * B + b) * NRED + 1];
+                    else npred[b] = sk[b] * npred[b] / sfwdC[b][t + 1];
+                    const double Nt = rt[b * NRED];
+                    if (!(std::fabs(npred[b] - Nt) <= rtol * Nt)) { E.ctx->resident_last_reason = BLHIP_FALLBACK_PREDICTION; return false; }
+                }
             }
         }
         if (std::isfinite(fold_ref)) {
             const double newref = std::max(ctx->acc_logref, fold_ref);
             const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
-            HIPCHECK(hipEventRecord(ctx->ev[4], st));
+            hipEvent_t e0, e1;
+            HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+            later_ev.push_back(e0); later_ev.push_back(e1);
+            HIPCHECK(hipEventRecord(e0, st));
             BL_LAUNCH(fold_parts_kernel, dim3((unsigned)(((G + 1) / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
                                ctx->accpart.as<double>(), (long long)T * Gk, slots_used, E.g.n0, E.g.n1, (int)T, r, rb,
                                ctx->acc_first ? 1 : 0, cp.n0p, Gk, ax1 ? 1 : 0);
-            HIPCHECK(hipEventRecord(ctx->ev[5], st));
-            sync_stream(ctx, st);
-            float fms = 0;
-            HIPCHECK(hipEventElapsedTime(&fms, ctx->ev[4], ctx->ev[5]));
-            ctx->timing.accumulate_ms += fms;
+            HIPCHECK(hipEventRecord(e1, st));
             ctx->timing.accumulate_launches += 1;
             int nfold = 0;
             for (int64_t b = 0; b < B; ++b) nfold += std::isfinite(fold_lw[b]) ? 1 : 0;
