@@ -114,7 +114,8 @@ static __global__ __launch_bounds__(256) void ax_lik_transpose_kernel(const doub
 // read-only inputs are read with bounds.  Lines beyond the grid pick up mirrored values in the first filter (and keep them through the
 // second: the filters act along one axis each): the epilogue drops them.
 template <int NK, int NTW, bool BWD, bool STORE, bool PAD = false>
-__global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
+__global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams Parg) {
+    const ChainParams P = own_chain_params(Parg);      // (every field a scalar of its own: the step loop reloaded whole argument tuples for single fields)
     static_assert(NTW == 1 || NTW == 2 || NTW == 4, "square geometries of 128 / 256 / 512 rows and columns");
     constexpr int R0 = (4 * NK - TM) / 2;
     static_assert(NK >= 6 && R0 % 4 == 0, "band = 16 + 2 R0 columns, R0 a multiple of 4");
@@ -231,9 +232,13 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         }
     };
     // the wave's product ring over the strip in `S`: fill / advance by one tile (reflection at the true last line `nlim`)
+    // (exact geometries whose waves own >= R0 lines: only the first / last wave reflect, at compile-time entries -- ring_fill_*_wave, blhip_chainres.hpp)
+    constexpr bool FASTEDGE = BLC_FASTEDGE && !PAD && NTW * TM >= R0;
     auto ring_fill = [&](const double *S, double (&Bv)[NK], bool edge, int nlim) {
         const int l = fresh_lane(), g = l >> 4, c = l & 15;
-        if (edge) {
+        if (FASTEDGE && wv == 0) ring_fill_first_wave(Bv, S, g, c, 0, NK, -R0);
+        else if (FASTEDGE && wv == NW - 1 && R0 + 12 >= NTW * TM) ring_fill_last_wave<N0, NTW * TM>(Bv, S, g, c, 0, NK, -R0);
+        else if (!FASTEDGE && edge) {
 #pragma unroll
             for (int kb = 0; kb < NK; ++kb) Bv[kb] = S[reflect1(row0 - R0 + 4 * kb + g, nlim) * WCOL + c];
         } else {
@@ -246,7 +251,8 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams P) {
         const int l = fresh_lane(), g = l >> 4, c = l & 15;
 #pragma unroll
         for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
-        if (edge) {
+        if (FASTEDGE && wv == NW - 1 && (i - row0) + TM + R0 + 12 >= NTW * TM) ring_fill_last_wave<N0, NTW * TM>(Bv, S, g, c, NK - 4, 4, (i - row0) + TM + R0);
+        else if (!FASTEDGE && edge) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = S[reflect1(i + TM + R0 + 4 * q + g, nlim) * WCOL + c];
         } else {

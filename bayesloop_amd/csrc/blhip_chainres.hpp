@@ -215,6 +215,65 @@ __device__ __forceinline__ LoopParams loop_params(const ChainParams &P) {
     return Q;
 }
 
+// Every field of the argument block as a scalar value of its own (see own_sgpr): the both-axes kernels' step loops reloaded one 16-register
+// tuple of the block 15 - 17 times per step (272 of 508 v_readlane in chainax_kernel<12, 4, backward, fold>) for single fields of it.
+__device__ __forceinline__ ChainParams own_chain_params(const ChainParams &P) {
+    ChainParams Q;
+    Q.n0 = own_sgpr(P.n0);
+    Q.n1 = own_sgpr(P.n1);
+    Q.strips = own_sgpr(P.strips);
+    Q.n0t = own_sgpr(P.n0t);
+    Q.n1t = own_sgpr(P.n1t);
+    Q.T = own_sgpr(P.T);
+    Q.d = own_sgpr(P.d);
+    Q.rec_len = own_sgpr(P.rec_len);
+    Q.lag = own_sgpr(P.lag);
+    Q.means = own_sgpr(P.means);
+    Q.strip_major = own_sgpr(P.strip_major);
+    Q.B = own_sgpr(P.B);
+    Q.nslots = own_sgpr(P.nslots);
+    Q.nblk = own_sgpr(P.nblk);
+    Q.chain_ids = own_sgpr(P.chain_ids);
+    Q.tap_id = own_sgpr(P.tap_id);
+    Q.taps = own_sgpr(P.taps);
+    Q.tap_off = own_sgpr(P.tap_off);
+    Q.tap_lw = own_sgpr(P.tap_lw);
+    Q.src0 = own_sgpr(P.src0);
+    Q.kinds = own_sgpr(P.kinds);
+    Q.reset = own_sgpr(P.reset);
+    Q.post = own_sgpr(P.post);
+    Q.post_stride = own_sgpr(P.post_stride);
+    Q.m0 = own_sgpr(P.m0);
+    Q.m1 = own_sgpr(P.m1);
+    Q.colA = own_sgpr(P.colA);
+    Q.colB = own_sgpr(P.colB);
+    Q.rec = own_sgpr(P.rec);
+    Q.step0 = own_sgpr(P.step0);
+    Q.psum = own_sgpr(P.psum);
+    Q.gran = own_sgpr(P.gran);
+    Q.sfwd = own_sgpr(P.sfwd);
+    Q.wchain = own_sgpr(P.wchain);
+    Q.infirst = own_sgpr(P.infirst);
+    Q.part = own_sgpr(P.part);
+    Q.part_stride = own_sgpr(P.part_stride);
+    Q.zeros = own_sgpr(P.zeros);
+    Q.part_fresh = own_sgpr(P.part_fresh);
+    Q.tshare = own_sgpr(P.tshare);
+    Q.bprov = own_sgpr(P.bprov);
+    Q.skip_prefix = own_sgpr(P.skip_prefix);
+    Q.abort_word = own_sgpr(P.abort_word);
+    Q.timeout_ticks = own_sgpr(P.timeout_ticks);
+    Q.prof = own_sgpr(P.prof);
+    Q.lik = own_sgpr(P.lik);
+    Q.tap_id1 = own_sgpr(P.tap_id1);
+    Q.xch = own_sgpr(P.xch);
+    Q.xch_chain = own_sgpr(P.xch_chain);
+    Q.lik_nat = own_sgpr(P.lik_nat);
+    Q.xch_mode = own_sgpr(P.xch_mode);
+    Q.anch = own_sgpr(P.anch);
+    return Q;
+}
+
 // streaming accesses (every byte of the sequence / the partial accumulators is touched once per launch): non-temporal hints --
 // measured: C4 backward + fold 306 -> 293 us, C5 backward 63.9 -> 59.9 us per logical step
 __device__ __forceinline__ double ldnt(const double *base, unsigned byteoff) { return __builtin_nontemporal_load((const double *)((const char *)base + byteoff)); }
