@@ -140,12 +140,11 @@ bool backward_bookkeeping(const blhip_problem *p, const ChainProgram &prog, cons
                           bool fused1d, int64_t rows_done_from, BatchOutcome &O, bool want_invN = true, bool want_means = true) {
     const int64_t T = p->T;
     bool raw_ok = true;
-    // (step by step over the chains: see forward_bookkeeping -- in tiles of 32 chains: a tile's rows of `local` / `invN` / `means` stay in
-    //  the cache while its records are read step-major)
-    constexpr int64_t TB = 32;
-    for (int64_t b0 = 0; b0 < B; b0 += TB)
+    // (step by step over all chains: see forward_bookkeeping.  Tiles of 32 chains -- rows of `local` / `invN` / `means` that stay in the first-level
+    //  cache -- were measured and dropped: the records come out of page-locked memory the copy engine has just written, and 2-KB pieces 65 KB
+    //  apart lose the prefetcher: the published break-point study, 23 batches of 1017 chains x 41 steps, 44 -> 49 ms per fit)
     for (int64_t t = T - 1; t >= 0; --t) {
-        for (int64_t b = b0; b < std::min(B, b0 + TB); ++b) {
+        for (int64_t b = 0; b < B; ++b) {
             if (O.abort_step[b] >= 0) continue;
             const double *r = &redB[((size_t)t * B + b) * NRED];
             if (fused1d && !(r[0] > 1e-200)) raw_ok = false;
