@@ -564,13 +564,27 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                                ctx->redF.as<double>(), nblk_now, NRED);
         ctx->pinF.ensure((size_t)T * B * NRED * 8);
         redF = ctx->pinF.as<double>();
-        HIPCHECK(hipMemcpyAsync(redF, nblk_now > 1 ? ctx->redF.p : (const void *)d_psF, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
-        tr.mark("forward pass queued");
-        sync_stream(ctx, st);
-        tr.mark("forward pass done + sums D2H");
-        ms = 0;
-        HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-        ctx->timing.forward_ms += ms;
+        // (the launch-per-step backward pass of a batch of chains needs nothing of the forward pass's host bookkeeping: it is done
+        //  while the GPU runs that pass -- 11 ms of the published break-point study's fit, 23 batches of 1017 chains)
+        const bool late_fb = full && (!fused1d || c1d_now) && !res_now && !cres_now && !p1d_now && B >= 64;
+        // ... and nobody waits for its sums either: they travel to the host on the copy stream BESIDE the backward pass (10 MB per batch
+        // of the break-point study, 2.4 of its 42 ms over PCIe with the chip idle)
+        const bool late_copy = late_fb && ctx->cstream && ctx->option("late_sums", 1.0) != 0.0;
+        if (late_copy) {
+            HIPCHECK(hipEventRecord(ctx->cev[0], st));
+            HIPCHECK(hipStreamWaitEvent(ctx->cstream, ctx->cev[0], 0));
+            HIPCHECK(hipMemcpyAsync(redF, nblk_now > 1 ? ctx->redF.p : (const void *)d_psF, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, ctx->cstream));
+            HIPCHECK(hipEventRecord(ctx->cev[1], ctx->cstream));
+            tr.mark("forward pass queued (its sums follow beside the backward pass)");
+        } else {
+            HIPCHECK(hipMemcpyAsync(redF, nblk_now > 1 ? ctx->redF.p : (const void *)d_psF, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
+            tr.mark("forward pass queued");
+            sync_stream(ctx, st);
+            tr.mark("forward pass done + sums D2H");
+            ms = 0;
+            HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            ctx->timing.forward_ms += ms;
+        }
         ctx->timing.forward_launches += T;
         if (n_mfma[0] > 0 && n_mfma[0] >= n_fast[0]) ctx->timing.fwd_kernel_variant = 3;
         if (res_now) {
@@ -588,9 +602,6 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (resident_gave_up(ctx, st, d_abort1)) { resident_failed = true; return false; }
         }
 
-        // (the launch-per-step backward pass of a batch of chains needs nothing of the forward pass's host bookkeeping: it is done
-        //  while the GPU runs that pass -- 11 ms of the published break-point study's fit, 23 batches of 1017 chains)
-        const bool late_fb = full && (!fused1d || c1d_now) && !res_now && !cres_now && !p1d_now && B >= 64;
         bool raw_ok = late_fb ? true : forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
         tr.mark("forward checks + bookkeeping");
 
@@ -640,9 +651,17 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             redB = ctx->pinB.as<double>();
             HIPCHECK(hipMemcpyAsync(redB, nblk_now > 1 ? ctx->redB.p : (const void *)d_psB, (size_t)T * B * NRED * 8, hipMemcpyDeviceToHost, st));
             tr.mark("backward pass queued");
-            if (late_fb) { raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O); tr.mark("forward bookkeeping (behind the backward pass)"); }
+            if (late_fb) {
+                if (late_copy) HIPCHECK(hipEventSynchronize(ctx->cev[1]));
+                raw_ok = forward_bookkeeping(p, prog, redF, B, dV, fused1d, K, evidence_only, forward_only, O);
+                tr.mark("forward bookkeeping (behind the backward pass)");
+            }
             sync_stream(ctx, st);
             tr.mark("backward pass done + sums D2H");
+            if (late_copy) {
+                HIPCHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                ctx->timing.forward_ms += ms;
+            }
             HIPCHECK(hipEventElapsedTime(&ms, ev[2], ev[3]));
             ctx->timing.backward_ms += ms;
             if (n_mfma[1] > 0 && n_mfma[1] >= n_fast[1]) ctx->timing.bwd_kernel_variant = 3;
@@ -663,9 +682,9 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
                 if (CR.fused && !CR.fold(E, redB, fold_ev)) { resident_failed = true; return false; }
                 tr.mark("  prediction check + fold queued");
             }
-            // (a batch the backward kernel folded: nobody reads its row normalisers; means only where the caller asked for them)
-            raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O, !(cres_now && CR.fold_done),
-                                          !(cres_now && CR.fold_done) || E.chain_means) && raw_ok;
+            // (a batch the backward kernel folded: nobody reads its row normalisers; per-chain means only where the caller asked for them --
+            //  hyper- / change-point studies take theirs from the average posterior)
+            raw_ok = backward_bookkeeping(p, prog, redF, redB, B, dV, fused1d, res_now ? 0 : -1, O, !(cres_now && CR.fold_done), E.chain_means) && raw_ok;
             tr.mark("backward checks + fused fold + bookkeeping");
         } else if (forward_only) {
             for (int64_t b = 0; b < B; ++b)
@@ -861,6 +880,8 @@ blhip_ctx *blhip_create(int device) {
         for (auto &e : ctx->bev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming));
+        HIPCHECK(hipStreamCreateWithFlags(&ctx->cstream, hipStreamNonBlocking));
+        for (auto &e : ctx->cev) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, device));
         ctx->num_cus = prop.multiProcessorCount;
@@ -898,6 +919,8 @@ void blhip_destroy(blhip_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
+    if (ctx->cstream) { (void)hipStreamSynchronize(ctx->cstream); (void)hipStreamDestroy(ctx->cstream); }
+    for (auto &e : ctx->cev) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -935,7 +958,7 @@ int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
     // (a key the library never reads is an error, not a silent no-op: an A/B run over a removed option measured nothing -- ADVICE r05)
     static const char *const known[] = {
         "accum_overlap", "chain1d", "chain1d_clamp", "chain1d_shift", "chain_ax1", "chain_depad", "chain_prof", "chain_resident", "chain_resident_lag",
-        "chain_table", "chain_wide", "comm_reduce_mode", "fast", "fast_S", "fold2", "fold2_cp", "fuse1d", "fuse_accumulate", "max_batch",
+        "chain_table", "chain_wide", "comm_reduce_mode", "fast", "fast_S", "fold2", "fold2_cp", "fuse1d", "fuse_accumulate", "late_sums", "max_batch",
         "mem_budget_bytes", "mfma", "mfma_S", "mfma_h", "mfma_h_max_cells", "peer_copy_mode", "persist1d", "quiet", "recurrence", "resident",
         "resident_force_abort", "resident_lag", "resident_probe", "resident_probe_force_busy", "resident_probe_interval_s", "resident_probe_timeout_s",
         "resident_table", "resident_timeout_s", "share_prefix", "skip_prefix", "trace", "wide_h",

@@ -131,6 +131,8 @@ struct blhip_ctx {
     DevBuf anchbuf;              // the anchors of the likelihood recurrence of a chain-resident batch, tabulated once per batch (blc::anchor_table_kernel)
     DevBuf axlik;                // ... its likelihood table of the even time steps (transposed layout): ceil(T / 2) x n0p^2 doubles
     DevBuf xch;                  // exchange buffers of the both-axes chain-resident kernel (blhip_chainax.hpp): [slot][2 step parities][Gk]
+    hipStream_t cstream = nullptr;      // copy stream: the forward pass's sums travel to the host beside the backward pass (do_fit: late_copy)
+    hipEvent_t cev[2] = {nullptr, nullptr};
     hipStream_t astream = nullptr;
     hipEvent_t aev_done[2] = {nullptr, nullptr};
     // the co-residency probe (blr::residency_probe_kernel): when it last ran (steady-clock seconds, < 0: never / run it again), what it saw
