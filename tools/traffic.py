@@ -14,11 +14,11 @@ def kernel_direction(name):
     # the axis-1 pre-pass (blhip_hwide.hpp) runs in both passes: its own row, per launch (two launches per time step of a full fit)
     return 'prepass' if 'hwide_kernel' in name else _kd(name)
 
-FITS = 2
+FITS = int(os.environ.get('TRAFFIC_FITS', '2'))      # fits under the profiler: bench.py --steps 1 --warmup 1 (fwd2048 steady-state run: 45)
 SHAPES = dict(c4=dict(batches=2, T=256, cells=256 * 512 * 512, alg=(16, 32)), c5=dict(batches=4, T=1000, cells=62.5 * 512 * 512, alg=(16, 32)),
               c3=dict(batches=1, T=2000, cells=1024 * 1024, alg=(16, 32)), fwd2048=dict(batches=1, T=200, cells=2048 * 2048, alg=(16, 32)),
               c4_both_axes=dict(batches=2, T=256, cells=256 * 512 * 512, alg=(16, 32)), c4_rows1024=dict(batches=1, T=128, cells=128 * 1024 * 512, alg=(16, 32)),
-              coal_hyper1000=dict(batches=1, T=110, cells=256 * 1000, alg=(16, 32)), coal_breakpoints=dict(batches=23, T=41, cells=23400 / 23 * 1000, alg=(16, 32)))
+              coal_hyper1000=dict(batches=1, T=110, cells=256 * 1000, alg=(16, 32)), coal_breakpoints=dict(batches=6, T=41, cells=23400 / 6 * 1000, alg=(16, 32)))
 
 
 def counters(sub):
