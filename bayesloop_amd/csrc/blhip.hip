@@ -275,6 +275,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         E.DT = &DT; E.M = &M; E.prog = &prog; E.taps = &taps; E.step0 = FP.step0; E.d_post = d_post; E.log_w = log_w;
         E.chain_means = res && res->posterior_mean;
         E.overlap_acc = overlap_acc;
+        E.tr = &tr;
         ResidentRun RR;
         RR.setup(E, n_chains, fast, FP.use_rec != 0, psz);
         ChainRun CR;

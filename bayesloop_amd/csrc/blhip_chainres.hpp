@@ -292,6 +292,15 @@ __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) {
 #ifndef BLC_FASTEDGE
 #define BLC_FASTEDGE 1
 #endif
+#ifndef BLC_HOIST_A
+#define BLC_HOIST_A 1
+#endif
+#ifndef BLC_OWNREG
+#define BLC_OWNREG 1
+#endif
+#ifndef BLC_FOLD_HOIST_MAX
+#define BLC_FOLD_HOIST_MAX 20
+#endif
 typedef const double __attribute__((address_space(3))) *band_cp;
 // (Bv: a ring of NR >= OFF + NK entries, the tile's window begins at entry OFF -- compile-time, so the entries stay registers)
 // (AST: doubles between the tables of two shifts.  64 = one entry per lane; 16 = one entry per (k, i) pair, read by the four lanes
@@ -317,6 +326,21 @@ __device__ __forceinline__ d4 band_products(band_cp Al, const double (&Bv)[NR]) 
     for (int kb = 0; kb < NK; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Al[kb * 64], Bv[OFF + kb], acc, 0, 0, 0);
     return acc;
 #endif
+}
+// ... with the band's entries in registers (read once per step for all the wave's tiles: the A operand was 180 of the 350 KB a forward
+// step of a 512-row strip moved through the LDS -- 44 reads of 512 bytes per wave, the same 11 values for each of its four tiles)
+template <int NK, int OFF = 0, int NR = NK>
+__device__ __forceinline__ d4 band_products_w(const double (&Aw)[NK > 3 ? NK - 3 : 1], const double (&Bv)[NR]) {
+    static_assert(OFF + NK <= NR, "the tile's window lies inside the ring");
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NK - 3; ++s) {
+        a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[OFF + s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[OFF + s + 1], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[OFF + s + 2], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[OFF + s + 3], a3, 0, 0, 0);
+    }
+    return d4{a0, a1, a2, a3};
 }
 // entry e of a band table [NK][64]: the distance |input row - output row| its lane multiplies
 __device__ __forceinline__ int band_distance(int e, int R0) {
@@ -511,6 +535,25 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
     const bool prof_me = blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 2);
 #endif
     __syncthreads();
+    // OWNREG (forward kernels of exact geometries of <= 512 rows): a wave's OWN rows of the state stay in its registers from step to step --
+    // the ring entries over them are exactly the epilogue's outputs of the step before, lane for lane (both are "row + g + 4 r, column c").
+    // LDS then carries only what a neighbour reads: the R0 rows next to a wave's boundaries (and the mirrored rows of the grid's edges).
+    // Per wave and step of a 512-row strip with R0 = 20: 10 ring reads instead of 26, 10 state writes instead of 16 (with the band's
+    // entries in registers -- band_products_w -- 31 LDS accesses of 512 bytes instead of 86).
+#ifdef BLC_NO_WHOLE_RING
+    constexpr bool OWNREG = false;
+#else
+    constexpr bool OWNREG = BLC_OWNREG && BLC_FASTEDGE && FILTER && !BWD && NTW <= 4 && !PAD && NTW * TM >= R0;
+#endif
+    double own[OWNREG ? NTW : 1][4];
+    auto own_from_lds = [&](const double *Xs) {
+        const int l = fresh_lane(), g = l >> 4, c = l & 15;
+#pragma unroll
+        for (int it = 0; it < NTW; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) own[OWNREG ? it : 0][r] = Xs[(row0 + it * TM + g + 4 * r) * WCOL + c];
+    };
+    if constexpr (OWNREG) own_from_lds(X);
 
     for (int k = kb; k < P.T; ++k) {
         const int t = BWD ? P.T - 1 - k : k;
@@ -558,6 +601,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 S[e] = (!PAD || (row < n0t && col < n1t)) ? P.reset[(long long)row * n1t + col] : 0.0;
             }
             __syncthreads();
+            if constexpr (OWNREG) own_from_lds(S);
         }
         // (interior waves: consecutive k-blocks are 512 bytes apart -- one address register, immediate offsets; only waves whose
         //  window reaches beyond the grid edge pay for the reflection)
@@ -575,7 +619,25 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 #endif
         constexpr int NRING = WHOLE_RING ? NK + 4 * (NTW - 1) : NK;
         double Bv[NRING];
-        if (FILTER) {
+        if constexpr (OWNREG) {
+            constexpr int H = R0 / 4;                // ring entries on either side of the wave's own rows
+            const int l = fresh_lane(), g = l >> 4, c = l & 15;
+            const double *s0 = S + (row0 - R0 + g) * WCOL + c;
+            if (wv == 0) ring_fill_first_wave(Bv, S, g, c, 0, H, -R0);
+            else {
+#pragma unroll
+                for (int kb = 0; kb < H; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
+            }
+            if (wv == NW - 1) ring_fill_last_wave<N0, NTW * TM>(Bv, S, g, c, H + 4 * NTW, H, NTW * TM);
+            else {
+#pragma unroll
+                for (int kb = H + 4 * NTW; kb < NRING; ++kb) Bv[kb] = s0[kb * 4 * WCOL];
+            }
+#pragma unroll
+            for (int it = 0; it < NTW; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Bv[H + 4 * it + r] = own[OWNREG ? it : 0][r];
+        } else if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (FASTEDGE && wv == 0) ring_fill_first_wave(Bv, S, g, c, 0, NRING, -R0);
             else if (FASTEDGE && wv == NW - 1) ring_fill_last_wave<N0, NTW * TM>(Bv, S, g, c, 0, NRING, -R0);
@@ -618,6 +680,16 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         double *const pslot_tn = FOLD ? pslot + (long long)tn * G : nullptr;
         double wq = 0.0, wfloor = 0.0;                 // w / N_t and w * 1e-300: w max(p / N, 1e-300) = max(p wq, wfloor)
 
+        // the band's entries of this lane, once per step for all the wave's tiles (band_products_w)
+        constexpr bool HOISTA = BLC_HOIST_A && BLC_BAND4 && FILTER && NTW >= 2 && NK <= (BWD ? 20 : 24);      // (the storing backward kernels of the longest rings have no 2 (NK - 3) registers to spare)
+        double Aw[(HOISTA && NK > 3) ? NK - 3 : 1];
+        if constexpr (HOISTA) {
+            const int l = fresh_lane();
+            const unsigned aoff = AST == 16 ? (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u : (unsigned)l * 8u;
+            lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
+#pragma unroll
+            for (int q = 0; q < NK - 3; ++q) Aw[q] = Al[q * AST];
+        }
 #pragma unroll
         for (int it = 0; it < NTW; ++it) {
             const int i = row0 + it * TM;
@@ -633,11 +705,16 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
                 if (nofilter) {                              // (the change point comes after the walk in the model's list: the source unfiltered)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = S[(i + g + 4 * r) * WCOL + c];
+                    for (int r = 0; r < 4; ++r) acc[r] = OWNREG ? own[OWNREG ? it : 0][r] : S[(i + g + 4 * r) * WCOL + c];
+                } else if constexpr (WHOLE_RING && HOISTA) {
+                    acc = it == 0 ? band_products_w<NK, 0, NRING>(Aw, Bv) : (it == 1 ? band_products_w<NK, (NTW > 1 ? 4 : 0), NRING>(Aw, Bv) :
+                          (it == 2 ? band_products_w<NK, (NTW > 2 ? 8 : 0), NRING>(Aw, Bv) : band_products_w<NK, (NTW > 3 ? 12 : 0), NRING>(Aw, Bv)));
                 } else if constexpr (WHOLE_RING) {
                     // (`it` is a compile-time constant of the unrolled loop: one instantiation per tile)
                     acc = it == 0 ? band_products<NK, 0, NRING, AST>(Al, Bv) : (it == 1 ? band_products<NK, (NTW > 1 ? 4 : 0), NRING, AST>(Al, Bv) :
                           (it == 2 ? band_products<NK, (NTW > 2 ? 8 : 0), NRING, AST>(Al, Bv) : band_products<NK, (NTW > 3 ? 12 : 0), NRING, AST>(Al, Bv)));
+                } else if constexpr (HOISTA) {
+                    acc = band_products_w<NK, 0, NK>(Aw, Bv);
                 } else {
                     acc = band_products<NK, 0, NK, AST>(Al, Bv);
                 }
@@ -711,7 +788,11 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                 const unsigned off = cell_off(l, it, r);
                 if (!BWD) {
                     const double a = (!PAD || (colok && li < n0t)) ? acc[r] * Lv : 0.0;          // (cells outside the grid stay zero)
-                    if (TALL && FILTER) nst[it][r] = a; else if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
+                    if constexpr (OWNREG) {
+                        own[OWNREG ? it : 0][r] = a;
+                        // (rows nobody else reads stay out of the LDS: a neighbour's ring reaches R0 rows into this wave's)
+                        if (it * TM + 4 * r < R0 || it * TM + 4 * r + 4 > NTW * TM - R0) D[li * WCOL + c] = a;
+                    } else if (TALL && FILTER) nst[it][r] = a; else if (FILTER) D[li * WCOL + c] = a; else stt[it][r] = a;
                     if (STORE && t >= tsh) stnt(pstep, off, a);
                     sN += a;
                     if (!FILTER && want_x) sS = fma(a, rst[it][r], sS);
@@ -1075,12 +1156,24 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
         const int tnext = last_chain ? tn : t;
         const double *const pnext = Q.post + (long long)(tnext < (last_chain ? tshv[0] : tshv[1]) ? Q.bprov : bnext) * Q.post_stride + (long long)tnext * G;
 
+        // the band's entries of this lane and chain, once per chain-step for all the wave's tiles (band_products_w) -- where the registers allow
+        constexpr bool HOISTA = BLC_HOIST_A && BLC_BAND4 && FILTER && NTW >= 2 && NK <= BLC_FOLD_HOIST_MAX;
+        double Aw[(HOISTA && NK > 3) ? NK - 3 : 1];
+        if constexpr (HOISTA) {
+            const int l = fresh_lane();
+            const unsigned aoff = (AST == 16 ? (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u : (unsigned)l * 8u) + (unsigned)(j * NK * AST * 8);
+            lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
+#pragma unroll
+            for (int q = 0; q < NK - 3; ++q) Aw[q] = Al[q * AST];
+        }
 #pragma unroll
         for (int it = 0; it < NTW; ++it) {
             const int i = row0 + it * TM;
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
-            if (FILTER) {
+            if constexpr (FILTER && HOISTA) {
+                acc = band_products_w<NK, 0, NK>(Aw, Bv);
+            } else if (FILTER) {
                 const unsigned aoff = (AST == 16 ? (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u : (unsigned)l * 8u) + (unsigned)(j * NK * AST * 8);
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
                 acc = band_products<NK, 0, NK, AST>(Al, Bv);

@@ -14,6 +14,8 @@ struct BatchEnv {
     const double *log_w;          // log weights of ALL chains of the call (accumulate)
     bool chain_means;             // the caller asked for per-chain posterior means
     bool overlap_acc;             // folds of earlier batches may still run on the second stream (option accum_overlap)
+    Trace *tr = nullptr;          // option trace: host phases on stderr
+    void mark(const char *what) const { if (tr) tr->mark(what); }
 };
 
 // The resident backward kernels normalise every posterior by a PREDICTED sum (self-adjoint stencil identity); the host accepts the
@@ -321,6 +323,7 @@ struct ChainRun {
             cp.r0_max = (!tab && ctx->option("chain_wide", 1.0) != 0.0) ? CHAIN_R0_MAX : FAST_R0_MAX;
             cp.allow_ax1 = may_ax1;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
+            E.mark("  plan_chainres");
             if (on && tab && cp.ntw > 4) on = false;
             if (on && tab && cp.pad && cp.ntw >= 3 && !cp.ax1) on = false;      // (padded 384 / 512-row geometries with a likelihood table: no kernel -- never selected by a test or workload, pruned in round 5)
             if (on && prog.LW1 > 0 && !cp.ax1) on = false;
@@ -349,6 +352,7 @@ struct ChainRun {
         HIPCHECK(hipMemcpyAsync(d_tapid, cp.tap_id.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         HIPCHECK(hipMemcpyAsync(d_tapid1, cp.tap_id1.data(), (size_t)B * 4, hipMemcpyHostToDevice, E.st));
         sync_stream(ctx, E.st);
+        E.mark("  chain metadata H2D");
         if (ax1) {               // the exchange buffers of a launch's chain slots: [slot][2 step parities][Gk] tagged elements
             xch_bytes = (size_t)cp.cpr * 2 * (size_t)Gk * 8;
             {   // the exchange buffers and the likelihood table of the even steps are not part of chains_per_batch's budget: a long series
@@ -402,6 +406,7 @@ struct ChainRun {
             BL_LAUNCH(blc::anchor_table_kernel, dim3((unsigned)cp.strips, (unsigned)T), dim3(blc::NT), 0, E.st, AP);
             HIPCHECK(hipGetLastError());
             CQ.anch = ctx->anchbuf.as<double>();
+            E.mark("  anchor table queued");
         }
         // (the separate fold reads pairs of cells: an even number of columns; the fused fold's partials take any grid -- fold_parts_kernel)
         post_private = E.ff.accumulate && E.ff.full && !E.ff.keep && !E.ff.carry && ((G & 1) == 0 || cp.pad || ax1) && ((uintptr_t)ctx->acc & 15) == 0;
@@ -462,6 +467,7 @@ struct ChainRun {
         // The same chains need not COMPUTE that prefix either (a restart consumes the reset distribution, not the chain's past): with
         // skip_prefix a chain's forward pass begins at its first restart, the sums of its earlier steps are copied from the providing chain
         // (forward_ok).  Also for evidence-only fits, which store nothing.  C5: 250 chains x 1000 steps -> 125 k chain-steps of 250 k.
+        E.mark("  fold plan");
         share_prefix = false; skip_prefix = false;
         const bool may_share = fused && ctx->option("share_prefix", 1.0) != 0.0;
         const bool may_skip = (fused || E.ff.evidence_only) && ctx->option("skip_prefix", 1.0) != 0.0;
@@ -488,6 +494,7 @@ struct ChainRun {
                 }
             }
         }
+        E.mark("  prefix plan");
         if (fused) {
             ctx->accpart.ensure((size_t)slots_used * T * Gk * 8);
             ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(8192));
