@@ -307,10 +307,19 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams Parg) 
             const bool edge = row0 < R0 || row0 + NTW * TM + R0 > nlim;
             double Bv[NK];
             ring_fill(X0, Bv, edge, nlim);
+            // (the band's entries once per filter for all the wave's tiles: band_products_w, blhip_chainres.hpp)
+            constexpr bool HOIST1 = BLC_HOIST_A && NTW >= 2;
+            double Aw[HOIST1 ? NK - 3 : 1];
+            if constexpr (HOIST1) {
+                const lds_cp Al = band_ptr(Ab, fresh_lane());
+#pragma unroll
+                for (int q = 0; q < NK - 3; ++q) Aw[q] = Al[q * AST];
+            }
 #pragma unroll
             for (int it = 0; it < NTW; ++it) {
                 const int l = fresh_lane();
-                const d4 acc = band_products<NK, 0, NK, AST>(band_ptr(Ab, l), Bv);
+                d4 acc;
+                if constexpr (HOIST1) acc = band_products_w<NK, 0, NK>(Aw, Bv); else acc = band_products<NK, 0, NK, AST>(band_ptr(Ab, l), Bv);
                 double a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
                 swap_rows(a0, a1);
                 swap_rows(a2, a3);
@@ -452,11 +461,20 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams Parg) 
                     if (x == x) { const double dq = x - mub; s2 = fma(dq, dq, s2); dnb += 1.0; }
                 }
             }
+            // (second filter: where the epilogue leaves 2 (NK - 3) registers -- the forward kernels)
+            constexpr bool HOIST2 = BLC_HOIST_A && NTW >= 2 && !BWD;
+            double Aw2[HOIST2 ? NK - 3 : 1];
+            if constexpr (HOIST2) {
+                const lds_cp Al = band_ptr(Ab, fresh_lane());
+#pragma unroll
+                for (int q = 0; q < NK - 3; ++q) Aw2[q] = Al[q * AST];
+            }
 #pragma unroll
             for (int it = 0; it < NTW; ++it) {
                 const int i = row0 + it * TM;
                 const int l = fresh_lane(), g = l >> 4, c = l & 15;
-                d4 acc = band_products<NK, 0, NK, AST>(band_ptr(Ab, l), Bv);
+                d4 acc;
+                if constexpr (HOIST2) acc = band_products_w<NK, 0, NK>(Aw2, Bv); else acc = band_products<NK, 0, NK, AST>(band_ptr(Ab, l), Bv);
                 if (it == 0 && !lay_b && !tabled) {
                     // arg(r) = sum_k [-(x_k - mu_r)^2 cA - cB]  (observationModels.py:566-567; product over dimensions :49-50; blhip_mfma.hpp)
                     const double mu0 = m0s[i + g], mu4 = m0s[i + g + 4];

@@ -298,6 +298,9 @@ __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) {
 #ifndef BLC_OWNREG
 #define BLC_OWNREG 1
 #endif
+#ifndef BLC_HOIST_LOOP
+#define BLC_HOIST_LOOP 1
+#endif
 #ifndef BLC_FOLD_HOIST_MAX
 #define BLC_FOLD_HOIST_MAX 20
 #endif
@@ -545,6 +548,12 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
 #else
     constexpr bool OWNREG = BLC_OWNREG && BLC_FASTEDGE && FILTER && !BWD && NTW <= 4 && !PAD && NTW * TM >= R0;
 #endif
+#if BLC_HOIST_LOOP
+    // the band's entries of this lane in registers (band_products_w): read when the band changes -- the identity of the first step, the
+    // chain's band from the second on -- instead of 11 .. 21 LDS reads per step (c4 evidence-only 66.8 -> 64.5 ms)
+    constexpr bool HOISTA = BLC_HOIST_A && BLC_BAND4 && FILTER && NTW >= 2 && NK <= (BWD ? 20 : 24);      // (the storing backward kernels of the longest rings have no 2 (NK - 3) registers to spare)
+    double Aw[(HOISTA && NK > 3) ? NK - 3 : 1];
+#endif
     double own[OWNREG ? NTW : 1][4];
     auto own_from_lds = [&](const double *Xs) {
         const int l = fresh_lane(), g = l >> 4, c = l & 15;
@@ -681,9 +690,15 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
         double wq = 0.0, wfloor = 0.0;                 // w / N_t and w * 1e-300: w max(p / N, 1e-300) = max(p wq, wfloor)
 
         // the band's entries of this lane, once per step for all the wave's tiles (band_products_w)
+#if !BLC_HOIST_LOOP
         constexpr bool HOISTA = BLC_HOIST_A && BLC_BAND4 && FILTER && NTW >= 2 && NK <= (BWD ? 20 : 24);      // (the storing backward kernels of the longest rings have no 2 (NK - 3) registers to spare)
+#endif
+#if BLC_HOIST_LOOP
+        if (HOISTA && k <= kb + 1) {
+#else
         double Aw[(HOISTA && NK > 3) ? NK - 3 : 1];
         if constexpr (HOISTA) {
+#endif
             const int l = fresh_lane();
             const unsigned aoff = AST == 16 ? (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u : (unsigned)l * 8u;
             lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
