@@ -409,7 +409,7 @@ def run_steady(bl, name, min_fits=1, warm_s=0.05, timed_s=0.03, max_fits=60):
     for at least `timed_s` seconds (at least `min_fits`).  -> (study, units, description, seconds per fit, warm-up fits, timed fits).
     Why: after the idle stretch in which a study is set up the chip needs ~25 ms of load before its kernels run at their steady rate --
     the 2048^2 forward launch (200 steps) takes 1.96, 1.93, 1.91, ... ms and settles at 1.69 ms with the 13th launch
-    (profiles/r06_fwd2048_kernel_trace_45_launches.csv); three warm-up fits of 2 ms measured the ramp, not the path."""
+    (profiles/r06d_fwd2048_kernel_trace.csv); three warm-up fits of 2 ms measured the ramp, not the path."""
     S, kw, units, desc = make_study(bl, name, None)
     eng = bl.get_engine()
     n_warm, t0 = 0, time.perf_counter()
