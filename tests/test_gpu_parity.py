@@ -1593,6 +1593,29 @@ def test_average_posterior_folded_on_the_second_stream():
     np.testing.assert_allclose(B.hyperParameterDistribution, A.hyperParameterDistribution, rtol=1e-11)
 
 
+def test_forward_sums_beside_the_backward_pass_change_nothing():
+    """late_sums (round 6): batches of >= 64 chains on the launch-per-step / 1-D chain kernels queue their backward pass without waiting for the
+    forward pass's sums, which travel to the host on a copy stream beside it.  Same numbers bit for bit as with the wait (late_sums = 0),
+    on a 1-D hyper-study (chain kernel) and a 2-D one outside the resident envelopes (launch-per-step kernels); and the oracle's."""
+    eng = bl.get_engine()
+    for c in (dict(study='HyperStudy', data=cases.COAL, timestamps=cases.COAL_T, om=('Poisson', [('rate', ('oint', 0, 6, 200))], 'default'),
+                   tm=('GRW', 'sigma', ('cint', 0, 1.0, 96), 'rate', None)),
+              _hyper(24, 32, 91, 7, ('cint', 0.1, 0.5, 70))):                 # fewer than 32 rows: no resident path
+        A = cases.build(bl, c); A.fit(silent=True)
+        eng.set_option('late_sums', 0)
+        try:
+            B = cases.build(bl, c); B.fit(silent=True)
+        finally:
+            eng.set_option('late_sums', 1)
+        assert A.logEvidence == B.logEvidence
+        assert np.array_equal(np.array(A.logEvidenceList), np.array(B.logEvidenceList))
+        assert np.array_equal(np.array(A.localEvidenceList), np.array(B.localEvidenceList), equal_nan=True)
+        assert np.array_equal(np.array(A.posteriorSequence), np.array(B.posteriorSequence))
+        with np.errstate(all='ignore'):
+            want = oa.run(c)
+        assert abs(A.logEvidence - want['logEvidence']) <= 1e-9 * abs(want['logEvidence'])
+
+
 def test_fused_fold_matches_the_separate_fold():
     """fuse_accumulate = 0: the backward chain kernel stores the posteriors and the average posterior is folded by a separate pass."""
     eng = bl.get_engine()
