@@ -83,6 +83,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     for (int k = 0; k < p->ndim; ++k) dV *= p->lattice[k];
 
     ctx->post_valid = false;
+    ctx->part = blhip_ctx::PartState{};            // (carried partial accumulators live inside one call)
     ctx->timing = blhip_timing{};
     ctx->resident_last_reason = 0;
     // a context whose resident launch once gave up tries the resident paths again after a while (one hiccup -- another process
@@ -167,6 +168,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     std::thread builder;
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } builder_guard{builder};      // (also when a batch throws)
     const bool build_ahead = nbatch > 1;
+    int64_t fallback_until = -1;                   // batches up to this one repeat on the launch-per-step kernels (poisoned carried slots, below)
     for (int64_t bi = 0; bi < nbatch; ++bi) {
         const int64_t c0 = batch_start[bi], B = batch_start[bi + 1] - c0;
         tr.mark("batch setup");
@@ -276,6 +278,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         E.chain_means = res && res->posterior_mean;
         E.overlap_acc = overlap_acc;
         E.tr = &tr;
+        E.fold_ev = &fold_ev; E.bi = bi; E.allow_chainres = bi > fallback_until;
         ResidentRun RR;
         RR.setup(E, n_chains, fast, FP.use_rec != 0, psz);
         ChainRun CR;
@@ -703,6 +706,21 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
             if (resident_failed) {                   // the launch-per-step kernels take over (timing of the failed attempt is dropped)
                 ctx->timing.resident_fallbacks += 1;
                 ctx->timing.resident_fallback_reason = ctx->resident_last_reason ? ctx->resident_last_reason : BLHIP_FALLBACK_RANGE;
+                if (CR.on && CR.touched_parts && !CR.part_fresh0) {
+                    // the failed backward pass has added to partial accumulators that carry earlier batches of this call: none of them is in
+                    // the average posterior yet -- those batches and this one are repeated on the launch-per-step kernels
+                    const int64_t from = ctx->part.live ? ctx->part.first_batch : bi;
+                    ctx->part = blhip_ctx::PartState{};
+                    ctx->timing.forward_ms = ctx->timing.backward_ms = 0.0;
+                    ctx->timing.fwd_hbm_bytes = ctx->timing.bwd_hbm_bytes = ctx->timing.fwd_flops = ctx->timing.bwd_flops = 0.0;
+                    ctx->timing.forward_launches = ctx->timing.backward_launches = 0;
+                    fallback_until = bi;
+                    if (builder.joinable()) builder.join();
+                    bprog[0].reset(); bprog[1].reset();
+                    sync_stream(ctx, st);
+                    bi = from - 1;
+                    continue;
+                }
                 ctx->timing.forward_ms = ctx->timing.backward_ms = 0.0;
                 ctx->timing.fwd_hbm_bytes = ctx->timing.bwd_hbm_bytes = ctx->timing.fwd_flops = ctx->timing.bwd_flops = 0.0;
                 ctx->timing.forward_launches = ctx->timing.backward_launches = 0;
@@ -764,6 +782,7 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
         tr.mark("fold / keep / carry");
         write_results(res, p, c0, B, O, !evidence_only);
     }
+    flush_partials(ctx, st, &fold_ev);         // the carried partial accumulators of the chain-resident fold -> the average posterior
     if (overlap_acc || !fold_ev.empty()) {     // the last fold(s) before anybody reads the accumulator; their time from their events
         sync_stream(ctx, overlap_acc ? ctx->astream : st);
         for (size_t k = 0; k + 1 < fold_ev.size(); k += 2) {
@@ -958,8 +977,8 @@ int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
     if (std::strcmp(key, "resident_retry_after") == 0) { ctx->resident_retry_after = std::max(1, (int)value); return 0; }
     // (a key the library never reads is an error, not a silent no-op: an A/B run over a removed option measured nothing -- ADVICE r05)
     static const char *const known[] = {
-        "accum_overlap", "chain1d", "chain1d_clamp", "chain1d_shift", "chain_ax1", "chain_depad", "chain_prof", "chain_resident", "chain_resident_lag",
-        "chain_table", "chain_wide", "comm_reduce_mode", "fast", "fast_S", "fold2", "fold2_cp", "fuse1d", "fuse_accumulate", "late_sums", "max_batch",
+        "accum_overlap", "carry_partials", "chain1d", "chain1d_clamp", "chain1d_shift", "chain_ax1", "chain_depad", "chain_prof", "chain_resident", "chain_resident_lag",
+        "chain_table", "chain_wide", "comm_reduce_mode", "fast", "fast_S", "fold2", "fold2_cp", "fold_force_fail_batch", "fuse1d", "fuse_accumulate", "late_sums", "max_batch",
         "mem_budget_bytes", "mfma", "mfma_S", "mfma_h", "mfma_h_max_cells", "peer_copy_mode", "persist1d", "quiet", "recurrence", "resident",
         "resident_force_abort", "resident_lag", "resident_probe", "resident_probe_force_busy", "resident_probe_interval_s", "resident_probe_timeout_s",
         "resident_table", "resident_timeout_s", "share_prefix", "skip_prefix", "trace", "wide_h",

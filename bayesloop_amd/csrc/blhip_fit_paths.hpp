@@ -14,6 +14,9 @@ struct BatchEnv {
     const double *log_w;          // log weights of ALL chains of the call (accumulate)
     bool chain_means;             // the caller asked for per-chain posterior means
     bool overlap_acc;             // folds of earlier batches may still run on the second stream (option accum_overlap)
+    std::vector<hipEvent_t> *fold_ev = nullptr;      // start / end events of fold kernels nobody waits for (do_fit reads them after its last batch)
+    int64_t bi = 0;               // index of the batch in the call
+    bool allow_chainres = true;   // false: a repeated batch (its first attempt poisoned the carried partial accumulators)
     Trace *tr = nullptr;          // option trace: host phases on stderr
     void mark(const char *what) const { if (tr) tr->mark(what); }
 };
@@ -266,6 +269,29 @@ struct ResidentRun {
 };
 
 // ---- the chain-resident path of a batch: rounds of chains stay in LDS for a whole pass (blhip_chainres.hpp) ---------------------------
+// The carried partial accumulators (blhip_ctx::PartState) -> the average posterior.  Nobody waits for the kernel here.
+void flush_partials(blhip_ctx *ctx, hipStream_t st, std::vector<hipEvent_t> *later_ev) {
+    blhip_ctx::PartState &ps = ctx->part;
+    if (!ps.live) return;
+    const double newref = std::max(ctx->acc_logref, ps.maxlw);
+    const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(ps.ref - newref);
+    const long long G = (long long)ps.n0 * ps.n1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (later_ev) {
+        HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+        later_ev->push_back(e0); later_ev->push_back(e1);
+        HIPCHECK(hipEventRecord(e0, st));
+    }
+    BL_LAUNCH(fold_parts_kernel, dim3((unsigned)(((G + 1) / 2 + NTHREADS - 1) / NTHREADS), (unsigned)ps.T), dim3(NTHREADS), 0, st, ctx->acc,
+                       ctx->accpart.as<double>(), (long long)ps.T * ps.Gk, ps.slots_init, ps.n0, ps.n1, ps.T, r, rb,
+                       ctx->acc_first ? 1 : 0, ps.n0p, ps.Gk, ps.ax1);
+    HIPCHECK(hipGetLastError());
+    if (later_ev) HIPCHECK(hipEventRecord(e1, st));
+    ctx->timing.accumulate_launches += 1;
+    ctx->acc_logref = newref; ctx->acc_first = false; ctx->acc_folded += ps.nfold;
+    ps = blhip_ctx::PartState{};
+}
+
 struct ChainRun {
     bool on = false;
     ChainResPlan cp;
@@ -289,7 +315,9 @@ struct ChainRun {
     // them (the separate fold re-read the whole sequence at the memory roof while the backward pass of the wide bands left
     // bandwidth unused: same bytes, one pass)
     bool fused = false;
-    bool fold_done = false;                        // this batch's posteriors are in the accumulator already
+    bool fold_done = false;                        // this batch's posteriors are in the accumulator already (or in the carried partial accumulators)
+    bool part_fresh0 = true;                       // the first launch of the backward pass starts the slots (false: they carry earlier batches)
+    bool touched_parts = false;                    // the backward pass of this batch has written the carried slots
     // fused fold with TWO chains per block (blc::chain_fold2_kernel): the backward pass runs rounds of 2 x cpr chains of its own
     bool fold2 = false;
     std::vector<int> round_start_b, round_nk_b;
@@ -304,7 +332,8 @@ struct ChainRun {
     long long Gk = 0;                              // cells per distribution on the geometry the kernels work on (padded: >= G)
     double *d_fold_sfwd = nullptr, *d_fold_w = nullptr, *d_fold_inf = nullptr, *d_zeros = nullptr;
     std::vector<double> fold_lw;                   // log weight of every chain of the batch (-inf: none)
-    double fold_ref = -INFINITY;
+    double fold_ref = -INFINITY;                    // the reference the batch's weights are relative to (the carried slots' one where they are continued)
+    double fold_max = -INFINITY;                    // the batch's largest log weight
 
     void setup(const BatchEnv &E, bool fast, bool use_rec, size_t &psz) {
         blhip_ctx *ctx = E.ctx;
@@ -319,7 +348,7 @@ struct ChainRun {
         const bool may_ax1 = (gauss || tab) && prog.LW1 > 0 && ctx->option("chain_ax1", 1.0) != 0.0;
         if (fast && (gauss || tab) && !E.ff.resume && !E.ff.carry && !E.p->backward_init &&
             !prog.has_clamp && (prog.LW1 == 0 || may_ax1) && (double)G * 8.0 < 4.0e9 && ctx->option("chain_resident", 1.0) != 0.0 && ctx->resident_ok &&
-            true) {
+            E.allow_chainres) {
             cp.r0_max = (!tab && ctx->option("chain_wide", 1.0) != 0.0) ? CHAIN_R0_MAX : FAST_R0_MAX;
             cp.allow_ax1 = may_ax1;
             on = plan_chainres(E.g, prog, *E.taps, B, T, E.ff.full, std::min(ctx->num_cus, 256), cp);
@@ -496,6 +525,10 @@ struct ChainRun {
         }
         E.mark("  prefix plan");
         if (fused) {
+            // (carried slots of earlier batches: a larger buffer or another layout takes them into the accumulator first)
+            if (ctx->part.live && ((size_t)slots_used * T * Gk * 8 > ctx->accpart.cap || ctx->part.T != (int)T || ctx->part.Gk != Gk || ctx->part.n0 != E.g.n0 ||
+                                   ctx->part.n1 != E.g.n1 || ctx->part.n0p != cp.n0p || ctx->part.ax1 != (ax1 ? 1 : 0)))
+                flush_partials(ctx, E.st, E.fold_ev);
             ctx->accpart.ensure((size_t)slots_used * T * Gk * 8);
             ctx->accw.ensure(carve_size((size_t)T * B * 8) + 2 * carve_size((size_t)B * 8) + carve_size(8192));
             char *wc = ctx->accw.as<char>();
@@ -531,7 +564,8 @@ struct ChainRun {
             if (fold_now) {
                 Q.sfwd = d_fold_sfwd; Q.wchain = d_fold_w; Q.infirst = d_fold_inf;
                 Q.part = ctx->accpart.as<double>(); Q.part_stride = (long long)T * Gk;
-                Q.zeros = d_zeros; Q.part_fresh = r == 0 ? 1 : 0;          // (every slot is first used by the first launch: no memset)
+                Q.zeros = d_zeros; Q.part_fresh = (r == 0 && part_fresh0) ? 1 : 0;          // (every slot is first used by the first launch: no memset)
+                touched_parts = true;
             }
 #ifdef BLC_PROF
             ctx->small.ensure(2 * 16 * 16 * 8);
@@ -635,6 +669,14 @@ struct ChainRun {
             fold_lw[b] = O.logE[b] + E.log_w[E.c0 + b];
             fold_ref = std::max(fold_ref, fold_lw[b]);
         }
+        // the slots carry earlier batches of this call: this batch's weights take THEIR reference (a batch whose evidence towers 500
+        // e-folds above it would overflow them: the carried slots go into the accumulator first and the batch starts afresh)
+        fold_max = fold_ref;
+        part_fresh0 = true;
+        if (ctx->part.live && ctx->option("carry_partials", 1.0) != 0.0) {
+            if (!(fold_ref - ctx->part.ref <= 500.0)) flush_partials(ctx, E.st, E.fold_ev);
+            else { fold_ref = ctx->part.ref; part_fresh0 = false; }
+        } else if (ctx->part.live) flush_partials(ctx, E.st, E.fold_ev);
         ctx->pinA.ensure(((size_t)T * B + 2 * (size_t)B) * 8);
         double *h = ctx->pinA.as<double>(), *hw = h + (size_t)T * B, *hi = hw + B;
         for (int64_t b = 0; b < B; ++b) {
@@ -653,8 +695,10 @@ struct ChainRun {
         // the slots need no memset: the first launch of the pass reads zeros instead of them (part_fresh) -- except slots it does not
         // use (a first launch with fewer chains than slots), which later launches may
         const int first_n = fold2 ? (round_start_b[1] - round_start_b[0] + 1) / 2 : cp.round_start[1] - cp.round_start[0];
-        if (first_n < slots_used)
-            HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)first_n * T * Gk, 0, (size_t)(slots_used - first_n) * T * Gk * 8, E.st));
+        // (carried slots: only those no earlier batch has written)
+        const int have = part_fresh0 ? first_n : ctx->part.slots_init;
+        if (have < slots_used)
+            HIPCHECK(hipMemsetAsync(ctx->accpart.as<double>() + (size_t)have * T * Gk, 0, (size_t)(slots_used - have) * T * Gk * 8, E.st));
         HIPCHECK(hipMemsetAsync(d_zeros, 0, 8192, E.st));
     }
 
@@ -676,6 +720,8 @@ struct ChainRun {
     //  setup run beside it, do_fit reads the events after its last batch)
     bool fold(const BatchEnv &E, const double *redB, std::vector<hipEvent_t> &later_ev) {
         blhip_ctx *ctx = E.ctx;
+        // (tests of the repeat after poisoned carried slots: pretend that this batch's prediction check failed)
+        if ((int64_t)ctx->option("fold_force_fail_batch", -1.0) == E.bi) { ctx->resident_last_reason = BLHIP_FALLBACK_PREDICTION; return false; }
         hipStream_t st = E.st;
         const int64_t T = E.T, B = E.B;
         const long long G = E.G;
@@ -703,20 +749,16 @@ struct ChainRun {
             }
         }
         if (std::isfinite(fold_ref)) {
-            const double newref = std::max(ctx->acc_logref, fold_ref);
-            const double r = ctx->acc_first ? 0.0 : std::exp(ctx->acc_logref - newref), rb = std::exp(fold_ref - newref);
-            hipEvent_t e0, e1;
-            HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
-            later_ev.push_back(e0); later_ev.push_back(e1);
-            HIPCHECK(hipEventRecord(e0, st));
-            BL_LAUNCH(fold_parts_kernel, dim3((unsigned)(((G + 1) / 2 + NTHREADS - 1) / NTHREADS), (unsigned)T), dim3(NTHREADS), 0, st, ctx->acc,
-                               ctx->accpart.as<double>(), (long long)T * Gk, slots_used, E.g.n0, E.g.n1, (int)T, r, rb,
-                               ctx->acc_first ? 1 : 0, cp.n0p, Gk, ax1 ? 1 : 0);
-            HIPCHECK(hipEventRecord(e1, st));
-            ctx->timing.accumulate_launches += 1;
+            // the slots stay where they are: the next batch of the call adds to them, do_fit folds them after the last one (flush_partials)
+            blhip_ctx::PartState &ps = ctx->part;
             int nfold = 0;
             for (int64_t b = 0; b < B; ++b) nfold += std::isfinite(fold_lw[b]) ? 1 : 0;
-            ctx->acc_logref = newref; ctx->acc_first = false; ctx->acc_folded += nfold;
+            if (!ps.live) { ps = blhip_ctx::PartState{}; ps.live = true; ps.ref = fold_ref; ps.first_batch = E.bi; }
+            ps.maxlw = std::max(ps.maxlw, fold_max);
+            ps.slots_init = std::max(ps.slots_init, slots_used);
+            ps.nfold += nfold;
+            ps.n0 = E.g.n0; ps.n1 = E.g.n1; ps.T = (int)T; ps.n0p = cp.n0p; ps.ax1 = ax1 ? 1 : 0; ps.Gk = Gk;
+            (void)later_ev; (void)G; (void)st;
         }
         fold_done = true;
         return true;

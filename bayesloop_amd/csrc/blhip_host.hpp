@@ -128,6 +128,19 @@ struct blhip_ctx {
     DevBuf p1d, p1w;             // hand-off buffers / weight table of the persistent 1-D kernel (blhip_persist1d.hpp)
     DevBuf lik1d;                // (T, n) likelihood table the chains of a 1-D batch share (blhip_chain1d.hpp)
     DevBuf accpart;              // partial accumulators of the fused fold (one per launch slot of the chain-resident kernel)
+    // The partial accumulators are CARRIED from batch to batch of one blhip_fit call (round 6): the batches' weights share the reference of
+    // the first one, the slots go into the average posterior once, after the call's last batch (fold_parts_kernel read 8 + 2 sequences of
+    // T x G cells per batch: 4 x 4 ms of BASELINE C5's 226).  A batch that fails its checks after its backward pass has written the slots
+    // poisons them: the call repeats the batches since `first_batch` on the launch-per-step kernels (do_fit).
+    struct PartState {
+        bool live = false;                  // the slots hold contributions that are not in the accumulator yet
+        double ref = -std::numeric_limits<double>::infinity();       // ... weighted relative to this log weight
+        double maxlw = -std::numeric_limits<double>::infinity();     // largest log weight among them
+        int slots_init = 0;                 // slots written so far (a batch that uses more zeroes the new ones)
+        int nfold = 0;                      // chains they hold
+        int64_t first_batch = 0;            // first batch of the call with contributions in them
+        int n0 = 0, n1 = 0, T = 0, n0p = 0, ax1 = 0; long long Gk = 0;      // layout (fold_parts_kernel's arguments)
+    } part;
     DevBuf anchbuf;              // the anchors of the likelihood recurrence of a chain-resident batch, tabulated once per batch (blc::anchor_table_kernel)
     DevBuf axlik;                // ... its likelihood table of the even time steps (transposed layout): ceil(T / 2) x n0p^2 doubles
     DevBuf xch;                  // exchange buffers of the both-axes chain-resident kernel (blhip_chainax.hpp): [slot][2 step parities][Gk]

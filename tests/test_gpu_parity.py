@@ -1593,6 +1593,46 @@ def test_average_posterior_folded_on_the_second_stream():
     np.testing.assert_allclose(B.hyperParameterDistribution, A.hyperParameterDistribution, rtol=1e-11)
 
 
+def test_partial_accumulators_carried_from_batch_to_batch():
+    """Round 6: the partial accumulators of the chain-resident fold are carried through the batches of a call (their weights share the first
+    batch's reference) and go into the average posterior ONCE.  Same results as one fold per batch (carry_partials = 0) up to the order of
+    the sums; a batch whose check fails after its backward pass has added to carried slots (forced here) makes the call repeat the batches
+    the slots held on the launch-per-step kernels -- same results again."""
+    eng = bl.get_engine()
+    c = _hyper(128, 64, 93, 8, ('cint', 0, 0.9, 40))
+    eng.set_option('max_batch', 16)
+    try:
+        A = cases.build(bl, c); A.fit(silent=True)
+        assert A.lastTiming['batches'] == 3 and A.lastTiming['accumulate_launches'] == 1 and A.lastTiming['bwd_kernel_variant'] == 6, A.lastTiming
+        eng.set_option('carry_partials', 0)
+        try:
+            B = cases.build(bl, c); B.fit(silent=True)
+            assert B.lastTiming['accumulate_launches'] == 3, B.lastTiming
+        finally:
+            eng.set_option('carry_partials', 1)
+        runs = [B]
+        for bad in (1, 2):
+            eng.set_option('fold_force_fail_batch', bad)
+            try:
+                C = cases.build(bl, c); C.fit(silent=True)
+                assert C.lastTiming['resident_fallbacks'] >= 1 and C.lastTiming['resident_fallback_reason'] == 3, C.lastTiming      # BLHIP_FALLBACK_PREDICTION
+            finally:
+                eng.set_option('fold_force_fail_batch', -1)
+            runs.append(C)
+    finally:
+        eng.set_option('max_batch', 1024)
+    for R in runs:
+        assert abs(A.logEvidence - R.logEvidence) <= 1e-12 * abs(A.logEvidence)
+        np.testing.assert_allclose(np.array(R.posteriorSequence), np.array(A.posteriorSequence), rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(R.posteriorMeanValues, A.posteriorMeanValues, rtol=1e-10)
+        np.testing.assert_allclose(R.hyperParameterDistribution, A.hyperParameterDistribution, rtol=1e-11)
+    with np.errstate(all='ignore'):
+        want = oa.run(c)
+    compare.check(dict(logEvidence=A.logEvidence, localEvidence=A.localEvidence, posteriorSequence=A.posteriorSequence, posteriorMeanValues=A.posteriorMeanValues),
+                  dict(logEvidence=want['logEvidence'], localEvidence=want['localEvidence'], posteriorSequence=want['posteriorSequence'],
+                       posteriorMeanValues=want['posteriorMeanValues']), compare.GPU_TOL)
+
+
 def test_forward_sums_beside_the_backward_pass_change_nothing():
     """late_sums (round 6): batches of >= 64 chains on the launch-per-step / 1-D chain kernels queue their backward pass without waiting for the
     forward pass's sums, which travel to the host on a copy stream beside it.  Same numbers bit for bit as with the wait (late_sums = 0),
