@@ -129,6 +129,12 @@ void do_fit(blhip_ctx *ctx, const blhip_problem *p_in, int64_t n_chains, const d
     const bool chain_wide = chain_shape && p->obs_model == BLHIP_OM_GAUSSIAN && ctx->option("chain_wide", 1.0) != 0.0;
     if (!overlap_acc && !ff.keep && !ff.resume && !ff.carry && ctx->option("wide_v", 1.0) != 0.0)
         split_wide_axis0(p, n_chains, op_values, batch_start, chain_wide ? CHAIN_R0_MAX : FAST_R0_MAX);
+    // Batches of thousands of chains (1-D studies: the published break-point study runs 6 x 3900): the per-(step, chain) program of batch
+    // bi + 1 is built by a second host thread while batch bi runs -- all but the FIRST one's, 3.9 ms of a 42-ms fit with the GPU idle.  A
+    // short first batch (1024 chains: 0.7 ms of program) starts the pipeline earlier.
+    if (!overlap_acc && batch_start.size() >= 2 && batch_start[1] - batch_start[0] >= 2048 && !ff.keep && !ff.resume && !ff.carry &&
+        ctx->option("short_first_batch", 1.0) != 0.0)
+        batch_start.insert(batch_start.begin() + 1, batch_start[0] + 1024);
     const int64_t nbatch = (int64_t)batch_start.size() - 1;
     ctx->timing.batches = nbatch;
 
@@ -981,7 +987,7 @@ int blhip_set_option(blhip_ctx *ctx, const char *key, double value) {
         "chain_table", "chain_wide", "comm_reduce_mode", "fast", "fast_S", "fold2", "fold2_cp", "fold_force_fail_batch", "fuse1d", "fuse_accumulate", "late_sums", "max_batch",
         "mem_budget_bytes", "mfma", "mfma_S", "mfma_h", "mfma_h_max_cells", "peer_copy_mode", "persist1d", "quiet", "recurrence", "resident",
         "resident_force_abort", "resident_lag", "resident_probe", "resident_probe_force_busy", "resident_probe_interval_s", "resident_probe_timeout_s",
-        "resident_table", "resident_timeout_s", "share_prefix", "skip_prefix", "trace", "wide_h",
+        "resident_table", "resident_timeout_s", "share_prefix", "short_first_batch", "skip_prefix", "trace", "wide_h",
         "wide_h_fused_max", "wide_h_split", "wide_v"};
     bool ok = false;
     for (const char *k : known) ok = ok || std::strcmp(key, k) == 0;
