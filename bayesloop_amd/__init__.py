@@ -15,11 +15,27 @@ from . import transitionModels
 from . import transitionModels as tm
 from .helper import cint, oint
 from .fileIO import save, load
-from .parser import Parser
-from . import jeffreys
-from .jeffreys import getJeffreysPrior, computeJeffreysPriorAR1
 from .exceptions import ConfigurationError, PostProcessingError, BackendError
 from . import dist
 from .engine import get_engine, set_engine
 
 __version__ = '0.1.0'
+
+# Parser (scipy.special: 0.2 - 0.4 s of import on its own) and the Jeffreys-prior helpers are not on the fit() path: first use imports them
+_LAZY = {'Parser': ('.parser', 'Parser'), 'parser': ('.parser', None), 'jeffreys': ('.jeffreys', None),
+         'getJeffreysPrior': ('.jeffreys', 'getJeffreysPrior'), 'computeJeffreysPriorAR1': ('.jeffreys', 'computeJeffreysPriorAR1')}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        mod, attr = _LAZY[name]
+        m = importlib.import_module(mod, __name__)
+        v = m if attr is None else getattr(m, attr)
+        globals()[name] = v
+        return v
+    raise AttributeError('module %r has no attribute %r' % (__name__, name))
+
+
+def __dir__():
+    return sorted(list(globals()) + list(_LAZY))
