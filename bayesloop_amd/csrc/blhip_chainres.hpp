@@ -298,6 +298,9 @@ __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) {
 #ifndef BLC_OWNREG
 #define BLC_OWNREG 1
 #endif
+#ifndef BLC_CIRC_RING
+#define BLC_CIRC_RING 1
+#endif
 #ifndef BLC_HOIST_LOOP
 #define BLC_HOIST_LOOP 1
 #endif
@@ -345,6 +348,37 @@ __device__ __forceinline__ d4 band_products_w(const double (&Aw)[NK > 3 ? NK - 3
     }
     return d4{a0, a1, a2, a3};
 }
+// ... over a CIRCULAR ring: entry e of the strip's ring lives in register Bv[e % NR].  A tile's window begins 4 entries behind the previous
+// one's, so the four entries a tile no longer needs are exactly the slots of the four new ones: no ring shift (the sliding ring copied
+// NK - 4 entries = 2 (NK - 4) v_mov per tile, 60 of the two-chain fold kernel's ~580 vector instructions per chain-step at NK 14).  NR = NK
+// where 4 divides NK, NK + 2 otherwise (the slots of a window's last entries must not be those of the next window's first ones while
+// the window is in use).  `first` = the window's first entry; a constant once the tile loop is unrolled.
+template <int NK> constexpr int ring_mod() { return NK % 4 == 0 ? NK : NK + 2; }
+template <int NK, int NR>
+__device__ __forceinline__ d4 band_products_wc(const double (&Aw)[NK > 3 ? NK - 3 : 1], const double (&Bv)[NR], int first) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NK - 3; ++s) {
+        a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[(first + s) % NR], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[(first + s + 1) % NR], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[(first + s + 2) % NR], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s], Bv[(first + s + 3) % NR], a3, 0, 0, 0);
+    }
+    return d4{a0, a1, a2, a3};
+}
+template <int NK, int NR, int AST>
+__device__ __forceinline__ d4 band_products_c(band_cp Al, const double (&Bv)[NR], int first) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NK - 3; ++s) {
+        const double A = Al[s * AST];
+        a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[(first + s) % NR], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[(first + s + 1) % NR], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[(first + s + 2) % NR], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bv[(first + s + 3) % NR], a3, 0, 0, 0);
+    }
+    return d4{a0, a1, a2, a3};
+}
 // entry e of a band table [NK][64]: the distance |input row - output row| its lane multiplies
 __device__ __forceinline__ int band_distance(int e, int R0) {
 #if BLC_BAND4
@@ -376,8 +410,9 @@ __device__ __forceinline__ void ring_fill_first_wave(double (&Bv)[NR], const dou
         if (q < cnt) Bv[k0 + q] = rel < 0 ? sm[(-rel - 4) * WCOL] : s0[rel * WCOL];
     }
 }
+// (kmod: slot of entry k0 + q = (k0 + q) % kmod -- the circular rings of the backward kernels; 0: the slot is the entry)
 template <int N0, int ROWS_W, int NR>
-__device__ __forceinline__ void ring_fill_last_wave(double (&Bv)[NR], const double *S, int g, int c, int k0, int cnt, int rel0) {       // (row0 = N0 - ROWS_W)
+__device__ __forceinline__ void ring_fill_last_wave(double (&Bv)[NR], const double *S, int g, int c, int k0, int cnt, int rel0, int kmod = 0) {       // (row0 = N0 - ROWS_W)
     constexpr int row0 = N0 - ROWS_W;
     const int relmax = rel0 + 4 * (cnt - 1);
     const double *sm = S + (2 * N0 - 1 - row0 - relmax - g) * WCOL + c;      // mirrored at the last row: row 2 N0 - 1 - (row0 + rel + g)
@@ -385,7 +420,7 @@ __device__ __forceinline__ void ring_fill_last_wave(double (&Bv)[NR], const doub
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
         const int rel = rel0 + 4 * q;
-        if (q < cnt) Bv[k0 + q] = rel >= ROWS_W ? sm[(relmax - rel) * WCOL] : s0[(rel - rel0) * WCOL];
+        if (q < cnt) Bv[kmod ? (k0 + q) % kmod : k0 + q] = rel >= ROWS_W ? sm[(relmax - rel) * WCOL] : s0[(rel - rel0) * WCOL];
     }
 }
 
@@ -1146,7 +1181,8 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
 
         const bool edge = row0 < R0 || row0 + NTW * TM + R0 > n0t;          // (the reflection is at the grid's true last row)
         constexpr bool FASTEDGE = BLC_FASTEDGE && FILTER && !PAD && NTW * TM >= R0;       // (see ring_fill_first_wave)
-        double Bv[NK];
+        constexpr int NRM = BLC_CIRC_RING ? ring_mod<NK>() : NK;      // (circular ring: band_products_wc)
+        double Bv[NRM];
         if (FILTER) {
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             if (FASTEDGE && wv == 0) ring_fill_first_wave(Bv, Xj, g, c, 0, NK, -R0);
@@ -1187,11 +1223,11 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             const int l = fresh_lane(), g = l >> 4, c = l & 15;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             if constexpr (FILTER && HOISTA) {
-                acc = band_products_w<NK, 0, NK>(Aw, Bv);
+                acc = band_products_wc<NK, NRM>(Aw, Bv, BLC_CIRC_RING ? 4 * it : 0);
             } else if (FILTER) {
                 const unsigned aoff = (AST == 16 ? (unsigned)(((l >> 4) << 2) | (l & 3)) * 8u : (unsigned)l * 8u) + (unsigned)(j * NK * AST * 8);
                 lds_cp Al = (lds_cp)((const char __attribute__((address_space(3))) *)(lds_cp)As + aoff);
-                acc = band_products<NK, 0, NK, AST>(Al, Bv);
+                acc = band_products_c<NK, NRM, AST>(Al, Bv, BLC_CIRC_RING ? 4 * it : 0);
             } else {
                 // no stencil: the product tile IS the state (at a restart: the reset distribution, written above)
 #pragma unroll
@@ -1289,16 +1325,21 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
             if (it == 0) BLC_STAMP2(5);
             // ---- advance the ring by one tile --------------------------------------------------------------------------------------
             if (FILTER && it + 1 < NTW) {
+                // (circular ring: the new entries 4 it + NK .. + 3 take the slots of the four this tile's window began with; else the ring slides)
+                constexpr bool CIRC = BLC_CIRC_RING != 0;
+                if (!CIRC) {
 #pragma unroll
-                for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
-                if (FASTEDGE && wv == NW - 1 && (it + 1) * TM + R0 + 12 >= NTW * TM) ring_fill_last_wave<N0, NTW * TM>(Bv, Xj, g, c, NK - 4, 4, (it + 1) * TM + R0);
+                    for (int kb = 0; kb < NK - 4; ++kb) Bv[kb] = Bv[kb + 4];
+                }
+                const int e0 = CIRC ? 4 * it + NK : NK - 4;
+                if (FASTEDGE && wv == NW - 1 && (it + 1) * TM + R0 + 12 >= NTW * TM) ring_fill_last_wave<N0, NTW * TM>(Bv, Xj, g, c, e0, 4, (it + 1) * TM + R0, CIRC ? NRM : 0);
                 else if (!FASTEDGE && edge) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = Xj[reflect1(i + TM + R0 + 4 * q + g, n0t) * WCOL + c];
+                    for (int q = 0; q < 4; ++q) Bv[CIRC ? (e0 + q) % NRM : e0 + q] = Xj[reflect1(i + TM + R0 + 4 * q + g, n0t) * WCOL + c];
                 } else {
                     const double *s1 = Xj + (i + TM + R0 + g) * WCOL + c;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) Bv[NK - 4 + q] = s1[q * 4 * WCOL];
+                    for (int q = 0; q < 4; ++q) Bv[CIRC ? (e0 + q) % NRM : e0 + q] = s1[q * 4 * WCOL];
                 }
             }
         }
