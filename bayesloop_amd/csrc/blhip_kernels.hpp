@@ -93,8 +93,11 @@ __device__ __forceinline__ long long strip_major_index(int row, int col, int n0p
 // of serial tail for the 5 sums of a step kernel.)  Fixed summation tree => deterministic.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    // (every row enabled: bound_ctrl gives the lanes without a source their 0 -- no `old` operand to materialise, two v_mov less per step
+    //  of the reduction: 24 of the two-chain fold kernel's ~580 vector instructions per chain-step)
+    constexpr bool BC = ROW_MASK == 0xf;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BC);
     return v + __hiloint2double(hi, lo);             // lanes without a source (or outside ROW_MASK) add 0.0
 }
 
