@@ -279,6 +279,11 @@ __device__ __forceinline__ ChainParams own_chain_params(const ChainParams &P) {
 __device__ __forceinline__ double ldnt(const double *base, unsigned byteoff) { return __builtin_nontemporal_load((const double *)((const char *)base + byteoff)); }
 __device__ __forceinline__ void stnt(double *base, unsigned byteoff, double v) { __builtin_nontemporal_store(v, (double *)((char *)base + byteoff)); }
 
+// x, or NaN where `nan` holds: ONE select on the high word (a NaN is a NaN whatever its low word holds; the 64-bit select is two v_cndmask)
+__device__ __forceinline__ double nan_if(bool nan, double x) {
+    return __hiloint2double(nan ? 0x7ff80000 : __double2hiint(x), __double2loint(x));
+}
+
 // The banded product of a 16-row tile.  As ONE v_mfma_f64_16x16x4 chain the band is 16 + 2 R0 columns wide: every output row
 // multiplies 16 structural zeros (NK products of 64 cycles).  v_mfma_f64_4x4x4_4b computes four INDEPENDENT 4 x 4 x 4 products per
 // instruction (16 cycles, measured: tools/ubench/mfma_f64_4x4.hip -- 70 TFLOP/s with 8 chains in flight, 60 with 4): the blocks are
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(NT, 1) void chain_kernel(const ChainParams P) {
                     const double p = al[it % ALD][r] * beta;
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
-                    const double pl = !in ? 0.0 : (TAB ? p / Lv : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE)));      // (0 / 0 -> NaN either way)
+                    const double pl = !in ? 0.0 : (TAB ? p / Lv : nan_if(Lv == 0.0, ldexp(p * iE, -nE)));      // (0 / 0 -> NaN either way)
                     if (TALL && FILTER) nst[it][r] = cn; else if (FILTER) D[li * WCOL + c] = cn; else stt[it][r] = cn;
                     if (!FOLD) stnt(pstep, off, p);
                     else stnt(pslot_t, off, pa[r] + fmax(p * wq, wfloor));      // (nobody else touches the slot's cell during the launch)
@@ -1293,7 +1298,7 @@ __global__ __launch_bounds__(NT, 1) void chain_fold2_kernel(const ChainParams P)
                 const double beta = in ? acc[r] * scale : 0.0;
                 const double p = al[it][r] * beta;
                 const double cn = beta * Lv;
-                const double pl = !in ? 0.0 : (Lv == 0.0 ? __builtin_nan("") : ldexp(p * iE, -nE));
+                const double pl = !in ? 0.0 : nan_if(Lv == 0.0, ldexp(p * iE, -nE));
                 if (FILTER) stt[it][r] = cn; else Xj[(i + g + 4 * r) * WCOL + c] = cn;
                 pacc[it][r] += fmax(p * wq, wfloor);
                 sN += p; sS += pl; sC += cn;
