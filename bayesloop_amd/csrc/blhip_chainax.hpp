@@ -528,7 +528,7 @@ __global__ __launch_bounds__(NT, 1) void chainax_kernel(const ChainParams Parg) 
                         if (tabled) pl = in ? p / Lv : 0.0;
                         else {
                             const double quot = ldexp(p * iE, -nE);
-                            pl = Lv == 0.0 ? __builtin_nan("") : quot;
+                            pl = nan_if(Lv == 0.0, quot);
                             if (PAD) pl = in ? pl : 0.0;
                         }
                         X0[li * WCOL + c] = cn;

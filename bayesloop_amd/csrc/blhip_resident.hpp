@@ -101,6 +101,7 @@ BLR_INL unsigned long long now_ticks() { return 0; }
 BLR_INL void nap() {}
 BLR_INL double ldexp_(double m, int n) { return std::ldexp(m, n); }
 BLR_INL double nan_() { return std::nan(""); }
+BLR_INL double nan_if_(bool n, double x) { return n ? std::nan("") : x; }
 BLR_INL double ldu(const double *p, long long i) { return p[i]; }
 BLR_INL int uni(int x) { return x; }
 BLR_INL double ld_stream(const double *p) { return *p; }
@@ -138,6 +139,8 @@ BLR_INL unsigned long long now_ticks() { return wall_clock64(); }
 BLR_INL void nap() { __builtin_amdgcn_s_sleep(2); }
 BLR_INL double ldexp_(double m, int n) { return ldexp(m, n); }
 BLR_INL double nan_() { return __builtin_nan(""); }
+// x, or NaN where `n` holds: one select on the high word (a NaN is a NaN whatever its low word holds; the 64-bit select is two v_cndmask)
+BLR_INL double nan_if_(bool n, double x) { return __hiloint2double(n ? 0x7ff80000 : __double2hiint(x), __double2loint(x)); }
 // wave-uniform read-only values (stencil weights, the step's data record) through the scalar cache: SGPRs, not VGPRs
 BLR_INL double ldu(const double *p, long long i) { return ((const double __attribute__((address_space(4))) *)(unsigned long long)p)[i]; }
 BLR_INL int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }       // a block-uniform value: SGPR
@@ -832,7 +835,7 @@ struct Res {
                     const double pp = al8[j] * beta;
                     const double cn = beta * Lv;
                     // p / L: reciprocal recurrence (no division, no intermediate overflow); 0/0 -> NaN (core.py:463)
-                    const double pl = !in ? 0.0 : (TAB ? pp / Lv : (Lv == 0.0 ? nan_() : ldexp_(pp * rc.iE, -rc.nE)));      // (0 / 0 -> NaN either way)
+                    const double pl = !in ? 0.0 : (TAB ? pp / Lv : nan_if_(Lv == 0.0, ldexp_(pp * rc.iE, -rc.nE)));      // (0 / 0 -> NaN either way)
                     keep = cn;
                     if (in) st_stream(pt0 + (long long)(DIR * p) * Q.n1, pp * invn);   // (invn = 1 / predicted sum: stored normalised)
                     sums[0] += pp; sums[1] += pl; sums[2] += cn;
