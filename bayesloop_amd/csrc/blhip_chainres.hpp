@@ -217,6 +217,7 @@ __device__ __forceinline__ LoopParams loop_params(const ChainParams &P) {
 
 // Every field of the argument block as a scalar value of its own (see own_sgpr): the both-axes kernels' step loops reloaded one 16-register
 // tuple of the block 15 - 17 times per step (272 of 508 v_readlane in chainax_kernel<12, 4, backward, fold>) for single fields of it.
+static_assert(sizeof(ChainParams) == 352, "own_chain_params copies ChainParams field by field: a new field needs its line there (and this size)");
 __device__ __forceinline__ ChainParams own_chain_params(const ChainParams &P) {
     ChainParams Q;
     Q.n0 = own_sgpr(P.n0);
